@@ -1,0 +1,159 @@
+/*
+ * rainhip.h -- C ABI of librainhip.so: the MI355X (gfx950) implementation of the
+ * per-image rain-streak rendering + compositing hot path of
+ * astra-vision/rain-rendering.
+ *
+ * The reference is pure Python and has no FFI; the boundary this library plugs
+ * into is the per-frame body of Generator.run (reference common/generator.py:389-467)
+ * and its two inner seams
+ *     Generator.compute_drop              reference common/generator.py:119-191
+ *     RainRenderer.add_drop_to_image      reference common/bad_weather.py:336-462
+ * A maintainer binds it with ctypes.  Plain pointers and
+ * sizes only; the caller owns every buffer; no function throws; every function
+ * returns 0 or a negative RR_E* code and rr_last_error() explains it.
+ *
+ * There is NO CPU implementation behind this ABI: rr_create fails with
+ * RR_E_NO_DEVICE when no gfx950 device is visible.
+ */
+#ifndef RAINHIP_H
+#define RAINHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_VERSION 100            /* 0.1.0 */
+
+enum {
+  RR_OK = 0,
+  RR_E_ARG = -1,                  /* bad argument (null pointer, bad size, mixed frame sizes) */
+  RR_E_NO_DEVICE = -2,            /* no HIP device / not gfx950 */
+  RR_E_HIP = -3,                  /* a HIP runtime call failed */
+  RR_E_STATE = -4,                /* streak DB or camera not set */
+  RR_E_ARENA = -5                 /* tile arena overflow even after regrowth */
+};
+
+/* per-drop status written to rr_frame_out.drop_status: 0 == composited.  The
+ * reference expresses all of these as "exception inside add_drop_to_image ->
+ * drop not composited" (common/generator.py:180-189). */
+enum {
+  RR_DROP_OK = 0,
+  RR_DROP_FOV_FAIL = 1,           /* compute_fov_plane_points returned [] (bad_weather.py:698-704): e.g. > radius */
+  RR_DROP_EMPTY_FOV = 2,          /* FOV polygon does not touch the envmap (bad_weather.py:372 IndexError) */
+  RR_DROP_BAD_COC = 3,            /* non-finite circle of confusion (int(10*c) raises, bad_weather.py:293) */
+  RR_DROP_TOO_BIG = 4             /* defocus pad > RR_MAX_SHIFT px: documented limit of this library */
+};
+
+#define RR_MAX_SHIFT 1024
+#define RR_MAX_FOV 32
+
+typedef struct rr_ctx rr_ctx;
+
+/* Camera / renderer constants.  Mirrors RainRenderer(focal, f_number, focus_plane=6,
+ * radius=10, fov=165) (generator.py:267), N=20 (generator.py:179) and the constants of
+ * bad_weather.py:344-345,425,469.  Transcendental-derived values are computed ONCE by
+ * the host with numpy so that device results do not depend on a device libm. */
+typedef struct {
+  double focal_m;                 /* settings["cam_focal"] / 1000 */
+  double focal_sq;                /* focal_m ** 2 evaluated by the host (bad_weather.py:468) */
+  double f_number;
+  double focus_plane;             /* 6 */
+  double exposure_s;              /* settings["cam_exposure"] / 1000 (bad_weather.py:344) */
+  double radius;                  /* 10 */
+  double sensor_px;               /* 4.65e-06 (bad_weather.py:469) */
+  double tau_zero;                /* sqrt(1.16e-3) / 50 (bad_weather.py:425) */
+  double fov_cos, fov_sin;        /* cos/sin(-deg2rad(fov/2)) (bad_weather.py:602,625) */
+  double phi_cos[RR_MAX_FOV];     /* cos(k * 2*pi/N)  (bad_weather.py:630-634) */
+  double phi_sin[RR_MAX_FOV];
+  int32_t n_fov;                  /* 20 */
+  int32_t reserved;
+} rr_camera;
+
+/* One streak that passed the frame filter (generator.py:413-420), as plain data.
+ * The legacy-RandomState draws (bad_weather.py:252-264, generator.py:136) stay in
+ * Python; their results arrive here as tex_index and rot_cos/rot_sin. */
+typedef struct {
+  int32_t x0, y0, x1, y1;         /* image_position_start / _end (ints, after the in-place noise rotation generator.py:152-161) */
+  int32_t max_width;              /* Streak.max_width */
+  int32_t length;                 /* Streak.length */
+  int32_t type;                   /* DropType: 0 Big, 1 Medium, 2 Small */
+  int32_t tex_index;              /* index into the streak DB chosen by take_drop_texture */
+  double iw1, iw2;                /* image_diameter_start / _end */
+  double wps[3], wpe[3];          /* world_position_start / _end (z already negated, bad_weather.py:223-224) */
+  double rot_cos, rot_sin;        /* cos/sin(-(theta+noise) * pi/180) for imutils.rotate_bound (non-Big) */
+} rr_drop;                        /* 112 bytes */
+
+typedef struct {
+  int32_t H, W;                   /* frame */
+  int32_t He, We;                 /* lat-long environment map */
+  const double* bg;               /* H*W*3 BGR, un-fogged image / 255 (used for the mean shift, generator.py:462) */
+  const double* rainy_bg;         /* H*W*3 BGR, output of the fog pre-pass (generator.py:386) */
+  const double* env_xyY;          /* He*We*3 (generator.py:407-408) */
+  const double* omega;            /* He*We solid angles (generator.py:410) */
+  const rr_drop* drops;           /* n_drops records in reference order */
+  int32_t n_drops;
+  int32_t strategy;               /* 0: default rendering strategy (rendering_strategy=None) */
+  double opacity_attenuation;     /* --opacity_attenuation */
+} rr_frame_in;
+
+typedef struct {
+  uint8_t* rainy_rgb;             /* H*W*3 RGB: what plt.imsave(rainy_image) stores (generator.py:461-466), alpha omitted */
+  double* rainy_bg_out;           /* optional (may be NULL): H*W*3 BGR composite before the mean shift */
+  double* mask_f64;               /* H*W: rainy_mask accumulator (bad_weather.py:450) */
+  int32_t* mask_i32;              /* H*W: floor(mask_f64 * 255)  (SURVEY decision D1) */
+  int32_t* drop_status;           /* n_drops RR_DROP_* codes (may be NULL) */
+} rr_frame_out;
+
+typedef struct {
+  char name[32];
+  int32_t launches;
+  int32_t reserved;
+  double total_ms;                /* sum of HIP-event durations */
+} rr_kernel_stat;
+
+int rr_version(void);
+
+/* device: HIP ordinal.  Fails (RR_E_NO_DEVICE) without a gfx9 device. */
+int rr_create(rr_ctx** out, int device);
+int rr_destroy(rr_ctx* ctx);
+const char* rr_last_error(rr_ctx* ctx);
+
+/* Streak database: n_tex gray uint8 textures, already normalised as
+ * uint8((255*norm*img)/65535) (bad_weather.py:141), concatenated in `texels`
+ * (host pointer) with per-texture height/width/offset. */
+int rr_set_streak_db(rr_ctx* ctx, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w,
+                     const int64_t* tex_off, int32_t n_tex);
+/* Same, but `texels` is a DEVICE pointer on ctx's device (e.g. the buffer that just
+ * received the RCCL broadcast of the packed database). */
+int rr_set_streak_db_device(rr_ctx* ctx, const uint8_t* texels_dev, int64_t n_bytes, const int32_t* tex_h,
+                            const int32_t* tex_w, const int64_t* tex_off, int32_t n_tex);
+int rr_set_camera(rr_ctx* ctx, const rr_camera* cam);
+
+/* Render n frames (all with identical H,W,He,We).  Pointers inside `in`/`out` are HOST
+ * pointers; the call uploads, renders, downloads and returns after completion. */
+int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out);
+
+/* Same, but every pointer inside `in`/`out` is a DEVICE pointer on ctx's device.
+ * Work is enqueued on `stream` (a hipStream_t; NULL = the ctx's own stream) and the
+ * call returns without waiting.  drop_status/arena overflow are checked at
+ * rr_synchronize(). */
+int rr_render_frames_device(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out, void* stream);
+int rr_synchronize(rr_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the launch stream (off by default). */
+int rr_profile_enable(rr_ctx* ctx, int32_t on);
+int rr_profile_reset(rr_ctx* ctx);
+int rr_profile_read(rr_ctx* ctx, rr_kernel_stat* out, int32_t cap);   /* returns #entries or <0 */
+
+/* sizes, for binding self-checks */
+int rr_sizeof_drop(void);
+int rr_sizeof_camera(void);
+int rr_sizeof_frame_in(void);
+int rr_sizeof_frame_out(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAINHIP_H */

@@ -1,0 +1,1046 @@
+// rainhip.hip -- gfx950 kernels and the C ABI (include/rainhip.h) of the rain-streak
+// rendering + compositing hot path.  Written for MI355X only: wave64, 256 CUs, no
+// portability layer.  See DESIGN.md for the kernel chain and the HBM layout.
+//
+//   k_env_prefix   row-wise prefix sums of (x*w, y*w, Y*w, w) of the environment map
+//   k_env_consts   sum(w), sum(Y*w)/sum(w)                       (bad_weather.py:403-404)
+//   k_plan         one thread per drop: geometry, homography / rotation, CoC, FOV polygon
+//   k_scan         per-frame exclusive scan of tile sizes -> arena offsets
+//   k_colour       one wave per drop: FOV row spans x prefix table -> colour constants
+//   k_tile_raw     one block per drop: warp / rotate+resize the streak texture -> alpha tile
+//   k_blur_rows / k_blur_cols   separable defocus blur of the padded tile
+//   k_composite    one block per 16x16 screen tile: ordered per-tile drop list (ballot
+//                  compaction, no atomics), in-register alpha blend + mask accumulate
+//   k_means / k_finalize   mean-contrast shift, clip, truncating u8 quantisation
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rainhip.h"
+#include "rr_device.h"
+
+using namespace rr;
+
+namespace {
+
+constexpr int TILE = 16;            // screen tile edge (256 threads = 16x16 pixels)
+constexpr int MAX_R = 416;          // >= 4*RR_MAX_SHIFT/10 + 1
+constexpr int POLY_STRIDE = RR_MAX_FOV + 4;
+
+struct FrameDesc {
+  const double* bg;
+  const double* rainy_bg;
+  const double* env;
+  const double* omega;
+  const rr_drop* drops;
+  uint8_t* rgb;
+  double* comp_out;                // H*W*3 composite before the mean shift (user buffer or ctx scratch)
+  double* mask_f64;
+  int32_t* mask_i32;
+  int32_t* status;
+  int32_t n_drops;
+  int32_t strategy;
+  double opacity;
+};
+
+struct Scratch {                    // per-batch device scratch, all indexed [frame][...]
+  DropPlan* plan;
+  CompRec* comp;
+  int32_t* poly;                    // [frame][drop][2][POLY_STRIDE]
+  int32_t* npts;
+  int64_t* sizes;
+  double* prefix;                   // [frame][He][We+1][4]
+  double* fconst;                   // [frame][2] = sum_omega, ambient
+  double* arena;                    // [frame][arena_cap]
+  double* partial;                  // [frame][ntiles][2]
+  double* means;                    // [frame][2]
+  int64_t* arena_need;              // [frame]
+  int32_t* overflow;                // [1]
+};
+
+// ---------------------------------------------------------------------------
+// environment map prefix sums
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_env_prefix(const FrameDesc* frames, Dims dm, double* prefix) {
+  const int row = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+  const FrameDesc& fr = frames[f];
+  const int We = dm.We;
+  const double* env = fr.env + (int64_t)row * We * 3;
+  const double* om = fr.omega + (int64_t)row * We;
+  double* P = prefix + ((int64_t)f * dm.He + row) * (int64_t)(We + 1) * 4;
+  const int chunk = (We + 255) / 256;
+  const int c0 = t * chunk, c1 = min(c0 + chunk, We);
+  double s[4] = {0, 0, 0, 0};
+  for (int c = c0; c < c1; c++) {
+    double w = om[c];
+    s[0] += env[c * 3 + 0] * w;
+    s[1] += env[c * 3 + 1] * w;
+    s[2] += env[c * 3 + 2] * w;
+    s[3] += w;
+  }
+  __shared__ double sh[256][4];
+  for (int k = 0; k < 4; k++) sh[t][k] = s[k];
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 256 thread totals
+  for (int ofs = 1; ofs < 256; ofs <<= 1) {
+    double v[4] = {0, 0, 0, 0};
+    if (t >= ofs)
+      for (int k = 0; k < 4; k++) v[k] = sh[t - ofs][k];
+    __syncthreads();
+    if (t >= ofs)
+      for (int k = 0; k < 4; k++) sh[t][k] += v[k];
+    __syncthreads();
+  }
+  double run[4];
+  for (int k = 0; k < 4; k++) run[k] = (t == 0) ? 0.0 : sh[t - 1][k];
+  if (t == 0)
+    for (int k = 0; k < 4; k++) P[k] = 0.0;
+  for (int c = c0; c < c1; c++) {
+    double w = om[c];
+    run[0] += env[c * 3 + 0] * w;
+    run[1] += env[c * 3 + 1] * w;
+    run[2] += env[c * 3 + 2] * w;
+    run[3] += w;
+    double* o = P + (int64_t)(c + 1) * 4;
+    o[0] = run[0];
+    o[1] = run[1];
+    o[2] = run[2];
+    o[3] = run[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_env_consts(Dims dm, const double* prefix, double* fconst) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  double sY = 0, sW = 0;
+  for (int r = t; r < dm.He; r += 256) {
+    const double* last = prefix + (((int64_t)f * dm.He + r) * (int64_t)(dm.We + 1) + dm.We) * 4;
+    sY += last[2];
+    sW += last[3];
+  }
+  __shared__ double a[256], b[256];
+  a[t] = sY;
+  b[t] = sW;
+  __syncthreads();
+  for (int ofs = 128; ofs > 0; ofs >>= 1) {
+    if (t < ofs) {
+      a[t] += a[t + ofs];
+      b[t] += b[t + ofs];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    fconst[f * 2 + 0] = b[0];
+    fconst[f * 2 + 1] = a[0] / b[0];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// per-drop plan
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, rr_camera cam, const int32_t* tex_h,
+                                              const int32_t* tex_w, int max_drops, Scratch sc) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const FrameDesc& fr = frames[f];
+  if (i >= fr.n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  rr_drop d = fr.drops[i];
+  DropPlan p;
+  int64_t size = 0;
+  plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, p, size);
+  int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
+  int32_t* py = px + POLY_STRIDE;
+  // the FOV polygon is evaluated for every drop: in the reference its failure is raised
+  // before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
+  int npts = fov_polygon(d, cam, dm.He, dm.We, px, py);
+  if (p.status != RR_DROP_OK || npts == 0) size = 0;
+  sc.npts[gi] = npts;
+  sc.sizes[gi] = size;
+  sc.plan[gi] = p;
+}
+
+// one block per frame: exclusive scan of arena sizes
+__global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_drops, int64_t arena_cap, Scratch sc) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int n = frames[f].n_drops;
+  const int chunk = (n + 1023) / 1024;
+  const int i0 = t * chunk, i1 = min(i0 + chunk, n);
+  const int64_t base = (int64_t)f * max_drops;
+  int64_t s = 0;
+  for (int i = i0; i < i1; i++) s += sc.sizes[base + i];
+  __shared__ int64_t sh[1024];
+  sh[t] = s;
+  __syncthreads();
+  for (int ofs = 1; ofs < 1024; ofs <<= 1) {
+    int64_t v = (t >= ofs) ? sh[t - ofs] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int64_t run = (t == 0) ? 0 : sh[t - 1];
+  const int64_t frame_base = (int64_t)f * arena_cap;
+  for (int i = i0; i < i1; i++) {
+    DropPlan& p = sc.plan[base + i];
+    int64_t sz = sc.sizes[base + i];
+    int64_t area = (int64_t)p.pw * p.ph;
+    if (run + sz > arena_cap) {
+      // does not fit: never touch the arena for this drop; host regrows and re-runs
+      sc.sizes[base + i] = 0;
+    } else {
+      p.a0_off = frame_base + run;
+      p.a1_off = frame_base + run + area;
+    }
+    run += sz;
+  }
+  if (t == 1023) {
+    sc.arena_need[f] = sh[1023];
+    if (sh[1023] > arena_cap) atomicExch(sc.overflow, 1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// colour: FOV polygon row spans x prefix table, one wave per drop
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+  const int f = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  const FrameDesc& fr = frames[f];
+  if (i >= fr.n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  DropPlan& p = sc.plan[gi];
+  CompRec rec;
+  rec.x0 = rec.y0 = rec.x1 = rec.y1 = 0;
+  rec.ox = rec.oy = rec.pitch = rec.pad = 0;
+  rec.off = 0;
+  rec.tau_one = rec.g = 0;
+  rec.K[0] = rec.K[1] = rec.K[2] = 0;
+  int status = p.status;
+  const int n = sc.npts[gi];
+  if (n == 0) status = RR_DROP_FOV_FAIL;
+  if (n > 0) {
+    const int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
+    const int32_t* py = px + POLY_STRIDE;
+    int ymin = py[0], ymax = py[0];
+    for (int k = 1; k < n; k++) {
+      ymin = min(ymin, py[k]);
+      ymax = max(ymax, py[k]);
+    }
+    const int ya = max(ymin, 0), yb = min(ymax, dm.He - 1);
+    double S[4] = {0, 0, 0, 0};
+    int any = 0;
+    const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
+    for (int y = ya + lane; y <= yb; y += 64) {
+      int xl, xr;
+      if (fov_rowspan(px, py, n, y, dm.We, xl, xr)) {
+        any = 1;
+        const double* row = P + (int64_t)y * (dm.We + 1) * 4;
+        const double* hi = row + (int64_t)(xr + 1) * 4;
+        const double* lo = row + (int64_t)xl * 4;
+        for (int k = 0; k < 4; k++) S[k] += hi[k] - lo[k];
+      }
+    }
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+      for (int k = 0; k < 4; k++) S[k] += __shfl_xor(S[k], ofs);
+      any |= __shfl_xor(any, ofs);
+    }
+    if (!any) status = RR_DROP_EMPTY_FOV;
+    if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
+      colour_from_sums(S, sc.fconst[f * 2 + 0], sc.fconst[f * 2 + 1], rec.K);
+      rec.x0 = p.vis_x0;
+      rec.y0 = p.vis_y0;
+      rec.x1 = p.vis_x0 + p.vis_w;
+      rec.y1 = p.vis_y0 + p.vis_h;
+      rec.ox = p.crop_x - p.vis_x0;
+      rec.oy = p.crop_y - p.vis_y0;
+      rec.pitch = p.pw;
+      rec.off = p.final_buf ? p.a1_off : p.a0_off;
+      rec.tau_one = p.tau_one;
+      rec.g = p.g;
+    }
+  }
+  if (lane == 0) {
+    if (status != p.status) p.status = status;
+    sc.comp[gi] = rec;
+    if (fr.status) fr.status[i] = status;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tile synthesis
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_raw(const FrameDesc* frames, int max_drops, const uint8_t* texels,
+                                                  const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                                                  const float* ctab, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  const DropPlan& p = sc.plan[gi];
+  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0) return;
+  const uint8_t* tex = texels + tex_off[p.tex];
+  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  double* A0 = sc.arena + p.a0_off;
+  const int n = p.pw * p.ph;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    int y = idx / p.pw, x = idx - y * p.pw;
+    int rx = x - p.shift, ry = y - p.shift;
+    double v = 0.0;
+    if (rx >= 0 && rx < p.tw && ry >= 0 && ry < p.th) v = raw_tile_pixel(p, tex, sh, sw, ctab, rx, ry);
+    A0[idx] = v;
+  }
+}
+
+// gaussian half-table: hw[k] = w[k], k = 0..r (centre at r), sequential normalisation
+__device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
+  const int t = threadIdx.x;
+  for (int k = t; k <= r; k += blockDim.x) hw[k] = gauss_phi(sigma, r - k);   // hw[k] = phi(|k - r|)
+  __syncthreads();
+  __shared__ double s_tot;
+  if (t == 0) {
+    double tot = 0.0;
+    for (int x = -r; x <= r; x++) tot = tot + hw[r - (x < 0 ? -x : x)];
+    s_tot = tot;
+  }
+  __syncthreads();
+  const double tot = s_tot;
+  for (int k = t; k <= r; k += blockDim.x) hw[k] = hw[k] / tot;
+  __syncthreads();
+}
+
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  const DropPlan& p = sc.plan[gi];
+  const int r = AXIS == 0 ? p.r1 : p.r2;
+  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || r == 0) return;
+  __shared__ double hw[MAX_R + 1];
+  gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
+  const double* src = sc.arena + (AXIS == 0 ? p.a0_off : p.a1_off);
+  double* dst = sc.arena + (AXIS == 0 ? p.a1_off : p.a0_off);
+  const int n = p.pw * p.ph;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    int y = idx / p.pw, x = idx - y * p.pw;
+    dst[idx] = AXIS == 0 ? blur_axis0(src, p.pw, p.ph, x, y, hw, r) : blur_axis1(src, p.pw, p.ph, x, y, hw, r);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// compositor: one block per 16x16 screen tile, drops applied in reference order
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
+                                                   int tiles_y, Scratch sc) {
+  const int f = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const FrameDesc& fr = frames[f];
+  const int n = fr.n_drops;
+  const int tx0 = txi * TILE, ty0 = tyi * TILE, tx1 = min(tx0 + TILE, dm.W), ty1 = min(ty0 + TILE, dm.H);
+  const int px = tx0 + (t & (TILE - 1)), py = ty0 + (t >> 4);
+  const bool live = px < dm.W && py < dm.H;
+  const int64_t pix = (int64_t)py * dm.W + px;
+  double c[3] = {0, 0, 0}, m = 0.0;
+  if (live) {
+    const double* s = fr.rainy_bg + pix * 3;
+    c[0] = s[0];
+    c[1] = s[1];
+    c[2] = s[2];
+  }
+  const CompRec* comp = sc.comp + (int64_t)f * max_drops;
+  const double* arena = sc.arena;
+  __shared__ int s_list[256];
+  __shared__ int s_cnt[4];
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + t;
+    bool hit = false;
+    if (i < n) {
+      const int4 bb = *reinterpret_cast<const int4*>(&comp[i].x0);
+      hit = bb.x < tx1 && bb.z > tx0 && bb.y < ty1 && bb.w > ty0;
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < 4; w++) {
+      int cw = s_cnt[w];
+      if (w < wave) off += cw;
+      total += cw;
+    }
+    if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    for (int e = 0; e < total; e++) {
+      const int idx = __builtin_amdgcn_readfirstlane(s_list[e]);
+      const CompRec& r = comp[idx];
+      if (live && px >= r.x0 && px < r.x1 && py >= r.y0 && py < r.y1) {
+        const double A = arena[r.off + (int64_t)(py + r.oy) * r.pitch + (px + r.ox)];
+        blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
+      }
+    }
+    __syncthreads();
+  }
+  double sum_c = 0.0, sum_b = 0.0;
+  if (live) {
+    double* o = fr.comp_out + pix * 3;
+    o[0] = c[0];
+    o[1] = c[1];
+    o[2] = c[2];
+    fr.mask_f64[pix] = m;
+    fr.mask_i32[pix] = (int32_t)floor(m * 255.0);
+    const double* b = fr.bg + pix * 3;
+    sum_c = (c[0] + c[1]) + c[2];
+    sum_b = (b[0] + b[1]) + b[2];
+  }
+  __shared__ double ra[256], rb[256];
+  ra[t] = sum_c;
+  rb[t] = sum_b;
+  __syncthreads();
+  for (int ofs = 128; ofs > 0; ofs >>= 1) {
+    if (t < ofs) {
+      ra[t] += ra[t + ofs];
+      rb[t] += rb[t + ofs];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double* part = sc.partial + ((int64_t)f * tiles_x * tiles_y + tile) * 2;
+    part[0] = ra[0];
+    part[1] = rb[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_means(Dims dm, int ntiles, Scratch sc) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  double a = 0, b = 0;
+  const double* part = sc.partial + (int64_t)f * ntiles * 2;
+  for (int i = t; i < ntiles; i += 256) {
+    a += part[i * 2];
+    b += part[i * 2 + 1];
+  }
+  __shared__ double ra[256], rb[256];
+  ra[t] = a;
+  rb[t] = b;
+  __syncthreads();
+  for (int ofs = 128; ofs > 0; ofs >>= 1) {
+    if (t < ofs) {
+      ra[t] += ra[t + ofs];
+      rb[t] += rb[t + ofs];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double cnt = (double)dm.H * (double)dm.W * 3.0;
+    sc.means[f * 2 + 0] = ra[0] / cnt;
+    sc.means[f * 2 + 1] = rb[0] / cnt;
+  }
+}
+
+// generator.py:461-466 + matplotlib's float->uint8 truncation
+__global__ __launch_bounds__(256) void k_finalize(const FrameDesc* frames, Dims dm, Scratch sc) {
+  const int f = blockIdx.y;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (int64_t)dm.H * dm.W) return;
+  const FrameDesc& fr = frames[f];
+  const double diff = sc.means[f * 2 + 0] - sc.means[f * 2 + 1];
+  const double* s = fr.comp_out + pix * 3;
+  uint8_t* o = fr.rgb + pix * 3;
+  for (int k = 0; k < 3; k++) {
+    double v = clip01(s[2 - k] - diff);      // BGR -> RGB
+    o[k] = (uint8_t)(int)(v * 255.0);
+  }
+}
+
+}  // namespace
+
+// ===========================================================================
+// host side
+// ===========================================================================
+struct ProfEntry {
+  const char* name;
+  hipEvent_t a, b;
+};
+
+struct rr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // streak DB
+  uint8_t* d_tex = nullptr;
+  bool own_tex = false;
+  int32_t* d_tex_h = nullptr;
+  int32_t* d_tex_w = nullptr;
+  int64_t* d_tex_off = nullptr;
+  int n_tex = 0;
+  float* d_ctab = nullptr;
+  rr_camera cam;
+  bool have_cam = false, have_db = false;
+  // scratch
+  Scratch sc{};
+  FrameDesc* d_frames = nullptr;
+  int cap_frames = 0, cap_drops = 0;
+  Dims cap_dims{0, 0, 0, 0};
+  int64_t arena_cap = 0;            // doubles per frame
+  double* d_comp_out = nullptr;     // [frame][H*W*3] when the caller passes rainy_bg_out == NULL
+  std::vector<FrameDesc> h_frames;
+  // last launch (for rr_synchronize bookkeeping)
+  int last_n = 0;
+  std::vector<int64_t> h_need;
+  // host-variant staging
+  struct Staging {
+    double *bg = nullptr, *rainy = nullptr, *env = nullptr, *omega = nullptr, *comp = nullptr, *mask = nullptr;
+    rr_drop* drops = nullptr;
+    uint8_t* rgb = nullptr;
+    int32_t *mask_i = nullptr, *status = nullptr;
+    int frames = 0, drops_cap = 0;
+    Dims dims{0, 0, 0, 0};
+  } st;
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> prof_pending;
+  std::vector<rr_kernel_stat> prof_stats;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+      return RR_E_HIP;                                                                            \
+    }                                                                                             \
+  } while (0)
+
+template <typename T>
+int dev_alloc(rr_ctx* ctx, T*& p, size_t count) {
+  if (p) {
+    hipFree(p);
+    p = nullptr;
+  }
+  if (count == 0) count = 1;
+  HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+  return RR_OK;
+}
+
+hipEvent_t get_event(rr_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) {
+    hipEvent_t e = ctx->ev_pool.back();
+    ctx->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  rr_ctx* ctx;
+  hipStream_t s;
+  ProfEntry pe;
+  bool on;
+  ProfScope(rr_ctx* c, hipStream_t st, const char* name) : ctx(c), s(st), on(c->prof) {
+    if (on) {
+      pe.name = name;
+      pe.a = get_event(c);
+      pe.b = get_event(c);
+      hipEventRecord(pe.a, s);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(pe.b, s);
+      ctx->prof_pending.push_back(pe);
+    }
+  }
+};
+
+void prof_collect(rr_ctx* ctx) {
+  for (auto& pe : ctx->prof_pending) {
+    float ms = 0.f;
+    hipEventSynchronize(pe.b);
+    hipEventElapsedTime(&ms, pe.a, pe.b);
+    bool found = false;
+    for (auto& s : ctx->prof_stats)
+      if (!strcmp(s.name, pe.name)) {
+        s.launches++;
+        s.total_ms += ms;
+        found = true;
+        break;
+      }
+    if (!found) {
+      rr_kernel_stat s;
+      memset(&s, 0, sizeof(s));
+      strncpy(s.name, pe.name, sizeof(s.name) - 1);
+      s.launches = 1;
+      s.total_ms = ms;
+      ctx->prof_stats.push_back(s);
+    }
+    ctx->ev_pool.push_back(pe.a);
+    ctx->ev_pool.push_back(pe.b);
+  }
+  ctx->prof_pending.clear();
+}
+
+int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_comp_out) {
+  const bool grow_frames = n > ctx->cap_frames;
+  const bool grow_drops = max_drops > ctx->cap_drops;
+  const bool dims_change = dm.H != ctx->cap_dims.H || dm.W != ctx->cap_dims.W || dm.He != ctx->cap_dims.He || dm.We != ctx->cap_dims.We;
+  if (grow_frames || grow_drops || dims_change || (need_comp_out && !ctx->d_comp_out)) {
+    HIPCHK(hipDeviceSynchronize());
+    const int F = grow_frames ? n : ctx->cap_frames;
+    const int D = grow_drops ? max_drops : ctx->cap_drops;
+    const size_t fd = (size_t)F * (size_t)(D > 0 ? D : 1);
+    int rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.plan, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.comp, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.poly, fd * 2 * POLY_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.npts, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.sizes, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.fconst, (size_t)F * 2))) return rc;
+    const int ntiles = ((dm.W + TILE - 1) / TILE) * ((dm.H + TILE - 1) / TILE);
+    if ((rc = dev_alloc(ctx, ctx->sc.partial, (size_t)F * ntiles * 2))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.means, (size_t)F * 2))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.arena_need, (size_t)F))) return rc;
+    if (!ctx->sc.overflow) {
+      if ((rc = dev_alloc(ctx, ctx->sc.overflow, 1))) return rc;
+      HIPCHK(hipMemset(ctx->sc.overflow, 0, sizeof(int32_t)));
+    }
+    if ((rc = dev_alloc(ctx, ctx->d_frames, (size_t)F))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_comp_out, (size_t)F * dm.H * dm.W * 3))) return rc;
+    // arena: keep per-frame capacity, reallocate for the new frame count
+    if (ctx->arena_cap == 0) ctx->arena_cap = (int64_t)(D > 0 ? D : 1) * 1024 + (1 << 20);
+    if ((rc = dev_alloc(ctx, ctx->sc.arena, (size_t)F * (size_t)ctx->arena_cap))) return rc;
+    ctx->cap_frames = F;
+    ctx->cap_drops = D;
+    ctx->cap_dims = dm;
+  }
+  return RR_OK;
+}
+
+int grow_arena(rr_ctx* ctx, int64_t need) {
+  HIPCHK(hipDeviceSynchronize());
+  int64_t cap = need + need / 4 + (1 << 16);
+  ctx->arena_cap = cap;
+  int rc = dev_alloc(ctx, ctx->sc.arena, (size_t)ctx->cap_frames * (size_t)cap);
+  if (rc) return rc;
+  HIPCHK(hipMemset(ctx->sc.overflow, 0, sizeof(int32_t)));
+  return RR_OK;
+}
+
+int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, hipStream_t s) {
+  if (!ctx->have_cam || !ctx->have_db) {
+    ctx->err = "streak DB and camera must be set before rendering";
+    return RR_E_STATE;
+  }
+  if (n <= 0 || !in || !out) {
+    ctx->err = "bad frame batch";
+    return RR_E_ARG;
+  }
+  Dims dm{in[0].H, in[0].W, in[0].He, in[0].We};
+  int max_drops = 0;
+  bool need_comp = false;
+  for (int f = 0; f < n; f++) {
+    if (in[f].H != dm.H || in[f].W != dm.W || in[f].He != dm.He || in[f].We != dm.We) {
+      ctx->err = "all frames of a batch must share H,W,He,We";
+      return RR_E_ARG;
+    }
+    if (in[f].strategy != 0) {
+      ctx->err = "only the default rendering strategy (0) is implemented";
+      return RR_E_ARG;
+    }
+    if (in[f].n_drops < 0 || in[f].n_drops > 65536 || !in[f].bg || !in[f].rainy_bg || !in[f].env_xyY || !in[f].omega ||
+        (in[f].n_drops > 0 && !in[f].drops) || !out[f].rainy_rgb || !out[f].mask_f64 || !out[f].mask_i32) {
+      ctx->err = "null frame pointer or n_drops outside [0, 2^16] (generator.py:425)";
+      return RR_E_ARG;
+    }
+    if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
+    if (!out[f].rainy_bg_out) need_comp = true;
+  }
+  if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
+    ctx->err = "bad frame size";
+    return RR_E_ARG;
+  }
+  int rc = ensure_scratch(ctx, n, max_drops, dm, need_comp);
+  if (rc) return rc;
+  const int D = ctx->cap_drops > 0 ? ctx->cap_drops : 1;
+  ctx->h_frames.resize(n);
+  for (int f = 0; f < n; f++) {
+    FrameDesc& fd = ctx->h_frames[f];
+    fd.bg = in[f].bg;
+    fd.rainy_bg = in[f].rainy_bg;
+    fd.env = in[f].env_xyY;
+    fd.omega = in[f].omega;
+    fd.drops = in[f].drops;
+    fd.rgb = out[f].rainy_rgb;
+    fd.comp_out = out[f].rainy_bg_out ? out[f].rainy_bg_out : ctx->d_comp_out + (size_t)f * dm.H * dm.W * 3;
+    fd.mask_f64 = out[f].mask_f64;
+    fd.mask_i32 = out[f].mask_i32;
+    fd.status = out[f].drop_status;
+    fd.n_drops = in[f].n_drops;
+    fd.strategy = in[f].strategy;
+    fd.opacity = in[f].opacity_attenuation;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_frames, ctx->h_frames.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, s));
+  const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
+  const int ntiles = tiles_x * tiles_y;
+  Scratch sc = ctx->sc;
+  {
+    ProfScope ps(ctx, s, "k_env_prefix");
+    hipLaunchKernelGGL(k_env_prefix, dim3(dm.He, n), dim3(256), 0, s, ctx->d_frames, dm, sc.prefix);
+  }
+  {
+    ProfScope ps(ctx, s, "k_env_consts");
+    hipLaunchKernelGGL(k_env_consts, dim3(n), dim3(256), 0, s, dm, sc.prefix, sc.fconst);
+  }
+  if (max_drops > 0) {
+    {
+      ProfScope ps(ctx, s, "k_plan");
+      hipLaunchKernelGGL(k_plan, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, dm, ctx->cam, ctx->d_tex_h,
+                         ctx->d_tex_w, D, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_scan");
+      hipLaunchKernelGGL(k_scan, dim3(n), dim3(1024), 0, s, ctx->d_frames, D, ctx->arena_cap, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_colour");
+      hipLaunchKernelGGL(k_colour, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_tile_raw");
+      hipLaunchKernelGGL(k_tile_raw, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+                         ctx->d_tex_off, ctx->d_ctab, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_blur_rows");
+      hipLaunchKernelGGL(k_blur<0>, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_blur_cols");
+      hipLaunchKernelGGL(k_blur<1>, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+    }
+  }
+  {
+    ProfScope ps(ctx, s, "k_composite");
+    hipLaunchKernelGGL(k_composite, dim3(ntiles, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, sc);
+  }
+  {
+    ProfScope ps(ctx, s, "k_means");
+    hipLaunchKernelGGL(k_means, dim3(n), dim3(256), 0, s, dm, ntiles, sc);
+  }
+  {
+    ProfScope ps(ctx, s, "k_finalize");
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)(((int64_t)dm.H * dm.W + 255) / 256), n), dim3(256), 0, s, ctx->d_frames, dm, sc);
+  }
+  HIPCHK(hipGetLastError());
+  ctx->last_n = n;
+  return RR_OK;
+}
+
+// returns RR_OK, or RR_E_ARENA after growing the arena (caller re-enqueues)
+int check_overflow(rr_ctx* ctx, hipStream_t s) {
+  int32_t ovf = 0;
+  HIPCHK(hipMemcpyAsync(&ovf, ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (!ovf) return RR_OK;
+  ctx->h_need.resize(ctx->last_n);
+  HIPCHK(hipMemcpy(ctx->h_need.data(), ctx->sc.arena_need, sizeof(int64_t) * ctx->last_n, hipMemcpyDeviceToHost));
+  int64_t need = 0;
+  for (int64_t v : ctx->h_need) need = v > need ? v : need;
+  int rc = grow_arena(ctx, need);
+  if (rc) return rc;
+  ctx->err = "tile arena overflow: arena regrown, re-enqueue the batch";
+  return RR_E_ARENA;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rr_version(void) { return RR_VERSION; }
+int rr_sizeof_drop(void) { return (int)sizeof(rr_drop); }
+int rr_sizeof_camera(void) { return (int)sizeof(rr_camera); }
+int rr_sizeof_frame_in(void) { return (int)sizeof(rr_frame_in); }
+int rr_sizeof_frame_out(void) { return (int)sizeof(rr_frame_out); }
+
+int rr_create(rr_ctx** out, int device) {
+  if (!out) return RR_E_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return RR_E_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RR_E_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx9", 4) != 0) return RR_E_NO_DEVICE;
+  rr_ctx* ctx = new rr_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return RR_E_HIP;
+  }
+  float tab[128];
+  build_cubic_tab(tab);
+  if (hipMalloc((void**)&ctx->d_ctab, sizeof(tab)) != hipSuccess ||
+      hipMemcpy(ctx->d_ctab, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
+    delete ctx;
+    return RR_E_HIP;
+  }
+  *out = ctx;
+  return RR_OK;
+}
+
+int rr_destroy(rr_ctx* ctx) {
+  if (!ctx) return RR_E_ARG;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  if (ctx->own_tex) hipFree(ctx->d_tex);
+  hipFree(ctx->d_tex_h);
+  hipFree(ctx->d_tex_w);
+  hipFree(ctx->d_tex_off);
+  hipFree(ctx->d_ctab);
+  hipFree(ctx->sc.plan);
+  hipFree(ctx->sc.comp);
+  hipFree(ctx->sc.poly);
+  hipFree(ctx->sc.npts);
+  hipFree(ctx->sc.sizes);
+  hipFree(ctx->sc.prefix);
+  hipFree(ctx->sc.fconst);
+  hipFree(ctx->sc.arena);
+  hipFree(ctx->sc.partial);
+  hipFree(ctx->sc.means);
+  hipFree(ctx->sc.arena_need);
+  hipFree(ctx->sc.overflow);
+  hipFree(ctx->d_frames);
+  hipFree(ctx->d_comp_out);
+  hipFree(ctx->st.bg);
+  hipFree(ctx->st.rainy);
+  hipFree(ctx->st.env);
+  hipFree(ctx->st.omega);
+  hipFree(ctx->st.comp);
+  hipFree(ctx->st.mask);
+  hipFree(ctx->st.drops);
+  hipFree(ctx->st.rgb);
+  hipFree(ctx->st.mask_i);
+  hipFree(ctx->st.status);
+  for (auto& pe : ctx->prof_pending) {
+    hipEventDestroy(pe.a);
+    hipEventDestroy(pe.b);
+  }
+  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return RR_OK;
+}
+
+const char* rr_last_error(rr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+static int set_db_meta(rr_ctx* ctx, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off, int32_t n_tex) {
+  int rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tex_h, (size_t)n_tex))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tex_w, (size_t)n_tex))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_tex_off, (size_t)n_tex))) return rc;
+  HIPCHK(hipMemcpy(ctx->d_tex_h, tex_h, sizeof(int32_t) * n_tex, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_tex_w, tex_w, sizeof(int32_t) * n_tex, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_tex_off, tex_off, sizeof(int64_t) * n_tex, hipMemcpyHostToDevice));
+  ctx->n_tex = n_tex;
+  ctx->have_db = true;
+  return RR_OK;
+}
+
+int rr_set_streak_db(rr_ctx* ctx, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                     int32_t n_tex) {
+  if (!ctx) return RR_E_ARG;
+  if (!texels || !tex_h || !tex_w || !tex_off || n_tex <= 0) {
+    ctx->err = "rr_set_streak_db: bad argument";
+    return RR_E_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  int64_t total = 0;
+  for (int i = 0; i < n_tex; i++) {
+    if (tex_h[i] <= 0 || tex_w[i] <= 0 || tex_off[i] < 0) {
+      ctx->err = "rr_set_streak_db: bad texture shape";
+      return RR_E_ARG;
+    }
+    int64_t end = tex_off[i] + (int64_t)tex_h[i] * tex_w[i];
+    if (end > total) total = end;
+  }
+  if (ctx->own_tex && ctx->d_tex) hipFree(ctx->d_tex);
+  ctx->d_tex = nullptr;
+  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)total));
+  ctx->own_tex = true;
+  HIPCHK(hipMemcpy(ctx->d_tex, texels, (size_t)total, hipMemcpyHostToDevice));
+  return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
+}
+
+int rr_set_streak_db_device(rr_ctx* ctx, const uint8_t* texels_dev, int64_t n_bytes, const int32_t* tex_h, const int32_t* tex_w,
+                            const int64_t* tex_off, int32_t n_tex) {
+  if (!ctx) return RR_E_ARG;
+  if (!texels_dev || !tex_h || !tex_w || !tex_off || n_tex <= 0 || n_bytes <= 0) {
+    ctx->err = "rr_set_streak_db_device: bad argument";
+    return RR_E_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (int i = 0; i < n_tex; i++) {
+    if (tex_h[i] <= 0 || tex_w[i] <= 0 || tex_off[i] < 0 || tex_off[i] + (int64_t)tex_h[i] * tex_w[i] > n_bytes) {
+      ctx->err = "rr_set_streak_db_device: texture outside the buffer";
+      return RR_E_ARG;
+    }
+  }
+  if (ctx->own_tex && ctx->d_tex) hipFree(ctx->d_tex);
+  ctx->d_tex = nullptr;
+  // private copy: the caller's (broadcast) buffer may be released afterwards
+  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)n_bytes));
+  ctx->own_tex = true;
+  HIPCHK(hipMemcpy(ctx->d_tex, texels_dev, (size_t)n_bytes, hipMemcpyDeviceToDevice));
+  return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
+}
+
+int rr_set_camera(rr_ctx* ctx, const rr_camera* cam) {
+  if (!ctx) return RR_E_ARG;
+  if (!cam || cam->n_fov < 3 || cam->n_fov > RR_MAX_FOV || !(cam->exposure_s > 0) || !(cam->tau_zero > 0)) {
+    ctx->err = "rr_set_camera: bad argument";
+    return RR_E_ARG;
+  }
+  ctx->cam = *cam;
+  ctx->have_cam = true;
+  return RR_OK;
+}
+
+int rr_render_frames_device(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out, void* stream) {
+  if (!ctx) return RR_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return enqueue(ctx, n, in, out, s);
+}
+
+int rr_synchronize(rr_ctx* ctx) {
+  if (!ctx) return RR_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (ctx->last_n > 0 && ctx->sc.overflow) {
+    int rc = check_overflow(ctx, ctx->stream);
+    if (rc) return rc;
+  }
+  return RR_OK;
+}
+
+int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out) {
+  if (!ctx) return RR_E_ARG;
+  if (n <= 0 || !in || !out) {
+    ctx->err = "bad frame batch";
+    return RR_E_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  Dims dm{in[0].H, in[0].W, in[0].He, in[0].We};
+  if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
+    ctx->err = "bad frame size";
+    return RR_E_ARG;
+  }
+  int max_drops = 1;
+  for (int f = 0; f < n; f++) {
+    if (in[f].n_drops < 0 || in[f].n_drops > 65536) {
+      ctx->err = "n_drops outside [0, 2^16] (generator.py:425)";
+      return RR_E_ARG;
+    }
+    if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
+  }
+  auto& st = ctx->st;
+  const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We;
+  if (n > st.frames || max_drops > st.drops_cap || dm.H != st.dims.H || dm.W != st.dims.W || dm.He != st.dims.He || dm.We != st.dims.We) {
+    HIPCHK(hipDeviceSynchronize());
+    int F = n > st.frames ? n : st.frames, D = max_drops > st.drops_cap ? max_drops : st.drops_cap, rc;
+    if ((rc = dev_alloc(ctx, st.bg, F * px * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.rainy, F * px * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.env, F * ex * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.omega, F * ex))) return rc;
+    if ((rc = dev_alloc(ctx, st.comp, F * px * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.mask, F * px))) return rc;
+    if ((rc = dev_alloc(ctx, st.drops, (size_t)F * D))) return rc;
+    if ((rc = dev_alloc(ctx, st.rgb, F * px * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.mask_i, F * px))) return rc;
+    if ((rc = dev_alloc(ctx, st.status, (size_t)F * D))) return rc;
+    st.frames = F;
+    st.drops_cap = D;
+    st.dims = dm;
+  }
+  hipStream_t s = ctx->stream;
+  std::vector<rr_frame_in> din(n);
+  std::vector<rr_frame_out> dout(n);
+  for (int f = 0; f < n; f++) {
+    if (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
+        !out[f].rainy_rgb || !out[f].mask_f64 || !out[f].mask_i32) {
+      ctx->err = "null frame pointer";
+      return RR_E_ARG;
+    }
+    din[f] = in[f];
+    din[f].bg = st.bg + f * px * 3;
+    din[f].rainy_bg = st.rainy + f * px * 3;
+    din[f].env_xyY = st.env + f * ex * 3;
+    din[f].omega = st.omega + f * ex;
+    din[f].drops = st.drops + (size_t)f * st.drops_cap;
+    HIPCHK(hipMemcpyAsync((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync((void*)din[f].omega, in[f].omega, ex * sizeof(double), hipMemcpyHostToDevice, s));
+    if (in[f].n_drops > 0)
+      HIPCHK(hipMemcpyAsync((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * in[f].n_drops, hipMemcpyHostToDevice, s));
+    dout[f].rainy_rgb = st.rgb + f * px * 3;
+    dout[f].rainy_bg_out = st.comp + f * px * 3;
+    dout[f].mask_f64 = st.mask + f * px;
+    dout[f].mask_i32 = st.mask_i + f * px;
+    dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
+  }
+  for (int attempt = 0; attempt < 3; attempt++) {
+    int rc = enqueue(ctx, n, din.data(), dout.data(), s);
+    if (rc) return rc;
+    rc = check_overflow(ctx, s);
+    if (rc == RR_OK) break;
+    if (rc != RR_E_ARENA || attempt == 2) return rc;
+  }
+  for (int f = 0; f < n; f++) {
+    HIPCHK(hipMemcpyAsync(out[f].rainy_rgb, dout[f].rainy_rgb, px * 3, hipMemcpyDeviceToHost, s));
+    if (out[f].rainy_bg_out)
+      HIPCHK(hipMemcpyAsync(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out[f].mask_f64, dout[f].mask_f64, px * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (out[f].drop_status && in[f].n_drops > 0)
+      HIPCHK(hipMemcpyAsync(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * in[f].n_drops, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return RR_OK;
+}
+
+int rr_profile_enable(rr_ctx* ctx, int32_t on) {
+  if (!ctx) return RR_E_ARG;
+  ctx->prof = on != 0;
+  return RR_OK;
+}
+
+int rr_profile_reset(rr_ctx* ctx) {
+  if (!ctx) return RR_E_ARG;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  prof_collect(ctx);
+  ctx->prof_stats.clear();
+  return RR_OK;
+}
+
+int rr_profile_read(rr_ctx* ctx, rr_kernel_stat* out, int32_t cap) {
+  if (!ctx || !out || cap < 0) return RR_E_ARG;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  prof_collect(ctx);
+  int n = (int)ctx->prof_stats.size();
+  if (n > cap) n = cap;
+  for (int i = 0; i < n; i++) out[i] = ctx->prof_stats[i];
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,734 @@
+// rr_device.h -- per-drop and per-pixel arithmetic of the rain-streak hot path.
+//
+// Every function here is `__host__ __device__`: the HIP kernels in rainhip.hip call
+// them on gfx950, and tests/hostemu compiles the very same functions with g++ so the
+// arithmetic can be unit-tested against the numpy oracle without a GPU (the product
+// never runs the host instantiation).
+//
+// Arithmetic contract (DESIGN.md "bit-exactness"): IEEE double with the evaluation
+// order spelled out below, no FMA contraction (-ffp-contract=off and the pragma
+// below), no device transcendental on any value that reaches an alpha tile.  Device
+// libm (sqrt/atan2) is used ONLY for the field-of-view polygon, which feeds the
+// per-drop colour constant (tolerance +-1 LSB on rainy_image).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "rainhip.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RR_HD __host__ __device__ inline
+#else
+#define RR_HD inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace rr {
+
+enum { KIND_BIG = 0, KIND_ROT = 1 };
+enum { RS_AREA = 0, RS_AREA_FAST = 1, RS_LINEAR = 2 };
+
+struct Dims {
+  int32_t H, W, He, We;
+};
+
+// Everything a kernel needs to know about one drop.  Written by plan_drop (one thread
+// per drop), arena offsets filled in by the per-frame scan.
+struct DropPlan {
+  int32_t status;            // RR_DROP_*
+  int32_t kind;              // KIND_BIG | KIND_ROT
+  int32_t tex;               // texture index
+  int32_t flip;              // cv2.flip(drop, 0) (generator.py:165)
+  int32_t tw, th;            // raw tile (before the defocus pad)
+  int32_t shift;             // int(10*c) (bad_weather.py:293)
+  int32_t pw, ph;            // padded tile
+  int32_t r1, r2;            // gaussian radii along axis 0 (rows) / axis 1 (cols)
+  int32_t vis_x0, vis_y0, vis_w, vis_h;   // footprint inside the frame
+  int32_t crop_x, crop_y;    // padded-tile coordinates of the footprint origin
+  int32_t final_buf;         // which arena buffer holds the finished alpha tile
+  int32_t bw0;               // warpPerspective block width
+  int32_t nW, nH;            // rotate_bound canvas
+  int32_t rs_mode;           // RS_*
+  int32_t isx, isy;          // integer scales (RS_AREA_FAST)
+  int32_t pad0;
+  int64_t a0_off, a1_off;    // arena offsets in doubles
+  double sig1, sig2;         // c, c/2 (bad_weather.py:291)
+  double tau_one, g;         // exposure*length_opacity, tau_one/tau_zero (bad_weather.py:425-427,443)
+  double mi[9];              // inverse homography (Big)
+  double ma[6];              // inverse rotate_bound affine (non-Big)
+  double scale_x, scale_y, inv_sx, inv_sy;   // cv2.resize scales
+};
+
+// What the compositor reads per (screen tile, drop): 80 bytes.
+struct CompRec {
+  int32_t x0, y0, x1, y1;    // footprint, exclusive upper bounds; empty if x1<=x0
+  int32_t ox, oy;            // tile_x = px + ox, tile_y = py + oy
+  int32_t pitch, pad;
+  int64_t off;               // arena offset of the finished tile
+  double tau_one, g;
+  double K[3];               // BGR colour constants
+};
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+RR_HD int64_t cv_round(double v) {   // saturate_cast<int>(double): rint + saturate
+  if (!(v == v)) return -2147483648LL;
+  if (v < -2147483648.0) return -2147483648LL;
+  if (v > 2147483647.0) return 2147483647LL;
+  return (int64_t)rint(v);
+}
+RR_HD int64_t sat_short(int64_t v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+RR_HD int32_t imin(int32_t a, int32_t b) { return b < a ? b : a; }
+RR_HD int32_t imax(int32_t a, int32_t b) { return b > a ? b : a; }
+RR_HD double dmin(double a, double b) { return b < a ? b : a; }   // Python / std::min semantics
+RR_HD double dmax(double a, double b) { return b > a ? b : a; }
+RR_HD double clip01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }   // np.clip keeps NaN
+RR_HD int32_t iabs(int32_t a) { return a < 0 ? -a : a; }
+
+// exp(x), -700 < x <= 0, from + - * / only (oracle/render.py det_exp).
+RR_HD double det_exp(double x) {
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  const double INV_LN2 = 1.44269504088896338700e+00;
+  double k = rint(x * INV_LN2);
+  double r = (x - k * LN2_HI) - k * LN2_LO;
+  double p = 1.0 / 6227020800.0;
+  p = p * r + 1.0 / 479001600.0;
+  p = p * r + 1.0 / 39916800.0;
+  p = p * r + 1.0 / 3628800.0;
+  p = p * r + 1.0 / 362880.0;
+  p = p * r + 1.0 / 40320.0;
+  p = p * r + 1.0 / 5040.0;
+  p = p * r + 1.0 / 720.0;
+  p = p * r + 1.0 / 120.0;
+  p = p * r + 1.0 / 24.0;
+  p = p * r + 1.0 / 6.0;
+  p = p * r + 1.0 / 2.0;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  return ldexp(p, (int)k);
+}
+
+// un-normalised gaussian weight phi(i) for tap distance i (scipy _gaussian_kernel1d)
+RR_HD double gauss_phi(double sigma, int i) {
+  double sigma2 = sigma * sigma;
+  return det_exp(-0.5 / sigma2 * (double)(i * i));
+}
+
+// interpolateCubic(i/32) in float, A = -0.75 (OpenCV imgwarp.cpp)
+inline void build_cubic_tab(float* tab /*32*4*/) {
+  const float A = -0.75f;
+  const float scale = 1.0f / 32.0f;
+  for (int i = 0; i < 32; i++) {
+    volatile float x = (float)i * scale;
+    volatile float xp = x + 1.0f;
+    volatile float t0 = A * xp;
+    t0 = t0 - 5.0f * A;
+    t0 = t0 * xp;
+    t0 = t0 + 8.0f * A;
+    t0 = t0 * xp;
+    t0 = t0 - 4.0f * A;
+    volatile float t1 = (A + 2.0f) * x;
+    t1 = t1 - (A + 3.0f);
+    t1 = t1 * x;
+    t1 = t1 * x;
+    t1 = t1 + 1.0f;
+    volatile float xm = 1.0f - x;
+    volatile float t2 = (A + 2.0f) * xm;
+    t2 = t2 - (A + 3.0f);
+    t2 = t2 * xm;
+    t2 = t2 * xm;
+    t2 = t2 + 1.0f;
+    volatile float t3 = 1.0f - t0;
+    t3 = t3 - t1;
+    t3 = t3 - t2;
+    tab[i * 4 + 0] = t0;
+    tab[i * 4 + 1] = t1;
+    tab[i * 4 + 2] = t2;
+    tab[i * 4 + 3] = t3;
+  }
+}
+
+// streaks_light[idx] / 255.0 with BORDER_CONSTANT 0 outside
+RR_HD double tex_tap(const uint8_t* tex, int th, int tw, int64_t y, int64_t x) {
+  if (y < 0 || y >= th || x < 0 || x >= tw) return 0.0;
+  return (double)tex[y * tw + x] / 255.0;
+}
+
+// ---------------------------------------------------------------------------
+// Big drops: cv2.warpPerspective(INTER_CUBIC)  (generator.py:126-132)
+// ---------------------------------------------------------------------------
+RR_HD double warp_big_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, const float* ctab, int x, int y) {
+  const double* Mi = p.mi;
+  int bx = (x / p.bw0) * p.bw0;
+  double x1 = (double)(x - bx);
+  double bxf = (double)bx, yf = (double)y;
+  double X0 = Mi[0] * bxf + Mi[1] * yf + Mi[2];
+  double Y0 = Mi[3] * bxf + Mi[4] * yf + Mi[5];
+  double W0 = Mi[6] * bxf + Mi[7] * yf + Mi[8];
+  double W = W0 + Mi[6] * x1;
+  W = (W != 0.0) ? 32.0 / W : 0.0;
+  double fX = dmax(-2147483648.0, dmin(2147483647.0, (X0 + Mi[0] * x1) * W));
+  double fY = dmax(-2147483648.0, dmin(2147483647.0, (Y0 + Mi[3] * x1) * W));
+  int64_t X = cv_round(fX), Y = cv_round(fY);
+  int64_t sx = sat_short(X >> 5) - 1, sy = sat_short(Y >> 5) - 1;
+  int fx = (int)(X & 31), fy = (int)(Y & 31);
+  const float* cx = ctab + fx * 4;
+  const float* cy = ctab + fy * 4;
+  int width1 = imax(sw - 3, 0), height1 = imax(sh - 3, 0);
+  bool interior = sx >= 0 && sx < width1 && sy >= 0 && sy < height1;
+  double sum = 0.0;
+  if (interior) {
+    for (int i = 0; i < 4; i++) {
+      float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
+      const uint8_t* row = tex + (sy + i) * sw + sx;
+      double r = (((double)row[0] / 255.0) * (double)w0 + ((double)row[1] / 255.0) * (double)w1) +
+                 ((double)row[2] / 255.0) * (double)w2;
+      r = r + ((double)row[3] / 255.0) * (double)w3;
+      sum = (i == 0) ? r : sum + r;
+    }
+  } else {
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        float w = cy[i] * cx[j];
+        sum = sum + tex_tap(tex, sh, sw, sy + i, sx + j) * (double)w;
+      }
+  }
+  return clip01(sum);
+}
+
+// ---------------------------------------------------------------------------
+// Medium/Small drops: imutils.rotate_bound -> cv2.flip -> cv2.resize(INTER_AREA)
+// (generator.py:163-170)
+// ---------------------------------------------------------------------------
+// one pixel of warpAffine(INTER_LINEAR) of the texture into the nW x nH canvas
+RR_HD double rot_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, int ry, int rx) {
+  const double* m = p.ma;
+  int64_t adelta = cv_round(m[0] * (double)rx * 1024.0);
+  int64_t bdelta = cv_round(m[3] * (double)rx * 1024.0);
+  int64_t X0 = cv_round((m[1] * (double)ry + m[2]) * 1024.0) + 16;
+  int64_t Y0 = cv_round((m[4] * (double)ry + m[5]) * 1024.0) + 16;
+  int64_t X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  int64_t sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+  int fx = (int)(X & 31), fy = (int)(Y & 31);
+  double w00 = (double)((32 - fy) * (32 - fx)) / 1024.0;
+  double w01 = (double)((32 - fy) * fx) / 1024.0;
+  double w10 = (double)(fy * (32 - fx)) / 1024.0;
+  double w11 = (double)(fy * fx) / 1024.0;
+  double v00 = tex_tap(tex, sh, sw, sy, sx), v01 = tex_tap(tex, sh, sw, sy, sx + 1);
+  double v10 = tex_tap(tex, sh, sw, sy + 1, sx), v11 = tex_tap(tex, sh, sw, sy + 1, sx + 1);
+  return ((v00 * w00 + v01 * w01) + v10 * w10) + v11 * w11;
+}
+
+// the image cv2.resize reads: rotated canvas, vertically flipped if p.flip
+RR_HD double canvas_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, int cy, int cx) {
+  return rot_pixel(p, tex, sh, sw, p.flip ? (p.nH - 1 - cy) : cy, cx);
+}
+
+// computeResizeAreaTab for one destination index
+struct AreaSpan {
+  int32_t s1, s2;            // full cells s1 .. s2-1
+  int32_t has_l, has_r;      // partial cells at s1-1 and s2
+  float a_l, a_m, a_r;
+};
+RR_HD AreaSpan area_span(int ssize, double scale, int d) {
+  AreaSpan a;
+  double fsx1 = (double)d * scale;
+  double fsx2 = fsx1 + scale;
+  double cell = dmin(scale, (double)ssize - fsx1);
+  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+  sx2 = imin(sx2, ssize - 1);
+  sx1 = imin(sx1, sx2);
+  a.s1 = sx1;
+  a.s2 = sx2;
+  a.has_l = ((double)sx1 - fsx1 > 1e-3) ? 1 : 0;
+  a.a_l = (float)(((double)sx1 - fsx1) / cell);
+  a.a_m = (float)(1.0 / cell);
+  a.has_r = (fsx2 - (double)sx2 > 1e-3) ? 1 : 0;
+  a.a_r = (float)(dmin(dmin(fsx2 - (double)sx2, 1.0), cell) / cell);
+  return a;
+}
+
+// horizontal pass of resizeArea_ for one source row and one destination column
+RR_HD double area_hsum(const DropPlan& p, const uint8_t* tex, int sh, int sw, const AreaSpan& ax, int sy) {
+  double b = 0.0;
+  if (ax.has_l) b = b + canvas_pixel(p, tex, sh, sw, sy, ax.s1 - 1) * (double)ax.a_l;
+  for (int sx = ax.s1; sx < ax.s2; sx++) b = b + canvas_pixel(p, tex, sh, sw, sy, sx) * (double)ax.a_m;
+  if (ax.has_r) b = b + canvas_pixel(p, tex, sh, sw, sy, ax.s2) * (double)ax.a_r;
+  return b;
+}
+
+// the area_mode branch of cv::resize's INTER_LINEAR coefficient set-up
+RR_HD void lin_coord(int ssize, double scale, double inv_scale, int d, bool is_x, int& s, float& f, bool& tail) {
+  s = (int)floor((double)d * scale);
+  f = (float)((double)(d + 1) - (double)(s + 1) * inv_scale);
+  f = (f <= 0.0f) ? 0.0f : f - floorf(f);
+  tail = false;
+  if (is_x) {
+    if (s < 0) { f = 0.0f; s = 0; }
+    if (s + 1 >= ssize) {
+      tail = true;
+      if (s >= ssize - 1) { f = 0.0f; s = ssize - 1; }
+    }
+  }
+}
+
+RR_HD double lin_hrow(const DropPlan& p, const uint8_t* tex, int sh, int sw, int row, int s, float f, bool tail) {
+  if (tail) return canvas_pixel(p, tex, sh, sw, row, s) * 1.0;
+  float a0 = 1.0f - f;
+  return canvas_pixel(p, tex, sh, sw, row, s) * (double)a0 + canvas_pixel(p, tex, sh, sw, row, s + 1) * (double)f;
+}
+
+RR_HD double resize_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, int dx, int dy) {
+  double v;
+  if (p.rs_mode == RS_AREA_FAST) {
+    int area = p.isx * p.isy;
+    float scale = 1.0f / (float)area;
+    int by = dy * p.isy, bx = dx * p.isx;
+    double s = 0.0;
+    int k = 0;
+    for (; k <= area - 4; k += 4) {
+      double q[4];
+      for (int t = 0; t < 4; t++) {
+        int kk = k + t;
+        q[t] = canvas_pixel(p, tex, sh, sw, by + kk / p.isx, bx + kk % p.isx);
+      }
+      s = s + (((q[0] + q[1]) + q[2]) + q[3]);
+    }
+    for (; k < area; k++) s = s + canvas_pixel(p, tex, sh, sw, by + k / p.isx, bx + k % p.isx);
+    v = s * (double)scale;
+  } else if (p.rs_mode == RS_AREA) {
+    AreaSpan ax = area_span(p.nW, p.scale_x, dx);
+    AreaSpan ay = area_span(p.nH, p.scale_y, dy);
+    double acc = 0.0;
+    bool first = true;
+    if (ay.has_l) {
+      acc = (double)ay.a_l * area_hsum(p, tex, sh, sw, ax, ay.s1 - 1);
+      first = false;
+    }
+    for (int sy = ay.s1; sy < ay.s2; sy++) {
+      double t = (double)ay.a_m * area_hsum(p, tex, sh, sw, ax, sy);
+      acc = first ? t : acc + t;
+      first = false;
+    }
+    if (ay.has_r) {
+      double t = (double)ay.a_r * area_hsum(p, tex, sh, sw, ax, ay.s2);
+      acc = first ? t : acc + t;
+    }
+    v = acc;
+  } else {
+    int sx, sy;
+    float fx, fy;
+    bool tx, ty;
+    lin_coord(p.nW, p.scale_x, p.inv_sx, dx, true, sx, fx, tx);
+    lin_coord(p.nH, p.scale_y, p.inv_sy, dy, false, sy, fy, ty);
+    int r0 = imin(imax(sy, 0), p.nH - 1), r1 = imin(imax(sy + 1, 0), p.nH - 1);
+    float b0 = 1.0f - fy;
+    v = lin_hrow(p, tex, sh, sw, r0, sx, fx, tx) * (double)b0 + lin_hrow(p, tex, sh, sw, r1, sx, fx, tx) * (double)fy;
+  }
+  return clip01(v);
+}
+
+// raw (un-blurred) alpha of tile pixel (x, y) in raw-tile coordinates
+RR_HD double raw_tile_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, const float* ctab, int x, int y) {
+  return p.kind == KIND_BIG ? warp_big_pixel(p, tex, sh, sw, ctab, x, y) : resize_pixel(p, tex, sh, sw, x, y);
+}
+
+// ---------------------------------------------------------------------------
+// field-of-view polygon   (bad_weather.py:596-704)
+// ---------------------------------------------------------------------------
+RR_HD void rotmat(const double a[3], double c, double s, double R[9]) {   // bad_weather.py:532-538
+  double omc = 1.0 - c;
+  R[0] = c + omc * (a[0] * a[0]);
+  R[1] = s * (-a[2]) + omc * (a[0] * a[1]);
+  R[2] = s * (a[1]) + omc * (a[0] * a[2]);
+  R[3] = s * (a[2]) + omc * (a[1] * a[0]);
+  R[4] = c + omc * (a[1] * a[1]);
+  R[5] = s * (-a[0]) + omc * (a[1] * a[2]);
+  R[6] = s * (-a[1]) + omc * (a[2] * a[0]);
+  R[7] = s * (a[0]) + omc * (a[2] * a[1]);
+  R[8] = c + omc * (a[2] * a[2]);
+}
+RR_HD void vecmat(const double v[3], const double R[9], double o[3]) {     // np.dot(v, R)
+  o[0] = v[0] * R[0] + v[1] * R[3] + v[2] * R[6];
+  o[1] = v[0] * R[1] + v[1] * R[4] + v[2] * R[7];
+  o[2] = v[0] * R[2] + v[1] * R[5] + v[2] * R[8];
+}
+RR_HD double py_mod(double a, double b) {   // numpy float remainder, b > 0
+  double m = fmod(a, b);
+  if (m != 0.0 && m < 0.0) m += b;
+  return m;
+}
+
+// returns the number of vertices (20 or 24), or 0 where the reference's `except:` fires;
+// vertices are truncated toward zero like pyclipper's integer cast.
+RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, int32_t* px, int32_t* py) {
+  const double PI = 3.141592653589793;
+  const double TWO_PI = 2.0 * PI;
+  int N = cam.n_fov;
+  double pos[3] = {(d.wps[0] + d.wpe[0]) / 2.0, (d.wps[2] + d.wpe[2]) / 2.0, (d.wps[1] + d.wpe[1]) / 2.0};
+  double nrm = sqrt(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+  double n[3] = {pos[0] / nrm, pos[1] / nrm, pos[2] / nrm};
+  double a = n[0], b = n[1], c = n[2];
+  double dd = pos[0] * n[0] + pos[1] * n[1] + pos[2] * n[2];
+  if (b == 0.0) b = 0.001;
+  double ppx = pos[1], ppz = 0.0;
+  double ppy = (-a * ppx + dd - c * ppz) / b;
+  double uu[3] = {pos[0] - ppx, pos[1] - ppy, pos[2] - ppz};
+  double un = sqrt(uu[0] * uu[0] + uu[1] * uu[1] + uu[2] * uu[2]);
+  uu[0] /= un; uu[1] /= un; uu[2] /= un;
+  if (!(uu[0] == uu[0]) || !(uu[1] == uu[1]) || !(uu[2] == uu[2])) return 0;
+  double rv[3] = {uu[1] * n[2] - uu[2] * n[1], uu[2] * n[0] - uu[0] * n[2], uu[0] * n[1] - uu[1] * n[0]};
+  double R[9], v[3];
+  rotmat(rv, cam.fov_cos, cam.fov_sin, R);
+  vecmat(n, R, v);
+  double ptx[RR_MAX_FOV], pty[RR_MAX_FOV], azs[RR_MAX_FOV + 1];
+  for (int k = 0; k < N; k++) {
+    double M[9], dir[3];
+    rotmat(n, cam.phi_cos[k], cam.phi_sin[k], M);
+    vecmat(v, M, dir);
+    double qa = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+    double qb = 2 * dir[0] * pos[0] + 2 * dir[1] * pos[1] + 2 * dir[2] * pos[2];
+    double qc = pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2] - cam.radius * cam.radius;
+    double disc = qb * qb - 4 * qa * qc;
+    double t1 = (-qb + sqrt(disc)) / (2 * qa);
+    double P[3] = {pos[0] + t1 * dir[0], pos[1] + t1 * dir[1], pos[2] + t1 * dir[2]};
+    double el = atan2(P[2], sqrt(P[0] * P[0] + P[1] * P[1]));
+    double az = atan2(P[1], P[0]);
+    if (az < 0) az += TWO_PI;
+    if (el < 0) el += TWO_PI;
+    if (az > TWO_PI) az -= TWO_PI;
+    if (el > TWO_PI) el -= TWO_PI;
+    double azimuth = py_mod((TWO_PI - az) - PI / 2.0, TWO_PI);
+    double u = azimuth / TWO_PI;
+    double elevation = py_mod(el + PI / 2.0, TWO_PI);
+    double vv = 1.0 - elevation / PI;
+    azs[k] = azimuth;
+    ptx[k] = u * (double)We;
+    pty[k] = vv * (double)He;
+  }
+  azs[N] = azs[0];
+  int count_true = 0, count_false = 0, pos_true = -1, pos_false = -1;
+  for (int k = 0; k < N; k++) {
+    double df = azs[k + 1] - azs[k];
+    bool close = fabs(df) <= 1e-8;       // np.isclose(df, 0): false for NaN
+    bool cnd = close || (df < 0);
+    if (cnd) { count_true++; if (pos_true < 0) pos_true = k; }
+    else { count_false++; if (pos_false < 0) pos_false = k; }
+  }
+  if (pos_true < 0 || pos_false < 0) return 0;
+  double fx[RR_MAX_FOV + 4], fy[RR_MAX_FOV + 4];
+  int m = 0;
+  double rows = (double)He, cols = (double)We;
+  if (count_true == 1 || count_false == 1) {
+    bool top = (count_true == 1);
+    int pp = top ? pos_true : pos_false;
+    for (int k = 0; k <= pp; k++) { fx[m] = ptx[k]; fy[m] = pty[k]; m++; }
+    int nxt = (pp + 1) % N;
+    if (top) {
+      fx[m] = cols; fy[m] = pty[pp]; m++;
+      fx[m] = cols; fy[m] = 0; m++;
+      fx[m] = 0; fy[m] = 0; m++;
+      fx[m] = 0; fy[m] = pty[nxt]; m++;
+    } else {
+      fx[m] = 0; fy[m] = pty[pp]; m++;
+      fx[m] = 0; fy[m] = rows; m++;
+      fx[m] = cols; fy[m] = rows; m++;
+      fx[m] = cols; fy[m] = pty[nxt]; m++;
+    }
+    for (int k = pp + 1; k < N; k++) { fx[m] = ptx[k]; fy[m] = pty[k]; m++; }
+  } else {
+    for (int k = 0; k < N; k++) { fx[m] = ptx[k]; fy[m] = pty[k]; m++; }
+  }
+  for (int k = 0; k < m; k++) {
+    if (!(fabs(fx[k]) < 1e15) || !(fabs(fy[k]) < 1e15)) return 0;   // NaN/inf -> Clipper range error
+    px[k] = (int32_t)fx[k];
+    py[k] = (int32_t)fy[k];
+  }
+  return m;
+}
+
+// FOV row span at pixel row y (oracle/cvlike.py fov_rowspans). false if the row is empty.
+RR_HD bool fov_rowspan(const int32_t* px, const int32_t* py, int n, int y, int We, int& xl, int& xr) {
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int i = 0; i < n; i++) {
+    int j = (i + 1 == n) ? 0 : i + 1;
+    int x0 = px[i], y0 = py[i], x1 = px[j], y1 = py[j];
+    int ylo = imin(y0, y1), yhi = imax(y0, y1);
+    if (y < ylo || y > yhi) continue;
+    if (y0 == y1) {
+      lo = imin(lo, imin(x0, x1));
+      hi = imax(hi, imax(x0, x1));
+    } else {
+      int xa, yA, xb, yB;
+      if (y1 < y0) { xa = x1; yA = y1; xb = x0; yB = y0; } else { xa = x0; yA = y0; xb = x1; yB = y1; }
+      int64_t den = yB - yA;
+      int64_t num = (int64_t)(xb - xa) * (int64_t)(y - yA);
+      // floor((2*num + den) / (2*den)), exact: |values| < 2^40
+      int64_t nn = 2 * num + den, dn = 2 * den;
+      int64_t q = nn / dn;
+      if ((nn % dn != 0) && ((nn < 0) != (dn < 0))) q -= 1;
+      int xv = xa + (int)q;
+      lo = imin(lo, xv);
+      hi = imax(hi, xv);
+    }
+  }
+  xl = imax(lo, 0);
+  xr = imin(hi, We - 1);
+  return xl <= xr;
+}
+
+// colour constants from the FOV sums (bad_weather.py:397-412, my_utils.py:55-85)
+// S = {sum x*w, sum y*w, sum Y*w, sum w} over the FOV mask.
+RR_HD void colour_from_sums(const double S[4], double sum_omega, double ambient, double Kbgr[3]) {
+  double x = S[0] / S[3], y = S[1] / S[3];
+  double avg_fov_lum = S[2] / sum_omega;
+  double drop_Y = 0.94 * avg_fov_lum + 0.06 * ambient;
+  // a gray pixel v has Y = v*(0.31+0.8124+0.01)/0.17697 (row-vector times matrix)
+  double Yg = ((0.31 + 0.8124) + 0.01) / 0.17697 * drop_Y;
+  double X = (Yg * x) / y;
+  double Z = (Yg * (1 - x - y)) / y;
+  double r = (X * 0.41847 + Yg * -0.091169) + Z * 0.0009209;
+  double g = (X * -0.15866 + Yg * 0.25243) + Z * -0.0025498;
+  double b = (X * -0.082835 + Yg * 0.015708) + Z * 0.1786;
+  Kbgr[0] = b;
+  Kbgr[1] = g;
+  Kbgr[2] = r;
+}
+
+// ---------------------------------------------------------------------------
+// per-drop plan  (generator.py:119-174, bad_weather.py:286-329,416-427)
+// ---------------------------------------------------------------------------
+RR_HD void solve8(double A[8][8], double b[8], double x[8]) {   // oracle/cvlike.py solve8
+  for (int col = 0; col < 8; col++) {
+    int piv = col;
+    double best = fabs(A[col][col]);
+    for (int r = col + 1; r < 8; r++)
+      if (fabs(A[r][col]) > best) { best = fabs(A[r][col]); piv = r; }
+    if (piv != col) {
+      for (int c = 0; c < 8; c++) { double t = A[col][c]; A[col][c] = A[piv][c]; A[piv][c] = t; }
+      double t = b[col]; b[col] = b[piv]; b[piv] = t;
+    }
+    for (int r = col + 1; r < 8; r++) {
+      double f = A[r][col] / A[col][col];
+      for (int c = col + 1; c < 8; c++) A[r][c] = A[r][c] - f * A[col][c];
+      b[r] = b[r] - f * b[col];
+    }
+  }
+  for (int r = 7; r >= 0; r--) {
+    double s = b[r];
+    for (int c = r + 1; c < 8; c++) s = s - A[r][c] * x[c];
+    x[r] = s / A[r][r];
+  }
+}
+
+RR_HD void invert3(const double m[9], double t[9]) {             // cv::invert 3x3
+  double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+  if (d == 0.0 || !(fabs(d) < 1.7e308)) {
+    for (int i = 0; i < 9; i++) t[i] = 0.0;
+    return;
+  }
+  d = 1.0 / d;
+  t[0] = (m[4] * m[8] - m[5] * m[7]) * d;
+  t[1] = (m[2] * m[7] - m[1] * m[8]) * d;
+  t[2] = (m[1] * m[5] - m[2] * m[4]) * d;
+  t[3] = (m[5] * m[6] - m[3] * m[8]) * d;
+  t[4] = (m[0] * m[8] - m[2] * m[6]) * d;
+  t[5] = (m[2] * m[3] - m[0] * m[5]) * d;
+  t[6] = (m[3] * m[7] - m[4] * m[6]) * d;
+  t[7] = (m[1] * m[6] - m[0] * m[7]) * d;
+  t[8] = (m[0] * m[4] - m[1] * m[3]) * d;
+}
+
+// Fills everything in `p` except the arena offsets.  `size_out` = doubles of arena needed.
+RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, const int32_t* tex_h, const int32_t* tex_w,
+                     double opacity_attenuation, DropPlan& p, int64_t& size_out) {
+  size_out = 0;
+  p.status = RR_DROP_OK;
+  p.tex = d.tex_index;
+  p.flip = 0;
+  p.bw0 = 1;
+  p.nW = p.nH = 0;
+  p.rs_mode = RS_AREA;
+  p.isx = p.isy = 1;
+  p.pad0 = 0;
+  p.a0_off = p.a1_off = 0;
+  p.final_buf = 0;
+  p.scale_x = p.scale_y = p.inv_sx = p.inv_sy = 1.0;
+  for (int i = 0; i < 9; i++) p.mi[i] = 0.0;
+  for (int i = 0; i < 6; i++) p.ma[i] = 0.0;
+  p.vis_x0 = p.vis_y0 = p.vis_w = p.vis_h = p.crop_x = p.crop_y = 0;
+  p.tw = p.th = p.pw = p.ph = p.shift = p.r1 = p.r2 = 0;
+  p.sig1 = p.sig2 = 0.0;
+  const int W = dm.W, H = dm.H;
+  const int sh = tex_h[d.tex_index], sw = tex_w[d.tex_index];
+
+  int minCx, minCy;
+  if (d.type == 0) {
+    p.kind = KIND_BIG;
+    double d0 = floor(d.iw1), d1 = floor(d.iw2);
+    int minx = imax(imin(d.x0, d.x1), 0), miny = imax(imin(d.y0, d.y1), 0);
+    double maxx = dmin(dmax((double)d.x0 + d0, (double)d.x1 + d1), (double)W);
+    int maxy = imin(imax(d.y0, d.y1), H);
+    int s0 = (int)(maxx - (double)minx), s1 = maxy - miny;
+    p.tw = imax(s0, 1);
+    p.th = imax(s1, 1);
+    float src[4][2] = {{0.f, 0.f}, {(float)sw, 0.f}, {(float)sw, (float)sh}, {0.f, (float)sh}};
+    float dst[4][2];
+    dst[0][0] = (float)(d.x0 - minx);                        dst[0][1] = (float)(d.y0 - miny);
+    dst[1][0] = (float)((double)(d.x0 - minx) + d0);         dst[1][1] = (float)(d.y0 - miny);
+    dst[2][0] = (float)(((double)(d.x1 - minx) + d1) + 0.001); dst[2][1] = (float)(d.y1 - miny);
+    dst[3][0] = (float)((double)(d.x1 - minx) + 0.001);      dst[3][1] = (float)(d.y1 - miny);
+    double A[8][8], bb[8], xx[8];
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < 8; j++) A[i][j] = 0.0;
+    for (int i = 0; i < 4; i++) {
+      double sx = src[i][0], sy = src[i][1], ddx = dst[i][0], ddy = dst[i][1];
+      A[i][0] = A[i + 4][3] = sx;
+      A[i][1] = A[i + 4][4] = sy;
+      A[i][2] = A[i + 4][5] = 1.0;
+      A[i][6] = -sx * ddx;
+      A[i][7] = -sy * ddx;
+      A[i + 4][6] = -sx * ddy;
+      A[i + 4][7] = -sy * ddy;
+      bb[i] = ddx;
+      bb[i + 4] = ddy;
+    }
+    solve8(A, bb, xx);
+    double M[9] = {xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], 1.0};
+    invert3(M, p.mi);
+    int bh0 = imin(16, p.th);
+    int bw0 = imin(1024 / bh0, p.tw);
+    p.bw0 = bw0;
+    minCx = minx;
+    minCy = miny;
+  } else {
+    p.kind = KIND_ROT;
+    p.flip = (d.x1 > W / 2) ? 1 : 0;
+    p.th = imax(iabs(d.y1 - d.y0), 2);
+    p.tw = imax(iabs(d.x1 - d.x0), d.max_width + 2);
+    // imutils.rotate_bound geometry
+    double cX = (double)sw / 2.0, cY = (double)sh / 2.0;
+    double cxf = (double)(float)cX, cyf = (double)(float)cY;
+    double al = d.rot_cos, be = d.rot_sin;
+    double M[6] = {al, be, (1 - al) * cxf - be * cyf, -be, al, be * cxf + (1 - al) * cyf};
+    double cs = fabs(M[0]), sn = fabs(M[1]);
+    int nW = (int)((double)sh * sn + (double)sw * cs);
+    int nH = (int)((double)sh * cs + (double)sw * sn);
+    M[2] += ((double)nW / 2.0) - cX;
+    M[5] += ((double)nH / 2.0) - cY;
+    p.nW = nW;
+    p.nH = nH;
+    // cv::warpAffine's in-place inversion
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = (D != 0.0) ? 1.0 / D : 0.0;
+    double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11;
+    M[1] = M[1] * (-D);
+    M[3] = M[3] * (-D);
+    M[4] = A22;
+    double b1 = -M[0] * M[2] - M[1] * M[5];
+    double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1;
+    M[5] = b2;
+    for (int i = 0; i < 6; i++) p.ma[i] = M[i];
+    if (nW <= 0 || nH <= 0) {
+      p.status = RR_DROP_FOV_FAIL;   // cv2.resize of an empty image raises in the reference
+      return;
+    }
+    p.inv_sx = (double)p.tw / (double)nW;
+    p.inv_sy = (double)p.th / (double)nH;
+    p.scale_x = 1.0 / p.inv_sx;
+    p.scale_y = 1.0 / p.inv_sy;
+    int isx = (int)cv_round(p.scale_x), isy = (int)cv_round(p.scale_y);
+    const double EPS = 2.220446049250313e-16;
+    bool fast = fabs(p.scale_x - (double)isx) < EPS && fabs(p.scale_y - (double)isy) < EPS;
+    if (p.scale_x >= 1.0 && p.scale_y >= 1.0) {
+      if (fast) { p.rs_mode = RS_AREA_FAST; p.isx = isx; p.isy = isy; }
+      else p.rs_mode = RS_AREA;
+    } else {
+      p.rs_mode = RS_LINEAR;
+    }
+    minCx = d.x0;
+    minCy = d.y0;
+  }
+
+  // circle of confusion (bad_weather.py:286-298,464-469)
+  double o = fabs(d.wps[2]);
+  double cc = ((o - cam.focus_plane) * cam.focal_sq) / (o * (cam.focus_plane - cam.focal_m) * cam.f_number);
+  cc = fabs(cc / cam.sensor_px);
+  if (!(cc < 1.7e308)) { p.status = RR_DROP_BAD_COC; return; }
+  if (10.0 * cc >= (double)(RR_MAX_SHIFT + 1)) { p.status = RR_DROP_TOO_BIG; return; }
+  p.shift = (int)(10.0 * cc);
+  p.sig1 = cc;
+  p.sig2 = cc / 2.0;
+  p.r1 = (p.sig1 > 1e-15) ? (int)(4.0 * p.sig1 + 0.5) : 0;
+  p.r2 = (p.sig2 > 1e-15) ? (int)(4.0 * p.sig2 + 0.5) : 0;
+  p.pw = p.tw + 2 * p.shift;
+  p.ph = p.th + 2 * p.shift;
+
+  // placement and crop (bad_weather.py:418-422,429-441)
+  int tmpx = minCx - p.shift, tmpy = minCy - p.shift;
+  int mcx = imin(imax(tmpx, 0), W), mcy = imin(imax(tmpy, 0), H);
+  int dx = mcx - tmpx, dy = mcy - tmpy;
+  int cw, ch;
+  if (dx < 0) { cw = imax(p.pw + dx, 0); p.crop_x = 0; } else { cw = imax(p.pw - dx, 0); p.crop_x = dx; }
+  if (dy < 0) { ch = imax(p.ph + dy, 0); p.crop_y = 0; } else { ch = imax(p.ph - dy, 0); p.crop_y = dy; }
+  p.vis_x0 = mcx;
+  p.vis_y0 = mcy;
+  p.vis_w = imax(imin(mcx + cw, W) - mcx, 0);
+  p.vis_h = imax(imin(mcy + ch, H) - mcy, 0);
+
+  // blend scalars (bad_weather.py:376,425-427)
+  double d_avg = (d.iw1 + d.iw2) / 2.0;
+  double length_opacity = opacity_attenuation * d_avg / ((double)d.length + d_avg);
+  p.tau_one = cam.exposure_s * length_opacity;
+  p.g = p.tau_one / cam.tau_zero;
+
+  p.final_buf = (p.r1 > 0 && p.r2 == 0) ? 1 : 0;
+  int64_t area = (int64_t)p.pw * (int64_t)p.ph;
+  size_out = (p.vis_w > 0 && p.vis_h > 0) ? area * (p.r1 > 0 ? 2 : 1) : 0;
+}
+
+// one output sample of the symmetric correlate1d (scipy ni_filters.c), zero extension.
+// src: padded tile (pitch pw), hw: half-table hw[k] = w[k], k = 0..r (w[r] is the centre).
+RR_HD double blur_axis0(const double* src, int pw, int ph, int x, int y, const double* hw, int r) {
+  double acc = src[(int64_t)y * pw + x] * hw[r];
+  for (int ii = -r; ii < 0; ii++) {
+    int ya = y + ii, yb = y - ii;
+    double va = (ya >= 0) ? src[(int64_t)ya * pw + x] : 0.0;
+    double vb = (yb < ph) ? src[(int64_t)yb * pw + x] : 0.0;
+    acc = acc + (va + vb) * hw[ii + r];
+  }
+  return acc;
+}
+RR_HD double blur_axis1(const double* src, int pw, int ph, int x, int y, const double* hw, int r) {
+  (void)ph;
+  const double* row = src + (int64_t)y * pw;
+  double acc = row[x] * hw[r];
+  for (int ii = -r; ii < 0; ii++) {
+    int xa = x + ii, xb = x - ii;
+    double va = (xa >= 0) ? row[xa] : 0.0;
+    double vb = (xb < pw) ? row[xb] : 0.0;
+    acc = acc + (va + vb) * hw[ii + r];
+  }
+  return acc;
+}
+
+// alpha-composite one drop sample into one pixel (bad_weather.py:443-446,450)
+RR_HD void blend_pixel(double A, double tau_one, double exposure, double g, const double K[3], double bgr[3], double& mask) {
+  double t = (A * tau_one) / exposure;
+  double u = 1.0 - t;
+  for (int c = 0; c < 3; c++) {
+    double v = u * bgr[c] + (A * K[c]) * g;
+    bgr[c] = clip01(v);
+  }
+  mask = mask + A;
+}
+
+}  // namespace rr

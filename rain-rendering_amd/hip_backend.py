@@ -1,0 +1,315 @@
+"""ctypes binding of librainhip.so (include/rainhip.h) and the host-side packing of the
+per-frame drop table.
+
+There is no CPU implementation behind this module: if the shared library or a gfx950
+device is missing, construction fails loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'librainhip.so')
+
+RR_MAX_FOV = 32
+RR_E_ARENA = -5
+
+# numpy mirror of rr_drop (112 bytes)
+DROP_DTYPE = np.dtype([
+    ('x0', '<i4'), ('y0', '<i4'), ('x1', '<i4'), ('y1', '<i4'),
+    ('max_width', '<i4'), ('length', '<i4'), ('type', '<i4'), ('tex_index', '<i4'),
+    ('iw1', '<f8'), ('iw2', '<f8'),
+    ('wps', '<f8', (3,)), ('wpe', '<f8', (3,)),
+    ('rot_cos', '<f8'), ('rot_sin', '<f8'),
+], align=True)
+
+
+class rr_camera(ctypes.Structure):
+    _fields_ = [('focal_m', ctypes.c_double), ('focal_sq', ctypes.c_double), ('f_number', ctypes.c_double),
+                ('focus_plane', ctypes.c_double), ('exposure_s', ctypes.c_double), ('radius', ctypes.c_double),
+                ('sensor_px', ctypes.c_double), ('tau_zero', ctypes.c_double),
+                ('fov_cos', ctypes.c_double), ('fov_sin', ctypes.c_double),
+                ('phi_cos', ctypes.c_double * RR_MAX_FOV), ('phi_sin', ctypes.c_double * RR_MAX_FOV),
+                ('n_fov', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class rr_frame_in(ctypes.Structure):
+    _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('He', ctypes.c_int32), ('We', ctypes.c_int32),
+                ('bg', ctypes.c_void_p), ('rainy_bg', ctypes.c_void_p), ('env_xyY', ctypes.c_void_p),
+                ('omega', ctypes.c_void_p), ('drops', ctypes.c_void_p),
+                ('n_drops', ctypes.c_int32), ('strategy', ctypes.c_int32),
+                ('opacity_attenuation', ctypes.c_double)]
+
+
+class rr_frame_out(ctypes.Structure):
+    _fields_ = [('rainy_rgb', ctypes.c_void_p), ('rainy_bg_out', ctypes.c_void_p), ('mask_f64', ctypes.c_void_p),
+                ('mask_i32', ctypes.c_void_p), ('drop_status', ctypes.c_void_p)]
+
+
+class rr_kernel_stat(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 32), ('launches', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('total_ms', ctypes.c_double)]
+
+
+EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_streak_db', 'rr_set_streak_db_device',
+           'rr_set_camera', 'rr_render_frames', 'rr_render_frames_device', 'rr_synchronize', 'rr_profile_enable',
+           'rr_profile_reset', 'rr_profile_read', 'rr_sizeof_drop', 'rr_sizeof_camera', 'rr_sizeof_frame_in',
+           'rr_sizeof_frame_out']
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load librainhip.so and check the struct layouts against the header."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("librainhip.so not found at %s -- run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                           "there is no CPU fallback" % p)
+    lib = ctypes.CDLL(p)
+    lib.rr_last_error.restype = ctypes.c_char_p
+    lib.rr_last_error.argtypes = [ctypes.c_void_p]
+    lib.rr_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    lib.rr_destroy.argtypes = [ctypes.c_void_p]
+    lib.rr_set_streak_db.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_int32]
+    lib.rr_set_streak_db_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    lib.rr_set_camera.argtypes = [ctypes.c_void_p, ctypes.POINTER(rr_camera)]
+    lib.rr_render_frames.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(rr_frame_in),
+                                     ctypes.POINTER(rr_frame_out)]
+    lib.rr_render_frames_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(rr_frame_in),
+                                            ctypes.POINTER(rr_frame_out), ctypes.c_void_p]
+    lib.rr_synchronize.argtypes = [ctypes.c_void_p]
+    lib.rr_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.rr_profile_reset.argtypes = [ctypes.c_void_p]
+    lib.rr_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(rr_kernel_stat), ctypes.c_int32]
+    assert lib.rr_sizeof_drop() == DROP_DTYPE.itemsize == 112, (lib.rr_sizeof_drop(), DROP_DTYPE.itemsize)
+    assert lib.rr_sizeof_camera() == ctypes.sizeof(rr_camera)
+    assert lib.rr_sizeof_frame_in() == ctypes.sizeof(rr_frame_in)
+    assert lib.rr_sizeof_frame_out() == ctypes.sizeof(rr_frame_out)
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def make_camera(focal_m, f_number, exposure_ms, focus_plane=6, radius=10, fov=165, n_fov=20):
+    """rr_camera from the reference's settings.  The hard-wired 6 / 10 / 165 / 20 are
+    generator.py:267 and generator.py:179; exposure is settings["cam_exposure"] in ms
+    (bad_weather.py:344)."""
+    cam = rr_camera()
+    cam.focal_m = float(focal_m)
+    cam.focal_sq = float(focal_m) ** 2                      # bad_weather.py:468 `self.f ** 2`
+    cam.f_number = float(f_number)
+    cam.focus_plane = float(focus_plane)
+    cam.exposure_s = exposure_ms / 1000.
+    cam.radius = float(radius)
+    cam.sensor_px = 4.65e-06
+    drop_size = 1.16 * 1e-3
+    cam.tau_zero = float(np.sqrt(drop_size) / 50)           # bad_weather.py:425
+    theta = np.deg2rad(fov / 2)
+    cam.fov_cos, cam.fov_sin = float(np.cos(-theta)), float(np.sin(-theta))
+    phi = np.arange(0, 2 * np.pi, (2 * np.pi) / n_fov)      # bad_weather.py:630
+    assert len(phi) == n_fov <= RR_MAX_FOV
+    for k in range(n_fov):
+        cam.phi_cos[k] = float(np.cos(phi[k]))
+        cam.phi_sin[k] = float(np.sin(phi[k]))
+    cam.n_fov = n_fov
+    return cam
+
+
+def filter_streaks(table, imW, imH):
+    """The frame filter of Generator.run (generator.py:413-420) on a StreakTable."""
+    m = max(imH, imW)
+    s, e = table.ips, table.ipe
+    inside_s = (0 <= s[:, 0]) & (s[:, 0] < imW) & (0 <= s[:, 1]) & (s[:, 1] < imH)
+    inside_e = (0 <= e[:, 0]) & (e[:, 0] < imW) & (0 <= e[:, 1]) & (e[:, 1] < imH)
+    keep = (1 <= table.max_width) & (table.max_width < m) & (1 <= table.length) & (table.length < m) & \
+        (inside_s | inside_e)
+    return np.nonzero(keep)[0]
+
+
+def pack_drops(table, idx, db, noise_std=0.0, noise_scale=0.0):
+    """rr_drop[] for the streaks table[idx], consuming the legacy global RandomState exactly
+    like the reference's per-drop loop does: one randint per drop (bad_weather.py:252-264),
+    then one normal per non-Big drop (generator.py:136).  Applies the in-place endpoint
+    rotation of generator.py:152-161 to the table (persistent, like the reference)."""
+    n = len(idx)
+    out = np.zeros(n, DROP_DTYPE)
+    if n == 0:
+        return out
+    bucket = db.texture_bucket(table.ratio[idx])
+    types = table.type[idx]
+    tex = np.empty(n, np.int32)
+    noise = np.zeros(n)
+    randint, normal = np.random.randint, np.random.normal
+    lo = (bucket * 10).tolist()
+    big = (types == 0).tolist()
+    for k in range(n):
+        tex[k] = randint(lo[k], lo[k] + 10)
+        if not big[k]:
+            noise[k] = normal(0.0, noise_std) * noise_scale
+    s = table.ips[idx].astype(np.float64)
+    e = table.ipe[idx].astype(np.float64)
+    nb = types != 0
+    with np.errstate(all='ignore'):
+        d = s - e
+        n1 = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+        theta = np.rad2deg(np.arccos((d[:, 0] / n1) * 0 + (d[:, 1] / n1) * -1))
+        ang = -(theta + noise) * (np.pi / 180)
+        rot_cos, rot_sin = np.cos(ang), np.sin(ang)
+    if np.any(noise != 0):
+        nx, ny = np.cos(np.deg2rad(noise)), np.sin(np.deg2rad(noise))
+        mx = (e[:, 0] + s[:, 0]) / 2
+        my = (e[:, 1] + s[:, 1]) / 2
+        s2 = np.stack([(s[:, 0] - mx) * nx - (s[:, 1] - my) * ny + mx,
+                       (s[:, 0] - mx) * ny + (s[:, 1] - my) * nx + my], axis=1).astype(np.int64)
+        e2 = np.stack([(e[:, 0] - mx) * nx - (e[:, 1] - my) * ny + mx,
+                       (e[:, 0] - mx) * ny + (e[:, 1] - my) * nx + my], axis=1).astype(np.int64)
+        sel = idx[nb]
+        table.ips[sel] = s2[nb]
+        table.ipe[sel] = e2[nb]
+    out['x0'] = table.ips[idx, 0]
+    out['y0'] = table.ips[idx, 1]
+    out['x1'] = table.ipe[idx, 0]
+    out['y1'] = table.ipe[idx, 1]
+    out['max_width'] = table.max_width[idx]
+    out['length'] = table.length[idx]
+    out['type'] = types
+    out['tex_index'] = tex
+    out['iw1'] = table.iw1[idx]
+    out['iw2'] = table.iw2[idx]
+    out['wps'] = table.wps[idx]
+    out['wpe'] = table.wpe[idx]
+    out['rot_cos'] = np.where(nb, rot_cos, 1.0)
+    out['rot_sin'] = np.where(nb, rot_sin, 0.0)
+    return out
+
+
+def pack_streak_db(textures):
+    """(texels uint8[], tex_h int32[], tex_w int32[], tex_off int64[]) for rr_set_streak_db."""
+    hs = np.array([t.shape[0] for t in textures], np.int32)
+    ws = np.array([t.shape[1] for t in textures], np.int32)
+    sizes = hs.astype(np.int64) * ws
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    texels = np.concatenate([np.ascontiguousarray(t, np.uint8).ravel() for t in textures])
+    return texels, hs, ws, offs
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class RainHip:
+    """One rendering context on one GPU (one per process / per GPU)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.rr_create(ctypes.byref(h), int(device))
+        if rc != 0:
+            raise RuntimeError("rr_create(device=%d) failed with %d: this path needs a gfx950 GPU "
+                               "(no CPU fallback)" % (device, rc))
+        self.h = h
+        self.device = device
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.rr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.rr_last_error(self.h).decode()))
+        return rc
+
+    def set_streak_db(self, textures):
+        texels, hs, ws, offs = pack_streak_db(textures)
+        self._db_meta = (hs, ws, offs, int(texels.size))
+        self._check(self.lib.rr_set_streak_db(self.h, _ptr(texels), _ptr(hs), _ptr(ws), _ptr(offs), len(hs)),
+                    'rr_set_streak_db')
+
+    def set_streak_db_device(self, dev_ptr, n_bytes, hs, ws, offs):
+        hs = np.ascontiguousarray(hs, np.int32)
+        ws = np.ascontiguousarray(ws, np.int32)
+        offs = np.ascontiguousarray(offs, np.int64)
+        self._check(self.lib.rr_set_streak_db_device(self.h, ctypes.c_void_p(dev_ptr), int(n_bytes), _ptr(hs), _ptr(ws),
+                                                     _ptr(offs), len(hs)), 'rr_set_streak_db_device')
+
+    def set_camera(self, cam):
+        self.cam = cam
+        self._check(self.lib.rr_set_camera(self.h, ctypes.byref(cam)), 'rr_set_camera')
+
+    def render_frames(self, frames, want_composite=True):
+        """frames: list of dict(bg, rainy_bg, env_xyY, omega, drops[, opacity_attenuation]) with
+        C-contiguous float64 arrays and a DROP_DTYPE drop table.  Returns a list of
+        dict(image_u8 RGB, rainy_bg, mask, mask_i32, status)."""
+        n = len(frames)
+        fin = (rr_frame_in * n)()
+        fout = (rr_frame_out * n)()
+        outs = []
+        keep = []
+        for k, fr in enumerate(frames):
+            bg = np.ascontiguousarray(fr['bg'], np.float64)
+            rb = np.ascontiguousarray(fr['rainy_bg'], np.float64)
+            env = np.ascontiguousarray(fr['env_xyY'], np.float64)
+            om = np.ascontiguousarray(fr['omega'], np.float64)
+            drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
+            H, W = bg.shape[:2]
+            He, We = om.shape[:2]
+            assert bg.shape == (H, W, 3) and rb.shape == (H, W, 3) and env.shape == (He, We, 3)
+            o = dict(image_u8=np.zeros((H, W, 3), np.uint8),
+                     rainy_bg=np.zeros((H, W, 3), np.float64) if want_composite else None,
+                     mask=np.zeros((H, W), np.float64), mask_i32=np.zeros((H, W), np.int32),
+                     status=np.zeros(len(drops), np.int32))
+            fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, He, We
+            fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY, fin[k].omega = _ptr(bg), _ptr(rb), _ptr(env), _ptr(om)
+            fin[k].drops = _ptr(drops) if len(drops) else None
+            fin[k].n_drops = len(drops)
+            fin[k].strategy = 0
+            fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
+            fout[k].rainy_rgb = _ptr(o['image_u8'])
+            fout[k].rainy_bg_out = _ptr(o['rainy_bg'])
+            fout[k].mask_f64 = _ptr(o['mask'])
+            fout[k].mask_i32 = _ptr(o['mask_i32'])
+            fout[k].drop_status = _ptr(o['status']) if len(drops) else None
+            keep.append((bg, rb, env, om, drops))
+            outs.append(o)
+        self._check(self.lib.rr_render_frames(self.h, n, fin, fout), 'rr_render_frames')
+        return outs
+
+    # ---- device-resident path (bench / multi-frame pipelines) -------------------------------
+    def render_frames_device(self, fin, fout, n, stream=None):
+        """fin/fout: ctypes arrays of rr_frame_in/out holding DEVICE pointers."""
+        rc = self.lib.rr_render_frames_device(self.h, n, fin, fout, ctypes.c_void_p(stream) if stream else None)
+        self._check(rc, 'rr_render_frames_device')
+
+    def synchronize(self):
+        """Returns True if the batch completed, False if the tile arena had to be regrown
+        (re-enqueue the batch)."""
+        rc = self.lib.rr_synchronize(self.h)
+        if rc == RR_E_ARENA:
+            return False
+        self._check(rc, 'rr_synchronize')
+        return True
+
+    def profile(self, on):
+        self.lib.rr_profile_enable(self.h, 1 if on else 0)
+
+    def profile_reset(self):
+        self.lib.rr_profile_reset(self.h)
+
+    def profile_read(self):
+        buf = (rr_kernel_stat * 32)()
+        n = self._check(self.lib.rr_profile_read(self.h, buf, 32), 'rr_profile_read')
+        return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(n)}

@@ -1,0 +1,170 @@
+// tests/hostemu/hostemu.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the __host__ __device__ arithmetic of rain-rendering_amd/csrc/rr_device.h with
+// g++ and drives it with plain loops that mirror the kernel chain of rainhip.hip, so the
+// CPU-only test tier can check the kernel arithmetic against the numpy oracle bit for bit
+// without a GPU.  Nothing in the product loads this library; it exists to find arithmetic
+// bugs before spending GPU minutes.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "rr_device.h"
+
+using namespace rr;
+
+extern "C" {
+
+int emu_sizeof_plan(void) { return (int)sizeof(DropPlan); }
+
+// plan + polygon for n drops.  poly: n*2*36 int32, npts: n, sizes: n
+int emu_plan(const rr_drop* drops, int n, const rr_camera* cam, int H, int W, int He, int We, const int32_t* tex_h,
+             const int32_t* tex_w, double opacity, DropPlan* plans, int32_t* poly, int32_t* npts, int64_t* sizes) {
+  Dims dm{H, W, He, We};
+  for (int i = 0; i < n; i++) {
+    int64_t size = 0;
+    plan_drop(drops[i], *cam, dm, tex_h, tex_w, opacity, plans[i], size);
+    int32_t* px = poly + (int64_t)i * 2 * 36;
+    npts[i] = fov_polygon(drops[i], *cam, He, We, px, px + 36);
+    if (plans[i].status != RR_DROP_OK || npts[i] == 0) size = 0;
+    sizes[i] = size;
+  }
+  return 0;
+}
+
+// finished (padded, blurred) alpha tile of one drop into out[ph*pw]
+int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+             double* out) {
+  float ctab[128];
+  build_cubic_tab(ctab);
+  const uint8_t* tex = texels + tex_off[p->tex];
+  const int sh = tex_h[p->tex], sw = tex_w[p->tex];
+  const int n = p->pw * p->ph;
+  std::vector<double> a0(n), a1(n);
+  for (int idx = 0; idx < n; idx++) {
+    int y = idx / p->pw, x = idx - y * p->pw;
+    int rx = x - p->shift, ry = y - p->shift;
+    double v = 0.0;
+    if (rx >= 0 && rx < p->tw && ry >= 0 && ry < p->th) v = raw_tile_pixel(*p, tex, sh, sw, ctab, rx, ry);
+    a0[idx] = v;
+  }
+  auto half = [](double sigma, int r, std::vector<double>& hw) {
+    hw.resize(r + 1);
+    for (int k = 0; k <= r; k++) hw[k] = gauss_phi(sigma, r - k);
+    double tot = 0.0;
+    for (int x = -r; x <= r; x++) tot = tot + hw[r - (x < 0 ? -x : x)];
+    for (int k = 0; k <= r; k++) hw[k] = hw[k] / tot;
+  };
+  std::vector<double> hw;
+  double* cur = a0.data();
+  if (p->r1 > 0) {
+    half(p->sig1, p->r1, hw);
+    for (int idx = 0; idx < n; idx++) {
+      int y = idx / p->pw, x = idx - y * p->pw;
+      a1[idx] = blur_axis0(a0.data(), p->pw, p->ph, x, y, hw.data(), p->r1);
+    }
+    cur = a1.data();
+    if (p->r2 > 0) {
+      half(p->sig2, p->r2, hw);
+      for (int idx = 0; idx < n; idx++) {
+        int y = idx / p->pw, x = idx - y * p->pw;
+        a0[idx] = blur_axis1(a1.data(), p->pw, p->ph, x, y, hw.data(), p->r2);
+      }
+      cur = a0.data();
+    }
+  }
+  memcpy(out, cur, sizeof(double) * n);
+  return 0;
+}
+
+// whole frame, mirroring the kernel chain
+int emu_render_frame(int H, int W, int He, int We, const double* bg, const double* rainy_bg, const double* env,
+                     const double* omega, const rr_drop* drops, int n, const rr_camera* cam, double opacity,
+                     const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                     uint8_t* rgb, double* comp_out, double* mask, int32_t* mask_i32, int32_t* status, double* Kout) {
+  Dims dm{H, W, He, We};
+  // prefix table + frame constants
+  std::vector<double> P((size_t)He * (We + 1) * 4, 0.0);
+  double sumW = 0, sumY = 0;
+  for (int r = 0; r < He; r++) {
+    double run[4] = {0, 0, 0, 0};
+    double* row = P.data() + (size_t)r * (We + 1) * 4;
+    for (int c = 0; c < We; c++) {
+      double w = omega[(size_t)r * We + c];
+      const double* e = env + ((size_t)r * We + c) * 3;
+      run[0] += e[0] * w; run[1] += e[1] * w; run[2] += e[2] * w; run[3] += w;
+      for (int k = 0; k < 4; k++) row[(size_t)(c + 1) * 4 + k] = run[k];
+    }
+    sumY += run[2];
+    sumW += run[3];
+  }
+  const double ambient = sumY / sumW;
+  std::vector<DropPlan> plans(n);
+  std::vector<CompRec> recs(n);
+  std::vector<std::vector<double>> tiles(n);
+  for (int i = 0; i < n; i++) {
+    int64_t size = 0;
+    DropPlan& p = plans[i];
+    plan_drop(drops[i], *cam, dm, tex_h, tex_w, opacity, p, size);
+    int32_t px[36], py[36];
+    int np_ = fov_polygon(drops[i], *cam, He, We, px, py);
+    if (p.status != RR_DROP_OK || np_ == 0) size = 0;
+    CompRec& rec = recs[i];
+    memset(&rec, 0, sizeof(rec));
+    int st = p.status;
+    if (np_ == 0) st = RR_DROP_FOV_FAIL;
+    if (np_ > 0) {
+      int ymin = py[0], ymax = py[0];
+      for (int k = 1; k < np_; k++) { ymin = imin(ymin, py[k]); ymax = imax(ymax, py[k]); }
+      int ya = imax(ymin, 0), yb = imin(ymax, He - 1);
+      double S[4] = {0, 0, 0, 0};
+      bool any = false;
+      for (int y = ya; y <= yb; y++) {
+        int xl, xr;
+        if (fov_rowspan(px, py, np_, y, We, xl, xr)) {
+          any = true;
+          const double* row = P.data() + (size_t)y * (We + 1) * 4;
+          for (int k = 0; k < 4; k++) S[k] += row[(size_t)(xr + 1) * 4 + k] - row[(size_t)xl * 4 + k];
+        }
+      }
+      if (!any) st = RR_DROP_EMPTY_FOV;
+      if (st == RR_DROP_OK && size > 0) {
+        colour_from_sums(S, sumW, ambient, rec.K);
+        rec.x0 = p.vis_x0; rec.y0 = p.vis_y0; rec.x1 = p.vis_x0 + p.vis_w; rec.y1 = p.vis_y0 + p.vis_h;
+        rec.ox = p.crop_x - p.vis_x0; rec.oy = p.crop_y - p.vis_y0;
+        rec.pitch = p.pw; rec.tau_one = p.tau_one; rec.g = p.g;
+        tiles[i].resize((size_t)p.pw * p.ph);
+        emu_tile(&p, texels, tex_h, tex_w, tex_off, tiles[i].data());
+      }
+    }
+    if (status) status[i] = st;
+    if (Kout) { Kout[i * 3] = rec.K[0]; Kout[i * 3 + 1] = rec.K[1]; Kout[i * 3 + 2] = rec.K[2]; }
+  }
+  // compositor, drop order per pixel
+  for (size_t k = 0; k < (size_t)H * W * 3; k++) comp_out[k] = rainy_bg[k];
+  for (size_t k = 0; k < (size_t)H * W; k++) mask[k] = 0.0;
+  for (int i = 0; i < n; i++) {
+    const CompRec& r = recs[i];
+    for (int y = r.y0; y < r.y1; y++)
+      for (int x = r.x0; x < r.x1; x++) {
+        double A = tiles[i][(size_t)(y + r.oy) * r.pitch + (x + r.ox)];
+        size_t pix = (size_t)y * W + x;
+        blend_pixel(A, r.tau_one, cam->exposure_s, r.g, r.K, comp_out + pix * 3, mask[pix]);
+      }
+  }
+  double sc = 0, sb = 0;
+  for (size_t k = 0; k < (size_t)H * W * 3; k++) { sc += comp_out[k]; sb += bg[k]; }
+  const double cnt = (double)H * W * 3.0;
+  const double diff = sc / cnt - sb / cnt;
+  for (size_t pix = 0; pix < (size_t)H * W; pix++) {
+    mask_i32[pix] = (int32_t)floor(mask[pix] * 255.0);
+    for (int k = 0; k < 3; k++) {
+      double v = clip01(comp_out[pix * 3 + (2 - k)] - diff);
+      rgb[pix * 3 + k] = (uint8_t)(int)(v * 255.0);
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"
