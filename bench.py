@@ -1,0 +1,200 @@
+"""bench.py -- rainy frames/sec of the MI355X hot path on synthetic KITTI-shaped inputs.
+
+  python bench.py --gpus N --steps K --warmup W            (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (rr_render_frames_device: environment-map prefix
+sums, per-drop plan, colour, tile synthesis, defocus blur, ordered compositing, finalise)
+over one batch of --batch synthetic frames whose inputs are already resident in HBM.
+Workload = BASELINE.json configs[2]: 1242x375, "100 mm/hr" = 8192 streaks per frame
+(synthetic count).  Frames shard across ranks (weak scaling: every rank renders
+its own batch); the only collective on the data path is one RCCL broadcast of the packed
+streak database from rank 0 at start-up.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(H, W, He, We, N):
+    """bytes(frame) = 27*H*W + 16*He*We + 64*N."""
+    return 27 * H * W + 16 * He * We + 64 * N
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4, help='frames per step and per GPU')
+    ap.add_argument('--height', type=int, default=375)
+    ap.add_argument('--width', type=int, default=1242)
+    ap.add_argument('--rate', type=int, default=100, help='mm/hr (selects the synthetic drop count)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-drops', type=int, default=1024)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import helpers as h
+    hb, synthetic = h.hb, h.synthetic
+
+    H, W, B = args.height, args.width, args.batch
+    N = synthetic.DROPS_PER_RATE[args.rate]
+    tmp = tempfile.mkdtemp(prefix='rainbench_r%d_' % rank)
+    # every rank simulates its own frames (seeded by rank); rank 0 owns the streak database
+    sc = h.Scene(tmp, H, W, N, n_frames=B, seed0=3000 + 1000 * rank)
+    He, We = sc.He, sc.We
+
+    rh = hb.RainHip(local_rank)
+    # --- the one collective: RCCL broadcast of the packed streak DB over xGMI -----------------
+    texels, hs, ws, offs = hb.pack_streak_db(sc.db.streaks_light)
+    t_tex = torch.from_numpy(texels).to(dev)
+    if world > 1:
+        dist.broadcast(t_tex, src=0)
+        torch.cuda.synchronize()
+    rh.set_streak_db_device(t_tex.data_ptr(), t_tex.numel(), hs, ws, offs)
+    rh.set_camera(sc.cam)
+
+    # --- inputs resident in HBM ----------------------------------------------------------------
+    keep = []
+    fin = (hb.rr_frame_in * B)()
+    fout = (hb.rr_frame_out * B)()
+    omega_t = torch.from_numpy(np.ascontiguousarray(sc.omega)).to(dev)
+    host_frames = []
+    for i in range(B):
+        bg, env = sc.frame_inputs(i + 100 * rank)
+        drops = sc.product_drops(i)
+        host_frames.append((bg, env, drops))
+        t_bg = torch.from_numpy(bg).to(dev)
+        t_env = torch.from_numpy(env).to(dev)
+        t_dr = torch.from_numpy(drops.view(np.uint8).reshape(-1)).to(dev)
+        o_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        o_m = torch.empty((H, W), dtype=torch.float64, device=dev)
+        o_mi = torch.empty((H, W), dtype=torch.int32, device=dev)
+        o_st = torch.empty((max(len(drops), 1),), dtype=torch.int32, device=dev)
+        keep += [t_bg, t_env, t_dr, o_rgb, o_m, o_mi, o_st]
+        fin[i].H, fin[i].W, fin[i].He, fin[i].We = H, W, He, We
+        fin[i].bg = fin[i].rainy_bg = t_bg.data_ptr()
+        fin[i].env_xyY = t_env.data_ptr()
+        fin[i].omega = omega_t.data_ptr()
+        fin[i].drops = t_dr.data_ptr()
+        fin[i].n_drops = len(drops)
+        fin[i].strategy = 0
+        fin[i].opacity_attenuation = 1.0
+        fout[i].rainy_rgb = o_rgb.data_ptr()
+        fout[i].rainy_bg_out = None
+        fout[i].mask_f64 = o_m.data_ptr()
+        fout[i].mask_i32 = o_mi.data_ptr()
+        fout[i].drop_status = o_st.data_ptr()
+    n_drops_mean = float(np.mean([len(f[2]) for f in host_frames]))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        rh.render_frames_device(fin, fout, B, stream)
+
+    # warm-up (also sizes the tile arena: re-enqueue until it fits)
+    for _ in range(max(args.warmup, 1)):
+        step()
+        while not rh.synchronize():
+            step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
+    rh.profile_reset()
+    rh.profile(True)               # HIP events around every launch, on the launch stream
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    rh.profile(False)
+    assert rh.synchronize(), "tile arena regrew inside the timed region"
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    stats = rh.profile_read()
+
+    if rank == 0:
+        frames_total = B * args.steps * world
+        fps = frames_total / elapsed
+        dom = max(stats.items(), key=lambda kv: kv[1][1])
+        dom_name, (dom_launches, dom_ms) = dom
+        avg_ms = dom_ms / dom_launches
+        alg = algorithmic_bytes(H, W, He, We, n_drops_mean) * B
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "rainy frames/sec @ 1242x375, 100 mm/hr",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "KITTI data_object shape %dx%d, %d mm/hr (%d streaks/frame after the frame filter: %.0f), "
+                                   "precomputed particles; BASELINE.json configs[2]" % (W, H, args.rate, N, n_drops_mean),
+                       "frames_per_step_per_gpu": B, "envmap": "%dx%d" % (We, He), "parallelism": "frames sharded, dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
+            "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+        }
+        if not args.no_cpu_baseline:
+            # CPU reference = the numpy oracle in its op-for-op ("faithful") mode, 1 core, on the
+            # first --cpu-sample-drops streaks of frame 0; extrapolated linearly in the drop count.
+            from oracle import render as orc
+            bg, env, drops = host_frames[0]
+            textures, ratio = sc.oracle_db()
+            streaks = sc.oracle_streaks(0)
+            ns = min(args.cpu_sample_drops, len(streaks))
+            c0 = time.perf_counter()
+            orc.render_frame(bg, bg, env, sc.omega, streaks, textures, ratio, sc.ocam, frame_seed=0, faithful=True,
+                             max_drops=ns)
+            c1 = time.perf_counter()
+            per_drop = (c1 - c0) / ns
+            cpu_fps = 1.0 / (per_drop * len(streaks))
+            out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d of %d streaks of frame 0 (%.1f s, %.2f ms/drop), extrapolated linearly"
+                                             % (ns, len(streaks), c1 - c0, 1e3 * per_drop)}
+            out["speedup_vs_cpu"] = fps / cpu_fps
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    rh.close()
+
+
+if __name__ == '__main__':
+    main()
