@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -272,24 +273,142 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
 // ---------------------------------------------------------------------------
 // tile synthesis
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_raw(const FrameDesc* frames, int max_drops, const uint8_t* texels,
-                                                  const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                                  const float* ctab, Scratch sc) {
+// Simple variant (one thread per output pixel, texels from global memory).  Kept as the
+// readable definition of the tile and as an A/B reference (RAINHIP_SIMPLE_TILE=1).
+__global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, int max_drops, const uint8_t* texels,
+                                                     const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                                                     const float* ctab, Scratch sc) {
   const int f = blockIdx.y, i = blockIdx.x;
   if (i >= frames[f].n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
   const DropPlan& p = sc.plan[gi];
   if (p.status != RR_DROP_OK || sc.sizes[gi] == 0) return;
-  const uint8_t* tex = texels + tex_off[p.tex];
-  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  TexGlobal tx{texels + tex_off[p.tex], tex_h[p.tex], tex_w[p.tex]};
   double* A0 = sc.arena + p.a0_off;
   const int n = p.pw * p.ph;
   for (int idx = threadIdx.x; idx < n; idx += 256) {
     int y = idx / p.pw, x = idx - y * p.pw;
     int rx = x - p.shift, ry = y - p.shift;
     double v = 0.0;
-    if (rx >= 0 && rx < p.tw && ry >= 0 && ry < p.th) v = raw_tile_pixel(p, tex, sh, sw, ctab, rx, ry);
+    if (rx >= 0 && rx < p.tw && ry >= 0 && ry < p.th) v = raw_tile_pixel(p, tx, ctab, rx, ry);
     A0[idx] = v;
+  }
+}
+
+// Production variant: one 256-thread block per drop.
+//   * texels (u8) and the 256-entry v/255.0 table live in LDS;
+//   * the INTER_AREA resize of the rotated canvas -- ~nW*nH bilinear samples for a handful of
+//     output pixels -- is split into (source row, destination column) partial sums that all
+//     256 threads compute in parallel into an LDS buffer, followed by the short vertical
+//     accumulation per output pixel.  Every partial sum and every accumulation runs in the
+//     order resizeArea_ uses, so the result is bit-identical to k_tile_simple / the oracle.
+constexpr int TEX_LDS = 12288;
+constexpr int NW_MAX = 512;
+constexpr int TW_MAX = 128;
+constexpr int BUF_MAX = 2048;
+
+__global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
+                                              const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                                              const float* ctab, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  if (sc.sizes[gi] == 0) return;
+  __shared__ DropPlan sp;
+  __shared__ double s_lut[256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
+  __shared__ int32_t s_ad[NW_MAX], s_bd[NW_MAX];
+  __shared__ AreaSpan s_ax[TW_MAX];
+  __shared__ double s_buf[BUF_MAX];
+  {
+    const int32_t* src = reinterpret_cast<const int32_t*>(&sc.plan[gi]);
+    int32_t* dst = reinterpret_cast<int32_t*>(&sp);
+    for (int k = t; k < (int)(sizeof(DropPlan) / 4); k += 256) dst[k] = src[k];
+  }
+  s_lut[t] = (double)t / 255.0;
+  __syncthreads();
+  const DropPlan& p = sp;
+  if (p.status != RR_DROP_OK) return;
+  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  const uint8_t* gtex = texels + tex_off[p.tex];
+  const bool tex_fits = sh * sw <= TEX_LDS;
+  if (tex_fits)
+    for (int k = t; k < sh * sw; k += 256) s_tex[k] = gtex[k];
+  TexLut tx{tex_fits ? s_tex : gtex, s_lut, sh, sw};
+  double* A0 = sc.arena + p.a0_off;
+  const int pw = p.pw, ph = p.ph, shift = p.shift, tw = p.tw, th = p.th;
+  // zero the defocus pad
+  if (shift > 0) {
+    const int n = pw * ph;
+    for (int idx = t; idx < n; idx += 256) {
+      int y = idx / pw, x = idx - y * pw;
+      int rx = x - shift, ry = y - shift;
+      if (!(rx >= 0 && rx < tw && ry >= 0 && ry < th)) A0[idx] = 0.0;
+    }
+  }
+  const double sy_scale = p.scale_y;
+  const int rows_per_dy = (int)ceil(sy_scale) + 3;
+  const bool fast = p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.nW <= NW_MAX && tw <= TW_MAX && rows_per_dy * tw <= BUF_MAX;
+  if (!fast) {
+    __syncthreads();
+    const int n = tw * th;
+    for (int idx = t; idx < n; idx += 256) {
+      int y = idx / tw, x = idx - y * tw;
+      A0[(int64_t)(y + shift) * pw + (x + shift)] = raw_tile_pixel(p, tx, ctab, x, y);
+    }
+    return;
+  }
+  for (int rx = t; rx < p.nW; rx += 256) {
+    s_ad[rx] = (int32_t)rot_adelta(p, rx);
+    s_bd[rx] = (int32_t)rot_bdelta(p, rx);
+  }
+  for (int dx = t; dx < tw; dx += 256) s_ax[dx] = area_span(p.nW, p.scale_x, dx);
+  __syncthreads();
+  // destination rows per chunk so that the source rows x tw fit the LDS buffer
+  int k_dy = (int)(((double)(BUF_MAX / tw) - 3.0) / sy_scale);
+  if (k_dy < 1) k_dy = 1;
+  for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
+    const int dy1 = imin(dy0 + k_dy, th);
+    const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
+    const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, p.nH - 1);
+    const int rows = hi - lo + 1;                 // <= k_dy*scale_y + 3 <= BUF_MAX / tw
+    const int items = rows * tw;
+    for (int it = t; it < items; it += 256) {
+      const int r = it / tw, dx = it - r * tw;
+      const int sy = lo + r;
+      const int ry = p.flip ? (p.nH - 1 - sy) : sy;
+      const int64_t X0 = rot_X0(p, ry), Y0 = rot_Y0(p, ry);
+      const AreaSpan ax = s_ax[dx];
+      double b = 0.0;
+      if (ax.has_l) b = b + rot_sample(tx, X0, Y0, (int64_t)s_ad[ax.s1 - 1], (int64_t)s_bd[ax.s1 - 1]) * (double)ax.a_l;
+      for (int sx = ax.s1; sx < ax.s2; sx++) b = b + rot_sample(tx, X0, Y0, (int64_t)s_ad[sx], (int64_t)s_bd[sx]) * (double)ax.a_m;
+      if (ax.has_r) b = b + rot_sample(tx, X0, Y0, (int64_t)s_ad[ax.s2], (int64_t)s_bd[ax.s2]) * (double)ax.a_r;
+      s_buf[it] = b;
+    }
+    __syncthreads();
+    const int npx = (dy1 - dy0) * tw;
+    for (int it = t; it < npx; it += 256) {
+      const int r = it / tw, dx = it - r * tw;
+      const int dy = dy0 + r;
+      const AreaSpan ay = area_span(p.nH, sy_scale, dy);
+      double acc = 0.0;
+      bool first = true;
+      if (ay.has_l) {
+        acc = (double)ay.a_l * s_buf[(ay.s1 - 1 - lo) * tw + dx];
+        first = false;
+      }
+      for (int sy = ay.s1; sy < ay.s2; sy++) {
+        double v = (double)ay.a_m * s_buf[(sy - lo) * tw + dx];
+        acc = first ? v : acc + v;
+        first = false;
+      }
+      if (ay.has_r) {
+        double v = (double)ay.a_r * s_buf[(ay.s2 - lo) * tw + dx];
+        acc = first ? v : acc + v;
+      }
+      A0[(int64_t)(dy + shift) * pw + (dx + shift)] = clip01(acc);
+    }
+    __syncthreads();
   }
 }
 
@@ -500,6 +619,7 @@ struct rr_ctx {
   } st;
   // profiling
   bool prof = false;
+  bool simple_tile = false;          // RAINHIP_SIMPLE_TILE=1: one-thread-per-pixel tile kernel (A/B reference)
   std::vector<ProfEntry> prof_pending;
   std::vector<rr_kernel_stat> prof_stats;
   std::vector<hipEvent_t> ev_pool;
@@ -713,9 +833,13 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       hipLaunchKernelGGL(k_colour, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
     }
     {
-      ProfScope ps(ctx, s, "k_tile_raw");
-      hipLaunchKernelGGL(k_tile_raw, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
-                         ctx->d_tex_off, ctx->d_ctab, sc);
+      ProfScope ps(ctx, s, "k_tile");
+      if (ctx->simple_tile)
+        hipLaunchKernelGGL(k_tile_simple, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
+                           ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
+      else
+        hipLaunchKernelGGL(k_tile, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+                           ctx->d_tex_off, ctx->d_ctab, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
@@ -779,6 +903,10 @@ int rr_create(rr_ctx** out, int device) {
   if (strncmp(prop.gcnArchName, "gfx9", 4) != 0) return RR_E_NO_DEVICE;
   rr_ctx* ctx = new rr_ctx();
   ctx->device = device;
+  {
+    const char* e = getenv("RAINHIP_SIMPLE_TILE");
+    ctx->simple_tile = e && e[0] == '1';
+  }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return RR_E_HIP;

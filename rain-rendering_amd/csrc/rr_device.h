@@ -154,17 +154,36 @@ inline void build_cubic_tab(float* tab /*32*4*/) {
   }
 }
 
-// streaks_light[idx] / 255.0 with BORDER_CONSTANT 0 outside
-RR_HD double tex_tap(const uint8_t* tex, int th, int tw, int64_t y, int64_t x) {
-  if (y < 0 || y >= th || x < 0 || x >= tw) return 0.0;
-  return (double)tex[y * tw + x] / 255.0;
-}
+// Texture accessors: streaks_light[idx] / 255.0 (bad_weather.py:252) with BORDER_CONSTANT 0.
+// TexGlobal divides on the fly; TexLut reads the same quotients from a 256-entry table
+// (identical bits), which the tile kernel keeps in LDS next to the texels.
+struct TexGlobal {
+  const uint8_t* t;
+  int h, w;
+  RR_HD double at(int64_t y, int64_t x) const { return (double)t[y * w + x] / 255.0; }
+  RR_HD double tap(int64_t y, int64_t x) const {
+    if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
+    return at(y, x);
+  }
+};
+struct TexLut {
+  const uint8_t* t;
+  const double* lut;
+  int h, w;
+  RR_HD double at(int64_t y, int64_t x) const { return lut[t[y * w + x]]; }
+  RR_HD double tap(int64_t y, int64_t x) const {
+    if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
+    return at(y, x);
+  }
+};
 
 // ---------------------------------------------------------------------------
 // Big drops: cv2.warpPerspective(INTER_CUBIC)  (generator.py:126-132)
 // ---------------------------------------------------------------------------
-RR_HD double warp_big_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, const float* ctab, int x, int y) {
+template <class Tex>
+RR_HD double warp_big_pixel(const DropPlan& p, const Tex& tx, const float* ctab, int x, int y) {
   const double* Mi = p.mi;
+  const int sh = tx.h, sw = tx.w;
   int bx = (x / p.bw0) * p.bw0;
   double x1 = (double)(x - bx);
   double bxf = (double)bx, yf = (double)y;
@@ -186,17 +205,15 @@ RR_HD double warp_big_pixel(const DropPlan& p, const uint8_t* tex, int sh, int s
   if (interior) {
     for (int i = 0; i < 4; i++) {
       float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
-      const uint8_t* row = tex + (sy + i) * sw + sx;
-      double r = (((double)row[0] / 255.0) * (double)w0 + ((double)row[1] / 255.0) * (double)w1) +
-                 ((double)row[2] / 255.0) * (double)w2;
-      r = r + ((double)row[3] / 255.0) * (double)w3;
+      double r = (tx.at(sy + i, sx) * (double)w0 + tx.at(sy + i, sx + 1) * (double)w1) + tx.at(sy + i, sx + 2) * (double)w2;
+      r = r + tx.at(sy + i, sx + 3) * (double)w3;
       sum = (i == 0) ? r : sum + r;
     }
   } else {
     for (int i = 0; i < 4; i++)
       for (int j = 0; j < 4; j++) {
         float w = cy[i] * cx[j];
-        sum = sum + tex_tap(tex, sh, sw, sy + i, sx + j) * (double)w;
+        sum = sum + tx.tap(sy + i, sx + j) * (double)w;
       }
   }
   return clip01(sum);
@@ -206,13 +223,10 @@ RR_HD double warp_big_pixel(const DropPlan& p, const uint8_t* tex, int sh, int s
 // Medium/Small drops: imutils.rotate_bound -> cv2.flip -> cv2.resize(INTER_AREA)
 // (generator.py:163-170)
 // ---------------------------------------------------------------------------
-// one pixel of warpAffine(INTER_LINEAR) of the texture into the nW x nH canvas
-RR_HD double rot_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, int ry, int rx) {
-  const double* m = p.ma;
-  int64_t adelta = cv_round(m[0] * (double)rx * 1024.0);
-  int64_t bdelta = cv_round(m[3] * (double)rx * 1024.0);
-  int64_t X0 = cv_round((m[1] * (double)ry + m[2]) * 1024.0) + 16;
-  int64_t Y0 = cv_round((m[4] * (double)ry + m[5]) * 1024.0) + 16;
+// warpAffine(INTER_LINEAR) sample given the fixed-point row/column terms
+// (X0, Y0 include round_delta; adelta/bdelta are the per-column increments)
+template <class Tex>
+RR_HD double rot_sample(const Tex& tx, int64_t X0, int64_t Y0, int64_t adelta, int64_t bdelta) {
   int64_t X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
   int64_t sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
   int fx = (int)(X & 31), fy = (int)(Y & 31);
@@ -220,14 +234,29 @@ RR_HD double rot_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, in
   double w01 = (double)((32 - fy) * fx) / 1024.0;
   double w10 = (double)(fy * (32 - fx)) / 1024.0;
   double w11 = (double)(fy * fx) / 1024.0;
-  double v00 = tex_tap(tex, sh, sw, sy, sx), v01 = tex_tap(tex, sh, sw, sy, sx + 1);
-  double v10 = tex_tap(tex, sh, sw, sy + 1, sx), v11 = tex_tap(tex, sh, sw, sy + 1, sx + 1);
+  double v00, v01, v10, v11;
+  if (sx >= 0 && sx + 1 < tx.w && sy >= 0 && sy + 1 < tx.h) {
+    v00 = tx.at(sy, sx); v01 = tx.at(sy, sx + 1); v10 = tx.at(sy + 1, sx); v11 = tx.at(sy + 1, sx + 1);
+  } else {
+    v00 = tx.tap(sy, sx); v01 = tx.tap(sy, sx + 1); v10 = tx.tap(sy + 1, sx); v11 = tx.tap(sy + 1, sx + 1);
+  }
   return ((v00 * w00 + v01 * w01) + v10 * w10) + v11 * w11;
+}
+RR_HD int64_t rot_adelta(const DropPlan& p, int rx) { return cv_round(p.ma[0] * (double)rx * 1024.0); }
+RR_HD int64_t rot_bdelta(const DropPlan& p, int rx) { return cv_round(p.ma[3] * (double)rx * 1024.0); }
+RR_HD int64_t rot_X0(const DropPlan& p, int ry) { return cv_round((p.ma[1] * (double)ry + p.ma[2]) * 1024.0) + 16; }
+RR_HD int64_t rot_Y0(const DropPlan& p, int ry) { return cv_round((p.ma[4] * (double)ry + p.ma[5]) * 1024.0) + 16; }
+
+// one pixel of warpAffine(INTER_LINEAR) of the texture into the nW x nH canvas
+template <class Tex>
+RR_HD double rot_pixel(const DropPlan& p, const Tex& tx, int ry, int rx) {
+  return rot_sample(tx, rot_X0(p, ry), rot_Y0(p, ry), rot_adelta(p, rx), rot_bdelta(p, rx));
 }
 
 // the image cv2.resize reads: rotated canvas, vertically flipped if p.flip
-RR_HD double canvas_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, int cy, int cx) {
-  return rot_pixel(p, tex, sh, sw, p.flip ? (p.nH - 1 - cy) : cy, cx);
+template <class Tex>
+RR_HD double canvas_pixel(const DropPlan& p, const Tex& tx, int cy, int cx) {
+  return rot_pixel(p, tx, p.flip ? (p.nH - 1 - cy) : cy, cx);
 }
 
 // computeResizeAreaTab for one destination index
@@ -255,11 +284,12 @@ RR_HD AreaSpan area_span(int ssize, double scale, int d) {
 }
 
 // horizontal pass of resizeArea_ for one source row and one destination column
-RR_HD double area_hsum(const DropPlan& p, const uint8_t* tex, int sh, int sw, const AreaSpan& ax, int sy) {
+template <class Tex>
+RR_HD double area_hsum(const DropPlan& p, const Tex& tx, const AreaSpan& ax, int sy) {
   double b = 0.0;
-  if (ax.has_l) b = b + canvas_pixel(p, tex, sh, sw, sy, ax.s1 - 1) * (double)ax.a_l;
-  for (int sx = ax.s1; sx < ax.s2; sx++) b = b + canvas_pixel(p, tex, sh, sw, sy, sx) * (double)ax.a_m;
-  if (ax.has_r) b = b + canvas_pixel(p, tex, sh, sw, sy, ax.s2) * (double)ax.a_r;
+  if (ax.has_l) b = b + canvas_pixel(p, tx, sy, ax.s1 - 1) * (double)ax.a_l;
+  for (int sx = ax.s1; sx < ax.s2; sx++) b = b + canvas_pixel(p, tx, sy, sx) * (double)ax.a_m;
+  if (ax.has_r) b = b + canvas_pixel(p, tx, sy, ax.s2) * (double)ax.a_r;
   return b;
 }
 
@@ -278,13 +308,15 @@ RR_HD void lin_coord(int ssize, double scale, double inv_scale, int d, bool is_x
   }
 }
 
-RR_HD double lin_hrow(const DropPlan& p, const uint8_t* tex, int sh, int sw, int row, int s, float f, bool tail) {
-  if (tail) return canvas_pixel(p, tex, sh, sw, row, s) * 1.0;
+template <class Tex>
+RR_HD double lin_hrow(const DropPlan& p, const Tex& tx, int row, int s, float f, bool tail) {
+  if (tail) return canvas_pixel(p, tx, row, s) * 1.0;
   float a0 = 1.0f - f;
-  return canvas_pixel(p, tex, sh, sw, row, s) * (double)a0 + canvas_pixel(p, tex, sh, sw, row, s + 1) * (double)f;
+  return canvas_pixel(p, tx, row, s) * (double)a0 + canvas_pixel(p, tx, row, s + 1) * (double)f;
 }
 
-RR_HD double resize_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, int dx, int dy) {
+template <class Tex>
+RR_HD double resize_pixel(const DropPlan& p, const Tex& tx, int dx, int dy) {
   double v;
   if (p.rs_mode == RS_AREA_FAST) {
     int area = p.isx * p.isy;
@@ -296,11 +328,11 @@ RR_HD double resize_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw,
       double q[4];
       for (int t = 0; t < 4; t++) {
         int kk = k + t;
-        q[t] = canvas_pixel(p, tex, sh, sw, by + kk / p.isx, bx + kk % p.isx);
+        q[t] = canvas_pixel(p, tx, by + kk / p.isx, bx + kk % p.isx);
       }
       s = s + (((q[0] + q[1]) + q[2]) + q[3]);
     }
-    for (; k < area; k++) s = s + canvas_pixel(p, tex, sh, sw, by + k / p.isx, bx + k % p.isx);
+    for (; k < area; k++) s = s + canvas_pixel(p, tx, by + k / p.isx, bx + k % p.isx);
     v = s * (double)scale;
   } else if (p.rs_mode == RS_AREA) {
     AreaSpan ax = area_span(p.nW, p.scale_x, dx);
@@ -308,35 +340,36 @@ RR_HD double resize_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw,
     double acc = 0.0;
     bool first = true;
     if (ay.has_l) {
-      acc = (double)ay.a_l * area_hsum(p, tex, sh, sw, ax, ay.s1 - 1);
+      acc = (double)ay.a_l * area_hsum(p, tx, ax, ay.s1 - 1);
       first = false;
     }
     for (int sy = ay.s1; sy < ay.s2; sy++) {
-      double t = (double)ay.a_m * area_hsum(p, tex, sh, sw, ax, sy);
+      double t = (double)ay.a_m * area_hsum(p, tx, ax, sy);
       acc = first ? t : acc + t;
       first = false;
     }
     if (ay.has_r) {
-      double t = (double)ay.a_r * area_hsum(p, tex, sh, sw, ax, ay.s2);
+      double t = (double)ay.a_r * area_hsum(p, tx, ax, ay.s2);
       acc = first ? t : acc + t;
     }
     v = acc;
   } else {
     int sx, sy;
     float fx, fy;
-    bool tx, ty;
-    lin_coord(p.nW, p.scale_x, p.inv_sx, dx, true, sx, fx, tx);
-    lin_coord(p.nH, p.scale_y, p.inv_sy, dy, false, sy, fy, ty);
+    bool tlx, tly;
+    lin_coord(p.nW, p.scale_x, p.inv_sx, dx, true, sx, fx, tlx);
+    lin_coord(p.nH, p.scale_y, p.inv_sy, dy, false, sy, fy, tly);
     int r0 = imin(imax(sy, 0), p.nH - 1), r1 = imin(imax(sy + 1, 0), p.nH - 1);
     float b0 = 1.0f - fy;
-    v = lin_hrow(p, tex, sh, sw, r0, sx, fx, tx) * (double)b0 + lin_hrow(p, tex, sh, sw, r1, sx, fx, tx) * (double)fy;
+    v = lin_hrow(p, tx, r0, sx, fx, tlx) * (double)b0 + lin_hrow(p, tx, r1, sx, fx, tlx) * (double)fy;
   }
   return clip01(v);
 }
 
 // raw (un-blurred) alpha of tile pixel (x, y) in raw-tile coordinates
-RR_HD double raw_tile_pixel(const DropPlan& p, const uint8_t* tex, int sh, int sw, const float* ctab, int x, int y) {
-  return p.kind == KIND_BIG ? warp_big_pixel(p, tex, sh, sw, ctab, x, y) : resize_pixel(p, tex, sh, sw, x, y);
+template <class Tex>
+RR_HD double raw_tile_pixel(const DropPlan& p, const Tex& tx, const float* ctab, int x, int y) {
+  return p.kind == KIND_BIG ? warp_big_pixel(p, tx, ctab, x, y) : resize_pixel(p, tx, x, y);
 }
 
 // ---------------------------------------------------------------------------

@@ -38,15 +38,14 @@ int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, con
              double* out) {
   float ctab[128];
   build_cubic_tab(ctab);
-  const uint8_t* tex = texels + tex_off[p->tex];
-  const int sh = tex_h[p->tex], sw = tex_w[p->tex];
+  TexGlobal tx{texels + tex_off[p->tex], tex_h[p->tex], tex_w[p->tex]};
   const int n = p->pw * p->ph;
   std::vector<double> a0(n), a1(n);
   for (int idx = 0; idx < n; idx++) {
     int y = idx / p->pw, x = idx - y * p->pw;
     int rx = x - p->shift, ry = y - p->shift;
     double v = 0.0;
-    if (rx >= 0 && rx < p->tw && ry >= 0 && ry < p->th) v = raw_tile_pixel(*p, tex, sh, sw, ctab, rx, ry);
+    if (rx >= 0 && rx < p->tw && ry >= 0 && ry < p->th) v = raw_tile_pixel(*p, tx, ctab, rx, ry);
     a0[idx] = v;
   }
   auto half = [](double sigma, int r, std::vector<double>& hw) {
