@@ -1,0 +1,240 @@
+"""Drop-in for the reference's common/generator.py: `Generator(args).run()` with the same
+argument object (fields consumed at reference generator.py:25-67), the same input trees and
+the same output tree.  The per-drop loop of the reference (generator.py:431-452 ->
+compute_drop -> add_drop_to_image) is replaced by ONE call per batch of frames into the HIP
+library (rr_render_frames); everything around it (file walking, conflict strategy, seeding,
+streak filter, pre-pass, saving) follows the reference.
+
+Multi-GPU: started under torch.distributed.run (or with RANK/WORLD_SIZE set) every rank
+renders frames idx[rank::world] of each sequence on its own GPU; the streak database is
+packed on rank 0 and broadcast once (sharding.broadcast_streak_db); no other collective.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import add_attenuation, my_utils, solid_angle, imgops, envmap
+from .bad_weather import DBManager, RainRenderer
+from .. import hip_backend, sharding
+
+FOG_ATT = 1                  # reference generator.py:19
+USE_DEPTH_WEIGHTING = 0      # reference generator.py:20 (dead in the reference, not implemented)
+
+
+class Generator:
+    def __init__(self, args):
+        self.conflict_strategy = args.conflict_strategy
+        self.rendering_strategy = args.rendering_strategy
+        if args.rendering_strategy is None:
+            self.output_root = os.path.join(args.output, args.dataset)
+        else:
+            self.output_root = os.path.join(args.output, args.dataset + '_' + args.rendering_strategy)
+        self.dataset = args.dataset
+        self.dataset_root = args.dataset_root
+        self.images = args.images
+        self.sequences = args.sequences
+        self.depth = args.depth
+        self.particles = args.particles
+        self.weather = args.weather
+        self.texture = args.texture
+        self.norm_coeff = args.norm_coeff
+        self.save_envmap = args.save_envmap
+        self.settings = args.settings
+        self.calib = args.calib
+        self.exposure = args.settings["cam_exposure"]
+        self.camera_gain = args.settings["cam_gain"]
+        self.focal = args.settings["cam_focal"] / 1000.
+        self.f_number = args.settings["cam_f_number"]
+        self.focus_plane = args.settings["cam_focus_plane"]
+        self.noise_scale = args.noise_scale
+        self.noise_std = args.noise_std
+        self.opacity_attenuation = args.opacity_attenuation
+        self.frame_start = args.frame_start
+        self.frame_end = args.frame_end
+        self.frame_step = args.frame_step
+        self.frames = args.frames
+        self.verbose = args.verbose
+        self.env_type = 'ours'
+        self.irrad_type = 'ambient'
+        self.db = None
+        self.renderer = None
+        self.batch = int(os.environ.get('RAIN_BATCH', '4'))
+        self.rank, self.world = sharding.rank_world()
+        self.device = int(getattr(args, 'device', os.environ.get('LOCAL_RANK', '0')))
+        self._hip = None
+        self.stats = []
+        if self.rendering_strategy is not None:
+            raise NotImplementedError("rendering_strategy %r: only the default strategy runs on the HIP path "
+                                      "('naive_db' is broken in the reference, bad_weather.py:355)" % self.rendering_strategy)
+        self.check_folders()
+
+    def check_folders(self):
+        """reference generator.py:85-104."""
+        print('Output directory: {}'.format(self.output_root))
+        existing = []
+        for sequence in self.sequences:
+            for w in self.weather:
+                out_dir = os.path.join(self.output_root, sequence, w["weather"], '{}mm'.format(w["fallrate"]))
+                if os.path.exists(out_dir):
+                    existing.append(out_dir)
+        if len(existing) != 0 and self.conflict_strategy is None:
+            print("\r\nFolders already exist: \n%s" % "\n".join(existing))
+            while self.conflict_strategy not in ["overwrite", "skip", "rename_folder"]:
+                self.conflict_strategy = input("\r\nWhat strategy to use (overwrite|skip|rename_folder):   ")
+        assert self.conflict_strategy in [None, "overwrite", "skip", "rename_folder"]
+
+    # ------------------------------------------------------------------------------------------
+    def _hip_ctx(self):
+        if self._hip is None:
+            self._hip = hip_backend.RainHip(self.device)
+        return self._hip
+
+    def _flush(self, pending):
+        """Render the pending frames in one library call and save their outputs."""
+        if not pending:
+            return
+        t0 = time.time()
+        outs = self._hip_ctx().render_frames([p['frame'] for p in pending], want_composite=False)
+        dt = time.time() - t0
+        for p, o in zip(pending, outs):
+            os.makedirs(os.path.dirname(p['out_rainy_path']), exist_ok=True)
+            os.makedirs(os.path.dirname(p['out_rainy_mask_path']), exist_ok=True)
+            imgops.imsave_rgb(p['out_rainy_path'], o['image_u8'])                  # generator.py:466
+            imgops.imsave_scalar(p['out_rainy_mask_path'], o['mask'])               # generator.py:467
+            if self.save_envmap:
+                os.makedirs(os.path.dirname(p['out_env_path']), exist_ok=True)
+                imgops.imsave_rgb(p['out_env_path'], (np.clip(p['env_bgr'][..., ::-1], 0, 1) * 255).astype(np.uint8))
+            n_skip = int(np.count_nonzero(o['status']))
+            self.stats.append(dict(file=p['out_rainy_path'], drops=len(o['status']), skipped=n_skip,
+                                   gpu_ms=1e3 * dt / len(pending)))
+            if n_skip and self.verbose:
+                print("\nTrace: %d of %d rain drops not rendered in %s" % (n_skip, len(o['status']), p['out_rainy_path']))
+        pending.clear()
+
+    def run(self):
+        folders_num = len(self.images)
+        for folder_idx, sequence in enumerate(self.sequences):
+            print('\nSequence: ' + sequence)
+            depth_folder = self.depth[sequence]
+            for sim_idx, sim_weather in enumerate(self.weather):
+                weather, fallrate = sim_weather["weather"], sim_weather["fallrate"]
+                out_seq_dir = os.path.join(self.output_root, sequence)
+                out_dir = os.path.join(out_seq_dir, weather, '{}mm'.format(fallrate))
+                sim_file = self.particles[sequence][sim_idx]
+                if os.path.exists(out_dir):                                         # generator.py:213-226
+                    if self.conflict_strategy in ("skip", "overwrite"):
+                        pass
+                    elif self.conflict_strategy == "rename_folder":
+                        shift = 0
+                        while os.path.exists(out_dir + '_copy%05d' % shift):
+                            shift += 1
+                        out_dir = out_dir + '_copy%05d' % shift
+                    else:
+                        raise NotImplementedError
+                os.makedirs(out_dir, exist_ok=True)
+                fog_params = {"rain_intensity": fallrate, "focal": self.focal, "f_number": self.f_number, "angle": 90,
+                              "exposure": self.exposure, "camera_gain": self.camera_gain}
+                files = [os.path.join(self.images[sequence], p) for p in my_utils.os_listdir(self.images[sequence])
+                         if os.path.isfile(os.path.join(self.images[sequence], p))]
+                depth_files = [os.path.join(depth_folder, d) for d in my_utils.os_listdir(depth_folder)]
+                im = files[0]
+                if im.endswith(".png"):
+                    imH, imW = imgops.imread_bgr(im).shape[0:2]
+                elif im.endswith(".npy"):
+                    imH, imW = np.load(im).shape[0:2]
+                else:
+                    raise Exception("Invalid extension", im)
+                rs = self.settings["render_scale"]
+                imH, imW = imH // rs, imW // rs
+
+                print('Simulation: rain {}mm/hr'.format(fallrate))
+                self.db = DBManager(streaks_path_xml=sim_file, streaks_path=self.texture, norm_coeff_path=self.norm_coeff)
+                self.renderer = RainRenderer(focal=self.focal, f_number=self.f_number, focus_plane=6, radius=10, fov=165)
+                map_generator = envmap.EnvironmentMapGenerator(self.focal, imW, imH)
+                FOG = add_attenuation.FogRain(**fog_params)
+                # streak DB: loaded by rank 0, one broadcast, then resident on every GPU
+                hip = self._hip_ctx()
+                sharding.load_and_broadcast_streak_db(self.db, hip, self.rank, self.world)
+                hip.set_camera(hip_backend.make_camera(self.focal, self.f_number, self.exposure))
+                self.db.load_streaks_from_xml(self.dataset, self.settings, [imW, imH], use_pickle=False, verbose=self.verbose)
+                frame_render_dict = list(self.db.streaks_simulator.values())
+
+                f_end = len(files) if self.frame_end is None else min(self.frame_end, len(files))
+                if self.frames:
+                    idx = np.unique(np.clip(self.frames, 0, f_end - 1)).tolist()
+                else:
+                    idx = list(range(self.frame_start, f_end, self.frame_step))
+                print("{} images".format(len(idx)))
+                idx = sharding.shard(idx, self.rank, self.world)
+                frames_exist_nb = 0
+                pending = []
+                sim_t0 = time.time()
+                for f_idx, i in enumerate(idx):
+                    image_file, depth_file = files[i], depth_files[i]
+                    f_name_idx = i                                                   # generator.py:312 (nuscenes remap not supported)
+                    assert os.path.exists(image_file), "Image file {} does not exist".format(image_file)
+                    assert os.path.exists(depth_file), "Depth file {} does not exist".format(depth_file)
+                    np.random.seed(f_name_idx)                                       # generator.py:318
+                    frame = frame_render_dict[f_name_idx % len(frame_render_dict)]
+                    file_name = os.path.split(image_file)[-1]
+                    out_rainy_path = os.path.join(out_dir, 'rainy_image', '{}.png'.format(file_name[:-4]))
+                    out_rainy_mask_path = os.path.join(out_dir, 'rain_mask', '{}.png'.format(file_name[:-4]))
+                    out_env_path = os.path.join(out_seq_dir, 'envmap', '{}.png'.format(file_name[:-4]))
+                    if os.path.exists(out_rainy_path) or os.path.exists(out_rainy_mask_path):
+                        if self.conflict_strategy == "skip":
+                            frames_exist_nb += 1
+                            continue
+                        elif self.conflict_strategy == "overwrite":
+                            pass
+                        else:
+                            raise NotImplementedError
+                    bg = imgops.imread_bgr(image_file) / 255.0                      # generator.py:352
+                    if rs != 1:
+                        bg = imgops.resize_linear(bg, int(bg.shape[1] // rs), int(bg.shape[0] // rs))
+                    if depth_file.endswith(".png"):
+                        depth = imgops.imread_unchanged(depth_file)
+                        if depth is None:
+                            print('Missing/Corrupted depth data (%s)' % depth_file)
+                            continue
+                        depth = depth.astype(np.float32) / 256.
+                    elif depth_file.endswith(".npy"):
+                        depth = np.load(depth_file)
+                    else:
+                        raise Exception("Invalid extension")
+                    ds = self.settings["depth_scale"]
+                    depthHW = np.array([int((depth.shape[0] * ds) // rs), int((depth.shape[1] * ds) // rs)])
+                    if not np.all(depth.shape[:2] == depthHW):
+                        depth = imgops.resize_linear(depth.astype(np.float64), int(depthHW[1]), int(depthHW[0]))
+                    assert np.all(np.array(depth.shape[:2]) <= np.array(bg.shape[:2])), "Depth cannot be larger than the image"
+                    if not np.all(np.array(depth.shape[:2]) == np.array(bg.shape[:2])):
+                        bg = my_utils.crop_center(bg, depth.shape[0], depth.shape[1])
+                    bg = np.ascontiguousarray(bg)
+                    rainy_bg = FOG.fog_rain_layer(bg, depth)                         # generator.py:386
+                    env_bgr = map_generator.generate_map(rainy_bg)                   # generator.py:400
+                    env_xyY = my_utils.convert_rgb_to_xyY(env_bgr[..., ::-1])        # generator.py:407-408
+                    env_xyY[np.isnan(env_xyY)] = 0
+                    omega = solid_angle.get_solid_angles(env_bgr)                    # generator.py:410
+                    H, W = bg.shape[:2]
+                    keep = hip_backend.filter_streaks(frame.table, imW, imH)         # generator.py:413-420
+                    assert len(keep) <= 2 ** 16, \
+                        "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
+                    drops = hip_backend.pack_drops(frame.table, keep, self.db, self.noise_std, self.noise_scale)
+                    pending.append(dict(frame=dict(bg=bg, rainy_bg=rainy_bg, env_xyY=env_xyY, omega=omega, drops=drops,
+                                                   opacity_attenuation=self.opacity_attenuation),
+                                        out_rainy_path=out_rainy_path, out_rainy_mask_path=out_rainy_mask_path,
+                                        out_env_path=out_env_path, env_bgr=env_bgr))
+                    same_shape = all(p['frame']['bg'].shape == pending[0]['frame']['bg'].shape for p in pending)
+                    if len(pending) >= self.batch or not same_shape:
+                        last = None if same_shape else pending.pop()
+                        self._flush(pending)
+                        if last is not None:
+                            pending.append(last)
+                    if self.verbose:
+                        sys.stdout.write('\r          S. {} / {}, F. {} / {}   ({:.1f}s)'.format(
+                            folder_idx + 1, folders_num, f_idx + 1, len(idx), time.time() - sim_t0))
+                self._flush(pending)
+                if frames_exist_nb > 0:
+                    print("Skipped {}/{} already existing renderings".format(frames_exist_nb, len(idx)))
+            print("\n\nEnd of the simulation")

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats and PMC passes of the bench command.
+# Usage: scripts/gpu_profile.sh <tag> [bench args...]
+# Writes gpurun_out/prof_<tag>/{stats,pmc_*}/...  Copy the summaries you want judged into profiles/.
+set -u
+TAG=${1:-r01}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum"; do
+  NAME=$(echo $C | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$NAME -- $BENCH > $OUT/pmc_$NAME.log 2>&1
+done
+# compact summaries
+python - <<PY
+import csv, glob, os, collections
+out = "$OUT"
+for f in glob.glob(out + '/stats/**/*kernel_stats.csv', recursive=True):
+    print('== kernel stats', f)
+    print(open(f).read())
+for d in sorted(glob.glob(out + '/pmc_*')):
+    if not os.path.isdir(d): continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row.get('Kernel_Name', '')[:60]
+            agg[k][row['Counter_Name']] += float(row['Counter_Value'])
+            cnt[(k, row['Counter_Name'])] += 1
+    print('== pmc', os.path.basename(d))
+    for k in agg:
+        print('  ', k, {c: (v, cnt[(k, c)]) for c, v in agg[k].items()})
+PY

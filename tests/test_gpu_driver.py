@@ -1,0 +1,69 @@
+"""GPU tier: the main.py-compatible driver end to end on a synthetic on-disk dataset (the
+reference's input trees and output tree), and its frames against the oracle."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import helpers as h
+from oracle import render as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dataset(tmp, n_frames=3, H=96, W=160, rate=5):
+    src = os.path.join(tmp, 'source')
+    h.synthetic.write_dataset(src, 'kitti', os.path.join('data_object', 'training'), n_frames, H, W)
+    tex_dir, norm = h.synthetic.write_streak_db(os.path.join(tmp, 'rainstreakdb'))
+    frames = h.synthetic.simulate_particles(2, 150, W, H)
+    xml = os.path.join(tmp, 'particles', 'kitti', 'data_object', 'rain', '%dmm' % rate, 'sim_camera0.xml')
+    h.synthetic.write_particles_xml(xml, frames)
+    return src, xml
+
+
+def test_main_cli_end_to_end(tmp_path, built):
+    tmp = str(tmp_path)
+    src, xml = _make_dataset(tmp)
+    main = importlib.import_module('rain-rendering_amd.main')
+    argv = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd',
+            os.path.join(tmp, 'rainstreakdb'), '-i', '5', '--output', os.path.join(tmp, 'out'), '--noverbose', '--save_envmap']
+    gen = main.main(argv)
+    out_dir = os.path.join(tmp, 'out', 'kitti', 'data_object', 'training', 'rain', '5mm')
+    for i in range(3):
+        p = os.path.join(out_dir, 'rainy_image', '%06d.png' % i)
+        m = os.path.join(out_dir, 'rain_mask', '%06d.png' % i)
+        assert os.path.exists(p) and os.path.exists(m)
+        assert np.array(Image.open(p)).shape == (96, 160, 4)
+    assert os.path.exists(os.path.join(tmp, 'out', 'kitti', 'data_object', 'training', 'envmap', '000000.png'))
+    assert len(gen.stats) == 3 and all(s['drops'] > 50 for s in gen.stats)
+
+    # frame 1 against the oracle fed with the driver's own pre-pass outputs
+    bw = h.bw
+    fog = importlib.import_module('rain-rendering_amd.common.add_attenuation')
+    em = importlib.import_module('rain-rendering_amd.common.envmap')
+    imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+    i = 1
+    img_dir = os.path.join(src, 'kitti', 'data_object', 'training', 'image_2')
+    bg = imgops.imread_bgr(os.path.join(img_dir, '%06d.png' % i)) / 255.0
+    depth = imgops.imread_unchanged(os.path.join(img_dir, 'depth', '%06d.png' % i)).astype(np.float32) / 256.
+    rainy = fog.FogRain(rain_intensity=5, focal=0.006, f_number=6.0, angle=90, exposure=2, camera_gain=20).fog_rain_layer(bg, depth)
+    env_bgr = em.EnvironmentMapGenerator(0.006, 160, 96).generate_map(rainy)
+    env = h.my_utils.convert_rgb_to_xyY(env_bgr[..., ::-1])
+    env[np.isnan(env)] = 0
+    omega = h.solid_angle.get_solid_angles(env_bgr)
+    sim = orc.load_streaks_from_xml(xml, 1, [160, 96])
+    fr = list(sim.values())[i % 2]
+    streaks = list(orc.streak_filter(fr.streaks, 160, 96).values())
+    textures, ratio = orc.load_streak_database(os.path.join(tmp, 'rainstreakdb', 'env_light_database', 'size32'),
+                                               os.path.join(tmp, 'rainstreakdb', 'env_light_database', 'txt', 'normalized_env_max.txt'))
+    ref = orc.render_frame(bg, rainy, env, omega, streaks, textures, ratio,
+                           dict(focal_m=0.006, f_number=6.0, exposure_ms=2), frame_seed=i, faithful=True)
+    got = np.array(Image.open(os.path.join(out_dir, 'rainy_image', '%06d.png' % i)))[..., :3]
+    assert np.abs(got.astype(int) - ref['image_u8'].astype(int)).max() <= 1        # +-1 LSB
+
+    # conflict_strategy skip: a second run renders nothing new
+    argv2 = argv[:-1] + ['--conflict_strategy', 'skip']
+    gen2 = main.main(argv2)
+    assert len(gen2.stats) == 0

@@ -1,0 +1,73 @@
+"""GPU tier, BASELINE.json full size (1242x375, 100 mm/hr): size-independent properties and
+the host-emulation comparison where the numpy oracle would take minutes."""
+import numpy as np
+import pytest
+
+import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(tmp_path_factory, built):
+    tmp = tmp_path_factory.mktemp('kitti100')
+    sc = h.Scene(tmp, 375, 1242, 8192, seed0=3000)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    base = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)])[0]
+    yield sc, bg, env, drops, rh, base
+    rh.close()
+
+
+def test_full_size_matches_hostemu_and_oracle_prefix(setup):
+    sc, bg, env, drops, rh, base = setup
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    assert np.array_equal(base['status'], emu['status'])
+    assert np.array_equal(base['mask'], emu['mask'])                      # bit-exact
+    assert np.array_equal(base['mask_i32'], emu['mask_i32'])
+    assert np.abs(base['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+    # the first 300 streaks through the numpy oracle (faithful FOV integration)
+    n = 300
+    out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[:n])])[0]
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=True, max_drops=n)
+    assert np.array_equal(out['status'], ref['status'])
+    assert np.array_equal(out['mask'], ref['mask'])
+    assert np.array_equal(out['mask_i32'], ref['mask_i32'])
+    assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+
+
+def test_determinism_and_batch_invariance(setup):
+    sc, bg, env, drops, rh, base = setup
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    small = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[:100])
+    outs = rh.render_frames([small, fr, small])
+    for k in ('mask', 'mask_i32', 'image_u8', 'status'):
+        assert np.array_equal(outs[1][k], base[k]), k                      # same bits alone or inside a batch
+        assert np.array_equal(outs[0][k], outs[2][k]), k
+
+
+def test_mask_export_and_skips(setup):
+    sc, bg, env, drops, rh, base = setup
+    assert np.array_equal(base['mask_i32'], np.floor(base['mask'] * 255).astype(np.int32))   # decision D1
+    assert base['mask'].min() >= 0 and base['mask'].max() > 1.0            # accumulator, not clipped
+    skipped = base['status'] != 0
+    assert 0 < skipped.sum() < len(drops) // 10
+    kept = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[~skipped])])[0]
+    for k in ('mask', 'image_u8'):
+        assert np.array_equal(kept[k], base[k]), k                         # skipped drops contribute nothing
+
+
+def test_zero_opacity_and_mean_shift(setup):
+    sc, bg, env, drops, rh, base = setup
+    out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops, opacity_attenuation=0.0)])[0]
+    assert np.array_equal(out['mask'], base['mask'])                       # the mask ignores opacity (bad_weather.py:450)
+    assert np.array_equal(out['rainy_bg'], bg)                             # tau_one = 0: the blend is the identity
+    assert np.array_equal(out['image_u8'], (np.clip(bg[..., ::-1], 0, 1) * 255).astype(np.uint8))
+    # epilogue: image = clip(rainy - (mean(rainy) - mean(bg))) truncated (generator.py:461-466)
+    comp = base['rainy_bg']
+    exp = (np.clip((comp - (comp.mean() - bg.mean()))[..., ::-1], 0, 1) * 255).astype(np.uint8)
+    assert np.abs(exp.astype(int) - base['image_u8'].astype(int)).max() <= 1
+    assert (exp != base['image_u8']).mean() < 1e-3

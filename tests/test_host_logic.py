@@ -1,0 +1,72 @@
+"""CPU tier: the host-side packing (filter, RNG order, rotation terms, in-place endpoint
+noise) against the oracle's per-drop loop, and the camera constants."""
+import copy
+
+import numpy as np
+import pytest
+
+import helpers as h
+from oracle import render as orc
+
+
+@pytest.mark.parametrize("noise_std,noise_scale", [(0.0, 0.0), (4.0, 1.0)])
+def test_pack_drops_matches_oracle_loop(tmp_path, noise_std, noise_scale):
+    sc = h.Scene(tmp_path, 96, 160, 200, seed0=31)
+    drops = sc.product_drops(0, noise_std, noise_scale)
+    streaks = sc.oracle_streaks(0)
+    textures, ratio = sc.oracle_db()
+    assert len(drops) == len(streaks)
+    np.random.seed(0)
+    for k, s in enumerate(streaks):
+        tex = orc.take_drop_texture_index(s, ratio)
+        assert drops['tex_index'][k] == tex
+        if s.drop_type != orc.DropType.Big:
+            noise = np.random.normal(0.0, noise_std) * noise_scale
+            d = s.image_position_start - s.image_position_end
+            theta = np.rad2deg(np.arccos(np.dot(d / np.linalg.norm(d), np.array([0, -1]))))
+            ang = -(theta + noise) * (np.pi / 180)
+            assert drops['rot_cos'][k] == np.cos(ang) and drops['rot_sin'][k] == np.sin(ang)
+            s2 = copy.deepcopy(s)
+            orc.make_drop_tile(s2, textures[tex], noise, 160, 96)          # applies the endpoint rotation
+            assert (drops['x0'][k], drops['y0'][k]) == tuple(s2.image_position_start)
+            assert (drops['x1'][k], drops['y1'][k]) == tuple(s2.image_position_end)
+        else:
+            assert (drops['x0'][k], drops['y0'][k]) == tuple(s.image_position_start)
+        assert drops['type'][k] == s.drop_type.value
+        assert drops['max_width'][k] == s.max_width and drops['length'][k] == s.length
+        assert drops['iw1'][k] == s.image_diameter_start and drops['iw2'][k] == s.image_diameter_end
+        assert np.array_equal(drops['wps'][k], s.world_position_start)
+
+
+def test_noise_mutation_persists_like_the_reference(tmp_path):
+    sc = h.Scene(tmp_path, 96, 160, 100, seed0=32)
+    fr = list(sc.db.streaks_simulator.values())[0]
+    before = fr.table.ips.copy()
+    sc.product_drops(0, noise_std=10.0, noise_scale=1.0)
+    assert not np.array_equal(before, fr.table.ips)        # Streak endpoints were rotated in place (generator.py:152-161)
+
+
+def test_filter_matches_oracle(tmp_path):
+    sc = h.Scene(tmp_path, 64, 96, 300, seed0=33)
+    fr = list(sc.db.streaks_simulator.values())[0]
+    idx = h.hb.filter_streaks(fr.table, 96, 64)
+    sim = orc.load_streaks_from_xml(sc.xml, 1, [96, 64])
+    kept = orc.streak_filter(list(sim.values())[0].streaks, 96, 64)
+    assert list(fr.table.pid[idx]) == list(kept.keys())
+    assert 0 < len(idx) < len(fr.table)
+
+
+def test_camera_constants():
+    cam = h.hb.make_camera(0.006, 6.0, 2.0)
+    assert cam.focal_sq == 0.006 ** 2 and cam.exposure_s == 0.002 and cam.n_fov == 20
+    assert cam.tau_zero == np.sqrt(1.16 * 1e-3) / 50
+    phi = np.arange(0, 2 * np.pi, (2 * np.pi) / 20)
+    assert cam.phi_cos[7] == np.cos(phi[7]) and cam.phi_sin[19] == np.sin(phi[19])
+    assert cam.fov_cos == np.cos(-np.deg2rad(82.5))
+
+
+def test_envmap_width_matches_reference_formula():
+    # 256x256 -> 256x393; 1242x375 -> 375x1909; 1024x512 -> 512x1573; 2048x1024 -> 1024x3149
+    for W, We in [(256, 393), (1242, 1909), (1024, 1573), (2048, 3149)]:
+        assert h.synthetic.envmap_width(6.0, W) == We
+    assert h.synthetic.envmap_width(5.5, 1600) == 2373

@@ -1,0 +1,64 @@
+"""CPU tier, world_size 2 over gloo: the N>1 path (frame sharding + the one broadcast of the
+packed streak database)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import helpers as h
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tex_dir, norm, q):
+    import importlib
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sharding = importlib.import_module('rain-rendering_amd.sharding')
+    hb = importlib.import_module('rain-rendering_amd.hip_backend')
+    bw = importlib.import_module('rain-rendering_amd.common.bad_weather')
+    packed = None
+    if rank == 0:                                   # only rank 0 touches the database files
+        db = bw.DBManager(streaks_path=tex_dir, norm_coeff_path=norm)
+        db.load_streak_database()
+        packed = hb.pack_streak_db(db.streaks_light)
+    texels, hs, ws, offs = sharding.broadcast_streak_db(packed, 0)
+    frames = sharding.shard(list(range(11)), *sharding.rank_world())
+    q.put((rank, texels.numpy().tobytes(), hs.tolist(), ws.tolist(), offs.tolist(), frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_shard_world2(tmp_path):
+    import torch.multiprocessing as mp
+    tex_dir, norm = h.synthetic.write_streak_db(str(tmp_path / 'db'))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tex_dir, norm, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, t0, h0, w0, o0, f0), (r1, t1, h1, w1, o1, f1) = res
+    assert t0 == t1 and h0 == h1 and w0 == w1 and o0 == o1            # identical database on both ranks
+    assert len(h0) == 50 and len(t0) == sum(a * b for a, b in zip(h0, w0))
+    assert sorted(f0 + f1) == list(range(11)) and not set(f0) & set(f1)  # every frame exactly once
+    assert f0 == [0, 2, 4, 6, 8, 10] and f1 == [1, 3, 5, 7, 9]
+
+
+def test_shard_degenerate():
+    sharding = h.pkg and __import__('importlib').import_module('rain-rendering_amd.sharding')
+    assert sharding.shard([5, 6, 7], 0, 1) == [5, 6, 7]
+    assert sharding.shard([5, 6, 7], 3, 8) == []
