@@ -296,30 +296,140 @@ __global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, in
 }
 
 // Production variant: one 256-thread block per drop.
-//   * texels (u8) and the 256-entry v/255.0 table live in LDS;
-//   * the INTER_AREA resize of the rotated canvas -- ~nW*nH bilinear samples for a handful of
-//     output pixels -- is split into (source row, destination column) partial sums that all
-//     256 threads compute in parallel into an LDS buffer, followed by the short vertical
-//     accumulation per output pixel.  Every partial sum and every accumulation runs in the
-//     order resizeArea_ uses, so the result is bit-identical to k_tile_simple / the oracle.
-constexpr int TEX_LDS = 12288;
-constexpr int NW_MAX = 512;
-constexpr int TW_MAX = 128;
+//   * the texture (u8, with a 2-texel zero border) and the 256-entry v/255.0 table live in LDS;
+//   * cv2.resize(INTER_AREA) of the rotated canvas -- ~nW*nH bilinear samples for a handful of
+//     output pixels -- is evaluated in three LDS-staged steps per chunk of canvas rows:
+//       1a  lanes run ALONG canvas rows and sample only the column interval that can touch
+//           the texture (samples outside are exactly 0 and adding them is a no-op);
+//       1b  one lane per (canvas row, destination column) folds its samples left to right
+//           with the resizeArea_ weights -> s_buf;
+//       2   one lane per output pixel folds s_buf top to bottom.
+//     Every fold runs in the order resizeArea_ uses, so the tile is bit-identical to
+//     k_tile_simple / the oracle.
+constexpr int TEX_LDS = 11776;      // padded texels: (h+4)*(w+4) <= TEX_LDS
+constexpr int NW_MAX = 400;
+constexpr int TW_MAX = 64;
 constexpr int BUF_MAX = 2048;
+constexpr int CAN_MAX = 2048;
+constexpr int ROWS_MAX = 128;
+
+// Columns rx of the canvas rows ry0..ry1 (un-flipped row numbers, any order) whose bilinear
+// footprint can touch the texture, conservatively (+-1 texel, +-1 column); false if none.
+// Per texture axis the admissible rx-interval is affine in the row, so its union over the row
+// range is spanned by the two end rows; the two axis unions are then intersected (a superset
+// of the union of the per-row intersections).
+__device__ inline bool rows_interval(const DropPlan& p, int sh, int sw, int ry0, int ry1, int& xa, int& xb) {
+  double lo = 0.0, hi = (double)(p.nW - 1);
+  const double A[2] = {p.ma[0] * 1024.0, p.ma[3] * 1024.0};
+  const double Bc[2] = {p.ma[1], p.ma[4]};
+  const double Cc[2] = {p.ma[2], p.ma[5]};
+  const double U[2] = {(double)(sw + 1) * 1024.0, (double)(sh + 1) * 1024.0};
+  const double L = -2048.0;
+  for (int k = 0; k < 2; k++) {
+    const double c0 = (Bc[k] * (double)ry0 + Cc[k]) * 1024.0 + 16.0;
+    const double c1 = (Bc[k] * (double)ry1 + Cc[k]) * 1024.0 + 16.0;
+    if (fabs(A[k]) < 1e-6) {
+      const double cmin = fmin(c0, c1), cmax = fmax(c0, c1);
+      if (cmax < L - 1024.0 || cmin > U[k] + 1024.0) return false;
+    } else {
+      double lo_k = 1e300, hi_k = -1e300;
+      const double cs[2] = {c0, c1};
+      for (int e = 0; e < 2; e++) {
+        double t0 = (L - cs[e]) / A[k], t1 = (U[k] - cs[e]) / A[k];
+        if (t0 > t1) { double t = t0; t0 = t1; t1 = t; }
+        lo_k = fmin(lo_k, t0);
+        hi_k = fmax(hi_k, t1);
+      }
+      lo = fmax(lo, floor(lo_k) - 1.0);
+      hi = fmin(hi, ceil(hi_k) + 1.0);
+    }
+  }
+  if (lo > hi) return false;
+  xa = (int)lo;
+  xb = (int)hi;
+  return true;
+}
+
+// which drops take the LDS-staged rotate+area-resize path (everything else: k_tile_generic)
+__device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
+  const int rows_per_dy = (int)ceil(p.scale_y) + 3;
+  // fixed-point coordinates must stay inside the int32 / short range the fast sampler assumes
+  const double cmax = (fabs(p.ma[1]) * p.nH + fabs(p.ma[2]) + fabs(p.ma[0]) * p.nW + fabs(p.ma[4]) * p.nH + fabs(p.ma[5]) +
+                       fabs(p.ma[3]) * p.nW) * 1024.0 + 64.0;
+  return (sh + 4) * (sw + 4) <= TEX_LDS && p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.nW <= NW_MAX && p.tw <= TW_MAX &&
+         rows_per_dy * p.tw <= BUF_MAX && cmax < 3.0e7;
+}
+
+// zero the defocus pad of the raw tile
+__device__ inline void zero_pad(const DropPlan& p, double* A0) {
+  if (p.shift <= 0) return;
+  const int n = p.pw * p.ph;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    int y = idx / p.pw, x = idx - y * p.pw;
+    int rx = x - p.shift, ry = y - p.shift;
+    if (!(rx >= 0 && rx < p.tw && ry >= 0 && ry < p.th)) A0[idx] = 0.0;
+  }
+}
+
+// Big drops (bicubic warp) and the rare resize modes: one thread per output pixel, texels in LDS.
+__global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, int max_drops, const uint8_t* texels,
+                                                      const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                                                      const float* ctab, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  if (sc.sizes[gi] == 0) return;
+  const DropPlan& p = sc.plan[gi];
+  if (p.status != RR_DROP_OK) return;
+  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  if (tile_is_fast(p, sh, sw)) return;
+  __shared__ double s_lut[256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
+  s_lut[t] = (double)t / 255.0;
+  const uint8_t* gtex = texels + tex_off[p.tex];
+  const int P = sw + 4;
+  const bool tex_fits = (sh + 4) * P <= TEX_LDS;
+  if (tex_fits) {
+    for (int y = wave; y < sh + 4; y += 4)
+      for (int x = lane; x < P; x += 64) {
+        const bool in = y >= 2 && y < sh + 2 && x >= 2 && x < sw + 2;
+        s_tex[y * P + x] = in ? gtex[(y - 2) * sw + (x - 2)] : (uint8_t)0;
+      }
+  }
+  double* A0 = sc.arena + p.a0_off;
+  zero_pad(p, A0);
+  __syncthreads();
+  const int n = p.tw * p.th;
+  if (tex_fits) {
+    TexLutPad tx{s_tex, s_lut, sh, sw};
+    for (int idx = t; idx < n; idx += 256) {
+      int y = idx / p.tw, x = idx - y * p.tw;
+      A0[(int64_t)(y + p.shift) * p.pw + (x + p.shift)] = raw_tile_pixel(p, tx, ctab, x, y);
+    }
+  } else {
+    TexLut tx{gtex, s_lut, sh, sw};
+    for (int idx = t; idx < n; idx += 256) {
+      int y = idx / p.tw, x = idx - y * p.tw;
+      A0[(int64_t)(y + p.shift) * p.pw + (x + p.shift)] = raw_tile_pixel(p, tx, ctab, x, y);
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                              const float* ctab, Scratch sc) {
-  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+                                              Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (i >= frames[f].n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
   if (sc.sizes[gi] == 0) return;
   __shared__ DropPlan sp;
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
-  __shared__ int32_t s_ad[NW_MAX], s_bd[NW_MAX];
+  __shared__ int2 s_adbd[NW_MAX];
   __shared__ AreaSpan s_ax[TW_MAX];
   __shared__ double s_buf[BUF_MAX];
+  __shared__ double s_can[CAN_MAX];
+  __shared__ int2 s_row[ROWS_MAX];
   {
     const int32_t* src = reinterpret_cast<const int32_t*>(&sc.plan[gi]);
     int32_t* dst = reinterpret_cast<int32_t*>(&sp);
@@ -330,62 +440,88 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   const DropPlan& p = sp;
   if (p.status != RR_DROP_OK) return;
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  if (!tile_is_fast(p, sh, sw)) return;
   const uint8_t* gtex = texels + tex_off[p.tex];
-  const bool tex_fits = sh * sw <= TEX_LDS;
-  if (tex_fits)
-    for (int k = t; k < sh * sw; k += 256) s_tex[k] = gtex[k];
-  TexLut tx{tex_fits ? s_tex : gtex, s_lut, sh, sw};
+  const int P = sw + 4;
+  for (int y = wave; y < sh + 4; y += 4)
+    for (int x = lane; x < P; x += 64) {
+      const bool in = y >= 2 && y < sh + 2 && x >= 2 && x < sw + 2;
+      s_tex[y * P + x] = in ? gtex[(y - 2) * sw + (x - 2)] : (uint8_t)0;
+    }
   double* A0 = sc.arena + p.a0_off;
-  const int pw = p.pw, ph = p.ph, shift = p.shift, tw = p.tw, th = p.th;
-  // zero the defocus pad
-  if (shift > 0) {
-    const int n = pw * ph;
-    for (int idx = t; idx < n; idx += 256) {
-      int y = idx / pw, x = idx - y * pw;
-      int rx = x - shift, ry = y - shift;
-      if (!(rx >= 0 && rx < tw && ry >= 0 && ry < th)) A0[idx] = 0.0;
-    }
-  }
+  const int pw = p.pw, shift = p.shift, tw = p.tw, th = p.th;
+  zero_pad(p, A0);
   const double sy_scale = p.scale_y;
-  const int rows_per_dy = (int)ceil(sy_scale) + 3;
-  const bool fast = p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.nW <= NW_MAX && tw <= TW_MAX && rows_per_dy * tw <= BUF_MAX;
-  if (!fast) {
-    __syncthreads();
-    const int n = tw * th;
-    for (int idx = t; idx < n; idx += 256) {
-      int y = idx / tw, x = idx - y * tw;
-      A0[(int64_t)(y + shift) * pw + (x + shift)] = raw_tile_pixel(p, tx, ctab, x, y);
-    }
-    return;
-  }
-  for (int rx = t; rx < p.nW; rx += 256) {
-    s_ad[rx] = (int32_t)rot_adelta(p, rx);
-    s_bd[rx] = (int32_t)rot_bdelta(p, rx);
-  }
+  for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   for (int dx = t; dx < tw; dx += 256) s_ax[dx] = area_span(p.nW, p.scale_x, dx);
   __syncthreads();
-  // destination rows per chunk so that the source rows x tw fit the LDS buffer
   int k_dy = (int)(((double)(BUF_MAX / tw) - 3.0) / sy_scale);
   if (k_dy < 1) k_dy = 1;
   for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
     const int dy1 = imin(dy0 + k_dy, th);
     const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
     const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, p.nH - 1);
-    const int rows = hi - lo + 1;                 // <= k_dy*scale_y + 3 <= BUF_MAX / tw
-    const int items = rows * tw;
-    for (int it = t; it < items; it += 256) {
-      const int r = it / tw, dx = it - r * tw;
-      const int sy = lo + r;
-      const int ry = p.flip ? (p.nH - 1 - sy) : sy;
-      const int64_t X0 = rot_X0(p, ry), Y0 = rot_Y0(p, ry);
-      const AreaSpan ax = s_ax[dx];
-      double b = 0.0;
-      if (ax.has_l) b = b + rot_sample(tx, X0, Y0, (int64_t)s_ad[ax.s1 - 1], (int64_t)s_bd[ax.s1 - 1]) * (double)ax.a_l;
-      for (int sx = ax.s1; sx < ax.s2; sx++) b = b + rot_sample(tx, X0, Y0, (int64_t)s_ad[sx], (int64_t)s_bd[sx]) * (double)ax.a_m;
-      if (ax.has_r) b = b + rot_sample(tx, X0, Y0, (int64_t)s_ad[ax.s2], (int64_t)s_bd[ax.s2]) * (double)ax.a_r;
-      s_buf[it] = b;
+    // ---- canvas rows lo..hi in chunks that fit s_can ----
+    int rc = lo;
+    while (rc <= hi) {
+      int R = imin(imin(ROWS_MAX, hi - rc + 1), CAN_MAX / 8);
+      int xa = 0, xb = -1;
+      for (int pass = 0; pass < 2; pass++) {
+        const int c0 = rc, c1 = rc + R - 1;
+        const int ry0 = p.flip ? (p.nH - 1 - c0) : c0, ry1 = p.flip ? (p.nH - 1 - c1) : c1;
+        if (!rows_interval(p, sh, sw, ry0, ry1, xa, xb)) { xa = 0; xb = -1; }
+        const int width = xb - xa + 1;
+        if (width <= 0 || width * R <= CAN_MAX) break;
+        R = imax(CAN_MAX / width, 1);
+      }
+      const int width = xb - xa + 1;
+      if (width > 0 && width * R > CAN_MAX) R = imax(CAN_MAX / width, 1);   // [xa, xb] stays a superset
+      if (width > 0) {
+        for (int r = t; r < R; r += 256) {
+          const int c = rc + r;
+          const int ry = p.flip ? (p.nH - 1 - c) : c;
+          s_row[r] = make_int2((int)rot_X0(p, ry), (int)rot_Y0(p, ry));
+        }
+        __syncthreads();
+        // ---- 1a: samples, lanes along the row ----
+        for (int r = wave; r < R; r += 4) {
+          const int2 xy0 = s_row[r];
+          double* out = s_can + r * width;
+          for (int x = lane; x < width; x += 64) {
+            const int2 d = s_adbd[xa + x];
+            const int X = (xy0.x + d.x) >> 5, Y = (xy0.y + d.y) >> 5;
+            int sx = X >> 5, sy = Y >> 5;
+            const int fx = X & 31, fy = Y & 31;
+            sx = imin(imax(sx, -2), sw);
+            sy = imin(imax(sy, -2), sh);
+            const uint8_t* q = s_tex + (sy + 2) * P + (sx + 2);
+            const double v00 = s_lut[q[0]], v01 = s_lut[q[1]], v10 = s_lut[q[P]], v11 = s_lut[q[P + 1]];
+            const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
+            // integer-valued weights; the common factor 2^-10 is applied once (exact)
+            const double s = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
+            out[x] = s * (1.0 / 1024.0);
+          }
+        }
+        __syncthreads();
+      }
+      // ---- 1b: horizontal folds ----
+      const int items = R * tw;
+      for (int it = t; it < items; it += 256) {
+        const int r = it / tw, dx = it - r * tw;
+        const AreaSpan ax = s_ax[dx];
+        const int e0 = imax(ax.s1 - ax.has_l, xa), e1 = imin(ax.s2 - 1 + ax.has_r, xb);
+        const double* row = s_can + r * width - xa;
+        double b = 0.0;
+        for (int sx = e0; sx <= e1; sx++) {
+          const float a = sx < ax.s1 ? ax.a_l : (sx >= ax.s2 ? ax.a_r : ax.a_m);
+          b = b + row[sx] * (double)a;
+        }
+        s_buf[(rc - lo + r) * tw + dx] = b;
+      }
+      __syncthreads();
+      rc += R;
     }
-    __syncthreads();
+    // ---- 2: vertical folds ----
     const int npx = (dy1 - dy0) * tw;
     for (int it = t; it < npx; it += 256) {
       const int r = it / tw, dx = it - r * tw;
@@ -834,12 +970,18 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_tile");
-      if (ctx->simple_tile)
+      if (ctx->simple_tile) {
         hipLaunchKernelGGL(k_tile_simple, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
                            ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
-      else
+      } else {
         hipLaunchKernelGGL(k_tile, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
-                           ctx->d_tex_off, ctx->d_ctab, sc);
+                           ctx->d_tex_off, sc);
+      }
+    }
+    if (!ctx->simple_tile) {
+      ProfScope ps(ctx, s, "k_tile_generic");
+      hipLaunchKernelGGL(k_tile_generic, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
+                         ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");

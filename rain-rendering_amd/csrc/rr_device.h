@@ -177,6 +177,19 @@ struct TexLut {
   }
 };
 
+// LDS copy with a 2-texel zero border (pitch w+4): lets the hot sampling loop clamp
+// coordinates to [-2, w] x [-2, h] instead of testing every tap.
+struct TexLutPad {
+  const uint8_t* t;
+  const double* lut;
+  int h, w;
+  RR_HD double at(int64_t y, int64_t x) const { return lut[t[(y + 2) * (w + 4) + (x + 2)]]; }
+  RR_HD double tap(int64_t y, int64_t x) const {
+    if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
+    return at(y, x);
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Big drops: cv2.warpPerspective(INTER_CUBIC)  (generator.py:126-132)
 // ---------------------------------------------------------------------------
