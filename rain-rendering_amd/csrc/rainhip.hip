@@ -313,41 +313,38 @@ constexpr int BUF_MAX = 2048;
 constexpr int CAN_MAX = 2048;
 constexpr int ROWS_MAX = 128;
 
-// Columns rx of the canvas rows ry0..ry1 (un-flipped row numbers, any order) whose bilinear
-// footprint can touch the texture, conservatively (+-1 texel, +-1 column); false if none.
-// Per texture axis the admissible rx-interval is affine in the row, so its union over the row
-// range is spanned by the two end rows; the two axis unions are then intersected (a superset
-// of the union of the per-row intersections).
-__device__ inline bool rows_interval(const DropPlan& p, int sh, int sw, int ry0, int ry1, int& xa, int& xb) {
+// Columns rx of canvas row `ry` (un-flipped row number) whose bilinear footprint can touch
+// the texture, conservatively (+-1 texel, +-1 column): [xa, xa+n).  Samples outside are
+// exactly 0.0.  The interval length is bounded by tile_pitch() for every row.
+__device__ inline void row_interval(const DropPlan& p, int sh, int sw, int ry, int& xa, int& n) {
   double lo = 0.0, hi = (double)(p.nW - 1);
   const double A[2] = {p.ma[0] * 1024.0, p.ma[3] * 1024.0};
-  const double Bc[2] = {p.ma[1], p.ma[4]};
-  const double Cc[2] = {p.ma[2], p.ma[5]};
+  const double C[2] = {(p.ma[1] * (double)ry + p.ma[2]) * 1024.0 + 16.0, (p.ma[4] * (double)ry + p.ma[5]) * 1024.0 + 16.0};
   const double U[2] = {(double)(sw + 1) * 1024.0, (double)(sh + 1) * 1024.0};
   const double L = -2048.0;
+  bool empty = false;
   for (int k = 0; k < 2; k++) {
-    const double c0 = (Bc[k] * (double)ry0 + Cc[k]) * 1024.0 + 16.0;
-    const double c1 = (Bc[k] * (double)ry1 + Cc[k]) * 1024.0 + 16.0;
     if (fabs(A[k]) < 1e-6) {
-      const double cmin = fmin(c0, c1), cmax = fmax(c0, c1);
-      if (cmax < L - 1024.0 || cmin > U[k] + 1024.0) return false;
+      if (C[k] < L - 1024.0 || C[k] > U[k] + 1024.0) empty = true;
     } else {
-      double lo_k = 1e300, hi_k = -1e300;
-      const double cs[2] = {c0, c1};
-      for (int e = 0; e < 2; e++) {
-        double t0 = (L - cs[e]) / A[k], t1 = (U[k] - cs[e]) / A[k];
-        if (t0 > t1) { double t = t0; t0 = t1; t1 = t; }
-        lo_k = fmin(lo_k, t0);
-        hi_k = fmax(hi_k, t1);
-      }
-      lo = fmax(lo, floor(lo_k) - 1.0);
-      hi = fmin(hi, ceil(hi_k) + 1.0);
+      double t0 = (L - C[k]) / A[k], t1 = (U[k] - C[k]) / A[k];
+      if (t0 > t1) { double t = t0; t0 = t1; t1 = t; }
+      lo = fmax(lo, floor(t0) - 1.0);
+      hi = fmin(hi, ceil(t1) + 1.0);
     }
   }
-  if (lo > hi) return false;
+  if (empty || lo > hi) { xa = 0; n = 0; return; }
   xa = (int)lo;
-  xb = (int)hi;
-  return true;
+  n = (int)hi - xa + 1;
+}
+// upper bound of row_interval's n over all rows
+__device__ inline int tile_pitch(const DropPlan& p, int sh, int sw) {
+  double w = (double)p.nW;
+  const double A[2] = {fabs(p.ma[0]) * 1024.0, fabs(p.ma[3]) * 1024.0};
+  const double span[2] = {(double)(sw + 1) * 1024.0 + 2048.0, (double)(sh + 1) * 1024.0 + 2048.0};
+  for (int k = 0; k < 2; k++)
+    if (A[k] >= 1e-6) w = fmin(w, span[k] / A[k] + 6.0);
+  return (int)w;
 }
 
 // which drops take the LDS-staged rotate+area-resize path (everything else: k_tile_generic)
@@ -429,7 +426,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ AreaSpan s_ax[TW_MAX];
   __shared__ double s_buf[BUF_MAX];
   __shared__ double s_can[CAN_MAX];
-  __shared__ int2 s_row[ROWS_MAX];
+  __shared__ int4 s_row[ROWS_MAX];
   {
     const int32_t* src = reinterpret_cast<const int32_t*>(&sc.plan[gi]);
     int32_t* dst = reinterpret_cast<int32_t*>(&sp);
@@ -455,6 +452,8 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   for (int dx = t; dx < tw; dx += 256) s_ax[dx] = area_span(p.nW, p.scale_x, dx);
   __syncthreads();
+  const int pitch = imax(tile_pitch(p, sh, sw), 1);
+  const int R = imax(imin(ROWS_MAX, CAN_MAX / pitch), 1);
   int k_dy = (int)(((double)(BUF_MAX / tw) - 3.0) / sy_scale);
   if (k_dy < 1) k_dy = 1;
   for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
@@ -462,55 +461,44 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
     const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, p.nH - 1);
     // ---- canvas rows lo..hi in chunks that fit s_can ----
-    int rc = lo;
-    while (rc <= hi) {
-      int R = imin(imin(ROWS_MAX, hi - rc + 1), CAN_MAX / 8);
-      int xa = 0, xb = -1;
-      for (int pass = 0; pass < 2; pass++) {
-        const int c0 = rc, c1 = rc + R - 1;
-        const int ry0 = p.flip ? (p.nH - 1 - c0) : c0, ry1 = p.flip ? (p.nH - 1 - c1) : c1;
-        if (!rows_interval(p, sh, sw, ry0, ry1, xa, xb)) { xa = 0; xb = -1; }
-        const int width = xb - xa + 1;
-        if (width <= 0 || width * R <= CAN_MAX) break;
-        R = imax(CAN_MAX / width, 1);
+    for (int rc = lo; rc <= hi; rc += R) {
+      const int Rn = imin(R, hi - rc + 1);
+      for (int r = t; r < Rn; r += 256) {
+        const int c = rc + r;
+        const int ry = p.flip ? (p.nH - 1 - c) : c;
+        int xa, n;
+        row_interval(p, sh, sw, ry, xa, n);
+        s_row[r] = make_int4((int)rot_X0(p, ry), (int)rot_Y0(p, ry), xa, imin(n, pitch));
       }
-      const int width = xb - xa + 1;
-      if (width > 0 && width * R > CAN_MAX) R = imax(CAN_MAX / width, 1);   // [xa, xb] stays a superset
-      if (width > 0) {
-        for (int r = t; r < R; r += 256) {
-          const int c = rc + r;
-          const int ry = p.flip ? (p.nH - 1 - c) : c;
-          s_row[r] = make_int2((int)rot_X0(p, ry), (int)rot_Y0(p, ry));
+      __syncthreads();
+      // ---- 1a: samples, lanes along the row ----
+      for (int r = wave; r < Rn; r += 4) {
+        const int4 rw = s_row[r];
+        double* out = s_can + r * pitch;
+        for (int x = lane; x < rw.w; x += 64) {
+          const int2 d = s_adbd[rw.z + x];
+          const int X = (rw.x + d.x) >> 5, Y = (rw.y + d.y) >> 5;
+          int sx = X >> 5, sy = Y >> 5;
+          const int fx = X & 31, fy = Y & 31;
+          sx = imin(imax(sx, -2), sw);
+          sy = imin(imax(sy, -2), sh);
+          const uint8_t* q = s_tex + (sy + 2) * P + (sx + 2);
+          const double v00 = s_lut[q[0]], v01 = s_lut[q[1]], v10 = s_lut[q[P]], v11 = s_lut[q[P + 1]];
+          const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
+          // integer-valued weights; the common factor 2^-10 is applied once (exact)
+          const double sm = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
+          out[x] = sm * (1.0 / 1024.0);
         }
-        __syncthreads();
-        // ---- 1a: samples, lanes along the row ----
-        for (int r = wave; r < R; r += 4) {
-          const int2 xy0 = s_row[r];
-          double* out = s_can + r * width;
-          for (int x = lane; x < width; x += 64) {
-            const int2 d = s_adbd[xa + x];
-            const int X = (xy0.x + d.x) >> 5, Y = (xy0.y + d.y) >> 5;
-            int sx = X >> 5, sy = Y >> 5;
-            const int fx = X & 31, fy = Y & 31;
-            sx = imin(imax(sx, -2), sw);
-            sy = imin(imax(sy, -2), sh);
-            const uint8_t* q = s_tex + (sy + 2) * P + (sx + 2);
-            const double v00 = s_lut[q[0]], v01 = s_lut[q[1]], v10 = s_lut[q[P]], v11 = s_lut[q[P + 1]];
-            const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
-            // integer-valued weights; the common factor 2^-10 is applied once (exact)
-            const double s = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
-            out[x] = s * (1.0 / 1024.0);
-          }
-        }
-        __syncthreads();
       }
+      __syncthreads();
       // ---- 1b: horizontal folds ----
-      const int items = R * tw;
+      const int items = Rn * tw;
       for (int it = t; it < items; it += 256) {
         const int r = it / tw, dx = it - r * tw;
         const AreaSpan ax = s_ax[dx];
-        const int e0 = imax(ax.s1 - ax.has_l, xa), e1 = imin(ax.s2 - 1 + ax.has_r, xb);
-        const double* row = s_can + r * width - xa;
+        const int4 rw = s_row[r];
+        const int e0 = imax(ax.s1 - ax.has_l, rw.z), e1 = imin(ax.s2 - 1 + ax.has_r, rw.z + rw.w - 1);
+        const double* row = s_can + r * pitch - rw.z;
         double b = 0.0;
         for (int sx = e0; sx <= e1; sx++) {
           const float a = sx < ax.s1 ? ax.a_l : (sx >= ax.s2 ? ax.a_r : ax.a_m);
@@ -519,7 +507,6 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
         s_buf[(rc - lo + r) * tw + dx] = b;
       }
       __syncthreads();
-      rc += R;
     }
     // ---- 2: vertical folds ----
     const int npx = (dy1 - dy0) * tw;
