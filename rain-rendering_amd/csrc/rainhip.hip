@@ -309,9 +309,9 @@ __global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, in
 constexpr int TEX_LDS = 11776;      // padded texels: (h+4)*(w+4) <= TEX_LDS
 constexpr int NW_MAX = 400;
 constexpr int TW_MAX = 64;
-constexpr int BUF_MAX = 2048;
-constexpr int CAN_MAX = 2048;
-constexpr int ROWS_MAX = 128;
+constexpr int BUF_MAX = 1024;
+constexpr int CAN_W = 256;        // doubles of sample staging per wave
+constexpr int ROWS_W = 16;        // canvas rows a wave stages at most
 
 // Columns rx of canvas row `ry` (un-flipped row number) whose bilinear footprint can touch
 // the texture, conservatively (+-1 texel, +-1 column): [xa, xa+n).  Samples outside are
@@ -348,13 +348,16 @@ __device__ inline int tile_pitch(const DropPlan& p, int sh, int sw) {
 }
 
 // which drops take the LDS-staged rotate+area-resize path (everything else: k_tile_generic)
-__device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
-  const int rows_per_dy = (int)ceil(p.scale_y) + 3;
-  // fixed-point coordinates must stay inside the int32 / short range the fast sampler assumes
+// fixed-point coordinates stay inside the int32 / short range the LDS sampler assumes
+__device__ inline bool tile_coords_safe(const DropPlan& p) {
   const double cmax = (fabs(p.ma[1]) * p.nH + fabs(p.ma[2]) + fabs(p.ma[0]) * p.nW + fabs(p.ma[4]) * p.nH + fabs(p.ma[5]) +
                        fabs(p.ma[3]) * p.nW) * 1024.0 + 64.0;
+  return cmax < 3.0e7;
+}
+__device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
+  const int rows_per_dy = (int)ceil(p.scale_y) + 3;
   return (sh + 4) * (sw + 4) <= TEX_LDS && p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.nW <= NW_MAX && p.tw <= TW_MAX &&
-         rows_per_dy * p.tw <= BUF_MAX && cmax < 3.0e7;
+         rows_per_dy * p.tw <= BUF_MAX && tile_coords_safe(p);
 }
 
 // zero the defocus pad of the raw tile
@@ -366,6 +369,23 @@ __device__ inline void zero_pad(const DropPlan& p, double* A0) {
     int rx = x - p.shift, ry = y - p.shift;
     if (!(rx >= 0 && rx < p.tw && ry >= 0 && ry < p.th)) A0[idx] = 0.0;
   }
+}
+
+// fixed-point bilinear sample of the padded LDS texture (same arithmetic as rot_sample; valid
+// when tile_coords_safe(p) holds)
+__device__ inline double lds_rot_sample(const uint8_t* s_tex, const double* s_lut, int P, int sh, int sw, int X0, int Y0,
+                                        int2 d) {
+  const int X = (X0 + d.x) >> 5, Y = (Y0 + d.y) >> 5;
+  int sx = X >> 5, sy = Y >> 5;
+  const int fx = X & 31, fy = Y & 31;
+  sx = imin(imax(sx, -2), sw);
+  sy = imin(imax(sy, -2), sh);
+  const uint8_t* q = s_tex + (sy + 2) * P + (sx + 2);
+  const double v00 = s_lut[q[0]], v01 = s_lut[q[1]], v10 = s_lut[q[P]], v11 = s_lut[q[P + 1]];
+  const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
+  // integer-valued weights; the common factor 2^-10 is applied once (exact)
+  const double sm = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
+  return sm * (1.0 / 1024.0);
 }
 
 // Big drops (bicubic warp) and the rare resize modes: one thread per output pixel, texels in LDS.
@@ -382,6 +402,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   if (tile_is_fast(p, sh, sw)) return;
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
+  __shared__ int2 s_adbd[NW_MAX];
   s_lut[t] = (double)t / 255.0;
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
@@ -395,9 +416,39 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   }
   double* A0 = sc.arena + p.a0_off;
   zero_pad(p, A0);
+  // integer-ratio INTER_AREA (ResizeAreaFast): the per-pixel chain is sequential by definition;
+  // keep it short with the LDS fixed-point sampler
+  const bool area_fast = tex_fits && p.kind == KIND_ROT && p.rs_mode == RS_AREA_FAST && p.nW <= NW_MAX && tile_coords_safe(p);
+  if (area_fast)
+    for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   __syncthreads();
   const int n = p.tw * p.th;
-  if (tex_fits) {
+  if (area_fast) {
+    const int area = p.isx * p.isy, n4 = area & ~3;
+    const float scale = 1.0f / (float)area;
+    for (int idx = t; idx < n; idx += 256) {
+      const int dy = idx / p.tw, dx = idx - dy * p.tw;
+      double sum = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
+      int k = 0;
+      for (int ky = 0; ky < p.isy; ky++) {
+        const int c = dy * p.isy + ky;
+        const int ry = p.flip ? (p.nH - 1 - c) : c;
+        const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
+        for (int kx = 0; kx < p.isx; kx++, k++) {
+          const double v = lds_rot_sample(s_tex, s_lut, P, sh, sw, X0, Y0, s_adbd[dx * p.isx + kx]);
+          if (k >= n4) sum = sum + v;
+          else {
+            const int m = k & 3;
+            if (m == 0) q0 = v;
+            else if (m == 1) q1 = v;
+            else if (m == 2) q2 = v;
+            else sum = sum + (((q0 + q1) + q2) + v);
+          }
+        }
+      }
+      A0[(int64_t)(dy + p.shift) * p.pw + (dx + p.shift)] = clip01(sum * (double)scale);
+    }
+  } else if (tex_fits) {
     TexLutPad tx{s_tex, s_lut, sh, sw};
     for (int idx = t; idx < n; idx += 256) {
       int y = idx / p.tw, x = idx - y * p.tw;
@@ -410,6 +461,13 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
       A0[(int64_t)(y + p.shift) * p.pw + (x + p.shift)] = raw_tile_pixel(p, tx, ctab, x, y);
     }
   }
+}
+
+__device__ inline void wave_lds_sync() {
+  // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
+  // stops the compiler from moving accesses across the hand-off point.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
@@ -425,8 +483,8 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ int2 s_adbd[NW_MAX];
   __shared__ AreaSpan s_ax[TW_MAX];
   __shared__ double s_buf[BUF_MAX];
-  __shared__ double s_can[CAN_MAX];
-  __shared__ int4 s_row[ROWS_MAX];
+  __shared__ double s_can[4][CAN_W];
+  __shared__ int4 s_row[4][ROWS_W];
   {
     const int32_t* src = reinterpret_cast<const int32_t*>(&sc.plan[gi]);
     int32_t* dst = reinterpret_cast<int32_t*>(&sp);
@@ -440,11 +498,40 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   if (!tile_is_fast(p, sh, sw)) return;
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
-  for (int y = wave; y < sh + 4; y += 4)
-    for (int x = lane; x < P; x += 64) {
-      const bool in = y >= 2 && y < sh + 2 && x >= 2 && x < sw + 2;
-      s_tex[y * P + x] = in ? gtex[(y - 2) * sw + (x - 2)] : (uint8_t)0;
+  // texture -> LDS with a 2-texel zero border: zero everything, then copy the interior with
+  // independent dword loads (all in flight together)
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(s_tex);
+    const int nz = ((sh + 4) * P + 3) >> 2;
+    for (int k = t; k < nz; k += 256) z[k] = 0u;
+  }
+  __syncthreads();
+  {
+    const int nbytes = sh * sw;
+    const float inv_sw = 1.0f / (float)sw;
+    if ((reinterpret_cast<uintptr_t>(gtex) & 3u) == 0) {
+      const uint32_t* g4 = reinterpret_cast<const uint32_t*>(gtex);
+      const int nd = nbytes >> 2;
+      for (int k = t; k < nd; k += 256) {
+        const uint32_t v = g4[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int idx = 4 * k + j;
+          const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
+          s_tex[(y + 2) * P + (x + 2)] = (uint8_t)(v >> (8 * j));
+        }
+      }
+      for (int idx = (nd << 2) + t; idx < nbytes; idx += 256) {
+        const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
+        s_tex[(y + 2) * P + (x + 2)] = gtex[idx];
+      }
+    } else {
+      for (int idx = t; idx < nbytes; idx += 256) {
+        const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
+        s_tex[(y + 2) * P + (x + 2)] = gtex[idx];
+      }
     }
+  }
   double* A0 = sc.arena + p.a0_off;
   const int pw = p.pw, shift = p.shift, tw = p.tw, th = p.th;
   zero_pad(p, A0);
@@ -452,62 +539,57 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   for (int dx = t; dx < tw; dx += 256) s_ax[dx] = area_span(p.nW, p.scale_x, dx);
   __syncthreads();
-  const int pitch = imax(tile_pitch(p, sh, sw), 1);
-  const int R = imax(imin(ROWS_MAX, CAN_MAX / pitch), 1);
+  const int pitch = imin(imax(tile_pitch(p, sh, sw), 1), CAN_W);
+  const int Rw = imax(imin(ROWS_W, CAN_W / pitch), 1);       // canvas rows a wave stages at a time
+  const float inv_pitch = 1.0f / (float)pitch, inv_tw = 1.0f / (float)tw;
   int k_dy = (int)(((double)(BUF_MAX / tw) - 3.0) / sy_scale);
   if (k_dy < 1) k_dy = 1;
+  double* can = s_can[wave];
+  int4* rowp = s_row[wave];
   for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
     const int dy1 = imin(dy0 + k_dy, th);
     const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
     const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, p.nH - 1);
-    // ---- canvas rows lo..hi in chunks that fit s_can ----
-    for (int rc = lo; rc <= hi; rc += R) {
-      const int Rn = imin(R, hi - rc + 1);
-      for (int r = t; r < Rn; r += 256) {
-        const int c = rc + r;
+    // ---- canvas rows lo..hi: each wave takes groups of Rw rows, no block barrier needed ----
+    for (int r0 = lo + wave * Rw; r0 <= hi; r0 += 4 * Rw) {
+      const int nr = imin(Rw, hi - r0 + 1);
+      if (lane < nr) {
+        const int c = r0 + lane;
         const int ry = p.flip ? (p.nH - 1 - c) : c;
         int xa, n;
         row_interval(p, sh, sw, ry, xa, n);
-        s_row[r] = make_int4((int)rot_X0(p, ry), (int)rot_Y0(p, ry), xa, imin(n, pitch));
+        rowp[lane] = make_int4((int)rot_X0(p, ry), (int)rot_Y0(p, ry), xa, imin(n, pitch));
       }
-      __syncthreads();
-      // ---- 1a: samples, lanes along the row ----
-      for (int r = wave; r < Rn; r += 4) {
-        const int4 rw = s_row[r];
-        double* out = s_can + r * pitch;
-        for (int x = lane; x < rw.w; x += 64) {
-          const int2 d = s_adbd[rw.z + x];
-          const int X = (rw.x + d.x) >> 5, Y = (rw.y + d.y) >> 5;
-          int sx = X >> 5, sy = Y >> 5;
-          const int fx = X & 31, fy = Y & 31;
-          sx = imin(imax(sx, -2), sw);
-          sy = imin(imax(sy, -2), sh);
-          const uint8_t* q = s_tex + (sy + 2) * P + (sx + 2);
-          const double v00 = s_lut[q[0]], v01 = s_lut[q[1]], v10 = s_lut[q[P]], v11 = s_lut[q[P + 1]];
-          const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
-          // integer-valued weights; the common factor 2^-10 is applied once (exact)
-          const double sm = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
-          out[x] = sm * (1.0 / 1024.0);
+      wave_lds_sync();
+      // ---- 1a: bilinear samples of the rotated texture, lanes flattened over (row, column) ----
+      const int nidx = nr * pitch;
+#pragma unroll 2
+      for (int idx = lane; idx < nidx; idx += 64) {
+        const int r = (int)(((float)idx + 0.5f) * inv_pitch), x = idx - r * pitch;
+        const int4 rw = rowp[r];
+        if (x < rw.w) {
+          can[idx] = lds_rot_sample(s_tex, s_lut, P, sh, sw, rw.x, rw.y, s_adbd[rw.z + x]);
         }
       }
-      __syncthreads();
-      // ---- 1b: horizontal folds ----
-      const int items = Rn * tw;
-      for (int it = t; it < items; it += 256) {
-        const int r = it / tw, dx = it - r * tw;
+      wave_lds_sync();
+      // ---- 1b: horizontal folds, one lane per (row, destination column) ----
+      const int items = nr * tw;
+      for (int it = lane; it < items; it += 64) {
+        const int r = (int)(((float)it + 0.5f) * inv_tw), dx = it - r * tw;
         const AreaSpan ax = s_ax[dx];
-        const int4 rw = s_row[r];
+        const int4 rw = rowp[r];
         const int e0 = imax(ax.s1 - ax.has_l, rw.z), e1 = imin(ax.s2 - 1 + ax.has_r, rw.z + rw.w - 1);
-        const double* row = s_can + r * pitch - rw.z;
+        const double* row = can + r * pitch - rw.z;
         double b = 0.0;
         for (int sx = e0; sx <= e1; sx++) {
           const float a = sx < ax.s1 ? ax.a_l : (sx >= ax.s2 ? ax.a_r : ax.a_m);
           b = b + row[sx] * (double)a;
         }
-        s_buf[(rc - lo + r) * tw + dx] = b;
+        s_buf[(r0 - lo + r) * tw + dx] = b;
       }
-      __syncthreads();
+      wave_lds_sync();
     }
+    __syncthreads();
     // ---- 2: vertical folds ----
     const int npx = (dy1 - dy0) * tw;
     for (int it = t; it < npx; it += 256) {

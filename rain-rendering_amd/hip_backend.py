@@ -194,8 +194,11 @@ def pack_streak_db(textures):
     hs = np.array([t.shape[0] for t in textures], np.int32)
     ws = np.array([t.shape[1] for t in textures], np.int32)
     sizes = hs.astype(np.int64) * ws
-    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
-    texels = np.concatenate([np.ascontiguousarray(t, np.uint8).ravel() for t in textures])
+    padded = (sizes + 15) // 16 * 16                 # 16-byte aligned textures: the kernels copy them with dword loads
+    offs = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.int64)
+    texels = np.zeros(int(padded.sum()), np.uint8)
+    for t, o, n in zip(textures, offs, sizes):
+        texels[o:o + n] = np.ascontiguousarray(t, np.uint8).ravel()
     return texels, hs, ws, offs
 
 
