@@ -202,6 +202,39 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
   }
 }
 
+// blur work layout (needed by k_colour to know where the finished tile will live)
+constexpr int BX_MAX = 3072;        // doubles: input sub-tile incl. halo
+constexpr int BY_MAX = 2048;        // doubles: after the row (axis 0) pass
+constexpr int BR_MAX = 48;          // largest axis-0 radius the fused kernel takes
+
+struct BlurLayout {
+  int fused;        // 0: two global passes (k_blur<0>, k_blur<1>)
+  int wo, ho;       // output sub-tile
+  int single;       // one sub-tile covers the padded tile: result written in place (A0)
+};
+__device__ inline BlurLayout blur_layout(const DropPlan& p) {
+  BlurLayout b{0, 0, 0, 0};
+  if (p.r1 <= 0 || p.r1 > BR_MAX) return b;
+  if (p.pw * p.ph <= BY_MAX) { b.fused = 1; b.wo = p.pw; b.ho = p.ph; b.single = 1; return b; }
+  int wo = imin(p.pw, 64), ho = imin(p.ph, 64);
+  for (int it = 0; it < 12; it++) {
+    const int wi = imin(wo + 2 * p.r2, p.pw), hi = imin(ho + 2 * p.r1, p.ph);
+    if (wi * hi <= BX_MAX && wi * ho <= BY_MAX) { b.fused = 1; b.wo = wo; b.ho = ho; return b; }
+    if (ho >= wo && ho > 4) ho = (ho + 1) / 2;
+    else if (wo > 4) wo = (wo + 1) / 2;
+    else if (ho > 4) ho = (ho + 1) / 2;
+    else break;
+  }
+  return b;
+}
+// which arena buffer holds the finished alpha tile
+__device__ inline int blur_final_buf(const DropPlan& p) {
+  if (p.r1 <= 0) return 0;
+  const BlurLayout b = blur_layout(p);
+  if (b.fused) return b.single ? 0 : 1;
+  return p.r2 == 0 ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------
 // colour: FOV polygon row spans x prefix table, one wave per drop
 // ---------------------------------------------------------------------------
@@ -258,7 +291,7 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
       rec.ox = p.crop_x - p.vis_x0;
       rec.oy = p.crop_y - p.vis_y0;
       rec.pitch = p.pw;
-      rec.off = p.final_buf ? p.a1_off : p.a0_off;
+      rec.off = blur_final_buf(p) ? p.a1_off : p.a0_off;
       rec.tau_one = p.tau_one;
       rec.g = p.g;
     }
@@ -472,7 +505,7 @@ __device__ inline void wave_lds_sync() {
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                              Scratch sc) {
+                                              Scratch sc, int dbg) {
   const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (i >= frames[f].n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
@@ -506,7 +539,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     for (int k = t; k < nz; k += 256) z[k] = 0u;
   }
   __syncthreads();
-  {
+  if (!(dbg & 8)) {
     const int nbytes = sh * sw;
     const float inv_sw = 1.0f / (float)sw;
     if ((reinterpret_cast<uintptr_t>(gtex) & 3u) == 0) {
@@ -553,7 +586,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     // ---- canvas rows lo..hi: each wave takes groups of Rw rows, no block barrier needed ----
     for (int r0 = lo + wave * Rw; r0 <= hi; r0 += 4 * Rw) {
       const int nr = imin(Rw, hi - r0 + 1);
-      if (lane < nr) {
+      if (lane < nr && !((dbg & 16) && r0 > lo)) {
         const int c = r0 + lane;
         const int ry = p.flip ? (p.nH - 1 - c) : c;
         int xa, n;
@@ -564,7 +597,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       // ---- 1a: bilinear samples of the rotated texture, lanes flattened over (row, column) ----
       const int nidx = nr * pitch;
 #pragma unroll 2
-      for (int idx = lane; idx < nidx; idx += 64) {
+      for (int idx = lane; idx < ((dbg & 1) ? 0 : nidx); idx += 64) {
         const int r = (int)(((float)idx + 0.5f) * inv_pitch), x = idx - r * pitch;
         const int4 rw = rowp[r];
         if (x < rw.w) {
@@ -574,7 +607,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       wave_lds_sync();
       // ---- 1b: horizontal folds, one lane per (row, destination column) ----
       const int items = nr * tw;
-      for (int it = lane; it < items; it += 64) {
+      for (int it = lane; it < ((dbg & 2) ? 0 : items); it += 64) {
         const int r = (int)(((float)it + 0.5f) * inv_tw), dx = it - r * tw;
         const AreaSpan ax = s_ax[dx];
         const int4 rw = rowp[r];
@@ -591,7 +624,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     }
     __syncthreads();
     // ---- 2: vertical folds ----
-    const int npx = (dy1 - dy0) * tw;
+    const int npx = (dbg & 4) ? 0 : (dy1 - dy0) * tw;
     for (int it = t; it < npx; it += 256) {
       const int r = it / tw, dx = it - r * tw;
       const int dy = dy0 + r;
@@ -634,6 +667,74 @@ __device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------
+// fused defocus blur: both axes of the separable filter through LDS
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  const DropPlan& p = sc.plan[gi];
+  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || p.r1 == 0) return;
+  const BlurLayout L = blur_layout(p);
+  if (!L.fused) return;
+  __shared__ double hw1[BR_MAX + 1], hw2[BR_MAX + 1];
+  __shared__ double X[BX_MAX], Y[BY_MAX];
+  const int r1 = p.r1, r2 = p.r2, pw = p.pw, ph = p.ph;
+  gauss_half_table(p.sig1, r1, hw1);
+  if (r2 > 0) gauss_half_table(p.sig2, r2, hw2);
+  const double* src = sc.arena + p.a0_off;
+  double* dst = sc.arena + (L.single ? p.a0_off : p.a1_off);
+  for (int y0 = 0; y0 < ph; y0 += L.ho) {
+    const int y1 = imin(y0 + L.ho, ph);
+    const int iy0 = imax(y0 - r1, 0), iy1 = imin(y1 + r1, ph);
+    for (int x0 = 0; x0 < pw; x0 += L.wo) {
+      const int x1 = imin(x0 + L.wo, pw);
+      const int ix0 = imax(x0 - r2, 0), ix1 = imin(x1 + r2, pw);
+      const int wi = ix1 - ix0, hi = iy1 - iy0, ho = y1 - y0, wo = x1 - x0;
+      const float inv_wi = 1.0f / (float)wi, inv_wo = 1.0f / (float)wo;
+      for (int idx = t; idx < wi * hi; idx += 256) {
+        const int y = (int)(((float)idx + 0.5f) * inv_wi), x = idx - y * wi;
+        X[idx] = src[(int64_t)(iy0 + y) * pw + (ix0 + x)];
+      }
+      __syncthreads();
+      // axis 0 (rows, sigma = c): symmetric correlate1d, zero extension outside the padded tile
+      for (int idx = t; idx < wi * ho; idx += 256) {
+        const int yy = (int)(((float)idx + 0.5f) * inv_wi), x = idx - yy * wi;
+        const int y = y0 + yy;                       // row in the padded tile
+        const double* col = X + (y - iy0) * wi + x;
+        double acc = col[0] * hw1[r1];
+        for (int ii = -r1; ii < 0; ii++) {
+          const double va = (y + ii >= 0) ? col[ii * wi] : 0.0;
+          const double vb = (y - ii < ph) ? col[-ii * wi] : 0.0;
+          acc = acc + (va + vb) * hw1[ii + r1];
+        }
+        Y[idx] = acc;
+      }
+      __syncthreads();
+      // axis 1 (columns, sigma = c/2)
+      for (int idx = t; idx < wo * ho; idx += 256) {
+        const int yy = (int)(((float)idx + 0.5f) * inv_wo), xx = idx - yy * wo;
+        const int x = x0 + xx;
+        const double* row = Y + yy * wi + (x - ix0);
+        double acc;
+        if (r2 > 0) {
+          acc = row[0] * hw2[r2];
+          for (int ii = -r2; ii < 0; ii++) {
+            const double va = (x + ii >= 0) ? row[ii] : 0.0;
+            const double vb = (x - ii < pw) ? row[-ii] : 0.0;
+            acc = acc + (va + vb) * hw2[ii + r2];
+          }
+        } else {
+          acc = row[0];
+        }
+        dst[(int64_t)(y0 + yy) * pw + x] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int AXIS>
 __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_drops, Scratch sc) {
   const int f = blockIdx.y, i = blockIdx.x;
@@ -642,6 +743,7 @@ __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_d
   const DropPlan& p = sc.plan[gi];
   const int r = AXIS == 0 ? p.r1 : p.r2;
   if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || r == 0) return;
+  if (blur_layout(p).fused) return;
   __shared__ double hw[MAX_R + 1];
   gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
   const double* src = sc.arena + (AXIS == 0 ? p.a0_off : p.a1_off);
@@ -824,6 +926,7 @@ struct rr_ctx {
   } st;
   // profiling
   bool prof = false;
+  int tile_dbg = 0;                 // RAINHIP_TILE_DBG: timing experiments only (skips stages of k_tile)
   bool simple_tile = false;          // RAINHIP_SIMPLE_TILE=1: one-thread-per-pixel tile kernel (A/B reference)
   std::vector<ProfEntry> prof_pending;
   std::vector<rr_kernel_stat> prof_stats;
@@ -1044,13 +1147,17 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
                            ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
       } else {
         hipLaunchKernelGGL(k_tile, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
-                           ctx->d_tex_off, sc);
+                           ctx->d_tex_off, sc, ctx->tile_dbg);
       }
     }
     if (!ctx->simple_tile) {
       ProfScope ps(ctx, s, "k_tile_generic");
       hipLaunchKernelGGL(k_tile_generic, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
                          ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_blur_fused");
+      hipLaunchKernelGGL(k_blur_fused, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
@@ -1117,6 +1224,8 @@ int rr_create(rr_ctx** out, int device) {
   {
     const char* e = getenv("RAINHIP_SIMPLE_TILE");
     ctx->simple_tile = e && e[0] == '1';
+    const char* d = getenv("RAINHIP_TILE_DBG");
+    ctx->tile_dbg = d ? atoi(d) : 0;
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
