@@ -215,11 +215,14 @@ struct BlurLayout {
 __device__ inline BlurLayout blur_layout(const DropPlan& p) {
   BlurLayout b{0, 0, 0, 0};
   if (p.r1 <= 0 || p.r1 > BR_MAX) return b;
-  if (p.pw * p.ph <= BY_MAX) { b.fused = 1; b.wo = p.pw; b.ho = p.ph; b.single = 1; return b; }
-  int wo = imin(p.pw, 64), ho = imin(p.ph, 64);
-  for (int it = 0; it < 12; it++) {
-    const int wi = imin(wo + 2 * p.r2, p.pw), hi = imin(ho + 2 * p.r1, p.ph);
-    if (wi * hi <= BX_MAX && wi * ho <= BY_MAX) { b.fused = 1; b.wo = wo; b.ho = ho; return b; }
+  // the LDS tiles carry explicit zero halos (r2 columns, r1 rows) so the filter loops are branch-free
+  int wo = p.pw, ho = p.ph;
+  for (int it = 0; it < 16; it++) {
+    const int wi = wo + 2 * p.r2, hi = ho + 2 * p.r1;
+    if (wi * hi <= BX_MAX && wi * ho <= BY_MAX) {
+      b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo == p.pw && ho == p.ph) ? 1 : 0;
+      return b;
+    }
     if (ho >= wo && ho > 4) ho = (ho + 1) / 2;
     else if (wo > 4) wo = (wo + 1) / 2;
     else if (ho > 4) ho = (ho + 1) / 2;
@@ -349,21 +352,32 @@ constexpr int ROWS_W = 16;        // canvas rows a wave stages at most
 // Columns rx of canvas row `ry` (un-flipped row number) whose bilinear footprint can touch
 // the texture, conservatively (+-1 texel, +-1 column): [xa, xa+n).  Samples outside are
 // exactly 0.0.  The interval length is bounded by tile_pitch() for every row.
-__device__ inline void row_interval(const DropPlan& p, int sh, int sw, int ry, int& xa, int& n) {
-  double lo = 0.0, hi = (double)(p.nW - 1);
+struct RowGeom {                    // per-drop constants of row_interval
+  double inv[2];                    // 1 / (m0*1024), 1 / (m3*1024); 0 when the axis does not depend on rx
+  double U[2];
+};
+__device__ inline RowGeom row_geom(const DropPlan& p, int sh, int sw) {
+  RowGeom g;
   const double A[2] = {p.ma[0] * 1024.0, p.ma[3] * 1024.0};
-  const double C[2] = {(p.ma[1] * (double)ry + p.ma[2]) * 1024.0 + 16.0, (p.ma[4] * (double)ry + p.ma[5]) * 1024.0 + 16.0};
-  const double U[2] = {(double)(sw + 1) * 1024.0, (double)(sh + 1) * 1024.0};
+  for (int k = 0; k < 2; k++) g.inv[k] = fabs(A[k]) < 1e-6 ? 0.0 : 1.0 / A[k];
+  g.U[0] = (double)(sw + 1) * 1024.0;
+  g.U[1] = (double)(sh + 1) * 1024.0;
+  return g;
+}
+// X0/Y0 are the row's fixed-point terms (rot_X0 / rot_Y0)
+__device__ inline void row_interval(const DropPlan& p, const RowGeom& g, int X0, int Y0, int& xa, int& n) {
+  double lo = 0.0, hi = (double)(p.nW - 1);
+  const double C[2] = {(double)X0, (double)Y0};
   const double L = -2048.0;
   bool empty = false;
   for (int k = 0; k < 2; k++) {
-    if (fabs(A[k]) < 1e-6) {
-      if (C[k] < L - 1024.0 || C[k] > U[k] + 1024.0) empty = true;
+    if (g.inv[k] == 0.0) {
+      if (C[k] < L - 1024.0 || C[k] > g.U[k] + 1024.0) empty = true;
     } else {
-      double t0 = (L - C[k]) / A[k], t1 = (U[k] - C[k]) / A[k];
+      double t0 = (L - C[k]) * g.inv[k], t1 = (g.U[k] - C[k]) * g.inv[k];
       if (t0 > t1) { double t = t0; t0 = t1; t1 = t; }
-      lo = fmax(lo, floor(t0) - 1.0);
-      hi = fmin(hi, ceil(t1) + 1.0);
+      lo = fmax(lo, floor(t0) - 2.0);
+      hi = fmin(hi, ceil(t1) + 2.0);
     }
   }
   if (empty || lo > hi) { xa = 0; n = 0; return; }
@@ -376,7 +390,7 @@ __device__ inline int tile_pitch(const DropPlan& p, int sh, int sw) {
   const double A[2] = {fabs(p.ma[0]) * 1024.0, fabs(p.ma[3]) * 1024.0};
   const double span[2] = {(double)(sw + 1) * 1024.0 + 2048.0, (double)(sh + 1) * 1024.0 + 2048.0};
   for (int k = 0; k < 2; k++)
-    if (A[k] >= 1e-6) w = fmin(w, span[k] / A[k] + 6.0);
+    if (A[k] >= 1e-6) w = fmin(w, span[k] / A[k] + 8.0);
   return (int)w;
 }
 
@@ -404,6 +418,45 @@ __device__ inline void zero_pad(const DropPlan& p, double* A0) {
   }
 }
 
+// texture -> LDS with a 2-texel zero border (pitch sw+4).  Border texels are zeroed directly,
+// the interior is copied with independent dword loads (textures are 16-byte aligned by
+// pack_streak_db; unaligned bases fall back to byte loads).  Caller syncs afterwards.
+__device__ inline void load_tex_padded(uint8_t* s_tex, const uint8_t* gtex, int sh, int sw) {
+  const int t = threadIdx.x, P = sw + 4;
+  for (int k = t; k < 4 * P; k += 256) {               // two rows above, two below
+    const int r = k / P, x = k - r * P;
+    s_tex[(r < 2 ? r : sh + r) * P + x] = 0;
+  }
+  for (int k = t; k < 4 * sh; k += 256) {               // two columns left, two right
+    const int y = k >> 2, c = k & 3;
+    s_tex[(y + 2) * P + (c < 2 ? c : sw + c)] = 0;
+  }
+  const int nbytes = sh * sw;
+  const float inv_sw = 1.0f / (float)sw;
+  if ((reinterpret_cast<uintptr_t>(gtex) & 3u) == 0) {
+    const uint32_t* g4 = reinterpret_cast<const uint32_t*>(gtex);
+    const int nd = nbytes >> 2;
+    for (int k = t; k < nd; k += 256) {
+      const uint32_t v = g4[k];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int idx = 4 * k + j;
+        const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
+        s_tex[(y + 2) * P + (x + 2)] = (uint8_t)(v >> (8 * j));
+      }
+    }
+    for (int idx = (nd << 2) + t; idx < nbytes; idx += 256) {
+      const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
+      s_tex[(y + 2) * P + (x + 2)] = gtex[idx];
+    }
+  } else {
+    for (int idx = t; idx < nbytes; idx += 256) {
+      const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
+      s_tex[(y + 2) * P + (x + 2)] = gtex[idx];
+    }
+  }
+}
+
 // fixed-point bilinear sample of the padded LDS texture (same arithmetic as rot_sample; valid
 // when tile_coords_safe(p) holds)
 __device__ inline double lds_rot_sample(const uint8_t* s_tex, const double* s_lut, int P, int sh, int sw, int X0, int Y0,
@@ -425,7 +478,7 @@ __device__ inline double lds_rot_sample(const uint8_t* s_tex, const double* s_lu
 __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                                       const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
                                                       const float* ctab, Scratch sc) {
-  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
   if (i >= frames[f].n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
   if (sc.sizes[gi] == 0) return;
@@ -440,13 +493,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
   const bool tex_fits = (sh + 4) * P <= TEX_LDS;
-  if (tex_fits) {
-    for (int y = wave; y < sh + 4; y += 4)
-      for (int x = lane; x < P; x += 64) {
-        const bool in = y >= 2 && y < sh + 2 && x >= 2 && x < sw + 2;
-        s_tex[y * P + x] = in ? gtex[(y - 2) * sw + (x - 2)] : (uint8_t)0;
-      }
-  }
+  if (tex_fits) load_tex_padded(s_tex, gtex, sh, sw);
   double* A0 = sc.arena + p.a0_off;
   zero_pad(p, A0);
   // integer-ratio INTER_AREA (ResizeAreaFast): the per-pixel chain is sequential by definition;
@@ -531,40 +578,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   if (!tile_is_fast(p, sh, sw)) return;
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
-  // texture -> LDS with a 2-texel zero border: zero everything, then copy the interior with
-  // independent dword loads (all in flight together)
-  {
-    uint32_t* z = reinterpret_cast<uint32_t*>(s_tex);
-    const int nz = ((sh + 4) * P + 3) >> 2;
-    for (int k = t; k < nz; k += 256) z[k] = 0u;
-  }
-  __syncthreads();
-  if (!(dbg & 8)) {
-    const int nbytes = sh * sw;
-    const float inv_sw = 1.0f / (float)sw;
-    if ((reinterpret_cast<uintptr_t>(gtex) & 3u) == 0) {
-      const uint32_t* g4 = reinterpret_cast<const uint32_t*>(gtex);
-      const int nd = nbytes >> 2;
-      for (int k = t; k < nd; k += 256) {
-        const uint32_t v = g4[k];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int idx = 4 * k + j;
-          const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
-          s_tex[(y + 2) * P + (x + 2)] = (uint8_t)(v >> (8 * j));
-        }
-      }
-      for (int idx = (nd << 2) + t; idx < nbytes; idx += 256) {
-        const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
-        s_tex[(y + 2) * P + (x + 2)] = gtex[idx];
-      }
-    } else {
-      for (int idx = t; idx < nbytes; idx += 256) {
-        const int y = (int)(((float)idx + 0.5f) * inv_sw), x = idx - y * sw;
-        s_tex[(y + 2) * P + (x + 2)] = gtex[idx];
-      }
-    }
-  }
+  if (!(dbg & 8)) load_tex_padded(s_tex, gtex, sh, sw);
   double* A0 = sc.arena + p.a0_off;
   const int pw = p.pw, shift = p.shift, tw = p.tw, th = p.th;
   zero_pad(p, A0);
@@ -572,6 +586,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   for (int dx = t; dx < tw; dx += 256) s_ax[dx] = area_span(p.nW, p.scale_x, dx);
   __syncthreads();
+  const RowGeom geom = row_geom(p, sh, sw);
   const int pitch = imin(imax(tile_pitch(p, sh, sw), 1), CAN_W);
   const int Rw = imax(imin(ROWS_W, CAN_W / pitch), 1);       // canvas rows a wave stages at a time
   const float inv_pitch = 1.0f / (float)pitch, inv_tw = 1.0f / (float)tw;
@@ -589,9 +604,10 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       if (lane < nr && !((dbg & 16) && r0 > lo)) {
         const int c = r0 + lane;
         const int ry = p.flip ? (p.nH - 1 - c) : c;
+        const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
         int xa, n;
-        row_interval(p, sh, sw, ry, xa, n);
-        rowp[lane] = make_int4((int)rot_X0(p, ry), (int)rot_Y0(p, ry), xa, imin(n, pitch));
+        row_interval(p, geom, X0, Y0, xa, n);
+        rowp[lane] = make_int4(X0, Y0, xa, imin(n, pitch));
       }
       wave_lds_sync();
       // ---- 1a: bilinear samples of the rotated texture, lanes flattened over (row, column) ----
@@ -611,13 +627,26 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
         const int r = (int)(((float)it + 0.5f) * inv_tw), dx = it - r * tw;
         const AreaSpan ax = s_ax[dx];
         const int4 rw = rowp[r];
-        const int e0 = imax(ax.s1 - ax.has_l, rw.z), e1 = imin(ax.s2 - 1 + ax.has_r, rw.z + rw.w - 1);
+        const int xlo = rw.z, xhi = rw.z + rw.w - 1;          // staged (possibly non-zero) columns
         const double* row = can + r * pitch - rw.z;
         double b = 0.0;
-        for (int sx = e0; sx <= e1; sx++) {
-          const float a = sx < ax.s1 ? ax.a_l : (sx >= ax.s2 ? ax.a_r : ax.a_m);
-          b = b + row[sx] * (double)a;
+        // resizeArea_ order: left partial cell, full cells, right partial cell; columns outside
+        // [xlo, xhi] hold exact zeros and are skipped
+        if (ax.has_l && ax.s1 - 1 >= xlo && ax.s1 - 1 <= xhi) b = b + row[ax.s1 - 1] * (double)ax.a_l;
+        {
+          const int m0 = imax(ax.s1, xlo), m1 = imin(ax.s2 - 1, xhi);
+          const double am = (double)ax.a_m;
+          int sx = m0;
+          for (; sx + 3 <= m1; sx += 4) {
+            const double v0 = row[sx], v1 = row[sx + 1], v2 = row[sx + 2], v3 = row[sx + 3];
+            b = b + v0 * am;
+            b = b + v1 * am;
+            b = b + v2 * am;
+            b = b + v3 * am;
+          }
+          for (; sx <= m1; sx++) b = b + row[sx] * am;
         }
+        if (ax.has_r && ax.s2 >= xlo && ax.s2 <= xhi) b = b + row[ax.s2] * (double)ax.a_r;
         s_buf[(r0 - lo + r) * tw + dx] = b;
       }
       wave_lds_sync();
@@ -686,49 +715,71 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const double* src = sc.arena + p.a0_off;
   double* dst = sc.arena + (L.single ? p.a0_off : p.a1_off);
   for (int y0 = 0; y0 < ph; y0 += L.ho) {
-    const int y1 = imin(y0 + L.ho, ph);
-    const int iy0 = imax(y0 - r1, 0), iy1 = imin(y1 + r1, ph);
+    const int ho = imin(L.ho, ph - y0);
     for (int x0 = 0; x0 < pw; x0 += L.wo) {
-      const int x1 = imin(x0 + L.wo, pw);
-      const int ix0 = imax(x0 - r2, 0), ix1 = imin(x1 + r2, pw);
-      const int wi = ix1 - ix0, hi = iy1 - iy0, ho = y1 - y0, wo = x1 - x0;
+      const int wo = imin(L.wo, pw - x0);
+      const int wi = wo + 2 * r2, hi = ho + 2 * r1;       // LDS tile with zero halos
       const float inv_wi = 1.0f / (float)wi, inv_wo = 1.0f / (float)wo;
-      for (int idx = t; idx < wi * hi; idx += 256) {
-        const int y = (int)(((float)idx + 0.5f) * inv_wi), x = idx - y * wi;
-        X[idx] = src[(int64_t)(iy0 + y) * pw + (ix0 + x)];
+      // haloed tile -> LDS; eight independent global loads in flight per thread
+      const int nx = wi * hi;
+      for (int base = t; base < nx; base += 2048) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int idx = base + 256 * k;
+          const int yy = (int)(((float)idx + 0.5f) * inv_wi), xx = idx - yy * wi;
+          const int y = y0 - r1 + yy, x = x0 - r2 + xx;
+          v[k] = (idx < nx && y >= 0 && y < ph && x >= 0 && x < pw) ? src[(int64_t)y * pw + x] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (base + 256 * k < nx) X[base + 256 * k] = v[k];
       }
       __syncthreads();
-      // axis 0 (rows, sigma = c): symmetric correlate1d, zero extension outside the padded tile
-      for (int idx = t; idx < wi * ho; idx += 256) {
-        const int yy = (int)(((float)idx + 0.5f) * inv_wi), x = idx - yy * wi;
-        const int y = y0 + yy;                       // row in the padded tile
-        const double* col = X + (y - iy0) * wi + x;
-        double acc = col[0] * hw1[r1];
-        for (int ii = -r1; ii < 0; ii++) {
-          const double va = (y + ii >= 0) ? col[ii * wi] : 0.0;
-          const double vb = (y - ii < ph) ? col[-ii * wi] : 0.0;
-          acc = acc + (va + vb) * hw1[ii + r1];
+      // axis 0 (rows, sigma = c): symmetric correlate1d; four independent outputs per thread
+      const int nv = wi * ho;
+      for (int base = t; base < nv; base += 1024) {
+        double acc[4];
+        const double* col[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int idx = imin(base + 256 * k, nv - 1);
+          col[k] = X + idx + r1 * wi;                 // (row yy + r1, column xx) of the haloed tile
+          acc[k] = col[k][0] * hw1[r1];
         }
-        Y[idx] = acc;
+        for (int ii = -r1; ii < 0; ii++) {
+          const double w = hw1[ii + r1];
+          const int o = ii * wi;
+#pragma unroll
+          for (int k = 0; k < 4; k++) acc[k] = acc[k] + (col[k][o] + col[k][-o]) * w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (base + 256 * k < nv) Y[base + 256 * k] = acc[k];
       }
       __syncthreads();
       // axis 1 (columns, sigma = c/2)
-      for (int idx = t; idx < wo * ho; idx += 256) {
-        const int yy = (int)(((float)idx + 0.5f) * inv_wo), xx = idx - yy * wo;
-        const int x = x0 + xx;
-        const double* row = Y + yy * wi + (x - ix0);
-        double acc;
-        if (r2 > 0) {
-          acc = row[0] * hw2[r2];
-          for (int ii = -r2; ii < 0; ii++) {
-            const double va = (x + ii >= 0) ? row[ii] : 0.0;
-            const double vb = (x - ii < pw) ? row[-ii] : 0.0;
-            acc = acc + (va + vb) * hw2[ii + r2];
-          }
-        } else {
-          acc = row[0];
+      const int nh = wo * ho;
+      for (int base = t; base < nh; base += 1024) {
+        double acc[4];
+        const double* row[4];
+        int oidx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int idx = imin(base + 256 * k, nh - 1);
+          const int yy = (int)(((float)idx + 0.5f) * inv_wo), xx = idx - yy * wo;
+          row[k] = Y + yy * wi + xx + r2;
+          oidx[k] = (y0 + yy) * pw + (x0 + xx);
+          acc[k] = (r2 > 0) ? row[k][0] * hw2[r2] : row[k][0];
         }
-        dst[(int64_t)(y0 + yy) * pw + x] = acc;
+        for (int ii = -r2; ii < 0; ii++) {
+          const double w = hw2[ii + r2];
+#pragma unroll
+          for (int k = 0; k < 4; k++) acc[k] = acc[k] + (row[k][ii] + row[k][-ii]) * w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (base + 256 * k < nh) dst[oidx[k]] = acc[k];
       }
       __syncthreads();
     }
@@ -799,13 +850,24 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     }
     if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
     __syncthreads();
+    // software-pipelined: the alpha sample of entry e+1 is in flight while entry e is blended
+    bool in_n = false;
+    double A_n = 0.0;
+    if (total > 0) {
+      const CompRec& r = comp[__builtin_amdgcn_readfirstlane(s_list[0])];
+      in_n = live && px >= r.x0 && px < r.x1 && py >= r.y0 && py < r.y1;
+      if (in_n) A_n = arena[r.off + (int64_t)(py + r.oy) * r.pitch + (px + r.ox)];
+    }
     for (int e = 0; e < total; e++) {
-      const int idx = __builtin_amdgcn_readfirstlane(s_list[e]);
-      const CompRec& r = comp[idx];
-      if (live && px >= r.x0 && px < r.x1 && py >= r.y0 && py < r.y1) {
-        const double A = arena[r.off + (int64_t)(py + r.oy) * r.pitch + (px + r.ox)];
-        blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
+      const CompRec& r = comp[__builtin_amdgcn_readfirstlane(s_list[e])];
+      const bool in_c = in_n;
+      const double A = A_n;
+      if (e + 1 < total) {
+        const CompRec& q = comp[__builtin_amdgcn_readfirstlane(s_list[e + 1])];
+        in_n = live && px >= q.x0 && px < q.x1 && py >= q.y0 && py < q.y1;
+        if (in_n) A_n = arena[q.off + (int64_t)(py + q.oy) * q.pitch + (px + q.ox)];
       }
+      if (in_c) blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
     }
     __syncthreads();
   }
