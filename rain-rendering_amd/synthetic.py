@@ -57,14 +57,15 @@ def make_envmap(i, He, We):
     return np.ascontiguousarray(0.05 + 0.9 * a)
 
 
-def make_textures(seed=7):
+def make_textures(seed=7, tex_heights=None, tex_width=None):
     """50 uint16 gray streak images: a Gaussian ridge along the streak modulated by the
     drop's shape oscillation (Garg & Nayar style appearance), brighter at the ends."""
     rng = np.random.RandomState(seed)
     out = []
-    for v, h in enumerate(TEX_H):
+    tw = tex_width or TEX_W
+    for v, h in enumerate(tex_heights or TEX_H):
         y = (np.arange(h) + 0.5) / h
-        x = (np.arange(TEX_W) + 0.5) / TEX_W - 0.5
+        x = (np.arange(tw) + 0.5) / tw - 0.5
         for osc in range(10):
             amp = 0.05 + 0.03 * osc
             freq = 1.5 + 0.7 * osc + 0.2 * v
@@ -78,7 +79,7 @@ def make_textures(seed=7):
     return out
 
 
-def write_streak_db(root, seed=7):
+def write_streak_db(root, seed=7, tex_heights=None, tex_width=None):
     """Writes the rainstreakdb layout under `root`; returns (texture_dir, norm_file)."""
     from PIL import Image
     tex_dir = os.path.join(root, 'env_light_database', 'size32')
@@ -87,7 +88,7 @@ def write_streak_db(root, seed=7):
     os.makedirs(txt_dir, exist_ok=True)
     rng = np.random.RandomState(seed + 1)
     coeffs = {}
-    for v, osc, img in make_textures(seed):
+    for v, osc, img in make_textures(seed, tex_heights, tex_width):
         Image.fromarray(img).save(os.path.join(tex_dir, 'cv%d_osc%d.png' % (v, osc)))
         coeffs.setdefault(v, []).append(0.3 + 0.7 * rng.rand())
     norm = os.path.join(txt_dir, 'normalized_env_max.txt')

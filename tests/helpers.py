@@ -28,12 +28,15 @@ KITTI = dict(focal_mm=6.0, f_number=6.0, exposure_ms=2.0, pix_um=4.65)
 class Scene:
     """One synthetic sequence: streak DB + particles on disk, frames/envmaps in memory."""
 
-    def __init__(self, tmpdir, H, W, n_drops, n_frames=1, cam=KITTI, seed0=3000, far_fraction=0.02):
+    def __init__(self, tmpdir, H, W, n_drops, n_frames=1, cam=KITTI, seed0=3000, far_fraction=0.02, frames=None,
+                 tex_heights=None, tex_width=None):
         self.H, self.W = H, W
         self.cam_settings = cam
-        self.tex_dir, self.norm = synthetic.write_streak_db(os.path.join(str(tmpdir), 'rainstreakdb'))
-        frames = synthetic.simulate_particles(n_frames, n_drops, W, H, cam['focal_mm'], cam['pix_um'], cam['exposure_ms'],
-                                              seed0=seed0, far_fraction=far_fraction)
+        self.tex_dir, self.norm = synthetic.write_streak_db(os.path.join(str(tmpdir), 'rainstreakdb'),
+                                                            tex_heights=tex_heights, tex_width=tex_width)
+        if frames is None:
+            frames = synthetic.simulate_particles(n_frames, n_drops, W, H, cam['focal_mm'], cam['pix_um'], cam['exposure_ms'],
+                                                  seed0=seed0, far_fraction=far_fraction)
         self.xml = synthetic.write_particles_xml(os.path.join(str(tmpdir), 'particles', 'rain', 'sim_camera0.xml'), frames)
         self.He = H
         self.We = synthetic.envmap_width(cam['focal_mm'], W)

@@ -1,0 +1,106 @@
+"""GPU tier: hand-built streaks that force the code paths random scenes rarely reach:
+integer-ratio INTER_AREA (ResizeAreaFast), the bilinear fallback of INTER_AREA when the
+streak is longer than the rotated texture, frame-border crops on every side, footprints
+entirely outside the frame, drops beyond the 10 m sphere, heavy defocus, huge textures that
+do not fit the LDS staging, and an empty drop list."""
+import numpy as np
+import pytest
+
+import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+H, W = 400, 300
+FPX = 6e-3 / 4.65e-6
+
+
+def _drop(pid, x0, y0, x1, y1, iw1, iw2, depth):
+    """Streak from image (x0,y0) to (x1,y1) in TOP-LEFT pixel coordinates; the XML carries
+    bottom-left y (the loader flips it, bad_weather.py:221-222)."""
+    X = (x0 - W / 2) * depth / FPX
+    Y = ((H - y0) - H / 2) * depth / FPX
+    return dict(pid=pid, wp1=(X, Y, -depth), wp2=(X + 0.001, Y - 0.01, -depth + 0.005), wd1=0.002, wd2=0.002,
+                ip1=(x0, H - y0), ip2=(x1, H - y1), iw1=iw1, iw2=iw2)
+
+
+def _frames():
+    d = []
+    k = 0
+    # exactly vertical -> theta = 0 -> canvas 32x320 / 32x229 ...; tw = max_width+2, th = |dy|
+    for (dy, iw) in [(160, 2.5), (80, 2.5), (40, 2.5), (320, 1.5), (64, 3.5), (20, 2.2)]:
+        d.append(_drop(k, 40 + 12 * k, 20, 40 + 12 * k, 20 + dy, iw, iw, 5.0)); k += 1
+    # longer than the texture: bilinear fallback (dst height > canvas height)
+    for (dy, dx, iw) in [(380, 0, 1.2), (350, 3, 2.4), (390, -2, 3.2)]:
+        d.append(_drop(k, 150 + 10 * k, 5, 150 + 10 * k + dx, 5 + dy, iw, iw, 4.0)); k += 1
+    # oblique small/medium streaks
+    for (dx, dy, iw) in [(7, 30, 1.5), (-9, 25, 2.7), (25, 26, 3.9), (-30, 12, 1.1), (3, 3, 1.9)]:
+        d.append(_drop(k, 100 + 9 * k, 200, 100 + 9 * k + dx, 200 + dy, iw, iw, 6.0)); k += 1
+    # Big drops, some heavily defocused (close), crossing every border
+    for (x0, y0, dx, dy, iw1, iw2, z) in [(-6, 50, 8, 60, 7.0, 9.0, 0.5), (290, 100, 14, 70, 6.0, 6.5, 0.8), (120, -20, 5, 50, 5.0, 5.5, 1.5),
+                                          (200, 380, -4, 40, 8.0, 8.0, 0.3), (60, 300, 0, 45, 4.0, 12.0, 2.5), (150, 150, 20, 5, 10.0, 4.0, 6.0)]:
+        d.append(_drop(k, x0, y0, x0 + dx, y0 + dy, iw1, iw2, z)); k += 1
+    # start outside top-left with the end inside; start beyond bottom-right with the end inside
+    d.append(_drop(k, -10, -12, 4, 6, 2.5, 2.5, 0.4)); k += 1
+    d.append(_drop(k, 310, 405, 295, 390, 1.5, 1.5, 0.6)); k += 1
+    # beyond the rendering sphere: skipped; just inside: rendered
+    d.append(_drop(k, 80, 120, 82, 140, 2.0, 2.0, 10.3)); k += 1
+    d.append(_drop(k, 90, 120, 92, 140, 2.0, 2.0, 9.95)); k += 1
+    # very close: large circle of confusion
+    d.append(_drop(k, 220, 60, 223, 110, 5.0, 6.0, 0.12)); k += 1
+    return [dict(id=0, t=2000, d=0, drops=d)]
+
+
+def _run(tmp_path, built, **kw):
+    sc = h.Scene(tmp_path, H, W, 0, frames=_frames(), **kw)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)])[0]
+    rh.close()
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=False)
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    return sc, drops, out, ref, emu
+
+
+def _check(out, ref):
+    assert np.array_equal(out['status'], ref['status'])
+    assert np.array_equal(out['mask'], ref['mask']), np.abs(out['mask'] - ref['mask']).max()
+    assert np.array_equal(out['mask_i32'], ref['mask_i32'])
+    assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1     # +-1 LSB
+
+
+def test_forced_paths_match_oracle(tmp_path, built):
+    sc, drops, out, ref, emu = _run(tmp_path, built)
+    assert len(drops) >= 24
+    assert (ref['status'] == 1).sum() >= 1 and (ref['status'] == 0).sum() >= 20          # > radius skipped, rest rendered
+    _check(out, ref)
+    _check(out, emu)
+    assert out['mask'].max() > 0
+
+
+def test_textures_too_large_for_lds(tmp_path, built):
+    """64-wide, up to 640-tall textures exceed the LDS staging: the global-memory sampler path."""
+    sc, drops, out, ref, emu = _run(tmp_path, built, tex_heights=(640, 458, 320, 228, 160), tex_width=64)
+    _check(out, ref)
+
+
+def test_empty_drop_list_is_identity(tmp_path, built):
+    sc = h.Scene(tmp_path, 64, 96, 10)
+    bg, env = sc.frame_inputs(0)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=np.zeros(0, h.hb.DROP_DTYPE))])[0]
+    rh.close()
+    assert out['mask'].max() == 0 and np.array_equal(out['rainy_bg'], bg)
+    assert np.array_equal(out['image_u8'], (np.clip(bg[..., ::-1], 0, 1) * 255).astype(np.uint8))
+
+
+def test_bad_arguments_are_errors(built):
+    rh = h.hb.RainHip(0)
+    with pytest.raises(RuntimeError):           # DB / camera not set
+        rh.render_frames([dict(bg=np.zeros((8, 8, 3)), rainy_bg=np.zeros((8, 8, 3)), env_xyY=np.zeros((8, 9, 3)),
+                               omega=np.ones((8, 9)), drops=np.zeros(0, h.hb.DROP_DTYPE))])
+    rh.close()

@@ -19,3 +19,33 @@ def test_hostemu_matches_oracle(tmp_path, H, W, N, seed, noise):
     assert np.array_equal(emu['mask_i32'], ref['mask_i32'])
     assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
     assert np.abs(emu['rainy_bg'] - ref['rainy_bg']).max() < 1e-12
+
+
+def test_hostemu_forced_paths(tmp_path):
+    """The hand-built edge-case scene of the GPU tier (integer-ratio and bilinear INTER_AREA
+    modes, border crops, skipped and heavily defocused drops), kernel arithmetic vs oracle."""
+    import ctypes
+    import test_gpu_edge_cases as e
+    sc = h.Scene(tmp_path, e.H, e.W, 0, frames=e._frames())
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=False)
+    assert np.array_equal(emu['status'], ref['status'])
+    assert np.array_equal(emu['mask'], ref['mask'])
+    assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+    # all three resize modes and both drop kinds are present in this scene
+    lib = h.hostemu()
+    n, psz = len(drops), lib.emu_sizeof_plan()
+    plans = np.zeros(n * psz, np.uint8)
+    poly = np.zeros(n * 72, np.int32)
+    npts = np.zeros(n, np.int32)
+    sizes = np.zeros(n, np.int64)
+    texels, hs, ws, offs = h.hb.pack_streak_db(sc.db.streaks_light)
+    lib.emu_plan(h._p(drops), n, ctypes.byref(sc.cam), e.H, e.W, sc.He, sc.We, h._p(hs), h._p(ws), ctypes.c_double(1.0),
+                 h._p(plans), h._p(poly), h._p(npts), h._p(sizes))
+    ints = plans.reshape(n, psz)[:, :24 * 4].copy().view(np.int32).reshape(n, 24)
+    kind, rs_mode = ints[:, 1], ints[:, 21]
+    assert set(kind) == {0, 1}
+    assert set(rs_mode[kind == 1]) == {0, 1, 2}
+    assert (npts == 24).any() or (npts == 20).all()
