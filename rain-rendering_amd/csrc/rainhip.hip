@@ -60,6 +60,11 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* means;                    // [frame][2]
   int64_t* arena_need;              // [frame]
   int32_t* overflow;                // [1]
+  int32_t* list_rot;                // [frame][drops]  drops taken by k_tile
+  int32_t* list_gen;                // [frame][drops]  drops taken by k_tile_generic
+  int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
+  int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
+  int32_t* counts;                  // [frame][4] = #rot, #gen, #blur items, #slow
 };
 
 // ---------------------------------------------------------------------------
@@ -215,19 +220,24 @@ struct BlurLayout {
 __device__ inline BlurLayout blur_layout(const DropPlan& p) {
   BlurLayout b{0, 0, 0, 0};
   if (p.r1 <= 0 || p.r1 > BR_MAX) return b;
-  // the LDS tiles carry explicit zero halos (r2 columns, r1 rows) so the filter loops are branch-free
-  int wo = p.pw, ho = p.ph;
-  for (int it = 0; it < 16; it++) {
-    const int wi = wo + 2 * p.r2, hi = ho + 2 * p.r1;
-    if (wi * hi <= BX_MAX && wi * ho <= BY_MAX) {
-      b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo == p.pw && ho == p.ph) ? 1 : 0;
-      return b;
-    }
-    if (ho >= wo && ho > 4) ho = (ho + 1) / 2;
-    else if (wo > 4) wo = (wo + 1) / 2;
-    else if (ho > 4) ho = (ho + 1) / 2;
-    else break;
+  // The LDS tiles carry explicit zero halos (r2 columns, r1 rows) so the filter loops are
+  // branch-free.  Whole tile if it fits; otherwise the output sub-tile that maximises
+  // wo*ho under (wo+2*r2)*(ho+2*r1) <= BX_MAX (halo-aware aspect), (wo+2*r2)*ho <= BY_MAX.
+  if ((p.pw + 2 * p.r2) * (p.ph + 2 * p.r1) <= BX_MAX && (p.pw + 2 * p.r2) * p.ph <= BY_MAX) {
+    b.fused = 1; b.wo = p.pw; b.ho = p.ph; b.single = 1;
+    return b;
   }
+  const double rr2 = (double)imax(p.r2, 1), rr1 = (double)p.r1;
+  int wi = (int)sqrt((double)BX_MAX * rr2 / rr1);            // ideal haloed width
+  wi = imax(imin(wi, p.pw + 2 * p.r2), 2 * p.r2 + 1);
+  int hi = BX_MAX / wi;
+  hi = imin(hi, p.ph + 2 * p.r1);
+  wi = imin(BX_MAX / hi, p.pw + 2 * p.r2);                   // give unused height back to the width
+  int wo = wi - 2 * p.r2, ho = hi - 2 * p.r1;
+  if (wo < 1 || ho < 1) return b;                            // halo alone exceeds the LDS: two-pass fallback
+  if (wi * ho > BY_MAX) ho = BY_MAX / wi;
+  if (ho < 1) return b;
+  b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo >= p.pw && ho >= p.ph) ? 1 : 0;
   return b;
 }
 // which arena buffer holds the finished alpha tile
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   const FrameDesc& fr = frames[f];
   if (i >= fr.n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
-  DropPlan& p = sc.plan[gi];
+  const DropPlan& p = sc.plan[gi];
   CompRec rec;
   rec.x0 = rec.y0 = rec.x1 = rec.y1 = 0;
   rec.ox = rec.oy = rec.pitch = rec.pad = 0;
@@ -300,7 +310,6 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     }
   }
   if (lane == 0) {
-    if (status != p.status) p.status = status;
     sc.comp[gi] = rec;
     if (fr.status) fr.status[i] = status;
   }
@@ -478,18 +487,17 @@ __device__ inline double lds_rot_sample(const uint8_t* s_tex, const double* s_lu
 __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                                       const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
                                                       const float* ctab, Scratch sc) {
-  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
-  if (i >= frames[f].n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  if (sc.sizes[gi] == 0) return;
-  const DropPlan& p = sc.plan[gi];
-  if (p.status != RR_DROP_OK) return;
-  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
-  if (tile_is_fast(p, sh, sw)) return;
+  const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
   __shared__ int2 s_adbd[NW_MAX];
   s_lut[t] = (double)t / 255.0;
+  const int n_items = sc.counts[f * 4 + 1];
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the generic list
+  const int64_t gi = (int64_t)f * max_drops + sc.list_gen[(int64_t)f * max_drops + item];
+  const DropPlan& p = sc.plan[gi];
+  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  __syncthreads();
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
   const bool tex_fits = (sh + 4) * P <= TEX_LDS;
@@ -541,6 +549,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
       A0[(int64_t)(y + p.shift) * p.pw + (x + p.shift)] = raw_tile_pixel(p, tx, ctab, x, y);
     }
   }
+  }
 }
 
 __device__ inline void wave_lds_sync() {
@@ -553,10 +562,7 @@ __device__ inline void wave_lds_sync() {
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
                                               Scratch sc, int dbg) {
-  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (i >= frames[f].n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  if (sc.sizes[gi] == 0) return;
+  const int f = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   __shared__ DropPlan sp;
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
@@ -565,17 +571,19 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ double s_buf[BUF_MAX];
   __shared__ double s_can[4][CAN_W];
   __shared__ int4 s_row[4][ROWS_W];
+  s_lut[t] = (double)t / 255.0;
+  const int n_items = sc.counts[f * 4 + 0];
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the rot-fast list
+  const int64_t gi = (int64_t)f * max_drops + sc.list_rot[(int64_t)f * max_drops + item];
+  __syncthreads();
   {
     const int32_t* src = reinterpret_cast<const int32_t*>(&sc.plan[gi]);
     int32_t* dst = reinterpret_cast<int32_t*>(&sp);
     for (int k = t; k < (int)(sizeof(DropPlan) / 4); k += 256) dst[k] = src[k];
   }
-  s_lut[t] = (double)t / 255.0;
   __syncthreads();
   const DropPlan& p = sp;
-  if (p.status != RR_DROP_OK) return;
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
-  if (!tile_is_fast(p, sh, sw)) return;
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
   if (!(dbg & 8)) load_tex_padded(s_tex, gtex, sh, sw);
@@ -677,6 +685,74 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     }
     __syncthreads();
   }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// work lists: which kernel takes which drop, blur work split into items of sub-tiles
+// ---------------------------------------------------------------------------
+constexpr int BLUR_ITEMS_PER_DROP = 8;
+
+__device__ inline int blur_subtiles(const DropPlan& p, const BlurLayout& L) {
+  return ((p.pw + L.wo - 1) / L.wo) * ((p.ph + L.ho - 1) / L.ho);
+}
+
+__global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max_drops, const int32_t* tex_h, const int32_t* tex_w,
+                                                Scratch sc) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int n = frames[f].n_drops;
+  const int chunk = (n + 1023) / 1024;
+  const int i0 = t * chunk, i1 = min(i0 + chunk, n);
+  const int64_t base = (int64_t)f * max_drops;
+  // class: 0 none, 1 rot-fast, 2 generic; blur: #items (fused) or -1 (slow path)
+  int c[4] = {0, 0, 0, 0};
+  for (int i = i0; i < i1; i++) {
+    const DropPlan& p = sc.plan[base + i];
+    if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
+    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) c[0]++; else c[1]++;
+    if (p.r1 > 0) {
+      const BlurLayout L = blur_layout(p);
+      if (L.fused) c[2] += imin(blur_subtiles(p, L), BLUR_ITEMS_PER_DROP); else c[3]++;
+    }
+  }
+  __shared__ int sh[1024][4];
+  for (int k = 0; k < 4; k++) sh[t][k] = c[k];
+  __syncthreads();
+  for (int ofs = 1; ofs < 1024; ofs <<= 1) {
+    int v[4] = {0, 0, 0, 0};
+    if (t >= ofs)
+      for (int k = 0; k < 4; k++) v[k] = sh[t - ofs][k];
+    __syncthreads();
+    for (int k = 0; k < 4; k++) sh[t][k] += v[k];
+    __syncthreads();
+  }
+  int o[4];
+  for (int k = 0; k < 4; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
+  int32_t* lrot = sc.list_rot + base;
+  int32_t* lgen = sc.list_gen + base;
+  int32_t* lslow = sc.list_slow + base;
+  int4* items = sc.blur_items + base * BLUR_ITEMS_PER_DROP;
+  for (int i = i0; i < i1; i++) {
+    const DropPlan& p = sc.plan[base + i];
+    if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
+    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) lrot[o[0]++] = i; else lgen[o[1]++] = i;
+    if (p.r1 > 0) {
+      const BlurLayout L = blur_layout(p);
+      if (L.fused) {
+        const int ns = blur_subtiles(p, L);
+        const int ni = imin(ns, BLUR_ITEMS_PER_DROP);
+        const int per = (ns + ni - 1) / ni;
+        for (int k = 0; k < ni; k++) {
+          const int st0 = k * per;
+          items[o[2]++] = make_int4(i, st0, imax(imin(per, ns - st0), 0), 0);
+        }
+      } else {
+        lslow[o[3]++] = i;
+      }
+    }
+  }
+  if (t == 1023)
+    for (int k = 0; k < 4; k++) sc.counts[f * 4 + k] = sh[1023][k];
 }
 
 // gaussian half-table: hw[k] = w[k], k = 0..r (centre at r), sequential normalisation
@@ -699,29 +775,39 @@ __device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
 // ---------------------------------------------------------------------------
 // fused defocus blur: both axes of the separable filter through LDS
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int max_drops, Scratch sc) {
-  const int f = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
-  if (i >= frames[f].n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  const DropPlan& p = sc.plan[gi];
-  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || p.r1 == 0) return;
-  const BlurLayout L = blur_layout(p);
-  if (!L.fused) return;
+__global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int max_drops, Scratch sc, int dbg) {
+  const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double hw1[BR_MAX + 1], hw2[BR_MAX + 1];
   __shared__ double X[BX_MAX], Y[BY_MAX];
+  const int n_items = sc.counts[f * 4 + 2];
+  const int4* items = sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP;
+  int cur = -1;
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // grid-stride over (drop, sub-tile range) items
+  const int4 item = items[it];
+  const int64_t gi = (int64_t)f * max_drops + item.x;
+  const DropPlan& p = sc.plan[gi];
+  const BlurLayout L = blur_layout(p);
   const int r1 = p.r1, r2 = p.r2, pw = p.pw, ph = p.ph;
-  gauss_half_table(p.sig1, r1, hw1);
-  if (r2 > 0) gauss_half_table(p.sig2, r2, hw2);
+  if (cur != item.x && !(dbg & 256)) {                 // the weight tables depend on the drop only
+    __syncthreads();
+    gauss_half_table(p.sig1, r1, hw1);
+    if (r2 > 0) gauss_half_table(p.sig2, r2, hw2);
+    cur = item.x;
+  }
   const double* src = sc.arena + p.a0_off;
   double* dst = sc.arena + (L.single ? p.a0_off : p.a1_off);
-  for (int y0 = 0; y0 < ph; y0 += L.ho) {
-    const int ho = imin(L.ho, ph - y0);
-    for (int x0 = 0; x0 < pw; x0 += L.wo) {
+  const int ntx = (pw + L.wo - 1) / L.wo, nty = (ph + L.ho - 1) / L.ho;
+  (void)nty;
+  for (int st = item.y; st < item.y + item.z; st++) {
+    const int sty = st / ntx, stx = st - sty * ntx;
+    const int y0 = sty * L.ho, x0 = stx * L.wo;
+    {
+      const int ho = imin(L.ho, ph - y0);
       const int wo = imin(L.wo, pw - x0);
       const int wi = wo + 2 * r2, hi = ho + 2 * r1;       // LDS tile with zero halos
       const float inv_wi = 1.0f / (float)wi, inv_wo = 1.0f / (float)wo;
       // haloed tile -> LDS; eight independent global loads in flight per thread
-      const int nx = wi * hi;
+      const int nx = (dbg & 512) ? 0 : wi * hi;
       for (int base = t; base < nx; base += 2048) {
         double v[8];
 #pragma unroll
@@ -737,7 +823,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       }
       __syncthreads();
       // axis 0 (rows, sigma = c): symmetric correlate1d; four independent outputs per thread
-      const int nv = wi * ho;
+      const int nv = (dbg & 1024) ? 0 : wi * ho;
       for (int base = t; base < nv; base += 1024) {
         double acc[4];
         const double* col[4];
@@ -759,7 +845,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       }
       __syncthreads();
       // axis 1 (columns, sigma = c/2)
-      const int nh = wo * ho;
+      const int nh = (dbg & 2048) ? 0 : wo * ho;
       for (int base = t; base < nh; base += 1024) {
         double acc[4];
         const double* row[4];
@@ -784,25 +870,28 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       __syncthreads();
     }
   }
+  }
 }
 
 template <int AXIS>
 __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_drops, Scratch sc) {
-  const int f = blockIdx.y, i = blockIdx.x;
-  if (i >= frames[f].n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  const DropPlan& p = sc.plan[gi];
-  const int r = AXIS == 0 ? p.r1 : p.r2;
-  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || r == 0) return;
-  if (blur_layout(p).fused) return;
+  const int f = blockIdx.y;
   __shared__ double hw[MAX_R + 1];
-  gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
-  const double* src = sc.arena + (AXIS == 0 ? p.a0_off : p.a1_off);
-  double* dst = sc.arena + (AXIS == 0 ? p.a1_off : p.a0_off);
-  const int n = p.pw * p.ph;
-  for (int idx = threadIdx.x; idx < n; idx += 256) {
-    int y = idx / p.pw, x = idx - y * p.pw;
-    dst[idx] = AXIS == 0 ? blur_axis0(src, p.pw, p.ph, x, y, hw, r) : blur_axis1(src, p.pw, p.ph, x, y, hw, r);
+  const int n_items = sc.counts[f * 4 + 3];
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // blurred drops the fused kernel cannot take
+    const int64_t gi = (int64_t)f * max_drops + sc.list_slow[(int64_t)f * max_drops + it];
+    const DropPlan& p = sc.plan[gi];
+    const int r = AXIS == 0 ? p.r1 : p.r2;
+    __syncthreads();
+    if (r == 0) continue;
+    gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
+    const double* src = sc.arena + (AXIS == 0 ? p.a0_off : p.a1_off);
+    double* dst = sc.arena + (AXIS == 0 ? p.a1_off : p.a0_off);
+    const int n = p.pw * p.ph;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+      int y = idx / p.pw, x = idx - y * p.pw;
+      dst[idx] = AXIS == 0 ? blur_axis0(src, p.pw, p.ph, x, y, hw, r) : blur_axis1(src, p.pw, p.ph, x, y, hw, r);
+    }
   }
 }
 
@@ -955,6 +1044,9 @@ struct ProfEntry {
 struct rr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t s_col = nullptr, s_gen = nullptr;     // side streams: colour chain, generic tiles
+  hipEvent_t ev_start = nullptr, ev_scan = nullptr, ev_col = nullptr, ev_gen = nullptr;
+  bool serial = false;              // RAINHIP_SERIAL=1: everything on the caller's stream
   std::string err;
   // streak DB
   uint8_t* d_tex = nullptr;
@@ -1091,6 +1183,11 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.poly, fd * 2 * POLY_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.npts, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.sizes, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.list_rot, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.list_gen, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.list_slow, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.blur_items, fd * 8))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fconst, (size_t)F * 2))) return rc;
     const int ntiles = ((dm.W + TILE - 1) / TILE) * ((dm.H + TILE - 1) / TILE);
@@ -1180,13 +1277,22 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
   const int ntiles = tiles_x * tiles_y;
   Scratch sc = ctx->sc;
-  {
-    ProfScope ps(ctx, s, "k_env_prefix");
-    hipLaunchKernelGGL(k_env_prefix, dim3(dm.He, n), dim3(256), 0, s, ctx->d_frames, dm, sc.prefix);
+  // Three in-order streams: `s` (caller's) carries plan -> scan -> tile -> blur -> composite;
+  // the colour chain (env prefix sums, FOV integration) and the generic tile kernel only meet
+  // it again at the blur / compositor, so they run beside it on side streams.
+  hipStream_t sc_col = ctx->serial ? s : ctx->s_col, sc_gen = ctx->serial ? s : ctx->s_gen;
+  if (!ctx->serial) {
+    HIPCHK(hipEventRecord(ctx->ev_start, s));
+    HIPCHK(hipStreamWaitEvent(sc_col, ctx->ev_start, 0));
+    HIPCHK(hipStreamWaitEvent(sc_gen, ctx->ev_start, 0));
   }
   {
-    ProfScope ps(ctx, s, "k_env_consts");
-    hipLaunchKernelGGL(k_env_consts, dim3(n), dim3(256), 0, s, dm, sc.prefix, sc.fconst);
+    ProfScope ps(ctx, sc_col, "k_env_prefix");
+    hipLaunchKernelGGL(k_env_prefix, dim3(dm.He, n), dim3(256), 0, sc_col, ctx->d_frames, dm, sc.prefix);
+  }
+  {
+    ProfScope ps(ctx, sc_col, "k_env_consts");
+    hipLaunchKernelGGL(k_env_consts, dim3(n), dim3(256), 0, sc_col, dm, sc.prefix, sc.fconst);
   }
   if (max_drops > 0) {
     {
@@ -1199,36 +1305,54 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       hipLaunchKernelGGL(k_scan, dim3(n), dim3(1024), 0, s, ctx->d_frames, D, ctx->arena_cap, sc);
     }
     {
-      ProfScope ps(ctx, s, "k_colour");
-      hipLaunchKernelGGL(k_colour, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
+      ProfScope ps(ctx, s, "k_lists");
+      hipLaunchKernelGGL(k_lists, dim3(n), dim3(1024), 0, s, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
+    }
+    if (!ctx->serial) {
+      HIPCHK(hipEventRecord(ctx->ev_scan, s));
+      HIPCHK(hipStreamWaitEvent(sc_col, ctx->ev_scan, 0));
+      HIPCHK(hipStreamWaitEvent(sc_gen, ctx->ev_scan, 0));
     }
     {
+      ProfScope ps(ctx, sc_col, "k_colour");
+      hipLaunchKernelGGL(k_colour, dim3((max_drops + 3) / 4, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc);
+    }
+    if (ctx->simple_tile) {
       ProfScope ps(ctx, s, "k_tile");
-      if (ctx->simple_tile) {
-        hipLaunchKernelGGL(k_tile_simple, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
-                           ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
-      } else {
+      hipLaunchKernelGGL(k_tile_simple, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
+                         ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
+    } else {
+      {
+        ProfScope ps(ctx, sc_gen, "k_tile_generic");
+        hipLaunchKernelGGL(k_tile_generic, dim3((max_drops + 3) / 4, n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex,
+                           ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
+      }
+      {
+        ProfScope ps(ctx, s, "k_tile");
         hipLaunchKernelGGL(k_tile, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
                            ctx->d_tex_off, sc, ctx->tile_dbg);
       }
     }
-    if (!ctx->simple_tile) {
-      ProfScope ps(ctx, s, "k_tile_generic");
-      hipLaunchKernelGGL(k_tile_generic, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
-                         ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
+    if (!ctx->serial) {
+      HIPCHK(hipEventRecord(ctx->ev_gen, sc_gen));
+      HIPCHK(hipStreamWaitEvent(s, ctx->ev_gen, 0));
     }
     {
       ProfScope ps(ctx, s, "k_blur_fused");
-      hipLaunchKernelGGL(k_blur_fused, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur_fused, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc, ctx->tile_dbg);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
-      hipLaunchKernelGGL(k_blur<0>, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur<0>, dim3(64, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_cols");
-      hipLaunchKernelGGL(k_blur<1>, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur<1>, dim3(64, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
+  }
+  if (!ctx->serial) {
+    HIPCHK(hipEventRecord(ctx->ev_col, sc_col));
+    HIPCHK(hipStreamWaitEvent(s, ctx->ev_col, 0));
   }
   {
     ProfScope ps(ctx, s, "k_composite");
@@ -1293,6 +1417,19 @@ int rr_create(rr_ctx** out, int device) {
     delete ctx;
     return RR_E_HIP;
   }
+  {
+    const char* e = getenv("RAINHIP_SERIAL");
+    ctx->serial = e && e[0] == '1';
+  }
+  if (hipStreamCreateWithFlags(&ctx->s_col, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->s_gen, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_scan, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_col, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming) != hipSuccess) {
+    delete ctx;
+    return RR_E_HIP;
+  }
   float tab[128];
   build_cubic_tab(tab);
   if (hipMalloc((void**)&ctx->d_ctab, sizeof(tab)) != hipSuccess ||
@@ -1318,6 +1455,11 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.poly);
   hipFree(ctx->sc.npts);
   hipFree(ctx->sc.sizes);
+  hipFree(ctx->sc.list_rot);
+  hipFree(ctx->sc.list_gen);
+  hipFree(ctx->sc.list_slow);
+  hipFree(ctx->sc.blur_items);
+  hipFree(ctx->sc.counts);
   hipFree(ctx->sc.prefix);
   hipFree(ctx->sc.fconst);
   hipFree(ctx->sc.arena);
@@ -1342,6 +1484,12 @@ int rr_destroy(rr_ctx* ctx) {
     hipEventDestroy(pe.b);
   }
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_scan) hipEventDestroy(ctx->ev_scan);
+  if (ctx->ev_col) hipEventDestroy(ctx->ev_col);
+  if (ctx->ev_gen) hipEventDestroy(ctx->ev_gen);
+  if (ctx->s_col) hipStreamDestroy(ctx->s_col);
+  if (ctx->s_gen) hipStreamDestroy(ctx->s_gen);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return RR_OK;
