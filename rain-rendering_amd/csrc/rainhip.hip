@@ -64,7 +64,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* list_gen;                // [frame][drops]  drops taken by k_tile_generic
   int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
   int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
-  int32_t* counts;                  // [frame][4] = #rot, #gen, #blur items, #slow
+  int32_t* list_small;              // [frame][drops]  blurred drops handled one wave each (k_blur_small)
+  int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small
 };
 
 // ---------------------------------------------------------------------------
@@ -143,70 +144,6 @@ __global__ __launch_bounds__(256) void k_env_consts(Dims dm, const double* prefi
   }
 }
 
-// ---------------------------------------------------------------------------
-// per-drop plan
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, rr_camera cam, const int32_t* tex_h,
-                                              const int32_t* tex_w, int max_drops, Scratch sc) {
-  const int f = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const FrameDesc& fr = frames[f];
-  if (i >= fr.n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  rr_drop d = fr.drops[i];
-  DropPlan p;
-  int64_t size = 0;
-  plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, p, size);
-  int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
-  int32_t* py = px + POLY_STRIDE;
-  // the FOV polygon is evaluated for every drop: in the reference its failure is raised
-  // before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
-  int npts = fov_polygon(d, cam, dm.He, dm.We, px, py);
-  if (p.status != RR_DROP_OK || npts == 0) size = 0;
-  sc.npts[gi] = npts;
-  sc.sizes[gi] = size;
-  sc.plan[gi] = p;
-}
-
-// one block per frame: exclusive scan of arena sizes
-__global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_drops, int64_t arena_cap, Scratch sc) {
-  const int f = blockIdx.x, t = threadIdx.x;
-  const int n = frames[f].n_drops;
-  const int chunk = (n + 1023) / 1024;
-  const int i0 = t * chunk, i1 = min(i0 + chunk, n);
-  const int64_t base = (int64_t)f * max_drops;
-  int64_t s = 0;
-  for (int i = i0; i < i1; i++) s += sc.sizes[base + i];
-  __shared__ int64_t sh[1024];
-  sh[t] = s;
-  __syncthreads();
-  for (int ofs = 1; ofs < 1024; ofs <<= 1) {
-    int64_t v = (t >= ofs) ? sh[t - ofs] : 0;
-    __syncthreads();
-    sh[t] += v;
-    __syncthreads();
-  }
-  int64_t run = (t == 0) ? 0 : sh[t - 1];
-  const int64_t frame_base = (int64_t)f * arena_cap;
-  for (int i = i0; i < i1; i++) {
-    DropPlan& p = sc.plan[base + i];
-    int64_t sz = sc.sizes[base + i];
-    int64_t area = (int64_t)p.pw * p.ph;
-    if (run + sz > arena_cap) {
-      // does not fit: never touch the arena for this drop; host regrows and re-runs
-      sc.sizes[base + i] = 0;
-    } else {
-      p.a0_off = frame_base + run;
-      p.a1_off = frame_base + run + area;
-    }
-    run += sz;
-  }
-  if (t == 1023) {
-    sc.arena_need[f] = sh[1023];
-    if (sh[1023] > arena_cap) atomicExch(sc.overflow, 1);
-  }
-}
-
 // blur work layout (needed by k_colour to know where the finished tile will live)
 constexpr int BX_MAX = 3072;        // doubles: input sub-tile incl. halo
 constexpr int BY_MAX = 2048;        // doubles: after the row (axis 0) pass
@@ -240,12 +177,82 @@ __device__ inline BlurLayout blur_layout(const DropPlan& p) {
   b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo >= p.pw && ho >= p.ph) ? 1 : 0;
   return b;
 }
-// which arena buffer holds the finished alpha tile
-__device__ inline int blur_final_buf(const DropPlan& p) {
-  if (p.r1 <= 0) return 0;
-  const BlurLayout b = blur_layout(p);
-  if (b.fused) return b.single ? 0 : 1;
-  return p.r2 == 0 ? 1 : 0;
+// small blurred tiles are filtered by one wave each, in place (k_blur_small)
+constexpr int BS_X = 768;           // doubles per wave: haloed input tile
+constexpr int BS_Y = 512;           // doubles per wave: after the row pass (halo columns kept)
+
+__device__ inline bool blur_is_small(const DropPlan& p) {
+  return p.r1 > 0 && p.r1 <= 31 && (p.pw + 2 * p.r2) * (p.ph + 2 * p.r1) <= BS_X && (p.pw + 2 * p.r2) * p.ph <= BS_Y;
+}
+
+// blurred drops neither k_blur_small nor k_blur_fused can take (radius > BR_MAX): two global passes
+// through one extra padded scratch tile
+__device__ inline bool blur_is_slow(const DropPlan& p) {
+  return p.r1 > 0 && !blur_is_small(p) && !blur_layout(p).fused;
+}
+
+// ---------------------------------------------------------------------------
+// per-drop plan
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, rr_camera cam, const int32_t* tex_h,
+                                              const int32_t* tex_w, int max_drops, Scratch sc) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const FrameDesc& fr = frames[f];
+  if (i >= fr.n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  rr_drop d = fr.drops[i];
+  DropPlan p;
+  int64_t size = 0;
+  plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, p, size);
+  int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
+  int32_t* py = px + POLY_STRIDE;
+  // the FOV polygon is evaluated for every drop: in the reference its failure is raised
+  // before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
+  int npts = fov_polygon(d, cam, dm.He, dm.We, px, py);
+  if (p.status != RR_DROP_OK || npts == 0) size = 0;
+  if (size > 0 && blur_is_slow(p)) size += (int64_t)p.pw * p.ph;
+  sc.npts[gi] = npts;
+  sc.sizes[gi] = size;
+  sc.plan[gi] = p;
+}
+
+// one block per frame: exclusive scan of arena sizes
+__global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_drops, int64_t arena_cap, Scratch sc) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int n = frames[f].n_drops;
+  const int chunk = (n + 1023) / 1024;
+  const int i0 = t * chunk, i1 = min(i0 + chunk, n);
+  const int64_t base = (int64_t)f * max_drops;
+  int64_t s = 0;
+  for (int i = i0; i < i1; i++) s += sc.sizes[base + i];
+  __shared__ int64_t sh[1024];
+  sh[t] = s;
+  __syncthreads();
+  for (int ofs = 1; ofs < 1024; ofs <<= 1) {
+    int64_t v = (t >= ofs) ? sh[t - ofs] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int64_t run = (t == 0) ? 0 : sh[t - 1];
+  const int64_t frame_base = (int64_t)f * arena_cap;
+  for (int i = i0; i < i1; i++) {
+    DropPlan& p = sc.plan[base + i];
+    int64_t sz = sc.sizes[base + i];
+    if (run + sz > arena_cap) {
+      // does not fit: never touch the arena for this drop; host regrows and re-runs
+      sc.sizes[base + i] = 0;
+    } else {
+      p.a0_off = frame_base + run;
+      p.a1_off = frame_base + run + (int64_t)p.tw * p.th;
+    }
+    run += sz;
+  }
+  if (t == 1023) {
+    sc.arena_need[f] = sh[1023];
+    if (sh[1023] > arena_cap) atomicExch(sc.overflow, 1);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -297,14 +304,27 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     if (!any) status = RR_DROP_EMPTY_FOV;
     if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
       colour_from_sums(S, sc.fconst[f * 2 + 0], sc.fconst[f * 2 + 1], rec.K);
-      rec.x0 = p.vis_x0;
-      rec.y0 = p.vis_y0;
-      rec.x1 = p.vis_x0 + p.vis_w;
-      rec.y1 = p.vis_y0 + p.vis_h;
-      rec.ox = p.crop_x - p.vis_x0;
-      rec.oy = p.crop_y - p.vis_y0;
-      rec.pitch = p.pw;
-      rec.off = blur_final_buf(p) ? p.a1_off : p.a0_off;
+      if (p.r1 > 0) {                  // finished padded tile written by the blur kernels
+        rec.x0 = p.vis_x0;
+        rec.y0 = p.vis_y0;
+        rec.x1 = p.vis_x0 + p.vis_w;
+        rec.y1 = p.vis_y0 + p.vis_h;
+        rec.ox = p.crop_x - p.vis_x0;
+        rec.oy = p.crop_y - p.vis_y0;
+        rec.pitch = p.pw;
+        rec.off = p.a1_off;
+      } else {                         // no blur: the pad is exact zeros (a no-op in the blend); read the raw tile
+        const int rx0 = p.vis_x0 - p.crop_x + p.shift, ry0 = p.vis_y0 - p.crop_y + p.shift;   // frame position of raw (0,0)
+        rec.x0 = imax(p.vis_x0, rx0);
+        rec.y0 = imax(p.vis_y0, ry0);
+        rec.x1 = imin(p.vis_x0 + p.vis_w, rx0 + p.tw);
+        rec.y1 = imin(p.vis_y0 + p.vis_h, ry0 + p.th);
+        if (rec.x1 <= rec.x0 || rec.y1 <= rec.y0) { rec.x0 = rec.y0 = rec.x1 = rec.y1 = 0; }
+        rec.ox = -rx0;
+        rec.oy = -ry0;
+        rec.pitch = p.tw;
+        rec.off = p.a0_off;
+      }
       rec.tau_one = p.tau_one;
       rec.g = p.g;
     }
@@ -330,13 +350,10 @@ __global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, in
   if (p.status != RR_DROP_OK || sc.sizes[gi] == 0) return;
   TexGlobal tx{texels + tex_off[p.tex], tex_h[p.tex], tex_w[p.tex]};
   double* A0 = sc.arena + p.a0_off;
-  const int n = p.pw * p.ph;
+  const int n = p.tw * p.th;
   for (int idx = threadIdx.x; idx < n; idx += 256) {
-    int y = idx / p.pw, x = idx - y * p.pw;
-    int rx = x - p.shift, ry = y - p.shift;
-    double v = 0.0;
-    if (rx >= 0 && rx < p.tw && ry >= 0 && ry < p.th) v = raw_tile_pixel(p, tx, ctab, rx, ry);
-    A0[idx] = v;
+    int y = idx / p.tw, x = idx - y * p.tw;
+    A0[idx] = raw_tile_pixel(p, tx, ctab, x, y);
   }
 }
 
@@ -416,17 +433,6 @@ __device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
          rows_per_dy * p.tw <= BUF_MAX && tile_coords_safe(p);
 }
 
-// zero the defocus pad of the raw tile
-__device__ inline void zero_pad(const DropPlan& p, double* A0) {
-  if (p.shift <= 0) return;
-  const int n = p.pw * p.ph;
-  for (int idx = threadIdx.x; idx < n; idx += 256) {
-    int y = idx / p.pw, x = idx - y * p.pw;
-    int rx = x - p.shift, ry = y - p.shift;
-    if (!(rx >= 0 && rx < p.tw && ry >= 0 && ry < p.th)) A0[idx] = 0.0;
-  }
-}
-
 // texture -> LDS with a 2-texel zero border (pitch sw+4).  Border texels are zeroed directly,
 // the interior is copied with independent dword loads (textures are 16-byte aligned by
 // pack_streak_db; unaligned bases fall back to byte loads).  Caller syncs afterwards.
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
   __shared__ int2 s_adbd[NW_MAX];
   s_lut[t] = (double)t / 255.0;
-  const int n_items = sc.counts[f * 4 + 1];
+  const int n_items = sc.counts[f * 8 + 1];
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the generic list
   const int64_t gi = (int64_t)f * max_drops + sc.list_gen[(int64_t)f * max_drops + item];
   const DropPlan& p = sc.plan[gi];
@@ -502,8 +508,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   const int P = sw + 4;
   const bool tex_fits = (sh + 4) * P <= TEX_LDS;
   if (tex_fits) load_tex_padded(s_tex, gtex, sh, sw);
-  double* A0 = sc.arena + p.a0_off;
-  zero_pad(p, A0);
+  double* A0 = sc.arena + p.a0_off;      // raw tile, pitch tw
   // integer-ratio INTER_AREA (ResizeAreaFast): the per-pixel chain is sequential by definition;
   // keep it short with the LDS fixed-point sampler
   const bool area_fast = tex_fits && p.kind == KIND_ROT && p.rs_mode == RS_AREA_FAST && p.nW <= NW_MAX && tile_coords_safe(p);
@@ -534,19 +539,19 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
           }
         }
       }
-      A0[(int64_t)(dy + p.shift) * p.pw + (dx + p.shift)] = clip01(sum * (double)scale);
+      A0[dy * p.tw + dx] = clip01(sum * (double)scale);
     }
   } else if (tex_fits) {
     TexLutPad tx{s_tex, s_lut, sh, sw};
     for (int idx = t; idx < n; idx += 256) {
       int y = idx / p.tw, x = idx - y * p.tw;
-      A0[(int64_t)(y + p.shift) * p.pw + (x + p.shift)] = raw_tile_pixel(p, tx, ctab, x, y);
+      A0[idx] = raw_tile_pixel(p, tx, ctab, x, y);
     }
   } else {
     TexLut tx{gtex, s_lut, sh, sw};
     for (int idx = t; idx < n; idx += 256) {
       int y = idx / p.tw, x = idx - y * p.tw;
-      A0[(int64_t)(y + p.shift) * p.pw + (x + p.shift)] = raw_tile_pixel(p, tx, ctab, x, y);
+      A0[idx] = raw_tile_pixel(p, tx, ctab, x, y);
     }
   }
   }
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ double s_can[4][CAN_W];
   __shared__ int4 s_row[4][ROWS_W];
   s_lut[t] = (double)t / 255.0;
-  const int n_items = sc.counts[f * 4 + 0];
+  const int n_items = sc.counts[f * 8 + 0];
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the rot-fast list
   const int64_t gi = (int64_t)f * max_drops + sc.list_rot[(int64_t)f * max_drops + item];
   __syncthreads();
@@ -588,8 +593,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   const int P = sw + 4;
   if (!(dbg & 8)) load_tex_padded(s_tex, gtex, sh, sw);
   double* A0 = sc.arena + p.a0_off;
-  const int pw = p.pw, shift = p.shift, tw = p.tw, th = p.th;
-  zero_pad(p, A0);
+  const int tw = p.tw, th = p.th;
   const double sy_scale = p.scale_y;
   for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   for (int dx = t; dx < tw; dx += 256) s_ax[dx] = area_span(p.nW, p.scale_x, dx);
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
         double v = (double)ay.a_r * s_buf[(ay.s2 - lo) * tw + dx];
         acc = first ? v : acc + v;
       }
-      A0[(int64_t)(dy + shift) * pw + (dx + shift)] = clip01(acc);
+      A0[dy * tw + dx] = clip01(acc);
     }
     __syncthreads();
   }
@@ -704,39 +708,41 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   const int chunk = (n + 1023) / 1024;
   const int i0 = t * chunk, i1 = min(i0 + chunk, n);
   const int64_t base = (int64_t)f * max_drops;
-  // class: 0 none, 1 rot-fast, 2 generic; blur: #items (fused) or -1 (slow path)
-  int c[4] = {0, 0, 0, 0};
+  int c[5] = {0, 0, 0, 0, 0};       // #rot-fast, #generic, #fused blur items, #slow blur drops, #small blur drops
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) c[0]++; else c[1]++;
     if (p.r1 > 0) {
+      if (blur_is_small(p)) { c[4]++; continue; }
       const BlurLayout L = blur_layout(p);
       if (L.fused) c[2] += imin(blur_subtiles(p, L), BLUR_ITEMS_PER_DROP); else c[3]++;
     }
   }
-  __shared__ int sh[1024][4];
-  for (int k = 0; k < 4; k++) sh[t][k] = c[k];
+  __shared__ int sh[1024][5];
+  for (int k = 0; k < 5; k++) sh[t][k] = c[k];
   __syncthreads();
   for (int ofs = 1; ofs < 1024; ofs <<= 1) {
-    int v[4] = {0, 0, 0, 0};
+    int v[5] = {0, 0, 0, 0, 0};
     if (t >= ofs)
-      for (int k = 0; k < 4; k++) v[k] = sh[t - ofs][k];
+      for (int k = 0; k < 5; k++) v[k] = sh[t - ofs][k];
     __syncthreads();
-    for (int k = 0; k < 4; k++) sh[t][k] += v[k];
+    for (int k = 0; k < 5; k++) sh[t][k] += v[k];
     __syncthreads();
   }
-  int o[4];
-  for (int k = 0; k < 4; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
+  int o[5];
+  for (int k = 0; k < 5; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
   int32_t* lrot = sc.list_rot + base;
   int32_t* lgen = sc.list_gen + base;
   int32_t* lslow = sc.list_slow + base;
+  int32_t* lsmall = sc.list_small + base;
   int4* items = sc.blur_items + base * BLUR_ITEMS_PER_DROP;
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) lrot[o[0]++] = i; else lgen[o[1]++] = i;
     if (p.r1 > 0) {
+      if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
       const BlurLayout L = blur_layout(p);
       if (L.fused) {
         const int ns = blur_subtiles(p, L);
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     }
   }
   if (t == 1023)
-    for (int k = 0; k < 4; k++) sc.counts[f * 4 + k] = sh[1023][k];
+    for (int k = 0; k < 5; k++) sc.counts[f * 8 + k] = sh[1023][k];
 }
 
 // gaussian half-table: hw[k] = w[k], k = 0..r (centre at r), sequential normalisation
@@ -772,6 +778,23 @@ __device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
   __syncthreads();
 }
 
+// Wave-level Gaussian half-table for r <= 63: lane l holds phi(l); the normalisation sum runs
+// in the oracle's order (x = -r..r, left to right) on values fetched with v_readlane, so no
+// LDS round trips and no block barrier are involved.  hw[k] = w[k], k = 0..r (centre at r).
+__device__ inline double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline void gauss_half_table_wave(double sigma, int r, double* hw) {
+  const int lane = threadIdx.x & 63;
+  const double ph = (lane <= r) ? gauss_phi(sigma, lane) : 0.0;
+  double tot = 0.0;
+  for (int x = -r; x <= r; x++) tot = tot + readlane_f64(ph, x < 0 ? -x : x);
+  if (lane <= r) hw[r - lane] = ph / tot;
+}
+
 // ---------------------------------------------------------------------------
 // fused defocus blur: both axes of the separable filter through LDS
 // ---------------------------------------------------------------------------
@@ -779,7 +802,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double hw1[BR_MAX + 1], hw2[BR_MAX + 1];
   __shared__ double X[BX_MAX], Y[BY_MAX];
-  const int n_items = sc.counts[f * 4 + 2];
+  const int n_items = sc.counts[f * 8 + 2];
   const int4* items = sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP;
   int cur = -1;
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // grid-stride over (drop, sub-tile range) items
@@ -790,12 +813,13 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const int r1 = p.r1, r2 = p.r2, pw = p.pw, ph = p.ph;
   if (cur != item.x && !(dbg & 256)) {                 // the weight tables depend on the drop only
     __syncthreads();
-    gauss_half_table(p.sig1, r1, hw1);
-    if (r2 > 0) gauss_half_table(p.sig2, r2, hw2);
-    cur = item.x;
+    if ((t >> 6) == 0) gauss_half_table_wave(p.sig1, r1, hw1);
+    if ((t >> 6) == 1 && r2 > 0) gauss_half_table_wave(p.sig2, r2, hw2);
+    cur = item.x;                      // (the barrier after the tile load publishes the tables)
   }
-  const double* src = sc.arena + p.a0_off;
-  double* dst = sc.arena + (L.single ? p.a0_off : p.a1_off);
+  const double* src = sc.arena + p.a0_off;          // raw tile (tw x th); the pad is implicit zeros
+  double* dst = sc.arena + p.a1_off;                // finished padded tile
+  const int shift = p.shift, tw = p.tw, th = p.th;
   const int ntx = (pw + L.wo - 1) / L.wo, nty = (ph + L.ho - 1) / L.ho;
   (void)nty;
   for (int st = item.y; st < item.y + item.z; st++) {
@@ -814,8 +838,8 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
         for (int k = 0; k < 8; k++) {
           const int idx = base + 256 * k;
           const int yy = (int)(((float)idx + 0.5f) * inv_wi), xx = idx - yy * wi;
-          const int y = y0 - r1 + yy, x = x0 - r2 + xx;
-          v[k] = (idx < nx && y >= 0 && y < ph && x >= 0 && x < pw) ? src[(int64_t)y * pw + x] : 0.0;
+          const int y = y0 - r1 + yy - shift, x = x0 - r2 + xx - shift;      // raw-tile coordinates
+          v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++)
@@ -873,24 +897,131 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   }
 }
 
+// Small blurred tiles (haloed tile <= BS_X doubles, which is most of them): one WAVE per drop,
+// wave-private LDS, no block barrier; the filter weights stay in registers and are handed to
+// the fold loop with v_readlane.
+__global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double Xs[4][BS_X], Ys[4][BS_Y];
+  double* X = Xs[wave];
+  double* Y = Ys[wave];
+  const int n_items = sc.counts[f * 8 + 4];
+  const int32_t* list = sc.list_small + (int64_t)f * max_drops;
+  for (int it = blockIdx.x * 4 + wave; it < n_items; it += gridDim.x * 4) {
+    const DropPlan& p = sc.plan[(int64_t)f * max_drops + list[it]];
+    const int r1 = p.r1, r2 = p.r2, pw = p.pw, ph = p.ph;
+    const int wi = pw + 2 * r2, hi = ph + 2 * r1;
+    const double* raw = sc.arena + p.a0_off;        // raw tile (tw x th); the pad is implicit zeros
+    double* tile = sc.arena + p.a1_off;             // finished padded tile
+    const int shift = p.shift, tw = p.tw, th = p.th;
+    // weights: lane l holds w(distance l) of each axis
+    double w1, w2 = 0.0;
+    {
+      const double ph1 = (lane <= r1) ? gauss_phi(p.sig1, lane) : 0.0;
+      double tot = 0.0;
+      for (int x = -r1; x <= r1; x++) tot = tot + readlane_f64(ph1, x < 0 ? -x : x);
+      w1 = ph1 / tot;
+      if (r2 > 0) {
+        const double ph2 = (lane <= r2) ? gauss_phi(p.sig2, lane) : 0.0;
+        double tot2 = 0.0;
+        for (int x = -r2; x <= r2; x++) tot2 = tot2 + readlane_f64(ph2, x < 0 ? -x : x);
+        w2 = ph2 / tot2;
+      }
+    }
+    const float inv_wi = 1.0f / (float)wi, inv_pw = 1.0f / (float)pw;
+    const int nx = wi * hi;
+    for (int base = lane; base < nx; base += 256) {       // haloed tile -> LDS, 4 loads in flight
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int idx = base + 64 * k;
+        const int yy = (int)(((float)idx + 0.5f) * inv_wi), xx = idx - yy * wi;
+        const int y = yy - r1 - shift, x = xx - r2 - shift;      // raw-tile coordinates
+        v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? raw[y * tw + x] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (base + 64 * k < nx) X[base + 64 * k] = v[k];
+    }
+    wave_lds_sync();
+    // axis 0 (rows): outputs for all wi columns (halo columns are zero but needed by axis 1)
+    const int nv = wi * ph;
+    for (int base = lane; base < nv; base += 128) {
+      const int i0 = base, i1 = imin(base + 64, nv - 1);
+      const double* c0 = X + i0 + r1 * wi;
+      const double* c1 = X + i1 + r1 * wi;
+      double a0 = c0[0] * readlane_f64(w1, 0), a1 = c1[0] * readlane_f64(w1, 0);
+      for (int ii = -r1; ii < 0; ii++) {
+        const double w = readlane_f64(w1, -ii);
+        const int o = ii * wi;
+        a0 = a0 + (c0[o] + c0[-o]) * w;
+        a1 = a1 + (c1[o] + c1[-o]) * w;
+      }
+      Y[i0] = a0;
+      if (base + 64 < nv) Y[i1] = a1;
+    }
+    wave_lds_sync();
+    // axis 1 (columns) -> global, in place
+    const int nh = pw * ph;
+    for (int base = lane; base < nh; base += 128) {
+      const int i0 = base, i1 = imin(base + 64, nh - 1);
+      const int y0 = (int)(((float)i0 + 0.5f) * inv_pw), x0 = i0 - y0 * pw;
+      const int y1 = (int)(((float)i1 + 0.5f) * inv_pw), x1 = i1 - y1 * pw;
+      const double* q0 = Y + y0 * wi + x0 + r2;
+      const double* q1 = Y + y1 * wi + x1 + r2;
+      double a0, a1;
+      if (r2 > 0) {
+        const double wc = readlane_f64(w2, 0);
+        a0 = q0[0] * wc;
+        a1 = q1[0] * wc;
+        for (int ii = -r2; ii < 0; ii++) {
+          const double w = readlane_f64(w2, -ii);
+          a0 = a0 + (q0[ii] + q0[-ii]) * w;
+          a1 = a1 + (q1[ii] + q1[-ii]) * w;
+        }
+      } else {
+        a0 = q0[0];
+        a1 = q1[0];
+      }
+      tile[i0] = a0;
+      if (base + 64 < nh) tile[i1] = a1;
+    }
+    wave_lds_sync();
+  }
+}
+
 template <int AXIS>
 __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_drops, Scratch sc) {
   const int f = blockIdx.y;
   __shared__ double hw[MAX_R + 1];
-  const int n_items = sc.counts[f * 4 + 3];
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // blurred drops the fused kernel cannot take
+  const int n_items = sc.counts[f * 8 + 3];
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // blurred drops with radius > BR_MAX
     const int64_t gi = (int64_t)f * max_drops + sc.list_slow[(int64_t)f * max_drops + it];
     const DropPlan& p = sc.plan[gi];
     const int r = AXIS == 0 ? p.r1 : p.r2;
+    const int pw = p.pw, ph = p.ph, n = pw * ph;
+    const double* raw = sc.arena + p.a0_off;
+    double* fin = sc.arena + p.a1_off;
+    double* tmp = fin + n;                            // scratch tile reserved by k_plan for slow drops
     __syncthreads();
-    if (r == 0) continue;
-    gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
-    const double* src = sc.arena + (AXIS == 0 ? p.a0_off : p.a1_off);
-    double* dst = sc.arena + (AXIS == 0 ? p.a1_off : p.a0_off);
-    const int n = p.pw * p.ph;
+    if (r > 0) gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
     for (int idx = threadIdx.x; idx < n; idx += 256) {
-      int y = idx / p.pw, x = idx - y * p.pw;
-      dst[idx] = AXIS == 0 ? blur_axis0(src, p.pw, p.ph, x, y, hw, r) : blur_axis1(src, p.pw, p.ph, x, y, hw, r);
+      const int y = idx / pw, x = idx - y * pw;
+      if (AXIS == 0) {
+        const int rx = x - p.shift;
+        double acc = 0.0;
+        if (rx >= 0 && rx < p.tw) {                   // a column outside the raw tile is all zeros
+          auto R = [&](int yy) -> double {
+            const int ry = yy - p.shift;
+            return (ry >= 0 && ry < p.th) ? raw[ry * p.tw + rx] : 0.0;
+          };
+          acc = R(y) * hw[r];
+          for (int ii = -r; ii < 0; ii++) acc = acc + (R(y + ii) + R(y - ii)) * hw[ii + r];
+        }
+        tmp[idx] = acc;
+      } else {
+        fin[idx] = r > 0 ? blur_axis1(tmp, pw, ph, x, y, hw, r) : tmp[idx];
+      }
     }
   }
 }
@@ -1046,7 +1177,7 @@ struct rr_ctx {
   hipStream_t stream = nullptr;
   hipStream_t s_col = nullptr, s_gen = nullptr;     // side streams: colour chain, generic tiles
   hipEvent_t ev_start = nullptr, ev_scan = nullptr, ev_col = nullptr, ev_gen = nullptr;
-  bool serial = false;              // RAINHIP_SERIAL=1: everything on the caller's stream
+  bool serial = true;               // RAINHIP_CONCURRENT=1 moves the colour chain / generic tiles to side streams
   std::string err;
   // streak DB
   uint8_t* d_tex = nullptr;
@@ -1187,7 +1318,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.list_gen, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_slow, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.blur_items, fd * 8))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 4))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.list_small, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fconst, (size_t)F * 2))) return rc;
     const int ntiles = ((dm.W + TILE - 1) / TILE) * ((dm.H + TILE - 1) / TILE);
@@ -1338,8 +1470,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       HIPCHK(hipStreamWaitEvent(s, ctx->ev_gen, 0));
     }
     {
+      ProfScope ps(ctx, s, "k_blur_small");
+      hipLaunchKernelGGL(k_blur_small, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+    }
+    {
       ProfScope ps(ctx, s, "k_blur_fused");
-      hipLaunchKernelGGL(k_blur_fused, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, sc, ctx->tile_dbg);
+      hipLaunchKernelGGL(k_blur_fused, dim3((max_drops + 1) / 2, n), dim3(256), 0, s, ctx->d_frames, D, sc, ctx->tile_dbg);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
@@ -1418,8 +1554,8 @@ int rr_create(rr_ctx** out, int device) {
     return RR_E_HIP;
   }
   {
-    const char* e = getenv("RAINHIP_SERIAL");
-    ctx->serial = e && e[0] == '1';
+    const char* e = getenv("RAINHIP_CONCURRENT");      // side streams buy ~1%: off unless asked for
+    ctx->serial = !(e && e[0] == '1');
   }
   if (hipStreamCreateWithFlags(&ctx->s_col, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->s_gen, hipStreamNonBlocking) != hipSuccess ||
@@ -1460,6 +1596,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.list_slow);
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
+  hipFree(ctx->sc.list_small);
   hipFree(ctx->sc.prefix);
   hipFree(ctx->sc.fconst);
   hipFree(ctx->sc.arena);

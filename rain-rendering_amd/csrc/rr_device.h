@@ -49,13 +49,13 @@ struct DropPlan {
   int32_t r1, r2;            // gaussian radii along axis 0 (rows) / axis 1 (cols)
   int32_t vis_x0, vis_y0, vis_w, vis_h;   // footprint inside the frame
   int32_t crop_x, crop_y;    // padded-tile coordinates of the footprint origin
-  int32_t final_buf;         // which arena buffer holds the finished alpha tile
+  int32_t final_buf;         // unused (kept for layout stability)
   int32_t bw0;               // warpPerspective block width
   int32_t nW, nH;            // rotate_bound canvas
   int32_t rs_mode;           // RS_*
   int32_t isx, isy;          // integer scales (RS_AREA_FAST)
   int32_t pad0;
-  int64_t a0_off, a1_off;    // arena offsets in doubles
+  int64_t a0_off, a1_off;    // arena offsets in doubles: raw tile (tw x th) / finished padded tile (pw x ph, blurred drops only)
   double sig1, sig2;         // c, c/2 (bad_weather.py:291)
   double tau_one, g;         // exposure*length_opacity, tau_one/tau_zero (bad_weather.py:425-427,443)
   double mi[9];              // inverse homography (Big)
@@ -736,9 +736,11 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
   p.tau_one = cam.exposure_s * length_opacity;
   p.g = p.tau_one / cam.tau_zero;
 
-  p.final_buf = (p.r1 > 0 && p.r2 == 0) ? 1 : 0;
+  p.final_buf = 0;
+  // arena need: the raw tile, plus the padded tile when the drop is defocus-blurred (the pad of an
+  // un-blurred drop is all zeros and never materialised; the kernels may add scratch on top)
   int64_t area = (int64_t)p.pw * (int64_t)p.ph;
-  size_out = (p.vis_w > 0 && p.vis_h > 0) ? area * (p.r1 > 0 ? 2 : 1) : 0;
+  size_out = (p.vis_w > 0 && p.vis_h > 0) ? (int64_t)p.tw * p.th + (p.r1 > 0 ? area : 0) : 0;
 }
 
 // one output sample of the symmetric correlate1d (scipy ni_filters.c), zero extension.

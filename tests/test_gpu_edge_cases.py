@@ -47,6 +47,9 @@ def _frames():
     d.append(_drop(k, 90, 120, 92, 140, 2.0, 2.0, 9.95)); k += 1
     # very close: large circle of confusion
     d.append(_drop(k, 220, 60, 223, 110, 5.0, 6.0, 0.12)); k += 1
+    # closer still: blur radius > 48 -> the two-pass global fallback; and a Medium one through the same path
+    d.append(_drop(k, 60, 150, 62, 190, 4.5, 4.5, 0.08)); k += 1
+    d.append(_drop(k, 250, 250, 251, 262, 2.5, 2.5, 0.09)); k += 1
     return [dict(id=0, t=2000, d=0, drops=d)]
 
 
@@ -73,7 +76,7 @@ def _check(out, ref):
 
 def test_forced_paths_match_oracle(tmp_path, built):
     sc, drops, out, ref, emu = _run(tmp_path, built)
-    assert len(drops) >= 24
+    assert len(drops) >= 26
     assert (ref['status'] == 1).sum() >= 1 and (ref['status'] == 0).sum() >= 20          # > radius skipped, rest rendered
     _check(out, ref)
     _check(out, emu)
