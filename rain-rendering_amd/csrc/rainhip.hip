@@ -28,6 +28,7 @@ using namespace rr;
 namespace {
 
 constexpr int TILE = 16;            // screen tile edge (256 threads = 16x16 pixels)
+constexpr int CTILE = 64;           // coarse binning tile (4x4 screen tiles)
 constexpr int MAX_R = 416;          // >= 4*RR_MAX_SHIFT/10 + 1
 constexpr int POLY_STRIDE = RR_MAX_FOV + 4;
 
@@ -65,57 +66,56 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
   int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
   int32_t* list_small;              // [frame][drops]  blurred drops handled one wave each (k_blur_small)
+  double* colpart;                  // [frame][drops][COL_BANDS][5] FOV partial sums per envmap row band
+  int4* bbox;                       // [frame][drops] footprint (x0,y0,x1,y1), empty when not composited
+  uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
+  int32_t* ccount;                  // [frame][coarse tiles]
   int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small
 };
 
 // ---------------------------------------------------------------------------
 // environment map prefix sums
 // ---------------------------------------------------------------------------
+// One wave per environment-map row, 64 consecutive texels per step: coalesced loads
+// (24 B + 8 B per lane), a Hillis-Steele scan across the wave with shuffles, the running
+// carry in a register, one coalesced 32-byte store per lane.
 __global__ __launch_bounds__(256) void k_env_prefix(const FrameDesc* frames, Dims dm, double* prefix) {
-  const int row = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), f = blockIdx.y;
+  if (row >= dm.He) return;
   const FrameDesc& fr = frames[f];
   const int We = dm.We;
   const double* env = fr.env + (int64_t)row * We * 3;
   const double* om = fr.omega + (int64_t)row * We;
   double* P = prefix + ((int64_t)f * dm.He + row) * (int64_t)(We + 1) * 4;
-  const int chunk = (We + 255) / 256;
-  const int c0 = t * chunk, c1 = min(c0 + chunk, We);
-  double s[4] = {0, 0, 0, 0};
-  for (int c = c0; c < c1; c++) {
-    double w = om[c];
-    s[0] += env[c * 3 + 0] * w;
-    s[1] += env[c * 3 + 1] * w;
-    s[2] += env[c * 3 + 2] * w;
-    s[3] += w;
-  }
-  __shared__ double sh[256][4];
-  for (int k = 0; k < 4; k++) sh[t][k] = s[k];
-  __syncthreads();
-  // Hillis-Steele inclusive scan over the 256 thread totals
-  for (int ofs = 1; ofs < 256; ofs <<= 1) {
+  if (lane == 0) { P[0] = 0.0; P[1] = 0.0; P[2] = 0.0; P[3] = 0.0; }
+  double carry[4] = {0, 0, 0, 0};
+  for (int c0 = 0; c0 < We; c0 += 64) {
+    const int c = c0 + lane;
     double v[4] = {0, 0, 0, 0};
-    if (t >= ofs)
-      for (int k = 0; k < 4; k++) v[k] = sh[t - ofs][k];
-    __syncthreads();
-    if (t >= ofs)
-      for (int k = 0; k < 4; k++) sh[t][k] += v[k];
-    __syncthreads();
-  }
-  double run[4];
-  for (int k = 0; k < 4; k++) run[k] = (t == 0) ? 0.0 : sh[t - 1][k];
-  if (t == 0)
-    for (int k = 0; k < 4; k++) P[k] = 0.0;
-  for (int c = c0; c < c1; c++) {
-    double w = om[c];
-    run[0] += env[c * 3 + 0] * w;
-    run[1] += env[c * 3 + 1] * w;
-    run[2] += env[c * 3 + 2] * w;
-    run[3] += w;
-    double* o = P + (int64_t)(c + 1) * 4;
-    o[0] = run[0];
-    o[1] = run[1];
-    o[2] = run[2];
-    o[3] = run[3];
+    if (c < We) {
+      const double w = om[c];
+      v[0] = env[c * 3 + 0] * w;
+      v[1] = env[c * 3 + 1] * w;
+      v[2] = env[c * 3 + 2] * w;
+      v[3] = w;
+    }
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double u = __shfl_up(v[k], ofs);
+        if (lane >= ofs) v[k] += u;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] += carry[k];
+    if (c < We) {
+      double* o = P + (int64_t)(c + 1) * 4;
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) carry[k] = __shfl(v[k], 63);
   }
 }
 
@@ -258,10 +258,88 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
 // ---------------------------------------------------------------------------
 // colour: FOV polygon row spans x prefix table, one wave per drop
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+// fov_rowspan (rr_device.h) with the rounded edge intersection evaluated in double: exact,
+// because |2*num+den| < 2^26 and a non-integer quotient is at least 1/(2*den) away from an integer.
+__device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, int n, int y, int We, int& xl, int& xr) {
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int i = 0; i < n; i++) {
+    const int j = (i + 1 == n) ? 0 : i + 1;
+    const int x0 = px[i], y0 = py[i], x1 = px[j], y1 = py[j];
+    const int ylo = imin(y0, y1), yhi = imax(y0, y1);
+    if (y < ylo || y > yhi) continue;
+    if (y0 == y1) {
+      lo = imin(lo, imin(x0, x1));
+      hi = imax(hi, imax(x0, x1));
+    } else {
+      const bool sw = y1 < y0;
+      const int xa = sw ? x1 : x0, yA = sw ? y1 : y0, xb = sw ? x0 : x1, yB = sw ? y0 : y1;
+      const int den = yB - yA;
+      const int nn = 2 * (xb - xa) * (y - yA) + den;
+      const int xv = xa + (int)floor((double)nn / (double)(2 * den));
+      lo = imin(lo, xv);
+      hi = imax(hi, xv);
+    }
+  }
+  xl = imax(lo, 0);
+  xr = imin(hi, We - 1);
+  return xl <= xr;
+}
+
+// Colour, pass 1: one wave per (drop, row band): polygon row spans x prefix table, wave reduce.
+constexpr int COL_BANDS = 1;        // row bands per drop (8 = one per XCD L2 was measured slower: the kernel is ALU-bound)
+
+__global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
   const int f = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
+  const int band = blockIdx.x % COL_BANDS;
+  const int i = (blockIdx.x / COL_BANDS) * 4 + wave;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  const int n = sc.npts[gi];
+  double S[4] = {0, 0, 0, 0};
+  int any = 0;
+  if (n > 0) {
+    const int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
+    const int32_t* py = px + POLY_STRIDE;
+    int ymin = py[0], ymax = py[0];
+    for (int k = 1; k < n; k++) {
+      ymin = min(ymin, py[k]);
+      ymax = max(ymax, py[k]);
+    }
+    const int rows_per_band = (dm.He + COL_BANDS - 1) / COL_BANDS;
+    const int ya = max(max(ymin, 0), band * rows_per_band), yb = min(min(ymax, dm.He - 1), (band + 1) * rows_per_band - 1);
+    const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
+    for (int y = ya + lane; y <= yb; y += 64) {
+      int xl, xr;
+      if (fov_rowspan_fast(px, py, n, y, dm.We, xl, xr)) {
+        any = 1;
+        const double* row = P + (int64_t)y * (dm.We + 1) * 4;
+        const double* hi = row + (int64_t)(xr + 1) * 4;
+        const double* lo = row + (int64_t)xl * 4;
+        if (xl > 0) {
+          for (int k = 0; k < 4; k++) S[k] += hi[k] - lo[k];
+        } else {
+          for (int k = 0; k < 4; k++) S[k] += hi[k];                 // P[row][0] == 0
+        }
+      }
+    }
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+      for (int k = 0; k < 4; k++) S[k] += __shfl_xor(S[k], ofs);
+      any |= __shfl_xor(any, ofs);
+    }
+  }
+  if (lane == 0) {
+    double* o = sc.colpart + (gi * COL_BANDS + band) * 5;
+    o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[3];
+    o[4] = (double)any;
+  }
+}
+
+// Colour, pass 2: one thread per drop adds the band partials in band order and writes the
+// compositor record.
+__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
   const FrameDesc& fr = frames[f];
   if (i >= fr.n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
@@ -276,30 +354,12 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   const int n = sc.npts[gi];
   if (n == 0) status = RR_DROP_FOV_FAIL;
   if (n > 0) {
-    const int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
-    const int32_t* py = px + POLY_STRIDE;
-    int ymin = py[0], ymax = py[0];
-    for (int k = 1; k < n; k++) {
-      ymin = min(ymin, py[k]);
-      ymax = max(ymax, py[k]);
-    }
-    const int ya = max(ymin, 0), yb = min(ymax, dm.He - 1);
     double S[4] = {0, 0, 0, 0};
-    int any = 0;
-    const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
-    for (int y = ya + lane; y <= yb; y += 64) {
-      int xl, xr;
-      if (fov_rowspan(px, py, n, y, dm.We, xl, xr)) {
-        any = 1;
-        const double* row = P + (int64_t)y * (dm.We + 1) * 4;
-        const double* hi = row + (int64_t)(xr + 1) * 4;
-        const double* lo = row + (int64_t)xl * 4;
-        for (int k = 0; k < 4; k++) S[k] += hi[k] - lo[k];
-      }
-    }
-    for (int ofs = 32; ofs > 0; ofs >>= 1) {
-      for (int k = 0; k < 4; k++) S[k] += __shfl_xor(S[k], ofs);
-      any |= __shfl_xor(any, ofs);
+    bool any = false;
+    const double* part = sc.colpart + gi * COL_BANDS * 5;
+    for (int b = 0; b < COL_BANDS; b++) {
+      for (int k = 0; k < 4; k++) S[k] += part[b * 5 + k];
+      any = any || part[b * 5 + 4] != 0.0;
     }
     if (!any) status = RR_DROP_EMPTY_FOV;
     if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
@@ -329,10 +389,9 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
       rec.g = p.g;
     }
   }
-  if (lane == 0) {
-    sc.comp[gi] = rec;
-    if (fr.status) fr.status[i] = status;
-  }
+  sc.comp[gi] = rec;
+  sc.bbox[gi] = make_int4(rec.x0, rec.y0, rec.x1, rec.y1);
+  if (fr.status) fr.status[i] = status;
 }
 
 // ---------------------------------------------------------------------------
@@ -369,10 +428,10 @@ __global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, in
 //     Every fold runs in the order resizeArea_ uses, so the tile is bit-identical to
 //     k_tile_simple / the oracle.
 constexpr int TEX_LDS = 11776;      // padded texels: (h+4)*(w+4) <= TEX_LDS
-constexpr int NW_MAX = 400;
+constexpr int NW_MAX = 384;
 constexpr int TW_MAX = 64;
-constexpr int BUF_MAX = 1024;
-constexpr int CAN_W = 256;        // doubles of sample staging per wave
+constexpr int BUF_MAX = 512;
+constexpr int CAN_W = 512;        // doubles of sample staging per wave
 constexpr int ROWS_W = 16;        // canvas rows a wave stages at most
 
 // Columns rx of canvas row `ry` (un-flipped row number) whose bilinear footprint can touch
@@ -489,10 +548,31 @@ __device__ inline double lds_rot_sample(const uint8_t* s_tex, const double* s_lu
   return sm * (1.0 / 1024.0);
 }
 
+// two samples at once: all LDS loads of both samples are issued before either is consumed
+__device__ inline void lds_rot_sample2(const uint8_t* s_tex, const double* s_lut, int P, int sh, int sw, int XA, int YA, int2 dA,
+                                       int XB, int YB, int2 dB, double& outA, double& outB) {
+  const int Xa = (XA + dA.x) >> 5, Ya = (YA + dA.y) >> 5, Xb = (XB + dB.x) >> 5, Yb = (YB + dB.y) >> 5;
+  const int sxa = imin(imax(Xa >> 5, -2), sw), sya = imin(imax(Ya >> 5, -2), sh);
+  const int sxb = imin(imax(Xb >> 5, -2), sw), syb = imin(imax(Yb >> 5, -2), sh);
+  const uint8_t* qa = s_tex + (sya + 2) * P + (sxa + 2);
+  const uint8_t* qb = s_tex + (syb + 2) * P + (sxb + 2);
+  const int a0 = qa[0], a1 = qa[1], a2 = qa[P], a3 = qa[P + 1];
+  const int b0 = qb[0], b1 = qb[1], b2 = qb[P], b3 = qb[P + 1];
+  const double va0 = s_lut[a0], va1 = s_lut[a1], va2 = s_lut[a2], va3 = s_lut[a3];
+  const double vb0 = s_lut[b0], vb1 = s_lut[b1], vb2 = s_lut[b2], vb3 = s_lut[b3];
+  const int fxa = Xa & 31, fya = Ya & 31, fxb = Xb & 31, fyb = Yb & 31;
+  const double axa = (double)(32 - fxa), bxa = (double)fxa, aya = (double)(32 - fya), bya = (double)fya;
+  const double axb = (double)(32 - fxb), bxb = (double)fxb, ayb = (double)(32 - fyb), byb = (double)fyb;
+  const double sa = ((va0 * (aya * axa) + va1 * (aya * bxa)) + va2 * (bya * axa)) + va3 * (bya * bxa);
+  const double sb = ((vb0 * (ayb * axb) + vb1 * (ayb * bxb)) + vb2 * (byb * axb)) + vb3 * (byb * bxb);
+  outA = sa * (1.0 / 1024.0);
+  outB = sb * (1.0 / 1024.0);
+}
+
 // Big drops (bicubic warp) and the rare resize modes: one thread per output pixel, texels in LDS.
 __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                                       const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                                      const float* ctab, Scratch sc) {
+                                                      const float* ctab, Scratch sc, int dbg) {
   const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
@@ -515,7 +595,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   if (area_fast)
     for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   __syncthreads();
-  const int n = p.tw * p.th;
+  const int n = ((dbg & 4096) && area_fast) || ((dbg & 8192) && p.kind == KIND_BIG) ? 0 : p.tw * p.th;
   if (area_fast) {
     const int area = p.isx * p.isy, n4 = area & ~3;
     const float scale = 1.0f / (float)area;
@@ -624,13 +704,17 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       wave_lds_sync();
       // ---- 1a: bilinear samples of the rotated texture, lanes flattened over (row, column) ----
       const int nidx = nr * pitch;
-#pragma unroll 2
-      for (int idx = lane; idx < ((dbg & 1) ? 0 : nidx); idx += 64) {
-        const int r = (int)(((float)idx + 0.5f) * inv_pitch), x = idx - r * pitch;
-        const int4 rw = rowp[r];
-        if (x < rw.w) {
-          can[idx] = lds_rot_sample(s_tex, s_lut, P, sh, sw, rw.x, rw.y, s_adbd[rw.z + x]);
-        }
+      for (int idx = lane; idx < ((dbg & 1) ? 0 : nidx); idx += 128) {
+        const int ia = idx, ib = imin(idx + 64, nidx - 1);
+        const int ra = (int)(((float)ia + 0.5f) * inv_pitch), xa = ia - ra * pitch;
+        const int rb = (int)(((float)ib + 0.5f) * inv_pitch), xb = ib - rb * pitch;
+        const int4 rwa = rowp[ra], rwb = rowp[rb];
+        const bool oka = xa < rwa.w, okb = (idx + 64 < nidx) && xb < rwb.w;
+        const int2 da = s_adbd[rwa.z + (oka ? xa : 0)], db = s_adbd[rwb.z + (okb ? xb : 0)];
+        double va, vb;
+        lds_rot_sample2(s_tex, s_lut, P, sh, sw, rwa.x, rwa.y, da, rwb.x, rwb.y, db, va, vb);
+        if (oka) can[ia] = va;
+        if (okb) can[ib] = vb;
       }
       wave_lds_sync();
       // ---- 1b: horizontal folds, one lane per (row, destination column) ----
@@ -1029,14 +1113,47 @@ __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_d
 // ---------------------------------------------------------------------------
 // compositor: one block per 16x16 screen tile, drops applied in reference order
 // ---------------------------------------------------------------------------
+// Coarse binning: one block per 64x64 coarse tile scans every drop's footprint once and keeps,
+// IN DROP ORDER (ballot + prefix popcount, no atomics, no sort), the ones that touch it.
+__global__ __launch_bounds__(256) void k_bin(const FrameDesc* frames, Dims dm, int max_drops, int ctiles_x, int nct, Scratch sc) {
+  const int f = blockIdx.y, ct = blockIdx.x;
+  const int cty = ct / ctiles_x, ctx_ = ct - cty * ctiles_x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = frames[f].n_drops;
+  const int x0 = ctx_ * CTILE, y0 = cty * CTILE, x1 = min(x0 + CTILE, dm.W), y1 = min(y0 + CTILE, dm.H);
+  const int4* bbox = sc.bbox + (int64_t)f * max_drops;
+  uint16_t* out = sc.clist + ((int64_t)f * nct + ct) * max_drops;
+  __shared__ int s_cnt[4];
+  int total = 0;
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + t;
+    bool hit = false;
+    if (i < n) {
+      const int4 bb = bbox[i];
+      hit = bb.x < x1 && bb.z > x0 && bb.y < y1 && bb.w > y0;
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = total;
+    for (int w = 0; w < 4; w++) {
+      const int cw = s_cnt[w];
+      if (w < wave) off += cw;
+      total += cw;
+    }
+    if (hit) out[off + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    __syncthreads();
+  }
+  if (t == 0) sc.ccount[(int64_t)f * nct + ct] = total;
+}
+
 __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
-                                                   int tiles_y, Scratch sc) {
+                                                   int tiles_y, int ctiles_x, int nct, Scratch sc) {
   const int f = blockIdx.y;
   const int tile = blockIdx.x;
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const FrameDesc& fr = frames[f];
-  const int n = fr.n_drops;
   const int tx0 = txi * TILE, ty0 = tyi * TILE, tx1 = min(tx0 + TILE, dm.W), ty1 = min(ty0 + TILE, dm.H);
   const int px = tx0 + (t & (TILE - 1)), py = ty0 + (t >> 4);
   const bool live = px < dm.W && py < dm.H;
@@ -1049,14 +1166,20 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     c[2] = s[2];
   }
   const CompRec* comp = sc.comp + (int64_t)f * max_drops;
+  const int4* bbox = sc.bbox + (int64_t)f * max_drops;
   const double* arena = sc.arena;
+  const int ct = (ty0 / CTILE) * ctiles_x + (tx0 / CTILE);
+  const uint16_t* clist = sc.clist + ((int64_t)f * nct + ct) * max_drops;
+  const int n = sc.ccount[(int64_t)f * nct + ct];
   __shared__ int s_list[256];
   __shared__ int s_cnt[4];
   for (int base = 0; base < n; base += 256) {
-    const int i = base + t;
+    const int k = base + t;
     bool hit = false;
-    if (i < n) {
-      const int4 bb = *reinterpret_cast<const int4*>(&comp[i].x0);
+    int i = 0;
+    if (k < n) {
+      i = clist[k];
+      const int4 bb = bbox[i];
       hit = bb.x < tx1 && bb.z > tx0 && bb.y < ty1 && bb.w > ty0;
     }
     const unsigned long long bal = __ballot(hit);
@@ -1319,6 +1442,13 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.list_slow, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.blur_items, fd * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_small, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.colpart, fd * COL_BANDS * 5))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.bbox, fd))) return rc;
+    {
+      const size_t nct = (size_t)((dm.W + CTILE - 1) / CTILE) * ((dm.H + CTILE - 1) / CTILE);
+      if ((rc = dev_alloc(ctx, ctx->sc.clist, fd * nct))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->sc.ccount, (size_t)F * nct))) return rc;
+    }
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fconst, (size_t)F * 2))) return rc;
@@ -1420,7 +1550,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   {
     ProfScope ps(ctx, sc_col, "k_env_prefix");
-    hipLaunchKernelGGL(k_env_prefix, dim3(dm.He, n), dim3(256), 0, sc_col, ctx->d_frames, dm, sc.prefix);
+    hipLaunchKernelGGL(k_env_prefix, dim3((dm.He + 3) / 4, n), dim3(256), 0, sc_col, ctx->d_frames, dm, sc.prefix);
   }
   {
     ProfScope ps(ctx, sc_col, "k_env_consts");
@@ -1447,7 +1577,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, sc_col, "k_colour");
-      hipLaunchKernelGGL(k_colour, dim3((max_drops + 3) / 4, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc);
+      hipLaunchKernelGGL(k_colour_bands, dim3(((max_drops + 3) / 4) * COL_BANDS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc);
+      hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc);
     }
     if (ctx->simple_tile) {
       ProfScope ps(ctx, s, "k_tile");
@@ -1457,7 +1588,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       {
         ProfScope ps(ctx, sc_gen, "k_tile_generic");
         hipLaunchKernelGGL(k_tile_generic, dim3((max_drops + 3) / 4, n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex,
-                           ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
+                           ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc, ctx->tile_dbg);
       }
       {
         ProfScope ps(ctx, s, "k_tile");
@@ -1490,9 +1621,15 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     HIPCHK(hipEventRecord(ctx->ev_col, sc_col));
     HIPCHK(hipStreamWaitEvent(s, ctx->ev_col, 0));
   }
+  const int ctiles_x = (dm.W + CTILE - 1) / CTILE, nct = ctiles_x * ((dm.H + CTILE - 1) / CTILE);
+  {
+    ProfScope ps(ctx, s, "k_bin");
+    hipLaunchKernelGGL(k_bin, dim3(nct, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctiles_x, nct, sc);
+  }
   {
     ProfScope ps(ctx, s, "k_composite");
-    hipLaunchKernelGGL(k_composite, dim3(ntiles, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, sc);
+    hipLaunchKernelGGL(k_composite, dim3(ntiles, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
+                       sc);
   }
   {
     ProfScope ps(ctx, s, "k_means");
@@ -1597,6 +1734,10 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
   hipFree(ctx->sc.list_small);
+  hipFree(ctx->sc.colpart);
+  hipFree(ctx->sc.bbox);
+  hipFree(ctx->sc.clist);
+  hipFree(ctx->sc.ccount);
   hipFree(ctx->sc.prefix);
   hipFree(ctx->sc.fconst);
   hipFree(ctx->sc.arena);

@@ -274,8 +274,8 @@ RR_HD double canvas_pixel(const DropPlan& p, const Tex& tx, int cy, int cx) {
 
 // computeResizeAreaTab for one destination index
 struct AreaSpan {
-  int32_t s1, s2;            // full cells s1 .. s2-1
-  int32_t has_l, has_r;      // partial cells at s1-1 and s2
+  int16_t s1, s2;            // full cells s1 .. s2-1
+  int16_t has_l, has_r;      // partial cells at s1-1 and s2
   float a_l, a_m, a_r;
 };
 RR_HD AreaSpan area_span(int ssize, double scale, int d) {
@@ -286,8 +286,8 @@ RR_HD AreaSpan area_span(int ssize, double scale, int d) {
   int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
   sx2 = imin(sx2, ssize - 1);
   sx1 = imin(sx1, sx2);
-  a.s1 = sx1;
-  a.s2 = sx2;
+  a.s1 = (int16_t)sx1;
+  a.s2 = (int16_t)sx2;
   a.has_l = ((double)sx1 - fsx1 > 1e-3) ? 1 : 0;
   a.a_l = (float)(((double)sx1 - fsx1) / cell);
   a.a_m = (float)(1.0 / cell);
