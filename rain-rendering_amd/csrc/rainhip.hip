@@ -154,35 +154,47 @@ struct BlurLayout {
   int wo, ho;       // output sub-tile
   int single;       // one sub-tile covers the padded tile: result written in place (A0)
 };
+// LDS footprints of an output sub-tile wo x ho: each thread filters four consecutive outputs
+// along the filter axis with a rotating register window, so rows/columns are padded to
+// multiples of four (zero / don't-care slack); the column-pass tile has an odd pitch so that
+// lanes running down a column hit distinct LDS banks.
+__device__ inline int blur_x_doubles(int wo, int ho, int r1, int r2) { return (wo + 2 * r2) * (((ho + 3) & ~3) + 2 * r1); }
+__device__ inline int blur_y_pitch(int wo, int r2) { return (((wo + 3) & ~3) + 2 * r2) | 1; }
+__device__ inline int blur_y_doubles(int wo, int ho, int r2) { return blur_y_pitch(wo, r2) * ho; }
+
 __device__ inline BlurLayout blur_layout(const DropPlan& p) {
   BlurLayout b{0, 0, 0, 0};
   if (p.r1 <= 0 || p.r1 > BR_MAX) return b;
-  // The LDS tiles carry explicit zero halos (r2 columns, r1 rows) so the filter loops are
-  // branch-free.  Whole tile if it fits; otherwise the output sub-tile that maximises
-  // wo*ho under (wo+2*r2)*(ho+2*r1) <= BX_MAX (halo-aware aspect), (wo+2*r2)*ho <= BY_MAX.
-  if ((p.pw + 2 * p.r2) * (p.ph + 2 * p.r1) <= BX_MAX && (p.pw + 2 * p.r2) * p.ph <= BY_MAX) {
-    b.fused = 1; b.wo = p.pw; b.ho = p.ph; b.single = 1;
+  // Whole tile if it fits; otherwise the output sub-tile that (roughly) maximises wo*ho under
+  // the two LDS capacities -- halo-aware aspect: (wo+2*r2)*(ho+2*r1) <= BX_MAX.
+  if (blur_x_doubles(p.ew, p.eh, p.r1, p.r2) <= BX_MAX && blur_y_doubles(p.ew, p.eh, p.r2) <= BY_MAX) {
+    b.fused = 1; b.wo = p.ew; b.ho = p.eh; b.single = 1;
     return b;
   }
   const double rr2 = (double)imax(p.r2, 1), rr1 = (double)p.r1;
   int wi = (int)sqrt((double)BX_MAX * rr2 / rr1);            // ideal haloed width
-  wi = imax(imin(wi, p.pw + 2 * p.r2), 2 * p.r2 + 1);
+  wi = imax(imin(wi, p.ew + 2 * p.r2), 2 * p.r2 + 4);
   int hi = BX_MAX / wi;
-  hi = imin(hi, p.ph + 2 * p.r1);
-  wi = imin(BX_MAX / hi, p.pw + 2 * p.r2);                   // give unused height back to the width
-  int wo = wi - 2 * p.r2, ho = hi - 2 * p.r1;
-  if (wo < 1 || ho < 1) return b;                            // halo alone exceeds the LDS: two-pass fallback
-  if (wi * ho > BY_MAX) ho = BY_MAX / wi;
-  if (ho < 1) return b;
-  b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo >= p.pw && ho >= p.ph) ? 1 : 0;
-  return b;
+  hi = imin(hi, ((p.eh + 3) & ~3) + 2 * p.r1);
+  wi = imin(BX_MAX / hi, p.ew + 2 * p.r2);                   // give unused height back to the width
+  int wo = wi - 2 * p.r2, ho = (hi - 2 * p.r1) & ~3;         // ho a multiple of four: no slack rows wasted
+  if (ho > p.eh) ho = p.eh;
+  for (int it = 0; it < 64 && wo >= 1 && ho >= 1; it++) {
+    if (blur_x_doubles(wo, ho, p.r1, p.r2) <= BX_MAX && blur_y_doubles(wo, ho, p.r2) <= BY_MAX) {
+      b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo >= p.ew && ho >= p.eh) ? 1 : 0;
+      return b;
+    }
+    if (blur_x_doubles(wo, ho, p.r1, p.r2) > BX_MAX) { if (wo > 4) wo -= 1; else ho -= 4; }
+    else ho -= 4;
+  }
+  return b;                                                  // halo alone exceeds the LDS: two-pass fallback
 }
 // small blurred tiles are filtered by one wave each, in place (k_blur_small)
 constexpr int BS_X = 768;           // doubles per wave: haloed input tile
 constexpr int BS_Y = 512;           // doubles per wave: after the row pass (halo columns kept)
 
 __device__ inline bool blur_is_small(const DropPlan& p) {
-  return p.r1 > 0 && p.r1 <= 31 && (p.pw + 2 * p.r2) * (p.ph + 2 * p.r1) <= BS_X && (p.pw + 2 * p.r2) * p.ph <= BS_Y;
+  return p.r1 > 0 && p.r1 <= 31 && (p.ew + 2 * p.r2) * (p.eh + 2 * p.r1) <= BS_X && (p.ew + 2 * p.r2) * p.eh <= BS_Y;
 }
 
 // blurred drops neither k_blur_small nor k_blur_fused can take (radius > BR_MAX): two global passes
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
   // before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
   int npts = fov_polygon(d, cam, dm.He, dm.We, px, py);
   if (p.status != RR_DROP_OK || npts == 0) size = 0;
-  if (size > 0 && blur_is_slow(p)) size += (int64_t)p.pw * p.ph;
+  if (size > 0 && blur_is_slow(p)) size += (int64_t)p.ew * p.eh;
   sc.npts[gi] = npts;
   sc.sizes[gi] = size;
   sc.plan[gi] = p;
@@ -364,14 +376,16 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     if (!any) status = RR_DROP_EMPTY_FOV;
     if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
       colour_from_sums(S, sc.fconst[f * 2 + 0], sc.fconst[f * 2 + 1], rec.K);
-      if (p.r1 > 0) {                  // finished padded tile written by the blur kernels
-        rec.x0 = p.vis_x0;
-        rec.y0 = p.vis_y0;
-        rec.x1 = p.vis_x0 + p.vis_w;
-        rec.y1 = p.vis_y0 + p.vis_h;
-        rec.ox = p.crop_x - p.vis_x0;
-        rec.oy = p.crop_y - p.vis_y0;
-        rec.pitch = p.pw;
+      if (p.r1 > 0) {                  // finished effective tile written by the blur kernels
+        const int fx0 = p.vis_x0 - p.crop_x + (p.shift - p.r2), fy0 = p.vis_y0 - p.crop_y + (p.shift - p.r1);   // its frame position
+        rec.x0 = imax(p.vis_x0, fx0);
+        rec.y0 = imax(p.vis_y0, fy0);
+        rec.x1 = imin(p.vis_x0 + p.vis_w, fx0 + p.ew);
+        rec.y1 = imin(p.vis_y0 + p.vis_h, fy0 + p.eh);
+        if (rec.x1 <= rec.x0 || rec.y1 <= rec.y0) { rec.x0 = rec.y0 = rec.x1 = rec.y1 = 0; }
+        rec.ox = -fx0;
+        rec.oy = -fy0;
+        rec.pitch = p.ew;
         rec.off = p.a1_off;
       } else {                         // no blur: the pad is exact zeros (a no-op in the blend); read the raw tile
         const int rx0 = p.vis_x0 - p.crop_x + p.shift, ry0 = p.vis_y0 - p.crop_y + p.shift;   // frame position of raw (0,0)
@@ -487,9 +501,10 @@ __device__ inline bool tile_coords_safe(const DropPlan& p) {
   return cmax < 3.0e7;
 }
 __device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
+  if (!((sh + 4) * (sw + 4) <= TEX_LDS && p.kind == KIND_ROT && p.nW <= NW_MAX && p.tw <= TW_MAX && tile_coords_safe(p))) return false;
+  if (p.rs_mode == RS_AREA_FAST) return true;                      // integer ratios: per-wave sequential chains
   const int rows_per_dy = (int)ceil(p.scale_y) + 3;
-  return (sh + 4) * (sw + 4) <= TEX_LDS && p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.nW <= NW_MAX && p.tw <= TW_MAX &&
-         rows_per_dy * p.tw <= BUF_MAX && tile_coords_safe(p);
+  return p.rs_mode == RS_AREA && rows_per_dy * p.tw <= BUF_MAX;
 }
 
 // texture -> LDS with a 2-texel zero border (pitch sw+4).  Border texels are zeroed directly,
@@ -682,10 +697,78 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   const int pitch = imin(imax(tile_pitch(p, sh, sw), 1), CAN_W);
   const int Rw = imax(imin(ROWS_W, CAN_W / pitch), 1);       // canvas rows a wave stages at a time
   const float inv_pitch = 1.0f / (float)pitch, inv_tw = 1.0f / (float)tw;
-  int k_dy = (int)(((double)(BUF_MAX / tw) - 3.0) / sy_scale);
-  if (k_dy < 1) k_dy = 1;
   double* can = s_can[wave];
   int4* rowp = s_row[wave];
+  if (p.rs_mode == RS_AREA_FAST) {
+    // cv2's ResizeAreaFast: every output pixel is ONE sequential chain over its isx*isy source
+    // samples (k = ky*isx + kx, groups of four pre-added).  The chains of a destination row are
+    // split over up to four waves; a wave stages only the canvas columns of its own pixels and
+    // lane l carries the chain of its l-th pixel.
+    const int isx = p.isx, isy = p.isy, area = isx * isy, n4 = area & ~3;
+    const float scale = 1.0f / (float)area;
+    const int nsplit = th >= 3 ? 1 : (th == 2 ? 2 : 4);        // waves per destination row
+    const int rows_par = 4 / nsplit;
+    for (int dyb = 0; dyb < th; dyb += rows_par) {
+      const int dy = dyb + wave / nsplit, part = wave % nsplit;
+      const int dx0 = (part * tw) / nsplit, dx1 = ((part + 1) * tw) / nsplit;
+      if (dy >= th || dx1 <= dx0) continue;
+      const int colA = dx0 * isx, colB = dx1 * isx;
+      const int pitch2 = imax(imin(pitch, colB - colA), 1);
+      const int Rw2 = imax(imin(ROWS_W, CAN_W / pitch2), 1);
+      const float inv_pitch2 = 1.0f / (float)pitch2;
+      double sum = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
+      int k = 0;
+      for (int c0 = dy * isy; c0 < (dy + 1) * isy; c0 += Rw2) {
+        const int nr = imin(Rw2, (dy + 1) * isy - c0);
+        if (lane < nr) {
+          const int c = c0 + lane;
+          const int ry = p.flip ? (p.nH - 1 - c) : c;
+          const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
+          int xa, n;
+          row_interval(p, geom, X0, Y0, xa, n);
+          const int xa2 = imax(xa, colA), xe2 = imin(xa + n, colB);
+          rowp[lane] = make_int4(X0, Y0, xa2, imax(imin(xe2 - xa2, pitch2), 0));
+        }
+        wave_lds_sync();
+        const int nidx = nr * pitch2;
+        for (int idx = lane; idx < nidx; idx += 128) {
+          const int ia = idx, ib = imin(idx + 64, nidx - 1);
+          const int ra = (int)(((float)ia + 0.5f) * inv_pitch2), xa = ia - ra * pitch2;
+          const int rb = (int)(((float)ib + 0.5f) * inv_pitch2), xb = ib - rb * pitch2;
+          const int4 rwa = rowp[ra], rwb = rowp[rb];
+          const bool oka = xa < rwa.w, okb = (idx + 64 < nidx) && xb < rwb.w;
+          const int2 da = s_adbd[rwa.z + (oka ? xa : 0)], db = s_adbd[rwb.z + (okb ? xb : 0)];
+          double va, vb;
+          lds_rot_sample2(s_tex, s_lut, P, sh, sw, rwa.x, rwa.y, da, rwb.x, rwb.y, db, va, vb);
+          if (oka) can[ia] = va;
+          if (okb) can[ib] = vb;
+        }
+        wave_lds_sync();
+        const bool mine = lane < dx1 - dx0;
+        for (int r = 0; r < nr; r++) {
+          const int4 rw = rowp[r];
+          const double* row = can + r * pitch2 - rw.z;
+          for (int kx = 0; kx < isx; kx++, k++) {
+            const int col = (dx0 + lane) * isx + kx;
+            const double v = (mine && col >= rw.z && col < rw.z + rw.w) ? row[col] : 0.0;
+            if (k >= n4) sum = sum + v;
+            else {
+              const int m = k & 3;
+              if (m == 0) q0 = v;
+              else if (m == 1) q1 = v;
+              else if (m == 2) q2 = v;
+              else sum = sum + (((q0 + q1) + q2) + v);
+            }
+          }
+        }
+        wave_lds_sync();
+      }
+      if (lane < dx1 - dx0) A0[dy * tw + dx0 + lane] = clip01(sum * (double)scale);
+    }
+    continue;
+  }
+  int k_dy = (int)(((double)(BUF_MAX / tw) - 3.0) / sy_scale);
+  if (k_dy < 1) k_dy = 1;
   for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
     const int dy1 = imin(dy0 + k_dy, th);
     const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
@@ -782,7 +865,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
 constexpr int BLUR_ITEMS_PER_DROP = 8;
 
 __device__ inline int blur_subtiles(const DropPlan& p, const BlurLayout& L) {
-  return ((p.pw + L.wo - 1) / L.wo) * ((p.ph + L.ho - 1) / L.ho);
+  return ((p.ew + L.wo - 1) / L.wo) * ((p.eh + L.ho - 1) / L.ho);
 }
 
 __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max_drops, const int32_t* tex_h, const int32_t* tex_w,
@@ -792,30 +875,32 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   const int chunk = (n + 1023) / 1024;
   const int i0 = t * chunk, i1 = min(i0 + chunk, n);
   const int64_t base = (int64_t)f * max_drops;
-  int c[5] = {0, 0, 0, 0, 0};       // #rot-fast, #generic, #fused blur items, #slow blur drops, #small blur drops
+  int c[6] = {0, 0, 0, 0, 0, 0};    // #rot-fast (general), #generic, #fused blur items, #slow blur, #small blur, #rot-fast (integer ratio)
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
-    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) c[0]++; else c[1]++;
+    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
     if (p.r1 > 0) {
       if (blur_is_small(p)) { c[4]++; continue; }
       const BlurLayout L = blur_layout(p);
       if (L.fused) c[2] += imin(blur_subtiles(p, L), BLUR_ITEMS_PER_DROP); else c[3]++;
     }
   }
-  __shared__ int sh[1024][5];
-  for (int k = 0; k < 5; k++) sh[t][k] = c[k];
+  __shared__ int sh[1024][6];
+  for (int k = 0; k < 6; k++) sh[t][k] = c[k];
   __syncthreads();
   for (int ofs = 1; ofs < 1024; ofs <<= 1) {
-    int v[5] = {0, 0, 0, 0, 0};
+    int v[6] = {0, 0, 0, 0, 0, 0};
     if (t >= ofs)
-      for (int k = 0; k < 5; k++) v[k] = sh[t - ofs][k];
+      for (int k = 0; k < 6; k++) v[k] = sh[t - ofs][k];
     __syncthreads();
-    for (int k = 0; k < 5; k++) sh[t][k] += v[k];
+    for (int k = 0; k < 6; k++) sh[t][k] += v[k];
     __syncthreads();
   }
-  int o[5];
-  for (int k = 0; k < 5; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
+  int o[6];
+  for (int k = 0; k < 6; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
+  const int n_int = sh[1023][5];     // integer-ratio drops go to the FRONT of the rot list (longest blocks first)
+  o[0] += n_int;
   int32_t* lrot = sc.list_rot + base;
   int32_t* lgen = sc.list_gen + base;
   int32_t* lslow = sc.list_slow + base;
@@ -824,7 +909,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
-    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) lrot[o[0]++] = i; else lgen[o[1]++] = i;
+    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
     if (p.r1 > 0) {
       if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
       const BlurLayout L = blur_layout(p);
@@ -841,8 +926,10 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
       }
     }
   }
-  if (t == 1023)
+  if (t == 1023) {
     for (int k = 0; k < 5; k++) sc.counts[f * 8 + k] = sh[1023][k];
+    sc.counts[f * 8 + 0] = sh[1023][0] + sh[1023][5];
+  }
 }
 
 // gaussian half-table: hw[k] = w[k], k = 0..r (centre at r), sequential normalisation
@@ -894,7 +981,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const int64_t gi = (int64_t)f * max_drops + item.x;
   const DropPlan& p = sc.plan[gi];
   const BlurLayout L = blur_layout(p);
-  const int r1 = p.r1, r2 = p.r2, pw = p.pw, ph = p.ph;
+  const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;            // the tile being produced is the EFFECTIVE tile
   if (cur != item.x && !(dbg & 256)) {                 // the weight tables depend on the drop only
     __syncthreads();
     if ((t >> 6) == 0) gauss_half_table_wave(p.sig1, r1, hw1);
@@ -902,8 +989,8 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
     cur = item.x;                      // (the barrier after the tile load publishes the tables)
   }
   const double* src = sc.arena + p.a0_off;          // raw tile (tw x th); the pad is implicit zeros
-  double* dst = sc.arena + p.a1_off;                // finished padded tile
-  const int shift = p.shift, tw = p.tw, th = p.th;
+  double* dst = sc.arena + p.a1_off;                // finished effective tile (ew x eh); raw sits at (r2, r1) inside it
+  const int tw = p.tw, th = p.th;
   const int ntx = (pw + L.wo - 1) / L.wo, nty = (ph + L.ho - 1) / L.ho;
   (void)nty;
   for (int st = item.y; st < item.y + item.z; st++) {
@@ -912,8 +999,10 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
     {
       const int ho = imin(L.ho, ph - y0);
       const int wo = imin(L.wo, pw - x0);
-      const int wi = wo + 2 * r2, hi = ho + 2 * r1;       // LDS tile with zero halos
-      const float inv_wi = 1.0f / (float)wi, inv_wo = 1.0f / (float)wo;
+      const int hop = (ho + 3) & ~3;                      // rows/columns padded to the 4-output blocks
+      const int wi = wo + 2 * r2, hi = hop + 2 * r1;      // LDS input tile with zero halos (+ slack rows)
+      const int yp = blur_y_pitch(wo, r2);                // odd pitch of the row-pass result
+      const float inv_wi = 1.0f / (float)wi;
       // haloed tile -> LDS; eight independent global loads in flight per thread
       const int nx = (dbg & 512) ? 0 : wi * hi;
       for (int base = t; base < nx; base += 2048) {
@@ -922,58 +1011,85 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
         for (int k = 0; k < 8; k++) {
           const int idx = base + 256 * k;
           const int yy = (int)(((float)idx + 0.5f) * inv_wi), xx = idx - yy * wi;
-          const int y = y0 - r1 + yy - shift, x = x0 - r2 + xx - shift;      // raw-tile coordinates
-          v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
+          const int yt = y0 - r1 + yy, xt = x0 - r2 + xx;                    // effective-tile coordinates
+          const int y = yt - r1, x = xt - r2;                                // raw-tile coordinates
+          v[k] = (idx < nx && yt < ph && xt < pw && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++)
           if (base + 256 * k < nx) X[base + 256 * k] = v[k];
       }
       __syncthreads();
-      // axis 0 (rows, sigma = c): symmetric correlate1d; four independent outputs per thread
-      const int nv = (dbg & 1024) ? 0 : wi * ho;
-      for (int base = t; base < nv; base += 1024) {
-        double acc[4];
-        const double* col[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int idx = imin(base + 256 * k, nv - 1);
-          col[k] = X + idx + r1 * wi;                 // (row yy + r1, column xx) of the haloed tile
-          acc[k] = col[k][0] * hw1[r1];
+      // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns column x and FOUR consecutive
+      // rows; as the tap distance shrinks the upper/lower operand windows slide by one row, so each
+      // step needs two new LDS values instead of eight (register rotation).  Lanes run along x.
+      {
+        const int nrb = hop >> 2;
+        const int nv = (dbg & 1024) ? 0 : nrb * wi;
+        for (int idx = t; idx < nv; idx += 256) {
+          const int rb = (int)(((float)idx + 0.5f) * inv_wi), x = idx - rb * wi;
+          const double* c0 = X + (4 * rb + r1) * wi + x;                      // centre of the first of the four rows
+          const double wc = hw1[r1];
+          double acc0 = c0[0] * wc, acc1 = c0[wi] * wc, acc2 = c0[2 * wi] * wc, acc3 = c0[3 * wi] * wc;
+          // operands for ii = -r1: upper rows (y+ii) and lower rows (y-ii) of outputs 0..3
+          double a0 = c0[(-r1) * wi], a1 = c0[(1 - r1) * wi], a2 = c0[(2 - r1) * wi], a3 = c0[(3 - r1) * wi];
+          double b0 = c0[r1 * wi], b1 = c0[(1 + r1) * wi], b2 = c0[(2 + r1) * wi], b3 = c0[(3 + r1) * wi];
+          for (int ii = -r1; ii < 0; ii++) {
+            const double w = hw1[ii + r1];
+            const double na = c0[(4 + ii) * wi];                              // next upper row of output 3
+            const double nb = c0[(-ii - 1) * wi];                             // next lower row of output 0
+            acc0 = acc0 + (a0 + b0) * w;
+            acc1 = acc1 + (a1 + b1) * w;
+            acc2 = acc2 + (a2 + b2) * w;
+            acc3 = acc3 + (a3 + b3) * w;
+            a0 = a1; a1 = a2; a2 = a3; a3 = na;
+            b3 = b2; b2 = b1; b1 = b0; b0 = nb;
+          }
+          const int yb = 4 * rb;
+          double* o = Y + yb * yp + x;
+          if (yb < ho) o[0] = acc0;
+          if (yb + 1 < ho) o[yp] = acc1;
+          if (yb + 2 < ho) o[2 * yp] = acc2;
+          if (yb + 3 < ho) o[3 * yp] = acc3;
         }
-        for (int ii = -r1; ii < 0; ii++) {
-          const double w = hw1[ii + r1];
-          const int o = ii * wi;
-#pragma unroll
-          for (int k = 0; k < 4; k++) acc[k] = acc[k] + (col[k][o] + col[k][-o]) * w;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (base + 256 * k < nv) Y[base + 256 * k] = acc[k];
       }
       __syncthreads();
-      // axis 1 (columns, sigma = c/2)
-      const int nh = (dbg & 2048) ? 0 : wo * ho;
-      for (int base = t; base < nh; base += 1024) {
-        double acc[4];
-        const double* row[4];
-        int oidx[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int idx = imin(base + 256 * k, nh - 1);
-          const int yy = (int)(((float)idx + 0.5f) * inv_wo), xx = idx - yy * wo;
-          row[k] = Y + yy * wi + xx + r2;
-          oidx[k] = (y0 + yy) * pw + (x0 + xx);
-          acc[k] = (r2 > 0) ? row[k][0] * hw2[r2] : row[k][0];
+      // axis 1 (columns, sigma = c/2): a thread owns row y and four consecutive columns; lanes run
+      // down the rows (odd pitch -> distinct banks).
+      {
+        const int ncb = (wo + 3) >> 2;
+        const int nh = (dbg & 2048) ? 0 : ncb * ho;
+        const float inv_ho = 1.0f / (float)ho;
+        for (int idx = t; idx < nh; idx += 256) {
+          const int cb = (int)(((float)idx + 0.5f) * inv_ho), yy = idx - cb * ho;
+          const double* c0 = Y + yy * yp + 4 * cb + r2;                       // centre of the first of the four columns
+          double acc0, acc1, acc2, acc3;
+          if (r2 > 0) {
+            const double wc = hw2[r2];
+            acc0 = c0[0] * wc; acc1 = c0[1] * wc; acc2 = c0[2] * wc; acc3 = c0[3] * wc;
+            double a0 = c0[-r2], a1 = c0[1 - r2], a2 = c0[2 - r2], a3 = c0[3 - r2];
+            double b0 = c0[r2], b1 = c0[1 + r2], b2 = c0[2 + r2], b3 = c0[3 + r2];
+            for (int ii = -r2; ii < 0; ii++) {
+              const double w = hw2[ii + r2];
+              const double na = c0[4 + ii];
+              const double nb = c0[-ii - 1];
+              acc0 = acc0 + (a0 + b0) * w;
+              acc1 = acc1 + (a1 + b1) * w;
+              acc2 = acc2 + (a2 + b2) * w;
+              acc3 = acc3 + (a3 + b3) * w;
+              a0 = a1; a1 = a2; a2 = a3; a3 = na;
+              b3 = b2; b2 = b1; b1 = b0; b0 = nb;
+            }
+          } else {
+            acc0 = c0[0]; acc1 = c0[1]; acc2 = c0[2]; acc3 = c0[3];
+          }
+          const int xb = 4 * cb;
+          double* o = dst + (int64_t)(y0 + yy) * pw + (x0 + xb);
+          if (xb < wo) o[0] = acc0;
+          if (xb + 1 < wo) o[1] = acc1;
+          if (xb + 2 < wo) o[2] = acc2;
+          if (xb + 3 < wo) o[3] = acc3;
         }
-        for (int ii = -r2; ii < 0; ii++) {
-          const double w = hw2[ii + r2];
-#pragma unroll
-          for (int k = 0; k < 4; k++) acc[k] = acc[k] + (row[k][ii] + row[k][-ii]) * w;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (base + 256 * k < nh) dst[oidx[k]] = acc[k];
       }
       __syncthreads();
     }
@@ -993,11 +1109,11 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
   const int32_t* list = sc.list_small + (int64_t)f * max_drops;
   for (int it = blockIdx.x * 4 + wave; it < n_items; it += gridDim.x * 4) {
     const DropPlan& p = sc.plan[(int64_t)f * max_drops + list[it]];
-    const int r1 = p.r1, r2 = p.r2, pw = p.pw, ph = p.ph;
+    const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;          // effective tile
     const int wi = pw + 2 * r2, hi = ph + 2 * r1;
     const double* raw = sc.arena + p.a0_off;        // raw tile (tw x th); the pad is implicit zeros
-    double* tile = sc.arena + p.a1_off;             // finished padded tile
-    const int shift = p.shift, tw = p.tw, th = p.th;
+    double* tile = sc.arena + p.a1_off;             // finished effective tile
+    const int tw = p.tw, th = p.th;
     // weights: lane l holds w(distance l) of each axis
     double w1, w2 = 0.0;
     {
@@ -1020,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
       for (int k = 0; k < 4; k++) {
         const int idx = base + 64 * k;
         const int yy = (int)(((float)idx + 0.5f) * inv_wi), xx = idx - yy * wi;
-        const int y = yy - r1 - shift, x = xx - r2 - shift;      // raw-tile coordinates
+        const int y = yy - 2 * r1, x = xx - 2 * r2;              // raw-tile coordinates (raw sits at (r2, r1) in the effective tile)
         v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? raw[y * tw + x] : 0.0;
       }
 #pragma unroll
@@ -1083,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_d
     const int64_t gi = (int64_t)f * max_drops + sc.list_slow[(int64_t)f * max_drops + it];
     const DropPlan& p = sc.plan[gi];
     const int r = AXIS == 0 ? p.r1 : p.r2;
-    const int pw = p.pw, ph = p.ph, n = pw * ph;
+    const int pw = p.ew, ph = p.eh, n = pw * ph;              // effective tile
     const double* raw = sc.arena + p.a0_off;
     double* fin = sc.arena + p.a1_off;
     double* tmp = fin + n;                            // scratch tile reserved by k_plan for slow drops
@@ -1092,11 +1208,11 @@ __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_d
     for (int idx = threadIdx.x; idx < n; idx += 256) {
       const int y = idx / pw, x = idx - y * pw;
       if (AXIS == 0) {
-        const int rx = x - p.shift;
+        const int rx = x - p.r2;
         double acc = 0.0;
         if (rx >= 0 && rx < p.tw) {                   // a column outside the raw tile is all zeros
           auto R = [&](int yy) -> double {
-            const int ry = yy - p.shift;
+            const int ry = yy - p.r1;
             return (ry >= 0 && ry < p.th) ? raw[ry * p.tw + rx] : 0.0;
           };
           acc = R(y) * hw[r];

@@ -49,13 +49,13 @@ struct DropPlan {
   int32_t r1, r2;            // gaussian radii along axis 0 (rows) / axis 1 (cols)
   int32_t vis_x0, vis_y0, vis_w, vis_h;   // footprint inside the frame
   int32_t crop_x, crop_y;    // padded-tile coordinates of the footprint origin
-  int32_t final_buf;         // unused (kept for layout stability)
+  int32_t ew;                // effective blurred tile width  tw + 2*r2 (== tw when not blurred)
   int32_t bw0;               // warpPerspective block width
   int32_t nW, nH;            // rotate_bound canvas
   int32_t rs_mode;           // RS_*
   int32_t isx, isy;          // integer scales (RS_AREA_FAST)
-  int32_t pad0;
-  int64_t a0_off, a1_off;    // arena offsets in doubles: raw tile (tw x th) / finished padded tile (pw x ph, blurred drops only)
+  int32_t eh;                // effective blurred tile height th + 2*r1
+  int64_t a0_off, a1_off;    // arena offsets in doubles: raw tile (tw x th) / finished effective tile (ew x eh, blurred drops only)
   double sig1, sig2;         // c, c/2 (bad_weather.py:291)
   double tau_one, g;         // exposure*length_opacity, tau_one/tau_zero (bad_weather.py:425-427,443)
   double mi[9];              // inverse homography (Big)
@@ -602,9 +602,9 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
   p.nW = p.nH = 0;
   p.rs_mode = RS_AREA;
   p.isx = p.isy = 1;
-  p.pad0 = 0;
+  p.eh = 0;
   p.a0_off = p.a1_off = 0;
-  p.final_buf = 0;
+  p.ew = 0;
   p.scale_x = p.scale_y = p.inv_sx = p.inv_sy = 1.0;
   for (int i = 0; i < 9; i++) p.mi[i] = 0.0;
   for (int i = 0; i < 6; i++) p.ma[i] = 0.0;
@@ -736,11 +736,14 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
   p.tau_one = cam.exposure_s * length_opacity;
   p.g = p.tau_one / cam.tau_zero;
 
-  p.final_buf = 0;
-  // arena need: the raw tile, plus the padded tile when the drop is defocus-blurred (the pad of an
-  // un-blurred drop is all zeros and never materialised; the kernels may add scratch on top)
-  int64_t area = (int64_t)p.pw * (int64_t)p.ph;
-  size_out = (p.vis_w > 0 && p.vis_h > 0) ? (int64_t)p.tw * p.th + (p.r1 > 0 ? area : 0) : 0;
+  // The reference pads the tile by shift = int(10c) >= radius, but the truncated Gaussian only
+  // reaches r1 rows / r2 columns beyond the raw tile: everything further out is EXACTLY zero, and
+  // a zero alpha is a no-op in the blend and in the mask.  Only this effective tile is ever
+  // materialised:  origin (shift - r2, shift - r1) inside the padded tile.
+  p.ew = p.tw + 2 * p.r2;
+  p.eh = p.th + 2 * p.r1;
+  // arena need: the raw tile, plus the effective tile when the drop is defocus-blurred
+  size_out = (p.vis_w > 0 && p.vis_h > 0) ? (int64_t)p.tw * p.th + (p.r1 > 0 ? (int64_t)p.ew * p.eh : 0) : 0;
 }
 
 // one output sample of the symmetric correlate1d (scipy ni_filters.c), zero extension.
