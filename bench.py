@@ -39,7 +39,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=4, help='frames per step and per GPU')
+    ap.add_argument('--batch', type=int, default=16, help='frames per step and per GPU')
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     ap.add_argument('--rate', type=int, default=100, help='mm/hr (selects the synthetic drop count)')
@@ -158,6 +158,17 @@ def main():
         avg_ms = dom_ms / dom_launches
         alg = algorithmic_bytes(H, W, He, We, n_drops_mean) * B
         achieved = alg / (avg_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this very
+        # command (scripts/gpu_profile.sh -> profiles/*_traffic.json); null when no matching pass exists
+        traffic = None
+        tfile = os.environ.get('RAIN_TRAFFIC_JSON', os.path.join(ROOT, 'profiles', 'r01_traffic.json'))
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get('batch') == B and tj.get('workload') == [W, H, args.rate]:
+                    traffic = tj['kernels'].get(dom_name, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
         out = {
             "metric": "rainy frames/sec @ 1242x375, 100 mm/hr",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,7 +178,7 @@ def main():
                                    "precomputed particles; BASELINE.json configs[2]" % (W, H, args.rate, N, n_drops_mean),
                        "frames_per_step_per_gpu": B, "envmap": "%dx%d" % (We, He), "parallelism": "frames sharded, dp%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
         }

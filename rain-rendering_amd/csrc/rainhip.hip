@@ -270,6 +270,13 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
 // ---------------------------------------------------------------------------
 // colour: FOV polygon row spans x prefix table, one wave per drop
 // ---------------------------------------------------------------------------
+__device__ inline void wave_lds_sync() {
+  // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
+  // stops the compiler from moving accesses across the hand-off point.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // fov_rowspan (rr_device.h) with the rounded edge intersection evaluated in double: exact,
 // because |2*num+den| < 2^26 and a non-integer quotient is at least 1/(2*den) away from an integer.
 __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, int n, int y, int We, int& xl, int& xr) {
@@ -298,7 +305,9 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
 }
 
 // Colour, pass 1: one wave per (drop, row band): polygon row spans x prefix table, wave reduce.
-constexpr int COL_BANDS = 1;        // row bands per drop (8 = one per XCD L2 was measured slower: the kernel is ALU-bound)
+constexpr int COL_BANDS = 1;        // row bands per drop (8 = one band per XCD L2 measured 2.7x SLOWER: per-wave edge scan dominates)
+
+constexpr int HE_MAX = 1024;        // tallest environment map the LDS span tables hold (else per-row edge scan)
 
 __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
   const int f = blockIdx.y;
@@ -308,6 +317,7 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
   if (i >= frames[f].n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
   const int n = sc.npts[gi];
+  __shared__ int s_xl[4][HE_MAX], s_xr[4][HE_MAX];
   double S[4] = {0, 0, 0, 0};
   int any = 0;
   if (n > 0) {
@@ -321,14 +331,57 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
     const int rows_per_band = (dm.He + COL_BANDS - 1) / COL_BANDS;
     const int ya = max(max(ymin, 0), band * rows_per_band), yb = min(min(ymax, dm.He - 1), (band + 1) * rows_per_band - 1);
     const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
+    const bool use_lds = dm.He <= HE_MAX;
+    if (use_lds) {
+      // scan conversion: every edge only visits the rows it spans (~2 edges per row) instead of
+      // every row testing all edges; the wave owns its span tables, rows of one edge are distinct
+      int* xl = s_xl[wave];
+      int* xr = s_xr[wave];
+      for (int y = ya + lane; y <= yb; y += 64) { xl[y] = 1 << 30; xr[y] = -(1 << 30); }
+      wave_lds_sync();
+      for (int e = 0; e < n; e++) {
+        const int j = (e + 1 == n) ? 0 : e + 1;
+        const int x0 = px[e], y0 = py[e], x1 = px[j], y1 = py[j];
+        if (y0 == y1) {
+          if (lane == 0 && y0 >= ya && y0 <= yb) {
+            xl[y0] = min(xl[y0], min(x0, x1));
+            xr[y0] = max(xr[y0], max(x0, x1));
+          }
+        } else {
+          const bool swp = y1 < y0;
+          const int xa = swp ? x1 : x0, yA = swp ? y1 : y0, xb = swp ? x0 : x1, yB = swp ? y0 : y1;
+          const int den = yB - yA;
+          const double inv = 1.0 / (double)(2 * den);
+          for (int y = max(yA, ya) + lane; y <= min(yB, yb); y += 64) {
+            const int nn = 2 * (xb - xa) * (y - yA) + den;
+            // floor(nn / (2*den)): the reciprocal product can be off by one ulp only; fix up exactly
+            int q = (int)floor((double)nn * inv);
+            const int rem = nn - q * 2 * den;
+            if (rem < 0) q -= 1; else if (rem >= 2 * den) q += 1;
+            const int xv = xa + q;
+            xl[y] = min(xl[y], xv);
+            xr[y] = max(xr[y], xv);
+          }
+        }
+        wave_lds_sync();
+      }
+    }
     for (int y = ya + lane; y <= yb; y += 64) {
-      int xl, xr;
-      if (fov_rowspan_fast(px, py, n, y, dm.We, xl, xr)) {
+      int xl_, xr_;
+      bool ok;
+      if (use_lds) {
+        xl_ = max(s_xl[wave][y], 0);
+        xr_ = min(s_xr[wave][y], dm.We - 1);
+        ok = xl_ <= xr_;
+      } else {
+        ok = fov_rowspan_fast(px, py, n, y, dm.We, xl_, xr_);
+      }
+      if (ok) {
         any = 1;
         const double* row = P + (int64_t)y * (dm.We + 1) * 4;
-        const double* hi = row + (int64_t)(xr + 1) * 4;
-        const double* lo = row + (int64_t)xl * 4;
-        if (xl > 0) {
+        const double* hi = row + (int64_t)(xr_ + 1) * 4;
+        const double* lo = row + (int64_t)xl_ * 4;
+        if (xl_ > 0) {
           for (int k = 0; k < 4; k++) S[k] += hi[k] - lo[k];
         } else {
           for (int k = 0; k < 4; k++) S[k] += hi[k];                 // P[row][0] == 0
@@ -652,12 +705,6 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   }
 }
 
-__device__ inline void wave_lds_sync() {
-  // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
-  // stops the compiler from moving accesses across the hand-off point.
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
