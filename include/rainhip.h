@@ -94,7 +94,7 @@ typedef struct {
   const double* omega;            /* He*We solid angles (generator.py:410) */
   const rr_drop* drops;           /* n_drops records in reference order */
   int32_t n_drops;
-  int32_t strategy;               /* 0: default rendering strategy (rendering_strategy=None) */
+  int32_t strategy;               /* 0: default (rendering_strategy=None); 1: 'white' (bad_weather.py:349-353) */
   double opacity_attenuation;     /* --opacity_attenuation */
 } rr_frame_in;
 

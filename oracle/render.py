@@ -554,10 +554,30 @@ def fov_colour(env_map_xyY, solid_angle_map, poly_int, fc, faithful=True):
 
 
 def add_drop_to_image(env_map_xyY, solid_angle_map, fc, drop_fov_pts, drop_minC, bg_shape, rainy_bg, rainy_mask,
-                      tile, drop, cam, opacity_attenuation=1.0, faithful=True):
-    """Default rendering strategy branch of bad_weather.py:336-462.  Raises (like the
-    reference) when the drop must be skipped; the caller turns that into a status."""
+                      tile, drop, cam, opacity_attenuation=1.0, faithful=True, rendering_strategy=None):
+    """bad_weather.py:336-462: the default rendering strategy and 'white' ('naive_db' reads a
+    non-existent attribute in the reference, bad_weather.py:355, and cannot run).  Raises (like
+    the reference) when the drop must be skipped; the caller turns that into a status."""
     exposure_time = cam['exposure_ms'] / 1000.
+    if rendering_strategy in ['white']:
+        # bad_weather.py:349-353: gray tile, no colour, no defocus, no clamp of the origin
+        tau_zero = np.sqrt(DROP_SIZE) / 50
+        length_opacity = 1.
+        tau_one = exposure_time * length_opacity
+        drop_minC = np.array(drop_minC)
+        y0, x0 = int(drop_minC[1]), int(drop_minC[0])
+        rainy_bg_occ = rainy_bg[y0:y0 + tile.shape[0], x0:x0 + tile.shape[1], :].copy()
+        rainy_mask_occ = rainy_mask[y0:y0 + tile.shape[0], x0:x0 + tile.shape[1]].copy()
+        drop_vis = tile[:rainy_bg_occ.shape[0], :rainy_bg_occ.shape[1]]
+        drop_vis_alpha = drop_vis[:, :, 3]
+        drop_vis_alpha_ = np.expand_dims(drop_vis_alpha, axis=-1)
+        rainy_bg_occ = ((1. - ((drop_vis_alpha_ * tau_one) / exposure_time)) * rainy_bg_occ) + drop_vis[:, :, :3] * (
+            tau_one / tau_zero)
+        rainy_bg_occ = np.clip(rainy_bg_occ, 0, 1)
+        rainy_mask_occ += drop_vis_alpha
+        rainy_bg[y0:y0 + rainy_bg_occ.shape[0], x0:x0 + rainy_bg_occ.shape[1]] = rainy_bg_occ
+        rainy_mask[y0:y0 + tile.shape[0], x0:x0 + tile.shape[1]] = rainy_mask_occ
+        return drop_minC
     if len(drop_fov_pts) == 0:
         raise IndexError(ST_FOV_FAIL)                # pyclipper.AddPath on an empty path
     if not np.all(np.isfinite(drop_fov_pts)):
@@ -639,7 +659,7 @@ def quantise_mask(rainy_mask):
 
 def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textures, ratio, cam,
                  frame_seed, noise_std=0.0, noise_scale=0.0, opacity_attenuation=1.0,
-                 faithful=True, max_drops=None):
+                 faithful=True, max_drops=None, rendering_strategy=None):
     """The hot loop of Generator.run for one frame (generator.py:318,389-394,428-438,461-467).
 
     streak_list: the already filtered list of Streak objects (mutated like the reference does).
@@ -662,7 +682,7 @@ def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textur
                                        RADIUS, FOV_DEG, N_FOV, env_map_xyY.shape)
         try:
             add_drop_to_image(env_map_xyY, solid_angle_map, fc, pts, minC, bg.shape, rainy_bg, rainy_mask,
-                              tile, drop, cam, opacity_attenuation, faithful)
+                              tile, drop, cam, opacity_attenuation, faithful, rendering_strategy)
         except IndexError as e:                       # generator.py:185-189: any exception == skip
             status[i] = e.args[0] if e.args and isinstance(e.args[0], int) else ST_FOV_FAIL
     return dict(rainy_bg=rainy_bg, mask=rainy_mask, mask_i32=quantise_mask(rainy_mask),

@@ -65,9 +65,9 @@ class Generator:
         self.device = int(getattr(args, 'device', os.environ.get('LOCAL_RANK', '0')))
         self._hip = None
         self.stats = []
-        if self.rendering_strategy is not None:
-            raise NotImplementedError("rendering_strategy %r: only the default strategy runs on the HIP path "
-                                      "('naive_db' is broken in the reference, bad_weather.py:355)" % self.rendering_strategy)
+        if self.rendering_strategy not in (None, 'white'):
+            raise NotImplementedError("rendering_strategy %r: 'naive_db' reads a non-existent attribute in the reference "
+                                      "(bad_weather.py:355) and cannot run there either" % self.rendering_strategy)
         self.check_folders()
 
     def check_folders(self):
@@ -222,7 +222,8 @@ class Generator:
                         "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
                     drops = hip_backend.pack_drops(frame.table, keep, self.db, self.noise_std, self.noise_scale)
                     pending.append(dict(frame=dict(bg=bg, rainy_bg=rainy_bg, env_xyY=env_xyY, omega=omega, drops=drops,
-                                                   opacity_attenuation=self.opacity_attenuation),
+                                                   opacity_attenuation=self.opacity_attenuation,
+                                                   strategy=1 if self.rendering_strategy == 'white' else 0),
                                         out_rainy_path=out_rainy_path, out_rainy_mask_path=out_rainy_mask_path,
                                         out_env_path=out_env_path, env_bgr=env_bgr))
                     same_shape = all(p['frame']['bg'].shape == pending[0]['frame']['bg'].shape for p in pending)

@@ -216,12 +216,13 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
   rr_drop d = fr.drops[i];
   DropPlan p;
   int64_t size = 0;
-  plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, p, size);
+  plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size);
   int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
   int32_t* py = px + POLY_STRIDE;
   // the FOV polygon is evaluated for every drop: in the reference its failure is raised
   // before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
   int npts = fov_polygon(d, cam, dm.He, dm.We, px, py);
+  if (fr.strategy == 1) npts = -1;                // 'white': the FOV is computed by the reference but never used
   if (p.status != RR_DROP_OK || npts == 0) size = 0;
   if (size > 0 && blur_is_slow(p)) size += (int64_t)p.ew * p.eh;
   sc.npts[gi] = npts;
@@ -418,6 +419,21 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   int status = p.status;
   const int n = sc.npts[gi];
   if (n == 0) status = RR_DROP_FOV_FAIL;
+  if (n < 0) {                         // rendering_strategy 'white': gray tile, no colour
+    if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
+      rec.K[0] = rec.K[1] = rec.K[2] = 1.0;
+      rec.x0 = p.vis_x0;
+      rec.y0 = p.vis_y0;
+      rec.x1 = p.vis_x0 + p.vis_w;
+      rec.y1 = p.vis_y0 + p.vis_h;
+      rec.ox = -p.vis_x0;
+      rec.oy = -p.vis_y0;
+      rec.pitch = p.tw;
+      rec.off = p.a0_off;
+      rec.tau_one = p.tau_one;
+      rec.g = p.g;
+    }
+  }
   if (n > 0) {
     double S[4] = {0, 0, 0, 0};
     bool any = false;
@@ -1662,8 +1678,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ctx->err = "all frames of a batch must share H,W,He,We";
       return RR_E_ARG;
     }
-    if (in[f].strategy != 0) {
-      ctx->err = "only the default rendering strategy (0) is implemented";
+    if (in[f].strategy != 0 && in[f].strategy != 1) {
+      ctx->err = "rendering strategy must be 0 (default) or 1 ('white'); 'naive_db' is broken in the reference (bad_weather.py:355)";
       return RR_E_ARG;
     }
     if (in[f].n_drops < 0 || in[f].n_drops > 65536 || !in[f].bg || !in[f].rainy_bg || !in[f].env_xyY || !in[f].omega ||

@@ -592,8 +592,14 @@ RR_HD void invert3(const double m[9], double t[9]) {             // cv::invert 3
 }
 
 // Fills everything in `p` except the arena offsets.  `size_out` = doubles of arena needed.
+RR_HD int py_slice_index(int i, int n) {   // CPython slice normalisation of one bound, step 1
+  if (i < 0) { i += n; if (i < 0) i = 0; }
+  else if (i > n) i = n;
+  return i;
+}
+
 RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, const int32_t* tex_h, const int32_t* tex_w,
-                     double opacity_attenuation, DropPlan& p, int64_t& size_out) {
+                     double opacity_attenuation, int strategy, DropPlan& p, int64_t& size_out) {
   size_out = 0;
   p.status = RR_DROP_OK;
   p.tex = d.tex_index;
@@ -704,6 +710,24 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
     minCy = d.y0;
   }
 
+  if (strategy == 1) {
+    // rendering_strategy 'white' (bad_weather.py:349-353): no colour, no defocus, no clamp of the
+    // tile origin -- the region is a plain numpy slice, negative starts wrap like Python's.
+    p.pw = p.tw;
+    p.ph = p.th;
+    const int sx = py_slice_index(minCx, W), ex = py_slice_index(minCx + p.tw, W);
+    const int sy = py_slice_index(minCy, H), ey = py_slice_index(minCy + p.th, H);
+    p.vis_x0 = sx;
+    p.vis_y0 = sy;
+    p.vis_w = imax(ex - sx, 0);
+    p.vis_h = imax(ey - sy, 0);
+    p.tau_one = cam.exposure_s * 1.0;
+    p.g = p.tau_one / cam.tau_zero;
+    p.ew = p.tw;
+    p.eh = p.th;
+    size_out = (p.vis_w > 0 && p.vis_h > 0) ? (int64_t)p.tw * p.th : 0;
+    return;
+  }
   // circle of confusion (bad_weather.py:286-298,464-469)
   double o = fabs(d.wps[2]);
   double cc = ((o - cam.focus_plane) * cam.focal_sq) / (o * (cam.focus_plane - cam.focal_m) * cam.f_number);

@@ -279,7 +279,7 @@ class RainHip:
             fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY, fin[k].omega = _ptr(bg), _ptr(rb), _ptr(env), _ptr(om)
             fin[k].drops = _ptr(drops) if len(drops) else None
             fin[k].n_drops = len(drops)
-            fin[k].strategy = 0
+            fin[k].strategy = int(fr.get('strategy', 0))
             fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
             fout[k].rainy_rgb = _ptr(o['image_u8'])
             fout[k].rainy_bg_out = _ptr(o['rainy_bg'])

@@ -274,6 +274,23 @@ def main():
         out['add_%s_rainy_bg' % variant] = rb
         out['add_%s_mask' % variant] = rm
         out['add_%s_skipped' % variant] = np.array(st)
+    # ---- 8b. rendering_strategy 'white' (bad_weather.py:349-353): no cv2/pyclipper call at all ----
+    np.random.seed(0)
+    rb = rainy_bg.copy()
+    rm = rainy_mask.copy()
+    for i, d in enumerate(streaks):
+        tex_idx = orc.take_drop_texture_index(d, ratio)
+        if d.drop_type != orc.DropType.Big:
+            np.random.normal(0.0, 0.0)
+        import copy
+        dd = copy.deepcopy(d)
+        tile, minC = orc.make_drop_tile(dd, textures[tex_idx], 0.0, W, H)
+        rs = rbw.Streak()
+        rs.image_diameter_start, rs.image_diameter_end = dd.image_diameter_start, dd.image_diameter_end
+        rs.length = dd.length
+        rr.add_drop_to_image('kitti', env, sc.omega, np.array([]), minC, bg, rb, rm, sat, tile.copy(), rs, 'ambient', 'white', 1.0)
+    out['add_white_rainy_bg'] = rb
+    out['add_white_mask'] = rm
     out['add_scene'] = np.array([H, W, 60, 4200])
     out['add_rainy_bg_in'] = rainy_bg
 

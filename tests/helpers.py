@@ -101,7 +101,7 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def emu_render(scene, bg, rainy_bg, env_xyY, drops, opacity=1.0):
+def emu_render(scene, bg, rainy_bg, env_xyY, drops, opacity=1.0, strategy=0):
     emu = hostemu()
     texels, hs, ws, offs = hb.pack_streak_db(scene.db.streaks_light)
     H, W = bg.shape[:2]
@@ -112,13 +112,14 @@ def emu_render(scene, bg, rainy_bg, env_xyY, drops, opacity=1.0):
     emu.emu_render_frame(H, W, scene.He, scene.We, _p(bg), _p(rainy_bg), _p(env_xyY), _p(scene.omega), _p(drops), n,
                          ctypes.byref(scene.cam), ctypes.c_double(opacity), _p(texels), _p(hs), _p(ws), _p(offs),
                          _p(out['image_u8']), _p(out['rainy_bg']), _p(out['mask']), _p(out['mask_i32']), _p(out['status']),
-                         _p(out['K']))
+                         _p(out['K']), int(strategy))
     out['status'] = out['status'][:n]
     return out
 
 
-def oracle_render(scene, i, bg, rainy_bg, env_xyY, faithful=True, noise_std=0.0, noise_scale=0.0, max_drops=None):
+def oracle_render(scene, i, bg, rainy_bg, env_xyY, faithful=True, noise_std=0.0, noise_scale=0.0, max_drops=None, strategy=None):
     textures, ratio = scene.oracle_db()
     streaks = scene.oracle_streaks(i)
     return orc.render_frame(bg, rainy_bg, env_xyY, scene.omega, streaks, textures, ratio, scene.ocam, frame_seed=i,
-                            noise_std=noise_std, noise_scale=noise_scale, faithful=faithful, max_drops=max_drops)
+                            noise_std=noise_std, noise_scale=noise_scale, faithful=faithful, max_drops=max_drops,
+                            rendering_strategy=strategy)

@@ -21,10 +21,11 @@ int emu_sizeof_plan(void) { return (int)sizeof(DropPlan); }
 // plan + polygon for n drops.  poly: n*2*36 int32, npts: n, sizes: n
 int emu_plan(const rr_drop* drops, int n, const rr_camera* cam, int H, int W, int He, int We, const int32_t* tex_h,
              const int32_t* tex_w, double opacity, DropPlan* plans, int32_t* poly, int32_t* npts, int64_t* sizes) {
+  const int strategy = 0;
   Dims dm{H, W, He, We};
   for (int i = 0; i < n; i++) {
     int64_t size = 0;
-    plan_drop(drops[i], *cam, dm, tex_h, tex_w, opacity, plans[i], size);
+    plan_drop(drops[i], *cam, dm, tex_h, tex_w, opacity, strategy, plans[i], size);
     int32_t* px = poly + (int64_t)i * 2 * 36;
     npts[i] = fov_polygon(drops[i], *cam, He, We, px, px + 36);
     if (plans[i].status != RR_DROP_OK || npts[i] == 0) size = 0;
@@ -81,7 +82,7 @@ int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, con
 int emu_render_frame(int H, int W, int He, int We, const double* bg, const double* rainy_bg, const double* env,
                      const double* omega, const rr_drop* drops, int n, const rr_camera* cam, double opacity,
                      const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                     uint8_t* rgb, double* comp_out, double* mask, int32_t* mask_i32, int32_t* status, double* Kout) {
+                     uint8_t* rgb, double* comp_out, double* mask, int32_t* mask_i32, int32_t* status, double* Kout, int strategy) {
   Dims dm{H, W, He, We};
   // prefix table + frame constants
   std::vector<double> P((size_t)He * (We + 1) * 4, 0.0);
@@ -105,15 +106,25 @@ int emu_render_frame(int H, int W, int He, int We, const double* bg, const doubl
   for (int i = 0; i < n; i++) {
     int64_t size = 0;
     DropPlan& p = plans[i];
-    plan_drop(drops[i], *cam, dm, tex_h, tex_w, opacity, p, size);
+    plan_drop(drops[i], *cam, dm, tex_h, tex_w, opacity, strategy, p, size);
     int32_t px[36], py[36];
     int np_ = fov_polygon(drops[i], *cam, He, We, px, py);
+    if (strategy == 1) np_ = -1;            // 'white': the FOV is never consulted
     if (p.status != RR_DROP_OK || np_ == 0) size = 0;
     CompRec& rec = recs[i];
     memset(&rec, 0, sizeof(rec));
     int st = p.status;
-    if (np_ == 0) st = RR_DROP_FOV_FAIL;
-    if (np_ > 0) {
+    if (strategy == 1) {                    // 'white': no colour, no FOV dependency
+      if (size > 0) {
+        rec.K[0] = rec.K[1] = rec.K[2] = 1.0;
+        rec.x0 = p.vis_x0; rec.y0 = p.vis_y0; rec.x1 = p.vis_x0 + p.vis_w; rec.y1 = p.vis_y0 + p.vis_h;
+        rec.ox = -p.vis_x0; rec.oy = -p.vis_y0;
+        rec.pitch = p.pw; rec.tau_one = p.tau_one; rec.g = p.g;
+        tiles[i].resize((size_t)p.pw * p.ph);
+        emu_tile(&p, texels, tex_h, tex_w, tex_off, tiles[i].data());
+      }
+    } else if (np_ == 0) st = RR_DROP_FOV_FAIL;
+    if (strategy != 1 && np_ > 0) {
       int ymin = py[0], ymax = py[0];
       for (int k = 1; k < np_; k++) { ymin = imin(ymin, py[k]); ymax = imax(ymax, py[k]); }
       int ya = imax(ymin, 0), yb = imin(ymax, He - 1);

@@ -80,3 +80,21 @@ def test_gpu_fogged_background_and_opacity(rh, tmp_path):
     ref = h.orc.render_frame(bg, rainy, env, sc.omega, sc.oracle_streaks(0), textures, ratio, sc.ocam, frame_seed=0,
                              opacity_attenuation=0.7, faithful=True)
     _check(out, ref, 'fog')
+
+
+def test_gpu_white_strategy(rh, tmp_path):
+    """rendering_strategy='white' (bad_weather.py:349-353): gray streaks, no defocus, numpy-slice placement
+    (negative origins wrap), nothing skipped."""
+    sc = h.Scene(tmp_path, 96, 160, 250, seed0=41, far_fraction=0.1)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops, strategy=1)])[0]
+    ref = h.oracle_render(sc, 0, bg, bg, env, strategy='white')
+    assert not out['status'].any()
+    assert np.array_equal(out['mask'], ref['mask'])
+    assert np.array_equal(out['mask_i32'], ref['mask_i32'])
+    assert np.array_equal(out['rainy_bg'], ref['rainy_bg'])           # no colour constant involved: bit-exact composite
+    assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+    assert (drops['x0'] < 0).any() or (drops['y0'] < 0).any()          # the wrap-around path is exercised

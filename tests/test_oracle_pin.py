@@ -180,6 +180,22 @@ def test_add_drop_to_image_body(tmp_path, variant):
         assert np.abs(out['rainy_bg'] - G['add_scipy_rainy_bg']).max() < 1e-14
 
 
+def test_add_drop_to_image_white_strategy(tmp_path):
+    """rendering_strategy='white' through the reference's own add_drop_to_image: bit for bit."""
+    H, W, N, seed = (int(v) for v in G['add_scene'])
+    sc = h.Scene(tmp_path, H, W, N, seed0=seed, far_fraction=0.1)
+    bg, env = sc.frame_inputs(0)
+    textures, ratio = sc.oracle_db()
+    out = orc.render_frame(bg, G['add_rainy_bg_in'], env, sc.omega, sc.oracle_streaks(0), textures, ratio, sc.ocam,
+                           frame_seed=0, rendering_strategy='white')
+    assert not out['status'].any()                      # nothing is skipped in this strategy, not even > 10 m drops
+    assert np.array_equal(out['mask'], G['add_white_mask'])
+    assert np.array_equal(out['rainy_bg'], G['add_white_rainy_bg'])
+    # and the kernel arithmetic (host build) agrees with the oracle
+    emu = h.emu_render(sc, bg, G['add_rainy_bg_in'], env, sc.product_drops(0), strategy=1)
+    assert np.array_equal(emu['mask'], out['mask']) and np.array_equal(emu['rainy_bg'], out['rainy_bg'])
+
+
 def test_imsave_truncation_rule():
     """plt.imsave(np.clip(x[..., ::-1], 0, 1)) stores (x*255) truncated, RGBA (generator.py:466)."""
     x = G['imsave_in']
