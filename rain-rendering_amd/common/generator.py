@@ -113,6 +113,42 @@ class Generator:
                 print("\nTrace: %d of %d rain drops not rendered in %s" % (n_skip, len(o['status']), p['out_rainy_path']))
         pending.clear()
 
+    def compute_drop(self, bg, drop_dict, rainy_bg, rainy_mask, rainy_saturation_mask):
+        """Single-drop compatibility seam with the reference's signature (generator.py:119-191):
+        consumes the same RNG draws, composites ONE streak into rainy_bg / rainy_mask (in place and
+        returned) by calling the library with a one-record drop table.  self.env_map_xyY,
+        self.solid_angle_map, self.db and the camera must be set like Generator.run does.  Returns
+        (rainy_bg, rainy_mask, rainy_saturation_mask, None, blended, minC): `blended` is None when the
+        reference would have printed "Erroneous drop"; the tile itself stays on the GPU.  One launch
+        chain per drop -- use run() / rr_render_frames for throughput."""
+        H, W = bg.shape[:2]
+        t = drop_dict._table if hasattr(drop_dict, '_table') else None
+        if t is None:
+            from .bad_weather import StreakTable
+            t = StreakTable(1)
+            t.pid[0] = drop_dict.pid
+            t.wps[0], t.wpe[0] = drop_dict.world_position_start, drop_dict.world_position_end
+            t.ips[0], t.ipe[0] = drop_dict.image_position_start, drop_dict.image_position_end
+            t.iw1[0], t.iw2[0] = drop_dict.image_diameter_start, drop_dict.image_diameter_end
+            t.ratio[0], t.max_width[0], t.length[0] = drop_dict.ratio, drop_dict.max_width, drop_dict.length
+            t.type[0] = drop_dict.drop_type.value
+        drops = hip_backend.pack_drops(t, np.array([0]), self.db, self.noise_std, self.noise_scale)
+        if hasattr(drop_dict, 'image_position_start'):        # the in-place endpoint rotation (generator.py:152-161)
+            drop_dict.image_position_start[:] = t.ips[0]
+            drop_dict.image_position_end[:] = t.ipe[0]
+        out = self._hip_ctx().render_frames([dict(bg=bg, rainy_bg=rainy_bg, env_xyY=self.env_map_xyY,
+                                                  omega=self.solid_angle_map, drops=drops,
+                                                  opacity_attenuation=self.opacity_attenuation,
+                                                  strategy=1 if self.rendering_strategy == 'white' else 0)])[0]
+        ok = out['status'][0] == 0
+        if ok:
+            rainy_bg[...] = out['rainy_bg']
+            rainy_mask += out['mask']
+        else:
+            print('Erroneous drop (status %d)' % out['status'][0])
+        minC = np.array([drops['x0'][0], drops['y0'][0]])
+        return rainy_bg, rainy_mask, rainy_saturation_mask, None, (rainy_bg if ok else None), minC
+
     def run(self):
         folders_num = len(self.images)
         for folder_idx, sequence in enumerate(self.sequences):

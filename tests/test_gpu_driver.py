@@ -67,3 +67,34 @@ def test_main_cli_end_to_end(tmp_path, built):
     argv2 = argv[:-1] + ['--conflict_strategy', 'skip']
     gen2 = main.main(argv2)
     assert len(gen2.stats) == 0
+
+
+def test_compute_drop_seam_equals_batched_call(tmp_path, built):
+    """The reference-shaped single-drop seam Generator.compute_drop (generator.py:119-191), looped over a
+    frame's streaks in order, reproduces the batched rr_render_frames result bit for bit."""
+    import types
+    gen_mod = importlib.import_module('rain-rendering_amd.common.generator')
+    sc = h.Scene(tmp_path, 64, 96, 60, seed0=23)
+    bg, env = sc.frame_inputs(0)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    batched = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=sc.product_drops(0))])[0]
+    # fresh loaders (product_drops consumed the RNG and may have mutated the table)
+    sc2 = h.Scene(tmp_path / 'b', 64, 96, 60, seed0=23)
+    g = gen_mod.Generator.__new__(gen_mod.Generator)
+    g.db, g._hip, g.noise_std, g.noise_scale, g.opacity_attenuation, g.rendering_strategy = sc2.db, rh, 0.0, 0.0, 1.0, None
+    g.env_map_xyY, g.solid_angle_map = env, sc2.omega
+    fr = list(sc2.db.streaks_simulator.values())[0]
+    keep = h.hb.filter_streaks(fr.table, 96, 64)
+    streaks = [fr.table.streak(int(i)) for i in keep]
+    np.random.seed(0)
+    rainy, mask, sat = bg.copy(), np.zeros((64, 96)), np.zeros((64, 96, 3))
+    skipped = 0
+    for s in streaks:
+        rainy, mask, sat, _, blended, _ = g.compute_drop(bg, s, rainy, mask, sat)
+        skipped += blended is None
+    assert skipped == int(np.count_nonzero(batched['status']))
+    assert np.array_equal(mask, batched['mask'])
+    assert np.array_equal(rainy, batched['rainy_bg'])
+    rh.close()
