@@ -142,6 +142,58 @@ int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_fra
 int rr_render_frames_device(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out, void* stream);
 int rr_synchronize(rr_ctx* ctx);
 
+/* ---------------------------------------------------------------------------------------
+ * Pre-passes (SURVEY 8f "next" #1, #2): the two image passes that PRODUCE rainy_bg and
+ * env_xyY, so that they are born in HBM.  Optional: a caller may keep computing them itself.
+ *   fog-like rain attenuation   FogRain.fog_rain_layer           common/add_attenuation.py:88-95
+ *   environment map             EnvironmentMapGenerator.generate_map  common/bad_weather.py:742-819
+ *                               + convert_rgb_to_xyY              common/generator.py:407-408
+ * As with rr_camera, everything derived from transcendentals is computed once by the host. */
+#define RR_MAX_TAPS 33
+
+typedef struct {
+  int32_t fog_ksize, env_ksize;   /* 25 (add_attenuation.py:79), 15 (bad_weather.py:815); odd, <= RR_MAX_TAPS */
+  double fog_w[RR_MAX_TAPS];      /* cv::getGaussianKernel(25, 25) */
+  double env_w[RR_MAX_TAPS];      /* cv::getGaussianKernel(15, 0) -> sigma 2.6 */
+} rr_prepass_kernels;
+
+typedef struct {
+  int32_t H, W;
+  const double* bg;               /* H*W*3 BGR image / 255 (generator.py:352) */
+  const void* depth;              /* H*W metres, float32 (depth_f64 == 0) or float64 (generator.py:362-383) */
+  int32_t depth_f64, reserved;
+  double beta_ext;                /* 0.312 * R**0.67                               add_attenuation.py:40-43 */
+  double beta_hg;                 /* Henyey-Greenstein phase term, g = 0.97         add_attenuation.py:60-64 */
+  double irr_num, irr_den;        /* 4*N**2  and  exposure_s*gain*pi                add_attenuation.py:51-54 */
+} rr_prepass_in;
+
+typedef struct {
+  double* rainy_bg;               /* H*W*3: FOG.fog_rain_layer(bg, depth) */
+  double* env_xyY;                /* H*We*3, We = cw + 2*(cw/2) (may be NULL) */
+  uint8_t* env_bgr_u8;            /* H*We*3: the map the reference saves with --save_envmap (may be NULL) */
+} rr_prepass_out;
+
+int rr_set_prepass_kernels(rr_ctx* ctx, const rr_prepass_kernels* k);
+
+/* Projection tables of EnvironmentMapGenerator for HxW frames (bad_weather.py:716-762): `uniq` are the
+ * n_uniq distinct cylinder cells row*cw+col in ascending order and `first` the source pixel (row*W+col)
+ * np.unique(..., return_index=True) pairs with each of them.  Host pointers; copied. */
+int rr_set_envmap_geometry(rr_ctx* ctx, int32_t H, int32_t W, int32_t cw, int32_t n_uniq, const int32_t* uniq,
+                           const int32_t* first);
+int rr_envmap_width(rr_ctx* ctx);                    /* We for the geometry set above, or < 0 */
+
+/* n frames of identical H,W.  DEVICE pointers, enqueued on `stream` (NULL = ctx stream). */
+int rr_prepass_frames_device(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_prepass_out* out, void* stream);
+/* HOST pointers: upload, run, download, return after completion. */
+int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_prepass_out* out);
+
+/* Pre-pass + hot path for n frames with HOST pointers and no host round trip in between:
+ * in[f].rainy_bg and in[f].env_xyY are ignored (produced on the device from pre[f]); in[f].bg must
+ * equal pre[f].bg; in[f].He/We must be H / rr_envmap_width().  pre_out may be NULL, as may each of
+ * its members: what is non-NULL is downloaded as well. */
+int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
+                       const rr_prepass_out* pre_out);
+
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
 int rr_profile_enable(rr_ctx* ctx, int32_t on);
 int rr_profile_reset(rr_ctx* ctx);
@@ -152,6 +204,9 @@ int rr_sizeof_drop(void);
 int rr_sizeof_camera(void);
 int rr_sizeof_frame_in(void);
 int rr_sizeof_frame_out(void);
+int rr_sizeof_prepass_in(void);
+int rr_sizeof_prepass_out(void);
+int rr_sizeof_prepass_kernels(void);
 
 #ifdef __cplusplus
 }

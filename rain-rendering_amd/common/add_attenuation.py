@@ -17,6 +17,15 @@ class FogRain:
         self.exposure_time = exposure * 1e-3
         self.camera_gain = camera_gain
 
+    def constants(self):
+        """(beta_ext, beta_hg, irr_num, irr_den) for rr_prepass_in: the scalar part of fog_rain_layer,
+        evaluated here so the device needs no pow/cos."""
+        beta_ext = 0.312 * self.rain_intensity ** 0.67                              # :40-43
+        g = 0.97
+        cos_term = math.cos(math.radians(self.angle))
+        beta_hg = (1 - (g ** 2)) / (4 * np.pi * ((1 + g ** 2 - 2 * g * cos_term) ** 1.5))   # :60-64
+        return beta_ext, beta_hg, 4 * (self.f_number ** 2), self.exposure_time * self.camera_gain * np.pi   # :51-54
+
     def fog_rain_layer(self, image, depth):
         beta_ext = 0.312 * self.rain_intensity ** 0.67                              # :40-43
         f_ext = np.exp((-beta_ext) * (depth / 1000))                                 # :48 (depth in km)

@@ -49,6 +49,11 @@ class EnvironmentMapGenerator:
         self._tables[key] = tab
         return tab
 
+    def device_tables(self, H, W):
+        """(cw, uniq, first) for rr_set_envmap_geometry."""
+        t = self._projection(H, W)
+        return t['cw'], t['uniq'].astype(np.int32), t['first'].astype(np.int32)
+
     def generate_map(self, background):
         """reference bad_weather.py:742-819; background is float BGR in [0,1]."""
         bg8 = (background * 255).astype(np.uint8)

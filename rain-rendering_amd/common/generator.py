@@ -96,7 +96,8 @@ class Generator:
         if not pending:
             return
         t0 = time.time()
-        outs = self._hip_ctx().render_frames([p['frame'] for p in pending], want_composite=False)
+        # fog attenuation + environment map + streak rendering, all on the GPU in one call
+        outs = self._hip_ctx().pipeline_frames([p['frame'] for p in pending], want_env_u8=self.save_envmap)
         dt = time.time() - t0
         for p, o in zip(pending, outs):
             os.makedirs(os.path.dirname(p['out_rainy_path']), exist_ok=True)
@@ -105,7 +106,8 @@ class Generator:
             imgops.imsave_scalar(p['out_rainy_mask_path'], o['mask'])               # generator.py:467
             if self.save_envmap:
                 os.makedirs(os.path.dirname(p['out_env_path']), exist_ok=True)
-                imgops.imsave_rgb(p['out_env_path'], (np.clip(p['env_bgr'][..., ::-1], 0, 1) * 255).astype(np.uint8))
+                env_bgr = o['env_bgr_u8'] / 255.0                                  # generator.py:469 (plt.imsave of a float map)
+                imgops.imsave_rgb(p['out_env_path'], (np.clip(env_bgr[..., ::-1], 0, 1) * 255).astype(np.uint8))
             n_skip = int(np.count_nonzero(o['status']))
             self.stats.append(dict(file=p['out_rainy_path'], drops=len(o['status']), skipped=n_skip,
                                    gpu_ms=1e3 * dt / len(pending)))
@@ -194,6 +196,9 @@ class Generator:
                 hip = self._hip_ctx()
                 sharding.load_and_broadcast_streak_db(self.db, hip, self.rank, self.world)
                 hip.set_camera(hip_backend.make_camera(self.focal, self.f_number, self.exposure))
+                hip.set_prepass_kernels(imgops.gaussian_kernel(25, 25), imgops.gaussian_kernel(15, 0))
+                fog_const = FOG.constants()
+                geom_hw, env_w = None, 0
                 self.db.load_streaks_from_xml(self.dataset, self.settings, [imW, imH], use_pickle=False, verbose=self.verbose)
                 frame_render_dict = list(self.db.streaks_simulator.values())
 
@@ -247,21 +252,24 @@ class Generator:
                     if not np.all(np.array(depth.shape[:2]) == np.array(bg.shape[:2])):
                         bg = my_utils.crop_center(bg, depth.shape[0], depth.shape[1])
                     bg = np.ascontiguousarray(bg)
-                    rainy_bg = FOG.fog_rain_layer(bg, depth)                         # generator.py:386
-                    env_bgr = map_generator.generate_map(rainy_bg)                   # generator.py:400
-                    env_xyY = my_utils.convert_rgb_to_xyY(env_bgr[..., ::-1])        # generator.py:407-408
-                    env_xyY[np.isnan(env_xyY)] = 0
-                    omega = solid_angle.get_solid_angles(env_bgr)                    # generator.py:410
                     H, W = bg.shape[:2]
+                    # FOG.fog_rain_layer (generator.py:386), map_generator.generate_map (:400) and the xyY
+                    # conversion (:407-408) run on the GPU inside rr_pipeline_frames; the host only provides
+                    # the scalar fog constants and, once per frame size, the projection tables
+                    if geom_hw != (H, W):
+                        self._flush(pending)
+                        env_w = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
+                        geom_hw = (H, W)
+                    omega = solid_angle.get_solid_angles(np.empty((H, env_w, 0)))    # generator.py:410
                     keep = hip_backend.filter_streaks(frame.table, imW, imH)         # generator.py:413-420
                     assert len(keep) <= 2 ** 16, \
                         "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
                     drops = hip_backend.pack_drops(frame.table, keep, self.db, self.noise_std, self.noise_scale)
-                    pending.append(dict(frame=dict(bg=bg, rainy_bg=rainy_bg, env_xyY=env_xyY, omega=omega, drops=drops,
+                    pending.append(dict(frame=dict(bg=bg, depth=depth, fog=fog_const, omega=omega, drops=drops,
                                                    opacity_attenuation=self.opacity_attenuation,
                                                    strategy=1 if self.rendering_strategy == 'white' else 0),
                                         out_rainy_path=out_rainy_path, out_rainy_mask_path=out_rainy_mask_path,
-                                        out_env_path=out_env_path, env_bgr=env_bgr))
+                                        out_env_path=out_env_path))
                     same_shape = all(p['frame']['bg'].shape == pending[0]['frame']['bg'].shape for p in pending)
                     if len(pending) >= self.batch or not same_shape:
                         last = None if same_shape else pending.pop()

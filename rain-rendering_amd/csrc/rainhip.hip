@@ -22,6 +22,7 @@
 
 #include "rainhip.h"
 #include "rr_device.h"
+#include "rr_prepass.h"
 
 using namespace rr;
 
@@ -1508,9 +1509,20 @@ struct rr_ctx {
     rr_drop* drops = nullptr;
     uint8_t* rgb = nullptr;
     int32_t *mask_i = nullptr, *status = nullptr;
+    double* depth = nullptr;         // pre-pass input (float32 or float64 per frame slot of 8 bytes/pixel)
+    uint8_t* env_u8 = nullptr;
     int frames = 0, drops_cap = 0;
     Dims dims{0, 0, 0, 0};
   } st;
+  // pre-pass (fog + environment map)
+  rrpre::Kernels pk{};
+  bool have_pk = false, have_eg = false;
+  rrpre::EnvGeom eg{};
+  int32_t *d_esrc = nullptr, *d_etop = nullptr, *d_ebot = nullptr;
+  rrpre::PreScratch psc{};
+  rrpre::PreFrame* d_pre = nullptr;
+  std::vector<rrpre::PreFrame> h_pre;
+  int pre_frames = 0, pre_H = 0, pre_W = 0, pre_We = 0;
   // profiling
   bool prof = false;
   int tile_dbg = 0;                 // RAINHIP_TILE_DBG: timing experiments only (skips stages of k_tile)
@@ -1823,6 +1835,108 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   return RR_OK;
 }
 
+int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepass_out* out, hipStream_t s) {
+  if (!ctx->have_pk) {
+    ctx->err = "rr_set_prepass_kernels must be called before the pre-pass";
+    return RR_E_STATE;
+  }
+  if (n <= 0 || !in || !out) {
+    ctx->err = "bad pre-pass batch";
+    return RR_E_ARG;
+  }
+  const int H = in[0].H, W = in[0].W;
+  if (H <= 0 || W <= 0) {
+    ctx->err = "bad frame size";
+    return RR_E_ARG;
+  }
+  bool want_env = false;
+  for (int f = 0; f < n; f++) {
+    if (in[f].H != H || in[f].W != W) {
+      ctx->err = "all frames of a batch must share H,W";
+      return RR_E_ARG;
+    }
+    if (!in[f].bg || !in[f].depth || !out[f].rainy_bg || !(in[f].irr_den != 0.0)) {
+      ctx->err = "pre-pass: null pointer or zero irradiance denominator";
+      return RR_E_ARG;
+    }
+    if (out[f].env_xyY || out[f].env_bgr_u8) want_env = true;
+  }
+  if (want_env && (!ctx->have_eg || ctx->eg.H != H || ctx->eg.W != W)) {
+    ctx->err = "rr_set_envmap_geometry must be called for this frame size before an environment map is requested";
+    return RR_E_STATE;
+  }
+  const int We = want_env ? ctx->eg.We : 0;
+  if (n > ctx->pre_frames || H != ctx->pre_H || W != ctx->pre_W || We > ctx->pre_We) {
+    HIPCHK(hipDeviceSynchronize());
+    const int F = n > ctx->pre_frames ? n : ctx->pre_frames;
+    const int we = We > ctx->pre_We ? We : ctx->pre_We;
+    const size_t px = (size_t)H * W, ex = (size_t)H * (we > 0 ? we : 1);
+    int rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.fext, F * px))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.tmpF, F * px))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.tmpL, F * px * 3))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.part, (size_t)F * rrpre::FOG_BLOCKS * 3))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.mean, (size_t)F * 3))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.epack, F * ex))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.etmp, F * ex * 3))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_pre, (size_t)F))) return rc;
+    ctx->pre_frames = F;
+    ctx->pre_H = H;
+    ctx->pre_W = W;
+    ctx->pre_We = we;
+  }
+  ctx->h_pre.resize(n);
+  for (int f = 0; f < n; f++) {
+    rrpre::PreFrame& p = ctx->h_pre[f];
+    p.bg = in[f].bg;
+    p.depth = in[f].depth;
+    p.rainy = out[f].rainy_bg;
+    p.env_xyY = out[f].env_xyY;
+    p.env_u8 = out[f].env_bgr_u8;
+    p.beta_ext = in[f].beta_ext;
+    p.beta_hg = in[f].beta_hg;
+    p.irr_num = in[f].irr_num;
+    p.irr_den = in[f].irr_den;
+    p.depth_f64 = in[f].depth_f64;
+    p.pad = 0;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_pre, ctx->h_pre.data(), sizeof(rrpre::PreFrame) * n, hipMemcpyHostToDevice, s));
+  const rrpre::PreScratch sc = ctx->psc;
+  const unsigned px_blocks = (unsigned)(((int64_t)H * W + 255) / 256);
+  {
+    ProfScope ps(ctx, s, "k_fog_stats");
+    hipLaunchKernelGGL(rrpre::k_fog_sum, dim3(rrpre::FOG_BLOCKS, n), dim3(256), 0, s, ctx->d_pre, H, W, sc);
+    hipLaunchKernelGGL(rrpre::k_fog_mean, dim3(n), dim3(64), 0, s, H, W, sc);
+    hipLaunchKernelGGL(rrpre::k_fog_ext, dim3(px_blocks, n), dim3(256), 0, s, ctx->d_pre, H, W, sc);
+  }
+  {
+    ProfScope ps(ctx, s, "k_fog_h");
+    hipLaunchKernelGGL(rrpre::k_fog_h, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
+  }
+  {
+    ProfScope ps(ctx, s, "k_fog_v");
+    hipLaunchKernelGGL(rrpre::k_fog_v, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
+  }
+  if (want_env) {
+    const rrpre::EnvGeom g = ctx->eg;
+    const dim3 grid((g.We + 255) / 256, H, n);
+    {
+      ProfScope ps(ctx, s, "k_env_build");
+      hipLaunchKernelGGL(rrpre::k_env_build, grid, dim3(256), 0, s, ctx->d_pre, g, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_env_h");
+      hipLaunchKernelGGL(rrpre::k_env_h, grid, dim3(256), 0, s, g, ctx->pk, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_env_v");
+      hipLaunchKernelGGL(rrpre::k_env_v, grid, dim3(256), 0, s, ctx->d_pre, g, ctx->pk, sc);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 // returns RR_OK, or RR_E_ARENA after growing the arena (caller re-enqueues)
 int check_overflow(rr_ctx* ctx, hipStream_t s) {
   int32_t ovf = 0;
@@ -1848,6 +1962,9 @@ int rr_sizeof_drop(void) { return (int)sizeof(rr_drop); }
 int rr_sizeof_camera(void) { return (int)sizeof(rr_camera); }
 int rr_sizeof_frame_in(void) { return (int)sizeof(rr_frame_in); }
 int rr_sizeof_frame_out(void) { return (int)sizeof(rr_frame_out); }
+int rr_sizeof_prepass_in(void) { return (int)sizeof(rr_prepass_in); }
+int rr_sizeof_prepass_out(void) { return (int)sizeof(rr_prepass_out); }
+int rr_sizeof_prepass_kernels(void) { return (int)sizeof(rr_prepass_kernels); }
 
 int rr_create(rr_ctx** out, int device) {
   if (!out) return RR_E_ARG;
@@ -1936,6 +2053,19 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->st.rgb);
   hipFree(ctx->st.mask_i);
   hipFree(ctx->st.status);
+  hipFree(ctx->st.depth);
+  hipFree(ctx->st.env_u8);
+  hipFree(ctx->d_esrc);
+  hipFree(ctx->d_etop);
+  hipFree(ctx->d_ebot);
+  hipFree(ctx->d_pre);
+  hipFree(ctx->psc.fext);
+  hipFree(ctx->psc.tmpF);
+  hipFree(ctx->psc.tmpL);
+  hipFree(ctx->psc.part);
+  hipFree(ctx->psc.mean);
+  hipFree(ctx->psc.epack);
+  hipFree(ctx->psc.etmp);
   for (auto& pe : ctx->prof_pending) {
     hipEventDestroy(pe.a);
     hipEventDestroy(pe.b);
@@ -2046,20 +2176,35 @@ int rr_synchronize(rr_ctx* ctx) {
   return RR_OK;
 }
 
-int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out) {
+// Host-pointer runner shared by rr_render_frames (pre == NULL), rr_prepass_frames (in == NULL)
+// and rr_pipeline_frames (both): stage, enqueue, download.
+static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
+                    const rr_prepass_out* pre_out) {
   if (!ctx) return RR_E_ARG;
-  if (n <= 0 || !in || !out) {
+  if (n <= 0 || (!pre && !in) || (in && !out) || (pre && !in && !pre_out)) {
     ctx->err = "bad frame batch";
     return RR_E_ARG;
   }
   HIPCHK(hipSetDevice(ctx->device));
-  Dims dm{in[0].H, in[0].W, in[0].He, in[0].We};
+  Dims dm{0, 0, 0, 0};
+  if (in) dm = Dims{in[0].H, in[0].W, in[0].He, in[0].We};
+  else {
+    bool want_env = false;
+    for (int f = 0; f < n; f++) want_env = want_env || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
+    dm = Dims{pre[0].H, pre[0].W, pre[0].H, (want_env && ctx->have_eg) ? ctx->eg.We : 1};
+  }
   if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
     ctx->err = "bad frame size";
     return RR_E_ARG;
   }
+  if (pre && in) {
+    if (!ctx->have_eg || dm.He != dm.H || dm.We != ctx->eg.We || pre[0].H != dm.H || pre[0].W != dm.W) {
+      ctx->err = "pipeline: He/We must be H / rr_envmap_width() of the geometry set for this frame size";
+      return RR_E_ARG;
+    }
+  }
   int max_drops = 1;
-  for (int f = 0; f < n; f++) {
+  for (int f = 0; in && f < n; f++) {
     if (in[f].n_drops < 0 || in[f].n_drops > 65536) {
       ctx->err = "n_drops outside [0, 2^16] (generator.py:425)";
       return RR_E_ARG;
@@ -2081,15 +2226,34 @@ int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_fra
     if ((rc = dev_alloc(ctx, st.rgb, F * px * 3))) return rc;
     if ((rc = dev_alloc(ctx, st.mask_i, F * px))) return rc;
     if ((rc = dev_alloc(ctx, st.status, (size_t)F * D))) return rc;
+    if ((rc = dev_alloc(ctx, st.depth, F * px))) return rc;
+    if ((rc = dev_alloc(ctx, st.env_u8, F * ex * 3))) return rc;
     st.frames = F;
     st.drops_cap = D;
     st.dims = dm;
   }
   hipStream_t s = ctx->stream;
-  std::vector<rr_frame_in> din(n);
-  std::vector<rr_frame_out> dout(n);
-  for (int f = 0; f < n; f++) {
-    if (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
+  std::vector<rr_frame_in> din(in ? n : 0);
+  std::vector<rr_frame_out> dout(in ? n : 0);
+  std::vector<rr_prepass_in> pin(pre ? n : 0);
+  std::vector<rr_prepass_out> pout(pre ? n : 0);
+  for (int f = 0; pre && f < n; f++) {
+    if (!pre[f].bg || !pre[f].depth) {
+      ctx->err = "null pre-pass pointer";
+      return RR_E_ARG;
+    }
+    pin[f] = pre[f];
+    pin[f].bg = st.bg + f * px * 3;
+    pin[f].depth = st.depth + f * px;
+    HIPCHK(hipMemcpyAsync((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4), hipMemcpyHostToDevice, s));
+    pout[f].rainy_bg = st.rainy + f * px * 3;
+    const bool env = in || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
+    pout[f].env_xyY = env ? st.env + f * ex * 3 : nullptr;
+    pout[f].env_bgr_u8 = (pre_out && pre_out[f].env_bgr_u8) ? st.env_u8 + f * ex * 3 : nullptr;
+  }
+  for (int f = 0; in && f < n; f++) {
+    if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
         !out[f].rainy_rgb || !out[f].mask_f64 || !out[f].mask_i32) {
       ctx->err = "null frame pointer";
       return RR_E_ARG;
@@ -2100,9 +2264,11 @@ int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_fra
     din[f].env_xyY = st.env + f * ex * 3;
     din[f].omega = st.omega + f * ex;
     din[f].drops = st.drops + (size_t)f * st.drops_cap;
-    HIPCHK(hipMemcpyAsync((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (!pre) {
+      HIPCHK(hipMemcpyAsync((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     HIPCHK(hipMemcpyAsync((void*)din[f].omega, in[f].omega, ex * sizeof(double), hipMemcpyHostToDevice, s));
     if (in[f].n_drops > 0)
       HIPCHK(hipMemcpyAsync((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * in[f].n_drops, hipMemcpyHostToDevice, s));
@@ -2112,14 +2278,18 @@ int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_fra
     dout[f].mask_i32 = st.mask_i + f * px;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
   }
-  for (int attempt = 0; attempt < 3; attempt++) {
+  if (pre) {
+    int rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s);
+    if (rc) return rc;
+  }
+  for (int attempt = 0; in && attempt < 3; attempt++) {
     int rc = enqueue(ctx, n, din.data(), dout.data(), s);
     if (rc) return rc;
     rc = check_overflow(ctx, s);
     if (rc == RR_OK) break;
     if (rc != RR_E_ARENA || attempt == 2) return rc;
   }
-  for (int f = 0; f < n; f++) {
+  for (int f = 0; in && f < n; f++) {
     HIPCHK(hipMemcpyAsync(out[f].rainy_rgb, dout[f].rainy_rgb, px * 3, hipMemcpyDeviceToHost, s));
     if (out[f].rainy_bg_out)
       HIPCHK(hipMemcpyAsync(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2128,8 +2298,125 @@ int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_fra
     if (out[f].drop_status && in[f].n_drops > 0)
       HIPCHK(hipMemcpyAsync(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * in[f].n_drops, hipMemcpyDeviceToHost, s));
   }
+  for (int f = 0; pre && pre_out && f < n; f++) {
+    if (pre_out[f].rainy_bg)
+      HIPCHK(hipMemcpyAsync(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (pre_out[f].env_xyY)
+      HIPCHK(hipMemcpyAsync(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (pre_out[f].env_bgr_u8)
+      HIPCHK(hipMemcpyAsync(pre_out[f].env_bgr_u8, pout[f].env_bgr_u8, ex * 3, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(hipStreamSynchronize(s));
   return RR_OK;
+}
+
+int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out) {
+  if (!ctx) return RR_E_ARG;
+  if (!in || !out) {
+    ctx->err = "bad frame batch";
+    return RR_E_ARG;
+  }
+  return run_host(ctx, n, nullptr, in, out, nullptr);
+}
+
+int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_prepass_out* out) {
+  if (!ctx) return RR_E_ARG;
+  if (!in || !out) {
+    ctx->err = "bad pre-pass batch";
+    return RR_E_ARG;
+  }
+  for (int f = 0; f < n; f++)
+    if (!out[f].rainy_bg) {
+      ctx->err = "pre-pass: null rainy_bg output";
+      return RR_E_ARG;
+    }
+  return run_host(ctx, n, in, nullptr, nullptr, out);
+}
+
+int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
+                       const rr_prepass_out* pre_out) {
+  if (!ctx) return RR_E_ARG;
+  if (!pre || !in || !out) {
+    ctx->err = "bad pipeline batch";
+    return RR_E_ARG;
+  }
+  return run_host(ctx, n, pre, in, out, pre_out);
+}
+
+int rr_prepass_frames_device(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_prepass_out* out, void* stream) {
+  if (!ctx) return RR_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  return enqueue_prepass(ctx, n, in, out, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int rr_set_prepass_kernels(rr_ctx* ctx, const rr_prepass_kernels* k) {
+  if (!ctx) return RR_E_ARG;
+  if (!k || k->fog_ksize < 1 || k->env_ksize < 1 || k->fog_ksize > RR_MAX_TAPS || k->env_ksize > RR_MAX_TAPS ||
+      !(k->fog_ksize & 1) || !(k->env_ksize & 1)) {
+    ctx->err = "rr_set_prepass_kernels: tap counts must be odd and <= RR_MAX_TAPS";
+    return RR_E_ARG;
+  }
+  static_assert(RR_MAX_TAPS == rrpre::KMAX, "tap capacity");
+  ctx->pk.fog_k = k->fog_ksize;
+  ctx->pk.env_k = k->env_ksize;
+  for (int i = 0; i < RR_MAX_TAPS; i++) {
+    ctx->pk.fog_w[i] = i < k->fog_ksize ? k->fog_w[i] : 0.0;
+    ctx->pk.env_w[i] = i < k->env_ksize ? k->env_w[i] : 0.0;
+  }
+  // scipy.ndimage.correlate1d (the oracle's convolution) folds symmetric kernels; anything else is refused
+  for (int i = 0; i < k->fog_ksize / 2; i++)
+    if (k->fog_w[i] != k->fog_w[k->fog_ksize - 1 - i]) {
+      ctx->err = "rr_set_prepass_kernels: fog kernel is not symmetric";
+      return RR_E_ARG;
+    }
+  for (int i = 0; i < k->env_ksize / 2; i++)
+    if (k->env_w[i] != k->env_w[k->env_ksize - 1 - i]) {
+      ctx->err = "rr_set_prepass_kernels: envmap kernel is not symmetric";
+      return RR_E_ARG;
+    }
+  ctx->have_pk = true;
+  return RR_OK;
+}
+
+int rr_set_envmap_geometry(rr_ctx* ctx, int32_t H, int32_t W, int32_t cw, int32_t n_uniq, const int32_t* uniq, const int32_t* first) {
+  if (!ctx) return RR_E_ARG;
+  if (H <= 0 || W <= 0 || cw <= 0 || n_uniq < 0 || (n_uniq > 0 && (!uniq || !first)) || (int64_t)H * cw > INT32_MAX) {
+    ctx->err = "rr_set_envmap_geometry: bad argument";
+    return RR_E_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<int32_t> src((size_t)H * cw), top(cw), bot(cw);
+  if (!rrpre::build_env_tables(H, W, cw, n_uniq, uniq, first, src.data(), top.data(), bot.data())) {
+    ctx->err = "rr_set_envmap_geometry: cell or source pixel outside the frame";
+    return RR_E_ARG;
+  }
+  int rc;
+  if ((rc = dev_alloc(ctx, ctx->d_esrc, src.size()))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_etop, top.size()))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_ebot, bot.size()))) return rc;
+  HIPCHK(hipMemcpy(ctx->d_esrc, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_etop, top.data(), top.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_ebot, bot.data(), bot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  ctx->eg.H = H;
+  ctx->eg.W = W;
+  ctx->eg.cw = cw;
+  ctx->eg.lw = cw / 2;
+  ctx->eg.We = cw + 2 * (cw / 2);
+  ctx->eg.src = ctx->d_esrc;
+  ctx->eg.top_row = ctx->d_etop;
+  ctx->eg.bot_row = ctx->d_ebot;
+  ctx->have_eg = true;
+  return RR_OK;
+}
+
+int rr_envmap_width(rr_ctx* ctx) {
+  if (!ctx) return RR_E_ARG;
+  if (!ctx->have_eg) {
+    ctx->err = "no environment-map geometry set";
+    return RR_E_STATE;
+  }
+  return ctx->eg.We;
 }
 
 int rr_profile_enable(rr_ctx* ctx, int32_t on) {

@@ -1,0 +1,312 @@
+// rr_prepass.h -- gfx950 kernels of the two per-frame pre-passes that feed the hot path
+// (SURVEY 8f "next" #1, #2):
+//   fog-like rain attenuation     reference common/add_attenuation.py:26-95
+//   environment-map estimation    reference common/bad_weather.py:742-853 + generator.py:407-408
+// Both are HBM-bound image passes (one thread per pixel, coalesced rows); they exist so that
+// rainy_bg and env_xyY are born in HBM instead of crossing PCIe as float64 planes.
+// Arithmetic follows the numpy restatement in oracle/prepass.py op for op: the Gaussian taps
+// are summed in scipy.ndimage.correlate1d's symmetric order, borders are BORDER_REFLECT_101.
+// The per-pixel bodies are `__host__ __device__` (like rr_device.h) so that tests/hostemu can run
+// the very same arithmetic on the CPU; the __global__ wrappers only compute indices.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RRP_HD __host__ __device__ inline
+#else
+#define RRP_HD inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace rrpre {
+
+constexpr int KMAX = 33;            // max Gaussian taps
+
+struct Kernels {                    // passed by value to the kernels
+  int fog_k, env_k;
+  double fog_w[KMAX];
+  double env_w[KMAX];
+};
+
+struct PreFrame {
+  const double* bg;                 // H*W*3
+  const void* depth;                // H*W float32 or float64
+  double* rainy;                    // H*W*3
+  double* env_xyY;                  // H*We*3 (may be null)
+  uint8_t* env_u8;                  // H*We*3 BGR (may be null)
+  double beta_ext, beta_hg, irr_num, irr_den;
+  int32_t depth_f64, pad;
+};
+
+struct EnvGeom {
+  int H, W, cw, lw, We;
+  const int32_t* src;               // [H*cw] source pixel index (r*W+c) or -1
+  const int32_t* top_row;           // [cw] row the unfilled pixels of the top half copy
+  const int32_t* bot_row;           // [cw] same, bottom half
+};
+
+struct PreScratch {                 // [frame][...]
+  double* fext;                     // [H*W]
+  double* tmpF;                     // [H*W]
+  double* tmpL;                     // [H*W*3]
+  double* part;                     // [64*3]
+  double* mean;                     // [3]
+  uint32_t* epack;                  // [H*We] b | g<<8 | r<<16 | mask<<24
+  double* etmp;                     // [H*We*3]
+};
+
+constexpr int FOG_BLOCKS = 64;
+
+RRP_HD double one_minus(double fe, int f64) { return f64 ? 1.0 - fe : (double)(1.0f - (float)fe); }
+RRP_HD double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+
+RRP_HD int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+#if defined(__HIPCC__)
+// irradiance = (4 N^2 image) / (t G pi); per-channel mean           add_attenuation.py:51-58
+__global__ void __launch_bounds__(256) k_fog_sum(const PreFrame* fr, int H, int W, PreScratch sc) {
+  const int f = blockIdx.y;
+  const PreFrame F = fr[f];
+  const int64_t px = (int64_t)H * W;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < px; p += (int64_t)FOG_BLOCKS * 256) {
+    s0 += (F.irr_num * F.bg[p * 3 + 0]) / F.irr_den;
+    s1 += (F.irr_num * F.bg[p * 3 + 1]) / F.irr_den;
+    s2 += (F.irr_num * F.bg[p * 3 + 2]) / F.irr_den;
+  }
+  __shared__ double red[3][256];
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  red[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+      for (int c = 0; c < 3; c++) red[c][threadIdx.x] += red[c][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) sc.part[((int64_t)f * FOG_BLOCKS + blockIdx.x) * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void k_fog_mean(int H, int W, PreScratch sc) {
+  const int f = blockIdx.x, c = threadIdx.x;
+  if (c >= 3) return;
+  double s = 0;
+  for (int b = 0; b < FOG_BLOCKS; b++) s += sc.part[((int64_t)f * FOG_BLOCKS + b) * 3 + c];
+  sc.mean[f * 3 + c] = s / (double)((int64_t)H * W);
+}
+
+#endif
+
+// extinction map f_ext = exp(-beta_ext * depth_km)                      add_attenuation.py:45-49
+RRP_HD void fog_ext_px(const PreFrame& F, int f, int H, int W, const PreScratch& sc, int64_t p) {
+  const int64_t px = (int64_t)H * W;
+  double e;
+  if (F.depth_f64) {
+    e = exp(-F.beta_ext * (((const double*)F.depth)[p] / 1000.0));
+  } else {                          // numpy keeps float32: float32 / int, weak python scalar * float32
+    const float t = ((const float*)F.depth)[p] / 1000.0f;
+    e = (double)expf((float)(-F.beta_ext) * t);
+  }
+  sc.fext[f * px + p] = e;
+}
+
+
+// horizontal 25-tap pass of f_ext and of l_in = clip(beta_hg * mean * (1 - f_ext))   :66-73,79-80
+RRP_HD void fog_h_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y, int x) {
+  const int64_t px = (int64_t)H * W;
+  const double* fe = sc.fext + f * px + (int64_t)y * W;
+  const int f64 = F.depth_f64, half = kn.fog_k / 2;
+  double k3[3];
+  for (int c = 0; c < 3; c++) k3[c] = F.beta_hg * sc.mean[f * 3 + c];
+  const double v0 = fe[x], o0 = one_minus(v0, f64);
+  double aF = v0 * kn.fog_w[half], aL[3];
+  for (int c = 0; c < 3; c++) aL[c] = clip01(k3[c] * o0) * kn.fog_w[half];
+  for (int j = -half; j < 0; j++) {
+    const double va = fe[reflect101(x + j, W)], vb = fe[reflect101(x - j, W)], w = kn.fog_w[half + j];
+    aF += (va + vb) * w;
+    const double oa = one_minus(va, f64), ob = one_minus(vb, f64);
+    for (int c = 0; c < 3; c++) aL[c] += (clip01(k3[c] * oa) + clip01(k3[c] * ob)) * w;
+  }
+  const int64_t p = f * px + (int64_t)y * W + x;
+  sc.tmpF[p] = f64 ? aF : (double)(float)aF;
+  for (int c = 0; c < 3; c++) sc.tmpL[p * 3 + c] = aL[c];
+}
+
+// vertical pass + rainy = clip(image * f_ext + l_in, 0, 1)                            :82-86,93
+RRP_HD void fog_v_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y, int x) {
+  const int64_t px = (int64_t)H * W, base = f * px;
+  const int half = kn.fog_k / 2;
+  const int64_t p0 = base + (int64_t)y * W + x;
+  double aF = sc.tmpF[p0] * kn.fog_w[half], aL[3];
+  for (int c = 0; c < 3; c++) aL[c] = sc.tmpL[p0 * 3 + c] * kn.fog_w[half];
+  for (int j = -half; j < 0; j++) {
+    const int64_t pa = base + (int64_t)reflect101(y + j, H) * W + x, pb = base + (int64_t)reflect101(y - j, H) * W + x;
+    const double w = kn.fog_w[half + j];
+    aF += (sc.tmpF[pa] + sc.tmpF[pb]) * w;
+    for (int c = 0; c < 3; c++) aL[c] += (sc.tmpL[pa * 3 + c] + sc.tmpL[pb * 3 + c]) * w;
+  }
+  if (!F.depth_f64) aF = (double)(float)aF;
+  const int64_t q = ((int64_t)y * W + x) * 3;
+  for (int c = 0; c < 3; c++) F.rainy[q + c] = clip01(F.bg[q + c] * aF + aL[c]);
+}
+
+// --- environment map ------------------------------------------------------------------------
+RRP_HD uint32_t bg8_px(const double* img, int32_t p) {      // (background*255).astype(uint8)
+  const uint32_t b = (uint32_t)(int)(img[(int64_t)p * 3 + 0] * 255.0) & 255u;
+  const uint32_t g = (uint32_t)(int)(img[(int64_t)p * 3 + 1] * 255.0) & 255u;
+  const uint32_t r = (uint32_t)(int)(img[(int64_t)p * 3 + 2] * 255.0) & 255u;
+  return b | (g << 8) | (r << 16);
+}
+
+// cylindrical un-projection, column fills, mirrored sides                    bad_weather.py:742-813
+RRP_HD void env_build_px(const PreFrame& F, int f, const EnvGeom& g, const PreScratch& sc, int r, int x) {
+  const double* img = F.rainy;
+  const int wr = g.cw - g.cw / 2;
+  int c;
+  if (x >= g.We - wr) c = g.cw - 1 - (x - (g.We - wr));      // right side (written last, :806-811)
+  else if (x < g.lw) c = g.lw - 1 - x;                         // left side (:798-804)
+  else c = x - g.lw;                                           // centre (:792-796)
+  const int32_t s = g.src[(int64_t)r * g.cw + c];
+  const int half = g.H / 2;
+  uint32_t v = 0;
+  if (s >= 0) {
+    v = bg8_px(img, s) | 0xff000000u;
+  } else {
+    int rr = -1;
+    if (r < half) rr = g.top_row[c];
+    else if (r >= g.H - half) rr = g.bot_row[c];
+    if (rr >= 0) {
+      const int32_t s2 = g.src[(int64_t)rr * g.cw + c];
+      if (s2 >= 0) v = bg8_px(img, s2);
+    }
+  }
+  sc.epack[((int64_t)f * g.H + r) * g.We + x] = v;
+}
+
+RRP_HD void env_h_px(int f, const EnvGeom& g, const Kernels& kn, const PreScratch& sc, int r, int x) {
+  const uint32_t* row = sc.epack + ((int64_t)f * g.H + r) * g.We;
+  const int half = kn.env_k / 2;
+  const uint32_t v0 = row[x];
+  double a[3];
+  for (int c = 0; c < 3; c++) a[c] = (double)((v0 >> (8 * c)) & 255u) * kn.env_w[half];
+  for (int j = -half; j < 0; j++) {
+    const uint32_t va = row[reflect101(x + j, g.We)], vb = row[reflect101(x - j, g.We)];
+    const double w = kn.env_w[half + j];
+    for (int c = 0; c < 3; c++) a[c] += ((double)((va >> (8 * c)) & 255u) + (double)((vb >> (8 * c)) & 255u)) * w;
+  }
+  double* o = sc.etmp + (((int64_t)f * g.H + r) * g.We + x) * 3;
+  o[0] = a[0];
+  o[1] = a[1];
+  o[2] = a[2];
+}
+
+// vertical pass where the map is unfilled (:815-817), /255, RGB -> xyY (my_utils.py:55-68), nan -> 0
+RRP_HD void env_v_px(const PreFrame& F, int f, const EnvGeom& g, const Kernels& kn, const PreScratch& sc, int r, int x) {
+  const int64_t fb = (int64_t)f * g.H * g.We, q = (int64_t)r * g.We + x;
+  const uint32_t v0 = sc.epack[fb + q];
+  double bgr[3];
+  if ((v0 >> 24) == 0) {
+    const int half = kn.env_k / 2;
+    const double* t = sc.etmp + fb * 3;
+    double a[3];
+    for (int c = 0; c < 3; c++) a[c] = t[q * 3 + c] * kn.env_w[half];
+    for (int j = -half; j < 0; j++) {
+      const int64_t qa = (int64_t)reflect101(r + j, g.H) * g.We + x, qb = (int64_t)reflect101(r - j, g.H) * g.We + x;
+      const double w = kn.env_w[half + j];
+      for (int c = 0; c < 3; c++) a[c] += (t[qa * 3 + c] + t[qb * 3 + c]) * w;
+    }
+    for (int c = 0; c < 3; c++) {
+      double v = rint(a[c]);
+      bgr[c] = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    }
+  } else {
+    for (int c = 0; c < 3; c++) bgr[c] = (double)((v0 >> (8 * c)) & 255u);
+  }
+  if (F.env_u8) {
+    F.env_u8[q * 3 + 0] = (uint8_t)bgr[0];
+    F.env_u8[q * 3 + 1] = (uint8_t)bgr[1];
+    F.env_u8[q * 3 + 2] = (uint8_t)bgr[2];
+  }
+  if (F.env_xyY) {
+    const double R = bgr[2] / 255.0, G = bgr[1] / 255.0, B = bgr[0] / 255.0;
+    const double X = (R * 0.49000 + G * 0.17697 + B * 0.00000) / 0.17697;
+    const double Y = (R * 0.31000 + G * 0.81240 + B * 0.01000) / 0.17697;
+    const double Z = (R * 0.20000 + G * 0.01063 + B * 0.99000) / 0.17697;
+    const double s = X + Y + Z;
+    double xx = X / s, yy = Y / s;
+    if (xx != xx) xx = 0.0;
+    if (yy != yy) yy = 0.0;
+    F.env_xyY[q * 3 + 0] = xx;
+    F.env_xyY[q * 3 + 1] = yy;
+    F.env_xyY[q * 3 + 2] = Y;
+  }
+}
+
+// Host side of rr_set_envmap_geometry: cell -> source-pixel table and the column-fill rows of
+// fill_matrices (bad_weather.py:821-853): the first filled row of each column seen from the top of the
+// top half / from the bottom over rows [H/2, H); argmax of an all-false column is its first row.
+// src: H*cw, top/bot: cw.  Returns false when a cell or source pixel lies outside the frame.
+inline bool build_env_tables(int H, int W, int cw, int n_uniq, const int32_t* uniq, const int32_t* first, int32_t* src,
+                             int32_t* top, int32_t* bot) {
+  for (int64_t i = 0; i < (int64_t)H * cw; i++) src[i] = -1;
+  for (int i = 0; i < n_uniq; i++) {
+    if (uniq[i] < 0 || uniq[i] >= H * cw || first[i] < 0 || first[i] >= H * W) return false;
+    src[uniq[i]] = first[i];
+  }
+  const int half = H / 2;
+  for (int c = 0; c < cw; c++) {
+    int t = 0;
+    for (int r = 0; r < half; r++)
+      if (src[(int64_t)r * cw + c] >= 0) {
+        t = r;
+        break;
+      }
+    top[c] = t;
+    int b = H - 1;
+    for (int r = H - 1; r >= half; r--)
+      if (src[(int64_t)r * cw + c] >= 0) {
+        b = r;
+        break;
+      }
+    bot[c] = b;
+  }
+  return true;
+}
+
+#if defined(__HIPCC__)
+__global__ void __launch_bounds__(256) k_fog_ext(const PreFrame* fr, int H, int W, PreScratch sc) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < (int64_t)H * W) fog_ext_px(fr[blockIdx.y], blockIdx.y, H, W, sc, p);
+}
+__global__ void __launch_bounds__(256) k_fog_h(const PreFrame* fr, int H, int W, Kernels kn, PreScratch sc) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < W) fog_h_px(fr[blockIdx.z], blockIdx.z, H, W, kn, sc, blockIdx.y, x);
+}
+__global__ void __launch_bounds__(256) k_fog_v(const PreFrame* fr, int H, int W, Kernels kn, PreScratch sc) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < W) fog_v_px(fr[blockIdx.z], blockIdx.z, H, W, kn, sc, blockIdx.y, x);
+}
+__global__ void __launch_bounds__(256) k_env_build(const PreFrame* fr, EnvGeom g, PreScratch sc) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < g.We) env_build_px(fr[blockIdx.z], blockIdx.z, g, sc, blockIdx.y, x);
+}
+__global__ void __launch_bounds__(256) k_env_h(EnvGeom g, Kernels kn, PreScratch sc) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < g.We) env_h_px(blockIdx.z, g, kn, sc, blockIdx.y, x);
+}
+__global__ void __launch_bounds__(256) k_env_v(const PreFrame* fr, EnvGeom g, Kernels kn, PreScratch sc) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < g.We) env_v_px(fr[blockIdx.z], blockIdx.z, g, kn, sc, blockIdx.y, x);
+}
+#endif
+
+}  // namespace rrpre

@@ -52,10 +52,31 @@ class rr_kernel_stat(ctypes.Structure):
                 ('total_ms', ctypes.c_double)]
 
 
+RR_MAX_TAPS = 33
+
+
+class rr_prepass_kernels(ctypes.Structure):
+    _fields_ = [('fog_ksize', ctypes.c_int32), ('env_ksize', ctypes.c_int32),
+                ('fog_w', ctypes.c_double * RR_MAX_TAPS), ('env_w', ctypes.c_double * RR_MAX_TAPS)]
+
+
+class rr_prepass_in(ctypes.Structure):
+    _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('bg', ctypes.c_void_p), ('depth', ctypes.c_void_p),
+                ('depth_f64', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('beta_ext', ctypes.c_double), ('beta_hg', ctypes.c_double),
+                ('irr_num', ctypes.c_double), ('irr_den', ctypes.c_double)]
+
+
+class rr_prepass_out(ctypes.Structure):
+    _fields_ = [('rainy_bg', ctypes.c_void_p), ('env_xyY', ctypes.c_void_p), ('env_bgr_u8', ctypes.c_void_p)]
+
+
 EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_streak_db', 'rr_set_streak_db_device',
            'rr_set_camera', 'rr_render_frames', 'rr_render_frames_device', 'rr_synchronize', 'rr_profile_enable',
            'rr_profile_reset', 'rr_profile_read', 'rr_sizeof_drop', 'rr_sizeof_camera', 'rr_sizeof_frame_in',
-           'rr_sizeof_frame_out']
+           'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
+           'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
+           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels']
 
 _lib = None
 
@@ -87,6 +108,20 @@ def load_library(path=None):
     lib.rr_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.rr_profile_reset.argtypes = [ctypes.c_void_p]
     lib.rr_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(rr_kernel_stat), ctypes.c_int32]
+    lib.rr_set_prepass_kernels.argtypes = [ctypes.c_void_p, ctypes.POINTER(rr_prepass_kernels)]
+    lib.rr_set_envmap_geometry.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_envmap_width.argtypes = [ctypes.c_void_p]
+    lib.rr_prepass_frames.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(rr_prepass_in),
+                                      ctypes.POINTER(rr_prepass_out)]
+    lib.rr_prepass_frames_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(rr_prepass_in),
+                                             ctypes.POINTER(rr_prepass_out), ctypes.c_void_p]
+    lib.rr_pipeline_frames.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(rr_prepass_in),
+                                       ctypes.POINTER(rr_frame_in), ctypes.POINTER(rr_frame_out),
+                                       ctypes.POINTER(rr_prepass_out)]
+    assert lib.rr_sizeof_prepass_in() == ctypes.sizeof(rr_prepass_in)
+    assert lib.rr_sizeof_prepass_out() == ctypes.sizeof(rr_prepass_out)
+    assert lib.rr_sizeof_prepass_kernels() == ctypes.sizeof(rr_prepass_kernels)
     assert lib.rr_sizeof_drop() == DROP_DTYPE.itemsize == 112, (lib.rr_sizeof_drop(), DROP_DTYPE.itemsize)
     assert lib.rr_sizeof_camera() == ctypes.sizeof(rr_camera)
     assert lib.rr_sizeof_frame_in() == ctypes.sizeof(rr_frame_in)
@@ -289,6 +324,102 @@ class RainHip:
             keep.append((bg, rb, env, om, drops))
             outs.append(o)
         self._check(self.lib.rr_render_frames(self.h, n, fin, fout), 'rr_render_frames')
+        return outs
+
+    # ---- pre-pass (fog attenuation + environment map), SURVEY 8f next #1/#2 ------------------
+    def set_prepass_kernels(self, fog_w, env_w):
+        """Gaussian taps of the two blurs (cv::getGaussianKernel(25, 25) and (15, 0)), computed by the host."""
+        k = rr_prepass_kernels()
+        k.fog_ksize, k.env_ksize = len(fog_w), len(env_w)
+        for i, v in enumerate(fog_w):
+            k.fog_w[i] = float(v)
+        for i, v in enumerate(env_w):
+            k.env_w[i] = float(v)
+        self._check(self.lib.rr_set_prepass_kernels(self.h, ctypes.byref(k)), 'rr_set_prepass_kernels')
+
+    def set_envmap_geometry(self, H, W, cw, uniq, first):
+        """Projection tables of EnvironmentMapGenerator for HxW frames; returns the map width We."""
+        uniq = np.ascontiguousarray(uniq, np.int32)
+        first = np.ascontiguousarray(first, np.int32)
+        self._check(self.lib.rr_set_envmap_geometry(self.h, int(H), int(W), int(cw), len(uniq), _ptr(uniq), _ptr(first)),
+                    'rr_set_envmap_geometry')
+        return self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width')
+
+    @staticmethod
+    def _fill_prepass(pin, fr, keep):
+        bg = np.ascontiguousarray(fr['bg'], np.float64)
+        depth = np.asarray(fr['depth'])
+        depth = np.ascontiguousarray(depth, np.float32 if depth.dtype == np.float32 else np.float64)
+        H, W = bg.shape[:2]
+        assert bg.shape == (H, W, 3) and depth.shape == (H, W), (bg.shape, depth.shape)
+        pin.H, pin.W, pin.bg, pin.depth = H, W, _ptr(bg), _ptr(depth)
+        pin.depth_f64 = 1 if depth.dtype == np.float64 else 0
+        pin.beta_ext, pin.beta_hg, pin.irr_num, pin.irr_den = [float(v) for v in fr['fog']]
+        keep.append((bg, depth))
+        return bg
+
+    def prepass_frames(self, frames, want_env=True, want_env_u8=False):
+        """frames: list of dict(bg, depth, fog=(beta_ext, beta_hg, irr_num, irr_den)).  Returns a list of
+        dict(rainy_bg[, env_xyY][, env_bgr_u8])."""
+        n = len(frames)
+        pin = (rr_prepass_in * n)()
+        pout = (rr_prepass_out * n)()
+        keep, outs = [], []
+        We = self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width') if (want_env or want_env_u8) else 0
+        for k, fr in enumerate(frames):
+            bg = self._fill_prepass(pin[k], fr, keep)
+            H, W = bg.shape[:2]
+            o = dict(rainy_bg=np.zeros((H, W, 3), np.float64))
+            if want_env:
+                o['env_xyY'] = np.zeros((H, We, 3), np.float64)
+            if want_env_u8:
+                o['env_bgr_u8'] = np.zeros((H, We, 3), np.uint8)
+            pout[k].rainy_bg = _ptr(o['rainy_bg'])
+            pout[k].env_xyY = _ptr(o.get('env_xyY'))
+            pout[k].env_bgr_u8 = _ptr(o.get('env_bgr_u8'))
+            outs.append(o)
+        self._check(self.lib.rr_prepass_frames(self.h, n, pin, pout), 'rr_prepass_frames')
+        return outs
+
+    def pipeline_frames(self, frames, want_composite=False, want_rainy_bg=False, want_env_u8=False):
+        """Pre-pass + hot path without a host round trip.  frames: list of dict(bg, depth, fog, omega, drops
+        [, opacity_attenuation, strategy]).  Returns what render_frames returns (+ env_bgr_u8 / fog_bg)."""
+        n = len(frames)
+        pin = (rr_prepass_in * n)()
+        pout = (rr_prepass_out * n)()
+        fin = (rr_frame_in * n)()
+        fout = (rr_frame_out * n)()
+        keep, outs = [], []
+        We = self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width')
+        for k, fr in enumerate(frames):
+            bg = self._fill_prepass(pin[k], fr, keep)
+            H, W = bg.shape[:2]
+            om = np.ascontiguousarray(fr['omega'], np.float64)
+            assert om.shape == (H, We), (om.shape, (H, We))
+            drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
+            o = dict(image_u8=np.zeros((H, W, 3), np.uint8),
+                     rainy_bg=np.zeros((H, W, 3), np.float64) if want_composite else None,
+                     mask=np.zeros((H, W), np.float64), mask_i32=np.zeros((H, W), np.int32),
+                     status=np.zeros(len(drops), np.int32),
+                     fog_bg=np.zeros((H, W, 3), np.float64) if want_rainy_bg else None,
+                     env_bgr_u8=np.zeros((H, We, 3), np.uint8) if want_env_u8 else None)
+            fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, H, We
+            fin[k].bg, fin[k].omega = _ptr(bg), _ptr(om)
+            fin[k].drops = _ptr(drops) if len(drops) else None
+            fin[k].n_drops = len(drops)
+            fin[k].strategy = int(fr.get('strategy', 0))
+            fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
+            fout[k].rainy_rgb = _ptr(o['image_u8'])
+            fout[k].rainy_bg_out = _ptr(o['rainy_bg'])
+            fout[k].mask_f64 = _ptr(o['mask'])
+            fout[k].mask_i32 = _ptr(o['mask_i32'])
+            fout[k].drop_status = _ptr(o['status']) if len(drops) else None
+            pout[k].rainy_bg = _ptr(o['fog_bg'])
+            pout[k].env_xyY = None
+            pout[k].env_bgr_u8 = _ptr(o['env_bgr_u8'])
+            keep.append((om, drops))
+            outs.append(o)
+        self._check(self.lib.rr_pipeline_frames(self.h, n, pin, fin, fout, pout), 'rr_pipeline_frames')
         return outs
 
     # ---- device-resident path (bench / multi-frame pipelines) -------------------------------

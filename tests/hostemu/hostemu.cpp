@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "rr_device.h"
+#include "rr_prepass.h"
 
 using namespace rr;
 
@@ -175,6 +176,45 @@ int emu_render_frame(int H, int W, int He, int We, const double* bg, const doubl
     }
   }
   return 0;
+}
+
+
+// Pre-pass of one frame (fog + environment map) with the per-pixel bodies of rr_prepass.h.
+// rainy: H*W*3, env_xyY: H*We*3, env_u8: H*We*3 (We = cw + 2*(cw/2)); returns We or < 0.
+int emu_prepass(int H, int W, const double* bg, const void* depth, int depth_f64, double beta_ext, double beta_hg, double irr_num,
+                double irr_den, int fog_k, const double* fog_w, int env_k, const double* env_w, int cw, int n_uniq,
+                const int32_t* uniq, const int32_t* first, double* rainy, double* env_xyY, uint8_t* env_u8) {
+  using namespace rrpre;
+  Kernels kn{};
+  kn.fog_k = fog_k;
+  kn.env_k = env_k;
+  for (int i = 0; i < fog_k; i++) kn.fog_w[i] = fog_w[i];
+  for (int i = 0; i < env_k; i++) kn.env_w[i] = env_w[i];
+  std::vector<int32_t> src((size_t)H * cw), top(cw), bot(cw);
+  if (!build_env_tables(H, W, cw, n_uniq, uniq, first, src.data(), top.data(), bot.data())) return -1;
+  EnvGeom g{H, W, cw, cw / 2, cw + 2 * (cw / 2), src.data(), top.data(), bot.data()};
+  const size_t px = (size_t)H * W, ex = (size_t)H * g.We;
+  std::vector<double> fext(px), tmpF(px), tmpL(px * 3), mean(3), etmp(ex * 3);
+  std::vector<uint32_t> epack(ex);
+  PreScratch sc{fext.data(), tmpF.data(), tmpL.data(), nullptr, mean.data(), epack.data(), etmp.data()};
+  PreFrame F{bg, depth, rainy, env_xyY, env_u8, beta_ext, beta_hg, irr_num, irr_den, depth_f64, 0};
+  for (int c = 0; c < 3; c++) {         // k_fog_sum / k_fog_mean (sum order differs from the device's tree: ~1e-16)
+    double s = 0;
+    for (size_t p = 0; p < px; p++) s += (irr_num * bg[p * 3 + c]) / irr_den;
+    mean[c] = s / (double)px;
+  }
+  for (size_t p = 0; p < px; p++) fog_ext_px(F, 0, H, W, sc, (int64_t)p);
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) fog_h_px(F, 0, H, W, kn, sc, y, x);
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) fog_v_px(F, 0, H, W, kn, sc, y, x);
+  for (int r = 0; r < H; r++)
+    for (int x = 0; x < g.We; x++) env_build_px(F, 0, g, sc, r, x);
+  for (int r = 0; r < H; r++)
+    for (int x = 0; x < g.We; x++) env_h_px(0, g, kn, sc, r, x);
+  for (int r = 0; r < H; r++)
+    for (int x = 0; x < g.We; x++) env_v_px(F, 0, g, kn, sc, r, x);
+  return g.We;
 }
 
 }  // extern "C"
