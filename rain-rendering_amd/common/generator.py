@@ -64,6 +64,8 @@ class Generator:
         self.rank, self.world = sharding.rank_world()
         self.device = int(getattr(args, 'device', os.environ.get('LOCAL_RANK', '0')))
         self._hip = None
+        self._pool = None
+        self._saves = []
         self.stats = []
         if self.rendering_strategy not in (None, 'white'):
             raise NotImplementedError("rendering_strategy %r: 'naive_db' reads a non-existent attribute in the reference "
@@ -91,8 +93,53 @@ class Generator:
             self._hip = hip_backend.RainHip(self.device)
         return self._hip
 
+    def _io_pool(self):
+        """Threads for PNG decode / encode (PIL's codecs release the GIL).  SURVEY 8f next #3: the host I/O
+        around the GPU call is what bounds the driver end to end, so it runs ahead of / behind the GPU."""
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4))))
+        return self._pool
+
+    def _load_frame(self, image_file, depth_file, rs):
+        """Image and depth of one frame as Generator.run reads them (generator.py:352-384)."""
+        bg = imgops.imread_bgr(image_file) / 255.0                                   # generator.py:352
+        if rs != 1:
+            bg = imgops.resize_linear(bg, int(bg.shape[1] // rs), int(bg.shape[0] // rs))
+        if depth_file.endswith(".png"):
+            depth = imgops.imread_unchanged(depth_file)
+            if depth is None:
+                return None
+            depth = depth.astype(np.float32) / 256.
+        elif depth_file.endswith(".npy"):
+            depth = np.load(depth_file)
+        else:
+            raise Exception("Invalid extension")
+        ds = self.settings["depth_scale"]
+        depthHW = np.array([int((depth.shape[0] * ds) // rs), int((depth.shape[1] * ds) // rs)])
+        if not np.all(depth.shape[:2] == depthHW):
+            depth = imgops.resize_linear(depth.astype(np.float64), int(depthHW[1]), int(depthHW[0]))
+        assert np.all(np.array(depth.shape[:2]) <= np.array(bg.shape[:2])), "Depth cannot be larger than the image"
+        if not np.all(np.array(depth.shape[:2]) == np.array(bg.shape[:2])):
+            bg = my_utils.crop_center(bg, depth.shape[0], depth.shape[1])
+        return np.ascontiguousarray(bg), depth
+
+    def _save_frame(self, p, o):
+        os.makedirs(os.path.dirname(p['out_rainy_path']), exist_ok=True)
+        os.makedirs(os.path.dirname(p['out_rainy_mask_path']), exist_ok=True)
+        imgops.imsave_rgb(p['out_rainy_path'], o['image_u8'])                      # generator.py:466
+        imgops.imsave_scalar(p['out_rainy_mask_path'], o['mask'])                   # generator.py:467
+        if self.save_envmap:
+            os.makedirs(os.path.dirname(p['out_env_path']), exist_ok=True)
+            env_bgr = o['env_bgr_u8'] / 255.0                                      # generator.py:469 (plt.imsave of a float map)
+            imgops.imsave_rgb(p['out_env_path'], (np.clip(env_bgr[..., ::-1], 0, 1) * 255).astype(np.uint8))
+
+    def _drain_saves(self, keep=0):
+        while len(self._saves) > keep:
+            self._saves.pop(0).result()
+
     def _flush(self, pending):
-        """Render the pending frames in one library call and save their outputs."""
+        """Render the pending frames in one library call; their outputs are encoded on the I/O pool."""
         if not pending:
             return
         t0 = time.time()
@@ -100,20 +147,14 @@ class Generator:
         outs = self._hip_ctx().pipeline_frames([p['frame'] for p in pending], want_env_u8=self.save_envmap)
         dt = time.time() - t0
         for p, o in zip(pending, outs):
-            os.makedirs(os.path.dirname(p['out_rainy_path']), exist_ok=True)
-            os.makedirs(os.path.dirname(p['out_rainy_mask_path']), exist_ok=True)
-            imgops.imsave_rgb(p['out_rainy_path'], o['image_u8'])                  # generator.py:466
-            imgops.imsave_scalar(p['out_rainy_mask_path'], o['mask'])               # generator.py:467
-            if self.save_envmap:
-                os.makedirs(os.path.dirname(p['out_env_path']), exist_ok=True)
-                env_bgr = o['env_bgr_u8'] / 255.0                                  # generator.py:469 (plt.imsave of a float map)
-                imgops.imsave_rgb(p['out_env_path'], (np.clip(env_bgr[..., ::-1], 0, 1) * 255).astype(np.uint8))
+            self._saves.append(self._io_pool().submit(self._save_frame, dict(p, frame=None), o))
             n_skip = int(np.count_nonzero(o['status']))
             self.stats.append(dict(file=p['out_rainy_path'], drops=len(o['status']), skipped=n_skip,
                                    gpu_ms=1e3 * dt / len(pending)))
             if n_skip and self.verbose:
                 print("\nTrace: %d of %d rain drops not rendered in %s" % (n_skip, len(o['status']), p['out_rainy_path']))
         pending.clear()
+        self._drain_saves(keep=4 * self.batch)          # bound the frames in flight
 
     def compute_drop(self, bg, drop_dict, rainy_bg, rainy_mask, rainy_saturation_mask):
         """Single-drop compatibility seam with the reference's signature (generator.py:119-191):
@@ -212,13 +253,13 @@ class Generator:
                 frames_exist_nb = 0
                 pending = []
                 sim_t0 = time.time()
-                for f_idx, i in enumerate(idx):
+                # work items first (skip / overwrite decisions), so that image + depth decoding can run ahead
+                # of the GPU on the I/O pool; everything that touches the legacy global RNG stays on this thread
+                work = []
+                for i in idx:
                     image_file, depth_file = files[i], depth_files[i]
-                    f_name_idx = i                                                   # generator.py:312 (nuscenes remap not supported)
                     assert os.path.exists(image_file), "Image file {} does not exist".format(image_file)
                     assert os.path.exists(depth_file), "Depth file {} does not exist".format(depth_file)
-                    np.random.seed(f_name_idx)                                       # generator.py:318
-                    frame = frame_render_dict[f_name_idx % len(frame_render_dict)]
                     file_name = os.path.split(image_file)[-1]
                     out_rainy_path = os.path.join(out_dir, 'rainy_image', '{}.png'.format(file_name[:-4]))
                     out_rainy_mask_path = os.path.join(out_dir, 'rain_mask', '{}.png'.format(file_name[:-4]))
@@ -231,27 +272,21 @@ class Generator:
                             pass
                         else:
                             raise NotImplementedError
-                    bg = imgops.imread_bgr(image_file) / 255.0                      # generator.py:352
-                    if rs != 1:
-                        bg = imgops.resize_linear(bg, int(bg.shape[1] // rs), int(bg.shape[0] // rs))
-                    if depth_file.endswith(".png"):
-                        depth = imgops.imread_unchanged(depth_file)
-                        if depth is None:
-                            print('Missing/Corrupted depth data (%s)' % depth_file)
-                            continue
-                        depth = depth.astype(np.float32) / 256.
-                    elif depth_file.endswith(".npy"):
-                        depth = np.load(depth_file)
-                    else:
-                        raise Exception("Invalid extension")
-                    ds = self.settings["depth_scale"]
-                    depthHW = np.array([int((depth.shape[0] * ds) // rs), int((depth.shape[1] * ds) // rs)])
-                    if not np.all(depth.shape[:2] == depthHW):
-                        depth = imgops.resize_linear(depth.astype(np.float64), int(depthHW[1]), int(depthHW[0]))
-                    assert np.all(np.array(depth.shape[:2]) <= np.array(bg.shape[:2])), "Depth cannot be larger than the image"
-                    if not np.all(np.array(depth.shape[:2]) == np.array(bg.shape[:2])):
-                        bg = my_utils.crop_center(bg, depth.shape[0], depth.shape[1])
-                    bg = np.ascontiguousarray(bg)
+                    work.append((i, image_file, depth_file, out_rainy_path, out_rainy_mask_path, out_env_path))
+                ahead = max(2 * self.batch, 4)
+                loads = {}
+                for f_idx, (i, image_file, depth_file, out_rainy_path, out_rainy_mask_path, out_env_path) in enumerate(work):
+                    for j in range(f_idx, min(f_idx + ahead, len(work))):
+                        if j not in loads:
+                            loads[j] = self._io_pool().submit(self._load_frame, work[j][1], work[j][2], rs)
+                    loaded = loads.pop(f_idx).result()
+                    f_name_idx = i                                                   # generator.py:312 (nuscenes remap not supported)
+                    np.random.seed(f_name_idx)                                       # generator.py:318
+                    frame = frame_render_dict[f_name_idx % len(frame_render_dict)]
+                    if loaded is None:
+                        print('Missing/Corrupted depth data (%s)' % depth_file)
+                        continue
+                    bg, depth = loaded
                     H, W = bg.shape[:2]
                     # FOG.fog_rain_layer (generator.py:386), map_generator.generate_map (:400) and the xyY
                     # conversion (:407-408) run on the GPU inside rr_pipeline_frames; the host only provides
@@ -270,16 +305,13 @@ class Generator:
                                                    strategy=1 if self.rendering_strategy == 'white' else 0),
                                         out_rainy_path=out_rainy_path, out_rainy_mask_path=out_rainy_mask_path,
                                         out_env_path=out_env_path))
-                    same_shape = all(p['frame']['bg'].shape == pending[0]['frame']['bg'].shape for p in pending)
-                    if len(pending) >= self.batch or not same_shape:
-                        last = None if same_shape else pending.pop()
+                    if len(pending) >= self.batch:
                         self._flush(pending)
-                        if last is not None:
-                            pending.append(last)
                     if self.verbose:
                         sys.stdout.write('\r          S. {} / {}, F. {} / {}   ({:.1f}s)'.format(
-                            folder_idx + 1, folders_num, f_idx + 1, len(idx), time.time() - sim_t0))
+                            folder_idx + 1, folders_num, f_idx + 1, len(work), time.time() - sim_t0))
                 self._flush(pending)
+                self._drain_saves()
                 if frames_exist_nb > 0:
                     print("Skipped {}/{} already existing renderings".format(frames_exist_nb, len(idx)))
             print("\n\nEnd of the simulation")
