@@ -190,6 +190,21 @@ def main():
                    "ms_per_step": 1e3 * (p1 - p0) / args.steps, "frames_per_s": B * args.steps / (p1 - p0),
                    "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(pstats.items(), key=lambda kv: -kv[1][1])}}
 
+    # --- extra: the host-pointer entry (rr_pipeline_frames): bg + depth + drops up over PCIe, pre-pass and hot
+    # path on the device, u8 image + masks down.  Reported, never `value`.
+    host_incl = None
+    if prepass is not None:
+        depth_h = np.ascontiguousarray(depth_t.cpu().numpy())
+        hf = [dict(bg=host_frames[i][0], depth=depth_h, fog=consts, omega=sc.omega, drops=host_frames[i][2]) for i in range(B)]
+        rh.pipeline_frames(hf)
+        h0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            rh.pipeline_frames(hf)
+        h1 = time.perf_counter()
+        host_incl = {"what": "rr_pipeline_frames with pageable host buffers (PCIe + pre-pass + hot path), not `value`",
+                     "frames_per_s": B * reps / (h1 - h0), "ms_per_step": 1e3 * (h1 - h0) / reps}
+
     if rank == 0:
         frames_total = B * args.steps * world
         fps = frames_total / elapsed
@@ -224,6 +239,8 @@ def main():
         }
         if prepass is not None:
             out["prepass"] = prepass
+        if host_incl is not None:
+            out["host_inclusive"] = host_incl
         if not args.no_cpu_baseline:
             # CPU reference = the numpy oracle in its op-for-op ("faithful") mode, 1 core, on the
             # first --cpu-sample-drops streaks of frame 0; extrapolated linearly in the drop count.

@@ -199,6 +199,14 @@ int rr_profile_enable(rr_ctx* ctx, int32_t on);
 int rr_profile_reset(rr_ctx* ctx);
 int rr_profile_read(rr_ctx* ctx, rr_kernel_stat* out, int32_t cap);   /* returns #entries or <0 */
 
+/* Host-only helper (no device, no ctx): the random draws of one frame's drop loop, bit-identical to
+ * numpy's legacy global RandomState after np.random.seed(seed) (generator.py:318): per drop one
+ * randint(tex_lo[k], tex_lo[k]+10) (bad_weather.py:252-264) and, for non-Big drops, one
+ * normal(0, noise_std) (generator.py:136; noise[k] is the raw deviate, 0 for Big drops).  Lets a
+ * driver prepare frames on worker threads instead of the process-global generator. */
+int rr_host_drop_draws(uint32_t seed, int32_t n, const int32_t* tex_lo, const uint8_t* is_big, double noise_std,
+                       int32_t* tex_index, double* noise);
+
 /* sizes, for binding self-checks */
 int rr_sizeof_drop(void);
 int rr_sizeof_camera(void);

@@ -98,8 +98,22 @@ class Generator:
         around the GPU call is what bounds the driver end to end, so it runs ahead of / behind the GPU."""
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4))))
+            self._pool = ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 4))))
         return self._pool
+
+    def _pack(self, frame, imW, imH, seed):
+        """Frame filter + drop table with the frame's random draws (generator.py:318,413-425)."""
+        keep = hip_backend.filter_streaks(frame.table, imW, imH)                    # generator.py:413-420
+        assert len(keep) <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
+        return hip_backend.pack_drops(frame.table, keep, self.db, self.noise_std, self.noise_scale, seed=seed)
+
+    def _prepare_frame(self, image_file, depth_file, rs, seed, frame, imW, imH, pack):
+        """Worker-thread part of one frame: decode image + depth and (when no state is shared between
+        frames) build the drop table from the library's own per-frame generator."""
+        loaded = self._load_frame(image_file, depth_file, rs)
+        if loaded is None:
+            return None
+        return loaded[0], loaded[1], (self._pack(frame, imW, imH, seed) if pack else None)
 
     def _load_frame(self, image_file, depth_file, rs):
         """Image and depth of one frame as Generator.run reads them (generator.py:352-384)."""
@@ -274,19 +288,23 @@ class Generator:
                             raise NotImplementedError
                     work.append((i, image_file, depth_file, out_rainy_path, out_rainy_mask_path, out_env_path))
                 ahead = max(2 * self.batch, 4)
+                noisy = bool(self.noise_scale) and bool(self.noise_std)
                 loads = {}
                 for f_idx, (i, image_file, depth_file, out_rainy_path, out_rainy_mask_path, out_env_path) in enumerate(work):
                     for j in range(f_idx, min(f_idx + ahead, len(work))):
                         if j not in loads:
-                            loads[j] = self._io_pool().submit(self._load_frame, work[j][1], work[j][2], rs)
+                            # f_name_idx = i (generator.py:312; nuscenes remap not supported)
+                            loads[j] = self._io_pool().submit(self._prepare_frame, work[j][1], work[j][2], rs, work[j][0],
+                                                              frame_render_dict[work[j][0] % len(frame_render_dict)],
+                                                              imW, imH, not noisy)
                     loaded = loads.pop(f_idx).result()
-                    f_name_idx = i                                                   # generator.py:312 (nuscenes remap not supported)
-                    np.random.seed(f_name_idx)                                       # generator.py:318
+                    f_name_idx = i
+                    np.random.seed(f_name_idx)                                       # generator.py:318 (kept for callers)
                     frame = frame_render_dict[f_name_idx % len(frame_render_dict)]
                     if loaded is None:
                         print('Missing/Corrupted depth data (%s)' % depth_file)
                         continue
-                    bg, depth = loaded
+                    bg, depth, drops = loaded
                     H, W = bg.shape[:2]
                     # FOG.fog_rain_layer (generator.py:386), map_generator.generate_map (:400) and the xyY
                     # conversion (:407-408) run on the GPU inside rr_pipeline_frames; the host only provides
@@ -296,10 +314,10 @@ class Generator:
                         env_w = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
                         geom_hw = (H, W)
                     omega = solid_angle.get_solid_angles(np.empty((H, env_w, 0)))    # generator.py:410
-                    keep = hip_backend.filter_streaks(frame.table, imW, imH)         # generator.py:413-420
-                    assert len(keep) <= 2 ** 16, \
-                        "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
-                    drops = hip_backend.pack_drops(frame.table, keep, self.db, self.noise_std, self.noise_scale)
+                    if drops is None:
+                        # angular noise rotates the streak end points IN the shared table (generator.py:152-161),
+                        # so frames that reuse a simulator frame must be packed in order, on this thread
+                        drops = self._pack(frame, imW, imH, f_name_idx)
                     pending.append(dict(frame=dict(bg=bg, depth=depth, fog=fog_const, omega=omega, drops=drops,
                                                    opacity_attenuation=self.opacity_attenuation,
                                                    strategy=1 if self.rendering_strategy == 'white' else 0),

@@ -76,7 +76,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_profile_reset', 'rr_profile_read', 'rr_sizeof_drop', 'rr_sizeof_camera', 'rr_sizeof_frame_in',
            'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
-           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels']
+           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws']
 
 _lib = None
 
@@ -119,6 +119,8 @@ def load_library(path=None):
     lib.rr_pipeline_frames.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(rr_prepass_in),
                                        ctypes.POINTER(rr_frame_in), ctypes.POINTER(rr_frame_out),
                                        ctypes.POINTER(rr_prepass_out)]
+    lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+                                       ctypes.c_void_p, ctypes.c_void_p]
     assert lib.rr_sizeof_prepass_in() == ctypes.sizeof(rr_prepass_in)
     assert lib.rr_sizeof_prepass_out() == ctypes.sizeof(rr_prepass_out)
     assert lib.rr_sizeof_prepass_kernels() == ctypes.sizeof(rr_prepass_kernels)
@@ -167,26 +169,52 @@ def filter_streaks(table, imW, imH):
     return np.nonzero(keep)[0]
 
 
-def pack_drops(table, idx, db, noise_std=0.0, noise_scale=0.0):
-    """rr_drop[] for the streaks table[idx], consuming the legacy global RandomState exactly
-    like the reference's per-drop loop does: one randint per drop (bad_weather.py:252-264),
-    then one normal per non-Big drop (generator.py:136).  Applies the in-place endpoint
-    rotation of generator.py:152-161 to the table (persistent, like the reference)."""
+def drop_draws(seed, tex_lo, is_big, noise_std):
+    """(tex_index, raw normal deviates) of one frame's drop loop for np.random.seed(seed), from the
+    library's host-side legacy-RandomState implementation (rr_host_drop_draws): thread-safe, leaves
+    the process-global generator untouched."""
+    lib = load_library()
+    n = len(tex_lo)
+    lo = np.ascontiguousarray(tex_lo, np.int32)
+    big = np.ascontiguousarray(is_big, np.uint8)
+    tex = np.empty(n, np.int32)
+    noise = np.zeros(n, np.float64)
+    rc = lib.rr_host_drop_draws(ctypes.c_uint32(int(seed) & 0xffffffff), n, _ptr(lo), _ptr(big), float(noise_std),
+                                _ptr(tex), _ptr(noise))
+    if rc != 0:
+        raise RuntimeError("rr_host_drop_draws failed (%d)" % rc)
+    return tex, noise
+
+
+def pack_drops(table, idx, db, noise_std=0.0, noise_scale=0.0, seed=None):
+    """rr_drop[] for the streaks table[idx] with the random draws of the reference's per-drop loop:
+    one randint per drop (bad_weather.py:252-264), then one normal per non-Big drop (generator.py:136).
+    seed=None consumes the legacy process-global RandomState like the reference does (the caller has
+    called np.random.seed); an integer seed gives the identical draws from the library's own generator
+    (rr_host_drop_draws) without touching global state, so frames can be packed on worker threads.
+    Applies the in-place endpoint rotation of generator.py:152-161 to the table (persistent, like the
+    reference)."""
     n = len(idx)
     out = np.zeros(n, DROP_DTYPE)
     if n == 0:
         return out
     bucket = db.texture_bucket(table.ratio[idx])
     types = table.type[idx]
-    tex = np.empty(n, np.int32)
-    noise = np.zeros(n)
-    randint, normal = np.random.randint, np.random.normal
-    lo = (bucket * 10).tolist()
-    big = (types == 0).tolist()
-    for k in range(n):
-        tex[k] = randint(lo[k], lo[k] + 10)
-        if not big[k]:
-            noise[k] = normal(0.0, noise_std) * noise_scale
+    if seed is not None:
+        if not 0 <= int(seed) <= 2 ** 32 - 1:
+            raise ValueError("Seed must be between 0 and 2**32 - 1")
+        tex, noise = drop_draws(seed, bucket * 10, types == 0, noise_std)
+        noise = noise * noise_scale
+    else:
+        tex = np.empty(n, np.int32)
+        noise = np.zeros(n)
+        randint, normal = np.random.randint, np.random.normal
+        lo = (bucket * 10).tolist()
+        big = (types == 0).tolist()
+        for k in range(n):
+            tex[k] = randint(lo[k], lo[k] + 10)
+            if not big[k]:
+                noise[k] = normal(0.0, noise_std) * noise_scale
     s = table.ips[idx].astype(np.float64)
     e = table.ipe[idx].astype(np.float64)
     nb = types != 0

@@ -70,3 +70,36 @@ def test_envmap_width_matches_reference_formula():
     for W, We in [(256, 393), (1242, 1909), (1024, 1573), (2048, 3149)]:
         assert h.synthetic.envmap_width(6.0, W) == We
     assert h.synthetic.envmap_width(5.5, 1600) == 2373
+
+
+def test_native_drop_draws_equal_numpy_legacy_randomstate(built):
+    """rr_host_drop_draws (csrc/rr_host.cpp) against numpy's global legacy generator, draw for draw."""
+    for seed in (0, 1, 7, 123456, 2 ** 32 - 1):
+        n = 3000
+        lo = (np.random.RandomState(seed % 1000).randint(0, 8, n) * 10).astype(np.int32)
+        big = np.random.RandomState(seed % 1000 + 1).rand(n) < 0.3
+        for std in (0.0, 2.5):
+            np.random.seed(seed)
+            tex, noise = np.empty(n, np.int32), np.zeros(n)
+            for k in range(n):
+                tex[k] = np.random.randint(lo[k], lo[k] + 10)
+                if not big[k]:
+                    noise[k] = np.random.normal(0.0, std)
+            t, nz = h.hb.drop_draws(seed, lo, big, std)
+            assert np.array_equal(t, tex) and np.array_equal(nz, noise)
+
+
+def test_pack_drops_seeded_equals_global_rng(tmp_path, built):
+    sc = h.Scene(tmp_path, 64, 96, 300, seed0=5)
+    fr = list(sc.db.streaks_simulator.values())[0]
+    idx = h.hb.filter_streaks(fr.table, 96, 64)
+    for std, scale in ((0.0, 0.0), (3.0, 1.0)):
+        ips, ipe = fr.table.ips.copy(), fr.table.ipe.copy()
+        np.random.seed(11)
+        a = h.hb.pack_drops(fr.table, idx, sc.db, std, scale)
+        mut = (fr.table.ips.copy(), fr.table.ipe.copy())
+        fr.table.ips[:], fr.table.ipe[:] = ips, ipe
+        b = h.hb.pack_drops(fr.table, idx, sc.db, std, scale, seed=11)
+        assert a.tobytes() == b.tobytes()
+        assert np.array_equal(mut[0], fr.table.ips) and np.array_equal(mut[1], fr.table.ipe)
+        fr.table.ips[:], fr.table.ipe[:] = ips, ipe
