@@ -71,7 +71,9 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int4* bbox;                       // [frame][drops] footprint (x0,y0,x1,y1), empty when not composited
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
   int32_t* ccount;                  // [frame][coarse tiles]
-  int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small
+  int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small, -, -, #duplicate raw tiles
+  int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
+  int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
 };
 
 // ---------------------------------------------------------------------------
@@ -267,6 +269,67 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
     sc.arena_need[f] = sh[1023];
     if (sh[1023] > arena_cap) atomicExch(sc.overflow, 1);
   }
+}
+
+// ---------------------------------------------------------------------------
+// raw-tile de-duplication
+// ---------------------------------------------------------------------------
+// The raw alpha tile of a drop (before the defocus blur) is a pure function of the texture, the
+// flip, the tile size and the rotation / homography -- nothing of the drop's position, depth or
+// colour enters.  Streak end points are integer pixels and there are 50 textures, so within a
+// batch most drops share their raw tile with another drop (typically 5 of 6 at 16 frames per
+// batch).  One thread per drop: drops with bit-identical tile parameters elect one of them
+// through an open-addressing table (atomicCAS); the others take over its arena offset and drop
+// out of the tile work lists.  Which drop wins the election is irrelevant: every candidate
+// would write the same bits.
+__device__ inline bool same_raw_tile(const DropPlan& a, const DropPlan& b) {
+  if (a.kind != b.kind || a.tex != b.tex || a.flip != b.flip || a.tw != b.tw || a.th != b.th || a.bw0 != b.bw0 ||
+      a.nW != b.nW || a.nH != b.nH || a.rs_mode != b.rs_mode || a.isx != b.isx || a.isy != b.isy)
+    return false;
+  // doubles compared as bit patterns: -0.0 / NaN never compare "equal by accident"
+  for (int k = 0; k < 9; k++)
+    if (__double_as_longlong(a.mi[k]) != __double_as_longlong(b.mi[k])) return false;
+  for (int k = 0; k < 6; k++)
+    if (__double_as_longlong(a.ma[k]) != __double_as_longlong(b.ma[k])) return false;
+  return __double_as_longlong(a.scale_x) == __double_as_longlong(b.scale_x) &&
+         __double_as_longlong(a.scale_y) == __double_as_longlong(b.scale_y) &&
+         __double_as_longlong(a.inv_sx) == __double_as_longlong(b.inv_sx) &&
+         __double_as_longlong(a.inv_sy) == __double_as_longlong(b.inv_sy);
+}
+__device__ inline uint32_t raw_tile_hash(const DropPlan& p) {
+  uint32_t h = 2166136261u;
+  auto mix = [&](uint32_t v) { h = (h ^ v) * 16777619u; };
+  mix((uint32_t)p.kind); mix((uint32_t)p.tex); mix((uint32_t)p.flip); mix((uint32_t)p.tw); mix((uint32_t)p.th);
+  mix((uint32_t)p.nW); mix((uint32_t)p.nH);
+  for (int k = 0; k < 9; k++) { const long long b = __double_as_longlong(p.mi[k]); mix((uint32_t)b); mix((uint32_t)(b >> 32)); }
+  for (int k = 0; k < 6; k++) { const long long b = __double_as_longlong(p.ma[k]); mix((uint32_t)b); mix((uint32_t)(b >> 32)); }
+  h ^= h >> 15;
+  return h;
+}
+__global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_drops, int n_frames, int enable, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= frames[f].n_drops) return;
+  const int gi = f * max_drops + i;
+  DropPlan& p = sc.plan[gi];
+  int canon = gi;
+  if (enable && p.status == RR_DROP_OK && sc.sizes[gi] != 0) {
+    const uint32_t cap = 2u * (uint32_t)n_frames * (uint32_t)max_drops;
+    uint32_t h = raw_tile_hash(p) % cap;
+    for (;;) {
+      const int prev = atomicCAS(&sc.htab[h], 0, gi + 1);
+      if (prev == 0) break;                               // this drop renders the tile
+      if (same_raw_tile(sc.plan[prev - 1], p)) {
+        canon = prev - 1;
+        break;
+      }
+      h = h + 1 == cap ? 0 : h + 1;
+    }
+    if (canon != gi) {
+      p.a0_off = sc.plan[canon].a0_off;                   // an elected drop never changes its own offset
+      atomicAdd(&sc.counts[f * 8 + 7], 1);
+    }
+  }
+  sc.canon[gi] = canon;
 }
 
 // ---------------------------------------------------------------------------
@@ -490,7 +553,7 @@ __global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, in
   if (i >= frames[f].n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
   const DropPlan& p = sc.plan[gi];
-  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0) return;
+  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || sc.canon[gi] != (int)gi) return;
   TexGlobal tx{texels + tex_off[p.tex], tex_h[p.tex], tex_w[p.tex]};
   double* A0 = sc.arena + p.a0_off;
   const int n = p.tw * p.th;
@@ -943,7 +1006,9 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
-    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
+    if (sc.canon[base + i] == (int)(base + i)) {         // duplicates of another drop's raw tile render nothing
+      if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
+    }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { c[4]++; continue; }
       const BlurLayout L = blur_layout(p);
@@ -973,7 +1038,9 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
-    if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
+    if (sc.canon[base + i] == (int)(base + i)) {
+      if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
+    }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
       const BlurLayout L = blur_layout(p);
@@ -1526,6 +1593,7 @@ struct rr_ctx {
   // profiling
   bool prof = false;
   int tile_dbg = 0;                 // RAINHIP_TILE_DBG: timing experiments only (skips stages of k_tile)
+  bool dedup = true;                 // RAINHIP_NO_DEDUP=1 renders every drop's raw tile (A/B check of k_dedup)
   bool simple_tile = false;          // RAINHIP_SIMPLE_TILE=1: one-thread-per-pixel tile kernel (A/B reference)
   std::vector<ProfEntry> prof_pending;
   std::vector<rr_kernel_stat> prof_stats;
@@ -1641,6 +1709,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
       if ((rc = dev_alloc(ctx, ctx->sc.ccount, (size_t)F * nct))) return rc;
     }
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.canon, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.htab, fd * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fconst, (size_t)F * 2))) return rc;
     const int ntiles = ((dm.W + TILE - 1) / TILE) * ((dm.H + TILE - 1) / TILE);
@@ -1756,6 +1826,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     {
       ProfScope ps(ctx, s, "k_scan");
       hipLaunchKernelGGL(k_scan, dim3(n), dim3(1024), 0, s, ctx->d_frames, D, ctx->arena_cap, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_dedup");
+      HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, s));
+      HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, s));
+      hipLaunchKernelGGL(k_dedup, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
       ProfScope ps(ctx, s, "k_lists");
@@ -1979,6 +2055,8 @@ int rr_create(rr_ctx** out, int device) {
   {
     const char* e = getenv("RAINHIP_SIMPLE_TILE");
     ctx->simple_tile = e && e[0] == '1';
+    const char* nd = getenv("RAINHIP_NO_DEDUP");
+    ctx->dedup = !(nd && nd[0] == '1');
     const char* d = getenv("RAINHIP_TILE_DBG");
     ctx->tile_dbg = d ? atoi(d) : 0;
   }
@@ -2029,6 +2107,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.list_slow);
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
+  hipFree(ctx->sc.canon);
+  hipFree(ctx->sc.htab);
   hipFree(ctx->sc.list_small);
   hipFree(ctx->sc.colpart);
   hipFree(ctx->sc.bbox);
@@ -2417,6 +2497,14 @@ int rr_envmap_width(rr_ctx* ctx) {
     return RR_E_STATE;
   }
   return ctx->eg.We;
+}
+
+int rr_batch_counts(rr_ctx* ctx, int32_t frame, int32_t out[8]) {
+  if (!ctx || !out || frame < 0 || frame >= ctx->last_n || !ctx->sc.counts) return RR_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, ctx->sc.counts + (size_t)frame * 8, sizeof(int32_t) * 8, hipMemcpyDeviceToHost));
+  return RR_OK;
 }
 
 int rr_profile_enable(rr_ctx* ctx, int32_t on) {

@@ -76,7 +76,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_profile_reset', 'rr_profile_read', 'rr_sizeof_drop', 'rr_sizeof_camera', 'rr_sizeof_frame_in',
            'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
-           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws']
+           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts']
 
 _lib = None
 
@@ -119,6 +119,7 @@ def load_library(path=None):
     lib.rr_pipeline_frames.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(rr_prepass_in),
                                        ctypes.POINTER(rr_frame_in), ctypes.POINTER(rr_frame_out),
                                        ctypes.POINTER(rr_prepass_out)]
+    lib.rr_batch_counts.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                        ctypes.c_void_p, ctypes.c_void_p]
     assert lib.rr_sizeof_prepass_in() == ctypes.sizeof(rr_prepass_in)
@@ -464,6 +465,12 @@ class RainHip:
             return False
         self._check(rc, 'rr_synchronize')
         return True
+
+    def batch_counts(self, frame):
+        """Work-list sizes of one frame of the last batch (see rr_batch_counts)."""
+        out = (ctypes.c_int32 * 8)()
+        self._check(self.lib.rr_batch_counts(self.h, int(frame), out), 'rr_batch_counts')
+        return list(out)
 
     def profile(self, on):
         self.lib.rr_profile_enable(self.h, 1 if on else 0)

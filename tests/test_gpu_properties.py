@@ -71,3 +71,25 @@ def test_zero_opacity_and_mean_shift(setup):
     exp = (np.clip((comp - (comp.mean() - bg.mean()))[..., ::-1], 0, 1) * 255).astype(np.uint8)
     assert np.abs(exp.astype(int) - base['image_u8'].astype(int)).max() <= 1
     assert (exp != base['image_u8']).mean() < 1e-3
+
+
+def test_raw_tile_dedup_is_invisible(setup, monkeypatch):
+    """k_dedup lets drops with bit-identical tile parameters share one raw tile (within a frame and across
+    the frames of a batch).  Same bits with the election switched off (RAINHIP_NO_DEDUP=1)."""
+    sc, bg, env, drops, rh, base = setup
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    two = rh.render_frames([fr, fr])                                       # second frame: every tile is a duplicate
+    c0, c1 = rh.batch_counts(0), rh.batch_counts(1)
+    ok = int(np.count_nonzero(base['status'] == 0))
+    assert c0[7] + c1[7] > ok                                              # > one frame's worth of duplicates
+    assert (c0[0] + c0[1]) + (c1[0] + c1[1]) + (c0[7] + c1[7]) >= 2 * ok   # every composited drop has a tile
+    monkeypatch.setenv('RAINHIP_NO_DEDUP', '1')
+    plain = h.hb.RainHip(0)
+    plain.set_streak_db(sc.db.streaks_light)
+    plain.set_camera(sc.cam)
+    ref = plain.render_frames([fr])[0]
+    assert plain.batch_counts(0)[7] == 0
+    plain.close()
+    for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
+        assert np.array_equal(ref[k], base[k]), k
+        assert np.array_equal(two[0][k], base[k]) and np.array_equal(two[1][k], base[k]), k
