@@ -72,6 +72,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
   int32_t* ccount;                  // [frame][coarse tiles]
   int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small, -, -, #duplicate raw tiles
+  int32_t* list_col;                // [frame][drops] drops grouped by image region (k_col_order), for XCD-local colour gathers
+  int32_t* col_off;                 // [frame][16] start of each of the 8 region groups (+ total at [8])
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
   int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
 };
@@ -369,20 +371,66 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
   return xl <= xr;
 }
 
+// The FOV polygon of a drop sits where the drop is seen, so drops that are close in the image
+// gather from neighbouring entries of the prefix table.  Workgroups go to the 8 XCDs round robin,
+// each XCD with its own 4 MB L2: k_col_order groups the drops of a frame by image region (4 x 2)
+// and k_colour_bands gives region r to the workgroups with blockIdx.x % 8 == r, so that one L2
+// only ever sees the part of the 23 MB table its region's polygon outlines sweep.
+constexpr int COL_REGIONS = 8;
+__device__ inline int colour_region(const rr_drop& d, const Dims& dm) {
+  const int rx = imin(imax((d.x0 * 4) / imax(dm.W, 1), 0), 3), ry = imin(imax((d.y0 * 2) / imax(dm.H, 1), 0), 1);
+  return ry * 4 + rx;
+}
+__global__ __launch_bounds__(1024) void k_col_order(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int n = frames[f].n_drops;
+  const rr_drop* drops = frames[f].drops;
+  const int chunk = (n + 1023) / 1024;
+  const int i0 = t * chunk, i1 = min(i0 + chunk, n);
+  int c[COL_REGIONS];
+  for (int k = 0; k < COL_REGIONS; k++) c[k] = 0;
+  for (int i = i0; i < i1; i++) c[colour_region(drops[i], dm)]++;
+  __shared__ int sh[1024][COL_REGIONS];
+  for (int k = 0; k < COL_REGIONS; k++) sh[t][k] = c[k];
+  __syncthreads();
+  for (int ofs = 1; ofs < 1024; ofs <<= 1) {
+    int v[COL_REGIONS];
+    for (int k = 0; k < COL_REGIONS; k++) v[k] = (t >= ofs) ? sh[t - ofs][k] : 0;
+    __syncthreads();
+    for (int k = 0; k < COL_REGIONS; k++) sh[t][k] += v[k];
+    __syncthreads();
+  }
+  int o[COL_REGIONS], start = 0;
+  for (int k = 0; k < COL_REGIONS; k++) {
+    o[k] = start + ((t == 0) ? 0 : sh[t - 1][k]);
+    if (t == 0) sc.col_off[f * 16 + k] = start;
+    start += sh[1023][k];
+  }
+  if (t == 0) sc.col_off[f * 16 + COL_REGIONS] = start;
+  int32_t* lst = sc.list_col + (int64_t)f * max_drops;
+  for (int i = i0; i < i1; i++) lst[o[colour_region(drops[i], dm)]++] = i;
+}
+
 // Colour, pass 1: one wave per (drop, row band): polygon row spans x prefix table, wave reduce.
 constexpr int COL_BANDS = 1;        // row bands per drop (8 = one band per XCD L2 measured 2.7x SLOWER: per-wave edge scan dominates)
 
 constexpr int HE_MAX = 1024;        // tallest environment map the LDS span tables hold (else per-row edge scan)
 
-__global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+template <int HE_CAP>                // rows the LDS span tables hold: 512 (7 workgroups per CU) or HE_MAX
+__global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int dbg) {
+  static_assert(COL_BANDS == 1, "region scheduling assumes one band");
   const int f = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int band = blockIdx.x % COL_BANDS;
-  const int i = (blockIdx.x / COL_BANDS) * 4 + wave;
-  if (i >= frames[f].n_drops) return;
+  const int band = 0;
+  // gridDim.x is a multiple of 8: workgroup (f, bx) runs on XCD bx % 8 and takes drops of region bx % 8
+  const int region = blockIdx.x % COL_REGIONS;
+  const int r_begin = sc.col_off[f * 16 + region], r_end = sc.col_off[f * 16 + region + 1];
+  __shared__ int s_xl[4][HE_CAP], s_xr[4][HE_CAP];
+  __shared__ int s_edge[4][5][64];                 // per wave: item range end, x0, y0, x1, y1 of every polygon edge
+  for (int j = r_begin + (blockIdx.x / COL_REGIONS) * 4 + wave; j < r_end; j += (gridDim.x / COL_REGIONS) * 4) {
+  const int i = sc.list_col[(int64_t)f * max_drops + j];
   const int64_t gi = (int64_t)f * max_drops + i;
   const int n = sc.npts[gi];
-  __shared__ int s_xl[4][HE_MAX], s_xr[4][HE_MAX];
   double S[4] = {0, 0, 0, 0};
   int any = 0;
   if (n > 0) {
@@ -396,42 +444,63 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
     const int rows_per_band = (dm.He + COL_BANDS - 1) / COL_BANDS;
     const int ya = max(max(ymin, 0), band * rows_per_band), yb = min(min(ymax, dm.He - 1), (band + 1) * rows_per_band - 1);
     const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
-    const bool use_lds = dm.He <= HE_MAX;
+    const bool use_lds = dm.He <= HE_CAP;
     if (use_lds) {
-      // scan conversion: every edge only visits the rows it spans (~2 edges per row) instead of
-      // every row testing all edges; the wave owns its span tables, rows of one edge are distinct
+      // scan conversion over flattened (edge, row) items: lane e describes edge e (rows it covers inside
+      // [ya, yb]); an inclusive scan gives every edge its item range; item k finds its edge by binary
+      // search and folds its x into the row's [min, max] with LDS atomics (order-free, exact).
       int* xl = s_xl[wave];
       int* xr = s_xr[wave];
+      int* e_end = s_edge[wave][0];
+      int* e_x0 = s_edge[wave][1];
+      int* e_y0 = s_edge[wave][2];
+      int* e_x1 = s_edge[wave][3];
+      int* e_y1 = s_edge[wave][4];
       for (int y = ya + lane; y <= yb; y += 64) { xl[y] = 1 << 30; xr[y] = -(1 << 30); }
+      int cnt = 0, ex0 = 0, ey0 = 0, ex1 = 0, ey1 = 0;
+      if (lane < n) {
+        const int j = (lane + 1 == n) ? 0 : lane + 1;
+        ex0 = px[lane]; ey0 = py[lane]; ex1 = px[j]; ey1 = py[j];
+        cnt = max(min(max(ey0, ey1), yb) - max(min(ey0, ey1), ya) + 1, 0);
+      }
+      int run = cnt;
+      for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const int v = __shfl_up(run, ofs);
+        if (lane >= ofs) run += v;
+      }
+      const int total = (dbg & 0x20000) ? 0 : __shfl(run, n - 1);
+      e_end[lane] = lane < n ? run : 0x7fffffff;
+      e_x0[lane] = ex0; e_y0[lane] = ey0; e_x1[lane] = ex1; e_y1[lane] = ey1;
       wave_lds_sync();
-      for (int e = 0; e < n; e++) {
-        const int j = (e + 1 == n) ? 0 : e + 1;
-        const int x0 = px[e], y0 = py[e], x1 = px[j], y1 = py[j];
+      for (int k = lane; k < total; k += 64) {
+        int e = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (e_end[e + step - 1] <= k) e += step;             // first edge whose range ends after k
+        const int x0 = e_x0[e], y0 = e_y0[e], x1 = e_x1[e], y1 = e_y1[e];
+        const int first = e > 0 ? e_end[e - 1] : 0;
+        const int y = max(min(y0, y1), ya) + (k - first);
+        int xlo, xhi;
         if (y0 == y1) {
-          if (lane == 0 && y0 >= ya && y0 <= yb) {
-            xl[y0] = min(xl[y0], min(x0, x1));
-            xr[y0] = max(xr[y0], max(x0, x1));
-          }
+          xlo = min(x0, x1);
+          xhi = max(x0, x1);
         } else {
           const bool swp = y1 < y0;
           const int xa = swp ? x1 : x0, yA = swp ? y1 : y0, xb = swp ? x0 : x1, yB = swp ? y0 : y1;
           const int den = yB - yA;
-          const double inv = 1.0 / (double)(2 * den);
-          for (int y = max(yA, ya) + lane; y <= min(yB, yb); y += 64) {
-            const int nn = 2 * (xb - xa) * (y - yA) + den;
-            // floor(nn / (2*den)): the reciprocal product can be off by one ulp only; fix up exactly
-            int q = (int)floor((double)nn * inv);
-            const int rem = nn - q * 2 * den;
-            if (rem < 0) q -= 1; else if (rem >= 2 * den) q += 1;
-            const int xv = xa + q;
-            xl[y] = min(xl[y], xv);
-            xr[y] = max(xr[y], xv);
-          }
+          const int nn = 2 * (xb - xa) * (y - yA) + den;
+          // floor(nn / (2*den)): the reciprocal product can be off by one ulp only; fix up exactly
+          int q = (int)floor((double)nn * (1.0 / (double)(2 * den)));
+          const int rem = nn - q * 2 * den;
+          if (rem < 0) q -= 1; else if (rem >= 2 * den) q += 1;
+          xlo = xhi = xa + q;
         }
-        wave_lds_sync();
+        atomicMin(&xl[y], xlo);
+        atomicMax(&xr[y], xhi);
       }
+      wave_lds_sync();
     }
-    for (int y = ya + lane; y <= yb; y += 64) {
+    for (int y = ya + lane; y <= ((dbg & 0x10000) ? ya - 1 : yb); y += 64) {
       int xl_, xr_;
       bool ok;
       if (use_lds) {
@@ -462,6 +531,8 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
     double* o = sc.colpart + (gi * COL_BANDS + band) * 5;
     o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[3];
     o[4] = (double)any;
+  }
+  wave_lds_sync();                  // the span tables are reused by this wave's next drop
   }
 }
 
@@ -1710,6 +1781,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     }
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.canon, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.list_col, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.col_off, (size_t)F * 16))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.htab, fd * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fconst, (size_t)F * 2))) return rc;
@@ -1844,7 +1917,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, sc_col, "k_colour");
-      hipLaunchKernelGGL(k_colour_bands, dim3(((max_drops + 3) / 4) * COL_BANDS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc);
+      hipLaunchKernelGGL(k_col_order, dim3(n), dim3(1024), 0, sc_col, ctx->d_frames, dm, D, sc);
+      const int col_blocks = (((max_drops + 3) / 4 + COL_REGIONS - 1) / COL_REGIONS) * COL_REGIONS;
+      if (dm.He <= 512)
+        hipLaunchKernelGGL(k_colour_bands<512>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg);
+      else
+        hipLaunchKernelGGL(k_colour_bands<HE_MAX>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg);
       hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc);
     }
     if (ctx->simple_tile) {
@@ -2108,6 +2186,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
   hipFree(ctx->sc.canon);
+  hipFree(ctx->sc.list_col);
+  hipFree(ctx->sc.col_off);
   hipFree(ctx->sc.htab);
   hipFree(ctx->sc.list_small);
   hipFree(ctx->sc.colpart);
