@@ -107,3 +107,22 @@ def test_bad_arguments_are_errors(built):
         rh.render_frames([dict(bg=np.zeros((8, 8, 3)), rainy_bg=np.zeros((8, 8, 3)), env_xyY=np.zeros((8, 9, 3)),
                                omega=np.ones((8, 9)), drops=np.zeros(0, h.hb.DROP_DTYPE))])
     rh.close()
+
+
+@pytest.mark.parametrize("Hh,Ww", [(600, 200), (1100, 96)])
+def test_tall_environment_maps(tmp_path, built, Hh, Ww):
+    """He = 600 uses the 1024-row LDS span tables of the colour kernel, He = 1100 exceeds them and falls
+    back to the per-row edge scan; the kitti-shaped tests only reach the 512-row variant."""
+    sc = h.Scene(tmp_path, Hh, Ww, 80, seed0=13)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)])[0]
+    rh.close()
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    assert np.array_equal(out['status'], emu['status'])
+    assert np.array_equal(out['mask'], emu['mask'])
+    assert np.abs(out['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+    assert np.abs(out['rainy_bg'] - emu['rainy_bg']).max() < 1e-9
