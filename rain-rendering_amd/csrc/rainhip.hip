@@ -2065,11 +2065,15 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
   }
   {
     ProfScope ps(ctx, s, "k_fog_h");
-    hipLaunchKernelGGL(rrpre::k_fog_h, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
+    hipLaunchKernelGGL(rrpre::k_fog_h, dim3((W + rrpre::FOG_SEG - 1) / rrpre::FOG_SEG, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
   }
   {
     ProfScope ps(ctx, s, "k_fog_v");
-    hipLaunchKernelGGL(rrpre::k_fog_v, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
+    if (ctx->pk.fog_k == 25)        // the reference's 25 taps: register strips of FOG_RV rows
+      hipLaunchKernelGGL(rrpre::k_fog_v_strip<12>, dim3((W + 255) / 256, (H + rrpre::FOG_RV - 1) / rrpre::FOG_RV, n), dim3(256), 0, s,
+                         ctx->d_pre, H, W, ctx->pk, sc);
+    else
+      hipLaunchKernelGGL(rrpre::k_fog_v, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
   }
   if (want_env) {
     const rrpre::EnvGeom g = ctx->eg;

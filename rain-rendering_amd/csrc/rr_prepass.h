@@ -53,7 +53,7 @@ struct EnvGeom {
 struct PreScratch {                 // [frame][...]
   double* fext;                     // [H*W]
   double* tmpF;                     // [H*W]
-  double* tmpL;                     // [H*W*3]
+  double* tmpL;                     // [3][H*W] (planar: the vertical pass reads whole rows of one plane)
   double* part;                     // [64*3]
   double* mean;                     // [3]
   uint32_t* epack;                  // [H*We] b | g<<8 | r<<16 | mask<<24
@@ -120,39 +120,86 @@ RRP_HD void fog_ext_px(const PreFrame& F, int f, int H, int W, const PreScratch&
 }
 
 
-// horizontal 25-tap pass of f_ext and of l_in = clip(beta_hg * mean * (1 - f_ext))   :66-73,79-80
-RRP_HD void fog_h_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y, int x) {
-  const int64_t px = (int64_t)H * W;
-  const double* fe = sc.fext + f * px + (int64_t)y * W;
-  const int f64 = F.depth_f64, half = kn.fog_k / 2;
-  double k3[3];
-  for (int c = 0; c < 3; c++) k3[c] = F.beta_hg * sc.mean[f * 3 + c];
-  const double v0 = fe[x], o0 = one_minus(v0, f64);
-  double aF = v0 * kn.fog_w[half], aL[3];
-  for (int c = 0; c < 3; c++) aL[c] = clip01(k3[c] * o0) * kn.fog_w[half];
-  for (int j = -half; j < 0; j++) {
-    const double va = fe[reflect101(x + j, W)], vb = fe[reflect101(x - j, W)], w = kn.fog_w[half + j];
-    aF += (va + vb) * w;
-    const double oa = one_minus(va, f64), ob = one_minus(vb, f64);
-    for (int c = 0; c < 3; c++) aL[c] += (clip01(k3[c] * oa) + clip01(k3[c] * ob)) * w;
-  }
-  const int64_t p = f * px + (int64_t)y * W + x;
-  sc.tmpF[p] = f64 ? aF : (double)(float)aF;
-  for (int c = 0; c < 3; c++) sc.tmpL[p * 3 + c] = aL[c];
+// The four source planes of the fog blur at one pixel: f_ext and l_in = clip(beta_hg * mean * (1 - f_ext))
+// per channel (:66-73).  Evaluated once per SOURCE pixel, then shared by the taps that read it.
+RRP_HD void fog_src(double fe, int f64, const double k3[3], double out[4]) {
+  const double om = one_minus(fe, f64);
+  out[0] = fe;
+  for (int c = 0; c < 3; c++) out[1 + c] = clip01(k3[c] * om);
 }
 
-// vertical pass + rainy = clip(image * f_ext + l_in, 0, 1)                            :82-86,93
+// horizontal pass (:79-80) at staged position i: S[p][i + j], j = -half..half, are plane p's taps
+// (LDS on the device, plain arrays in tests/hostemu).  scipy.ndimage.correlate1d's symmetric order.
+RRP_HD void fog_h_taps(const double* S, int pitch, int i, const Kernels& kn, int f64, double out[4]) {
+  const int half = kn.fog_k / 2;
+  for (int p = 0; p < 4; p++) {
+    const double* v = S + p * pitch + i;
+    double a = v[0] * kn.fog_w[half];
+    for (int j = -half; j < 0; j++) a += (v[j] + v[-j]) * kn.fog_w[half + j];
+    out[p] = a;
+  }
+  if (!f64) out[0] = (double)(float)out[0];          // the float32 depth path keeps f_ext in float32
+}
+
+constexpr int FOG_SEG = 256;        // output columns per staged row segment
+constexpr int FOG_RV = 8;           // output rows per thread of the vertical pass
+
+// stages plane values of columns x0-half .. x0+n+half-1 of row y (reflect-101) into S[4][pitch]
+RRP_HD void fog_stage_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y, int x0, int i,
+                         double* S, int pitch) {
+  const int half = kn.fog_k / 2;
+  const double fe = sc.fext[(int64_t)f * H * W + (int64_t)y * W + reflect101(x0 - half + i, W)];
+  double k3[3], o[4];
+  for (int c = 0; c < 3; c++) k3[c] = F.beta_hg * sc.mean[f * 3 + c];
+  fog_src(fe, F.depth_f64, k3, o);
+  for (int p = 0; p < 4; p++) S[p * pitch + i] = o[p];
+}
+RRP_HD void fog_h_store(int f, int H, int W, const PreScratch& sc, int y, int x, const double o[4]) {
+  const int64_t px = (int64_t)H * W, q = (int64_t)y * W + x;
+  sc.tmpF[f * px + q] = o[0];
+  for (int c = 0; c < 3; c++) sc.tmpL[(f * 3 + c) * px + q] = o[1 + c];
+}
+
+// vertical pass + rainy = clip(image * f_ext + l_in, 0, 1)  (:82-86,93) for FOG_RV consecutive rows of
+// column x.  The HALF + FOG_RV + HALF source rows of a plane are read once into registers and shared by
+// the FOG_RV outputs (the per-pixel form reads 2*HALF+1 rows per output through L2: the pass was L2-bound).
+template <int HALF>
+RRP_HD void fog_v_strip(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y0, int x) {
+  const int64_t px = (int64_t)H * W;
+  double outF[FOG_RV];
+#pragma unroll 1                      // one plane's window live at a time (registers)
+  for (int plane = 0; plane < 4; plane++) {
+    const double* src = (plane == 0 ? sc.tmpF + f * px : sc.tmpL + (f * 3 + (plane - 1)) * px) + x;
+    double v[FOG_RV + 2 * HALF];
+#pragma unroll
+    for (int k = 0; k < FOG_RV + 2 * HALF; k++) v[k] = src[(int64_t)reflect101(y0 - HALF + k, H) * W];
+#pragma unroll
+    for (int r = 0; r < FOG_RV; r++) {
+      double a = v[HALF + r] * kn.fog_w[HALF];
+#pragma unroll
+      for (int j = -HALF; j < 0; j++) a += (v[HALF + r + j] + v[HALF + r - j]) * kn.fog_w[HALF + j];
+      if (plane == 0) {
+        outF[r] = F.depth_f64 ? a : (double)(float)a;
+      } else if (y0 + r < H) {
+        const int64_t q = ((int64_t)(y0 + r) * W + x) * 3 + (plane - 1);
+        F.rainy[q] = clip01(F.bg[q] * outF[r] + a);
+      }
+    }
+  }
+}
+
+// generic tap count: one output per call
 RRP_HD void fog_v_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y, int x) {
   const int64_t px = (int64_t)H * W, base = f * px;
   const int half = kn.fog_k / 2;
   const int64_t p0 = base + (int64_t)y * W + x;
   double aF = sc.tmpF[p0] * kn.fog_w[half], aL[3];
-  for (int c = 0; c < 3; c++) aL[c] = sc.tmpL[p0 * 3 + c] * kn.fog_w[half];
+  for (int c = 0; c < 3; c++) aL[c] = sc.tmpL[(p0 - base) + (f * 3 + c) * px] * kn.fog_w[half];
   for (int j = -half; j < 0; j++) {
     const int64_t pa = base + (int64_t)reflect101(y + j, H) * W + x, pb = base + (int64_t)reflect101(y - j, H) * W + x;
     const double w = kn.fog_w[half + j];
     aF += (sc.tmpF[pa] + sc.tmpF[pb]) * w;
-    for (int c = 0; c < 3; c++) aL[c] += (sc.tmpL[pa * 3 + c] + sc.tmpL[pb * 3 + c]) * w;
+    for (int c = 0; c < 3; c++) aL[c] += (sc.tmpL[(pa - base) + (f * 3 + c) * px] + sc.tmpL[(pb - base) + (f * 3 + c) * px]) * w;
   }
   if (!F.depth_f64) aF = (double)(float)aF;
   const int64_t q = ((int64_t)y * W + x) * 3;
@@ -287,13 +334,31 @@ __global__ void __launch_bounds__(256) k_fog_ext(const PreFrame* fr, int H, int 
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p < (int64_t)H * W) fog_ext_px(fr[blockIdx.y], blockIdx.y, H, W, sc, p);
 }
+// one workgroup per (row, segment of FOG_SEG columns): the segment plus its halos is staged in LDS as
+// four planes, then every thread folds its 2*half+1 taps from LDS
 __global__ void __launch_bounds__(256) k_fog_h(const PreFrame* fr, int H, int W, Kernels kn, PreScratch sc) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x < W) fog_h_px(fr[blockIdx.z], blockIdx.z, H, W, kn, sc, blockIdx.y, x);
+  constexpr int PITCH = FOG_SEG + KMAX - 1;
+  __shared__ double S[4 * PITCH];
+  const int f = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * FOG_SEG, half = kn.fog_k / 2;
+  const PreFrame F = fr[f];
+  const int n = min(FOG_SEG, W - x0) + 2 * half;
+  for (int i = threadIdx.x; i < n; i += 256) fog_stage_px(F, f, H, W, kn, sc, y, x0, i, S, PITCH);
+  __syncthreads();
+  const int x = x0 + threadIdx.x;
+  if (x < W) {
+    double o[4];
+    fog_h_taps(S, PITCH, half + threadIdx.x, kn, F.depth_f64, o);
+    fog_h_store(f, H, W, sc, y, x, o);
+  }
 }
 __global__ void __launch_bounds__(256) k_fog_v(const PreFrame* fr, int H, int W, Kernels kn, PreScratch sc) {
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x < W) fog_v_px(fr[blockIdx.z], blockIdx.z, H, W, kn, sc, blockIdx.y, x);
+}
+template <int HALF>
+__global__ void __launch_bounds__(256) k_fog_v_strip(const PreFrame* fr, int H, int W, Kernels kn, PreScratch sc) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < W) fog_v_strip<HALF>(fr[blockIdx.z], blockIdx.z, H, W, kn, sc, blockIdx.y * FOG_RV, x);
 }
 __global__ void __launch_bounds__(256) k_env_build(const PreFrame* fr, EnvGeom g, PreScratch sc) {
   const int x = blockIdx.x * 256 + threadIdx.x;

@@ -204,10 +204,27 @@ int emu_prepass(int H, int W, const double* bg, const void* depth, int depth_f64
     mean[c] = s / (double)px;
   }
   for (size_t p = 0; p < px; p++) fog_ext_px(F, 0, H, W, sc, (int64_t)p);
-  for (int y = 0; y < H; y++)
-    for (int x = 0; x < W; x++) fog_h_px(F, 0, H, W, kn, sc, y, x);
-  for (int y = 0; y < H; y++)
-    for (int x = 0; x < W; x++) fog_v_px(F, 0, H, W, kn, sc, y, x);
+  {                                     // k_fog_h: staged row segments (LDS on the device)
+    const int half = fog_k / 2, pitch = FOG_SEG + KMAX - 1;
+    std::vector<double> S(4 * pitch);
+    for (int y = 0; y < H; y++)
+      for (int x0 = 0; x0 < W; x0 += FOG_SEG) {
+        const int nseg = (W - x0 < FOG_SEG ? W - x0 : FOG_SEG);
+        for (int i = 0; i < nseg + 2 * half; i++) fog_stage_px(F, 0, H, W, kn, sc, y, x0, i, S.data(), pitch);
+        for (int t = 0; t < nseg; t++) {
+          double o[4];
+          fog_h_taps(S.data(), pitch, half + t, kn, depth_f64, o);
+          fog_h_store(0, H, W, sc, y, x0 + t, o);
+        }
+      }
+  }
+  if (fog_k == 25) {                    // k_fog_v_strip<12>
+    for (int y0 = 0; y0 < H; y0 += FOG_RV)
+      for (int x = 0; x < W; x++) fog_v_strip<12>(F, 0, H, W, kn, sc, y0, x);
+  } else {
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) fog_v_px(F, 0, H, W, kn, sc, y, x);
+  }
   for (int r = 0; r < H; r++)
     for (int x = 0; x < g.We; x++) env_build_px(F, 0, g, sc, r, x);
   for (int r = 0; r < H; r++)
