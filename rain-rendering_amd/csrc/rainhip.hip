@@ -1168,6 +1168,42 @@ __device__ inline void gauss_half_table_wave(double sigma, int r, double* hw) {
   if (lane <= r) hw[r - lane] = ph / tot;
 }
 
+// Four consecutive outputs (stride `st` doubles apart) of the symmetric correlate1d of radius r:
+//   acc_k = c[k]*w[r];  for ii = -r..-1:  acc_k = acc_k + (c[k+ii] + c[k-ii]) * w[ii+r]
+// As the tap distance shrinks the upper/lower operand windows of the four outputs slide by one
+// element, so each tap needs two new LDS values instead of eight; the loop is unrolled by four so
+// that the sliding is pure register renaming (no moves).  c0 = centre of output 0.
+__device__ inline void blur4(const double* c0, int st, const double* hw, int r, double& acc0, double& acc1, double& acc2,
+                             double& acc3) {
+  const double wc = hw[r];
+  acc0 = c0[0] * wc; acc1 = c0[st] * wc; acc2 = c0[2 * st] * wc; acc3 = c0[3 * st] * wc;
+  double a0 = c0[(-r) * st], a1 = c0[(1 - r) * st], a2 = c0[(2 - r) * st], a3 = c0[(3 - r) * st];
+  double b0 = c0[r * st], b1 = c0[(1 + r) * st], b2 = c0[(2 + r) * st], b3 = c0[(3 + r) * st];
+  int ii = -r;
+  for (; ii + 3 < 0; ii += 4) {
+    const double w0 = hw[ii + r], w1 = hw[ii + 1 + r], w2 = hw[ii + 2 + r], w3 = hw[ii + 3 + r];
+    const double na0 = c0[(4 + ii) * st], na1 = c0[(5 + ii) * st], na2 = c0[(6 + ii) * st], na3 = c0[(7 + ii) * st];
+    const double nb0 = c0[(-ii - 1) * st], nb1 = c0[(-ii - 2) * st], nb2 = c0[(-ii - 3) * st], nb3 = c0[(-ii - 4) * st];
+    acc0 = acc0 + (a0 + b0) * w0; acc1 = acc1 + (a1 + b1) * w0; acc2 = acc2 + (a2 + b2) * w0; acc3 = acc3 + (a3 + b3) * w0;
+    acc0 = acc0 + (a1 + nb0) * w1; acc1 = acc1 + (a2 + b0) * w1; acc2 = acc2 + (a3 + b1) * w1; acc3 = acc3 + (na0 + b2) * w1;
+    acc0 = acc0 + (a2 + nb1) * w2; acc1 = acc1 + (a3 + nb0) * w2; acc2 = acc2 + (na0 + b0) * w2; acc3 = acc3 + (na1 + b1) * w2;
+    acc0 = acc0 + (a3 + nb2) * w3; acc1 = acc1 + (na0 + nb1) * w3; acc2 = acc2 + (na1 + nb0) * w3; acc3 = acc3 + (na2 + b0) * w3;
+    a0 = na0; a1 = na1; a2 = na2; a3 = na3;
+    b3 = nb0; b2 = nb1; b1 = nb2; b0 = nb3;
+  }
+  for (; ii < 0; ii++) {
+    const double w = hw[ii + r];
+    const double na = c0[(4 + ii) * st];                               // next upper element of output 3
+    const double nb = c0[(-ii - 1) * st];                              // next lower element of output 0
+    acc0 = acc0 + (a0 + b0) * w;
+    acc1 = acc1 + (a1 + b1) * w;
+    acc2 = acc2 + (a2 + b2) * w;
+    acc3 = acc3 + (a3 + b3) * w;
+    a0 = a1; a1 = a2; a2 = a3; a3 = na;
+    b3 = b2; b2 = b1; b1 = b0; b0 = nb;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // fused defocus blur: both axes of the separable filter through LDS
 // ---------------------------------------------------------------------------
@@ -1184,12 +1220,9 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const DropPlan& p = sc.plan[gi];
   const BlurLayout L = blur_layout(p);
   const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;            // the tile being produced is the EFFECTIVE tile
-  if (cur != item.x && !(dbg & 256)) {                 // the weight tables depend on the drop only
-    __syncthreads();
-    if ((t >> 6) == 0) gauss_half_table_wave(p.sig1, r1, hw1);
-    if ((t >> 6) == 1 && r2 > 0) gauss_half_table_wave(p.sig2, r2, hw2);
-    cur = item.x;                      // (the barrier after the tile load publishes the tables)
-  }
+  // the weight tables depend on the drop only; they are computed by waves 0 and 1 while the first
+  // batch of tile loads is in flight (every item ends with a barrier, so the old tables are free)
+  bool need_tables = cur != item.x && !(dbg & 256);
   const double* src = sc.arena + p.a0_off;          // raw tile (tw x th); the pad is implicit zeros
   double* dst = sc.arena + p.a1_off;                // finished effective tile (ew x eh); raw sits at (r2, r1) inside it
   const int tw = p.tw, th = p.th;
@@ -1207,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       const float inv_wi = 1.0f / (float)wi;
       // haloed tile -> LDS; eight independent global loads in flight per thread
       const int nx = (dbg & 512) ? 0 : wi * hi;
-      for (int base = t; base < nx; base += 2048) {
+      for (int base = t; base < nx || need_tables; base += 2048) {
         double v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1216,6 +1249,12 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
           const int yt = y0 - r1 + yy, xt = x0 - r2 + xx;                    // effective-tile coordinates
           const int y = yt - r1, x = xt - r2;                                // raw-tile coordinates
           v[k] = (idx < nx && yt < ph && xt < pw && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
+        }
+        if (need_tables) {
+          if ((t >> 6) == 0) gauss_half_table_wave(p.sig1, r1, hw1);
+          if ((t >> 6) == 1 && r2 > 0) gauss_half_table_wave(p.sig2, r2, hw2);
+          need_tables = false;           // (the barrier after the tile load publishes the tables)
+          cur = item.x;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++)
@@ -1231,22 +1270,8 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
         for (int idx = t; idx < nv; idx += 256) {
           const int rb = (int)(((float)idx + 0.5f) * inv_wi), x = idx - rb * wi;
           const double* c0 = X + (4 * rb + r1) * wi + x;                      // centre of the first of the four rows
-          const double wc = hw1[r1];
-          double acc0 = c0[0] * wc, acc1 = c0[wi] * wc, acc2 = c0[2 * wi] * wc, acc3 = c0[3 * wi] * wc;
-          // operands for ii = -r1: upper rows (y+ii) and lower rows (y-ii) of outputs 0..3
-          double a0 = c0[(-r1) * wi], a1 = c0[(1 - r1) * wi], a2 = c0[(2 - r1) * wi], a3 = c0[(3 - r1) * wi];
-          double b0 = c0[r1 * wi], b1 = c0[(1 + r1) * wi], b2 = c0[(2 + r1) * wi], b3 = c0[(3 + r1) * wi];
-          for (int ii = -r1; ii < 0; ii++) {
-            const double w = hw1[ii + r1];
-            const double na = c0[(4 + ii) * wi];                              // next upper row of output 3
-            const double nb = c0[(-ii - 1) * wi];                             // next lower row of output 0
-            acc0 = acc0 + (a0 + b0) * w;
-            acc1 = acc1 + (a1 + b1) * w;
-            acc2 = acc2 + (a2 + b2) * w;
-            acc3 = acc3 + (a3 + b3) * w;
-            a0 = a1; a1 = a2; a2 = a3; a3 = na;
-            b3 = b2; b2 = b1; b1 = b0; b0 = nb;
-          }
+          double acc0, acc1, acc2, acc3;
+          blur4(c0, wi, hw1, r1, acc0, acc1, acc2, acc3);
           const int yb = 4 * rb;
           double* o = Y + yb * yp + x;
           if (yb < ho) o[0] = acc0;
@@ -1267,21 +1292,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
           const double* c0 = Y + yy * yp + 4 * cb + r2;                       // centre of the first of the four columns
           double acc0, acc1, acc2, acc3;
           if (r2 > 0) {
-            const double wc = hw2[r2];
-            acc0 = c0[0] * wc; acc1 = c0[1] * wc; acc2 = c0[2] * wc; acc3 = c0[3] * wc;
-            double a0 = c0[-r2], a1 = c0[1 - r2], a2 = c0[2 - r2], a3 = c0[3 - r2];
-            double b0 = c0[r2], b1 = c0[1 + r2], b2 = c0[2 + r2], b3 = c0[3 + r2];
-            for (int ii = -r2; ii < 0; ii++) {
-              const double w = hw2[ii + r2];
-              const double na = c0[4 + ii];
-              const double nb = c0[-ii - 1];
-              acc0 = acc0 + (a0 + b0) * w;
-              acc1 = acc1 + (a1 + b1) * w;
-              acc2 = acc2 + (a2 + b2) * w;
-              acc3 = acc3 + (a3 + b3) * w;
-              a0 = a1; a1 = a2; a2 = a3; a3 = na;
-              b3 = b2; b2 = b1; b1 = b0; b0 = nb;
-            }
+            blur4(c0, 1, hw2, r2, acc0, acc1, acc2, acc3);
           } else {
             acc0 = c0[0]; acc1 = c0[1]; acc2 = c0[2]; acc3 = c0[3];
           }
