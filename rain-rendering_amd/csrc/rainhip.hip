@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
         const int per = (ns + ni - 1) / ni;
         for (int k = 0; k < ni; k++) {
           const int st0 = k * per;
-          items[o[2]++] = make_int4(i, st0, imax(imin(per, ns - st0), 0), 0);
+          items[o[2]++] = make_int4(i, st0, imax(imin(per, ns - st0), 0), L.wo | (L.ho << 16));   // layout travels with the item
         }
       } else {
         lslow[o[3]++] = i;
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const int4 item = items[it];
   const int64_t gi = (int64_t)f * max_drops + item.x;
   const DropPlan& p = sc.plan[gi];
-  const BlurLayout L = blur_layout(p);
+  BlurLayout L{1, item.w & 0xffff, item.w >> 16, 0};               // computed once, by k_lists
   const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;            // the tile being produced is the EFFECTIVE tile
   // the weight tables depend on the drop only; they are computed by waves 0 and 1 while the first
   // batch of tile loads is in flight (every item ends with a barrier, so the old tables are free)
