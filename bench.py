@@ -153,7 +153,7 @@ def main():
         elapsed = float(tt.item())
     stats = rh.profile_read()
     cnts = np.array([rh.batch_counts(i) for i in range(B)])
-    tiles_rendered, tiles_shared = int(cnts[:, 0].sum() + cnts[:, 1].sum()), int(cnts[:, 7].sum())
+    tiles_rendered, tiles_shared = int(cnts[:, 0].sum() + cnts[:, 1].sum() + cnts[:, 5].sum()), int(cnts[:, 7].sum())
 
     # --- extra (outside the timed region, not part of `value`): the fog + environment-map pre-pass that
     # produces rainy_bg / env_xyY on the device (rr_prepass_frames_device), same batch

@@ -196,7 +196,8 @@ int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const r
 
 /* Work-list sizes of frame `frame` of the last batch (after completion): out[0] drops whose raw tile went
  * through the rotate+resize kernel, [1] through the generic kernel, [2] fused-blur work items, [3] slow-blur
- * drops, [4] small-blur drops, [7] drops that re-used another drop's bit-identical raw tile (k_dedup). */
+ * drops, [4] small-blur drops, [5] Big drops (bicubic warp kernel), [6] their pixels, [7] drops that re-used
+ * another drop's bit-identical raw tile (k_dedup). */
 int rr_batch_counts(rr_ctx* ctx, int32_t frame, int32_t out[8]);
 
 /* Per-kernel timing with HIP events on the launch stream (off by default). */

@@ -72,6 +72,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
   int32_t* ccount;                  // [frame][coarse tiles]
   int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small, -, -, #duplicate raw tiles
+  int32_t* list_big;                // [frame][drops] Big drops (bicubic warp) rendered by k_tile_big, one thread per pixel
+  int32_t* big_off;                 // [frame][drops+1] exclusive prefix of their tile sizes, in pixels
   int32_t* list_col;                // [frame][drops] drops grouped by image region (k_col_order), for XCD-local colour gathers
   int32_t* col_off;                 // [frame][16] start of each of the 8 region groups (+ total at [8])
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
@@ -805,7 +807,9 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   __syncthreads();
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
-  const bool tex_fits = (sh + 4) * P <= TEX_LDS;
+  // Staging the texture in LDS costs one pass over all its texels; a small Big tile (bicubic: 16 taps
+  // per output pixel) touches fewer texels than that, and the 50 textures (~350 KB) live in L2 anyway
+  const bool tex_fits = (sh + 4) * P <= TEX_LDS && !(p.kind == KIND_BIG && p.tw * p.th * 12 < sh * sw);
   if (tex_fits) load_tex_padded(s_tex, gtex, sh, sw);
   double* A0 = sc.arena + p.a0_off;      // raw tile, pitch tw
   // integer-ratio INTER_AREA (ResizeAreaFast): the per-pixel chain is sequential by definition;
@@ -856,6 +860,46 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   }
 }
 
+
+// Big drops (cv2.warpPerspective, INTER_CUBIC): ONE THREAD PER OUTPUT PIXEL over the concatenation of
+// all Big tiles of the frame (k_lists' pixel prefix).  A Big tile has ~400 pixels, so a workgroup per
+// drop was all per-item latency; flattened, every lane has a pixel and the grid is full.  Texels come
+// from global memory (the streak DB is L2 resident), the v/255 table and the cubic table from LDS.
+__global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int max_drops, const uint8_t* texels,
+                                                  const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                                                  const float* ctab, Scratch sc) {
+  const int f = blockIdx.y, t = threadIdx.x;
+  __shared__ double s_lut[256];
+  __shared__ float s_ctab[128];
+  __shared__ int s_first;
+  s_lut[t] = (double)t / 255.0;
+  if (t < 128) s_ctab[t] = ctab[t];
+  const int n_big = sc.counts[f * 8 + 5], total = sc.counts[f * 8 + 6];
+  const int32_t* lbig = sc.list_big + (int64_t)f * max_drops;
+  const int32_t* boff = sc.big_off + (int64_t)f * max_drops + f;
+  for (int pb = blockIdx.x * 256; pb < total; pb += gridDim.x * 256) {
+    __syncthreads();
+    if (t == 0) {                                   // last item whose first pixel is <= pb
+      int lo = 0, hi = n_big - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (boff[mid] <= pb) lo = mid; else hi = mid - 1;
+      }
+      s_first = lo;
+    }
+    __syncthreads();
+    const int pix = pb + t;
+    if (pix >= total) continue;
+    int j = s_first;
+    while (boff[j + 1] <= pix) j++;
+    const int64_t gi = (int64_t)f * max_drops + lbig[j];
+    const DropPlan& p = sc.plan[gi];
+    const int local = pix - boff[j];
+    const int y = local / p.tw, x = local - y * p.tw;
+    TexLut tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
+    sc.arena[p.a0_off + local] = warp_big_pixel(p, tx, s_ctab, x, y);
+  }
+}
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
@@ -1073,12 +1117,14 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   const int chunk = (n + 1023) / 1024;
   const int i0 = t * chunk, i1 = min(i0 + chunk, n);
   const int64_t base = (int64_t)f * max_drops;
-  int c[6] = {0, 0, 0, 0, 0, 0};    // #rot-fast (general), #generic, #fused blur items, #slow blur, #small blur, #rot-fast (integer ratio)
+  // #rot-fast (general), #generic, #fused blur items, #slow blur, #small blur, #rot-fast (integer ratio), #big, big pixels
+  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {         // duplicates of another drop's raw tile render nothing
-      if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
+      if (p.kind == KIND_BIG) { c[6]++; c[7] += p.tw * p.th; }
+      else if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { c[4]++; continue; }
@@ -1086,31 +1132,37 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
       if (L.fused) c[2] += imin(blur_subtiles(p, L), BLUR_ITEMS_PER_DROP); else c[3]++;
     }
   }
-  __shared__ int sh[1024][6];
-  for (int k = 0; k < 6; k++) sh[t][k] = c[k];
+  __shared__ int sh[1024][8];
+  for (int k = 0; k < 8; k++) sh[t][k] = c[k];
   __syncthreads();
   for (int ofs = 1; ofs < 1024; ofs <<= 1) {
-    int v[6] = {0, 0, 0, 0, 0, 0};
+    int v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (t >= ofs)
-      for (int k = 0; k < 6; k++) v[k] = sh[t - ofs][k];
+      for (int k = 0; k < 8; k++) v[k] = sh[t - ofs][k];
     __syncthreads();
-    for (int k = 0; k < 6; k++) sh[t][k] += v[k];
+    for (int k = 0; k < 8; k++) sh[t][k] += v[k];
     __syncthreads();
   }
-  int o[6];
-  for (int k = 0; k < 6; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
+  int o[8];
+  for (int k = 0; k < 8; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
   const int n_int = sh[1023][5];     // integer-ratio drops go to the FRONT of the rot list (longest blocks first)
   o[0] += n_int;
   int32_t* lrot = sc.list_rot + base;
   int32_t* lgen = sc.list_gen + base;
   int32_t* lslow = sc.list_slow + base;
   int32_t* lsmall = sc.list_small + base;
+  int32_t* lbig = sc.list_big + base;
+  int32_t* boff = sc.big_off + base + f;                 // n_big + 1 entries per frame
   int4* items = sc.blur_items + base * BLUR_ITEMS_PER_DROP;
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {
-      if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
+      if (p.kind == KIND_BIG) {
+        boff[o[6]] = o[7];
+        lbig[o[6]++] = i;
+        o[7] += p.tw * p.th;
+      } else if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
@@ -1131,6 +1183,9 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   if (t == 1023) {
     for (int k = 0; k < 5; k++) sc.counts[f * 8 + k] = sh[1023][k];
     sc.counts[f * 8 + 0] = sh[1023][0] + sh[1023][5];
+    sc.counts[f * 8 + 5] = sh[1023][6];
+    sc.counts[f * 8 + 6] = sh[1023][7];
+    boff[sh[1023][6]] = sh[1023][7];
   }
 }
 
@@ -1793,6 +1848,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.canon, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_col, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.list_big, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.big_off, fd + F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.col_off, (size_t)F * 16))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.htab, fd * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
@@ -1945,6 +2002,11 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         ProfScope ps(ctx, sc_gen, "k_tile_generic");
         hipLaunchKernelGGL(k_tile_generic, dim3((max_drops + 3) / 4, n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex,
                            ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc, ctx->tile_dbg);
+      }
+      {
+        ProfScope ps(ctx, sc_gen, "k_tile_big");
+        hipLaunchKernelGGL(k_tile_big, dim3(1024, n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+                           ctx->d_tex_off, ctx->d_ctab, sc);
       }
       {
         ProfScope ps(ctx, s, "k_tile");
@@ -2202,6 +2264,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.counts);
   hipFree(ctx->sc.canon);
   hipFree(ctx->sc.list_col);
+  hipFree(ctx->sc.list_big);
+  hipFree(ctx->sc.big_off);
   hipFree(ctx->sc.col_off);
   hipFree(ctx->sc.htab);
   hipFree(ctx->sc.list_small);

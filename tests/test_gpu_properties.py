@@ -82,7 +82,7 @@ def test_raw_tile_dedup_is_invisible(setup, monkeypatch):
     c0, c1 = rh.batch_counts(0), rh.batch_counts(1)
     ok = int(np.count_nonzero(base['status'] == 0))
     assert c0[7] + c1[7] > ok                                              # > one frame's worth of duplicates
-    assert (c0[0] + c0[1]) + (c1[0] + c1[1]) + (c0[7] + c1[7]) >= 2 * ok   # every composited drop has a tile
+    assert (c0[0] + c0[1] + c0[5]) + (c1[0] + c1[1] + c1[5]) + (c0[7] + c1[7]) >= 2 * ok   # every composited drop has a tile
     monkeypatch.setenv('RAINHIP_NO_DEDUP', '1')
     plain = h.hb.RainHip(0)
     plain.set_streak_db(sc.db.streaks_light)
