@@ -239,7 +239,11 @@ def main():
             "config": {"workload": "KITTI data_object shape %dx%d, %d mm/hr (%d streaks/frame after the frame filter: %.0f), "
                                    "precomputed particles; BASELINE.json configs[2]" % (W, H, args.rate, N, n_drops_mean),
                        "frames_per_step_per_gpu": B, "envmap": "%dx%d" % (We, He), "parallelism": "frames sharded, dp%d" % world,
-                       "raw_tiles_per_step": {"rendered": tiles_rendered, "shared_bit_identical": tiles_shared}},
+                       "raw_tiles_per_step": {"rendered": tiles_rendered, "shared_bit_identical": tiles_shared,
+                                              "rotate_resize": int(cnts[:, 0].sum()), "bicubic_warp": int(cnts[:, 5].sum()),
+                                              "generic": int(cnts[:, 1].sum())},
+                       "blur_per_step": {"fused_items": int(cnts[:, 2].sum()), "wave_per_drop": int(cnts[:, 4].sum()),
+                                         "two_pass": int(cnts[:, 3].sum())}},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},

@@ -710,7 +710,7 @@ __device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
   if (!((sh + 4) * (sw + 4) <= TEX_LDS && p.kind == KIND_ROT && p.nW <= NW_MAX && p.tw <= TW_MAX && tile_coords_safe(p))) return false;
   if (p.rs_mode == RS_AREA_FAST) return true;                      // integer ratios: per-wave sequential chains
   const int rows_per_dy = (int)ceil(p.scale_y) + 3;
-  return p.rs_mode == RS_AREA && rows_per_dy * p.tw <= BUF_MAX;
+  return p.rs_mode == RS_AREA && rows_per_dy <= BUF_MAX;             // wide tiles are folded in column chunks
 }
 
 // texture -> LDS with a 2-texel zero border (pitch sw+4).  Border texels are zeroed directly,
@@ -790,6 +790,7 @@ __device__ inline void lds_rot_sample2(const uint8_t* s_tex, const double* s_lut
   outB = sb * (1.0 / 1024.0);
 }
 
+constexpr int GEN_SLICES = 16;
 // Big drops (bicubic warp) and the rare resize modes: one thread per output pixel, texels in LDS.
 __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                                       const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
@@ -800,7 +801,10 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   __shared__ int2 s_adbd[NW_MAX];
   s_lut[t] = (double)t / 255.0;
   const int n_items = sc.counts[f * 8 + 1];
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the generic list
+  // the generic list is a handful of heavy tiles (every pixel a long sequential sum): each is split
+  // over GEN_SLICES workgroups by pixel index, or one of them would be the tail of the whole batch
+  for (int work = blockIdx.x; work < n_items * GEN_SLICES; work += gridDim.x) {      // grid-stride over (item, slice)
+  const int item = work / GEN_SLICES, slice = work - item * GEN_SLICES;
   const int64_t gi = (int64_t)f * max_drops + sc.list_gen[(int64_t)f * max_drops + item];
   const DropPlan& p = sc.plan[gi];
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   if (area_fast) {
     const int area = p.isx * p.isy, n4 = area & ~3;
     const float scale = 1.0f / (float)area;
-    for (int idx = t; idx < n; idx += 256) {
+    for (int idx = t + 256 * slice; idx < n; idx += 256 * GEN_SLICES) {
       const int dy = idx / p.tw, dx = idx - dy * p.tw;
       double sum = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
       int k = 0;
@@ -846,13 +850,13 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
     }
   } else if (tex_fits) {
     TexLutPad tx{s_tex, s_lut, sh, sw};
-    for (int idx = t; idx < n; idx += 256) {
+    for (int idx = t + 256 * slice; idx < n; idx += 256 * GEN_SLICES) {
       int y = idx / p.tw, x = idx - y * p.tw;
       A0[idx] = raw_tile_pixel(p, tx, ctab, x, y);
     }
   } else {
     TexLut tx{gtex, s_lut, sh, sw};
-    for (int idx = t; idx < n; idx += 256) {
+    for (int idx = t + 256 * slice; idx < n; idx += 256 * GEN_SLICES) {
       int y = idx / p.tw, x = idx - y * p.tw;
       A0[idx] = raw_tile_pixel(p, tx, ctab, x, y);
     }
@@ -938,7 +942,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   const RowGeom geom = row_geom(p, sh, sw);
   const int pitch = imin(imax(tile_pitch(p, sh, sw), 1), CAN_W);
   const int Rw = imax(imin(ROWS_W, CAN_W / pitch), 1);       // canvas rows a wave stages at a time
-  const float inv_pitch = 1.0f / (float)pitch, inv_tw = 1.0f / (float)tw;
+  const float inv_pitch = 1.0f / (float)pitch;
   double* can = s_can[wave];
   int4* rowp = s_row[wave];
   if (p.rs_mode == RS_AREA_FAST) {
@@ -1009,7 +1013,13 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     }
     continue;
   }
-  int k_dy = (int)(((double)(BUF_MAX / tw) - 3.0) / sy_scale);
+  // very wide tiles: the row sums of one destination row must fit s_buf, so the destination columns
+  // are taken in chunks of twc (a handful of drops per frame; their canvas rows are sampled once per chunk)
+  const int twc_max = imax(imin(tw, BUF_MAX / ((int)ceil(sy_scale) + 3)), 1);
+  for (int dxa = 0; dxa < tw; dxa += twc_max) {
+  const int twc = imin(twc_max, tw - dxa);
+  const float inv_twc = 1.0f / (float)twc;
+  int k_dy = (int)(((double)(BUF_MAX / twc) - 3.0) / sy_scale);
   if (k_dy < 1) k_dy = 1;
   for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
     const int dy1 = imin(dy0 + k_dy, th);
@@ -1043,9 +1053,9 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       }
       wave_lds_sync();
       // ---- 1b: horizontal folds, one lane per (row, destination column) ----
-      const int items = nr * tw;
+      const int items = nr * twc;
       for (int it = lane; it < ((dbg & 2) ? 0 : items); it += 64) {
-        const int r = (int)(((float)it + 0.5f) * inv_tw), dx = it - r * tw;
+        const int r = (int)(((float)it + 0.5f) * inv_twc), dxl = it - r * twc, dx = dxa + dxl;
         const AreaSpan ax = s_ax[dx];
         const int4 rw = rowp[r];
         const int xlo = rw.z, xhi = rw.z + rw.w - 1;          // staged (possibly non-zero) columns
@@ -1068,35 +1078,36 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
           for (; sx <= m1; sx++) b = b + row[sx] * am;
         }
         if (ax.has_r && ax.s2 >= xlo && ax.s2 <= xhi) b = b + row[ax.s2] * (double)ax.a_r;
-        s_buf[(r0 - lo + r) * tw + dx] = b;
+        s_buf[(r0 - lo + r) * twc + dxl] = b;
       }
       wave_lds_sync();
     }
     __syncthreads();
     // ---- 2: vertical folds ----
-    const int npx = (dbg & 4) ? 0 : (dy1 - dy0) * tw;
+    const int npx = (dbg & 4) ? 0 : (dy1 - dy0) * twc;
     for (int it = t; it < npx; it += 256) {
-      const int r = it / tw, dx = it - r * tw;
+      const int r = it / twc, dxl = it - r * twc, dx = dxa + dxl;
       const int dy = dy0 + r;
       const AreaSpan ay = area_span(p.nH, sy_scale, dy);
       double acc = 0.0;
       bool first = true;
       if (ay.has_l) {
-        acc = (double)ay.a_l * s_buf[(ay.s1 - 1 - lo) * tw + dx];
+        acc = (double)ay.a_l * s_buf[(ay.s1 - 1 - lo) * twc + dxl];
         first = false;
       }
       for (int sy = ay.s1; sy < ay.s2; sy++) {
-        double v = (double)ay.a_m * s_buf[(sy - lo) * tw + dx];
+        double v = (double)ay.a_m * s_buf[(sy - lo) * twc + dxl];
         acc = first ? v : acc + v;
         first = false;
       }
       if (ay.has_r) {
-        double v = (double)ay.a_r * s_buf[(ay.s2 - lo) * tw + dx];
+        double v = (double)ay.a_r * s_buf[(ay.s2 - lo) * twc + dxl];
         acc = first ? v : acc + v;
       }
       A0[dy * tw + dx] = clip01(acc);
     }
     __syncthreads();
+  }
   }
   }
 }
@@ -2000,7 +2011,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     } else {
       {
         ProfScope ps(ctx, sc_gen, "k_tile_generic");
-        hipLaunchKernelGGL(k_tile_generic, dim3((max_drops + 3) / 4, n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex,
+        hipLaunchKernelGGL(k_tile_generic, dim3(imin((max_drops + 3) / 4, 64), n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex,
                            ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc, ctx->tile_dbg);
       }
       {
@@ -2010,7 +2021,9 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       }
       {
         ProfScope ps(ctx, s, "k_tile");
-        hipLaunchKernelGGL(k_tile, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+        // after de-duplication a frame keeps a fraction of its tiles: a capped grid (items are taken
+        // grid-stride) avoids dispatching tens of thousands of empty workgroups
+        hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, 1536), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
                            ctx->d_tex_off, sc, ctx->tile_dbg);
       }
     }
