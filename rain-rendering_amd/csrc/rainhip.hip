@@ -1695,7 +1695,7 @@ struct rr_ctx {
   hipStream_t stream = nullptr;
   hipStream_t s_col = nullptr, s_gen = nullptr;     // side streams: colour chain, generic tiles
   hipEvent_t ev_start = nullptr, ev_scan = nullptr, ev_col = nullptr, ev_gen = nullptr;
-  bool serial = false;              // RAINHIP_CONCURRENT=0: no side streams
+  bool serial = true;               // RAINHIP_CONCURRENT=1 moves the colour chain / Big-drop tiles to side streams
   std::string err;
   // streak DB
   uint8_t* d_tex = nullptr;
@@ -2233,10 +2233,11 @@ int rr_create(rr_ctx** out, int device) {
     return RR_E_HIP;
   }
   {
-    // the colour chain and the Big-drop tiles run beside the rotate/resize tiles on side streams
-    // (+3.5 % at 64 frames per batch); RAINHIP_CONCURRENT=0 puts every kernel on the caller's stream
+    // RAINHIP_CONCURRENT=1: the colour chain and the Big-drop tiles run beside the rotate/resize tiles on
+    // side streams (+3.5 % frames/s at 64 frames per batch).  Off by default: with every kernel on the
+    // caller's stream the per-kernel timings (rr_profile_*, rocprofv3) are not inflated by overlap
     const char* e = getenv("RAINHIP_CONCURRENT");
-    ctx->serial = e && e[0] == '0';
+    ctx->serial = !(e && e[0] == '1');
   }
   if (hipStreamCreateWithFlags(&ctx->s_col, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->s_gen, hipStreamNonBlocking) != hipSuccess ||
