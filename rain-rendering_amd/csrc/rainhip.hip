@@ -2517,14 +2517,16 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
     din[f].bg = st.bg + f * px * 3;
     din[f].rainy_bg = st.rainy + f * px * 3;
     din[f].env_xyY = st.env + f * ex * 3;
-    din[f].omega = st.omega + f * ex;
+    // the solid-angle map depends on the map size only: frames that pass the same host array share one upload
+    const bool same_omega = f > 0 && in[f].omega == in[0].omega;
+    din[f].omega = same_omega ? din[0].omega : st.omega + f * ex;
     din[f].drops = st.drops + (size_t)f * st.drops_cap;
     if (!pre) {
       HIPCHK(hipMemcpyAsync((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
       HIPCHK(hipMemcpyAsync((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
       HIPCHK(hipMemcpyAsync((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    HIPCHK(hipMemcpyAsync((void*)din[f].omega, in[f].omega, ex * sizeof(double), hipMemcpyHostToDevice, s));
+    if (!same_omega) HIPCHK(hipMemcpyAsync((void*)din[f].omega, in[f].omega, ex * sizeof(double), hipMemcpyHostToDevice, s));
     if (in[f].n_drops > 0)
       HIPCHK(hipMemcpyAsync((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * in[f].n_drops, hipMemcpyHostToDevice, s));
     dout[f].rainy_rgb = st.rgb + f * px * 3;
