@@ -199,14 +199,17 @@ def main():
     host_incl = None
     if prepass is not None:
         depth_h = np.ascontiguousarray(depth_t.cpu().numpy())
-        hf = [dict(bg=host_frames[i][0], depth=depth_h, fog=consts, omega=sc.omega, drops=host_frames[i][2]) for i in range(B)]
-        rh.pipeline_frames(hf)
+        # what the main.py driver sends: the uint8 image (bg = bytes / 255.0 on the device), float32 depth, drop table
+        hf = [dict(bg_u8=(host_frames[i][0] * 255).astype(np.uint8), depth=depth_h, fog=consts, omega=sc.omega,
+                   drops=host_frames[i][2]) for i in range(B)]
+        rh.pipeline_frames(hf, want_mask_i32=False)
         h0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            rh.pipeline_frames(hf)
+            rh.pipeline_frames(hf, want_mask_i32=False)
         h1 = time.perf_counter()
-        host_incl = {"what": "rr_pipeline_frames with pageable host buffers (PCIe + pre-pass + hot path), not `value`",
+        host_incl = {"what": "rr_pipeline_frames with pageable host buffers (PCIe up: u8 image + f32 depth + drops; pre-pass + hot "
+                             "path; PCIe down: u8 image + f64 mask), not `value`",
                      "frames_per_s": B * reps / (h1 - h0), "ms_per_step": 1e3 * (h1 - h0) / reps}
 
     if rank == 0:

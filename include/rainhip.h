@@ -102,7 +102,7 @@ typedef struct {
   uint8_t* rainy_rgb;             /* H*W*3 RGB: what plt.imsave(rainy_image) stores (generator.py:461-466), alpha omitted */
   double* rainy_bg_out;           /* optional (may be NULL): H*W*3 BGR composite before the mean shift */
   double* mask_f64;               /* H*W: rainy_mask accumulator (bad_weather.py:450) */
-  int32_t* mask_i32;              /* H*W: floor(mask_f64 * 255)  (SURVEY decision D1) */
+  int32_t* mask_i32;              /* H*W: floor(mask_f64 * 255)  (SURVEY decision D1); may be NULL */
   int32_t* drop_status;           /* n_drops RR_DROP_* codes (may be NULL) */
 } rr_frame_out;
 
@@ -165,6 +165,9 @@ typedef struct {
   double beta_ext;                /* 0.312 * R**0.67                               add_attenuation.py:40-43 */
   double beta_hg;                 /* Henyey-Greenstein phase term, g = 0.97         add_attenuation.py:60-64 */
   double irr_num, irr_den;        /* 4*N**2  and  exposure_s*gain*pi                add_attenuation.py:51-54 */
+  const uint8_t* bg_u8;           /* optional, HOST entry points only: the H*W*3 BGR bytes cv2.imread returned; when set,
+                                   * `bg` is ignored and bg = bytes / 255.0 (generator.py:352) is formed on the device:
+                                   * 1/8 of the PCIe traffic of the float64 image */
 } rr_prepass_in;
 
 typedef struct {
@@ -188,8 +191,8 @@ int rr_prepass_frames_device(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, co
 int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_prepass_out* out);
 
 /* Pre-pass + hot path for n frames with HOST pointers and no host round trip in between:
- * in[f].rainy_bg and in[f].env_xyY are ignored (produced on the device from pre[f]); in[f].bg must
- * equal pre[f].bg; in[f].He/We must be H / rr_envmap_width().  pre_out may be NULL, as may each of
+ * in[f].rainy_bg and in[f].env_xyY are ignored (produced on the device from pre[f]); in[f].bg is ignored
+ * too (the mean shift uses pre[f]'s background); in[f].He/We must be H / rr_envmap_width().  pre_out may be NULL, as may each of
  * its members: what is non-NULL is downloaded as well. */
 int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
                        const rr_prepass_out* pre_out);

@@ -117,8 +117,11 @@ class Generator:
 
     def _load_frame(self, image_file, depth_file, rs):
         """Image and depth of one frame as Generator.run reads them (generator.py:352-384)."""
-        bg = imgops.imread_bgr(image_file) / 255.0                                   # generator.py:352
+        # generator.py:352 `cv2.imread(f) / 255.0`: at render_scale 1 the bytes themselves go to the GPU
+        # (rr_prepass_in.bg_u8) and the division happens there; a resized image has to be float64
+        bg = imgops.imread_bgr(image_file)
         if rs != 1:
+            bg = bg / 255.0
             bg = imgops.resize_linear(bg, int(bg.shape[1] // rs), int(bg.shape[0] // rs))
         if depth_file.endswith(".png"):
             depth = imgops.imread_unchanged(depth_file)
@@ -158,7 +161,7 @@ class Generator:
             return
         t0 = time.time()
         # fog attenuation + environment map + streak rendering, all on the GPU in one call
-        outs = self._hip_ctx().pipeline_frames([p['frame'] for p in pending], want_env_u8=self.save_envmap)
+        outs = self._hip_ctx().pipeline_frames([p['frame'] for p in pending], want_env_u8=self.save_envmap, want_mask_i32=False)
         dt = time.time() - t0
         for p, o in zip(pending, outs):
             self._saves.append(self._io_pool().submit(self._save_frame, dict(p, frame=None), o))
@@ -318,7 +321,9 @@ class Generator:
                         # angular noise rotates the streak end points IN the shared table (generator.py:152-161),
                         # so frames that reuse a simulator frame must be packed in order, on this thread
                         drops = self._pack(frame, imW, imH, f_name_idx)
-                    pending.append(dict(frame=dict(bg=bg, depth=depth, fog=fog_const, omega=omega, drops=drops,
+                    pending.append(dict(frame=dict(bg=None if bg.dtype == np.uint8 else bg,
+                                                   bg_u8=bg if bg.dtype == np.uint8 else None,
+                                                   depth=depth, fog=fog_const, omega=omega, drops=drops,
                                                    opacity_attenuation=self.opacity_attenuation,
                                                    strategy=1 if self.rendering_strategy == 'white' else 0),
                                         out_rainy_path=out_rainy_path, out_rainy_mask_path=out_rainy_mask_path,

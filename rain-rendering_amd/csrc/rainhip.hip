@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     o[1] = c[1];
     o[2] = c[2];
     fr.mask_f64[pix] = m;
-    fr.mask_i32[pix] = (int32_t)floor(m * 255.0);
+    if (fr.mask_i32) fr.mask_i32[pix] = (int32_t)floor(m * 255.0);
     const double* b = fr.bg + pix * 3;
     sum_c = (c[0] + c[1]) + c[2];
     sum_b = (b[0] + b[1]) + b[2];
@@ -1725,6 +1725,7 @@ struct rr_ctx {
     uint8_t* rgb = nullptr;
     int32_t *mask_i = nullptr, *status = nullptr;
     double* depth = nullptr;         // pre-pass input (float32 or float64 per frame slot of 8 bytes/pixel)
+    uint8_t* bg8 = nullptr;          // pre-pass input given as bytes (rr_prepass_in.bg_u8)
     uint8_t* env_u8 = nullptr;
     int frames = 0, drops_cap = 0;
     Dims dims{0, 0, 0, 0};
@@ -1917,7 +1918,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       return RR_E_ARG;
     }
     if (in[f].n_drops < 0 || in[f].n_drops > 65536 || !in[f].bg || !in[f].rainy_bg || !in[f].env_xyY || !in[f].omega ||
-        (in[f].n_drops > 0 && !in[f].drops) || !out[f].rainy_rgb || !out[f].mask_f64 || !out[f].mask_i32) {
+        (in[f].n_drops > 0 && !in[f].drops) || !out[f].rainy_rgb || !out[f].mask_f64) {
       ctx->err = "null frame pointer or n_drops outside [0, 2^16] (generator.py:425)";
       return RR_E_ARG;
     }
@@ -2096,7 +2097,7 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
       return RR_E_ARG;
     }
     if (!in[f].bg || !in[f].depth || !out[f].rainy_bg || !(in[f].irr_den != 0.0)) {
-      ctx->err = "pre-pass: null pointer or zero irradiance denominator";
+      ctx->err = "pre-pass: null pointer or zero irradiance denominator (bg_u8 is for the host entry points only)";
       return RR_E_ARG;
     }
     if (out[f].env_xyY || out[f].env_bgr_u8) want_env = true;
@@ -2310,6 +2311,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->st.status);
   hipFree(ctx->st.depth);
   hipFree(ctx->st.env_u8);
+  hipFree(ctx->st.bg8);
   hipFree(ctx->d_esrc);
   hipFree(ctx->d_etop);
   hipFree(ctx->d_ebot);
@@ -2483,6 +2485,7 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
     if ((rc = dev_alloc(ctx, st.status, (size_t)F * D))) return rc;
     if ((rc = dev_alloc(ctx, st.depth, F * px))) return rc;
     if ((rc = dev_alloc(ctx, st.env_u8, F * ex * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.bg8, F * px * 3))) return rc;
     st.frames = F;
     st.drops_cap = D;
     st.dims = dm;
@@ -2493,14 +2496,22 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
   std::vector<rr_prepass_in> pin(pre ? n : 0);
   std::vector<rr_prepass_out> pout(pre ? n : 0);
   for (int f = 0; pre && f < n; f++) {
-    if (!pre[f].bg || !pre[f].depth) {
+    if ((!pre[f].bg && !pre[f].bg_u8) || !pre[f].depth) {
       ctx->err = "null pre-pass pointer";
       return RR_E_ARG;
     }
     pin[f] = pre[f];
     pin[f].bg = st.bg + f * px * 3;
+    pin[f].bg_u8 = nullptr;
     pin[f].depth = st.depth + f * px;
-    HIPCHK(hipMemcpyAsync((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (pre[f].bg_u8) {               // bytes over PCIe (1/8 of the float64 image), bg = bytes / 255.0 formed on the device
+      uint8_t* b8 = st.bg8 + f * px * 3;
+      HIPCHK(hipMemcpyAsync(b8, pre[f].bg_u8, px * 3, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256)), dim3(256), 0, s, b8, (double*)pin[f].bg,
+                         (int64_t)(px * 3));
+    } else {
+      HIPCHK(hipMemcpyAsync((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     HIPCHK(hipMemcpyAsync((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4), hipMemcpyHostToDevice, s));
     pout[f].rainy_bg = st.rainy + f * px * 3;
     const bool env = in || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
@@ -2509,7 +2520,7 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
   }
   for (int f = 0; in && f < n; f++) {
     if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
-        !out[f].rainy_rgb || !out[f].mask_f64 || !out[f].mask_i32) {
+        !out[f].rainy_rgb || !out[f].mask_f64) {
       ctx->err = "null frame pointer";
       return RR_E_ARG;
     }
@@ -2532,7 +2543,7 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
     dout[f].rainy_rgb = st.rgb + f * px * 3;
     dout[f].rainy_bg_out = st.comp + f * px * 3;
     dout[f].mask_f64 = st.mask + f * px;
-    dout[f].mask_i32 = st.mask_i + f * px;
+    dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * px : nullptr;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
   }
   if (pre) {
@@ -2551,7 +2562,7 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
     if (out[f].rainy_bg_out)
       HIPCHK(hipMemcpyAsync(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out[f].mask_f64, dout[f].mask_f64, px * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (out[f].mask_i32) HIPCHK(hipMemcpyAsync(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (out[f].drop_status && in[f].n_drops > 0)
       HIPCHK(hipMemcpyAsync(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * in[f].n_drops, hipMemcpyDeviceToHost, s));
   }

@@ -330,6 +330,11 @@ inline bool build_env_tables(int H, int W, int cw, int n_uniq, const int32_t* un
 }
 
 #if defined(__HIPCC__)
+// bg = cv2.imread(...) / 255.0 (generator.py:352) from the bytes: IEEE division, same bits as numpy's
+__global__ void __launch_bounds__(256) k_bytes_to_unit(const uint8_t* src, double* dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i] / 255.0;
+}
 __global__ void __launch_bounds__(256) k_fog_ext(const PreFrame* fr, int H, int W, PreScratch sc) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p < (int64_t)H * W) fog_ext_px(fr[blockIdx.y], blockIdx.y, H, W, sc, p);

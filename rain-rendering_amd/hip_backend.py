@@ -64,7 +64,7 @@ class rr_prepass_in(ctypes.Structure):
     _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('bg', ctypes.c_void_p), ('depth', ctypes.c_void_p),
                 ('depth_f64', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('beta_ext', ctypes.c_double), ('beta_hg', ctypes.c_double),
-                ('irr_num', ctypes.c_double), ('irr_den', ctypes.c_double)]
+                ('irr_num', ctypes.c_double), ('irr_den', ctypes.c_double), ('bg_u8', ctypes.c_void_p)]
 
 
 class rr_prepass_out(ctypes.Structure):
@@ -376,12 +376,18 @@ class RainHip:
 
     @staticmethod
     def _fill_prepass(pin, fr, keep):
-        bg = np.ascontiguousarray(fr['bg'], np.float64)
+        """fr['bg'] float64 in [0,1], or fr['bg_u8'] = the uint8 BGR image (bg = bg_u8 / 255.0 on the device)."""
+        if fr.get('bg_u8') is not None:
+            bg = np.ascontiguousarray(fr['bg_u8'], np.uint8)
+            pin.bg, pin.bg_u8 = None, _ptr(bg)
+        else:
+            bg = np.ascontiguousarray(fr['bg'], np.float64)
+            pin.bg, pin.bg_u8 = _ptr(bg), None
         depth = np.asarray(fr['depth'])
         depth = np.ascontiguousarray(depth, np.float32 if depth.dtype == np.float32 else np.float64)
         H, W = bg.shape[:2]
         assert bg.shape == (H, W, 3) and depth.shape == (H, W), (bg.shape, depth.shape)
-        pin.H, pin.W, pin.bg, pin.depth = H, W, _ptr(bg), _ptr(depth)
+        pin.H, pin.W, pin.depth = H, W, _ptr(depth)
         pin.depth_f64 = 1 if depth.dtype == np.float64 else 0
         pin.beta_ext, pin.beta_hg, pin.irr_num, pin.irr_den = [float(v) for v in fr['fog']]
         keep.append((bg, depth))
@@ -410,7 +416,7 @@ class RainHip:
         self._check(self.lib.rr_prepass_frames(self.h, n, pin, pout), 'rr_prepass_frames')
         return outs
 
-    def pipeline_frames(self, frames, want_composite=False, want_rainy_bg=False, want_env_u8=False):
+    def pipeline_frames(self, frames, want_composite=False, want_rainy_bg=False, want_env_u8=False, want_mask_i32=True):
         """Pre-pass + hot path without a host round trip.  frames: list of dict(bg, depth, fog, omega, drops
         [, opacity_attenuation, strategy]).  Returns what render_frames returns (+ env_bgr_u8 / fog_bg)."""
         n = len(frames)
@@ -428,12 +434,12 @@ class RainHip:
             drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
             o = dict(image_u8=np.zeros((H, W, 3), np.uint8),
                      rainy_bg=np.zeros((H, W, 3), np.float64) if want_composite else None,
-                     mask=np.zeros((H, W), np.float64), mask_i32=np.zeros((H, W), np.int32),
+                     mask=np.zeros((H, W), np.float64), mask_i32=np.zeros((H, W), np.int32) if want_mask_i32 else None,
                      status=np.zeros(len(drops), np.int32),
                      fog_bg=np.zeros((H, W, 3), np.float64) if want_rainy_bg else None,
                      env_bgr_u8=np.zeros((H, We, 3), np.uint8) if want_env_u8 else None)
             fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, H, We
-            fin[k].bg, fin[k].omega = _ptr(bg), _ptr(om)
+            fin[k].bg, fin[k].omega = None, _ptr(om)           # the background comes from the pre-pass input
             fin[k].drops = _ptr(drops) if len(drops) else None
             fin[k].n_drops = len(drops)
             fin[k].strategy = int(fr.get('strategy', 0))

@@ -89,3 +89,27 @@ def test_prepass_errors(built):
     with pytest.raises(RuntimeError, match='symmetric'):
         rh.set_prepass_kernels(np.arange(1, 6) / 15.0, op.gaussian_kernel(15, 0))
     rh.close()
+
+
+def test_byte_background_equals_float_background(tmp_path, built):
+    """rr_prepass_in.bg_u8: the uint8 image goes over PCIe and bg = bytes / 255.0 is formed on the device --
+    same bits as uploading cv2.imread(...) / 255.0; mask_i32 may be left out."""
+    H, W = 96, 160
+    sc = h.Scene(tmp_path, H, W, 120, seed0=7)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    consts, We = _setup(rh, H, W, 25)
+    bg, depth = _scene(H, W, 7)
+    bg8 = (bg * 255).astype(np.uint8)
+    drops = sc.product_drops(0)
+    base = dict(depth=depth, fog=consts, omega=sc.omega, drops=drops)
+    a = rh.pipeline_frames([dict(base, bg=bg8 / 255.0)], want_composite=True, want_rainy_bg=True)[0]
+    b = rh.pipeline_frames([dict(base, bg_u8=bg8)], want_composite=True, want_rainy_bg=True, want_mask_i32=False)[0]
+    assert b['mask_i32'] is None
+    for k in ('image_u8', 'rainy_bg', 'mask', 'status', 'fog_bg'):
+        assert np.array_equal(a[k], b[k]), k
+    pa = rh.prepass_frames([dict(bg=bg8 / 255.0, depth=depth, fog=consts)])[0]
+    pb = rh.prepass_frames([dict(bg_u8=bg8, depth=depth, fog=consts)])[0]
+    assert np.array_equal(pa['rainy_bg'], pb['rainy_bg']) and np.array_equal(pa['env_xyY'], pb['env_xyY'])
+    rh.close()
