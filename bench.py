@@ -39,7 +39,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=64, help='frames per step and per GPU')
+    ap.add_argument('--batch', type=int, default=128, help='frames per step and per GPU')
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     ap.add_argument('--rate', type=int, default=100, help='mm/hr (selects the synthetic drop count)')
@@ -55,11 +55,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # test hooks (one-GPU smoke test of the N>1 path): RAIN_BENCH_DEVICE pins every rank to one device,
+    # RAIN_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    if 'RAIN_BENCH_DEVICE' in os.environ:
+        local_rank = int(os.environ['RAIN_BENCH_DEVICE'])
+    backend = os.environ.get('RAIN_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -158,7 +166,7 @@ def main():
     # --- extra (outside the timed region, not part of `value`): the fog + environment-map pre-pass that
     # produces rainy_bg / env_xyY on the device (rr_prepass_frames_device), same batch
     prepass = None
-    if rank == 0 and not args.no_prepass:
+    if rank == 0 and world == 1 and not args.no_prepass:
         fogmod = importlib.import_module('rain-rendering_amd.common.add_attenuation')
         envmod = importlib.import_module('rain-rendering_amd.common.envmap')
         imgops = importlib.import_module('rain-rendering_amd.common.imgops')
@@ -256,7 +264,7 @@ def main():
             out["prepass"] = prepass
         if host_incl is not None:
             out["host_inclusive"] = host_incl
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             # CPU reference = the numpy oracle in its op-for-op ("faithful") mode, 1 core, on the
             # first --cpu-sample-drops streaks of frame 0; extrapolated linearly in the drop count.
             from oracle import render as orc

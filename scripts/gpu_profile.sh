@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BATCH=${RAIN_PROFILE_BATCH:-64}
+BATCH=${RAIN_PROFILE_BATCH:-128}
 BENCH="python $REPO/bench.py --steps 5 --warmup 2 --batch $BATCH --no-cpu-baseline --no-prepass $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum"; do
