@@ -6,12 +6,21 @@
 //   k_env_consts   sum(w), sum(Y*w)/sum(w)                       (bad_weather.py:403-404)
 //   k_plan         one thread per drop: geometry, homography / rotation, CoC, FOV polygon
 //   k_scan         per-frame exclusive scan of tile sizes -> arena offsets
-//   k_colour       one wave per drop: FOV row spans x prefix table -> colour constants
-//   k_tile_raw     one block per drop: warp / rotate+resize the streak texture -> alpha tile
-//   k_blur_rows / k_blur_cols   separable defocus blur of the padded tile
-//   k_composite    one block per 16x16 screen tile: ordered per-tile drop list (ballot
-//                  compaction, no atomics), in-register alpha blend + mask accumulate
+//   k_dedup        drops with bit-identical raw-tile parameters share one tile (batch-wide election)
+//   k_lists        work lists: rotate/resize tiles, Big tiles (+ pixel prefix), generic, blur items
+//   k_col_order / k_colour_bands / k_colour
+//                  one wave per drop, grouped by image region per XCD: FOV row spans x prefix table
+//                  -> colour constants and the compositor record
+//   k_tile         one workgroup per rotate+flip+INTER_AREA tile, texture and samples staged in LDS
+//   k_tile_big     Big drops (bicubic warpPerspective): one thread per output pixel
+//   k_tile_generic the rare rest (up-sampling resize, oversize textures)
+//   k_blur_small / k_blur_fused / k_blur<0|1>
+//                  separable defocus blur of the effective tile (raw tile dilated by the radii)
+//   k_bin / k_composite
+//                  ordered per-tile drop lists (ballot compaction, no atomics), in-register alpha
+//                  blend + mask accumulate per 16x16 screen tile
 //   k_means / k_finalize   mean-contrast shift, clip, truncating u8 quantisation
+// rr_prepass.h holds the fog / environment-map pre-pass kernels, rr_host.cpp the host-only helpers.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
