@@ -237,7 +237,8 @@ def main():
                 tj = json.load(open(tfile))
                 if tj.get('batch') == B and tj.get('workload') == [W, H, args.rate]:
                     # a timing scope can hold several kernels (the colour scope: order + bands + finalise)
-                    parts = {'k_colour': ['k_col_order', 'k_colour_bands', 'k_colour']}.get(dom_name, [dom_name])
+                    parts = {'k_colour_spans': ['k_col_order', 'k_colour_bands'], 'k_fog_stats': ['k_fog_sum', 'k_fog_mean', 'k_fog_ext'],
+                             'k_dedup': ['k_dedup', '__amd_rocclr_fillBufferAligned']}.get(dom_name, [dom_name])
                     vals = [tj['kernels'].get(k, {}).get('hbm_bytes_per_launch') for k in parts]
                     traffic = sum(v for v in vals if v is not None) if any(v is not None for v in vals) else None
             except Exception:

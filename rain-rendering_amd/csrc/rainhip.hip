@@ -76,7 +76,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
   int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
   int32_t* list_small;              // [frame][drops]  blurred drops handled one wave each (k_blur_small)
-  double* colpart;                  // [frame][drops][COL_BANDS][5] FOV partial sums per envmap row band
+  double* colpart;                  // [frame][drops][COL_PARTS][5] FOV partial sums per envmap row band
+  uint32_t* spans;                  // [frame][tiles of 64 drops][He][64] FOV row spans xl | (xr+1) << 16, 0 = empty row
   int4* bbox;                       // [frame][drops] footprint (x0,y0,x1,y1), empty when not composited
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
   int32_t* ccount;                  // [frame][coarse tiles]
@@ -388,47 +389,57 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
 // and k_colour_bands gives region r to the workgroups with blockIdx.x % 8 == r, so that one L2
 // only ever sees the part of the 23 MB table its region's polygon outlines sweep.
 constexpr int COL_REGIONS = 8;
-__device__ inline int colour_region(const rr_drop& d, const Dims& dm) {
-  const int rx = imin(imax((d.x0 * 4) / imax(dm.W, 1), 0), 3), ry = imin(imax((d.y0 * 2) / imax(dm.H, 1), 0), 1);
-  return ry * 4 + rx;
+constexpr int COL_CELLS = 64;        // 8 x 8 cells per region, visited along a Z curve
+__device__ inline int colour_bin(const rr_drop& d, const Dims& dm) {
+  const int W = imax(dm.W, 1), H = imax(dm.H, 1);
+  // 32 x 16 cells over the frame: region = (cx / 8, cy / 8), cell inside the region by bit interleave
+  const int cx = imin(imax((d.x0 * 32) / W, 0), 31), cy = imin(imax((d.y0 * 16) / H, 0), 15);
+  const int region = (cy >> 3) * 4 + (cx >> 3);
+  const int lx = cx & 7, ly = cy & 7;
+  int z = 0;
+  for (int b = 0; b < 3; b++) z |= ((lx >> b) & 1) << (2 * b) | ((ly >> b) & 1) << (2 * b + 1);
+  return region * COL_CELLS + z;
 }
+// Counting sort of a frame's drops by (region, cell): consecutive list entries are neighbours in the
+// image, so the 64 drops a wave of k_colour_rows handles read neighbouring prefix-table entries (the
+// texture unit merges lanes that hit the same 128-byte line).  The order inside a cell is whatever the
+// atomics produce; no result depends on it (every drop's sums are its own).
 __global__ __launch_bounds__(1024) void k_col_order(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
   const int f = blockIdx.x, t = threadIdx.x;
   const int n = frames[f].n_drops;
   const rr_drop* drops = frames[f].drops;
-  const int chunk = (n + 1023) / 1024;
-  const int i0 = t * chunk, i1 = min(i0 + chunk, n);
-  int c[COL_REGIONS];
-  for (int k = 0; k < COL_REGIONS; k++) c[k] = 0;
-  for (int i = i0; i < i1; i++) c[colour_region(drops[i], dm)]++;
-  __shared__ int sh[1024][COL_REGIONS];
-  for (int k = 0; k < COL_REGIONS; k++) sh[t][k] = c[k];
+  __shared__ int s_cnt[COL_REGIONS * COL_CELLS], s_off[COL_REGIONS * COL_CELLS];
+  for (int k = t; k < COL_REGIONS * COL_CELLS; k += 1024) s_cnt[k] = 0;
   __syncthreads();
-  for (int ofs = 1; ofs < 1024; ofs <<= 1) {
-    int v[COL_REGIONS];
-    for (int k = 0; k < COL_REGIONS; k++) v[k] = (t >= ofs) ? sh[t - ofs][k] : 0;
-    __syncthreads();
-    for (int k = 0; k < COL_REGIONS; k++) sh[t][k] += v[k];
-    __syncthreads();
+  for (int i = t; i < n; i += 1024) atomicAdd(&s_cnt[colour_bin(drops[i], dm)], 1);
+  __syncthreads();
+  if (t < 64) {                        // exclusive scan of the 512 bins: 8 per lane, then across the wave
+    int loc[8], sum = 0;
+    for (int k = 0; k < 8; k++) { loc[k] = sum; sum += s_cnt[t * 8 + k]; }
+    int run = sum;
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+      const int v = __shfl_up(run, ofs);
+      if (t >= ofs) run += v;
+    }
+    const int base = run - sum;
+    for (int k = 0; k < 8; k++) s_off[t * 8 + k] = base + loc[k];
+    if ((t & 7) == 0) sc.col_off[f * 16 + (t >> 3)] = base;       // region r starts at bin r * 64 = lane r * 8
+    if (t == 63) sc.col_off[f * 16 + COL_REGIONS] = run;
   }
-  int o[COL_REGIONS], start = 0;
-  for (int k = 0; k < COL_REGIONS; k++) {
-    o[k] = start + ((t == 0) ? 0 : sh[t - 1][k]);
-    if (t == 0) sc.col_off[f * 16 + k] = start;
-    start += sh[1023][k];
-  }
-  if (t == 0) sc.col_off[f * 16 + COL_REGIONS] = start;
+  __syncthreads();
   int32_t* lst = sc.list_col + (int64_t)f * max_drops;
-  for (int i = i0; i < i1; i++) lst[o[colour_region(drops[i], dm)]++] = i;
+  for (int i = t; i < n; i += 1024) lst[atomicAdd(&s_off[colour_bin(drops[i], dm)], 1)] = i;
 }
 
 // Colour, pass 1: one wave per (drop, row band): polygon row spans x prefix table, wave reduce.
-constexpr int COL_BANDS = 1;        // row bands per drop (8 = one band per XCD L2 measured 2.7x SLOWER: per-wave edge scan dominates)
+constexpr int COL_BANDS = 1;        // legacy single-kernel path: one band
+constexpr int COL_PARTS = 8;        // banded path: one row band of the prefix table per XCD L2
 
 constexpr int HE_MAX = 1024;        // tallest environment map the LDS span tables hold (else per-row edge scan)
 
 template <int HE_CAP>                // rows the LDS span tables hold: 512 (7 workgroups per CU) or HE_MAX
-__global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int dbg) {
+__global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int dbg, int write_spans,
+                                                      int ntile) {
   static_assert(COL_BANDS == 1, "region scheduling assumes one band");
   const int f = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -511,6 +522,21 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
       }
       wave_lds_sync();
     }
+    if (write_spans) {
+      // banded path: the row spans go to global memory ([He][64 drops] tiles, drop = position in the
+      // region-sorted list) and k_colour_rows does the look-ups band by band
+      uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + (j & 63);
+      for (int y = lane; y < dm.He; y += 64) {
+        uint32_t v = 0;
+        if (y >= ya && y <= yb) {
+          const int xl_ = max(s_xl[wave][y], 0), xr_ = min(s_xr[wave][y], dm.We - 1);
+          if (xl_ <= xr_) v = (uint32_t)xl_ | ((uint32_t)(xr_ + 1) << 16);
+        }
+        sp[(int64_t)y * 64] = v;
+      }
+      wave_lds_sync();
+      continue;
+    }
     for (int y = ya + lane; y <= ((dbg & 0x10000) ? ya - 1 : yb); y += 64) {
       int xl_, xr_;
       bool ok;
@@ -538,8 +564,13 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
       any |= __shfl_xor(any, ofs);
     }
   }
+  if (write_spans) {                 // no polygon: every row empty
+    uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + (j & 63);
+    for (int y = lane; y < dm.He; y += 64) sp[(int64_t)y * 64] = 0;
+    continue;
+  }
   if (lane == 0) {
-    double* o = sc.colpart + (gi * COL_BANDS + band) * 5;
+    double* o = sc.colpart + (gi * COL_PARTS + band) * 5;
     o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[3];
     o[4] = (double)any;
   }
@@ -547,9 +578,44 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
   }
 }
 
+// Colour, banded look-ups: ONE THREAD PER DROP, rows of one band in sequence.  Workgroup bx takes band
+// bx % 8, i.e. XCD bx % 8 only ever reads rows [band*He/8, (band+1)*He/8) of the frame's prefix table
+// (2.9 MB at KITTI size: L2 resident), and the 64 lanes of a wave -- neighbouring drops of one image
+// region -- read the same table row at nearby columns.  Spans arrive coalesced ([row][64 drops]).
+__global__ __launch_bounds__(256) void k_colour_rows(const FrameDesc* frames, Dims dm, int max_drops, int ntile, Scratch sc) {
+  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS;
+  const int j = (blockIdx.x / COL_PARTS) * 256 + threadIdx.x;
+  if (j >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + sc.list_col[(int64_t)f * max_drops + j];
+  const int rpb = (dm.He + COL_PARTS - 1) / COL_PARTS;
+  const int y0 = band * rpb, y1 = min(dm.He, y0 + rpb);
+  const uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + (j & 63);
+  const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
+  double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0;
+  int any = 0;
+#pragma unroll 4
+  for (int y = y0; y < y1; y++) {
+    const uint32_t v = sp[(int64_t)y * 64];
+    const int xr1 = (int)(v >> 16), xl = (int)(v & 0xffffu);
+    if (xr1) {
+      any = 1;
+      const double* row = P + (int64_t)y * (dm.We + 1) * 4;
+      const double* hi = row + (int64_t)xr1 * 4;
+      const double* lo = row + (int64_t)xl * 4;                     // P[row][0] == 0
+      S0 += hi[0] - lo[0];
+      S1 += hi[1] - lo[1];
+      S2 += hi[2] - lo[2];
+      S3 += hi[3] - lo[3];
+    }
+  }
+  double* o = sc.colpart + (gi * COL_PARTS + band) * 5;
+  o[0] = S0; o[1] = S1; o[2] = S2; o[3] = S3;
+  o[4] = (double)any;
+}
+
 // Colour, pass 2: one thread per drop adds the band partials in band order and writes the
 // compositor record.
-__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int nparts) {
   const int f = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const FrameDesc& fr = frames[f];
@@ -583,8 +649,8 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   if (n > 0) {
     double S[4] = {0, 0, 0, 0};
     bool any = false;
-    const double* part = sc.colpart + gi * COL_BANDS * 5;
-    for (int b = 0; b < COL_BANDS; b++) {
+    const double* part = sc.colpart + gi * COL_PARTS * 5;
+    for (int b = 0; b < nparts; b++) {
       for (int k = 0; k < 4; k++) S[k] += part[b * 5 + k];
       any = any || part[b * 5 + 4] != 0.0;
     }
@@ -1859,7 +1925,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.list_slow, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.blur_items, fd * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_small, fd))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.colpart, fd * COL_BANDS * 5))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.colpart, fd * COL_PARTS * 5))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.spans, (size_t)F * (size_t)((D + 63) / 64 + 1) * 64 * (size_t)dm.He))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.bbox, fd))) return rc;
     {
       const size_t nct = (size_t)((dm.W + CTILE - 1) / CTILE) * ((dm.H + CTILE - 1) / CTILE);
@@ -2005,14 +2072,29 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       HIPCHK(hipStreamWaitEvent(sc_gen, ctx->ev_scan, 0));
     }
     {
-      ProfScope ps(ctx, sc_col, "k_colour");
-      hipLaunchKernelGGL(k_col_order, dim3(n), dim3(1024), 0, sc_col, ctx->d_frames, dm, D, sc);
       const int col_blocks = (((max_drops + 3) / 4 + COL_REGIONS - 1) / COL_REGIONS) * COL_REGIONS;
-      if (dm.He <= 512)
-        hipLaunchKernelGGL(k_colour_bands<512>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg);
-      else
-        hipLaunchKernelGGL(k_colour_bands<HE_MAX>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg);
-      hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc);
+      // banded path: spans to global memory, look-ups one row band per XCD; maps too tall for the LDS span
+      // tables or too wide for 16-bit columns keep the single-kernel path
+      const bool banded = dm.He <= HE_MAX && dm.We < 32767;
+      const int ntile = (D + 63) / 64 + 1;
+      {
+        ProfScope ps(ctx, sc_col, banded ? "k_colour_spans" : "k_colour_bands");
+        hipLaunchKernelGGL(k_col_order, dim3(n), dim3(1024), 0, sc_col, ctx->d_frames, dm, D, sc);
+        if (dm.He <= 512)
+          hipLaunchKernelGGL(k_colour_bands<512>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg,
+                             banded ? 1 : 0, ntile);
+        else
+          hipLaunchKernelGGL(k_colour_bands<HE_MAX>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg,
+                             banded ? 1 : 0, ntile);
+      }
+      if (banded) {
+        ProfScope ps(ctx, sc_col, "k_colour_rows");
+        hipLaunchKernelGGL(k_colour_rows, dim3(((max_drops + 255) / 256) * COL_PARTS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, ntile, sc);
+      }
+      {
+        ProfScope ps(ctx, sc_col, "k_colour");
+        hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, banded ? COL_PARTS : 1);
+      }
     }
     if (ctx->simple_tile) {
       ProfScope ps(ctx, s, "k_tile");
@@ -2296,6 +2378,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.htab);
   hipFree(ctx->sc.list_small);
   hipFree(ctx->sc.colpart);
+  hipFree(ctx->sc.spans);
   hipFree(ctx->sc.bbox);
   hipFree(ctx->sc.clist);
   hipFree(ctx->sc.ccount);
