@@ -39,7 +39,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=128, help='frames per step and per GPU')
+    ap.add_argument('--batch', type=int, default=256, help='frames per step and per GPU')
     ap.add_argument('--height', type=int, default=375)
     ap.add_argument('--width', type=int, default=1242)
     ap.add_argument('--rate', type=int, default=100, help='mm/hr (selects the synthetic drop count)')

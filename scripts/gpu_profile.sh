@@ -8,10 +8,16 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BATCH=${RAIN_PROFILE_BATCH:-128}
+BATCH=${RAIN_PROFILE_BATCH:-256}
 BENCH="python $REPO/bench.py --steps 5 --warmup 2 --batch $BATCH --no-cpu-baseline --no-prepass $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum"; do
+# RAIN_PROFILE_QUICK=1: only the two HBM-traffic passes (each pass re-runs the bench incl. its scene set-up)
+if [ "${RAIN_PROFILE_QUICK:-0}" = "1" ]; then
+  PASSES=("FETCH_SIZE" "WRITE_SIZE")
+else
+  PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum")
+fi
+for C in "${PASSES[@]}"; do
   NAME=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$NAME -- $BENCH > $OUT/pmc_$NAME.log 2>&1
 done
