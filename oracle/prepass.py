@@ -5,11 +5,14 @@ hot path's inputs (SURVEY 8f "next" #1 and #2), restated from the reference in n
   generate_env_map   reference common/bad_weather.py:707-853     (EnvironmentMapGenerator)
   env_to_xyY         reference common/generator.py:407-408
 
-PARITY UNPINNED where OpenCV is involved (cv2.GaussianBlur on float and on uint8 images,
-cv2.flip / copyMakeBorder are trivial): the reference has no golden outputs and cv2 is not
-installed.  The Gaussian kernels follow cv::getGaussianKernel; borders are BORDER_REFLECT_101;
-the uint8 blur rounds half to even.  Data types follow the reference's numpy arithmetic
-(float32 depth -> float32 extinction map)."""
+PINNED by tests/golden/prepass_vectors.npz (tests/golden/make_golden_prepass.py runs the
+reference's own FogRain.fog_rain_layer and EnvironmentMapGenerator.generate_map in the build
+container; tests/test_oracle_pin.py reproduces them bit for bit) -- EXCEPT the arithmetic of
+cv2.GaussianBlur itself, which stays PARITY UNPINNED: cv2 is not installed, so the generator
+substitutes gaussian_blur() below for it.  The kernels follow cv::getGaussianKernel, borders
+are BORDER_REFLECT_101, the uint8 blur rounds half to even (OpenCV's uint8 path is
+fixed-point and may differ by 1 LSB in the filled-in parts of the environment map).  Data
+types follow the reference's numpy arithmetic (float32 depth -> float32 extinction map)."""
 import math
 
 import numpy as np

@@ -228,3 +228,21 @@ def test_fill_rule_properties():
     assert np.all(xl > xr)                         # entirely left of the map
     y0, xl, xr = cvlike.fov_rowspans(np.array([[-5, -5], [100, -5], [100, 100], [-5, 100]]), 20, 30)
     assert y0 == 0 and len(xl) == 20 and np.all(xl == 0) and np.all(xr == 29)
+
+
+def test_prepass_oracle_equals_reference_vectors():
+    """oracle/prepass.py against outputs of the reference's own FogRain.fog_rain_layer and
+    EnvironmentMapGenerator.generate_map (tests/golden/make_golden_prepass.py; cv2.GaussianBlur replaced by
+    the oracle's blur there, so the blur arithmetic itself stays unpinned -- everything around it is pinned,
+    bit for bit: extinction map in the depth's dtype, irradiance mean, clips, np.unique's first-pixel rule,
+    the fill_matrices loops, the mirrored sides)."""
+    import os
+    from oracle import prepass as op
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'prepass_vectors.npz'))
+    for k in range(2):
+        H, W, rain, seed = [int(x) for x in v['case%d_meta' % k]]
+        bg, depth = v['case%d_bg' % k], v['case%d_depth' % k]
+        rainy = op.fog_rain_layer(bg, depth, rain, 6.0, 2, 20)
+        assert rainy.dtype == v['case%d_rainy' % k].dtype and np.array_equal(rainy, v['case%d_rainy' % k])
+        env = op.generate_env_map(v['case%d_rainy' % k], 0.006)
+        assert env.shape == v['case%d_env' % k].shape and np.array_equal(env, v['case%d_env' % k])
