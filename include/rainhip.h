@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RR_VERSION 100            /* 0.1.0 */
+#define RR_VERSION 120            /* 0.1.2: + pre-pass, pipeline, host draws, batch counts */
 
 enum {
   RR_OK = 0,
