@@ -1378,18 +1378,22 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       const int hop = (ho + 3) & ~3;                      // rows/columns padded to the 4-output blocks
       const int wi = wo + 2 * r2, hi = hop + 2 * r1;      // LDS input tile with zero halos (+ slack rows)
       const int yp = blur_y_pitch(wo, r2);                // odd pitch of the row-pass result
-      const float inv_wi = 1.0f / (float)wi;
-      // haloed tile -> LDS; eight independent global loads in flight per thread
-      const int nx = (dbg & 512) ? 0 : wi * hi;
+      // Only the columns under the raw tile carry data through the row pass (it filters along y: a column
+      // without raw pixels stays exactly zero).  X holds those wd columns, the row pass runs over them, and
+      // the remaining columns of Y are written as zeros for the column pass.
+      const int xa = imax(0, 2 * r2 - x0), xb = imin(wi, tw + 2 * r2 - x0);   // data columns of the haloed sub-tile
+      const int wd = imax(xb - xa, 1);
+      const float inv_wd = 1.0f / (float)wd;
+      // data columns of the haloed tile -> LDS; eight independent global loads in flight per thread
+      const int nx = (dbg & 512) ? 0 : wd * hi;
       for (int base = t; base < nx || need_tables; base += 2048) {
         double v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           const int idx = base + 256 * k;
-          const int yy = (int)(((float)idx + 0.5f) * inv_wi), xx = idx - yy * wi;
-          const int yt = y0 - r1 + yy, xt = x0 - r2 + xx;                    // effective-tile coordinates
-          const int y = yt - r1, x = xt - r2;                                // raw-tile coordinates
-          v[k] = (idx < nx && yt < ph && xt < pw && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
+          const int yy = (int)(((float)idx + 0.5f) * inv_wd), xc = idx - yy * wd;
+          const int y = y0 - 2 * r1 + yy, x = x0 - 2 * r2 + xa + xc;         // raw-tile coordinates
+          v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
         }
         if (need_tables) {
           if ((t >> 6) == 0) gauss_half_table_wave(p.sig1, r1, hw1);
@@ -1401,20 +1405,28 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
         for (int k = 0; k < 8; k++)
           if (base + 256 * k < nx) X[base + 256 * k] = v[k];
       }
+      {
+        const int nzc = wi - wd, nz = nzc * ho;                    // zero columns of the row-pass result
+        const float inv_nzc = nzc > 0 ? 1.0f / (float)nzc : 0.0f;
+        for (int i = t; i < nz; i += 256) {
+          const int yy = (int)(((float)i + 0.5f) * inv_nzc), k = i - yy * nzc;
+          Y[yy * yp + (k < xa ? k : k + wd)] = 0.0;
+        }
+      }
       __syncthreads();
-      // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns column x and FOUR consecutive
+      // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns data column xc and FOUR consecutive
       // rows; as the tap distance shrinks the upper/lower operand windows slide by one row, so each
       // step needs two new LDS values instead of eight (register rotation).  Lanes run along x.
       {
         const int nrb = hop >> 2;
-        const int nv = (dbg & 1024) ? 0 : nrb * wi;
+        const int nv = (dbg & 1024) ? 0 : nrb * wd;
         for (int idx = t; idx < nv; idx += 256) {
-          const int rb = (int)(((float)idx + 0.5f) * inv_wi), x = idx - rb * wi;
-          const double* c0 = X + (4 * rb + r1) * wi + x;                      // centre of the first of the four rows
+          const int rb = (int)(((float)idx + 0.5f) * inv_wd), xc = idx - rb * wd;
+          const double* c0 = X + (4 * rb + r1) * wd + xc;                     // centre of the first of the four rows
           double acc0, acc1, acc2, acc3;
-          blur4(c0, wi, hw1, r1, acc0, acc1, acc2, acc3);
+          blur4(c0, wd, hw1, r1, acc0, acc1, acc2, acc3);
           const int yb = 4 * rb;
-          double* o = Y + yb * yp + x;
+          double* o = Y + yb * yp + xa + xc;
           if (yb < ho) o[0] = acc0;
           if (yb + 1 < ho) o[yp] = acc1;
           if (yb + 2 < ho) o[2 * yp] = acc2;
@@ -1482,37 +1494,49 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
         w2 = ph2 / tot2;
       }
     }
-    const float inv_wi = 1.0f / (float)wi, inv_pw = 1.0f / (float)pw;
-    const int nx = wi * hi;
-    for (int base = lane; base < nx; base += 256) {       // haloed tile -> LDS, 4 loads in flight
+    // Only the tw columns under the raw tile carry data through the row pass (axis 0 filters along y: a
+    // column without raw pixels stays exactly zero), so X holds tw columns x hi rows and the row pass
+    // runs over tw*ph outputs; the other 4*r2 columns of Y are written as zeros for the column pass.
+    const float inv_tw = 1.0f / (float)tw, inv_pw = 1.0f / (float)pw;
+    const int nx = tw * hi;
+    for (int base = lane; base < nx; base += 256) {       // data columns of the haloed tile -> LDS, 4 loads in flight
       double v[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int idx = base + 64 * k;
-        const int yy = (int)(((float)idx + 0.5f) * inv_wi), xx = idx - yy * wi;
-        const int y = yy - 2 * r1, x = xx - 2 * r2;              // raw-tile coordinates (raw sits at (r2, r1) in the effective tile)
-        v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? raw[y * tw + x] : 0.0;
+        const int yy = (int)(((float)idx + 0.5f) * inv_tw), x = idx - yy * tw;
+        const int y = yy - 2 * r1;                                // raw-tile row (raw sits at (r2, r1) in the effective tile)
+        v[k] = (idx < nx && y >= 0 && y < th) ? raw[y * tw + x] : 0.0;
       }
 #pragma unroll
       for (int k = 0; k < 4; k++)
         if (base + 64 * k < nx) X[base + 64 * k] = v[k];
     }
+    {
+      const int nzc = 4 * r2, nz = nzc * ph;                      // zero columns of Y: [0, 2*r2) and [2*r2 + tw, wi)
+      const float inv_nzc = nzc > 0 ? 1.0f / (float)nzc : 0.0f;
+      for (int i = lane; i < nz; i += 64) {
+        const int yy = (int)(((float)i + 0.5f) * inv_nzc), k = i - yy * nzc;
+        Y[yy * wi + (k < 2 * r2 ? k : k + tw)] = 0.0;
+      }
+    }
     wave_lds_sync();
-    // axis 0 (rows): outputs for all wi columns (halo columns are zero but needed by axis 1)
-    const int nv = wi * ph;
+    // axis 0 (rows) for the data columns
+    const int nv = tw * ph;
     for (int base = lane; base < nv; base += 128) {
       const int i0 = base, i1 = imin(base + 64, nv - 1);
-      const double* c0 = X + i0 + r1 * wi;
-      const double* c1 = X + i1 + r1 * wi;
+      const double* c0 = X + i0 + r1 * tw;
+      const double* c1 = X + i1 + r1 * tw;
       double a0 = c0[0] * readlane_f64(w1, 0), a1 = c1[0] * readlane_f64(w1, 0);
       for (int ii = -r1; ii < 0; ii++) {
         const double w = readlane_f64(w1, -ii);
-        const int o = ii * wi;
+        const int o = ii * tw;
         a0 = a0 + (c0[o] + c0[-o]) * w;
         a1 = a1 + (c1[o] + c1[-o]) * w;
       }
-      Y[i0] = a0;
-      if (base + 64 < nv) Y[i1] = a1;
+      const int ya = (int)(((float)i0 + 0.5f) * inv_tw), yb = (int)(((float)i1 + 0.5f) * inv_tw);
+      Y[ya * wi + 2 * r2 + (i0 - ya * tw)] = a0;
+      if (base + 64 < nv) Y[yb * wi + 2 * r2 + (i1 - yb * tw)] = a1;
     }
     wave_lds_sync();
     // axis 1 (columns) -> global, in place
