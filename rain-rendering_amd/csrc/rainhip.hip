@@ -207,11 +207,11 @@ __device__ inline BlurLayout blur_layout(const DropPlan& p) {
   return b;                                                  // halo alone exceeds the LDS: two-pass fallback
 }
 // small blurred tiles are filtered by one wave each, in place (k_blur_small)
-constexpr int BS_X = 768;           // doubles per wave: haloed input tile
-constexpr int BS_Y = 512;           // doubles per wave: after the row pass (halo columns kept)
+constexpr int BS_X = 512;           // doubles per wave: data columns of the haloed input tile (tw x (eh + 2 r1))
+constexpr int BS_Y = 768;           // doubles per wave: after the row pass (halo columns kept)
 
 __device__ inline bool blur_is_small(const DropPlan& p) {
-  return p.r1 > 0 && p.r1 <= 31 && (p.ew + 2 * p.r2) * (p.eh + 2 * p.r1) <= BS_X && (p.ew + 2 * p.r2) * p.eh <= BS_Y;
+  return p.r1 > 0 && p.r1 <= 31 && p.tw * (p.eh + 2 * p.r1) <= BS_X && (p.ew + 2 * p.r2) * p.eh <= BS_Y;
 }
 
 // blurred drops neither k_blur_small nor k_blur_fused can take (radius > BR_MAX): two global passes
