@@ -458,10 +458,12 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
   if (n > 0) {
     const int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
     const int32_t* py = px + POLY_STRIDE;
-    int ymin = py[0], ymax = py[0];
-    for (int k = 1; k < n; k++) {
-      ymin = min(ymin, py[k]);
-      ymax = max(ymax, py[k]);
+    // y extent of the polygon: lane e holds vertex e, butterfly min/max across the wave (a serial loop
+    // over the vertices is a chain of ~20 dependent global loads per drop)
+    int ymin = lane < n ? py[lane] : 0x7fffffff, ymax = lane < n ? py[lane] : -0x7fffffff;
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+      ymin = min(ymin, __shfl_xor(ymin, ofs));
+      ymax = max(ymax, __shfl_xor(ymax, ofs));
     }
     const int rows_per_band = (dm.He + COL_BANDS - 1) / COL_BANDS;
     const int ya = max(max(ymin, 0), band * rows_per_band), yb = min(min(ymax, dm.He - 1), (band + 1) * rows_per_band - 1);
