@@ -595,24 +595,24 @@ __global__ __launch_bounds__(256) void k_colour_rows(const FrameDesc* frames, Di
   const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
   double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0;
   int any = 0;
+  // no branch on empty rows: their span is (0, 0) and P[row][0] - P[row][0] adds an exact zero, so the
+  // four independent rows of an unrolled step keep all their loads in flight
 #pragma unroll 4
   for (int y = y0; y < y1; y++) {
     const uint32_t v = sp[(int64_t)y * 64];
     const int xr1 = (int)(v >> 16), xl = (int)(v & 0xffffu);
-    if (xr1) {
-      any = 1;
-      const double* row = P + (int64_t)y * (dm.We + 1) * 4;
-      const double* hi = row + (int64_t)xr1 * 4;
-      const double* lo = row + (int64_t)xl * 4;                     // P[row][0] == 0
-      S0 += hi[0] - lo[0];
-      S1 += hi[1] - lo[1];
-      S2 += hi[2] - lo[2];
-      S3 += hi[3] - lo[3];
-    }
+    any |= xr1;
+    const double* row = P + (int64_t)y * (dm.We + 1) * 4;
+    const double* hi = row + (int64_t)xr1 * 4;
+    const double* lo = row + (int64_t)xl * 4;                       // P[row][0] == 0
+    S0 += hi[0] - lo[0];
+    S1 += hi[1] - lo[1];
+    S2 += hi[2] - lo[2];
+    S3 += hi[3] - lo[3];
   }
   double* o = sc.colpart + (gi * COL_PARTS + band) * 5;
   o[0] = S0; o[1] = S1; o[2] = S2; o[3] = S3;
-  o[4] = (double)any;
+  o[4] = any ? 1.0 : 0.0;
 }
 
 // Colour, pass 2: one thread per drop adds the band partials in band order and writes the
