@@ -1,12 +1,12 @@
-"""main.py-compatible command line (same 23 flags as reference main.py:15-127, same derived
-fields main.py:131-161, same particles resolution main.py:187-220) driving the MI355X path:
+"""Command line of the MI355X rain renderer.  It accepts the flag set of the reference's
+main.py (main.py:15-127) and derives the same fields for Generator (main.py:131-161, particle
+files main.py:187-220), so an existing invocation keeps working:
 
-    python -m rain_rendering_amd.main --dataset kitti --intensity 25 --frame_end 10
+    python rain-rendering_amd/main.py --dataset kitti --intensity 25 --frame_end 10
     python -m torch.distributed.run --nproc-per-node 8 rain-rendering_amd/main.py --dataset kitti ...
 
-The external particle simulator (reference tools/) is NOT driven from here: particle files
-must exist (reference main.py would launch AHLSimulation, which has no source in the
-reference tree)."""
+Not driven from here: the external particle simulator (reference tools/, no source in the
+reference tree).  Particle files have to exist already."""
 import argparse
 import glob
 import os
@@ -29,89 +29,118 @@ else:
 np.random.seed(0)
 warnings.filterwarnings("ignore")
 
+_J = os.path.join
+# (flags, argparse keywords): names, types and defaults are the reference's; the wording is ours
+_FLAGS = [
+    (('--dataset',), dict(type=str, required=True, help='dataset name; its data lives in <dataset_root>/<dataset>')),
+    (('-k', '--dataset_root'), dict(default=_J('data', 'source'), help='root of the source datasets')),
+    (('-p', '--post_fix'), dict(type=str, default='', help='suffix of a GAN-translated dataset variant')),
+    (('-s', '--sequences'), dict(default='', help='comma separated sequence prefixes to keep')),
+    (('-ns', '--noise_scale'), dict(type=float, default=0.0, help='scale of the angular streak noise')),
+    (('-nv', '--noise_std'), dict(type=float, default=0.0, help='standard deviation of the angular streak noise (degrees)')),
+    (('-oa', '--opacity_attenuation'), dict(type=float, default=1.0, help='rain layer opacity factor in [0, 1]')),
+    (('-r', '--particles'), dict(default=_J('data', 'particles'), help='root of the particle simulations')),
+    (('-sd', '--streaks_db'), dict(default=_J('3rdparty', 'rainstreakdb'), help='Garg & Nayar rain streak database')),
+    (('-i', '--intensity'), dict(type=str, default='25', help='fall rates in mm/hr, comma separated (e.g. 1,15,25,50)')),
+    (('-d', '--depth'), dict(default=_J('data', 'source'), help='root of the depth maps')),
+    (('-fs', '--frame_start'), dict(type=int, default=0, help='first frame index')),
+    (('-fe', '--frame_end'), dict(type=int, default=None, help='one past the last frame index')),
+    (('-fst', '--frame_step'), dict(type=int, default=1, help='frame stride')),
+    (('-ff', '--frames'), dict(type=str, default='', help='explicit comma separated frame indices')),
+    (('--conflict_strategy',), dict(type=str, default='overwrite', choices=['overwrite', 'skip', 'rename_folder'],
+                                    help='what to do when the output folder exists')),
+    (('--rendering_strategy',), dict(type=str, default=None, choices=[None, 'white', 'naive_db'], help="None (photometric) or 'white'")),
+    (('--output',), dict(default=_J('data', 'output'), help='output root')),
+    (('--save_envmap',), dict(action='store_true', help='also write the estimated environment maps')),
+    (('--noverbose',), dict(action='store_true', help='no progress output')),
+    (('--force_particles',), dict(action='store_true', help='(reference only) re-run the particle simulator')),
+]
 
-def check_arg(args):
-    p = argparse.ArgumentParser(description='Rain renderer method (MI355X hot path)')
-    p.add_argument('--dataset', help='Enter dataset name. Dataset data must be located in: DATASET_ROOT/DATASET', type=str, required=True)
-    p.add_argument('-k', '--dataset_root', help='Path to database root', default=os.path.join('data', 'source'))
-    p.add_argument('-p', '--post_fix', help='Post fix added at the end of the modified gan file', default="", type=str)
-    p.add_argument('-s', '--sequences', help='List of sequences comma separated', default='')
-    p.add_argument('-ns', '--noise_scale', type=float, default=0.0)
-    p.add_argument('-nv', '--noise_std', type=float, default=0.0)
-    p.add_argument('-oa', '--opacity_attenuation', help='Opacity attenuation of the rain layer. Values must be between 0 and 1', type=float, default=1.0)
-    p.add_argument('-r', '--particles', help='Path to particles simulations', default=os.path.join('data', 'particles'))
-    p.add_argument('-sd', '--streaks_db', help='Path to rain streaks database (Garg and Nayar, 2006)', default=os.path.join('3rdparty', 'rainstreakdb'))
-    p.add_argument('-i', '--intensity', help='Rain Intensities. List of fall rate comma-separated. E.g.: 1,15,25,50.', type=str, default='25')
-    p.add_argument('-d', '--depth', help='Path to depths', default=os.path.join('data', 'source'))
-    p.add_argument('-fs', '--frame_start', help='Frame start', type=int, default=0)
-    p.add_argument('-fe', '--frame_end', help='Frame end', type=int, default=None)
-    p.add_argument('-fst', '--frame_step', help='Frame step', type=int, default=1)
-    p.add_argument('-ff', '--frames', type=str, default="")
-    p.add_argument('--conflict_strategy', help='Strategy to use if output already exists.', type=str,
-                   choices=['overwrite', 'skip', 'rename_folder'], default='overwrite')
-    p.add_argument('--rendering_strategy', help='Rendering strategy', choices=[None, 'white', 'naive_db'], type=str, default=None)
-    p.add_argument('--output', default=os.path.join('data', 'output'), help='Where to save the output')
-    p.add_argument('--save_envmap', help='Save environment maps, useful for debug purposes.', action='store_true')
-    p.add_argument('--noverbose', action='store_true')
-    p.add_argument('--force_particles', help='Force particles simulator to run even if simulation exist', action='store_true')
-    results = p.parse_args(args)
 
-    assert not results.force_particles or results.conflict_strategy != "skip", "If particles simulator is forced, cannot skip"
-    results.verbose = not results.noverbose
-    results.texture = os.path.join(results.streaks_db, 'env_light_database', 'size32')
-    results.norm_coeff = os.path.join(results.streaks_db, 'env_light_database', 'txt', 'normalized_env_max.txt')
-    assert os.path.exists(results.streaks_db), ("rainstreakdb database is missing.", results.streaks_db)
-    assert os.path.exists(results.texture), ("rainstreakdb database is not valid. Some files are missing.", results.texture)
-    assert os.path.exists(results.norm_coeff), ("rainstreakdb database is not valid. Some files are missing.", results.norm_coeff)
-    results.intensity = [int(i) for i in results.intensity.split(",")]
-    if results.frames:
-        results.frames = [int(i) for i in results.frames.split(",")]
-    dataset_name = results.dataset if "_gan" not in results.dataset else results.dataset[:-4]
-    results.dataset_root = os.path.join(results.dataset_root, dataset_name)
-    results.depth_root = os.path.join(results.depth, dataset_name)
-    results.calib = None
-    results.images_root = os.path.join(results.dataset_root)
-    assert os.path.exists(results.images_root), ("Dataset folder does not exist.", results.images_root)
-    sequences_filter = results.sequences.split(',')
-    results = db.resolve_paths(results.dataset, results)
-    results.settings = db.settings(results.dataset)
-    results.sequences = np.asarray([seq for seq in results.sequences if np.any([seq[:len(_s)] == _s for _s in sequences_filter])])
-    results.weather = np.asarray([{"weather": "rain", "fallrate": i} for i in results.intensity])
+def _parse(argv):
+    ap = argparse.ArgumentParser(description='Rain rendering on MI355X (hot path in librainhip.so)')
+    for names, kw in _FLAGS:
+        ap.add_argument(*names, **kw)
+    return ap.parse_args(argv)
 
+
+def _derive(ns):
+    """The fields the reference computes after parsing (main.py:131-161)."""
+    if ns.force_particles and ns.conflict_strategy == "skip":
+        raise AssertionError("If particles simulator is forced, cannot skip")
+    ns.verbose = not ns.noverbose
+    light_db = _J(ns.streaks_db, 'env_light_database')
+    ns.texture = _J(light_db, 'size32')
+    ns.norm_coeff = _J(light_db, 'txt', 'normalized_env_max.txt')
+    for what, path in (("rainstreakdb database is missing.", ns.streaks_db),
+                       ("rainstreakdb database is not valid. Some files are missing.", ns.texture),
+                       ("rainstreakdb database is not valid. Some files are missing.", ns.norm_coeff)):
+        assert os.path.exists(path), (what, path)
+    ns.intensity = [int(v) for v in ns.intensity.split(",")]
+    ns.frames = [int(v) for v in ns.frames.split(",")] if ns.frames else ns.frames
+    base_name = ns.dataset[:-4] if "_gan" in ns.dataset else ns.dataset
+    ns.dataset_root = _J(ns.dataset_root, base_name)
+    ns.depth_root = _J(ns.depth, base_name)
+    ns.images_root = ns.dataset_root
+    ns.calib = None
+    assert os.path.exists(ns.images_root), ("Dataset folder does not exist.", ns.images_root)
+    wanted = ns.sequences.split(',')
+    ns = db.resolve_paths(ns.dataset, ns)                   # dataset plug-in: fills sequences / images / depth / calib
+    ns.settings = db.settings(ns.dataset)
+    ns.sequences = np.asarray([s for s in ns.sequences if any(s.startswith(w) for w in wanted)])
+    ns.weather = np.asarray([dict(weather="rain", fallrate=r) for r in ns.intensity])
+    return ns
+
+
+def _exists(entry):
+    if entry is None:
+        return True
+    return all(os.path.exists(e) for e in entry) if isinstance(entry, list) else os.path.exists(entry)
+
+
+def _drop_incomplete_sequences(ns):
+    """A sequence needs its image folder, depth folder and (if the plug-in names one) calibration."""
     print("\nChecking sequences...")
-    print(" {} sequences found: {}".format(len(results.sequences), [s for s in results.sequences]))
-    for seq in list(results.sequences):
-        valid = True
-        if not os.path.exists(results.images[seq]):
-            print(" Skip sequence '{}': images folder is missing {}".format(seq, results.images[seq]))
-            valid = False
-        if not os.path.exists(results.depth[seq]):
-            print(" Skip sequence '{}': depth folder is missing {}".format(seq, results.depth[seq]))
-            valid = False
-        c = results.calib[seq]
-        if c is not None and not (np.all([os.path.exists(f) for f in c]) if isinstance(c, list) else os.path.exists(c)):
-            print(" Skip sequence '{}': calib data is missing {}".format(seq, c))
-            valid = False
-        if not valid:
-            results.sequences = results.sequences[results.sequences != seq]
-            del results.images[seq]
-            del results.depth[seq]
-            del results.calib[seq]
-    print("Found {} valid sequence(s): {}".format(len(results.sequences), [s for s in results.sequences]))
+    print(" {} sequences found: {}".format(len(ns.sequences), list(ns.sequences)))
+    for seq in list(ns.sequences):
+        problems = [(kind, tree[seq]) for kind, tree in (("images folder", ns.images), ("depth folder", ns.depth),
+                                                         ("calib data", ns.calib)) if not _exists(tree[seq])]
+        for kind, where in problems:
+            print(" Skip sequence '{}': {} is missing {}".format(seq, kind, where))
+        if problems:
+            ns.sequences = ns.sequences[ns.sequences != seq]
+            for tree in (ns.images, ns.depth, ns.calib):
+                del tree[seq]
+    print("Found {} valid sequence(s): {}".format(len(ns.sequences), list(ns.sequences)))
 
+
+def _locate_particles(ns):
+    """One particle file per (sequence, fall rate); the simulator itself is not run from here."""
     print("\nResolving particles simulations...")
-    particles_root = os.path.join(results.particles, results.dataset)
-    sims = {seq: db.sim(results.dataset, seq, particles_root) for seq in results.sequences}
-    missing = [(seq, w) for seq in results.sequences for w in results.weather
-               if len(glob.glob(my_utils.particles_path(sims[seq]["path"], w))) == 0]
-    if missing or results.force_particles:
+    root = _J(ns.particles, ns.dataset)
+    found, missing = {}, []
+    for seq in ns.sequences:
+        sim = db.sim(ns.dataset, seq, root)
+        found[seq] = []
+        for w in ns.weather:
+            hits = glob.glob(my_utils.particles_path(sim["path"], w))
+            if hits:
+                found[seq].append(hits[0])
+            else:
+                missing.append((seq, w))
+    if missing or ns.force_particles:
         raise SystemExit(" {} particles simulations are missing ({}) and the external weather-particle-simulator is not "
                          "driven by this build: generate them with the reference's tools/ or with "
                          "rain_rendering_amd.synthetic".format(len(missing), missing[:3]))
     print(" All particles simulations ready")
-    results.particles = {seq: [glob.glob(my_utils.particles_path(sims[seq]["path"], w))[0] for w in results.weather]
-                         for seq in results.sequences}
-    return results
+    ns.particles = found
+
+
+def check_arg(argv):
+    ns = _derive(_parse(argv))
+    _drop_incomplete_sequences(ns)
+    _locate_particles(ns)
+    return ns
 
 
 def main(argv=None):
@@ -120,10 +149,9 @@ def main(argv=None):
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         import torch
         import torch.distributed as dist
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group(backend)
+        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
     print("\nRunning renderers...")
     generator = Generator(args)
     generator.run()

@@ -103,3 +103,29 @@ def test_pack_drops_seeded_equals_global_rng(tmp_path, built):
         assert a.tobytes() == b.tobytes()
         assert np.array_equal(mut[0], fr.table.ips) and np.array_equal(mut[1], fr.table.ipe)
         fr.table.ips[:], fr.table.ipe[:] = ips, ipe
+
+
+def test_cli_flags_and_particle_resolution(tmp_path):
+    """main.check_arg: the reference's flag set, derived fields (main.py:131-161) and particle files (main.py:187-220);
+    a missing simulation is an error here (the external simulator is not driven)."""
+    import importlib
+    import os
+    tmp = str(tmp_path)
+    src = os.path.join(tmp, 'source')
+    h.synthetic.write_dataset(src, 'kitti', os.path.join('data_object', 'training'), 2, 48, 80)
+    h.synthetic.write_streak_db(os.path.join(tmp, 'rainstreakdb'))
+    xml = os.path.join(tmp, 'particles', 'kitti', 'data_object', 'rain', '5mm', 'sim_camera0.xml')
+    h.synthetic.write_particles_xml(xml, h.synthetic.simulate_particles(2, 30, 80, 48))
+    main = importlib.import_module('rain-rendering_amd.main')
+    base = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd', os.path.join(tmp, 'rainstreakdb'),
+            '--output', os.path.join(tmp, 'out')]
+    ns = main.check_arg(base + ['-i', '5', '--noverbose', '-ff', '0,1', '-oa', '0.5', '--rendering_strategy', 'white'])
+    assert list(ns.sequences) == ['data_object/training'] and ns.particles['data_object/training'] == [xml]
+    assert ns.frames == [0, 1] and ns.verbose is False and ns.opacity_attenuation == 0.5 and ns.rendering_strategy == 'white'
+    assert ns.intensity == [5] and ns.weather[0] == dict(weather='rain', fallrate=5)
+    assert ns.texture.endswith(os.path.join('env_light_database', 'size32')) and ns.settings['cam_focal'] == 6
+    assert main.check_arg(base + ['-i', '5', '-s', 'nope']).sequences.size == 0          # sequence prefix filter
+    with pytest.raises(SystemExit, match='particles simulations are missing'):
+        main.check_arg(base + ['-i', '7'])
+    with pytest.raises(AssertionError):
+        main.check_arg(base[:-2] + ['-sd', os.path.join(tmp, 'no_db')])
