@@ -77,6 +77,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
   int32_t* list_small;              // [frame][drops]  blurred drops handled one wave each (k_blur_small)
   double* colpart;                  // [frame][drops][COL_PARTS][5] FOV partial sums per envmap row band
+  double* wtab;                     // [frame][drops][2][BR_MAX+1] normalised Gaussian half tables of the blurred drops (k_blur_weights)
   uint32_t* spans;                  // [frame][tiles of 64 drops][He][64] FOV row spans xl | (xr+1) << 16, 0 = empty row
   int4* bbox;                       // [frame][drops] footprint (x0,y0,x1,y1), empty when not composited
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
@@ -1311,6 +1312,26 @@ __device__ inline void gauss_half_table_wave(double sigma, int r, double* hw) {
   if (lane <= r) hw[r - lane] = ph / tot;
 }
 
+// Normalised Gaussian half tables of every blurred drop, one thread per (drop, axis): hw[k] = w(|k - r|),
+// k = 0..r, with the oracle's left-to-right normalisation sum.  The blur kernels used to build them per
+// work item (two waves busy, the rest of the workgroup waiting); a table is 8*(r+1) bytes to load.
+__global__ __launch_bounds__(256) void k_blur_weights(const FrameDesc* frames, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+  const int i = idx >> 1, axis = idx & 1;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  const DropPlan& p = sc.plan[gi];
+  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || p.r1 <= 0 || p.r1 > BR_MAX) return;
+  const int r = axis ? p.r2 : p.r1;
+  if (r <= 0) return;
+  const double sigma = axis ? p.sig2 : p.sig1;
+  double* hw = sc.wtab + (gi * 2 + axis) * (BR_MAX + 1);
+  for (int l = 0; l <= r; l++) hw[r - l] = gauss_phi(sigma, l);        // hw[k] = phi(|k - r|)
+  double tot = 0.0;
+  for (int x = -r; x <= r; x++) tot = tot + hw[r - (x < 0 ? -x : x)];
+  for (int k = 0; k <= r; k++) hw[k] = hw[k] / tot;
+}
+
 // Four consecutive outputs (stride `st` doubles apart) of the symmetric correlate1d of radius r:
 //   acc_k = c[k]*w[r];  for ii = -r..-1:  acc_k = acc_k + (c[k+ii] + c[k-ii]) * w[ii+r]
 // As the tap distance shrinks the upper/lower operand windows of the four outputs slide by one
@@ -1398,8 +1419,9 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
           v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
         }
         if (need_tables) {
-          if ((t >> 6) == 0) gauss_half_table_wave(p.sig1, r1, hw1);
-          if ((t >> 6) == 1 && r2 > 0) gauss_half_table_wave(p.sig2, r2, hw2);
+          const double* wt = sc.wtab + gi * 2 * (BR_MAX + 1);                // built by k_blur_weights
+          if (t <= r1) hw1[t] = wt[t];
+          if (t >= 64 && t - 64 <= r2 && r2 > 0) hw2[t - 64] = wt[(BR_MAX + 1) + t - 64];
           need_tables = false;           // (the barrier after the tile load publishes the tables)
           cur = item.x;
         }
@@ -1482,20 +1504,10 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
     const double* raw = sc.arena + p.a0_off;        // raw tile (tw x th); the pad is implicit zeros
     double* tile = sc.arena + p.a1_off;             // finished effective tile
     const int tw = p.tw, th = p.th;
-    // weights: lane l holds w(distance l) of each axis
-    double w1, w2 = 0.0;
-    {
-      const double ph1 = (lane <= r1) ? gauss_phi(p.sig1, lane) : 0.0;
-      double tot = 0.0;
-      for (int x = -r1; x <= r1; x++) tot = tot + readlane_f64(ph1, x < 0 ? -x : x);
-      w1 = ph1 / tot;
-      if (r2 > 0) {
-        const double ph2 = (lane <= r2) ? gauss_phi(p.sig2, lane) : 0.0;
-        double tot2 = 0.0;
-        for (int x = -r2; x <= r2; x++) tot2 = tot2 + readlane_f64(ph2, x < 0 ? -x : x);
-        w2 = ph2 / tot2;
-      }
-    }
+    // weights: lane l holds w(distance l) of each axis, from the tables k_blur_weights built (hw[k] = w(|k - r|))
+    const double* wt = sc.wtab + ((int64_t)f * max_drops + list[it]) * 2 * (BR_MAX + 1);
+    const double w1 = (lane <= r1) ? wt[r1 - lane] : 0.0;
+    const double w2 = (r2 > 0 && lane <= r2) ? wt[(BR_MAX + 1) + r2 - lane] : 0.0;
     // Only the tw columns under the raw tile carry data through the row pass (axis 0 filters along y: a
     // column without raw pixels stays exactly zero), so X holds tw columns x hi rows and the row pass
     // runs over tw*ph outputs; the other 4*r2 columns of Y are written as zeros for the column pass.
@@ -1952,6 +1964,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.blur_items, fd * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_small, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.colpart, fd * COL_PARTS * 5))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.wtab, fd * 2 * (BR_MAX + 1)))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.spans, (size_t)F * (size_t)((D + 63) / 64 + 1) * 64 * (size_t)dm.He))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.bbox, fd))) return rc;
     {
@@ -2148,6 +2161,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     if (!ctx->serial) {
       HIPCHK(hipEventRecord(ctx->ev_gen, sc_gen));
       HIPCHK(hipStreamWaitEvent(s, ctx->ev_gen, 0));
+    }
+    {
+      ProfScope ps(ctx, s, "k_blur_weights");
+      hipLaunchKernelGGL(k_blur_weights, dim3((2 * max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_small");
@@ -2404,6 +2421,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.htab);
   hipFree(ctx->sc.list_small);
   hipFree(ctx->sc.colpart);
+  hipFree(ctx->sc.wtab);
   hipFree(ctx->sc.spans);
   hipFree(ctx->sc.bbox);
   hipFree(ctx->sc.clist);
