@@ -12,7 +12,9 @@ BATCH=${RAIN_PROFILE_BATCH:-256}
 BENCH="python $REPO/bench.py --steps 5 --warmup 2 --batch $BATCH --no-cpu-baseline --no-prepass $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 # RAIN_PROFILE_QUICK=1: only the two HBM-traffic passes (each pass re-runs the bench incl. its scene set-up)
-if [ "${RAIN_PROFILE_QUICK:-0}" = "1" ]; then
+if [ "${RAIN_PROFILE_QUICK:-0}" = "2" ]; then
+  PASSES=()                        # kernel-trace statistics only
+elif [ "${RAIN_PROFILE_QUICK:-0}" = "1" ]; then
   PASSES=("FETCH_SIZE" "WRITE_SIZE")
 else
   PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum")
