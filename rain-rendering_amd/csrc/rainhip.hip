@@ -1295,21 +1295,11 @@ __device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
   __syncthreads();
 }
 
-// Wave-level Gaussian half-table for r <= 63: lane l holds phi(l); the normalisation sum runs
-// in the oracle's order (x = -r..r, left to right) on values fetched with v_readlane, so no
-// LDS round trips and no block barrier are involved.  hw[k] = w[k], k = 0..r (centre at r).
 __device__ inline double readlane_f64(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, l);
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
-}
-__device__ inline void gauss_half_table_wave(double sigma, int r, double* hw) {
-  const int lane = threadIdx.x & 63;
-  const double ph = (lane <= r) ? gauss_phi(sigma, lane) : 0.0;
-  double tot = 0.0;
-  for (int x = -r; x <= r; x++) tot = tot + readlane_f64(ph, x < 0 ? -x : x);
-  if (lane <= r) hw[r - lane] = ph / tot;
 }
 
 // Normalised Gaussian half tables of every blurred drop, one thread per (drop, axis): hw[k] = w(|k - r|),
