@@ -60,6 +60,38 @@ def resize_linear(img, dw, dh):
 PNG_LEVEL = int(os.environ.get('RAIN_PNG_LEVEL', '1'))
 
 
+def write_png_rgba(path, rgba, level=None):
+    """8-bit RGBA PNG with the Sub filter on every row and one zlib stream: pixel-identical to what PIL (and
+    therefore plt.imsave) decodes, in about half the time of PIL's adaptive filtering.  zlib releases the GIL,
+    so the driver's I/O threads scale."""
+    import struct
+    import zlib
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    hh, ww = rgba.shape[:2]
+    assert rgba.shape == (hh, ww, 4)
+    flat = rgba.reshape(hh, -1)
+    rows = np.empty((hh, 1 + ww * 4), np.uint8)
+    rows[:, 0] = 1                                  # filter type 1 (Sub): byte - byte of the pixel to the left
+    rows[:, 1:5] = flat[:, :4]
+    rows[:, 5:] = flat[:, 4:] - flat[:, :-4]        # uint8 arithmetic wraps modulo 256, as the filter requires
+
+    def chunk(tag, data):
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+
+    blob = (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', ww, hh, 8, 6, 0, 0, 0)) +
+            chunk(b'IDAT', zlib.compress(rows.tobytes(), PNG_LEVEL if level is None else level)) + chunk(b'IEND', b''))
+    with open(path, 'wb') as fh:
+        fh.write(blob)
+
+
+def _save_rgba(path, rgba):
+    if os.environ.get('RAIN_PNG_WRITER', 'fast') == 'pil':
+        from PIL import Image
+        Image.fromarray(rgba, 'RGBA').save(path, compress_level=PNG_LEVEL)
+    else:
+        write_png_rgba(path, rgba)
+
+
 def imread_bgr(path):
     """cv2.imread(path): 8-bit, 3 channels, BGR order."""
     from PIL import Image
@@ -83,7 +115,7 @@ def imsave_rgb(path, rgb_u8):
     rgba = np.empty((h, w, 4), np.uint8)
     rgba[..., :3] = rgb_u8
     rgba[..., 3] = 255
-    Image.fromarray(rgba, 'RGBA').save(path, compress_level=PNG_LEVEL)
+    _save_rgba(path, rgba)
 
 
 _viridis = None
@@ -105,4 +137,4 @@ def imsave_scalar(path, a):
             g = np.arange(256, dtype=np.uint8)
             _viridis = np.stack([g, g, g, np.full(256, 255, np.uint8)], axis=1)
     idx = np.clip((norm * 256).astype(np.int64), 0, 255)
-    Image.fromarray(_viridis[idx], 'RGBA').save(path, compress_level=PNG_LEVEL)
+    _save_rgba(path, np.ascontiguousarray(_viridis[idx]))

@@ -129,3 +129,28 @@ def test_cli_flags_and_particle_resolution(tmp_path):
         main.check_arg(base + ['-i', '7'])
     with pytest.raises(AssertionError):
         main.check_arg(base[:-2] + ['-sd', os.path.join(tmp, 'no_db')])
+
+
+def test_fast_png_writer_is_pixel_identical(tmp_path):
+    """imgops.write_png_rgba (Sub filter + one zlib stream) decodes to exactly what was written, like PIL's file."""
+    import importlib
+    import os
+    from PIL import Image
+    imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+    rng = np.random.RandomState(3)
+    for shape in ((37, 53), (1, 1), (2, 300)):
+        rgb = rng.randint(0, 256, shape + (3,)).astype(np.uint8)
+        p = str(tmp_path / ('a_%d_%d.png' % shape))
+        imgops.imsave_rgb(p, rgb)
+        back = np.array(Image.open(p))
+        assert back.shape == shape + (4,) and np.array_equal(back[..., :3], rgb) and np.all(back[..., 3] == 255)
+        m = rng.rand(*shape) * 3
+        q = str(tmp_path / ('m_%d_%d.png' % shape))
+        imgops.imsave_scalar(q, m)
+        os.environ['RAIN_PNG_WRITER'] = 'pil'
+        try:
+            q2 = str(tmp_path / ('m2_%d_%d.png' % shape))
+            imgops.imsave_scalar(q2, m)
+        finally:
+            del os.environ['RAIN_PNG_WRITER']
+        assert np.array_equal(np.array(Image.open(q)), np.array(Image.open(q2)))
