@@ -616,6 +616,78 @@ __global__ __launch_bounds__(256) void k_colour_rows(const FrameDesc* frames, Di
   o[4] = any ? 1.0 : 0.0;
 }
 
+// Variant of k_colour_rows that stages, per table row, the two windows of entries the 64 drops of a wave
+// look up (left ends / right ends: image neighbours read nearby columns) in wave-private LDS with full-line
+// loads, and takes the look-ups from LDS.  A plain look-up pulls a 128-byte line into L1 for 32 bytes.
+constexpr int RW_CAP = 256;          // entries of both windows together, per wave (8 KB)
+__device__ inline int wave_min_i32(int v) {
+  for (int ofs = 32; ofs > 0; ofs >>= 1) v = min(v, __shfl_xor(v, ofs));
+  return v;
+}
+__device__ inline int wave_max_i32(int v) {
+  for (int ofs = 32; ofs > 0; ofs >>= 1) v = max(v, __shfl_xor(v, ofs));
+  return v;
+}
+__global__ __launch_bounds__(256) void k_colour_rows_lds(const FrameDesc* frames, Dims dm, int max_drops, int ntile, Scratch sc) {
+  __shared__ __attribute__((aligned(16))) double s_win[4][RW_CAP * 4];
+  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = (blockIdx.x / COL_PARTS) * 256 + threadIdx.x;
+  const int n = frames[f].n_drops;
+  if ((j & ~63) >= n) return;                      // the whole wave lies beyond the list
+  const bool live = j < n;
+  const int64_t gi = (int64_t)f * max_drops + (live ? sc.list_col[(int64_t)f * max_drops + j] : 0);
+  const int rpb = (dm.He + COL_PARTS - 1) / COL_PARTS;
+  const int y0 = band * rpb, y1 = min(dm.He, y0 + rpb);
+  const uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + lane;
+  const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
+  double* win = s_win[wave];
+  double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0;
+  int any = 0;
+  for (int y = y0; y < y1; y++) {
+    const uint32_t v = live ? sp[(int64_t)y * 64] : 0u;
+    const int xr1 = (int)(v >> 16), xl = (int)(v & 0xffffu);
+    const bool valid = xr1 != 0;
+    any |= xr1;
+    const int lmax = wave_max_i32(valid ? xl : -1);
+    if (lmax < 0) continue;                        // empty row for the whole wave
+    const int lmin = wave_min_i32(valid ? xl : 0x7fffffff);
+    const int hmin = wave_min_i32(valid ? xr1 : 0x7fffffff), hmax = wave_max_i32(valid ? xr1 : -1);
+    const int nl = lmax - lmin + 1, nh = hmax - hmin + 1;
+    const double* row = P + (int64_t)y * (dm.We + 1) * 4;
+    if (nl + nh <= RW_CAP) {
+      for (int c = lane; c < 2 * (nl + nh); c += 64) {           // 16-byte pieces, consecutive lanes = consecutive bytes
+        const int e = c >> 1, half = c & 1;
+        const int col = e < nl ? lmin + e : hmin + (e - nl);
+        const double2 d = *reinterpret_cast<const double2*>(row + (int64_t)col * 4 + half * 2);
+        *reinterpret_cast<double2*>(win + e * 4 + half * 2) = d;
+      }
+      wave_lds_sync();
+      if (valid) {
+        const double* lo = win + (xl - lmin) * 4;
+        const double* hi = win + (nl + xr1 - hmin) * 4;
+        S0 += hi[0] - lo[0];
+        S1 += hi[1] - lo[1];
+        S2 += hi[2] - lo[2];
+        S3 += hi[3] - lo[3];
+      }
+      wave_lds_sync();
+    } else if (valid) {
+      const double* hi = row + (int64_t)xr1 * 4;
+      const double* lo = row + (int64_t)xl * 4;
+      S0 += hi[0] - lo[0];
+      S1 += hi[1] - lo[1];
+      S2 += hi[2] - lo[2];
+      S3 += hi[3] - lo[3];
+    }
+  }
+  if (live) {
+    double* o = sc.colpart + (gi * COL_PARTS + band) * 5;
+    o[0] = S0; o[1] = S1; o[2] = S2; o[3] = S3;
+    o[4] = any ? 1.0 : 0.0;
+  }
+}
+
 // Colour, pass 2: one thread per drop adds the band partials in band order and writes the
 // compositor record.
 __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int nparts) {
@@ -1845,6 +1917,7 @@ struct rr_ctx {
   // profiling
   bool prof = false;
   int tile_dbg = 0;                 // RAINHIP_TILE_DBG: timing experiments only (skips stages of k_tile)
+  bool rows_lds = false;             // RAINHIP_ROWS_LDS=1: LDS-staged look-up windows in the colour row kernel (A/B)
   bool dedup = true;                 // RAINHIP_NO_DEDUP=1 renders every drop's raw tile (A/B check of k_dedup)
   bool simple_tile = false;          // RAINHIP_SIMPLE_TILE=1: one-thread-per-pixel tile kernel (A/B reference)
   std::vector<ProfEntry> prof_pending;
@@ -2118,7 +2191,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       }
       if (banded) {
         ProfScope ps(ctx, sc_col, "k_colour_rows");
-        hipLaunchKernelGGL(k_colour_rows, dim3(((max_drops + 255) / 256) * COL_PARTS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, ntile, sc);
+        if (ctx->rows_lds)
+          hipLaunchKernelGGL(k_colour_rows_lds, dim3(((max_drops + 255) / 256) * COL_PARTS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, ntile, sc);
+        else
+          hipLaunchKernelGGL(k_colour_rows, dim3(((max_drops + 255) / 256) * COL_PARTS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, ntile, sc);
       }
       {
         ProfScope ps(ctx, sc_col, "k_colour");
@@ -2348,6 +2424,8 @@ int rr_create(rr_ctx** out, int device) {
   {
     const char* e = getenv("RAINHIP_SIMPLE_TILE");
     ctx->simple_tile = e && e[0] == '1';
+    const char* rl = getenv("RAINHIP_ROWS_LDS");
+    ctx->rows_lds = rl && rl[0] == '1';
     const char* nd = getenv("RAINHIP_NO_DEDUP");
     ctx->dedup = !(nd && nd[0] == '1');
     const char* d = getenv("RAINHIP_TILE_DBG");
