@@ -131,8 +131,9 @@ def imsave_scalar(path, a):
     norm = np.zeros_like(a) if hi <= lo else (a - lo) / (hi - lo)
     if _viridis is None:
         try:
-            from matplotlib import cm
-            _viridis = (np.asarray(cm.get_cmap('viridis', 256)(np.arange(256))) * 255).astype(np.uint8)
+            import matplotlib
+            cmap = matplotlib.colormaps['viridis'] if hasattr(matplotlib, 'colormaps') else matplotlib.cm.get_cmap('viridis', 256)
+            _viridis = (np.asarray(cmap(np.arange(256))) * 255).astype(np.uint8)
         except Exception:
             g = np.arange(256, dtype=np.uint8)
             _viridis = np.stack([g, g, g, np.full(256, 255, np.uint8)], axis=1)
