@@ -243,7 +243,11 @@ def rotation_matrix_2d(cx, cy, alpha, beta):
 
 
 def rotate_bound_geometry(h, w, alpha, beta):
-    """imutils.rotate_bound canvas and matrix: cos/sin of (-angle)."""
+    """imutils.rotate_bound canvas and matrix: cos/sin of (-angle).
+
+    Centre convention: `(cX, cY) = (w / 2, h / 2)` with TRUE division, as in the released imutils (>= 0.4,
+    Python 3); very old copies used `w // 2, h // 2`, which differs by half a pixel for odd sizes and is not
+    implemented (tests/test_known_answers.py pins the choice on a 33 x 229 canvas)."""
     cX, cY = w / 2, h / 2
     M = rotation_matrix_2d(cX, cY, alpha, beta)
     cos = abs(M[0, 0])

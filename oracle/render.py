@@ -659,10 +659,13 @@ def quantise_mask(rainy_mask):
 
 def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textures, ratio, cam,
                  frame_seed, noise_std=0.0, noise_scale=0.0, opacity_attenuation=1.0,
-                 faithful=True, max_drops=None, rendering_strategy=None):
+                 faithful=True, max_drops=None, rendering_strategy=None, first_drop=0):
     """The hot loop of Generator.run for one frame (generator.py:318,389-394,428-438,461-467).
 
     streak_list: the already filtered list of Streak objects (mutated like the reference does).
+    first_drop > 0 renders the window [first_drop, max_drops) only: the earlier drops still consume their
+    random draws (so the window sees the reference's RNG stream) but are not composited (test windows;
+    noise-free scenes only, since the skipped drops' in-place end-point rotation is not replayed).
     Returns dict(rainy_bg f64, mask f64, mask_i32, image_u8 RGB, status int32[n])."""
     np.random.seed(frame_seed)                        # generator.py:318
     H, W = bg.shape[:2]
@@ -677,6 +680,8 @@ def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textur
         noise = 0.0
         if drop.drop_type != DropType.Big:
             noise = np.random.normal(0.0, noise_std) * noise_scale       # RNG draw 2 (generator.py:136)
+        if i < first_drop:
+            continue
         tile, minC = make_drop_tile(drop, textures[tex_idx], noise, W, H)
         pts = compute_fov_plane_points(drop.world_position_start, drop.world_position_end,
                                        RADIUS, FOV_DEG, N_FOV, env_map_xyY.shape)
@@ -686,4 +691,4 @@ def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textur
         except IndexError as e:                       # generator.py:185-189: any exception == skip
             status[i] = e.args[0] if e.args and isinstance(e.args[0], int) else ST_FOV_FAIL
     return dict(rainy_bg=rainy_bg, mask=rainy_mask, mask_i32=quantise_mask(rainy_mask),
-                image_u8=quantise_image(rainy_bg, bg), status=status)
+                image_u8=quantise_image(rainy_bg, bg), status=status[first_drop:])

@@ -245,6 +245,7 @@ def main():
     sat = np.zeros((H, W, 3))
     statuses = []
     tiles_used = []
+    scipy_filter = rbw.gaussian_filter
     for variant in ('scipy', 'detexp'):
         if variant == 'detexp':
             # same reference code, but with the defocus filter swapped for the oracle's deterministic
@@ -274,6 +275,48 @@ def main():
         out['add_%s_rainy_bg' % variant] = rb
         out['add_%s_mask' % variant] = rm
         out['add_%s_skipped' % variant] = np.array(st)
+    # the int32 export north_star grades (SURVEY decision D1), from the UNTOUCHED reference (real scipy filter)
+    out['add_scipy_mask_i32'] = np.floor(out['add_scipy_mask'] * 255).astype(np.int32)
+    # ---- 8c. a larger scene through the untouched reference (real scipy.ndimage.gaussian_filter): only what the
+    # contract grades is stored -- floor(mask * 255) and the uint8 image of the epilogue (generator.py:461-466)
+    rbw.gaussian_filter = scipy_filter
+    BH, BW, BN, BSEED = 256, 384, 700, 4300
+    scb = h.Scene(os.path.join(tmp, 'scene_big'), BH, BW, BN, seed0=BSEED, far_fraction=0.05)
+    bgb, envb = scb.frame_inputs(0)
+    texb, ratiob = scb.oracle_db()
+    np.random.seed(0)
+    rb = bgb.copy()
+    rm = np.zeros((BH, BW))
+    satb = np.zeros((BH, BW, 3))
+    st = []
+    import copy
+    for d in scb.oracle_streaks(0):
+        tex_idx = orc.take_drop_texture_index(d, ratiob)
+        if d.drop_type != orc.DropType.Big:
+            np.random.normal(0.0, 0.0)
+        dd = copy.deepcopy(d)
+        tile, minC = orc.make_drop_tile(dd, texb[tex_idx], 0.0, BW, BH)
+        rs = rbw.Streak()
+        rs.world_position_start, rs.world_position_end = dd.world_position_start, dd.world_position_end
+        rs.image_diameter_start, rs.image_diameter_end = dd.image_diameter_start, dd.image_diameter_end
+        rs.length = dd.length
+        pts, _, _, _ = fov.compute_fov_plane_points(rs, 10, 165, 20, envb.shape)
+        try:
+            rr.add_drop_to_image('kitti', envb, scb.omega, pts, minC, bgb, rb, rm, satb, tile.copy(), rs, 'ambient', None, 1.0)
+            st.append(0)
+        except Exception:
+            st.append(1)
+    import io as _io
+    import matplotlib.pyplot as _plt
+    from PIL import Image as _PILImage
+    final = rb - (np.mean(rb) - np.mean(bgb))                                  # generator.py:461-462
+    buf = _io.BytesIO()
+    _plt.imsave(buf, np.clip(final[..., ::-1], 0, 1))                            # generator.py:466
+    buf.seek(0)
+    out['big_scene'] = np.array([BH, BW, BN, BSEED])
+    out['big_scipy_mask_i32'] = np.floor(rm * 255).astype(np.int32)
+    out['big_scipy_image_u8'] = np.array(_PILImage.open(buf))[..., :3]
+    out['big_scipy_skipped'] = np.array(st)
     # ---- 8b. rendering_strategy 'white' (bad_weather.py:349-353): no cv2/pyclipper call at all ----
     np.random.seed(0)
     rb = rainy_bg.copy()

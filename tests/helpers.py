@@ -22,49 +22,16 @@ solid_angle = importlib.import_module("rain-rendering_amd.common.solid_angle")
 
 from oracle import render as orc  # noqa: E402
 
-KITTI = dict(focal_mm=6.0, f_number=6.0, exposure_ms=2.0, pix_um=4.65)
+scenes = importlib.import_module("rain-rendering_amd.scenes")
+KITTI, CITYSCAPES, NUSCENES = scenes.KITTI, scenes.CITYSCAPES, scenes.NUSCENES
 
 
-class Scene:
-    """One synthetic sequence: streak DB + particles on disk, frames/envmaps in memory."""
-
-    def __init__(self, tmpdir, H, W, n_drops, n_frames=1, cam=KITTI, seed0=3000, far_fraction=0.02, frames=None,
-                 tex_heights=None, tex_width=None):
-        self.H, self.W = H, W
-        self.cam_settings = cam
-        self.tex_dir, self.norm = synthetic.write_streak_db(os.path.join(str(tmpdir), 'rainstreakdb'),
-                                                            tex_heights=tex_heights, tex_width=tex_width)
-        if frames is None:
-            frames = synthetic.simulate_particles(n_frames, n_drops, W, H, cam['focal_mm'], cam['pix_um'], cam['exposure_ms'],
-                                                  seed0=seed0, far_fraction=far_fraction)
-        self.xml = synthetic.write_particles_xml(os.path.join(str(tmpdir), 'particles', 'rain', 'sim_camera0.xml'), frames)
-        self.He = H
-        self.We = synthetic.envmap_width(cam['focal_mm'], W)
-        # product loaders
-        self.db = bw.DBManager(streaks_path=self.tex_dir, streaks_path_xml=self.xml, norm_coeff_path=self.norm)
-        self.db.load_streak_database()
-        self.db.load_streaks_from_xml('kitti', {"render_scale": 1}, [W, H], use_pickle=False, verbose=False)
-        self.omega = solid_angle.get_solid_angles(np.zeros((self.He, self.We)))
-        self.cam = hb.make_camera(cam['focal_mm'] / 1000., cam['f_number'], cam['exposure_ms'])
-        self.ocam = dict(focal_m=cam['focal_mm'] / 1000., f_number=cam['f_number'], exposure_ms=cam['exposure_ms'])
-
-    def frame_inputs(self, i):
-        bg = synthetic.make_frame(i, self.H, self.W)
-        env_bgr = synthetic.make_envmap(i, self.He, self.We)
-        env_xyY = my_utils.convert_rgb_to_xyY(env_bgr[..., ::-1])
-        env_xyY[np.isnan(env_xyY)] = 0
-        return bg, np.ascontiguousarray(env_xyY)
-
-    def product_drops(self, i, noise_std=0.0, noise_scale=0.0):
-        """What Generator.run does before the GPU call: seed, filter, pack."""
-        frames = list(self.db.streaks_simulator.values())
-        fr = frames[i % len(frames)]
-        np.random.seed(i)
-        idx = hb.filter_streaks(fr.table, self.W, self.H)
-        return hb.pack_drops(fr.table, idx, self.db, noise_std, noise_scale)
+class Scene(scenes.Scene):
+    """The product-side synthetic sequence (rain-rendering_amd/scenes.py) plus the ORACLE loaders of the
+    same files, so a test can feed identical inputs to both."""
 
     def oracle_streaks(self, i):
-        sim = orc.load_streaks_from_xml(self.xml, 1, [self.W, self.H])
+        sim = orc.load_streaks_from_xml(self.xml, self.render_scale, [self.W, self.H])
         frames = list(sim.values())
         fr = frames[i % len(frames)]
         return list(orc.streak_filter(fr.streaks, self.W, self.H).values())
@@ -117,9 +84,10 @@ def emu_render(scene, bg, rainy_bg, env_xyY, drops, opacity=1.0, strategy=0):
     return out
 
 
-def oracle_render(scene, i, bg, rainy_bg, env_xyY, faithful=True, noise_std=0.0, noise_scale=0.0, max_drops=None, strategy=None):
+def oracle_render(scene, i, bg, rainy_bg, env_xyY, faithful=True, noise_std=0.0, noise_scale=0.0, max_drops=None, strategy=None,
+                  first_drop=0):
     textures, ratio = scene.oracle_db()
     streaks = scene.oracle_streaks(i)
     return orc.render_frame(bg, rainy_bg, env_xyY, scene.omega, streaks, textures, ratio, scene.ocam, frame_seed=i,
                             noise_std=noise_std, noise_scale=noise_scale, faithful=faithful, max_drops=max_drops,
-                            rendering_strategy=strategy)
+                            rendering_strategy=strategy, first_drop=first_drop)

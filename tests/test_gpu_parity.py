@@ -45,7 +45,8 @@ def test_gpu_matches_oracle(rh, tmp_path, H, W, N, seed, noise):
 
 def test_gpu_matches_hostemu_kitti_shape(rh, tmp_path):
     """KITTI-shaped frame, 25 mm/hr drop count: GPU vs the g++ build of the same arithmetic
-    (bit-exact everywhere except the colour sums' order), plus oracle on a drop prefix."""
+    (bit-exact everywhere except the colour sums' order).  The numpy oracle on this configuration:
+    tests/test_gpu_configs.py::kitti_25 (500-drop window)."""
     sc = h.Scene(tmp_path, 375, 1242, 2048, seed0=77)
     bg, env = sc.frame_inputs(0)
     drops = sc.product_drops(0)
@@ -98,3 +99,18 @@ def test_gpu_white_strategy(rh, tmp_path):
     assert np.array_equal(out['rainy_bg'], ref['rainy_bg'])           # no colour constant involved: bit-exact composite
     assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
     assert (drops['x0'] < 0).any() or (drops['y0'] < 0).any()          # the wrap-around path is exercised
+
+
+def test_gpu_int32_mask_equals_untouched_reference(rh, tmp_path):
+    """The 620-streak scene of tests/golden/make_golden.py section 8c: the REFERENCE's own add_drop_to_image with the
+    real scipy.ndimage.gaussian_filter.  The kernels' deterministic exp moves blurred alphas by <= 4 ulp; the
+    graded quantities must not notice: int32 mask identical, uint8 image within 1 LSB."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_vectors.npz'))
+    BH, BW, BN, BSEED = (int(v) for v in G['big_scene'])
+    sc = h.Scene(tmp_path, BH, BW, BN, seed0=BSEED, far_fraction=0.05)
+    bg, env = sc.frame_inputs(0)
+    out = _render(rh, sc, 0, bg, bg, env, sc.product_drops(0))
+    assert np.array_equal((out['status'] != 0).astype(int), G['big_scipy_skipped'])
+    assert np.array_equal(out['mask_i32'], G['big_scipy_mask_i32'])
+    assert np.abs(out['image_u8'].astype(int) - G['big_scipy_image_u8'].astype(int)).max() <= 1     # +-1 LSB

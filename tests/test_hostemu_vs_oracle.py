@@ -49,3 +49,24 @@ def test_hostemu_forced_paths(tmp_path):
     assert set(kind) == {0, 1}
     assert set(rs_mode[kind == 1]) == {0, 1, 2}
     assert (npts == 24).any() or (npts == 20).all()
+
+
+@pytest.mark.parametrize("name,window", [('cityscapes_half', (200, 300)), ('cityscapes_full', (1000, 1060)),
+                                         ('nuscenes_100', (3000, 3080)), ('kitti_100', (4000, 4150))])
+def test_hostemu_matches_oracle_on_baseline_configs(tmp_path, name, window):
+    """Windows of the BASELINE.json configurations (Cityscapes 5 ms / render_scale 2, nuScenes f/1.8 5.5 mm,
+    KITTI 100 mm/hr) at their full frame and environment-map sizes: kernel arithmetic vs the op-for-op oracle.
+    The GPU tier (tests/test_gpu_configs.py) repeats this through the kernels with larger windows."""
+    import test_gpu_configs as cfg
+    H, W, N, cam, rs, _ = cfg.CONFIGS[name]
+    sc = h.Scene(tmp_path, H, W, N, cam=cam, render_scale=rs, seed0=4000)
+    bg, env = sc.frame_inputs(0)
+    a, b = window
+    drops = sc.product_drops(0)[a:b]
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=True, first_drop=a, max_drops=b)
+    assert np.array_equal(emu['status'], ref['status'])
+    assert np.array_equal(emu['mask'], ref['mask'])
+    assert np.array_equal(emu['mask_i32'], ref['mask_i32'])
+    assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+    assert (emu['status'] == 0).sum() > 0.8 * len(drops)
