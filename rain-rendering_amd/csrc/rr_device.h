@@ -411,15 +411,22 @@ RR_HD double py_mod(double a, double b) {   // numpy float remainder, b > 0
   return m;
 }
 
-// returns the number of vertices (20 or 24), or 0 where the reference's `except:` fires;
-// vertices are truncated toward zero like pyclipper's integer cast.
-RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, int32_t* px, int32_t* py) {
-  const double PI = 3.141592653589793;
-  const double TWO_PI = 2.0 * PI;
-  int N = cam.n_fov;
-  double pos[3] = {(d.wps[0] + d.wpe[0]) / 2.0, (d.wps[2] + d.wpe[2]) / 2.0, (d.wps[1] + d.wpe[1]) / 2.0};
+// The polygon is evaluated in three steps so that the HIP kernel can give every (drop, vertex) pair its own
+// lane (k_fov_spans) while tests/hostemu runs the same arithmetic serially:
+//   fov_setup   per drop: mid-point, view direction, tilted direction v                (bad_weather.py:596-628)
+//   fov_vertex  per vertex k: spin, sphere intersection, lat-long pixel                 (bad_weather.py:630-664)
+//   fov_polygon the serial composition + wrap handling                                  (bad_weather.py:669-704)
+struct FovSetup {
+  double pos[3], n[3], v[3];
+};
+RR_HD bool fov_setup(const rr_drop& d, const rr_camera& cam, FovSetup& F) {
+  double* pos = F.pos;
+  double* n = F.n;
+  pos[0] = (d.wps[0] + d.wpe[0]) / 2.0;
+  pos[1] = (d.wps[2] + d.wpe[2]) / 2.0;
+  pos[2] = (d.wps[1] + d.wpe[1]) / 2.0;
   double nrm = sqrt(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
-  double n[3] = {pos[0] / nrm, pos[1] / nrm, pos[2] / nrm};
+  n[0] = pos[0] / nrm; n[1] = pos[1] / nrm; n[2] = pos[2] / nrm;
   double a = n[0], b = n[1], c = n[2];
   double dd = pos[0] * n[0] + pos[1] * n[1] + pos[2] * n[2];
   if (b == 0.0) b = 0.001;
@@ -428,42 +435,61 @@ RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, in
   double uu[3] = {pos[0] - ppx, pos[1] - ppy, pos[2] - ppz};
   double un = sqrt(uu[0] * uu[0] + uu[1] * uu[1] + uu[2] * uu[2]);
   uu[0] /= un; uu[1] /= un; uu[2] /= un;
-  if (!(uu[0] == uu[0]) || !(uu[1] == uu[1]) || !(uu[2] == uu[2])) return 0;
+  if (!(uu[0] == uu[0]) || !(uu[1] == uu[1]) || !(uu[2] == uu[2])) return false;
   double rv[3] = {uu[1] * n[2] - uu[2] * n[1], uu[2] * n[0] - uu[0] * n[2], uu[0] * n[1] - uu[1] * n[0]};
-  double R[9], v[3];
+  double R[9];
   rotmat(rv, cam.fov_cos, cam.fov_sin, R);
-  vecmat(n, R, v);
+  vecmat(n, R, F.v);
+  return true;
+}
+// vertex k: azimuth (for the wrap test) and the float pixel position on the lat-long map
+RR_HD void fov_vertex(const FovSetup& F, const rr_camera& cam, double phi_cos, double phi_sin, int He, int We, double& azimuth,
+                      double& ptx, double& pty) {
+  const double PI = 3.141592653589793;
+  const double TWO_PI = 2.0 * PI;
+  const double* pos = F.pos;
+  double M[9], dir[3];
+  rotmat(F.n, phi_cos, phi_sin, M);
+  vecmat(F.v, M, dir);
+  double qa = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+  double qb = 2 * dir[0] * pos[0] + 2 * dir[1] * pos[1] + 2 * dir[2] * pos[2];
+  double qc = pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2] - cam.radius * cam.radius;
+  double disc = qb * qb - 4 * qa * qc;
+  double t1 = (-qb + sqrt(disc)) / (2 * qa);
+  double P[3] = {pos[0] + t1 * dir[0], pos[1] + t1 * dir[1], pos[2] + t1 * dir[2]};
+  double el = atan2(P[2], sqrt(P[0] * P[0] + P[1] * P[1]));
+  double az = atan2(P[1], P[0]);
+  if (az < 0) az += TWO_PI;
+  if (el < 0) el += TWO_PI;
+  if (az > TWO_PI) az -= TWO_PI;
+  if (el > TWO_PI) el -= TWO_PI;
+  azimuth = py_mod((TWO_PI - az) - PI / 2.0, TWO_PI);
+  double u = azimuth / TWO_PI;
+  double elevation = py_mod(el + PI / 2.0, TWO_PI);
+  double vv = 1.0 - elevation / PI;
+  ptx = u * (double)We;
+  pty = vv * (double)He;
+}
+// wrap test of one polygon side (bad_weather.py:669-672): np.isclose(df, 0) or df < 0
+RR_HD bool fov_wrap_cnd(double az_k, double az_next) {
+  double df = az_next - az_k;
+  bool close = fabs(df) <= 1e-8;       // np.isclose(df, 0): false for NaN
+  return close || (df < 0);
+}
+RR_HD bool fov_coord_ok(double v) { return fabs(v) < 1e15; }   // NaN/inf -> Clipper range error
+
+// returns the number of vertices (20 or 24), or 0 where the reference's `except:` fires;
+// vertices are truncated toward zero like pyclipper's integer cast.
+RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, int32_t* px, int32_t* py) {
+  int N = cam.n_fov;
+  FovSetup F;
+  if (!fov_setup(d, cam, F)) return 0;
   double ptx[RR_MAX_FOV], pty[RR_MAX_FOV], azs[RR_MAX_FOV + 1];
-  for (int k = 0; k < N; k++) {
-    double M[9], dir[3];
-    rotmat(n, cam.phi_cos[k], cam.phi_sin[k], M);
-    vecmat(v, M, dir);
-    double qa = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
-    double qb = 2 * dir[0] * pos[0] + 2 * dir[1] * pos[1] + 2 * dir[2] * pos[2];
-    double qc = pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2] - cam.radius * cam.radius;
-    double disc = qb * qb - 4 * qa * qc;
-    double t1 = (-qb + sqrt(disc)) / (2 * qa);
-    double P[3] = {pos[0] + t1 * dir[0], pos[1] + t1 * dir[1], pos[2] + t1 * dir[2]};
-    double el = atan2(P[2], sqrt(P[0] * P[0] + P[1] * P[1]));
-    double az = atan2(P[1], P[0]);
-    if (az < 0) az += TWO_PI;
-    if (el < 0) el += TWO_PI;
-    if (az > TWO_PI) az -= TWO_PI;
-    if (el > TWO_PI) el -= TWO_PI;
-    double azimuth = py_mod((TWO_PI - az) - PI / 2.0, TWO_PI);
-    double u = azimuth / TWO_PI;
-    double elevation = py_mod(el + PI / 2.0, TWO_PI);
-    double vv = 1.0 - elevation / PI;
-    azs[k] = azimuth;
-    ptx[k] = u * (double)We;
-    pty[k] = vv * (double)He;
-  }
+  for (int k = 0; k < N; k++) fov_vertex(F, cam, cam.phi_cos[k], cam.phi_sin[k], He, We, azs[k], ptx[k], pty[k]);
   azs[N] = azs[0];
   int count_true = 0, count_false = 0, pos_true = -1, pos_false = -1;
   for (int k = 0; k < N; k++) {
-    double df = azs[k + 1] - azs[k];
-    bool close = fabs(df) <= 1e-8;       // np.isclose(df, 0): false for NaN
-    bool cnd = close || (df < 0);
+    bool cnd = fov_wrap_cnd(azs[k], azs[k + 1]);
     if (cnd) { count_true++; if (pos_true < 0) pos_true = k; }
     else { count_false++; if (pos_false < 0) pos_false = k; }
   }
@@ -492,7 +518,7 @@ RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, in
     for (int k = 0; k < N; k++) { fx[m] = ptx[k]; fy[m] = pty[k]; m++; }
   }
   for (int k = 0; k < m; k++) {
-    if (!(fabs(fx[k]) < 1e15) || !(fabs(fy[k]) < 1e15)) return 0;   // NaN/inf -> Clipper range error
+    if (!fov_coord_ok(fx[k]) || !fov_coord_ok(fy[k])) return 0;
     px[k] = (int32_t)fx[k];
     py[k] = (int32_t)fy[k];
   }
