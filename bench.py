@@ -24,7 +24,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
@@ -46,6 +45,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prepass', action='store_true', help='skip the extra (untimed) pre-pass measurement')
     ap.add_argument('--cpu-sample-drops', type=int, default=1024)
+    ap.add_argument('--opt', action='append', default=[], help='rr_set_option as ID=VALUE (tuning switches that never change results)')
     args = ap.parse_args()
 
     import torch
@@ -74,7 +74,7 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    import helpers as h
+    h = importlib.import_module('rain-rendering_amd.scenes')
     hb, synthetic = h.hb, h.synthetic
 
     H, W, B = args.height, args.width, args.batch
@@ -87,6 +87,9 @@ def main():
     He, We = sc.He, sc.We
 
     rh = hb.RainHip(local_rank)
+    for kv in args.opt:
+        k, v = kv.split('=')
+        rh.set_option(int(k), int(v))
     # --- the one collective: RCCL broadcast of the packed streak DB over xGMI -----------------
     texels, hs, ws, offs = hb.pack_streak_db(sc.db.streaks_light)
     t_tex = torch.from_numpy(texels).to(dev)
@@ -268,10 +271,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             # CPU reference = the numpy oracle in its op-for-op ("faithful") mode, 1 core, on the
             # first --cpu-sample-drops streaks of frame 0; extrapolated linearly in the drop count.
-            from oracle import render as orc
+            from oracle import render as orc             # the checker, timed: the only place bench.py touches oracle/
             bg, env, drops = host_frames[0]
-            textures, ratio = sc.oracle_db()
-            streaks = sc.oracle_streaks(0)
+            textures, ratio = orc.load_streak_database(sc.tex_dir, sc.norm)
+            sim0 = list(orc.load_streaks_from_xml(sc.xml, 1, [W, H]).values())[0]
+            streaks = list(orc.streak_filter(sim0.streaks, W, H).values())
             ns = min(args.cpu_sample_drops, len(streaks))
             c0 = time.perf_counter()
             orc.render_frame(bg, bg, env, sc.omega, streaks, textures, ratio, sc.ocam, frame_seed=0, faithful=True,

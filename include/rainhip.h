@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RR_VERSION 120            /* 0.1.2: + pre-pass, pipeline, host draws, batch counts */
+#define RR_VERSION 200            /* 0.2.0: + rr_set_option; colour path without the HBM prefix table */
 
 enum {
   RR_OK = 0,
@@ -196,6 +196,17 @@ int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_
  * its members: what is non-NULL is downloaded as well. */
 int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
                        const rr_prepass_out* pre_out);
+
+/* Tuning / A-B switches.  NONE of them changes a result bit (tests/test_gpu_properties.py); unknown options or
+ * values are RR_E_ARG.  The library reads no environment variables. */
+enum {
+  RR_OPT_DEDUP = 1,                 /* 1 (default): drops with bit-identical raw-tile parameters share one tile inside a batch */
+  RR_OPT_GENERAL_FOV = 2,           /* 1: force the general colour path (prefix table in HBM) that maps taller than 1024 rows,
+                                     *    wider than 4096 columns or with He*We >= 2^22 always take; default 0 */
+  RR_OPT_FOV_THREADS = 3,           /* workgroup size of the FOV-sum kernel: 0 (library's choice), 512 or 1024 */
+  RR_OPT_FOV_DROPS_PER_THREAD = 4   /* drops per thread of the FOV-sum kernel: 0 (library's choice), 1, 2 or 4 */
+};
+int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 
 /* Work-list sizes of frame `frame` of the last batch (after completion): out[0] drops whose raw tile went
  * through the rotate+resize kernel, [1] through the generic kernel, [2] fused-blur work items, [3] slow-blur

@@ -58,14 +58,30 @@ struct FrameDesc {
   double opacity;
 };
 
+// Pointers that arrive inside FrameDesc are loaded from memory, so the compiler has to treat them as generic
+// ("flat": every access also counts against the LDS counter).  They are all device-global: say so.
+template <class T>
+using global_ptr = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ inline global_ptr<T> as_global(T* p) { return (global_ptr<T>)p; }
+__device__ inline rr_drop load_drop(const rr_drop* p) {       // 14 global 8-byte loads
+  static_assert(sizeof(rr_drop) % 8 == 0, "rr_drop layout");
+  rr_drop d;
+  const global_ptr<const uint64_t> src = as_global(reinterpret_cast<const uint64_t*>(p));
+  uint64_t* dst = reinterpret_cast<uint64_t*>(&d);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(rr_drop) / 8); k++) dst[k] = src[k];
+  return d;
+}
+
 struct Scratch {                    // per-batch device scratch, all indexed [frame][...]
   DropPlan* plan;
   CompRec* comp;
   int32_t* poly;                    // [frame][drop][2][POLY_STRIDE]
   int32_t* npts;
   int64_t* sizes;
-  double* prefix;                   // [frame][He][We+1][4]
-  double* fconst;                   // [frame][2] = sum_omega, ambient
+  double* prefix;                   // [frame][He][We+1][4]: general path only (maps beyond HE_MAX / FOV_WE_MAX)
+  double* fband;                    // [frame][COL_PARTS][2] = sum w, sum Y*w of every row band
   double* arena;                    // [frame][arena_cap]
   double* partial;                  // [frame][ntiles][2]
   double* means;                    // [frame][2]
@@ -76,17 +92,16 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
   int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
   int32_t* list_small;              // [frame][drops]  blurred drops handled one wave each (k_blur_small)
-  double* colpart;                  // [frame][drops][COL_PARTS][5] FOV partial sums per envmap row band
+  double* colpart;                  // [frame][COL_PARTS][5][drops] FOV partial sums per envmap row band
   double* wtab;                     // [frame][drops][2][BR_MAX+1] normalised Gaussian half tables of the blurred drops (k_blur_weights)
-  uint32_t* spans;                  // [frame][tiles of 64 drops][He][64] FOV row spans xl | (xr+1) << 16, 0 = empty row
+  uint32_t* spans;                  // [frame][drops + 1][Hp] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4;
+                                    // row `drops` of every frame stays all zeros: what a drop without a polygon reads
   int4* bbox;                       // [frame][drops] footprint (x0,y0,x1,y1), empty when not composited
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
   int32_t* ccount;                  // [frame][coarse tiles]
   int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small, -, -, #duplicate raw tiles
   int32_t* list_big;                // [frame][drops] Big drops (bicubic warp) rendered by k_tile_big, one thread per pixel
   int32_t* big_off;                 // [frame][drops+1] exclusive prefix of their tile sizes, in pixels
-  int32_t* list_col;                // [frame][drops] drops grouped by image region (k_col_order), for XCD-local colour gathers
-  int32_t* col_off;                 // [frame][16] start of each of the 8 region groups (+ total at [8])
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
   int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
 };
@@ -103,8 +118,8 @@ __global__ __launch_bounds__(256) void k_env_prefix(const FrameDesc* frames, Dim
   if (row >= dm.He) return;
   const FrameDesc& fr = frames[f];
   const int We = dm.We;
-  const double* env = fr.env + (int64_t)row * We * 3;
-  const double* om = fr.omega + (int64_t)row * We;
+  const global_ptr<const double> env = as_global(fr.env) + (int64_t)row * We * 3;
+  const global_ptr<const double> om = as_global(fr.omega) + (int64_t)row * We;
   double* P = prefix + ((int64_t)f * dm.He + row) * (int64_t)(We + 1) * 4;
   if (lane == 0) { P[0] = 0.0; P[1] = 0.0; P[2] = 0.0; P[3] = 0.0; }
   double carry[4] = {0, 0, 0, 0};
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256) void k_env_prefix(const FrameDesc* frames, Dim
   }
 }
 
-__global__ __launch_bounds__(256) void k_env_consts(Dims dm, const double* prefix, double* fconst) {
+__global__ __launch_bounds__(256) void k_env_consts(Dims dm, const double* prefix, double* fband) {
   const int f = blockIdx.x, t = threadIdx.x;
   double sY = 0, sW = 0;
   for (int r = t; r < dm.He; r += 256) {
@@ -156,9 +171,9 @@ __global__ __launch_bounds__(256) void k_env_consts(Dims dm, const double* prefi
     }
     __syncthreads();
   }
-  if (t == 0) {
-    fconst[f * 2 + 0] = b[0];
-    fconst[f * 2 + 1] = a[0] / b[0];
+  if (t < 8) {                         // same layout as k_fov_sums' row-band totals: band 0 carries everything
+    fband[(f * 8 + t) * 2 + 0] = t == 0 ? b[0] : 0.0;
+    fband[(f * 8 + t) * 2 + 1] = t == 0 ? a[0] : 0.0;
   }
 }
 
@@ -231,19 +246,15 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
   const FrameDesc& fr = frames[f];
   if (i >= fr.n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
-  rr_drop d = fr.drops[i];
+  rr_drop d = load_drop(fr.drops + i);
   DropPlan p;
   int64_t size = 0;
   plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size);
-  int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
-  int32_t* py = px + POLY_STRIDE;
-  // the FOV polygon is evaluated for every drop: in the reference its failure is raised
-  // before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
-  int npts = fov_polygon(d, cam, dm.He, dm.We, px, py);
-  if (fr.strategy == 1) npts = -1;                // 'white': the FOV is computed by the reference but never used
+  // the FOV polygon (k_fov_spans, launched before this kernel) is evaluated for every drop: in the reference
+  // its failure is raised before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
+  const int npts = sc.npts[gi];                   // 0: failed; -1: 'white' strategy (never used)
   if (p.status != RR_DROP_OK || npts == 0) size = 0;
   if (size > 0 && blur_is_slow(p)) size += (int64_t)p.ew * p.eh;
-  sc.npts[gi] = npts;
   sc.sizes[gi] = size;
   sc.plan[gi] = p;
 }
@@ -348,8 +359,18 @@ __global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_
 }
 
 // ---------------------------------------------------------------------------
-// colour: FOV polygon row spans x prefix table, one wave per drop
+// colour: FOV polygon -> row spans -> sums over the environment map
 // ---------------------------------------------------------------------------
+// The reference reduces the whole environment map under a polygon mask for every drop
+// (bad_weather.py:383-409).  Here the mask of a drop is its per-row span [xl, xr] (k_fov_spans) and the
+// masked sums are differences of row prefix sums (k_fov_sums).  The prefix sums of a row only ever live
+// in LDS: every environment-map row is read from HBM once per batch.
+constexpr int COL_PARTS = 8;        // row bands of the environment map; partials are added in band order (fixed: results
+                                    // do not depend on the batch size)
+constexpr int HE_MAX = 1024;        // tallest map of the fast path: 16 chunks of 64 rows in registers
+constexpr int FOV_WE_MAX = 4096;    // widest map of the fast path: (We + 1) * 32 B of LDS, <= 4 columns per thread
+constexpr int FOV_GROUPS = 3;       // drops per wave in k_fov_spans (n_fov = 20: 60 of 64 lanes busy)
+
 __device__ inline void wave_lds_sync() {
   // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
   // stops the compiler from moving accesses across the hand-off point.
@@ -384,74 +405,339 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
   return xl <= xr;
 }
 
-// The FOV polygon of a drop sits where the drop is seen, so drops that are close in the image
-// gather from neighbouring entries of the prefix table.  Workgroups go to the 8 XCDs round robin,
-// each XCD with its own 4 MB L2: k_col_order groups the drops of a frame by image region (4 x 2)
-// and k_colour_bands gives region r to the workgroups with blockIdx.x % 8 == r, so that one L2
-// only ever sees the part of the 23 MB table its region's polygon outlines sweep.
-constexpr int COL_REGIONS = 8;
-constexpr int COL_CELLS = 64;        // 8 x 8 cells per region, visited along a Z curve
-__device__ inline int colour_bin(const rr_drop& d, const Dims& dm) {
-  const int W = imax(dm.W, 1), H = imax(dm.H, 1);
-  // 32 x 16 cells over the frame: region = (cx / 8, cy / 8), cell inside the region by bit interleave
-  const int cx = imin(imax((d.x0 * 32) / W, 0), 31), cy = imin(imax((d.y0 * 16) / H, 0), 15);
-  const int region = (cy >> 3) * 4 + (cx >> 3);
-  const int lx = cx & 7, ly = cy & 7;
-  int z = 0;
-  for (int b = 0; b < 3; b++) z |= ((lx >> b) & 1) << (2 * b) | ((ly >> b) & 1) << (2 * b + 1);
-  return region * COL_CELLS + z;
-}
-// Counting sort of a frame's drops by (region, cell): consecutive list entries are neighbours in the
-// image, so the 64 drops a wave of k_colour_rows handles read neighbouring prefix-table entries (the
-// texture unit merges lanes that hit the same 128-byte line).  The order inside a cell is whatever the
-// atomics produce; no result depends on it (every drop's sums are its own).
-__global__ __launch_bounds__(1024) void k_col_order(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
-  const int f = blockIdx.x, t = threadIdx.x;
-  const int n = frames[f].n_drops;
-  const rr_drop* drops = frames[f].drops;
-  __shared__ int s_cnt[COL_REGIONS * COL_CELLS], s_off[COL_REGIONS * COL_CELLS];
-  for (int k = t; k < COL_REGIONS * COL_CELLS; k += 1024) s_cnt[k] = 0;
-  __syncthreads();
-  for (int i = t; i < n; i += 1024) atomicAdd(&s_cnt[colour_bin(drops[i], dm)], 1);
-  __syncthreads();
-  if (t < 64) {                        // exclusive scan of the 512 bins: 8 per lane, then across the wave
-    int loc[8], sum = 0;
-    for (int k = 0; k < 8; k++) { loc[k] = sum; sum += s_cnt[t * 8 + k]; }
-    int run = sum;
-    for (int ofs = 1; ofs < 64; ofs <<= 1) {
-      const int v = __shfl_up(run, ofs);
-      if (t >= ofs) run += v;
-    }
-    const int base = run - sum;
-    for (int k = 0; k < 8; k++) s_off[t * 8 + k] = base + loc[k];
-    if ((t & 7) == 0) sc.col_off[f * 16 + (t >> 3)] = base;       // region r starts at bin r * 64 = lane r * 8
-    if (t == 63) sc.col_off[f * 16 + COL_REGIONS] = run;
+// FOV polygon and its row spans.  One wave handles FOV_GROUPS drops:
+//   1. every (drop, vertex) pair has a lane: spin direction, sphere intersection, lat-long pixel (fov_vertex); the
+//      wrap test of the reference (bad_weather.py:669-695) is a ballot inside the 20-lane group, the four border
+//      vertices of a wrapping polygon are inserted by the lane in front of the gap.  The polygon goes to
+//      wave-private LDS, never to global memory.
+//   2. per drop, edges in a uniform loop, lanes along the rows an edge covers: the x of edge e at row y is
+//      xa + floor((2*dx*(y-ya) + den) / (2*den)) (fov_rowspan), evaluated with a float reciprocal and an exact
+//      integer fix-up (|2*dx*dy| < 2^23 is checked by the host), folded into the row's [min, max] with LDS
+//      ds_min / ds_max (order-free, no return value).  The spans leave as one u32 per row, xl | (xr + 1) << 16
+//      (0 = empty), rows of a drop contiguous: coalesced stores.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, Scratch sc) {
+  const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const FrameDesc& fr = frames[f];
+  const int N = cam.n_fov, G = imin(64 / N, FOV_GROUPS);
+  __shared__ double s_phi[2][RR_MAX_FOV];
+  __shared__ int s_px[4][FOV_GROUPS][POLY_STRIDE], s_py[4][FOV_GROUPS][POLY_STRIDE];
+  __shared__ int s_xl[4][NCH * 64], s_xr[4][NCH * 64];         // per wave: the row spans of the drop being converted
+  if (threadIdx.x < RR_MAX_FOV) {
+    s_phi[0][threadIdx.x] = cam.phi_cos[threadIdx.x];
+    s_phi[1][threadIdx.x] = cam.phi_sin[threadIdx.x];
   }
   __syncthreads();
-  int32_t* lst = sc.list_col + (int64_t)f * max_drops;
-  for (int i = t; i < n; i += 1024) lst[atomicAdd(&s_off[colour_bin(drops[i], dm)], 1)] = i;
+  const int i0 = (blockIdx.x * 4 + wave) * G;                  // first drop of this wave
+  if (i0 >= fr.n_drops) return;
+  const int g = lane / N, k = lane - g * N;                    // (drop slot, vertex)
+  const bool act = g < G && i0 + g < fr.n_drops;
+  const int64_t gi = (int64_t)f * max_drops + i0 + (act ? g : 0);
+  if (fr.strategy == 1) {                                      // 'white': the FOV is computed by the reference but never used
+    if (act && k == 0) sc.npts[gi] = -1;
+    return;
+  }
+  double az = 0.0, ptx = 0.0, pty = 0.0;
+  bool ok = false;
+  if (act) {
+    FovSetup F;
+    const rr_drop d = load_drop(fr.drops + i0 + g);
+    ok = fov_setup(d, cam, F);
+    fov_vertex(F, cam, s_phi[0][k], s_phi[1][k], dm.He, dm.We, az, ptx, pty);
+  }
+  const int base = g * N, nxt_lane = base + (k + 1 == N ? 0 : k + 1);
+  const double az_next = __shfl(az, act ? nxt_lane : lane), pty_next = __shfl(pty, act ? nxt_lane : lane);
+  const bool cnd = act && fov_wrap_cnd(az, az_next);
+  const unsigned long long gmask = act ? (((N >= 64 ? 0ull : (1ull << N)) - 1ull) << base) : 0ull;
+  const unsigned long long bt = __ballot(cnd) & gmask, bf = __ballot(act && !cnd) & gmask;
+  const unsigned long long bad = __ballot(act && (!fov_coord_ok(ptx) || !fov_coord_ok(pty))) & gmask;
+  int m = 0;
+  if (act && ok && bt && bf && !bad) {
+    const int count_true = __popcll(bt), count_false = __popcll(bf);
+    const bool top = count_true == 1, wrap = top || count_false == 1;
+    const int pp = (top ? __ffsll((long long)bt) : __ffsll((long long)bf)) - 1 - base;
+    m = wrap ? N + 4 : N;
+    int* qx = s_px[wave][g];
+    int* qy = s_py[wave][g];
+    const int idx = (wrap && k > pp) ? k + 4 : k;
+    qx[idx] = (int32_t)ptx;
+    qy[idx] = (int32_t)pty;
+    if (wrap && k == pp) {                                     // the border vertices between pp and pp + 1
+      const int cols = dm.We, rows = dm.He;
+      if (top) {
+        qx[pp + 1] = cols; qy[pp + 1] = (int32_t)pty;
+        qx[pp + 2] = cols; qy[pp + 2] = 0;
+        qx[pp + 3] = 0;    qy[pp + 3] = 0;
+        qx[pp + 4] = 0;    qy[pp + 4] = (int32_t)pty_next;
+      } else {
+        qx[pp + 1] = 0;    qy[pp + 1] = (int32_t)pty;
+        qx[pp + 2] = 0;    qy[pp + 2] = rows;
+        qx[pp + 3] = cols; qy[pp + 3] = rows;
+        qx[pp + 4] = cols; qy[pp + 4] = (int32_t)pty_next;
+      }
+    }
+  }
+  if (act && k == 0) sc.npts[gi] = m;
+  wave_lds_sync();
+  const int He = dm.He;
+  int* xl = s_xl[wave];
+  int* xr = s_xr[wave];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) { xl[c * 64 + lane] = 1 << 30; xr[c * 64 + lane] = -(1 << 30); }
+  for (int gg = 0; gg < G; gg++) {
+    const int mg = __builtin_amdgcn_readfirstlane(__shfl(m, gg * N));
+    if (mg <= 0) continue;                                     // no polygon: k_fov_sums never reads this drop's spans
+    // lane e describes edge e
+    int e_ylo = 0x7fffffff, e_yhi = -0x7fffffff, e_xa = 0, e_dx = 0, e_hl = 0, e_hh = 0;
+    float e_inv = 0.f;
+    if (lane < mg) {
+      const int j = (lane + 1 == mg) ? 0 : lane + 1;
+      const int x0 = s_px[wave][gg][lane], y0 = s_py[wave][gg][lane], x1 = s_px[wave][gg][j], y1 = s_py[wave][gg][j];
+      const bool swp = y1 < y0;
+      e_ylo = swp ? y1 : y0;
+      e_yhi = swp ? y0 : y1;
+      e_xa = swp ? x1 : x0;
+      e_dx = (swp ? x0 : x1) - e_xa;
+      e_hl = imin(x0, x1);
+      e_hh = imax(x0, x1);
+      const int den = e_yhi - e_ylo;
+      e_inv = den > 0 ? 1.0f / (float)(2 * den) : 0.f;
+    }
+    wave_lds_sync();                                           // span tables initialised (start / previous drop's read-out)
+    for (int e = 0; e < mg; e++) {
+      const int ylo = __builtin_amdgcn_readlane(e_ylo, e), yhi = __builtin_amdgcn_readlane(e_yhi, e);
+      const int ra = imax(ylo, 0), rb = imin(yhi, He - 1);
+      if (ra > rb) continue;
+      const int den = yhi - ylo;
+      if (den == 0) {                                          // horizontal edge: both end points on this row
+        if (lane == 0) {
+          atomicMin(&xl[ylo], __builtin_amdgcn_readlane(e_hl, e));
+          atomicMax(&xr[ylo], __builtin_amdgcn_readlane(e_hh, e));
+        }
+      } else {
+        const int xa = __builtin_amdgcn_readlane(e_xa, e), dx2 = 2 * __builtin_amdgcn_readlane(e_dx, e), dn = 2 * den;
+        const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_inv), e));
+        for (int yb = ra; yb <= rb; yb += 64) {                // rows of the edge, 64 per step; a row is touched by one lane
+          const int y = yb + lane;
+          if (y <= rb) {
+            const int t = y - ylo;
+            const int nn = __mul24(dx2, t) + den;              // exact: |dx2 * t| < 2^23 (host check)
+            int q = (int)floorf((float)nn * inv);              // floor(nn / dn) up to +-1 ...
+            const int rem = nn - __mul24(q, dn);
+            q += rem < 0 ? -1 : (rem >= dn ? 1 : 0);           // ... made exact
+            atomicMin(&xl[y], xa + q);
+            atomicMax(&xr[y], xa + q);
+          }
+        }
+      }
+    }
+    wave_lds_sync();
+    uint32_t* out = sc.spans + ((int64_t)f * (max_drops + 1) + i0 + gg) * Hp;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const int y = c * 64 + lane;
+      const int a = imax(xl[y], 0), b = imin(xr[y], dm.We - 1);
+      xl[y] = 1 << 30;                                         // ready for the wave's next drop
+      xr[y] = -(1 << 30);
+      if (y < Hp) {
+        uint32_t v = 0;
+        if (y < He && a <= b) v = (uint32_t)a | ((uint32_t)(b + 1) << 16);
+        out[y] = v;
+      }
+    }
+  }
 }
 
-// Colour, pass 1: one wave per (drop, row band): polygon row spans x prefix table, wave reduce.
-constexpr int COL_BANDS = 1;        // legacy single-kernel path: one band
-constexpr int COL_PARTS = 8;        // banded path: one row band of the prefix table per XCD L2
+// ---- wave64 scans on DPP (cross-lane moves inside the VALU; __shfl_* would go through the LDS crossbar) ----
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_move_f64(double v) {        // lanes without a source (bound_ctrl) or masked rows read 0.0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double row16_incl_scan_f64(double v) {  // inclusive scan inside every row of 16 lanes
+  v += dpp_move_f64<0x111, 0xf>(v);                      // row_shr:1
+  v += dpp_move_f64<0x112, 0xf>(v);                      // row_shr:2
+  v += dpp_move_f64<0x114, 0xf>(v);                      // row_shr:4
+  v += dpp_move_f64<0x118, 0xf>(v);                      // row_shr:8
+  return v;
+}
+__device__ inline double wave_incl_scan_f64(double v) {
+  v = row16_incl_scan_f64(v);
+  v += dpp_move_f64<0x142, 0xa>(v);                      // row_bcast:15 into rows 1 and 3
+  v += dpp_move_f64<0x143, 0xc>(v);                      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ inline double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
 
-constexpr int HE_MAX = 1024;        // tallest environment map the LDS span tables hold (else per-row edge scan)
+// Sums of (x*w, y*w, Y*w, w) under every drop's spans.  Workgroup (frame, row band, chunk of NT*DPT drops); per map
+// row of the band:
+//   1. the row (24 B of xyY + 8 B of solid angle per texel) is read from HBM -- once per batch: the chunks of a
+//      (frame, band) run on the same XCD and the later ones find it in L2 -- and its inclusive prefix sums are built
+//      in LDS.  Wave w owns the columns [w*Cw, (w+1)*Cw) in passes of 64 consecutive columns (coalesced loads,
+//      conflict-free LDS stores): DPP scan per pass, carry between passes, wave totals through LDS;
+//   2. every thread takes its DPT drops' look-ups P[xr + 1] - P[xl] from LDS (an empty span is (0, 0): an exact
+//      zero, no branch) and keeps the running sums in registers.
+// The next row's global loads are issued before the look-ups of the current one.  Band partials go to
+// colpart[frame][band][5][drop]; the chunk-0 workgroups also leave the band's row totals (sum w, sum Y*w) for the
+// frame constants.  LDS: P as two arrays of double2 (x*w, y*w) / (Y*w, w): 16-byte entries spread a wave's random
+// look-ups over all 64 banks.
+constexpr int FOV_EMAX = 4;
+template <int DPT, int EMAX>
+__global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int rpb, Scratch sc) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const int We = dm.We;
+  double2* s_P01 = reinterpret_cast<double2*>(s_dyn);    // [We + 1] inclusive prefix of (x*w, y*w); entry 0 = zeros
+  double2* s_P23 = s_P01 + (We + 1);                     // [We + 1] ... of (Y*w, w)
+  double* s_wt = reinterpret_cast<double*>(s_P23 + (We + 1));   // [16][4] wave totals of the row being scanned
+  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS, chunk = blockIdx.x / COL_PARTS;
+  const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, nw = NT >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const FrameDesc& fr = frames[f];
+  const int n = fr.n_drops;
+  const int d0 = chunk * NT * DPT;
+  if (d0 >= n) return;
+  const int y0 = band * rpb, y1 = imin(dm.He, y0 + rpb);
+  const int Cw = (We + nw - 1) / nw;                     // columns per wave, taken in passes of 64 (<= EMAX passes)
+  const int cw0 = wave * Cw;
+  // spans of frame f: [max_drops + 1][Hp]; row max_drops is all zeros (what a drop without a polygon reads)
+  const uint32_t* spf = sc.spans + (int64_t)f * (max_drops + 1) * Hp;
+  uint32_t sp[DPT];
+#pragma unroll
+  for (int d = 0; d < DPT; d++) {
+    const int i = d0 + d * NT + t;
+    sp[d] = (uint32_t)((i < n && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops) * (uint32_t)Hp;
+  }
+  if (t == 0) { s_P01[0] = make_double2(0.0, 0.0); s_P23[0] = make_double2(0.0, 0.0); }
+  double S[DPT][4];
+  uint32_t any[DPT];
+#pragma unroll
+  for (int d = 0; d < DPT; d++) { S[d][0] = S[d][1] = S[d][2] = S[d][3] = 0.0; any[d] = 0; }
+  double totY = 0.0, totW = 0.0;                         // row totals, kept by the thread that owns the last column
+  double pv[EMAX][4];
+  auto load_row = [&](int y) {
+    const global_ptr<const double> env = as_global(fr.env) + (int64_t)y * We * 3;
+    const global_ptr<const double> om = as_global(fr.omega) + (int64_t)y * We;
+#pragma unroll
+    for (int e = 0; e < EMAX; e++) {
+      const int cl = e * 64 + lane, c = cw0 + cl;
+      if (cl < Cw && c < We) {
+        const double w = om[c];
+        pv[e][0] = env[c * 3 + 0] * w;
+        pv[e][1] = env[c * 3 + 1] * w;
+        pv[e][2] = env[c * 3 + 2] * w;
+        pv[e][3] = w;
+      } else {
+        pv[e][0] = pv[e][1] = pv[e][2] = pv[e][3] = 0.0;
+      }
+    }
+  };
+  if (y0 < y1) load_row(y0);
+  for (int yq = y0; yq < y1; yq += 4) {                  // y0 is a multiple of four: one 16-byte span load per drop and quad
+    uint4 q[DPT];
+#pragma unroll
+    for (int d = 0; d < DPT; d++) q[d] = *reinterpret_cast<const uint4*>(spf + sp[d] + yq);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int y = yq + j;
+      if (y >= y1) break;
+      // ---- 1. prefix sums of row y into LDS ----
+      double carry[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int e = 0; e < EMAX; e++) {
+        if (e * 64 < Cw) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const double v = wave_incl_scan_f64(pv[e][k]) + carry[k];
+            pv[e][k] = v;
+            carry[k] = readlane_f64(v, 63);
+          }
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_wt[wave * 4 + k] = carry[k];
+      }
+      __syncthreads();                                   // wave totals visible; the previous row's look-ups are done
+      double basev[4];                                   // totals of the waves in front: 16-lane scan of the wave totals
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double wt = row16_incl_scan_f64(lane < nw ? s_wt[lane * 4 + k] : 0.0);
+        const double u = readlane_f64(wt, wave > 0 ? wave - 1 : 0);
+        basev[k] = wave > 0 ? u : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < EMAX; e++) {
+        const int cl = e * 64 + lane, c = cw0 + cl;
+        if (cl < Cw && c < We) {
+          const double o0 = basev[0] + pv[e][0], o1 = basev[1] + pv[e][1], o2 = basev[2] + pv[e][2], o3 = basev[3] + pv[e][3];
+          s_P01[c + 1] = make_double2(o0, o1);
+          s_P23[c + 1] = make_double2(o2, o3);
+          if (c == We - 1) { totY += o2; totW += o3; }
+        }
+      }
+      if (y + 1 < y1) load_row(y + 1);                   // in flight under the look-ups
+      __syncthreads();                                   // row prefix complete
+      // ---- 2. look-ups ----
+#pragma unroll
+      for (int d = 0; d < DPT; d++) {
+        const uint32_t v = j == 0 ? q[d].x : (j == 1 ? q[d].y : (j == 2 ? q[d].z : q[d].w));
+        any[d] |= v;
+        const uint32_t ih = v >> 16, il = v & 0xffffu;
+        const double2 h0 = s_P01[ih], h1 = s_P23[ih], l0 = s_P01[il], l1 = s_P23[il];
+        S[d][0] += h0.x - l0.x;
+        S[d][1] += h0.y - l0.y;
+        S[d][2] += h1.x - l1.x;
+        S[d][3] += h1.y - l1.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DPT; d++) {
+    const int i = d0 + d * NT + t;
+    if (i < n) {
+      double* o = sc.colpart + ((int64_t)(f * COL_PARTS + band) * 5) * max_drops + i;
+      o[0] = S[d][0];
+      o[(int64_t)max_drops] = S[d][1];
+      o[(int64_t)max_drops * 2] = S[d][2];
+      o[(int64_t)max_drops * 3] = S[d][3];
+      o[(int64_t)max_drops * 4] = any[d] ? 1.0 : 0.0;
+    }
+  }
+  {                                                      // the thread that owns the last column
+    const int cl = We - 1 - cw0;
+    if (chunk == 0 && cl >= 0 && cl < Cw && (cl & 63) == lane) {
+      sc.fband[(f * COL_PARTS + band) * 2 + 0] = totW;
+      sc.fband[(f * COL_PARTS + band) * 2 + 1] = totY;
+    }
+  }
+}
 
-template <int HE_CAP>                // rows the LDS span tables hold: 512 (7 workgroups per CU) or HE_MAX
-__global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int dbg, int write_spans,
-                                                      int ntile) {
-  static_assert(COL_BANDS == 1, "region scheduling assumes one band");
+// ---- general path (maps taller than HE_MAX / wider than FOV_WE_MAX): polygon per thread, prefix table in HBM ----
+__global__ __launch_bounds__(128) void k_fov_poly_general(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  const FrameDesc& fr = frames[f];
+  if (i >= fr.n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
+  const rr_drop d = load_drop(fr.drops + i);
+  int npts = fov_polygon(d, cam, dm.He, dm.We, px, px + POLY_STRIDE);
+  if (fr.strategy == 1) npts = -1;
+  sc.npts[gi] = npts;
+}
+
+// one wave per drop: per-row edge scan x prefix table (gathers from HBM / L2)
+__global__ __launch_bounds__(256) void k_fov_sums_general(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
   const int f = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int band = 0;
-  // gridDim.x is a multiple of 8: workgroup (f, bx) runs on XCD bx % 8 and takes drops of region bx % 8
-  const int region = blockIdx.x % COL_REGIONS;
-  const int r_begin = sc.col_off[f * 16 + region], r_end = sc.col_off[f * 16 + region + 1];
-  __shared__ int s_xl[4][HE_CAP], s_xr[4][HE_CAP];
-  __shared__ int s_edge[4][5][64];                 // per wave: item range end, x0, y0, x1, y1 of every polygon edge
-  for (int j = r_begin + (blockIdx.x / COL_REGIONS) * 4 + wave; j < r_end; j += (gridDim.x / COL_REGIONS) * 4) {
-  const int i = sc.list_col[(int64_t)f * max_drops + j];
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= frames[f].n_drops) return;
   const int64_t gi = (int64_t)f * max_drops + i;
   const int n = sc.npts[gi];
   double S[4] = {0, 0, 0, 0};
@@ -459,107 +745,21 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
   if (n > 0) {
     const int32_t* px = sc.poly + gi * 2 * POLY_STRIDE;
     const int32_t* py = px + POLY_STRIDE;
-    // y extent of the polygon: lane e holds vertex e, butterfly min/max across the wave (a serial loop
-    // over the vertices is a chain of ~20 dependent global loads per drop)
     int ymin = lane < n ? py[lane] : 0x7fffffff, ymax = lane < n ? py[lane] : -0x7fffffff;
     for (int ofs = 32; ofs > 0; ofs >>= 1) {
       ymin = min(ymin, __shfl_xor(ymin, ofs));
       ymax = max(ymax, __shfl_xor(ymax, ofs));
     }
-    const int rows_per_band = (dm.He + COL_BANDS - 1) / COL_BANDS;
-    const int ya = max(max(ymin, 0), band * rows_per_band), yb = min(min(ymax, dm.He - 1), (band + 1) * rows_per_band - 1);
+    const int ya = max(ymin, 0), yb = min(ymax, dm.He - 1);
     const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
-    const bool use_lds = dm.He <= HE_CAP;
-    if (use_lds) {
-      // scan conversion over flattened (edge, row) items: lane e describes edge e (rows it covers inside
-      // [ya, yb]); an inclusive scan gives every edge its item range; item k finds its edge by binary
-      // search and folds its x into the row's [min, max] with LDS atomics (order-free, exact).
-      int* xl = s_xl[wave];
-      int* xr = s_xr[wave];
-      int* e_end = s_edge[wave][0];
-      int* e_x0 = s_edge[wave][1];
-      int* e_y0 = s_edge[wave][2];
-      int* e_x1 = s_edge[wave][3];
-      int* e_y1 = s_edge[wave][4];
-      for (int y = ya + lane; y <= yb; y += 64) { xl[y] = 1 << 30; xr[y] = -(1 << 30); }
-      int cnt = 0, ex0 = 0, ey0 = 0, ex1 = 0, ey1 = 0;
-      if (lane < n) {
-        const int j = (lane + 1 == n) ? 0 : lane + 1;
-        ex0 = px[lane]; ey0 = py[lane]; ex1 = px[j]; ey1 = py[j];
-        cnt = max(min(max(ey0, ey1), yb) - max(min(ey0, ey1), ya) + 1, 0);
-      }
-      int run = cnt;
-      for (int ofs = 1; ofs < 64; ofs <<= 1) {
-        const int v = __shfl_up(run, ofs);
-        if (lane >= ofs) run += v;
-      }
-      const int total = (dbg & 0x20000) ? 0 : __shfl(run, n - 1);
-      e_end[lane] = lane < n ? run : 0x7fffffff;
-      e_x0[lane] = ex0; e_y0[lane] = ey0; e_x1[lane] = ex1; e_y1[lane] = ey1;
-      wave_lds_sync();
-      for (int k = lane; k < total; k += 64) {
-        int e = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-          if (e_end[e + step - 1] <= k) e += step;             // first edge whose range ends after k
-        const int x0 = e_x0[e], y0 = e_y0[e], x1 = e_x1[e], y1 = e_y1[e];
-        const int first = e > 0 ? e_end[e - 1] : 0;
-        const int y = max(min(y0, y1), ya) + (k - first);
-        int xlo, xhi;
-        if (y0 == y1) {
-          xlo = min(x0, x1);
-          xhi = max(x0, x1);
-        } else {
-          const bool swp = y1 < y0;
-          const int xa = swp ? x1 : x0, yA = swp ? y1 : y0, xb = swp ? x0 : x1, yB = swp ? y0 : y1;
-          const int den = yB - yA;
-          const int nn = 2 * (xb - xa) * (y - yA) + den;
-          // floor(nn / (2*den)): the reciprocal product can be off by one ulp only; fix up exactly
-          int q = (int)floor((double)nn * (1.0 / (double)(2 * den)));
-          const int rem = nn - q * 2 * den;
-          if (rem < 0) q -= 1; else if (rem >= 2 * den) q += 1;
-          xlo = xhi = xa + q;
-        }
-        atomicMin(&xl[y], xlo);
-        atomicMax(&xr[y], xhi);
-      }
-      wave_lds_sync();
-    }
-    if (write_spans) {
-      // banded path: the row spans go to global memory ([He][64 drops] tiles, drop = position in the
-      // region-sorted list) and k_colour_rows does the look-ups band by band
-      uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + (j & 63);
-      for (int y = lane; y < dm.He; y += 64) {
-        uint32_t v = 0;
-        if (y >= ya && y <= yb) {
-          const int xl_ = max(s_xl[wave][y], 0), xr_ = min(s_xr[wave][y], dm.We - 1);
-          if (xl_ <= xr_) v = (uint32_t)xl_ | ((uint32_t)(xr_ + 1) << 16);
-        }
-        sp[(int64_t)y * 64] = v;
-      }
-      wave_lds_sync();
-      continue;
-    }
-    for (int y = ya + lane; y <= ((dbg & 0x10000) ? ya - 1 : yb); y += 64) {
+    for (int y = ya + lane; y <= yb; y += 64) {
       int xl_, xr_;
-      bool ok;
-      if (use_lds) {
-        xl_ = max(s_xl[wave][y], 0);
-        xr_ = min(s_xr[wave][y], dm.We - 1);
-        ok = xl_ <= xr_;
-      } else {
-        ok = fov_rowspan_fast(px, py, n, y, dm.We, xl_, xr_);
-      }
-      if (ok) {
+      if (fov_rowspan_fast(px, py, n, y, dm.We, xl_, xr_)) {
         any = 1;
         const double* row = P + (int64_t)y * (dm.We + 1) * 4;
         const double* hi = row + (int64_t)(xr_ + 1) * 4;
         const double* lo = row + (int64_t)xl_ * 4;
-        if (xl_ > 0) {
-          for (int k = 0; k < 4; k++) S[k] += hi[k] - lo[k];
-        } else {
-          for (int k = 0; k < 4; k++) S[k] += hi[k];                 // P[row][0] == 0
-        }
+        for (int k = 0; k < 4; k++) S[k] += hi[k] - lo[k];             // P[row][0] == 0
       }
     }
     for (int ofs = 32; ofs > 0; ofs >>= 1) {
@@ -567,130 +767,18 @@ __global__ __launch_bounds__(256) void k_colour_bands(const FrameDesc* frames, D
       any |= __shfl_xor(any, ofs);
     }
   }
-  if (write_spans) {                 // no polygon: every row empty
-    uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + (j & 63);
-    for (int y = lane; y < dm.He; y += 64) sp[(int64_t)y * 64] = 0;
-    continue;
-  }
-  if (lane == 0) {
-    double* o = sc.colpart + (gi * COL_PARTS + band) * 5;
-    o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[3];
-    o[4] = (double)any;
-  }
-  wave_lds_sync();                  // the span tables are reused by this wave's next drop
-  }
-}
-
-// Colour, banded look-ups: ONE THREAD PER DROP, rows of one band in sequence.  Workgroup bx takes band
-// bx % 8, i.e. XCD bx % 8 only ever reads rows [band*He/8, (band+1)*He/8) of the frame's prefix table
-// (2.9 MB at KITTI size: L2 resident), and the 64 lanes of a wave -- neighbouring drops of one image
-// region -- read the same table row at nearby columns.  Spans arrive coalesced ([row][64 drops]).
-__global__ __launch_bounds__(256) void k_colour_rows(const FrameDesc* frames, Dims dm, int max_drops, int ntile, Scratch sc) {
-  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS;
-  const int j = (blockIdx.x / COL_PARTS) * 256 + threadIdx.x;
-  if (j >= frames[f].n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + sc.list_col[(int64_t)f * max_drops + j];
-  const int rpb = (dm.He + COL_PARTS - 1) / COL_PARTS;
-  const int y0 = band * rpb, y1 = min(dm.He, y0 + rpb);
-  const uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + (j & 63);
-  const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
-  double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0;
-  int any = 0;
-  // no branch on empty rows: their span is (0, 0) and P[row][0] - P[row][0] adds an exact zero, so the
-  // four independent rows of an unrolled step keep all their loads in flight
-#pragma unroll 4
-  for (int y = y0; y < y1; y++) {
-    const uint32_t v = sp[(int64_t)y * 64];
-    const int xr1 = (int)(v >> 16), xl = (int)(v & 0xffffu);
-    any |= xr1;
-    const double* row = P + (int64_t)y * (dm.We + 1) * 4;
-    const double* hi = row + (int64_t)xr1 * 4;
-    const double* lo = row + (int64_t)xl * 4;                       // P[row][0] == 0
-    S0 += hi[0] - lo[0];
-    S1 += hi[1] - lo[1];
-    S2 += hi[2] - lo[2];
-    S3 += hi[3] - lo[3];
-  }
-  double* o = sc.colpart + (gi * COL_PARTS + band) * 5;
-  o[0] = S0; o[1] = S1; o[2] = S2; o[3] = S3;
-  o[4] = any ? 1.0 : 0.0;
-}
-
-// Variant of k_colour_rows that stages, per table row, the two windows of entries the 64 drops of a wave
-// look up (left ends / right ends: image neighbours read nearby columns) in wave-private LDS with full-line
-// loads, and takes the look-ups from LDS.  A plain look-up pulls a 128-byte line into L1 for 32 bytes.
-constexpr int RW_CAP = 256;          // entries of both windows together, per wave (8 KB)
-__device__ inline int wave_min_i32(int v) {
-  for (int ofs = 32; ofs > 0; ofs >>= 1) v = min(v, __shfl_xor(v, ofs));
-  return v;
-}
-__device__ inline int wave_max_i32(int v) {
-  for (int ofs = 32; ofs > 0; ofs >>= 1) v = max(v, __shfl_xor(v, ofs));
-  return v;
-}
-__global__ __launch_bounds__(256) void k_colour_rows_lds(const FrameDesc* frames, Dims dm, int max_drops, int ntile, Scratch sc) {
-  __shared__ __attribute__((aligned(16))) double s_win[4][RW_CAP * 4];
-  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = (blockIdx.x / COL_PARTS) * 256 + threadIdx.x;
-  const int n = frames[f].n_drops;
-  if ((j & ~63) >= n) return;                      // the whole wave lies beyond the list
-  const bool live = j < n;
-  const int64_t gi = (int64_t)f * max_drops + (live ? sc.list_col[(int64_t)f * max_drops + j] : 0);
-  const int rpb = (dm.He + COL_PARTS - 1) / COL_PARTS;
-  const int y0 = band * rpb, y1 = min(dm.He, y0 + rpb);
-  const uint32_t* sp = sc.spans + (((int64_t)f * ntile + (j >> 6)) * dm.He) * 64 + lane;
-  const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
-  double* win = s_win[wave];
-  double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0;
-  int any = 0;
-  for (int y = y0; y < y1; y++) {
-    const uint32_t v = live ? sp[(int64_t)y * 64] : 0u;
-    const int xr1 = (int)(v >> 16), xl = (int)(v & 0xffffu);
-    const bool valid = xr1 != 0;
-    any |= xr1;
-    const int lmax = wave_max_i32(valid ? xl : -1);
-    if (lmax < 0) continue;                        // empty row for the whole wave
-    const int lmin = wave_min_i32(valid ? xl : 0x7fffffff);
-    const int hmin = wave_min_i32(valid ? xr1 : 0x7fffffff), hmax = wave_max_i32(valid ? xr1 : -1);
-    const int nl = lmax - lmin + 1, nh = hmax - hmin + 1;
-    const double* row = P + (int64_t)y * (dm.We + 1) * 4;
-    if (nl + nh <= RW_CAP) {
-      for (int c = lane; c < 2 * (nl + nh); c += 64) {           // 16-byte pieces, consecutive lanes = consecutive bytes
-        const int e = c >> 1, half = c & 1;
-        const int col = e < nl ? lmin + e : hmin + (e - nl);
-        const double2 d = *reinterpret_cast<const double2*>(row + (int64_t)col * 4 + half * 2);
-        *reinterpret_cast<double2*>(win + e * 4 + half * 2) = d;
-      }
-      wave_lds_sync();
-      if (valid) {
-        const double* lo = win + (xl - lmin) * 4;
-        const double* hi = win + (nl + xr1 - hmin) * 4;
-        S0 += hi[0] - lo[0];
-        S1 += hi[1] - lo[1];
-        S2 += hi[2] - lo[2];
-        S3 += hi[3] - lo[3];
-      }
-      wave_lds_sync();
-    } else if (valid) {
-      const double* hi = row + (int64_t)xr1 * 4;
-      const double* lo = row + (int64_t)xl * 4;
-      S0 += hi[0] - lo[0];
-      S1 += hi[1] - lo[1];
-      S2 += hi[2] - lo[2];
-      S3 += hi[3] - lo[3];
+  if (lane == 0) {                                       // band 0 carries everything, the other bands are zero
+    for (int b = 0; b < COL_PARTS; b++) {
+      double* o = sc.colpart + ((int64_t)(f * COL_PARTS + b) * 5) * max_drops + i;
+      for (int k = 0; k < 4; k++) o[(int64_t)max_drops * k] = b == 0 ? S[k] : 0.0;
+      o[(int64_t)max_drops * 4] = b == 0 ? (double)any : 0.0;
     }
-  }
-  if (live) {
-    double* o = sc.colpart + (gi * COL_PARTS + band) * 5;
-    o[0] = S0; o[1] = S1; o[2] = S2; o[3] = S3;
-    o[4] = any ? 1.0 : 0.0;
   }
 }
 
 // Colour, pass 2: one thread per drop adds the band partials in band order and writes the
 // compositor record.
-__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int nparts) {
+__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
   const int f = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const FrameDesc& fr = frames[f];
@@ -724,14 +812,17 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   if (n > 0) {
     double S[4] = {0, 0, 0, 0};
     bool any = false;
-    const double* part = sc.colpart + gi * COL_PARTS * 5;
-    for (int b = 0; b < nparts; b++) {
-      for (int k = 0; k < 4; k++) S[k] += part[b * 5 + k];
-      any = any || part[b * 5 + 4] != 0.0;
+    double sumW = 0.0, sumY = 0.0;                       // whole-map sums (bad_weather.py:403-404), band order
+    for (int b = 0; b < COL_PARTS; b++) {
+      const double* part = sc.colpart + ((int64_t)(f * COL_PARTS + b) * 5) * max_drops + i;
+      for (int k = 0; k < 4; k++) S[k] += part[(int64_t)max_drops * k];
+      any = any || part[(int64_t)max_drops * 4] != 0.0;
+      sumW += sc.fband[(f * COL_PARTS + b) * 2 + 0];
+      sumY += sc.fband[(f * COL_PARTS + b) * 2 + 1];
     }
     if (!any) status = RR_DROP_EMPTY_FOV;
     if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
-      colour_from_sums(S, sc.fconst[f * 2 + 0], sc.fconst[f * 2 + 1], rec.K);
+      colour_from_sums(S, sumW, sumY / sumW, rec.K);
       if (p.r1 > 0) {                  // finished effective tile written by the blur kernels
         const int fx0 = p.vis_x0 - p.crop_x + (p.shift - p.r2), fy0 = p.vis_y0 - p.crop_y + (p.shift - p.r1);   // its frame position
         rec.x0 = imax(p.vis_x0, fx0);
@@ -761,32 +852,13 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   }
   sc.comp[gi] = rec;
   sc.bbox[gi] = make_int4(rec.x0, rec.y0, rec.x1, rec.y1);
-  if (fr.status) fr.status[i] = status;
+  if (fr.status) as_global(fr.status)[i] = status;
 }
 
 // ---------------------------------------------------------------------------
 // tile synthesis
 // ---------------------------------------------------------------------------
-// Simple variant (one thread per output pixel, texels from global memory).  Kept as the
-// readable definition of the tile and as an A/B reference (RAINHIP_SIMPLE_TILE=1).
-__global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, int max_drops, const uint8_t* texels,
-                                                     const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                                     const float* ctab, Scratch sc) {
-  const int f = blockIdx.y, i = blockIdx.x;
-  if (i >= frames[f].n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  const DropPlan& p = sc.plan[gi];
-  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || sc.canon[gi] != (int)gi) return;
-  TexGlobal tx{texels + tex_off[p.tex], tex_h[p.tex], tex_w[p.tex]};
-  double* A0 = sc.arena + p.a0_off;
-  const int n = p.tw * p.th;
-  for (int idx = threadIdx.x; idx < n; idx += 256) {
-    int y = idx / p.tw, x = idx - y * p.tw;
-    A0[idx] = raw_tile_pixel(p, tx, ctab, x, y);
-  }
-}
-
-// Production variant: one 256-thread block per drop.
+// One 256-thread block per drop.
 //   * the texture (u8, with a 2-texel zero border) and the 256-entry v/255.0 table live in LDS;
 //   * cv2.resize(INTER_AREA) of the rotated canvas -- ~nW*nH bilinear samples for a handful of
 //     output pixels -- is evaluated in three LDS-staged steps per chunk of canvas rows:
@@ -796,7 +868,7 @@ __global__ __launch_bounds__(256) void k_tile_simple(const FrameDesc* frames, in
 //           with the resizeArea_ weights -> s_buf;
 //       2   one lane per output pixel folds s_buf top to bottom.
 //     Every fold runs in the order resizeArea_ uses, so the tile is bit-identical to
-//     k_tile_simple / the oracle.
+//     raw_tile_pixel (rr_device.h, the one-thread-per-pixel definition) / the oracle.
 constexpr int TEX_LDS = 11776;      // padded texels: (h+4)*(w+4) <= TEX_LDS
 constexpr int NW_MAX = 384;
 constexpr int TW_MAX = 64;
@@ -944,7 +1016,7 @@ constexpr int GEN_SLICES = 16;
 // Big drops (bicubic warp) and the rare resize modes: one thread per output pixel, texels in LDS.
 __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                                       const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                                      const float* ctab, Scratch sc, int dbg) {
+                                                      const float* ctab, Scratch sc) {
   const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
@@ -972,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   if (area_fast)
     for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   __syncthreads();
-  const int n = ((dbg & 4096) && area_fast) || ((dbg & 8192) && p.kind == KIND_BIG) ? 0 : p.tw * p.th;
+  const int n = p.tw * p.th;
   if (area_fast) {
     const int area = p.isx * p.isy, n4 = area & ~3;
     const float scale = 1.0f / (float)area;
@@ -1057,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                              Scratch sc, int dbg) {
+                                              Scratch sc) {
   const int f = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   __shared__ DropPlan sp;
   __shared__ double s_lut[256];
@@ -1082,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
-  if (!(dbg & 8)) load_tex_padded(s_tex, gtex, sh, sw);
+  load_tex_padded(s_tex, gtex, sh, sw);
   double* A0 = sc.arena + p.a0_off;
   const int tw = p.tw, th = p.th;
   const double sy_scale = p.scale_y;
@@ -1178,7 +1250,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     // ---- canvas rows lo..hi: each wave takes groups of Rw rows, no block barrier needed ----
     for (int r0 = lo + wave * Rw; r0 <= hi; r0 += 4 * Rw) {
       const int nr = imin(Rw, hi - r0 + 1);
-      if (lane < nr && !((dbg & 16) && r0 > lo)) {
+      if (lane < nr) {
         const int c = r0 + lane;
         const int ry = p.flip ? (p.nH - 1 - c) : c;
         const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
@@ -1189,7 +1261,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       wave_lds_sync();
       // ---- 1a: bilinear samples of the rotated texture, lanes flattened over (row, column) ----
       const int nidx = nr * pitch;
-      for (int idx = lane; idx < ((dbg & 1) ? 0 : nidx); idx += 128) {
+      for (int idx = lane; idx < nidx; idx += 128) {
         const int ia = idx, ib = imin(idx + 64, nidx - 1);
         const int ra = (int)(((float)ia + 0.5f) * inv_pitch), xa = ia - ra * pitch;
         const int rb = (int)(((float)ib + 0.5f) * inv_pitch), xb = ib - rb * pitch;
@@ -1204,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       wave_lds_sync();
       // ---- 1b: horizontal folds, one lane per (row, destination column) ----
       const int items = nr * twc;
-      for (int it = lane; it < ((dbg & 2) ? 0 : items); it += 64) {
+      for (int it = lane; it < items; it += 64) {
         const int r = (int)(((float)it + 0.5f) * inv_twc), dxl = it - r * twc, dx = dxa + dxl;
         const AreaSpan ax = s_ax[dx];
         const int4 rw = rowp[r];
@@ -1234,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     }
     __syncthreads();
     // ---- 2: vertical folds ----
-    const int npx = (dbg & 4) ? 0 : (dy1 - dy0) * twc;
+    const int npx = (dy1 - dy0) * twc;
     for (int it = t; it < npx; it += 256) {
       const int r = it / twc, dxl = it - r * twc, dx = dxa + dxl;
       const int dy = dy0 + r;
@@ -1367,12 +1439,6 @@ __device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
   __syncthreads();
 }
 
-__device__ inline double readlane_f64(double v, int l) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
 
 // Normalised Gaussian half tables of every blurred drop, one thread per (drop, axis): hw[k] = w(|k - r|),
 // k = 0..r, with the oracle's left-to-right normalisation sum.  The blur kernels used to build them per
@@ -1433,7 +1499,7 @@ __device__ inline void blur4(const double* c0, int st, const double* hw, int r, 
 // ---------------------------------------------------------------------------
 // fused defocus blur: both axes of the separable filter through LDS
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int max_drops, Scratch sc, int dbg) {
+__global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int max_drops, Scratch sc) {
   const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double hw1[BR_MAX + 1], hw2[BR_MAX + 1];
   __shared__ double X[BX_MAX], Y[BY_MAX];
@@ -1448,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;            // the tile being produced is the EFFECTIVE tile
   // the weight tables depend on the drop only; they are computed by waves 0 and 1 while the first
   // batch of tile loads is in flight (every item ends with a barrier, so the old tables are free)
-  bool need_tables = cur != item.x && !(dbg & 256);
+  bool need_tables = cur != item.x;
   const double* src = sc.arena + p.a0_off;          // raw tile (tw x th); the pad is implicit zeros
   double* dst = sc.arena + p.a1_off;                // finished effective tile (ew x eh); raw sits at (r2, r1) inside it
   const int tw = p.tw, th = p.th;
@@ -1470,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       const int wd = imax(xb - xa, 1);
       const float inv_wd = 1.0f / (float)wd;
       // data columns of the haloed tile -> LDS; eight independent global loads in flight per thread
-      const int nx = (dbg & 512) ? 0 : wd * hi;
+      const int nx = wd * hi;
       for (int base = t; base < nx || need_tables; base += 2048) {
         double v[8];
 #pragma unroll
@@ -1505,7 +1571,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       // step needs two new LDS values instead of eight (register rotation).  Lanes run along x.
       {
         const int nrb = hop >> 2;
-        const int nv = (dbg & 1024) ? 0 : nrb * wd;
+        const int nv = nrb * wd;
         for (int idx = t; idx < nv; idx += 256) {
           const int rb = (int)(((float)idx + 0.5f) * inv_wd), xc = idx - rb * wd;
           const double* c0 = X + (4 * rb + r1) * wd + xc;                     // centre of the first of the four rows
@@ -1524,7 +1590,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       // down the rows (odd pitch -> distinct banks).
       {
         const int ncb = (wo + 3) >> 2;
-        const int nh = (dbg & 2048) ? 0 : ncb * ho;
+        const int nh = ncb * ho;
         const float inv_ho = 1.0f / (float)ho;
         for (int idx = t; idx < nh; idx += 256) {
           const int cb = (int)(((float)idx + 0.5f) * inv_ho), yy = idx - cb * ho;
@@ -1730,7 +1796,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   const int64_t pix = (int64_t)py * dm.W + px;
   double c[3] = {0, 0, 0}, m = 0.0;
   if (live) {
-    const double* s = fr.rainy_bg + pix * 3;
+    const global_ptr<const double> s = as_global(fr.rainy_bg) + pix * 3;
     c[0] = s[0];
     c[1] = s[1];
     c[2] = s[2];
@@ -1786,13 +1852,13 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   }
   double sum_c = 0.0, sum_b = 0.0;
   if (live) {
-    double* o = fr.comp_out + pix * 3;
+    const global_ptr<double> o = as_global(fr.comp_out) + pix * 3;
     o[0] = c[0];
     o[1] = c[1];
     o[2] = c[2];
-    fr.mask_f64[pix] = m;
-    if (fr.mask_i32) fr.mask_i32[pix] = (int32_t)floor(m * 255.0);
-    const double* b = fr.bg + pix * 3;
+    as_global(fr.mask_f64)[pix] = m;
+    if (fr.mask_i32) as_global(fr.mask_i32)[pix] = (int32_t)floor(m * 255.0);
+    const global_ptr<const double> b = as_global(fr.bg) + pix * 3;
     sum_c = (c[0] + c[1]) + c[2];
     sum_b = (b[0] + b[1]) + b[2];
   }
@@ -1847,8 +1913,8 @@ __global__ __launch_bounds__(256) void k_finalize(const FrameDesc* frames, Dims 
   if (pix >= (int64_t)dm.H * dm.W) return;
   const FrameDesc& fr = frames[f];
   const double diff = sc.means[f * 2 + 0] - sc.means[f * 2 + 1];
-  const double* s = fr.comp_out + pix * 3;
-  uint8_t* o = fr.rgb + pix * 3;
+  const global_ptr<const double> s = as_global((const double*)fr.comp_out) + pix * 3;
+  const global_ptr<uint8_t> o = as_global(fr.rgb) + pix * 3;
   for (int k = 0; k < 3; k++) {
     double v = clip01(s[2 - k] - diff);      // BGR -> RGB
     o[k] = (uint8_t)(int)(v * 255.0);
@@ -1868,9 +1934,6 @@ struct ProfEntry {
 struct rr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t s_col = nullptr, s_gen = nullptr;     // side streams: colour chain, generic tiles
-  hipEvent_t ev_start = nullptr, ev_scan = nullptr, ev_col = nullptr, ev_gen = nullptr;
-  bool serial = true;               // RAINHIP_CONCURRENT=1 moves the colour chain / Big-drop tiles to side streams
   std::string err;
   // streak DB
   uint8_t* d_tex = nullptr;
@@ -1916,10 +1979,12 @@ struct rr_ctx {
   int pre_frames = 0, pre_H = 0, pre_W = 0, pre_We = 0;
   // profiling
   bool prof = false;
-  int tile_dbg = 0;                 // RAINHIP_TILE_DBG: timing experiments only (skips stages of k_tile)
-  bool rows_lds = false;             // RAINHIP_ROWS_LDS=1: LDS-staged look-up windows in the colour row kernel (A/B)
-  bool dedup = true;                 // RAINHIP_NO_DEDUP=1 renders every drop's raw tile (A/B check of k_dedup)
-  bool simple_tile = false;          // RAINHIP_SIMPLE_TILE=1: one-thread-per-pixel tile kernel (A/B reference)
+  // options (rr_set_option): none of them changes a result bit
+  bool dedup = true;                 // RR_OPT_DEDUP: share bit-identical raw tiles inside a batch (k_dedup)
+  int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
+  bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
+  int scratch_hp = 0;                // span pitch the scratch was sized for
+  bool scratch_general = false;      // prefix table / polygons of the general colour path allocated
   std::vector<ProfEntry> prof_pending;
   std::vector<rr_kernel_stat> prof_stats;
   std::vector<hipEvent_t> ev_pool;
@@ -2006,19 +2071,27 @@ void prof_collect(rr_ctx* ctx) {
   ctx->prof_pending.clear();
 }
 
+// the fast colour path needs the span state of a drop in registers and a map row in LDS, and its exact span
+// arithmetic needs |2*dx*dy| < 2^23 (k_fov_spans)
+bool fov_fast_path(const rr_ctx* ctx, const Dims& dm) {
+  return !ctx->general_fov && dm.He <= HE_MAX && dm.We <= FOV_WE_MAX && (int64_t)dm.We * dm.He < (1 << 22) && ctx->cam.n_fov * 1 <= 64 &&
+         ctx->cam.n_fov >= 3;
+}
+
 int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_comp_out) {
   const bool grow_frames = n > ctx->cap_frames;
   const bool grow_drops = max_drops > ctx->cap_drops;
   const bool dims_change = dm.H != ctx->cap_dims.H || dm.W != ctx->cap_dims.W || dm.He != ctx->cap_dims.He || dm.We != ctx->cap_dims.We;
-  if (grow_frames || grow_drops || dims_change || (need_comp_out && !ctx->d_comp_out)) {
+  const bool general = !fov_fast_path(ctx, dm);
+  if (grow_frames || grow_drops || dims_change || (need_comp_out && !ctx->d_comp_out) || general != ctx->scratch_general) {
     HIPCHK(hipDeviceSynchronize());
     const int F = grow_frames ? n : ctx->cap_frames;
     const int D = grow_drops ? max_drops : ctx->cap_drops;
     const size_t fd = (size_t)F * (size_t)(D > 0 ? D : 1);
+    const int Hp = (dm.He + 3) & ~3;
     int rc;
     if ((rc = dev_alloc(ctx, ctx->sc.plan, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.comp, fd))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.poly, fd * 2 * POLY_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.npts, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.sizes, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_rot, fd))) return rc;
@@ -2028,7 +2101,19 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.list_small, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.colpart, fd * COL_PARTS * 5))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.wtab, fd * 2 * (BR_MAX + 1)))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.spans, (size_t)F * (size_t)((D + 63) / 64 + 1) * 64 * (size_t)dm.He))) return rc;
+    if (general) {                     // polygons and the prefix table only exist on the general colour path
+      if ((rc = dev_alloc(ctx, ctx->sc.poly, fd * 2 * POLY_STRIDE))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->sc.spans, 1))) return rc;
+    } else {
+      if ((rc = dev_alloc(ctx, ctx->sc.poly, 1))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->sc.prefix, 1))) return rc;
+      const size_t per_frame = (size_t)((D > 0 ? D : 1) + 1) * (size_t)Hp;
+      if ((rc = dev_alloc(ctx, ctx->sc.spans, (size_t)F * per_frame))) return rc;
+      HIPCHK(hipMemset(ctx->sc.spans, 0, sizeof(uint32_t) * (size_t)F * per_frame));      // incl. every frame's zero row
+    }
+    ctx->scratch_general = general;
+    ctx->scratch_hp = Hp;
     if ((rc = dev_alloc(ctx, ctx->sc.bbox, fd))) return rc;
     {
       const size_t nct = (size_t)((dm.W + CTILE - 1) / CTILE) * ((dm.H + CTILE - 1) / CTILE);
@@ -2037,13 +2122,10 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     }
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.canon, fd))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.list_col, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_big, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.big_off, fd + F))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.col_off, (size_t)F * 16))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.htab, fd * 2))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.fconst, (size_t)F * 2))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.fband, (size_t)F * COL_PARTS * 2))) return rc;
     const int ntiles = ((dm.W + TILE - 1) / TILE) * ((dm.H + TILE - 1) / TILE);
     if ((rc = dev_alloc(ctx, ctx->sc.partial, (size_t)F * ntiles * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.means, (size_t)F * 2))) return rc;
@@ -2131,24 +2213,25 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
   const int ntiles = tiles_x * tiles_y;
   Scratch sc = ctx->sc;
-  // Three in-order streams: `s` (caller's) carries plan -> scan -> tile -> blur -> composite;
-  // the colour chain (env prefix sums, FOV integration) and the generic tile kernel only meet
-  // it again at the blur / compositor, so they run beside it on side streams.
-  hipStream_t sc_col = ctx->serial ? s : ctx->s_col, sc_gen = ctx->serial ? s : ctx->s_gen;
-  if (!ctx->serial) {
-    HIPCHK(hipEventRecord(ctx->ev_start, s));
-    HIPCHK(hipStreamWaitEvent(sc_col, ctx->ev_start, 0));
-    HIPCHK(hipStreamWaitEvent(sc_gen, ctx->ev_start, 0));
-  }
-  {
-    ProfScope ps(ctx, sc_col, "k_env_prefix");
-    hipLaunchKernelGGL(k_env_prefix, dim3((dm.He + 3) / 4, n), dim3(256), 0, sc_col, ctx->d_frames, dm, sc.prefix);
-  }
-  {
-    ProfScope ps(ctx, sc_col, "k_env_consts");
-    hipLaunchKernelGGL(k_env_consts, dim3(n), dim3(256), 0, sc_col, dm, sc.prefix, sc.fconst);
-  }
+  // One in-order stream: FOV spans -> plan -> scan -> dedup -> lists -> FOV sums -> colour -> tiles -> blur ->
+  // composite -> finalise.
   if (max_drops > 0) {
+    const bool fast = fov_fast_path(ctx, dm);
+    const int Hp = ctx->scratch_hp;
+    if (fast) {
+      ProfScope ps(ctx, s, "k_fov_spans");
+      const int G = imin(64 / ctx->cam.n_fov, FOV_GROUPS);
+      const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
+      if (dm.He <= 384)
+        hipLaunchKernelGGL(k_fov_spans<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, sc);
+      else if (dm.He <= 512)
+        hipLaunchKernelGGL(k_fov_spans<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, sc);
+      else
+        hipLaunchKernelGGL(k_fov_spans<16>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, sc);
+    } else {
+      ProfScope ps(ctx, s, "k_fov_poly");
+      hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, dm, ctx->cam, D, sc);
+    }
     {
       ProfScope ps(ctx, s, "k_plan");
       hipLaunchKernelGGL(k_plan, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, dm, ctx->cam, ctx->d_tex_h,
@@ -2168,65 +2251,63 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_lists");
       hipLaunchKernelGGL(k_lists, dim3(n), dim3(1024), 0, s, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
     }
-    if (!ctx->serial) {
-      HIPCHK(hipEventRecord(ctx->ev_scan, s));
-      HIPCHK(hipStreamWaitEvent(sc_col, ctx->ev_scan, 0));
-      HIPCHK(hipStreamWaitEvent(sc_gen, ctx->ev_scan, 0));
-    }
-    {
-      const int col_blocks = (((max_drops + 3) / 4 + COL_REGIONS - 1) / COL_REGIONS) * COL_REGIONS;
-      // banded path: spans to global memory, look-ups one row band per XCD; maps too tall for the LDS span
-      // tables or too wide for 16-bit columns keep the single-kernel path
-      const bool banded = dm.He <= HE_MAX && dm.We < 32767;
-      const int ntile = (D + 63) / 64 + 1;
-      {
-        ProfScope ps(ctx, sc_col, banded ? "k_colour_spans" : "k_colour_bands");
-        hipLaunchKernelGGL(k_col_order, dim3(n), dim3(1024), 0, sc_col, ctx->d_frames, dm, D, sc);
-        if (dm.He <= 512)
-          hipLaunchKernelGGL(k_colour_bands<512>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg,
-                             banded ? 1 : 0, ntile);
-        else
-          hipLaunchKernelGGL(k_colour_bands<HE_MAX>, dim3(col_blocks, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, ctx->tile_dbg,
-                             banded ? 1 : 0, ntile);
+    if (fast) {
+      ProfScope ps(ctx, s, "k_fov_sums");
+      // a chunk of NT*DPT drops re-scans the band's rows, so DPT grows with the drop count (register budget: 8
+      // doubles of running sums per drop)
+      const size_t row_bytes = ((size_t)(dm.We + 1) * 4 + 16 * 4) * sizeof(double);      // P01 + P23 + wave totals
+      // a wave owns ceil(We / waves) columns, in passes of 64
+      auto passes = [&](int nt) { return ((dm.We + nt / 64 - 1) / (nt / 64) + 63) / 64; };
+      int NT = ctx->fov_threads ? ctx->fov_threads : 1024;
+      if (passes(NT) > FOV_EMAX) NT = 1024;
+      const bool e2 = passes(NT) <= 2;                   // <= 2 passes: 16 fewer registers, 4 drops per thread fit
+      const int DPT = ctx->fov_dpt ? ctx->fov_dpt : (max_drops <= NT ? 1 : (max_drops <= 2 * NT || !e2 ? 2 : 4));
+      const int rpb = ((dm.He + COL_PARTS - 1) / COL_PARTS + 3) & ~3;
+      const int nchunk = (max_drops + NT * DPT - 1) / (NT * DPT);
+      const dim3 grid(COL_PARTS * nchunk, n);
+      auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(NT), row_bytes, s, ctx->d_frames, dm, D, Hp, rpb, sc);
+        return hipSuccess;
+      };
+      hipError_t e = e2 ? (DPT == 1 ? launch(k_fov_sums<1, 2>) : DPT == 2 ? launch(k_fov_sums<2, 2>) : launch(k_fov_sums<4, 2>))
+                        : (DPT == 1 ? launch(k_fov_sums<1, 4>) : DPT == 2 ? launch(k_fov_sums<2, 4>) : launch(k_fov_sums<4, 4>));
+      if (e != hipSuccess) {
+        ctx->err = std::string("k_fov_sums: ") + hipGetErrorString(e);
+        return RR_E_HIP;
       }
-      if (banded) {
-        ProfScope ps(ctx, sc_col, "k_colour_rows");
-        if (ctx->rows_lds)
-          hipLaunchKernelGGL(k_colour_rows_lds, dim3(((max_drops + 255) / 256) * COL_PARTS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, ntile, sc);
-        else
-          hipLaunchKernelGGL(k_colour_rows, dim3(((max_drops + 255) / 256) * COL_PARTS, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, ntile, sc);
-      }
-      {
-        ProfScope ps(ctx, sc_col, "k_colour");
-        hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, sc_col, ctx->d_frames, dm, D, sc, banded ? COL_PARTS : 1);
-      }
-    }
-    if (ctx->simple_tile) {
-      ProfScope ps(ctx, s, "k_tile");
-      hipLaunchKernelGGL(k_tile_simple, dim3(max_drops, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h,
-                         ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
     } else {
       {
-        ProfScope ps(ctx, sc_gen, "k_tile_generic");
-        hipLaunchKernelGGL(k_tile_generic, dim3(imin((max_drops + 3) / 4, 64), n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex,
-                           ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc, ctx->tile_dbg);
+        ProfScope ps(ctx, s, "k_env_prefix");
+        hipLaunchKernelGGL(k_env_prefix, dim3((dm.He + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, sc.prefix);
+        hipLaunchKernelGGL(k_env_consts, dim3(n), dim3(256), 0, s, dm, sc.prefix, sc.fband);
       }
       {
-        ProfScope ps(ctx, sc_gen, "k_tile_big");
-        hipLaunchKernelGGL(k_tile_big, dim3(1024, n), dim3(256), 0, sc_gen, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
-                           ctx->d_tex_off, ctx->d_ctab, sc);
-      }
-      {
-        ProfScope ps(ctx, s, "k_tile");
-        // after de-duplication a frame keeps a fraction of its tiles: a capped grid (items are taken
-        // grid-stride) avoids dispatching tens of thousands of empty workgroups
-        hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, 1536), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
-                           ctx->d_tex_off, sc, ctx->tile_dbg);
+        ProfScope ps(ctx, s, "k_fov_sums_general");
+        hipLaunchKernelGGL(k_fov_sums_general, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
       }
     }
-    if (!ctx->serial) {
-      HIPCHK(hipEventRecord(ctx->ev_gen, sc_gen));
-      HIPCHK(hipStreamWaitEvent(s, ctx->ev_gen, 0));
+    {
+      ProfScope ps(ctx, s, "k_colour");
+      hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_tile_generic");
+      hipLaunchKernelGGL(k_tile_generic, dim3(imin((max_drops + 3) / 4, 64), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex,
+                         ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_tile_big");
+      hipLaunchKernelGGL(k_tile_big, dim3(1024, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+                         ctx->d_tex_off, ctx->d_ctab, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_tile");
+      // after de-duplication a frame keeps a fraction of its tiles: a capped grid (items are taken
+      // grid-stride) avoids dispatching tens of thousands of empty workgroups
+      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, 1536), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+                         ctx->d_tex_off, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_weights");
@@ -2238,7 +2319,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_fused");
-      hipLaunchKernelGGL(k_blur_fused, dim3((max_drops + 1) / 2, n), dim3(256), 0, s, ctx->d_frames, D, sc, ctx->tile_dbg);
+      hipLaunchKernelGGL(k_blur_fused, dim3((max_drops + 1) / 2, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
@@ -2248,10 +2329,6 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_blur_cols");
       hipLaunchKernelGGL(k_blur<1>, dim3(64, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
-  }
-  if (!ctx->serial) {
-    HIPCHK(hipEventRecord(ctx->ev_col, sc_col));
-    HIPCHK(hipStreamWaitEvent(s, ctx->ev_col, 0));
   }
   const int ctiles_x = (dm.W + CTILE - 1) / CTILE, nct = ctiles_x * ((dm.H + CTILE - 1) / CTILE);
   {
@@ -2421,33 +2498,7 @@ int rr_create(rr_ctx** out, int device) {
   if (strncmp(prop.gcnArchName, "gfx9", 4) != 0) return RR_E_NO_DEVICE;
   rr_ctx* ctx = new rr_ctx();
   ctx->device = device;
-  {
-    const char* e = getenv("RAINHIP_SIMPLE_TILE");
-    ctx->simple_tile = e && e[0] == '1';
-    const char* rl = getenv("RAINHIP_ROWS_LDS");
-    ctx->rows_lds = rl && rl[0] == '1';
-    const char* nd = getenv("RAINHIP_NO_DEDUP");
-    ctx->dedup = !(nd && nd[0] == '1');
-    const char* d = getenv("RAINHIP_TILE_DBG");
-    ctx->tile_dbg = d ? atoi(d) : 0;
-  }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete ctx;
-    return RR_E_HIP;
-  }
-  {
-    // RAINHIP_CONCURRENT=1: the colour chain and the Big-drop tiles run beside the rotate/resize tiles on
-    // side streams (+3.5 % frames/s at 64 frames per batch).  Off by default: with every kernel on the
-    // caller's stream the per-kernel timings (rr_profile_*, rocprofv3) are not inflated by overlap
-    const char* e = getenv("RAINHIP_CONCURRENT");
-    ctx->serial = !(e && e[0] == '1');
-  }
-  if (hipStreamCreateWithFlags(&ctx->s_col, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->s_gen, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_scan, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_col, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return RR_E_HIP;
   }
@@ -2482,10 +2533,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
   hipFree(ctx->sc.canon);
-  hipFree(ctx->sc.list_col);
   hipFree(ctx->sc.list_big);
   hipFree(ctx->sc.big_off);
-  hipFree(ctx->sc.col_off);
   hipFree(ctx->sc.htab);
   hipFree(ctx->sc.list_small);
   hipFree(ctx->sc.colpart);
@@ -2495,7 +2544,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.clist);
   hipFree(ctx->sc.ccount);
   hipFree(ctx->sc.prefix);
-  hipFree(ctx->sc.fconst);
+  hipFree(ctx->sc.fband);
   hipFree(ctx->sc.arena);
   hipFree(ctx->sc.partial);
   hipFree(ctx->sc.means);
@@ -2532,12 +2581,6 @@ int rr_destroy(rr_ctx* ctx) {
     hipEventDestroy(pe.b);
   }
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
-  if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_scan) hipEventDestroy(ctx->ev_scan);
-  if (ctx->ev_col) hipEventDestroy(ctx->ev_col);
-  if (ctx->ev_gen) hipEventDestroy(ctx->ev_gen);
-  if (ctx->s_col) hipStreamDestroy(ctx->s_col);
-  if (ctx->s_gen) hipStreamDestroy(ctx->s_gen);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return RR_OK;
@@ -2889,6 +2932,25 @@ int rr_envmap_width(rr_ctx* ctx) {
     return RR_E_STATE;
   }
   return ctx->eg.We;
+}
+
+int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
+  if (!ctx) return RR_E_ARG;
+  switch (option) {
+    case RR_OPT_DEDUP: ctx->dedup = value != 0; return RR_OK;
+    case RR_OPT_GENERAL_FOV: ctx->general_fov = value != 0; return RR_OK;
+    case RR_OPT_FOV_THREADS:
+      if (value != 0 && value != 512 && value != 1024) break;
+      ctx->fov_threads = value;
+      return RR_OK;
+    case RR_OPT_FOV_DROPS_PER_THREAD:
+      if (value != 0 && value != 1 && value != 2 && value != 4) break;
+      ctx->fov_dpt = value;
+      return RR_OK;
+    default: break;
+  }
+  ctx->err = "rr_set_option: unknown option or value";
+  return RR_E_ARG;
 }
 
 int rr_batch_counts(rr_ctx* ctx, int32_t frame, int32_t out[8]) {

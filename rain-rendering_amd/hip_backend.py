@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'librainhip.so')
 
 RR_MAX_FOV = 32
 RR_E_ARENA = -5
+RR_OPT_DEDUP, RR_OPT_GENERAL_FOV, RR_OPT_FOV_THREADS, RR_OPT_FOV_DROPS_PER_THREAD = 1, 2, 3, 4
 
 # numpy mirror of rr_drop (112 bytes)
 DROP_DTYPE = np.dtype([
@@ -76,7 +77,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_profile_reset', 'rr_profile_read', 'rr_sizeof_drop', 'rr_sizeof_camera', 'rr_sizeof_frame_in',
            'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
-           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts']
+           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option']
 
 _lib = None
 
@@ -120,6 +121,7 @@ def load_library(path=None):
                                        ctypes.POINTER(rr_frame_in), ctypes.POINTER(rr_frame_out),
                                        ctypes.POINTER(rr_prepass_out)]
     lib.rr_batch_counts.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
+    lib.rr_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                        ctypes.c_void_p, ctypes.c_void_p]
     assert lib.rr_sizeof_prepass_in() == ctypes.sizeof(rr_prepass_in)
@@ -312,6 +314,10 @@ class RainHip:
         offs = np.ascontiguousarray(offs, np.int64)
         self._check(self.lib.rr_set_streak_db_device(self.h, ctypes.c_void_p(dev_ptr), int(n_bytes), _ptr(hs), _ptr(ws),
                                                      _ptr(offs), len(hs)), 'rr_set_streak_db_device')
+
+    def set_option(self, option, value):
+        """rr_set_option: tuning / A-B switches that never change a result bit (include/rainhip.h)."""
+        self._check(self.lib.rr_set_option(self.h, int(option), int(value)), 'rr_set_option')
 
     def set_camera(self, cam):
         self.cam = cam

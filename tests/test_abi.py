@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     for n in names:
         assert hasattr(lib, n), "librainhip.so does not export %s" % n
     assert sorted(h.hb.EXPORTS) == names
-    assert lib.rr_version() == 120
+    assert lib.rr_version() == 200
 
 
 def test_struct_layouts(built):
@@ -61,3 +61,11 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert 'hostemu' not in src or f in ('rr_device.h', 'rr_prepass.h'), f
+
+
+def test_library_reads_no_environment_switches():
+    """Debug / A-B switches live behind rr_set_option (never changing a result bit), not in environment variables:
+    a stray variable must not be able to produce a fast wrong answer."""
+    for f in ('rainhip.hip', 'rr_host.cpp', 'rr_device.h', 'rr_prepass.h'):
+        src = open(os.path.join(h.ROOT, 'rain-rendering_amd', 'csrc', f)).read()
+        assert 'getenv' not in src, f

@@ -73,9 +73,9 @@ def test_zero_opacity_and_mean_shift(setup):
     assert (exp != base['image_u8']).mean() < 1e-3
 
 
-def test_raw_tile_dedup_is_invisible(setup, monkeypatch):
+def test_raw_tile_dedup_is_invisible(setup):
     """k_dedup lets drops with bit-identical tile parameters share one raw tile (within a frame and across
-    the frames of a batch).  Same bits with the election switched off (RAINHIP_NO_DEDUP=1)."""
+    the frames of a batch).  Same bits with the election switched off (rr_set_option RR_OPT_DEDUP 0)."""
     sc, bg, env, drops, rh, base = setup
     fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
     two = rh.render_frames([fr, fr])                                       # second frame: every tile is a duplicate
@@ -83,8 +83,8 @@ def test_raw_tile_dedup_is_invisible(setup, monkeypatch):
     ok = int(np.count_nonzero(base['status'] == 0))
     assert c0[7] + c1[7] > ok                                              # > one frame's worth of duplicates
     assert (c0[0] + c0[1] + c0[5]) + (c1[0] + c1[1] + c1[5]) + (c0[7] + c1[7]) >= 2 * ok   # every composited drop has a tile
-    monkeypatch.setenv('RAINHIP_NO_DEDUP', '1')
     plain = h.hb.RainHip(0)
+    plain.set_option(h.hb.RR_OPT_DEDUP, 0)
     plain.set_streak_db(sc.db.streaks_light)
     plain.set_camera(sc.cam)
     ref = plain.render_frames([fr])[0]
@@ -93,3 +93,30 @@ def test_raw_tile_dedup_is_invisible(setup, monkeypatch):
     for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
         assert np.array_equal(ref[k], base[k]), k
         assert np.array_equal(two[0][k], base[k]) and np.array_equal(two[1][k], base[k]), k
+
+
+def test_colour_path_options_do_not_change_results(setup):
+    """The FOV-sum kernel's workgroup size / drops per thread and the general colour path (prefix table in HBM, what
+    maps beyond 1024 rows / 4096 columns take) are tuning switches: the mask must be identical, the image within
+    1 LSB (the colour sums are added in a different order), the statuses equal."""
+    sc, bg, env, drops, rh, base = setup
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    for opts in ({h.hb.RR_OPT_FOV_THREADS: 512, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 1},
+                 {h.hb.RR_OPT_FOV_THREADS: 512, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 4},
+                 {h.hb.RR_OPT_FOV_THREADS: 1024, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 2},
+                 {h.hb.RR_OPT_GENERAL_FOV: 1}):
+        alt = h.hb.RainHip(0)
+        try:
+            for k, v in opts.items():
+                alt.set_option(k, v)
+            alt.set_streak_db(sc.db.streaks_light)
+            alt.set_camera(sc.cam)
+            out = alt.render_frames([fr])[0]
+        finally:
+            alt.close()
+        assert np.array_equal(out['status'], base['status']), opts
+        assert np.array_equal(out['mask'], base['mask']) and np.array_equal(out['mask_i32'], base['mask_i32']), opts
+        assert np.abs(out['image_u8'].astype(int) - base['image_u8'].astype(int)).max() <= 1, opts
+        assert np.abs(out['rainy_bg'] - base['rainy_bg']).max() < 1e-9, opts
+    with pytest.raises(RuntimeError):
+        rh.set_option(99, 1)
