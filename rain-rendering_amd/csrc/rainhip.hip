@@ -94,8 +94,9 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* list_small;              // [frame][drops]  blurred drops handled one wave each (k_blur_small)
   double* colpart;                  // [frame][COL_PARTS][5][drops] FOV partial sums per envmap row band
   double* wtab;                     // [frame][drops][2][BR_MAX+1] normalised Gaussian half tables of the blurred drops (k_blur_weights)
-  uint32_t* spans;                  // [frame][drops + 1][Hp] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4;
-                                    // row `drops` of every frame stays all zeros: what a drop without a polygon reads
+  uint32_t* spans;                  // [frame][Hp / 4][Dp][4] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4,
+                                    // Dp = drops + 1 rounded up to 8; slot `drops` of every quad stays all zeros: what a drop
+                                    // without a polygon reads
   int4* bbox;                       // [frame][drops] footprint (x0,y0,x1,y1), empty when not composited
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
   int32_t* ccount;                  // [frame][coarse tiles]
@@ -414,9 +415,9 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
 //      xa + floor((2*dx*(y-ya) + den) / (2*den)) (fov_rowspan), evaluated with a float reciprocal and an exact
 //      integer fix-up (|2*dx*dy| < 2^23 is checked by the host), folded into the row's [min, max] with LDS
 //      ds_min / ds_max (order-free, no return value).  The spans leave as one u32 per row, xl | (xr + 1) << 16
-//      (0 = empty), rows of a drop contiguous: coalesced stores.
+//      (0 = empty), in the [row quad][drop] layout k_fov_sums reads coalesced.
 template <int NCH>
-__global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, Scratch sc) {
+__global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
   const int N = cam.n_fov, G = imin(64 / N, FOV_GROUPS);
@@ -482,8 +483,14 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   const int He = dm.He;
   int* xl = s_xl[wave];
   int* xr = s_xr[wave];
+  uint32_t packed[FOV_GROUPS][NCH];                            // the finished spans of the wave's drops, lane = row
 #pragma unroll
-  for (int c = 0; c < NCH; c++) { xl[c * 64 + lane] = 1 << 30; xr[c * 64 + lane] = -(1 << 30); }
+  for (int c = 0; c < NCH; c++) {
+    xl[c * 64 + lane] = 1 << 30;
+    xr[c * 64 + lane] = -(1 << 30);
+#pragma unroll
+    for (int k = 0; k < FOV_GROUPS; k++) packed[k][c] = 0;
+  }
   for (int gg = 0; gg < G; gg++) {
     const int mg = __builtin_amdgcn_readfirstlane(__shfl(m, gg * N));
     if (mg <= 0) continue;                                     // no polygon: k_fov_sums never reads this drop's spans
@@ -532,18 +539,33 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
       }
     }
     wave_lds_sync();
-    uint32_t* out = sc.spans + ((int64_t)f * (max_drops + 1) + i0 + gg) * Hp;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       const int y = c * 64 + lane;
       const int a = imax(xl[y], 0), b = imin(xr[y], dm.We - 1);
       xl[y] = 1 << 30;                                         // ready for the wave's next drop
       xr[y] = -(1 << 30);
-      if (y < Hp) {
-        uint32_t v = 0;
-        if (y < He && a <= b) v = (uint32_t)a | ((uint32_t)(b + 1) << 16);
-        out[y] = v;
-      }
+      uint32_t v = 0;
+      if (y < He && a <= b) v = (uint32_t)a | ((uint32_t)(b + 1) << 16);
+#pragma unroll
+      for (int k = 0; k < FOV_GROUPS; k++)
+        if (k == gg) packed[k][c] = v;
+    }
+  }
+  // spans[frame][row quad][drop slot][4 rows]: the wave's drops are neighbours, so the 16-byte pieces of a quad are
+  // contiguous (and the next waves' follow them); k_fov_sums reads one 16-byte piece per lane, lanes = consecutive drops
+  const int NQ = Hp >> 2;
+  bool have[FOV_GROUPS];                                       // (cross-lane reads stay outside the divergent stores)
+#pragma unroll
+  for (int k = 0; k < FOV_GROUPS; k++) have[k] = k < G && __builtin_amdgcn_readfirstlane(__shfl(m, k < G ? k * N : 0)) > 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int y = c * 64 + lane;
+    if (y < Hp) {
+      uint32_t* out = sc.spans + (((int64_t)f * NQ + (y >> 2)) * Dp + i0) * 4 + (y & 3);
+#pragma unroll
+      for (int k = 0; k < FOV_GROUPS; k++)
+        if (have[k]) out[k * 4] = packed[k][c];
     }
   }
 }
@@ -590,7 +612,7 @@ __device__ inline double readlane_f64(double v, int l) {
 // look-ups over all 64 banks.
 constexpr int FOV_EMAX = 4;
 template <int DPT, int EMAX>
-__global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int rpb, Scratch sc) {
+__global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int Dp, int rpb, int nchunk, Scratch sc) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   const int We = dm.We;
   double2* s_P01 = reinterpret_cast<double2*>(s_dyn);    // [We + 1] inclusive prefix of (x*w, y*w); entry 0 = zeros
@@ -601,18 +623,22 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const FrameDesc& fr = frames[f];
   const int n = fr.n_drops;
-  const int d0 = chunk * NT * DPT;
+  // the chunks of a frame take equal shares of its drops: workgroups that stream the same map rows then advance
+  // at the same pace, and the one behind finds the rows in its XCD's L2
+  const int per = (n + nchunk - 1) / nchunk;             // <= NT * DPT
+  const int d0 = chunk * per, d1 = imin(n, d0 + per);
   if (d0 >= n) return;
   const int y0 = band * rpb, y1 = imin(dm.He, y0 + rpb);
   const int Cw = (We + nw - 1) / nw;                     // columns per wave, taken in passes of 64 (<= EMAX passes)
   const int cw0 = wave * Cw;
-  // spans of frame f: [max_drops + 1][Hp]; row max_drops is all zeros (what a drop without a polygon reads)
-  const uint32_t* spf = sc.spans + (int64_t)f * (max_drops + 1) * Hp;
+  // spans of frame f: [Hp / 4][Dp] pieces of 16 bytes (4 rows); slot max_drops of every quad is all zeros (what a
+  // drop without a polygon reads)
+  const uint4* spf = reinterpret_cast<const uint4*>(sc.spans) + (int64_t)f * (Hp >> 2) * Dp;
   uint32_t sp[DPT];
 #pragma unroll
   for (int d = 0; d < DPT; d++) {
     const int i = d0 + d * NT + t;
-    sp[d] = (uint32_t)((i < n && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops) * (uint32_t)Hp;
+    sp[d] = (uint32_t)((i < d1 && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops);
   }
   if (t == 0) { s_P01[0] = make_double2(0.0, 0.0); s_P23[0] = make_double2(0.0, 0.0); }
   double S[DPT][4];
@@ -642,7 +668,7 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
   for (int yq = y0; yq < y1; yq += 4) {                  // y0 is a multiple of four: one 16-byte span load per drop and quad
     uint4 q[DPT];
 #pragma unroll
-    for (int d = 0; d < DPT; d++) q[d] = *reinterpret_cast<const uint4*>(spf + sp[d] + yq);
+    for (int d = 0; d < DPT; d++) q[d] = spf[(int64_t)(yq >> 2) * Dp + sp[d]];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int y = yq + j;
@@ -701,7 +727,7 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
 #pragma unroll
   for (int d = 0; d < DPT; d++) {
     const int i = d0 + d * NT + t;
-    if (i < n) {
+    if (i < d1) {
       double* o = sc.colpart + ((int64_t)(f * COL_PARTS + band) * 5) * max_drops + i;
       o[0] = S[d][0];
       o[(int64_t)max_drops] = S[d][1];
@@ -1786,7 +1812,12 @@ __global__ __launch_bounds__(256) void k_bin(const FrameDesc* frames, Dims dm, i
 __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
                                                    int tiles_y, int ctiles_x, int nct, Scratch sc) {
   const int f = blockIdx.y;
-  const int tile = blockIdx.x;
+  // Workgroups go to the 8 XCDs round robin (blockIdx.x % 8), each with its own L2.  XCD k takes the k-th eighth of
+  // the frame's screen tiles (row-major), so the workgroups that share an L2 cover one compact band of the image: a
+  // drop's alpha tile, split over neighbouring screen tiles, is fetched from HBM once, not once per screen tile.
+  const int ntiles = tiles_x * tiles_y, per_xcd = (ntiles + 7) / 8;
+  const int tile = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (tile >= ntiles) return;
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const FrameDesc& fr = frames[f];
@@ -1795,11 +1826,18 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   const bool live = px < dm.W && py < dm.H;
   const int64_t pix = (int64_t)py * dm.W + px;
   double c[3] = {0, 0, 0}, m = 0.0;
+  double sum_b = 0.0;                // this pixel's share of sum(bg) for the mean shift (generator.py:462)
   if (live) {
     const global_ptr<const double> s = as_global(fr.rainy_bg) + pix * 3;
     c[0] = s[0];
     c[1] = s[1];
     c[2] = s[2];
+    if (fr.bg == fr.rainy_bg) {      // no fog pre-pass: one read serves both
+      sum_b = (c[0] + c[1]) + c[2];
+    } else {
+      const global_ptr<const double> b = as_global(fr.bg) + pix * 3;
+      sum_b = (b[0] + b[1]) + b[2];
+    }
   }
   const CompRec* comp = sc.comp + (int64_t)f * max_drops;
   const int4* bbox = sc.bbox + (int64_t)f * max_drops;
@@ -1850,7 +1888,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     }
     __syncthreads();
   }
-  double sum_c = 0.0, sum_b = 0.0;
+  double sum_c = 0.0;
   if (live) {
     const global_ptr<double> o = as_global(fr.comp_out) + pix * 3;
     o[0] = c[0];
@@ -1858,9 +1896,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     o[2] = c[2];
     as_global(fr.mask_f64)[pix] = m;
     if (fr.mask_i32) as_global(fr.mask_i32)[pix] = (int32_t)floor(m * 255.0);
-    const global_ptr<const double> b = as_global(fr.bg) + pix * 3;
     sum_c = (c[0] + c[1]) + c[2];
-    sum_b = (b[0] + b[1]) + b[2];
   }
   __shared__ double ra[256], rb[256];
   ra[t] = sum_c;
@@ -2108,7 +2144,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     } else {
       if ((rc = dev_alloc(ctx, ctx->sc.poly, 1))) return rc;
       if ((rc = dev_alloc(ctx, ctx->sc.prefix, 1))) return rc;
-      const size_t per_frame = (size_t)((D > 0 ? D : 1) + 1) * (size_t)Hp;
+      const size_t per_frame = (size_t)(((D > 0 ? D : 1) + 1 + 7) & ~7) * (size_t)Hp;
       if ((rc = dev_alloc(ctx, ctx->sc.spans, (size_t)F * per_frame))) return rc;
       HIPCHK(hipMemset(ctx->sc.spans, 0, sizeof(uint32_t) * (size_t)F * per_frame));      // incl. every frame's zero row
     }
@@ -2217,17 +2253,17 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   // composite -> finalise.
   if (max_drops > 0) {
     const bool fast = fov_fast_path(ctx, dm);
-    const int Hp = ctx->scratch_hp;
+    const int Hp = ctx->scratch_hp, Dp = (D + 1 + 7) & ~7;
     if (fast) {
       ProfScope ps(ctx, s, "k_fov_spans");
       const int G = imin(64 / ctx->cam.n_fov, FOV_GROUPS);
       const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
       if (dm.He <= 384)
-        hipLaunchKernelGGL(k_fov_spans<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, sc);
+        hipLaunchKernelGGL(k_fov_spans<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
       else if (dm.He <= 512)
-        hipLaunchKernelGGL(k_fov_spans<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, sc);
+        hipLaunchKernelGGL(k_fov_spans<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
       else
-        hipLaunchKernelGGL(k_fov_spans<16>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, sc);
+        hipLaunchKernelGGL(k_fov_spans<16>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
     } else {
       ProfScope ps(ctx, s, "k_fov_poly");
       hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, dm, ctx->cam, D, sc);
@@ -2268,7 +2304,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(NT), row_bytes, s, ctx->d_frames, dm, D, Hp, rpb, sc);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), row_bytes, s, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
       hipError_t e = e2 ? (DPT == 1 ? launch(k_fov_sums<1, 2>) : DPT == 2 ? launch(k_fov_sums<2, 2>) : launch(k_fov_sums<4, 2>))
@@ -2337,7 +2373,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   {
     ProfScope ps(ctx, s, "k_composite");
-    hipLaunchKernelGGL(k_composite, dim3(ntiles, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
+    hipLaunchKernelGGL(k_composite, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
                        sc);
   }
   {
