@@ -1,21 +1,36 @@
-"""bench.py -- rainy frames/sec of the MI355X hot path on synthetic KITTI-shaped inputs.
+"""bench.py -- rainy frames/sec of the MI355X hot path on synthetic inputs shaped like BASELINE.json's configs.
 
   python bench.py --gpus N --steps K --warmup W            (N=1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (rr_render_frames_device: environment-map prefix
-sums, per-drop plan, colour, tile synthesis, defocus blur, ordered compositing, finalise)
-over one batch of --batch synthetic frames whose inputs are already resident in HBM.
-Workload = BASELINE.json configs[2]: 1242x375, "100 mm/hr" = 8192 streaks per frame
-(synthetic count).  Frames shard across ranks (weak scaling: every rank renders
-its own batch); the only collective on the data path is one RCCL broadcast of the packed
-streak database from rank 0 at start-up.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path (rr_render_frames_device: FOV spans + sums, per-drop plan, colour, tile synthesis,
+defocus blur, ordered compositing, finalise) over one batch of --batch synthetic frames whose inputs are already
+resident in HBM.  Workload (default) = BASELINE.json configs[2]: 1242x375, "100 mm/hr" = 8192 streaks per frame
+(synthetic count); --workload cityscapes50 = configs[3]: 2048x1024, 4096 streaks, 5 ms exposure.
+Frames shard across ranks; the only collective on the data path is one RCCL broadcast of the packed streak
+database from rank 0 at start-up.  Rank 0 prints ONE JSON line.
+
+  default            weak scaling: every rank renders its own --batch frames per step
+  --total-frames T   strong scaling: ONE T-frame sequence, frames idx[rank::world] per rank (sharding.shard), a step
+                     renders the rank's share in chunks of --batch; value = T * steps / time
+
+Extra keys (N=1 only, outside the timed region, never `value`): `host_inclusive` (pinned, three-stream
+rr_pipeline_submit/wait incl. PCIe both ways and the fog / environment-map pre-pass), `prepass`, `variants`
+(no tile sharing, angular noise, smaller library calls), `chain` (whole-step HBM fraction), `cpu_baseline` (+ its
+multi-process and C++ legs).  roofline.traffic is measured by two rocprofv3 --pmc passes of this very workload that
+bench.py spawns itself (skip with --no-traffic).
 """
 import argparse
+import contextlib
+import csv
 import ctypes
+import glob
 import importlib
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -27,10 +42,187 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
+WORKLOADS = {
+    # name: frame size, rate -> synthetic drop count, camera preset, render_scale, BASELINE.json config
+    'kitti100': dict(H=375, W=1242, rate=100, cam='KITTI', rs=1, cfg='configs[2]', metric="rainy frames/sec @ 1242x375, 100 mm/hr"),
+    'kitti25': dict(H=375, W=1242, rate=25, cam='KITTI', rs=1, cfg='configs[1]', metric="rainy frames/sec @ 1242x375, 25 mm/hr"),
+    'cityscapes50': dict(H=1024, W=2048, rate=50, cam='CITYSCAPES', rs=1, cfg='configs[3]', metric="rainy frames/sec @ 2048x1024, 50 mm/hr"),
+}
+
 
 def algorithmic_bytes(H, W, He, We, N):
     """bytes(frame) = 27*H*W + 16*He*We + 64*N."""
     return 27 * H * W + 16 * He * We + 64 * N
+
+
+class DeviceBatch:
+    """n frames resident in HBM as torch tensors + the ctypes descriptors rr_render_frames_device takes."""
+
+    def __init__(self, torch, hb, sc, dev, frame_ids, drop_ids, noise_std=0.0):
+        self.n = len(frame_ids)
+        self.keep = []
+        self.fin = (hb.rr_frame_in * max(self.n, 1))()
+        self.fout = (hb.rr_frame_out * max(self.n, 1))()
+        self.host = []
+        H, W, He, We = sc.H, sc.W, sc.He, sc.We
+        omega_t = torch.from_numpy(np.ascontiguousarray(sc.omega)).to(dev)
+        self.keep.append(omega_t)
+        for k, (fi, di) in enumerate(zip(frame_ids, drop_ids)):
+            bg, env = sc.frame_inputs(fi)
+            drops = sc.product_drops(di, noise_std=noise_std, noise_scale=1.0 if noise_std else 0.0)
+            self.host.append((bg, env, drops))
+            t_bg = torch.from_numpy(bg).to(dev)
+            t_env = torch.from_numpy(env).to(dev)
+            t_dr = torch.from_numpy(drops.view(np.uint8).reshape(-1)).to(dev)
+            o_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+            o_m = torch.empty((H, W), dtype=torch.float64, device=dev)
+            o_mi = torch.empty((H, W), dtype=torch.int32, device=dev)
+            o_st = torch.empty((max(len(drops), 1),), dtype=torch.int32, device=dev)
+            self.keep += [t_bg, t_env, t_dr, o_rgb, o_m, o_mi, o_st]
+            fi_, fo_ = self.fin[k], self.fout[k]
+            fi_.H, fi_.W, fi_.He, fi_.We = H, W, He, We
+            fi_.bg = fi_.rainy_bg = t_bg.data_ptr()
+            fi_.env_xyY = t_env.data_ptr()
+            fi_.omega = omega_t.data_ptr()
+            fi_.drops = t_dr.data_ptr()
+            fi_.n_drops = len(drops)
+            fi_.strategy = 0
+            fi_.opacity_attenuation = 1.0
+            fo_.rainy_rgb = o_rgb.data_ptr()
+            fo_.rainy_bg_out = None
+            fo_.mask_f64 = o_m.data_ptr()
+            fo_.mask_i32 = o_mi.data_ptr()
+            fo_.drop_status = o_st.data_ptr()
+        self.mean_drops = float(np.mean([len(f[2]) for f in self.host])) if self.host else 0.0
+
+    def chunk(self, hb, a, b):
+        """Descriptor arrays of frames [a, b) (they point into the same tensors)."""
+        n = b - a
+        fin, fout = (hb.rr_frame_in * n)(), (hb.rr_frame_out * n)()
+        for k in range(n):
+            ctypes.memmove(ctypes.byref(fin[k]), ctypes.byref(self.fin[a + k]), ctypes.sizeof(hb.rr_frame_in))
+            ctypes.memmove(ctypes.byref(fout[k]), ctypes.byref(self.fout[a + k]), ctypes.sizeof(hb.rr_frame_out))
+        return fin, fout, n
+
+
+def timed(torch, dist, world, dev, fn, steps):
+    """K calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el
+
+
+def measure_traffic(args, dom_kernels):
+    """HBM bytes per launch of the dominant kernel: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not
+    fit one pass) of a short run of this same workload, corrected as MI355X_MICROARCH.md's HBM section prescribes:
+    KB * 1024, FETCH_SIZE doubled on gfx950.  None when rocprofv3 is missing or anything goes wrong."""
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = tempfile.mkdtemp(prefix='rainpmc_', dir='/tmp')
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
+                   os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1', '--batch', str(args.batch),
+                   '--workload', args.workload] + sum((['--opt', o] for o in args.opt), [])
+            env = dict(os.environ, TMPDIR='/tmp')
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+            tot, cnt = 0.0, 0
+            for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+                for row in csv.DictReader(open(f)):
+                    m = re.search(r'(k_[a-z_0-9]+)', row.get('Kernel_Name', ''))
+                    if m and m.group(1) in dom_kernels and row['Counter_Name'] == counter:
+                        tot += float(row['Counter_Value'])
+                        cnt += 1
+            shutil.rmtree(out, ignore_errors=True)
+            if not cnt:
+                return None, "kernel not found in the counter file"
+            vals[counter] = tot / cnt * len(dom_kernels)            # a timing scope may hold several kernels
+        return ((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
+                "(2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per launch, two rocprofv3 --pmc passes of this workload spawned by bench.py")
+    except Exception as e:                                          # noqa: BLE001 -- reported, never fatal
+        return None, "pmc pass failed: %r" % (e,)
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(sc, host, W, H, sample_drops, procs):
+    """The CPU legs (rank 0, N=1 only).  `port`: the numpy oracle in its op-for-op mode (per-drop masked reduction
+    over the whole environment map, like the reference) on ONE core, on a bounded sample (the first `sample_drops`
+    streaks of frame 0), extrapolated linearly in the drop count.  `processes`: P copies of that sample on P cores
+    (reference main_threaded.py:176 caps its pool at 10).  `cpp`: the g++ -O2 build of the kernel arithmetic
+    (tests/hostemu), whole frame, one core -- the stronger CPU baseline."""
+    from oracle import render as orc                 # the checker, timed: the only place bench.py touches oracle/
+    bg, env, drops = host[0]
+    textures, ratio = orc.load_streak_database(sc.tex_dir, sc.norm)
+    sim0 = list(orc.load_streaks_from_xml(sc.xml, sc.render_scale, [W, H]).values())[0]
+    streaks = list(orc.streak_filter(sim0.streaks, W, H).values())
+    ns = min(sample_drops, len(streaks))
+    c0 = time.perf_counter()
+    orc.render_frame(bg, bg, env, sc.omega, streaks, textures, ratio, sc.ocam, frame_seed=0, faithful=True, max_drops=ns)
+    c1 = time.perf_counter()
+    per_drop = (c1 - c0) / ns
+    out = {"value": 1.0 / (per_drop * len(streaks)), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "numpy oracle (op-for-op), first %d of %d streaks of frame 0: %.1f s, %.2f ms/drop, extrapolated linearly "
+                     "in the drop count; whole-frame medians: profiles/ (scripts/cpu_baseline_full.py)"
+                     % (ns, len(streaks), c1 - c0, 1e3 * per_drop),
+           "nproc": os.cpu_count(), "cpu_model": _cpu_model()}
+    try:                                                            # P processes, same sample each
+        import multiprocessing as mp
+        P = max(1, min(10, procs))
+        ctx = mp.get_context('fork')
+        q = ctx.Queue()
+
+        def work(k):
+            import copy
+            t0 = time.perf_counter()
+            orc.render_frame(bg, bg, env, sc.omega, copy.deepcopy(streaks[:ns]), textures, ratio, sc.ocam, frame_seed=k, faithful=True)
+            q.put(time.perf_counter() - t0)
+        p0 = time.perf_counter()
+        ps = [ctx.Process(target=work, args=(k,)) for k in range(P)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join()
+        wall = time.perf_counter() - p0
+        out["processes"] = {"value": P / (wall / ns * len(streaks)), "unit": "frames/s", "cores": P,
+                            "sample": "%d processes (min(10, nproc), main_threaded.py:176) x the same %d-streak sample: %.1f s wall" % (P, ns, wall)}
+    except Exception as e:                                          # noqa: BLE001
+        out["processes"] = {"error": repr(e)}
+    try:                                                            # C++ build of the kernel arithmetic
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import helpers as th
+        th.hostemu()
+        e0 = time.perf_counter()
+        th.emu_render(sc, bg, bg, env, drops)
+        e1 = time.perf_counter()
+        out["cpp"] = {"value": 1.0 / (e1 - e0), "unit": "frames/s", "cores": 1, "kind": "port",
+                      "sample": "tests/hostemu (rr_device.h compiled with g++ -O2 -ffp-contract=off), whole frame 0 (%d streaks): %.2f s"
+                                % (len(drops), e1 - e0)}
+    except Exception as e:                                          # noqa: BLE001
+        out["cpp"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -38,15 +230,20 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=256, help='frames per step and per GPU')
-    ap.add_argument('--height', type=int, default=375)
-    ap.add_argument('--width', type=int, default=1242)
-    ap.add_argument('--rate', type=int, default=100, help='mm/hr (selects the synthetic drop count)')
+    ap.add_argument('--batch', type=int, default=256, help='frames per library call (and, in weak scaling, per step and GPU)')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='kitti100')
+    ap.add_argument('--total-frames', type=int, default=0, help='strong scaling: one sequence of this many frames sharded over the ranks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-prepass', action='store_true', help='skip the extra (untimed) pre-pass measurement')
-    ap.add_argument('--cpu-sample-drops', type=int, default=1024)
+    ap.add_argument('--no-prepass', action='store_true', help='skip the pre-pass / host-inclusive extras')
+    ap.add_argument('--no-variants', action='store_true')
+    ap.add_argument('--no-traffic', action='store_true')
+    ap.add_argument('--cpu-sample-drops', type=int, default=2048)
+    ap.add_argument('--pipe-batch', type=int, default=32, help='frames per slot of the host-inclusive pipeline')
     ap.add_argument('--opt', action='append', default=[], help='rr_set_option as ID=VALUE (tuning switches that never change results)')
+    ap.add_argument('--inner', action='store_true', help='(used by the PMC passes) timed loop only, no extras, no JSON')
     args = ap.parse_args()
+    if args.inner:
+        args.no_cpu_baseline = args.no_prepass = args.no_variants = args.no_traffic = True
 
     import torch
     import torch.distributed as dist
@@ -74,16 +271,25 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    h = importlib.import_module('rain-rendering_amd.scenes')
-    hb, synthetic = h.hb, h.synthetic
+    scenes = importlib.import_module('rain-rendering_amd.scenes')
+    sharding = importlib.import_module('rain-rendering_amd.sharding')
+    hb, synthetic = scenes.hb, scenes.synthetic
 
-    H, W, B = args.height, args.width, args.batch
-    N = synthetic.DROPS_PER_RATE[args.rate]
+    wl = WORKLOADS[args.workload]
+    H, W, B = wl['H'], wl['W'], args.batch
+    N = synthetic.DROPS_PER_RATE[wl['rate']]
+    cam = getattr(scenes, wl['cam'])
+    strong = args.total_frames > 0
+    # frames of this rank: weak = its own B frames (seeded by rank); strong = its share of ONE sequence
+    if strong:
+        my_frames = sharding.shard(list(range(args.total_frames)), rank, world)
+        n_sim, seed0 = args.total_frames, 3000
+    else:
+        my_frames = list(range(B))
+        n_sim, seed0 = B, 3000 + 1000 * rank
     tmp = tempfile.mkdtemp(prefix='rainbench_r%d_' % rank)
-    # every rank simulates its own frames (seeded by rank); rank 0 owns the streak database
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):       # loaders print like the reference's do; stdout carries the JSON line only
-        sc = h.Scene(tmp, H, W, N, n_frames=B, seed0=3000 + 1000 * rank)
+        sc = scenes.Scene(tmp, H, W, N, n_frames=n_sim, cam=cam, seed0=seed0, render_scale=wl['rs'])
     He, We = sc.He, sc.We
 
     rh = hb.RainHip(local_rank)
@@ -100,193 +306,183 @@ def main():
     rh.set_camera(sc.cam)
 
     # --- inputs resident in HBM ----------------------------------------------------------------
-    keep = []
-    fin = (hb.rr_frame_in * B)()
-    fout = (hb.rr_frame_out * B)()
-    omega_t = torch.from_numpy(np.ascontiguousarray(sc.omega)).to(dev)
-    host_frames = []
-    for i in range(B):
-        bg, env = sc.frame_inputs(i + 100 * rank)
-        drops = sc.product_drops(i)
-        host_frames.append((bg, env, drops))
-        t_bg = torch.from_numpy(bg).to(dev)
-        t_env = torch.from_numpy(env).to(dev)
-        t_dr = torch.from_numpy(drops.view(np.uint8).reshape(-1)).to(dev)
-        o_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        o_m = torch.empty((H, W), dtype=torch.float64, device=dev)
-        o_mi = torch.empty((H, W), dtype=torch.int32, device=dev)
-        o_st = torch.empty((max(len(drops), 1),), dtype=torch.int32, device=dev)
-        keep += [t_bg, t_env, t_dr, o_rgb, o_m, o_mi, o_st]
-        fin[i].H, fin[i].W, fin[i].He, fin[i].We = H, W, He, We
-        fin[i].bg = fin[i].rainy_bg = t_bg.data_ptr()
-        fin[i].env_xyY = t_env.data_ptr()
-        fin[i].omega = omega_t.data_ptr()
-        fin[i].drops = t_dr.data_ptr()
-        fin[i].n_drops = len(drops)
-        fin[i].strategy = 0
-        fin[i].opacity_attenuation = 1.0
-        fout[i].rainy_rgb = o_rgb.data_ptr()
-        fout[i].rainy_bg_out = None
-        fout[i].mask_f64 = o_m.data_ptr()
-        fout[i].mask_i32 = o_mi.data_ptr()
-        fout[i].drop_status = o_st.data_ptr()
-    n_drops_mean = float(np.mean([len(f[2]) for f in host_frames]))
+    fids = [f if strong else f + 100 * rank for f in my_frames]
+    batch = DeviceBatch(torch, hb, sc, dev, fids, my_frames)
     stream = torch.cuda.current_stream().cuda_stream
+    chunks = [batch.chunk(hb, a, min(a + B, batch.n)) for a in range(0, batch.n, B)]
 
-    def step():
-        rh.render_frames_device(fin, fout, B, stream)
+    def render(chs=None):
+        for fin, fout, n in (chunks if chs is None else chs):
+            rh.render_frames_device(fin, fout, n, stream)
 
-    # warm-up (also sizes the tile arena: re-enqueue until it fits)
-    for _ in range(max(args.warmup, 1)):
-        step()
-        while not rh.synchronize():
-            step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    def warm(fn, reps):
+        for _ in range(max(reps, 1)):          # also sizes the tile arena: re-enqueue until it fits
+            fn()
+            while not rh.synchronize():
+                fn()
+        torch.cuda.synchronize()
 
+    warm(render, args.warmup)
     rh.profile_reset()
     rh.profile(True)               # HIP events around every launch, on the launch stream
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
+    elapsed = timed(torch, dist, world, dev, render, args.steps)
     rh.profile(False)
     assert rh.synchronize(), "tile arena regrew inside the timed region"
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     stats = rh.profile_read()
-    cnts = np.array([rh.batch_counts(i) for i in range(B)])
-    tiles_rendered, tiles_shared = int(cnts[:, 0].sum() + cnts[:, 1].sum() + cnts[:, 5].sum()), int(cnts[:, 7].sum())
+    if args.inner:
+        rh.close()
+        return
+    nb = min(B, batch.n)
+    cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)
 
-    # --- extra (outside the timed region, not part of `value`): the fog + environment-map pre-pass that
-    # produces rainy_bg / env_xyY on the device (rr_prepass_frames_device), same batch
-    prepass = None
-    if rank == 0 and world == 1 and not args.no_prepass:
+    extras = {}
+    single = rank == 0 and world == 1
+    # --- variants (N=1): what the headline's conditions hide ------------------------------------
+    if single and not args.no_variants and not strong:
+        var = {}
+
+        def rate(fn, frames, reps=3):
+            warm(fn, 1)
+            return frames * reps / timed(torch, dist, 1, dev, fn, reps)
+        rh.set_option(hb.RR_OPT_DEDUP, 0)
+        var["no_tile_sharing"] = {"frames_per_s": rate(render, batch.n), "what": "RR_OPT_DEDUP=0: every drop renders its own raw tile"}
+        rh.set_option(hb.RR_OPT_DEDUP, 1)
+        nn = min(64, batch.n)
+        nz = DeviceBatch(torch, hb, sc, dev, fids[:nn], my_frames[:nn], noise_std=3.0)
+        nzc = [nz.chunk(hb, 0, nz.n)]
+        var["noise_std_3"] = {"frames_per_s": rate(lambda: render(nzc), nz.n),
+                              "what": "%d frames with --noise_std 3 --noise_scale 1 (rotations differ per drop: raw tiles stop being shareable)" % nn}
+        small = [batch.chunk(hb, a, a + 4) for a in range(0, min(batch.n, 64) - 3, 4)]
+        var["calls_of_4"] = {"frames_per_s": rate(lambda: render(small), 4 * len(small)), "what": "library calls of 4 frames"}
+        mid = [batch.chunk(hb, a, a + 32) for a in range(0, min(batch.n, 128) - 31, 32)]
+        if mid:
+            var["calls_of_32"] = {"frames_per_s": rate(lambda: render(mid), 32 * len(mid)), "what": "library calls of 32 frames (the driver's default)"}
+        del nz, nzc
+        warm(render, 1)                      # back to the headline configuration (arena / scratch sized for it)
+        extras["variants"] = var
+
+    # --- the fog + environment-map pre-pass (rr_prepass_frames_device); not part of `value` ------------------
+    if single and not args.no_prepass and not strong:
         fogmod = importlib.import_module('rain-rendering_amd.common.add_attenuation')
         envmod = importlib.import_module('rain-rendering_amd.common.envmap')
         imgops = importlib.import_module('rain-rendering_amd.common.imgops')
         cs = sc.cam_settings
-        consts = fogmod.FogRain(rain_intensity=args.rate, focal=cs['focal_mm'] / 1000., f_number=cs['f_number'], angle=90,
+        consts = fogmod.FogRain(rain_intensity=wl['rate'], focal=cs['focal_mm'] / 1000., f_number=cs['f_number'], angle=90,
                                 exposure=cs['exposure_ms'], camera_gain=20).constants()
         rh.set_prepass_kernels(imgops.gaussian_kernel(25, 25), imgops.gaussian_kernel(15, 0))
         we = rh.set_envmap_geometry(H, W, *envmod.EnvironmentMapGenerator(cs['focal_mm'] / 1000., W, H).device_tables(H, W))
         assert we == We
-        pin = (hb.rr_prepass_in * B)()
-        pout = (hb.rr_prepass_out * B)()
+        nb_pre = min(batch.n, 64)
+        pin = (hb.rr_prepass_in * nb_pre)()
+        pout = (hb.rr_prepass_out * nb_pre)()
         depth_t = torch.from_numpy((np.linspace(80, 2, H, dtype=np.float32)[:, None] * np.ones((1, W), np.float32))).to(dev)
-        for i in range(B):
+        keep = [depth_t]
+        for i in range(nb_pre):
             o_r = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
             o_e = torch.empty((He, We, 3), dtype=torch.float64, device=dev)
             keep += [o_r, o_e]
-            pin[i].H, pin[i].W, pin[i].bg, pin[i].depth, pin[i].depth_f64 = H, W, fin[i].bg, depth_t.data_ptr(), 0
+            pin[i].H, pin[i].W, pin[i].bg, pin[i].depth, pin[i].depth_f64 = H, W, batch.fin[i].bg, depth_t.data_ptr(), 0
             pin[i].beta_ext, pin[i].beta_hg, pin[i].irr_num, pin[i].irr_den = [float(v) for v in consts]
             pout[i].rainy_bg, pout[i].env_xyY, pout[i].env_bgr_u8 = o_r.data_ptr(), o_e.data_ptr(), None
-        run_pre = lambda: rh._check(rh.lib.rr_prepass_frames_device(rh.h, B, pin, pout, ctypes.c_void_p(stream)), 'prepass')
+
+        def run_pre():
+            rh._check(rh.lib.rr_prepass_frames_device(rh.h, nb_pre, pin, pout, ctypes.c_void_p(stream)), 'prepass')
         run_pre()
         torch.cuda.synchronize()
         rh.profile_reset()
         rh.profile(True)
-        p0 = time.perf_counter()
-        for _ in range(args.steps):
-            run_pre()
-        torch.cuda.synchronize()
-        p1 = time.perf_counter()
+        t = timed(torch, dist, 1, dev, run_pre, args.steps)
         rh.profile(False)
         pstats = rh.profile_read()
-        prepass = {"what": "fog attenuation + environment map + xyY (rr_prepass_frames_device), not included in value",
-                   "ms_per_step": 1e3 * (p1 - p0) / args.steps, "frames_per_s": B * args.steps / (p1 - p0),
-                   "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(pstats.items(), key=lambda kv: -kv[1][1])}}
-
-    # --- extra: the host-pointer entry (rr_pipeline_frames): bg + depth + drops up over PCIe, pre-pass and hot
-    # path on the device, u8 image + masks down.  Reported, never `value`.
-    host_incl = None
-    if prepass is not None:
+        extras["prepass"] = {"what": "fog attenuation + environment map + xyY (rr_prepass_frames_device), %d frames per call; not in value" % nb_pre,
+                             "ms_per_frame": 1e3 * t / args.steps / nb_pre, "frames_per_s": nb_pre * args.steps / t,
+                             "kernels_ms_per_call": {k: v[1] / args.steps for k, v in sorted(pstats.items(), key=lambda kv: -kv[1][1])}}
         depth_h = np.ascontiguousarray(depth_t.cpu().numpy())
-        # what the main.py driver sends: the uint8 image (bg = bytes / 255.0 on the device), float32 depth, drop table
-        hf = [dict(bg_u8=(host_frames[i][0] * 255).astype(np.uint8), depth=depth_h, fog=consts, omega=sc.omega,
-                   drops=host_frames[i][2]) for i in range(B)]
-        rh.pipeline_frames(hf, want_mask_i32=False)
+        del keep, pin, pout
+
+        # --- host-inclusive: pinned buffers, three slots in flight (upload | kernels | download overlap) -----
+        PB = max(1, min(args.pipe_batch, batch.n))
+        nslot = hb.RR_PIPE_SLOTS
+        slots = []
+        for s_ in range(nslot):
+            frs, outs = [], []
+            for k in range(PB):
+                i = (s_ * PB + k) % batch.n
+                bg8 = rh.host_array((H, W, 3), np.uint8)
+                bg8[...] = (batch.host[i][0] * 255).astype(np.uint8)
+                dep = rh.host_array((H, W), np.float32)
+                dep[...] = depth_h
+                dr = rh.host_array((len(batch.host[i][2]),), hb.DROP_DTYPE)
+                dr[...] = batch.host[i][2]
+                frs.append(dict(bg_u8=bg8, depth=dep, fog=consts, omega=sc.omega, drops=dr))
+                outs.append(dict(image_u8=rh.host_array((H, W, 3), np.uint8), mask_i32=rh.host_array((H, W), np.int32)))
+            slots.append((frs, outs))
+
+        def pipe(rounds):
+            done = 0
+            for r in range(rounds + nslot):
+                s_ = r % nslot
+                if r >= nslot:
+                    while not rh.pipeline_wait(s_):
+                        rh.pipeline_submit(s_, *slots[s_])
+                    done += PB
+                if r < rounds:
+                    rh.pipeline_submit(s_, *slots[s_])
+            return done
+        pipe(nslot)                                   # warm-up: staging buffers, arena
+        rounds = max(2 * nslot, (192 + PB - 1) // PB)  # >= 192 frames
         h0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            rh.pipeline_frames(hf, want_mask_i32=False)
+        done = pipe(rounds)
         h1 = time.perf_counter()
-        host_incl = {"what": "rr_pipeline_frames with pageable host buffers (PCIe up: u8 image + f32 depth + drops; pre-pass + hot "
-                             "path; PCIe down: u8 image + f64 mask), not `value`",
-                     "frames_per_s": B * reps / (h1 - h0), "ms_per_step": 1e3 * (h1 - h0) / reps}
+        up = 3 * H * W + 4 * H * W + 112 * batch.mean_drops
+        down = 3 * H * W + 4 * H * W
+        extras["host_inclusive"] = {
+            "what": "rr_pipeline_submit/wait, %d slots x %d frames, pinned host buffers (rr_host_alloc): PCIe up (u8 image + f32 depth "
+                    "+ drop table), fog + environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask); "
+                    "PNG codec excluded; %d frames timed" % (nslot, PB, done),
+            "frames_per_s": done / (h1 - h0), "ms_per_frame": 1e3 * (h1 - h0) / done,
+            "pcie_bytes_per_frame": {"up": up, "down": down},
+            "pcie_GBps": {"up": up * done / (h1 - h0) / 1e9, "down": down * done / (h1 - h0) / 1e9}}
+        warm(render, 1)
 
     if rank == 0:
-        frames_total = B * args.steps * world
-        fps = frames_total / elapsed
-        dom = max(stats.items(), key=lambda kv: kv[1][1])
-        dom_name, (dom_launches, dom_ms) = dom
-        avg_ms = dom_ms / dom_launches
-        alg = algorithmic_bytes(H, W, He, We, n_drops_mean) * B
+        frames_step = args.total_frames if strong else B * world
+        fps = frames_step * args.steps / elapsed
+        per_launch = {k: v[1] / v[0] for k, v in stats.items()}
+        dom_name = max(per_launch, key=per_launch.get)
+        avg_ms = per_launch[dom_name]
+        alg = algorithmic_bytes(H, W, He, We, batch.mean_drops) * nb
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this very
-        # command (scripts/gpu_profile.sh -> profiles/*_traffic.json); null when no matching pass exists
-        traffic = None
-        tfile = os.environ.get('RAIN_TRAFFIC_JSON', os.path.join(ROOT, 'profiles', 'r01_traffic.json'))
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                if tj.get('batch') == B and tj.get('workload') == [W, H, args.rate]:
-                    # a timing scope can hold several kernels (the colour scope: order + bands + finalise)
-                    parts = {'k_colour_spans': ['k_col_order', 'k_colour_bands'], 'k_fog_stats': ['k_fog_sum', 'k_fog_mean', 'k_fog_ext'],
-                             'k_dedup': ['k_dedup', '__amd_rocclr_fillBufferAligned']}.get(dom_name, [dom_name])
-                    vals = [tj['kernels'].get(k, {}).get('hbm_bytes_per_launch') for k in parts]
-                    traffic = sum(v for v in vals if v is not None) if any(v is not None for v in vals) else None
-            except Exception:
-                traffic = None
+        traffic, traffic_how = None, "not measured (--no-traffic, N>1 or strong scaling)"
+        if single and not args.no_traffic and not strong:
+            parts = {'k_env_prefix': ['k_env_prefix', 'k_env_consts']}.get(dom_name, [dom_name])
+            traffic, traffic_how = measure_traffic(args, parts)
+        chain_ms = sum(per_launch.values())
         out = {
-            "metric": "rainy frames/sec @ 1242x375, 100 mm/hr",
+            "metric": wl['metric'],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "KITTI data_object shape %dx%d, %d mm/hr (%d streaks/frame after the frame filter: %.0f), "
-                                   "precomputed particles; BASELINE.json configs[2]" % (W, H, args.rate, N, n_drops_mean),
-                       "frames_per_step_per_gpu": B, "envmap": "%dx%d" % (We, He), "parallelism": "frames sharded, dp%d" % world,
-                       "raw_tiles_per_step": {"rendered": tiles_rendered, "shared_bit_identical": tiles_shared,
-                                              "rotate_resize": int(cnts[:, 0].sum()), "bicubic_warp": int(cnts[:, 5].sum()),
-                                              "generic": int(cnts[:, 1].sum())},
-                       "blur_per_step": {"fused_items": int(cnts[:, 2].sum()), "wave_per_drop": int(cnts[:, 4].sum()),
-                                         "two_pass": int(cnts[:, 3].sum())}},
+            "config": {"workload": "%s shape %dx%d, %d mm/hr (%d streaks/frame simulated, %.0f after the frame filter), precomputed "
+                                   "particles; BASELINE.json %s" % (wl['cam'], W, H, wl['rate'], N, batch.mean_drops, wl['cfg']),
+                       "frames_per_call": nb, "frames_per_step": frames_step, "envmap": "%dx%d" % (We, He),
+                       "parallelism": "frames sharded round-robin, dp%d; one RCCL broadcast of the streak DB" % world,
+                       "raw_tiles_last_call": {"rotate_resize": int(cnts[:, 0].sum()), "bicubic_warp": int(cnts[:, 5].sum()),
+                                               "generic": int(cnts[:, 1].sum()), "shared_bit_identical": int(cnts[:, 7].sum())},
+                       "blur_last_call": {"fused_items": int(cnts[:, 2].sum()), "wave_per_drop": int(cnts[:, 4].sum()),
+                                          "two_pass": int(cnts[:, 3].sum())}},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
-            "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_how,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
+                         "definition": "algorithmic bytes of the frames of one launch (27*H*W + 16*He*We + 64*N each, SURVEY 8d) / "
+                                       "average launch time of the slowest kernel of the chain (HIP events on the launch stream)"},
+            "chain": {"ms_per_call_sum_of_kernels": chain_ms, "algorithmic_GBps": alg / (chain_ms * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "kernels_ms_per_call": {k: v for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
         }
-        if prepass is not None:
-            out["prepass"] = prepass
-        if host_incl is not None:
-            out["host_inclusive"] = host_incl
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
-            # CPU reference = the numpy oracle in its op-for-op ("faithful") mode, 1 core, on the
-            # first --cpu-sample-drops streaks of frame 0; extrapolated linearly in the drop count.
-            from oracle import render as orc             # the checker, timed: the only place bench.py touches oracle/
-            bg, env, drops = host_frames[0]
-            textures, ratio = orc.load_streak_database(sc.tex_dir, sc.norm)
-            sim0 = list(orc.load_streaks_from_xml(sc.xml, 1, [W, H]).values())[0]
-            streaks = list(orc.streak_filter(sim0.streaks, W, H).values())
-            ns = min(args.cpu_sample_drops, len(streaks))
-            c0 = time.perf_counter()
-            orc.render_frame(bg, bg, env, sc.omega, streaks, textures, ratio, sc.ocam, frame_seed=0, faithful=True,
-                             max_drops=ns)
-            c1 = time.perf_counter()
-            per_drop = (c1 - c0) / ns
-            cpu_fps = 1.0 / (per_drop * len(streaks))
-            out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d of %d streaks of frame 0 (%.1f s, %.2f ms/drop), extrapolated linearly"
-                                             % (ns, len(streaks), c1 - c0, 1e3 * per_drop)}
-            out["speedup_vs_cpu"] = fps / cpu_fps
+        out.update(extras)
+        if not args.no_cpu_baseline and single and not strong:
+            out["cpu_baseline"] = cpu_baseline(sc, batch.host, W, H, args.cpu_sample_drops, os.cpu_count() or 1)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -101,7 +101,7 @@ typedef struct {
 typedef struct {
   uint8_t* rainy_rgb;             /* H*W*3 RGB: what plt.imsave(rainy_image) stores (generator.py:461-466), alpha omitted */
   double* rainy_bg_out;           /* optional (may be NULL): H*W*3 BGR composite before the mean shift */
-  double* mask_f64;               /* H*W: rainy_mask accumulator (bad_weather.py:450) */
+  double* mask_f64;               /* H*W: rainy_mask accumulator (bad_weather.py:450); may be NULL */
   int32_t* mask_i32;              /* H*W: floor(mask_f64 * 255)  (SURVEY decision D1); may be NULL */
   int32_t* drop_status;           /* n_drops RR_DROP_* codes (may be NULL) */
 } rr_frame_out;
@@ -207,6 +207,19 @@ enum {
   RR_OPT_FOV_DROPS_PER_THREAD = 4   /* drops per thread of the FOV-sum kernel: 0 (library's choice), 1, 2 or 4 */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
+
+/* Asynchronous form of rr_pipeline_frames (pre may be NULL: then it is the asynchronous rr_render_frames): up to
+ * RR_PIPE_SLOTS batches in flight.  The upload of one batch, the kernels of another and the download of a third
+ * overlap (three streams inside the library).  Buffers must stay valid and untouched until rr_pipeline_wait(slot)
+ * returns; buffers from rr_host_alloc (pinned) move at PCIe rate, pageable ones serialise the copies.
+ * rr_pipeline_wait returns RR_E_ARENA when the tile arena had to grow: submit that batch again. */
+#define RR_PIPE_SLOTS 3
+int rr_pipeline_submit(rr_ctx* ctx, int32_t slot, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in,
+                       const rr_frame_out* out, const rr_prepass_out* pre_out);
+int rr_pipeline_wait(rr_ctx* ctx, int32_t slot);
+/* Page-locked host memory (hipHostMalloc) for the buffers of the host-pointer entry points. */
+int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes);
+int rr_host_free(rr_ctx* ctx, void* p);
 
 /* Work-list sizes of frame `frame` of the last batch (after completion): out[0] drops whose raw tile went
  * through the rotate+resize kernel, [1] through the generic kernel, [2] fused-blur work items, [3] slow-blur

@@ -1894,7 +1894,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     o[0] = c[0];
     o[1] = c[1];
     o[2] = c[2];
-    as_global(fr.mask_f64)[pix] = m;
+    if (fr.mask_f64) as_global(fr.mask_f64)[pix] = m;
     if (fr.mask_i32) as_global(fr.mask_i32)[pix] = (int32_t)floor(m * 255.0);
     sum_c = (c[0] + c[1]) + c[2];
   }
@@ -1992,7 +1992,7 @@ struct rr_ctx {
   // last launch (for rr_synchronize bookkeeping)
   int last_n = 0;
   std::vector<int64_t> h_need;
-  // host-variant staging
+  // host-pointer entry points: device staging per pipeline slot (slot 0 serves the synchronous calls)
   struct Staging {
     double *bg = nullptr, *rainy = nullptr, *env = nullptr, *omega = nullptr, *comp = nullptr, *mask = nullptr;
     rr_drop* drops = nullptr;
@@ -2003,7 +2003,14 @@ struct rr_ctx {
     uint8_t* env_u8 = nullptr;
     int frames = 0, drops_cap = 0;
     Dims dims{0, 0, 0, 0};
-  } st;
+  };
+  struct Slot {
+    Staging st;
+    hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_down = nullptr;
+    int64_t* h_flags = nullptr;      // pinned: [0] arena-overflow flag as seen after this batch
+    bool busy = false, rendered = false;
+  } slots[RR_PIPE_SLOTS];
+  hipStream_t s_up = nullptr, s_down = nullptr;
   // pre-pass (fog + environment map)
   rrpre::Kernels pk{};
   bool have_pk = false, have_eg = false;
@@ -2214,7 +2221,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       return RR_E_ARG;
     }
     if (in[f].n_drops < 0 || in[f].n_drops > 65536 || !in[f].bg || !in[f].rainy_bg || !in[f].env_xyY || !in[f].omega ||
-        (in[f].n_drops > 0 && !in[f].drops) || !out[f].rainy_rgb || !out[f].mask_f64) {
+        (in[f].n_drops > 0 && !in[f].drops) || !out[f].rainy_rgb) {
       ctx->err = "null frame pointer or n_drops outside [0, 2^16] (generator.py:425)";
       return RR_E_ARG;
     }
@@ -2588,19 +2595,27 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.overflow);
   hipFree(ctx->d_frames);
   hipFree(ctx->d_comp_out);
-  hipFree(ctx->st.bg);
-  hipFree(ctx->st.rainy);
-  hipFree(ctx->st.env);
-  hipFree(ctx->st.omega);
-  hipFree(ctx->st.comp);
-  hipFree(ctx->st.mask);
-  hipFree(ctx->st.drops);
-  hipFree(ctx->st.rgb);
-  hipFree(ctx->st.mask_i);
-  hipFree(ctx->st.status);
-  hipFree(ctx->st.depth);
-  hipFree(ctx->st.env_u8);
-  hipFree(ctx->st.bg8);
+  for (auto& sl : ctx->slots) {
+    hipFree(sl.st.bg);
+    hipFree(sl.st.rainy);
+    hipFree(sl.st.env);
+    hipFree(sl.st.omega);
+    hipFree(sl.st.comp);
+    hipFree(sl.st.mask);
+    hipFree(sl.st.drops);
+    hipFree(sl.st.rgb);
+    hipFree(sl.st.mask_i);
+    hipFree(sl.st.status);
+    hipFree(sl.st.depth);
+    hipFree(sl.st.env_u8);
+    hipFree(sl.st.bg8);
+    if (sl.ev_up) hipEventDestroy(sl.ev_up);
+    if (sl.ev_comp) hipEventDestroy(sl.ev_comp);
+    if (sl.ev_down) hipEventDestroy(sl.ev_down);
+    if (sl.h_flags) hipHostFree(sl.h_flags);
+  }
+  if (ctx->s_up) hipStreamDestroy(ctx->s_up);
+  if (ctx->s_down) hipStreamDestroy(ctx->s_down);
   hipFree(ctx->d_esrc);
   hipFree(ctx->d_etop);
   hipFree(ctx->d_ebot);
@@ -2716,45 +2731,40 @@ int rr_synchronize(rr_ctx* ctx) {
   return RR_OK;
 }
 
-// Host-pointer runner shared by rr_render_frames (pre == NULL), rr_prepass_frames (in == NULL)
-// and rr_pipeline_frames (both): stage, enqueue, download.
-static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
-                    const rr_prepass_out* pre_out) {
-  if (!ctx) return RR_E_ARG;
-  if (n <= 0 || (!pre && !in) || (in && !out) || (pre && !in && !pre_out)) {
-    ctx->err = "bad frame batch";
-    return RR_E_ARG;
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// host-pointer entry points: slots of device staging, three streams
+// ---------------------------------------------------------------------------
+// A batch given by HOST pointers goes through one of RR_PIPE_SLOTS staging slots:
+//   upload   (stream s_up)     caller's buffers -> slot staging (pinned buffers from rr_host_alloc move at PCIe rate)
+//   compute  (ctx->stream)     [bytes -> unit interval] -> [pre-pass] -> [hot path], device scratch shared by all slots
+//   download (stream s_down)   slot staging -> caller's buffers, plus the arena-overflow flag
+// chained by events, so that the upload of batch k+1 and the download of batch k-1 run under the kernels of
+// batch k.  rr_render_frames / rr_prepass_frames / rr_pipeline_frames are submit + wait on slot 0.
+namespace {
+
+struct CopyList {                      // merges copies whose source AND destination continue the previous one
+  struct C { void* dst; const void* src; size_t bytes; };
+  std::vector<C> v;
+  void add(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    if (!v.empty() && (char*)v.back().dst + v.back().bytes == (char*)dst && (const char*)v.back().src + v.back().bytes == (const char*)src)
+      v.back().bytes += bytes;
+    else
+      v.push_back(C{dst, src, bytes});
   }
-  HIPCHK(hipSetDevice(ctx->device));
-  Dims dm{0, 0, 0, 0};
-  if (in) dm = Dims{in[0].H, in[0].W, in[0].He, in[0].We};
-  else {
-    bool want_env = false;
-    for (int f = 0; f < n; f++) want_env = want_env || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
-    dm = Dims{pre[0].H, pre[0].W, pre[0].H, (want_env && ctx->have_eg) ? ctx->eg.We : 1};
-  }
-  if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
-    ctx->err = "bad frame size";
-    return RR_E_ARG;
-  }
-  if (pre && in) {
-    if (!ctx->have_eg || dm.He != dm.H || dm.We != ctx->eg.We || pre[0].H != dm.H || pre[0].W != dm.W) {
-      ctx->err = "pipeline: He/We must be H / rr_envmap_width() of the geometry set for this frame size";
-      return RR_E_ARG;
-    }
-  }
-  int max_drops = 1;
-  for (int f = 0; in && f < n; f++) {
-    if (in[f].n_drops < 0 || in[f].n_drops > 65536) {
-      ctx->err = "n_drops outside [0, 2^16] (generator.py:425)";
-      return RR_E_ARG;
-    }
-    if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
-  }
-  auto& st = ctx->st;
-  const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We;
+};
+
+int issue(rr_ctx* ctx, const CopyList& cl, hipMemcpyKind kind, hipStream_t s) {
+  for (const auto& c : cl.v) HIPCHK(hipMemcpyAsync(c.dst, c.src, c.bytes, kind, s));
+  return RR_OK;
+}
+
+int slot_reserve(rr_ctx* ctx, rr_ctx::Staging& st, int n, int max_drops, const Dims& dm) {
   if (n > st.frames || max_drops > st.drops_cap || dm.H != st.dims.H || dm.W != st.dims.W || dm.He != st.dims.He || dm.We != st.dims.We) {
     HIPCHK(hipDeviceSynchronize());
+    const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We;
     int F = n > st.frames ? n : st.frames, D = max_drops > st.drops_cap ? max_drops : st.drops_cap, rc;
     if ((rc = dev_alloc(ctx, st.bg, F * px * 3))) return rc;
     if ((rc = dev_alloc(ctx, st.rainy, F * px * 3))) return rc;
@@ -2773,40 +2783,131 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
     st.drops_cap = D;
     st.dims = dm;
   }
+  return RR_OK;
+}
+
+int slot_init(rr_ctx* ctx, rr_ctx::Slot& sl) {
+  if (sl.ev_up) return RR_OK;
+  if (!ctx->s_up) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
+  }
+  HIPCHK(hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&sl.ev_down, hipEventDisableTiming));
+  HIPCHK(hipHostMalloc((void**)&sl.h_flags, sizeof(int64_t) * 2, hipHostMallocDefault));
+  return RR_OK;
+}
+
+// Validate the WHOLE batch before anything is copied or mutated (sizes, pointers, per-frame dimensions).
+int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
+                        const rr_prepass_out* pre_out, Dims& dm, int& max_drops) {
+  if (n <= 0 || (!pre && !in) || (in && !out) || (pre && !in && !pre_out)) {
+    ctx->err = "bad frame batch";
+    return RR_E_ARG;
+  }
+  if (in) dm = Dims{in[0].H, in[0].W, in[0].He, in[0].We};
+  else {
+    bool want_env = false;
+    for (int f = 0; f < n; f++) want_env = want_env || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
+    dm = Dims{pre[0].H, pre[0].W, pre[0].H, (want_env && ctx->have_eg) ? ctx->eg.We : 1};
+  }
+  if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
+    ctx->err = "bad frame size";
+    return RR_E_ARG;
+  }
+  if (pre && in && (!ctx->have_eg || dm.He != dm.H || dm.We != ctx->eg.We)) {
+    ctx->err = "pipeline: He/We must be H / rr_envmap_width() of the geometry set for this frame size";
+    return RR_E_ARG;
+  }
+  max_drops = 1;
+  for (int f = 0; f < n; f++) {
+    if (pre) {
+      if (pre[f].H != dm.H || pre[f].W != dm.W) {
+        ctx->err = "all frames of a batch must share H,W";
+        return RR_E_ARG;
+      }
+      if ((!pre[f].bg && !pre[f].bg_u8) || !pre[f].depth || !(pre[f].irr_den != 0.0)) {
+        ctx->err = "null pre-pass pointer or zero irradiance denominator";
+        return RR_E_ARG;
+      }
+      if (!in && !pre_out[f].rainy_bg) {
+        ctx->err = "pre-pass: null rainy_bg output";
+        return RR_E_ARG;
+      }
+    }
+    if (in) {
+      if (in[f].H != dm.H || in[f].W != dm.W || in[f].He != dm.He || in[f].We != dm.We) {
+        ctx->err = "all frames of a batch must share H,W,He,We";
+        return RR_E_ARG;
+      }
+      if (in[f].n_drops < 0 || in[f].n_drops > 65536) {
+        ctx->err = "n_drops outside [0, 2^16] (generator.py:425)";
+        return RR_E_ARG;
+      }
+      if (in[f].strategy != 0 && in[f].strategy != 1) {
+        ctx->err = "rendering strategy must be 0 (default) or 1 ('white'); 'naive_db' is broken in the reference (bad_weather.py:355)";
+        return RR_E_ARG;
+      }
+      if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
+          !out[f].rainy_rgb) {
+        ctx->err = "null frame pointer";
+        return RR_E_ARG;
+      }
+      if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
+    }
+  }
+  if (in && (!ctx->have_cam || !ctx->have_db)) {
+    ctx->err = "streak DB and camera must be set before rendering";
+    return RR_E_STATE;
+  }
+  if (pre && !ctx->have_pk) {
+    ctx->err = "rr_set_prepass_kernels must be called before the pre-pass";
+    return RR_E_STATE;
+  }
+  return RR_OK;
+}
+
+int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
+                const rr_prepass_out* pre_out) {
+  if (slot < 0 || slot >= RR_PIPE_SLOTS) {
+    ctx->err = "bad pipeline slot";
+    return RR_E_ARG;
+  }
+  rr_ctx::Slot& sl = ctx->slots[slot];
+  if (sl.busy) {
+    ctx->err = "pipeline slot still in flight: call rr_pipeline_wait first";
+    return RR_E_STATE;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  Dims dm{0, 0, 0, 0};
+  int max_drops = 1, rc;
+  if ((rc = validate_host_batch(ctx, n, pre, in, out, pre_out, dm, max_drops))) return rc;
+  if ((rc = slot_init(ctx, sl))) return rc;
+  auto& st = sl.st;
+  if ((rc = slot_reserve(ctx, st, n, max_drops, dm))) return rc;
+  const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We;
   hipStream_t s = ctx->stream;
   std::vector<rr_frame_in> din(in ? n : 0);
   std::vector<rr_frame_out> dout(in ? n : 0);
   std::vector<rr_prepass_in> pin(pre ? n : 0);
   std::vector<rr_prepass_out> pout(pre ? n : 0);
+  CopyList up, down;
+  // ---- upload ----
   for (int f = 0; pre && f < n; f++) {
-    if ((!pre[f].bg && !pre[f].bg_u8) || !pre[f].depth) {
-      ctx->err = "null pre-pass pointer";
-      return RR_E_ARG;
-    }
     pin[f] = pre[f];
     pin[f].bg = st.bg + f * px * 3;
     pin[f].bg_u8 = nullptr;
     pin[f].depth = st.depth + f * px;
-    if (pre[f].bg_u8) {               // bytes over PCIe (1/8 of the float64 image), bg = bytes / 255.0 formed on the device
-      uint8_t* b8 = st.bg8 + f * px * 3;
-      HIPCHK(hipMemcpyAsync(b8, pre[f].bg_u8, px * 3, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256)), dim3(256), 0, s, b8, (double*)pin[f].bg,
-                         (int64_t)(px * 3));
-    } else {
-      HIPCHK(hipMemcpyAsync((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    }
-    HIPCHK(hipMemcpyAsync((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4), hipMemcpyHostToDevice, s));
+    if (pre[f].bg_u8) up.add(st.bg8 + f * px * 3, pre[f].bg_u8, px * 3);      // bytes over PCIe: 1/8 of the float64 image
+    else up.add((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double));
+    up.add((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4));
     pout[f].rainy_bg = st.rainy + f * px * 3;
     const bool env = in || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
     pout[f].env_xyY = env ? st.env + f * ex * 3 : nullptr;
     pout[f].env_bgr_u8 = (pre_out && pre_out[f].env_bgr_u8) ? st.env_u8 + f * ex * 3 : nullptr;
   }
   for (int f = 0; in && f < n; f++) {
-    if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
-        !out[f].rainy_rgb || !out[f].mask_f64) {
-      ctx->err = "null frame pointer";
-      return RR_E_ARG;
-    }
     din[f] = in[f];
     din[f].bg = st.bg + f * px * 3;
     din[f].rainy_bg = st.rainy + f * px * 3;
@@ -2816,50 +2917,95 @@ static int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_f
     din[f].omega = same_omega ? din[0].omega : st.omega + f * ex;
     din[f].drops = st.drops + (size_t)f * st.drops_cap;
     if (!pre) {
-      HIPCHK(hipMemcpyAsync((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-      HIPCHK(hipMemcpyAsync((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-      HIPCHK(hipMemcpyAsync((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+      up.add((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double));
+      up.add((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double));
+      up.add((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double));
     }
-    if (!same_omega) HIPCHK(hipMemcpyAsync((void*)din[f].omega, in[f].omega, ex * sizeof(double), hipMemcpyHostToDevice, s));
-    if (in[f].n_drops > 0)
-      HIPCHK(hipMemcpyAsync((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * in[f].n_drops, hipMemcpyHostToDevice, s));
+    if (!same_omega) up.add((void*)din[f].omega, in[f].omega, ex * sizeof(double));
+    up.add((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * (size_t)in[f].n_drops);
     dout[f].rainy_rgb = st.rgb + f * px * 3;
     dout[f].rainy_bg_out = st.comp + f * px * 3;
     dout[f].mask_f64 = st.mask + f * px;
     dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * px : nullptr;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
   }
-  if (pre) {
-    int rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s);
-    if (rc) return rc;
-  }
-  for (int attempt = 0; in && attempt < 3; attempt++) {
-    int rc = enqueue(ctx, n, din.data(), dout.data(), s);
-    if (rc) return rc;
-    rc = check_overflow(ctx, s);
-    if (rc == RR_OK) break;
-    if (rc != RR_E_ARENA || attempt == 2) return rc;
-  }
+  if ((rc = issue(ctx, up, hipMemcpyHostToDevice, ctx->s_up))) return rc;
+  HIPCHK(hipEventRecord(sl.ev_up, ctx->s_up));
+  // ---- compute ----
+  HIPCHK(hipStreamWaitEvent(s, sl.ev_up, 0));
+  for (int f = 0; pre && f < n; f++)
+    if (pre[f].bg_u8)                 // bg = bytes / 255.0 (generator.py:352) formed on the device
+      hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256)), dim3(256), 0, s, st.bg8 + f * px * 3,
+                         (double*)pin[f].bg, (int64_t)(px * 3));
+  if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return rc;
+  if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return rc;
+  HIPCHK(hipEventRecord(sl.ev_comp, s));
+  // ---- download ----
+  HIPCHK(hipStreamWaitEvent(ctx->s_down, sl.ev_comp, 0));
   for (int f = 0; in && f < n; f++) {
-    HIPCHK(hipMemcpyAsync(out[f].rainy_rgb, dout[f].rainy_rgb, px * 3, hipMemcpyDeviceToHost, s));
-    if (out[f].rainy_bg_out)
-      HIPCHK(hipMemcpyAsync(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out[f].mask_f64, dout[f].mask_f64, px * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (out[f].mask_i32) HIPCHK(hipMemcpyAsync(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (out[f].drop_status && in[f].n_drops > 0)
-      HIPCHK(hipMemcpyAsync(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * in[f].n_drops, hipMemcpyDeviceToHost, s));
+    down.add(out[f].rainy_rgb, dout[f].rainy_rgb, px * 3);
+    if (out[f].rainy_bg_out) down.add(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double));
+    if (out[f].mask_f64) down.add(out[f].mask_f64, dout[f].mask_f64, px * sizeof(double));
+    if (out[f].mask_i32) down.add(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t));
+    if (out[f].drop_status) down.add(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * (size_t)in[f].n_drops);
   }
   for (int f = 0; pre && pre_out && f < n; f++) {
-    if (pre_out[f].rainy_bg)
-      HIPCHK(hipMemcpyAsync(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (pre_out[f].env_xyY)
-      HIPCHK(hipMemcpyAsync(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (pre_out[f].env_bgr_u8)
-      HIPCHK(hipMemcpyAsync(pre_out[f].env_bgr_u8, pout[f].env_bgr_u8, ex * 3, hipMemcpyDeviceToHost, s));
+    if (pre_out[f].rainy_bg) down.add(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * sizeof(double));
+    if (pre_out[f].env_xyY) down.add(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * sizeof(double));
+    if (pre_out[f].env_bgr_u8) down.add(pre_out[f].env_bgr_u8, pout[f].env_bgr_u8, ex * 3);
   }
-  HIPCHK(hipStreamSynchronize(s));
+  if ((rc = issue(ctx, down, hipMemcpyDeviceToHost, ctx->s_down))) return rc;
+  sl.h_flags[0] = 0;
+  if (in) HIPCHK(hipMemcpyAsync(&sl.h_flags[0], ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_down));
+  HIPCHK(hipEventRecord(sl.ev_down, ctx->s_down));
+  sl.busy = true;
+  sl.rendered = in != nullptr;
   return RR_OK;
 }
+
+// RR_OK, or RR_E_ARENA after growing the tile arena (the batch's outputs are invalid: submit it again)
+int host_wait(rr_ctx* ctx, int slot) {
+  if (slot < 0 || slot >= RR_PIPE_SLOTS) {
+    ctx->err = "bad pipeline slot";
+    return RR_E_ARG;
+  }
+  rr_ctx::Slot& sl = ctx->slots[slot];
+  if (!sl.busy) return RR_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventSynchronize(sl.ev_down));
+  sl.busy = false;
+  if (sl.rendered && (int32_t)sl.h_flags[0] != 0) {
+    // every batch submitted since the overflow ran against the short arena too: they all report it
+    HIPCHK(hipDeviceSynchronize());
+    int32_t still = 0;
+    HIPCHK(hipMemcpy(&still, ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (still) {
+      ctx->h_need.resize(ctx->last_n);
+      HIPCHK(hipMemcpy(ctx->h_need.data(), ctx->sc.arena_need, sizeof(int64_t) * ctx->last_n, hipMemcpyDeviceToHost));
+      int64_t need = 0;
+      for (int64_t v : ctx->h_need) need = v > need ? v : need;
+      int rc = grow_arena(ctx, need);
+      if (rc) return rc;
+    }
+    ctx->err = "tile arena overflow: arena regrown, submit the batch again";
+    return RR_E_ARENA;
+  }
+  return RR_OK;
+}
+
+int run_host(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
+             const rr_prepass_out* pre_out) {
+  for (int attempt = 0;; attempt++) {
+    int rc = host_submit(ctx, 0, n, pre, in, out, pre_out);
+    if (rc) return rc;
+    rc = host_wait(ctx, 0);
+    if (rc != RR_E_ARENA || attempt == 2) return rc;
+  }
+}
+
+}  // namespace
+
+extern "C" {
 
 int rr_render_frames(rr_ctx* ctx, int32_t n, const rr_frame_in* in, const rr_frame_out* out) {
   if (!ctx) return RR_E_ARG;
@@ -2876,11 +3022,6 @@ int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_
     ctx->err = "bad pre-pass batch";
     return RR_E_ARG;
   }
-  for (int f = 0; f < n; f++)
-    if (!out[f].rainy_bg) {
-      ctx->err = "pre-pass: null rainy_bg output";
-      return RR_E_ARG;
-    }
   return run_host(ctx, n, in, nullptr, nullptr, out);
 }
 
@@ -2892,6 +3033,39 @@ int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const r
     return RR_E_ARG;
   }
   return run_host(ctx, n, pre, in, out, pre_out);
+}
+
+int rr_pipeline_submit(rr_ctx* ctx, int32_t slot, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
+                       const rr_prepass_out* pre_out) {
+  if (!ctx) return RR_E_ARG;
+  if (!in || !out) {
+    ctx->err = "bad pipeline batch";
+    return RR_E_ARG;
+  }
+  return host_submit(ctx, slot, n, pre, in, out, pre_out);
+}
+
+int rr_pipeline_wait(rr_ctx* ctx, int32_t slot) {
+  if (!ctx) return RR_E_ARG;
+  return host_wait(ctx, slot);
+}
+
+int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes) {
+  if (!ctx) return RR_E_ARG;
+  if (!out || bytes <= 0) {
+    ctx->err = "rr_host_alloc: bad argument";
+    return RR_E_ARG;
+  }
+  *out = nullptr;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  return RR_OK;
+}
+
+int rr_host_free(rr_ctx* ctx, void* p) {
+  if (!ctx) return RR_E_ARG;
+  if (p) HIPCHK(hipHostFree(p));
+  return RR_OK;
 }
 
 int rr_prepass_frames_device(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_prepass_out* out, void* stream) {
@@ -2908,13 +3082,8 @@ int rr_set_prepass_kernels(rr_ctx* ctx, const rr_prepass_kernels* k) {
     return RR_E_ARG;
   }
   static_assert(RR_MAX_TAPS == rrpre::KMAX, "tap capacity");
-  ctx->pk.fog_k = k->fog_ksize;
-  ctx->pk.env_k = k->env_ksize;
-  for (int i = 0; i < RR_MAX_TAPS; i++) {
-    ctx->pk.fog_w[i] = i < k->fog_ksize ? k->fog_w[i] : 0.0;
-    ctx->pk.env_w[i] = i < k->env_ksize ? k->env_w[i] : 0.0;
-  }
-  // scipy.ndimage.correlate1d (the oracle's convolution) folds symmetric kernels; anything else is refused
+  // scipy.ndimage.correlate1d (the oracle's convolution) folds symmetric kernels; anything else is refused --
+  // BEFORE the context is touched
   for (int i = 0; i < k->fog_ksize / 2; i++)
     if (k->fog_w[i] != k->fog_w[k->fog_ksize - 1 - i]) {
       ctx->err = "rr_set_prepass_kernels: fog kernel is not symmetric";
@@ -2925,6 +3094,12 @@ int rr_set_prepass_kernels(rr_ctx* ctx, const rr_prepass_kernels* k) {
       ctx->err = "rr_set_prepass_kernels: envmap kernel is not symmetric";
       return RR_E_ARG;
     }
+  ctx->pk.fog_k = k->fog_ksize;
+  ctx->pk.env_k = k->env_ksize;
+  for (int i = 0; i < RR_MAX_TAPS; i++) {
+    ctx->pk.fog_w[i] = i < k->fog_ksize ? k->fog_w[i] : 0.0;
+    ctx->pk.env_w[i] = i < k->env_ksize ? k->env_w[i] : 0.0;
+  }
   ctx->have_pk = true;
   return RR_OK;
 }

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'librainhip.so')
 
 RR_MAX_FOV = 32
 RR_E_ARENA = -5
+RR_PIPE_SLOTS = 3
 RR_OPT_DEDUP, RR_OPT_GENERAL_FOV, RR_OPT_FOV_THREADS, RR_OPT_FOV_DROPS_PER_THREAD = 1, 2, 3, 4
 
 # numpy mirror of rr_drop (112 bytes)
@@ -77,7 +78,8 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_profile_reset', 'rr_profile_read', 'rr_sizeof_drop', 'rr_sizeof_camera', 'rr_sizeof_frame_in',
            'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
-           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option']
+           'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option',
+           'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free']
 
 _lib = None
 
@@ -122,6 +124,11 @@ def load_library(path=None):
                                        ctypes.POINTER(rr_prepass_out)]
     lib.rr_batch_counts.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     lib.rr_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    lib.rr_pipeline_submit.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(rr_prepass_in),
+                                       ctypes.POINTER(rr_frame_in), ctypes.POINTER(rr_frame_out), ctypes.POINTER(rr_prepass_out)]
+    lib.rr_pipeline_wait.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.rr_host_alloc.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64]
+    lib.rr_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                        ctypes.c_void_p, ctypes.c_void_p]
     assert lib.rr_sizeof_prepass_in() == ctypes.sizeof(rr_prepass_in)
@@ -288,8 +295,86 @@ class RainHip:
 
     def close(self):
         if self.h:
+            for s in range(RR_PIPE_SLOTS):
+                self.lib.rr_pipeline_wait(self.h, s)
+            self._inflight = {}
+            for p in getattr(self, '_pinned', []):
+                self.lib.rr_host_free(self.h, ctypes.c_void_p(p))
+            self._pinned = []
             self.lib.rr_destroy(self.h)
             self.h = None
+
+    # ---- pinned host memory + asynchronous pipeline -------------------------------------------
+    def host_array(self, shape, dtype):
+        """numpy array over page-locked memory (rr_host_alloc): what the asynchronous pipeline moves at PCIe rate.
+        Lives until close()."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        ptr = ctypes.c_void_p()
+        self._check(self.lib.rr_host_alloc(self.h, ctypes.byref(ptr), max(n, 1)), 'rr_host_alloc')
+        if not hasattr(self, '_pinned'):
+            self._pinned = []
+        self._pinned.append(ptr.value)
+        buf = (ctypes.c_uint8 * max(n, 1)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def pipeline_submit(self, slot, frames, outs):
+        """rr_pipeline_submit: frames as for pipeline_frames (dict(bg | bg_u8, depth, fog, omega, drops, ...)), or as for
+        render_frames (dict(bg, rainy_bg, env_xyY, omega, drops)) when they carry no 'depth'; outs: list of
+        dict(image_u8[, mask][, mask_i32][, rainy_bg][, status]) of caller-owned arrays (ideally from host_array)
+        that the library fills.  Nothing may be touched until pipeline_wait(slot)."""
+        n = len(frames)
+        with_pre = 'depth' in frames[0]
+        pin = (rr_prepass_in * n)() if with_pre else None
+        fin = (rr_frame_in * n)()
+        fout = (rr_frame_out * n)()
+        keep = []
+        We = self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width') if with_pre else 0
+        for k, (fr, o) in enumerate(zip(frames, outs)):
+            om = np.ascontiguousarray(fr['omega'], np.float64)
+            drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
+            if with_pre:
+                bg = self._fill_prepass(pin[k], fr, keep)
+                H, W = bg.shape[:2]
+                fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, H, We
+                fin[k].bg = None
+            else:
+                bg = np.ascontiguousarray(fr['bg'], np.float64)
+                rb = np.ascontiguousarray(fr['rainy_bg'], np.float64)
+                env = np.ascontiguousarray(fr['env_xyY'], np.float64)
+                H, W = bg.shape[:2]
+                fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, om.shape[0], om.shape[1]
+                fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY = _ptr(bg), _ptr(rb), _ptr(env)
+                keep.append((bg, rb, env))
+            fin[k].omega = _ptr(om)
+            fin[k].drops = _ptr(drops) if len(drops) else None
+            fin[k].n_drops = len(drops)
+            fin[k].strategy = int(fr.get('strategy', 0))
+            fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
+            for name, dt in (('image_u8', np.uint8), ('mask', np.float64), ('mask_i32', np.int32), ('rainy_bg', np.float64),
+                             ('status', np.int32)):
+                a = o.get(name)
+                assert a is None or (a.dtype == dt and a.flags['C_CONTIGUOUS']), name
+            assert o['image_u8'].shape == (H, W, 3)
+            fout[k].rainy_rgb = _ptr(o['image_u8'])
+            fout[k].rainy_bg_out = _ptr(o.get('rainy_bg'))
+            fout[k].mask_f64 = _ptr(o.get('mask'))
+            fout[k].mask_i32 = _ptr(o.get('mask_i32'))
+            fout[k].drop_status = _ptr(o.get('status')) if len(drops) else None
+            keep.append((om, drops))
+        self._check(self.lib.rr_pipeline_submit(self.h, int(slot), n, pin, fin, fout, None), 'rr_pipeline_submit')
+        if not hasattr(self, '_inflight'):
+            self._inflight = {}
+        self._inflight[int(slot)] = (pin, fin, fout, keep, outs)
+
+    def pipeline_wait(self, slot):
+        """True when the batch of `slot` is complete; False when the tile arena had to grow (submit the batch again)."""
+        rc = self.lib.rr_pipeline_wait(self.h, int(slot))
+        getattr(self, '_inflight', {}).pop(int(slot), None)
+        if rc == RR_E_ARENA:
+            return False
+        self._check(rc, 'rr_pipeline_wait')
+        return True
 
     def __del__(self):
         try:

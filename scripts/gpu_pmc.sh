@@ -5,7 +5,7 @@ TAG=$1; BARGS=$2; shift 2
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prepass $BARGS"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --inner $BARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 i=0
 for C in "$@"; do

@@ -14,13 +14,13 @@ cat $OUT/${TAG}_tests.log
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
-  timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prepass $line 2> $OUT/${TAG}_bench$i.err | tail -1 > $OUT/${TAG}_bench$i.json
+  timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prepass --no-variants --no-traffic $line 2> $OUT/${TAG}_bench$i.err | tail -1 > $OUT/${TAG}_bench$i.json
   python - <<PY
 import json
 try:
     d = json.load(open("$OUT/${TAG}_bench$i.json"))
     print("bench[$line]: %.0f frames/s  %.2f ms/step" % (d['value'], d['ms_per_step']))
-    print("   ", {k: round(v, 3) for k, v in d['kernels_ms_per_step'].items()})
+    print("   ", {k: round(v, 3) for k, v in d['kernels_ms_per_call'].items()})
 except Exception as e:
     print("bench[$line] failed:", e); print(open("$OUT/${TAG}_bench$i.err").read()[-2000:])
 PY

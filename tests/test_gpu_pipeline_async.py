@@ -1,0 +1,96 @@
+"""GPU tier: the asynchronous host-pointer pipeline (rr_pipeline_submit / rr_pipeline_wait, pinned buffers from
+rr_host_alloc) and the tile-arena regrowth protocol (RR_E_ARENA -> submit again)."""
+import numpy as np
+import pytest
+
+import helpers as h
+import test_gpu_edge_cases as edge
+import test_gpu_prepass as tp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_async_pipeline_equals_synchronous_call(tmp_path, built):
+    """Six frames as three two-frame batches in flight at once (three slots, pinned inputs and outputs) against
+    rr_pipeline_frames on the same frames: identical bits."""
+    H, W = 96, 160
+    sc = h.Scene(tmp_path, H, W, 150, n_frames=6, seed0=31)
+    rh = h.hb.RainHip(0)
+    try:
+        rh.set_streak_db(sc.db.streaks_light)
+        rh.set_camera(sc.cam)
+        consts, We = tp._setup(rh, H, W, 25)
+        frames = []
+        for i in range(6):
+            bg, depth = tp._scene(H, W, 31 + i)
+            bg8 = rh.host_array((H, W, 3), np.uint8)
+            bg8[...] = (bg * 255).astype(np.uint8)
+            dep = rh.host_array((H, W), np.float32)
+            dep[...] = depth.astype(np.float32)
+            frames.append(dict(bg_u8=bg8, depth=dep, fog=consts, omega=sc.omega, drops=sc.product_drops(i)))
+        ref = rh.pipeline_frames(frames, want_mask_i32=True)
+        outs = [dict(image_u8=rh.host_array((H, W, 3), np.uint8), mask_i32=rh.host_array((H, W), np.int32),
+                     mask=rh.host_array((H, W), np.float64), status=np.zeros(len(frames[i]['drops']), np.int32))
+                for i in range(6)]
+        for slot in range(3):
+            rh.pipeline_submit(slot, frames[2 * slot:2 * slot + 2], outs[2 * slot:2 * slot + 2])
+        with pytest.raises(RuntimeError):                       # a slot in flight cannot be reused
+            rh.pipeline_submit(0, frames[:2], outs[:2])
+        for slot in range(3):
+            assert rh.pipeline_wait(slot)
+        for o, r in zip(outs, ref):
+            for k in ('image_u8', 'mask_i32', 'mask', 'status'):
+                assert np.array_equal(o[k], r[k]), k
+        # image + int32 mask only (what a driver downloads): the float64 mask is optional
+        o2 = [dict(image_u8=rh.host_array((H, W, 3), np.uint8), mask_i32=rh.host_array((H, W), np.int32)) for _ in range(2)]
+        rh.pipeline_submit(1, frames[:2], o2)
+        assert rh.pipeline_wait(1)
+        assert np.array_equal(o2[1]['image_u8'], ref[1]['image_u8']) and np.array_equal(o2[1]['mask_i32'], ref[1]['mask_i32'])
+    finally:
+        rh.close()
+
+
+def _defocused_frames(n):
+    """n streaks 12 cm from the lens: circle of confusion ~10 px, effective tiles of several thousand pixels each."""
+    d = []
+    for k in range(n):
+        x0, y0 = 8 + (k * 37) % 280, 6 + (k * 53) % 330
+        d.append(edge._drop(k, x0, y0, x0 + (k % 5) - 2, y0 + 30 + k % 25, 4.5 + (k % 3), 5.0 + (k % 4), 0.12 + 0.0005 * (k % 7)))
+    return [dict(id=0, t=2000, d=0, drops=d)]
+
+
+def test_arena_regrowth_mid_batch(tmp_path, built):
+    """A first batch whose tiles exceed the arena's initial capacity: the asynchronous entry reports RR_E_ARENA once
+    (arena regrown) and the re-submitted batch is complete; the synchronous entry retries internally.  Both equal the
+    host build of the kernel arithmetic."""
+    sc = h.Scene(tmp_path, edge.H, edge.W, 0, frames=_defocused_frames(420))
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    assert len(drops) >= 400
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    assert (emu['status'] == 0).sum() >= 400
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    rh = h.hb.RainHip(0)
+    try:
+        rh.set_streak_db(sc.db.streaks_light)
+        rh.set_camera(sc.cam)
+        out = dict(image_u8=np.zeros((edge.H, edge.W, 3), np.uint8), mask=np.zeros((edge.H, edge.W)),
+                   mask_i32=np.zeros((edge.H, edge.W), np.int32), status=np.zeros(len(drops), np.int32))
+        rh.pipeline_submit(0, [fr], [out])
+        assert rh.pipeline_wait(0) is False                     # arena overflow: regrown, batch incomplete
+        rh.pipeline_submit(0, [fr], [out])
+        assert rh.pipeline_wait(0) is True
+        for k in ('mask', 'mask_i32', 'status'):
+            assert np.array_equal(out[k], emu[k]), k
+        assert np.abs(out['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+    finally:
+        rh.close()
+    rh = h.hb.RainHip(0)                                        # fresh context, synchronous entry: retried inside
+    try:
+        rh.set_streak_db(sc.db.streaks_light)
+        rh.set_camera(sc.cam)
+        two = rh.render_frames([fr, fr])
+        for o in two:
+            assert np.array_equal(o['mask'], emu['mask']) and np.array_equal(o['status'], emu['status'])
+    finally:
+        rh.close()
