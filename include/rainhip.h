@@ -32,7 +32,10 @@ enum {
   RR_E_NO_DEVICE = -2,            /* no HIP device / not gfx950 */
   RR_E_HIP = -3,                  /* a HIP runtime call failed */
   RR_E_STATE = -4,                /* streak DB or camera not set */
-  RR_E_ARENA = -5                 /* tile arena overflow even after regrowth */
+  RR_E_ARENA = -5,                /* tile arena overflow: arena regrown, enqueue / submit the batch again */
+  RR_E_PARSE = -6,                /* rr_host_parse_particles: malformed file or missing / non-numeric attribute */
+  RR_E_UNSUPPORTED = -7           /* rr_host_parse_particles: XML construct outside the simulator's subset (DOCTYPE, CDATA,
+                                   * entity references): use a full XML parser */
 };
 
 /* per-drop status written to rr_frame_out.drop_status: 0 == composited.  The
@@ -239,6 +242,23 @@ int rr_profile_read(rr_ctx* ctx, rr_kernel_stat* out, int32_t cap);   /* returns
  * driver prepare frames on worker threads instead of the process-global generator. */
 int rr_host_drop_draws(uint32_t seed, int32_t n, const int32_t* tex_lo, const uint8_t* is_big, double noise_std,
                        int32_t* tex_index, double* noise);
+
+/* Host-only (no device, no ctx): the particles XML of the rain simulator -> flat records, replacing the reference's
+ * pure-Python walk (common/bad_weather.py:192-211).  Raw attribute values only; the derived fields (render scale, y flip,
+ * z sign, widths, ratio, rounding, the pid dictionary; bad_weather.py:208-241) stay with the caller.  Counts are always
+ * returned; records beyond the capacities are not stored (call again with larger arrays). */
+typedef struct {
+  int64_t id, t, d, rs;           /* frame attributes id, t (exposure), d (start time), rs (count) */
+  int64_t first_drop, n_drops;    /* its drops are records [first_drop, first_drop + n_drops) */
+} rr_particle_frame;
+typedef struct {
+  int64_t pid;
+  double wp1[3], wp2[3], wd1, wd2, ip1[2], ip2[2], iw1, iw2;
+} rr_particle;                    /* 120 bytes */
+int rr_host_parse_particles(const char* path, rr_particle_frame* frames, int64_t cap_frames, rr_particle* drops,
+                            int64_t cap_drops, int64_t* n_frames, int64_t* n_drops);
+int rr_sizeof_particle(void);
+int rr_sizeof_particle_frame(void);
 
 /* sizes, for binding self-checks */
 int rr_sizeof_drop(void);

@@ -129,6 +129,65 @@ def _bulk_vec(strings, k):
     return vals.reshape(len(strings), k)
 
 
+PARTICLE_FRAME_DTYPE = np.dtype([('id', '<i8'), ('t', '<i8'), ('d', '<i8'), ('rs', '<i8'), ('first_drop', '<i8'), ('n_drops', '<i8')])
+PARTICLE_DTYPE = np.dtype([('pid', '<i8'), ('wp1', '<f8', (3,)), ('wp2', '<f8', (3,)), ('wd1', '<f8'), ('wd2', '<f8'),
+                           ('ip1', '<f8', (2,)), ('ip2', '<f8', (2,)), ('iw1', '<f8'), ('iw2', '<f8')])
+
+
+def _read_particles_native(path):
+    """(frames, drops) record arrays from librainhip's rr_host_parse_particles; None when the file uses XML the
+    native parser leaves to a full parser (RR_E_UNSUPPORTED); raises on a malformed file."""
+    import ctypes
+    from .. import hip_backend
+    lib = hip_backend.load_library()
+    assert lib.rr_sizeof_particle() == PARTICLE_DTYPE.itemsize and lib.rr_sizeof_particle_frame() == PARTICLE_FRAME_DTYPE.itemsize
+    nf, nd = ctypes.c_int64(0), ctypes.c_int64(0)
+    cap_f, cap_d = 0, 0
+    frames, drops = np.zeros(0, PARTICLE_FRAME_DTYPE), np.zeros(0, PARTICLE_DTYPE)
+    for _ in range(2):                       # count, then fill
+        rc = lib.rr_host_parse_particles(os.fsencode(path), frames.ctypes.data_as(ctypes.c_void_p), cap_f,
+                                         drops.ctypes.data_as(ctypes.c_void_p), cap_d, ctypes.byref(nf), ctypes.byref(nd))
+        if rc == -7:                         # RR_E_UNSUPPORTED
+            return None
+        if rc != 0:
+            raise ValueError("rr_host_parse_particles(%s) failed with %d" % (path, rc))
+        if nf.value <= cap_f and nd.value <= cap_d:
+            return frames[:nf.value], drops[:nd.value]
+        cap_f, cap_d = nf.value, nd.value
+        frames, drops = np.zeros(cap_f, PARTICLE_FRAME_DTYPE), np.zeros(cap_d, PARTICLE_DTYPE)
+    raise RuntimeError("particles file changed while it was being read")
+
+
+def _read_particles_etree(path):
+    """The same records through xml.etree (files the native parser does not take)."""
+    simulation = parse(path).getroot()
+    fr_rows, chunks, n_tot = [], [], 0
+    for frame in simulation:
+        att = [d.attrib for d in frame]
+        n = len(att)
+        rec = np.zeros(n, PARTICLE_DTYPE)
+        if n:
+            rec['pid'] = [int(a["pid"]) for a in att]
+            rec['wp1'] = _bulk_vec([a["wp1"] for a in att], 3)
+            rec['wp2'] = _bulk_vec([a["wp2"] for a in att], 3)
+            rec['wd1'] = _bulk_vec([a['wd1'] for a in att], 1)[:, 0]
+            rec['wd2'] = _bulk_vec([a['wd2'] for a in att], 1)[:, 0]
+            rec['ip1'] = _bulk_vec([a["ip1"] for a in att], 2)
+            rec['ip2'] = _bulk_vec([a["ip2"] for a in att], 2)
+            rec['iw1'] = _bulk_vec([a['iw1'] for a in att], 1)[:, 0]
+            rec['iw2'] = _bulk_vec([a['iw2'] for a in att], 1)[:, 0]
+        fr_rows.append((int(frame.attrib['id']), int(frame.attrib['t']), int(frame.attrib['d']), int(frame.attrib['rs']), n_tot, n))
+        chunks.append(rec)
+        n_tot += n
+    frames = np.array(fr_rows, PARTICLE_FRAME_DTYPE) if fr_rows else np.zeros(0, PARTICLE_FRAME_DTYPE)
+    return frames, (np.concatenate(chunks) if chunks else np.zeros(0, PARTICLE_DTYPE))
+
+
+def _read_particles(path):
+    out = _read_particles_native(path)
+    return out if out is not None else _read_particles_etree(path)
+
+
 class DBManager:
     def __init__(self, streaks_path=None, streaks_path_xml=None, norm_coeff_path=None):
         """Same constructor as the reference (bad_weather.py:79-91)."""
@@ -180,13 +239,17 @@ class DBManager:
 
     def load_streaks_from_xml(self, dataset, settings, image_shape_WH, use_pickle=True, verbose=True):
         """reference bad_weather.py:148-248 (the pickle cache is read-only in the reference and
-        its call site passes use_pickle=False, generator.py:281; not implemented)."""
+        its call site passes use_pickle=False, generator.py:281; not implemented).
+
+        The file is read by the library's native parser (rr_host_parse_particles: raw attribute values, strtod /
+        strtoll -- the doubles Python's float() gives); an XML construct outside the simulator's subset (DOCTYPE,
+        CDATA, entity references) goes through xml.etree instead.  Everything derived follows in bulk below."""
         print('Reading particles file {}'.format(self.streaks_path_xml))
         if not os.path.exists(self.streaks_path_xml):
             print("No existing path for XML file (" + str(self.streaks_path_xml) + ")")
             sys.exit(-1)
         try:
-            simulation = parse(self.streaks_path_xml).getroot()
+            frames, drops = _read_particles(self.streaks_path_xml)
         except Exception:
             raise Exception("Reading XML file {} crashed, which is likely due to corrupted particles simulation "
                             "files. If so, delete this simulation folder manually and re-run to allow generation "
@@ -195,67 +258,58 @@ class DBManager:
         gan = dataset == 'nuscenes_gan'
         r_gan = np.mean((image_shape_WH[0] / 1600, image_shape_WH[1] / 900)) if gan else None
         try:
-            for frame in simulation:
+            # every drop of the file at once (bad_weather.py:208-241)
+            pid = drops['pid']
+            wps, wpe = drops['wp1'].copy(), drops['wp2'].copy()
+            iw = np.stack([drops['iw1'], drops['iw2']], axis=1)
+            if gan:
+                ips, ipe, iws = drops['ip1'] * r_gan, drops['ip2'] * r_gan, iw * r_gan
+            else:
+                ips, ipe, iws = drops['ip1'] / rs, drops['ip2'] / rs, iw / rs
+            ips[:, 1] = image_shape_WH[1] - ips[:, 1]
+            ipe[:, 1] = image_shape_WH[1] - ipe[:, 1]
+            wps[:, 2] *= -1
+            wpe[:, 2] *= -1
+            diff = np.abs(ips - ipe)
+            max_width = np.maximum(iws[:, 0], iws[:, 1]).astype(np.int64)     # int(max(..)) truncation
+            with np.errstate(all='ignore'):
+                nrm = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1])
+                dir2y = -(diff[:, 1] / nrm)
+                cos_theta = (diff[:, 0] / nrm) * 0 + dir2y * -1
+                actual_length = diff[:, 1] / cos_theta
+                ratio = max_width / actual_length
+            ipe_i = np.round(ipe).astype(np.int64)
+            ips_i = np.round(ips).astype(np.int64)
+            dd = (ips_i - ipe_i).astype(np.float64)
+            length = np.ceil(np.sqrt(dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1])).astype(np.int64)
+            dtype = np.where(max_width >= 4, 0, np.where(max_width > 1, 1, 2)).astype(np.int32)
+            keep = (max_width >= 1) & (length >= 1)
+            for fr in frames:
                 f = Frame()
-                f.id = int(frame.attrib['id'])
-                f.exposure_time = int(frame.attrib['t'])
-                f.starting_time = int(frame.attrib['d'])
-                f.streaks_count = int(frame.attrib['rs'])
-                drops = list(frame)
-                n = len(drops)
-                # all drops of a frame are converted in bulk (one strtod pass per attribute instead of
-                # ~20 Python float() calls per drop); same correctly rounded doubles
-                att = [d.attrib for d in drops]
-                pid = np.array([int(a["pid"]) for a in att], np.int64).reshape(n)
-                wps = _bulk_vec([a["wp1"] for a in att], 3)
-                wpe = _bulk_vec([a["wp2"] for a in att], 3)
-                wd = np.stack([_bulk_vec([a['wd1'] for a in att], 1)[:, 0], _bulk_vec([a['wd2'] for a in att], 1)[:, 0]], axis=1) \
-                    if n else np.zeros((0, 2))
-                ip1 = _bulk_vec([a["ip1"] for a in att], 2)
-                ip2 = _bulk_vec([a["ip2"] for a in att], 2)
-                iw = np.stack([_bulk_vec([a['iw1'] for a in att], 1)[:, 0], _bulk_vec([a['iw2'] for a in att], 1)[:, 0]], axis=1) \
-                    if n else np.zeros((0, 2))
-                if gan:
-                    ips, ipe, iws = ip1 * r_gan, ip2 * r_gan, iw * r_gan
-                else:
-                    ips, ipe, iws = ip1 / rs, ip2 / rs, iw / rs
-                ips[:, 1] = image_shape_WH[1] - ips[:, 1]
-                ipe[:, 1] = image_shape_WH[1] - ipe[:, 1]
-                wps[:, 2] *= -1
-                wpe[:, 2] *= -1
-                diff = np.abs(ips - ipe)
-                max_width = np.maximum(iws[:, 0], iws[:, 1]).astype(np.int64)     # int(max(..)) truncation
-                with np.errstate(all='ignore'):
-                    nrm = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1])
-                    dir2y = -(diff[:, 1] / nrm)
-                    cos_theta = (diff[:, 0] / nrm) * 0 + dir2y * -1
-                    actual_length = diff[:, 1] / cos_theta
-                    ratio = max_width / actual_length
-                ipe_i = np.round(ipe).astype(np.int64)
-                ips_i = np.round(ips).astype(np.int64)
-                dd = (ips_i - ipe_i).astype(np.float64)
-                length = np.ceil(np.sqrt(dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1])).astype(np.int64)
-                dtype = np.where(max_width >= 4, 0, np.where(max_width > 1, 1, 2)).astype(np.int32)
-                keep = (max_width >= 1) & (length >= 1)
-                # dict.update semantics: a repeated pid keeps its FIRST position, LAST value
-                order = {}
-                for k in np.nonzero(keep)[0]:
-                    order[int(pid[k])] = k
-                idx = np.fromiter(order.values(), dtype=np.int64, count=len(order))
-                t = StreakTable(len(idx))
-                t.pid[:] = pid[idx]
-                t.wps[:] = wps[idx]
-                t.wpe[:] = wpe[idx]
-                t.wd1[:] = wd[idx, 0]
-                t.wd2[:] = wd[idx, 1]
-                t.ips[:] = ips_i[idx]
-                t.ipe[:] = ipe_i[idx]
-                t.iw1[:] = iws[idx, 0]
-                t.iw2[:] = iws[idx, 1]
-                t.ratio[:] = ratio[idx]
-                t.max_width[:] = max_width[idx]
-                t.length[:] = length[idx]
-                t.type[:] = dtype[idx]
+                f.id, f.exposure_time, f.starting_time, f.streaks_count = int(fr['id']), int(fr['t']), int(fr['d']), int(fr['rs'])
+                a, n = int(fr['first_drop']), int(fr['n_drops'])
+                kept = a + np.nonzero(keep[a:a + n])[0]
+                p_f = pid[kept]
+                if len(np.unique(p_f)) != len(p_f):
+                    # dict.update semantics: a repeated pid keeps its FIRST position, LAST value
+                    order = {}
+                    for k in kept:
+                        order[int(pid[k])] = k
+                    kept = np.fromiter(order.values(), dtype=np.int64, count=len(order))
+                t = StreakTable(len(kept))
+                t.pid[:] = pid[kept]
+                t.wps[:] = wps[kept]
+                t.wpe[:] = wpe[kept]
+                t.wd1[:] = drops['wd1'][kept]
+                t.wd2[:] = drops['wd2'][kept]
+                t.ips[:] = ips_i[kept]
+                t.ipe[:] = ipe_i[kept]
+                t.iw1[:] = iws[kept, 0]
+                t.iw2[:] = iws[kept, 1]
+                t.ratio[:] = ratio[kept]
+                t.max_width[:] = max_width[kept]
+                t.length[:] = length[kept]
+                t.type[:] = dtype[kept]
                 f.table = t
                 self.streaks_simulator.update({f.id: f})
         except Exception:

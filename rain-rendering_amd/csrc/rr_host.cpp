@@ -117,3 +117,200 @@ extern "C" int rr_host_drop_draws(uint32_t seed, int32_t n, const int32_t* tex_l
   }
   return RR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// rr_host_parse_particles: the particles XML of the rain simulator (schema read by the reference's
+// DBManager.load_streaks_from_xml, common/bad_weather.py:192-211) -> flat records.
+//   root element: any name; its child elements are frames (attributes id, t, d, rs; tag names ignored);
+//   their child elements are drops (attributes pid, wp1, wp2 = "(x;y;z)", wd1, wd2, ip1, ip2 = "(x;y)", iw1, iw2).
+// Numbers are converted with strtod / strtoll: the same correctly rounded doubles Python's float() gives.
+// Only the raw attribute values are returned; everything derived (render scale, y flip, z sign, widths,
+// ratios, rounding, the pid dictionary) stays in the loader that calls this.
+// ---------------------------------------------------------------------------------------------------
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Attr {
+  const char* name;
+  size_t nlen;
+  const char* val;
+  size_t vlen;
+};
+
+bool attr_is(const Attr& a, const char* n) { return a.nlen == strlen(n) && memcmp(a.name, n, a.nlen) == 0; }
+
+// The file buffer is NUL-terminated, so strtoll / strtod run in place and stop at the field's delimiter.
+// whole-token integer like Python's int(str): optional surrounding blanks, optional sign, decimal digits
+bool parse_i64(const char* s, size_t n, int64_t& out) {
+  errno = 0;
+  char* end = nullptr;
+  long long v = strtoll(s, &end, 10);
+  if (end == s || errno || end > s + n) return false;
+  while (end < s + n && (*end == ' ' || *end == '\t' || *end == '\n' || *end == '\r')) end++;
+  if (end != s + n) return false;
+  out = (int64_t)v;
+  return true;
+}
+
+bool parse_f64(const char* s, size_t n, double& out) {
+  char* end = nullptr;
+  out = strtod(s, &end);
+  if (end == s || end > s + n) return false;
+  while (end < s + n && (*end == ' ' || *end == '\t' || *end == '\n' || *end == '\r')) end++;
+  return end == s + n;
+}
+
+// "(a;b;c)"[1:-1].split(';') -> k doubles (bad_weather.py:202-207)
+bool parse_vec(const char* s, size_t n, double* out, int k) {
+  if (n < 2) return false;
+  const char* p = s + 1;
+  const char* e = s + n - 1;
+  for (int i = 0; i < k; i++) {
+    const char* q = (const char*)memchr(p, ';', (size_t)(e - p));
+    const char* stop = q ? q : e;
+    if ((i < k - 1) != (q != nullptr)) return false;     // exactly k fields
+    if (!parse_f64(p, (size_t)(stop - p), out[i])) return false;
+    p = stop + 1;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int rr_host_parse_particles(const char* path, rr_particle_frame* frames, int64_t cap_frames, rr_particle* drops,
+                                       int64_t cap_drops, int64_t* n_frames, int64_t* n_drops) {
+  if (!path || !n_frames || !n_drops || cap_frames < 0 || cap_drops < 0 || (cap_frames > 0 && !frames) || (cap_drops > 0 && !drops))
+    return RR_E_ARG;
+  *n_frames = *n_drops = 0;
+  FILE* fh = fopen(path, "rb");
+  if (!fh) return RR_E_ARG;
+  std::vector<char> buf;
+  {
+    fseek(fh, 0, SEEK_END);
+    long sz = ftell(fh);
+    fseek(fh, 0, SEEK_SET);
+    if (sz < 0) { fclose(fh); return RR_E_ARG; }
+    buf.resize((size_t)sz + 1);
+    size_t got = fread(buf.data(), 1, (size_t)sz, fh);
+    fclose(fh);
+    buf[got] = 0;
+    buf.resize(got + 1);
+  }
+  const char* p = buf.data();
+  const char* end = p + buf.size() - 1;
+  int depth = 0;
+  int64_t nf = 0, nd = 0;
+  std::vector<Attr> attrs;
+  while (p < end) {
+    const char* lt = (const char*)memchr(p, '<', (size_t)(end - p));
+    if (!lt) break;
+    p = lt + 1;
+    if (p >= end) return RR_E_PARSE;
+    if (*p == '?') {                                         // <? ... ?>
+      const char* q = strstr(p, "?>");
+      if (!q) return RR_E_PARSE;
+      p = q + 2;
+      continue;
+    }
+    if (*p == '!') {
+      if (end - p >= 3 && p[1] == '-' && p[2] == '-') {      // <!-- ... -->
+        const char* q = strstr(p, "-->");
+        if (!q) return RR_E_PARSE;
+        p = q + 3;
+        continue;
+      }
+      return RR_E_UNSUPPORTED;                               // DOCTYPE / CDATA: leave it to a full XML parser
+    }
+    if (*p == '/') {                                         // </name>
+      const char* q = (const char*)memchr(p, '>', (size_t)(end - p));
+      if (!q || depth <= 0) return RR_E_PARSE;
+      depth--;
+      p = q + 1;
+      continue;
+    }
+    // element: name, attributes, '>' or '/>'
+    while (p < end && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r' && *p != '>' && *p != '/') p++;
+    attrs.clear();
+    bool self_close = false;
+    for (;;) {
+      while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+      if (p >= end) return RR_E_PARSE;
+      if (*p == '>') { p++; break; }
+      if (*p == '/') {
+        if (p + 1 >= end || p[1] != '>') return RR_E_PARSE;
+        self_close = true;
+        p += 2;
+        break;
+      }
+      Attr a;
+      a.name = p;
+      while (p < end && *p != '=' && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r' && *p != '>') p++;
+      a.nlen = (size_t)(p - a.name);
+      while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+      if (p >= end || *p != '=') return RR_E_PARSE;
+      p++;
+      while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+      if (p >= end || (*p != '"' && *p != '\'')) return RR_E_PARSE;
+      const char quote = *p++;
+      a.val = p;
+      const char* q = (const char*)memchr(p, quote, (size_t)(end - p));
+      if (!q) return RR_E_PARSE;
+      a.vlen = (size_t)(q - p);
+      if (memchr(a.val, '&', a.vlen)) return RR_E_UNSUPPORTED;      // entity references: full XML parser
+      p = q + 1;
+      attrs.push_back(a);
+    }
+    const int level = depth;                                  // 0: root, 1: frame, 2: drop, deeper: ignored
+    if (!self_close) depth++;
+    if (level == 1) {
+      rr_particle_frame fr;
+      memset(&fr, 0, sizeof(fr));
+      int have = 0;
+      for (const Attr& a : attrs) {
+        int64_t* dst = attr_is(a, "id") ? &fr.id : attr_is(a, "t") ? &fr.t : attr_is(a, "d") ? &fr.d : attr_is(a, "rs") ? &fr.rs : nullptr;
+        if (!dst) continue;
+        if (!parse_i64(a.val, a.vlen, *dst)) return RR_E_PARSE;
+        have |= attr_is(a, "id") ? 1 : attr_is(a, "t") ? 2 : attr_is(a, "d") ? 4 : 8;
+      }
+      if (have != 15) return RR_E_PARSE;                      // a missing attribute is a KeyError in the reference
+      fr.first_drop = nd;
+      fr.n_drops = 0;
+      if (nf < cap_frames) frames[nf] = fr;
+      nf++;
+    } else if (level == 2) {
+      rr_particle d;
+      memset(&d, 0, sizeof(d));
+      int have = 0;
+      for (const Attr& a : attrs) {
+        bool ok = true;
+        if (attr_is(a, "pid")) { ok = parse_i64(a.val, a.vlen, d.pid); have |= 1; }
+        else if (attr_is(a, "wp1")) { ok = parse_vec(a.val, a.vlen, d.wp1, 3); have |= 2; }
+        else if (attr_is(a, "wp2")) { ok = parse_vec(a.val, a.vlen, d.wp2, 3); have |= 4; }
+        else if (attr_is(a, "wd1")) { ok = parse_f64(a.val, a.vlen, d.wd1); have |= 8; }
+        else if (attr_is(a, "wd2")) { ok = parse_f64(a.val, a.vlen, d.wd2); have |= 16; }
+        else if (attr_is(a, "ip1")) { ok = parse_vec(a.val, a.vlen, d.ip1, 2); have |= 32; }
+        else if (attr_is(a, "ip2")) { ok = parse_vec(a.val, a.vlen, d.ip2, 2); have |= 64; }
+        else if (attr_is(a, "iw1")) { ok = parse_f64(a.val, a.vlen, d.iw1); have |= 128; }
+        else if (attr_is(a, "iw2")) { ok = parse_f64(a.val, a.vlen, d.iw2); have |= 256; }
+        if (!ok) return RR_E_PARSE;
+      }
+      if (have != 511) return RR_E_PARSE;
+      if (nd < cap_drops) drops[nd] = d;
+      if (nf >= 1 && nf <= cap_frames) frames[nf - 1].n_drops++;
+      nd++;
+    }
+  }
+  if (depth != 0) return RR_E_PARSE;
+  *n_frames = nf;
+  *n_drops = nd;
+  return RR_OK;
+}
+
+extern "C" int rr_sizeof_particle(void) { return (int)sizeof(rr_particle); }
+extern "C" int rr_sizeof_particle_frame(void) { return (int)sizeof(rr_particle_frame); }

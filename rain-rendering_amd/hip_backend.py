@@ -79,7 +79,8 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
            'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option',
-           'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free']
+           'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
+           'rr_sizeof_particle', 'rr_sizeof_particle_frame']
 
 _lib = None
 
@@ -129,6 +130,8 @@ def load_library(path=None):
     lib.rr_pipeline_wait.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.rr_host_alloc.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64]
     lib.rr_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_host_parse_particles.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                        ctypes.c_void_p, ctypes.c_void_p]
     assert lib.rr_sizeof_prepass_in() == ctypes.sizeof(rr_prepass_in)

@@ -152,20 +152,22 @@ def simulate_particles(n_frames, n_drops, W, H, focal_mm=6.0, pix_um=4.65, expos
 def write_particles_xml(path, frames):
     """The schema load_streaks_from_xml reads (reference bad_weather.py:192-211): the root's
     children are frames (attributes id, t, d, rs); their children are drops (pid, wp1, wp2,
-    wd1, wd2, ip1, ip2, iw1, iw2); vectors are "(a;b;c)"."""
+    wd1, wd2, ip1, ip2, iw1, iw2); vectors are "(a;b;c)".  Numbers are written with 17 significant
+    digits (they parse back to the same doubles), formatted a frame at a time."""
     os.makedirs(os.path.dirname(path), exist_ok=True)
-
-    def vec(v):
-        return '(' + ';'.join(repr(float(c)) for c in v) + ')'
-
+    fmt = ('    <streak pid="%d" wp1="(%.17g;%.17g;%.17g)" wp2="(%.17g;%.17g;%.17g)" wd1="%.17g" wd2="%.17g" '
+           'ip1="(%.17g;%.17g)" ip2="(%.17g;%.17g)" iw1="%.17g" iw2="%.17g"/>')
     with open(path, 'w') as fh:
         fh.write('<?xml version="1.0" ?>\n<simulation>\n')
         for fr in frames:
-            fh.write('  <frame id="%d" t="%d" d="%d" rs="%d">\n' % (fr['id'], fr['t'], fr['d'], len(fr['drops'])))
-            for d in fr['drops']:
-                fh.write('    <streak pid="%d" wp1="%s" wp2="%s" wd1="%r" wd2="%r" ip1="%s" ip2="%s" iw1="%r" iw2="%r"/>\n'
-                         % (d['pid'], vec(d['wp1']), vec(d['wp2']), float(d['wd1']), float(d['wd2']),
-                            vec(d['ip1']), vec(d['ip2']), float(d['iw1']), float(d['iw2'])))
+            ds = fr['drops']
+            fh.write('  <frame id="%d" t="%d" d="%d" rs="%d">\n' % (fr['id'], fr['t'], fr['d'], len(ds)))
+            if ds:
+                rows = [(d['pid'],) + tuple(float(c) for c in d['wp1']) + tuple(float(c) for c in d['wp2']) +
+                        (float(d['wd1']), float(d['wd2'])) + tuple(float(c) for c in d['ip1']) + tuple(float(c) for c in d['ip2']) +
+                        (float(d['iw1']), float(d['iw2'])) for d in ds]
+                fh.write('\n'.join(fmt % r for r in rows))
+                fh.write('\n')
             fh.write('  </frame>\n')
         fh.write('</simulation>\n')
     return path

@@ -154,3 +154,50 @@ def test_fast_png_writer_is_pixel_identical(tmp_path):
         finally:
             del os.environ['RAIN_PNG_WRITER']
         assert np.array_equal(np.array(Image.open(q)), np.array(Image.open(q2)))
+
+
+def test_native_particles_parser_equals_etree(tmp_path):
+    """rr_host_parse_particles against xml.etree on the same file: attribute order, quoting style, comments,
+    blanks inside numbers' fields, non-self-closing drops with ignored children, repeated pids, empty frames;
+    constructs outside the simulator's subset are handed to the full parser; malformed files are errors."""
+    bw = h.bw
+    xml = tmp_path / 'p.xml'
+    xml.write_text("""<?xml version="1.0" ?>
+<!-- header comment -->
+<sim>
+  <f id="3" t="2000" d="0" rs="4">
+    <s pid="7" wp1="(0.5;-0.25;-3.0)" wp2="(0.5;-0.26;-2.99)" wd1="0.002" wd2="0.002" ip1="(100.25;50.5)" ip2="(101.0;20.125)" iw1="2.5" iw2="2.75"/>
+    <s iw2='1.5' iw1='1.25' ip2='( 11.0 ; 29.0 )' ip1='(10.0;60.0)' wd2='1e-3' wd1='1e-3' wp2='(1;2;-3e0)' wp1='(1;2.0;-3.01)' pid=' 9 ' ></s>
+    <s pid="7" wp1="(0.1;0.2;-4.0)" wp2="(0.1;0.19;-3.99)" wd1="0.003" wd2="0.003" ip1="(30.0;70.0)" ip2="(31.0;40.0)" iw1="4.5" iw2="5.0"><extra k="v"/></s>
+    <!-- a drop too thin to keep -->
+    <s pid="11" wp1="(0;0;-9)" wp2="(0;0;-9)" wd1="0.001" wd2="0.001" ip1="(5.0;5.0)" ip2="(5.0;4.0)" iw1="0.4" iw2="0.3"/>
+  </f>
+  <g rs="0" d="100000" t="2000" id="4"/>
+</sim>
+""")
+    fr_n, dr_n = bw._read_particles_native(str(xml))
+    fr_e, dr_e = bw._read_particles_etree(str(xml))
+    assert fr_n.tolist() == fr_e.tolist() == [(3, 2000, 0, 4, 0, 4), (4, 2000, 100000, 0, 4, 0)]
+    assert dr_n.tobytes() == dr_e.tobytes() and len(dr_n) == 4
+    assert dr_n['pid'].tolist() == [7, 9, 7, 11] and dr_n['wp1'][1].tolist() == [1.0, 2.0, -3.01]
+    db = bw.DBManager(streaks_path_xml=str(xml))
+    db.load_streaks_from_xml('kitti', {"render_scale": 1}, [160, 96], use_pickle=False, verbose=False)
+    t = db.streaks_simulator[3].table
+    assert t.pid.tolist() == [7, 9] and t.iw1.tolist() == [4.5, 1.25]           # pid 7: first position, last value
+    assert len(db.streaks_simulator[4].table) == 0
+    # outside the subset -> None (the loader then uses xml.etree)
+    ent = tmp_path / 'e.xml'
+    ent.write_text(xml.read_text().replace('<sim>', '<sim note="a &amp; b">'))
+    assert bw._read_particles_native(str(ent)) is None
+    assert bw._read_particles(str(ent))[1].tobytes() == dr_e.tobytes()
+    # malformed -> error
+    bad = tmp_path / 'b.xml'
+    bad.write_text(xml.read_text().replace('wd1="0.002"', 'wd1="abc"'))
+    with pytest.raises(ValueError):
+        bw._read_particles_native(str(bad))
+    bad.write_text(xml.read_text().replace(' iw2="2.75"', ''))                    # KeyError in the reference
+    with pytest.raises(ValueError):
+        bw._read_particles_native(str(bad))
+    bad.write_text(xml.read_text().replace('</sim>', ''))
+    with pytest.raises(ValueError):
+        bw._read_particles_native(str(bad))
