@@ -107,6 +107,12 @@ typedef struct {
   double* mask_f64;               /* H*W: rainy_mask accumulator (bad_weather.py:450); may be NULL */
   int32_t* mask_i32;              /* H*W: floor(mask_f64 * 255)  (SURVEY decision D1); may be NULL */
   int32_t* drop_status;           /* n_drops RR_DROP_* codes (may be NULL) */
+  /* Optional: the two PNG files the reference writes per frame (generator.py:466-467), as PNG
+   * scanlines ready for deflate: H rows of 1 + 4*W bytes = filter byte 1 (Sub) + the Sub-filtered RGBA pixels.
+   * rainy_png: plt.imsave(rainy_image) (alpha 255); mask_png: plt.imsave(rainy_mask) = (mask - min) / (max - min) through
+   * the 256-entry colour map given to rr_set_colormap (needs mask_f64 in the device-pointer entry points). */
+  uint8_t* rainy_png;
+  uint8_t* mask_png;
 } rr_frame_out;
 
 typedef struct {
@@ -133,6 +139,8 @@ int rr_set_streak_db(rr_ctx* ctx, const uint8_t* texels, const int32_t* tex_h, c
 int rr_set_streak_db_device(rr_ctx* ctx, const uint8_t* texels_dev, int64_t n_bytes, const int32_t* tex_h,
                             const int32_t* tex_w, const int64_t* tex_off, int32_t n_tex);
 int rr_set_camera(rr_ctx* ctx, const rr_camera* cam);
+/* 256 RGBA byte entries of the colour map plt.imsave applies to rainy_mask (matplotlib's default: viridis). */
+int rr_set_colormap(rr_ctx* ctx, const uint8_t* lut_rgba);
 
 /* Render n frames (all with identical H,W,He,We).  Pointers inside `in`/`out` are HOST
  * pointers; the call uploads, renders, downloads and returns after completion. */

@@ -69,9 +69,10 @@ class StreakTable:
         return len(self.pid)
 
     def take(self, idx):
+        """A new table (own storage, also for slices) of the rows idx."""
         t = StreakTable(0)
         for k in self.FIELDS:
-            setattr(t, k, getattr(self, k)[idx])
+            setattr(t, k, np.array(getattr(self, k)[idx], copy=True))
         return t
 
     def streak(self, i):

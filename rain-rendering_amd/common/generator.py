@@ -5,9 +5,10 @@ compute_drop -> add_drop_to_image) is replaced by ONE call per batch of frames i
 library (rr_render_frames); everything around it (file walking, conflict strategy, seeding,
 streak filter, pre-pass, saving) follows the reference.
 
-Multi-GPU: started under torch.distributed.run (or with RANK/WORLD_SIZE set) every rank
+Multi-GPU: started under torch.distributed.run (or with RANK/WORLD_SIZE/MASTER_* set) every rank
 renders frames idx[rank::world] of each sequence on its own GPU; the streak database is
-packed on rank 0 and broadcast once (sharding.broadcast_streak_db); no other collective.
+packed on rank 0 and broadcast once (sharding.broadcast_streak_db); no other collective on the
+data path (rank 0 also decides the output folder name, one small object broadcast per sequence).
 """
 import os
 import sys
@@ -60,12 +61,11 @@ class Generator:
         self.irrad_type = 'ambient'
         self.db = None
         self.renderer = None
-        self.batch = int(os.environ.get('RAIN_BATCH', '4'))
+        self.batch = int(os.environ.get('RAIN_BATCH', '32'))      # frames per library call (three calls in flight)
         self.rank, self.world = sharding.rank_world()
         self.device = int(getattr(args, 'device', os.environ.get('LOCAL_RANK', '0')))
         self._hip = None
         self._pool = None
-        self._saves = []
         self.stats = []
         if self.rendering_strategy not in (None, 'white'):
             raise NotImplementedError("rendering_strategy %r: 'naive_db' reads a non-existent attribute in the reference "
@@ -94,26 +94,27 @@ class Generator:
         return self._hip
 
     def _io_pool(self):
-        """Threads for PNG decode / encode (PIL's codecs release the GIL).  SURVEY 8f next #3: the host I/O
+        """Threads for PNG decode / deflate (PIL's decoder and zlib release the GIL).  SURVEY 8f next #3: the host I/O
         around the GPU call is what bounds the driver end to end, so it runs ahead of / behind the GPU."""
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 4))))
+            self._pool = ThreadPoolExecutor(max_workers=max(2, min(int(os.environ.get('RAIN_IO_THREADS', '96')), (os.cpu_count() or 4))))
         return self._pool
 
-    def _pack(self, frame, imW, imH, seed):
-        """Frame filter + drop table with the frame's random draws (generator.py:318,413-425)."""
-        keep = hip_backend.filter_streaks(frame.table, imW, imH)                    # generator.py:413-420
+    def _pack(self, pristine, imW, imH, seed, earlier_seeds=()):
+        """Frame filter + drop table with the frame's random draws (generator.py:318,413-425) on a private copy of the
+        simulator frame's table.  With angular noise the reference rotates the streak end points IN the shared table
+        (generator.py:152-161), so a frame that re-uses a simulator frame sees the rotations of the earlier frames of
+        the run that used it: `earlier_seeds` replays those (same draws, same order) first.  The result therefore
+        equals the reference's sequential run, does not depend on how frames are sharded over GPUs, and can be
+        computed on any thread."""
+        table = pristine.take(slice(None))
+        for s_ in earlier_seeds:
+            keep = hip_backend.filter_streaks(table, imW, imH)
+            hip_backend.pack_drops(table, keep, self.db, self.noise_std, self.noise_scale, seed=s_)
+        keep = hip_backend.filter_streaks(table, imW, imH)                          # generator.py:413-420
         assert len(keep) <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
-        return hip_backend.pack_drops(frame.table, keep, self.db, self.noise_std, self.noise_scale, seed=seed)
-
-    def _prepare_frame(self, image_file, depth_file, rs, seed, frame, imW, imH, pack):
-        """Worker-thread part of one frame: decode image + depth and (when no state is shared between
-        frames) build the drop table from the library's own per-frame generator."""
-        loaded = self._load_frame(image_file, depth_file, rs)
-        if loaded is None:
-            return None
-        return loaded[0], loaded[1], (self._pack(frame, imW, imH, seed) if pack else None)
+        return hip_backend.pack_drops(table, keep, self.db, self.noise_std, self.noise_scale, seed=seed)
 
     def _load_frame(self, image_file, depth_file, rs):
         """Image and depth of one frame as Generator.run reads them (generator.py:352-384)."""
@@ -135,43 +136,53 @@ class Generator:
         ds = self.settings["depth_scale"]
         depthHW = np.array([int((depth.shape[0] * ds) // rs), int((depth.shape[1] * ds) // rs)])
         if not np.all(depth.shape[:2] == depthHW):
-            depth = imgops.resize_linear(depth.astype(np.float64), int(depthHW[1]), int(depthHW[0]))
+            # cv2.resize keeps the depth's own type (float32 for PNG depth): so does the fog pre-pass that follows
+            dt = depth.dtype if depth.dtype in (np.float32, np.float64) else np.float64
+            depth = imgops.resize_linear(depth, int(depthHW[1]), int(depthHW[0])).astype(dt)
         assert np.all(np.array(depth.shape[:2]) <= np.array(bg.shape[:2])), "Depth cannot be larger than the image"
         if not np.all(np.array(depth.shape[:2]) == np.array(bg.shape[:2])):
             bg = my_utils.crop_center(bg, depth.shape[0], depth.shape[1])
         return np.ascontiguousarray(bg), depth
 
-    def _save_frame(self, p, o):
-        os.makedirs(os.path.dirname(p['out_rainy_path']), exist_ok=True)
-        os.makedirs(os.path.dirname(p['out_rainy_mask_path']), exist_ok=True)
-        imgops.imsave_rgb(p['out_rainy_path'], o['image_u8'])                      # generator.py:466
-        imgops.imsave_scalar(p['out_rainy_mask_path'], o['mask'])                   # generator.py:467
+    # ---- the asynchronous frame pipeline ------------------------------------------------------------------
+    class _Slot:
+        """Pinned host buffers of one batch in flight (inputs the I/O threads decode into, outputs they deflate from)."""
+
+        def __init__(self, hip, B, H, W, We, bg_dtype, depth_dtype, save_envmap, drops_cap):
+            self.B, self.H, self.W = B, H, W
+            self.bg = hip.host_array((B, H, W, 3), bg_dtype)
+            self.depth = hip.host_array((B, H, W), depth_dtype)
+            self.drops = hip.host_array((B, drops_cap), hip_backend.DROP_DTYPE)
+            self.status = hip.host_array((B, drops_cap), np.int32)
+            row = H * (1 + 4 * W)
+            self.png_i = hip.host_array((B, row), np.uint8)
+            self.png_m = hip.host_array((B, row), np.uint8)
+            self.env = hip.host_array((B, H, We, 3), np.uint8) if save_envmap else None
+            self.drops_cap = drops_cap
+            self.key = (B, H, W, We, np.dtype(bg_dtype), np.dtype(depth_dtype), bool(save_envmap))
+            self.items, self.encodes, self.busy = [], [], False
+
+    def _decode_into(self, slot, k, item, rs, pristine, imW, imH, seeds):
+        """I/O-thread part of one frame: decode image + depth into the slot's pinned buffers, build the drop table."""
+        loaded = self._load_frame(item['image_file'], item['depth_file'], rs)
+        if loaded is None:
+            return None
+        bg, depth = loaded
+        drops = self._pack(pristine, imW, imH, seeds[-1], seeds[:-1])
+        return bg, depth, drops
+
+    def _encode(self, slot, k, item, n_drops):
+        """I/O-thread part after the GPU: deflate the two PNG files from the scanlines the library delivered."""
+        H, W = slot.H, slot.W
+        os.makedirs(os.path.dirname(item['out_rainy_path']), exist_ok=True)
+        os.makedirs(os.path.dirname(item['out_rainy_mask_path']), exist_ok=True)
+        imgops.png_from_scanlines(item['out_rainy_path'], slot.png_i[k], W, H)        # generator.py:466
+        imgops.png_from_scanlines(item['out_rainy_mask_path'], slot.png_m[k], W, H)   # generator.py:467
         if self.save_envmap:
-            os.makedirs(os.path.dirname(p['out_env_path']), exist_ok=True)
-            env_bgr = o['env_bgr_u8'] / 255.0                                      # generator.py:469 (plt.imsave of a float map)
-            imgops.imsave_rgb(p['out_env_path'], (np.clip(env_bgr[..., ::-1], 0, 1) * 255).astype(np.uint8))
-
-    def _drain_saves(self, keep=0):
-        while len(self._saves) > keep:
-            self._saves.pop(0).result()
-
-    def _flush(self, pending):
-        """Render the pending frames in one library call; their outputs are encoded on the I/O pool."""
-        if not pending:
-            return
-        t0 = time.time()
-        # fog attenuation + environment map + streak rendering, all on the GPU in one call
-        outs = self._hip_ctx().pipeline_frames([p['frame'] for p in pending], want_env_u8=self.save_envmap, want_mask_i32=False)
-        dt = time.time() - t0
-        for p, o in zip(pending, outs):
-            self._saves.append(self._io_pool().submit(self._save_frame, dict(p, frame=None), o))
-            n_skip = int(np.count_nonzero(o['status']))
-            self.stats.append(dict(file=p['out_rainy_path'], drops=len(o['status']), skipped=n_skip,
-                                   gpu_ms=1e3 * dt / len(pending)))
-            if n_skip and self.verbose:
-                print("\nTrace: %d of %d rain drops not rendered in %s" % (n_skip, len(o['status']), p['out_rainy_path']))
-        pending.clear()
-        self._drain_saves(keep=4 * self.batch)          # bound the frames in flight
+            os.makedirs(os.path.dirname(item['out_env_path']), exist_ok=True)
+            env_bgr = slot.env[k] / 255.0                                              # generator.py:469 (plt.imsave of a float map)
+            imgops.imsave_rgb(item['out_env_path'], (np.clip(env_bgr[..., ::-1], 0, 1) * 255).astype(np.uint8))
+        return int(np.count_nonzero(slot.status[k, :n_drops]))
 
     def compute_drop(self, bg, drop_dict, rainy_bg, rainy_mask, rainy_saturation_mask):
         """Single-drop compatibility seam with the reference's signature (generator.py:119-191):
@@ -209,27 +220,43 @@ class Generator:
         minC = np.array([drops['x0'][0], drops['y0'][0]])
         return rainy_bg, rainy_mask, rainy_saturation_mask, None, (rainy_bg if ok else None), minC
 
+    def _resolve_out_dir(self, out_dir):
+        """generator.py:213-226.  Under several ranks the choice (incl. the _copyNNNNN shift of 'rename_folder') is made
+        by rank 0 alone and broadcast: every rank of a run writes into the same folder."""
+        def resolve():
+            d = out_dir
+            if os.path.exists(d):
+                if self.conflict_strategy in ("skip", "overwrite"):
+                    pass
+                elif self.conflict_strategy == "rename_folder":
+                    shift = 0
+                    while os.path.exists(d + '_copy%05d' % shift):
+                        shift += 1
+                    d = d + '_copy%05d' % shift
+                else:
+                    raise NotImplementedError
+            os.makedirs(d, exist_ok=True)
+            return d
+        return sharding.rank0_decides(resolve, self.rank, self.world)
+
+    def _frame_name_index(self, i, n_files, n_sim):
+        """generator.py:304-312: the index that seeds the frame and picks its simulated frame.  nuScenes spreads the
+        simulated frames over the sequence's files."""
+        if self.dataset == 'nuscenes':
+            return int(np.linspace(0, n_sim, n_files, endpoint=False, dtype=int)[i])
+        return i
+
     def run(self):
         folders_num = len(self.images)
+        B = max(1, self.batch)
         for folder_idx, sequence in enumerate(self.sequences):
             print('\nSequence: ' + sequence)
             depth_folder = self.depth[sequence]
             for sim_idx, sim_weather in enumerate(self.weather):
                 weather, fallrate = sim_weather["weather"], sim_weather["fallrate"]
                 out_seq_dir = os.path.join(self.output_root, sequence)
-                out_dir = os.path.join(out_seq_dir, weather, '{}mm'.format(fallrate))
+                out_dir = self._resolve_out_dir(os.path.join(out_seq_dir, weather, '{}mm'.format(fallrate)))
                 sim_file = self.particles[sequence][sim_idx]
-                if os.path.exists(out_dir):                                         # generator.py:213-226
-                    if self.conflict_strategy in ("skip", "overwrite"):
-                        pass
-                    elif self.conflict_strategy == "rename_folder":
-                        shift = 0
-                        while os.path.exists(out_dir + '_copy%05d' % shift):
-                            shift += 1
-                        out_dir = out_dir + '_copy%05d' % shift
-                    else:
-                        raise NotImplementedError
-                os.makedirs(out_dir, exist_ok=True)
                 fog_params = {"rain_intensity": fallrate, "focal": self.focal, "f_number": self.f_number, "angle": 90,
                               "exposure": self.exposure, "camera_gain": self.camera_gain}
                 files = [os.path.join(self.images[sequence], p) for p in my_utils.os_listdir(self.images[sequence])
@@ -255,10 +282,11 @@ class Generator:
                 sharding.load_and_broadcast_streak_db(self.db, hip, self.rank, self.world)
                 hip.set_camera(hip_backend.make_camera(self.focal, self.f_number, self.exposure))
                 hip.set_prepass_kernels(imgops.gaussian_kernel(25, 25), imgops.gaussian_kernel(15, 0))
+                hip.set_colormap(imgops.viridis_lut())
                 fog_const = FOG.constants()
-                geom_hw, env_w = None, 0
                 self.db.load_streaks_from_xml(self.dataset, self.settings, [imW, imH], use_pickle=False, verbose=self.verbose)
                 frame_render_dict = list(self.db.streaks_simulator.values())
+                n_sim = len(frame_render_dict)
 
                 f_end = len(files) if self.frame_end is None else min(self.frame_end, len(files))
                 if self.frames:
@@ -266,22 +294,19 @@ class Generator:
                 else:
                     idx = list(range(self.frame_start, f_end, self.frame_step))
                 print("{} images".format(len(idx)))
-                idx = sharding.shard(idx, self.rank, self.world)
+                # work items of the WHOLE run first (skip / overwrite decisions), then this rank's share
                 frames_exist_nb = 0
-                pending = []
-                sim_t0 = time.time()
-                # work items first (skip / overwrite decisions), so that image + depth decoding can run ahead
-                # of the GPU on the I/O pool; everything that touches the legacy global RNG stays on this thread
                 work = []
                 for i in idx:
                     image_file, depth_file = files[i], depth_files[i]
                     assert os.path.exists(image_file), "Image file {} does not exist".format(image_file)
                     assert os.path.exists(depth_file), "Depth file {} does not exist".format(depth_file)
                     file_name = os.path.split(image_file)[-1]
-                    out_rainy_path = os.path.join(out_dir, 'rainy_image', '{}.png'.format(file_name[:-4]))
-                    out_rainy_mask_path = os.path.join(out_dir, 'rain_mask', '{}.png'.format(file_name[:-4]))
-                    out_env_path = os.path.join(out_seq_dir, 'envmap', '{}.png'.format(file_name[:-4]))
-                    if os.path.exists(out_rainy_path) or os.path.exists(out_rainy_mask_path):
+                    item = dict(i=i, image_file=image_file, depth_file=depth_file,
+                                out_rainy_path=os.path.join(out_dir, 'rainy_image', '{}.png'.format(file_name[:-4])),
+                                out_rainy_mask_path=os.path.join(out_dir, 'rain_mask', '{}.png'.format(file_name[:-4])),
+                                out_env_path=os.path.join(out_seq_dir, 'envmap', '{}.png'.format(file_name[:-4])))
+                    if os.path.exists(item['out_rainy_path']) or os.path.exists(item['out_rainy_mask_path']):
                         if self.conflict_strategy == "skip":
                             frames_exist_nb += 1
                             continue
@@ -289,52 +314,123 @@ class Generator:
                             pass
                         else:
                             raise NotImplementedError
-                    work.append((i, image_file, depth_file, out_rainy_path, out_rainy_mask_path, out_env_path))
-                ahead = max(2 * self.batch, 4)
+                    item['f_name_idx'] = self._frame_name_index(i, len(files), n_sim)  # generator.py:304-312
+                    work.append(item)
+                # with angular noise a frame inherits the end-point rotations of the run's earlier frames that used the
+                # same simulated frame (generator.py:152-161): remember their seeds, whoever renders them
                 noisy = bool(self.noise_scale) and bool(self.noise_std)
-                loads = {}
-                for f_idx, (i, image_file, depth_file, out_rainy_path, out_rainy_mask_path, out_env_path) in enumerate(work):
-                    for j in range(f_idx, min(f_idx + ahead, len(work))):
-                        if j not in loads:
-                            # f_name_idx = i (generator.py:312; nuscenes remap not supported)
-                            loads[j] = self._io_pool().submit(self._prepare_frame, work[j][1], work[j][2], rs, work[j][0],
-                                                              frame_render_dict[work[j][0] % len(frame_render_dict)],
-                                                              imW, imH, not noisy)
-                    loaded = loads.pop(f_idx).result()
-                    f_name_idx = i
-                    np.random.seed(f_name_idx)                                       # generator.py:318 (kept for callers)
-                    frame = frame_render_dict[f_name_idx % len(frame_render_dict)]
-                    if loaded is None:
-                        print('Missing/Corrupted depth data (%s)' % depth_file)
-                        continue
-                    bg, depth, drops = loaded
-                    H, W = bg.shape[:2]
-                    # FOG.fog_rain_layer (generator.py:386), map_generator.generate_map (:400) and the xyY
-                    # conversion (:407-408) run on the GPU inside rr_pipeline_frames; the host only provides
-                    # the scalar fog constants and, once per frame size, the projection tables
-                    if geom_hw != (H, W):
-                        self._flush(pending)
-                        env_w = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
-                        geom_hw = (H, W)
-                    omega = solid_angle.get_solid_angles(np.empty((H, env_w, 0)))    # generator.py:410
-                    if drops is None:
-                        # angular noise rotates the streak end points IN the shared table (generator.py:152-161),
-                        # so frames that reuse a simulator frame must be packed in order, on this thread
-                        drops = self._pack(frame, imW, imH, f_name_idx)
-                    pending.append(dict(frame=dict(bg=None if bg.dtype == np.uint8 else bg,
-                                                   bg_u8=bg if bg.dtype == np.uint8 else None,
-                                                   depth=depth, fog=fog_const, omega=omega, drops=drops,
-                                                   opacity_attenuation=self.opacity_attenuation,
-                                                   strategy=1 if self.rendering_strategy == 'white' else 0),
-                                        out_rainy_path=out_rainy_path, out_rainy_mask_path=out_rainy_mask_path,
-                                        out_env_path=out_env_path))
-                    if len(pending) >= self.batch:
-                        self._flush(pending)
-                    if self.verbose:
-                        sys.stdout.write('\r          S. {} / {}, F. {} / {}   ({:.1f}s)'.format(
-                            folder_idx + 1, folders_num, f_idx + 1, len(work), time.time() - sim_t0))
-                self._flush(pending)
-                self._drain_saves()
+                seen = {}
+                for item in work:
+                    k = item['f_name_idx'] % n_sim
+                    item['seeds'] = tuple(seen.get(k, ())) + (item['f_name_idx'],) if noisy else (item['f_name_idx'],)
+                    if noisy:
+                        seen.setdefault(k, []).append(item['f_name_idx'])
+                work = sharding.shard(work, self.rank, self.world)
+                sim_t0 = time.time()
+                self._run_batches(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0)
                 if frames_exist_nb > 0:
                     print("Skipped {}/{} already existing renderings".format(frames_exist_nb, len(idx)))
             print("\n\nEnd of the simulation")
+
+    def _run_batches(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
+        """Batches of B frames through the three-slot asynchronous pipeline (rr_pipeline_submit / rr_pipeline_wait):
+        decode + drop tables on the I/O threads (into pinned buffers), upload | kernels | download overlapped inside
+        the library, deflate + file writes on the I/O threads again.  FOG.fog_rain_layer (generator.py:386),
+        map_generator.generate_map (:400), the xyY conversion (:407-408), the streak loop (:431-452), the epilogue
+        (:461-466), the mask's colour map (:467) and the PNG filtering all run on the GPU; the host provides the scalar
+        fog constants and, once per frame size, the projection tables of the environment map."""
+        pool = self._io_pool()
+        nslot = hip_backend.RR_PIPE_SLOTS
+        batches = [work[a:a + B] for a in range(0, len(work), B)]
+        slots = [None] * nslot
+        n_sim = len(frame_render_dict)
+        state = dict(geom=None, env_w=0, omega=None, done=0)
+
+        def decode_batch(bi):
+            """Start the I/O-thread work of batch bi; returns the futures (the slot's buffers are filled at submit)."""
+            return [pool.submit(self._decode_into, None, k, it, rs, frame_render_dict[it['f_name_idx'] % n_sim].table, imW, imH, it['seeds'])
+                    for k, it in enumerate(batches[bi])]
+
+        def finish(si):
+            """Wait for slot si's GPU work, hand its frames to the encoders."""
+            sl = slots[si]
+            if sl is None or not sl.busy:
+                return
+            while not hip.pipeline_wait(si):                    # tile arena regrown: submit the batch again
+                hip.pipeline_submit(si, sl.frames, sl.outs)
+            sl.busy = False
+            dt = time.time() - sl.t_submit
+            for k, (it, nd) in enumerate(sl.items):
+                fut = pool.submit(self._encode, sl, k, it, nd)
+                sl.encodes.append((fut, it, nd, 1e3 * dt / max(len(sl.items), 1)))
+
+        def drain(si):
+            """Slot si's buffers are free again once its encoders are done."""
+            sl = slots[si]
+            if sl is None:
+                return
+            for fut, it, nd, ms in sl.encodes:
+                n_skip = fut.result()
+                self.stats.append(dict(file=it['out_rainy_path'], drops=nd, skipped=n_skip, gpu_ms=ms))
+                if n_skip and self.verbose:
+                    print("\nTrace: %d of %d rain drops not rendered in %s" % (n_skip, nd, it['out_rainy_path']))
+            sl.encodes = []
+
+        ahead = {}
+        for bi in range(len(batches)):
+            for bj in range(bi, min(bi + 2, len(batches))):     # decode two batches ahead of the GPU
+                if bj not in ahead:
+                    ahead[bj] = decode_batch(bj)
+            si = bi % nslot
+            finish(si)
+            drain(si)
+            loaded = [f.result() for f in ahead.pop(bi)]
+            valid = [(it, ld) for it, ld in zip(batches[bi], loaded) if ld is not None]
+            for it, ld in zip(batches[bi], loaded):
+                if ld is None:
+                    print('Missing/Corrupted depth data (%s)' % it['depth_file'])
+            if not valid:
+                continue
+            H, W = valid[0][1][0].shape[:2]
+            if state['geom'] != (H, W):
+                for sj in range(nslot):                         # a new frame size: let the pipeline run dry first
+                    finish(sj)
+                    drain(sj)
+                state['env_w'] = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
+                state['omega'] = solid_angle.get_solid_angles(np.empty((H, state['env_w'], 0)))    # generator.py:410
+                state['geom'] = (H, W)
+            bg0, dep0 = valid[0][1][0], valid[0][1][1]
+            need_drops = max(len(ld[2]) for _, ld in valid)
+            key = (B, H, W, state['env_w'], bg0.dtype, dep0.dtype, bool(self.save_envmap))
+            sl = slots[si]
+            if sl is None or sl.key != key or sl.drops_cap < need_drops:
+                sl = slots[si] = Generator._Slot(hip, B, H, W, state['env_w'], bg0.dtype, dep0.dtype, self.save_envmap,
+                                                 max(need_drops + need_drops // 4, 1024))
+            frames, outs, sl.items = [], [], []
+            for k, (it, (bg, depth, drops)) in enumerate(valid):
+                assert bg.shape[:2] == (H, W) and bg.dtype == bg0.dtype, "frames of one sequence share their size"
+                np.copyto(sl.bg[k], bg)
+                np.copyto(sl.depth[k], depth)
+                nd = len(drops)
+                sl.drops[k, :nd] = drops
+                frames.append(dict(bg=None if bg.dtype == np.uint8 else sl.bg[k], bg_u8=sl.bg[k] if bg.dtype == np.uint8 else None,
+                                   depth=sl.depth[k], fog=fog_const, omega=state['omega'], drops=sl.drops[k, :nd],
+                                   opacity_attenuation=self.opacity_attenuation,
+                                   strategy=1 if self.rendering_strategy == 'white' else 0))
+                o = dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k, :nd])
+                if self.save_envmap:
+                    o['env_bgr_u8'] = sl.env[k]
+                outs.append(o)
+                sl.items.append((it, nd))
+            sl.frames, sl.outs = frames, outs
+            sl.t_submit = time.time()
+            hip.pipeline_submit(si, frames, outs)
+            sl.busy = True
+            state['done'] += len(valid)
+            if self.verbose:
+                sys.stdout.write('\r          S. {} / {}, F. {} / {}   ({:.1f}s)'.format(
+                    folder_idx + 1, folders_num, state['done'], len(work), time.time() - sim_t0))
+        for si in range(nslot):
+            finish(si)
+        for si in range(nslot):
+            drain(si)

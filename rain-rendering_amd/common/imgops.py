@@ -118,24 +118,57 @@ def imsave_rgb(path, rgb_u8):
     _save_rgba(path, rgba)
 
 
+# matplotlib's default colour map (viridis) as plt.imsave uses it for a 2-D array: the 256 RGBA byte entries
+# (cmap(arange(256)) * 255).astype(uint8), embedded so that the rain-mask PNGs do not depend on matplotlib being
+# importable (tests/test_host_logic.py compares the table with matplotlib when it is).
+_VIRIDIS_B64 = (
+    "RAFU/0QCVf9EA1f/RQVY/0UGWv9FCFv/Rglc/0YLXv9GDF//Rg5h/0cPYv9HEWP/RxJl/0cUZv9HFWf/RxZp/0cYav9IGWv/SBps/0gcbv9IHW"
+    "//SB5w/0ggcf9IIXL/SCJz/0gjdP9HJXX/RyZ2/0cnd/9HKHj/Ryp5/0crev9HLHv/Ri18/0YvfP9GMH3/RjF+/0Uyf/9FNH//RTWA/0U2gf9E"
+    "N4H/RDmC/0M6g/9DO4P/QzyE/0I9hP9CPoX/QkCF/0FBhv9BQob/QEOH/0BEh/8/RYf/P0eI/z5IiP8+SYn/PUqJ/z1Lif89TIn/PE2K/zxOiv"
+    "87UIr/O1GK/zpSi/86U4v/OVSL/zlVi/84Vov/OFeM/zdYjP83WYz/NlqM/zZbjP81XIz/NV2M/zRejf80X43/M2CN/zNhjf8yYo3/MmON/zFk"
+    "jf8xZY3/MWaN/zBnjf8waI3/L2mN/y9qjf8ua47/LmyO/y5tjv8tbo7/LW+O/yxwjv8scY7/LHKO/ytzjv8rdI7/KnWO/yp2jv8qd47/KXiO/y"
+    "l5jv8oeo7/KHqO/yh7jv8nfI7/J32O/yd+jv8mf47/JoCO/yaBjv8lgo7/JYON/ySEjf8khY3/JIaN/yOHjf8jiI3/I4mN/yKJjf8iio3/IouN"
+    "/yGMjf8hjYz/IY6M/yCPjP8gkIz/IJGM/x+SjP8fk4v/H5SL/x+Vi/8flov/HpeK/x6Yiv8emYr/HpmK/x6aif8em4n/HpyJ/x6diP8enoj/Hp"
+    "+I/x6gh/8foYf/H6KG/x+jhv8gpIX/IKWF/yGmhf8hp4T/IqeE/yOog/8jqYL/JKqC/yWrgf8mrIH/J62A/yiuf/8pr3//KrB+/yuxff8ssX3/"
+    "LrJ8/y+ze/8wtHr/MrV6/zO2ef81t3j/Nrh3/zi5dv85uXb/O7p1/z27dP8+vHP/QL1y/0K+cf9EvnD/Rb9v/0fAbv9JwW3/S8Js/03Ca/9Pw2"
+    "n/UcRo/1PFZ/9Vxmb/V8Zl/1nHZP9byGL/Xslh/2DJYP9iyl//ZMtd/2fMXP9pzFv/a81Z/23OWP9wzlb/cs9V/3TQVP930FL/edFR/3zST/9+"
+    "0k7/gdNM/4PTS/+G1En/iNVH/4vVRv+N1kT/kNZD/5LXQf+V1z//l9g+/5rYPP+d2Tr/n9k4/6LaN/+l2jX/p9sz/6rbMv+t3DD/r9wu/7LdLP"
+    "+13Sv/t90p/7reJ/+93ib/v98k/8LfIv/F3yH/x+Af/8rgHv/N4B3/z+Ec/9LhG//U4Rr/1+IZ/9riGP/c4hj/3+MY/+HjGP/k4xj/5+QZ/+nk"
+    "Gf/s5Br/7uUb//HlHP/z5R7/9uYf//jmIf/65iL//eck/w=="
+)
 _viridis = None
+
+
+def viridis_lut():
+    """(256, 4) uint8 RGBA."""
+    global _viridis
+    if _viridis is None:
+        import base64
+        _viridis = np.frombuffer(base64.b64decode(_VIRIDIS_B64), np.uint8).reshape(256, 4).copy()
+    return _viridis
+
+
+def png_from_scanlines(path, rows, width, height, level=None):
+    """An RGBA PNG file from its filtered scanlines (height rows of 1 + 4*width bytes, as the library's
+    rr_frame_out.rainy_png / mask_png deliver them): one zlib stream + chunk framing.  zlib releases the GIL."""
+    import struct
+    import zlib
+    assert len(rows) == height * (1 + 4 * width) if not hasattr(rows, 'nbytes') else rows.nbytes == height * (1 + 4 * width)
+
+    def chunk(tag, data):
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+
+    blob = (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', width, height, 8, 6, 0, 0, 0)) +
+            chunk(b'IDAT', zlib.compress(rows, PNG_LEVEL if level is None else level)) + chunk(b'IEND', b''))
+    with open(path, 'wb') as fh:
+        fh.write(blob)
 
 
 def imsave_scalar(path, a):
     """plt.imsave(path, 2-D float array): min/max normalised, viridis colour map, RGBA
     (reference generator.py:467)."""
-    global _viridis
-    from PIL import Image
     a = np.asarray(a, np.float64)
     lo, hi = float(a.min()), float(a.max())
     norm = np.zeros_like(a) if hi <= lo else (a - lo) / (hi - lo)
-    if _viridis is None:
-        try:
-            import matplotlib
-            cmap = matplotlib.colormaps['viridis'] if hasattr(matplotlib, 'colormaps') else matplotlib.cm.get_cmap('viridis', 256)
-            _viridis = (np.asarray(cmap(np.arange(256))) * 255).astype(np.uint8)
-        except Exception:
-            g = np.arange(256, dtype=np.uint8)
-            _viridis = np.stack([g, g, g, np.full(256, 255, np.uint8)], axis=1)
     idx = np.clip((norm * 256).astype(np.int64), 0, 255)
-    _save_rgba(path, np.ascontiguousarray(_viridis[idx]))
+    _save_rgba(path, np.ascontiguousarray(viridis_lut()[idx]))

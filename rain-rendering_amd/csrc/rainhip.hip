@@ -53,6 +53,8 @@ struct FrameDesc {
   double* mask_f64;
   int32_t* mask_i32;
   int32_t* status;
+  uint8_t* png_image;              // optional: PNG scanlines (Sub filter) of the RGBA rainy image, H * (1 + 4 W) bytes
+  uint8_t* png_mask;               // optional: same for the colour-mapped rain mask
   int32_t n_drops;
   int32_t strategy;
   double opacity;
@@ -83,8 +85,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* prefix;                   // [frame][He][We+1][4]: general path only (maps beyond HE_MAX / FOV_WE_MAX)
   double* fband;                    // [frame][COL_PARTS][2] = sum w, sum Y*w of every row band
   double* arena;                    // [frame][arena_cap]
-  double* partial;                  // [frame][ntiles][2]
-  double* means;                    // [frame][2]
+  double* partial;                  // [frame][ntiles][4] per screen tile: sum(composite), sum(bg), min(mask), max(mask)
+  double* means;                    // [frame][4] = mean(composite), mean(bg), min(mask), max(mask)
   int64_t* arena_need;              // [frame]
   int32_t* overflow;                // [1]
   int32_t* list_rot;                // [frame][drops]  drops taken by k_tile
@@ -1898,47 +1900,61 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     if (fr.mask_i32) as_global(fr.mask_i32)[pix] = (int32_t)floor(m * 255.0);
     sum_c = (c[0] + c[1]) + c[2];
   }
-  __shared__ double ra[256], rb[256];
+  __shared__ double ra[256], rb[256], rlo[256], rhi[256];
   ra[t] = sum_c;
   rb[t] = sum_b;
+  rlo[t] = live ? m : 1.0e300;
+  rhi[t] = live ? m : -1.0e300;
   __syncthreads();
   for (int ofs = 128; ofs > 0; ofs >>= 1) {
     if (t < ofs) {
       ra[t] += ra[t + ofs];
       rb[t] += rb[t + ofs];
+      rlo[t] = dmin(rlo[t], rlo[t + ofs]);
+      rhi[t] = dmax(rhi[t], rhi[t + ofs]);
     }
     __syncthreads();
   }
   if (t == 0) {
-    double* part = sc.partial + ((int64_t)f * tiles_x * tiles_y + tile) * 2;
+    double* part = sc.partial + ((int64_t)f * tiles_x * tiles_y + tile) * 4;
     part[0] = ra[0];
     part[1] = rb[0];
+    part[2] = rlo[0];
+    part[3] = rhi[0];
   }
 }
 
 __global__ __launch_bounds__(256) void k_means(Dims dm, int ntiles, Scratch sc) {
   const int f = blockIdx.x, t = threadIdx.x;
-  double a = 0, b = 0;
-  const double* part = sc.partial + (int64_t)f * ntiles * 2;
+  double a = 0, b = 0, lo = 1.0e300, hi = -1.0e300;
+  const double* part = sc.partial + (int64_t)f * ntiles * 4;
   for (int i = t; i < ntiles; i += 256) {
-    a += part[i * 2];
-    b += part[i * 2 + 1];
+    a += part[i * 4];
+    b += part[i * 4 + 1];
+    lo = dmin(lo, part[i * 4 + 2]);
+    hi = dmax(hi, part[i * 4 + 3]);
   }
-  __shared__ double ra[256], rb[256];
+  __shared__ double ra[256], rb[256], rlo[256], rhi[256];
   ra[t] = a;
   rb[t] = b;
+  rlo[t] = lo;
+  rhi[t] = hi;
   __syncthreads();
   for (int ofs = 128; ofs > 0; ofs >>= 1) {
     if (t < ofs) {
       ra[t] += ra[t + ofs];
       rb[t] += rb[t + ofs];
+      rlo[t] = dmin(rlo[t], rlo[t + ofs]);
+      rhi[t] = dmax(rhi[t], rhi[t + ofs]);
     }
     __syncthreads();
   }
   if (t == 0) {
     const double cnt = (double)dm.H * (double)dm.W * 3.0;
-    sc.means[f * 2 + 0] = ra[0] / cnt;
-    sc.means[f * 2 + 1] = rb[0] / cnt;
+    sc.means[f * 4 + 0] = ra[0] / cnt;
+    sc.means[f * 4 + 1] = rb[0] / cnt;
+    sc.means[f * 4 + 2] = rlo[0];                  // min / max of rainy_mask: the normalisation of its colour-mapped PNG
+    sc.means[f * 4 + 3] = rhi[0];
   }
 }
 
@@ -1948,13 +1964,63 @@ __global__ __launch_bounds__(256) void k_finalize(const FrameDesc* frames, Dims 
   const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (pix >= (int64_t)dm.H * dm.W) return;
   const FrameDesc& fr = frames[f];
-  const double diff = sc.means[f * 2 + 0] - sc.means[f * 2 + 1];
+  const double diff = sc.means[f * 4 + 0] - sc.means[f * 4 + 1];
   const global_ptr<const double> s = as_global((const double*)fr.comp_out) + pix * 3;
   const global_ptr<uint8_t> o = as_global(fr.rgb) + pix * 3;
   for (int k = 0; k < 3; k++) {
     double v = clip01(s[2 - k] - diff);      // BGR -> RGB
     o[k] = (uint8_t)(int)(v * 255.0);
   }
+}
+
+// ---------------------------------------------------------------------------
+// the two PNG files of a frame, ready for deflate  
+// ---------------------------------------------------------------------------
+// plt.imsave writes RGBA PNGs (generator.py:466-467).  A PNG scanline is one filter byte + the filtered pixels; with
+// filter type 1 (Sub) every byte is stored minus the byte one pixel to the left.  These kernels leave the scanlines of
+// both files in HBM, so the host only runs zlib over them and frames the chunks.
+__global__ __launch_bounds__(256) void k_png_image(const FrameDesc* frames, Dims dm) {
+  const int f = blockIdx.y;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const FrameDesc& fr = frames[f];
+  if (!fr.png_image || pix >= (int64_t)dm.H * dm.W) return;
+  const int y = (int)(pix / dm.W), x = (int)(pix - (int64_t)y * dm.W);
+  const global_ptr<const uint8_t> s = as_global((const uint8_t*)fr.rgb) + pix * 3;
+  const global_ptr<uint8_t> o = as_global(fr.png_image) + (int64_t)y * (1 + 4 * dm.W) + 1 + 4 * x;
+  if (x == 0) {
+    o[-1] = 1;                                        // filter type: Sub
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 255;
+  } else {
+    o[0] = (uint8_t)(s[0] - s[-3]); o[1] = (uint8_t)(s[1] - s[-2]); o[2] = (uint8_t)(s[2] - s[-1]);
+    o[3] = 0;                                         // alpha 255 - 255
+  }
+}
+
+// plt.imsave(path, rainy_mask) (generator.py:467): Normalize(min, max), then the colour map's 256-entry byte table at
+// int(norm * 256) clipped to 255 (matplotlib Colormap.__call__, bytes=True).  lut: [256][4] RGBA.
+__device__ inline int mask_lut_index(double a, double lo, double hi) {
+  if (!(hi > lo)) return 0;
+  const double v = ((a - lo) / (hi - lo)) * 256.0;
+  const long long i = (long long)v;
+  return i < 0 ? 0 : (i > 255 ? 255 : (int)i);
+}
+__global__ __launch_bounds__(256) void k_png_mask(const FrameDesc* frames, Dims dm, const uint8_t* lut, Scratch sc) {
+  const int f = blockIdx.y;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const FrameDesc& fr = frames[f];
+  __shared__ uint32_t s_lut[256];
+  s_lut[threadIdx.x] = reinterpret_cast<const uint32_t*>(lut)[threadIdx.x];
+  __syncthreads();
+  if (!fr.png_mask || pix >= (int64_t)dm.H * dm.W) return;
+  const int y = (int)(pix / dm.W), x = (int)(pix - (int64_t)y * dm.W);
+  const double lo = sc.means[f * 4 + 2], hi = sc.means[f * 4 + 3];
+  const global_ptr<const double> m = as_global((const double*)fr.mask_f64) + pix;
+  const uint32_t c = s_lut[mask_lut_index(m[0], lo, hi)];
+  const uint32_t l = x > 0 ? s_lut[mask_lut_index(m[-1], lo, hi)] : 0u;
+  const global_ptr<uint8_t> o = as_global(fr.png_mask) + (int64_t)y * (1 + 4 * dm.W) + 1 + 4 * x;
+  if (x == 0) o[-1] = 1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) o[k] = (uint8_t)(((c >> (8 * k)) & 0xffu) - ((l >> (8 * k)) & 0xffu));
 }
 
 }  // namespace
@@ -1979,6 +2045,8 @@ struct rr_ctx {
   int64_t* d_tex_off = nullptr;
   int n_tex = 0;
   float* d_ctab = nullptr;
+  uint8_t* d_lut = nullptr;         // [256][4] RGBA colour map of the rain-mask PNG (rr_set_colormap)
+  bool have_lut = false;
   rr_camera cam;
   bool have_cam = false, have_db = false;
   // scratch
@@ -2001,6 +2069,7 @@ struct rr_ctx {
     double* depth = nullptr;         // pre-pass input (float32 or float64 per frame slot of 8 bytes/pixel)
     uint8_t* bg8 = nullptr;          // pre-pass input given as bytes (rr_prepass_in.bg_u8)
     uint8_t* env_u8 = nullptr;
+    uint8_t *png_i = nullptr, *png_m = nullptr;   // PNG scanlines of the image / of the colour-mapped mask
     int frames = 0, drops_cap = 0;
     Dims dims{0, 0, 0, 0};
   };
@@ -2170,8 +2239,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.htab, fd * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fband, (size_t)F * COL_PARTS * 2))) return rc;
     const int ntiles = ((dm.W + TILE - 1) / TILE) * ((dm.H + TILE - 1) / TILE);
-    if ((rc = dev_alloc(ctx, ctx->sc.partial, (size_t)F * ntiles * 2))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.means, (size_t)F * 2))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.partial, (size_t)F * ntiles * 4))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.means, (size_t)F * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.arena_need, (size_t)F))) return rc;
     if (!ctx->sc.overflow) {
       if ((rc = dev_alloc(ctx, ctx->sc.overflow, 1))) return rc;
@@ -2210,7 +2279,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   Dims dm{in[0].H, in[0].W, in[0].He, in[0].We};
   int max_drops = 0;
-  bool need_comp = false;
+  bool need_comp = false, want_png = false;
   for (int f = 0; f < n; f++) {
     if (in[f].H != dm.H || in[f].W != dm.W || in[f].He != dm.He || in[f].We != dm.We) {
       ctx->err = "all frames of a batch must share H,W,He,We";
@@ -2225,8 +2294,13 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ctx->err = "null frame pointer or n_drops outside [0, 2^16] (generator.py:425)";
       return RR_E_ARG;
     }
+    if (out[f].mask_png && (!out[f].mask_f64 || !ctx->have_lut)) {
+      ctx->err = "mask_png needs mask_f64 and rr_set_colormap";
+      return RR_E_ARG;
+    }
     if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
     if (!out[f].rainy_bg_out) need_comp = true;
+    want_png = want_png || out[f].rainy_png || out[f].mask_png;
   }
   if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
     ctx->err = "bad frame size";
@@ -2248,6 +2322,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.mask_f64 = out[f].mask_f64;
     fd.mask_i32 = out[f].mask_i32;
     fd.status = out[f].drop_status;
+    fd.png_image = out[f].rainy_png;
+    fd.png_mask = out[f].mask_png;
     fd.n_drops = in[f].n_drops;
     fd.strategy = in[f].strategy;
     fd.opacity = in[f].opacity_attenuation;
@@ -2390,6 +2466,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   {
     ProfScope ps(ctx, s, "k_finalize");
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)(((int64_t)dm.H * dm.W + 255) / 256), n), dim3(256), 0, s, ctx->d_frames, dm, sc);
+  }
+  if (want_png) {
+    ProfScope ps(ctx, s, "k_png_rows");
+    const dim3 grid((unsigned)(((int64_t)dm.H * dm.W + 255) / 256), n);
+    hipLaunchKernelGGL(k_png_image, grid, dim3(256), 0, s, ctx->d_frames, dm);
+    if (ctx->have_lut) hipLaunchKernelGGL(k_png_mask, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->d_lut, sc);
   }
   HIPCHK(hipGetLastError());
   ctx->last_n = n;
@@ -2565,6 +2647,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->d_tex_w);
   hipFree(ctx->d_tex_off);
   hipFree(ctx->d_ctab);
+  hipFree(ctx->d_lut);
   hipFree(ctx->sc.plan);
   hipFree(ctx->sc.comp);
   hipFree(ctx->sc.poly);
@@ -2609,6 +2692,8 @@ int rr_destroy(rr_ctx* ctx) {
     hipFree(sl.st.depth);
     hipFree(sl.st.env_u8);
     hipFree(sl.st.bg8);
+    hipFree(sl.st.png_i);
+    hipFree(sl.st.png_m);
     if (sl.ev_up) hipEventDestroy(sl.ev_up);
     if (sl.ev_comp) hipEventDestroy(sl.ev_comp);
     if (sl.ev_down) hipEventDestroy(sl.ev_down);
@@ -2779,6 +2864,8 @@ int slot_reserve(rr_ctx* ctx, rr_ctx::Staging& st, int n, int max_drops, const D
     if ((rc = dev_alloc(ctx, st.depth, F * px))) return rc;
     if ((rc = dev_alloc(ctx, st.env_u8, F * ex * 3))) return rc;
     if ((rc = dev_alloc(ctx, st.bg8, F * px * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.png_i, F * (size_t)dm.H * (1 + 4 * (size_t)dm.W)))) return rc;
+    if ((rc = dev_alloc(ctx, st.png_m, F * (size_t)dm.H * (1 + 4 * (size_t)dm.W)))) return rc;
     st.frames = F;
     st.drops_cap = D;
     st.dims = dm;
@@ -2850,9 +2937,13 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         return RR_E_ARG;
       }
       if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
-          !out[f].rainy_rgb) {
-        ctx->err = "null frame pointer";
+          (!out[f].rainy_rgb && !out[f].rainy_png)) {
+        ctx->err = "null frame pointer (an image output is needed: rainy_rgb or rainy_png)";
         return RR_E_ARG;
+      }
+      if (out[f].mask_png && !ctx->have_lut) {
+        ctx->err = "mask_png needs rr_set_colormap";
+        return RR_E_STATE;
       }
       if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
     }
@@ -2886,7 +2977,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   if ((rc = slot_init(ctx, sl))) return rc;
   auto& st = sl.st;
   if ((rc = slot_reserve(ctx, st, n, max_drops, dm))) return rc;
-  const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We;
+  const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We, png_bytes = (size_t)dm.H * (1 + 4 * (size_t)dm.W);
   hipStream_t s = ctx->stream;
   std::vector<rr_frame_in> din(in ? n : 0);
   std::vector<rr_frame_out> dout(in ? n : 0);
@@ -2928,6 +3019,8 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     dout[f].mask_f64 = st.mask + f * px;
     dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * px : nullptr;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
+    dout[f].rainy_png = out[f].rainy_png ? st.png_i + (size_t)f * png_bytes : nullptr;
+    dout[f].mask_png = out[f].mask_png ? st.png_m + (size_t)f * png_bytes : nullptr;
   }
   if ((rc = issue(ctx, up, hipMemcpyHostToDevice, ctx->s_up))) return rc;
   HIPCHK(hipEventRecord(sl.ev_up, ctx->s_up));
@@ -2943,11 +3036,13 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   // ---- download ----
   HIPCHK(hipStreamWaitEvent(ctx->s_down, sl.ev_comp, 0));
   for (int f = 0; in && f < n; f++) {
-    down.add(out[f].rainy_rgb, dout[f].rainy_rgb, px * 3);
+    if (out[f].rainy_rgb) down.add(out[f].rainy_rgb, dout[f].rainy_rgb, px * 3);
     if (out[f].rainy_bg_out) down.add(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double));
     if (out[f].mask_f64) down.add(out[f].mask_f64, dout[f].mask_f64, px * sizeof(double));
     if (out[f].mask_i32) down.add(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t));
     if (out[f].drop_status) down.add(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * (size_t)in[f].n_drops);
+    if (out[f].rainy_png) down.add(out[f].rainy_png, dout[f].rainy_png, png_bytes);
+    if (out[f].mask_png) down.add(out[f].mask_png, dout[f].mask_png, png_bytes);
   }
   for (int f = 0; pre && pre_out && f < n; f++) {
     if (pre_out[f].rainy_bg) down.add(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * sizeof(double));
@@ -3143,6 +3238,20 @@ int rr_envmap_width(rr_ctx* ctx) {
     return RR_E_STATE;
   }
   return ctx->eg.We;
+}
+
+int rr_set_colormap(rr_ctx* ctx, const uint8_t* lut_rgba) {
+  if (!ctx) return RR_E_ARG;
+  if (!lut_rgba) {
+    ctx->err = "rr_set_colormap: null table";
+    return RR_E_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->d_lut) HIPCHK(hipMalloc((void**)&ctx->d_lut, 1024));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(ctx->d_lut, lut_rgba, 1024, hipMemcpyHostToDevice));
+  ctx->have_lut = true;
+  return RR_OK;
 }
 
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {

@@ -46,7 +46,8 @@ class rr_frame_in(ctypes.Structure):
 
 class rr_frame_out(ctypes.Structure):
     _fields_ = [('rainy_rgb', ctypes.c_void_p), ('rainy_bg_out', ctypes.c_void_p), ('mask_f64', ctypes.c_void_p),
-                ('mask_i32', ctypes.c_void_p), ('drop_status', ctypes.c_void_p)]
+                ('mask_i32', ctypes.c_void_p), ('drop_status', ctypes.c_void_p),
+                ('rainy_png', ctypes.c_void_p), ('mask_png', ctypes.c_void_p)]
 
 
 class rr_kernel_stat(ctypes.Structure):
@@ -80,7 +81,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
            'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option',
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
-           'rr_sizeof_particle', 'rr_sizeof_particle_frame']
+           'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap']
 
 _lib = None
 
@@ -130,6 +131,7 @@ def load_library(path=None):
     lib.rr_pipeline_wait.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.rr_host_alloc.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64]
     lib.rr_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_set_colormap.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.rr_host_parse_particles.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
@@ -355,20 +357,29 @@ class RainHip:
             fin[k].strategy = int(fr.get('strategy', 0))
             fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
             for name, dt in (('image_u8', np.uint8), ('mask', np.float64), ('mask_i32', np.int32), ('rainy_bg', np.float64),
-                             ('status', np.int32)):
+                             ('status', np.int32), ('rainy_png', np.uint8), ('mask_png', np.uint8)):
                 a = o.get(name)
                 assert a is None or (a.dtype == dt and a.flags['C_CONTIGUOUS']), name
-            assert o['image_u8'].shape == (H, W, 3)
-            fout[k].rainy_rgb = _ptr(o['image_u8'])
+            assert o.get('image_u8') is None or o['image_u8'].shape == (H, W, 3)
+            fout[k].rainy_rgb = _ptr(o.get('image_u8'))
             fout[k].rainy_bg_out = _ptr(o.get('rainy_bg'))
             fout[k].mask_f64 = _ptr(o.get('mask'))
             fout[k].mask_i32 = _ptr(o.get('mask_i32'))
             fout[k].drop_status = _ptr(o.get('status')) if len(drops) else None
+            fout[k].rainy_png = _ptr(o.get('rainy_png'))
+            fout[k].mask_png = _ptr(o.get('mask_png'))
             keep.append((om, drops))
-        self._check(self.lib.rr_pipeline_submit(self.h, int(slot), n, pin, fin, fout, None), 'rr_pipeline_submit')
+        pout = None
+        if with_pre and any(o.get('env_bgr_u8') is not None for o in outs):
+            pout = (rr_prepass_out * n)()
+            for k, o in enumerate(outs):
+                e = o.get('env_bgr_u8')
+                assert e is None or (e.dtype == np.uint8 and e.flags['C_CONTIGUOUS'])
+                pout[k].env_bgr_u8 = _ptr(e)
+        self._check(self.lib.rr_pipeline_submit(self.h, int(slot), n, pin, fin, fout, pout), 'rr_pipeline_submit')
         if not hasattr(self, '_inflight'):
             self._inflight = {}
-        self._inflight[int(slot)] = (pin, fin, fout, keep, outs)
+        self._inflight[int(slot)] = (pin, fin, fout, pout, keep, outs)
 
     def pipeline_wait(self, slot):
         """True when the batch of `slot` is complete; False when the tile arena had to grow (submit the batch again)."""
@@ -402,6 +413,12 @@ class RainHip:
         offs = np.ascontiguousarray(offs, np.int64)
         self._check(self.lib.rr_set_streak_db_device(self.h, ctypes.c_void_p(dev_ptr), int(n_bytes), _ptr(hs), _ptr(ws),
                                                      _ptr(offs), len(hs)), 'rr_set_streak_db_device')
+
+    def set_colormap(self, lut_rgba):
+        """256x4 uint8 RGBA table of the colour map plt.imsave applies to the rain mask (common/imgops.viridis_lut())."""
+        lut = np.ascontiguousarray(lut_rgba, np.uint8)
+        assert lut.shape == (256, 4)
+        self._check(self.lib.rr_set_colormap(self.h, _ptr(lut)), 'rr_set_colormap')
 
     def set_option(self, option, value):
         """rr_set_option: tuning / A-B switches that never change a result bit (include/rainhip.h)."""

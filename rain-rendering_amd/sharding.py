@@ -22,6 +22,30 @@ def rank_world():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
 
 
+def ensure_group(rank, world):
+    """A launcher that only sets RANK / WORLD_SIZE / MASTER_* (no process group yet): create one, RCCL when a GPU is
+    there, gloo otherwise, so that the streak-database broadcast and rank0_decides work."""
+    if world <= 1:
+        return
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+
+
+def rank0_decides(fn, rank, world):
+    """fn() evaluated on rank 0 only; every rank returns rank 0's (picklable) result."""
+    if world <= 1:
+        return fn()
+    import torch.distributed as dist
+    ensure_group(rank, world)
+    box = [fn() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def shard(indices, rank, world):
     """Round-robin frame assignment."""
     return list(indices)[rank::world]
@@ -69,6 +93,7 @@ def load_and_broadcast_streak_db(db, hip, rank, world):
         hip.set_streak_db(db.streaks_light)
         return
     import torch
+    ensure_group(rank, world)
     packed = None
     if rank == 0:
         db.load_streak_database()
