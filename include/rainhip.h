@@ -251,6 +251,25 @@ int rr_profile_read(rr_ctx* ctx, rr_kernel_stat* out, int32_t cap);   /* returns
 int rr_host_drop_draws(uint32_t seed, int32_t n, const int32_t* tex_lo, const uint8_t* is_big, double noise_std,
                        int32_t* tex_index, double* noise);
 
+/* Host-only (no device, no ctx, no Python interpreter lock): one frame's drop table from the column store of its
+ * simulated frame.  rr_host_frame_draws applies the frame filter (common/generator.py:413-420), picks the texture block
+ * (bad_weather.py:250-265; ratio_db = DBManager.ratio, >= 4 entries) and makes the frame's draws in the reference's order;
+ * returns the number of kept streaks (<= t->n; keep / tex_index / noise need that capacity), noise = raw deviate * 1.
+ * rr_host_assemble_drops writes the rr_drop records once the caller has evaluated cos / sin of the rotation. */
+typedef struct {
+  int64_t n;
+  const double *wps, *wpe;        /* [n][3] world_position_start / _end */
+  const int64_t *ips, *ipe;       /* [n][2] image_position_start / _end (integers) */
+  const double *iw1, *iw2, *ratio;
+  const int64_t *max_width, *length;
+  const int32_t* type;            /* DropType */
+} rr_streak_table;
+int64_t rr_host_frame_draws(const rr_streak_table* t, int32_t W, int32_t H, const double* ratio_db, int32_t n_ratio,
+                            uint32_t seed, double noise_std, int64_t* keep, int32_t* tex_index, double* noise);
+int rr_host_assemble_drops(const rr_streak_table* t, int64_t n_keep, const int64_t* keep, const int32_t* tex_index,
+                           const double* rot_cos, const double* rot_sin, rr_drop* out);
+int rr_sizeof_streak_table(void);
+
 /* Host-only (no device, no ctx): the particles XML of the rain simulator -> flat records, replacing the reference's
  * pure-Python walk (common/bad_weather.py:192-211).  Raw attribute values only; the derived fields (render scale, y flip,
  * z sign, widths, ratio, rounding, the pid dictionary; bad_weather.py:208-241) stay with the caller.  Counts are always

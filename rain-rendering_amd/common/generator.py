@@ -67,6 +67,7 @@ class Generator:
         self._hip = None
         self._pool = None
         self.stats = []
+        self.timing = []
         if self.rendering_strategy not in (None, 'white'):
             raise NotImplementedError("rendering_strategy %r: 'naive_db' reads a non-existent attribute in the reference "
                                       "(bad_weather.py:355) and cannot run there either" % self.rendering_strategy)
@@ -108,13 +109,13 @@ class Generator:
         the run that used it: `earlier_seeds` replays those (same draws, same order) first.  The result therefore
         equals the reference's sequential run, does not depend on how frames are sharded over GPUs, and can be
         computed on any thread."""
-        table = pristine.take(slice(None))
+        noisy = bool(self.noise_std) and bool(self.noise_scale)
+        table = pristine.take(slice(None)) if noisy else pristine              # nothing is mutated without noise
         for s_ in earlier_seeds:
-            keep = hip_backend.filter_streaks(table, imW, imH)
-            hip_backend.pack_drops(table, keep, self.db, self.noise_std, self.noise_scale, seed=s_)
-        keep = hip_backend.filter_streaks(table, imW, imH)                          # generator.py:413-420
-        assert len(keep) <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
-        return hip_backend.pack_drops(table, keep, self.db, self.noise_std, self.noise_scale, seed=seed)
+            hip_backend.pack_frame(table, self.db, imW, imH, s_, self.noise_std, self.noise_scale)
+        drops = hip_backend.pack_frame(table, self.db, imW, imH, seed, self.noise_std, self.noise_scale)   # generator.py:413-420
+        assert len(drops) <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
+        return drops
 
     def _load_frame(self, image_file, depth_file, rs):
         """Image and depth of one frame as Generator.run reads them (generator.py:352-384)."""
@@ -377,6 +378,8 @@ class Generator:
             sl.encodes = []
 
         ahead = {}
+        t_loop0 = time.time()
+        t_first = None
         for bi in range(len(batches)):
             for bj in range(bi, min(bi + 2, len(batches))):     # decode two batches ahead of the GPU
                 if bj not in ahead:
@@ -425,6 +428,8 @@ class Generator:
             sl.frames, sl.outs = frames, outs
             sl.t_submit = time.time()
             hip.pipeline_submit(si, frames, outs)
+            if t_first is None:
+                t_first = time.time()                            # set-up (pinned buffers, first decodes) ends here
             sl.busy = True
             state['done'] += len(valid)
             if self.verbose:
@@ -434,3 +439,6 @@ class Generator:
             finish(si)
         for si in range(nslot):
             drain(si)
+        t_end = time.time()
+        self.timing.append(dict(frames=state['done'], first_batch_s=(t_first or t_end) - t_loop0, total_s=t_end - t_loop0,
+                                steady_frames_per_s=(max(state['done'] - B, 0) / (t_end - t_first)) if t_first and t_end > t_first else None))

@@ -119,6 +119,67 @@ extern "C" int rr_host_drop_draws(uint32_t seed, int32_t n, const int32_t* tex_l
 }
 
 // ---------------------------------------------------------------------------------------------------
+// rr_host_frame_draws / rr_host_assemble_drops: one frame's drop table off the Python interpreter.
+//   step 1  the frame filter of Generator.run (common/generator.py:413-420), the texture bucket of
+//           take_drop_texture (common/bad_weather.py:250-265) and the frame's random draws (above);
+//   (the caller's numpy evaluates the rotation terms: acos / cos / sin stay with numpy so that their bits do)
+//   step 2  rr_drop records from the table columns.
+// Both run without the GIL when called through ctypes: the driver's I/O threads scale.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int64_t rr_host_frame_draws(const rr_streak_table* t, int32_t W, int32_t H, const double* ratio_db, int32_t n_ratio,
+                                       uint32_t seed, double noise_std, int64_t* keep, int32_t* tex_index, double* noise) {
+  if (!t || t->n < 0 || !ratio_db || n_ratio < 4 || !keep || !tex_index || !noise) return RR_E_ARG;
+  const int64_t m = H > W ? H : W;
+  MT s;
+  mt_seed(s, seed);
+  int64_t nk = 0;
+  for (int64_t i = 0; i < t->n; i++) {
+    const int64_t sx = t->ips[2 * i], sy = t->ips[2 * i + 1], ex = t->ipe[2 * i], ey = t->ipe[2 * i + 1];
+    const bool in_s = 0 <= sx && sx < W && 0 <= sy && sy < H, in_e = 0 <= ex && ex < W && 0 <= ey && ey < H;
+    if (!(1 <= t->max_width[i] && t->max_width[i] < m && 1 <= t->length[i] && t->length[i] < m && (in_s || in_e))) continue;
+    const double r = t->ratio[i];
+    int b = 4;                                               // NaN falls through to the last block, like the reference's else
+    for (int k = 3; k >= 0; k--)
+      if (r < ratio_db[k]) b = k;
+    keep[nk] = i;
+    tex_index[nk] = (int32_t)mt_randint(s, 10 * b, 10 * b + 10);
+    noise[nk] = t->type[i] == 0 ? 0.0 : 0.0 + noise_std * mt_gauss(s);
+    nk++;
+  }
+  return nk;
+}
+
+extern "C" int rr_host_assemble_drops(const rr_streak_table* t, int64_t n_keep, const int64_t* keep, const int32_t* tex_index,
+                                      const double* rot_cos, const double* rot_sin, rr_drop* out) {
+  if (!t || n_keep < 0 || (n_keep > 0 && (!keep || !tex_index || !rot_cos || !rot_sin || !out))) return RR_E_ARG;
+  for (int64_t k = 0; k < n_keep; k++) {
+    const int64_t i = keep[k];
+    if (i < 0 || i >= t->n) return RR_E_ARG;
+    rr_drop& d = out[k];
+    d.x0 = (int32_t)t->ips[2 * i];
+    d.y0 = (int32_t)t->ips[2 * i + 1];
+    d.x1 = (int32_t)t->ipe[2 * i];
+    d.y1 = (int32_t)t->ipe[2 * i + 1];
+    d.max_width = (int32_t)t->max_width[i];
+    d.length = (int32_t)t->length[i];
+    d.type = t->type[i];
+    d.tex_index = tex_index[k];
+    d.iw1 = t->iw1[i];
+    d.iw2 = t->iw2[i];
+    for (int c = 0; c < 3; c++) {
+      d.wps[c] = t->wps[3 * i + c];
+      d.wpe[c] = t->wpe[3 * i + c];
+    }
+    const bool big = t->type[i] == 0;
+    d.rot_cos = big ? 1.0 : rot_cos[k];
+    d.rot_sin = big ? 0.0 : rot_sin[k];
+  }
+  return RR_OK;
+}
+
+extern "C" int rr_sizeof_streak_table(void) { return (int)sizeof(rr_streak_table); }
+
+// ---------------------------------------------------------------------------------------------------
 // rr_host_parse_particles: the particles XML of the rain simulator (schema read by the reference's
 // DBManager.load_streaks_from_xml, common/bad_weather.py:192-211) -> flat records.
 //   root element: any name; its child elements are frames (attributes id, t, d, rs; tag names ignored);

@@ -70,6 +70,12 @@ class rr_prepass_in(ctypes.Structure):
                 ('irr_num', ctypes.c_double), ('irr_den', ctypes.c_double), ('bg_u8', ctypes.c_void_p)]
 
 
+class rr_streak_table(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int64), ('wps', ctypes.c_void_p), ('wpe', ctypes.c_void_p), ('ips', ctypes.c_void_p),
+                ('ipe', ctypes.c_void_p), ('iw1', ctypes.c_void_p), ('iw2', ctypes.c_void_p), ('ratio', ctypes.c_void_p),
+                ('max_width', ctypes.c_void_p), ('length', ctypes.c_void_p), ('type', ctypes.c_void_p)]
+
+
 class rr_prepass_out(ctypes.Structure):
     _fields_ = [('rainy_bg', ctypes.c_void_p), ('env_xyY', ctypes.c_void_p), ('env_bgr_u8', ctypes.c_void_p)]
 
@@ -81,7 +87,8 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
            'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option',
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
-           'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap']
+           'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
+           'rr_sizeof_streak_table']
 
 _lib = None
 
@@ -132,6 +139,12 @@ def load_library(path=None):
     lib.rr_host_alloc.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64]
     lib.rr_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.rr_set_colormap.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_host_frame_draws.restype = ctypes.c_int64
+    lib.rr_host_frame_draws.argtypes = [ctypes.POINTER(rr_streak_table), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                        ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_host_assemble_drops.argtypes = [ctypes.POINTER(rr_streak_table), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.rr_sizeof_streak_table() == ctypes.sizeof(rr_streak_table)
     lib.rr_host_parse_particles.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
@@ -264,6 +277,67 @@ def pack_drops(table, idx, db, noise_std=0.0, noise_scale=0.0, seed=None):
     out['wpe'] = table.wpe[idx]
     out['rot_cos'] = np.where(nb, rot_cos, 1.0)
     out['rot_sin'] = np.where(nb, rot_sin, 0.0)
+    return out
+
+
+def _table_view(table):
+    """rr_streak_table over a StreakTable's columns (which must stay alive and C-contiguous)."""
+    t = rr_streak_table()
+    cols = dict(wps=np.float64, wpe=np.float64, ips=np.int64, ipe=np.int64, iw1=np.float64, iw2=np.float64, ratio=np.float64,
+                max_width=np.int64, length=np.int64, type=np.int32)
+    for k, dt in cols.items():
+        a = getattr(table, k)
+        assert a.dtype == dt and a.flags['C_CONTIGUOUS'], k
+        setattr(t, k, a.ctypes.data)
+    t.n = len(table)
+    return t
+
+
+def pack_frame(table, db, imW, imH, seed, noise_std=0.0, noise_scale=0.0):
+    """filter_streaks + pack_drops(seed=...) of one frame with the per-drop work in the library
+    (rr_host_frame_draws / rr_host_assemble_drops: no interpreter lock held, so I/O threads scale); numpy keeps the
+    rotation terms (acos / cos / sin).  Same records as pack_drops(table, filter_streaks(table, imW, imH), db, ..., seed);
+    rotates the end points of `table` in place when angular noise is on, like the reference (generator.py:152-161)."""
+    lib = load_library()
+    if not 0 <= int(seed) <= 2 ** 32 - 1:
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    n = len(table)
+    tv = _table_view(table)
+    keep = np.empty(n, np.int64)
+    tex = np.empty(n, np.int32)
+    noise = np.empty(n, np.float64)
+    ratio_db = np.ascontiguousarray(db.ratio, np.float64)
+    nk = lib.rr_host_frame_draws(ctypes.byref(tv), int(imW), int(imH), _ptr(ratio_db), len(ratio_db), ctypes.c_uint32(int(seed)),
+                                 float(noise_std), _ptr(keep), _ptr(tex), _ptr(noise))
+    if nk < 0:
+        raise RuntimeError("rr_host_frame_draws failed (%d)" % nk)
+    keep, tex, noise = keep[:nk], tex[:nk], noise[:nk] * noise_scale
+    out = np.zeros(nk, DROP_DTYPE)
+    if nk == 0:
+        return out
+    s = table.ips[keep].astype(np.float64)
+    e = table.ipe[keep].astype(np.float64)
+    with np.errstate(all='ignore'):
+        d = s - e
+        n1 = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+        theta = np.rad2deg(np.arccos((d[:, 0] / n1) * 0 + (d[:, 1] / n1) * -1))
+        ang = -(theta + noise) * (np.pi / 180)
+        rot_cos, rot_sin = np.cos(ang), np.sin(ang)
+    if np.any(noise != 0):
+        nb = table.type[keep] != 0
+        nx, ny = np.cos(np.deg2rad(noise)), np.sin(np.deg2rad(noise))
+        mx = (e[:, 0] + s[:, 0]) / 2
+        my = (e[:, 1] + s[:, 1]) / 2
+        s2 = np.stack([(s[:, 0] - mx) * nx - (s[:, 1] - my) * ny + mx,
+                       (s[:, 0] - mx) * ny + (s[:, 1] - my) * nx + my], axis=1).astype(np.int64)
+        e2 = np.stack([(e[:, 0] - mx) * nx - (e[:, 1] - my) * ny + mx,
+                       (e[:, 0] - mx) * ny + (e[:, 1] - my) * nx + my], axis=1).astype(np.int64)
+        sel = keep[nb]
+        table.ips[sel] = s2[nb]
+        table.ipe[sel] = e2[nb]
+    rc = lib.rr_host_assemble_drops(ctypes.byref(tv), nk, _ptr(keep), _ptr(tex), _ptr(rot_cos), _ptr(rot_sin), _ptr(out))
+    if rc != 0:
+        raise RuntimeError("rr_host_assemble_drops failed (%d)" % rc)
     return out
 
 

@@ -94,3 +94,39 @@ def test_arena_regrowth_mid_batch(tmp_path, built):
             assert np.array_equal(o['mask'], emu['mask']) and np.array_equal(o['status'], emu['status'])
     finally:
         rh.close()
+
+
+def test_png_scanlines_from_the_device(tmp_path, built):
+    """rr_frame_out.rainy_png / mask_png: the PNG files built from the device's Sub-filtered scanlines decode to the
+    very pixels the host-side writers produce from image_u8 / mask (generator.py:466-467)."""
+    import importlib
+    from PIL import Image
+    imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+    H, W = 96, 160
+    sc = h.Scene(tmp_path, H, W, 150, n_frames=2, seed0=31)
+    rh = h.hb.RainHip(0)
+    try:
+        rh.set_streak_db(sc.db.streaks_light)
+        rh.set_camera(sc.cam)
+        rh.set_colormap(imgops.viridis_lut())
+        consts, We = tp._setup(rh, H, W, 25)
+        frames, outs = [], []
+        for i in range(2):
+            bg, depth = tp._scene(H, W, 31 + i)
+            frames.append(dict(bg_u8=(bg * 255).astype(np.uint8), depth=depth, fog=consts, omega=sc.omega,
+                               drops=sc.product_drops(i) if i == 0 else np.zeros(0, h.hb.DROP_DTYPE)))   # frame 1: empty mask
+            outs.append(dict(image_u8=np.zeros((H, W, 3), np.uint8), mask=np.zeros((H, W)),
+                             rainy_png=np.zeros(H * (1 + 4 * W), np.uint8), mask_png=np.zeros(H * (1 + 4 * W), np.uint8)))
+        rh.pipeline_submit(0, frames, outs)
+        assert rh.pipeline_wait(0)
+        for i, o in enumerate(outs):
+            p1, p2 = str(tmp_path / ('i%d.png' % i)), str(tmp_path / ('m%d.png' % i))
+            imgops.png_from_scanlines(p1, o['rainy_png'], W, H)
+            imgops.png_from_scanlines(p2, o['mask_png'], W, H)
+            img = np.array(Image.open(p1))
+            assert img.shape == (H, W, 4) and np.array_equal(img[..., :3], o['image_u8']) and np.all(img[..., 3] == 255)
+            imgops.imsave_scalar(str(tmp_path / 'ref.png'), o['mask'])
+            assert np.array_equal(np.array(Image.open(p2)), np.array(Image.open(str(tmp_path / 'ref.png'))))
+        assert outs[0]['mask'].max() > 0 and outs[1]['mask'].max() == 0
+    finally:
+        rh.close()

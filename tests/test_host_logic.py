@@ -266,3 +266,17 @@ def test_noisy_pack_replays_earlier_frames(tmp_path):
         got = g._pack(pristine[i % 2], 160, 96, i, earlier)
         assert got.tobytes() == seq[i].tobytes(), i
     assert seq[2].tobytes() != g._pack(pristine[0], 160, 96, 2).tobytes()      # the replay matters
+
+
+@pytest.mark.parametrize("noise_std,noise_scale", [(0.0, 0.0), (4.0, 1.0)])
+def test_native_pack_frame_equals_numpy_pack(tmp_path, noise_std, noise_scale):
+    """hip_backend.pack_frame (filter + bucket + draws + record assembly in the library) against
+    filter_streaks + pack_drops: byte-identical drop tables and the same in-place end-point rotation."""
+    sc = h.Scene(tmp_path, 96, 160, 300, n_frames=2, seed0=5, far_fraction=0.1)
+    for fi, fr in enumerate(sc.db.streaks_simulator.values()):
+        a, b = fr.table.take(slice(None)), fr.table.take(slice(None))
+        for seed in (fi, 1000 + fi):                           # two frames using the same simulated frame
+            ref = h.hb.pack_drops(a, h.hb.filter_streaks(a, 160, 96), sc.db, noise_std, noise_scale, seed=seed)
+            got = h.hb.pack_frame(b, sc.db, 160, 96, seed, noise_std, noise_scale)
+            assert len(ref) > 100 and got.tobytes() == ref.tobytes()
+            assert np.array_equal(a.ips, b.ips) and np.array_equal(a.ipe, b.ipe)
