@@ -385,8 +385,8 @@ class Generator:
                 if bj not in ahead:
                     ahead[bj] = decode_batch(bj)
             si = bi % nslot
-            finish(si)
-            drain(si)
+            finish(si)                                           # (no-op unless fewer batches than slots ran in between)
+            drain(si)                                            # its deflate jobs had two iterations to finish
             loaded = [f.result() for f in ahead.pop(bi)]
             valid = [(it, ld) for it, ld in zip(batches[bi], loaded) if ld is not None]
             for it, ld in zip(batches[bi], loaded):
@@ -432,6 +432,8 @@ class Generator:
                 t_first = time.time()                            # set-up (pinned buffers, first decodes) ends here
             sl.busy = True
             state['done'] += len(valid)
+            # the GPU now has this batch queued: collect the previous one and start deflating it right away
+            finish((bi - 1) % nslot)
             if self.verbose:
                 sys.stdout.write('\r          S. {} / {}, F. {} / {}   ({:.1f}s)'.format(
                     folder_idx + 1, folders_num, state['done'], len(work), time.time() - sim_t0))

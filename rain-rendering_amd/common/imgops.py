@@ -92,8 +92,29 @@ def _save_rgba(path, rgba):
         write_png_rgba(path, rgba)
 
 
-def imread_bgr(path):
-    """cv2.imread(path): 8-bit, 3 channels, BGR order."""
+def _native_png(path):
+    """(lib, W, H, channels, depth) when the library's PNG reader takes the file, else None."""
+    import ctypes
+    from .. import hip_backend
+    if not str(path).lower().endswith('.png'):
+        return None
+    lib = hip_backend.load_library()
+    w, h, c, d = (ctypes.c_int32() for _ in range(4))
+    if lib.rr_png_info(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), ctypes.byref(c), ctypes.byref(d)) != 0:
+        return None
+    return lib, w.value, h.value, c.value, d.value
+
+
+def imread_bgr(path, out=None):
+    """cv2.imread(path): 8-bit, 3 channels, BGR order.  PNGs go through the library's reader (rr_png_read_bgr8: no
+    interpreter lock, straight into `out` when given); anything it does not take through PIL."""
+    info = _native_png(path)
+    if info is not None and info[4] == 8:
+        lib, w, h = info[:3]
+        dst = out if out is not None else np.empty((h, w, 3), np.uint8)
+        if dst.shape == (h, w, 3) and dst.dtype == np.uint8 and dst.flags['C_CONTIGUOUS']:
+            if lib.rr_png_read_bgr8(os.fsencode(path), dst.ctypes.data, h, w) == 0:
+                return dst
     from PIL import Image
     im = np.array(Image.open(path).convert('RGB'))
     return np.ascontiguousarray(im[..., ::-1])
@@ -101,6 +122,12 @@ def imread_bgr(path):
 
 def imread_unchanged(path):
     """cv2.imread(path, cv2.IMREAD_UNCHANGED) for 8/16-bit single-channel PNGs."""
+    info = _native_png(path)
+    if info is not None and info[3] == 1 and info[4] == 16:
+        lib, w, h = info[:3]
+        dst = np.empty((h, w), np.uint16)
+        if lib.rr_png_read_gray16(os.fsencode(path), dst.ctypes.data, h, w) == 0:
+            return dst
     from PIL import Image
     try:
         return np.array(Image.open(path))
@@ -150,18 +177,15 @@ def viridis_lut():
 
 def png_from_scanlines(path, rows, width, height, level=None):
     """An RGBA PNG file from its filtered scanlines (height rows of 1 + 4*width bytes, as the library's
-    rr_frame_out.rainy_png / mask_png deliver them): one zlib stream + chunk framing.  zlib releases the GIL."""
-    import struct
-    import zlib
-    assert len(rows) == height * (1 + 4 * width) if not hasattr(rows, 'nbytes') else rows.nbytes == height * (1 + 4 * width)
-
-    def chunk(tag, data):
-        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
-
-    blob = (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', width, height, 8, 6, 0, 0, 0)) +
-            chunk(b'IDAT', zlib.compress(rows, PNG_LEVEL if level is None else level)) + chunk(b'IEND', b''))
-    with open(path, 'wb') as fh:
-        fh.write(blob)
+    rr_frame_out.rainy_png / mask_png deliver them): zlib deflate + chunk framing inside the library
+    (rr_png_write_scanlines), off the interpreter lock."""
+    from .. import hip_backend
+    rows = np.ascontiguousarray(rows, np.uint8)
+    assert rows.nbytes == height * (1 + 4 * width)
+    rc = hip_backend.load_library().rr_png_write_scanlines(os.fsencode(path), rows.ctypes.data, int(width), int(height),
+                                                           PNG_LEVEL if level is None else int(level))
+    if rc != 0:
+        raise IOError("rr_png_write_scanlines(%s) failed (%d)" % (path, rc))
 
 
 def imsave_scalar(path, a):

