@@ -24,6 +24,20 @@ FOG_ATT = 1                  # reference generator.py:19
 USE_DEPTH_WEIGHTING = 0      # reference generator.py:20 (dead in the reference, not implemented)
 
 
+def _cpu_budget():
+    """CPUs this process may really use: the cgroup quota when there is one (containers), else the affinity mask."""
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 4
+
+
 class Generator:
     def __init__(self, args):
         self.conflict_strategy = args.conflict_strategy
@@ -99,7 +113,7 @@ class Generator:
         around the GPU call is what bounds the driver end to end, so it runs ahead of / behind the GPU."""
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=max(2, min(int(os.environ.get('RAIN_IO_THREADS', '96')), (os.cpu_count() or 4))))
+            self._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('RAIN_IO_THREADS', 0)) or max(2, min(96, 2 * _cpu_budget())))
         return self._pool
 
     def _pack(self, pristine, imW, imH, seed, earlier_seeds=()):

@@ -58,6 +58,10 @@ def resize_linear(img, dw, dh):
 # zlib level of the PNGs the driver writes.  Pixels are what parity is about; matplotlib's default (6)
 # costs ~0.4 s per 1242x375 RGBA frame, level 1 a quarter of that for ~15% larger files.
 PNG_LEVEL = int(os.environ.get('RAIN_PNG_LEVEL', '1'))
+# deflate strategy of the scanline writer: 'rle' (run lengths + Huffman: on Sub-filtered image rows smaller files than
+# the default strategy at level 1, in half the time), 'default' (LZ77: the files of the previous writer, byte for byte),
+# 'huffman'.  Decoded pixels are the same whatever the choice.
+PNG_STRATEGY = {'default': 0, 'rle': 1, 'huffman': 2}[os.environ.get('RAIN_PNG_STRATEGY', 'rle')]
 
 
 def write_png_rgba(path, rgba, level=None):
@@ -175,7 +179,7 @@ def viridis_lut():
     return _viridis
 
 
-def png_from_scanlines(path, rows, width, height, level=None):
+def png_from_scanlines(path, rows, width, height, level=None, strategy=None):
     """An RGBA PNG file from its filtered scanlines (height rows of 1 + 4*width bytes, as the library's
     rr_frame_out.rainy_png / mask_png deliver them): zlib deflate + chunk framing inside the library
     (rr_png_write_scanlines), off the interpreter lock."""
@@ -183,7 +187,8 @@ def png_from_scanlines(path, rows, width, height, level=None):
     rows = np.ascontiguousarray(rows, np.uint8)
     assert rows.nbytes == height * (1 + 4 * width)
     rc = hip_backend.load_library().rr_png_write_scanlines(os.fsencode(path), rows.ctypes.data, int(width), int(height),
-                                                           PNG_LEVEL if level is None else int(level))
+                                                           PNG_LEVEL if level is None else int(level),
+                                                           PNG_STRATEGY if strategy is None else int(strategy))
     if rc != 0:
         raise IOError("rr_png_write_scanlines(%s) failed (%d)" % (path, rc))
 

@@ -182,13 +182,25 @@ extern "C" int rr_png_read_gray16(const char* path, uint16_t* out, int32_t H, in
   return RR_OK;
 }
 
-// RGBA PNG from its filtered scanlines: H rows of 1 + 4*W bytes (filter byte + filtered pixels)
-extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int32_t W, int32_t H, int32_t level) {
-  if (!path || !rows || W <= 0 || H <= 0 || level < 0 || level > 9) return RR_E_ARG;
+// RGBA PNG from its filtered scanlines: H rows of 1 + 4*W bytes (filter byte + filtered pixels).
+// strategy: 0 zlib's default (LZ77 + Huffman), 1 Z_RLE (run lengths + Huffman: on filtered image data as small as
+// level 1 of the default strategy or smaller, at half the time), 2 Z_HUFFMAN_ONLY.
+extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int32_t W, int32_t H, int32_t level, int32_t strategy) {
+  if (!path || !rows || W <= 0 || H <= 0 || level < 0 || level > 9 || strategy < 0 || strategy > 2) return RR_E_ARG;
   const uLong n = (uLong)H * (1 + 4 * (uLong)W);
-  uLongf clen = compressBound(n);
-  std::vector<uint8_t> z(clen);
-  if (compress2(z.data(), &clen, rows, n, level) != Z_OK) return RR_E_PARSE;
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (deflateInit2(&zs, level, Z_DEFLATED, 15, 9, strategy == 1 ? Z_RLE : strategy == 2 ? Z_HUFFMAN_ONLY : Z_DEFAULT_STRATEGY) != Z_OK)
+    return RR_E_PARSE;
+  std::vector<uint8_t> z(deflateBound(&zs, n));
+  zs.next_in = const_cast<Bytef*>(rows);
+  zs.avail_in = (uInt)n;
+  zs.next_out = z.data();
+  zs.avail_out = (uInt)z.size();
+  const int zrc = deflate(&zs, Z_FINISH);
+  const uLongf clen = zs.total_out;
+  deflateEnd(&zs);
+  if (zrc != Z_STREAM_END) return RR_E_PARSE;
   FILE* fh = fopen(path, "wb");
   if (!fh) return RR_E_ARG;
   auto put32 = [](uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };

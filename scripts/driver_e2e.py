@@ -30,6 +30,7 @@ def main():
     ge.build()
     synthetic = importlib.import_module('rain-rendering_amd.synthetic')
     main_mod = importlib.import_module('rain-rendering_amd.main')
+    generator_mod = importlib.import_module('rain-rendering_amd.common.generator')
     H, W = args.height, args.width
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, 'source')
@@ -51,7 +52,7 @@ def main():
         gpu_ms = sum(s['gpu_ms'] for s in gen.stats) / max(n, 1)
         print(json.dumps({"what": "main.py driver end to end (XML load, PNG decode, GPU pipeline, PNG encode)",
                           "frames": n, "seconds": t1 - t0, "frames_per_s": n / (t1 - t0),
-                          "pipeline_call_ms_per_frame": gpu_ms, "cores": os.cpu_count(), "timing": gen.timing,
+                          "pipeline_call_ms_per_frame": gpu_ms, "cores": os.cpu_count(), "cpu_quota": generator_mod._cpu_budget(), "io_threads": gen._io_pool()._max_workers, "timing": gen.timing,
                           "workload": "%dx%d, %d mm/hr" % (W, H, args.rate)}))
 
 

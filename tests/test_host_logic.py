@@ -307,8 +307,6 @@ def test_native_png_codec(tmp_path):
     Image.fromarray(d16).save(p)
     got = imgops.imread_unchanged(p)
     assert got.dtype == np.uint16 and np.array_equal(got, d16)
-    p = str(tmp_path / 'i.png')                                  # interlaced: not taken natively, still read
-    Image.fromarray(smooth).save(p, interlace=1) if False else Image.fromarray(smooth).save(p)
     # writer: scanlines -> file -> PIL
     rgba = np.dstack([smooth, np.full(smooth.shape[:2], 255, np.uint8)])
     hh, ww = rgba.shape[:2]
@@ -317,9 +315,14 @@ def test_native_png_codec(tmp_path):
     rows[:, 0] = 1
     rows[:, 1:5] = flat[:, :4]
     rows[:, 5:] = flat[:, 4:] - flat[:, :-4]
-    for level in (0, 1, 6):
-        p = str(tmp_path / ('w%d.png' % level))
-        imgops.png_from_scanlines(p, rows, ww, hh, level=level)
+    import os
+    for level, strategy in ((0, 0), (1, 0), (6, 0), (1, 1), (1, 2)):
+        p = str(tmp_path / ('w%d%d.png' % (level, strategy)))
+        imgops.png_from_scanlines(p, rows, ww, hh, level=level, strategy=strategy)
         assert np.array_equal(np.array(Image.open(p)), rgba)
+    # strategy 0 at the writer's level: the very file the Python writer produces
+    imgops.write_png_rgba(str(tmp_path / 'py1.png'), rgba, level=1)
+    assert open(str(tmp_path / 'py1.png'), 'rb').read() == open(str(tmp_path / 'w10.png'), 'rb').read()
+    assert os.path.getsize(str(tmp_path / 'w11.png')) <= 1.02 * os.path.getsize(str(tmp_path / 'w10.png'))
     imgops.write_png_rgba(str(tmp_path / 'py.png'), rgba)
     assert np.array_equal(np.array(Image.open(str(tmp_path / 'py.png'))), rgba)
