@@ -76,6 +76,13 @@ __device__ inline rr_drop load_drop(const rr_drop* p) {       // 14 global 8-byt
   return d;
 }
 
+__device__ inline void wave_lds_sync() {
+  // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
+  // stops the compiler from moving accesses across the hand-off point.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 struct Scratch {                    // per-batch device scratch, all indexed [frame][...]
   DropPlan* plan;
   CompRec* comp;
@@ -242,24 +249,48 @@ __device__ inline bool blur_is_slow(const DropPlan& p) {
 // ---------------------------------------------------------------------------
 // per-drop plan
 // ---------------------------------------------------------------------------
+// One thread per drop.  The 312-byte plans leave through LDS: a thread storing its own record would touch 78 different
+// lines with 4-byte pieces (the L2 then writes partial lines back: 5x the payload); staged 32 records at a time per
+// wave, the stores are whole, consecutive lines.
+constexpr int PLAN_DW = (int)(sizeof(DropPlan) / 4);
 __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, rr_camera cam, const int32_t* tex_h,
                                               const int32_t* tex_w, int max_drops, Scratch sc) {
+  static_assert(sizeof(DropPlan) % 4 == 0, "DropPlan layout");
   const int f = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const FrameDesc& fr = frames[f];
-  if (i >= fr.n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  rr_drop d = load_drop(fr.drops + i);
+  __shared__ uint32_t s_plan[2][32 * PLAN_DW];
+  const bool act = i < fr.n_drops;
+  const int64_t gi = (int64_t)f * max_drops + (act ? i : 0);
   DropPlan p;
-  int64_t size = 0;
-  plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size);
-  // the FOV polygon (k_fov_spans, launched before this kernel) is evaluated for every drop: in the reference
-  // its failure is raised before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
-  const int npts = sc.npts[gi];                   // 0: failed; -1: 'white' strategy (never used)
-  if (p.status != RR_DROP_OK || npts == 0) size = 0;
-  if (size > 0 && blur_is_slow(p)) size += (int64_t)p.ew * p.eh;
-  sc.sizes[gi] = size;
-  sc.plan[gi] = p;
+  if (act) {
+    rr_drop d = load_drop(fr.drops + i);
+    int64_t size = 0;
+    plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size);
+    // the FOV polygon (k_fov_spans, launched before this kernel) is evaluated for every drop: in the reference
+    // its failure is raised before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
+    const int npts = sc.npts[gi];                 // 0: failed; -1: 'white' strategy (never used)
+    if (p.status != RR_DROP_OK || npts == 0) size = 0;
+    if (size > 0 && blur_is_slow(p)) size += ((int64_t)p.ew * p.eh + 15) & ~15LL;     // dense scratch tile of the two-pass blur
+    sc.sizes[gi] = size;
+  }
+  const int wave_i0 = blockIdx.x * blockDim.x + wave * 64;         // first drop of this wave
+  uint32_t* stage = s_plan[wave];
+  uint32_t* out = reinterpret_cast<uint32_t*>(sc.plan + (int64_t)f * max_drops + wave_i0);
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if (act && (lane >> 5) == half) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&p);
+#pragma unroll
+      for (int k = 0; k < PLAN_DW; k++) stage[(lane & 31) * PLAN_DW + k] = src[k];
+    }
+    wave_lds_sync();
+    const int first = wave_i0 + half * 32;
+    const int nrec = imax(imin(32, fr.n_drops - first), 0);
+    for (int k = lane; k < nrec * PLAN_DW; k += 64) out[half * 32 * PLAN_DW + k] = stage[k];
+    wave_lds_sync();
+  }
 }
 
 // one block per frame: exclusive scan of arena sizes
@@ -290,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
       sc.sizes[base + i] = 0;
     } else {
       p.a0_off = frame_base + run;
-      p.a1_off = frame_base + run + (int64_t)p.tw * p.th;
+      p.a1_off = frame_base + run + (((int64_t)p.tw * p.th + 15) & ~15LL);
     }
     run += sz;
   }
@@ -373,13 +404,6 @@ constexpr int COL_PARTS = 8;        // row bands of the environment map; partial
 constexpr int HE_MAX = 1024;        // tallest map of the fast path: 16 chunks of 64 rows in registers
 constexpr int FOV_WE_MAX = 4096;    // widest map of the fast path: (We + 1) * 32 B of LDS, <= 4 columns per thread
 constexpr int FOV_GROUPS = 3;       // drops per wave in k_fov_spans (n_fov = 20: 60 of 64 lanes busy)
-
-__device__ inline void wave_lds_sync() {
-  // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
-  // stops the compiler from moving accesses across the hand-off point.
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // fov_rowspan (rr_device.h) with the rounded edge intersection evaluated in double: exact,
 // because |2*num+den| < 2^26 and a non-integer quotient is at least 1/(2*den) away from an integer.
@@ -858,9 +882,9 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
         rec.x1 = imin(p.vis_x0 + p.vis_w, fx0 + p.ew);
         rec.y1 = imin(p.vis_y0 + p.vis_h, fy0 + p.eh);
         if (rec.x1 <= rec.x0 || rec.y1 <= rec.y0) { rec.x0 = rec.y0 = rec.x1 = rec.y1 = 0; }
-        rec.ox = -fx0;
+        rec.ox = -(fx0 - p.epad);
         rec.oy = -fy0;
-        rec.pitch = p.ew;
+        rec.pitch = p.epitch;
         rec.off = p.a1_off;
       } else {                         // no blur: the pad is exact zeros (a no-op in the blend); read the raw tile
         const int rx0 = p.vis_x0 - p.crop_x + p.shift, ry0 = p.vis_y0 - p.crop_y + p.shift;   // frame position of raw (0,0)
@@ -1630,7 +1654,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
             acc0 = c0[0]; acc1 = c0[1]; acc2 = c0[2]; acc3 = c0[3];
           }
           const int xb = 4 * cb;
-          double* o = dst + (int64_t)(y0 + yy) * pw + (x0 + xb);
+          double* o = dst + (int64_t)(y0 + yy) * p.epitch + p.epad + (x0 + xb);
           if (xb < wo) o[0] = acc0;
           if (xb + 1 < wo) o[1] = acc1;
           if (xb + 2 < wo) o[2] = acc2;
@@ -1731,8 +1755,8 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
         a0 = q0[0];
         a1 = q1[0];
       }
-      tile[i0] = a0;
-      if (base + 64 < nh) tile[i1] = a1;
+      tile[y0 * p.epitch + p.epad + x0] = a0;
+      if (base + 64 < nh) tile[y1 * p.epitch + p.epad + x1] = a1;
     }
     wave_lds_sync();
   }
@@ -1749,8 +1773,8 @@ __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_d
     const int r = AXIS == 0 ? p.r1 : p.r2;
     const int pw = p.ew, ph = p.eh, n = pw * ph;              // effective tile
     const double* raw = sc.arena + p.a0_off;
-    double* fin = sc.arena + p.a1_off;
-    double* tmp = fin + n;                            // scratch tile reserved by k_plan for slow drops
+    double* fin = sc.arena + p.a1_off;               // pitch p.epitch, first column p.epad
+    double* tmp = fin + (((int64_t)p.epitch * ph + 15) & ~15LL);   // dense scratch tile reserved by k_plan for slow drops
     __syncthreads();
     if (r > 0) gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
     for (int idx = threadIdx.x; idx < n; idx += 256) {
@@ -1768,7 +1792,7 @@ __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_d
         }
         tmp[idx] = acc;
       } else {
-        fin[idx] = r > 0 ? blur_axis1(tmp, pw, ph, x, y, hw, r) : tmp[idx];
+        fin[(int64_t)y * p.epitch + p.epad + x] = r > 0 ? blur_axis1(tmp, pw, ph, x, y, hw, r) : tmp[idx];
       }
     }
   }
@@ -1869,7 +1893,9 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     }
     if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
     __syncthreads();
-    // software-pipelined: the alpha sample of entry e+1 is in flight while entry e is blended
+    // software-pipelined: the alpha sample of entry e+1 is in flight while entry e is blended.  (Measured and
+    // rejected: records staged through LDS with four samples in flight per lane -- 20 % slower: the records are
+    // wave-uniform and cost nothing as scalar operands, and the kernel is bound by its f64 blend arithmetic.)
     bool in_n = false;
     double A_n = 0.0;
     if (total > 0) {
@@ -2249,7 +2275,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->d_frames, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->d_comp_out, (size_t)F * dm.H * dm.W * 3))) return rc;
     // arena: keep per-frame capacity, reallocate for the new frame count
-    if (ctx->arena_cap == 0) ctx->arena_cap = (int64_t)(D > 0 ? D : 1) * 1024 + (1 << 20);
+    if (ctx->arena_cap == 0) ctx->arena_cap = (int64_t)(D > 0 ? D : 1) * 1024 + (1 << 20);      // a multiple of 16 doubles
     if ((rc = dev_alloc(ctx, ctx->sc.arena, (size_t)F * (size_t)ctx->arena_cap))) return rc;
     ctx->cap_frames = F;
     ctx->cap_drops = D;
@@ -2260,7 +2286,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
 
 int grow_arena(rr_ctx* ctx, int64_t need) {
   HIPCHK(hipDeviceSynchronize());
-  int64_t cap = need + need / 4 + (1 << 16);
+  int64_t cap = (need + need / 4 + (1 << 16) + 15) & ~15LL;
   ctx->arena_cap = cap;
   int rc = dev_alloc(ctx, ctx->sc.arena, (size_t)ctx->cap_frames * (size_t)cap);
   if (rc) return rc;
