@@ -255,11 +255,16 @@ class DBManager:
             raise Exception("Reading XML file {} crashed, which is likely due to corrupted particles simulation "
                             "files. If so, delete this simulation folder manually and re-run to allow generation "
                             "of new simulation.".format(self.streaks_path_xml))
+        self.load_streaks_from_records(frames, drops, dataset, settings, image_shape_WH)
+
+    def load_streaks_from_records(self, frames, drops, dataset, settings, image_shape_WH):
+        """The derived fields of reference bad_weather.py:208-241 for raw particle records (PARTICLE_FRAME_DTYPE /
+        PARTICLE_DTYPE arrays: what rr_host_parse_particles reads from an XML file, or what tools/particles.py
+        generates without one), every drop of the sequence at once."""
         rs = settings["render_scale"]
         gan = dataset == 'nuscenes_gan'
         r_gan = np.mean((image_shape_WH[0] / 1600, image_shape_WH[1] / 900)) if gan else None
         try:
-            # every drop of the file at once (bad_weather.py:208-241)
             pid = drops['pid']
             wps, wpe = drops['wp1'].copy(), drops['wp2'].copy()
             iw = np.stack([drops['iw1'], drops['iw2']], axis=1)

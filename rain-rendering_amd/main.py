@@ -5,8 +5,8 @@ files main.py:187-220), so an existing invocation keeps working:
     python rain-rendering_amd/main.py --dataset kitti --intensity 25 --frame_end 10
     python -m torch.distributed.run --nproc-per-node 8 rain-rendering_amd/main.py --dataset kitti ...
 
-Not driven from here: the external particle simulator (reference tools/, no source in the
-reference tree).  Particle files have to exist already."""
+Missing particle files are produced by this build's own generator (tools/particles.py) where the
+reference would start its external, closed-source simulator."""
 import argparse
 import glob
 import os
@@ -115,24 +115,31 @@ def _drop_incomplete_sequences(ns):
 
 
 def _locate_particles(ns):
-    """One particle file per (sequence, fall rate); the simulator itself is not run from here."""
+    """One particle file per (sequence, fall rate) (reference main.py:187-220).  Where the reference launches the external
+    weather-particle-simulator for missing (or --force_particles) files, this build runs its own generator
+    (tools/particles.py: same settings in, same XML schema out; there is no source of the reference's simulator)."""
     print("\nResolving particles simulations...")
     root = _J(ns.particles, ns.dataset)
-    found, missing = {}, []
+    found, to_run = {}, []
     for seq in ns.sequences:
         sim = db.sim(ns.dataset, seq, root)
-        found[seq] = []
         for w in ns.weather:
-            hits = glob.glob(my_utils.particles_path(sim["path"], w))
-            if hits:
-                found[seq].append(hits[0])
-            else:
-                missing.append((seq, w))
-    if missing or ns.force_particles:
-        raise SystemExit(" {} particles simulations are missing ({}) and the external weather-particle-simulator is not "
-                         "driven by this build: generate them with the reference's tools/ or with "
-                         "rain_rendering_amd.synthetic".format(len(missing), missing[:3]))
-    print(" All particles simulations ready")
+            if ns.force_particles or not glob.glob(my_utils.particles_path(sim["path"], w)):
+                to_run.append((sim, w))
+    if not to_run:
+        print(" All particles simulations ready")
+    else:
+        print(" {} particles simulations to compute...".format(len(to_run)))
+        if __package__ in (None, ''):
+            particles = importlib.import_module('rain-rendering_amd.tools.particles')
+        else:
+            from .tools import particles
+        for sim, w in to_run:
+            print("  " + particles.simulate(sim, w, force_recompute=True))
+        print(" All particles simulation completed")
+    for seq in ns.sequences:
+        sim = db.sim(ns.dataset, seq, root)
+        found[seq] = [glob.glob(my_utils.particles_path(sim["path"], w))[0] for w in ns.weather]
     ns.particles = found
 
 

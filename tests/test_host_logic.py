@@ -107,7 +107,7 @@ def test_pack_drops_seeded_equals_global_rng(tmp_path, built):
 
 def test_cli_flags_and_particle_resolution(tmp_path):
     """main.check_arg: the reference's flag set, derived fields (main.py:131-161) and particle files (main.py:187-220);
-    a missing simulation is an error here (the external simulator is not driven)."""
+    a missing simulation is generated (tools/particles.py) where the reference would start its external simulator."""
     import importlib
     import os
     tmp = str(tmp_path)
@@ -125,8 +125,10 @@ def test_cli_flags_and_particle_resolution(tmp_path):
     assert ns.intensity == [5] and ns.weather[0] == dict(weather='rain', fallrate=5)
     assert ns.texture.endswith(os.path.join('env_light_database', 'size32')) and ns.settings['cam_focal'] == 6
     assert main.check_arg(base + ['-i', '5', '-s', 'nope']).sequences.size == 0          # sequence prefix filter
-    with pytest.raises(SystemExit, match='particles simulations are missing'):
-        main.check_arg(base + ['-i', '7'])
+    ns7 = main.check_arg(base + ['-i', '7', '-fe', '3'])                                 # no 7 mm/hr file yet: generated
+    gen = ns7.particles['data_object/training'][0]
+    assert gen.endswith(os.path.join('rain', '7mm', 'sim_camera0.xml')) and os.path.getsize(gen) > 1000
+    assert main.check_arg(base + ['-i', '7']).particles['data_object/training'] == [gen]   # found the second time
     with pytest.raises(AssertionError):
         main.check_arg(base[:-2] + ['-sd', os.path.join(tmp, 'no_db')])
 
