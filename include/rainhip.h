@@ -99,6 +99,9 @@ typedef struct {
   int32_t n_drops;
   int32_t strategy;               /* 0: default (rendering_strategy=None); 1: 'white' (bad_weather.py:349-353) */
   double opacity_attenuation;     /* --opacity_attenuation */
+  const void* depth;              /* optional, only read with RR_OPT_DEPTH_OCCLUSION: scene depth in metres, H*W float32
+                                   * (depth_f64 == 0) or float64; rr_pipeline_* use the pre-pass' depth instead */
+  int32_t depth_f64, reserved;
 } rr_frame_in;
 
 typedef struct {
@@ -208,14 +211,19 @@ int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_
 int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
                        const rr_prepass_out* pre_out);
 
-/* Tuning / A-B switches.  NONE of them changes a result bit (tests/test_gpu_properties.py); unknown options or
- * values are RR_E_ARG.  The library reads no environment variables. */
+/* Options.  1-4 are tuning / A-B switches: NONE of them changes a result bit (tests/test_gpu_properties.py).  Unknown
+ * options or values are RR_E_ARG.  The library reads no environment variables. */
 enum {
   RR_OPT_DEDUP = 1,                 /* 1 (default): drops with bit-identical raw-tile parameters share one tile inside a batch */
   RR_OPT_GENERAL_FOV = 2,           /* 1: force the general colour path (prefix table in HBM) that maps taller than 1024 rows,
                                      *    wider than 4096 columns or with He*We >= 2^22 always take; default 0 */
   RR_OPT_FOV_THREADS = 3,           /* workgroup size of the FOV-sum kernel: 0 (library's choice), 512 or 1024 */
-  RR_OPT_FOV_DROPS_PER_THREAD = 4   /* drops per thread of the FOV-sum kernel: 0 (library's choice), 1, 2 or 4 */
+  RR_OPT_FOV_DROPS_PER_THREAD = 4,  /* drops per thread of the FOV-sum kernel: 0 (library's choice), 1, 2 or 4 */
+  /* NOT a tuning switch -- a feature the reference only sketches (common/drop_depth_map.py, dead code behind
+   * USE_DEPTH_WEIGHTING = 0, generator.py:20): with 1, a drop is not composited at pixels whose scene depth
+   * (rr_frame_in.depth / the pre-pass' depth) is smaller than the drop's distance |world z|.  Default 0: the reference's
+   * output.  Excluded from every parity run. */
+  RR_OPT_DEPTH_OCCLUSION = 5
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -55,6 +55,8 @@ struct FrameDesc {
   int32_t* status;
   uint8_t* png_image;              // optional: PNG scanlines (Sub filter) of the RGBA rainy image, H * (1 + 4 W) bytes
   uint8_t* png_mask;               // optional: same for the colour-mapped rain mask
+  const void* depth;               // optional (RR_OPT_DEPTH_OCCLUSION): scene depth in metres, H*W float32 / float64
+  int32_t depth_f64;
   int32_t n_drops;
   int32_t strategy;
   double opacity;
@@ -843,6 +845,7 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   rec.off = 0;
   rec.tau_one = rec.g = 0;
   rec.K[0] = rec.K[1] = rec.K[2] = 0;
+  rec.zdist = fr.depth ? fabs(as_global((const double*)fr.drops[i].wps)[2]) : 0.0;
   int status = p.status;
   const int n = sc.npts[gi];
   if (n == 0) status = RR_DROP_FOV_FAIL;
@@ -1865,6 +1868,11 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
       sum_b = (b[0] + b[1]) + b[2];
     }
   }
+  // depth-occlusion option (default off; not part of the reference's output): a drop farther than the scene at a
+  // pixel is hidden there
+  double scene = 1.0e300;
+  if (fr.depth && live)
+    scene = fr.depth_f64 ? as_global((const double*)fr.depth)[pix] : (double)as_global((const float*)fr.depth)[pix];
   const CompRec* comp = sc.comp + (int64_t)f * max_drops;
   const int4* bbox = sc.bbox + (int64_t)f * max_drops;
   const double* arena = sc.arena;
@@ -1912,7 +1920,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
         in_n = live && px >= q.x0 && px < q.x1 && py >= q.y0 && py < q.y1;
         if (in_n) A_n = arena[q.off + (int64_t)(py + q.oy) * q.pitch + (px + q.ox)];
       }
-      if (in_c) blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
+      if (in_c && !(r.zdist > scene)) blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
     }
     __syncthreads();
   }
@@ -2121,6 +2129,7 @@ struct rr_ctx {
   bool dedup = true;                 // RR_OPT_DEDUP: share bit-identical raw tiles inside a batch (k_dedup)
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
+  bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
   int scratch_hp = 0;                // span pitch the scratch was sized for
   bool scratch_general = false;      // prefix table / polygons of the general colour path allocated
   std::vector<ProfEntry> prof_pending;
@@ -2350,6 +2359,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.status = out[f].drop_status;
     fd.png_image = out[f].rainy_png;
     fd.png_mask = out[f].mask_png;
+    fd.depth = ctx->depth_occlusion ? in[f].depth : nullptr;
+    fd.depth_f64 = in[f].depth_f64;
     fd.n_drops = in[f].n_drops;
     fd.strategy = in[f].strategy;
     fd.opacity = in[f].opacity_attenuation;
@@ -3033,6 +3044,15 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     const bool same_omega = f > 0 && in[f].omega == in[0].omega;
     din[f].omega = same_omega ? din[0].omega : st.omega + f * ex;
     din[f].drops = st.drops + (size_t)f * st.drops_cap;
+    if (pre) {                        // the pre-pass' depth buffer doubles as the occlusion depth
+      din[f].depth = st.depth + f * px;
+      din[f].depth_f64 = pre[f].depth_f64;
+    } else if (in[f].depth && ctx->depth_occlusion) {
+      up.add((void*)(st.depth + f * px), in[f].depth, px * (in[f].depth_f64 ? 8 : 4));
+      din[f].depth = st.depth + f * px;
+    } else {
+      din[f].depth = nullptr;
+    }
     if (!pre) {
       up.add((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double));
       up.add((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double));
@@ -3285,6 +3305,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
   switch (option) {
     case RR_OPT_DEDUP: ctx->dedup = value != 0; return RR_OK;
     case RR_OPT_GENERAL_FOV: ctx->general_fov = value != 0; return RR_OK;
+    case RR_OPT_DEPTH_OCCLUSION: ctx->depth_occlusion = value != 0; return RR_OK;
     case RR_OPT_FOV_THREADS:
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;

@@ -64,7 +64,7 @@ struct DropPlan {
   double scale_x, scale_y, inv_sx, inv_sy;   // cv2.resize scales
 };
 
-// What the compositor reads per (screen tile, drop): 80 bytes.
+// What the compositor reads per (screen tile, drop): 88 bytes.
 struct CompRec {
   int32_t x0, y0, x1, y1;    // footprint, exclusive upper bounds; empty if x1<=x0
   int32_t ox, oy;            // tile_x = px + ox, tile_y = py + oy
@@ -72,6 +72,7 @@ struct CompRec {
   int64_t off;               // arena offset of the finished tile
   double tau_one, g;
   double K[3];               // BGR colour constants
+  double zdist;              // distance of the drop from the camera, |world z| (depth-occlusion option only)
 };
 
 // ---------------------------------------------------------------------------

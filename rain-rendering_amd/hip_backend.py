@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'librainhip.so')
 RR_MAX_FOV = 32
 RR_E_ARENA = -5
 RR_PIPE_SLOTS = 3
-RR_OPT_DEDUP, RR_OPT_GENERAL_FOV, RR_OPT_FOV_THREADS, RR_OPT_FOV_DROPS_PER_THREAD = 1, 2, 3, 4
+RR_OPT_DEDUP, RR_OPT_GENERAL_FOV, RR_OPT_FOV_THREADS, RR_OPT_FOV_DROPS_PER_THREAD, RR_OPT_DEPTH_OCCLUSION = 1, 2, 3, 4, 5
 
 # numpy mirror of rr_drop (112 bytes)
 DROP_DTYPE = np.dtype([
@@ -41,7 +41,8 @@ class rr_frame_in(ctypes.Structure):
                 ('bg', ctypes.c_void_p), ('rainy_bg', ctypes.c_void_p), ('env_xyY', ctypes.c_void_p),
                 ('omega', ctypes.c_void_p), ('drops', ctypes.c_void_p),
                 ('n_drops', ctypes.c_int32), ('strategy', ctypes.c_int32),
-                ('opacity_attenuation', ctypes.c_double)]
+                ('opacity_attenuation', ctypes.c_double), ('depth', ctypes.c_void_p), ('depth_f64', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
 
 
 class rr_frame_out(ctypes.Structure):
@@ -534,6 +535,12 @@ class RainHip:
             fin[k].n_drops = len(drops)
             fin[k].strategy = int(fr.get('strategy', 0))
             fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
+            if fr.get('depth') is not None:            # only read with RR_OPT_DEPTH_OCCLUSION
+                dep = np.asarray(fr['depth'])
+                dep = np.ascontiguousarray(dep, np.float32 if dep.dtype == np.float32 else np.float64)
+                assert dep.shape == (H, W)
+                fin[k].depth, fin[k].depth_f64 = _ptr(dep), 1 if dep.dtype == np.float64 else 0
+                keep.append(dep)
             fout[k].rainy_rgb = _ptr(o['image_u8'])
             fout[k].rainy_bg_out = _ptr(o['rainy_bg'])
             fout[k].mask_f64 = _ptr(o['mask'])

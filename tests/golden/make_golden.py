@@ -337,6 +337,24 @@ def main():
     out['add_scene'] = np.array([H, W, 60, 4200])
     out['add_rainy_bg_in'] = rainy_bg
 
+    # ---- 8d. DropDepthMap (dead in the reference: constructed behind USE_DEPTH_WEIGHTING = 0 only) -----
+    from common import drop_depth_map as rddm
+    calib = os.path.join(tmp, 'calib_cam_to_cam.txt')
+    with open(calib, 'w') as fh:                       # KITTI raw calib lines the class parses (values of 2011_09_26)
+        fh.write('calib_time: 09-Jan-2012 13:57:47\n'
+                 'R_rect_02: 9.998817e-01 1.511453e-02 -2.841595e-03 -1.511724e-02 9.998853e-01 -9.338510e-04 2.827154e-03 9.766976e-04 9.999955e-01\n'
+                 'P_rect_02: 7.215377e+02 0.000000e+00 6.095593e+02 4.485728e+01 0.000000e+00 7.215377e+02 1.728540e+02 2.163791e-01 0.000000e+00 0.000000e+00 1.000000e+00 2.745884e-03\n')
+    dmap = np.random.RandomState(12).uniform(2.0, 60.0, (352, 1216))
+    ev = rddm.DropDepthMap(filename=calib)
+    xyz = ev.get_world_points(dmap)
+    starts = np.random.RandomState(13).uniform(-3, 3, (4, 3))
+    dd = rddm.DropDepthMap.depth_map_drop(starts, xyz)
+    out['ddm_calib'] = np.array(open(calib).read())
+    out['ddm_depth_seed'] = np.array([12, 13])
+    out['ddm_xyz_sub'] = xyz[::37, ::53].copy()
+    out['ddm_dist_sub'] = dd[:, ::37, ::53].copy()
+    out['ddm_cam_pos'] = ev.camera_pos_world.copy()
+
     # ---- 9. matplotlib's float -> uint8 rule (generator.py:466) ------------------------------------
     import io
     import matplotlib.pyplot as plt

@@ -276,3 +276,24 @@ def test_int32_mask_equals_untouched_reference(tmp_path):
         d = np.abs(got['image_u8'].astype(int) - G['big_scipy_image_u8'].astype(int))
         assert d.max() <= 1, name                                     # tolerance: +-1 LSB per channel
     assert G['big_scipy_mask_i32'].max() > 150 and G['big_scipy_skipped'].sum() > 10
+
+
+def test_drop_depth_map_mirror_equals_reference(tmp_path):
+    """common/drop_depth_map.py (dead code in the reference, kept for API parity) against the reference's own class
+    (make_golden.py section 8d): the calibration parsing, the pixel -> XYZ back-projection and the per-drop distance
+    maps, bit for bit on a sub-grid."""
+    import importlib
+    ddm = importlib.import_module('rain-rendering_amd.common.drop_depth_map')
+    calib = tmp_path / 'calib_cam_to_cam.txt'
+    calib.write_text(str(G['ddm_calib']))
+    s1, s2 = (int(v) for v in G['ddm_depth_seed'])
+    dmap = np.random.RandomState(s1).uniform(2.0, 60.0, (352, 1216))
+    ev = ddm.DropDepthMap(filename=str(calib))
+    xyz = ev.get_world_points(dmap)
+    assert np.array_equal(xyz[::37, ::53], G['ddm_xyz_sub'])
+    assert np.array_equal(ev.camera_pos_world, G['ddm_cam_pos'])
+    starts = np.random.RandomState(s2).uniform(-3, 3, (4, 3))
+    dd = ddm.DropDepthMap.depth_map_drop(starts, xyz)
+    assert dd.dtype == np.float16 and np.array_equal(dd[:, ::37, ::53], G['ddm_dist_sub'])
+    # any frame size (the reference hard-codes 352 x 1216)
+    assert ev.return_xyz(np.full((10, 20), 5.0)).shape == (10, 20, 3)
