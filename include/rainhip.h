@@ -88,6 +88,18 @@ typedef struct {
   double rot_cos, rot_sin;        /* cos/sin(-(theta+noise) * pi/180) for imutils.rotate_bound (non-Big) */
 } rr_drop;                        /* 112 bytes */
 
+/* A caller-made tile for one drop: the seam of RainRenderer.add_drop_to_image (common/bad_weather.py:336-338), whose
+ * arguments `drop` (the RGBA tile Generator.compute_drop built: gray, alpha == channel 0), `drop_minC` and `drop_fov_pts`
+ * these are.  With alpha != NULL the library neither synthesises the streak tile nor evaluates the field-of-view polygon
+ * of that drop; everything after that (colour, defocus, placement, blend) is the common path. */
+typedef struct {
+  const double* alpha;            /* th*tw values in [0,1], row-major; NULL: this drop is rendered the normal way */
+  int32_t tw, th;
+  int32_t min_x, min_y;           /* drop_minC */
+  int32_t n_poly, reserved;       /* vertices of drop_fov_pts (<= RR_MAX_FOV + 4); 0: compute_fov_plane_points failed ([]) */
+  const double* poly_xy;          /* n_poly (x, y) pairs, float pixels of the environment map (truncated like pyclipper does) */
+} rr_ext_tile;
+
 typedef struct {
   int32_t H, W;                   /* frame */
   int32_t He, We;                 /* lat-long environment map */
@@ -102,6 +114,7 @@ typedef struct {
   const void* depth;              /* optional, only read with RR_OPT_DEPTH_OCCLUSION: scene depth in metres, H*W float32
                                    * (depth_f64 == 0) or float64; rr_pipeline_* use the pre-pass' depth instead */
   int32_t depth_f64, reserved;
+  const rr_ext_tile* ext;         /* optional: n_drops entries (rr_render_frames / rr_render_frames_device only) */
 } rr_frame_in;
 
 typedef struct {

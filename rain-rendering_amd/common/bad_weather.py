@@ -361,3 +361,160 @@ class RainRenderer:
             return self.f ** 2 / (self.N * o)
         result = ((o - self.focus_plane) * self.f ** 2) / (o * (self.focus_plane - self.f) * self.N)
         return result / 4.65e-06
+
+    @staticmethod
+    def warping_points(drop, drop_texture, image_width, image_height):
+        """reference bad_weather.py:300-329: source / destination quads of the Big-drop warp, max and min corner."""
+        x0 = round(drop.image_position_start[0])
+        x1 = round(drop.image_position_end[0])
+        y0 = round(drop.image_position_start[1])
+        y1 = round(drop.image_position_end[1])
+        d0 = np.floor(drop.image_diameter_start)
+        d1 = np.floor(drop.image_diameter_end)
+        minx = max(min(x0, x1), 0)
+        miny = max(min(y0, y1), 0)
+        maxx = min(max(x0 + d0, x1 + d1), image_width)
+        maxy = min(max(y0, y1), image_height)
+        epsilon = 0.001                                   # to prevent singularity of the perspective matrix
+        p1 = np.float32([[0, 0], [drop_texture.shape[1], 0], [drop_texture.shape[1], drop_texture.shape[0]],
+                         [0, drop_texture.shape[0]]])
+        p2 = np.float32([[x0 - minx, y0 - miny], [x0 - minx + d0, y0 - miny], [x1 - minx + d1 + epsilon, y1 - miny],
+                         [x1 - minx + epsilon, y1 - miny]])
+        return p1, p2, np.array([maxx, maxy]), np.array([minx, miny])
+
+    def _ctx(self, dataset):
+        """The library context behind the single-drop seam (created on first use; Generator.run shares its own)."""
+        from . import db as settings_db
+        from .. import hip_backend
+        if getattr(self, '_hip', None) is None:
+            self._hip = hip_backend.RainHip(int(os.environ.get('LOCAL_RANK', '0')))
+            self._hip_cam = None
+            self._hip.set_streak_db([np.zeros((2, 2), np.uint8)])          # the tile comes from the caller: no texture is read
+        exposure = settings_db.settings(dataset)["cam_exposure"]            # bad_weather.py:344
+        key = (self.f, self.N, exposure, self.focus_plane, self.radius, self.fov)
+        if self._hip_cam != key:
+            self._hip.set_camera(hip_backend.make_camera(self.f, self.N, exposure, self.focus_plane, self.radius, self.fov))
+            self._hip_cam = key
+        return self._hip
+
+    def add_drop_to_image(self, dataset, env_map_xyY, solid_angle_map, drop_fov_pts, drop_minC, bg, rainy_bg,
+                          rainy_mask, rainy_saturation_mask, drop, drop_dict, irrad_type, rendering_strategy,
+                          opacity_attenuation=1.0):
+        """The reference's inner seam, same signature (bad_weather.py:336-462): composite ONE caller-made tile `drop`
+        (H x W x 4, gray with alpha, as Generator.compute_drop builds it) whose field-of-view polygon is `drop_fov_pts`
+        and whose position is `drop_minC` into rainy_bg / rainy_mask -- in place and returned.  Colour from the
+        environment map, defocus, placement, blend and mask accumulation run in the library (rr_ext_tile entry of
+        rr_render_frames: one launch chain per call -- use Generator.run / rr_render_frames for throughput).
+
+        Like the reference, a drop that cannot be rendered (empty polygon, polygon off the map, non-finite circle of
+        confusion) raises; Generator.compute_drop catches that (generator.py:180-189).  rainy_saturation_mask is passed
+        through untouched and blended_drop is None: both are dead outputs in the reference (never read after the loop)."""
+        from .. import hip_backend
+        hip = self._ctx(dataset)
+        alpha = np.ascontiguousarray(np.asarray(drop)[..., 3] if np.asarray(drop).ndim == 3 else drop, np.float64)
+        rec = np.zeros(1, hip_backend.DROP_DTYPE)
+        rec['x0'], rec['y0'] = int(drop_minC[0]), int(drop_minC[1])
+        rec['x1'], rec['y1'] = rec['x0'], rec['y0']
+        rec['max_width'] = int(max(drop_dict.image_diameter_start, drop_dict.image_diameter_end))
+        rec['length'] = int(drop_dict.length)
+        rec['type'] = 0
+        rec['iw1'], rec['iw2'] = drop_dict.image_diameter_start, drop_dict.image_diameter_end
+        rec['rot_cos'] = 1.0
+        white = rendering_strategy == 'white'
+        if not white:
+            rec['wps'], rec['wpe'] = drop_dict.world_position_start, drop_dict.world_position_end
+        elif getattr(drop_dict, 'world_position_start', None) is not None:
+            rec['wps'], rec['wpe'] = drop_dict.world_position_start, drop_dict.world_position_end
+        poly = None if white else np.asarray(drop_fov_pts, np.float64).reshape(-1, 2)
+        out = hip.render_frames([dict(bg=bg, rainy_bg=rainy_bg, env_xyY=env_map_xyY, omega=solid_angle_map, drops=rec,
+                                      ext=[dict(alpha=alpha, minC=(int(drop_minC[0]), int(drop_minC[1])), poly=poly)],
+                                      opacity_attenuation=opacity_attenuation, strategy=1 if white else 0)])[0]
+        if out['status'][0] != 0:
+            raise IndexError("drop not rendered (status %d: 1 no field of view, 2 field of view off the map, 3/4 circle of "
+                             "confusion)" % out['status'][0])
+        rainy_bg[...] = out['rainy_bg']
+        rainy_mask += out['mask']
+        return rainy_bg, rainy_mask, rainy_saturation_mask, None
+
+
+class FovComputation:
+    """reference bad_weather.py:497-704: the polygon on the lat-long environment map seen from a drop.  Host-side
+    restatement with the reference's method name and return value (points, [], [], []) for callers of the single-drop
+    seam; the batched path evaluates the same arithmetic on the device (csrc/rr_device.h fov_vertex / k_fov_spans)."""
+
+    def __init__(self, camera):
+        self.camera = camera
+
+    @staticmethod
+    def rotation_matrix(axis, theta):                       # bad_weather.py:532-538 (Rodrigues)
+        axis = np.asarray(axis)
+        c, s = np.cos(theta), np.sin(theta)
+        skv = np.roll(np.roll(np.diag(axis.flatten()), 1, 1), -1, 0)
+        return (c * np.identity(3)) + s * (skv - skv.T) + ((1 - c) * np.outer(axis, axis))
+
+    @staticmethod
+    def intersection_sphere(position, direction, radius):   # bad_weather.py:540-568, sphere about the origin, far root
+        dx, dy, dz = direction
+        x0, y0, z0 = position
+        a = dx * dx + dy * dy + dz * dz
+        b = 2 * dx * x0 + 2 * dy * y0 + 2 * dz * z0
+        c = 0 + x0 * x0 + y0 * y0 + z0 * z0 + -2 * 0 - radius * radius
+        t1 = (-b + np.sqrt(b ** 2 - 4 * a * c)) / (2 * a)
+        return position + (t1 * direction)
+
+    @staticmethod
+    def cart2sph(p):                                        # bad_weather.py:570-586
+        x, y, z = p
+        el = np.arctan2(z, np.sqrt(x ** 2 + y ** 2))
+        az = np.arctan2(y, x)
+        if az < 0:
+            az += 2 * np.pi
+        if el < 0:
+            el += 2 * np.pi
+        if az > np.pi * 2:
+            az -= 2 * np.pi
+        if el > np.pi * 2:
+            el -= 2 * np.pi
+        return az, el
+
+    def compute_fov_plane_points(self, drop, radius, fov, N, env_shape):
+        """bad_weather.py:596-704.  Returns (points (M, 2) float, [], [], []) with M = N or N + 4, or ([], [], [], [])
+        where the reference's `except:` fires.  Same operations in the same order as the reference (pinned bit for bit
+        by tests/golden)."""
+        try:
+            with np.errstate(all='ignore'):
+                pos = np.array((np.asarray(drop.world_position_start, np.float64) + np.asarray(drop.world_position_end, np.float64)) / 2)
+                pos[1], pos[2] = pos[2], pos[1].copy()                       # y <-> z
+                n = (pos - self.camera) / np.linalg.norm(pos - self.camera)
+                a, b, c = n[0], n[1], n[2]
+                d = np.dot(pos, n)
+                if b == 0:
+                    b = 0.001
+                px_, pz_ = pos[1], 0
+                point = np.array([px_, (-a * px_ + d - c * pz_) / b, pz_])
+                u = (pos - point) / np.linalg.norm(pos - point)
+                if not np.all(~np.isnan(u)):
+                    return [], [], [], []
+                v = np.dot(n, self.rotation_matrix(np.cross(u, n), -np.deg2rad(fov / 2)))
+                azs, pts = [], []
+                for angle in np.arange(0, 2 * np.pi, (2 * np.pi) / N):
+                    P = self.intersection_sphere(pos, np.dot(v, self.rotation_matrix(n, angle)), radius)
+                    azimuth, elevation = self.cart2sph(P)
+                    azimuth = ((2 * np.pi - azimuth) - np.pi / 2) % (2 * np.pi)
+                    elevation = (elevation + np.pi / 2) % (2 * np.pi)
+                    azs.append(azimuth)
+                    pts.append([azimuth / (2 * np.pi) * env_shape[1], (1. - elevation / np.pi) * env_shape[0]])
+                pts = np.array(pts)
+                df = np.diff(np.array(azs + [azs[0]]))
+                cnd = np.bitwise_or(np.isclose(df, 0), df < 0)
+                p_true, p_false = np.where(cnd)[0][0], np.where(~cnd)[0][0]    # IndexError -> the reference's except
+                rows, cols = env_shape[:2]
+                if np.sum(cnd) == 1:        # top
+                    pts = np.vstack([pts[:p_true + 1], [cols, pts[p_true][1]], [cols, 0], [0, 0],
+                                     [0, pts[np.mod(p_true + 1, N)][1]], pts[p_true + 1:]])
+                elif np.sum(~cnd) == 1:     # bottom
+                    pts = np.vstack([pts[:p_false + 1], [0, pts[p_false][1]], [0, rows], [cols, rows],
+                                     [cols, pts[np.mod(p_false + 1, N)][1]], pts[p_false + 1:]])
+                return np.array(pts), [], [], []
+        except Exception:
+            return [], [], [], []

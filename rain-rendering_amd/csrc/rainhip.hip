@@ -56,6 +56,7 @@ struct FrameDesc {
   uint8_t* png_image;              // optional: PNG scanlines (Sub filter) of the RGBA rainy image, H * (1 + 4 W) bytes
   uint8_t* png_mask;               // optional: same for the colour-mapped rain mask
   const void* depth;               // optional (RR_OPT_DEPTH_OCCLUSION): scene depth in metres, H*W float32 / float64
+  const rr_ext_tile* ext;          // optional: caller-made tiles / FOV polygons per drop (device pointers inside)
   int32_t depth_f64;
   int32_t n_drops;
   int32_t strategy;
@@ -269,7 +270,9 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
   if (act) {
     rr_drop d = load_drop(fr.drops + i);
     int64_t size = 0;
-    plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size);
+    rr_ext_tile ext;
+    if (fr.ext) ext = fr.ext[i];
+    plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size, fr.ext ? &ext : nullptr);
     // the FOV polygon (k_fov_spans, launched before this kernel) is evaluated for every drop: in the reference
     // its failure is raised before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
     const int npts = sc.npts[gi];                 // 0: failed; -1: 'white' strategy (never used)
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_
   const int gi = f * max_drops + i;
   DropPlan& p = sc.plan[gi];
   int canon = gi;
-  if (enable && p.status == RR_DROP_OK && sc.sizes[gi] != 0) {
+  if (enable && p.status == RR_DROP_OK && sc.sizes[gi] != 0 && p.kind != KIND_EXT) {
     const uint32_t cap = 2u * (uint32_t)n_frames * (uint32_t)max_drops;
     uint32_t h = raw_tile_hash(p) % cap;
     for (;;) {
@@ -468,7 +471,8 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   }
   double az = 0.0, ptx = 0.0, pty = 0.0;
   bool ok = false;
-  if (act) {
+  const bool ext = act && fr.ext && fr.ext[i0 + g].alpha != nullptr;      // the caller's polygon (rr_ext_tile)
+  if (act && !ext) {
     FovSetup F;
     const rr_drop d = load_drop(fr.drops + i0 + g);
     ok = fov_setup(d, cam, F);
@@ -505,6 +509,19 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
         qx[pp + 4] = cols; qy[pp + 4] = (int32_t)pty_next;
       }
     }
+  }
+  if (ext) {                                                   // lane k of the group copies vertex k, k + N, ...
+    const rr_ext_tile e = fr.ext[i0 + g];
+    const int np = imin(imax(e.n_poly, 0), POLY_STRIDE);
+    bool fine = true;
+    for (int v = k; v < np; v += N) {
+      const double vx = e.poly_xy[2 * v], vy = e.poly_xy[2 * v + 1];
+      fine = fine && fov_coord_ok(vx) && fov_coord_ok(vy);
+      s_px[wave][g][v] = (int32_t)vx;
+      s_py[wave][g][v] = (int32_t)vy;
+    }
+    const unsigned long long bad_e = __ballot(!fine) & gmask;
+    m = bad_e ? 0 : np;
   }
   if (act && k == 0) sc.npts[gi] = m;
   wave_lds_sync();
@@ -1082,8 +1099,15 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   // over GEN_SLICES workgroups by pixel index, or one of them would be the tail of the whole batch
   for (int work = blockIdx.x; work < n_items * GEN_SLICES; work += gridDim.x) {      // grid-stride over (item, slice)
   const int item = work / GEN_SLICES, slice = work - item * GEN_SLICES;
-  const int64_t gi = (int64_t)f * max_drops + sc.list_gen[(int64_t)f * max_drops + item];
+  const int li = sc.list_gen[(int64_t)f * max_drops + item];
+  const int64_t gi = (int64_t)f * max_drops + li;
   const DropPlan& p = sc.plan[gi];
+  if (p.kind == KIND_EXT) {                               // the caller's tile: copy (clip like generator.py:132,170)
+    const double* src = frames[f].ext[li].alpha;
+    double* A0e = sc.arena + p.a0_off;
+    for (int idx = t + 256 * slice; idx < p.tw * p.th; idx += 256 * GEN_SLICES) A0e[idx] = clip01(src[idx]);
+    continue;
+  }
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
   __syncthreads();
   const uint8_t* gtex = texels + tex_off[p.tex];
@@ -1412,7 +1436,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {         // duplicates of another drop's raw tile render nothing
       if (p.kind == KIND_BIG) { c[6]++; c[7] += p.tw * p.th; }
-      else if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
+      else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { c[4]++; continue; }
@@ -1450,7 +1474,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
         boff[o[6]] = o[7];
         lbig[o[6]++] = i;
         o[7] += p.tw * p.th;
-      } else if (tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
+      } else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
@@ -2112,6 +2136,7 @@ struct rr_ctx {
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_down = nullptr;
     int64_t* h_flags = nullptr;      // pinned: [0] arena-overflow flag as seen after this batch
     bool busy = false, rendered = false;
+    std::vector<void*> ext_blobs;     // device copies of caller-made tiles (rr_ext_tile), freed when the slot is reused
   } slots[RR_PIPE_SLOTS];
   hipStream_t s_up = nullptr, s_down = nullptr;
   // pre-pass (fog + environment map)
@@ -2361,6 +2386,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.png_mask = out[f].mask_png;
     fd.depth = ctx->depth_occlusion ? in[f].depth : nullptr;
     fd.depth_f64 = in[f].depth_f64;
+    fd.ext = in[f].ext;
     fd.n_drops = in[f].n_drops;
     fd.strategy = in[f].strategy;
     fd.opacity = in[f].opacity_attenuation;
@@ -2735,6 +2761,7 @@ int rr_destroy(rr_ctx* ctx) {
     if (sl.ev_comp) hipEventDestroy(sl.ev_comp);
     if (sl.ev_down) hipEventDestroy(sl.ev_down);
     if (sl.h_flags) hipHostFree(sl.h_flags);
+    for (void* b : sl.ext_blobs) hipFree(b);
   }
   if (ctx->s_up) hipStreamDestroy(ctx->s_up);
   if (ctx->s_down) hipStreamDestroy(ctx->s_down);
@@ -2940,6 +2967,12 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
     ctx->err = "bad frame size";
     return RR_E_ARG;
   }
+  if (pre && in)
+    for (int f = 0; f < n; f++)
+      if (in[f].ext) {
+        ctx->err = "rr_ext_tile is taken by rr_render_frames / rr_render_frames_device only";
+        return RR_E_ARG;
+      }
   if (pre && in && (!ctx->have_eg || dm.He != dm.H || dm.We != ctx->eg.We)) {
     ctx->err = "pipeline: He/We must be H / rr_envmap_width() of the geometry set for this frame size";
     return RR_E_ARG;
@@ -3012,6 +3045,8 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   int max_drops = 1, rc;
   if ((rc = validate_host_batch(ctx, n, pre, in, out, pre_out, dm, max_drops))) return rc;
   if ((rc = slot_init(ctx, sl))) return rc;
+  for (void* b : sl.ext_blobs) hipFree(b);             // the slot's previous batch is complete (not busy)
+  sl.ext_blobs.clear();
   auto& st = sl.st;
   if ((rc = slot_reserve(ctx, st, n, max_drops, dm))) return rc;
   const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We, png_bytes = (size_t)dm.H * (1 + 4 * (size_t)dm.W);
@@ -3065,6 +3100,40 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     dout[f].mask_f64 = st.mask + f * px;
     dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * px : nullptr;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
+    din[f].ext = nullptr;
+    if (in[f].ext && in[f].n_drops > 0) {
+      // caller-made tiles (the single-drop seam; not a throughput path): one device blob per frame =
+      // [rr_ext_tile x n_drops | alphas | polygons], pointers rewritten to the device copies
+      const int nd = in[f].n_drops;
+      size_t bytes = sizeof(rr_ext_tile) * (size_t)nd;
+      for (int k = 0; k < nd; k++) {
+        const rr_ext_tile& e = in[f].ext[k];
+        if (!e.alpha) continue;
+        if (e.tw <= 0 || e.th <= 0 || e.n_poly < 0 || e.n_poly > POLY_STRIDE || (e.n_poly > 0 && !e.poly_xy)) {
+          ctx->err = "bad rr_ext_tile";
+          return RR_E_ARG;
+        }
+        bytes += sizeof(double) * ((size_t)e.tw * e.th + 2 * (size_t)e.n_poly);
+      }
+      char* blob = nullptr;
+      HIPCHK(hipMalloc((void**)&blob, bytes));
+      sl.ext_blobs.push_back(blob);
+      std::vector<rr_ext_tile> dev(in[f].ext, in[f].ext + nd);
+      size_t off = sizeof(rr_ext_tile) * (size_t)nd;
+      for (int k = 0; k < nd; k++) {
+        rr_ext_tile& e = dev[k];
+        if (!e.alpha) continue;
+        const size_t na = sizeof(double) * (size_t)e.tw * e.th, np = sizeof(double) * 2 * (size_t)e.n_poly;
+        HIPCHK(hipMemcpy(blob + off, e.alpha, na, hipMemcpyHostToDevice));
+        e.alpha = reinterpret_cast<const double*>(blob + off);
+        off += na;
+        if (np) HIPCHK(hipMemcpy(blob + off, e.poly_xy, np, hipMemcpyHostToDevice));
+        e.poly_xy = reinterpret_cast<const double*>(blob + off);
+        off += np;
+      }
+      HIPCHK(hipMemcpy(blob, dev.data(), sizeof(rr_ext_tile) * (size_t)nd, hipMemcpyHostToDevice));
+      din[f].ext = reinterpret_cast<const rr_ext_tile*>(blob);
+    }
     dout[f].rainy_png = out[f].rainy_png ? st.png_i + (size_t)f * png_bytes : nullptr;
     dout[f].mask_png = out[f].mask_png ? st.png_m + (size_t)f * png_bytes : nullptr;
   }

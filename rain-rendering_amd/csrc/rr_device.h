@@ -29,7 +29,7 @@
 
 namespace rr {
 
-enum { KIND_BIG = 0, KIND_ROT = 1 };
+enum { KIND_BIG = 0, KIND_ROT = 1, KIND_EXT = 2 };   // EXT: the tile and the FOV polygon come from the caller (rr_ext_tile)
 enum { RS_AREA = 0, RS_AREA_FAST = 1, RS_LINEAR = 2 };
 
 struct Dims {
@@ -627,7 +627,7 @@ RR_HD int py_slice_index(int i, int n) {   // CPython slice normalisation of one
 }
 
 RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, const int32_t* tex_h, const int32_t* tex_w,
-                     double opacity_attenuation, int strategy, DropPlan& p, int64_t& size_out) {
+                     double opacity_attenuation, int strategy, DropPlan& p, int64_t& size_out, const rr_ext_tile* ext = nullptr) {
   size_out = 0;
   p.status = RR_DROP_OK;
   p.tex = d.tex_index;
@@ -650,7 +650,14 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
   const int sh = tex_h[d.tex_index], sw = tex_w[d.tex_index];
 
   int minCx, minCy;
-  if (d.type == 0) {
+  if (ext && ext->alpha) {
+    // the caller's tile (RainRenderer.add_drop_to_image's `drop` and `drop_minC`, bad_weather.py:336-338)
+    p.kind = KIND_EXT;
+    p.tw = imax(ext->tw, 1);
+    p.th = imax(ext->th, 1);
+    minCx = ext->min_x;
+    minCy = ext->min_y;
+  } else if (d.type == 0) {
     p.kind = KIND_BIG;
     double d0 = floor(d.iw1), d1 = floor(d.iw2);
     int minx = imax(imin(d.x0, d.x1), 0), miny = imax(imin(d.y0, d.y1), 0);

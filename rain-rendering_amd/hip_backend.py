@@ -42,7 +42,12 @@ class rr_frame_in(ctypes.Structure):
                 ('omega', ctypes.c_void_p), ('drops', ctypes.c_void_p),
                 ('n_drops', ctypes.c_int32), ('strategy', ctypes.c_int32),
                 ('opacity_attenuation', ctypes.c_double), ('depth', ctypes.c_void_p), ('depth_f64', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('reserved', ctypes.c_int32), ('ext', ctypes.c_void_p)]
+
+
+class rr_ext_tile(ctypes.Structure):
+    _fields_ = [('alpha', ctypes.c_void_p), ('tw', ctypes.c_int32), ('th', ctypes.c_int32), ('min_x', ctypes.c_int32),
+                ('min_y', ctypes.c_int32), ('n_poly', ctypes.c_int32), ('reserved', ctypes.c_int32), ('poly_xy', ctypes.c_void_p)]
 
 
 class rr_frame_out(ctypes.Structure):
@@ -535,6 +540,19 @@ class RainHip:
             fin[k].n_drops = len(drops)
             fin[k].strategy = int(fr.get('strategy', 0))
             fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
+            if fr.get('ext') is not None:              # caller-made tiles: [None | dict(alpha HxW, minC (x, y), poly Nx2 | None)] per drop
+                ext = (rr_ext_tile * max(len(drops), 1))()
+                for j, e in enumerate(fr['ext']):
+                    if e is None:
+                        continue
+                    a = np.ascontiguousarray(e['alpha'], np.float64)
+                    poly = np.ascontiguousarray(e['poly'] if e.get('poly') is not None else np.zeros((0, 2)), np.float64).reshape(-1, 2)
+                    ext[j].alpha, ext[j].th, ext[j].tw = _ptr(a), a.shape[0], a.shape[1]
+                    ext[j].min_x, ext[j].min_y = int(e['minC'][0]), int(e['minC'][1])
+                    ext[j].n_poly, ext[j].poly_xy = len(poly), (_ptr(poly) if len(poly) else None)
+                    keep.append((a, poly))
+                fin[k].ext = ctypes.cast(ext, ctypes.c_void_p)
+                keep.append(ext)
             if fr.get('depth') is not None:            # only read with RR_OPT_DEPTH_OCCLUSION
                 dep = np.asarray(fr['depth'])
                 dep = np.ascontiguousarray(dep, np.float32 if dep.dtype == np.float32 else np.float64)

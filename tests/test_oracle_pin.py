@@ -297,3 +297,25 @@ def test_drop_depth_map_mirror_equals_reference(tmp_path):
     assert dd.dtype == np.float16 and np.array_equal(dd[:, ::37, ::53], G['ddm_dist_sub'])
     # any frame size (the reference hard-codes 352 x 1216)
     assert ev.return_xyz(np.full((10, 20), 5.0)).shape == (10, 20, 3)
+
+
+def test_product_fov_and_warping_points_equal_reference():
+    """The Python surface of the single-drop seam (common/bad_weather.py: FovComputation.compute_fov_plane_points,
+    RainRenderer.warping_points) against the reference's own outputs: bit for bit."""
+    fov = h.bw.FovComputation(camera=np.array([0, 0, 0]))
+    env_shape = tuple(int(v) for v in G['fov_env_shape'])
+    for k in range(len(G['fov_in'])):
+        s = h.bw.Streak()
+        s.world_position_start, s.world_position_end = G['fov_in'][k, :3], G['fov_in'][k, 3:]
+        pts, a, b, c = fov.compute_fov_plane_points(s, 10, 165, 20, env_shape)
+        n = int(G['fov_n'][k])
+        assert len(pts) == n and (a, b, c) == ([], [], [])
+        if n:
+            assert np.array_equal(np.asarray(pts), G['fov_pts'][k][:n])
+    for row, ref in zip(G['wp_in'], G['wp_out']):
+        s = h.bw.Streak()
+        s.image_position_start, s.image_position_end = row[0:2].astype(int), row[2:4].astype(int)
+        s.image_diameter_start, s.image_diameter_end = row[4], row[5]
+        p1, p2, maxC, minC = h.bw.RainRenderer.warping_points(s, np.zeros((int(row[6]), int(row[7]), 3)), 160, 96)
+        assert p1.dtype == np.float32 and p2.dtype == np.float32
+        assert np.array_equal(np.concatenate([p1.ravel(), p2.ravel(), maxC.astype(float), minC.astype(float)]), ref)
