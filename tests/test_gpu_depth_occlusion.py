@@ -40,7 +40,7 @@ def test_depth_occlusion_option(tmp_path, built):
         assert wall['mask'].sum() < base['mask'].sum()
         # per pixel: wall only in the left half
         rh.set_option(h.hb.RR_OPT_DEPTH_OCCLUSION, 1)
-        half = far.copy()
+        half = far.astype(np.float64)                         # (float64: d0 is one of the drops' own distances)
         half[:, :W // 2] = d0
         mixed = rh.render_frames([dict(fr, depth=half)])[0]
         assert np.array_equal(mixed['mask'][:, :W // 2], near['mask'][:, :W // 2])
