@@ -41,6 +41,8 @@ constexpr int TILE = 16;            // screen tile edge (256 threads = 16x16 pix
 constexpr int CTILE = 64;           // coarse binning tile (4x4 screen tiles)
 constexpr int MAX_R = 416;          // >= 4*RR_MAX_SHIFT/10 + 1
 constexpr int POLY_STRIDE = RR_MAX_FOV + 4;
+constexpr int COL_PARTS = 8;        // row bands of the environment map; partials are added in band order (fixed: results
+                                    // do not depend on the batch size)
 
 struct FrameDesc {
   const double* bg;
@@ -184,9 +186,9 @@ __global__ __launch_bounds__(256) void k_env_consts(Dims dm, const double* prefi
     }
     __syncthreads();
   }
-  if (t < 8) {                         // same layout as k_fov_sums' row-band totals: band 0 carries everything
-    fband[(f * 8 + t) * 2 + 0] = t == 0 ? b[0] : 0.0;
-    fband[(f * 8 + t) * 2 + 1] = t == 0 ? a[0] : 0.0;
+  if (t < COL_PARTS) {                 // same layout as k_fov_sums' row-band totals: band 0 carries everything
+    fband[(f * COL_PARTS + t) * 2 + 0] = t == 0 ? b[0] : 0.0;
+    fband[(f * COL_PARTS + t) * 2 + 1] = t == 0 ? a[0] : 0.0;
   }
 }
 
@@ -404,8 +406,6 @@ __global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_
 // (bad_weather.py:383-409).  Here the mask of a drop is its per-row span [xl, xr] (k_fov_spans) and the
 // masked sums are differences of row prefix sums (k_fov_sums).  The prefix sums of a row only ever live
 // in LDS: every environment-map row is read from HBM once per batch.
-constexpr int COL_PARTS = 8;        // row bands of the environment map; partials are added in band order (fixed: results
-                                    // do not depend on the batch size)
 constexpr int HE_MAX = 1024;        // tallest map of the fast path: 16 chunks of 64 rows in registers
 constexpr int FOV_WE_MAX = 4096;    // widest map of the fast path: (We + 1) * 32 B of LDS, <= 4 columns per thread
 constexpr int FOV_GROUPS = 3;       // drops per wave in k_fov_spans (n_fov = 20: 60 of 64 lanes busy)
