@@ -177,6 +177,7 @@ int rr_synchronize(rr_ctx* ctx);
  *                               + convert_rgb_to_xyY              common/generator.py:407-408
  * As with rr_camera, everything derived from transcendentals is computed once by the host. */
 #define RR_MAX_TAPS 33
+#define RR_PRE_ENV_ONLY 1
 
 typedef struct {
   int32_t fog_ksize, env_ksize;   /* 25 (add_attenuation.py:79), 15 (bad_weather.py:815); odd, <= RR_MAX_TAPS */
@@ -188,7 +189,11 @@ typedef struct {
   int32_t H, W;
   const double* bg;               /* H*W*3 BGR image / 255 (generator.py:352) */
   const void* depth;              /* H*W metres, float32 (depth_f64 == 0) or float64 (generator.py:362-383) */
-  int32_t depth_f64, reserved;
+  int32_t depth_f64;
+  int32_t mode;                   /* 0: fog layer (+ the map if an output asks for it).  RR_PRE_ENV_ONLY (1), rr_prepass_frames*
+                                   * only: `bg` IS the fogged image and only the map is made -- the stand-alone
+                                   * EnvironmentMapGenerator.generate_map(background) (bad_weather.py:742-819); depth and the fog
+                                   * constants are ignored, rr_prepass_out.rainy_bg may be NULL.  One mode per batch. */
   double beta_ext;                /* 0.312 * R**0.67                               add_attenuation.py:40-43 */
   double beta_hg;                 /* Henyey-Greenstein phase term, g = 0.97         add_attenuation.py:60-64 */
   double irr_num, irr_den;        /* 4*N**2  and  exposure_s*gain*pi                add_attenuation.py:51-54 */

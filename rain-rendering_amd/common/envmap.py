@@ -1,8 +1,9 @@
 """Environment-map estimation pre-pass (reference common/bad_weather.py:707-853,
 EnvironmentMapGenerator): cylindrical un-projection of the frame into a 360-degree lat-long
-map.  It produces the `envmap` INPUT of the hot path and runs on the host (SURVEY 8f "next"
-#2).  The projection tables depend only on (H, W, focal) and are cached; the reference's
-per-pixel Python fill loops (fill_matrices) are replaced by equivalent vector operations."""
+map.  It produces the `envmap` INPUT of the hot path and runs on the device (csrc/rr_prepass.h;
+SURVEY 8f "next" #2).  This class builds the projection tables the kernels gather through -- they depend only on
+(H, W, focal) and are cached; the reference's per-pixel Python fill loops (fill_matrices) are replaced by equivalent
+vector operations -- and keeps the reference-signature call."""
 import numpy as np
 
 from . import imgops
@@ -35,17 +36,7 @@ class EnvironmentMapGenerator:
         cols = np.round(self.focal * np.arctan(d_col / self.focal) + center[0]) - min_x
         key_flat = rows.astype(np.int32).astype(np.int64).ravel() * cw + cols.astype(np.int32).astype(np.int64).ravel()
         uniq, first = np.unique(key_flat, return_index=True)                # first source pixel wins (:762)
-        mask = np.zeros((H, cw), np.uint8)
-        mask.reshape(-1)[uniq] = 255
-        tab = dict(cw=cw, uniq=uniq, first=first, mask=mask)
-        # column-fill tables (fill_matrices :821-853): first filled row from the top / from the bottom
-        half = H // 2
-        top = mask[:half]
-        tab['top_unfilled'] = np.nonzero(top == 0)
-        tab['top_src_row'] = np.argmax(top > 0, axis=0)
-        bot = mask[::-1][:half]
-        tab['bot_unfilled'] = np.nonzero(bot == 0)
-        tab['bot_src_row'] = np.argmax(mask[half:][::-1] > 0, axis=0)
+        tab = dict(cw=cw, uniq=uniq, first=first)     # the column fills (fill_matrices :821-853) are derived on the device
         self._tables[key] = tab
         return tab
 
@@ -54,38 +45,13 @@ class EnvironmentMapGenerator:
         t = self._projection(H, W)
         return t['cw'], t['uniq'].astype(np.int32), t['first'].astype(np.int32)
 
-    def generate_map(self, background):
-        """reference bad_weather.py:742-819; background is float BGR in [0,1]."""
-        bg8 = (background * 255).astype(np.uint8)
-        H, W = bg8.shape[:2]
-        t = self._projection(H, W)
-        cw = t['cw']
-        cyl = np.zeros((H, cw, 3), np.uint8)
-        cyl.reshape(-1, 3)[t['uniq']] = bg8.reshape(-1, 3)[t['first']]
-        mask = t['mask']
-        half = H // 2
-        # bottom half: every unfilled pixel takes its column's first filled pixel seen from the bottom
-        fl = cyl[::-1]
-        tmp = fl[:half].copy()
-        r, c = t['bot_unfilled']
-        tmp[r, c] = fl[t['bot_src_row'][c], c]
-        cyl[-half:] = tmp[::-1] if half else cyl[-half:]
-        # top half
-        r, c = t['top_unfilled']
-        cyl[r, c] = cyl[t['top_src_row'][c], c]
-        lw = int(cw / 2)
-        result = np.zeros((H, cw + 2 * lw, 3), np.uint8)
-        result[:, lw:lw + cw] = cyl
-        mres = np.zeros((H, cw + 2 * lw), np.uint8)
-        mres[:, lw:lw + cw] = mask
-        side = cyl[:, 0:lw][:, ::-1]
-        result[:, 0:side.shape[1]] = side
-        mside = mask[:, :cw // 2][:, ::-1]
-        mres[:, :mside.shape[1]] = mside
-        side = cyl[:, cw // 2:][:, ::-1]
-        result[:, result.shape[1] - side.shape[1]:] = side
-        mside = mask[:, cw // 2:][:, ::-1]
-        mres[:, mres.shape[1] - side.shape[1]:] = mside
-        blur = imgops.gaussian_blur_u8(result, 15, 0)                       # :815
-        result = np.where(mres[..., None] == 0, blur, result)               # :816-817
-        return result / 255.0
+    def generate_map(self, background, hip=None):
+        """The reference's call (bad_weather.py:742-819; generator.py:400) for one frame, on the device
+        (rr_prepass_frames in RR_PRE_ENV_ONLY mode): background float BGR in [0,1] -> float BGR map of width
+        We = cw + 2*(cw // 2).  Generator.run does not come through here (no host round trip there)."""
+        from .. import hip_backend
+        hip = hip or hip_backend.shared_context()
+        H, W = background.shape[:2]
+        hip.set_prepass_kernels(imgops.gaussian_kernel(25, 25), imgops.gaussian_kernel(15, 0))
+        hip.set_envmap_geometry(H, W, *self.device_tables(H, W))
+        return hip.env_maps([background])[0] / 255.0

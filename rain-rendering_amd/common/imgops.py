@@ -5,7 +5,6 @@ documented conventions (BORDER_REFLECT_101, half-pixel-centre bilinear resize)."
 import os
 
 import numpy as np
-from scipy.ndimage import correlate1d
 
 
 def gaussian_kernel(ksize, sigma):
@@ -15,18 +14,6 @@ def gaussian_kernel(ksize, sigma):
     x = np.arange(ksize) - (ksize - 1) / 2.0
     k = np.exp(-(x * x) / (2.0 * sigma * sigma))
     return k / k.sum()
-
-
-def gaussian_blur(img, ksize, sigma):
-    """cv2.GaussianBlur(img, (ksize, ksize), sigma) for float images, BORDER_REFLECT_101."""
-    k = gaussian_kernel(ksize, sigma)
-    out = correlate1d(img, k, axis=1, mode='mirror')
-    return correlate1d(out, k, axis=0, mode='mirror')
-
-
-def gaussian_blur_u8(img, ksize, sigma=0):
-    out = gaussian_blur(img.astype(np.float64), ksize, sigma)
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
 def resize_linear(img, dw, dh):

@@ -2556,12 +2556,18 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     return RR_E_ARG;
   }
   bool want_env = false;
+  const bool env_only = in[0].mode == RR_PRE_ENV_ONLY;
   for (int f = 0; f < n; f++) {
     if (in[f].H != H || in[f].W != W) {
       ctx->err = "all frames of a batch must share H,W";
       return RR_E_ARG;
     }
-    if (!in[f].bg || !in[f].depth || !out[f].rainy_bg || !(in[f].irr_den != 0.0)) {
+    if ((in[f].mode != 0 && in[f].mode != RR_PRE_ENV_ONLY) || (in[f].mode == RR_PRE_ENV_ONLY) != env_only) {
+      ctx->err = "pre-pass: mode must be 0 or RR_PRE_ENV_ONLY, the same for every frame of a batch";
+      return RR_E_ARG;
+    }
+    if (env_only ? (!in[f].bg || !(out[f].env_xyY || out[f].env_bgr_u8))
+                 : (!in[f].bg || !in[f].depth || !out[f].rainy_bg || !(in[f].irr_den != 0.0))) {
       ctx->err = "pre-pass: null pointer or zero irradiance denominator (bg_u8 is for the host entry points only)";
       return RR_E_ARG;
     }
@@ -2596,7 +2602,7 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     rrpre::PreFrame& p = ctx->h_pre[f];
     p.bg = in[f].bg;
     p.depth = in[f].depth;
-    p.rainy = out[f].rainy_bg;
+    p.rainy = env_only ? const_cast<double*>(in[f].bg) : out[f].rainy_bg;   // env-only: the map kernels read the caller's image
     p.env_xyY = out[f].env_xyY;
     p.env_u8 = out[f].env_bgr_u8;
     p.beta_ext = in[f].beta_ext;
@@ -2609,17 +2615,17 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
   HIPCHK(hipMemcpyAsync(ctx->d_pre, ctx->h_pre.data(), sizeof(rrpre::PreFrame) * n, hipMemcpyHostToDevice, s));
   const rrpre::PreScratch sc = ctx->psc;
   const unsigned px_blocks = (unsigned)(((int64_t)H * W + 255) / 256);
-  {
+  if (!env_only) {
     ProfScope ps(ctx, s, "k_fog_stats");
     hipLaunchKernelGGL(rrpre::k_fog_sum, dim3(rrpre::FOG_BLOCKS, n), dim3(256), 0, s, ctx->d_pre, H, W, sc);
     hipLaunchKernelGGL(rrpre::k_fog_mean, dim3(n), dim3(64), 0, s, H, W, sc);
     hipLaunchKernelGGL(rrpre::k_fog_ext, dim3(px_blocks, n), dim3(256), 0, s, ctx->d_pre, H, W, sc);
   }
-  {
+  if (!env_only) {
     ProfScope ps(ctx, s, "k_fog_h");
     hipLaunchKernelGGL(rrpre::k_fog_h, dim3((W + rrpre::FOG_SEG - 1) / rrpre::FOG_SEG, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
   }
-  {
+  if (!env_only) {
     ProfScope ps(ctx, s, "k_fog_v");
     if (ctx->pk.fog_k == 25)        // the reference's 25 taps: register strips of FOG_RV rows
       hipLaunchKernelGGL(rrpre::k_fog_v_strip<12>, dim3((W + 255) / 256, (H + rrpre::FOG_RV - 1) / rrpre::FOG_RV, n), dim3(256), 0, s,
@@ -2984,11 +2990,16 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         ctx->err = "all frames of a batch must share H,W";
         return RR_E_ARG;
       }
-      if ((!pre[f].bg && !pre[f].bg_u8) || !pre[f].depth || !(pre[f].irr_den != 0.0)) {
+      const bool env_only = pre[f].mode == RR_PRE_ENV_ONLY;
+      if (env_only && in) {
+        ctx->err = "RR_PRE_ENV_ONLY is for rr_prepass_frames only";
+        return RR_E_ARG;
+      }
+      if ((!pre[f].bg && !pre[f].bg_u8) || (!env_only && (!pre[f].depth || !(pre[f].irr_den != 0.0)))) {
         ctx->err = "null pre-pass pointer or zero irradiance denominator";
         return RR_E_ARG;
       }
-      if (!in && !pre_out[f].rainy_bg) {
+      if (!in && !env_only && !pre_out[f].rainy_bg) {
         ctx->err = "pre-pass: null rainy_bg output";
         return RR_E_ARG;
       }
@@ -3064,7 +3075,8 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     pin[f].depth = st.depth + f * px;
     if (pre[f].bg_u8) up.add(st.bg8 + f * px * 3, pre[f].bg_u8, px * 3);      // bytes over PCIe: 1/8 of the float64 image
     else up.add((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double));
-    up.add((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4));
+    const bool env_only = pre[f].mode == RR_PRE_ENV_ONLY;
+    if (!env_only) up.add((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4));
     pout[f].rainy_bg = st.rainy + f * px * 3;
     const bool env = in || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
     pout[f].env_xyY = env ? st.env + f * ex * 3 : nullptr;
@@ -3160,7 +3172,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     if (out[f].mask_png) down.add(out[f].mask_png, dout[f].mask_png, png_bytes);
   }
   for (int f = 0; pre && pre_out && f < n; f++) {
-    if (pre_out[f].rainy_bg) down.add(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * sizeof(double));
+    if (pre_out[f].rainy_bg && pre[f].mode != RR_PRE_ENV_ONLY) down.add(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * sizeof(double));
     if (pre_out[f].env_xyY) down.add(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * sizeof(double));
     if (pre_out[f].env_bgr_u8) down.add(pre_out[f].env_bgr_u8, pout[f].env_bgr_u8, ex * 3);
   }

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'librainhip.so')
 RR_MAX_FOV = 32
 RR_E_ARENA = -5
 RR_PIPE_SLOTS = 3
+RR_PRE_ENV_ONLY = 1
 RR_OPT_DEDUP, RR_OPT_GENERAL_FOV, RR_OPT_FOV_THREADS, RR_OPT_FOV_DROPS_PER_THREAD, RR_OPT_DEPTH_OCCLUSION = 1, 2, 3, 4, 5
 
 # numpy mirror of rr_drop (112 bytes)
@@ -71,7 +72,7 @@ class rr_prepass_kernels(ctypes.Structure):
 
 class rr_prepass_in(ctypes.Structure):
     _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('bg', ctypes.c_void_p), ('depth', ctypes.c_void_p),
-                ('depth_f64', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('depth_f64', ctypes.c_int32), ('mode', ctypes.c_int32),
                 ('beta_ext', ctypes.c_double), ('beta_hg', ctypes.c_double),
                 ('irr_num', ctypes.c_double), ('irr_den', ctypes.c_double), ('bg_u8', ctypes.c_void_p)]
 
@@ -364,6 +365,19 @@ def pack_streak_db(textures):
     return texels, hs, ws, offs
 
 
+_SHARED = {}
+
+
+def shared_context(device=None):
+    """One library context per (process, device) for the reference-signature single-frame seams
+    (FogRain.fog_rain_layer, EnvironmentMapGenerator.generate_map)."""
+    import os
+    device = int(os.environ.get('LOCAL_RANK', '0')) if device is None else int(device)
+    if device not in _SHARED:
+        _SHARED[device] = RainHip(device)
+    return _SHARED[device]
+
+
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
@@ -627,6 +641,27 @@ class RainHip:
             pout[k].env_xyY = _ptr(o.get('env_xyY'))
             pout[k].env_bgr_u8 = _ptr(o.get('env_bgr_u8'))
             outs.append(o)
+        self._check(self.lib.rr_prepass_frames(self.h, n, pin, pout), 'rr_prepass_frames')
+        return outs
+
+    def env_maps(self, backgrounds, want_xyY=False):
+        """EnvironmentMapGenerator.generate_map alone (bad_weather.py:742-819) for float BGR images in [0,1] that already
+        carry the fog layer: list of uint8 BGR maps (what --save_envmap stores), or (map, xyY) pairs."""
+        n = len(backgrounds)
+        pin = (rr_prepass_in * n)()
+        pout = (rr_prepass_out * n)()
+        We = self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width')
+        keep, outs = [], []
+        for k, b in enumerate(backgrounds):
+            bg = np.ascontiguousarray(b, np.float64)
+            H, W = bg.shape[:2]
+            assert bg.shape == (H, W, 3), bg.shape
+            u8 = np.zeros((H, We, 3), np.uint8)
+            xyY = np.zeros((H, We, 3), np.float64) if want_xyY else None
+            pin[k].H, pin[k].W, pin[k].bg, pin[k].mode = H, W, _ptr(bg), RR_PRE_ENV_ONLY
+            pout[k].env_bgr_u8, pout[k].env_xyY = _ptr(u8), _ptr(xyY)
+            keep.append(bg)
+            outs.append((u8, xyY) if want_xyY else u8)
         self._check(self.lib.rr_prepass_frames(self.h, n, pin, pout), 'rr_prepass_frames')
         return outs
 

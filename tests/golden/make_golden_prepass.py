@@ -59,6 +59,22 @@ def main():
         out['case%d_depth' % k] = depth
         out['case%d_rainy' % k] = rainy
         out['case%d_env' % k] = env
+    # ---- KITTI size (1242x375), fog -> environment map end to end through the reference's classes.  The inputs are
+    # regenerated from the seed by the tests; the outputs are recorded as SHA-256 digests of the full float64 arrays
+    # (the oracle must reproduce them bit for bit) plus every 25th row for diagnosis.
+    import hashlib
+    H, W, rain, seed = 375, 1242, 50, 3
+    bg = h.synthetic.make_frame(seed, H, W)
+    rng = np.random.RandomState(seed)
+    depth = (np.linspace(80, 2, H)[:, None] * np.ones((1, W)) + rng.uniform(0, 3, (H, W))).astype(np.float32)
+    fog = radd.FogRain(rain_intensity=rain, focal=0.006, f_number=6.0, angle=90, exposure=2, camera_gain=20)
+    rainy = fog.fog_rain_layer(bg.copy(), depth.copy())
+    env = rbw.EnvironmentMapGenerator(0.006, W, H).generate_map(rainy.copy())
+    out['kitti_meta'] = np.array([H, W, rain, seed], np.int64)
+    out['kitti_env_shape'] = np.array(env.shape, np.int64)
+    out['kitti_digests'] = np.array([hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in (bg, depth, rainy, env)])
+    out['kitti_rainy_rows'] = rainy[::25]
+    out['kitti_env_rows'] = env[::25]
     np.savez_compressed(os.path.join(HERE, 'prepass_vectors.npz'), **out)
     print({k: (v.shape, str(v.dtype)) for k, v in out.items()})
 

@@ -91,3 +91,12 @@ def oracle_render(scene, i, bg, rainy_bg, env_xyY, faithful=True, noise_std=0.0,
     return orc.render_frame(bg, rainy_bg, env_xyY, scene.omega, streaks, textures, ratio, scene.ocam, frame_seed=i,
                             noise_std=noise_std, noise_scale=noise_scale, faithful=faithful, max_drops=max_drops,
                             rendering_strategy=strategy, first_drop=first_drop)
+
+
+def prepass_scene(H, W, seed, dtype=np.float32):
+    """Seeded inputs of the pre-pass tests (image / 255 and a depth map in metres); tests/golden/make_golden_prepass.py
+    feeds the same arrays to the reference."""
+    bg = synthetic.make_frame(seed, H, W)
+    rng = np.random.RandomState(seed)
+    depth = (np.linspace(80, 2, H)[:, None] * np.ones((1, W)) + rng.uniform(0, 3, (H, W))).astype(dtype)
+    return bg, depth

@@ -17,11 +17,7 @@ envmod = importlib.import_module('rain-rendering_amd.common.envmap')
 FOCAL, FNUM, EXPO, GAIN = 0.006, 6.0, 2, 20
 
 
-def _scene(H, W, seed, dtype=np.float32):
-    bg = h.synthetic.make_frame(seed, H, W)
-    rng = np.random.RandomState(seed)
-    depth = (np.linspace(80, 2, H)[:, None] * np.ones((1, W)) + rng.uniform(0, 3, (H, W))).astype(dtype)
-    return bg, depth
+_scene = h.prepass_scene
 
 
 def _setup(rh, H, W, rain):
@@ -48,6 +44,52 @@ def test_prepass_matches_oracle(built, H, W, dtype):
     only = rh.prepass_frames(frames[:1], want_env=False)
     assert np.array_equal(only[0]['rainy_bg'], outs[0]['rainy_bg'])
     rh.close()
+
+
+def test_fog_to_envmap_end_to_end_equals_reference_at_kitti_size(built):
+    """The chain fog -> cylinder map -> xyY at 1242x375 against the REFERENCE's own FogRain + EnvironmentMapGenerator
+    (tests/golden/prepass_vectors.npz 'kitti_*': digests pinned to the oracle on the CPU tier, every 25th row here):
+    nothing in the expected values comes from the GPU.  The device's float32 expf moves the fog layer by <= 2e-7;
+    through the map (a gather, two 15-tap blurs, the xyY ratios) that stays below 1e-6 and 1 LSB of the uint8 map."""
+    import os
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'prepass_vectors.npz'))
+    H, W, rain, seed = [int(x) for x in v['kitti_meta']]
+    rh = h.hb.RainHip(0)
+    consts, We = _setup(rh, H, W, rain)
+    bg, depth = _scene(H, W, seed)
+    o = rh.prepass_frames([dict(bg=bg, depth=depth, fog=consts)], want_env=True, want_env_u8=True)[0]
+    assert (H, We, 3) == tuple(v['kitti_env_shape'])
+    assert np.abs(o['rainy_bg'][::25] - v['kitti_rainy_rows']).max() < 2e-7
+    ref_env = v['kitti_env_rows']
+    assert np.abs(o['env_bgr_u8'][::25].astype(int) - np.rint(ref_env * 255).astype(int)).max() <= 1
+    d = np.abs(o['env_xyY'][::25] - op.env_to_xyY(ref_env))
+    assert d.max() < 1e-6, d.max()
+    rh.close()
+
+
+def test_reference_signature_seams(built):
+    """FOG.fog_rain_layer(bg, depth) (generator.py:386) and map_generator.generate_map(rainy_bg) (:400) with the
+    reference's signatures, one frame at a time on the device; the map call takes ANY fogged image (RR_PRE_ENV_ONLY)."""
+    H, W = 96, 160
+    bg, depth = _scene(H, W, 9)
+    fog = fogmod.FogRain(rain_intensity=25, focal=FOCAL, f_number=FNUM, angle=90, exposure=EXPO, camera_gain=GAIN)
+    rainy = fog.fog_rain_layer(bg, depth)
+    assert np.abs(rainy - op.fog_rain_layer(bg, depth, 25, FNUM, EXPO, GAIN)).max() < 2e-7
+    gen = envmod.EnvironmentMapGenerator(FOCAL, W, H)
+    for img in (rainy, op.fog_rain_layer(bg, depth, 25, FNUM, EXPO, GAIN), bg):
+        e = gen.generate_map(img)
+        assert np.array_equal(np.rint(e * 255).astype(np.uint8), np.rint(op.generate_env_map(img, FOCAL) * 255).astype(np.uint8))
+    rh = h.hb.shared_context()
+    u8, xyY = rh.env_maps([bg], want_xyY=True)[0]
+    assert np.abs(xyY - op.env_to_xyY(op.generate_env_map(bg, FOCAL))).max() < 1e-12
+    # the pipeline form rejects the map-only mode; a batch may not mix modes
+    pin = (h.hb.rr_prepass_in * 2)()
+    pout = (h.hb.rr_prepass_out * 2)()
+    keep = np.ascontiguousarray(bg)
+    for k in range(2):
+        pin[k].H, pin[k].W, pin[k].bg, pin[k].mode = H, W, keep.ctypes.data, k
+        pout[k].env_bgr_u8 = u8.ctypes.data
+    assert rh.lib.rr_prepass_frames(rh.h, 2, pin, pout) < 0
 
 
 def test_pipeline_equals_two_calls_and_oracle(tmp_path, built):

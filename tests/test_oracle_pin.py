@@ -246,6 +246,17 @@ def test_prepass_oracle_equals_reference_vectors():
         assert rainy.dtype == v['case%d_rainy' % k].dtype and np.array_equal(rainy, v['case%d_rainy' % k])
         env = op.generate_env_map(v['case%d_rainy' % k], 0.006)
         assert env.shape == v['case%d_env' % k].shape and np.array_equal(env, v['case%d_env' % k])
+    # KITTI size, fog -> environment map chained (the map is made from the oracle's OWN fog output): digests of the
+    # reference's full float64 arrays + every 25th row
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    H, W, rain, seed = [int(x) for x in v['kitti_meta']]
+    bg, depth = h.prepass_scene(H, W, seed)
+    assert [sha(bg), sha(depth)] == list(v['kitti_digests'][:2])
+    rainy = op.fog_rain_layer(bg, depth, rain, 6.0, 2, 20)
+    env = op.generate_env_map(rainy, 0.006)
+    assert np.array_equal(rainy[::25], v['kitti_rainy_rows']) and np.array_equal(env[::25], v['kitti_env_rows'])
+    assert env.shape == tuple(v['kitti_env_shape']) and [sha(rainy), sha(env)] == list(v['kitti_digests'][2:])
 
 
 def test_int32_mask_equals_untouched_reference(tmp_path):
