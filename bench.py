@@ -240,9 +240,11 @@ def main():
     ap.add_argument('--cpu-sample-drops', type=int, default=2048)
     ap.add_argument('--pipe-batch', type=int, default=32, help='frames per slot of the host-inclusive pipeline')
     ap.add_argument('--opt', action='append', default=[], help='rr_set_option as ID=VALUE (tuning switches that never change results)')
+    ap.add_argument('--sweep', action='append', default=[], help='A/B: after the headline, time the loop again under these '
+                    'rr_set_option sets ("6=3,3=512"); one JSON line each on stderr; implies the lean run')
     ap.add_argument('--inner', action='store_true', help='(used by the PMC passes) timed loop only, no extras, no JSON')
     args = ap.parse_args()
-    if args.inner:
+    if args.inner or args.sweep:
         args.no_cpu_baseline = args.no_prepass = args.no_variants = args.no_traffic = True
 
     import torch
@@ -332,6 +334,24 @@ def main():
     if args.inner:
         rh.close()
         return
+    if args.sweep and rank == 0:
+        def line(tag, el, st):
+            ks = {k: round(v[1] / args.steps, 3) for k, v in sorted(st.items(), key=lambda kv: -kv[1][1])[:12]}
+            sys.stderr.write("SWEEP " + json.dumps({"opts": tag, "ms_per_step": round(1e3 * el / args.steps, 3), "kernels_ms": ks}) + "\n")
+        line("default", elapsed, stats)
+        for spec in args.sweep:
+            pairs = [kv.split('=') for kv in spec.split(',') if kv]
+            for k, v in pairs:
+                rh.set_option(int(k), int(v))
+            warm(render, 1)
+            rh.profile_reset()
+            rh.profile(True)
+            el = timed(torch, dist, world, dev, render, args.steps)
+            rh.profile(False)
+            line(spec, el, rh.profile_read())
+            for k, v in pairs:
+                rh.set_option(int(k), 0 if int(k) != 1 else 1)
+        warm(render, 1)
     nb = min(B, batch.n)
     cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)
 

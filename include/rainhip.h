@@ -229,7 +229,7 @@ int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_
 int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
                        const rr_prepass_out* pre_out);
 
-/* Options.  1-4 are tuning / A-B switches: NONE of them changes a result bit (tests/test_gpu_properties.py).  Unknown
+/* Options.  1-4 and 6 are tuning / A-B switches: NONE of them changes a result bit (tests/test_gpu_properties.py).  Unknown
  * options or values are RR_E_ARG.  The library reads no environment variables. */
 enum {
   RR_OPT_DEDUP = 1,                 /* 1 (default): drops with bit-identical raw-tile parameters share one tile inside a batch */
@@ -241,7 +241,9 @@ enum {
    * USE_DEPTH_WEIGHTING = 0, generator.py:20): with 1, a drop is not composited at pixels whose scene depth
    * (rr_frame_in.depth / the pre-pass' depth) is smaller than the drop's distance |world z|.  Default 0: the reference's
    * output.  Excluded from every parity run. */
-  RR_OPT_DEPTH_OCCLUSION = 5
+  RR_OPT_DEPTH_OCCLUSION = 5,
+  RR_OPT_BLUR_WORKGROUPS = 6        /* tuning: workgroups per CU the fused defocus blur is sized for (LDS tiles + registers):
+                                     * 0 (library's choice = 4), 3, 4 or 5 */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

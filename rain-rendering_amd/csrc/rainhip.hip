@@ -71,6 +71,12 @@ template <class T>
 using global_ptr = T __attribute__((address_space(1)))*;
 template <class T>
 __device__ inline global_ptr<T> as_global(T* p) { return (global_ptr<T>)p; }
+// Data a kernel only reads and an EARLIER kernel wrote: the constant address space lets a wave-uniform access use the
+// scalar unit (s_load into SGPRs) even after barriers, which otherwise count as possible writers.
+template <class T>
+using const_ptr = const T __attribute__((address_space(4)))*;
+template <class T>
+__device__ inline const_ptr<T> as_constant(const T* p) { return (const_ptr<T>)p; }
 __device__ inline rr_drop load_drop(const rr_drop* p) {       // 14 global 8-byte loads
   static_assert(sizeof(rr_drop) % 8 == 0, "rr_drop layout");
   rr_drop d;
@@ -119,6 +125,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* big_off;                 // [frame][drops+1] exclusive prefix of their tile sizes, in pixels
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
   int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
+  int32_t blur_bx, blur_by;         // LDS capacities (doubles) of the fused blur's two staging tiles (RR_OPT_BLUR_WORKGROUPS)
 };
 
 // ---------------------------------------------------------------------------
@@ -193,8 +200,10 @@ __global__ __launch_bounds__(256) void k_env_consts(Dims dm, const double* prefi
 }
 
 // blur work layout (needed by k_colour to know where the finished tile will live)
-constexpr int BX_MAX = 3072;        // doubles: input sub-tile incl. halo
-constexpr int BY_MAX = 2048;        // doubles: after the row (axis 0) pass
+// LDS capacities of the fused blur (doubles): input sub-tile incl. halo / result of the row (axis 0) pass.  They set how
+// many workgroups share a CU (160 KB of LDS; the kernel is compiled for the matching register budget):
+//   3 per CU: 3072 + 2048     4 per CU: 2816 + 2048 (default)     5 per CU: 2304 + 1600
+// Smaller tiles mean more sub-tiles per drop (more halo re-loaded), more workgroups mean better latency hiding.
 constexpr int BR_MAX = 48;          // largest axis-0 radius the fused kernel takes
 
 struct BlurLayout {
@@ -208,9 +217,9 @@ struct BlurLayout {
 // lanes running down a column hit distinct LDS banks.
 __device__ inline int blur_x_doubles(int wo, int ho, int r1, int r2) { return (wo + 2 * r2) * (((ho + 3) & ~3) + 2 * r1); }
 __device__ inline int blur_y_pitch(int wo, int r2) { return (((wo + 3) & ~3) + 2 * r2) | 1; }
-__device__ inline int blur_y_doubles(int wo, int ho, int r2) { return blur_y_pitch(wo, r2) * ho; }
+__device__ inline int blur_y_doubles(int wo, int ho, int r2) { return blur_y_pitch(wo, r2) * ((ho + 3) & ~3); }
 
-__device__ inline BlurLayout blur_layout(const DropPlan& p) {
+__device__ inline BlurLayout blur_layout(const DropPlan& p, int BX_MAX, int BY_MAX) {
   BlurLayout b{0, 0, 0, 0};
   if (p.r1 <= 0 || p.r1 > BR_MAX) return b;
   // Whole tile if it fits; otherwise the output sub-tile that (roughly) maximises wo*ho under
@@ -247,8 +256,8 @@ __device__ inline bool blur_is_small(const DropPlan& p) {
 
 // blurred drops neither k_blur_small nor k_blur_fused can take (radius > BR_MAX): two global passes
 // through one extra padded scratch tile
-__device__ inline bool blur_is_slow(const DropPlan& p) {
-  return p.r1 > 0 && !blur_is_small(p) && !blur_layout(p).fused;
+__device__ inline bool blur_is_slow(const DropPlan& p, const Scratch& sc) {
+  return p.r1 > 0 && !blur_is_small(p) && !blur_layout(p, sc.blur_bx, sc.blur_by).fused;
 }
 
 // ---------------------------------------------------------------------------
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
     // its failure is raised before the circle of confusion is looked at (bad_weather.py:363-373 vs :416)
     const int npts = sc.npts[gi];                 // 0: failed; -1: 'white' strategy (never used)
     if (p.status != RR_DROP_OK || npts == 0) size = 0;
-    if (size > 0 && blur_is_slow(p)) size += ((int64_t)p.ew * p.eh + 15) & ~15LL;     // dense scratch tile of the two-pass blur
+    if (size > 0 && blur_is_slow(p, sc)) size += ((int64_t)p.ew * p.eh + 15) & ~15LL;     // dense scratch tile of the two-pass blur
     sc.sizes[gi] = size;
   }
   const int wave_i0 = blockIdx.x * blockDim.x + wave * 64;         // first drop of this wave
@@ -643,27 +652,29 @@ __device__ inline double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// Sums of (x*w, y*w, Y*w, w) under every drop's spans.  Workgroup (frame, row band, chunk of NT*DPT drops); per map
-// row of the band:
-//   1. the row (24 B of xyY + 8 B of solid angle per texel) is read from HBM -- once per batch: the chunks of a
-//      (frame, band) run on the same XCD and the later ones find it in L2 -- and its inclusive prefix sums are built
-//      in LDS.  Wave w owns the columns [w*Cw, (w+1)*Cw) in passes of 64 consecutive columns (coalesced loads,
-//      conflict-free LDS stores): DPP scan per pass, carry between passes, wave totals through LDS;
+// Sums of (x*w, y*w, Y*w, w) under every drop's spans.  Workgroup (frame, row band, component half, chunk of NT*DPT
+// drops); half 0 accumulates (x*w, y*w), half 1 (Y*w, w).  Per map row of the band:
+//   1. the row (xyY + solid angle per texel) is read from HBM -- once per batch: the workgroups of a (frame, band) run
+//      on the same XCD in lock step and the later ones find it in L2 -- and the inclusive prefix sums of the half's two
+//      components are built in LDS.  Wave w owns the columns [w*Cw, (w+1)*Cw) in passes of 128 consecutive columns,
+//      TWO per lane: the lane adds its pair, one DPP scan per pass runs over the pair sums (carry between passes, wave
+//      totals through LDS), and the pair's first column gets (inclusive sum - second value);
 //   2. every thread takes its DPT drops' look-ups P[xr + 1] - P[xl] from LDS (an empty span is (0, 0): an exact
 //      zero, no branch) and keeps the running sums in registers.
-// The next row's global loads are issued before the look-ups of the current one.  Band partials go to
-// colpart[frame][band][5][drop]; the chunk-0 workgroups also leave the band's row totals (sum w, sum Y*w) for the
-// frame constants.  LDS: P as two arrays of double2 (x*w, y*w) / (Y*w, w): 16-byte entries spread a wave's random
-// look-ups over all 64 banks.
-constexpr int FOV_EMAX = 4;
+// The scan is the expensive part (it does not depend on the drops): splitting the four components over two workgroups
+// that each carry twice the drops halves it, two columns per lane halve it again.  The next row's global loads are
+// issued before the look-ups of the current one.  Band partials go to colpart[frame][band][5][drop]; the half-1
+// workgroup of chunk 0 also leaves the band's row totals (sum w, sum Y*w) for the frame constants.  LDS: P as one array
+// of double2: 16-byte entries spread a wave's random look-ups over all 64 banks.
+constexpr int FOV_EMAX = 2;
 template <int DPT, int EMAX>
 __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int Dp, int rpb, int nchunk, Scratch sc) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   const int We = dm.We;
-  double2* s_P01 = reinterpret_cast<double2*>(s_dyn);    // [We + 1] inclusive prefix of (x*w, y*w); entry 0 = zeros
-  double2* s_P23 = s_P01 + (We + 1);                     // [We + 1] ... of (Y*w, w)
-  double* s_wt = reinterpret_cast<double*>(s_P23 + (We + 1));   // [16][4] wave totals of the row being scanned
-  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS, chunk = blockIdx.x / COL_PARTS;
+  double2* s_P = reinterpret_cast<double2*>(s_dyn);      // [We + 1] inclusive prefix of the half's two components; entry 0 = zeros
+  double* s_wt = reinterpret_cast<double*>(s_P + (We + 1));     // [16][2] wave totals of the row being scanned
+  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS, part = blockIdx.x / COL_PARTS;
+  const int half = part & 1, chunk = part >> 1;
   const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, nw = NT >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const FrameDesc& fr = frames[f];
@@ -674,7 +685,7 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
   const int d0 = chunk * per, d1 = imin(n, d0 + per);
   if (d0 >= n) return;
   const int y0 = band * rpb, y1 = imin(dm.He, y0 + rpb);
-  const int Cw = (We + nw - 1) / nw;                     // columns per wave, taken in passes of 64 (<= EMAX passes)
+  const int Cw = (((We + nw - 1) / nw) + 1) & ~1;        // columns per wave (even), taken in passes of 128 (<= EMAX passes)
   const int cw0 = wave * Cw;
   // spans of frame f: [Hp / 4][Dp] pieces of 16 bytes (4 rows); slot max_drops of every quad is all zeros (what a
   // drop without a polygon reads)
@@ -685,27 +696,29 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
     const int i = d0 + d * NT + t;
     sp[d] = (uint32_t)((i < d1 && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops);
   }
-  if (t == 0) { s_P01[0] = make_double2(0.0, 0.0); s_P23[0] = make_double2(0.0, 0.0); }
-  double S[DPT][4];
-  uint32_t any[DPT];
+  if (t == 0) s_P[0] = make_double2(0.0, 0.0);
+  double S[DPT][2];
+  uint32_t any = 0;                                      // bit d: drop d had a non-empty span in this band
 #pragma unroll
-  for (int d = 0; d < DPT; d++) { S[d][0] = S[d][1] = S[d][2] = S[d][3] = 0.0; any[d] = 0; }
-  double totY = 0.0, totW = 0.0;                         // row totals, kept by the thread that owns the last column
-  double pv[EMAX][4];
+  for (int d = 0; d < DPT; d++) S[d][0] = S[d][1] = 0.0;
+  double tot0 = 0.0, tot1 = 0.0;                         // row totals, kept by the thread that owns the last column
+  double pa[EMAX][2], pb[EMAX][2];                       // the lane's column pair (first / second column) x two components
   auto load_row = [&](int y) {
     const global_ptr<const double> env = as_global(fr.env) + (int64_t)y * We * 3;
     const global_ptr<const double> om = as_global(fr.omega) + (int64_t)y * We;
 #pragma unroll
     for (int e = 0; e < EMAX; e++) {
-      const int cl = e * 64 + lane, c = cw0 + cl;
+      const int cl = e * 128 + 2 * lane, c = cw0 + cl;
+      pa[e][0] = pa[e][1] = pb[e][0] = pb[e][1] = 0.0;
       if (cl < Cw && c < We) {
         const double w = om[c];
-        pv[e][0] = env[c * 3 + 0] * w;
-        pv[e][1] = env[c * 3 + 1] * w;
-        pv[e][2] = env[c * 3 + 2] * w;
-        pv[e][3] = w;
-      } else {
-        pv[e][0] = pv[e][1] = pv[e][2] = pv[e][3] = 0.0;
+        pa[e][0] = (half ? env[c * 3 + 2] : env[c * 3 + 0]) * w;
+        pa[e][1] = half ? w : env[c * 3 + 1] * w;
+        if (c + 1 < We) {
+          const double w1 = om[c + 1];
+          pb[e][0] = (half ? env[c * 3 + 5] : env[c * 3 + 3]) * w1;
+          pb[e][1] = half ? w1 : env[c * 3 + 4] * w1;
+        }
       }
     }
   };
@@ -719,38 +732,36 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
       const int y = yq + j;
       if (y >= y1) break;
       // ---- 1. prefix sums of row y into LDS ----
-      double carry[4] = {0.0, 0.0, 0.0, 0.0};
+      double carry[2] = {0.0, 0.0};
+      double ps[EMAX][2];                                // inclusive prefix through the lane's second column
 #pragma unroll
       for (int e = 0; e < EMAX; e++) {
-        if (e * 64 < Cw) {
+        if (e * 128 < Cw) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const double v = wave_incl_scan_f64(pv[e][k]) + carry[k];
-            pv[e][k] = v;
+          for (int k = 0; k < 2; k++) {
+            const double v = wave_incl_scan_f64(pa[e][k] + pb[e][k]) + carry[k];
+            ps[e][k] = v;
             carry[k] = readlane_f64(v, 63);
           }
         }
       }
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) s_wt[wave * 4 + k] = carry[k];
-      }
+      if (lane == 0) { s_wt[wave * 2 + 0] = carry[0]; s_wt[wave * 2 + 1] = carry[1]; }
       __syncthreads();                                   // wave totals visible; the previous row's look-ups are done
-      double basev[4];                                   // totals of the waves in front: 16-lane scan of the wave totals
+      double basev[2];                                   // totals of the waves in front: 16-lane scan of the wave totals
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const double wt = row16_incl_scan_f64(lane < nw ? s_wt[lane * 4 + k] : 0.0);
+      for (int k = 0; k < 2; k++) {
+        const double wt = row16_incl_scan_f64(lane < nw ? s_wt[lane * 2 + k] : 0.0);
         const double u = readlane_f64(wt, wave > 0 ? wave - 1 : 0);
         basev[k] = wave > 0 ? u : 0.0;
       }
 #pragma unroll
       for (int e = 0; e < EMAX; e++) {
-        const int cl = e * 64 + lane, c = cw0 + cl;
+        const int cl = e * 128 + 2 * lane, c = cw0 + cl;
         if (cl < Cw && c < We) {
-          const double o0 = basev[0] + pv[e][0], o1 = basev[1] + pv[e][1], o2 = basev[2] + pv[e][2], o3 = basev[3] + pv[e][3];
-          s_P01[c + 1] = make_double2(o0, o1);
-          s_P23[c + 1] = make_double2(o2, o3);
-          if (c == We - 1) { totY += o2; totW += o3; }
+          const double o0 = basev[0] + ps[e][0], o1 = basev[1] + ps[e][1];       // through column c + 1
+          s_P[c + 1] = make_double2(o0 - pb[e][0], o1 - pb[e][1]);               // through column c
+          if (c + 1 < We) s_P[c + 2] = make_double2(o0, o1);
+          if (c == We - 1 || c + 1 == We - 1) { tot0 += o0; tot1 += o1; }        // (an absent second column added 0)
         }
       }
       if (y + 1 < y1) load_row(y + 1);                   // in flight under the look-ups
@@ -759,13 +770,10 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
 #pragma unroll
       for (int d = 0; d < DPT; d++) {
         const uint32_t v = j == 0 ? q[d].x : (j == 1 ? q[d].y : (j == 2 ? q[d].z : q[d].w));
-        any[d] |= v;
-        const uint32_t ih = v >> 16, il = v & 0xffffu;
-        const double2 h0 = s_P01[ih], h1 = s_P23[ih], l0 = s_P01[il], l1 = s_P23[il];
-        S[d][0] += h0.x - l0.x;
-        S[d][1] += h0.y - l0.y;
-        S[d][2] += h1.x - l1.x;
-        S[d][3] += h1.y - l1.y;
+        any |= (v != 0u ? 1u : 0u) << d;
+        const double2 h = s_P[v >> 16], l = s_P[v & 0xffffu];
+        S[d][0] += h.x - l.x;
+        S[d][1] += h.y - l.y;
       }
     }
   }
@@ -774,18 +782,16 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
     const int i = d0 + d * NT + t;
     if (i < d1) {
       double* o = sc.colpart + ((int64_t)(f * COL_PARTS + band) * 5) * max_drops + i;
-      o[0] = S[d][0];
-      o[(int64_t)max_drops] = S[d][1];
-      o[(int64_t)max_drops * 2] = S[d][2];
-      o[(int64_t)max_drops * 3] = S[d][3];
-      o[(int64_t)max_drops * 4] = any[d] ? 1.0 : 0.0;
+      o[(int64_t)max_drops * (2 * half)] = S[d][0];
+      o[(int64_t)max_drops * (2 * half + 1)] = S[d][1];
+      if (half == 0) o[(int64_t)max_drops * 4] = ((any >> d) & 1u) ? 1.0 : 0.0;
     }
   }
   {                                                      // the thread that owns the last column
-    const int cl = We - 1 - cw0;
-    if (chunk == 0 && cl >= 0 && cl < Cw && (cl & 63) == lane) {
-      sc.fband[(f * COL_PARTS + band) * 2 + 0] = totW;
-      sc.fband[(f * COL_PARTS + band) * 2 + 1] = totY;
+    const int cl = (We - 1 - cw0) & ~1;
+    if (half == 1 && chunk == 0 && We - 1 >= cw0 && cl < Cw && ((cl >> 1) & 63) == lane) {
+      sc.fband[(f * COL_PARTS + band) * 2 + 0] = tot1;   // sum w
+      sc.fband[(f * COL_PARTS + band) * 2 + 1] = tot0;   // sum Y*w
     }
   }
 }
@@ -1440,7 +1446,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { c[4]++; continue; }
-      const BlurLayout L = blur_layout(p);
+      const BlurLayout L = blur_layout(p, sc.blur_bx, sc.blur_by);
       if (L.fused) c[2] += imin(blur_subtiles(p, L), BLUR_ITEMS_PER_DROP); else c[3]++;
     }
   }
@@ -1478,7 +1484,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
-      const BlurLayout L = blur_layout(p);
+      const BlurLayout L = blur_layout(p, sc.blur_bx, sc.blur_by);
       if (L.fused) {
         const int ns = blur_subtiles(p, L);
         const int ni = imin(ns, BLUR_ITEMS_PER_DROP);
@@ -1578,10 +1584,16 @@ __device__ inline void blur4(const double* c0, int st, const double* hw, int r, 
 // ---------------------------------------------------------------------------
 // fused defocus blur: both axes of the separable filter through LDS
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int max_drops, Scratch sc) {
+// WPE = waves per SIMD the register allocation is held to (= workgroups per CU; the LDS capacities in sc.blur_bx / blur_by
+// are chosen to match, see above).  LDS (dynamic): hw1 | hw2 | X[blur_bx] | Y[blur_by].
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames, int max_drops, Scratch sc) {
   const int f = blockIdx.y, t = threadIdx.x;
-  __shared__ double hw1[BR_MAX + 1], hw2[BR_MAX + 1];
-  __shared__ double X[BX_MAX], Y[BY_MAX];
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double* hw1 = s_dyn;
+  double* hw2 = s_dyn + (BR_MAX + 1);
+  double* X = s_dyn + 2 * (BR_MAX + 1);                                 // 98 doubles in front: X and Y stay 16-byte aligned
+  double* Y = X + sc.blur_bx;
   const int n_items = sc.counts[f * 8 + 2];
   const int4* items = sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP;
   int cur = -1;
@@ -1591,14 +1603,13 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
   const DropPlan& p = sc.plan[gi];
   BlurLayout L{1, item.w & 0xffff, item.w >> 16, 0};               // computed once, by k_lists
   const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;            // the tile being produced is the EFFECTIVE tile
-  // the weight tables depend on the drop only; they are computed by waves 0 and 1 while the first
+  // the weight tables depend on the drop only; they are fetched by waves 0 and 1 while the first
   // batch of tile loads is in flight (every item ends with a barrier, so the old tables are free)
   bool need_tables = cur != item.x;
   const double* src = sc.arena + p.a0_off;          // raw tile (tw x th); the pad is implicit zeros
   double* dst = sc.arena + p.a1_off;                // finished effective tile (ew x eh); raw sits at (r2, r1) inside it
   const int tw = p.tw, th = p.th;
-  const int ntx = (pw + L.wo - 1) / L.wo, nty = (ph + L.ho - 1) / L.ho;
-  (void)nty;
+  const int ntx = (pw + L.wo - 1) / L.wo;
   for (int st = item.y; st < item.y + item.z; st++) {
     const int sty = st / ntx, stx = st - sty * ntx;
     const int y0 = sty * L.ho, x0 = stx * L.wo;
@@ -1609,21 +1620,28 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
       const int wi = wo + 2 * r2, hi = hop + 2 * r1;      // LDS input tile with zero halos (+ slack rows)
       const int yp = blur_y_pitch(wo, r2);                // odd pitch of the row-pass result
       // Only the columns under the raw tile carry data through the row pass (it filters along y: a column
-      // without raw pixels stays exactly zero).  X holds those wd columns, the row pass runs over them, and
-      // the remaining columns of Y are written as zeros for the column pass.
+      // without raw pixels stays exactly zero).  X holds those wd columns, the row pass runs over them; Y is
+      // cleared as a whole first (wide stores, no index arithmetic) and the row pass writes its columns over it.
       const int xa = imax(0, 2 * r2 - x0), xb = imin(wi, tw + 2 * r2 - x0);   // data columns of the haloed sub-tile
-      const int wd = imax(xb - xa, 1);
-      const float inv_wd = 1.0f / (float)wd;
-      // data columns of the haloed tile -> LDS; eight independent global loads in flight per thread
+      const int wd = imax(xb - xa, 0);                    // 0: the sub-tile lies beside the raw tile (all zeros)
+      const int wdd = imax(wd, 1);
+      const float inv_wd = 1.0f / (float)wdd;
+      // data columns of the haloed tile -> LDS; eight independent global loads in flight per thread.  By the
+      // choice of xa / xb every column is inside the raw tile; only the row needs a test.  (row, column) of the
+      // thread's first element by one float division, the following ones (256 apart) incrementally.
       const int nx = wd * hi;
+      const int dq = (int)((256.0f + 0.5f) * inv_wd), dr = 256 - dq * wdd;
+      const int xs = x0 - 2 * r2 + xa, ys = y0 - 2 * r1;
+      int yy = (int)(((float)t + 0.5f) * inv_wd), xc = t - yy * wdd;
       for (int base = t; base < nx || need_tables; base += 2048) {
         double v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          const int idx = base + 256 * k;
-          const int yy = (int)(((float)idx + 0.5f) * inv_wd), xc = idx - yy * wd;
-          const int y = y0 - 2 * r1 + yy, x = x0 - 2 * r2 + xa + xc;         // raw-tile coordinates
-          v[k] = (idx < nx && y >= 0 && y < th && x >= 0 && x < tw) ? src[y * tw + x] : 0.0;
+          const int y = ys + yy;
+          v[k] = (base + 256 * k < nx && (unsigned)y < (unsigned)th) ? src[y * tw + (xs + xc)] : 0.0;
+          xc += dr;
+          yy += dq;
+          if (xc >= wdd) { xc -= wdd; yy += 1; }
         }
         if (need_tables) {
           const double* wt = sc.wtab + gi * 2 * (BR_MAX + 1);                // built by k_blur_weights
@@ -1637,12 +1655,9 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
           if (base + 256 * k < nx) X[base + 256 * k] = v[k];
       }
       {
-        const int nzc = wi - wd, nz = nzc * ho;                    // zero columns of the row-pass result
-        const float inv_nzc = nzc > 0 ? 1.0f / (float)nzc : 0.0f;
-        for (int i = t; i < nz; i += 256) {
-          const int yy = (int)(((float)i + 0.5f) * inv_nzc), k = i - yy * nzc;
-          Y[yy * yp + (k < xa ? k : k + wd)] = 0.0;
-        }
+        const int nz2 = (yp * hop + 1) >> 1;              // Y := 0, two doubles per store (capacity is even: no overrun)
+        double2* Y2 = reinterpret_cast<double2*>(Y);
+        for (int i = t; i < nz2; i += 256) Y2[i] = make_double2(0.0, 0.0);
       }
       __syncthreads();
       // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns data column xc and FOUR consecutive
@@ -1652,16 +1667,15 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
         const int nrb = hop >> 2;
         const int nv = nrb * wd;
         for (int idx = t; idx < nv; idx += 256) {
-          const int rb = (int)(((float)idx + 0.5f) * inv_wd), xc = idx - rb * wd;
-          const double* c0 = X + (4 * rb + r1) * wd + xc;                     // centre of the first of the four rows
+          const int rb = (int)(((float)idx + 0.5f) * inv_wd), xq = idx - rb * wd;
+          const double* c0 = X + (4 * rb + r1) * wd + xq;                     // centre of the first of the four rows
           double acc0, acc1, acc2, acc3;
           blur4(c0, wd, hw1, r1, acc0, acc1, acc2, acc3);
-          const int yb = 4 * rb;
-          double* o = Y + yb * yp + xa + xc;
-          if (yb < ho) o[0] = acc0;
-          if (yb + 1 < ho) o[yp] = acc1;
-          if (yb + 2 < ho) o[2 * yp] = acc2;
-          if (yb + 3 < ho) o[3 * yp] = acc3;
+          double* o = Y + 4 * rb * yp + xa + xq;                              // Y has hop rows: the slack rows are never read
+          o[0] = acc0;
+          o[yp] = acc1;
+          o[2 * yp] = acc2;
+          o[3 * yp] = acc3;
         }
       }
       __syncthreads();
@@ -1672,20 +1686,23 @@ __global__ __launch_bounds__(256) void k_blur_fused(const FrameDesc* frames, int
         const int nh = ncb * ho;
         const float inv_ho = 1.0f / (float)ho;
         for (int idx = t; idx < nh; idx += 256) {
-          const int cb = (int)(((float)idx + 0.5f) * inv_ho), yy = idx - cb * ho;
-          const double* c0 = Y + yy * yp + 4 * cb + r2;                       // centre of the first of the four columns
+          const int cb = (int)(((float)idx + 0.5f) * inv_ho), yq = idx - cb * ho;
+          const double* c0 = Y + yq * yp + 4 * cb + r2;                       // centre of the first of the four columns
           double acc0, acc1, acc2, acc3;
           if (r2 > 0) {
             blur4(c0, 1, hw2, r2, acc0, acc1, acc2, acc3);
           } else {
             acc0 = c0[0]; acc1 = c0[1]; acc2 = c0[2]; acc3 = c0[3];
           }
-          const int xb = 4 * cb;
-          double* o = dst + (int64_t)(y0 + yy) * p.epitch + p.epad + (x0 + xb);
-          if (xb < wo) o[0] = acc0;
-          if (xb + 1 < wo) o[1] = acc1;
-          if (xb + 2 < wo) o[2] = acc2;
-          if (xb + 3 < wo) o[3] = acc3;
+          const int xo = 4 * cb;
+          double* o = dst + (int64_t)(y0 + yq) * p.epitch + p.epad + (x0 + xo);
+          if (xo + 3 < wo) {
+            o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3;
+          } else {
+            o[0] = acc0;
+            if (xo + 1 < wo) o[1] = acc1;
+            if (xo + 2 < wo) o[2] = acc2;
+          }
         }
       }
       __syncthreads();
@@ -1925,26 +1942,51 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     }
     if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
     __syncthreads();
-    // software-pipelined: the alpha sample of entry e+1 is in flight while entry e is blended.  (Measured and
-    // rejected: records staged through LDS with four samples in flight per lane -- 20 % slower: the records are
-    // wave-uniform and cost nothing as scalar operands, and the kernel is bound by its f64 blend arithmetic.)
-    bool in_n = false;
-    double A_n = 0.0;
+    total = __builtin_amdgcn_readfirstlane(total);              // the same in every lane: says so to the compiler (uniform loops)
+    // Software pipeline over the ordered entries, three stages deep: while entry e is blended, the alpha sample of
+    // entry e+1 is in flight and so is the RECORD of entry e+2.  A record is wave-uniform: it is fetched whole with
+    // scalar loads into SGPRs (fetch), pinned there (the compiler would otherwise sink every field's load into the
+    // branch that uses it -- one scalar-cache round trip per field, serialised by the short-circuit tests), and the
+    // footprint test is branch-free.  (Measured and rejected: records staged through LDS with four samples in
+    // flight per lane -- 20 % slower: the kernel is bound by its f64 blend arithmetic once the latency is hidden.)
+    struct RecS {
+      int x0, y0, x1, y1, ox, oy, pitch;
+      long long off;
+      double tau, g, k0, k1, k2, z;
+    };
+    auto fetch = [&](int idx) {
+      const const_ptr<CompRec> r = as_constant(comp) + __builtin_amdgcn_readfirstlane(idx);
+      RecS o{r->x0, r->y0, r->x1, r->y1, r->ox, r->oy, r->pitch, (long long)r->off, r->tau_one, r->g, r->K[0], r->K[1], r->K[2], r->zdist};
+      return o;
+    };
+    auto inside = [&](const RecS& r) { return live & (px >= r.x0) & (px < r.x1) & (py >= r.y0) & (py < r.y1); };
+    // (every lane loads: one outside the footprint reads the tile's first sample -- the same line for all of them -- so
+    // that the number of loads in flight is known and the wait before a blend covers the OLDER load only)
+    auto sample = [&](const RecS& r, bool in) {
+      const int64_t o = in ? (int64_t)(py + r.oy) * r.pitch + (px + r.ox) : 0;
+      return arena[r.off + o];
+    };
     if (total > 0) {
-      const CompRec& r = comp[__builtin_amdgcn_readfirstlane(s_list[0])];
-      in_n = live && px >= r.x0 && px < r.x1 && py >= r.y0 && py < r.y1;
-      if (in_n) A_n = arena[r.off + (int64_t)(py + r.oy) * r.pitch + (px + r.ox)];
-    }
-    for (int e = 0; e < total; e++) {
-      const CompRec& r = comp[__builtin_amdgcn_readfirstlane(s_list[e])];
-      const bool in_c = in_n;
-      const double A = A_n;
-      if (e + 1 < total) {
-        const CompRec& q = comp[__builtin_amdgcn_readfirstlane(s_list[e + 1])];
-        in_n = live && px >= q.x0 && px < q.x1 && py >= q.y0 && py < q.y1;
-        if (in_n) A_n = arena[q.off + (int64_t)(py + q.oy) * q.pitch + (px + q.ox)];
+      RecS rc = fetch(s_list[0]);
+      RecS rn = fetch(s_list[total > 1 ? 1 : 0]);
+      int i_nn = s_list[total > 2 ? 2 : 0];                      // list index of entry e + 2, read one iteration ahead
+      bool in_c = inside(rc);
+      double A_c = sample(rc, in_c);
+      for (int e = 0; e < total; e++) {
+        // alpha of entry e + 1 (its record arrived an iteration ago; past the end: entry 0 again, never blended)
+        const bool in_n = inside(rn) & (e + 1 < total);
+        const double A_n = sample(rn, in_n);
+        const RecS rnn = fetch(i_nn);                            // record of entry e + 2
+        i_nn = s_list[e + 3 < total ? e + 3 : 0];
+        if (in_c && !(rc.z > scene)) {
+          const double K[3] = {rc.k0, rc.k1, rc.k2};
+          blend_pixel(A_c, rc.tau, cam.exposure_s, rc.g, K, c, m);
+        }
+        rc = rn;
+        rn = rnn;
+        in_c = in_n;
+        A_c = A_n;
       }
-      if (in_c && !(r.zdist > scene)) blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
     }
     __syncthreads();
   }
@@ -2153,6 +2195,7 @@ struct rr_ctx {
   // options (rr_set_option): none of them changes a result bit
   bool dedup = true;                 // RR_OPT_DEDUP: share bit-identical raw tiles inside a batch (k_dedup)
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
+  int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
   int scratch_hp = 0;                // span pitch the scratch was sized for
@@ -2395,6 +2438,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
   const int ntiles = tiles_x * tiles_y;
   Scratch sc = ctx->sc;
+  sc.blur_bx = ctx->blur_wg == 3 ? 3072 : (ctx->blur_wg == 5 ? 2304 : 2816);
+  sc.blur_by = ctx->blur_wg == 5 ? 1600 : 2048;
   // One in-order stream: FOV spans -> plan -> scan -> dedup -> lists -> FOV sums -> colour -> tiles -> blur ->
   // composite -> finalise.
   if (max_drops > 0) {
@@ -2435,26 +2480,26 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     if (fast) {
       ProfScope ps(ctx, s, "k_fov_sums");
-      // a chunk of NT*DPT drops re-scans the band's rows, so DPT grows with the drop count (register budget: 8
-      // doubles of running sums per drop)
-      const size_t row_bytes = ((size_t)(dm.We + 1) * 4 + 16 * 4) * sizeof(double);      // P01 + P23 + wave totals
-      // a wave owns ceil(We / waves) columns, in passes of 64
-      auto passes = [&](int nt) { return ((dm.We + nt / 64 - 1) / (nt / 64) + 63) / 64; };
+      // a chunk of NT*DPT drops re-scans the band's rows, so DPT grows with the drop count (register budget: 4
+      // doubles of running sums + one 16-byte span piece per drop)
+      const size_t row_bytes = ((size_t)(dm.We + 1) * 2 + 16 * 2) * sizeof(double);      // P + wave totals
+      // a wave owns ceil(We / waves) columns (rounded up to even), in passes of 128
+      auto passes = [&](int nt) { return ((((dm.We + nt / 64 - 1) / (nt / 64)) + 1) / 2 * 2 + 127) / 128; };
       int NT = ctx->fov_threads ? ctx->fov_threads : 1024;
       if (passes(NT) > FOV_EMAX) NT = 1024;
-      const bool e2 = passes(NT) <= 2;                   // <= 2 passes: 16 fewer registers, 4 drops per thread fit
-      const int DPT = ctx->fov_dpt ? ctx->fov_dpt : (max_drops <= NT ? 1 : (max_drops <= 2 * NT || !e2 ? 2 : 4));
+      const bool e1 = passes(NT) <= 1;
+      const int DPT = ctx->fov_dpt ? ctx->fov_dpt : (max_drops <= NT ? 1 : (max_drops <= 2 * NT ? 2 : (max_drops <= 4 * NT ? 4 : 8)));
       const int rpb = ((dm.He + COL_PARTS - 1) / COL_PARTS + 3) & ~3;
       const int nchunk = (max_drops + NT * DPT - 1) / (NT * DPT);
-      const dim3 grid(COL_PARTS * nchunk, n);
+      const dim3 grid(COL_PARTS * 2 * nchunk, n);         // x = band + COL_PARTS * (half + 2 * chunk): a band's workgroups share an XCD
       auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(NT), row_bytes, s, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
-      hipError_t e = e2 ? (DPT == 1 ? launch(k_fov_sums<1, 2>) : DPT == 2 ? launch(k_fov_sums<2, 2>) : launch(k_fov_sums<4, 2>))
-                        : (DPT == 1 ? launch(k_fov_sums<1, 4>) : DPT == 2 ? launch(k_fov_sums<2, 4>) : launch(k_fov_sums<4, 4>));
+      hipError_t e = e1 ? (DPT == 1 ? launch(k_fov_sums<1, 1>) : DPT == 2 ? launch(k_fov_sums<2, 1>) : DPT == 4 ? launch(k_fov_sums<4, 1>) : launch(k_fov_sums<8, 1>))
+                        : (DPT == 1 ? launch(k_fov_sums<1, 2>) : DPT == 2 ? launch(k_fov_sums<2, 2>) : DPT == 4 ? launch(k_fov_sums<4, 2>) : launch(k_fov_sums<8, 2>));
       if (e != hipSuccess) {
         ctx->err = std::string("k_fov_sums: ") + hipGetErrorString(e);
         return RR_E_HIP;
@@ -2501,7 +2546,11 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_fused");
-      hipLaunchKernelGGL(k_blur_fused, dim3((max_drops + 1) / 2, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      const size_t lds = sizeof(double) * (size_t)(2 * (BR_MAX + 1) + sc.blur_bx + sc.blur_by);
+      const dim3 grid((max_drops + 1) / 2, n);
+      if (ctx->blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
+      else if (ctx->blur_wg == 5) hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
+      else hipLaunchKernelGGL(k_blur_fused<4>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
@@ -3391,8 +3440,12 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;
       return RR_OK;
+    case RR_OPT_BLUR_WORKGROUPS:
+      if (value != 0 && value != 3 && value != 4 && value != 5) break;
+      ctx->blur_wg = value ? value : 4;
+      return RR_OK;
     case RR_OPT_FOV_DROPS_PER_THREAD:
-      if (value != 0 && value != 1 && value != 2 && value != 4) break;
+      if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) break;
       ctx->fov_dpt = value;
       return RR_OK;
     default: break;

@@ -29,6 +29,8 @@ def test_full_size_matches_hostemu_and_oracle_prefix(setup):
     assert np.array_equal(base['mask'], emu['mask'])                      # bit-exact
     assert np.array_equal(base['mask_i32'], emu['mask_i32'])
     assert np.abs(base['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+    # the float composite: same alpha bits, colour constants from FOV sums added in another order
+    assert np.abs(base['rainy_bg'] - emu['rainy_bg']).max() < 1e-9
     # the first 300 streaks through the numpy oracle (faithful FOV integration)
     n = 300
     out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[:n])])[0]
@@ -96,7 +98,7 @@ def test_raw_tile_dedup_is_invisible(setup):
 
 
 def test_colour_path_options_do_not_change_results(setup):
-    """The FOV-sum kernel's workgroup size / drops per thread and the general colour path (prefix table in HBM, what
+    """The FOV-sum kernel's workgroup size / drops per thread, the LDS tile sizes of the fused blur and the general colour path (prefix table in HBM, what
     maps beyond 1024 rows / 4096 columns take) are tuning switches: the mask must be identical, the image within
     1 LSB (the colour sums are added in a different order), the statuses equal."""
     sc, bg, env, drops, rh, base = setup
@@ -104,6 +106,8 @@ def test_colour_path_options_do_not_change_results(setup):
     for opts in ({h.hb.RR_OPT_FOV_THREADS: 512, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 1},
                  {h.hb.RR_OPT_FOV_THREADS: 512, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 4},
                  {h.hb.RR_OPT_FOV_THREADS: 1024, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 2},
+                 {h.hb.RR_OPT_FOV_THREADS: 1024, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 8},
+                 {h.hb.RR_OPT_BLUR_WORKGROUPS: 3}, {h.hb.RR_OPT_BLUR_WORKGROUPS: 5},
                  {h.hb.RR_OPT_GENERAL_FOV: 1}):
         alt = h.hb.RainHip(0)
         try:
