@@ -215,19 +215,32 @@ struct BlurLayout {
 // along the filter axis with a rotating register window, so rows/columns are padded to
 // multiples of four (zero / don't-care slack); the column-pass tile has an odd pitch so that
 // lanes running down a column hit distinct LDS banks.
-__device__ inline int blur_x_doubles(int wo, int ho, int r1, int r2) { return (wo + 2 * r2) * (((ho + 3) & ~3) + 2 * r1); }
+// X holds only the columns under the raw tile (tw wide): the others stay exactly zero through the row pass.
+__device__ inline int blur_x_doubles(int wo, int ho, int r1, int r2, int tw) { return imin(wo + 2 * r2, tw) * (((ho + 3) & ~3) + 2 * r1); }
 __device__ inline int blur_y_pitch(int wo, int r2) { return (((wo + 3) & ~3) + 2 * r2) | 1; }
 __device__ inline int blur_y_doubles(int wo, int ho, int r2) { return blur_y_pitch(wo, r2) * ((ho + 3) & ~3); }
 
 __device__ inline BlurLayout blur_layout(const DropPlan& p, int BX_MAX, int BY_MAX) {
   BlurLayout b{0, 0, 0, 0};
   if (p.r1 <= 0 || p.r1 > BR_MAX) return b;
-  // Whole tile if it fits; otherwise the output sub-tile that (roughly) maximises wo*ho under
-  // the two LDS capacities -- halo-aware aspect: (wo+2*r2)*(ho+2*r1) <= BX_MAX.
-  if (blur_x_doubles(p.ew, p.eh, p.r1, p.r2) <= BX_MAX && blur_y_doubles(p.ew, p.eh, p.r2) <= BY_MAX) {
+  // Whole tile if it fits ...
+  if (blur_x_doubles(p.ew, p.eh, p.r1, p.r2, p.tw) <= BX_MAX && blur_y_doubles(p.ew, p.eh, p.r2) <= BY_MAX) {
     b.fused = 1; b.wo = p.ew; b.ho = p.eh; b.single = 1;
     return b;
   }
+  // ... else full-width bands of rows (no column is filtered twice by the row pass; only the 2*r1 halo rows are
+  // loaded again per band), as tall as the two capacities allow ...
+  {
+    const int hy = (BY_MAX / blur_y_pitch(p.ew, p.r2)) & ~3;
+    const int hx = ((BX_MAX / imin(p.ew + 2 * p.r2, p.tw)) - 2 * p.r1) & ~3;
+    const int hb = imin(hy, hx);
+    if (hb >= imax(8, p.r1)) {
+      b.fused = 1; b.wo = p.ew; b.ho = imin(hb, p.eh);
+      return b;
+    }
+  }
+  // ... else (wide tiles with large radii) the output sub-tile that roughly maximises wo*ho under the two capacities --
+  // halo-aware aspect: (wo+2*r2)*(ho+2*r1) <= BX_MAX.
   const double rr2 = (double)imax(p.r2, 1), rr1 = (double)p.r1;
   int wi = (int)sqrt((double)BX_MAX * rr2 / rr1);            // ideal haloed width
   wi = imax(imin(wi, p.ew + 2 * p.r2), 2 * p.r2 + 4);
@@ -237,11 +250,11 @@ __device__ inline BlurLayout blur_layout(const DropPlan& p, int BX_MAX, int BY_M
   int wo = wi - 2 * p.r2, ho = (hi - 2 * p.r1) & ~3;         // ho a multiple of four: no slack rows wasted
   if (ho > p.eh) ho = p.eh;
   for (int it = 0; it < 64 && wo >= 1 && ho >= 1; it++) {
-    if (blur_x_doubles(wo, ho, p.r1, p.r2) <= BX_MAX && blur_y_doubles(wo, ho, p.r2) <= BY_MAX) {
+    if (blur_x_doubles(wo, ho, p.r1, p.r2, p.tw) <= BX_MAX && blur_y_doubles(wo, ho, p.r2) <= BY_MAX) {
       b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo >= p.ew && ho >= p.eh) ? 1 : 0;
       return b;
     }
-    if (blur_x_doubles(wo, ho, p.r1, p.r2) > BX_MAX) { if (wo > 4) wo -= 1; else ho -= 4; }
+    if (blur_x_doubles(wo, ho, p.r1, p.r2, p.tw) > BX_MAX) { if (wo > 4) wo -= 1; else ho -= 4; }
     else ho -= 4;
   }
   return b;                                                  // halo alone exceeds the LDS: two-pass fallback
@@ -1879,6 +1892,7 @@ __global__ __launch_bounds__(256) void k_bin(const FrameDesc* frames, Dims dm, i
   if (t == 0) sc.ccount[(int64_t)f * nct + ct] = total;
 }
 
+template <int PIPE>
 __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
                                                    int tiles_y, int ctiles_x, int nct, Scratch sc) {
   const int f = blockIdx.y;
@@ -1892,7 +1906,10 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const FrameDesc& fr = frames[f];
   const int tx0 = txi * TILE, ty0 = tyi * TILE, tx1 = min(tx0 + TILE, dm.W), ty1 = min(ty0 + TILE, dm.H);
-  const int px = tx0 + (t & (TILE - 1)), py = ty0 + (t >> 4);
+  // a wave owns one 8x8 quarter of the 16x16 tile (drops are narrow and tall: a square wave footprint has the most
+  // lanes inside a drop's rectangle) and walks its OWN ordered list: only the drops that reach its quarter
+  static_assert(TILE == 16, "k_composite: four 8x8 quarters");
+  const int px = tx0 + 8 * (wave & 1) + (lane & 7), py = ty0 + 8 * (wave >> 1) + (lane >> 3);
   const bool live = px < dm.W && py < dm.H;
   const int64_t pix = (int64_t)py * dm.W + px;
   double c[3] = {0, 0, 0}, m = 0.0;
@@ -1920,35 +1937,46 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   const int ct = (ty0 / CTILE) * ctiles_x + (tx0 / CTILE);
   const uint16_t* clist = sc.clist + ((int64_t)f * nct + ct) * max_drops;
   const int n = sc.ccount[(int64_t)f * nct + ct];
-  __shared__ int s_list[256];
-  __shared__ int s_cnt[4];
+  __shared__ int s_list[4][256];                                // per quarter: drop indices in compositing order
+  __shared__ int s_cnt[4][4];                                   // [wave][quarter] hits among the wave's 64 candidates
+  const int xm = tx0 + 8, ym = ty0 + 8;
   for (int base = 0; base < n; base += 256) {
     const int k = base + t;
-    bool hit = false;
+    unsigned hitm = 0;                                          // bit q: the drop's footprint reaches quarter q
     int i = 0;
     if (k < n) {
       i = clist[k];
       const int4 bb = bbox[i];
-      hit = bb.x < tx1 && bb.z > tx0 && bb.y < ty1 && bb.w > ty0;
+      if (bb.x < tx1 && bb.z > tx0 && bb.y < ty1 && bb.w > ty0) {
+        const unsigned xl = bb.x < xm, xr = bb.z > xm, yt = bb.y < ym, yb = bb.w > ym;
+        hitm = (xl & yt) | ((xr & yt) << 1) | ((xl & yb) << 2) | ((xr & yb) << 3);
+      }
     }
-    const unsigned long long bal = __ballot(hit);
-    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    unsigned long long bal[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bal[q] = __ballot((hitm >> q) & 1u);
+    if (lane < 4) s_cnt[wave][lane] = __popcll(lane == 0 ? bal[0] : (lane == 1 ? bal[1] : (lane == 2 ? bal[2] : bal[3])));
     __syncthreads();
-    int off = 0, total = 0;
-    for (int w = 0; w < 4; w++) {
-      int cw = s_cnt[w];
-      if (w < wave) off += cw;
-      total += cw;
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int off = 0, tq = 0;
+      for (int w = 0; w < 4; w++) {
+        const int cw = s_cnt[w][q];
+        if (w < wave) off += cw;
+        tq += cw;
+      }
+      if ((hitm >> q) & 1u) s_list[q][off + __popcll(bal[q] & ((1ull << lane) - 1ull))] = i;
+      if (q == wave) total = tq;
     }
-    if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
     __syncthreads();
+    const int* lst = s_list[wave];
     total = __builtin_amdgcn_readfirstlane(total);              // the same in every lane: says so to the compiler (uniform loops)
     // Software pipeline over the ordered entries, three stages deep: while entry e is blended, the alpha sample of
     // entry e+1 is in flight and so is the RECORD of entry e+2.  A record is wave-uniform: it is fetched whole with
-    // scalar loads into SGPRs (fetch), pinned there (the compiler would otherwise sink every field's load into the
-    // branch that uses it -- one scalar-cache round trip per field, serialised by the short-circuit tests), and the
-    // footprint test is branch-free.  (Measured and rejected: records staged through LDS with four samples in
-    // flight per lane -- 20 % slower: the kernel is bound by its f64 blend arithmetic once the latency is hidden.)
+    // wide scalar loads into SGPRs (fetch; the constant address space keeps them on the scalar unit) one iteration
+    // before its first use, and the footprint test is branch-free.  (Measured and rejected: records staged through
+    // LDS with four samples in flight per lane -- 20 % slower.)
     struct RecS {
       int x0, y0, x1, y1, ox, oy, pitch;
       long long off;
@@ -1966,10 +1994,29 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
       const int64_t o = in ? (int64_t)(py + r.oy) * r.pitch + (px + r.ox) : 0;
       return arena[r.off + o];
     };
-    if (total > 0) {
-      RecS rc = fetch(s_list[0]);
-      RecS rn = fetch(s_list[total > 1 ? 1 : 0]);
-      int i_nn = s_list[total > 2 ? 2 : 0];                      // list index of entry e + 2, read one iteration ahead
+    if (PIPE == 0) {                                             // A/B variant: field-by-field short-circuit tests, one entry ahead
+      bool in_n = false;
+      double A_n = 0.0;
+      if (total > 0) {
+        const CompRec& r = comp[__builtin_amdgcn_readfirstlane(lst[0])];
+        in_n = live && px >= r.x0 && px < r.x1 && py >= r.y0 && py < r.y1;
+        if (in_n) A_n = arena[r.off + (int64_t)(py + r.oy) * r.pitch + (px + r.ox)];
+      }
+      for (int e = 0; e < total; e++) {
+        const CompRec& r = comp[__builtin_amdgcn_readfirstlane(lst[e])];
+        const bool in_c = in_n;
+        const double A = A_n;
+        if (e + 1 < total) {
+          const CompRec& q = comp[__builtin_amdgcn_readfirstlane(lst[e + 1])];
+          in_n = live && px >= q.x0 && px < q.x1 && py >= q.y0 && py < q.y1;
+          if (in_n) A_n = arena[q.off + (int64_t)(py + q.oy) * q.pitch + (px + q.ox)];
+        }
+        if (in_c && !(r.zdist > scene)) blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
+      }
+    } else if (total > 0) {
+      RecS rc = fetch(lst[0]);
+      RecS rn = fetch(lst[total > 1 ? 1 : 0]);
+      int i_nn = lst[total > 2 ? 2 : 0];                      // list index of entry e + 2, read one iteration ahead
       bool in_c = inside(rc);
       double A_c = sample(rc, in_c);
       for (int e = 0; e < total; e++) {
@@ -1977,7 +2024,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
         const bool in_n = inside(rn) & (e + 1 < total);
         const double A_n = sample(rn, in_n);
         const RecS rnn = fetch(i_nn);                            // record of entry e + 2
-        i_nn = s_list[e + 3 < total ? e + 3 : 0];
+        i_nn = lst[e + 3 < total ? e + 3 : 0];
         if (in_c && !(rc.z > scene)) {
           const double K[3] = {rc.k0, rc.k1, rc.k2};
           blend_pixel(A_c, rc.tau, cam.exposure_s, rc.g, K, c, m);
@@ -2195,6 +2242,7 @@ struct rr_ctx {
   // options (rr_set_option): none of them changes a result bit
   bool dedup = true;                 // RR_OPT_DEDUP: share bit-identical raw tiles inside a batch (k_dedup)
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
+  int comp_loop = 0;                 // (A/B, option 7) 1: compositor with the short-circuit entry loop
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
@@ -2568,7 +2616,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   {
     ProfScope ps(ctx, s, "k_composite");
-    hipLaunchKernelGGL(k_composite, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
+    hipLaunchKernelGGL(ctx->comp_loop ? k_composite<0> : k_composite<1>, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
                        sc);
   }
   {
@@ -3440,6 +3488,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;
       return RR_OK;
+    case 7: ctx->comp_loop = value != 0; return RR_OK;
     case RR_OPT_BLUR_WORKGROUPS:
       if (value != 0 && value != 3 && value != 4 && value != 5) break;
       ctx->blur_wg = value ? value : 4;
