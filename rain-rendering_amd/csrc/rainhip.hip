@@ -1892,7 +1892,6 @@ __global__ __launch_bounds__(256) void k_bin(const FrameDesc* frames, Dims dm, i
   if (t == 0) sc.ccount[(int64_t)f * nct + ct] = total;
 }
 
-template <int PIPE>
 __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
                                                    int tiles_y, int ctiles_x, int nct, Scratch sc) {
   const int f = blockIdx.y;
@@ -1994,26 +1993,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
       const int64_t o = in ? (int64_t)(py + r.oy) * r.pitch + (px + r.ox) : 0;
       return arena[r.off + o];
     };
-    if (PIPE == 0) {                                             // A/B variant: field-by-field short-circuit tests, one entry ahead
-      bool in_n = false;
-      double A_n = 0.0;
-      if (total > 0) {
-        const CompRec& r = comp[__builtin_amdgcn_readfirstlane(lst[0])];
-        in_n = live && px >= r.x0 && px < r.x1 && py >= r.y0 && py < r.y1;
-        if (in_n) A_n = arena[r.off + (int64_t)(py + r.oy) * r.pitch + (px + r.ox)];
-      }
-      for (int e = 0; e < total; e++) {
-        const CompRec& r = comp[__builtin_amdgcn_readfirstlane(lst[e])];
-        const bool in_c = in_n;
-        const double A = A_n;
-        if (e + 1 < total) {
-          const CompRec& q = comp[__builtin_amdgcn_readfirstlane(lst[e + 1])];
-          in_n = live && px >= q.x0 && px < q.x1 && py >= q.y0 && py < q.y1;
-          if (in_n) A_n = arena[q.off + (int64_t)(py + q.oy) * q.pitch + (px + q.ox)];
-        }
-        if (in_c && !(r.zdist > scene)) blend_pixel(A, r.tau_one, cam.exposure_s, r.g, r.K, c, m);
-      }
-    } else if (total > 0) {
+    if (total > 0) {
       RecS rc = fetch(lst[0]);
       RecS rn = fetch(lst[total > 1 ? 1 : 0]);
       int i_nn = lst[total > 2 ? 2 : 0];                      // list index of entry e + 2, read one iteration ahead
@@ -2242,7 +2222,6 @@ struct rr_ctx {
   // options (rr_set_option): none of them changes a result bit
   bool dedup = true;                 // RR_OPT_DEDUP: share bit-identical raw tiles inside a batch (k_dedup)
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
-  int comp_loop = 0;                 // (A/B, option 7) 1: compositor with the short-circuit entry loop
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
@@ -2616,7 +2595,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   {
     ProfScope ps(ctx, s, "k_composite");
-    hipLaunchKernelGGL(ctx->comp_loop ? k_composite<0> : k_composite<1>, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
+    hipLaunchKernelGGL(k_composite, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
                        sc);
   }
   {
@@ -3488,7 +3467,6 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;
       return RR_OK;
-    case 7: ctx->comp_loop = value != 0; return RR_OK;
     case RR_OPT_BLUR_WORKGROUPS:
       if (value != 0 && value != 3 && value != 4 && value != 5) break;
       ctx->blur_wg = value ? value : 4;
