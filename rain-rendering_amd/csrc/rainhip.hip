@@ -1189,6 +1189,34 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
 // all Big tiles of the frame (k_lists' pixel prefix).  A Big tile has ~400 pixels, so a workgroup per
 // drop was all per-item latency; flattened, every lane has a pixel and the grid is full.  Texels come
 // from global memory (the streak DB is L2 resident), the v/255 table and the cubic table from LDS.
+// Texels in global memory, quotient table in LDS.  The bicubic kernel reads four horizontal neighbours per texture row:
+// as byte loads that is 16 scattered one-byte gathers per output pixel and the kernel is bound by the texture-address
+// unit; the two aligned dwords around them and v_alignbyte deliver the same four bytes with two loads.
+constexpr size_t TEX_PAD = 8;
+struct TexLutWide {
+  const uint8_t* t;
+  const double* lut;
+  int h, w;
+  __device__ double at(int64_t y, int64_t x) const { return lut[t[y * w + x]]; }
+  __device__ double tap(int64_t y, int64_t x) const {
+    if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
+    return at(y, x);
+  }
+  __device__ void at4(int64_t y, int64_t x, double v[4]) const {
+    const uint8_t* a = t + y * w + x;
+    const uintptr_t ai = reinterpret_cast<uintptr_t>(a);
+    const uint8_t* al = reinterpret_cast<const uint8_t*>(ai & ~(uintptr_t)3);
+    // (the window may reach 4 bytes past the texture: the library's copy of the database ends with TEX_PAD spare bytes)
+    const global_ptr<const uint32_t> q = as_global(reinterpret_cast<const uint32_t*>(al));
+    const uint32_t lo = q[0], hi = q[1];
+    const uint32_t four = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(ai & 3));
+    v[0] = lut[four & 255u];
+    v[1] = lut[(four >> 8) & 255u];
+    v[2] = lut[(four >> 16) & 255u];
+    v[3] = lut[four >> 24];
+  }
+};
+
 __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                                   const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
                                                   const float* ctab, Scratch sc) {
@@ -1220,7 +1248,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
     const DropPlan& p = sc.plan[gi];
     const int local = pix - boff[j];
     const int y = local / p.tw, x = local - y * p.tw;
-    TexLut tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
+    TexLutWide tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
     sc.arena[p.a0_off + local] = warp_big_pixel(p, tx, s_ctab, x, y);
   }
 }
@@ -1538,24 +1566,39 @@ __device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
 }
 
 
-// Normalised Gaussian half tables of every blurred drop, one thread per (drop, axis): hw[k] = w(|k - r|),
-// k = 0..r, with the oracle's left-to-right normalisation sum.  The blur kernels used to build them per
-// work item (two waves busy, the rest of the workgroup waiting); a table is 8*(r+1) bytes to load.
+// Normalised Gaussian half tables of every blurred drop: hw[k] = w(|k - r|), k = 0..r, with the oracle's left-to-right
+// normalisation sum.  16 lanes per (drop, axis): the r + 1 exponentials (the expensive part: exp from + - * / only) are
+// spread over the lanes, one lane adds them up in the oracle's order (x = -r..r), every lane divides its own entries.
+// A table is 8*(r+1) bytes for the blur kernels to load.
 __global__ __launch_bounds__(256) void k_blur_weights(const FrameDesc* frames, int max_drops, Scratch sc) {
-  const int f = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double s_hw[16][BR_MAX + 2];
+  const int f = blockIdx.y, grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int idx = blockIdx.x * 16 + grp;
   const int i = idx >> 1, axis = idx & 1;
-  if (i >= frames[f].n_drops) return;
-  const int64_t gi = (int64_t)f * max_drops + i;
-  const DropPlan& p = sc.plan[gi];
-  if (p.status != RR_DROP_OK || sc.sizes[gi] == 0 || p.r1 <= 0 || p.r1 > BR_MAX) return;
-  const int r = axis ? p.r2 : p.r1;
-  if (r <= 0) return;
-  const double sigma = axis ? p.sig2 : p.sig1;
-  double* hw = sc.wtab + (gi * 2 + axis) * (BR_MAX + 1);
-  for (int l = 0; l <= r; l++) hw[r - l] = gauss_phi(sigma, l);        // hw[k] = phi(|k - r|)
-  double tot = 0.0;
-  for (int x = -r; x <= r; x++) tot = tot + hw[r - (x < 0 ? -x : x)];
-  for (int k = 0; k <= r; k++) hw[k] = hw[k] / tot;
+  int r = 0;
+  double sigma = 0.0;
+  const int64_t gi = (int64_t)f * max_drops + (i < frames[f].n_drops ? i : 0);
+  if (i < frames[f].n_drops) {
+    const DropPlan& p = sc.plan[gi];
+    if (p.status == RR_DROP_OK && sc.sizes[gi] != 0 && p.r1 > 0 && p.r1 <= BR_MAX) {
+      r = axis ? p.r2 : p.r1;
+      sigma = axis ? p.sig2 : p.sig1;
+    }
+  }
+  double* tab = s_hw[grp];
+  for (int k = l; k <= r && r > 0; k += 16) tab[k] = gauss_phi(sigma, r - k);       // hw[k] = phi(|k - r|)
+  wave_lds_sync();                                       // (a group never spans two waves)
+  if (l == 0 && r > 0) {
+    double tot = 0.0;
+    for (int x = -r; x <= r; x++) tot = tot + tab[r - (x < 0 ? -x : x)];
+    tab[BR_MAX + 1] = tot;
+  }
+  wave_lds_sync();
+  if (r > 0) {
+    const double tot = tab[BR_MAX + 1];
+    double* hw = sc.wtab + (gi * 2 + axis) * (BR_MAX + 1);
+    for (int k = l; k <= r; k += 16) hw[k] = tab[k] / tot;
+  }
 }
 
 // Four consecutive outputs (stride `st` doubles apart) of the symmetric correlate1d of radius r:
@@ -2565,7 +2608,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_weights");
-      hipLaunchKernelGGL(k_blur_weights, dim3((2 * max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur_weights, dim3((2 * max_drops + 15) / 16, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_small");
@@ -2903,8 +2946,9 @@ int rr_set_streak_db(rr_ctx* ctx, const uint8_t* texels, const int32_t* tex_h, c
   }
   if (ctx->own_tex && ctx->d_tex) hipFree(ctx->d_tex);
   ctx->d_tex = nullptr;
-  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)total));
+  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)total + TEX_PAD));
   ctx->own_tex = true;
+  HIPCHK(hipMemset(ctx->d_tex + total, 0, TEX_PAD));
   HIPCHK(hipMemcpy(ctx->d_tex, texels, (size_t)total, hipMemcpyHostToDevice));
   return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
 }
@@ -2927,8 +2971,9 @@ int rr_set_streak_db_device(rr_ctx* ctx, const uint8_t* texels_dev, int64_t n_by
   if (ctx->own_tex && ctx->d_tex) hipFree(ctx->d_tex);
   ctx->d_tex = nullptr;
   // private copy: the caller's (broadcast) buffer may be released afterwards
-  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)n_bytes));
+  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)n_bytes + TEX_PAD));
   ctx->own_tex = true;
+  HIPCHK(hipMemset(ctx->d_tex + n_bytes, 0, TEX_PAD));
   HIPCHK(hipMemcpy(ctx->d_tex, texels_dev, (size_t)n_bytes, hipMemcpyDeviceToDevice));
   return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
 }

@@ -163,6 +163,7 @@ struct TexGlobal {
   const uint8_t* t;
   int h, w;
   RR_HD double at(int64_t y, int64_t x) const { return (double)t[y * w + x] / 255.0; }
+  RR_HD void at4(int64_t y, int64_t x, double v[4]) const { v[0] = at(y, x); v[1] = at(y, x + 1); v[2] = at(y, x + 2); v[3] = at(y, x + 3); }
   RR_HD double tap(int64_t y, int64_t x) const {
     if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
     return at(y, x);
@@ -173,6 +174,7 @@ struct TexLut {
   const double* lut;
   int h, w;
   RR_HD double at(int64_t y, int64_t x) const { return lut[t[y * w + x]]; }
+  RR_HD void at4(int64_t y, int64_t x, double v[4]) const { v[0] = at(y, x); v[1] = at(y, x + 1); v[2] = at(y, x + 2); v[3] = at(y, x + 3); }
   RR_HD double tap(int64_t y, int64_t x) const {
     if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
     return at(y, x);
@@ -186,6 +188,7 @@ struct TexLutPad {
   const double* lut;
   int h, w;
   RR_HD double at(int64_t y, int64_t x) const { return lut[t[(y + 2) * (w + 4) + (x + 2)]]; }
+  RR_HD void at4(int64_t y, int64_t x, double v[4]) const { v[0] = at(y, x); v[1] = at(y, x + 1); v[2] = at(y, x + 2); v[3] = at(y, x + 3); }
   RR_HD double tap(int64_t y, int64_t x) const {
     if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
     return at(y, x);
@@ -220,8 +223,10 @@ RR_HD double warp_big_pixel(const DropPlan& p, const Tex& tx, const float* ctab,
   if (interior) {
     for (int i = 0; i < 4; i++) {
       float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
-      double r = (tx.at(sy + i, sx) * (double)w0 + tx.at(sy + i, sx + 1) * (double)w1) + tx.at(sy + i, sx + 2) * (double)w2;
-      r = r + tx.at(sy + i, sx + 3) * (double)w3;
+      double v[4];
+      tx.at4(sy + i, sx, v);                                   // four neighbours of one texture row
+      double r = (v[0] * (double)w0 + v[1] * (double)w1) + v[2] * (double)w2;
+      r = r + v[3] * (double)w3;
       sum = (i == 0) ? r : sum + r;
     }
   } else {
