@@ -263,8 +263,9 @@ __device__ inline BlurLayout blur_layout(const DropPlan& p, int BX_MAX, int BY_M
 constexpr int BS_X = 512;           // doubles per wave: data columns of the haloed input tile (tw x (eh + 2 r1))
 constexpr int BS_Y = 768;           // doubles per wave: after the row pass (halo columns kept)
 
-__device__ inline bool blur_is_small(const DropPlan& p) {
-  return p.r1 > 0 && p.r1 <= 31 && p.tw * (p.eh + 2 * p.r1) <= BS_X && (p.ew + 2 * p.r2) * p.eh <= BS_Y;
+__device__ inline bool blur_is_small(const DropPlan& p) {      // (rows padded to the four-output blocks of blur4)
+  const int php = (p.eh + 3) & ~3;
+  return p.r1 > 0 && p.r1 <= 31 && p.tw * (php + 2 * p.r1) <= BS_X && blur_y_pitch(p.ew, p.r2) * php <= BS_Y;
 }
 
 // blurred drops neither k_blur_small nor k_blur_fused can take (radius > BR_MAX): two global passes
@@ -1606,15 +1607,16 @@ __global__ __launch_bounds__(256) void k_blur_weights(const FrameDesc* frames, i
 // As the tap distance shrinks the upper/lower operand windows of the four outputs slide by one
 // element, so each tap needs two new LDS values instead of eight; the loop is unrolled by four so
 // that the sliding is pure register renaming (no moves).  c0 = centre of output 0.
-__device__ inline void blur4(const double* c0, int st, const double* hw, int r, double& acc0, double& acc1, double& acc2,
-                             double& acc3) {
-  const double wc = hw[r];
+// hw(k) = w(|k - r|), k = 0..r: an LDS table (fused kernel) or the lanes of a register (wave-per-drop kernel).
+template <class W>
+__device__ inline void blur4(const double* c0, int st, W hw, int r, double& acc0, double& acc1, double& acc2, double& acc3) {
+  const double wc = hw(r);
   acc0 = c0[0] * wc; acc1 = c0[st] * wc; acc2 = c0[2 * st] * wc; acc3 = c0[3 * st] * wc;
   double a0 = c0[(-r) * st], a1 = c0[(1 - r) * st], a2 = c0[(2 - r) * st], a3 = c0[(3 - r) * st];
   double b0 = c0[r * st], b1 = c0[(1 + r) * st], b2 = c0[(2 + r) * st], b3 = c0[(3 + r) * st];
   int ii = -r;
   for (; ii + 3 < 0; ii += 4) {
-    const double w0 = hw[ii + r], w1 = hw[ii + 1 + r], w2 = hw[ii + 2 + r], w3 = hw[ii + 3 + r];
+    const double w0 = hw(ii + r), w1 = hw(ii + 1 + r), w2 = hw(ii + 2 + r), w3 = hw(ii + 3 + r);
     const double na0 = c0[(4 + ii) * st], na1 = c0[(5 + ii) * st], na2 = c0[(6 + ii) * st], na3 = c0[(7 + ii) * st];
     const double nb0 = c0[(-ii - 1) * st], nb1 = c0[(-ii - 2) * st], nb2 = c0[(-ii - 3) * st], nb3 = c0[(-ii - 4) * st];
     acc0 = acc0 + (a0 + b0) * w0; acc1 = acc1 + (a1 + b1) * w0; acc2 = acc2 + (a2 + b2) * w0; acc3 = acc3 + (a3 + b3) * w0;
@@ -1625,7 +1627,7 @@ __device__ inline void blur4(const double* c0, int st, const double* hw, int r, 
     b3 = nb0; b2 = nb1; b1 = nb2; b0 = nb3;
   }
   for (; ii < 0; ii++) {
-    const double w = hw[ii + r];
+    const double w = hw(ii + r);
     const double na = c0[(4 + ii) * st];                               // next upper element of output 3
     const double nb = c0[(-ii - 1) * st];                              // next lower element of output 0
     acc0 = acc0 + (a0 + b0) * w;
@@ -1726,7 +1728,7 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
           const int rb = (int)(((float)idx + 0.5f) * inv_wd), xq = idx - rb * wd;
           const double* c0 = X + (4 * rb + r1) * wd + xq;                     // centre of the first of the four rows
           double acc0, acc1, acc2, acc3;
-          blur4(c0, wd, hw1, r1, acc0, acc1, acc2, acc3);
+          blur4(c0, wd, [&](int k) { return hw1[k]; }, r1, acc0, acc1, acc2, acc3);
           double* o = Y + 4 * rb * yp + xa + xq;                              // Y has hop rows: the slack rows are never read
           o[0] = acc0;
           o[yp] = acc1;
@@ -1746,7 +1748,7 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
           const double* c0 = Y + yq * yp + 4 * cb + r2;                       // centre of the first of the four columns
           double acc0, acc1, acc2, acc3;
           if (r2 > 0) {
-            blur4(c0, 1, hw2, r2, acc0, acc1, acc2, acc3);
+            blur4(c0, 1, [&](int k) { return hw2[k]; }, r2, acc0, acc1, acc2, acc3);
           } else {
             acc0 = c0[0]; acc1 = c0[1]; acc2 = c0[2]; acc3 = c0[3];
           }
@@ -1767,12 +1769,13 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
   }
 }
 
-// Small blurred tiles (haloed tile <= BS_X doubles, which is most of them): one WAVE per drop,
-// wave-private LDS, no block barrier; the filter weights stay in registers and are handed to
-// the fold loop with v_readlane.
+// Small blurred tiles (most of them): one WAVE per drop, wave-private LDS, no block barrier.  Same scheme as the fused
+// kernel -- data columns of the haloed tile in X, row pass into Y (odd pitch), column pass to global memory, four
+// outputs per lane with the rotating register window of blur4 -- with the filter weights in registers: lane l holds
+// w(distance l) of each axis and the fold loop takes them with v_readlane.
 __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int max_drops, Scratch sc) {
   const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ double Xs[4][BS_X], Ys[4][BS_Y];
+  __shared__ __attribute__((aligned(16))) double Xs[4][BS_X], Ys[4][BS_Y];
   double* X = Xs[wave];
   double* Y = Ys[wave];
   const int n_items = sc.counts[f * 8 + 4];
@@ -1780,7 +1783,7 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
   for (int it = blockIdx.x * 4 + wave; it < n_items; it += gridDim.x * 4) {
     const DropPlan& p = sc.plan[(int64_t)f * max_drops + list[it]];
     const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;          // effective tile
-    const int wi = pw + 2 * r2, hi = ph + 2 * r1;
+    const int php = (ph + 3) & ~3, hi = php + 2 * r1, yp = blur_y_pitch(pw, r2);
     const double* raw = sc.arena + p.a0_off;        // raw tile (tw x th); the pad is implicit zeros
     double* tile = sc.arena + p.a1_off;             // finished effective tile
     const int tw = p.tw, th = p.th;
@@ -1788,75 +1791,74 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
     const double* wt = sc.wtab + ((int64_t)f * max_drops + list[it]) * 2 * (BR_MAX + 1);
     const double w1 = (lane <= r1) ? wt[r1 - lane] : 0.0;
     const double w2 = (r2 > 0 && lane <= r2) ? wt[(BR_MAX + 1) + r2 - lane] : 0.0;
-    // Only the tw columns under the raw tile carry data through the row pass (axis 0 filters along y: a
-    // column without raw pixels stays exactly zero), so X holds tw columns x hi rows and the row pass
-    // runs over tw*ph outputs; the other 4*r2 columns of Y are written as zeros for the column pass.
-    const float inv_tw = 1.0f / (float)tw, inv_pw = 1.0f / (float)pw;
+    // Only the tw columns under the raw tile carry data through the row pass (axis 0 filters along y: a column
+    // without raw pixels stays exactly zero): X holds tw columns x hi rows (row yy = raw row yy - 2*r1), Y is cleared
+    // as a whole and the row pass writes its tw columns at column offset 2*r2.
+    const float inv_tw = 1.0f / (float)tw;
     const int nx = tw * hi;
-    for (int base = lane; base < nx; base += 256) {       // data columns of the haloed tile -> LDS, 4 loads in flight
-      double v[4];
+    {
+      const int dq = (int)((64.0f + 0.5f) * inv_tw), dr = 64 - dq * tw;
+      int yy = (int)(((float)lane + 0.5f) * inv_tw), xc = lane - yy * tw;
+      for (int base = lane; base < nx; base += 256) {     // 4 loads in flight; (row, column) advanced incrementally
+        double v[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int idx = base + 64 * k;
-        const int yy = (int)(((float)idx + 0.5f) * inv_tw), x = idx - yy * tw;
-        const int y = yy - 2 * r1;                                // raw-tile row (raw sits at (r2, r1) in the effective tile)
-        v[k] = (idx < nx && y >= 0 && y < th) ? raw[y * tw + x] : 0.0;
+        for (int k = 0; k < 4; k++) {
+          const int y = yy - 2 * r1;
+          v[k] = (base + 64 * k < nx && (unsigned)y < (unsigned)th) ? raw[y * tw + xc] : 0.0;
+          xc += dr;
+          yy += dq;
+          if (xc >= tw) { xc -= tw; yy += 1; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (base + 64 * k < nx) X[base + 64 * k] = v[k];
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (base + 64 * k < nx) X[base + 64 * k] = v[k];
     }
     {
-      const int nzc = 4 * r2, nz = nzc * ph;                      // zero columns of Y: [0, 2*r2) and [2*r2 + tw, wi)
-      const float inv_nzc = nzc > 0 ? 1.0f / (float)nzc : 0.0f;
-      for (int i = lane; i < nz; i += 64) {
-        const int yy = (int)(((float)i + 0.5f) * inv_nzc), k = i - yy * nzc;
-        Y[yy * wi + (k < 2 * r2 ? k : k + tw)] = 0.0;
+      const int nz2 = (yp * php + 1) >> 1;                // (yp * php is even and <= BS_Y)
+      double2* Y2 = reinterpret_cast<double2*>(Y);
+      for (int i = lane; i < nz2; i += 64) Y2[i] = make_double2(0.0, 0.0);
+    }
+    wave_lds_sync();
+    // axis 0 (rows): a lane owns data column x and four consecutive rows
+    {
+      const int nv = (php >> 2) * tw;
+      for (int idx = lane; idx < nv; idx += 64) {
+        const int rb = (int)(((float)idx + 0.5f) * inv_tw), x = idx - rb * tw;
+        const double* c0 = X + (4 * rb + r1) * tw + x;
+        double a0, a1, a2, a3;
+        blur4(c0, tw, [&](int k) { return readlane_f64(w1, r1 - k); }, r1, a0, a1, a2, a3);
+        double* o = Y + 4 * rb * yp + 2 * r2 + x;                 // Y has php rows: the slack rows are never read
+        o[0] = a0;
+        o[yp] = a1;
+        o[2 * yp] = a2;
+        o[3 * yp] = a3;
       }
     }
     wave_lds_sync();
-    // axis 0 (rows) for the data columns
-    const int nv = tw * ph;
-    for (int base = lane; base < nv; base += 128) {
-      const int i0 = base, i1 = imin(base + 64, nv - 1);
-      const double* c0 = X + i0 + r1 * tw;
-      const double* c1 = X + i1 + r1 * tw;
-      double a0 = c0[0] * readlane_f64(w1, 0), a1 = c1[0] * readlane_f64(w1, 0);
-      for (int ii = -r1; ii < 0; ii++) {
-        const double w = readlane_f64(w1, -ii);
-        const int o = ii * tw;
-        a0 = a0 + (c0[o] + c0[-o]) * w;
-        a1 = a1 + (c1[o] + c1[-o]) * w;
-      }
-      const int ya = (int)(((float)i0 + 0.5f) * inv_tw), yb = (int)(((float)i1 + 0.5f) * inv_tw);
-      Y[ya * wi + 2 * r2 + (i0 - ya * tw)] = a0;
-      if (base + 64 < nv) Y[yb * wi + 2 * r2 + (i1 - yb * tw)] = a1;
-    }
-    wave_lds_sync();
-    // axis 1 (columns) -> global, in place
-    const int nh = pw * ph;
-    for (int base = lane; base < nh; base += 128) {
-      const int i0 = base, i1 = imin(base + 64, nh - 1);
-      const int y0 = (int)(((float)i0 + 0.5f) * inv_pw), x0 = i0 - y0 * pw;
-      const int y1 = (int)(((float)i1 + 0.5f) * inv_pw), x1 = i1 - y1 * pw;
-      const double* q0 = Y + y0 * wi + x0 + r2;
-      const double* q1 = Y + y1 * wi + x1 + r2;
-      double a0, a1;
-      if (r2 > 0) {
-        const double wc = readlane_f64(w2, 0);
-        a0 = q0[0] * wc;
-        a1 = q1[0] * wc;
-        for (int ii = -r2; ii < 0; ii++) {
-          const double w = readlane_f64(w2, -ii);
-          a0 = a0 + (q0[ii] + q0[-ii]) * w;
-          a1 = a1 + (q1[ii] + q1[-ii]) * w;
+    // axis 1 (columns) -> global: a lane owns row y and four consecutive columns; lanes run down the rows
+    {
+      const int ncb = (pw + 3) >> 2, nh = ncb * ph;
+      const float inv_ph = 1.0f / (float)ph;
+      for (int idx = lane; idx < nh; idx += 64) {
+        const int cb = (int)(((float)idx + 0.5f) * inv_ph), yq = idx - cb * ph;
+        const double* c0 = Y + yq * yp + 4 * cb + r2;
+        double a0, a1, a2, a3;
+        if (r2 > 0) {
+          blur4(c0, 1, [&](int k) { return readlane_f64(w2, r2 - k); }, r2, a0, a1, a2, a3);
+        } else {
+          a0 = c0[0]; a1 = c0[1]; a2 = c0[2]; a3 = c0[3];
         }
-      } else {
-        a0 = q0[0];
-        a1 = q1[0];
+        const int xo = 4 * cb;
+        double* o = tile + (int64_t)yq * p.epitch + p.epad + xo;
+        if (xo + 3 < pw) {
+          o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+        } else {
+          o[0] = a0;
+          if (xo + 1 < pw) o[1] = a1;
+          if (xo + 2 < pw) o[2] = a2;
+        }
       }
-      tile[y0 * p.epitch + p.epad + x0] = a0;
-      if (base + 64 < nh) tile[y1 * p.epitch + p.epad + x1] = a1;
     }
     wave_lds_sync();
   }
