@@ -1190,34 +1190,6 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
 // all Big tiles of the frame (k_lists' pixel prefix).  A Big tile has ~400 pixels, so a workgroup per
 // drop was all per-item latency; flattened, every lane has a pixel and the grid is full.  Texels come
 // from global memory (the streak DB is L2 resident), the v/255 table and the cubic table from LDS.
-// Texels in global memory, quotient table in LDS.  The bicubic kernel reads four horizontal neighbours per texture row:
-// as byte loads that is 16 scattered one-byte gathers per output pixel and the kernel is bound by the texture-address
-// unit; the two aligned dwords around them and v_alignbyte deliver the same four bytes with two loads.
-constexpr size_t TEX_PAD = 8;
-struct TexLutWide {
-  const uint8_t* t;
-  const double* lut;
-  int h, w;
-  __device__ double at(int64_t y, int64_t x) const { return lut[t[y * w + x]]; }
-  __device__ double tap(int64_t y, int64_t x) const {
-    if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
-    return at(y, x);
-  }
-  __device__ void at4(int64_t y, int64_t x, double v[4]) const {
-    const uint8_t* a = t + y * w + x;
-    const uintptr_t ai = reinterpret_cast<uintptr_t>(a);
-    const uint8_t* al = reinterpret_cast<const uint8_t*>(ai & ~(uintptr_t)3);
-    // (the window may reach 4 bytes past the texture: the library's copy of the database ends with TEX_PAD spare bytes)
-    const global_ptr<const uint32_t> q = as_global(reinterpret_cast<const uint32_t*>(al));
-    const uint32_t lo = q[0], hi = q[1];
-    const uint32_t four = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(ai & 3));
-    v[0] = lut[four & 255u];
-    v[1] = lut[(four >> 8) & 255u];
-    v[2] = lut[(four >> 16) & 255u];
-    v[3] = lut[four >> 24];
-  }
-};
-
 __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                                   const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
                                                   const float* ctab, Scratch sc) {
@@ -1249,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
     const DropPlan& p = sc.plan[gi];
     const int local = pix - boff[j];
     const int y = local / p.tw, x = local - y * p.tw;
-    TexLutWide tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
+    TexLut tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
     sc.arena[p.a0_off + local] = warp_big_pixel(p, tx, s_ctab, x, y);
   }
 }
@@ -2948,9 +2920,8 @@ int rr_set_streak_db(rr_ctx* ctx, const uint8_t* texels, const int32_t* tex_h, c
   }
   if (ctx->own_tex && ctx->d_tex) hipFree(ctx->d_tex);
   ctx->d_tex = nullptr;
-  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)total + TEX_PAD));
+  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)total));
   ctx->own_tex = true;
-  HIPCHK(hipMemset(ctx->d_tex + total, 0, TEX_PAD));
   HIPCHK(hipMemcpy(ctx->d_tex, texels, (size_t)total, hipMemcpyHostToDevice));
   return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
 }
@@ -2973,9 +2944,8 @@ int rr_set_streak_db_device(rr_ctx* ctx, const uint8_t* texels_dev, int64_t n_by
   if (ctx->own_tex && ctx->d_tex) hipFree(ctx->d_tex);
   ctx->d_tex = nullptr;
   // private copy: the caller's (broadcast) buffer may be released afterwards
-  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)n_bytes + TEX_PAD));
+  HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)n_bytes));
   ctx->own_tex = true;
-  HIPCHK(hipMemset(ctx->d_tex + n_bytes, 0, TEX_PAD));
   HIPCHK(hipMemcpy(ctx->d_tex, texels_dev, (size_t)n_bytes, hipMemcpyDeviceToDevice));
   return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
 }
