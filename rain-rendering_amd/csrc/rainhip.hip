@@ -465,7 +465,7 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
 //      wrap test of the reference (bad_weather.py:669-695) is a ballot inside the 20-lane group, the four border
 //      vertices of a wrapping polygon are inserted by the lane in front of the gap.  The polygon goes to
 //      wave-private LDS, never to global memory.
-//   2. per drop, edges in a uniform loop, lanes along the rows an edge covers: the x of edge e at row y is
+//   2. per drop, edges two at a time (one per half wave), lanes along the rows an edge covers: the x of edge e at row y is
 //      xa + floor((2*dx*(y-ya) + den) / (2*den)) (fov_rowspan), evaluated with a float reciprocal and an exact
 //      integer fix-up (|2*dx*dy| < 2^23 is checked by the host), folded into the row's [min, max] with LDS
 //      ds_min / ds_max (order-free, no return value).  The spans leave as one u32 per row, xl | (xr + 1) << 16
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   __shared__ double s_phi[2][RR_MAX_FOV];
   __shared__ int s_px[4][FOV_GROUPS][POLY_STRIDE], s_py[4][FOV_GROUPS][POLY_STRIDE];
   __shared__ int s_xl[4][NCH * 64], s_xr[4][NCH * 64];         // per wave: the row spans of the drop being converted
+  __shared__ int4 s_edge[4][2 * POLY_STRIDE];                  // per wave: the edges of that drop
   if (threadIdx.x < RR_MAX_FOV) {
     s_phi[0][threadIdx.x] = cam.phi_cos[threadIdx.x];
     s_phi[1][threadIdx.x] = cam.phi_sin[threadIdx.x];
@@ -562,47 +563,45 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   for (int gg = 0; gg < G; gg++) {
     const int mg = __builtin_amdgcn_readfirstlane(__shfl(m, gg * N));
     if (mg <= 0) continue;                                     // no polygon: k_fov_sums never reads this drop's spans
-    // lane e describes edge e
-    int e_ylo = 0x7fffffff, e_yhi = -0x7fffffff, e_xa = 0, e_dx = 0, e_hl = 0, e_hh = 0;
-    float e_inv = 0.f;
+    // lane e describes edge e and leaves the description in LDS: (ylo, first row, last row, xa), (dx, den, 1/(2 den))
+    int cnt = 0;                                               // rows of the map the edge touches (<= 0: none)
     if (lane < mg) {
       const int j = (lane + 1 == mg) ? 0 : lane + 1;
       const int x0 = s_px[wave][gg][lane], y0 = s_py[wave][gg][lane], x1 = s_px[wave][gg][j], y1 = s_py[wave][gg][j];
       const bool swp = y1 < y0;
-      e_ylo = swp ? y1 : y0;
-      e_yhi = swp ? y0 : y1;
-      e_xa = swp ? x1 : x0;
-      e_dx = (swp ? x0 : x1) - e_xa;
-      e_hl = imin(x0, x1);
-      e_hh = imax(x0, x1);
-      const int den = e_yhi - e_ylo;
-      e_inv = den > 0 ? 1.0f / (float)(2 * den) : 0.f;
-    }
-    wave_lds_sync();                                           // span tables initialised (start / previous drop's read-out)
-    for (int e = 0; e < mg; e++) {
-      const int ylo = __builtin_amdgcn_readlane(e_ylo, e), yhi = __builtin_amdgcn_readlane(e_yhi, e);
-      const int ra = imax(ylo, 0), rb = imin(yhi, He - 1);
-      if (ra > rb) continue;
+      const int ylo = swp ? y1 : y0, yhi = swp ? y0 : y1;
+      const int xa = swp ? x1 : x0, dx = (swp ? x0 : x1) - xa;
       const int den = yhi - ylo;
-      if (den == 0) {                                          // horizontal edge: both end points on this row
-        if (lane == 0) {
-          atomicMin(&xl[ylo], __builtin_amdgcn_readlane(e_hl, e));
-          atomicMax(&xr[ylo], __builtin_amdgcn_readlane(e_hh, e));
-        }
-      } else {
-        const int xa = __builtin_amdgcn_readlane(e_xa, e), dx2 = 2 * __builtin_amdgcn_readlane(e_dx, e), dn = 2 * den;
-        const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_inv), e));
-        for (int yb = ra; yb <= rb; yb += 64) {                // rows of the edge, 64 per step; a row is touched by one lane
-          const int y = yb + lane;
-          if (y <= rb) {
-            const int t = y - ylo;
-            const int nn = __mul24(dx2, t) + den;              // exact: |dx2 * t| < 2^23 (host check)
-            int q = (int)floorf((float)nn * inv);              // floor(nn / dn) up to +-1 ...
-            const int rem = nn - __mul24(q, dn);
-            q += rem < 0 ? -1 : (rem >= dn ? 1 : 0);           // ... made exact
-            atomicMin(&xl[y], xa + q);
-            atomicMax(&xr[y], xa + q);
-          }
+      const float inv = den > 0 ? 1.0f / (float)(2 * den) : 0.f;
+      const int ra = imax(ylo, 0), rb = imin(yhi, He - 1);
+      cnt = rb - ra + 1;
+      s_edge[wave][2 * lane] = make_int4(ylo, ra, rb, xa);
+      s_edge[wave][2 * lane + 1] = make_int4(dx, den, __float_as_int(inv), 0);
+    }
+    wave_lds_sync();                                           // edges published; span tables initialised (start / previous read-out)
+    // Two edges per step, one per half wave (an edge covers ~30 rows: a whole wave per edge would idle half its
+    // lanes), 32 rows of each per inner step; every lane fetches its edge's description with two 16-byte reads.
+    for (int e = 0; e < mg; e += 2) {
+      const int eb = imin(e + 1, mg - 1);                      // (an odd last edge is done by both halves: min / max are idempotent)
+      const int nmax = imax(__builtin_amdgcn_readlane(cnt, e), __builtin_amdgcn_readlane(cnt, eb));
+      if (nmax <= 0) continue;
+      const int me = lane < 32 ? e : eb;
+      const int4 A = s_edge[wave][2 * me], B = s_edge[wave][2 * me + 1];
+      const int ylo = A.x, ra = A.y, rbv = A.z, xa = A.w, dx = B.x, den = B.y;
+      const float inv = __int_as_float(B.z);
+      const bool hz = den == 0;                                // horizontal edge: both end points on its one row
+      const int hl = imin(xa, xa + dx), hh = imax(xa, xa + dx);
+      const int dx2 = 2 * dx, dn = 2 * den;
+      for (int c = 0; c < nmax; c += 32) {
+        const int y = ra + c + (lane & 31);
+        if (y <= rbv) {                                        // a row is touched by one lane
+          const int t = y - ylo;
+          const int nn = __mul24(dx2, t) + den;                // exact: |dx2 * t| < 2^23 (host check)
+          int q = (int)floorf((float)nn * inv);                // floor(nn / dn) up to +-1 ...
+          const int rem = nn - __mul24(q, dn);
+          q += rem < 0 ? -1 : (rem >= dn ? 1 : 0);             // ... made exact
+          atomicMin(&xl[y], hz ? hl : xa + q);
+          atomicMax(&xr[y], hz ? hh : xa + q);
         }
       }
     }
