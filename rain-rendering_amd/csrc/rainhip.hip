@@ -1928,9 +1928,6 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   const bool live = px < dm.W && py < dm.H;
   const int64_t pix = (int64_t)py * dm.W + px;
   double c[3] = {0, 0, 0}, m = 0.0;
-  bool nan0 = false, nan1 = false, nan2 = false;
-  const double ex = cam.exposure_s, ex_rcp = 1.0 / ex;
-  const bool div_fast = (__double_as_longlong(ex) & 0xFFFFFFFFFFFFFLL) != 0xFFFFFFFFFFFFFLL && ex > 1.0e-200 && ex < 1.0e200;
   double sum_b = 0.0;                // this pixel's share of sum(bg) for the mean shift (generator.py:462)
   if (live) {
     const global_ptr<const double> s = as_global(fr.rainy_bg) + pix * 3;
@@ -2005,31 +2002,6 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
       RecS o{r->x0, r->y0, r->x1, r->y1, r->ox, r->oy, r->pitch, (long long)r->off, r->tau_one, r->g, r->K[0], r->K[1], r->K[2], r->zdist};
       return o;
     };
-    // blend_pixel (rr_device.h; bad_weather.py:443-446,450) with the same result bits from fewer instructions:
-    //  * t = (A * tau) / exposure: the divisor is a constant of the launch.  With y = RN(1 / d), q0 = a * y,
-    //    q = fma(fma(-q0, d, a), y, q0) is the correctly rounded a / d (Markstein's theorem: y correctly rounded, the
-    //    significand of d not all ones -- checked here -- and no underflow: tiny a take the division);
-    //  * np.clip keeps a NaN: v_max / v_min would turn it into 0, so a sticky per-channel flag remembers that a NaN
-    //    passed (from then on the reference's value is NaN for good) and the pixel gets it back at the end.
-    auto blend = [&](double A, const RecS& r) {
-      const double a = A * r.tau;
-      double tq;
-      if (div_fast && (a >= 1.0e-280 || a == 0.0)) {
-        const double q0 = a * ex_rcp;
-        tq = __builtin_fma(__builtin_fma(-q0, ex, a), ex_rcp, q0);
-      } else {
-        tq = a / ex;
-      }
-      const double u = 1.0 - tq;
-      const double v0 = u * c[0] + (A * r.k0) * r.g, v1 = u * c[1] + (A * r.k1) * r.g, v2 = u * c[2] + (A * r.k2) * r.g;
-      nan0 |= v0 != v0;
-      nan1 |= v1 != v1;
-      nan2 |= v2 != v2;
-      c[0] = __builtin_fmin(__builtin_fmax(v0, 0.0), 1.0);
-      c[1] = __builtin_fmin(__builtin_fmax(v1, 0.0), 1.0);
-      c[2] = __builtin_fmin(__builtin_fmax(v2, 0.0), 1.0);
-      m = m + A;
-    };
     auto inside = [&](const RecS& r) { return live & (px >= r.x0) & (px < r.x1) & (py >= r.y0) & (py < r.y1); };
     // (every lane loads: one outside the footprint reads the tile's first sample -- the same line for all of them -- so
     // that the number of loads in flight is known and the wait before a blend covers the OLDER load only)
@@ -2049,7 +2021,10 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
         const double A_n = sample(rn, in_n);
         const RecS rnn = fetch(i_nn);                            // record of entry e + 2
         i_nn = lst[e + 3 < total ? e + 3 : 0];
-        if (in_c && !(rc.z > scene)) blend(A_c, rc);
+        if (in_c && !(rc.z > scene)) {
+          const double K[3] = {rc.k0, rc.k1, rc.k2};
+          blend_pixel(A_c, rc.tau, cam.exposure_s, rc.g, K, c, m);
+        }
         rc = rn;
         rn = rnn;
         in_c = in_n;
@@ -2059,9 +2034,6 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     __syncthreads();
   }
   double sum_c = 0.0;
-  if (nan0) c[0] = __builtin_nan("");
-  if (nan1) c[1] = __builtin_nan("");
-  if (nan2) c[2] = __builtin_nan("");
   if (live) {
     const global_ptr<double> o = as_global(fr.comp_out) + pix * 3;
     o[0] = c[0];
