@@ -2009,26 +2009,31 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
       const int64_t o = in ? (int64_t)(py + r.oy) * r.pitch + (px + r.ox) : 0;
       return arena[r.off + o];
     };
+    // One step: entry e (record rcur, alpha Acur) is blended while entry e+1 (record rnext, fetched a step ago) is
+    // sampled and the record of entry e+2 is fetched.  The loop below is unrolled three times over three register
+    // sets, so nothing is moved between steps: a load is waited for where its value is first used, one step later.
+    auto step = [&](int e, const RecS& rcur, double Acur, bool incur, const RecS& rnext, double& Anext, bool& innext, RecS& rfetch,
+                    int& i_nn) {
+      innext = inside(rnext) & (e + 1 < total);                  // (past the end: entry 0 again, never blended)
+      Anext = sample(rnext, innext);
+      rfetch = fetch(i_nn);
+      i_nn = lst[e + 3 < total ? e + 3 : 0];                     // list index of entry e + 3, read one step ahead
+      if (incur && !(rcur.z > scene)) {
+        const double K[3] = {rcur.k0, rcur.k1, rcur.k2};
+        blend_pixel(Acur, rcur.tau, cam.exposure_s, rcur.g, K, c, m);
+      }
+    };
     if (total > 0) {
-      RecS rc = fetch(lst[0]);
-      RecS rn = fetch(lst[total > 1 ? 1 : 0]);
-      int i_nn = lst[total > 2 ? 2 : 0];                      // list index of entry e + 2, read one iteration ahead
-      bool in_c = inside(rc);
-      double A_c = sample(rc, in_c);
-      for (int e = 0; e < total; e++) {
-        // alpha of entry e + 1 (its record arrived an iteration ago; past the end: entry 0 again, never blended)
-        const bool in_n = inside(rn) & (e + 1 < total);
-        const double A_n = sample(rn, in_n);
-        const RecS rnn = fetch(i_nn);                            // record of entry e + 2
-        i_nn = lst[e + 3 < total ? e + 3 : 0];
-        if (in_c && !(rc.z > scene)) {
-          const double K[3] = {rc.k0, rc.k1, rc.k2};
-          blend_pixel(A_c, rc.tau, cam.exposure_s, rc.g, K, c, m);
-        }
-        rc = rn;
-        rn = rnn;
-        in_c = in_n;
-        A_c = A_n;
+      RecS R0 = fetch(lst[0]), R1 = fetch(lst[total > 1 ? 1 : 0]), R2 = R0;
+      int i_nn = lst[total > 2 ? 2 : 0];
+      bool in0 = inside(R0), in1 = false, in2 = false;
+      double A0 = sample(R0, in0), A1 = 0.0, A2 = 0.0;
+      for (int e = 0; e < total; e += 3) {
+        step(e, R0, A0, in0, R1, A1, in1, R2, i_nn);
+        if (e + 1 >= total) break;
+        step(e + 1, R1, A1, in1, R2, A2, in2, R0, i_nn);
+        if (e + 2 >= total) break;
+        step(e + 2, R2, A2, in2, R0, A0, in0, R1, i_nn);
       }
     }
     __syncthreads();
