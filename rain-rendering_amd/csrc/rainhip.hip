@@ -941,6 +941,14 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
       rec.g = p.g;
     }
   }
+  // pad = 1: the compositor takes the literal blend_pixel for this drop (its short form needs every factor finite and
+  // the quotient A * tau / exposure in the normal range; a caller-made tile may hold anything)
+  {
+    const double BIG = 1.0e50;
+    const bool tame = fabs(rec.tau_one) < BIG && (rec.tau_one == 0.0 || rec.tau_one > 1.0e-200) && fabs(rec.g) < BIG &&
+                      fabs(rec.K[0]) < BIG && fabs(rec.K[1]) < BIG && fabs(rec.K[2]) < BIG && p.kind != KIND_EXT;
+    rec.pad = tame ? 0 : 1;
+  }
   sc.comp[gi] = rec;
   sc.bbox[gi] = make_int4(rec.x0, rec.y0, rec.x1, rec.y1);
   if (fr.status) as_global(fr.status)[i] = status;
@@ -1946,6 +1954,11 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   double scene = 1.0e300;
   if (fr.depth && live)
     scene = fr.depth_f64 ? as_global((const double*)fr.depth)[pix] : (double)as_global((const float*)fr.depth)[pix];
+  // the short form of the blend (see step) needs finite pixel values and an exposure whose reciprocal divides exactly
+  const double ex = cam.exposure_s, ex_rcp = 1.0 / ex;
+  const bool tame_px = !live || (fabs(c[0]) < 1.0e50 && fabs(c[1]) < 1.0e50 && fabs(c[2]) < 1.0e50);
+  const bool slow_wave = __ballot(!tame_px) != 0ull || (__double_as_longlong(ex) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL ||
+                         !(ex > 1.0e-100 && ex < 1.0e100);
   const CompRec* comp = sc.comp + (int64_t)f * max_drops;
   const int4* bbox = sc.bbox + (int64_t)f * max_drops;
   const double* arena = sc.arena;
@@ -1993,13 +2006,13 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
     // before its first use, and the footprint test is branch-free.  (Measured and rejected: records staged through
     // LDS with four samples in flight per lane -- 20 % slower.)
     struct RecS {
-      int x0, y0, x1, y1, ox, oy, pitch;
+      int x0, y0, x1, y1, ox, oy, pitch, slow;
       long long off;
       double tau, g, k0, k1, k2, z;
     };
     auto fetch = [&](int idx) {
       const const_ptr<CompRec> r = as_constant(comp) + __builtin_amdgcn_readfirstlane(idx);
-      RecS o{r->x0, r->y0, r->x1, r->y1, r->ox, r->oy, r->pitch, (long long)r->off, r->tau_one, r->g, r->K[0], r->K[1], r->K[2], r->zdist};
+      RecS o{r->x0, r->y0, r->x1, r->y1, r->ox, r->oy, r->pitch, r->pad, (long long)r->off, r->tau_one, r->g, r->K[0], r->K[1], r->K[2], r->zdist};
       return o;
     };
     auto inside = [&](const RecS& r) { return live & (px >= r.x0) & (px < r.x1) & (py >= r.y0) & (py < r.y1); };
@@ -2019,8 +2032,25 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
       rfetch = fetch(i_nn);
       i_nn = lst[e + 3 < total ? e + 3 : 0];                     // list index of entry e + 3, read one step ahead
       if (incur && !(rcur.z > scene)) {
-        const double K[3] = {rcur.k0, rcur.k1, rcur.k2};
-        blend_pixel(Acur, rcur.tau, cam.exposure_s, rcur.g, K, c, m);
+        if (slow_wave | rcur.slow) {                             // (wave-uniform) the literal form
+          const double K[3] = {rcur.k0, rcur.k1, rcur.k2};
+          blend_pixel(Acur, rcur.tau, cam.exposure_s, rcur.g, K, c, m);
+        } else {
+          // Same result bits as blend_pixel (bad_weather.py:443-446,450) from half the instructions, valid because every
+          // factor is finite here (k_colour's flag, the pixel test above) so no NaN can arise and clip == clamp:
+          //   t = (A * tau) / exposure: with y = RN(1 / d), q0 = a * y, the value fma(fma(-q0, d, a), y, q0) is the
+          //   correctly rounded a / d (Markstein; d's significand not all ones -- part of slow_wave -- and a, a / d
+          //   in the normal range or zero: tau is 0 or > 1e-200, an alpha sample is 0 or far above 1e-40).
+          const double a = Acur * rcur.tau;
+          const double q0 = a * ex_rcp;
+          const double u = 1.0 - __builtin_fma(__builtin_fma(-q0, ex, a), ex_rcp, q0);
+          const double v0 = u * c[0] + (Acur * rcur.k0) * rcur.g, v1 = u * c[1] + (Acur * rcur.k1) * rcur.g,
+                       v2 = u * c[2] + (Acur * rcur.k2) * rcur.g;
+          c[0] = __builtin_fmin(__builtin_fmax(v0, 0.0), 1.0);
+          c[1] = __builtin_fmin(__builtin_fmax(v1, 0.0), 1.0);
+          c[2] = __builtin_fmin(__builtin_fmax(v2, 0.0), 1.0);
+          m = m + Acur;
+        }
       }
     };
     if (total > 0) {

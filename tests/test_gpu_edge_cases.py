@@ -126,3 +126,33 @@ def test_tall_environment_maps(tmp_path, built, Hh, Ww):
     assert np.array_equal(out['mask'], emu['mask'])
     assert np.abs(out['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
     assert np.abs(out['rainy_bg'] - emu['rainy_bg']).max() < 1e-9
+
+
+def test_wild_pixel_values_follow_the_reference_blend(tmp_path, built):
+    """The compositor's short blend (exact reciprocal division, hardware clamp) is only taken where every factor is tame;
+    NaN / inf / huge / negative values in rainy_bg must come out as the literal blend (np.clip keeps a NaN,
+    bad_weather.py:443-446) produces them -- compared with the host build of blend_pixel, value for value."""
+    H2, W2 = 96, 160
+    sc = h.Scene(tmp_path, H2, W2, 400, seed0=77)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    wild = bg.copy()
+    rng = np.random.RandomState(5)
+    ys, xs = rng.randint(0, H2, 400), rng.randint(0, W2, 400)
+    vals = np.array([np.nan, np.inf, -np.inf, 1e60, -3.0, 7.5, 1e-300, -0.0])
+    wild[ys, xs, rng.randint(0, 3, 400)] = vals[rng.randint(0, len(vals), 400)]
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    for rb in (bg, wild):
+        out = rh.render_frames([dict(bg=bg, rainy_bg=rb, env_xyY=env, omega=sc.omega, drops=drops)])[0]
+        emu = h.emu_render(sc, bg, rb, env, drops)
+        assert np.array_equal(out['mask'], emu['mask'])
+        # colour constants come from FOV sums added in another order: 1e-9; everything else is the same arithmetic
+        a, b = out['rainy_bg'], emu['rainy_bg']
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin)
+        assert np.array_equal(a[~fin & ~np.isnan(b)], b[~fin & ~np.isnan(b)])        # the infinities, with their signs
+        assert np.abs(a[fin] - b[fin]).max() < 1e-9
+    rh.close()
