@@ -104,7 +104,8 @@ typedef struct {
   int32_t H, W;                   /* frame */
   int32_t He, We;                 /* lat-long environment map */
   const double* bg;               /* H*W*3 BGR, un-fogged image / 255 (used for the mean shift, generator.py:462) */
-  const double* rainy_bg;         /* H*W*3 BGR, output of the fog pre-pass (generator.py:386) */
+  const double* rainy_bg;         /* H*W*3 BGR, output of the fog pre-pass (generator.py:386): values in [0, 1] (it ends with
+                                   * np.clip); a NaN stays a NaN like in the reference */
   const double* env_xyY;          /* He*We*3 (generator.py:407-408) */
   const double* omega;            /* He*We solid angles (generator.py:410) */
   const rr_drop* drops;           /* n_drops records in reference order */
