@@ -414,12 +414,13 @@ __global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_
       }
       h = h + 1 == cap ? 0 : h + 1;
     }
-    if (canon != gi) {
-      p.a0_off = sc.plan[canon].a0_off;                   // an elected drop never changes its own offset
-      atomicAdd(&sc.counts[f * 8 + 7], 1);
-    }
+    if (canon != gi) p.a0_off = sc.plan[canon].a0_off;    // an elected drop never changes its own offset
   }
   sc.canon[gi] = canon;
+  // the frame's duplicate counter (a diagnostic): one atomic per wave -- one per drop is a chain of thousands of
+  // serialised read-modify-writes of the same address, which was most of this kernel's time
+  const unsigned long long dup = __ballot(canon != gi);
+  if (dup != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)dup) - 1) atomicAdd(&sc.counts[f * 8 + 7], __popcll(dup));
 }
 
 // ---------------------------------------------------------------------------
