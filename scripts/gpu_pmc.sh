@@ -1,15 +1,17 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel stats + PMC passes of the bench command, compact per-kernel summary.
 # Usage: scripts/gpu_pmc.sh <tag> "<bench args>" "<pass1 counters>" ["<pass2 counters>" ...]
+# FETCH_SIZE and WRITE_SIZE each need a pass of their own (together: "exceeds the capabilities of the hardware", and
+# rocprofv3 then sits on the aborted child until it is killed); every invocation runs under its own timeout.
 TAG=$1; BARGS=$2; shift 2
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 3 --warmup 1 --inner $BARGS"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 i=0
 for C in "$@"; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pass$i -- $BENCH > $OUT/pass$i.log 2>&1
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pass$i -- $BENCH > $OUT/pass$i.log 2>&1 || echo "pass $i ($C) failed or timed out"
   i=$((i+1))
 done
 python - <<PY
