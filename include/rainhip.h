@@ -237,7 +237,7 @@ enum {
   RR_OPT_GENERAL_FOV = 2,           /* 1: force the general colour path (prefix table in HBM) that maps taller than 1024 rows,
                                      *    wider than 4096 columns or with He*We >= 2^22 always take; default 0 */
   RR_OPT_FOV_THREADS = 3,           /* workgroup size of the FOV-sum kernel: 0 (library's choice), 512 or 1024 */
-  RR_OPT_FOV_DROPS_PER_THREAD = 4,  /* drops per thread of the FOV-sum kernel: 0 (library's choice), 1, 2 or 4 */
+  RR_OPT_FOV_DROPS_PER_THREAD = 4,  /* drops per thread of the FOV-sum kernel: 0 (library's choice), 1, 2, 4 or 8 */
   /* NOT a tuning switch -- a feature the reference only sketches (common/drop_depth_map.py, dead code behind
    * USE_DEPTH_WEIGHTING = 0, generator.py:20): with 1, a drop is not composited at pixels whose scene depth
    * (rr_frame_in.depth / the pre-pass' depth) is smaller than the drop's distance |world z|.  Default 0: the reference's

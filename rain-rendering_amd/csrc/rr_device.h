@@ -852,4 +852,78 @@ RR_HD void blend_pixel(double A, double tau_one, double exposure, double g, cons
   mask = mask + A;
 }
 
+// ---------------------------------------------------------------------------
+// defocus blur: which kernel takes a drop and how its tile is cut into LDS-sized sub-tiles
+// (tests/test_blur_layout.py sweeps these on the host: every sub-tile must fit the capacities)
+// ---------------------------------------------------------------------------
+// blur work layout (needed by k_colour to know where the finished tile will live)
+// LDS capacities of the fused blur (doubles): input sub-tile incl. halo / result of the row (axis 0) pass.  They set how
+// many workgroups share a CU (160 KB of LDS; the kernel is compiled for the matching register budget):
+//   3 per CU: 3072 + 2048     4 per CU: 2816 + 2048 (default)     5 per CU: 2304 + 1600
+// Smaller tiles mean more sub-tiles per drop (more halo re-loaded), more workgroups mean better latency hiding.
+constexpr int BR_MAX = 48;          // largest axis-0 radius the fused kernel takes
+
+struct BlurLayout {
+  int fused;        // 0: two global passes (k_blur<0>, k_blur<1>)
+  int wo, ho;       // output sub-tile
+  int single;       // one sub-tile covers the padded tile: result written in place (A0)
+};
+// LDS footprints of an output sub-tile wo x ho: each thread filters four consecutive outputs
+// along the filter axis with a rotating register window, so rows/columns are padded to
+// multiples of four (zero / don't-care slack); the column-pass tile has an odd pitch so that
+// lanes running down a column hit distinct LDS banks.
+// X holds only the columns under the raw tile (tw wide): the others stay exactly zero through the row pass.
+RR_HD int blur_x_doubles(int wo, int ho, int r1, int r2, int tw) { return imin(wo + 2 * r2, tw) * (((ho + 3) & ~3) + 2 * r1); }
+RR_HD int blur_y_pitch(int wo, int r2) { return (((wo + 3) & ~3) + 2 * r2) | 1; }
+RR_HD int blur_y_doubles(int wo, int ho, int r2) { return blur_y_pitch(wo, r2) * ((ho + 3) & ~3); }
+
+RR_HD BlurLayout blur_layout(const DropPlan& p, int BX_MAX, int BY_MAX) {
+  BlurLayout b{0, 0, 0, 0};
+  if (p.r1 <= 0 || p.r1 > BR_MAX) return b;
+  // Whole tile if it fits ...
+  if (blur_x_doubles(p.ew, p.eh, p.r1, p.r2, p.tw) <= BX_MAX && blur_y_doubles(p.ew, p.eh, p.r2) <= BY_MAX) {
+    b.fused = 1; b.wo = p.ew; b.ho = p.eh; b.single = 1;
+    return b;
+  }
+  // ... else full-width bands of rows (no column is filtered twice by the row pass; only the 2*r1 halo rows are
+  // loaded again per band), as tall as the two capacities allow ...
+  {
+    const int hy = (BY_MAX / blur_y_pitch(p.ew, p.r2)) & ~3;
+    const int hx = ((BX_MAX / imin(p.ew + 2 * p.r2, p.tw)) - 2 * p.r1) & ~3;
+    const int hb = imin(hy, hx);
+    if (hb >= imax(8, p.r1)) {
+      b.fused = 1; b.wo = p.ew; b.ho = imin(hb, p.eh);
+      return b;
+    }
+  }
+  // ... else (wide tiles with large radii) the output sub-tile that roughly maximises wo*ho under the two capacities --
+  // halo-aware aspect: (wo+2*r2)*(ho+2*r1) <= BX_MAX.
+  const double rr2 = (double)imax(p.r2, 1), rr1 = (double)p.r1;
+  int wi = (int)sqrt((double)BX_MAX * rr2 / rr1);            // ideal haloed width
+  wi = imax(imin(wi, p.ew + 2 * p.r2), 2 * p.r2 + 4);
+  int hi = BX_MAX / wi;
+  hi = imin(hi, ((p.eh + 3) & ~3) + 2 * p.r1);
+  wi = imin(BX_MAX / hi, p.ew + 2 * p.r2);                   // give unused height back to the width
+  int wo = wi - 2 * p.r2, ho = (hi - 2 * p.r1) & ~3;         // ho a multiple of four: no slack rows wasted
+  if (ho > p.eh) ho = p.eh;
+  for (int it = 0; it < 64 && wo >= 1 && ho >= 1; it++) {
+    if (blur_x_doubles(wo, ho, p.r1, p.r2, p.tw) <= BX_MAX && blur_y_doubles(wo, ho, p.r2) <= BY_MAX) {
+      b.fused = 1; b.wo = wo; b.ho = ho; b.single = (wo >= p.ew && ho >= p.eh) ? 1 : 0;
+      return b;
+    }
+    if (blur_x_doubles(wo, ho, p.r1, p.r2, p.tw) > BX_MAX) { if (wo > 4) wo -= 1; else ho -= 4; }
+    else ho -= 4;
+  }
+  return b;                                                  // halo alone exceeds the LDS: two-pass fallback
+}
+// small blurred tiles are filtered by one wave each, in place (k_blur_small)
+constexpr int BS_X = 512;           // doubles per wave: data columns of the haloed input tile (tw x (eh + 2 r1))
+constexpr int BS_Y = 768;           // doubles per wave: after the row pass (halo columns kept)
+
+RR_HD bool blur_is_small(const DropPlan& p) {      // (rows padded to the four-output blocks of blur4)
+  const int php = (p.eh + 3) & ~3;
+  return p.r1 > 0 && p.r1 <= 31 && p.tw * (php + 2 * p.r1) <= BS_X && blur_y_pitch(p.ew, p.r2) * php <= BS_Y;
+}
+
+
 }  // namespace rr

@@ -234,4 +234,34 @@ int emu_prepass(int H, int W, const double* bg, const void* depth, int depth_f64
   return g.We;
 }
 
+// The blur work split of one drop (rr_device.h: blur_is_small, blur_layout).  out = {small, fused, wo, ho}; returns the
+// number of sub-tiles whose LDS footprint -- computed the way k_blur_fused / k_blur_small index their tiles --
+// exceeds a capacity (must be 0).
+int emu_blur_layout(int ew, int eh, int r1, int r2, int tw, int th, int bx, int by, int32_t* out) {
+  DropPlan p{};
+  p.ew = ew; p.eh = eh; p.r1 = r1; p.r2 = r2; p.tw = tw; p.th = th;
+  const bool small = blur_is_small(p);
+  const BlurLayout L = blur_layout(p, bx, by);
+  out[0] = small; out[1] = L.fused; out[2] = L.wo; out[3] = L.ho;
+  int bad = 0;
+  if (small) {                                     // k_blur_small: X = tw x (php + 2 r1), Y = pitch x php
+    const int php = (eh + 3) & ~3;
+    if (tw * (php + 2 * r1) > BS_X || blur_y_pitch(ew, r2) * php > BS_Y || r1 > 63 || r2 > 63) bad++;
+  } else if (L.fused) {                            // k_blur_fused: per sub-tile X = wd x (hop + 2 r1), Y = pitch x hop
+    if (L.wo < 1 || L.ho < 1 || L.wo > 0xffff || L.ho > 0x7fff) return 1 << 30;
+    const int ntx = (ew + L.wo - 1) / L.wo, nty = (eh + L.ho - 1) / L.ho;
+    for (int sty = 0; sty < nty; sty++)
+      for (int stx = 0; stx < ntx; stx++) {
+        const int y0 = sty * L.ho, x0 = stx * L.wo;
+        const int ho = imin(L.ho, eh - y0), wo = imin(L.wo, ew - x0), hop = (ho + 3) & ~3;
+        const int wi = wo + 2 * r2, hi = hop + 2 * r1, yp = blur_y_pitch(wo, r2);
+        const int xa = imax(0, 2 * r2 - x0), xb = imin(wi, tw + 2 * r2 - x0), wd = imax(xb - xa, 0);
+        if (wd * hi > bx || yp * hop > by || ((yp * hop) & 1) || xa + wd > wi) bad++;
+        // the column pass reads columns up to 4 * (ceil(wo / 4) - 1) + 2 r2 + 3 of a row of pitch yp
+        if (4 * (((wo + 3) >> 2) - 1) + 2 * r2 + 3 >= yp) bad++;
+      }
+  }
+  return bad;
+}
+
 }  // extern "C"
