@@ -30,6 +30,7 @@ import json
 import os
 import re
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -124,7 +125,7 @@ def timed(torch, dist, world, dev, fn, steps):
     return el
 
 
-def measure_traffic(args, dom_kernels):
+def measure_traffic(args, dom_kernels, scene_dir=None):
     """HBM bytes per launch of the dominant kernel: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not
     fit one pass) of a short run of this same workload, corrected as MI355X_MICROARCH.md's HBM section prescribes:
     KB * 1024, FETCH_SIZE doubled on gfx950.  None when rocprofv3 is missing or anything goes wrong."""
@@ -138,8 +139,19 @@ def measure_traffic(args, dom_kernels):
             cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
                    os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1', '--batch', str(args.batch),
                    '--workload', args.workload] + sum((['--opt', o] for o in args.opt), [])
+            if scene_dir:
+                cmd += ['--scene-dir', scene_dir]                   # the simulation this process already wrote
             env = dict(os.environ, TMPDIR='/tmp')
-            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+            # own session + a hard limit: a profiler that aborts can sit on its child for ever; the whole group is killed
+            proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, "pmc pass timed out"
+            if rc != 0:
+                return None, "pmc pass exited with %d" % rc
             tot, cnt = 0.0, 0
             for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -242,6 +254,7 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='rr_set_option as ID=VALUE (tuning switches that never change results)')
     ap.add_argument('--sweep', action='append', default=[], help='A/B: after the headline, time the loop again under these '
                     'rr_set_option sets ("6=3,3=512"); one JSON line each on stderr; implies the lean run')
+    ap.add_argument('--scene-dir', default=None, help='(used by the PMC passes) directory of a simulation to reuse')
     ap.add_argument('--inner', action='store_true', help='(used by the PMC passes) timed loop only, no extras, no JSON')
     args = ap.parse_args()
     if args.inner or args.sweep:
@@ -289,7 +302,7 @@ def main():
     else:
         my_frames = list(range(B))
         n_sim, seed0 = B, 3000 + 1000 * rank
-    tmp = tempfile.mkdtemp(prefix='rainbench_r%d_' % rank)
+    tmp = args.scene_dir or tempfile.mkdtemp(prefix='rainbench_r%d_' % rank)
     with contextlib.redirect_stdout(sys.stderr):       # loaders print like the reference's do; stdout carries the JSON line only
         sc = scenes.Scene(tmp, H, W, N, n_frames=n_sim, cam=cam, seed0=seed0, render_scale=wl['rs'])
     He, We = sc.He, sc.We
@@ -476,7 +489,7 @@ def main():
         traffic, traffic_how = None, "not measured (--no-traffic, N>1 or strong scaling)"
         if single and not args.no_traffic and not strong:
             parts = {'k_env_prefix': ['k_env_prefix', 'k_env_consts']}.get(dom_name, [dom_name])
-            traffic, traffic_how = measure_traffic(args, parts)
+            traffic, traffic_how = measure_traffic(args, parts, scene_dir=tmp)
         chain_ms = sum(per_launch.values())
         out = {
             "metric": wl['metric'],

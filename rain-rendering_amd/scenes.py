@@ -39,10 +39,21 @@ class Scene:
         self.render_scale = render_scale
         self.tex_dir, self.norm = synthetic.write_streak_db(os.path.join(str(tmpdir), 'rainstreakdb'),
                                                             tex_heights=tex_heights, tex_width=tex_width)
-        if frames is None:
-            frames = synthetic.simulate_particles(n_frames, n_drops, W * render_scale, H * render_scale, cam['focal_mm'],
-                                                  cam['pix_um'], cam['exposure_ms'], seed0=seed0, far_fraction=far_fraction)
-        self.xml = synthetic.write_particles_xml(os.path.join(str(tmpdir), 'particles', 'rain', 'sim_camera0.xml'), frames)
+        xml = os.path.join(str(tmpdir), 'particles', 'rain', 'sim_camera0.xml')
+        # a directory that already holds this very simulation (same parameters: the stamp) is reused -- bench.py's
+        # counter passes run in child processes and would otherwise simulate and format the same 2 M streaks again
+        stamp = repr((n_frames, n_drops, W, H, render_scale, seed0, far_fraction, sorted(cam.items()))) if frames is None else None
+        stamp_path = xml + '.stamp'
+        if stamp is not None and os.path.exists(xml) and os.path.exists(stamp_path) and open(stamp_path).read() == stamp:
+            self.xml = xml
+        else:
+            if frames is None:
+                frames = synthetic.simulate_particles(n_frames, n_drops, W * render_scale, H * render_scale, cam['focal_mm'],
+                                                      cam['pix_um'], cam['exposure_ms'], seed0=seed0, far_fraction=far_fraction)
+            self.xml = synthetic.write_particles_xml(xml, frames)
+            if stamp is not None:
+                with open(stamp_path, 'w') as fh:
+                    fh.write(stamp)
         self.He = H
         self.We = synthetic.envmap_width(cam['focal_mm'], W)
         # product loaders

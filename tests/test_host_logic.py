@@ -328,3 +328,18 @@ def test_native_png_codec(tmp_path):
     assert os.path.getsize(str(tmp_path / 'w11.png')) <= 1.02 * os.path.getsize(str(tmp_path / 'w10.png'))
     imgops.write_png_rgba(str(tmp_path / 'py.png'), rgba)
     assert np.array_equal(np.array(Image.open(str(tmp_path / 'py.png'))), rgba)
+
+
+def test_scene_directory_is_reused_only_for_the_same_simulation(tmp_path):
+    """bench.py's counter passes run in child processes on the parent's scene directory: the simulation on disk is
+    reused when (and only when) it was made with the same parameters."""
+    import os
+    a = h.Scene(tmp_path, 48, 80, 30, n_frames=2, seed0=5)
+    xml = a.xml
+    t0 = os.path.getmtime(xml)
+    b = h.Scene(tmp_path, 48, 80, 30, n_frames=2, seed0=5)
+    assert os.path.getmtime(xml) == t0                                   # not rewritten
+    assert np.array_equal(a.product_drops(1), b.product_drops(1))
+    c = h.Scene(tmp_path, 48, 80, 31, n_frames=2, seed0=5)               # another simulation: written again
+    assert len(c.product_drops(0)) != len(a.product_drops(0)) or os.path.getmtime(xml) != t0
+    assert open(xml + '.stamp').read() != repr(None)
