@@ -45,10 +45,11 @@ def resize_linear(img, dw, dh):
 # zlib level of the PNGs the driver writes.  Pixels are what parity is about; matplotlib's default (6)
 # costs ~0.4 s per 1242x375 RGBA frame, level 1 a quarter of that for ~15% larger files.
 PNG_LEVEL = int(os.environ.get('RAIN_PNG_LEVEL', '1'))
-# deflate strategy of the scanline writer: 'rle' (run lengths + Huffman: on Sub-filtered image rows smaller files than
-# the default strategy at level 1, in half the time), 'default' (LZ77: the files of the previous writer, byte for byte),
-# 'huffman'.  Decoded pixels are the same whatever the choice.
-PNG_STRATEGY = {'default': 0, 'rle': 1, 'huffman': 2}[os.environ.get('RAIN_PNG_STRATEGY', 'rle')]
+# deflate strategy of the scanline writer: 'fast' (the library's own run-length + dynamic-Huffman encoder: the size of
+# zlib's Z_RLE at a third of its CPU time -- the driver is bound by the deflate of its two files per frame), 'rle' (zlib
+# Z_RLE), 'default' (zlib LZ77: the files of the Python writer, byte for byte), 'huffman'.  Decoded pixels are the same
+# whatever the choice.
+PNG_STRATEGY = {'default': 0, 'rle': 1, 'huffman': 2, 'fast': 3}[os.environ.get('RAIN_PNG_STRATEGY', 'fast')]
 
 
 def write_png_rgba(path, rgba, level=None):

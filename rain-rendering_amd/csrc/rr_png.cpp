@@ -11,10 +11,12 @@
 // RR_E_UNSUPPORTED and the caller uses its general-purpose decoder.  zlib does the (de)compression.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "rainhip.h"
@@ -117,6 +119,259 @@ int decode(const Png& p, std::vector<uint8_t>& img, size_t& stride) {
   return RR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast deflate for filtered scanlines (strategy 3).  zlib spends ~10 ns per input byte even with Z_RLE / Z_HUFFMAN_ONLY
+// (per-symbol tallying, bit-at-a-time block emission); at a few hundred frames per second on a handful of cores that is the
+// driver's bottleneck.  Sub-filtered image rows need no string matching: small residuals (a skewed byte histogram) and
+// runs of one value (flat regions, the colour-mapped mask).  So: per block of 128 KB, one pass turns the input into
+// literals and distance-1 matches (a run of the previous byte, like Z_RLE), a histogram gives a dynamic Huffman code
+// (RFC 1951 section 3.2.7; lengths limited to 15 bits), and the symbols are emitted through a 64-bit bit buffer.  The result
+// is an ordinary zlib stream (any inflate reads it); about the size of Z_RLE's, several times faster.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BitWriter {                                    // LSB-first bit buffer over a caller-sized byte array
+  uint8_t* p;
+  uint64_t acc = 0;
+  int n = 0;
+  explicit BitWriter(uint8_t* dst) : p(dst) {}
+  inline void put(uint32_t bits, int len) {           // len <= 32; at most 7 bits are pending before the call
+    acc |= (uint64_t)bits << n;
+    n += len;
+    memcpy(p, &acc, 8);                               // (little-endian host) the whole bytes of acc
+    p += n >> 3;
+    acc >>= n & ~7;
+    n &= 7;
+  }
+  inline void add(uint32_t bits, int len) {           // no store: the caller flushes before acc could overflow
+    acc |= (uint64_t)bits << n;
+    n += len;
+  }
+  inline void flush() {
+    memcpy(p, &acc, 8);
+    p += n >> 3;
+    acc >>= n & ~7;
+    n &= 7;
+  }
+  void finish() {                                     // pad to a byte boundary
+    if (n > 0) *p++ = (uint8_t)acc;
+    n = 0;
+    acc = 0;
+  }
+};
+
+// code lengths of a minimum-redundancy prefix code, limited to max_len bits (count-based fix-up of over-long codes)
+void huffman_lengths(const uint32_t* freq, int nsym, int max_len, uint8_t* len) {
+  struct Node { uint64_t w; int a, b; };
+  std::vector<int> used;
+  for (int i = 0; i < nsym; i++) {
+    len[i] = 0;
+    if (freq[i]) used.push_back(i);
+  }
+  if (used.empty()) return;
+  if (used.size() == 1) { len[used[0]] = 1; return; }
+  // two-queue construction over the symbols sorted by weight
+  std::sort(used.begin(), used.end(), [&](int x, int y) { return freq[x] != freq[y] ? freq[x] < freq[y] : x < y; });
+  const int m = (int)used.size();
+  std::vector<Node> nodes((size_t)2 * m);
+  for (int i = 0; i < m; i++) nodes[i] = Node{freq[used[i]], -1, -1};
+  int leaf = 0, inner = m, made = m;
+  auto take = [&]() {
+    if (leaf < m && (inner >= made || nodes[leaf].w <= nodes[inner].w)) return leaf++;
+    return inner++;
+  };
+  while (made < 2 * m - 1) {
+    const int x = take(), y = take();
+    nodes[made++] = Node{nodes[x].w + nodes[y].w, x, y};
+  }
+  std::vector<int> depth((size_t)2 * m, 0);
+  for (int i = 2 * m - 2; i >= m; i--) {              // parents come after their children: walk down from the root
+    depth[nodes[i].a] = depth[i] + 1;
+    depth[nodes[i].b] = depth[i] + 1;
+  }
+  std::vector<int> count((size_t)max_len + 2, 0);
+  for (int i = 0; i < m; i++) count[depth[i] > max_len ? max_len : depth[i]]++;
+  uint64_t total = 0;
+  for (int l = 1; l <= max_len; l++) total += (uint64_t)count[l] << (max_len - l);
+  while (total > (1ull << max_len)) {                 // Kraft sum too large after the clamp: lengthen the cheapest codes
+    count[max_len]--;
+    for (int l = max_len - 1; l >= 1; l--)
+      if (count[l]) {
+        count[l]--;
+        count[l + 1] += 2;
+        break;
+      }
+    total--;
+  }
+  int at = m - 1;                                     // `used` is sorted by rising weight: the rarest symbols get the longest codes
+  int l = max_len;
+  std::vector<int> c2(count);
+  for (int i = 0; i < m; i++) {
+    while (l > 0 && c2[l] == 0) l--;
+    len[used[i]] = (uint8_t)l;
+    c2[l]--;
+  }
+  (void)at;
+}
+
+// canonical codes (RFC 1951 3.2.2), bit-reversed for the LSB-first bit buffer
+void huffman_codes(const uint8_t* len, int nsym, uint16_t* code) {
+  int bl_count[16] = {0};
+  for (int i = 0; i < nsym; i++) bl_count[len[i]]++;
+  bl_count[0] = 0;
+  int next[16] = {0}, c = 0;
+  for (int b = 1; b <= 15; b++) {
+    c = (c + bl_count[b - 1]) << 1;
+    next[b] = c;
+  }
+  for (int i = 0; i < nsym; i++) {
+    const int L = len[i];
+    code[i] = 0;
+    if (!L) continue;
+    uint32_t v = (uint32_t)next[L]++, r = 0;
+    for (int k = 0; k < L; k++) r |= ((v >> k) & 1u) << (L - 1 - k);
+    code[i] = (uint16_t)r;
+  }
+}
+
+struct LenCode { uint16_t sym; uint8_t ebits; uint16_t eval; };
+struct LenTable {                                     // match length 3..258 -> (symbol, extra bits, extra value)
+  LenCode tab[259];
+  LenTable() {
+    static const int base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const int extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    for (int L = 0; L < 3; L++) tab[L] = LenCode{0, 0, 0};
+    for (int L = 3; L <= 258; L++) {
+      int k = 28;
+      while (base[k] > L) k--;
+      tab[L] = LenCode{(uint16_t)(257 + k), (uint8_t)extra[k], (uint16_t)(L - base[k])};
+    }
+  }
+};
+const LenCode* length_table() {
+  static const LenTable t;                            // (initialised once, thread-safe: the driver encodes on many threads)
+  return t.tab;
+}
+
+// the zlib stream (header, deflate blocks, adler32) of n bytes
+struct ByteBuf {                                      // uninitialised storage (a std::vector would zero megabytes per file)
+  std::unique_ptr<uint8_t[]> mem;
+  size_t cap = 0, len = 0;
+  void reserve_raw(size_t c) { mem.reset(new uint8_t[c]); cap = c; len = 0; }
+  uint8_t* data() { return mem.get(); }
+};
+void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
+  const LenCode* LT = length_table();
+  const size_t BLOCK = 128 * 1024;
+  // worst case: every byte a 15-bit literal is impossible for a Huffman code of the block's own histogram (< 9 bits per
+  // byte on average); 2 n + slack is a safe roof, trimmed at the end
+  out.reserve_raw(2 * n + (n / BLOCK + 2) * 512 + 64);
+  out.data()[0] = 0x78;
+  out.data()[1] = 0x01;
+  BitWriter bw(out.data() + 2);
+  std::vector<uint16_t> tok(BLOCK);                   // literal: byte value; match: 0x8000 | length (distance is always 1)
+  size_t pos = 0;
+  if (n == 0) {                                       // one empty stored block
+    bw.put(1, 1); bw.put(0, 2); bw.finish();
+    bw.put(0xffff0000u, 32);
+  }
+  while (pos < n) {
+    const size_t end = pos + BLOCK < n ? pos + BLOCK : n;
+    const bool last = end == n;
+    uint32_t fl[286] = {0}, fl2[256] = {0}, fd[30] = {0};   // (two literal histograms: neighbours often repeat a value)
+    size_t nt = 0;
+    size_t i = pos;
+    if (i == 0) {                                     // the very first byte has no predecessor
+      tok[nt++] = in[0];
+      fl[in[0]]++;
+      i = 1;
+    }
+    while (i < end) {
+      const uint8_t b = in[i];
+      if (b == in[i - 1] && i + 2 < end && in[i + 1] == b && in[i + 2] == b) {   // a run of the previous byte, >= 3 long
+        size_t r = 3;
+        const size_t lim = end - i < 258 ? end - i : 258;
+        while (r < lim && in[i + r] == b) r++;
+        tok[nt++] = (uint16_t)(0x8000u | (uint32_t)r);
+        fl[LT[r].sym]++;
+        fd[0]++;
+        i += r;
+      } else {
+        tok[nt++] = b;
+        if (nt & 1) fl[b]++; else fl2[b]++;
+        i++;
+      }
+    }
+    for (int k = 0; k < 256; k++) fl[k] += fl2[k];
+    fl[256] = 1;                                      // end of block
+    if (!fd[0]) fd[0] = 1;                            // a distance code must exist
+    uint8_t ll[286], dl[30];
+    uint16_t lc[286], dc[30];
+    huffman_lengths(fl, 286, 12, ll);                 // 12 bits: four literals (48 bits) + 7 pending fit the 64-bit buffer
+    huffman_lengths(fd, 30, 15, dl);
+    huffman_codes(ll, 286, lc);
+    huffman_codes(dl, 30, dc);
+    int nlit = 286;
+    while (nlit > 257 && ll[nlit - 1] == 0) nlit--;
+    const int ndist = 1;
+    // the code lengths themselves, Huffman coded without the repeat symbols (a few hundred bits per 128 KB block)
+    uint32_t fc[19] = {0};
+    for (int k = 0; k < nlit; k++) fc[ll[k]]++;
+    for (int k = 0; k < ndist; k++) fc[dl[k]]++;
+    uint8_t cl[19];
+    uint16_t cc[19];
+    huffman_lengths(fc, 19, 7, cl);
+    huffman_codes(cl, 19, cc);
+    static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int ncl = 19;
+    while (ncl > 4 && cl[order[ncl - 1]] == 0) ncl--;
+    bw.put(last ? 1 : 0, 1);
+    bw.put(2, 2);
+    bw.put((uint32_t)(nlit - 257), 5);
+    bw.put((uint32_t)(ndist - 1), 5);
+    bw.put((uint32_t)(ncl - 4), 4);
+    for (int k = 0; k < ncl; k++) bw.put(cl[order[k]], 3);
+    for (int k = 0; k < nlit; k++) bw.put(cc[ll[k]], cl[ll[k]]);
+    for (int k = 0; k < ndist; k++) bw.put(cc[dl[k]], cl[dl[k]]);
+    // literals: code and length in one table entry; a match: length symbol + extra bits + the distance code, pre-merged
+    uint32_t lit[256];
+    for (int k = 0; k < 256; k++) lit[k] = (uint32_t)lc[k] | ((uint32_t)ll[k] << 16);
+    size_t k = 0;
+    while (k < nt) {
+      if (k + 4 <= nt && (uint32_t)(tok[k] | tok[k + 1] | tok[k + 2] | tok[k + 3]) < 256u) {   // four literals, one store
+        const uint32_t a = lit[tok[k]], b = lit[tok[k + 1]], c = lit[tok[k + 2]], d = lit[tok[k + 3]];
+        bw.add(a & 0xffffu, (int)(a >> 16));
+        bw.add(b & 0xffffu, (int)(b >> 16));
+        bw.add(c & 0xffffu, (int)(c >> 16));
+        bw.add(d & 0xffffu, (int)(d >> 16));
+        bw.flush();
+        k += 4;
+        continue;
+      }
+      const uint32_t t = tok[k++];
+      if (t < 256) {
+        bw.put(lit[t] & 0xffffu, (int)(lit[t] >> 16));
+      } else {
+        const LenCode& L = LT[t & 0x1ffu];
+        uint32_t bits = lc[L.sym];
+        int len = ll[L.sym];
+        bits |= (uint32_t)L.eval << len;
+        len += L.ebits;
+        bits |= (uint32_t)dc[0] << len;               // distance 1: code 0, no extra bits
+        len += dl[0];
+        bw.put(bits, len);                            // <= 12 + 5 + 1 bits
+      }
+    }
+    bw.flush();
+    bw.put(lc[256], ll[256]);
+    pos = end;
+  }
+  bw.finish();
+  const uLong ad = adler32(adler32(0L, Z_NULL, 0), in, (uInt)n);
+  uint8_t* q = bw.p;
+  q[0] = (uint8_t)(ad >> 24); q[1] = (uint8_t)(ad >> 16); q[2] = (uint8_t)(ad >> 8); q[3] = (uint8_t)ad;
+  out.len = (size_t)(q + 4 - out.data());
+}
+
 }  // namespace
 
 extern "C" int rr_png_info(const char* path, int32_t* w, int32_t* h, int32_t* channels, int32_t* bit_depth) {
@@ -184,23 +439,35 @@ extern "C" int rr_png_read_gray16(const char* path, uint16_t* out, int32_t H, in
 
 // RGBA PNG from its filtered scanlines: H rows of 1 + 4*W bytes (filter byte + filtered pixels).
 // strategy: 0 zlib's default (LZ77 + Huffman), 1 Z_RLE (run lengths + Huffman: on filtered image data as small as
-// level 1 of the default strategy or smaller, at half the time), 2 Z_HUFFMAN_ONLY.
+// level 1 of the default strategy or smaller, at half the time), 2 Z_HUFFMAN_ONLY, 3 the library's own run-length +
+// dynamic-Huffman encoder (fast_deflate above; `level` is ignored).
 extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int32_t W, int32_t H, int32_t level, int32_t strategy) {
-  if (!path || !rows || W <= 0 || H <= 0 || level < 0 || level > 9 || strategy < 0 || strategy > 2) return RR_E_ARG;
+  if (!path || !rows || W <= 0 || H <= 0 || level < 0 || level > 9 || strategy < 0 || strategy > 3) return RR_E_ARG;
   const uLong n = (uLong)H * (1 + 4 * (uLong)W);
-  z_stream zs;
-  memset(&zs, 0, sizeof(zs));
-  if (deflateInit2(&zs, level, Z_DEFLATED, 15, 9, strategy == 1 ? Z_RLE : strategy == 2 ? Z_HUFFMAN_ONLY : Z_DEFAULT_STRATEGY) != Z_OK)
-    return RR_E_PARSE;
-  std::vector<uint8_t> z(deflateBound(&zs, n));
-  zs.next_in = const_cast<Bytef*>(rows);
-  zs.avail_in = (uInt)n;
-  zs.next_out = z.data();
-  zs.avail_out = (uInt)z.size();
-  const int zrc = deflate(&zs, Z_FINISH);
-  const uLongf clen = zs.total_out;
-  deflateEnd(&zs);
-  if (zrc != Z_STREAM_END) return RR_E_PARSE;
+  std::vector<uint8_t> z;
+  ByteBuf zf;
+  const uint8_t* zdata = nullptr;
+  uLongf clen = 0;
+  if (strategy == 3) {
+    fast_deflate(rows, (size_t)n, zf);
+    zdata = zf.data();
+    clen = (uLongf)zf.len;
+  } else {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15, 9, strategy == 1 ? Z_RLE : strategy == 2 ? Z_HUFFMAN_ONLY : Z_DEFAULT_STRATEGY) != Z_OK)
+      return RR_E_PARSE;
+    z.resize(deflateBound(&zs, n));
+    zs.next_in = const_cast<Bytef*>(rows);
+    zs.avail_in = (uInt)n;
+    zs.next_out = z.data();
+    zs.avail_out = (uInt)z.size();
+    const int zrc = deflate(&zs, Z_FINISH);
+    clen = zs.total_out;
+    deflateEnd(&zs);
+    if (zrc != Z_STREAM_END) return RR_E_PARSE;
+    zdata = z.data();
+  }
   FILE* fh = fopen(path, "wb");
   if (!fh) return RR_E_ARG;
   auto put32 = [](uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
@@ -218,7 +485,19 @@ extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int
   put32(ihdr, (uint32_t)W);
   put32(ihdr + 4, (uint32_t)H);
   ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
-  bool ok = fwrite(sig, 1, 8, fh) == 8 && chunk("IHDR", ihdr, 13) && chunk("IDAT", z.data(), (uint32_t)clen) && chunk("IEND", nullptr, 0);
+  bool ok = fwrite(sig, 1, 8, fh) == 8 && chunk("IHDR", ihdr, 13) && chunk("IDAT", zdata, (uint32_t)clen) && chunk("IEND", nullptr, 0);
   ok = (fclose(fh) == 0) && ok;
   return ok ? RR_OK : RR_E_ARG;
+}
+
+// The zlib stream strategy 3 writes, for n arbitrary bytes: out must hold rr_deflate_bound(n) bytes; returns the stream's
+// length (tests inflate it with zlib and compare; scripts time it against zlib's strategies).
+extern "C" int64_t rr_deflate_bound(int64_t n) { return n + n / 4 + 4096; }
+extern "C" int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
+  if (!in || !out || n < 0) return RR_E_ARG;
+  ByteBuf z;
+  fast_deflate(in, (size_t)n, z);
+  if ((int64_t)z.len > cap) return RR_E_ARG;
+  memcpy(out, z.data(), z.len);
+  return (int64_t)z.len;
 }

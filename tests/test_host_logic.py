@@ -318,7 +318,7 @@ def test_native_png_codec(tmp_path):
     rows[:, 1:5] = flat[:, :4]
     rows[:, 5:] = flat[:, 4:] - flat[:, :-4]
     import os
-    for level, strategy in ((0, 0), (1, 0), (6, 0), (1, 1), (1, 2)):
+    for level, strategy in ((0, 0), (1, 0), (6, 0), (1, 1), (1, 2), (1, 3)):
         p = str(tmp_path / ('w%d%d.png' % (level, strategy)))
         imgops.png_from_scanlines(p, rows, ww, hh, level=level, strategy=strategy)
         assert np.array_equal(np.array(Image.open(p)), rgba)
@@ -326,6 +326,7 @@ def test_native_png_codec(tmp_path):
     imgops.write_png_rgba(str(tmp_path / 'py1.png'), rgba, level=1)
     assert open(str(tmp_path / 'py1.png'), 'rb').read() == open(str(tmp_path / 'w10.png'), 'rb').read()
     assert os.path.getsize(str(tmp_path / 'w11.png')) <= 1.02 * os.path.getsize(str(tmp_path / 'w10.png'))
+    assert os.path.getsize(str(tmp_path / 'w13.png')) <= 1.03 * os.path.getsize(str(tmp_path / 'w11.png'))      # own encoder vs Z_RLE
     imgops.write_png_rgba(str(tmp_path / 'py.png'), rgba)
     assert np.array_equal(np.array(Image.open(str(tmp_path / 'py.png'))), rgba)
 
@@ -343,3 +344,31 @@ def test_scene_directory_is_reused_only_for_the_same_simulation(tmp_path):
     c = h.Scene(tmp_path, 48, 80, 31, n_frames=2, seed0=5)               # another simulation: written again
     assert len(c.product_drops(0)) != len(a.product_drops(0)) or os.path.getmtime(xml) != t0
     assert open(xml + '.stamp').read() != repr(None)
+
+
+def test_own_deflate_round_trips_through_zlib():
+    """rr_deflate_fast (strategy 3 of the PNG writer: distance-1 runs + one dynamic Huffman code per 128 KB block) is an
+    ordinary zlib stream: zlib inflates it to the input, whatever the input -- empty, one byte, runs across block
+    borders and beyond the 258-byte match limit, incompressible noise, every byte value, skewed residuals."""
+    import zlib
+    lib = h.hb.load_library()
+    rng = np.random.RandomState(0)
+
+    def comp(b):
+        a = np.frombuffer(b, np.uint8) if len(b) else np.zeros(1, np.uint8)
+        cap = lib.rr_deflate_bound(len(b))
+        out = np.zeros(cap, np.uint8)
+        n = lib.rr_deflate_fast(a.ctypes.data, len(b), out.ctypes.data, cap)
+        assert n > 0
+        return out[:n].tobytes()
+    cases = [b'', b'a', b'ab', b'aaa', bytes(1000), bytes(300000), rng.bytes(1000), rng.bytes(300000), bytes(range(256)) * 3,
+             b'x' * 257, b'y' * 259, b'z' * 260, bytes(131072) + b'\x01' + bytes(131072 * 2 + 5), bytes(131071) + b'\x07' * 600,
+             b''.join(bytes([rng.randint(256)]) * int(rng.randint(1, 600)) for _ in range(2000)),
+             np.abs(rng.normal(0, 3, 400000)).astype(np.uint8).tobytes(),
+             np.abs(rng.normal(0, 0.3, 400000)).astype(np.uint8).tobytes()]
+    for b in cases:
+        z = comp(b)
+        assert zlib.decompress(z) == b
+        assert len(z) <= len(b) + len(b) // 50 + 64          # never much larger than the input
+    assert len(comp(bytes(300000))) < 1000
+    assert lib.rr_deflate_fast(None, 5, None, 0) < 0
