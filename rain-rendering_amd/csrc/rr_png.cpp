@@ -82,6 +82,29 @@ inline int paeth(int a, int b, int c) {
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// Paeth rows after their first pixel (BPP = bytes per pixel: 1, 2, 3, 4, 6 or 8)
+template <int BPP>
+void paeth_row(uint8_t* cur, const uint8_t* src, const uint8_t* up, size_t stride) {
+  int a[BPP], c[BPP];
+  for (int k = 0; k < BPP; k++) { a[k] = cur[k]; c[k] = up[k]; }
+  size_t i = BPP;
+  for (; i + BPP <= stride; i += BPP) {
+#pragma GCC unroll 8
+    for (int k = 0; k < BPP; k++) {
+      const int bb = up[i + k];
+      const int d1 = bb - c[k], d2 = a[k] - c[k];
+      const int pa = d1 < 0 ? -d1 : d1, pb = d2 < 0 ? -d2 : d2, pc = (d1 + d2) < 0 ? -(d1 + d2) : (d1 + d2);
+      // (selection by masks: on image data the three-way choice is unpredictable, a branch would miss every few bytes)
+      const int m2 = -(int)(pb <= pc), t1 = (bb & m2) | (c[k] & ~m2);
+      const int m1 = -(int)((pa <= pb) & (pa <= pc)), pred = (a[k] & m1) | (t1 & ~m1);
+      const int v = (uint8_t)(src[i + k] + pred);
+      cur[i + k] = (uint8_t)v;
+      a[k] = v;
+      c[k] = bb;
+    }
+  }
+}
+
 // inflate + reverse the scanline filters: `img` = h rows of `stride` bytes
 int decode(const Png& p, std::vector<uint8_t>& img, size_t& stride) {
   const int ch = channels_of(p.ctype);
@@ -92,26 +115,37 @@ int decode(const Png& p, std::vector<uint8_t>& img, size_t& stride) {
   uLongf out_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &out_len, p.idat.data(), (uLong)p.idat.size()) != Z_OK || out_len != raw.size()) return RR_E_PARSE;
   img.resize(stride * p.h);
+  const std::vector<uint8_t> zero(stride, 0);         // the row above the first one
   for (uint32_t y = 0; y < p.h; y++) {
     const uint8_t* src = &raw[(stride + 1) * y];
     const int ft = src[0];
     src++;
     uint8_t* cur = &img[stride * y];
-    const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+    const uint8_t* up = y ? &img[stride * (y - 1)] : zero.data();
+    const size_t lead = bpp < stride ? bpp : stride;  // the first pixel has no left neighbour
     switch (ft) {
       case 0: memcpy(cur, src, stride); break;
       case 1:
-        for (size_t i = 0; i < stride; i++) cur[i] = (uint8_t)(src[i] + (i >= bpp ? cur[i - bpp] : 0));
+        memcpy(cur, src, lead);
+        for (size_t i = lead; i < stride; i++) cur[i] = (uint8_t)(src[i] + cur[i - bpp]);
         break;
       case 2:
-        for (size_t i = 0; i < stride; i++) cur[i] = (uint8_t)(src[i] + (up ? up[i] : 0));
+        for (size_t i = 0; i < stride; i++) cur[i] = (uint8_t)(src[i] + up[i]);
         break;
       case 3:
-        for (size_t i = 0; i < stride; i++) cur[i] = (uint8_t)(src[i] + (((i >= bpp ? cur[i - bpp] : 0) + (up ? up[i] : 0)) >> 1));
+        for (size_t i = 0; i < lead; i++) cur[i] = (uint8_t)(src[i] + (up[i] >> 1));
+        for (size_t i = lead; i < stride; i++) cur[i] = (uint8_t)(src[i] + ((cur[i - bpp] + up[i]) >> 1));
         break;
       case 4:
-        for (size_t i = 0; i < stride; i++)
-          cur[i] = (uint8_t)(src[i] + paeth(i >= bpp ? cur[i - bpp] : 0, up ? up[i] : 0, (up && i >= bpp) ? up[i - bpp] : 0));
+        for (size_t i = 0; i < lead; i++) cur[i] = (uint8_t)(src[i] + up[i]);          // paeth(0, b, 0) = b
+        switch (bpp) {                                // left / upper-left neighbours stay in registers, one chain per channel
+          case 1: paeth_row<1>(cur, src, up, stride); break;
+          case 2: paeth_row<2>(cur, src, up, stride); break;
+          case 3: paeth_row<3>(cur, src, up, stride); break;
+          case 4: paeth_row<4>(cur, src, up, stride); break;
+          case 6: paeth_row<6>(cur, src, up, stride); break;
+          default: paeth_row<8>(cur, src, up, stride); break;
+        }
         break;
       default: return RR_E_PARSE;
     }
@@ -403,6 +437,18 @@ extern "C" int rr_png_read_bgr8(const char* path, uint8_t* out, int32_t H, int32
   size_t stride = 0;
   if ((rc = decode(p, img, stride))) return rc;
   const int ch = channels_of(p.ctype);
+  if (p.ctype == 2 || p.ctype == 6) {                 // RGB / RGBA: the datasets' case, without per-pixel decisions
+    for (int y = 0; y < H; y++) {
+      const uint8_t* s = &img[stride * y];
+      uint8_t* o = out + (size_t)y * W * 3;
+      for (int x = 0; x < W; x++, s += ch, o += 3) {
+        o[0] = s[2];
+        o[1] = s[1];
+        o[2] = s[0];
+      }
+    }
+    return RR_OK;
+  }
   for (int y = 0; y < H; y++) {
     const uint8_t* s = &img[stride * y];
     uint8_t* o = out + (size_t)y * W * 3;
