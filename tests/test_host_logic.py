@@ -372,3 +372,59 @@ def test_own_deflate_round_trips_through_zlib():
         assert len(z) <= len(b) + len(b) // 50 + 64          # never much larger than the input
     assert len(comp(bytes(300000))) < 1000
     assert lib.rr_deflate_fast(None, 5, None, 0) < 0
+
+
+def test_own_inflate_agrees_with_zlib_or_declines():
+    """rr_inflate_fast (the PNG readers' decoder) on zlib streams of every kind -- stored, fixed and dynamic blocks, all
+    levels, strategies and window sizes, flush points, the library's own encoder -- returns zlib's bytes; on damaged
+    streams it either declines (0: the reader falls back to zlib) or, like zlib, still yields what the stream says."""
+    import zlib
+    lib = h.hb.load_library()
+    rng = np.random.RandomState(7)
+
+    def inf(z, n):
+        a = np.frombuffer(bytes(z), np.uint8)
+        out = np.zeros(max(n, 1), np.uint8)
+        rc = lib.rr_inflate_fast(a.ctypes.data, len(z), out.ctypes.data, n)
+        return rc, out[:n].tobytes()
+
+    def gen(kind, n):
+        if kind == 0:
+            return rng.randint(0, 256, n).astype(np.uint8).tobytes()
+        if kind == 1:
+            return np.abs(rng.normal(0, rng.uniform(0.1, 40), n)).astype(np.uint8).tobytes()
+        if kind == 2:
+            return np.repeat(rng.randint(0, 256, n // 50 + 1).astype(np.uint8), rng.randint(1, 700, n // 50 + 1))[:n].tobytes()
+        if kind == 3:
+            return bytes([rng.randint(256)]) * n
+        if kind == 4:
+            return np.tile(rng.randint(0, 4, int(rng.randint(1, 40))).astype(np.uint8), n)[:n].tobytes()
+        words = [bytes(rng.randint(97, 123, int(rng.randint(2, 12))).astype(np.uint8)) for _ in range(100)]
+        return b' '.join(words[rng.randint(100)] for _ in range(n // 6 + 1))[:n]
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+    vouched = 0
+    for it in range(600):
+        n = int(rng.randint(1, 200000)) if it % 15 == 0 else int(rng.randint(1, 5000))
+        b = gen(it % 6, n)
+        c = zlib.compressobj(int(rng.randint(0, 10)), zlib.DEFLATED, int(rng.randint(9, 16)), int(rng.randint(1, 10)), strategies[rng.randint(5)])
+        z = c.compress(b)
+        if rng.rand() < 0.3:
+            z += c.flush(zlib.Z_FULL_FLUSH)
+        z += c.flush()
+        rc, d = inf(z, len(b))
+        assert rc == 1 and d == b, (it, n)
+        vouched += rc
+        assert inf(z, len(b) + 1)[0] == 0 and (len(b) < 2 or inf(z, len(b) - 1)[0] == 0)      # wrong size: declined
+    assert vouched == 600
+    for it in range(600):                                       # damaged streams
+        b = gen(it % 6, int(rng.randint(1, 3000)))
+        z = bytearray(zlib.compress(b, int(rng.randint(0, 10))))
+        if it % 3 == 0:
+            z[rng.randint(len(z))] ^= 1 << rng.randint(8)
+        elif it % 3 == 1:
+            z = z[:rng.randint(1, len(z))]
+        else:
+            z += bytes(int(rng.randint(1, 9)))
+        rc, d = inf(z, len(b))
+        if rc == 1:
+            assert d == zlib.decompress(bytes(z))
