@@ -264,4 +264,30 @@ int emu_blur_layout(int ew, int eh, int r1, int r2, int tw, int th, int bx, int 
   return bad;
 }
 
+// The compositor's short blend divides by the launch's exposure through its reciprocal: q0 = a * y, q = fma(fma(-q0, d, a), y, q0)
+// with y = 1 / d (k_composite).  Returns how many of n pseudo-random numerators (products alpha * tau like the kernel's,
+// and raw bit patterns over 400 binades) give a result that differs from a / d -- Markstein's theorem says none.
+int64_t emu_reciprocal_division_mismatches(double d, int64_t n, uint64_t seed) {
+  const double y = 1.0 / d;
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  int64_t bad = 0;
+  for (int64_t i = 0; i < n; i++) {
+    const uint64_t r = rnd();
+    double a;
+    if ((i & 3) == 0) {
+      const uint64_t e = 1023 - 200 + (r >> 52) % 400, bits = (e << 52) | (r & 0xFFFFFFFFFFFFFull);
+      memcpy(&a, &bits, 8);
+    } else {
+      const double A = (double)(r >> 11) * (1.0 / 9007199254740992.0);
+      const double tau = (double)(rnd() >> 11) * (50.0 / 9007199254740992.0);
+      a = A * tau;
+    }
+    const double q0 = a * y;
+    const double q = fma(fma(-q0, d, a), y, q0);
+    if (q != a / d) bad++;
+  }
+  return bad;
+}
+
 }  // extern "C"

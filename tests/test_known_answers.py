@@ -219,3 +219,20 @@ def test_kernel_rotation_by_right_angles_is_a_permutation(tmp_path):
         exp[yp, 1:] = t[sh - 1:0:-1, yp]
     assert np.array_equal(out, exp)
     assert np.array_equal(out, cvlike.resize_area(cvlike.rotate_bound(t, 0.0, -1.0), sh, sw))
+
+
+def test_division_by_the_exposure_through_its_reciprocal_is_exact():
+    """k_composite's short blend computes (A * tau) / exposure as q0 = a * y, fma(fma(-q0, d, a), y, q0) with y = 1 / d.
+    With y correctly rounded that is the correctly rounded quotient (Markstein) unless d's significand is all ones (the
+    kernel then divides); checked here with the host's fma on millions of numerators for the cameras' exposures and a
+    spread of other divisors."""
+    import ctypes
+    import os
+    import __graft_entry__ as ge
+    ge.build()
+    emu = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hostemu', 'libhostemu.so'))
+    emu.emu_reciprocal_division_mismatches.restype = ctypes.c_int64
+    emu.emu_reciprocal_division_mismatches.argtypes = [ctypes.c_double, ctypes.c_int64, ctypes.c_uint64]
+    divisors = [2e-3, 5e-3, 1e-3, 1.0 / 60, 1.0 / 30, 0.0166, 2.5e-3, 0.04, 3.0, 0.75, 1e-6, 123.456, 1.0 / 3, 0.1]
+    for k, d in enumerate(divisors):
+        assert emu.emu_reciprocal_division_mismatches(d, 3_000_000, k + 1) == 0, d
