@@ -130,6 +130,10 @@ typedef struct {
    * the 256-entry colour map given to rr_set_colormap (needs mask_f64 in the device-pointer entry points). */
   uint8_t* rainy_png;
   uint8_t* mask_png;
+  /* Optional: n_drops * 3 doubles, the B, G, R colour constants K of every drop: the tile colour the reference derives
+   * from the environment map inside the drop's field of view (bad_weather.py:397-412) is K * gray value.  Zeros for a
+   * drop that is not composited.  Lets the single-drop seam hand back the reference's `drop_vis` (bad_weather.py:462). */
+  double* drop_colour;
 } rr_frame_out;
 
 typedef struct {

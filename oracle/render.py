@@ -553,11 +553,25 @@ def fov_colour(env_map_xyY, solid_angle_map, poly_int, fc, faithful=True):
     return fov_xy_avg, drop_Y
 
 
+def _visible(drop, scene_depth, y0, x0, shape_hw):
+    """DEPTH-OCCLUSION OPTION (not in the reference's output; the reference only sketches a depth test in the dead
+    common/drop_depth_map.py behind USE_DEPTH_WEIGHTING = 0, generator.py:20,339-341).  Definition, shared with
+    tests/hostemu and the library's RR_OPT_DEPTH_OCCLUSION: a drop is HIDDEN at a pixel -- neither blended nor added to
+    the mask there -- iff its distance from the camera |world_position_start.z| is greater than the scene depth (metres)
+    at that pixel; a NaN depth hides nothing.  Returns the boolean "visible" map of the region the tile covers, or None
+    when no depth buffer is given (the reference's behaviour)."""
+    if scene_depth is None:
+        return None
+    region = scene_depth[y0:y0 + shape_hw[0], x0:x0 + shape_hw[1]].astype(np.float64)
+    return ~(abs(float(drop.world_position_start[2])) > region)
+
+
 def add_drop_to_image(env_map_xyY, solid_angle_map, fc, drop_fov_pts, drop_minC, bg_shape, rainy_bg, rainy_mask,
-                      tile, drop, cam, opacity_attenuation=1.0, faithful=True, rendering_strategy=None):
+                      tile, drop, cam, opacity_attenuation=1.0, faithful=True, rendering_strategy=None, scene_depth=None):
     """bad_weather.py:336-462: the default rendering strategy and 'white' ('naive_db' reads a
     non-existent attribute in the reference, bad_weather.py:355, and cannot run).  Raises (like
-    the reference) when the drop must be skipped; the caller turns that into a status."""
+    the reference) when the drop must be skipped; the caller turns that into a status.  Returns the reference's
+    (drop_vis, drop_blend, drop_minC) (:462).  scene_depth (H x W metres): the depth-occlusion option, see _visible."""
     exposure_time = cam['exposure_ms'] / 1000.
     if rendering_strategy in ['white']:
         # bad_weather.py:349-353: gray tile, no colour, no defocus, no clamp of the origin
@@ -574,10 +588,14 @@ def add_drop_to_image(env_map_xyY, solid_angle_map, fc, drop_fov_pts, drop_minC,
         rainy_bg_occ = ((1. - ((drop_vis_alpha_ * tau_one) / exposure_time)) * rainy_bg_occ) + drop_vis[:, :, :3] * (
             tau_one / tau_zero)
         rainy_bg_occ = np.clip(rainy_bg_occ, 0, 1)
+        vis = _visible(drop, scene_depth, y0, x0, tile.shape[:2])
+        if vis is not None:
+            rainy_bg_occ = np.where(vis[..., None], rainy_bg_occ, rainy_bg[y0:y0 + tile.shape[0], x0:x0 + tile.shape[1], :])
+            drop_vis_alpha = np.where(vis, drop_vis_alpha, 0.0)
         rainy_mask_occ += drop_vis_alpha
         rainy_bg[y0:y0 + rainy_bg_occ.shape[0], x0:x0 + rainy_bg_occ.shape[1]] = rainy_bg_occ
         rainy_mask[y0:y0 + tile.shape[0], x0:x0 + tile.shape[1]] = rainy_mask_occ
-        return drop_minC
+        return drop_vis, rainy_bg_occ, drop_minC
     if len(drop_fov_pts) == 0:
         raise IndexError(ST_FOV_FAIL)                # pyclipper.AddPath on an empty path
     if not np.all(np.isfinite(drop_fov_pts)):
@@ -627,10 +645,14 @@ def add_drop_to_image(env_map_xyY, solid_angle_map, fc, drop_fov_pts, drop_minC,
     rainy_bg_occ = ((1. - ((drop_vis_alpha_ * tau_one) / exposure_time)) * rainy_bg_occ) + drop_vis[:, :, :3] * (
         tau_one / tau_zero)
     rainy_bg_occ = np.clip(rainy_bg_occ, 0, 1)
+    vis = _visible(drop, scene_depth, y0, x0, tile.shape[:2])
+    if vis is not None:
+        rainy_bg_occ = np.where(vis[..., None], rainy_bg_occ, rainy_bg[y0:y0 + tile.shape[0], x0:x0 + tile.shape[1], :])
+        drop_vis_alpha = np.where(vis, drop_vis_alpha, 0.0)
     rainy_mask_occ += drop_vis_alpha
     rainy_bg[y0:y0 + rainy_bg_occ.shape[0], x0:x0 + rainy_bg_occ.shape[1]] = rainy_bg_occ
     rainy_mask[y0:y0 + tile.shape[0], x0:x0 + tile.shape[1]] = rainy_mask_occ
-    return drop_minC
+    return drop_vis, rainy_bg_occ, drop_minC
 
 
 # ----------------------------------------------------------------------------
@@ -659,13 +681,14 @@ def quantise_mask(rainy_mask):
 
 def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textures, ratio, cam,
                  frame_seed, noise_std=0.0, noise_scale=0.0, opacity_attenuation=1.0,
-                 faithful=True, max_drops=None, rendering_strategy=None, first_drop=0):
+                 faithful=True, max_drops=None, rendering_strategy=None, first_drop=0, scene_depth=None):
     """The hot loop of Generator.run for one frame (generator.py:318,389-394,428-438,461-467).
 
     streak_list: the already filtered list of Streak objects (mutated like the reference does).
     first_drop > 0 renders the window [first_drop, max_drops) only: the earlier drops still consume their
     random draws (so the window sees the reference's RNG stream) but are not composited (test windows;
     noise-free scenes only, since the skipped drops' in-place end-point rotation is not replayed).
+    scene_depth (H x W, metres): the depth-occlusion OPTION (default None = the reference's output), see _visible.
     Returns dict(rainy_bg f64, mask f64, mask_i32, image_u8 RGB, status int32[n])."""
     np.random.seed(frame_seed)                        # generator.py:318
     H, W = bg.shape[:2]
@@ -687,7 +710,7 @@ def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textur
                                        RADIUS, FOV_DEG, N_FOV, env_map_xyY.shape)
         try:
             add_drop_to_image(env_map_xyY, solid_angle_map, fc, pts, minC, bg.shape, rainy_bg, rainy_mask,
-                              tile, drop, cam, opacity_attenuation, faithful, rendering_strategy)
+                              tile, drop, cam, opacity_attenuation, faithful, rendering_strategy, scene_depth)
         except IndexError as e:                       # generator.py:185-189: any exception == skip
             status[i] = e.args[0] if e.args and isinstance(e.args[0], int) else ST_FOV_FAIL
     return dict(rainy_bg=rainy_bg, mask=rainy_mask, mask_i32=quantise_mask(rainy_mask),

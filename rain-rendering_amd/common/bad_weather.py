@@ -382,6 +382,22 @@ class RainRenderer:
                          [x1 - minx + epsilon, y1 - miny]])
         return p1, p2, np.array([maxx, maxy]), np.array([minx, miny])
 
+    def placed_tile(self, drop_minC, tw, th, drop_distance, imW, imH):
+        """Where a tw x th tile anchored at drop_minC ends up, as the reference leaves it: (drop_minC, rows, columns) after
+        the defocus pad shift = int(10 c) (bad_weather.py:291-295), the clamp of the origin into the frame (:418-419) and
+        the crop of what that cut off (:420-422).  drop_distance None = rendering_strategy 'white' (:349-353): no pad,
+        no clamp."""
+        if drop_distance is None:
+            return np.array(drop_minC), th, tw
+        shift = int(10 * abs(self.compute_circle(abs(drop_distance))))
+        tmp = np.array([int(drop_minC[0]) - shift, int(drop_minC[1]) - shift])
+        min_c = np.array([np.clip(tmp[0], 0, imW), np.clip(tmp[1], 0, imH)])
+        delta = min_c - tmp                                   # > 0: rows / columns cut off at the top / left border
+        ph, pw = th + 2 * shift, tw + 2 * shift
+        ph = len(range(ph)[:delta[1]]) if delta[1] < 0 else max(ph - delta[1], 0)
+        pw = len(range(pw)[:delta[0]]) if delta[0] < 0 else max(pw - delta[0], 0)
+        return min_c, ph, pw
+
     def _ctx(self, dataset):
         """The library context behind the single-drop seam (created on first use; Generator.run shares its own)."""
         from . import db as settings_db
@@ -400,18 +416,27 @@ class RainRenderer:
     def add_drop_to_image(self, dataset, env_map_xyY, solid_angle_map, drop_fov_pts, drop_minC, bg, rainy_bg,
                           rainy_mask, rainy_saturation_mask, drop, drop_dict, irrad_type, rendering_strategy,
                           opacity_attenuation=1.0):
-        """The reference's inner seam, same signature (bad_weather.py:336-462): composite ONE caller-made tile `drop`
-        (H x W x 4, gray with alpha, as Generator.compute_drop builds it) whose field-of-view polygon is `drop_fov_pts`
-        and whose position is `drop_minC` into rainy_bg / rainy_mask -- in place and returned.  Colour from the
-        environment map, defocus, placement, blend and mask accumulation run in the library (rr_ext_tile entry of
-        rr_render_frames: one launch chain per call -- use Generator.run / rr_render_frames for throughput).
+        """The reference's inner seam, same signature and the same SIX return values (bad_weather.py:336-462):
+        composite ONE caller-made tile `drop` (H x W x 4, gray with alpha, as Generator.compute_drop builds it) whose
+        field-of-view polygon is `drop_fov_pts` and whose position is `drop_minC` into rainy_bg / rainy_mask -- in place
+        and returned -- and hand back
+
+            (rainy_bg, rainy_mask, rainy_saturation_mask, drop_vis, drop_blend, drop_minC)
+
+        as the reference does (:462): `drop_vis` the coloured, defocused tile cropped to the frame (h x w x 4: alpha =
+        what was added to the mask, colour = alpha x the drop's colour constants), `drop_blend` the blended image region
+        under it (h x w x 3) and `drop_minC` the tile's clamped position (:418-419) -- what the reference's caller passes
+        on to make_rain_layer (generator.py:437-438).  Colour from the environment map, defocus, placement, blend and mask
+        accumulation run in the library (rr_ext_tile entry of rr_render_frames: one launch chain per call -- use
+        Generator.run / rr_render_frames for throughput).
 
         Like the reference, a drop that cannot be rendered (empty polygon, polygon off the map, non-finite circle of
         confusion) raises; Generator.compute_drop catches that (generator.py:180-189).  rainy_saturation_mask is passed
-        through untouched and blended_drop is None: both are dead outputs in the reference (never read after the loop)."""
+        through untouched: it is a dead output in the reference (never read after the loop)."""
         from .. import hip_backend
         hip = self._ctx(dataset)
-        alpha = np.ascontiguousarray(np.asarray(drop)[..., 3] if np.asarray(drop).ndim == 3 else drop, np.float64)
+        tile = np.asarray(drop)
+        alpha = np.ascontiguousarray(tile[..., 3] if tile.ndim == 3 else tile, np.float64)
         rec = np.zeros(1, hip_backend.DROP_DTYPE)
         rec['x0'], rec['y0'] = int(drop_minC[0]), int(drop_minC[1])
         rec['x1'], rec['y1'] = rec['x0'], rec['y0']
@@ -428,13 +453,36 @@ class RainRenderer:
         poly = None if white else np.asarray(drop_fov_pts, np.float64).reshape(-1, 2)
         out = hip.render_frames([dict(bg=bg, rainy_bg=rainy_bg, env_xyY=env_map_xyY, omega=solid_angle_map, drops=rec,
                                       ext=[dict(alpha=alpha, minC=(int(drop_minC[0]), int(drop_minC[1])), poly=poly)],
-                                      opacity_attenuation=opacity_attenuation, strategy=1 if white else 0)])[0]
+                                      opacity_attenuation=opacity_attenuation, strategy=1 if white else 0)],
+                                want_colour=True)[0]
         if out['status'][0] != 0:
             raise IndexError("drop not rendered (status %d: 1 no field of view, 2 field of view off the map, 3/4 circle of "
                              "confusion)" % out['status'][0])
         rainy_bg[...] = out['rainy_bg']
         rainy_mask += out['mask']
-        return rainy_bg, rainy_mask, rainy_saturation_mask, None
+        min_c, th, tw = self.placed_tile(drop_minC, alpha.shape[1], alpha.shape[0], None if white else drop_dict.world_position_start[2],
+                                         np.asarray(bg).shape[1], np.asarray(bg).shape[0])
+        y0, x0 = int(min_c[1]), int(min_c[0])
+        drop_blend = rainy_bg[y0:y0 + th, x0:x0 + tw, :].copy()
+        if white:
+            drop_vis = tile[:drop_blend.shape[0], :drop_blend.shape[1]]
+        else:
+            a_vis = out['mask'][y0:y0 + th, x0:x0 + tw]
+            drop_vis = np.dstack([a_vis * out['colour'][0, 0], a_vis * out['colour'][0, 1], a_vis * out['colour'][0, 2], a_vis])
+        return rainy_bg, rainy_mask, rainy_saturation_mask, drop_vis, drop_blend, min_c
+
+    @staticmethod
+    def make_rain_layer(drop, blended_drop, rain_layer, mask, drop_min_C):
+        """reference bad_weather.py:482-495 (a dead output there: rain_layer is never read after the loop; kept so that a
+        reference-shaped caller of the seam above runs unchanged): where the mask is wet under the tile, alpha 255 and the
+        channel-wise maximum of the layer and the blended drop."""
+        x, y = int(drop_min_C[0]), int(drop_min_C[1])
+        h, w = drop.shape[:2]
+        region = rain_layer[y:y + h, x:x + w]
+        wet = mask[y:y + h, x:x + w] > 0
+        region[..., 3][wet] = 255
+        region[..., :3][wet] = np.maximum(region[..., :3][wet], blended_drop[wet])
+        return rain_layer
 
 
 class FovComputation:

@@ -203,10 +203,12 @@ class Generator:
         """Single-drop compatibility seam with the reference's signature (generator.py:119-191):
         consumes the same RNG draws, composites ONE streak into rainy_bg / rainy_mask (in place and
         returned) by calling the library with a one-record drop table.  self.env_map_xyY,
-        self.solid_angle_map, self.db and the camera must be set like Generator.run does.  Returns
-        (rainy_bg, rainy_mask, rainy_saturation_mask, None, blended, minC): `blended` is None when the
-        reference would have printed "Erroneous drop"; the tile itself stays on the GPU.  One launch
-        chain per drop -- use run() / rr_render_frames for throughput."""
+        self.solid_angle_map, self.db and the camera must be set like Generator.run does.  Returns the
+        reference's six values (rainy_bg, rainy_mask, rainy_saturation_mask, drop, blended_drop, minC):
+        `drop` the coloured, defocused tile as placed (h x w x 4), `blended_drop` the image region under
+        it after the blend, `minC` its clamped position -- or, where the reference prints "Erroneous
+        drop", blended_drop None, drop None and the un-clamped minC.  One launch chain per drop -- use
+        run() / rr_render_frames for throughput."""
         H, W = bg.shape[:2]
         t = drop_dict._table if hasattr(drop_dict, '_table') else None
         if t is None:
@@ -222,18 +224,33 @@ class Generator:
         if hasattr(drop_dict, 'image_position_start'):        # the in-place endpoint rotation (generator.py:152-161)
             drop_dict.image_position_start[:] = t.ips[0]
             drop_dict.image_position_end[:] = t.ipe[0]
+        white = self.rendering_strategy == 'white'
         out = self._hip_ctx().render_frames([dict(bg=bg, rainy_bg=rainy_bg, env_xyY=self.env_map_xyY,
                                                   omega=self.solid_angle_map, drops=drops,
                                                   opacity_attenuation=self.opacity_attenuation,
-                                                  strategy=1 if self.rendering_strategy == 'white' else 0)])[0]
-        ok = out['status'][0] == 0
-        if ok:
-            rainy_bg[...] = out['rainy_bg']
-            rainy_mask += out['mask']
+                                                  strategy=1 if white else 0)], want_colour=True)[0]
+        # the raw tile's frame (generator.py:126-132 Big, :166-171 otherwise)
+        x0, y0, x1, y1 = (int(drops[k][0]) for k in ('x0', 'y0', 'x1', 'y1'))
+        if int(drops['type'][0]) == 0:
+            _, _, maxC, minC = RainRenderer.warping_points(drop_dict, self.db.streaks_light[int(drops['tex_index'][0])], W, H)
+            shape = np.subtract(maxC, minC).astype(int)
+            tw, th = max(shape[0], 1), max(shape[1], 1)
         else:
+            tw, th = max(abs(x1 - x0), int(drops['max_width'][0]) + 2), max(abs(y1 - y0), 2)
+            minC = np.array([x0, y0])
+        if out['status'][0] != 0:
             print('Erroneous drop (status %d)' % out['status'][0])
-        minC = np.array([drops['x0'][0], drops['y0'][0]])
-        return rainy_bg, rainy_mask, rainy_saturation_mask, None, (rainy_bg if ok else None), minC
+            return rainy_bg, rainy_mask, rainy_saturation_mask, None, None, minC
+        rainy_bg[...] = out['rainy_bg']
+        rainy_mask += out['mask']
+        renderer = self.renderer or RainRenderer(self.focal, self.f_number, 6, 10, 165)
+        min_c, ph, pw = renderer.placed_tile(minC, tw, th, None if white else drop_dict.world_position_start[2], W, H)
+        ys, xs = int(min_c[1]), int(min_c[0])
+        blended = rainy_bg[ys:ys + ph, xs:xs + pw, :].copy()
+        a_vis = out['mask'][ys:ys + ph, xs:xs + pw]
+        K = out['colour'][0]
+        drop = np.dstack([a_vis * K[0], a_vis * K[1], a_vis * K[2], a_vis])
+        return rainy_bg, rainy_mask, rainy_saturation_mask, drop, blended, min_c
 
     def _resolve_out_dir(self, out_dir):
         """generator.py:213-226.  Under several ranks the choice (incl. the _copyNNNNN shift of 'rename_folder') is made

@@ -59,6 +59,7 @@ struct FrameDesc {
   uint8_t* png_mask;               // optional: same for the colour-mapped rain mask
   const void* depth;               // optional (RR_OPT_DEPTH_OCCLUSION): scene depth in metres, H*W float32 / float64
   const rr_ext_tile* ext;          // optional: caller-made tiles / FOV polygons per drop (device pointers inside)
+  double* colour_out;              // optional: n_drops * 3 colour constants (rr_frame_out.drop_colour)
   int32_t depth_f64;
   int32_t n_drops;
   int32_t strategy;
@@ -884,6 +885,10 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   }
   sc.comp[gi] = rec;
   sc.bbox[gi] = make_int4(rec.x0, rec.y0, rec.x1, rec.y1);
+  if (fr.colour_out) {
+    const global_ptr<double> ko = as_global(fr.colour_out) + (int64_t)i * 3;
+    ko[0] = rec.K[0]; ko[1] = rec.K[1]; ko[2] = rec.K[2];
+  }
   if (fr.status) as_global(fr.status)[i] = status;
 }
 
@@ -2177,6 +2182,7 @@ struct rr_ctx {
     rr_drop* drops = nullptr;
     uint8_t* rgb = nullptr;
     int32_t *mask_i = nullptr, *status = nullptr;
+    double* colour = nullptr;        // rr_frame_out.drop_colour
     double* depth = nullptr;         // pre-pass input (float32 or float64 per frame slot of 8 bytes/pixel)
     uint8_t* bg8 = nullptr;          // pre-pass input given as bytes (rr_prepass_in.bg_u8)
     uint8_t* env_u8 = nullptr;
@@ -2441,6 +2447,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.depth = ctx->depth_occlusion ? in[f].depth : nullptr;
     fd.depth_f64 = in[f].depth_f64;
     fd.ext = in[f].ext;
+    fd.colour_out = out[f].drop_colour;
     fd.n_drops = in[f].n_drops;
     fd.strategy = in[f].strategy;
     fd.opacity = in[f].opacity_attenuation;
@@ -2818,6 +2825,7 @@ int rr_destroy(rr_ctx* ctx) {
     hipFree(sl.st.rgb);
     hipFree(sl.st.mask_i);
     hipFree(sl.st.status);
+    hipFree(sl.st.colour);
     hipFree(sl.st.depth);
     hipFree(sl.st.env_u8);
     hipFree(sl.st.bg8);
@@ -2991,6 +2999,7 @@ int slot_reserve(rr_ctx* ctx, rr_ctx::Staging& st, int n, int max_drops, const D
     if ((rc = dev_alloc(ctx, st.rgb, F * px * 3))) return rc;
     if ((rc = dev_alloc(ctx, st.mask_i, F * px))) return rc;
     if ((rc = dev_alloc(ctx, st.status, (size_t)F * D))) return rc;
+    if ((rc = dev_alloc(ctx, st.colour, (size_t)F * D * 3))) return rc;
     if ((rc = dev_alloc(ctx, st.depth, F * px))) return rc;
     if ((rc = dev_alloc(ctx, st.env_u8, F * ex * 3))) return rc;
     if ((rc = dev_alloc(ctx, st.bg8, F * px * 3))) return rc;
@@ -3172,6 +3181,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     dout[f].mask_f64 = st.mask + f * px;
     dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * px : nullptr;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
+    dout[f].drop_colour = out[f].drop_colour ? st.colour + (size_t)f * st.drops_cap * 3 : nullptr;
     din[f].ext = nullptr;
     if (in[f].ext && in[f].n_drops > 0) {
       // caller-made tiles (the single-drop seam; not a throughput path): one device blob per frame =
@@ -3228,6 +3238,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     if (out[f].mask_f64) down.add(out[f].mask_f64, dout[f].mask_f64, px * sizeof(double));
     if (out[f].mask_i32) down.add(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t));
     if (out[f].drop_status) down.add(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * (size_t)in[f].n_drops);
+    if (out[f].drop_colour) down.add(out[f].drop_colour, dout[f].drop_colour, sizeof(double) * 3 * (size_t)in[f].n_drops);
     if (out[f].rainy_png) down.add(out[f].rainy_png, dout[f].rainy_png, png_bytes);
     if (out[f].mask_png) down.add(out[f].mask_png, dout[f].mask_png, png_bytes);
   }

@@ -55,7 +55,7 @@ class rr_ext_tile(ctypes.Structure):
 class rr_frame_out(ctypes.Structure):
     _fields_ = [('rainy_rgb', ctypes.c_void_p), ('rainy_bg_out', ctypes.c_void_p), ('mask_f64', ctypes.c_void_p),
                 ('mask_i32', ctypes.c_void_p), ('drop_status', ctypes.c_void_p),
-                ('rainy_png', ctypes.c_void_p), ('mask_png', ctypes.c_void_p)]
+                ('rainy_png', ctypes.c_void_p), ('mask_png', ctypes.c_void_p), ('drop_colour', ctypes.c_void_p)]
 
 
 class rr_kernel_stat(ctypes.Structure):
@@ -532,10 +532,10 @@ class RainHip:
         self.cam = cam
         self._check(self.lib.rr_set_camera(self.h, ctypes.byref(cam)), 'rr_set_camera')
 
-    def render_frames(self, frames, want_composite=True):
+    def render_frames(self, frames, want_composite=True, want_colour=False):
         """frames: list of dict(bg, rainy_bg, env_xyY, omega, drops[, opacity_attenuation]) with
         C-contiguous float64 arrays and a DROP_DTYPE drop table.  Returns a list of
-        dict(image_u8 RGB, rainy_bg, mask, mask_i32, status)."""
+        dict(image_u8 RGB, rainy_bg, mask, mask_i32, status[, colour = (n, 3) BGR colour constants])."""
         n = len(frames)
         fin = (rr_frame_in * n)()
         fout = (rr_frame_out * n)()
@@ -554,6 +554,9 @@ class RainHip:
                      rainy_bg=np.zeros((H, W, 3), np.float64) if want_composite else None,
                      mask=np.zeros((H, W), np.float64), mask_i32=np.zeros((H, W), np.int32),
                      status=np.zeros(len(drops), np.int32))
+            if want_colour:
+                o['colour'] = np.zeros((len(drops), 3), np.float64)
+                fout[k].drop_colour = _ptr(o['colour']) if len(drops) else None
             fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, He, We
             fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY, fin[k].omega = _ptr(bg), _ptr(rb), _ptr(env), _ptr(om)
             fin[k].drops = _ptr(drops) if len(drops) else None

@@ -68,7 +68,7 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def emu_render(scene, bg, rainy_bg, env_xyY, drops, opacity=1.0, strategy=0):
+def emu_render(scene, bg, rainy_bg, env_xyY, drops, opacity=1.0, strategy=0, depth=None):
     emu = hostemu()
     texels, hs, ws, offs = hb.pack_streak_db(scene.db.streaks_light)
     H, W = bg.shape[:2]
@@ -76,21 +76,25 @@ def emu_render(scene, bg, rainy_bg, env_xyY, drops, opacity=1.0, strategy=0):
     out = dict(image_u8=np.zeros((H, W, 3), np.uint8), rainy_bg=np.zeros((H, W, 3)), mask=np.zeros((H, W)),
                mask_i32=np.zeros((H, W), np.int32), status=np.zeros(max(n, 1), np.int32), K=np.zeros((max(n, 1), 3)))
     drops = np.ascontiguousarray(drops)
-    emu.emu_render_frame(H, W, scene.He, scene.We, _p(bg), _p(rainy_bg), _p(env_xyY), _p(scene.omega), _p(drops), n,
-                         ctypes.byref(scene.cam), ctypes.c_double(opacity), _p(texels), _p(hs), _p(ws), _p(offs),
-                         _p(out['image_u8']), _p(out['rainy_bg']), _p(out['mask']), _p(out['mask_i32']), _p(out['status']),
-                         _p(out['K']), int(strategy))
+    if depth is not None:
+        depth = np.ascontiguousarray(depth, np.float32 if np.asarray(depth).dtype == np.float32 else np.float64)
+        assert depth.shape == (H, W)
+    emu.emu_render_frame_depth(H, W, scene.He, scene.We, _p(bg), _p(rainy_bg), _p(env_xyY), _p(scene.omega), _p(drops), n,
+                               ctypes.byref(scene.cam), ctypes.c_double(opacity), _p(texels), _p(hs), _p(ws), _p(offs),
+                               _p(out['image_u8']), _p(out['rainy_bg']), _p(out['mask']), _p(out['mask_i32']), _p(out['status']),
+                               _p(out['K']), int(strategy), _p(depth) if depth is not None else None,
+                               1 if depth is not None and depth.dtype == np.float64 else 0)
     out['status'] = out['status'][:n]
     return out
 
 
 def oracle_render(scene, i, bg, rainy_bg, env_xyY, faithful=True, noise_std=0.0, noise_scale=0.0, max_drops=None, strategy=None,
-                  first_drop=0):
+                  first_drop=0, scene_depth=None):
     textures, ratio = scene.oracle_db()
     streaks = scene.oracle_streaks(i)
     return orc.render_frame(bg, rainy_bg, env_xyY, scene.omega, streaks, textures, ratio, scene.ocam, frame_seed=i,
                             noise_std=noise_std, noise_scale=noise_scale, faithful=faithful, max_drops=max_drops,
-                            rendering_strategy=strategy, first_drop=first_drop)
+                            rendering_strategy=strategy, first_drop=first_drop, scene_depth=scene_depth)
 
 
 def prepass_scene(H, W, seed, dtype=np.float32):

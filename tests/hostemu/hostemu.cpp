@@ -79,11 +79,14 @@ int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, con
   return 0;
 }
 
-// whole frame, mirroring the kernel chain
-int emu_render_frame(int H, int W, int He, int We, const double* bg, const double* rainy_bg, const double* env,
-                     const double* omega, const rr_drop* drops, int n, const rr_camera* cam, double opacity,
-                     const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                     uint8_t* rgb, double* comp_out, double* mask, int32_t* mask_i32, int32_t* status, double* Kout, int strategy) {
+// whole frame, mirroring the kernel chain.  depth (may be NULL): the depth-occlusion OPTION (RR_OPT_DEPTH_OCCLUSION;
+// definition: oracle/render.py _visible) -- H*W scene depth in metres, float32 or float64; a drop whose |world z| is
+// greater than the scene depth at a pixel is neither blended nor added to the mask there.
+int emu_render_frame_depth(int H, int W, int He, int We, const double* bg, const double* rainy_bg, const double* env,
+                           const double* omega, const rr_drop* drops, int n, const rr_camera* cam, double opacity,
+                           const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                           uint8_t* rgb, double* comp_out, double* mask, int32_t* mask_i32, int32_t* status, double* Kout, int strategy,
+                           const void* depth, int depth_f64) {
   Dims dm{H, W, He, We};
   // prefix table + frame constants
   std::vector<double> P((size_t)He * (We + 1) * 4, 0.0);
@@ -114,6 +117,7 @@ int emu_render_frame(int H, int W, int He, int We, const double* bg, const doubl
     if (p.status != RR_DROP_OK || np_ == 0) size = 0;
     CompRec& rec = recs[i];
     memset(&rec, 0, sizeof(rec));
+    rec.zdist = fabs(drops[i].wps[2]);
     int st = p.status;
     if (strategy == 1) {                    // 'white': no colour, no FOV dependency
       if (size > 0) {
@@ -161,6 +165,10 @@ int emu_render_frame(int H, int W, int He, int We, const double* bg, const doubl
       for (int x = r.x0; x < r.x1; x++) {
         double A = tiles[i][(size_t)(y + r.oy) * r.pitch + (x + r.ox)];
         size_t pix = (size_t)y * W + x;
+        if (depth) {
+          const double scene = depth_f64 ? ((const double*)depth)[pix] : (double)((const float*)depth)[pix];
+          if (r.zdist > scene) continue;
+        }
         blend_pixel(A, r.tau_one, cam->exposure_s, r.g, r.K, comp_out + pix * 3, mask[pix]);
       }
   }
@@ -178,6 +186,13 @@ int emu_render_frame(int H, int W, int He, int We, const double* bg, const doubl
   return 0;
 }
 
+int emu_render_frame(int H, int W, int He, int We, const double* bg, const double* rainy_bg, const double* env,
+                     const double* omega, const rr_drop* drops, int n, const rr_camera* cam, double opacity,
+                     const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
+                     uint8_t* rgb, double* comp_out, double* mask, int32_t* mask_i32, int32_t* status, double* Kout, int strategy) {
+  return emu_render_frame_depth(H, W, He, We, bg, rainy_bg, env, omega, drops, n, cam, opacity, texels, tex_h, tex_w, tex_off, rgb,
+                                comp_out, mask, mask_i32, status, Kout, strategy, nullptr, 0);
+}
 
 // Pre-pass of one frame (fog + environment map) with the per-pixel bodies of rr_prepass.h.
 // rainy: H*W*3, env_xyY: H*We*3, env_u8: H*We*3 (We = cw + 2*(cw/2)); returns We or < 0.

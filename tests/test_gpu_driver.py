@@ -82,15 +82,24 @@ def test_compute_drop_seam_equals_batched_call(tmp_path, built):
     g = gen_mod.Generator.__new__(gen_mod.Generator)
     g.db, g._hip, g.noise_std, g.noise_scale, g.opacity_attenuation, g.rendering_strategy = sc2.db, rh, 0.0, 0.0, 1.0, None
     g.env_map_xyY, g.solid_angle_map = env, sc2.omega
+    g.renderer = h.bw.RainRenderer(focal=sc2.ocam['focal_m'], f_number=sc2.ocam['f_number'], focus_plane=6, radius=10, fov=165)
     fr = list(sc2.db.streaks_simulator.values())[0]
     keep = h.hb.filter_streaks(fr.table, 96, 64)
     streaks = [fr.table.streak(int(i)) for i in keep]
     np.random.seed(0)
     rainy, mask, sat = bg.copy(), np.zeros((64, 96)), np.zeros((64, 96, 3))
+    rain_layer = np.zeros((64, 96, 4))
     skipped = 0
-    for s in streaks:
-        rainy, mask, sat, _, blended, _ = g.compute_drop(bg, s, rainy, mask, sat)
+    for s in streaks:                                  # the reference's loop body (generator.py:431-438)
+        rainy, mask, sat, drop, blended, minC = g.compute_drop(bg, s, rainy, mask, sat)
+        if blended is not None:
+            assert drop.shape[:2] == blended.shape[:2] and drop.shape[2] == 4
+            # the returned tile sits where the blend happened: its alpha is what the mask gained there
+            ys, xs = int(minC[1]), int(minC[0])
+            assert np.array_equal(blended, rainy[ys:ys + blended.shape[0], xs:xs + blended.shape[1]])
+            rain_layer = g.renderer.make_rain_layer(drop, blended, rain_layer, mask, minC)
         skipped += blended is None
+    assert np.array_equal(rain_layer[..., 3] > 0, mask > 0)
     assert skipped == int(np.count_nonzero(batched['status']))
     assert np.array_equal(mask, batched['mask'])
     assert np.array_equal(rainy, batched['rainy_bg'])

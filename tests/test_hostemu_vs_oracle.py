@@ -70,3 +70,23 @@ def test_hostemu_matches_oracle_on_baseline_configs(tmp_path, name, window):
     assert np.array_equal(emu['mask_i32'], ref['mask_i32'])
     assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
     assert (emu['status'] == 0).sum() > 0.8 * len(drops)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_depth_occlusion_hostemu_matches_oracle(tmp_path, dtype):
+    """The depth-occlusion OPTION (RR_OPT_DEPTH_OCCLUSION; default off, not part of the reference's output) has two
+    independent statements outside the library -- oracle/render.py (_visible, numpy) and tests/hostemu (C++ loops):
+    they must agree bit for bit before the GPU tier compares the HIP option with both."""
+    import test_gpu_depth_occlusion as tdo
+    H, W = 128, 256
+    sc = h.Scene(tmp_path, H, W, 400, seed0=21)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    depth = tdo._scene_depth(H, W, np.abs(drops['wps'][:, 2]), dtype)
+    emu = h.emu_render(sc, bg, bg, env, drops, depth=depth)
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=False, scene_depth=depth)
+    base = h.emu_render(sc, bg, bg, env, drops)
+    assert np.array_equal(emu['status'], ref['status'])
+    assert np.array_equal(emu['mask'], ref['mask']) and np.array_equal(emu['mask_i32'], ref['mask_i32'])
+    assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+    assert 0.2 * base['mask'].sum() < emu['mask'].sum() < 0.9 * base['mask'].sum()

@@ -289,25 +289,24 @@ def test_int32_mask_equals_untouched_reference(tmp_path):
     assert G['big_scipy_mask_i32'].max() > 150 and G['big_scipy_skipped'].sum() > 10
 
 
-def test_drop_depth_map_mirror_equals_reference(tmp_path):
-    """common/drop_depth_map.py (dead code in the reference, kept for API parity) against the reference's own class
-    (make_golden.py section 8d): the calibration parsing, the pixel -> XYZ back-projection and the per-drop distance
-    maps, bit for bit on a sub-grid."""
-    import importlib
-    ddm = importlib.import_module('rain-rendering_amd.common.drop_depth_map')
+def test_drop_depth_map_restatement_equals_reference(tmp_path):
+    """oracle/depth_map.py (the reference's common/drop_depth_map.py: dead code there, named by BASELINE.json's
+    north_star) against the reference's own class (make_golden.py section 8d): the calibration parsing, the pixel -> XYZ
+    back-projection and the per-drop distance maps, bit for bit on a sub-grid."""
+    from oracle import depth_map as odm
     calib = tmp_path / 'calib_cam_to_cam.txt'
     calib.write_text(str(G['ddm_calib']))
     s1, s2 = (int(v) for v in G['ddm_depth_seed'])
     dmap = np.random.RandomState(s1).uniform(2.0, 60.0, (352, 1216))
-    ev = ddm.DropDepthMap(filename=str(calib))
-    xyz = ev.get_world_points(dmap)
+    cal = odm.read_calibration(str(calib))
+    xyz = odm.backproject(dmap, cal['P_R_pinv'])
     assert np.array_equal(xyz[::37, ::53], G['ddm_xyz_sub'])
-    assert np.array_equal(ev.camera_pos_world, G['ddm_cam_pos'])
+    assert np.array_equal(cal['camera_pos_world'], G['ddm_cam_pos'])
     starts = np.random.RandomState(s2).uniform(-3, 3, (4, 3))
-    dd = ddm.DropDepthMap.depth_map_drop(starts, xyz)
+    dd = odm.drop_distance_maps(starts, xyz)
     assert dd.dtype == np.float16 and np.array_equal(dd[:, ::37, ::53], G['ddm_dist_sub'])
     # any frame size (the reference hard-codes 352 x 1216)
-    assert ev.return_xyz(np.full((10, 20), 5.0)).shape == (10, 20, 3)
+    assert odm.backproject(np.full((10, 20), 5.0), cal['P_R_pinv']).shape == (10, 20, 3)
 
 
 def test_product_fov_and_warping_points_equal_reference():
