@@ -48,7 +48,18 @@ WORKLOADS = {
     'kitti100': dict(H=375, W=1242, rate=100, cam='KITTI', rs=1, cfg='configs[2]', metric="rainy frames/sec @ 1242x375, 100 mm/hr"),
     'kitti25': dict(H=375, W=1242, rate=25, cam='KITTI', rs=1, cfg='configs[1]', metric="rainy frames/sec @ 1242x375, 25 mm/hr"),
     'cityscapes50': dict(H=1024, W=2048, rate=50, cam='CITYSCAPES', rs=1, cfg='configs[3]', metric="rainy frames/sec @ 2048x1024, 50 mm/hr"),
+    # the reference's default for Cityscapes: render_scale = depth_scale = 2 (config/cityscapes.py:41-42) -> 1024x512 frames
+    'cityscapes50_rs2': dict(H=512, W=1024, rate=50, cam='CITYSCAPES', rs=2, cfg='configs[3] at the plug-in\'s default render_scale 2',
+                             metric="rainy frames/sec @ 1024x512 (2048x1024 / render_scale 2), 50 mm/hr"),
 }
+# BASELINE.json configs[4]: nuScenes 1600x900, {1, 5, 25, 100, 200} mm/hr, IN-KERNEL particle simulation (no XML): the drop tables
+# are generated on the device inside the timed step (rr_generate_drops_device), at the physical (Poisson) counts of
+# tools/particles.py's model; nuscenes200x = the heaviest rain at SURVEY 8d's fixed 16384 particles per frame
+for _r in (1, 5, 25, 100, 200):
+    WORKLOADS['nuscenes%d' % _r] = dict(H=900, W=1600, rate=_r, cam='NUSCENES', rs=1, cfg='configs[4]', sim=True, count=None,
+                                        metric="rainy frames/sec @ 1600x900, %d mm/hr, in-kernel particles" % _r)
+WORKLOADS['nuscenes200x'] = dict(H=900, W=1600, rate=200, cam='NUSCENES', rs=1, cfg='configs[4]', sim=True, count=16384,
+                                 metric="rainy frames/sec @ 1600x900, 200 mm/hr (16384 particles/frame), in-kernel particles")
 
 
 def algorithmic_bytes(H, W, He, We, N):
@@ -59,8 +70,15 @@ def algorithmic_bytes(H, W, He, We, N):
 class DeviceBatch:
     """n frames resident in HBM as torch tensors + the ctypes descriptors rr_render_frames_device takes."""
 
-    def __init__(self, torch, hb, sc, dev, frame_ids, drop_ids, noise_std=0.0):
+    def __init__(self, torch, hb, sc, dev, frame_ids, drop_ids, noise_std=0.0, sims=None):
+        """sims: SIM_FRAME_DTYPE records, one per frame: the drop tables are generated on the device (generate()), `drops`
+        and the drop counts live in HBM only."""
         self.n = len(frame_ids)
+        self.sims = sims
+        if sims is not None:
+            self.cap = max(int(sims['n_particles'].max()), 1)
+            self.t_drops = torch.empty((self.n, self.cap * hb.DROP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+            self.t_counts = torch.zeros((self.n,), dtype=torch.int32, device=dev)
         self.keep = []
         self.fin = (hb.rr_frame_in * max(self.n, 1))()
         self.fout = (hb.rr_frame_out * max(self.n, 1))()
@@ -70,11 +88,15 @@ class DeviceBatch:
         self.keep.append(omega_t)
         for k, (fi, di) in enumerate(zip(frame_ids, drop_ids)):
             bg, env = sc.frame_inputs(fi)
-            drops = sc.product_drops(di, noise_std=noise_std, noise_scale=1.0 if noise_std else 0.0)
+            if sims is None:
+                drops = sc.product_drops(di, noise_std=noise_std, noise_scale=1.0 if noise_std else 0.0)
+                t_dr = torch.from_numpy(drops.view(np.uint8).reshape(-1)).to(dev)
+            else:
+                drops = np.zeros(self.cap, hb.DROP_DTYPE)           # (length = capacity; the records are made on the device)
+                t_dr = self.t_drops[k]
             self.host.append((bg, env, drops))
             t_bg = torch.from_numpy(bg).to(dev)
             t_env = torch.from_numpy(env).to(dev)
-            t_dr = torch.from_numpy(drops.view(np.uint8).reshape(-1)).to(dev)
             o_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
             o_m = torch.empty((H, W), dtype=torch.float64, device=dev)
             o_mi = torch.empty((H, W), dtype=torch.int32, device=dev)
@@ -87,6 +109,8 @@ class DeviceBatch:
             fi_.omega = omega_t.data_ptr()
             fi_.drops = t_dr.data_ptr()
             fi_.n_drops = len(drops)
+            if sims is not None:
+                fi_.n_drops_dev = self.t_counts[k:k + 1].data_ptr()
             fi_.strategy = 0
             fi_.opacity_attenuation = 1.0
             fo_.rainy_rgb = o_rgb.data_ptr()
@@ -95,6 +119,14 @@ class DeviceBatch:
             fo_.mask_i32 = o_mi.data_ptr()
             fo_.drop_status = o_st.data_ptr()
         self.mean_drops = float(np.mean([len(f[2]) for f in self.host])) if self.host else 0.0
+
+    def generate(self, rh, H, W, stream, a=0, b=None):
+        """Drop tables of frames [a, b) on the device (rr_generate_drops_device), on the launch stream."""
+        b = self.n if b is None else b
+        rh.generate_drops_device(self.sims[a:b], H, W, self.t_drops[a].data_ptr(), self.cap, self.t_counts[a:b].data_ptr(), stream)
+
+    def device_counts(self):
+        return self.t_counts.cpu().numpy()
 
     def chunk(self, hb, a, b):
         """Descriptor arrays of frames [a, b) (they point into the same tensors)."""
@@ -165,6 +197,56 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
             vals[counter] = tot / cnt * len(dom_kernels)            # a timing scope may hold several kernels
         return ((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
                 "(2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per launch, two rocprofv3 --pmc passes of this workload spawned by bench.py")
+    except Exception as e:                                          # noqa: BLE001 -- reported, never fatal
+        return None, "pmc pass failed: %r" % (e,)
+
+
+def measure_valu(args, scene_dir=None):
+    """VALU issue utilisation per kernel from one rocprofv3 --pmc pass of this workload: SQ_ACTIVE_INST_VALU (quad-cycles
+    in which a wave has a VALU instruction executing, summed over the chip) * 4 / (GRBM_GUI_ACTIVE cycles of the launch *
+    1024 SIMDs): the fraction of the chip's VALU issue capacity in use while the kernel runs.  Returns ({kernel: {...}}, how)."""
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    try:
+        out = tempfile.mkdtemp(prefix='rainpmc_', dir='/tmp')
+        cmd = [exe, '--kernel-trace', '--pmc', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE',
+               '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1',
+               '--batch', str(args.batch), '--workload', args.workload] + sum((['--opt', o] for o in args.opt), [])
+        if scene_dir:
+            cmd += ['--scene-dir', scene_dir]
+        proc = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                start_new_session=True)
+        try:
+            rc = proc.wait(timeout=300)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+            return None, "pmc pass timed out"
+        if rc != 0:
+            return None, "pmc pass exited with %d" % rc
+        agg, cnt = {}, {}
+        for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+            for row in csv.DictReader(open(f)):
+                m = re.search(r'(k_[a-z_0-9]+)', row.get('Kernel_Name', ''))
+                if not m:
+                    continue
+                key = (m.group(1), row['Counter_Name'])
+                agg[key] = agg.get(key, 0.0) + float(row['Counter_Value'])
+                cnt[key] = cnt.get(key, 0) + 1
+        shutil.rmtree(out, ignore_errors=True)
+        res = {}
+        for (k, c) in agg:
+            res.setdefault(k, {})[c] = agg[(k, c)] / cnt[(k, c)]
+        outp = {}
+        for k, v in res.items():
+            if v.get('GRBM_GUI_ACTIVE') and v.get('SQ_ACTIVE_INST_VALU') is not None:
+                outp[k] = {"valu_util": 4.0 * v['SQ_ACTIVE_INST_VALU'] / (v['GRBM_GUI_ACTIVE'] * 1024.0),
+                           "valu_insts": v.get('SQ_INSTS_VALU'), "gui_active_cycles": v['GRBM_GUI_ACTIVE']}
+        if not outp:
+            return None, "no counters in the pass' output"
+        return outp, ("per launch: 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE * 1024 SIMDs), one rocprofv3 --pmc pass of this workload "
+                      "spawned by bench.py")
     except Exception as e:                                          # noqa: BLE001 -- reported, never fatal
         return None, "pmc pass failed: %r" % (e,)
 
@@ -292,7 +374,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     H, W, B = wl['H'], wl['W'], args.batch
-    N = synthetic.DROPS_PER_RATE[wl['rate']]
+    is_sim = bool(wl.get('sim'))
+    N = 16 if is_sim else synthetic.DROPS_PER_RATE[wl['rate']]      # (in-kernel particles: the scene's XML is a stub, never rendered)
     cam = getattr(scenes, wl['cam'])
     strong = args.total_frames > 0
     # frames of this rank: weak = its own B frames (seeded by rank); strong = its share of ONE sequence
@@ -304,8 +387,18 @@ def main():
         n_sim, seed0 = B, 3000 + 1000 * rank
     tmp = args.scene_dir or tempfile.mkdtemp(prefix='rainbench_r%d_' % rank)
     with contextlib.redirect_stdout(sys.stderr):       # loaders print like the reference's do; stdout carries the JSON line only
-        sc = scenes.Scene(tmp, H, W, N, n_frames=n_sim, cam=cam, seed0=seed0, render_scale=wl['rs'])
+        sc = scenes.Scene(tmp, H, W, N, n_frames=1 if is_sim else n_sim, cam=cam, seed0=seed0, render_scale=wl['rs'])
     He, We = sc.He, sc.We
+    sims = None
+    if is_sim:
+        particles = importlib.import_module('rain-rendering_amd.tools.particles')
+        sdb = importlib.import_module('rain-rendering_amd.common.db')
+        opt = dict(sdb.settings('nuscenes'))
+        opt.pop('sequences', None)
+        # frame numbers of this rank's share of the sequence: particle (seed, frame, index) is the same whoever makes it
+        fnum = my_frames if strong else [f + 100000 * rank for f in my_frames]
+        sims, dgrid, cdf = particles.sim_frames(opt, wl['rate'], len(my_frames), render_scale=wl['rs'], seed=2024, count=wl['count'],
+                                                frame_ids=fnum, draw_seeds=[f % (2 ** 32) for f in fnum])
 
     rh = hb.RainHip(local_rank)
     for kv in args.opt:
@@ -319,15 +412,20 @@ def main():
         torch.cuda.synchronize()
     rh.set_streak_db_device(t_tex.data_ptr(), t_tex.numel(), hs, ws, offs)
     rh.set_camera(sc.cam)
+    if is_sim:
+        rh.set_particle_tables(dgrid, cdf)
 
     # --- inputs resident in HBM ----------------------------------------------------------------
     fids = [f if strong else f + 100 * rank for f in my_frames]
-    batch = DeviceBatch(torch, hb, sc, dev, fids, my_frames)
+    batch = DeviceBatch(torch, hb, sc, dev, fids, my_frames, sims=sims)
     stream = torch.cuda.current_stream().cuda_stream
     chunks = [batch.chunk(hb, a, min(a + B, batch.n)) for a in range(0, batch.n, B)]
+    bounds = [(a, min(a + B, batch.n)) for a in range(0, batch.n, B)]
 
     def render(chs=None):
-        for fin, fout, n in (chunks if chs is None else chs):
+        for ci, (fin, fout, n) in enumerate(chunks if chs is None else chs):
+            if is_sim:                 # in-kernel particle simulation: the drop tables of the call's frames are (re)made first
+                batch.generate(rh, H, W, stream, *bounds[ci])
             rh.render_frames_device(fin, fout, n, stream)
 
     def warm(fn, reps):
@@ -371,7 +469,11 @@ def main():
     extras = {}
     single = rank == 0 and world == 1
     # --- variants (N=1): what the headline's conditions hide ------------------------------------
-    if single and not args.no_variants and not strong:
+    if is_sim:
+        cnt_dev = batch.device_counts()
+        batch.mean_drops = float(cnt_dev.mean())
+        assert int(cnt_dev.max()) <= batch.cap
+    if single and not args.no_variants and not strong and not is_sim:
         var = {}
 
         def rate(fn, frames, reps=3):
@@ -395,7 +497,7 @@ def main():
         extras["variants"] = var
 
     # --- the fog + environment-map pre-pass (rr_prepass_frames_device); not part of `value` ------------------
-    if single and not args.no_prepass and not strong:
+    if single and not args.no_prepass and not strong and not is_sim:
         fogmod = importlib.import_module('rain-rendering_amd.common.add_attenuation')
         envmod = importlib.import_module('rain-rendering_amd.common.envmap')
         imgops = importlib.import_module('rain-rendering_amd.common.imgops')
@@ -491,13 +593,19 @@ def main():
             parts = {'k_env_prefix': ['k_env_prefix', 'k_env_consts']}.get(dom_name, [dom_name])
             traffic, traffic_how = measure_traffic(args, parts, scene_dir=tmp)
         chain_ms = sum(per_launch.values())
+        valu, valu_how = None, "not measured (--no-traffic, N>1 or strong scaling)"
+        if single and not args.no_traffic and not strong:
+            valu, valu_how = measure_valu(args, scene_dir=tmp)
         out = {
             "metric": wl['metric'],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s shape %dx%d, %d mm/hr (%d streaks/frame simulated, %.0f after the frame filter), precomputed "
-                                   "particles; BASELINE.json %s" % (wl['cam'], W, H, wl['rate'], N, batch.mean_drops, wl['cfg']),
+            "config": {"workload": ("%s shape %dx%d, %d mm/hr (%d streaks/frame simulated, %.0f after the frame filter), precomputed "
+                                    "particles; BASELINE.json %s" % (wl['cam'], W, H, wl['rate'], N, batch.mean_drops, wl['cfg'])) if not is_sim else
+                                   ("%s shape %dx%d, %d mm/hr, IN-KERNEL particle simulation inside the timed step (%.0f particles/frame "
+                                    "simulated on the device, %.0f drops after the frame filter; no XML, no host drop table); BASELINE.json %s"
+                                    % (wl['cam'], W, H, wl['rate'], float(sims['n_particles'].mean()), batch.mean_drops, wl['cfg'])),
                        "frames_per_call": nb, "frames_per_step": frames_step, "envmap": "%dx%d" % (We, He),
                        "parallelism": "frames sharded round-robin, dp%d; one RCCL broadcast of the streak DB" % world,
                        "raw_tiles_last_call": {"rotate_resize": int(cnts[:, 0].sum()), "bicubic_warp": int(cnts[:, 5].sum()),
@@ -512,9 +620,11 @@ def main():
             "chain": {"ms_per_call_sum_of_kernels": chain_ms, "algorithmic_GBps": alg / (chain_ms * 1e-3) / 1e9,
                       "frac_of_hbm_peak": alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernels_ms_per_call": {k: v for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
+            "valu": {"what": valu_how, "dominant_kernel": (valu or {}).get(dom_name, {}).get("valu_util") if valu else None,
+                     "per_kernel": {k: round(v["valu_util"], 4) for k, v in sorted((valu or {}).items(), key=lambda kv: -kv[1]["valu_util"])} if valu else None},
         }
         out.update(extras)
-        if not args.no_cpu_baseline and single and not strong:
+        if not args.no_cpu_baseline and single and not strong and not is_sim:
             out["cpu_baseline"] = cpu_baseline(sc, batch.host, W, H, args.cpu_sample_drops, os.cpu_count() or 1)
         print(json.dumps(out))
     if world > 1:

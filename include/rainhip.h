@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RR_VERSION 200            /* 0.2.0: + rr_set_option; colour path without the HBM prefix table */
+#define RR_VERSION 300            /* 0.3.0: + device-side particle generator (rr_sim_frame), rr_frame_out.drop_colour */
 
 enum {
   RR_OK = 0,
@@ -53,6 +53,8 @@ enum {
 #define RR_MAX_FOV 32
 
 typedef struct rr_ctx rr_ctx;
+
+struct rr_sim_frame;
 
 /* Camera / renderer constants.  Mirrors RainRenderer(focal, f_number, focus_plane=6,
  * radius=10, fov=165) (generator.py:267), N=20 (generator.py:179) and the constants of
@@ -116,6 +118,15 @@ typedef struct {
                                    * (depth_f64 == 0) or float64; rr_pipeline_* use the pre-pass' depth instead */
   int32_t depth_f64, reserved;
   const rr_ext_tile* ext;         /* optional: n_drops entries (rr_render_frames / rr_render_frames_device only) */
+  /* Drop tables born on the device (rr_generate_drops_device): with n_drops_dev != NULL (a DEVICE pointer to one int32;
+   * rr_render_frames_device only) the frame's drop count is read from there when the kernels run, clamped to n_drops, which
+   * then is the CAPACITY of `drops` (and of drop_status / drop_colour) the launch is sized for. */
+  const int32_t* n_drops_dev;
+  /* In-kernel particle simulation (BASELINE config 5; host-pointer entry points rr_render_frames / rr_pipeline_*): with
+   * sim != NULL (HOST pointer to this frame's generator settings) the frame's drop table is generated on the device
+   * (rr_generate_drops_device semantics) instead of uploaded: `drops` is ignored (may be NULL) and n_drops is the capacity
+   * the launch is sized for (0: sim->n_particles).  The count comes back in rr_frame_out.n_drops_out. */
+  const struct rr_sim_frame* sim;
 } rr_frame_in;
 
 typedef struct {
@@ -134,6 +145,7 @@ typedef struct {
    * from the environment map inside the drop's field of view (bad_weather.py:397-412) is K * gray value.  Zeros for a
    * drop that is not composited.  Lets the single-drop seam hand back the reference's `drop_vis` (bad_weather.py:462). */
   double* drop_colour;
+  int32_t* n_drops_out;           /* optional: one int32, the number of drops of a generated drop table (rr_frame_in.sim) */
 } rr_frame_out;
 
 typedef struct {
@@ -233,6 +245,56 @@ int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_
  * its members: what is non-NULL is downloaded as well. */
 int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
                        const rr_prepass_out* pre_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Particle generator on the device (SURVEY 8f "next" #4, BASELINE.json configs[4]: "in-kernel particle simulation (no
+ * XML)").  The reference drives a closed-source simulator binary through tools/simulation.py with the settings of
+ * common/db.py:41-70 and reads its output back as XML (bad_weather.py:192-211); there is no source to follow, so the
+ * model is this library's own (rain-rendering_amd/tools/particles.py is its bit-exact host statement: Marshall-Palmer
+ * sizes, Atlas terminal velocity, exposure-integrated streaks, pinhole projection, counter-based Philox4x32-10 numbers).
+ * For every frame the device
+ *   1. simulates n_particles streaks (one Philox counter per particle: any particle can be made by any lane),
+ *   2. applies the loader's derived fields (bad_weather.py:208-241: render scale, y flip, z sign, widths, ratio, rounding,
+ *      length, type) and the frame filter of Generator.run (generator.py:413-420), keeping the particle order,
+ *   3. makes the renderer's per-drop random draws (np.random.seed(draw_seed), one randint per drop, one normal per
+ *      non-Big drop: bad_weather.py:252-264, generator.py:136) from numpy's legacy MT19937 stream, like rr_host_frame_draws,
+ * and leaves rr_drop[] records in HBM: no XML, no host drop table, no PCIe traffic.  Angular noise (--noise_std) is not
+ * offered on this path (the reference's default is 0); the rotation terms are rot_cos = -dy / n, rot_sin = -|dx| / n
+ * (n = |end - start|): the values cos / sin(-(theta) * pi / 180), theta = acos(-dy / n), take when evaluated exactly.
+ * Everything derived from transcendentals (the diameter distribution) is tabulated once by the host. */
+typedef struct rr_sim_frame {
+  int32_t sensor_w, sensor_h;     /* cam_CCD_WH (db.py): the simulator's sensor in pixels; rendered frame = sensor / render_scale */
+  int32_t render_scale;           /* settings["render_scale"] (bad_weather.py:208-211) */
+  int32_t n_particles;            /* streaks simulated for this frame (host: Poisson(expected count), or a fixed count) */
+  uint32_t key0, key1;            /* Philox key: the simulation's seed */
+  uint32_t frame;                 /* simulated frame number (a word of the Philox counter) */
+  uint32_t draw_seed;             /* np.random.seed(...) of the renderer's per-drop draws (generator.py:318) */
+  int32_t table;                  /* diameter table of this frame's fall rate / camera (rr_set_particle_tables) */
+  int32_t reserved;
+  double fpx;                     /* focal length / pixel size (cam_focal, cam_CCD_pixsize) */
+  double exposure_s;              /* cam_exposure / 1000 */
+  double speed_mps;               /* sim_steps["cam_motion"] / 3.6 */
+  double wind_sigma;              /* m/s, horizontal */
+  double margin;                  /* the simulated field exceeds the sensor by this fraction on every side */
+  double min_px;                  /* narrowest streak simulated, pixels */
+  double z_far;                   /* farthest drop simulated, metres */
+} rr_sim_frame;
+
+/* n_tables inverse-CDF tables of the drop diameter (mm): d_grid[n_grid] ascending, cdf[t][n_grid] from 0 to 1,
+ * non-decreasing (host pointers, copied).  A diameter is d_grid[j] + (u - cdf[j]) * ((d_grid[j+1] - d_grid[j]) / (cdf[j+1] - cdf[j]))
+ * for the j with cdf[j] <= u < cdf[j+1]. */
+int rr_set_particle_tables(rr_ctx* ctx, int32_t n_tables, int32_t n_grid, const double* d_grid, const double* cdf);
+
+/* n frames of rendered size H x W: frame f's records go to drops_out + f * cap (DEVICE memory, cap records per frame; what
+ * does not fit is not stored) and its drop count to n_out[f] (DEVICE, may exceed cap).  `frames` is a HOST array.  Needs
+ * the streak database (texture ratios).  Enqueued on `stream` (NULL = the ctx stream); returns without waiting. */
+int rr_generate_drops_device(rr_ctx* ctx, int32_t n, const rr_sim_frame* frames, int32_t H, int32_t W, rr_drop* drops_out,
+                             int32_t cap, int32_t* n_out, void* stream);
+/* Same with HOST output buffers (n * cap records, n counts): generates on the device, downloads, returns after completion.
+ * (A driver that wants the generated particles as data, and the tests.) */
+int rr_generate_drops(rr_ctx* ctx, int32_t n, const rr_sim_frame* frames, int32_t H, int32_t W, rr_drop* drops_out, int32_t cap,
+                      int32_t* n_out);
+int rr_sizeof_sim_frame(void);
 
 /* Options.  1-4 and 6 are tuning / A-B switches: NONE of them changes a result bit (tests/test_gpu_properties.py).  Unknown
  * options or values are RR_E_ARG.  The library reads no environment variables. */

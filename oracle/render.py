@@ -467,9 +467,10 @@ def compute_fov_plane_points(wps, wpe, radius, fov, N, env_shape):
 # ----------------------------------------------------------------------------
 # one drop: texture -> tile   (generator.py:119-174)
 # ----------------------------------------------------------------------------
-def make_drop_tile(drop, tex_u8, noise_deg, W, H):
+def make_drop_tile(drop, tex_u8, noise_deg, W, H, rot=None):
     """Returns (tile HxWx4 f64, minC int[2]).  Mutates drop.image_position_* exactly as
-    generator.py:152-161 does for non-Big drops."""
+    generator.py:152-161 does for non-Big drops.  rot = (cos, sin) of -(theta + noise) * pi / 180: take the rotation
+    from a drop RECORD (render_drop_records) instead of evaluating generator.py:138-145 here."""
     tex = tex_u8.astype(np.float64) / 255.0          # bad_weather.py:252 (gray; 3 identical channels)
     if drop.drop_type == DropType.Big:
         pts1, pts2, maxC, minC = warping_points(drop, tex.shape, W, H)
@@ -494,7 +495,7 @@ def make_drop_tile(drop, tex_u8, noise_deg, W, H):
             (drop.image_position_end[0] - mean_x) * nx - (drop.image_position_end[1] - mean_y) * ny + mean_x, \
             (drop.image_position_end[0] - mean_x) * ny + (drop.image_position_end[1] - mean_y) * nx + mean_y
         ang = -(theta + noise) * (np.pi / 180)        # getRotationMatrix2D(center, -angle, 1)
-        g = cvlike.rotate_bound(tex, np.cos(ang), np.sin(ang))
+        g = cvlike.rotate_bound(tex, np.cos(ang), np.sin(ang)) if rot is None else cvlike.rotate_bound(tex, rot[0], rot[1])
         if drop.image_position_end[0] > W // 2:
             g = cvlike.flip0(g)
         height = max(abs(drop.image_position_end[1] - drop.image_position_start[1]), 2)
@@ -715,3 +716,36 @@ def render_frame(bg, rainy_bg, env_map_xyY, solid_angle_map, streak_list, textur
             status[i] = e.args[0] if e.args and isinstance(e.args[0], int) else ST_FOV_FAIL
     return dict(rainy_bg=rainy_bg, mask=rainy_mask, mask_i32=quantise_mask(rainy_mask),
                 image_u8=quantise_image(rainy_bg, bg), status=status[first_drop:])
+
+
+def render_drop_records(bg, rainy_bg, env_map_xyY, solid_angle_map, records, textures, cam, opacity_attenuation=1.0,
+                        faithful=True, rendering_strategy=None, scene_depth=None):
+    """render_frame for a drop table given as rr_drop RECORDS (a numpy structured array with the fields of
+    include/rainhip.h rr_drop: what the product's host packer -- or the library's device-side particle generator --
+    hands to the kernels): the reference's per-drop path with the random draws already made (tex_index) and the streak
+    rotation taken from the record (rot_cos / rot_sin; no angular noise).  Everything else -- tile synthesis, field of
+    view, colour, defocus, placement, blend, epilogue -- is render_frame's."""
+    H, W = bg.shape[:2]
+    rainy_bg = rainy_bg.copy()
+    rainy_mask = np.zeros((H, W), np.float64)
+    fc = FrameConsts(env_map_xyY, solid_angle_map)
+    status = np.zeros(len(records), np.int32)
+    for i, r in enumerate(records):
+        drop = Streak()
+        drop.pid = i
+        drop.world_position_start = np.array(r['wps'], np.float64)
+        drop.world_position_end = np.array(r['wpe'], np.float64)
+        drop.image_position_start = np.array([int(r['x0']), int(r['y0'])])
+        drop.image_position_end = np.array([int(r['x1']), int(r['y1'])])
+        drop.image_diameter_start, drop.image_diameter_end = float(r['iw1']), float(r['iw2'])
+        drop.max_width, drop.length = int(r['max_width']), int(r['length'])
+        drop.drop_type = DropType(int(r['type']))
+        tile, minC = make_drop_tile(drop, textures[int(r['tex_index'])], 0.0, W, H, rot=(float(r['rot_cos']), float(r['rot_sin'])))
+        pts = compute_fov_plane_points(drop.world_position_start, drop.world_position_end, RADIUS, FOV_DEG, N_FOV, env_map_xyY.shape)
+        try:
+            add_drop_to_image(env_map_xyY, solid_angle_map, fc, pts, minC, bg.shape, rainy_bg, rainy_mask,
+                              tile, drop, cam, opacity_attenuation, faithful, rendering_strategy, scene_depth)
+        except IndexError as e:
+            status[i] = e.args[0] if e.args and isinstance(e.args[0], int) else ST_FOV_FAIL
+    return dict(rainy_bg=rainy_bg, mask=rainy_mask, mask_i32=quantise_mask(rainy_mask),
+                image_u8=quantise_image(rainy_bg, bg), status=status)

@@ -177,6 +177,17 @@ class Generator:
             self.key = (B, H, W, We, np.dtype(bg_dtype), np.dtype(depth_dtype), bool(save_envmap))
             self.items, self.encodes, self.busy = [], [], False
 
+        def free(self, hip):
+            """Page-locked memory is only returned by rr_host_free (dropping the numpy views frees nothing): called when
+            a slot is replaced by a larger / differently shaped one, after its batch has been collected and encoded."""
+            assert not self.busy and not self.encodes
+            for name in ('bg', 'depth', 'drops', 'status', 'png_i', 'png_m', 'env'):
+                a = getattr(self, name)
+                if a is not None:
+                    hip.host_free(a)
+                setattr(self, name, None)
+            self.frames = self.outs = None
+
     def _decode_into(self, slot, k, item, rs, pristine, imW, imH, seeds):
         """I/O-thread part of one frame: decode image + depth into the slot's pinned buffers, build the drop table."""
         loaded = self._load_frame(item['image_file'], item['depth_file'], rs)
@@ -271,6 +282,41 @@ class Generator:
             return d
         return sharding.rank0_decides(resolve, self.rank, self.world)
 
+    def _work_list(self, files, depth_files, idx, out_dir, out_seq_dir, n_sim):
+        """(work items, #frames skipped because they exist) of one (sequence, weather) run: the file checks and the
+        conflict strategy of generator.py:324-350, the frame's simulation index (:304-312) and its noise-seed history."""
+        frames_exist_nb = 0
+        work = []
+        for i in idx:
+            image_file, depth_file = files[i], depth_files[i]
+            assert os.path.exists(image_file), "Image file {} does not exist".format(image_file)
+            assert os.path.exists(depth_file), "Depth file {} does not exist".format(depth_file)
+            file_name = os.path.split(image_file)[-1]
+            item = dict(i=i, image_file=image_file, depth_file=depth_file,
+                        out_rainy_path=os.path.join(out_dir, 'rainy_image', '{}.png'.format(file_name[:-4])),
+                        out_rainy_mask_path=os.path.join(out_dir, 'rain_mask', '{}.png'.format(file_name[:-4])),
+                        out_env_path=os.path.join(out_seq_dir, 'envmap', '{}.png'.format(file_name[:-4])))
+            if os.path.exists(item['out_rainy_path']) or os.path.exists(item['out_rainy_mask_path']):
+                if self.conflict_strategy == "skip":
+                    frames_exist_nb += 1
+                    continue
+                elif self.conflict_strategy == "overwrite":
+                    pass
+                else:
+                    raise NotImplementedError
+            item['f_name_idx'] = self._frame_name_index(i, len(files), n_sim)  # generator.py:304-312
+            work.append(item)
+        # with angular noise a frame inherits the end-point rotations of the run's earlier frames that used the
+        # same simulated frame (generator.py:152-161): remember their seeds, whoever renders them
+        noisy = bool(self.noise_scale) and bool(self.noise_std)
+        seen = {}
+        for item in work:
+            k = item['f_name_idx'] % n_sim
+            item['seeds'] = tuple(seen.get(k, ())) + (item['f_name_idx'],) if noisy else (item['f_name_idx'],)
+            if noisy:
+                seen.setdefault(k, []).append(item['f_name_idx'])
+        return work, frames_exist_nb
+
     def _frame_name_index(self, i, n_files, n_sim):
         """generator.py:304-312: the index that seeds the frame and picks its simulated frame.  nuScenes spreads the
         simulated frames over the sequence's files."""
@@ -326,37 +372,12 @@ class Generator:
                 else:
                     idx = list(range(self.frame_start, f_end, self.frame_step))
                 print("{} images".format(len(idx)))
-                # work items of the WHOLE run first (skip / overwrite decisions), then this rank's share
-                frames_exist_nb = 0
-                work = []
-                for i in idx:
-                    image_file, depth_file = files[i], depth_files[i]
-                    assert os.path.exists(image_file), "Image file {} does not exist".format(image_file)
-                    assert os.path.exists(depth_file), "Depth file {} does not exist".format(depth_file)
-                    file_name = os.path.split(image_file)[-1]
-                    item = dict(i=i, image_file=image_file, depth_file=depth_file,
-                                out_rainy_path=os.path.join(out_dir, 'rainy_image', '{}.png'.format(file_name[:-4])),
-                                out_rainy_mask_path=os.path.join(out_dir, 'rain_mask', '{}.png'.format(file_name[:-4])),
-                                out_env_path=os.path.join(out_seq_dir, 'envmap', '{}.png'.format(file_name[:-4])))
-                    if os.path.exists(item['out_rainy_path']) or os.path.exists(item['out_rainy_mask_path']):
-                        if self.conflict_strategy == "skip":
-                            frames_exist_nb += 1
-                            continue
-                        elif self.conflict_strategy == "overwrite":
-                            pass
-                        else:
-                            raise NotImplementedError
-                    item['f_name_idx'] = self._frame_name_index(i, len(files), n_sim)  # generator.py:304-312
-                    work.append(item)
-                # with angular noise a frame inherits the end-point rotations of the run's earlier frames that used the
-                # same simulated frame (generator.py:152-161): remember their seeds, whoever renders them
-                noisy = bool(self.noise_scale) and bool(self.noise_std)
-                seen = {}
-                for item in work:
-                    k = item['f_name_idx'] % n_sim
-                    item['seeds'] = tuple(seen.get(k, ())) + (item['f_name_idx'],) if noisy else (item['f_name_idx'],)
-                    if noisy:
-                        seen.setdefault(k, []).append(item['f_name_idx'])
+                # The work list of the WHOLE run -- which frames exist already (skip / overwrite), which simulated frame and
+                # which seeds a frame gets -- is made ONCE, by rank 0, and broadcast: every rank making its own would race with
+                # the ranks that are already writing into out_dir (a slower rank would skip, or refuse, frames its peers have
+                # just rendered, and the shares would neither partition nor cover the run).  Then this rank's share.
+                work, frames_exist_nb = sharding.rank0_decides(
+                    lambda: self._work_list(files, depth_files, idx, out_dir, out_seq_dir, n_sim), self.rank, self.world)
                 work = sharding.shard(work, self.rank, self.world)
                 sim_t0 = time.time()
                 self._run_batches(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0)
@@ -374,7 +395,11 @@ class Generator:
         pool = self._io_pool()
         nslot = hip_backend.RR_PIPE_SLOTS
         batches = [work[a:a + B] for a in range(0, len(work), B)]
-        slots = [None] * nslot
+        # the pinned slots live on the Generator and are re-used by every (sequence, weather) run of the process: a fresh
+        # set per run would leak ~0.7 GB of page-locked memory each time (pinned memory is only freed explicitly)
+        if getattr(self, '_slots', None) is None or getattr(self, '_slots_hip', None) is not hip:
+            self._slots, self._slots_hip = [None] * nslot, hip
+        slots = self._slots
         n_sim = len(frame_render_dict)
         state = dict(geom=None, env_w=0, omega=None, done=0)
 
@@ -438,6 +463,8 @@ class Generator:
             key = (B, H, W, state['env_w'], bg0.dtype, dep0.dtype, bool(self.save_envmap))
             sl = slots[si]
             if sl is None or sl.key != key or sl.drops_cap < need_drops:
+                if sl is not None:                               # (finish / drain above left it idle)
+                    sl.free(hip)
                 sl = slots[si] = Generator._Slot(hip, B, H, W, state['env_w'], bg0.dtype, dep0.dtype, self.save_envmap,
                                                  max(need_drops + need_drops // 4, 1024))
             frames, outs, sl.items = [], [], []

@@ -25,6 +25,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,6 +33,7 @@
 #include "rainhip.h"
 #include "rr_device.h"
 #include "rr_prepass.h"
+#include "rr_particles.h"
 
 using namespace rr;
 
@@ -60,6 +62,7 @@ struct FrameDesc {
   const void* depth;               // optional (RR_OPT_DEPTH_OCCLUSION): scene depth in metres, H*W float32 / float64
   const rr_ext_tile* ext;          // optional: caller-made tiles / FOV polygons per drop (device pointers inside)
   double* colour_out;              // optional: n_drops * 3 colour constants (rr_frame_out.drop_colour)
+  const int32_t* n_drops_dev;      // optional: the drop count lives on the device (k_patch_counts)
   int32_t depth_f64;
   int32_t n_drops;
   int32_t strategy;
@@ -108,6 +111,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* means;                    // [frame][4] = mean(composite), mean(bg), min(mask), max(mask)
   int64_t* arena_need;              // [frame]
   int32_t* overflow;                // [1]
+  unsigned long long* need_max;     // [1] largest per-frame arena need of every batch since the arena was last (re)sized
   int32_t* list_rot;                // [frame][drops]  drops taken by k_tile
   int32_t* list_gen;                // [frame][drops]  drops taken by k_tile_generic
   int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
@@ -290,7 +294,10 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
   }
   if (t == 1023) {
     sc.arena_need[f] = sh[1023];
-    if (sh[1023] > arena_cap) atomicExch(sc.overflow, 1);
+    if (sh[1023] > arena_cap) {
+      atomicExch(sc.overflow, 1);
+      atomicMax(sc.need_max, (unsigned long long)sh[1023]);       // sticky until the host regrows the arena
+    }
   }
 }
 
@@ -2139,6 +2146,188 @@ __global__ __launch_bounds__(256) void k_png_mask(const FrameDesc* frames, Dims 
   for (int k = 0; k < 4; k++) o[k] = (uint8_t)(((c >> (8 * k)) & 0xffu) - ((l >> (8 * k)) & 0xffu));
 }
 
+
+// ---------------------------------------------------------------------------
+// drop tables born on the device: particle generator + packer (BASELINE configs[4])
+// ---------------------------------------------------------------------------
+// k_particles: one workgroup per frame walks the frame's particles 512 at a time.  Thread t makes particle base + t
+// (three Philox blocks: any lane can make any particle), applies the loader's derived fields and the frame filter
+// (rr_particles.h), and the survivors are written IN PARTICLE ORDER (the reference composites in file order): ballot +
+// prefix popcount inside a wave, the wave totals through LDS, a running base per frame.  The record goes out through LDS
+// so that the stores are whole lines; tex_index temporarily holds the first texture of the drop's block of ten.
+constexpr int DROP_DW = (int)(sizeof(rr_drop) / 4);
+__global__ __launch_bounds__(512) void k_particles(const rr_sim_frame* sims, int H, int W, const double* dgrid, const double* cdf_tabs,
+                                                    int n_grid, const double* ratio_db, rr_drop* out, int cap, int32_t* n_out) {
+  const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __shared__ rr_sim_frame s_sf;
+  __shared__ int s_cnt[8];
+  __shared__ uint32_t s_stage[8][64 * DROP_DW];            // per wave: 64 records (57 KB)
+  if (t < (int)(sizeof(rr_sim_frame) / 4)) reinterpret_cast<uint32_t*>(&s_sf)[t] = reinterpret_cast<const uint32_t*>(sims + f)[t];
+  __syncthreads();
+  const rr_sim_frame sf = s_sf;
+  const double* cdf = cdf_tabs + (int64_t)sf.table * n_grid;
+  double rdb[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) rdb[k] = ratio_db[k];
+  rr_drop* fout = out + (int64_t)f * cap;
+  int base_out = 0;
+  for (int base = 0; base < sf.n_particles; base += 512) {
+    const int i = base + t;
+    bool keep = false;
+    rr_drop d;
+    if (i < sf.n_particles) {
+      rrsim::Particle p;
+      rrsim::make_particle(sf, dgrid, cdf, n_grid, (uint32_t)i, p);
+      double ratio;
+      keep = rrsim::derive_drop(p, sf.render_scale, W, H, d, ratio);
+      d.tex_index = 10 * rrsim::texture_bucket(ratio, rdb);
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base_out, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const int c = s_cnt[w];
+      if (w < wave) off += c;
+      tot += c;
+    }
+    const int nw = __popcll(bal);                            // records of this wave: consecutive output slots from `off`
+    if (keep) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&d);
+      uint32_t* dst = s_stage[wave] + __popcll(bal & ((1ull << lane) - 1ull)) * DROP_DW;
+#pragma unroll
+      for (int k = 0; k < DROP_DW; k++) dst[k] = src[k];
+    }
+    wave_lds_sync();
+    const int room = imax(imin(nw, cap - off), 0);          // what does not fit is not stored (the count still says so)
+    uint32_t* o = reinterpret_cast<uint32_t*>(fout + off);
+    for (int k = lane; k < room * DROP_DW; k += 64) o[k] = s_stage[wave][k];
+    base_out += tot;
+    __syncthreads();
+  }
+  if (t == 0) n_out[f] = base_out;
+}
+
+// k_particle_draws: the renderer's per-drop random draws of one frame (np.random.seed(draw_seed); per drop one
+// randint(lo, lo + 10), per non-Big drop one normal(0, 0): bad_weather.py:252-264, generator.py:136) from numpy's legacy
+// MT19937 stream, bit for bit what rr_host_frame_draws makes on the host.  The stream is sequential by nature (how many
+// words a drop consumes depends on the words): ONE WAVE per frame.  The 624-word state lives in wave-private LDS and is
+// regenerated by all lanes (the recurrence allows 227 independent updates at a time); the consumer runs wave-uniform:
+// lane l holds tempered word l of the current group of 64, v_readlane hands the next one to the scalar side, and the
+// texture indices of 64 drops are gathered into a register and stored together.  With a standard deviation of 0 the
+// normal deviate itself is never used: only its rejection loop (how many words it eats) and the cached-second-value
+// toggle are followed.
+__device__ inline uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+__global__ __launch_bounds__(64) void k_particle_draws(const rr_sim_frame* sims, rr_drop* out, int cap, const int32_t* n_out) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  __shared__ uint32_t key[624];
+  const int n = imin(n_out[f], cap);
+  rr_drop* drops = out + (int64_t)f * cap;
+  {                                                          // init_genrand (numpy _legacy_seeding): sequential by definition
+    uint32_t seed = sims[f].draw_seed;
+    if (lane == 0)
+      for (int pos = 0; pos < 624; pos++) {
+        key[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+      }
+  }
+  wave_lds_sync();
+  auto regenerate = [&]() {                                   // mt19937_gen: three dependent sweeps + the last word
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+    auto sweep = [&](int a, int b, int ofs) {
+      for (int k0 = a; k0 < b; k0 += 64) {
+        const int kk = k0 + lane;
+        uint32_t v = 0;
+        if (kk < b) {
+          const uint32_t y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
+          v = key[kk + ofs] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+        }
+        wave_lds_sync();                                     // key[kk + 1] of the neighbouring lane is read before it is overwritten
+        if (kk < b) key[kk] = v;
+        wave_lds_sync();
+      }
+    };
+    sweep(0, 227, 397);
+    sweep(227, 454, -227);
+    sweep(454, 623, -227);
+    if (lane == 0) {
+      const uint32_t y = (key[623] & UPPER) | (key[0] & LOWER);
+      key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+    }
+    wave_lds_sync();
+  };
+  int pos = 624;                                              // next state word (624: regenerate first)
+  uint32_t cur = 0;                                           // lane l: tempered word pos0 + l of the current group
+  int avail = 0, taken = 0;                                   // words in the group / already handed out
+  auto next_u32 = [&]() -> uint32_t {                         // wave-uniform
+    if (taken == avail) {
+      if (pos == 624) {
+        regenerate();
+        pos = 0;
+      }
+      avail = imin(64, 624 - pos);
+      cur = lane < avail ? mt_temper(key[pos + lane]) : 0u;
+      pos += avail;
+      taken = 0;
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)cur, taken++);
+  };
+  auto next_double = [&]() -> double {
+    const int32_t a = (int32_t)(next_u32() >> 5), b = (int32_t)(next_u32() >> 6);
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+  };
+  bool has_gauss = false;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    int lo = 0, big = 1;
+    if (i < n) {
+      const global_ptr<const int32_t> r = as_global(reinterpret_cast<const int32_t*>(drops + i));
+      big = r[6] == 0;                                        // rr_drop.type
+      lo = r[7];                                              // rr_drop.tex_index: first texture of the block of ten
+    }
+    int mine = 0;
+    const int cnt = imin(64, n - base);
+    for (int k = 0; k < cnt; k++) {
+      const int lo_k = __builtin_amdgcn_readlane(lo, k), big_k = __builtin_amdgcn_readlane(big, k);
+      uint32_t v;                                             // randint(lo, lo + 10): masked rejection, rng = 9, mask = 15
+      do {
+        v = next_u32() & 15u;
+      } while (v > 9u);
+      if (lane == k) mine = lo_k + (int)v;
+      if (!big_k) {                                           // legacy gauss (polar Box-Muller, second deviate cached)
+        if (has_gauss) {
+          has_gauss = false;
+        } else {
+          double r2;
+          do {
+            const double x1 = 2.0 * next_double() - 1.0;
+            const double x2 = 2.0 * next_double() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+          } while (r2 >= 1.0 || r2 == 0.0);
+          has_gauss = true;
+        }
+      }
+    }
+    if (i < n) as_global(reinterpret_cast<int32_t*>(drops + i))[7] = mine;
+  }
+}
+
+// drop counts that only exist on the device (rr_frame_in.n_drops_dev): patched into the frame descriptors before the
+// first kernel of the chain reads them; n_drops of the descriptor is the capacity
+__global__ void k_patch_counts(FrameDesc* frames, int n) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n || !frames[f].n_drops_dev) return;
+  const int c = *frames[f].n_drops_dev;
+  frames[f].n_drops = imax(imin(c, frames[f].n_drops), 0);
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -2161,6 +2350,14 @@ struct rr_ctx {
   int64_t* d_tex_off = nullptr;
   int n_tex = 0;
   float* d_ctab = nullptr;
+  // particle generator (rr_set_particle_tables / rr_generate_drops_device)
+  double *d_dgrid = nullptr, *d_cdf = nullptr, *d_ratio_db = nullptr;
+  int n_grid = 0, n_tables = 0, n_ratio = 0;
+  rr_sim_frame* d_sims = nullptr;
+  int cap_sims = 0;
+  rr_drop* d_gen_drops = nullptr;    // staging of rr_generate_drops (host-pointer variant)
+  int32_t* d_gen_counts = nullptr;
+  size_t cap_gen_drops = 0, cap_gen_counts = 0;
   uint8_t* d_lut = nullptr;         // [256][4] RGBA colour map of the rain-mask PNG (rr_set_colormap)
   bool have_lut = false;
   rr_camera cam;
@@ -2172,10 +2369,20 @@ struct rr_ctx {
   Dims cap_dims{0, 0, 0, 0};
   int64_t arena_cap = 0;            // doubles per frame
   double* d_comp_out = nullptr;     // [frame][H*W*3] when the caller passes rainy_bg_out == NULL
-  std::vector<FrameDesc> h_frames;
+  // Descriptor staging: a batch's FrameDesc / PreFrame records go to the device with an asynchronous copy from PINNED
+  // memory (a pageable source makes hipMemcpyAsync wait for the stream -- i.e. for the previous batch's kernels -- inside
+  // the submit call, which serialises the pipeline slots).  A ring of buffers, each guarded by an event recorded behind
+  // its copy, lets several batches be queued before the first copy has executed.
+  struct DescRing {
+    static constexpr int N = 2 * RR_PIPE_SLOTS + 2;
+    void* host[N] = {};
+    size_t cap[N] = {};
+    hipEvent_t ev[N] = {};
+    bool used[N] = {};
+    int next = 0;
+  } ring_frames, ring_pre, ring_sims;
   // last launch (for rr_synchronize bookkeeping)
   int last_n = 0;
-  std::vector<int64_t> h_need;
   // host-pointer entry points: device staging per pipeline slot (slot 0 serves the synchronous calls)
   struct Staging {
     double *bg = nullptr, *rainy = nullptr, *env = nullptr, *omega = nullptr, *comp = nullptr, *mask = nullptr;
@@ -2183,6 +2390,7 @@ struct rr_ctx {
     uint8_t* rgb = nullptr;
     int32_t *mask_i = nullptr, *status = nullptr;
     double* colour = nullptr;        // rr_frame_out.drop_colour
+    int32_t* ndrops = nullptr;       // drop counts of generated drop tables (rr_frame_in.sim)
     double* depth = nullptr;         // pre-pass input (float32 or float64 per frame slot of 8 bytes/pixel)
     uint8_t* bg8 = nullptr;          // pre-pass input given as bytes (rr_prepass_in.bg_u8)
     uint8_t* env_u8 = nullptr;
@@ -2205,7 +2413,6 @@ struct rr_ctx {
   int32_t *d_esrc = nullptr, *d_etop = nullptr, *d_ebot = nullptr;
   rrpre::PreScratch psc{};
   rrpre::PreFrame* d_pre = nullptr;
-  std::vector<rrpre::PreFrame> h_pre;
   int pre_frames = 0, pre_H = 0, pre_W = 0, pre_We = 0;
   // profiling
   bool prof = false;
@@ -2253,6 +2460,30 @@ hipEvent_t get_event(rr_ctx* ctx) {
   hipEvent_t e;
   hipEventCreate(&e);
   return e;
+}
+
+// next buffer of a descriptor ring (>= bytes, pinned); waits for the copy that last read it
+int ring_acquire(rr_ctx* ctx, rr_ctx::DescRing& r, size_t bytes, int& idx, void*& host) {
+  idx = r.next;
+  r.next = (r.next + 1) % rr_ctx::DescRing::N;
+  if (!r.ev[idx]) HIPCHK(hipEventCreateWithFlags(&r.ev[idx], hipEventDisableTiming));
+  if (r.used[idx]) HIPCHK(hipEventSynchronize(r.ev[idx]));
+  r.used[idx] = false;
+  if (bytes > r.cap[idx]) {
+    if (r.host[idx]) HIPCHK(hipHostFree(r.host[idx]));
+    r.host[idx] = nullptr;
+    r.cap[idx] = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    HIPCHK(hipHostMalloc(&r.host[idx], want, hipHostMallocDefault));
+    r.cap[idx] = want;
+  }
+  host = r.host[idx];
+  return RR_OK;
+}
+int ring_commit(rr_ctx* ctx, rr_ctx::DescRing& r, int idx, hipStream_t s) {
+  HIPCHK(hipEventRecord(r.ev[idx], s));
+  r.used[idx] = true;
+  return RR_OK;
 }
 
 struct ProfScope {
@@ -2365,6 +2596,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if (!ctx->sc.overflow) {
       if ((rc = dev_alloc(ctx, ctx->sc.overflow, 1))) return rc;
       HIPCHK(hipMemset(ctx->sc.overflow, 0, sizeof(int32_t)));
+      if ((rc = dev_alloc(ctx, ctx->sc.need_max, 1))) return rc;
+      HIPCHK(hipMemset(ctx->sc.need_max, 0, sizeof(unsigned long long)));
     }
     if ((rc = dev_alloc(ctx, ctx->d_frames, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->d_comp_out, (size_t)F * dm.H * dm.W * 3))) return rc;
@@ -2378,13 +2611,20 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
   return RR_OK;
 }
 
-int grow_arena(rr_ctx* ctx, int64_t need) {
+// After an overflow: a larger arena, sized by the largest need any batch reported since the last (re)size (need_max is
+// sticky on the device, so the batch that overflowed is covered even when later batches were queued behind it); the
+// capacity never shrinks.
+int grow_arena(rr_ctx* ctx) {
   HIPCHK(hipDeviceSynchronize());
-  int64_t cap = (need + need / 4 + (1 << 16) + 15) & ~15LL;
+  unsigned long long need = 0;
+  HIPCHK(hipMemcpy(&need, ctx->sc.need_max, sizeof(need), hipMemcpyDeviceToHost));
+  int64_t cap = ((int64_t)need + (int64_t)need / 4 + (1 << 16) + 15) & ~15LL;
+  if (cap < ctx->arena_cap) cap = ctx->arena_cap;
   ctx->arena_cap = cap;
   int rc = dev_alloc(ctx, ctx->sc.arena, (size_t)ctx->cap_frames * (size_t)cap);
   if (rc) return rc;
   HIPCHK(hipMemset(ctx->sc.overflow, 0, sizeof(int32_t)));
+  HIPCHK(hipMemset(ctx->sc.need_max, 0, sizeof(unsigned long long)));
   return RR_OK;
 }
 
@@ -2429,9 +2669,13 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   int rc = ensure_scratch(ctx, n, max_drops, dm, need_comp);
   if (rc) return rc;
   const int D = ctx->cap_drops > 0 ? ctx->cap_drops : 1;
-  ctx->h_frames.resize(n);
+  int ring_idx;
+  void* ring_host;
+  bool any_dev_count = false;
+  if ((rc = ring_acquire(ctx, ctx->ring_frames, sizeof(FrameDesc) * (size_t)n, ring_idx, ring_host))) return rc;
+  FrameDesc* h_frames = static_cast<FrameDesc*>(ring_host);
   for (int f = 0; f < n; f++) {
-    FrameDesc& fd = ctx->h_frames[f];
+    FrameDesc& fd = h_frames[f];
     fd.bg = in[f].bg;
     fd.rainy_bg = in[f].rainy_bg;
     fd.env = in[f].env_xyY;
@@ -2448,11 +2692,15 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.depth_f64 = in[f].depth_f64;
     fd.ext = in[f].ext;
     fd.colour_out = out[f].drop_colour;
+    fd.n_drops_dev = in[f].n_drops_dev;
+    any_dev_count = any_dev_count || in[f].n_drops_dev;
     fd.n_drops = in[f].n_drops;
     fd.strategy = in[f].strategy;
     fd.opacity = in[f].opacity_attenuation;
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_frames, ctx->h_frames.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->d_frames, h_frames, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, s));
+  if ((rc = ring_commit(ctx, ctx->ring_frames, ring_idx, s))) return rc;
+  if (any_dev_count) hipLaunchKernelGGL(k_patch_counts, dim3((n + 63) / 64), dim3(64), 0, s, ctx->d_frames, n);
   const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
   const int ntiles = tiles_x * tiles_y;
   Scratch sc = ctx->sc;
@@ -2664,9 +2912,12 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     ctx->pre_W = W;
     ctx->pre_We = we;
   }
-  ctx->h_pre.resize(n);
+  int ring_idx, rrc;
+  void* ring_host;
+  if ((rrc = ring_acquire(ctx, ctx->ring_pre, sizeof(rrpre::PreFrame) * (size_t)n, ring_idx, ring_host))) return rrc;
+  rrpre::PreFrame* h_pre = static_cast<rrpre::PreFrame*>(ring_host);
   for (int f = 0; f < n; f++) {
-    rrpre::PreFrame& p = ctx->h_pre[f];
+    rrpre::PreFrame& p = h_pre[f];
     p.bg = in[f].bg;
     p.depth = in[f].depth;
     p.rainy = env_only ? const_cast<double*>(in[f].bg) : out[f].rainy_bg;   // env-only: the map kernels read the caller's image
@@ -2679,7 +2930,8 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     p.depth_f64 = in[f].depth_f64;
     p.pad = 0;
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_pre, ctx->h_pre.data(), sizeof(rrpre::PreFrame) * n, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->d_pre, h_pre, sizeof(rrpre::PreFrame) * n, hipMemcpyHostToDevice, s));
+  if ((rrc = ring_commit(ctx, ctx->ring_pre, ring_idx, s))) return rrc;
   const rrpre::PreScratch sc = ctx->psc;
   const unsigned px_blocks = (unsigned)(((int64_t)H * W + 255) / 256);
   if (!env_only) {
@@ -2720,17 +2972,61 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
   return RR_OK;
 }
 
+// particle generator + packer of n frames (device output); see include/rainhip.h
+int enqueue_particles(rr_ctx* ctx, int n, const rr_sim_frame* sims, int H, int W, rr_drop* drops_out, int cap, int32_t* n_out, hipStream_t s) {
+  if (n <= 0 || !sims || !drops_out || !n_out || cap <= 0 || H <= 0 || W <= 0) {
+    ctx->err = "rr_generate_drops_device: bad argument";
+    return RR_E_ARG;
+  }
+  if (!ctx->have_db || !ctx->d_dgrid) {
+    ctx->err = "particle generator: the streak database and the diameter tables (rr_set_particle_tables) must be set first";
+    return RR_E_STATE;
+  }
+  if (ctx->n_ratio < 4) {
+    ctx->err = "particle generator: the streak database has fewer than four distinct width / height ratios (take_drop_texture, bad_weather.py:250-265)";
+    return RR_E_STATE;
+  }
+  for (int f = 0; f < n; f++) {
+    const rr_sim_frame& sf = sims[f];
+    if (sf.n_particles < 0 || sf.sensor_w <= 0 || sf.sensor_h <= 0 || sf.render_scale <= 0 || sf.table < 0 || sf.table >= ctx->n_tables ||
+        !(sf.fpx > 0) || !(sf.min_px > 0) || !(sf.z_far > 0) || !(sf.exposure_s > 0) || !(sf.margin >= 0) ||
+        sf.sensor_w / sf.render_scale != W || sf.sensor_h / sf.render_scale != H) {
+      ctx->err = "rr_sim_frame: bad settings (sizes must be positive, sensor / render_scale must be the rendered frame, table in range)";
+      return RR_E_ARG;
+    }
+  }
+  int rc;
+  if (n > ctx->cap_sims) {
+    HIPCHK(hipDeviceSynchronize());
+    if ((rc = dev_alloc(ctx, ctx->d_sims, (size_t)n))) return rc;
+    ctx->cap_sims = n;
+  }
+  int ring_idx;
+  void* host;
+  if ((rc = ring_acquire(ctx, ctx->ring_sims, sizeof(rr_sim_frame) * (size_t)n, ring_idx, host))) return rc;
+  memcpy(host, sims, sizeof(rr_sim_frame) * (size_t)n);
+  HIPCHK(hipMemcpyAsync(ctx->d_sims, host, sizeof(rr_sim_frame) * (size_t)n, hipMemcpyHostToDevice, s));
+  if ((rc = ring_commit(ctx, ctx->ring_sims, ring_idx, s))) return rc;
+  {
+    ProfScope ps(ctx, s, "k_particles");
+    hipLaunchKernelGGL(k_particles, dim3(n), dim3(512), 0, s, ctx->d_sims, H, W, ctx->d_dgrid, ctx->d_cdf, ctx->n_grid, ctx->d_ratio_db,
+                       drops_out, cap, n_out);
+  }
+  {
+    ProfScope ps(ctx, s, "k_particle_draws");
+    hipLaunchKernelGGL(k_particle_draws, dim3(n), dim3(64), 0, s, ctx->d_sims, drops_out, cap, n_out);
+  }
+  HIPCHK(hipGetLastError());
+  return RR_OK;
+}
+
 // returns RR_OK, or RR_E_ARENA after growing the arena (caller re-enqueues)
 int check_overflow(rr_ctx* ctx, hipStream_t s) {
   int32_t ovf = 0;
   HIPCHK(hipMemcpyAsync(&ovf, ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (!ovf) return RR_OK;
-  ctx->h_need.resize(ctx->last_n);
-  HIPCHK(hipMemcpy(ctx->h_need.data(), ctx->sc.arena_need, sizeof(int64_t) * ctx->last_n, hipMemcpyDeviceToHost));
-  int64_t need = 0;
-  for (int64_t v : ctx->h_need) need = v > need ? v : need;
-  int rc = grow_arena(ctx, need);
+  int rc = grow_arena(ctx);
   if (rc) return rc;
   ctx->err = "tile arena overflow: arena regrown, re-enqueue the batch";
   return RR_E_ARENA;
@@ -2812,6 +3108,18 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.means);
   hipFree(ctx->sc.arena_need);
   hipFree(ctx->sc.overflow);
+  hipFree(ctx->sc.need_max);
+  hipFree(ctx->d_dgrid);
+  hipFree(ctx->d_cdf);
+  hipFree(ctx->d_ratio_db);
+  hipFree(ctx->d_sims);
+  hipFree(ctx->d_gen_drops);
+  hipFree(ctx->d_gen_counts);
+  for (auto* r : {&ctx->ring_frames, &ctx->ring_pre, &ctx->ring_sims})
+    for (int k = 0; k < rr_ctx::DescRing::N; k++) {
+      if (r->host[k]) hipHostFree(r->host[k]);
+      if (r->ev[k]) hipEventDestroy(r->ev[k]);
+    }
   hipFree(ctx->d_frames);
   hipFree(ctx->d_comp_out);
   for (auto& sl : ctx->slots) {
@@ -2826,6 +3134,7 @@ int rr_destroy(rr_ctx* ctx) {
     hipFree(sl.st.mask_i);
     hipFree(sl.st.status);
     hipFree(sl.st.colour);
+    hipFree(sl.st.ndrops);
     hipFree(sl.st.depth);
     hipFree(sl.st.env_u8);
     hipFree(sl.st.bg8);
@@ -2872,6 +3181,15 @@ static int set_db_meta(rr_ctx* ctx, const int32_t* tex_h, const int32_t* tex_w, 
   HIPCHK(hipMemcpy(ctx->d_tex_off, tex_off, sizeof(int64_t) * n_tex, hipMemcpyHostToDevice));
   ctx->n_tex = n_tex;
   ctx->have_db = true;
+  {                                     // DBManager.ratio = np.unique(w / h) (bad_weather.py:134,144): take_drop_texture's thresholds
+    std::vector<double> r;
+    for (int i = 0; i < n_tex; i++) r.push_back((double)tex_w[i] / (double)tex_h[i]);
+    std::sort(r.begin(), r.end());
+    r.erase(std::unique(r.begin(), r.end()), r.end());
+    ctx->n_ratio = (int)r.size();
+    if ((rc = dev_alloc(ctx, ctx->d_ratio_db, r.size() < 4 ? 4 : r.size()))) return rc;
+    HIPCHK(hipMemcpy(ctx->d_ratio_db, r.data(), sizeof(double) * r.size(), hipMemcpyHostToDevice));
+  }
   return RR_OK;
 }
 
@@ -2954,6 +3272,72 @@ int rr_synchronize(rr_ctx* ctx) {
   return RR_OK;
 }
 
+int rr_set_particle_tables(rr_ctx* ctx, int32_t n_tables, int32_t n_grid, const double* d_grid, const double* cdf) {
+  if (!ctx) return RR_E_ARG;
+  if (n_tables <= 0 || n_grid < 2 || !d_grid || !cdf) {
+    ctx->err = "rr_set_particle_tables: bad argument";
+    return RR_E_ARG;
+  }
+  for (int t = 0; t < n_tables; t++) {
+    const double* c = cdf + (size_t)t * n_grid;
+    bool ok = c[0] == 0.0 && c[n_grid - 1] == 1.0;
+    for (int k = 1; k < n_grid && ok; k++) ok = c[k] >= c[k - 1] && d_grid[k] > d_grid[k - 1];
+    // the cell a number u in (0, 1) falls into must have a positive width: the first and the last cell are the ones u can
+    // reach with cdf[j] <= u < cdf[j + 1] for every u only if no run of equal values touches ... any run is skipped by
+    // the search (it returns the LAST j with cdf[j] <= u), so equal neighbours are harmless except at the very end
+    ok = ok && c[n_grid - 2] < 1.0;
+    if (!ok) {
+      ctx->err = "rr_set_particle_tables: d_grid must ascend, every cdf must run from 0 to 1 without decreasing (and reach 1 only at its last entry)";
+      return RR_E_ARG;
+    }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  int rc;
+  if ((rc = dev_alloc(ctx, ctx->d_dgrid, (size_t)n_grid))) return rc;
+  if ((rc = dev_alloc(ctx, ctx->d_cdf, (size_t)n_tables * n_grid))) return rc;
+  HIPCHK(hipMemcpy(ctx->d_dgrid, d_grid, sizeof(double) * n_grid, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_cdf, cdf, sizeof(double) * (size_t)n_tables * n_grid, hipMemcpyHostToDevice));
+  ctx->n_grid = n_grid;
+  ctx->n_tables = n_tables;
+  return RR_OK;
+}
+
+int rr_generate_drops_device(rr_ctx* ctx, int32_t n, const rr_sim_frame* frames, int32_t H, int32_t W, rr_drop* drops_out, int32_t cap,
+                             int32_t* n_out, void* stream) {
+  if (!ctx) return RR_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  return enqueue_particles(ctx, n, frames, H, W, drops_out, cap, n_out, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int rr_generate_drops(rr_ctx* ctx, int32_t n, const rr_sim_frame* frames, int32_t H, int32_t W, rr_drop* drops_out, int32_t cap, int32_t* n_out) {
+  if (!ctx) return RR_E_ARG;
+  if (n <= 0 || cap <= 0 || !drops_out || !n_out) {
+    ctx->err = "rr_generate_drops: bad argument";
+    return RR_E_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  const size_t nd = (size_t)n * (size_t)cap;
+  if (nd > ctx->cap_gen_drops) {
+    HIPCHK(hipDeviceSynchronize());
+    if ((rc = dev_alloc(ctx, ctx->d_gen_drops, nd))) return rc;
+    ctx->cap_gen_drops = nd;
+  }
+  if ((size_t)n > ctx->cap_gen_counts) {
+    HIPCHK(hipDeviceSynchronize());
+    if ((rc = dev_alloc(ctx, ctx->d_gen_counts, (size_t)n))) return rc;
+    ctx->cap_gen_counts = (size_t)n;
+  }
+  if ((rc = enqueue_particles(ctx, n, frames, H, W, ctx->d_gen_drops, cap, ctx->d_gen_counts, ctx->stream))) return rc;
+  HIPCHK(hipMemcpyAsync(n_out, ctx->d_gen_counts, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(drops_out, ctx->d_gen_drops, sizeof(rr_drop) * nd, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RR_OK;
+}
+
+int rr_sizeof_sim_frame(void) { return (int)sizeof(rr_sim_frame); }
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------
@@ -3000,6 +3384,7 @@ int slot_reserve(rr_ctx* ctx, rr_ctx::Staging& st, int n, int max_drops, const D
     if ((rc = dev_alloc(ctx, st.mask_i, F * px))) return rc;
     if ((rc = dev_alloc(ctx, st.status, (size_t)F * D))) return rc;
     if ((rc = dev_alloc(ctx, st.colour, (size_t)F * D * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st.ndrops, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, st.depth, F * px))) return rc;
     if ((rc = dev_alloc(ctx, st.env_u8, F * ex * 3))) return rc;
     if ((rc = dev_alloc(ctx, st.bg8, F * px * 3))) return rc;
@@ -3078,7 +3463,16 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         ctx->err = "all frames of a batch must share H,W,He,We";
         return RR_E_ARG;
       }
-      if (in[f].n_drops < 0 || in[f].n_drops > 65536) {
+      if (in[f].n_drops_dev) {
+        ctx->err = "n_drops_dev is a device pointer: rr_render_frames_device only";
+        return RR_E_ARG;
+      }
+      if ((in[f].sim != nullptr) != (in[0].sim != nullptr) || (in[f].sim && in[f].ext)) {
+        ctx->err = "generated drop tables (rr_frame_in.sim): for every frame of a batch or for none, and without rr_ext_tile";
+        return RR_E_ARG;
+      }
+      const int cap_f = in[f].sim ? (in[f].n_drops > 0 ? in[f].n_drops : in[f].sim->n_particles) : in[f].n_drops;
+      if (cap_f < 0 || cap_f > 65536) {
         ctx->err = "n_drops outside [0, 2^16] (generator.py:425)";
         return RR_E_ARG;
       }
@@ -3086,7 +3480,7 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         ctx->err = "rendering strategy must be 0 (default) or 1 ('white'); 'naive_db' is broken in the reference (bad_weather.py:355)";
         return RR_E_ARG;
       }
-      if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (in[f].n_drops > 0 && !in[f].drops) ||
+      if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (!in[f].sim && in[f].n_drops > 0 && !in[f].drops) ||
           (!out[f].rainy_rgb && !out[f].rainy_png)) {
         ctx->err = "null frame pointer (an image output is needed: rainy_rgb or rainy_png)";
         return RR_E_ARG;
@@ -3095,7 +3489,7 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         ctx->err = "mask_png needs rr_set_colormap";
         return RR_E_STATE;
       }
-      if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
+      if (cap_f > max_drops) max_drops = cap_f;
     }
   }
   if (in && (!ctx->have_cam || !ctx->have_db)) {
@@ -3136,6 +3530,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   std::vector<rr_prepass_in> pin(pre ? n : 0);
   std::vector<rr_prepass_out> pout(pre ? n : 0);
   CopyList up, down;
+  std::vector<rr_sim_frame> sims;
   // ---- upload ----
   for (int f = 0; pre && f < n; f++) {
     pin[f] = pre[f];
@@ -3175,7 +3570,14 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
       up.add((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double));
     }
     if (!same_omega) up.add((void*)din[f].omega, in[f].omega, ex * sizeof(double));
-    up.add((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * (size_t)in[f].n_drops);
+    din[f].sim = nullptr;
+    if (in[f].sim) {                  // the drop table is generated on the device (below): nothing to upload
+      sims.push_back(*in[f].sim);
+      din[f].n_drops = in[f].n_drops > 0 ? in[f].n_drops : in[f].sim->n_particles;
+      din[f].n_drops_dev = st.ndrops + f;
+    } else {
+      up.add((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * (size_t)in[f].n_drops);
+    }
     dout[f].rainy_rgb = st.rgb + f * px * 3;
     dout[f].rainy_bg_out = st.comp + f * px * 3;
     dout[f].mask_f64 = st.mask + f * px;
@@ -3228,6 +3630,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
       hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256)), dim3(256), 0, s, st.bg8 + f * px * 3,
                          (double*)pin[f].bg, (int64_t)(px * 3));
   if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return rc;
+  if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, st.drops_cap, st.ndrops, s))) return rc;
   if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return rc;
   HIPCHK(hipEventRecord(sl.ev_comp, s));
   // ---- download ----
@@ -3237,8 +3640,9 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     if (out[f].rainy_bg_out) down.add(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double));
     if (out[f].mask_f64) down.add(out[f].mask_f64, dout[f].mask_f64, px * sizeof(double));
     if (out[f].mask_i32) down.add(out[f].mask_i32, dout[f].mask_i32, px * sizeof(int32_t));
-    if (out[f].drop_status) down.add(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * (size_t)in[f].n_drops);
-    if (out[f].drop_colour) down.add(out[f].drop_colour, dout[f].drop_colour, sizeof(double) * 3 * (size_t)in[f].n_drops);
+    if (out[f].drop_status) down.add(out[f].drop_status, dout[f].drop_status, sizeof(int32_t) * (size_t)din[f].n_drops);
+    if (out[f].drop_colour) down.add(out[f].drop_colour, dout[f].drop_colour, sizeof(double) * 3 * (size_t)din[f].n_drops);
+    if (out[f].n_drops_out && in[f].sim) down.add(out[f].n_drops_out, st.ndrops + f, sizeof(int32_t));
     if (out[f].rainy_png) down.add(out[f].rainy_png, dout[f].rainy_png, png_bytes);
     if (out[f].mask_png) down.add(out[f].mask_png, dout[f].mask_png, png_bytes);
   }
@@ -3273,11 +3677,7 @@ int host_wait(rr_ctx* ctx, int slot) {
     int32_t still = 0;
     HIPCHK(hipMemcpy(&still, ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (still) {
-      ctx->h_need.resize(ctx->last_n);
-      HIPCHK(hipMemcpy(ctx->h_need.data(), ctx->sc.arena_need, sizeof(int64_t) * ctx->last_n, hipMemcpyDeviceToHost));
-      int64_t need = 0;
-      for (int64_t v : ctx->h_need) need = v > need ? v : need;
-      int rc = grow_arena(ctx, need);
+      int rc = grow_arena(ctx);
       if (rc) return rc;
     }
     ctx->err = "tile arena overflow: arena regrown, submit the batch again";

@@ -403,7 +403,9 @@ int decode(const Png& p, std::vector<uint8_t>& img, size_t& stride) {
   const size_t raw_len = (stride + 1) * p.h;
   std::vector<uint8_t> raw(raw_len + 16);               // (spare bytes: the fast decoder copies matches in 8-byte pieces)
   {
-    std::vector<uint8_t> zin(p.idat.size() + 16, 0);    // (it also loads 8 bytes at a time, up to 12 past the end)
+    // (it also loads 8 bytes at a time; between two of its bound checks a malformed stream can pull the read position up
+    //  to ~30 bytes past the end -- block header + code-length codes, or the refills of one match -- hence 64 spare bytes)
+    std::vector<uint8_t> zin(p.idat.size() + 64, 0);
     memcpy(zin.data(), p.idat.data(), p.idat.size());
     if (!inflate_fast::inflate(zin.data(), p.idat.size(), raw.data(), raw_len)) {      // anything unusual: zlib decides
       uLongf out_len = (uLongf)raw_len;
@@ -704,7 +706,7 @@ void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
 
 }  // namespace
 
-extern "C" int rr_png_info(const char* path, int32_t* w, int32_t* h, int32_t* channels, int32_t* bit_depth) {
+static int rr_png_info_impl(const char* path, int32_t* w, int32_t* h, int32_t* channels, int32_t* bit_depth) {
   if (!path || !w || !h || !channels || !bit_depth) return RR_E_ARG;
   std::vector<uint8_t> f;
   int rc = read_file(path, f);
@@ -720,7 +722,7 @@ extern "C" int rr_png_info(const char* path, int32_t* w, int32_t* h, int32_t* ch
 }
 
 // cv2.imread(path): 8 bits per channel, three channels, B G R
-extern "C" int rr_png_read_bgr8(const char* path, uint8_t* out, int32_t H, int32_t W) {
+static int rr_png_read_bgr8_impl(const char* path, uint8_t* out, int32_t H, int32_t W) {
   if (!path || !out) return RR_E_ARG;
   std::vector<uint8_t> f;
   int rc = read_file(path, f);
@@ -763,7 +765,7 @@ extern "C" int rr_png_read_bgr8(const char* path, uint8_t* out, int32_t H, int32
 }
 
 // cv2.imread(path, cv2.IMREAD_UNCHANGED) of a 16-bit single-channel PNG (depth maps: metres * 256, generator.py:365)
-extern "C" int rr_png_read_gray16(const char* path, uint16_t* out, int32_t H, int32_t W) {
+static int rr_png_read_gray16_impl(const char* path, uint16_t* out, int32_t H, int32_t W) {
   if (!path || !out) return RR_E_ARG;
   std::vector<uint8_t> f;
   int rc = read_file(path, f);
@@ -783,7 +785,7 @@ extern "C" int rr_png_read_gray16(const char* path, uint16_t* out, int32_t H, in
 // strategy: 0 zlib's default (LZ77 + Huffman), 1 Z_RLE (run lengths + Huffman: on filtered image data as small as
 // level 1 of the default strategy or smaller, at half the time), 2 Z_HUFFMAN_ONLY, 3 the library's own run-length +
 // dynamic-Huffman encoder (fast_deflate above; `level` is ignored).
-extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int32_t W, int32_t H, int32_t level, int32_t strategy) {
+static int rr_png_write_scanlines_impl(const char* path, const uint8_t* rows, int32_t W, int32_t H, int32_t level, int32_t strategy) {
   if (!path || !rows || W <= 0 || H <= 0 || level < 0 || level > 9 || strategy < 0 || strategy > 3) return RR_E_ARG;
   const uLong n = (uLong)H * (1 + 4 * (uLong)W);
   std::vector<uint8_t> z;
@@ -835,7 +837,7 @@ extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int
 // The zlib stream strategy 3 writes, for n arbitrary bytes: out must hold rr_deflate_bound(n) bytes; returns the stream's
 // length (tests inflate it with zlib and compare; scripts time it against zlib's strategies).
 extern "C" int64_t rr_deflate_bound(int64_t n) { return n + n / 4 + 4096; }
-extern "C" int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
+static int64_t rr_deflate_fast_impl(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
   if (!in || !out || n < 0) return RR_E_ARG;
   ByteBuf z;
   fast_deflate(in, (size_t)n, z);
@@ -846,11 +848,56 @@ extern "C" int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, i
 
 // The reader's own inflate on a complete zlib stream whose decoded size is known (tests compare it with zlib on streams of
 // every kind; returns 1 when it vouches for the result, 0 when the caller should use zlib).
-extern "C" int rr_inflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len) {
+static int rr_inflate_fast_impl(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len) {
   if (!in || !out || n < 0 || out_len < 0) return RR_E_ARG;
-  std::vector<uint8_t> zin((size_t)n + 16, 0), buf((size_t)out_len + 16);
+  std::vector<uint8_t> zin((size_t)n + 64, 0), buf((size_t)out_len + 16);
   memcpy(zin.data(), in, (size_t)n);
   const bool ok = inflate_fast::inflate(zin.data(), (size_t)n, buf.data(), (size_t)out_len);
   if (ok) memcpy(out, buf.data(), (size_t)out_len);
   return ok ? 1 : 0;
+}
+
+// No exception crosses the C ABI: an allocation failure (absurd sizes in a damaged file) or any other C++ exception inside
+// the codec comes back as RR_E_PARSE.
+extern "C" int rr_png_info(const char* path, int32_t* w, int32_t* h, int32_t* channels, int32_t* bit_depth) {
+  try {
+    return rr_png_info_impl(path, w, h, channels, bit_depth);
+  } catch (...) {
+    return RR_E_PARSE;
+  }
+}
+extern "C" int rr_png_read_bgr8(const char* path, uint8_t* out, int32_t H, int32_t W) {
+  try {
+    return rr_png_read_bgr8_impl(path, out, H, W);
+  } catch (...) {
+    return RR_E_PARSE;
+  }
+}
+extern "C" int rr_png_read_gray16(const char* path, uint16_t* out, int32_t H, int32_t W) {
+  try {
+    return rr_png_read_gray16_impl(path, out, H, W);
+  } catch (...) {
+    return RR_E_PARSE;
+  }
+}
+extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int32_t W, int32_t H, int32_t level, int32_t strategy) {
+  try {
+    return rr_png_write_scanlines_impl(path, rows, W, H, level, strategy);
+  } catch (...) {
+    return RR_E_PARSE;
+  }
+}
+extern "C" int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
+  try {
+    return rr_deflate_fast_impl(in, n, out, cap);
+  } catch (...) {
+    return RR_E_PARSE;
+  }
+}
+extern "C" int rr_inflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len) {
+  try {
+    return rr_inflate_fast_impl(in, n, out, out_len);
+  } catch (...) {
+    return RR_E_PARSE;
+  }
 }

@@ -29,6 +29,15 @@ DROP_DTYPE = np.dtype([
 ], align=True)
 
 
+# numpy mirror of rr_sim_frame (the particle generator's per-frame settings, include/rainhip.h)
+SIM_FRAME_DTYPE = np.dtype([
+    ('sensor_w', '<i4'), ('sensor_h', '<i4'), ('render_scale', '<i4'), ('n_particles', '<i4'),
+    ('key0', '<u4'), ('key1', '<u4'), ('frame', '<u4'), ('draw_seed', '<u4'), ('table', '<i4'), ('reserved', '<i4'),
+    ('fpx', '<f8'), ('exposure_s', '<f8'), ('speed_mps', '<f8'), ('wind_sigma', '<f8'), ('margin', '<f8'), ('min_px', '<f8'),
+    ('z_far', '<f8'),
+], align=True)
+
+
 class rr_camera(ctypes.Structure):
     _fields_ = [('focal_m', ctypes.c_double), ('focal_sq', ctypes.c_double), ('f_number', ctypes.c_double),
                 ('focus_plane', ctypes.c_double), ('exposure_s', ctypes.c_double), ('radius', ctypes.c_double),
@@ -44,7 +53,7 @@ class rr_frame_in(ctypes.Structure):
                 ('omega', ctypes.c_void_p), ('drops', ctypes.c_void_p),
                 ('n_drops', ctypes.c_int32), ('strategy', ctypes.c_int32),
                 ('opacity_attenuation', ctypes.c_double), ('depth', ctypes.c_void_p), ('depth_f64', ctypes.c_int32),
-                ('reserved', ctypes.c_int32), ('ext', ctypes.c_void_p)]
+                ('reserved', ctypes.c_int32), ('ext', ctypes.c_void_p), ('n_drops_dev', ctypes.c_void_p), ('sim', ctypes.c_void_p)]
 
 
 class rr_ext_tile(ctypes.Structure):
@@ -55,7 +64,8 @@ class rr_ext_tile(ctypes.Structure):
 class rr_frame_out(ctypes.Structure):
     _fields_ = [('rainy_rgb', ctypes.c_void_p), ('rainy_bg_out', ctypes.c_void_p), ('mask_f64', ctypes.c_void_p),
                 ('mask_i32', ctypes.c_void_p), ('drop_status', ctypes.c_void_p),
-                ('rainy_png', ctypes.c_void_p), ('mask_png', ctypes.c_void_p), ('drop_colour', ctypes.c_void_p)]
+                ('rainy_png', ctypes.c_void_p), ('mask_png', ctypes.c_void_p), ('drop_colour', ctypes.c_void_p),
+                ('n_drops_out', ctypes.c_void_p)]
 
 
 class rr_kernel_stat(ctypes.Structure):
@@ -97,7 +107,8 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
-           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast']
+           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops',
+           'rr_sizeof_sim_frame']
 
 _lib = None
 
@@ -166,6 +177,12 @@ def load_library(path=None):
                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                        ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_set_particle_tables.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_generate_drops_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_generate_drops.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    assert lib.rr_sizeof_sim_frame() == SIM_FRAME_DTYPE.itemsize, (lib.rr_sizeof_sim_frame(), SIM_FRAME_DTYPE.itemsize)
     assert lib.rr_sizeof_prepass_in() == ctypes.sizeof(rr_prepass_in)
     assert lib.rr_sizeof_prepass_out() == ctypes.sizeof(rr_prepass_out)
     assert lib.rr_sizeof_prepass_kernels() == ctypes.sizeof(rr_prepass_kernels)
@@ -310,11 +327,16 @@ def _table_view(table):
     return t
 
 
-def pack_frame(table, db, imW, imH, seed, noise_std=0.0, noise_scale=0.0):
+def pack_frame(table, db, imW, imH, seed, noise_std=0.0, noise_scale=0.0, rotation='numpy'):
     """filter_streaks + pack_drops(seed=...) of one frame with the per-drop work in the library
     (rr_host_frame_draws / rr_host_assemble_drops: no interpreter lock held, so I/O threads scale); numpy keeps the
     rotation terms (acos / cos / sin).  Same records as pack_drops(table, filter_streaks(table, imW, imH), db, ..., seed);
-    rotates the end points of `table` in place when angular noise is on, like the reference (generator.py:152-161)."""
+    rotates the end points of `table` in place when angular noise is on, like the reference (generator.py:152-161).
+
+    rotation='exact' (no angular noise only): the rotation terms the device-side packer writes (rr_particles.h
+    derive_drop) -- cos(-theta) = -dy / n and sin(-theta) = -|dx| / n, what the reference's acos / rad2deg / cos chain
+    (generator.py:138-145,163) evaluates to when carried out exactly, from + - * / sqrt alone: within an ulp or two of
+    the numpy chain and the same on every machine."""
     lib = load_library()
     if not 0 <= int(seed) <= 2 ** 32 - 1:
         raise ValueError("Seed must be between 0 and 2**32 - 1")
@@ -337,9 +359,15 @@ def pack_frame(table, db, imW, imH, seed, noise_std=0.0, noise_scale=0.0):
     with np.errstate(all='ignore'):
         d = s - e
         n1 = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
-        theta = np.rad2deg(np.arccos((d[:, 0] / n1) * 0 + (d[:, 1] / n1) * -1))
-        ang = -(theta + noise) * (np.pi / 180)
-        rot_cos, rot_sin = np.cos(ang), np.sin(ang)
+        if rotation == 'exact':
+            if np.any(noise != 0):
+                raise ValueError("rotation='exact' is defined without angular noise")
+            rot_cos = (d[:, 0] / n1) * 0.0 + (d[:, 1] / n1) * -1.0
+            rot_sin = -(np.abs(d[:, 0]) / n1)
+        else:
+            theta = np.rad2deg(np.arccos((d[:, 0] / n1) * 0 + (d[:, 1] / n1) * -1))
+            ang = -(theta + noise) * (np.pi / 180)
+            rot_cos, rot_sin = np.cos(ang), np.sin(ang)
     if np.any(noise != 0):
         nb = table.type[keep] != 0
         nx, ny = np.cos(np.deg2rad(noise)), np.sin(np.deg2rad(noise))
@@ -427,6 +455,16 @@ class RainHip:
         buf = (ctypes.c_uint8 * max(n, 1)).from_address(ptr.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def host_free(self, array):
+        """Give a host_array back (rr_host_free).  The array -- and every view of it -- must not be used afterwards and no
+        batch that reads or writes it may be in flight."""
+        addr = array.ctypes.data
+        pinned = getattr(self, '_pinned', [])
+        if addr not in pinned:
+            raise ValueError("not a host_array of this context (or already freed)")
+        pinned.remove(addr)
+        self._check(self.lib.rr_host_free(self.h, ctypes.c_void_p(addr)), 'rr_host_free')
+
     def pipeline_submit(self, slot, frames, outs):
         """rr_pipeline_submit: frames as for pipeline_frames (dict(bg | bg_u8, depth, fog, omega, drops, ...)), or as for
         render_frames (dict(bg, rainy_bg, env_xyY, omega, drops)) when they carry no 'depth'; outs: list of
@@ -441,7 +479,14 @@ class RainHip:
         We = self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width') if with_pre else 0
         for k, (fr, o) in enumerate(zip(frames, outs)):
             om = np.ascontiguousarray(fr['omega'], np.float64)
-            drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
+            sim = fr.get('sim')                        # SIM_FRAME_DTYPE record: the drop table is generated on the device;
+            if sim is not None:                        # o['status'] (if any) must hold fr['drops_cap'] entries
+                sim = np.ascontiguousarray(sim, SIM_FRAME_DTYPE).reshape(1)
+                drops = np.zeros(int(fr.get('drops_cap', 0)) or int(sim['n_particles'][0]), DROP_DTYPE)[:0]
+                cap = int(fr.get('drops_cap', 0)) or int(sim['n_particles'][0])
+            else:
+                drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
+                cap = len(drops)
             if with_pre:
                 bg = self._fill_prepass(pin[k], fr, keep)
                 H, W = bg.shape[:2]
@@ -457,7 +502,13 @@ class RainHip:
                 keep.append((bg, rb, env))
             fin[k].omega = _ptr(om)
             fin[k].drops = _ptr(drops) if len(drops) else None
-            fin[k].n_drops = len(drops)
+            fin[k].n_drops = cap
+            if sim is not None:
+                fin[k].sim = _ptr(sim)
+                keep.append(sim)
+                nd_out = o.get('n_drops')
+                assert nd_out is None or (nd_out.dtype == np.int32 and nd_out.size >= 1)
+                fout[k].n_drops_out = _ptr(nd_out)
             fin[k].strategy = int(fr.get('strategy', 0))
             fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
             for name, dt in (('image_u8', np.uint8), ('mask', np.float64), ('mask_i32', np.int32), ('rainy_bg', np.float64),
@@ -469,7 +520,8 @@ class RainHip:
             fout[k].rainy_bg_out = _ptr(o.get('rainy_bg'))
             fout[k].mask_f64 = _ptr(o.get('mask'))
             fout[k].mask_i32 = _ptr(o.get('mask_i32'))
-            fout[k].drop_status = _ptr(o.get('status')) if len(drops) else None
+            fout[k].drop_status = _ptr(o.get('status')) if cap else None
+            assert o.get('status') is None or o['status'].size >= cap
             fout[k].rainy_png = _ptr(o.get('rainy_png'))
             fout[k].mask_png = _ptr(o.get('mask_png'))
             keep.append((om, drops))
@@ -524,6 +576,33 @@ class RainHip:
         assert lut.shape == (256, 4)
         self._check(self.lib.rr_set_colormap(self.h, _ptr(lut)), 'rr_set_colormap')
 
+    # ---- drop tables born on the device (particle generator, BASELINE configs[4]) ---------------------------
+    def set_particle_tables(self, d_grid, cdf):
+        """Inverse-CDF tables of the drop diameter (tools/particles.diameter_tables): d_grid [n], cdf [n_tables, n]."""
+        d = np.ascontiguousarray(d_grid, np.float64)
+        c = np.ascontiguousarray(np.atleast_2d(cdf), np.float64)
+        assert c.shape[1] == len(d)
+        self._check(self.lib.rr_set_particle_tables(self.h, c.shape[0], len(d), _ptr(d), _ptr(c)), 'rr_set_particle_tables')
+
+    def generate_drops_device(self, sims, H, W, drops_ptr, cap, n_out_ptr, stream=None):
+        """rr_generate_drops_device: sims = SIM_FRAME_DTYPE records (host); drops_ptr / n_out_ptr = DEVICE addresses of
+        len(sims) * cap rr_drop records / len(sims) int32 counts."""
+        sims = np.ascontiguousarray(sims, SIM_FRAME_DTYPE)
+        self._check(self.lib.rr_generate_drops_device(self.h, len(sims), _ptr(sims), int(H), int(W), ctypes.c_void_p(drops_ptr), int(cap),
+                                                      ctypes.c_void_p(n_out_ptr), ctypes.c_void_p(stream) if stream else None),
+                    'rr_generate_drops_device')
+
+    def generate_drops(self, sims, H, W, cap=None):
+        """rr_generate_drops: list of DROP_DTYPE arrays (one per frame, what the device generated and packed) and the
+        drop counts (a count above `cap` means the frame's table was cut off at cap records)."""
+        sims = np.ascontiguousarray(sims, SIM_FRAME_DTYPE)
+        n = len(sims)
+        cap = int(cap or max(int(sims['n_particles'].max()), 1))
+        out = np.zeros((n, cap), DROP_DTYPE)
+        cnt = np.zeros(n, np.int32)
+        self._check(self.lib.rr_generate_drops(self.h, n, _ptr(sims), int(H), int(W), _ptr(out), cap, _ptr(cnt)), 'rr_generate_drops')
+        return [out[k, :min(int(cnt[k]), cap)] for k in range(n)], cnt
+
     def set_option(self, option, value):
         """rr_set_option: tuning / A-B switches that never change a result bit (include/rainhip.h)."""
         self._check(self.lib.rr_set_option(self.h, int(option), int(value)), 'rr_set_option')
@@ -546,7 +625,13 @@ class RainHip:
             rb = np.ascontiguousarray(fr['rainy_bg'], np.float64)
             env = np.ascontiguousarray(fr['env_xyY'], np.float64)
             om = np.ascontiguousarray(fr['omega'], np.float64)
-            drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
+            sim = fr.get('sim')                        # one SIM_FRAME_DTYPE record: the drop table is generated on the device
+            if sim is not None:
+                sim = np.ascontiguousarray(sim, SIM_FRAME_DTYPE).reshape(1)
+                cap = int(fr.get('drops_cap', 0)) or int(sim['n_particles'][0])
+                drops = np.zeros(cap, DROP_DTYPE)      # only its length is used (output sizes)
+            else:
+                drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
             H, W = bg.shape[:2]
             He, We = om.shape[:2]
             assert bg.shape == (H, W, 3) and rb.shape == (H, W, 3) and env.shape == (He, We, 3)
@@ -559,8 +644,13 @@ class RainHip:
                 fout[k].drop_colour = _ptr(o['colour']) if len(drops) else None
             fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, He, We
             fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY, fin[k].omega = _ptr(bg), _ptr(rb), _ptr(env), _ptr(om)
-            fin[k].drops = _ptr(drops) if len(drops) else None
+            fin[k].drops = _ptr(drops) if len(drops) and sim is None else None
             fin[k].n_drops = len(drops)
+            if sim is not None:
+                fin[k].sim = _ptr(sim)
+                o['n_drops'] = np.zeros(1, np.int32)
+                fout[k].n_drops_out = _ptr(o['n_drops'])
+                keep.append(sim)
             fin[k].strategy = int(fr.get('strategy', 0))
             fin[k].opacity_attenuation = float(fr.get('opacity_attenuation', 1.0))
             if fr.get('ext') is not None:              # caller-made tiles: [None | dict(alpha HxW, minC (x, y), poly Nx2 | None)] per drop
@@ -590,6 +680,13 @@ class RainHip:
             keep.append((bg, rb, env, om, drops))
             outs.append(o)
         self._check(self.lib.rr_render_frames(self.h, n, fin, fout), 'rr_render_frames')
+        for o in outs:                                 # a generated drop table: trim the per-drop outputs to its drop count
+            if 'n_drops' in o:
+                nd = int(o['n_drops'][0])
+                o['n_drops'] = nd
+                o['status'] = o['status'][:nd]
+                if 'colour' in o:
+                    o['colour'] = o['colour'][:nd]
         return outs
 
     # ---- pre-pass (fog attenuation + environment map), SURVEY 8f next #1/#2 ------------------

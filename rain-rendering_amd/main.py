@@ -117,30 +117,40 @@ def _drop_incomplete_sequences(ns):
 def _locate_particles(ns):
     """One particle file per (sequence, fall rate) (reference main.py:187-220).  Where the reference launches the external
     weather-particle-simulator for missing (or --force_particles) files, this build runs its own generator
-    (tools/particles.py: same settings in, same XML schema out; there is no source of the reference's simulator)."""
-    print("\nResolving particles simulations...")
-    root = _J(ns.particles, ns.dataset)
-    found, to_run = {}, []
-    for seq in ns.sequences:
-        sim = db.sim(ns.dataset, seq, root)
-        for w in ns.weather:
-            if ns.force_particles or not glob.glob(my_utils.particles_path(sim["path"], w)):
-                to_run.append((sim, w))
-    if not to_run:
-        print(" All particles simulations ready")
+    (tools/particles.py: same settings in, same XML schema out; there is no source of the reference's simulator).
+
+    Under several ranks (torch.distributed.run) rank 0 alone looks, generates and decides; the others receive its list
+    (sharding.rank0_decides: a broadcast, which also holds them back until the files are complete).  Every rank
+    regenerating the same file, or globbing while a peer rewrites it, would hand the loader a half-written file."""
+    if __package__ in (None, ''):
+        particles = importlib.import_module('rain-rendering_amd.tools.particles')
+        sharding = importlib.import_module('rain-rendering_amd.sharding')
     else:
-        print(" {} particles simulations to compute...".format(len(to_run)))
-        if __package__ in (None, ''):
-            particles = importlib.import_module('rain-rendering_amd.tools.particles')
-        else:
-            from .tools import particles
-        for sim, w in to_run:
-            print("  " + particles.simulate(sim, w, force_recompute=True))
-        print(" All particles simulation completed")
-    for seq in ns.sequences:
-        sim = db.sim(ns.dataset, seq, root)
-        found[seq] = [glob.glob(my_utils.particles_path(sim["path"], w))[0] for w in ns.weather]
-    ns.particles = found
+        from .tools import particles
+        from . import sharding
+    root = _J(ns.particles, ns.dataset)
+
+    def locate():
+        print("\nResolving particles simulations...")
+        found = {}
+        n_run = 0
+        for seq in ns.sequences:
+            sim = db.sim(ns.dataset, seq, root)
+            found[seq] = []
+            for w in ns.weather:
+                have = sorted(glob.glob(my_utils.particles_path(sim["path"], w)))
+                if ns.force_particles or not have:
+                    if n_run == 0:
+                        print(" particles simulations to compute...")
+                    n_run += 1
+                    path = particles.simulate(sim, w, force_recompute=True)      # the file just written, not a re-glob:
+                    print("  " + path)                                           # a stale *_camera0.xml may sit beside it
+                    found[seq].append(path)
+                else:
+                    found[seq].append(have[0])
+        print(" All particles simulations ready" if n_run == 0 else " All particles simulation completed")
+        return found
+    ns.particles = sharding.rank0_decides(locate, *sharding.rank_world())
 
 
 def check_arg(argv):
@@ -152,13 +162,15 @@ def check_arg(argv):
 
 def main(argv=None):
     print("\nBuilding internal parameters...")
-    args = check_arg(sys.argv[1:] if argv is None else argv)
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # before anything rank 0 decides for the others (particle files)
         import torch
         import torch.distributed as dist
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+    args = check_arg(sys.argv[1:] if argv is None else argv)
     print("\nRunning renderers...")
     generator = Generator(args)
     generator.run()

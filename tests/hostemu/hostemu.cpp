@@ -12,6 +12,7 @@
 
 #include "rr_device.h"
 #include "rr_prepass.h"
+#include "rr_particles.h"
 
 using namespace rr;
 
@@ -303,6 +304,73 @@ int64_t emu_reciprocal_division_mismatches(double d, int64_t n, uint64_t seed) {
     if (q != a / d) bad++;
   }
   return bad;
+}
+
+
+// One frame of the particle generator + packer (rr_particles.h under plain loops: what k_particles / k_particle_draws do
+// on the device), incl. the renderer's per-drop draws from numpy's legacy MT19937 stream (restated here; the product's
+// host version is rr_host.cpp, the device's k_particle_draws).  Also returns the raw particles (n_particles records of
+// 15 doubles: wp1 wp2 wd ip1 ip2 iw1 iw2) when `particles` is not NULL.
+int emu_generate_drops(const rr_sim_frame* sf, int H, int W, const double* dgrid, const double* cdf_tabs, int n_grid,
+                       const double* ratio_db, rr_drop* out, int cap, int32_t* n_out, double* particles) {
+  const double* cdf = cdf_tabs + (size_t)sf->table * n_grid;
+  int n = 0;
+  for (int i = 0; i < sf->n_particles; i++) {
+    rrsim::Particle p;
+    rrsim::make_particle(*sf, dgrid, cdf, n_grid, (uint32_t)i, p);
+    if (particles) {
+      double* q = particles + (size_t)i * 15;
+      for (int k = 0; k < 3; k++) { q[k] = p.wp1[k]; q[3 + k] = p.wp2[k]; }
+      q[6] = p.wd; q[7] = p.ip1[0]; q[8] = p.ip1[1]; q[9] = p.ip2[0]; q[10] = p.ip2[1]; q[11] = p.iw1; q[12] = p.iw2;
+    }
+    rr_drop d;
+    double ratio;
+    if (!rrsim::derive_drop(p, sf->render_scale, W, H, d, ratio)) continue;
+    d.tex_index = 10 * rrsim::texture_bucket(ratio, ratio_db);
+    if (n < cap) out[n] = d;
+    n++;
+  }
+  *n_out = n;
+  // MT19937, numpy's legacy seeding; randint(lo, lo + 10) by masked rejection; legacy gauss' consumption
+  uint32_t key[624];
+  uint32_t seed = sf->draw_seed;
+  for (int pos = 0; pos < 624; pos++) { key[pos] = seed; seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u; }
+  int pos = 624;
+  auto u32 = [&]() -> uint32_t {
+    if (pos == 624) {
+      for (int kk = 0; kk < 624; kk++) {
+        const uint32_t y = (key[kk] & 0x80000000u) | (key[(kk + 1) % 624] & 0x7fffffffu);
+        key[kk] = key[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      pos = 0;
+    }
+    uint32_t y = key[pos++];
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+  };
+  auto dbl = [&]() -> double {
+    const int32_t a = (int32_t)(u32() >> 5), b = (int32_t)(u32() >> 6);
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  };
+  bool has_gauss = false;
+  const int m = n < cap ? n : cap;
+  for (int k = 0; k < m; k++) {
+    uint32_t v;
+    do { v = u32() & 15u; } while (v > 9u);
+    out[k].tex_index += (int32_t)v;
+    if (out[k].type != 0) {
+      if (has_gauss) has_gauss = false;
+      else {
+        double r2;
+        do {
+          const double x1 = 2.0 * dbl() - 1.0, x2 = 2.0 * dbl() - 1.0;
+          r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        has_gauss = true;
+      }
+    }
+  }
+  return 0;
 }
 
 }  // extern "C"

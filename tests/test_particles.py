@@ -89,3 +89,70 @@ def test_simulate_writes_the_reference_layout(tmp_path):
     fr, dr = h.bw._read_particles(path)
     assert len(fr) == 2 and len(dr) == fr['n_drops'].sum() > 0
     assert particles.simulate(sim, {"weather": "rain", "fallrate": 5}) == path       # existing file: not recomputed
+
+
+# ---- the generator's two statements: numpy (tools/particles.py) and C++ (csrc/rr_particles.h, what k_particles runs) ----
+def _emu_generate(sims, dgrid, cdf, ratio_db, H, W):
+    emu = h.hostemu()
+    outs = []
+    for k in range(len(sims)):
+        s = sims[k:k + 1]
+        cap = max(int(s['n_particles'][0]), 1)
+        out = np.zeros(cap, h.hb.DROP_DTYPE)
+        n_out = np.zeros(1, np.int32)
+        raw = np.zeros((cap, 15))
+        emu.emu_generate_drops(h._p(s), H, W, h._p(dgrid), h._p(cdf), len(dgrid), h._p(ratio_db), h._p(out), cap, h._p(n_out), h._p(raw))
+        outs.append((out[:int(n_out[0])], raw[:int(s['n_particles'][0])]))
+    return outs
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 against the known-answer vectors of the Random123 distribution (kat_vectors: philox4x32 10)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = particles.philox4x32(*[np.array([c], np.uint64) for c in ctr], key[0], key[1])
+        assert tuple(int(g[0]) for g in got) == want
+
+
+@pytest.mark.parametrize("dataset,rs,rate,count", [('kitti', 1, 25, None), ('cityscapes', 2, 50, None), ('nuscenes', 1, 100, None),
+                                                   ('nuscenes', 1, 200, 3000)])
+def test_cpp_statement_equals_numpy_statement(tmp_path, dataset, rs, rate, count):
+    """csrc/rr_particles.h compiled with g++ (tests/hostemu: make_particle, derive_drop, the texture block, the legacy
+    MT19937 draws) against tools/particles.py: raw particles and packed rr_drop records, bit for bit -- before the GPU
+    tier asks the same of k_particles / k_particle_draws."""
+    sc = h.Scene(tmp_path, 64, 96, 10)
+    ratio_db = np.ascontiguousarray(sc.db.ratio, np.float64)
+    opt = _options(dataset, sim_steps={"cam_motion": np.array([30.0, 0.0, 50.0])})
+    sims, dgrid, cdf = particles.sim_frames(opt, rate, 3, render_scale=rs, seed=7 + 2 ** 33, draw_seeds=[3, 11, 400000], count=count)
+    want = particles.expected_records(sims, dgrid, cdf, sc.db)
+    W, H = opt["cam_CCD_WH"][0] // rs, opt["cam_CCD_WH"][1] // rs
+    got = _emu_generate(sims, dgrid, cdf, ratio_db, H, W)
+    for k, ((rec, raw), ref) in enumerate(zip(got, want)):
+        cam = particles.FrameCamera(opt, k)
+        p = particles.make_particles(cam, dgrid, cdf[sims['table'][k]], int(sims['n_particles'][k]), k, 7 + 2 ** 33)
+        cols = np.column_stack([p['wp1'], p['wp2'], p['wd1'], p['ip1'], p['ip2'], p['iw1'], p['iw2']])
+        assert np.array_equal(raw[:, :13], cols), 'raw particles of frame %d' % k
+        assert len(rec) == len(ref) > 50
+        for name in h.hb.DROP_DTYPE.names:
+            assert rec[name].tobytes() == ref[name].tobytes(), '%s of frame %d' % (name, k)
+    assert set(np.concatenate([r['type'] for r in want])) == {0, 1, 2}
+
+
+def test_generated_records_render_the_same_in_oracle_and_hostemu(tmp_path):
+    """A window of generator-made records (exact rotation terms, draws from the legacy stream) through the numpy oracle
+    (render_drop_records) and through the g++ build of the kernel arithmetic: mask bit-exact, image within 1 LSB."""
+    from oracle import render as orc
+    H, W = 225, 400
+    sc = h.Scene(tmp_path, H, W, 10, cam=h.NUSCENES)
+    opt = _options('nuscenes', cam_CCD_WH=[W, H])
+    sims, dgrid, cdf = particles.sim_frames(opt, 200, 1, seed=5, draw_seeds=[9], count=1500)
+    rec = particles.expected_records(sims, dgrid, cdf, sc.db)[0][:160]
+    bg, env = sc.frame_inputs(0)
+    textures, _ = sc.oracle_db()
+    ref = orc.render_drop_records(bg, bg, env, sc.omega, rec, textures, sc.ocam, faithful=False)
+    emu = h.emu_render(sc, bg, bg, env, rec)
+    assert np.array_equal(emu['status'], ref['status']) and (ref['status'] == 0).sum() > 100
+    assert np.array_equal(emu['mask'], ref['mask']) and np.array_equal(emu['mask_i32'], ref['mask_i32'])
+    assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1

@@ -97,3 +97,54 @@ def test_rename_folder_is_decided_once_world2(tmp_path):
         assert p.exitcode == 0
     assert res[0] == res[1] == out_dir + '_copy00000'
     assert sorted(os.listdir(os.path.dirname(out_dir))) == ['5mm', '5mm_copy00000']
+
+
+def _worklist_worker(rank, world, port, root, q):
+    """The work list of a run is made by rank 0 alone.  Rank 1 arrives late and -- as a peer that has already started
+    writing would -- finds an output file of frame 0 on disk: were it to make its own list with 'skip', it would drop that
+    frame and the two shares would neither partition nor cover the run."""
+    import importlib
+    import time
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    gen_mod = importlib.import_module('rain-rendering_amd.common.generator')
+    sharding = importlib.import_module('rain-rendering_amd.sharding')
+    g = object.__new__(gen_mod.Generator)
+    g.conflict_strategy, g.rank, g.world, g.dataset = 'skip', rank, world, 'kitti'
+    g.noise_std, g.noise_scale = 2.0, 1.0
+    files = [os.path.join(root, 'img', '%06d.png' % i) for i in range(7)]
+    out_dir = os.path.join(root, 'out')
+    dist.barrier()
+    if rank == 1:
+        time.sleep(1.0)
+        os.makedirs(os.path.join(out_dir, 'rainy_image'), exist_ok=True)
+        open(os.path.join(out_dir, 'rainy_image', '000000.png'), 'w').close()
+    work, n_exist = sharding.rank0_decides(lambda: g._work_list(files, files, list(range(7)), out_dir, root, 3), rank, world)
+    mine = sharding.shard(work, rank, world)
+    q.put((rank, [it['i'] for it in work], [it['i'] for it in mine], [it['seeds'] for it in work], n_exist))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_work_list_is_decided_once_world2(tmp_path):
+    import torch.multiprocessing as mp
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, 'img'))
+    for i in range(7):
+        open(os.path.join(root, 'img', '%06d.png' % i), 'w').close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worklist_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, m0, s0, e0), (_, w1, m1, s1, e1) = res
+    assert w0 == w1 == list(range(7)) and e0 == e1 == 0             # one list, made before any rank wrote
+    assert sorted(m0 + m1) == list(range(7)) and not set(m0) & set(m1)
+    assert s0 == s1 and s0[3] == (0, 3) and s0[6] == (0, 3, 6)      # noise-seed history: frames 0, 3, 6 share simulated frame 0
