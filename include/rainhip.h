@@ -296,7 +296,8 @@ int rr_generate_drops(rr_ctx* ctx, int32_t n, const rr_sim_frame* frames, int32_
                       int32_t* n_out);
 int rr_sizeof_sim_frame(void);
 
-/* Options.  1-4 and 6 are tuning / A-B switches: NONE of them changes a result bit (tests/test_gpu_properties.py).  Unknown
+/* Options.  1-4 and 6 are tuning / A-B switches: NONE of them changes a result bit (tests/test_gpu_properties.py); 7 trades
+ * float64 for float in the colour channels only.  Unknown
  * options or values are RR_E_ARG.  The library reads no environment variables. */
 enum {
   RR_OPT_DEDUP = 1,                 /* 1 (default): drops with bit-identical raw-tile parameters share one tile inside a batch */
@@ -309,8 +310,14 @@ enum {
    * (rr_frame_in.depth / the pre-pass' depth) is smaller than the drop's distance |world z|.  Default 0: the reference's
    * output.  Excluded from every parity run. */
   RR_OPT_DEPTH_OCCLUSION = 5,
-  RR_OPT_BLUR_WORKGROUPS = 6        /* tuning: workgroups per CU the fused defocus blur is sized for (LDS tiles + registers):
+  RR_OPT_BLUR_WORKGROUPS = 6,       /* tuning: workgroups per CU the fused defocus blur is sized for (LDS tiles + registers):
                                      * 0 (library's choice = 4), 3, 4 or 5 */
+  /* Colour arithmetic of the compositor.  rainy_mask is a float64 sum in drop order in either case (bit-exact); the three
+   * colour channels of rainy_image only have to land within 1 LSB of a uint8 (BASELINE.json), so by default they are
+   * blended in float whenever no frame of the batch asks for the float64 composite (rr_frame_out.rainy_bg_out == NULL).
+   * 1: float64 colours always (the reference's arithmetic; what rainy_bg_out != NULL gets anyway).  The uint8 image of
+   * the two differs by at most 1 LSB (tests/test_gpu_properties.py). */
+  RR_OPT_COMPOSITE_F64 = 7
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -53,7 +53,7 @@ struct FrameDesc {
   const double* omega;
   const rr_drop* drops;
   uint8_t* rgb;
-  double* comp_out;                // H*W*3 composite before the mean shift (user buffer or ctx scratch)
+  double* comp_out;                // H*W*3 composite before the mean shift (user buffer or ctx scratch); float[] when comp_f32
   double* mask_f64;
   int32_t* mask_i32;
   int32_t* status;
@@ -63,6 +63,7 @@ struct FrameDesc {
   const rr_ext_tile* ext;          // optional: caller-made tiles / FOV polygons per drop (device pointers inside)
   double* colour_out;              // optional: n_drops * 3 colour constants (rr_frame_out.drop_colour)
   const int32_t* n_drops_dev;      // optional: the drop count lives on the device (k_patch_counts)
+  int32_t comp_f32, pad0;          // comp_out holds floats (the float-colour compositor wrote it)
   int32_t depth_f64;
   int32_t n_drops;
   int32_t strategy;
@@ -101,6 +102,7 @@ __device__ inline void wave_lds_sync() {
 struct Scratch {                    // per-batch device scratch, all indexed [frame][...]
   DropPlan* plan;
   CompRec* comp;
+  CompRec32* comp32;
   int32_t* poly;                    // [frame][drop][2][POLY_STRIDE]
   int32_t* npts;
   int64_t* sizes;
@@ -278,8 +280,11 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
     sh[t] += v;
     __syncthreads();
   }
-  int64_t run = (t == 0) ? 0 : sh[t - 1];
+  // the first line (16 doubles) of a frame's arena stays all zeros: where the float compositor's lanes outside a footprint
+  // read their "sample" from
+  int64_t run = ((t == 0) ? 0 : sh[t - 1]) + 16;
   const int64_t frame_base = (int64_t)f * arena_cap;
+  if (t < 16 && arena_cap >= 16) sc.arena[frame_base + t] = 0.0;
   for (int i = i0; i < i1; i++) {
     DropPlan& p = sc.plan[base + i];
     int64_t sz = sc.sizes[base + i];
@@ -293,10 +298,11 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
     run += sz;
   }
   if (t == 1023) {
-    sc.arena_need[f] = sh[1023];
-    if (sh[1023] > arena_cap) {
+    const int64_t need = sh[1023] + 16;
+    sc.arena_need[f] = need;
+    if (need > arena_cap) {
       atomicExch(sc.overflow, 1);
-      atomicMax(sc.need_max, (unsigned long long)sh[1023]);       // sticky until the host regrows the arena
+      atomicMax(sc.need_max, (unsigned long long)need);           // sticky until the host regrows the arena
     }
   }
 }
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(256) void k_fov_sums_general(const FrameDesc* frame
 
 // Colour, pass 2: one thread per drop adds the band partials in band order and writes the
 // compositor record.
-__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+__global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm, int max_drops, double cam_exposure, Scratch sc) {
   const int f = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const FrameDesc& fr = frames[f];
@@ -891,6 +897,18 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     rec.pad = tame ? 0 : 1;
   }
   sc.comp[gi] = rec;
+  {
+    CompRec32 r32;
+    r32.xx = (uint32_t)(rec.x0 & 0xffff) | ((uint32_t)(rec.x1 & 0xffff) << 16);
+    r32.yy = (uint32_t)(rec.y0 & 0xffff) | ((uint32_t)(rec.y1 & 0xffff) << 16);
+    r32.ox = rec.ox; r32.oy = rec.oy; r32.pitch = rec.pitch; r32.slow = rec.pad;
+    r32.off = rec.off;
+    r32.te = (float)(rec.tau_one / cam_exposure);
+    r32.kg[0] = (float)(rec.K[0] * rec.g); r32.kg[1] = (float)(rec.K[1] * rec.g); r32.kg[2] = (float)(rec.K[2] * rec.g);
+    r32.zdist = rec.zdist;
+    r32.spare[0] = r32.spare[1] = 0;
+    sc.comp32[gi] = r32;
+  }
   sc.bbox[gi] = make_int4(rec.x0, rec.y0, rec.x1, rec.y1);
   if (fr.colour_out) {
     const global_ptr<double> ko = as_global(fr.colour_out) + (int64_t)i * 3;
@@ -1788,37 +1806,91 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
   }
 }
 
+// ---- large defocus radii (r > BR_MAX: drops a few centimetres from a fast lens) and tiles no LDS layout takes ----
+// The raw tile is small, the blurred one large: an output sample of the row pass has at most 2 * th taps whose operands
+// are not both outside the raw tile (exact zeros; acc + (0 + 0) * w == acc), the column pass 2 * tw.  Taps are visited in
+// the reference's order (ii ascending), only the all-zero ones are left out, so the sums keep their bits.
+//   pass 0 (rows)  work unit = (drop, raw column): the column (th values) in LDS, one thread per output row
+//                  -> tmp[eh][tw] (dense, in the scratch tile k_plan reserved behind the finished tile)
+//   pass 1 (cols)  work unit = (drop, group of BIG_ROWS output rows): their tmp rows in LDS, one thread per output sample
+constexpr int BIG_GROUPS = 64;      // work units per drop and pass (a unit strides over the columns / row groups)
+constexpr int BIG_ROWS = 16;
+constexpr int BIG_COL_LDS = 2048;   // longest raw column staged in LDS (longer: read from global memory)
+
+// f(ii) for ii ascending over ([a0, a1] u [b0, b1]) n [-r, -1]
+template <class F>
+__device__ inline void visit_taps(int a0, int a1, int b0, int b1, int r, F f) {
+  a0 = imax(a0, -r); a1 = imin(a1, -1);
+  b0 = imax(b0, -r); b1 = imin(b1, -1);
+  if (a0 > a1) { a0 = b0; a1 = b1; b0 = 0; b1 = -1; }                  // A empty: B alone
+  if (b0 <= b1 && b0 < a0) { int t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }
+  if (b0 <= b1 && b0 <= a1 + 1) { a1 = imax(a1, b1); b0 = 0; b1 = -1; }  // overlapping / adjacent: one run
+  for (int ii = a0; ii <= a1; ii++) f(ii);
+  for (int ii = b0; ii <= b1; ii++) f(ii);
+}
+
 template <int AXIS>
 __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_drops, Scratch sc) {
-  const int f = blockIdx.y;
+  const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double hw[MAX_R + 1];
+  __shared__ double s_in[BIG_COL_LDS];
   const int n_items = sc.counts[f * 8 + 3];
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // blurred drops with radius > BR_MAX
+  int cur = -1;
+  for (int w = blockIdx.x; w < n_items * BIG_GROUPS; w += gridDim.x) {
+    const int it = w / BIG_GROUPS, g = w - it * BIG_GROUPS;
     const int64_t gi = (int64_t)f * max_drops + sc.list_slow[(int64_t)f * max_drops + it];
     const DropPlan& p = sc.plan[gi];
     const int r = AXIS == 0 ? p.r1 : p.r2;
-    const int pw = p.ew, ph = p.eh, n = pw * ph;              // effective tile
+    const int tw = p.tw, th = p.th, ew = p.ew, eh = p.eh, r1 = p.r1, r2 = p.r2;
+    if (AXIS == 0 ? g >= tw : g * BIG_ROWS >= eh) continue;            // nothing for this unit
     const double* raw = sc.arena + p.a0_off;
     double* fin = sc.arena + p.a1_off;               // pitch p.epitch, first column p.epad
-    double* tmp = fin + (((int64_t)p.epitch * ph + 15) & ~15LL);   // dense scratch tile reserved by k_plan for slow drops
+    double* tmp = fin + (((int64_t)p.epitch * eh + 15) & ~15LL);   // scratch reserved by k_plan for slow drops: eh x tw
     __syncthreads();
-    if (r > 0) gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
-    for (int idx = threadIdx.x; idx < n; idx += 256) {
-      const int y = idx / pw, x = idx - y * pw;
-      if (AXIS == 0) {
-        const int rx = x - p.r2;
-        double acc = 0.0;
-        if (rx >= 0 && rx < p.tw) {                   // a column outside the raw tile is all zeros
-          auto R = [&](int yy) -> double {
-            const int ry = yy - p.r1;
-            return (ry >= 0 && ry < p.th) ? raw[ry * p.tw + rx] : 0.0;
-          };
-          acc = R(y) * hw[r];
-          for (int ii = -r; ii < 0; ii++) acc = acc + (R(y + ii) + R(y - ii)) * hw[ii + r];
+    if (cur != it) {
+      if (r > 0) gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
+      cur = it;
+    }
+    if (AXIS == 0) {
+      for (int rx = g; rx < tw; rx += BIG_GROUPS) {
+        const bool lds = th <= BIG_COL_LDS;
+        __syncthreads();
+        if (lds)
+          for (int k = t; k < th; k += 256) s_in[k] = raw[(int64_t)k * tw + rx];
+        __syncthreads();
+        auto R = [&](int yy) -> double {               // row yy of the effective tile: raw row yy - r1
+          const int ry = yy - r1;
+          return (ry >= 0 && ry < th) ? (lds ? s_in[ry] : raw[(int64_t)ry * tw + rx]) : 0.0;
+        };
+        for (int y = t; y < eh; y += 256) {
+          double acc = R(y) * hw[r];
+          visit_taps(r1 - y, r1 - y + th - 1, y - r1 - th + 1, y - r1, r, [&](int ii) { acc = acc + (R(y + ii) + R(y - ii)) * hw[ii + r]; });
+          tmp[(int64_t)y * tw + rx] = acc;
         }
-        tmp[idx] = acc;
-      } else {
-        fin[(int64_t)y * p.epitch + p.epad + x] = r > 0 ? blur_axis1(tmp, pw, ph, x, y, hw, r) : tmp[idx];
+      }
+    } else {
+      for (int y0 = g * BIG_ROWS; y0 < eh; y0 += BIG_GROUPS * BIG_ROWS) {
+        const int nr = imin(BIG_ROWS, eh - y0);
+        const bool lds = nr * tw <= BIG_COL_LDS;
+        __syncthreads();
+        if (lds)
+          for (int k = t; k < nr * tw; k += 256) s_in[k] = tmp[(int64_t)y0 * tw + k];
+        __syncthreads();
+        for (int idx = t; idx < nr * ew; idx += 256) {
+          const int yy = idx / ew, x = idx - yy * ew;
+          auto T = [&](int xx) -> double {             // column xx of the effective tile: raw column xx - r2
+            const int rx = xx - r2;
+            return (rx >= 0 && rx < tw) ? (lds ? s_in[yy * tw + rx] : tmp[(int64_t)(y0 + yy) * tw + rx]) : 0.0;
+          };
+          double acc;
+          if (r2 > 0) {
+            acc = T(x) * hw[r];
+            visit_taps(r2 - x, r2 - x + tw - 1, x - r2 - tw + 1, x - r2, r, [&](int ii) { acc = acc + (T(x + ii) + T(x - ii)) * hw[ii + r]; });
+          } else {
+            acc = T(x);
+          }
+          fin[(int64_t)(y0 + yy) * p.epitch + p.epad + x] = acc;
+        }
       }
     }
   }
@@ -2047,6 +2119,252 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   }
 }
 
+// ---------------------------------------------------------------------------
+// compositor with float colours (the default when the caller does not ask for the float64 composite)
+// ---------------------------------------------------------------------------
+// What must be bit-exact is the mask: it stays a float64 sum of float64 alpha samples in drop order.  The three colour
+// channels only have to land within 1 LSB of a uint8 (BASELINE.json), and hundreds of float blends err by ~1e-5: they are
+// carried in float -- full-rate VALU, packed two pixels at a time -- with the drop's factors pre-multiplied in its
+// 64-byte record (one scalar 16-dword load).  A workgroup takes a 16 x 32 screen tile; a wave owns an 8 x 16 part and its
+// own ordered drop list, a lane TWO pixels of one column, eight rows apart (drops are narrow and tall), so the scalar work
+// per list entry is shared by 128 pixels.  A pixel outside an entry's footprint blends with alpha 0: (1 - 0) c + 0 = c, and
+// the clamp leaves c alone as long as c is in [0, 1] -- true for the fog pre-pass' output (it ends with np.clip) and
+// after every blend; a wave that finds anything else (NaN, out of range) among its pixels, and an entry whose factors are
+// not tame, take the literal float64 blend_pixel per pixel instead.  The composite leaves as floats (12 B per pixel).
+typedef float float2_t __attribute__((ext_vector_type(2)));
+constexpr int TILE32_H = 32;
+// clamp(a * b + c, 0, 1) on both halves in one packed instruction (the compiler keeps the clamp as two extra instructions)
+__device__ inline float2_t pk_fma_clamp(float2_t a, float2_t b, float2_t c) {
+  float2_t d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__global__ __launch_bounds__(256) void k_composite32(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
+                                                     int tiles_y, int ctiles_x, int nct, int64_t arena_cap, Scratch sc) {
+  const int f = blockIdx.y;
+  const int ntiles = tiles_x * tiles_y, per_xcd = (ntiles + 7) / 8;
+  const int tile = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);      // XCD k: the k-th eighth of the tiles (shared L2)
+  if (tile >= ntiles) return;
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const FrameDesc& fr = frames[f];
+  const int tx0 = txi * TILE, ty0 = tyi * TILE32_H, tx1 = min(tx0 + TILE, dm.W), ty1 = min(ty0 + TILE32_H, dm.H);
+  const int px = tx0 + 8 * (wave & 1) + (lane & 7);
+  const int py0 = ty0 + 16 * (wave >> 1) + (lane >> 3), py1 = py0 + 8;
+  const bool live0 = px < dm.W && py0 < dm.H, live1 = px < dm.W && py1 < dm.H;
+  const int64_t pix0 = (int64_t)py0 * dm.W + px, pix1 = (int64_t)py1 * dm.W + px;
+  float2_t c0 = {0.f, 0.f}, c1 = {0.f, 0.f}, c2 = {0.f, 0.f};       // channel k of (pixel 0, pixel 1)
+  double m0 = 0.0, m1 = 0.0;
+  double sum_b = 0.0;
+  bool ok_px = true;                 // every colour value of the lane's live pixels is in [0, 1]
+  {
+    double in0[3] = {0, 0, 0}, in1[3] = {0, 0, 0};
+    if (live0) {
+      const global_ptr<const double> s = as_global(fr.rainy_bg) + pix0 * 3;
+      in0[0] = s[0]; in0[1] = s[1]; in0[2] = s[2];
+    }
+    if (live1) {
+      const global_ptr<const double> s = as_global(fr.rainy_bg) + pix1 * 3;
+      in1[0] = s[0]; in1[1] = s[1]; in1[2] = s[2];
+    }
+    if (fr.bg == fr.rainy_bg) {
+      sum_b = ((in0[0] + in0[1]) + in0[2]) + ((in1[0] + in1[1]) + in1[2]);
+    } else {
+      if (live0) {
+        const global_ptr<const double> b = as_global(fr.bg) + pix0 * 3;
+        sum_b = (b[0] + b[1]) + b[2];
+      }
+      if (live1) {
+        const global_ptr<const double> b = as_global(fr.bg) + pix1 * 3;
+        sum_b += (b[0] + b[1]) + b[2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) ok_px = ok_px && in0[k] >= 0.0 && in0[k] <= 1.0 && in1[k] >= 0.0 && in1[k] <= 1.0;
+    c0 = float2_t{(float)in0[0], (float)in1[0]};
+    c1 = float2_t{(float)in0[1], (float)in1[1]};
+    c2 = float2_t{(float)in0[2], (float)in1[2]};
+  }
+  double scene0 = 1.0e300, scene1 = 1.0e300;
+  if (fr.depth) {
+    if (live0) scene0 = fr.depth_f64 ? as_global((const double*)fr.depth)[pix0] : (double)as_global((const float*)fr.depth)[pix0];
+    if (live1) scene1 = fr.depth_f64 ? as_global((const double*)fr.depth)[pix1] : (double)as_global((const float*)fr.depth)[pix1];
+  }
+  const bool has_depth = fr.depth != nullptr;
+  const bool slow_wave = __ballot(!ok_px) != 0ull;
+  const CompRec32* comp = sc.comp32 + (int64_t)f * max_drops;
+  const CompRec* comp64 = sc.comp + (int64_t)f * max_drops;
+  const int4* bbox = sc.bbox + (int64_t)f * max_drops;
+  const double* arena = sc.arena;
+  const int ct = (ty0 / CTILE) * ctiles_x + (tx0 / CTILE);
+  const uint16_t* clist = sc.clist + ((int64_t)f * nct + ct) * max_drops;
+  const int n = sc.ccount[(int64_t)f * nct + ct];
+  __shared__ int s_list[4][256];
+  __shared__ int s_cnt[4][4];
+  const int xm = tx0 + 8, ym = ty0 + 16;
+  const float2_t one2 = {1.f, 1.f};
+  const int64_t zero_at = (int64_t)f * arena_cap;                  // the frame's all-zero arena line (k_scan)
+  for (int base = 0; base < n; base += 256) {
+    const int k = base + t;
+    unsigned hitm = 0;
+    int i = 0;
+    if (k < n) {
+      i = clist[k];
+      const int4 bb = bbox[i];
+      if (bb.x < tx1 && bb.z > tx0 && bb.y < ty1 && bb.w > ty0) {
+        const unsigned xl = bb.x < xm, xr = bb.z > xm, yt = bb.y < ym, yb = bb.w > ym;
+        hitm = (xl & yt) | ((xr & yt) << 1) | ((xl & yb) << 2) | ((xr & yb) << 3);
+      }
+    }
+    unsigned long long bal[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bal[q] = __ballot((hitm >> q) & 1u);
+    if (lane < 4) s_cnt[wave][lane] = __popcll(lane == 0 ? bal[0] : (lane == 1 ? bal[1] : (lane == 2 ? bal[2] : bal[3])));
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int off = 0, tq = 0;
+      for (int w = 0; w < 4; w++) {
+        const int cw = s_cnt[w][q];
+        if (w < wave) off += cw;
+        tq += cw;
+      }
+      if ((hitm >> q) & 1u) s_list[q][off + __popcll(bal[q] & ((1ull << lane) - 1ull))] = i;
+      if (q == wave) total = tq;
+    }
+    __syncthreads();
+    const int* lst = s_list[wave];
+    total = __builtin_amdgcn_readfirstlane(total);
+    struct RecS {
+      uint32_t xx, yy;
+      int ox, oy, pitch, slow;
+      long long off;
+      float te, k0, k1, k2;
+      double z;
+    };
+    auto fetch = [&](int idx) {
+      const const_ptr<CompRec32> r = as_constant(comp) + __builtin_amdgcn_readfirstlane(idx);
+      RecS o{r->xx, r->yy, r->ox, r->oy, r->pitch, r->slow, (long long)r->off, r->te, r->kg[0], r->kg[1], r->kg[2], r->zdist};
+      return o;
+    };
+    // Three stages, as in k_composite: entry e is blended while the samples of entry e + 1 are in flight and the record of
+    // entry e + 2 is fetched.  Every lane loads two samples per entry (a pixel outside the footprint reads the tile's first
+    // sample -- one line for all of them -- and its value is replaced by 0), so the number of loads in flight is known.
+    auto step = [&](int e, const RecS& rcur, double Acur0, double Acur1, int icur, const RecS& rnext, double& An0, double& An1, int& inext,
+                    RecS& rfetch, int& i_nn, int& i_cur_next) {
+      {
+        const int x0 = (int)(rnext.xx & 0xffffu), x1 = (int)(rnext.xx >> 16), y0 = (int)(rnext.yy & 0xffffu), y1 = (int)(rnext.yy >> 16);
+        const bool inx = (px >= x0) & (px < x1) & (e + 1 < total);
+        const bool in0 = inx & live0 & (py0 >= y0) & (py0 < y1), in1 = inx & live1 & (py1 >= y0) & (py1 < y1);
+        // outside the footprint: the frame's zero line (k_scan) -- the sample IS 0.0, nothing to select afterwards
+        const int64_t o0 = in0 ? rnext.off + ((int64_t)(py0 + rnext.oy) * rnext.pitch + (px + rnext.ox)) : zero_at;
+        const int64_t o1 = in1 ? rnext.off + ((int64_t)(py1 + rnext.oy) * rnext.pitch + (px + rnext.ox)) : zero_at;
+        An0 = arena[o0];
+        An1 = arena[o1];
+        inext = (in0 ? 1 : 0) | (in1 ? 2 : 0);
+      }
+      rfetch = fetch(i_nn);
+      i_cur_next = i_nn;
+      i_nn = lst[e + 3 < total ? e + 3 : 0];
+      bool v0 = (icur & 1) != 0, v1 = (icur & 2) != 0;
+      if (has_depth) {                                            // depth-occlusion option: hidden where the drop is behind the scene
+        v0 = v0 && !(rcur.z > scene0);
+        v1 = v1 && !(rcur.z > scene1);
+      }
+      double A0 = Acur0, A1 = Acur1;                              // (0.0 outside the footprint)
+      if (has_depth) {
+        A0 = v0 ? Acur0 : 0.0;
+        A1 = v1 ? Acur1 : 0.0;
+      }
+      if (slow_wave | rcur.slow) {                                // (wave-uniform) literal float64 blend, pixel by pixel
+        const const_ptr<CompRec> r64 = as_constant(comp64) + __builtin_amdgcn_readfirstlane(icur >> 2);
+        const double K[3] = {r64->K[0], r64->K[1], r64->K[2]};
+        const double tau = r64->tau_one, g = r64->g;
+        if (v0) {
+          double c[3] = {(double)c0.x, (double)c1.x, (double)c2.x};
+          blend_pixel(Acur0, tau, cam.exposure_s, g, K, c, m0);
+          c0.x = (float)c[0]; c1.x = (float)c[1]; c2.x = (float)c[2];
+        }
+        if (v1) {
+          double c[3] = {(double)c0.y, (double)c1.y, (double)c2.y};
+          blend_pixel(Acur1, tau, cam.exposure_s, g, K, c, m1);
+          c0.y = (float)c[0]; c1.y = (float)c[1]; c2.y = (float)c[2];
+        }
+      } else {
+        const float2_t Af = {(float)A0, (float)A1};
+        const float2_t u = __builtin_elementwise_fma(Af, float2_t{-rcur.te, -rcur.te}, one2);      // 1 - A te
+        c0 = pk_fma_clamp(u, c0, Af * rcur.k0);                   // clamp((1 - A te) c + A kg, 0, 1)
+        c1 = pk_fma_clamp(u, c1, Af * rcur.k1);
+        c2 = pk_fma_clamp(u, c2, Af * rcur.k2);
+        m0 = m0 + A0;                                             // (+ 0.0 outside the footprint: the mask keeps its bits)
+        m1 = m1 + A1;
+      }
+    };
+    if (total > 0) {
+      // icur packs the two "inside" bits with the drop index (for the rare float64 path): (index << 2) | bits
+      int idx0 = lst[0], idx1 = lst[total > 1 ? 1 : 0];
+      RecS R0 = fetch(idx0), R1 = fetch(idx1), R2 = R0;
+      int i_nn = lst[total > 2 ? 2 : 0];
+      int in0 = 0, in1 = 0, in2 = 0, id0 = idx0, id1 = idx1, id2 = 0;
+      double A00, A01, A10 = 0.0, A11 = 0.0, A20 = 0.0, A21 = 0.0;
+      {
+        const int x0 = (int)(R0.xx & 0xffffu), x1 = (int)(R0.xx >> 16), y0 = (int)(R0.yy & 0xffffu), y1 = (int)(R0.yy >> 16);
+        const bool inx = (px >= x0) & (px < x1);
+        const bool a = inx & live0 & (py0 >= y0) & (py0 < y1), b = inx & live1 & (py1 >= y0) & (py1 < y1);
+        A00 = arena[a ? R0.off + ((int64_t)(py0 + R0.oy) * R0.pitch + (px + R0.ox)) : zero_at];
+        A01 = arena[b ? R0.off + ((int64_t)(py1 + R0.oy) * R0.pitch + (px + R0.ox)) : zero_at];
+        in0 = (a ? 1 : 0) | (b ? 2 : 0);
+      }
+      for (int e = 0; e < total; e += 3) {
+        step(e, R0, A00, A01, in0 | (id0 << 2), R1, A10, A11, in1, R2, i_nn, id2);
+        if (e + 1 >= total) break;
+        step(e + 1, R1, A10, A11, in1 | (id1 << 2), R2, A20, A21, in2, R0, i_nn, id0);
+        if (e + 2 >= total) break;
+        step(e + 2, R2, A20, A21, in2 | (id2 << 2), R0, A00, A01, in0, R1, i_nn, id1);
+      }
+    }
+    __syncthreads();
+  }
+  double sum_c = 0.0;
+  if (live0) {
+    const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix0 * 3;
+    o[0] = c0.x; o[1] = c1.x; o[2] = c2.x;
+    if (fr.mask_f64) as_global(fr.mask_f64)[pix0] = m0;
+    if (fr.mask_i32) as_global(fr.mask_i32)[pix0] = (int32_t)floor(m0 * 255.0);
+    sum_c = ((double)c0.x + (double)c1.x) + (double)c2.x;
+  }
+  if (live1) {
+    const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix1 * 3;
+    o[0] = c0.y; o[1] = c1.y; o[2] = c2.y;
+    if (fr.mask_f64) as_global(fr.mask_f64)[pix1] = m1;
+    if (fr.mask_i32) as_global(fr.mask_i32)[pix1] = (int32_t)floor(m1 * 255.0);
+    sum_c += ((double)c0.y + (double)c1.y) + (double)c2.y;
+  }
+  __shared__ double ra[256], rb[256], rlo[256], rhi[256];
+  ra[t] = sum_c;
+  rb[t] = sum_b;
+  rlo[t] = dmin(live0 ? m0 : 1.0e300, live1 ? m1 : 1.0e300);
+  rhi[t] = dmax(live0 ? m0 : -1.0e300, live1 ? m1 : -1.0e300);
+  __syncthreads();
+  for (int ofs = 128; ofs > 0; ofs >>= 1) {
+    if (t < ofs) {
+      ra[t] += ra[t + ofs];
+      rb[t] += rb[t + ofs];
+      rlo[t] = dmin(rlo[t], rlo[t + ofs]);
+      rhi[t] = dmax(rhi[t], rhi[t + ofs]);
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double* part = sc.partial + ((int64_t)f * tiles_x * tiles_y + tile) * 4;
+    part[0] = ra[0];
+    part[1] = rb[0];
+    part[2] = rlo[0];
+    part[3] = rhi[0];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_means(Dims dm, int ntiles, Scratch sc) {
   const int f = blockIdx.x, t = threadIdx.x;
   double a = 0, b = 0, lo = 1.0e300, hi = -1.0e300;
@@ -2088,10 +2406,17 @@ __global__ __launch_bounds__(256) void k_finalize(const FrameDesc* frames, Dims 
   if (pix >= (int64_t)dm.H * dm.W) return;
   const FrameDesc& fr = frames[f];
   const double diff = sc.means[f * 4 + 0] - sc.means[f * 4 + 1];
-  const global_ptr<const double> s = as_global((const double*)fr.comp_out) + pix * 3;
   const global_ptr<uint8_t> o = as_global(fr.rgb) + pix * 3;
+  double c[3];
+  if (fr.comp_f32) {
+    const global_ptr<const float> s = as_global(reinterpret_cast<const float*>(fr.comp_out)) + pix * 3;
+    c[0] = (double)s[0]; c[1] = (double)s[1]; c[2] = (double)s[2];
+  } else {
+    const global_ptr<const double> s = as_global((const double*)fr.comp_out) + pix * 3;
+    c[0] = s[0]; c[1] = s[1]; c[2] = s[2];
+  }
   for (int k = 0; k < 3; k++) {
-    double v = clip01(s[2 - k] - diff);      // BGR -> RGB
+    double v = clip01(c[2 - k] - diff);      // BGR -> RGB
     o[k] = (uint8_t)(int)(v * 255.0);
   }
 }
@@ -2422,6 +2747,7 @@ struct rr_ctx {
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
+  bool composite_f64 = false;        // RR_OPT_COMPOSITE_F64: float64 colours in the compositor even when nobody asks for the composite
   int scratch_hp = 0;                // span pitch the scratch was sized for
   bool scratch_general = false;      // prefix table / polygons of the general colour path allocated
   std::vector<ProfEntry> prof_pending;
@@ -2555,6 +2881,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     int rc;
     if ((rc = dev_alloc(ctx, ctx->sc.plan, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.comp, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.comp32, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.npts, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.sizes, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_rot, fd))) return rc;
@@ -2639,7 +2966,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   Dims dm{in[0].H, in[0].W, in[0].He, in[0].We};
   int max_drops = 0;
-  bool need_comp = false, want_png = false;
+  bool need_comp = false, want_png = false, any_f64_comp = false;
   for (int f = 0; f < n; f++) {
     if (in[f].H != dm.H || in[f].W != dm.W || in[f].He != dm.He || in[f].We != dm.We) {
       ctx->err = "all frames of a batch must share H,W,He,We";
@@ -2660,8 +2987,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     if (in[f].n_drops > max_drops) max_drops = in[f].n_drops;
     if (!out[f].rainy_bg_out) need_comp = true;
+    else any_f64_comp = true;
     want_png = want_png || out[f].rainy_png || out[f].mask_png;
   }
+  const bool use32 = !any_f64_comp && !ctx->composite_f64;
   if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
     ctx->err = "bad frame size";
     return RR_E_ARG;
@@ -2693,6 +3022,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.ext = in[f].ext;
     fd.colour_out = out[f].drop_colour;
     fd.n_drops_dev = in[f].n_drops_dev;
+    fd.comp_f32 = use32 ? 1 : 0;
+    fd.pad0 = 0;
     any_dev_count = any_dev_count || in[f].n_drops_dev;
     fd.n_drops = in[f].n_drops;
     fd.strategy = in[f].strategy;
@@ -2783,7 +3114,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_colour");
-      hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
+      hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
     }
     {
       ProfScope ps(ctx, s, "k_tile_generic");
@@ -2820,11 +3151,11 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
-      hipLaunchKernelGGL(k_blur<0>, dim3(64, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur<0>, dim3(256, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_cols");
-      hipLaunchKernelGGL(k_blur<1>, dim3(64, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur<1>, dim3(256, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
   }
   const int ctiles_x = (dm.W + CTILE - 1) / CTILE, nct = ctiles_x * ((dm.H + CTILE - 1) / CTILE);
@@ -2832,14 +3163,22 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     ProfScope ps(ctx, s, "k_bin");
     hipLaunchKernelGGL(k_bin, dim3(nct, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctiles_x, nct, sc);
   }
-  {
+  // float colours unless a caller wants the float64 composite (or RR_OPT_COMPOSITE_F64): see k_composite32
+  int ntiles_c = ntiles;
+  if (use32) {
+    const int tiles_y32 = (dm.H + TILE32_H - 1) / TILE32_H;
+    ntiles_c = tiles_x * tiles_y32;
+    ProfScope ps(ctx, s, "k_composite");
+    hipLaunchKernelGGL(k_composite32, dim3(((ntiles_c + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x,
+                       nct, ctx->arena_cap, sc);
+  } else {
     ProfScope ps(ctx, s, "k_composite");
     hipLaunchKernelGGL(k_composite, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
                        sc);
   }
   {
     ProfScope ps(ctx, s, "k_means");
-    hipLaunchKernelGGL(k_means, dim3(n), dim3(256), 0, s, dm, ntiles, sc);
+    hipLaunchKernelGGL(k_means, dim3(n), dim3(256), 0, s, dm, ntiles_c, sc);
   }
   {
     ProfScope ps(ctx, s, "k_finalize");
@@ -3082,6 +3421,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->d_lut);
   hipFree(ctx->sc.plan);
   hipFree(ctx->sc.comp);
+  hipFree(ctx->sc.comp32);
   hipFree(ctx->sc.poly);
   hipFree(ctx->sc.npts);
   hipFree(ctx->sc.sizes);
@@ -3579,7 +3919,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
       up.add((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * (size_t)in[f].n_drops);
     }
     dout[f].rainy_rgb = st.rgb + f * px * 3;
-    dout[f].rainy_bg_out = st.comp + f * px * 3;
+    dout[f].rainy_bg_out = out[f].rainy_bg_out ? st.comp + f * px * 3 : nullptr;
     dout[f].mask_f64 = st.mask + f * px;
     dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * px : nullptr;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
@@ -3858,6 +4198,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_DEDUP: ctx->dedup = value != 0; return RR_OK;
     case RR_OPT_GENERAL_FOV: ctx->general_fov = value != 0; return RR_OK;
     case RR_OPT_DEPTH_OCCLUSION: ctx->depth_occlusion = value != 0; return RR_OK;
+    case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_FOV_THREADS:
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;

@@ -54,6 +54,8 @@ def test_config_matches_hostemu_and_oracle_windows(name, tmp_path, built):
         out = rh.render_frames([fr])[0]
         emu = h.emu_render(sc, bg, bg, env, drops)
         _assert_parity(out, emu, name + ' vs hostemu (%d drops)' % len(drops))
+        # the product's default colour arithmetic (float, when no float64 composite is requested): same mask bits, image <= 1 LSB
+        _assert_parity(rh.render_frames([fr], want_composite=False)[0], emu, name + ' (float colours) vs hostemu')
         assert (out['status'] == 0).sum() > 0.9 * len(drops) and out['mask'].max() > 0
         for a, b in windows:
             b = min(b, len(drops))

@@ -154,4 +154,10 @@ def test_nan_pixels_follow_the_reference_blend(tmp_path, built):
         fin = ~np.isnan(b)
         # colour constants come from FOV sums added in another order: 1e-9; everything else is the same arithmetic
         assert np.abs(a[fin] - b[fin]).max() < 1e-9
+        # the float-colour compositor (no float64 composite requested): a wave that meets such pixels blends them the
+        # literal way too; the mask is the same float64 sum
+        out32 = rh.render_frames([dict(bg=bg, rainy_bg=rb, env_xyY=env, omega=sc.omega, drops=drops)], want_composite=False)[0]
+        assert np.array_equal(out32['mask'], emu['mask']) and np.array_equal(out32['status'], out['status'])
+        if rb is bg:
+            assert np.abs(out32['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
     rh.close()

@@ -124,3 +124,40 @@ def test_colour_path_options_do_not_change_results(setup):
         assert np.abs(out['rainy_bg'] - base['rainy_bg']).max() < 1e-9, opts
     with pytest.raises(RuntimeError):
         rh.set_option(99, 1)
+
+
+def test_float_colour_compositor(setup):
+    """The default when nobody asks for the float64 composite (k_composite32: float colours, two pixels per lane, float
+    composite; include/rainhip.h RR_OPT_COMPOSITE_F64): rainy_mask -- float64 accumulator and int32 export -- identical to
+    the float64 compositor's and to the g++ build of the kernel arithmetic, drop statuses equal, the uint8 image within
+    1 LSB of both (BASELINE.json's bar) and almost everywhere equal."""
+    sc, bg, env, drops, rh, base = setup
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    f32 = rh.render_frames([fr], want_composite=False)[0]
+    assert f32['rainy_bg'] is None
+    assert np.array_equal(f32['status'], base['status'])
+    assert np.array_equal(f32['mask'], base['mask']) and np.array_equal(f32['mask_i32'], base['mask_i32'])     # bit-exact
+    d = np.abs(f32['image_u8'].astype(int) - base['image_u8'].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 5e-3
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    assert np.array_equal(f32['mask'], emu['mask'])
+    assert np.abs(f32['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+    # inside a batch, next to other frames, and with the option that forces float64 colours
+    small = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[:100])
+    outs = rh.render_frames([small, fr, small], want_composite=False)
+    for k in ('mask', 'mask_i32', 'image_u8', 'status'):
+        assert np.array_equal(outs[1][k], f32[k]), k
+    rh.set_option(h.hb.RR_OPT_COMPOSITE_F64, 1)
+    try:
+        f64 = rh.render_frames([fr], want_composite=False)[0]
+    finally:
+        rh.set_option(h.hb.RR_OPT_COMPOSITE_F64, 0)
+    for k in ('mask', 'mask_i32', 'image_u8', 'status'):
+        assert np.array_equal(f64[k], base[k]), k
+    # the first 300 streaks against the numpy oracle (faithful FOV integration), float colours
+    n = 300
+    out = rh.render_frames([dict(fr, drops=drops[:n])], want_composite=False)[0]
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=True, max_drops=n)
+    assert np.array_equal(out['status'], ref['status'])
+    assert np.array_equal(out['mask'], ref['mask']) and np.array_equal(out['mask_i32'], ref['mask_i32'])
+    assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
