@@ -332,7 +332,7 @@ def main():
     ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--no-traffic', action='store_true')
     ap.add_argument('--cpu-sample-drops', type=int, default=2048)
-    ap.add_argument('--pipe-batch', type=int, default=32, help='frames per slot of the host-inclusive pipeline')
+    ap.add_argument('--pipe-batch', type=int, default=128, help='frames per slot of the host-inclusive pipeline (the driver\'s default batch)')
     ap.add_argument('--opt', action='append', default=[], help='rr_set_option as ID=VALUE (tuning switches that never change results)')
     ap.add_argument('--sweep', action='append', default=[], help='A/B: after the headline, time the loop again under these '
                     'rr_set_option sets ("6=3,3=512"); one JSON line each on stderr; implies the lean run')
@@ -535,49 +535,64 @@ def main():
         depth_h = np.ascontiguousarray(depth_t.cpu().numpy())
         del keep, pin, pout
 
-        # --- host-inclusive: pinned buffers, three slots in flight (upload | kernels | download overlap) -----
-        PB = max(1, min(args.pipe_batch, batch.n))
+        # --- host-inclusive (SURVEY 8d's rate: "including H2D of frame inputs and D2H of outputs"): pinned buffers, three
+        #     slots in flight (upload | kernels | download overlap); PCIe up (u8 image + f32 depth + drop table), fog +
+        #     environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask) -----------------------
         nslot = hb.RR_PIPE_SLOTS
-        slots = []
-        for s_ in range(nslot):
-            frs, outs = [], []
-            for k in range(PB):
-                i = (s_ * PB + k) % batch.n
-                bg8 = rh.host_array((H, W, 3), np.uint8)
-                bg8[...] = (batch.host[i][0] * 255).astype(np.uint8)
-                dep = rh.host_array((H, W), np.float32)
-                dep[...] = depth_h
-                dr = rh.host_array((len(batch.host[i][2]),), hb.DROP_DTYPE)
-                dr[...] = batch.host[i][2]
-                frs.append(dict(bg_u8=bg8, depth=dep, fog=consts, omega=sc.omega, drops=dr))
-                outs.append(dict(image_u8=rh.host_array((H, W, 3), np.uint8), mask_i32=rh.host_array((H, W), np.int32)))
-            slots.append((frs, outs))
-
-        def pipe(rounds):
-            done = 0
-            for r in range(rounds + nslot):
-                s_ = r % nslot
-                if r >= nslot:
-                    while not rh.pipeline_wait(s_):
-                        rh.pipeline_submit(s_, *slots[s_])
-                    done += PB
-                if r < rounds:
-                    rh.pipeline_submit(s_, *slots[s_])
-            return done
-        pipe(nslot)                                   # warm-up: staging buffers, arena
-        rounds = max(2 * nslot, (192 + PB - 1) // PB)  # >= 192 frames
-        h0 = time.perf_counter()
-        done = pipe(rounds)
-        h1 = time.perf_counter()
         up = 3 * H * W + 4 * H * W + 112 * batch.mean_drops
         down = 3 * H * W + 4 * H * W
-        extras["host_inclusive"] = {
-            "what": "rr_pipeline_submit/wait, %d slots x %d frames, pinned host buffers (rr_host_alloc): PCIe up (u8 image + f32 depth "
-                    "+ drop table), fog + environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask); "
-                    "PNG codec excluded; %d frames timed" % (nslot, PB, done),
-            "frames_per_s": done / (h1 - h0), "ms_per_frame": 1e3 * (h1 - h0) / done,
-            "pcie_bytes_per_frame": {"up": up, "down": down},
-            "pcie_GBps": {"up": up * done / (h1 - h0) / 1e9, "down": down * done / (h1 - h0) / 1e9}}
+
+        def host_inclusive(PB, copy_kernels):
+            rh.set_option(hb.RR_OPT_COPY_KERNELS, 1 if copy_kernels else 0)
+            slots, pinned = [], []
+            for s_ in range(nslot):
+                frs, outs = [], []
+                for k in range(PB):
+                    i = (s_ * PB + k) % batch.n
+                    bg8 = rh.host_array((H, W, 3), np.uint8)
+                    bg8[...] = (batch.host[i][0] * 255).astype(np.uint8)
+                    dep = rh.host_array((H, W), np.float32)
+                    dep[...] = depth_h
+                    dr = rh.host_array((len(batch.host[i][2]),), hb.DROP_DTYPE)
+                    dr[...] = batch.host[i][2]
+                    im, mk = rh.host_array((H, W, 3), np.uint8), rh.host_array((H, W), np.int32)
+                    pinned += [bg8, dep, dr, im, mk]
+                    frs.append(dict(bg_u8=bg8, depth=dep, fog=consts, omega=sc.omega, drops=dr))
+                    outs.append(dict(image_u8=im, mask_i32=mk))
+                slots.append((frs, outs))
+
+            def pipe(rounds):
+                done = 0
+                for r in range(rounds + nslot):
+                    s_ = r % nslot
+                    if r >= nslot:
+                        while not rh.pipeline_wait(s_):
+                            rh.pipeline_submit(s_, *slots[s_])
+                        done += PB
+                    if r < rounds:
+                        rh.pipeline_submit(s_, *slots[s_])
+                return done
+            pipe(nslot)                                   # warm-up: staging buffers, arena
+            rounds = max(2 * nslot, (384 + PB - 1) // PB)  # >= 384 frames
+            h0 = time.perf_counter()
+            done = pipe(rounds)
+            h1 = time.perf_counter()
+            for a_ in pinned:
+                rh.host_free(a_)
+            rh.set_option(hb.RR_OPT_COPY_KERNELS, 1)
+            return {"frames_per_s": done / (h1 - h0), "ms_per_frame": 1e3 * (h1 - h0) / done, "frames_per_slot": PB, "frames_timed": done,
+                    "copies": "one copy kernel per direction and batch (RR_OPT_COPY_KERNELS 1)" if copy_kernels else "one hipMemcpyAsync per piece (RR_OPT_COPY_KERNELS 0)",
+                    "pcie_GBps": {"up": up * done / (h1 - h0) / 1e9, "down": down * done / (h1 - h0) / 1e9}}
+        PB = max(1, min(args.pipe_batch, batch.n))
+        hi = host_inclusive(PB, True)
+        hi["what"] = ("rr_pipeline_submit/wait, %d slots x %d frames, pinned host buffers (rr_host_alloc): PCIe up (u8 image + f32 depth + drop "
+                      "table), fog + environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask); PNG codec excluded"
+                      % (nslot, PB))
+        hi["pcie_bytes_per_frame"] = {"up": up, "down": down}
+        extras["host_inclusive"] = hi
+        if not args.no_variants:
+            extras["host_inclusive_variants"] = {"slots_of_32": host_inclusive(min(32, batch.n), True),
+                                                 "memcpy_per_piece": host_inclusive(PB, False)}
         warm(render, 1)
 
     if rank == 0:

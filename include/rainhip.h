@@ -317,7 +317,13 @@ enum {
    * blended in float whenever no frame of the batch asks for the float64 composite (rr_frame_out.rainy_bg_out == NULL).
    * 1: float64 colours always (the reference's arithmetic; what rainy_bg_out != NULL gets anyway).  The uint8 image of
    * the two differs by at most 1 LSB (tests/test_gpu_properties.py). */
-  RR_OPT_COMPOSITE_F64 = 7
+  RR_OPT_COMPOSITE_F64 = 7,
+  /* tuning: how the host-pointer entry points move a batch across PCIe.  1 (default): the pieces whose host side is
+   * page-locked (rr_host_alloc) and 16-byte aligned are moved by ONE copy kernel per direction that reads / writes the
+   * host memory directly; everything else, and with 0 every piece, by one hipMemcpyAsync each.  Frame-sized pieces of
+   * the two directions issued as individual hipMemcpyAsync calls queue behind each other (40 GB/s in total, measured);
+   * the kernels run both directions at once (90 GB/s). */
+  RR_OPT_COPY_KERNELS = 8
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -75,7 +75,7 @@ class Generator:
         self.irrad_type = 'ambient'
         self.db = None
         self.renderer = None
-        self.batch = int(os.environ.get('RAIN_BATCH', '32'))      # frames per library call (three calls in flight)
+        self.batch = int(os.environ.get('RAIN_BATCH', '128'))     # frames per library call (three calls in flight); bench.py's host-inclusive leg uses the same
         self.rank, self.world = sharding.rank_world()
         self.device = int(getattr(args, 'device', os.environ.get('LOCAL_RANK', '0')))
         self._hip = None
@@ -161,18 +161,30 @@ class Generator:
 
     # ---- the asynchronous frame pipeline ------------------------------------------------------------------
     class _Slot:
-        """Pinned host buffers of one batch in flight (inputs the I/O threads decode into, outputs they deflate from)."""
+        """Pinned host buffers of one batch in flight (inputs the I/O threads decode into, outputs they deflate from).
+        Every frame's piece of every buffer starts on a 16-byte boundary: the library then moves the whole batch with one
+        copy kernel per direction (include/rainhip.h RR_OPT_COPY_KERNELS) instead of one DMA request per piece."""
 
         def __init__(self, hip, B, H, W, We, bg_dtype, depth_dtype, save_envmap, drops_cap):
             self.B, self.H, self.W = B, H, W
-            self.bg = hip.host_array((B, H, W, 3), bg_dtype)
-            self.depth = hip.host_array((B, H, W), depth_dtype)
-            self.drops = hip.host_array((B, drops_cap), hip_backend.DROP_DTYPE)
-            self.status = hip.host_array((B, drops_cap), np.int32)
+            self._raw = []
+
+            def rows(shape, dtype):
+                """B arrays of `shape` / `dtype`, each 16-byte aligned inside one page-locked allocation."""
+                nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                stride = (nbytes + 15) // 16 * 16
+                raw = hip.host_array((B, max(stride, 16)), np.uint8)
+                self._raw.append(raw)
+                return [raw[k, :nbytes].view(dtype).reshape(shape) for k in range(B)]
+            drops_cap = (drops_cap + 3) // 4 * 4
+            self.bg = rows((H, W, 3), bg_dtype)
+            self.depth = rows((H, W), depth_dtype)
+            self.drops = rows((drops_cap,), hip_backend.DROP_DTYPE)
+            self.status = rows((drops_cap,), np.int32)
             row = H * (1 + 4 * W)
-            self.png_i = hip.host_array((B, row), np.uint8)
-            self.png_m = hip.host_array((B, row), np.uint8)
-            self.env = hip.host_array((B, H, We, 3), np.uint8) if save_envmap else None
+            self.png_i = rows((row,), np.uint8)
+            self.png_m = rows((row,), np.uint8)
+            self.env = rows((H, We, 3), np.uint8) if save_envmap else None
             self.drops_cap = drops_cap
             self.key = (B, H, W, We, np.dtype(bg_dtype), np.dtype(depth_dtype), bool(save_envmap))
             self.items, self.encodes, self.busy = [], [], False
@@ -181,12 +193,11 @@ class Generator:
             """Page-locked memory is only returned by rr_host_free (dropping the numpy views frees nothing): called when
             a slot is replaced by a larger / differently shaped one, after its batch has been collected and encoded."""
             assert not self.busy and not self.encodes
-            for name in ('bg', 'depth', 'drops', 'status', 'png_i', 'png_m', 'env'):
-                a = getattr(self, name)
-                if a is not None:
-                    hip.host_free(a)
-                setattr(self, name, None)
+            self.bg = self.depth = self.drops = self.status = self.png_i = self.png_m = self.env = None
             self.frames = self.outs = None
+            for raw in self._raw:
+                hip.host_free(raw)
+            self._raw = []
 
     def _decode_into(self, slot, k, item, rs, pristine, imW, imH, seeds):
         """I/O-thread part of one frame: decode image + depth into the slot's pinned buffers, build the drop table."""
@@ -208,7 +219,7 @@ class Generator:
             os.makedirs(os.path.dirname(item['out_env_path']), exist_ok=True)
             env_bgr = slot.env[k] / 255.0                                              # generator.py:469 (plt.imsave of a float map)
             imgops.imsave_rgb(item['out_env_path'], (np.clip(env_bgr[..., ::-1], 0, 1) * 255).astype(np.uint8))
-        return int(np.count_nonzero(slot.status[k, :n_drops]))
+        return int(np.count_nonzero(slot.status[k][:n_drops]))
 
     def compute_drop(self, bg, drop_dict, rainy_bg, rainy_mask, rainy_saturation_mask):
         """Single-drop compatibility seam with the reference's signature (generator.py:119-191):
@@ -473,12 +484,12 @@ class Generator:
                 np.copyto(sl.bg[k], bg)
                 np.copyto(sl.depth[k], depth)
                 nd = len(drops)
-                sl.drops[k, :nd] = drops
+                sl.drops[k][:nd] = drops
                 frames.append(dict(bg=None if bg.dtype == np.uint8 else sl.bg[k], bg_u8=sl.bg[k] if bg.dtype == np.uint8 else None,
-                                   depth=sl.depth[k], fog=fog_const, omega=state['omega'], drops=sl.drops[k, :nd],
+                                   depth=sl.depth[k], fog=fog_const, omega=state['omega'], drops=sl.drops[k][:nd],
                                    opacity_attenuation=self.opacity_attenuation,
                                    strategy=1 if self.rendering_strategy == 'white' else 0))
-                o = dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k, :nd])
+                o = dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k][:nd])
                 if self.save_envmap:
                     o['env_bgr_u8'] = sl.env[k]
                 outs.append(o)

@@ -2644,6 +2644,37 @@ __global__ __launch_bounds__(64) void k_particle_draws(const rr_sim_frame* sims,
   }
 }
 
+// ---------------------------------------------------------------------------
+// batched copies between pinned host memory and the device, by kernel
+// ---------------------------------------------------------------------------
+// A batch crosses PCIe as hundreds of frame-sized pieces (every frame has its own host arrays).  Issued as one
+// hipMemcpyAsync each, the pieces of the two directions queue behind each other -- measured on MI355X: 192 pieces of
+// 1.4 MB move at 40 GB/s in one direction and at the same 40 GB/s IN TOTAL when both directions run (scripts/probes/
+// pcie_probe.hip).  One kernel per direction that walks a list of pieces and reads / writes the pinned host memory
+// directly moves 56 GB/s one way and 90 GB/s both ways, next to the compute kernels.
+struct CopyPiece {
+  const void* src;
+  void* dst;
+  uint64_t bytes;
+};
+__global__ __launch_bounds__(256) void k_copy_pieces(const CopyPiece* pieces, int n) {
+  const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+  for (int j = 0; j < n; j++) {
+    const CopyPiece p = pieces[j];
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p.src) | reinterpret_cast<uintptr_t>(p.dst);
+    if ((a & 15) == 0) {
+      const size_t n16 = p.bytes >> 4;
+      const uint4* s16 = static_cast<const uint4*>(p.src);
+      uint4* d16 = static_cast<uint4*>(p.dst);
+      for (size_t i = gtid; i < n16; i += gsz) d16[i] = s16[i];
+      const size_t done = n16 << 4;
+      if (gtid < p.bytes - done) static_cast<uint8_t*>(p.dst)[done + gtid] = static_cast<const uint8_t*>(p.src)[done + gtid];
+    } else {                                                   // small odd pieces (counts, short status arrays)
+      for (size_t i = gtid; i < p.bytes; i += gsz) static_cast<uint8_t*>(p.dst)[i] = static_cast<const uint8_t*>(p.src)[i];
+    }
+  }
+}
+
 // drop counts that only exist on the device (rr_frame_in.n_drops_dev): patched into the frame descriptors before the
 // first kernel of the chain reads them; n_drops of the descriptor is the capacity
 __global__ void k_patch_counts(FrameDesc* frames, int n) {
@@ -2726,6 +2757,9 @@ struct rr_ctx {
   struct Slot {
     Staging st;
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_down = nullptr;
+    CopyPiece *d_up = nullptr, *d_down = nullptr;     // piece lists of the copy kernels
+    CopyPiece *h_up = nullptr, *h_down = nullptr;     // (pinned)
+    size_t cap_up = 0, cap_down = 0;
     int64_t* h_flags = nullptr;      // pinned: [0] arena-overflow flag as seen after this batch
     bool busy = false, rendered = false;
     std::vector<void*> ext_blobs;     // device copies of caller-made tiles (rr_ext_tile), freed when the slot is reused
@@ -2747,6 +2781,7 @@ struct rr_ctx {
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
+  bool copy_kernels = true;          // RR_OPT_COPY_KERNELS: batched copy kernels for pinned host buffers (else hipMemcpyAsync per piece)
   bool composite_f64 = false;        // RR_OPT_COMPOSITE_F64: float64 colours in the compositor even when nobody asks for the composite
   int scratch_hp = 0;                // span pitch the scratch was sized for
   bool scratch_general = false;      // prefix table / polygons of the general colour path allocated
@@ -3484,6 +3519,10 @@ int rr_destroy(rr_ctx* ctx) {
     if (sl.ev_comp) hipEventDestroy(sl.ev_comp);
     if (sl.ev_down) hipEventDestroy(sl.ev_down);
     if (sl.h_flags) hipHostFree(sl.h_flags);
+    hipFree(sl.d_up);
+    hipFree(sl.d_down);
+    if (sl.h_up) hipHostFree(sl.h_up);
+    if (sl.h_down) hipHostFree(sl.h_down);
     for (void* b : sl.ext_blobs) hipFree(b);
   }
   if (ctx->s_up) hipStreamDestroy(ctx->s_up);
@@ -3703,33 +3742,105 @@ struct CopyList {                      // merges copies whose source AND destina
   }
 };
 
-int issue(rr_ctx* ctx, const CopyList& cl, hipMemcpyKind kind, hipStream_t s) {
-  for (const auto& c : cl.v) HIPCHK(hipMemcpyAsync(c.dst, c.src, c.bytes, kind, s));
+// Is this host address device-accessible (page-locked: rr_host_alloc / hipHostMalloc / hipHostRegister)?
+bool host_is_pinned(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();                              // pageable memory: "invalid value", not an error of ours
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// The copies of one direction of one slot.  Pieces whose host side is pinned and whose ends are 16-byte aligned (or that
+// are tiny) go into ONE launch of k_copy_pieces; the rest -- pageable or oddly aligned buffers -- one hipMemcpyAsync each.
+int issue(rr_ctx* ctx, const CopyList& cl, hipMemcpyKind kind, hipStream_t s, CopyPiece*& d_list, CopyPiece*& h_list, size_t& cap) {
+  std::vector<CopyPiece> ker;
+  const bool up = kind == hipMemcpyHostToDevice;
+  const void* last_base = nullptr;
+  bool last_pinned = false;
+  for (const auto& c : cl.v) {
+    const void* host = up ? c.src : c.dst;
+    bool use_kernel = false;
+    if (ctx->copy_kernels) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(c.src) | reinterpret_cast<uintptr_t>(c.dst);
+      if ((a & 15) == 0 || c.bytes <= 4096) {
+        // (consecutive pieces usually come from one allocation: ask the runtime once per 2 MB neighbourhood)
+        const void* base = reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(host) >> 21);
+        if (base != last_base) {
+          last_pinned = host_is_pinned(host);
+          last_base = base;
+        }
+        use_kernel = last_pinned && host_is_pinned(static_cast<const char*>(host) + c.bytes - 1) ;
+      }
+    }
+    if (use_kernel) ker.push_back(CopyPiece{c.src, c.dst, (uint64_t)c.bytes});
+    else HIPCHK(hipMemcpyAsync(c.dst, c.src, c.bytes, kind, s));
+  }
+  if (!ker.empty()) {
+    if (ker.size() > cap) {
+      HIPCHK(hipStreamSynchronize(s));
+      if (d_list) HIPCHK(hipFree(d_list));
+      if (h_list) HIPCHK(hipHostFree(h_list));
+      d_list = h_list = nullptr;
+      cap = 0;
+      const size_t want = ker.size() * 2 + 64;
+      HIPCHK(hipMalloc((void**)&d_list, want * sizeof(CopyPiece)));
+      HIPCHK(hipHostMalloc((void**)&h_list, want * sizeof(CopyPiece), hipHostMallocDefault));
+      cap = want;
+    }
+    // (the slot is not in flight: its previous lists have been consumed)
+    memcpy(h_list, ker.data(), ker.size() * sizeof(CopyPiece));
+    HIPCHK(hipMemcpyAsync(d_list, h_list, ker.size() * sizeof(CopyPiece), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_copy_pieces, dim3(128), dim3(256), 0, s, d_list, (int)ker.size());
+  }
   return RR_OK;
 }
 
+// Per-frame strides of the staging arrays, padded so that every frame's piece starts on a 16-byte boundary (the copy
+// kernels move 16 bytes per lane): bytes for the uint8 arrays, elements for the others.
+struct Strides {
+  size_t px3b, ex3b, pngb;      // uint8: image, environment map, PNG scanlines
+  size_t pxd, px3d, exd, ex3d;  // float64 (also the float32 / float64 depth slot): H*W, H*W*3, He*We, He*We*3 elements, even
+  size_t pxi;                   // int32: H*W elements, a multiple of 4
+};
+Strides strides_of(const Dims& dm) {
+  const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We;
+  Strides t;
+  t.px3b = (px * 3 + 15) & ~(size_t)15;
+  t.ex3b = (ex * 3 + 15) & ~(size_t)15;
+  t.pngb = ((size_t)dm.H * (1 + 4 * (size_t)dm.W) + 15) & ~(size_t)15;
+  t.pxd = (px + 1) & ~(size_t)1;
+  t.px3d = (px * 3 + 1) & ~(size_t)1;
+  t.exd = (ex + 1) & ~(size_t)1;
+  t.ex3d = (ex * 3 + 1) & ~(size_t)1;
+  t.pxi = (px + 3) & ~(size_t)3;
+  return t;
+}
+
 int slot_reserve(rr_ctx* ctx, rr_ctx::Staging& st, int n, int max_drops, const Dims& dm) {
+  max_drops = (max_drops + 3) & ~3;                      // int32 per-drop arrays: every frame's piece 16-byte aligned
   if (n > st.frames || max_drops > st.drops_cap || dm.H != st.dims.H || dm.W != st.dims.W || dm.He != st.dims.He || dm.We != st.dims.We) {
     HIPCHK(hipDeviceSynchronize());
-    const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We;
+    const Strides t = strides_of(dm);
     int F = n > st.frames ? n : st.frames, D = max_drops > st.drops_cap ? max_drops : st.drops_cap, rc;
-    if ((rc = dev_alloc(ctx, st.bg, F * px * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.rainy, F * px * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.env, F * ex * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.omega, F * ex))) return rc;
-    if ((rc = dev_alloc(ctx, st.comp, F * px * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.mask, F * px))) return rc;
+    if ((rc = dev_alloc(ctx, st.bg, F * t.px3d))) return rc;
+    if ((rc = dev_alloc(ctx, st.rainy, F * t.px3d))) return rc;
+    if ((rc = dev_alloc(ctx, st.env, F * t.ex3d))) return rc;
+    if ((rc = dev_alloc(ctx, st.omega, F * t.exd))) return rc;
+    if ((rc = dev_alloc(ctx, st.comp, F * t.px3d))) return rc;
+    if ((rc = dev_alloc(ctx, st.mask, F * t.pxd))) return rc;
     if ((rc = dev_alloc(ctx, st.drops, (size_t)F * D))) return rc;
-    if ((rc = dev_alloc(ctx, st.rgb, F * px * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.mask_i, F * px))) return rc;
+    if ((rc = dev_alloc(ctx, st.rgb, F * t.px3b))) return rc;
+    if ((rc = dev_alloc(ctx, st.mask_i, F * t.pxi))) return rc;
     if ((rc = dev_alloc(ctx, st.status, (size_t)F * D))) return rc;
     if ((rc = dev_alloc(ctx, st.colour, (size_t)F * D * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.ndrops, (size_t)F))) return rc;
-    if ((rc = dev_alloc(ctx, st.depth, F * px))) return rc;
-    if ((rc = dev_alloc(ctx, st.env_u8, F * ex * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.bg8, F * px * 3))) return rc;
-    if ((rc = dev_alloc(ctx, st.png_i, F * (size_t)dm.H * (1 + 4 * (size_t)dm.W)))) return rc;
-    if ((rc = dev_alloc(ctx, st.png_m, F * (size_t)dm.H * (1 + 4 * (size_t)dm.W)))) return rc;
+    if ((rc = dev_alloc(ctx, st.ndrops, (size_t)((F + 3) & ~3)))) return rc;
+    if ((rc = dev_alloc(ctx, st.depth, F * t.pxd))) return rc;
+    if ((rc = dev_alloc(ctx, st.env_u8, F * t.ex3b))) return rc;
+    if ((rc = dev_alloc(ctx, st.bg8, F * t.px3b))) return rc;
+    if ((rc = dev_alloc(ctx, st.png_i, F * t.pngb))) return rc;
+    if ((rc = dev_alloc(ctx, st.png_m, F * t.pngb))) return rc;
     st.frames = F;
     st.drops_cap = D;
     st.dims = dm;
@@ -3864,6 +3975,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   auto& st = sl.st;
   if ((rc = slot_reserve(ctx, st, n, max_drops, dm))) return rc;
   const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We, png_bytes = (size_t)dm.H * (1 + 4 * (size_t)dm.W);
+  const Strides T = strides_of(dm);
   hipStream_t s = ctx->stream;
   std::vector<rr_frame_in> din(in ? n : 0);
   std::vector<rr_frame_out> dout(in ? n : 0);
@@ -3874,33 +3986,33 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   // ---- upload ----
   for (int f = 0; pre && f < n; f++) {
     pin[f] = pre[f];
-    pin[f].bg = st.bg + f * px * 3;
+    pin[f].bg = st.bg + f * T.px3d;
     pin[f].bg_u8 = nullptr;
-    pin[f].depth = st.depth + f * px;
-    if (pre[f].bg_u8) up.add(st.bg8 + f * px * 3, pre[f].bg_u8, px * 3);      // bytes over PCIe: 1/8 of the float64 image
+    pin[f].depth = st.depth + f * T.pxd;
+    if (pre[f].bg_u8) up.add(st.bg8 + f * T.px3b, pre[f].bg_u8, px * 3);      // bytes over PCIe: 1/8 of the float64 image
     else up.add((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double));
     const bool env_only = pre[f].mode == RR_PRE_ENV_ONLY;
     if (!env_only) up.add((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4));
-    pout[f].rainy_bg = st.rainy + f * px * 3;
+    pout[f].rainy_bg = st.rainy + f * T.px3d;
     const bool env = in || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
-    pout[f].env_xyY = env ? st.env + f * ex * 3 : nullptr;
-    pout[f].env_bgr_u8 = (pre_out && pre_out[f].env_bgr_u8) ? st.env_u8 + f * ex * 3 : nullptr;
+    pout[f].env_xyY = env ? st.env + f * T.ex3d : nullptr;
+    pout[f].env_bgr_u8 = (pre_out && pre_out[f].env_bgr_u8) ? st.env_u8 + f * T.ex3b : nullptr;
   }
   for (int f = 0; in && f < n; f++) {
     din[f] = in[f];
-    din[f].bg = st.bg + f * px * 3;
-    din[f].rainy_bg = st.rainy + f * px * 3;
-    din[f].env_xyY = st.env + f * ex * 3;
+    din[f].bg = st.bg + f * T.px3d;
+    din[f].rainy_bg = st.rainy + f * T.px3d;
+    din[f].env_xyY = st.env + f * T.ex3d;
     // the solid-angle map depends on the map size only: frames that pass the same host array share one upload
     const bool same_omega = f > 0 && in[f].omega == in[0].omega;
-    din[f].omega = same_omega ? din[0].omega : st.omega + f * ex;
+    din[f].omega = same_omega ? din[0].omega : st.omega + f * T.exd;
     din[f].drops = st.drops + (size_t)f * st.drops_cap;
     if (pre) {                        // the pre-pass' depth buffer doubles as the occlusion depth
-      din[f].depth = st.depth + f * px;
+      din[f].depth = st.depth + f * T.pxd;
       din[f].depth_f64 = pre[f].depth_f64;
     } else if (in[f].depth && ctx->depth_occlusion) {
-      up.add((void*)(st.depth + f * px), in[f].depth, px * (in[f].depth_f64 ? 8 : 4));
-      din[f].depth = st.depth + f * px;
+      up.add((void*)(st.depth + f * T.pxd), in[f].depth, px * (in[f].depth_f64 ? 8 : 4));
+      din[f].depth = st.depth + f * T.pxd;
     } else {
       din[f].depth = nullptr;
     }
@@ -3918,10 +4030,10 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     } else {
       up.add((void*)din[f].drops, in[f].drops, sizeof(rr_drop) * (size_t)in[f].n_drops);
     }
-    dout[f].rainy_rgb = st.rgb + f * px * 3;
-    dout[f].rainy_bg_out = out[f].rainy_bg_out ? st.comp + f * px * 3 : nullptr;
-    dout[f].mask_f64 = st.mask + f * px;
-    dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * px : nullptr;
+    dout[f].rainy_rgb = st.rgb + f * T.px3b;
+    dout[f].rainy_bg_out = out[f].rainy_bg_out ? st.comp + f * T.px3d : nullptr;
+    dout[f].mask_f64 = st.mask + f * T.pxd;
+    dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * T.pxi : nullptr;
     dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
     dout[f].drop_colour = out[f].drop_colour ? st.colour + (size_t)f * st.drops_cap * 3 : nullptr;
     din[f].ext = nullptr;
@@ -3958,16 +4070,16 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
       HIPCHK(hipMemcpy(blob, dev.data(), sizeof(rr_ext_tile) * (size_t)nd, hipMemcpyHostToDevice));
       din[f].ext = reinterpret_cast<const rr_ext_tile*>(blob);
     }
-    dout[f].rainy_png = out[f].rainy_png ? st.png_i + (size_t)f * png_bytes : nullptr;
-    dout[f].mask_png = out[f].mask_png ? st.png_m + (size_t)f * png_bytes : nullptr;
+    dout[f].rainy_png = out[f].rainy_png ? st.png_i + (size_t)f * T.pngb : nullptr;
+    dout[f].mask_png = out[f].mask_png ? st.png_m + (size_t)f * T.pngb : nullptr;
   }
-  if ((rc = issue(ctx, up, hipMemcpyHostToDevice, ctx->s_up))) return rc;
+  if ((rc = issue(ctx, up, hipMemcpyHostToDevice, ctx->s_up, sl.d_up, sl.h_up, sl.cap_up))) return rc;
   HIPCHK(hipEventRecord(sl.ev_up, ctx->s_up));
   // ---- compute ----
   HIPCHK(hipStreamWaitEvent(s, sl.ev_up, 0));
   for (int f = 0; pre && f < n; f++)
     if (pre[f].bg_u8)                 // bg = bytes / 255.0 (generator.py:352) formed on the device
-      hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256)), dim3(256), 0, s, st.bg8 + f * px * 3,
+      hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256)), dim3(256), 0, s, st.bg8 + f * T.px3b,
                          (double*)pin[f].bg, (int64_t)(px * 3));
   if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return rc;
   if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, st.drops_cap, st.ndrops, s))) return rc;
@@ -3991,7 +4103,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     if (pre_out[f].env_xyY) down.add(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * sizeof(double));
     if (pre_out[f].env_bgr_u8) down.add(pre_out[f].env_bgr_u8, pout[f].env_bgr_u8, ex * 3);
   }
-  if ((rc = issue(ctx, down, hipMemcpyDeviceToHost, ctx->s_down))) return rc;
+  if ((rc = issue(ctx, down, hipMemcpyDeviceToHost, ctx->s_down, sl.d_down, sl.h_down, sl.cap_down))) return rc;
   sl.h_flags[0] = 0;
   if (in) HIPCHK(hipMemcpyAsync(&sl.h_flags[0], ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_down));
   HIPCHK(hipEventRecord(sl.ev_down, ctx->s_down));
@@ -4199,6 +4311,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_GENERAL_FOV: ctx->general_fov = value != 0; return RR_OK;
     case RR_OPT_DEPTH_OCCLUSION: ctx->depth_occlusion = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
+    case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_FOV_THREADS:
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;

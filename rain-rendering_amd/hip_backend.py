@@ -19,6 +19,7 @@ RR_PRE_ENV_ONLY = 1
 RR_OPT_DEDUP, RR_OPT_GENERAL_FOV, RR_OPT_FOV_THREADS, RR_OPT_FOV_DROPS_PER_THREAD, RR_OPT_DEPTH_OCCLUSION = 1, 2, 3, 4, 5
 RR_OPT_BLUR_WORKGROUPS = 6
 RR_OPT_COMPOSITE_F64 = 7
+RR_OPT_COPY_KERNELS = 8
 
 # numpy mirror of rr_drop (112 bytes)
 DROP_DTYPE = np.dtype([
