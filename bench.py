@@ -542,24 +542,50 @@ def main():
         up = 3 * H * W + 4 * H * W + 112 * batch.mean_drops
         down = 3 * H * W + 4 * H * W
 
-        def host_inclusive(PB, copy_kernels):
+        rh.set_solid_angles(sc.omega)                     # resident: frames pass omega=None
+
+        def host_inclusive(PB, copy_kernels=False, packed=True, prepared=True):
+            """packed: the frames of a slot back to back in one page-locked block per array (RainHip.host_rows: one copy per
+            array and batch) -- else every frame its own allocations (one copy per frame and array).  prepared: descriptor
+            arrays built once per slot (what Generator does) -- else rebuilt in Python for every submission."""
             rh.set_option(hb.RR_OPT_COPY_KERNELS, 1 if copy_kernels else 0)
-            slots, pinned = [], []
+            cap = max(len(h_[2]) for h_ in batch.host)
+            cap = (cap + 3) // 4 * 4
+            slots, blocks = [], []
             for s_ in range(nslot):
-                frs, outs = [], []
+                if packed:
+                    arrs = [rh.host_rows(PB, shp, dt) for shp, dt in (((H, W, 3), np.uint8), ((H, W), np.float32), ((cap,), hb.DROP_DTYPE),
+                                                                      ((H, W, 3), np.uint8), ((H, W), np.int32))]
+                    blocks += [a[0] for a in arrs]
+                    bg8s, deps, drs, ims, mks = [a[1] for a in arrs]
+                else:
+                    bg8s = [rh.host_array((H, W, 3), np.uint8) for _ in range(PB)]
+                    deps = [rh.host_array((H, W), np.float32) for _ in range(PB)]
+                    drs = [rh.host_array((cap,), hb.DROP_DTYPE) for _ in range(PB)]
+                    ims = [rh.host_array((H, W, 3), np.uint8) for _ in range(PB)]
+                    mks = [rh.host_array((H, W), np.int32) for _ in range(PB)]
+                    blocks += bg8s + deps + drs + ims + mks
+                frs, outs, nds = [], [], []
                 for k in range(PB):
                     i = (s_ * PB + k) % batch.n
-                    bg8 = rh.host_array((H, W, 3), np.uint8)
-                    bg8[...] = (batch.host[i][0] * 255).astype(np.uint8)
-                    dep = rh.host_array((H, W), np.float32)
-                    dep[...] = depth_h
-                    dr = rh.host_array((len(batch.host[i][2]),), hb.DROP_DTYPE)
-                    dr[...] = batch.host[i][2]
-                    im, mk = rh.host_array((H, W, 3), np.uint8), rh.host_array((H, W), np.int32)
-                    pinned += [bg8, dep, dr, im, mk]
-                    frs.append(dict(bg_u8=bg8, depth=dep, fog=consts, omega=sc.omega, drops=dr))
-                    outs.append(dict(image_u8=im, mask_i32=mk))
-                slots.append((frs, outs))
+                    bg8s[k][...] = (batch.host[i][0] * 255).astype(np.uint8)
+                    deps[k][...] = depth_h
+                    nd = len(batch.host[i][2])
+                    drs[k][:nd] = batch.host[i][2]
+                    nds.append(nd)
+                    frs.append(dict(bg_u8=bg8s[k], depth=deps[k], fog=consts, omega=None, drops=drs[k]))
+                    outs.append(dict(image_u8=ims[k], mask_i32=mks[k]))
+                prep = rh.pipeline_prepare(frs, outs)
+                for k, nd in enumerate(nds):
+                    prep.set_drop_count(k, nd)
+                slots.append((frs, outs, nds, prep))
+
+            def submit(s_):
+                frs, outs, nds, prep = slots[s_]
+                if prepared:
+                    rh.pipeline_submit_prepared(s_, prep)
+                else:
+                    rh.pipeline_submit(s_, [dict(fr, drops=fr['drops'][:nd]) for fr, nd in zip(frs, nds)], outs)
 
             def pipe(rounds):
                 done = 0
@@ -567,32 +593,39 @@ def main():
                     s_ = r % nslot
                     if r >= nslot:
                         while not rh.pipeline_wait(s_):
-                            rh.pipeline_submit(s_, *slots[s_])
+                            submit(s_)
                         done += PB
                     if r < rounds:
-                        rh.pipeline_submit(s_, *slots[s_])
+                        submit(s_)
                 return done
             pipe(nslot)                                   # warm-up: staging buffers, arena
-            rounds = max(2 * nslot, (384 + PB - 1) // PB)  # >= 384 frames
+            rounds = max(2 * nslot, (512 + PB - 1) // PB)  # >= 512 frames
             h0 = time.perf_counter()
             done = pipe(rounds)
             h1 = time.perf_counter()
-            for a_ in pinned:
+            slots = None
+            for a_ in blocks:
                 rh.host_free(a_)
-            rh.set_option(hb.RR_OPT_COPY_KERNELS, 1)
+            rh.set_option(hb.RR_OPT_COPY_KERNELS, 0)
             return {"frames_per_s": done / (h1 - h0), "ms_per_frame": 1e3 * (h1 - h0) / done, "frames_per_slot": PB, "frames_timed": done,
-                    "copies": "one copy kernel per direction and batch (RR_OPT_COPY_KERNELS 1)" if copy_kernels else "one hipMemcpyAsync per piece (RR_OPT_COPY_KERNELS 0)",
+                    "copies": ("one copy kernel per direction and batch (RR_OPT_COPY_KERNELS 1)" if copy_kernels else
+                               ("hipMemcpyAsync, one per array and batch (frames back to back in one page-locked block per array)" if packed
+                                else "hipMemcpyAsync, one per frame and array (separate allocations)")),
+                    "descriptors": "prepared once per slot" if prepared else "rebuilt in Python for every submission",
                     "pcie_GBps": {"up": up * done / (h1 - h0) / 1e9, "down": down * done / (h1 - h0) / 1e9}}
         PB = max(1, min(args.pipe_batch, batch.n))
-        hi = host_inclusive(PB, True)
+        hi = host_inclusive(PB)
         hi["what"] = ("rr_pipeline_submit/wait, %d slots x %d frames, pinned host buffers (rr_host_alloc): PCIe up (u8 image + f32 depth + drop "
                       "table), fog + environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask); PNG codec excluded"
                       % (nslot, PB))
         hi["pcie_bytes_per_frame"] = {"up": up, "down": down}
         extras["host_inclusive"] = hi
         if not args.no_variants:
-            extras["host_inclusive_variants"] = {"slots_of_32": host_inclusive(min(32, batch.n), True),
-                                                 "memcpy_per_piece": host_inclusive(PB, False)}
+            extras["host_inclusive_variants"] = {"slots_of_32": host_inclusive(min(32, batch.n)),
+                                                 "slots_of_64": host_inclusive(min(64, batch.n)),
+                                                 "copy_kernels": host_inclusive(PB, copy_kernels=True),
+                                                 "separate_allocations": host_inclusive(PB, packed=False),
+                                                 "descriptors_rebuilt": host_inclusive(PB, prepared=False)}
         warm(render, 1)
 
     if rank == 0:

@@ -109,7 +109,7 @@ typedef struct {
   const double* rainy_bg;         /* H*W*3 BGR, output of the fog pre-pass (generator.py:386): values in [0, 1] (it ends with
                                    * np.clip); a NaN stays a NaN like in the reference */
   const double* env_xyY;          /* He*We*3 (generator.py:407-408) */
-  const double* omega;            /* He*We solid angles (generator.py:410) */
+  const double* omega;            /* He*We solid angles (generator.py:410); NULL: the map given to rr_set_solid_angles */
   const rr_drop* drops;           /* n_drops records in reference order */
   int32_t n_drops;
   int32_t strategy;               /* 0: default (rendering_strategy=None); 1: 'white' (bad_weather.py:349-353) */
@@ -172,6 +172,9 @@ int rr_set_streak_db(rr_ctx* ctx, const uint8_t* texels, const int32_t* tex_h, c
 int rr_set_streak_db_device(rr_ctx* ctx, const uint8_t* texels_dev, int64_t n_bytes, const int32_t* tex_h,
                             const int32_t* tex_w, const int64_t* tex_off, int32_t n_tex);
 int rr_set_camera(rr_ctx* ctx, const rr_camera* cam);
+/* The solid-angle map of He x We environment maps (generator.py:410: a function of the map's shape alone), kept resident
+ * on the device: frames of that map size may then pass omega == NULL instead of uploading it with every batch. */
+int rr_set_solid_angles(rr_ctx* ctx, int32_t He, int32_t We, const double* omega);
 /* 256 RGBA byte entries of the colour map plt.imsave applies to rainy_mask (matplotlib's default: viridis). */
 int rr_set_colormap(rr_ctx* ctx, const uint8_t* lut_rgba);
 
@@ -318,11 +321,12 @@ enum {
    * 1: float64 colours always (the reference's arithmetic; what rainy_bg_out != NULL gets anyway).  The uint8 image of
    * the two differs by at most 1 LSB (tests/test_gpu_properties.py). */
   RR_OPT_COMPOSITE_F64 = 7,
-  /* tuning: how the host-pointer entry points move a batch across PCIe.  1 (default): the pieces whose host side is
-   * page-locked (rr_host_alloc) and 16-byte aligned are moved by ONE copy kernel per direction that reads / writes the
-   * host memory directly; everything else, and with 0 every piece, by one hipMemcpyAsync each.  Frame-sized pieces of
-   * the two directions issued as individual hipMemcpyAsync calls queue behind each other (40 GB/s in total, measured);
-   * the kernels run both directions at once (90 GB/s). */
+  /* tuning: how the host-pointer entry points move a batch across PCIe.  0 (default): hipMemcpyAsync (the DMA engines),
+   * after merging neighbouring pieces -- frames laid out back to back in one rr_host_alloc block, each starting on a
+   * 16-byte boundary, travel as ONE copy per array.  1: the pieces whose host side is page-locked and 16-byte aligned are
+   * moved by one copy kernel per direction that reads / writes the host memory directly (faster than many small DMA
+   * requests -- 90 vs 40 GB/s both ways, scripts/probes/pcie_probe.hip -- but it takes compute units from the rendering
+   * kernels it runs beside: measured slower end to end). */
   RR_OPT_COPY_KERNELS = 8
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);

@@ -162,20 +162,17 @@ class Generator:
     # ---- the asynchronous frame pipeline ------------------------------------------------------------------
     class _Slot:
         """Pinned host buffers of one batch in flight (inputs the I/O threads decode into, outputs they deflate from).
-        Every frame's piece of every buffer starts on a 16-byte boundary: the library then moves the whole batch with one
-        copy kernel per direction (include/rainhip.h RR_OPT_COPY_KERNELS) instead of one DMA request per piece."""
+        Every array is one page-locked block with the frames back to back, each on a 16-byte boundary (RainHip.host_rows):
+        the library then moves an array of the whole batch with ONE copy instead of one DMA request per frame."""
 
         def __init__(self, hip, B, H, W, We, bg_dtype, depth_dtype, save_envmap, drops_cap):
             self.B, self.H, self.W = B, H, W
             self._raw = []
 
             def rows(shape, dtype):
-                """B arrays of `shape` / `dtype`, each 16-byte aligned inside one page-locked allocation."""
-                nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-                stride = (nbytes + 15) // 16 * 16
-                raw = hip.host_array((B, max(stride, 16)), np.uint8)
+                raw, views = hip.host_rows(B, shape, dtype)
                 self._raw.append(raw)
-                return [raw[k, :nbytes].view(dtype).reshape(shape) for k in range(B)]
+                return views
             drops_cap = (drops_cap + 3) // 4 * 4
             self.bg = rows((H, W, 3), bg_dtype)
             self.depth = rows((H, W), depth_dtype)
@@ -188,13 +185,14 @@ class Generator:
             self.drops_cap = drops_cap
             self.key = (B, H, W, We, np.dtype(bg_dtype), np.dtype(depth_dtype), bool(save_envmap))
             self.items, self.encodes, self.busy = [], [], False
+            self.prep, self.pkey, self.n_valid = None, None, 0
 
         def free(self, hip):
             """Page-locked memory is only returned by rr_host_free (dropping the numpy views frees nothing): called when
             a slot is replaced by a larger / differently shaped one, after its batch has been collected and encoded."""
             assert not self.busy and not self.encodes
             self.bg = self.depth = self.drops = self.status = self.png_i = self.png_m = self.env = None
-            self.frames = self.outs = None
+            self.prep = None
             for raw in self._raw:
                 hip.host_free(raw)
             self._raw = []
@@ -425,7 +423,7 @@ class Generator:
             if sl is None or not sl.busy:
                 return
             while not hip.pipeline_wait(si):                    # tile arena regrown: submit the batch again
-                hip.pipeline_submit(si, sl.frames, sl.outs)
+                hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
             sl.busy = False
             dt = time.time() - sl.t_submit
             for k, (it, nd) in enumerate(sl.items):
@@ -468,6 +466,7 @@ class Generator:
                     drain(sj)
                 state['env_w'] = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
                 state['omega'] = solid_angle.get_solid_angles(np.empty((H, state['env_w'], 0)))    # generator.py:410
+                hip.set_solid_angles(state['omega'])            # resident on the device: not uploaded with every batch
                 state['geom'] = (H, W)
             bg0, dep0 = valid[0][1][0], valid[0][1][1]
             need_drops = max(len(ld[2]) for _, ld in valid)
@@ -478,25 +477,32 @@ class Generator:
                     sl.free(hip)
                 sl = slots[si] = Generator._Slot(hip, B, H, W, state['env_w'], bg0.dtype, dep0.dtype, self.save_envmap,
                                                  max(need_drops + need_drops // 4, 1024))
-            frames, outs, sl.items = [], [], []
+            # the batch's descriptors are made once per slot (the buffers do not move) and for the run's constants
+            pkey = (tuple(float(v) for v in fog_const), float(self.opacity_attenuation), self.rendering_strategy)
+            if getattr(sl, 'prep', None) is None or sl.pkey != pkey:
+                u8 = bg0.dtype == np.uint8
+                frames = [dict(bg=None if u8 else sl.bg[k], bg_u8=sl.bg[k] if u8 else None, depth=sl.depth[k], fog=fog_const, omega=None,
+                               drops=sl.drops[k], opacity_attenuation=self.opacity_attenuation,
+                               strategy=1 if self.rendering_strategy == 'white' else 0) for k in range(B)]
+                outs = []
+                for k in range(B):
+                    o = dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k])
+                    if self.save_envmap:
+                        o['env_bgr_u8'] = sl.env[k]
+                    outs.append(o)
+                sl.prep, sl.pkey = hip.pipeline_prepare(frames, outs), pkey
+            sl.items = []
             for k, (it, (bg, depth, drops)) in enumerate(valid):
                 assert bg.shape[:2] == (H, W) and bg.dtype == bg0.dtype, "frames of one sequence share their size"
                 np.copyto(sl.bg[k], bg)
                 np.copyto(sl.depth[k], depth)
                 nd = len(drops)
                 sl.drops[k][:nd] = drops
-                frames.append(dict(bg=None if bg.dtype == np.uint8 else sl.bg[k], bg_u8=sl.bg[k] if bg.dtype == np.uint8 else None,
-                                   depth=sl.depth[k], fog=fog_const, omega=state['omega'], drops=sl.drops[k][:nd],
-                                   opacity_attenuation=self.opacity_attenuation,
-                                   strategy=1 if self.rendering_strategy == 'white' else 0))
-                o = dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k][:nd])
-                if self.save_envmap:
-                    o['env_bgr_u8'] = sl.env[k]
-                outs.append(o)
+                sl.prep.set_drop_count(k, nd)
                 sl.items.append((it, nd))
-            sl.frames, sl.outs = frames, outs
+            sl.n_valid = len(valid)
             sl.t_submit = time.time()
-            hip.pipeline_submit(si, frames, outs)
+            hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
             if t_first is None:
                 t_first = time.time()                            # set-up (pinned buffers, first decodes) ends here
             sl.busy = True

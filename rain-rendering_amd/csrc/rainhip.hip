@@ -2781,7 +2781,11 @@ struct rr_ctx {
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
-  bool copy_kernels = true;          // RR_OPT_COPY_KERNELS: batched copy kernels for pinned host buffers (else hipMemcpyAsync per piece)
+  bool copy_kernels = false;         // RR_OPT_COPY_KERNELS: batched copy kernels for pinned host buffers (default: hipMemcpyAsync;
+                                     // measured slower than the DMA engines once the pieces are merged)
+  double* d_omega = nullptr;         // resident solid-angle map (rr_set_solid_angles): frames may pass omega == NULL
+  int omega_He = 0, omega_We = 0;
+  std::vector<std::pair<const char*, size_t>> host_allocs;   // rr_host_alloc blocks: pieces inside one block may be merged across padding
   bool composite_f64 = false;        // RR_OPT_COMPOSITE_F64: float64 colours in the compositor even when nobody asks for the composite
   int scratch_hp = 0;                // span pitch the scratch was sized for
   bool scratch_general = false;      // prefix table / polygons of the general colour path allocated
@@ -3011,7 +3015,11 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ctx->err = "rendering strategy must be 0 (default) or 1 ('white'); 'naive_db' is broken in the reference (bad_weather.py:355)";
       return RR_E_ARG;
     }
-    if (in[f].n_drops < 0 || in[f].n_drops > 65536 || !in[f].bg || !in[f].rainy_bg || !in[f].env_xyY || !in[f].omega ||
+    if (!in[f].omega && !(ctx->d_omega && ctx->omega_He == dm.He && ctx->omega_We == dm.We)) {
+      ctx->err = "omega == NULL needs rr_set_solid_angles for this map size";
+      return RR_E_STATE;
+    }
+    if (in[f].n_drops < 0 || in[f].n_drops > 65536 || !in[f].bg || !in[f].rainy_bg || !in[f].env_xyY ||
         (in[f].n_drops > 0 && !in[f].drops) || !out[f].rainy_rgb) {
       ctx->err = "null frame pointer or n_drops outside [0, 2^16] (generator.py:425)";
       return RR_E_ARG;
@@ -3043,7 +3051,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.bg = in[f].bg;
     fd.rainy_bg = in[f].rainy_bg;
     fd.env = in[f].env_xyY;
-    fd.omega = in[f].omega;
+    fd.omega = in[f].omega ? in[f].omega : ctx->d_omega;
     fd.drops = in[f].drops;
     fd.rgb = out[f].rainy_rgb;
     fd.comp_out = out[f].rainy_bg_out ? out[f].rainy_bg_out : ctx->d_comp_out + (size_t)f * dm.H * dm.W * 3;
@@ -3484,6 +3492,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.arena_need);
   hipFree(ctx->sc.overflow);
   hipFree(ctx->sc.need_max);
+  hipFree(ctx->d_omega);
   hipFree(ctx->d_dgrid);
   hipFree(ctx->d_cdf);
   hipFree(ctx->d_ratio_db);
@@ -3733,12 +3742,30 @@ namespace {
 struct CopyList {                      // merges copies whose source AND destination continue the previous one
   struct C { void* dst; const void* src; size_t bytes; };
   std::vector<C> v;
+  const std::vector<std::pair<const char*, size_t>>* blocks = nullptr;   // rr_host_alloc blocks of the context
+  bool host_is_src = true;
+  // both host addresses inside ONE rr_host_alloc block: the bytes between them are the caller's own padding
+  bool same_block(const void* a, const void* b) const {
+    if (!blocks) return false;
+    for (const auto& blk : *blocks) {
+      const char *lo = blk.first, *hi = blk.first + blk.second;
+      if ((const char*)a >= lo && (const char*)a < hi) return (const char*)b >= lo && (const char*)b < hi;
+    }
+    return false;
+  }
   void add(void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
-    if (!v.empty() && (char*)v.back().dst + v.back().bytes == (char*)dst && (const char*)v.back().src + v.back().bytes == (const char*)src)
-      v.back().bytes += bytes;
-    else
-      v.push_back(C{dst, src, bytes});
+    if (!v.empty()) {
+      C& p = v.back();
+      const ptrdiff_t gd = (char*)dst - ((char*)p.dst + p.bytes), gs = (const char*)src - ((const char*)p.src + p.bytes);
+      // contiguous on both sides -- or separated on both sides by the same few bytes of alignment padding inside one
+      // page-locked block of the caller and (always) inside the library's own staging: one copy, padding included
+      if (gd == gs && gd >= 0 && (gd == 0 || (gd < 16 && same_block(host_is_src ? p.src : p.dst, host_is_src ? src : (const void*)dst)))) {
+        p.bytes += (size_t)gd + bytes;
+        return;
+      }
+    }
+    v.push_back(C{dst, src, bytes});
   }
 };
 
@@ -3931,7 +3958,11 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         ctx->err = "rendering strategy must be 0 (default) or 1 ('white'); 'naive_db' is broken in the reference (bad_weather.py:355)";
         return RR_E_ARG;
       }
-      if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || !in[f].omega || (!in[f].sim && in[f].n_drops > 0 && !in[f].drops) ||
+      if (!in[f].omega && !(ctx->d_omega && ctx->omega_He == dm.He && ctx->omega_We == dm.We)) {
+        ctx->err = "omega == NULL needs rr_set_solid_angles for this map size";
+        return RR_E_STATE;
+      }
+      if ((!pre && (!in[f].bg || !in[f].rainy_bg || !in[f].env_xyY)) || (!in[f].sim && in[f].n_drops > 0 && !in[f].drops) ||
           (!out[f].rainy_rgb && !out[f].rainy_png)) {
         ctx->err = "null frame pointer (an image output is needed: rainy_rgb or rainy_png)";
         return RR_E_ARG;
@@ -3982,6 +4013,9 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   std::vector<rr_prepass_in> pin(pre ? n : 0);
   std::vector<rr_prepass_out> pout(pre ? n : 0);
   CopyList up, down;
+  up.blocks = down.blocks = &ctx->host_allocs;
+  up.host_is_src = true;
+  down.host_is_src = false;
   std::vector<rr_sim_frame> sims;
   // ---- upload ----
   for (int f = 0; pre && f < n; f++) {
@@ -4003,9 +4037,10 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     din[f].bg = st.bg + f * T.px3d;
     din[f].rainy_bg = st.rainy + f * T.px3d;
     din[f].env_xyY = st.env + f * T.ex3d;
-    // the solid-angle map depends on the map size only: frames that pass the same host array share one upload
-    const bool same_omega = f > 0 && in[f].omega == in[0].omega;
-    din[f].omega = same_omega ? din[0].omega : st.omega + f * T.exd;
+    // the solid-angle map depends on the map size only: NULL = the resident one (rr_set_solid_angles); frames that pass
+    // the same host array share one upload
+    const bool same_omega = !in[f].omega || (f > 0 && in[f].omega == in[0].omega);
+    din[f].omega = !in[f].omega ? nullptr : (same_omega ? din[0].omega : st.omega + f * T.exd);
     din[f].drops = st.drops + (size_t)f * st.drops_cap;
     if (pre) {                        // the pre-pass' depth buffer doubles as the occlusion depth
       din[f].depth = st.depth + f * T.pxd;
@@ -4077,10 +4112,15 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   HIPCHK(hipEventRecord(sl.ev_up, ctx->s_up));
   // ---- compute ----
   HIPCHK(hipStreamWaitEvent(s, sl.ev_up, 0));
-  for (int f = 0; pre && f < n; f++)
-    if (pre[f].bg_u8)                 // bg = bytes / 255.0 (generator.py:352) formed on the device
-      hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256)), dim3(256), 0, s, st.bg8 + f * T.px3b,
-                         (double*)pin[f].bg, (int64_t)(px * 3));
+  // bg = bytes / 255.0 (generator.py:352) formed on the device: one launch per run of consecutive byte-image frames
+  for (int f = 0; pre && f < n;) {
+    if (!pre[f].bg_u8) { f++; continue; }
+    int g = f;
+    while (g < n && pre[g].bg_u8) g++;
+    hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256), (unsigned)(g - f)), dim3(256), 0, s, st.bg8 + f * T.px3b,
+                       st.bg + f * T.px3d, (int64_t)(px * 3), (int64_t)T.px3b, (int64_t)T.px3d);
+    f = g;
+  }
   if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return rc;
   if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, st.drops_cap, st.ndrops, s))) return rc;
   if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return rc;
@@ -4204,12 +4244,36 @@ int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes) {
   *out = nullptr;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  ctx->host_allocs.emplace_back((const char*)*out, (size_t)bytes);
   return RR_OK;
 }
 
 int rr_host_free(rr_ctx* ctx, void* p) {
   if (!ctx) return RR_E_ARG;
-  if (p) HIPCHK(hipHostFree(p));
+  if (p) {
+    for (size_t k = 0; k < ctx->host_allocs.size(); k++)
+      if (ctx->host_allocs[k].first == (const char*)p) {
+        ctx->host_allocs.erase(ctx->host_allocs.begin() + (ptrdiff_t)k);
+        break;
+      }
+    HIPCHK(hipHostFree(p));
+  }
+  return RR_OK;
+}
+
+int rr_set_solid_angles(rr_ctx* ctx, int32_t He, int32_t We, const double* omega) {
+  if (!ctx) return RR_E_ARG;
+  if (He <= 0 || We <= 0 || !omega) {
+    ctx->err = "rr_set_solid_angles: bad argument";
+    return RR_E_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  int rc = dev_alloc(ctx, ctx->d_omega, (size_t)He * We);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(ctx->d_omega, omega, sizeof(double) * (size_t)He * We, hipMemcpyHostToDevice));
+  ctx->omega_He = He;
+  ctx->omega_We = We;
   return RR_OK;
 }
 

@@ -331,9 +331,10 @@ inline bool build_env_tables(int H, int W, int cw, int n_uniq, const int32_t* un
 
 #if defined(__HIPCC__)
 // bg = cv2.imread(...) / 255.0 (generator.py:352) from the bytes: IEEE division, same bits as numpy's
-__global__ void __launch_bounds__(256) k_bytes_to_unit(const uint8_t* src, double* dst, int64_t n) {
+// (blockIdx.y = frame; the frames' byte images / float64 images lie src_stride bytes / dst_stride doubles apart)
+__global__ void __launch_bounds__(256) k_bytes_to_unit(const uint8_t* src, double* dst, int64_t n, int64_t src_stride, int64_t dst_stride) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = (double)src[i] / 255.0;
+  if (i < n) dst[(int64_t)blockIdx.y * dst_stride + i] = (double)src[(int64_t)blockIdx.y * src_stride + i] / 255.0;
 }
 __global__ void __launch_bounds__(256) k_fog_ext(const PreFrame* fr, int H, int W, PreScratch sc) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;

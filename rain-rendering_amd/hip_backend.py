@@ -109,7 +109,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
-           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops',
+           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
            'rr_sizeof_sim_frame']
 
 _lib = None
@@ -182,6 +182,7 @@ def load_library(path=None):
     lib.rr_set_particle_tables.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     lib.rr_generate_drops_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.rr_set_solid_angles.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     lib.rr_generate_drops.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                       ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
     assert lib.rr_sizeof_sim_frame() == SIM_FRAME_DTYPE.itemsize, (lib.rr_sizeof_sim_frame(), SIM_FRAME_DTYPE.itemsize)
@@ -418,6 +419,17 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
+class Prepared:
+    """Descriptor arrays of one batch (RainHip.pipeline_prepare) and everything they point to."""
+
+    def __init__(self, n, pin, fin, fout, pout, keep, frames, outs):
+        self.n, self.pin, self.fin, self.fout, self.pout, self.keep, self.frames, self.outs = n, pin, fin, fout, pout, keep, frames, outs
+
+    def set_drop_count(self, k, n_drops):
+        """Frame k renders the first n_drops records of the drop array it was prepared with."""
+        self.fin[k].n_drops = int(n_drops)
+
+
 class RainHip:
     """One rendering context on one GPU (one per process / per GPU)."""
 
@@ -457,6 +469,15 @@ class RainHip:
         buf = (ctypes.c_uint8 * max(n, 1)).from_address(ptr.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def host_rows(self, n, shape, dtype):
+        """n arrays of `shape` / `dtype` laid out back to back in ONE page-locked block, each starting on a 16-byte
+        boundary: (block, [views]).  The library's staging uses the same padding, so such a set of per-frame buffers
+        crosses PCIe as a single copy (include/rainhip.h RR_OPT_COPY_KERNELS).  Free the block with host_free."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        stride = max((nbytes + 15) // 16 * 16, 16)
+        raw = self.host_array((n, stride), np.uint8)
+        return raw, [raw[k, :nbytes].view(dtype).reshape(shape) for k in range(n)]
+
     def host_free(self, array):
         """Give a host_array back (rr_host_free).  The array -- and every view of it -- must not be used afterwards and no
         batch that reads or writes it may be in flight."""
@@ -467,11 +488,14 @@ class RainHip:
         pinned.remove(addr)
         self._check(self.lib.rr_host_free(self.h, ctypes.c_void_p(addr)), 'rr_host_free')
 
-    def pipeline_submit(self, slot, frames, outs):
-        """rr_pipeline_submit: frames as for pipeline_frames (dict(bg | bg_u8, depth, fog, omega, drops, ...)), or as for
-        render_frames (dict(bg, rainy_bg, env_xyY, omega, drops)) when they carry no 'depth'; outs: list of
-        dict(image_u8[, mask][, mask_i32][, rainy_bg][, status]) of caller-owned arrays (ideally from host_array)
-        that the library fills.  Nothing may be touched until pipeline_wait(slot)."""
+    def pipeline_prepare(self, frames, outs):
+        """The descriptor arrays of one batch for rr_pipeline_submit, built once: frames as for pipeline_frames
+        (dict(bg | bg_u8, depth, fog, omega, drops | sim, ...)), or as for render_frames (dict(bg, rainy_bg, env_xyY, omega,
+        drops)) when they carry no 'depth'; outs: list of dict(image_u8[, mask][, mask_i32][, rainy_bg][, status]
+        [, rainy_png][, mask_png][, n_drops]) of caller-owned arrays (ideally from host_array) that the library fills.
+        omega None = the map given to set_solid_angles.  A driver that re-uses the same buffers batch after batch
+        prepares once per slot and calls pipeline_submit_prepared (the per-frame Python work is what bounds a fast GPU);
+        Prepared.set_drop_count(k, n) adjusts a frame's drop count in place."""
         n = len(frames)
         with_pre = 'depth' in frames[0]
         pin = (rr_prepass_in * n)() if with_pre else None
@@ -480,11 +504,11 @@ class RainHip:
         keep = []
         We = self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width') if with_pre else 0
         for k, (fr, o) in enumerate(zip(frames, outs)):
-            om = np.ascontiguousarray(fr['omega'], np.float64)
+            om = np.ascontiguousarray(fr['omega'], np.float64) if fr.get('omega') is not None else None
             sim = fr.get('sim')                        # SIM_FRAME_DTYPE record: the drop table is generated on the device;
             if sim is not None:                        # o['status'] (if any) must hold fr['drops_cap'] entries
                 sim = np.ascontiguousarray(sim, SIM_FRAME_DTYPE).reshape(1)
-                drops = np.zeros(int(fr.get('drops_cap', 0)) or int(sim['n_particles'][0]), DROP_DTYPE)[:0]
+                drops = np.zeros(0, DROP_DTYPE)
                 cap = int(fr.get('drops_cap', 0)) or int(sim['n_particles'][0])
             else:
                 drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
@@ -499,7 +523,7 @@ class RainHip:
                 rb = np.ascontiguousarray(fr['rainy_bg'], np.float64)
                 env = np.ascontiguousarray(fr['env_xyY'], np.float64)
                 H, W = bg.shape[:2]
-                fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, om.shape[0], om.shape[1]
+                fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, env.shape[0], env.shape[1]
                 fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY = _ptr(bg), _ptr(rb), _ptr(env)
                 keep.append((bg, rb, env))
             fin[k].omega = _ptr(om)
@@ -534,10 +558,20 @@ class RainHip:
                 e = o.get('env_bgr_u8')
                 assert e is None or (e.dtype == np.uint8 and e.flags['C_CONTIGUOUS'])
                 pout[k].env_bgr_u8 = _ptr(e)
-        self._check(self.lib.rr_pipeline_submit(self.h, int(slot), n, pin, fin, fout, pout), 'rr_pipeline_submit')
+        return Prepared(n, pin, fin, fout, pout, keep, frames, outs)
+
+    def pipeline_submit_prepared(self, slot, prep, n=None):
+        """rr_pipeline_submit of a prepared batch (its first n frames).  Nothing may be touched until pipeline_wait(slot)."""
+        n = prep.n if n is None else int(n)
+        assert 0 < n <= prep.n
+        self._check(self.lib.rr_pipeline_submit(self.h, int(slot), n, prep.pin, prep.fin, prep.fout, prep.pout), 'rr_pipeline_submit')
         if not hasattr(self, '_inflight'):
             self._inflight = {}
-        self._inflight[int(slot)] = (pin, fin, fout, pout, keep, outs)
+        self._inflight[int(slot)] = prep
+
+    def pipeline_submit(self, slot, frames, outs):
+        """pipeline_prepare + pipeline_submit_prepared."""
+        self.pipeline_submit_prepared(slot, self.pipeline_prepare(frames, outs))
 
     def pipeline_wait(self, slot):
         """True when the batch of `slot` is complete; False when the tile arena had to grow (submit the batch again)."""
@@ -571,6 +605,12 @@ class RainHip:
         offs = np.ascontiguousarray(offs, np.int64)
         self._check(self.lib.rr_set_streak_db_device(self.h, ctypes.c_void_p(dev_ptr), int(n_bytes), _ptr(hs), _ptr(ws),
                                                      _ptr(offs), len(hs)), 'rr_set_streak_db_device')
+
+    def set_solid_angles(self, omega):
+        """The solid-angle map (common/solid_angle.get_solid_angles: a function of the environment map's shape alone), kept
+        resident on the device: frames of that map size may pass omega=None."""
+        om = np.ascontiguousarray(omega, np.float64)
+        self._check(self.lib.rr_set_solid_angles(self.h, om.shape[0], om.shape[1], _ptr(om)), 'rr_set_solid_angles')
 
     def set_colormap(self, lut_rgba):
         """256x4 uint8 RGBA table of the colour map plt.imsave applies to the rain mask (common/imgops.viridis_lut())."""
