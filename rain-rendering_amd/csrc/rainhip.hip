@@ -2657,6 +2657,11 @@ struct CopyPiece {
   void* dst;
   uint64_t bytes;
 };
+struct HostCopy {                    // one copy between host and device memory (host-side bookkeeping)
+  void* dst;
+  const void* src;
+  size_t bytes;
+};
 __global__ __launch_bounds__(256) void k_copy_pieces(const CopyPiece* pieces, int n) {
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
   for (int j = 0; j < n; j++) {
@@ -2757,6 +2762,7 @@ struct rr_ctx {
   struct Slot {
     Staging st;
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_down = nullptr;
+    std::vector<HostCopy> down;                       // the batch's device-to-host copies, issued by rr_pipeline_wait
     CopyPiece *d_up = nullptr, *d_down = nullptr;     // piece lists of the copy kernels
     CopyPiece *h_up = nullptr, *h_down = nullptr;     // (pinned)
     size_t cap_up = 0, cap_down = 0;
@@ -3740,7 +3746,7 @@ int rr_sizeof_sim_frame(void) { return (int)sizeof(rr_sim_frame); }
 namespace {
 
 struct CopyList {                      // merges copies whose source AND destination continue the previous one
-  struct C { void* dst; const void* src; size_t bytes; };
+  using C = HostCopy;
   std::vector<C> v;
   const std::vector<std::pair<const char*, size_t>>* blocks = nullptr;   // rr_host_alloc blocks of the context
   bool host_is_src = true;
@@ -4125,8 +4131,9 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, st.drops_cap, st.ndrops, s))) return rc;
   if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return rc;
   HIPCHK(hipEventRecord(sl.ev_comp, s));
-  // ---- download ----
-  HIPCHK(hipStreamWaitEvent(ctx->s_down, sl.ev_comp, 0));
+  // ---- download: only the LIST is made here.  The copies are issued by rr_pipeline_wait once the kernels have finished:
+  // a device-to-host copy queued now would sit in the DMA queue waiting for its kernels -- and hold up the NEXT batch's
+  // upload queued behind it (measured: the GPU then idles for the length of an upload between two batches).
   for (int f = 0; in && f < n; f++) {
     if (out[f].rainy_rgb) down.add(out[f].rainy_rgb, dout[f].rainy_rgb, px * 3);
     if (out[f].rainy_bg_out) down.add(out[f].rainy_bg_out, dout[f].rainy_bg_out, px * 3 * sizeof(double));
@@ -4143,10 +4150,8 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     if (pre_out[f].env_xyY) down.add(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * sizeof(double));
     if (pre_out[f].env_bgr_u8) down.add(pre_out[f].env_bgr_u8, pout[f].env_bgr_u8, ex * 3);
   }
-  if ((rc = issue(ctx, down, hipMemcpyDeviceToHost, ctx->s_down, sl.d_down, sl.h_down, sl.cap_down))) return rc;
+  sl.down = std::move(down.v);
   sl.h_flags[0] = 0;
-  if (in) HIPCHK(hipMemcpyAsync(&sl.h_flags[0], ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_down));
-  HIPCHK(hipEventRecord(sl.ev_down, ctx->s_down));
   sl.busy = true;
   sl.rendered = in != nullptr;
   return RR_OK;
@@ -4161,7 +4166,16 @@ int host_wait(rr_ctx* ctx, int slot) {
   rr_ctx::Slot& sl = ctx->slots[slot];
   if (!sl.busy) return RR_OK;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipEventSynchronize(sl.ev_down));
+  HIPCHK(hipEventSynchronize(sl.ev_comp));             // the batch's kernels are done (later batches keep the GPU busy meanwhile)
+  {
+    CopyList down;
+    down.v = std::move(sl.down);
+    sl.down.clear();
+    int rc = issue(ctx, down, hipMemcpyDeviceToHost, ctx->s_down, sl.d_down, sl.h_down, sl.cap_down);
+    if (rc) return rc;
+    if (sl.rendered) HIPCHK(hipMemcpyAsync(&sl.h_flags[0], ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_down));
+    HIPCHK(hipStreamSynchronize(ctx->s_down));
+  }
   sl.busy = false;
   if (sl.rendered && (int32_t)sl.h_flags[0] != 0) {
     // every batch submitted since the overflow ran against the short arena too: they all report it
