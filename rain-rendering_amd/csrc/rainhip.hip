@@ -3761,8 +3761,9 @@ struct CopyList {                      // merges copies whose source AND destina
   }
   void add(void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
-    if (!v.empty()) {
-      C& p = v.back();
+    // (a frame adds one piece per array: the piece this one continues is a few entries back)
+    for (size_t back = 1; back <= v.size() && back <= 12; back++) {
+      C& p = v[v.size() - back];
       const ptrdiff_t gd = (char*)dst - ((char*)p.dst + p.bytes), gs = (const char*)src - ((const char*)p.src + p.bytes);
       // contiguous on both sides -- or separated on both sides by the same few bytes of alignment padding inside one
       // page-locked block of the caller and (always) inside the library's own staging: one copy, padding included
@@ -4010,9 +4011,25 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   for (void* b : sl.ext_blobs) hipFree(b);             // the slot's previous batch is complete (not busy)
   sl.ext_blobs.clear();
   auto& st = sl.st;
-  if ((rc = slot_reserve(ctx, st, n, max_drops, dm))) return rc;
+  // Staging strides that follow the caller's layout where that lets a whole array travel as one copy: drop tables laid
+  // out at a constant distance (frames back to back in one block) get that distance on the device too
+  int drop_stride = 0;
+  if (in && n > 1 && in[0].drops && !in[0].sim) {
+    const ptrdiff_t hs = (const char*)in[1].drops - (const char*)in[0].drops;
+    bool regular = hs > 0 && hs % (ptrdiff_t)sizeof(rr_drop) == 0 && hs / (ptrdiff_t)sizeof(rr_drop) >= max_drops &&
+                   hs / (ptrdiff_t)sizeof(rr_drop) <= 65536 + 16 && (hs / (ptrdiff_t)sizeof(rr_drop)) % 4 == 0;
+    for (int f = 2; regular && f < n; f++) regular = (const char*)in[f].drops - (const char*)in[f - 1].drops == hs;
+    if (regular) drop_stride = (int)(hs / (ptrdiff_t)sizeof(rr_drop));
+  }
+  if ((rc = slot_reserve(ctx, st, n, drop_stride ? drop_stride : max_drops, dm))) return rc;
+  if (!drop_stride) drop_stride = st.drops_cap;
+  bool all_f32_depth = pre != nullptr || in != nullptr;
+  for (int f = 0; f < n; f++) all_f32_depth = all_f32_depth && !(pre ? pre[f].depth_f64 : in[f].depth_f64);
   const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We, png_bytes = (size_t)dm.H * (1 + 4 * (size_t)dm.W);
   const Strides T = strides_of(dm);
+  // the depth slot: float32 maps of a batch lie 4 * H * W bytes (rounded to 16) apart, float64 ones (or a mix) 8 * H * W
+  const size_t depth_stride = all_f32_depth ? (((size_t)dm.H * dm.W * 4 + 15) & ~(size_t)15) : T.pxd * 8;
+  auto depth_at = [&](int f) { return reinterpret_cast<double*>(reinterpret_cast<char*>(st.depth) + (size_t)f * depth_stride); };
   hipStream_t s = ctx->stream;
   std::vector<rr_frame_in> din(in ? n : 0);
   std::vector<rr_frame_out> dout(in ? n : 0);
@@ -4028,7 +4045,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     pin[f] = pre[f];
     pin[f].bg = st.bg + f * T.px3d;
     pin[f].bg_u8 = nullptr;
-    pin[f].depth = st.depth + f * T.pxd;
+    pin[f].depth = depth_at(f);
     if (pre[f].bg_u8) up.add(st.bg8 + f * T.px3b, pre[f].bg_u8, px * 3);      // bytes over PCIe: 1/8 of the float64 image
     else up.add((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double));
     const bool env_only = pre[f].mode == RR_PRE_ENV_ONLY;
@@ -4047,13 +4064,13 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     // the same host array share one upload
     const bool same_omega = !in[f].omega || (f > 0 && in[f].omega == in[0].omega);
     din[f].omega = !in[f].omega ? nullptr : (same_omega ? din[0].omega : st.omega + f * T.exd);
-    din[f].drops = st.drops + (size_t)f * st.drops_cap;
+    din[f].drops = st.drops + (size_t)f * drop_stride;
     if (pre) {                        // the pre-pass' depth buffer doubles as the occlusion depth
-      din[f].depth = st.depth + f * T.pxd;
+      din[f].depth = depth_at(f);
       din[f].depth_f64 = pre[f].depth_f64;
     } else if (in[f].depth && ctx->depth_occlusion) {
-      up.add((void*)(st.depth + f * T.pxd), in[f].depth, px * (in[f].depth_f64 ? 8 : 4));
-      din[f].depth = st.depth + f * T.pxd;
+      up.add((void*)depth_at(f), in[f].depth, px * (in[f].depth_f64 ? 8 : 4));
+      din[f].depth = depth_at(f);
     } else {
       din[f].depth = nullptr;
     }
@@ -4075,8 +4092,8 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     dout[f].rainy_bg_out = out[f].rainy_bg_out ? st.comp + f * T.px3d : nullptr;
     dout[f].mask_f64 = st.mask + f * T.pxd;
     dout[f].mask_i32 = out[f].mask_i32 ? st.mask_i + f * T.pxi : nullptr;
-    dout[f].drop_status = st.status + (size_t)f * st.drops_cap;
-    dout[f].drop_colour = out[f].drop_colour ? st.colour + (size_t)f * st.drops_cap * 3 : nullptr;
+    dout[f].drop_status = st.status + (size_t)f * drop_stride;
+    dout[f].drop_colour = out[f].drop_colour ? st.colour + (size_t)f * drop_stride * 3 : nullptr;
     din[f].ext = nullptr;
     if (in[f].ext && in[f].n_drops > 0) {
       // caller-made tiles (the single-drop seam; not a throughput path): one device blob per frame =
@@ -4128,7 +4145,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     f = g;
   }
   if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return rc;
-  if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, st.drops_cap, st.ndrops, s))) return rc;
+  if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, drop_stride, st.ndrops, s))) return rc;
   if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return rc;
   HIPCHK(hipEventRecord(sl.ev_comp, s));
   // ---- download: only the LIST is made here.  The copies are issued by rr_pipeline_wait once the kernels have finished:
