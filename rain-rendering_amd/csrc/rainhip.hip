@@ -2680,6 +2680,14 @@ __global__ __launch_bounds__(256) void k_copy_pieces(const CopyPiece* pieces, in
   }
 }
 
+// A batch's descriptor records (FrameDesc / PreFrame / rr_sim_frame) go from their pinned host buffer to the device by
+// KERNEL, not by hipMemcpyAsync: a DMA request in the compute stream waits in the DMA queue until the kernels in front of
+// it have run, and every copy queued after it -- the previous batch's download, the next batch's upload, on other
+// streams -- waits with it (measured: the download of batch k started when batch k+1 reached its descriptor copy).
+__global__ __launch_bounds__(256) void k_copy_small(const uint32_t* src_pinned_host, uint32_t* dst, int n_words) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) dst[i] = src_pinned_host[i];
+}
+
 // drop counts that only exist on the device (rr_frame_in.n_drops_dev): patched into the frame descriptors before the
 // first kernel of the chain reads them; n_drops of the descriptor is the capacity
 __global__ void k_patch_counts(FrameDesc* frames, int n) {
@@ -3078,7 +3086,9 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.strategy = in[f].strategy;
     fd.opacity = in[f].opacity_attenuation;
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_frames, h_frames, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, s));
+  static_assert(sizeof(FrameDesc) % 4 == 0 && sizeof(rrpre::PreFrame) % 4 == 0 && sizeof(rr_sim_frame) % 4 == 0, "descriptor sizes");
+  hipLaunchKernelGGL(k_copy_small, dim3(16), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(h_frames), reinterpret_cast<uint32_t*>(ctx->d_frames),
+                     (int)(sizeof(FrameDesc) * (size_t)n / 4));
   if ((rc = ring_commit(ctx, ctx->ring_frames, ring_idx, s))) return rc;
   if (any_dev_count) hipLaunchKernelGGL(k_patch_counts, dim3((n + 63) / 64), dim3(64), 0, s, ctx->d_frames, n);
   const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
@@ -3318,7 +3328,8 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     p.depth_f64 = in[f].depth_f64;
     p.pad = 0;
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_pre, h_pre, sizeof(rrpre::PreFrame) * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_copy_small, dim3(16), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(h_pre), reinterpret_cast<uint32_t*>(ctx->d_pre),
+                     (int)(sizeof(rrpre::PreFrame) * (size_t)n / 4));
   if ((rrc = ring_commit(ctx, ctx->ring_pre, ring_idx, s))) return rrc;
   const rrpre::PreScratch sc = ctx->psc;
   const unsigned px_blocks = (unsigned)(((int64_t)H * W + 255) / 256);
@@ -3393,7 +3404,8 @@ int enqueue_particles(rr_ctx* ctx, int n, const rr_sim_frame* sims, int H, int W
   void* host;
   if ((rc = ring_acquire(ctx, ctx->ring_sims, sizeof(rr_sim_frame) * (size_t)n, ring_idx, host))) return rc;
   memcpy(host, sims, sizeof(rr_sim_frame) * (size_t)n);
-  HIPCHK(hipMemcpyAsync(ctx->d_sims, host, sizeof(rr_sim_frame) * (size_t)n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_copy_small, dim3(16), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(host), reinterpret_cast<uint32_t*>(ctx->d_sims),
+                     (int)(sizeof(rr_sim_frame) * (size_t)n / 4));
   if ((rc = ring_commit(ctx, ctx->ring_sims, ring_idx, s))) return rc;
   {
     ProfScope ps(ctx, s, "k_particles");
