@@ -90,3 +90,21 @@ def test_depth_occlusion_hostemu_matches_oracle(tmp_path, dtype):
     assert np.array_equal(emu['mask'], ref['mask']) and np.array_equal(emu['mask_i32'], ref['mask_i32'])
     assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
     assert 0.2 * base['mask'].sum() < emu['mask'].sum() < 0.9 * base['mask'].sum()
+
+
+def test_whole_frame_kitti25_oracle_vs_hostemu(tmp_path):
+    """EVERY drop of a BASELINE configs[1] frame (KITTI 1242x375, 25 mm/hr) through the numpy oracle in its op-for-op mode
+    (per-drop masked reduction over the whole environment map, like the reference) against the g++ build of the kernel
+    arithmetic: statuses, float64 mask, int32 mask bit for bit; image within 1 LSB.  (The windows elsewhere cover parts of a
+    frame; the GPU tier compares the kernels with hostemu at full size, and with the whole-frame oracle at 100 mm/hr.)"""
+    import test_gpu_configs as cfg
+    H, W, N, cam, rs, _ = cfg.CONFIGS['kitti_25']
+    sc = h.Scene(tmp_path, H, W, N, cam=cam, render_scale=rs, seed0=4000)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=True)
+    assert len(drops) > 1500
+    assert np.array_equal(emu['status'], ref['status'])
+    assert np.array_equal(emu['mask'], ref['mask']) and np.array_equal(emu['mask_i32'], ref['mask_i32'])
+    assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
