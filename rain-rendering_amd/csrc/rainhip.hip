@@ -631,8 +631,8 @@ template <int DPT, int EMAX>
 __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int Dp, int rpb, int nchunk, Scratch sc) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   const int We = dm.We;
-  double2* s_P = reinterpret_cast<double2*>(s_dyn);      // 2 x [We + 1] inclusive prefix of the half's two components; entry 0 = zeros
-  double* s_wt = reinterpret_cast<double*>(s_P + 2 * (We + 1));     // 2 x [16][2] wave totals of the row being scanned
+  double2* s_P = reinterpret_cast<double2*>(s_dyn);      // [We + 1] inclusive prefix of the half's two components; entry 0 = zeros
+  double* s_wt = reinterpret_cast<double*>(s_P + (We + 1));     // [16][2] wave totals of the row being scanned
   const int f = blockIdx.y, band = blockIdx.x % COL_PARTS, part = blockIdx.x / COL_PARTS;
   const int half = part & 1, chunk = part >> 1;
   const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, nw = NT >> 6;
@@ -656,15 +656,7 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
     const int i = d0 + d * NT + t;
     sp[d] = (uint32_t)((i < d1 && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops);
   }
-  // Two prefix buffers and two sets of wave totals: while a wave takes its drops' look-ups from row y's prefix, another may
-  // already be finishing row y + 1 into the other buffer -- ONE barrier per map row, and the waves of the workgroup drift
-  // apart by up to a phase, so that look-ups (LDS) of some overlap the scans (VALU) of others.
-  double2* s_P1 = s_P + (We + 1);
-  double* s_wt1 = s_wt + 2 * 16;
-  if (t == 0) {
-    s_P[0] = make_double2(0.0, 0.0);
-    s_P1[0] = make_double2(0.0, 0.0);
-  }
+  if (t == 0) s_P[0] = make_double2(0.0, 0.0);
   double S[DPT][2];
   uint32_t any = 0;                                      // bit d: drop d had a non-empty span in this band
 #pragma unroll
@@ -690,84 +682,60 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
       }
     }
   };
-  double ps[EMAX][2], pbs[EMAX][2];                      // the row being built: inclusive prefix inside the wave through the lane's
-                                                         // second column, and that column's own values
-  // the wave's part of a row's scan (from pa / pb, which are free for the next load afterwards); wave totals to wt[]
-  auto local_scan = [&](double* wt) {
-    double carry[2] = {0.0, 0.0};
+  if (y0 < y1) load_row(y0);
+  for (int yq = y0; yq < y1; yq += 4) {                  // y0 is a multiple of four: one 16-byte span load per drop and quad
+    uint4 q[DPT];
 #pragma unroll
-    for (int e = 0; e < EMAX; e++) {
-      if (e * 128 < Cw) {
+    for (int d = 0; d < DPT; d++) q[d] = spf[(int64_t)(yq >> 2) * Dp + sp[d]];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const double v = wave_incl_scan_f64(pa[e][k] + pb[e][k]) + carry[k];
-          ps[e][k] = v;
-          pbs[e][k] = pb[e][k];
-          carry[k] = readlane_f64(v, 63);
+    for (int j = 0; j < 4; j++) {
+      const int y = yq + j;
+      if (y >= y1) break;
+      // ---- 1. prefix sums of row y into LDS ----
+      double carry[2] = {0.0, 0.0};
+      double ps[EMAX][2];                                // inclusive prefix through the lane's second column
+#pragma unroll
+      for (int e = 0; e < EMAX; e++) {
+        if (e * 128 < Cw) {
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const double v = wave_incl_scan_f64(pa[e][k] + pb[e][k]) + carry[k];
+            ps[e][k] = v;
+            carry[k] = readlane_f64(v, 63);
+          }
         }
       }
-    }
-    if (lane == 0) { wt[wave * 2 + 0] = carry[0]; wt[wave * 2 + 1] = carry[1]; }
-  };
-  // totals of the waves in front (16-lane scan of the wave totals), then the row's prefix goes to P
-  auto finish_row = [&](const double* wt, double2* P) {
-    double basev[2];
+      if (lane == 0) { s_wt[wave * 2 + 0] = carry[0]; s_wt[wave * 2 + 1] = carry[1]; }
+      __syncthreads();                                   // wave totals visible; the previous row's look-ups are done
+      double basev[2];                                   // totals of the waves in front: 16-lane scan of the wave totals
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const double w_ = row16_incl_scan_f64(lane < nw ? wt[lane * 2 + k] : 0.0);
-      const double u = readlane_f64(w_, wave > 0 ? wave - 1 : 0);
-      basev[k] = wave > 0 ? u : 0.0;
-    }
+      for (int k = 0; k < 2; k++) {
+        const double wt = row16_incl_scan_f64(lane < nw ? s_wt[lane * 2 + k] : 0.0);
+        const double u = readlane_f64(wt, wave > 0 ? wave - 1 : 0);
+        basev[k] = wave > 0 ? u : 0.0;
+      }
 #pragma unroll
-    for (int e = 0; e < EMAX; e++) {
-      const int cl = e * 128 + 2 * lane, c = cw0 + cl;
-      if (cl < Cw && c < We) {
-        const double o0 = basev[0] + ps[e][0], o1 = basev[1] + ps[e][1];       // through column c + 1
-        P[c + 1] = make_double2(o0 - pbs[e][0], o1 - pbs[e][1]);               // through column c
-        if (c + 1 < We) P[c + 2] = make_double2(o0, o1);
-        if (c == We - 1 || c + 1 == We - 1) { tot0 += o0; tot1 += o1; }        // (an absent second column added 0)
+      for (int e = 0; e < EMAX; e++) {
+        const int cl = e * 128 + 2 * lane, c = cw0 + cl;
+        if (cl < Cw && c < We) {
+          const double o0 = basev[0] + ps[e][0], o1 = basev[1] + ps[e][1];       // through column c + 1
+          s_P[c + 1] = make_double2(o0 - pb[e][0], o1 - pb[e][1]);               // through column c
+          if (c + 1 < We) s_P[c + 2] = make_double2(o0, o1);
+          if (c == We - 1 || c + 1 == We - 1) { tot0 += o0; tot1 += o1; }        // (an absent second column added 0)
+        }
+      }
+      if (y + 1 < y1) load_row(y + 1);                   // in flight under the look-ups
+      __syncthreads();                                   // row prefix complete
+      // ---- 2. look-ups ----
+#pragma unroll
+      for (int d = 0; d < DPT; d++) {
+        const uint32_t v = j == 0 ? q[d].x : (j == 1 ? q[d].y : (j == 2 ? q[d].z : q[d].w));
+        any |= (v != 0u ? 1u : 0u) << d;
+        const double2 h = s_P[v >> 16], l = s_P[v & 0xffffu];
+        S[d][0] += h.x - l.x;
+        S[d][1] += h.y - l.y;
       }
     }
-  };
-  if (y0 < y1) {
-    load_row(y0);
-    local_scan(s_wt);                                    // row y0 pending, its wave totals in s_wt
-    if (y0 + 1 < y1) load_row(y0 + 1);
-    __syncthreads();
-    finish_row(s_wt, s_P);                               // row y0 complete in buffer 0 (after the barrier below)
-    if (y0 + 1 < y1) {
-      local_scan(s_wt1);                                 // row y0 + 1 pending
-      if (y0 + 2 < y1) load_row(y0 + 2);
-    }
-    __syncthreads();
-  }
-  uint4 q[DPT];
-  for (int y = y0; y < y1; y++) {                        // y0 is a multiple of four: one 16-byte span load per drop and quad
-    const int j = (y - y0) & 3, par = (y - y0) & 1;
-    if (j == 0) {
-#pragma unroll
-      for (int d = 0; d < DPT; d++) q[d] = spf[(int64_t)(y >> 2) * Dp + sp[d]];
-    }
-    // ---- look-ups of row y (complete in buffer par) ----
-    const double2* P = par ? s_P1 : s_P;
-#pragma unroll
-    for (int d = 0; d < DPT; d++) {
-      const uint32_t v = j == 0 ? q[d].x : (j == 1 ? q[d].y : (j == 2 ? q[d].z : q[d].w));
-      any |= (v != 0u ? 1u : 0u) << d;
-      const double2 h = P[v >> 16], l = P[v & 0xffffu];
-      S[d][0] += h.x - l.x;
-      S[d][1] += h.y - l.y;
-    }
-    // ---- row y + 1 (pending: scanned inside the waves, totals published before the last barrier) into the other buffer;
-    //      row y + 2 scanned inside the waves; row y + 3 requested ----
-    if (y + 1 < y1) {
-      finish_row(par ? s_wt : s_wt1, par ? s_P : s_P1);
-      if (y + 2 < y1) {
-        local_scan(par ? s_wt1 : s_wt);
-        if (y + 3 < y1) load_row(y + 3);
-      }
-    }
-    __syncthreads();                                     // row y + 1 complete; everybody is done with row y's buffer and totals
   }
 #pragma unroll
   for (int d = 0; d < DPT; d++) {
@@ -3170,7 +3138,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_fov_sums");
       // a chunk of NT*DPT drops re-scans the band's rows, so DPT grows with the drop count (register budget: 4
       // doubles of running sums + one 16-byte span piece per drop)
-      const size_t row_bytes = ((size_t)(dm.We + 1) * 2 * 2 + 16 * 2 * 2) * sizeof(double);      // two prefix buffers + two sets of wave totals
+      const size_t row_bytes = ((size_t)(dm.We + 1) * 2 + 16 * 2) * sizeof(double);      // P + wave totals
       // a wave owns ceil(We / waves) columns (rounded up to even), in passes of 128
       auto passes = [&](int nt) { return ((((dm.We + nt / 64 - 1) / (nt / 64)) + 1) / 2 * 2 + 127) / 128; };
       int NT = ctx->fov_threads ? ctx->fov_threads : 1024;
