@@ -202,15 +202,19 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
 
 
 def measure_valu(args, scene_dir=None):
-    """VALU issue utilisation per kernel from one rocprofv3 --pmc pass of this workload: SQ_ACTIVE_INST_VALU (quad-cycles
-    in which a wave has a VALU instruction executing, summed over the chip) * 4 / (GRBM_GUI_ACTIVE cycles of the launch *
-    1024 SIMDs): the fraction of the chip's VALU issue capacity in use while the kernel runs.  Returns ({kernel: {...}}, how)."""
+    """VALU issue utilisation per kernel from one rocprofv3 --pmc pass of this workload.  SQ_INSTS_VALU counts wave-level
+    VALU instructions over the whole chip; a wave64 instruction occupies its SIMD-32 for 2 cycles (float / integer) or 4
+    (float64: half rate), so the fraction of the chip's VALU issue capacity in use while the kernel runs lies between
+        2 * SQ_INSTS_VALU / (cycles * 1024 SIMDs)   and   4 * SQ_INSTS_VALU / (cycles * 1024 SIMDs),
+    cycles = GRBM_GUI_ACTIVE / 8 (the counter adds up the 8 XCDs; checked against the kernel's duration).  The path's
+    arithmetic is float64 almost everywhere: the upper figure is the closer one.  `waiting` = SQ_WAIT_ANY / SQ_WAVE_CYCLES:
+    the share of wave time spent parked on s_waitcnt / barriers.  Returns ({kernel: {...}}, how)."""
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     try:
         out = tempfile.mkdtemp(prefix='rainpmc_', dir='/tmp')
-        cmd = [exe, '--kernel-trace', '--pmc', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE',
+        cmd = [exe, '--kernel-trace', '--pmc', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE',
                '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1',
                '--batch', str(args.batch), '--workload', args.workload] + sum((['--opt', o] for o in args.opt), [])
         if scene_dir:
@@ -240,13 +244,16 @@ def measure_valu(args, scene_dir=None):
             res.setdefault(k, {})[c] = agg[(k, c)] / cnt[(k, c)]
         outp = {}
         for k, v in res.items():
-            if v.get('GRBM_GUI_ACTIVE') and v.get('SQ_ACTIVE_INST_VALU') is not None:
-                outp[k] = {"valu_util": 4.0 * v['SQ_ACTIVE_INST_VALU'] / (v['GRBM_GUI_ACTIVE'] * 1024.0),
-                           "valu_insts": v.get('SQ_INSTS_VALU'), "gui_active_cycles": v['GRBM_GUI_ACTIVE']}
+            if v.get('GRBM_GUI_ACTIVE') and v.get('SQ_INSTS_VALU') is not None:
+                cyc = v['GRBM_GUI_ACTIVE'] / 8.0
+                outp[k] = {"valu_util": 4.0 * v['SQ_INSTS_VALU'] / (cyc * 1024.0), "valu_util_if_all_f32": 2.0 * v['SQ_INSTS_VALU'] / (cyc * 1024.0),
+                           "valu_insts": v['SQ_INSTS_VALU'], "cycles": cyc,
+                           "waiting": (v.get('SQ_WAIT_ANY', 0.0) / v['SQ_WAVE_CYCLES']) if v.get('SQ_WAVE_CYCLES') else None}
         if not outp:
             return None, "no counters in the pass' output"
-        return outp, ("per launch: 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE * 1024 SIMDs), one rocprofv3 --pmc pass of this workload "
-                      "spawned by bench.py")
+        return outp, ("valu_util = 4 * SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): the share of the chip's VALU issue capacity in use if "
+                      "every instruction were float64 (4 cycles per wave64 instruction; 2 for float / integer: half the figure is the lower "
+                      "bound); waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; one rocprofv3 --pmc pass of this workload spawned by bench.py")
     except Exception as e:                                          # noqa: BLE001 -- reported, never fatal
         return None, "pmc pass failed: %r" % (e,)
 
@@ -330,6 +337,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prepass', action='store_true', help='skip the pre-pass / host-inclusive extras')
     ap.add_argument('--no-variants', action='store_true')
+    ap.add_argument('--more-variants', action='store_true', help='further host-inclusive variants (slot sizes, buffer layouts)')
     ap.add_argument('--no-traffic', action='store_true')
     ap.add_argument('--cpu-sample-drops', type=int, default=2048)
     ap.add_argument('--pipe-batch', type=int, default=128, help='frames per slot of the host-inclusive pipeline (the driver\'s default batch)')
@@ -622,10 +630,12 @@ def main():
         extras["host_inclusive"] = hi
         if not args.no_variants:
             extras["host_inclusive_variants"] = {"slots_of_32": host_inclusive(min(32, batch.n)),
-                                                 "slots_of_64": host_inclusive(min(64, batch.n)),
-                                                 "copy_kernels": host_inclusive(PB, copy_kernels=True),
-                                                 "separate_allocations": host_inclusive(PB, packed=False),
-                                                 "descriptors_rebuilt": host_inclusive(PB, prepared=False)}
+                                                 "slots_of_256": host_inclusive(min(256, batch.n)),
+                                                 "copy_kernels": host_inclusive(PB, copy_kernels=True)}
+            if args.more_variants:
+                extras["host_inclusive_variants"].update({"slots_of_64": host_inclusive(min(64, batch.n)),
+                                                          "separate_allocations": host_inclusive(PB, packed=False),
+                                                          "descriptors_rebuilt": host_inclusive(PB, prepared=False)})
         warm(render, 1)
 
     if rank == 0:
@@ -669,7 +679,8 @@ def main():
                       "frac_of_hbm_peak": alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernels_ms_per_call": {k: v for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
             "valu": {"what": valu_how, "dominant_kernel": (valu or {}).get(dom_name, {}).get("valu_util") if valu else None,
-                     "per_kernel": {k: round(v["valu_util"], 4) for k, v in sorted((valu or {}).items(), key=lambda kv: -kv[1]["valu_util"])} if valu else None},
+                     "per_kernel": {k: {"valu_util": round(v["valu_util"], 4), "waiting": round(v["waiting"], 4) if v["waiting"] is not None else None}
+                                    for k, v in sorted((valu or {}).items(), key=lambda kv: -kv[1]["valu_util"])} if valu else None},
         }
         out.update(extras)
         if not args.no_cpu_baseline and single and not strong and not is_sim:

@@ -1208,8 +1208,9 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ double s_buf[BUF_MAX];
   __shared__ double s_can[4][CAN_W];
   __shared__ int4 s_row[4][ROWS_W];
-  s_lut[t] = (double)t / 255.0;
   const int n_items = sc.counts[f * 8 + 0];
+  if ((int)blockIdx.x >= n_items) return;                                // (before the division table: most frames have few tiles left after k_dedup)
+  s_lut[t] = (double)t / 255.0;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the rot-fast list
   const int64_t gi = (int64_t)f * max_drops + sc.list_rot[(int64_t)f * max_drops + item];
   __syncthreads();
@@ -3098,6 +3099,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   sc.blur_by = ctx->blur_wg == 5 ? 1600 : 2048;
   // One in-order stream: FOV spans -> plan -> scan -> dedup -> lists -> FOV sums -> colour -> tiles -> blur ->
   // composite -> finalise.
+  // Work-list kernels take their items grid-stride, the list lengths only exist on the device: with many frames per call
+  // a per-frame grid sized for the worst case is mostly workgroups that find nothing to do (hundreds of thousands of
+  // them per launch) -- the per-frame grid shrinks as the batch grows, keeping >= 16 K workgroups in flight overall.
+  auto grid_cap = [&](int single_frame) { return imax(64, imin(single_frame, 16384 / n)); };
   if (max_drops > 0) {
     const bool fast = fov_fast_path(ctx, dm);
     const int Hp = ctx->scratch_hp, Dp = (D + 1 + 7) & ~7;
@@ -3189,7 +3194,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_tile");
       // after de-duplication a frame keeps a fraction of its tiles: a capped grid (items are taken
       // grid-stride) avoids dispatching tens of thousands of empty workgroups
-      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, 1536), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, grid_cap(1536)), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
                          ctx->d_tex_off, sc);
     }
     {
@@ -3198,12 +3203,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_small");
-      hipLaunchKernelGGL(k_blur_small, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur_small, dim3(imin((max_drops + 3) / 4, grid_cap(2048)), n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_fused");
       const size_t lds = sizeof(double) * (size_t)(2 * (BR_MAX + 1) + sc.blur_bx + sc.blur_by);
-      const dim3 grid((max_drops + 1) / 2, n);
+      const dim3 grid(imin((max_drops + 1) / 2, grid_cap(4096)), n);
       if (ctx->blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else if (ctx->blur_wg == 5) hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else hipLaunchKernelGGL(k_blur_fused<4>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
