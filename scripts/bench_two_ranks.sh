@@ -4,7 +4,7 @@
 # Checks the launch line the driver uses, the streak-DB broadcast, the barrier + max-over-ranks timing and that the
 # two ranks of a strong-scaling run cover the sequence exactly once.  The numbers are NOT scaling results (one GPU).
 # Usage: scripts/bench_two_ranks.sh [tag]   -> gpurun_out/two_ranks_<tag>.log
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd $REPO

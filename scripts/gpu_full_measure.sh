@@ -1,23 +1,43 @@
 #!/bin/bash
-# One GPU call that re-measures everything a round reports (run via gpurun, ~12 min of box time):
-#   1. pytest -m gpu                          -> gpurun_out/<tag>_tests.log
-#   2. python bench.py (default: the JSON line with roofline / cpu_baseline / variants / host-inclusive)
-#                                             -> gpurun_out/<tag>_bench.json
-#   3. rocprofv3 kernel stats + PMC passes (scripts/gpu_pmc.sh; FETCH_SIZE and WRITE_SIZE in passes of their own)
-#                                             -> gpurun_out/pmc_<tag>/, gpurun_out/pmc_<tag>.txt
-#   4. driver end to end (PNG in -> PNG out)  -> gpurun_out/<tag>_e2e.json
-#   5. two ranks on the one GPU (gloo)        -> gpurun_out/two_ranks_<tag>.log
-# Every step runs under its own timeout; a step that fails does not stop the next.
-# Usage: scripts/gpu_full_measure.sh <tag>
-TAG=${1:-full}
+# Re-measures what a round reports, in two GPU calls (run via gpurun; every step under its own timeout, a failing step does
+# not stop the next).  Results land in gpurun_out/; copy what is to be judged into profiles/.
+#   scripts/gpu_full_measure.sh <tag> a     (~12 min of box time)
+#     1. pytest -m gpu                                          -> <tag>_gpu_tests.log
+#     2. python bench.py (the driver's line: roofline, valu, cpu_baseline, variants, host-inclusive pipeline, pre-pass)
+#                                                               -> <tag>_bench_default.json
+#     3. rocprofv3 kernel stats + PMC passes (scripts/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in passes of their own,
+#        VALU / wait / LDS / L2 counters)                       -> pmc_<tag>/summary.json, pmc_<tag>.txt
+#   scripts/gpu_full_measure.sh <tag> b     (~12 min)
+#     4. one lean bench line per other BASELINE configuration   -> <tag>_bench_<workload>.json
+#     5. driver end to end (PNG in -> PNG out, main.py)         -> <tag>_e2e.json
+#     6. two ranks on the one GPU (gloo): the N>1 launch line   -> two_ranks_<tag>.log
+#     7. host CPU scaling probe (deflate threads)               -> <tag>_cpuscale.txt
+TAG=${1:-full}; PART=${2:-a}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd $REPO
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_tests.log 2>&1; echo "tests exit $?"; tail -3 $OUT/${TAG}_tests.log
-timeout -k 10 600 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench exit $?"; tail -c 400 $OUT/${TAG}_bench.json
-timeout -k 10 900 scripts/gpu_pmc.sh $TAG "" "FETCH_SIZE" "WRITE_SIZE" \
-  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" \
-  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-  "TCC_HIT_sum TCC_MISS_sum" > $OUT/pmc_$TAG.txt 2>&1; echo "pmc exit $?"; head -25 $OUT/pmc_$TAG.txt
-timeout -k 10 300 python scripts/driver_e2e.py --frames 512 2> $OUT/${TAG}_e2e.err | tail -1 > $OUT/${TAG}_e2e.json; echo "e2e exit $?"; cat $OUT/${TAG}_e2e.json
-timeout -k 10 400 scripts/bench_two_ranks.sh $TAG; echo "two ranks exit $?"
+if [ "$PART" = "a" ]; then
+  timeout -k 10 1200 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_tests.log 2>&1; echo "tests exit $?"; tail -3 $OUT/${TAG}_gpu_tests.log
+  timeout -k 10 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; echo "bench exit $?"; tail -c 300 $OUT/${TAG}_bench_default.json
+  timeout -k 10 1500 scripts/gpu_pmc.sh $TAG "" "FETCH_SIZE" "WRITE_SIZE" \
+    "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
+    "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
+    "TCC_HIT_sum TCC_MISS_sum" > $OUT/pmc_$TAG.txt 2>&1; echo "pmc exit $?"; grep -A12 "== pmc" $OUT/pmc_$TAG.txt | cut -c1-300
+else
+  LEAN="--steps 5 --warmup 2 --no-cpu-baseline --no-prepass --no-variants --no-traffic"
+  for WL in "kitti25 128" "cityscapes50 32" "cityscapes50_rs2 128" "nuscenes1 64" "nuscenes5 64" "nuscenes25 64" "nuscenes100 64" "nuscenes200 64" "nuscenes200x 64"; do
+    set -- $WL
+    timeout -k 10 400 python bench.py --workload $1 --batch $2 $LEAN > $OUT/${TAG}_bench_$1.json 2> $OUT/${TAG}_bench_$1.err; echo "$1 exit $?"
+    python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/${TAG}_bench_$1.json"))
+    print("  ", round(d["value"], 1), "frames/s,", round(d["ms_per_step"], 2), "ms/step of", d["config"]["frames_per_call"], "frames; dominant", d["roofline"]["kernel"], round(d["roofline"]["avg_launch_ms"], 2), "ms, frac", round(d["roofline"]["frac"], 3))
+except Exception as e:
+    print("   parse failed", e)
+PY
+  done
+  timeout -k 10 400 python scripts/driver_e2e.py --frames 1024 --batch 128 2> $OUT/${TAG}_e2e.err | tail -1 > $OUT/${TAG}_e2e.json; echo "e2e exit $?"; cut -c1-600 $OUT/${TAG}_e2e.json
+  timeout -k 10 500 scripts/bench_two_ranks.sh $TAG; echo "two ranks exit $?"
+  timeout -k 10 120 python scripts/cpuscale_probe.py > $OUT/${TAG}_cpuscale.txt 2>&1; cat $OUT/${TAG}_cpuscale.txt
+fi
