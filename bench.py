@@ -607,7 +607,7 @@ def main():
                         submit(s_)
                 return done
             pipe(nslot)                                   # warm-up: staging buffers, arena
-            rounds = max(2 * nslot, (512 + PB - 1) // PB)  # >= 512 frames
+            rounds = max(4 * nslot, (2048 + PB - 1) // PB)  # >= 12 batches and >= 2048 frames: the ramp-up of the three slots is a small part
             h0 = time.perf_counter()
             done = pipe(rounds)
             h1 = time.perf_counter()
