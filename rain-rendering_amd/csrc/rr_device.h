@@ -598,24 +598,37 @@ RR_HD void colour_from_sums(const double S[4], double sum_omega, double ambient,
 // ---------------------------------------------------------------------------
 // per-drop plan  (generator.py:119-174, bad_weather.py:286-329,416-427)
 // ---------------------------------------------------------------------------
+// Gaussian elimination with partial pivoting, the operations of oracle/cvlike.py solve8 in their order.  Every index is a
+// compile-time constant once the loops are unrolled (the pivot row is swapped in by comparing each candidate's number
+// with the pivot's, not by indexing with it): on the GPU the 8 x 8 system then lives in registers instead of scratch
+// memory -- k_plan's dynamically indexed private arrays were 5 GB of scratch traffic per launch.
 RR_HD void solve8(double A[8][8], double b[8], double x[8]) {   // oracle/cvlike.py solve8
+#pragma unroll
   for (int col = 0; col < 8; col++) {
     int piv = col;
     double best = fabs(A[col][col]);
+#pragma unroll
     for (int r = col + 1; r < 8; r++)
       if (fabs(A[r][col]) > best) { best = fabs(A[r][col]); piv = r; }
-    if (piv != col) {
-      for (int c = 0; c < 8; c++) { double t = A[col][c]; A[col][c] = A[piv][c]; A[piv][c] = t; }
-      double t = b[col]; b[col] = b[piv]; b[piv] = t;
-    }
+#pragma unroll
+    for (int r = col + 1; r < 8; r++)
+      if (r == piv) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) { double t = A[col][c]; A[col][c] = A[r][c]; A[r][c] = t; }
+        double t = b[col]; b[col] = b[r]; b[r] = t;
+      }
+#pragma unroll
     for (int r = col + 1; r < 8; r++) {
       double f = A[r][col] / A[col][col];
+#pragma unroll
       for (int c = col + 1; c < 8; c++) A[r][c] = A[r][c] - f * A[col][c];
       b[r] = b[r] - f * b[col];
     }
   }
+#pragma unroll
   for (int r = 7; r >= 0; r--) {
     double s = b[r];
+#pragma unroll
     for (int c = r + 1; c < 8; c++) s = s - A[r][c] * x[c];
     x[r] = s / A[r][r];
   }
@@ -693,8 +706,11 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
     dst[2][0] = (float)(((double)(d.x1 - minx) + d1) + 0.001); dst[2][1] = (float)(d.y1 - miny);
     dst[3][0] = (float)((double)(d.x1 - minx) + 0.001);      dst[3][1] = (float)(d.y1 - miny);
     double A[8][8], bb[8], xx[8];
+#pragma unroll
     for (int i = 0; i < 8; i++)
+#pragma unroll
       for (int j = 0; j < 8; j++) A[i][j] = 0.0;
+#pragma unroll
     for (int i = 0; i < 4; i++) {
       double sx = src[i][0], sy = src[i][1], ddx = dst[i][0], ddy = dst[i][1];
       A[i][0] = A[i + 4][3] = sx;
