@@ -121,6 +121,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* list_small;              // [frame][drops]  blurred drops handled one wave each (k_blur_small)
   double* colpart;                  // [frame][COL_PARTS][5][drops] FOV partial sums per envmap row band
   double* wtab;                     // [frame][drops][2][BR_MAX+1] normalised Gaussian half tables of the blurred drops (k_blur_weights)
+  double* wtab_big;                 // [frame][SLOW_CAP][2][MAX_R+1] the same for the first SLOW_CAP large-radius drops of a frame (k_blur_big_weights)
   uint32_t* spans;                  // [frame][Hp / 4][Dp][4] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4,
                                     // Dp = drops + 1 rounded up to 8; slot `drops` of every quad stays all zeros: what a drop
                                     // without a polygon reads
@@ -342,11 +343,22 @@ __device__ inline uint32_t raw_tile_hash(const DropPlan& p) {
   h ^= h >> 15;
   return h;
 }
-__global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_drops, int n_frames, int enable, Scratch sc) {
-  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= frames[f].n_drops) return;
+// (The workgroup's 128 plans come in as whole lines through LDS: a thread reading its own 312-byte record field by field
+//  touches a different line with every lane of every load -- six times the payload between L1 and L2.)
+__global__ __launch_bounds__(128) void k_dedup(const FrameDesc* frames, int max_drops, int n_frames, int enable, Scratch sc) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_plan[128 * PLAN_DW];
+  const int f = blockIdx.y, i0 = blockIdx.x * 128, i = i0 + (int)threadIdx.x;
+  const int n = frames[f].n_drops;
+  if (i0 >= n) return;
+  {
+    const int cnt = imin(128, n - i0);
+    const global_ptr<const uint32_t> src = as_global(reinterpret_cast<const uint32_t*>(sc.plan + (int64_t)f * max_drops + i0));
+    for (int k = threadIdx.x; k < cnt * PLAN_DW; k += 128) s_plan[k] = src[k];
+  }
+  __syncthreads();
+  if (i >= n) return;
   const int gi = f * max_drops + i;
-  DropPlan& p = sc.plan[gi];
+  const DropPlan& p = *reinterpret_cast<const DropPlan*>(s_plan + threadIdx.x * PLAN_DW);
   int canon = gi;
   if (enable && p.status == RR_DROP_OK && sc.sizes[gi] != 0 && p.kind != KIND_EXT) {
     const uint32_t cap = 2u * (uint32_t)n_frames * (uint32_t)max_drops;
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_
       }
       h = h + 1 == cap ? 0 : h + 1;
     }
-    if (canon != gi) p.a0_off = sc.plan[canon].a0_off;    // an elected drop never changes its own offset
+    if (canon != gi) sc.plan[gi].a0_off = sc.plan[canon].a0_off;    // an elected drop never changes its own offset
   }
   sc.canon[gi] = canon;
   // the frame's duplicate counter (a diagnostic): one atomic per wave -- one per drop is a chain of thousands of
@@ -1830,6 +1842,26 @@ __device__ inline void visit_taps(int a0, int a1, int b0, int b1, int r, F f) {
   for (int ii = b0; ii <= b1; ii++) f(ii);
 }
 
+// Both Gaussian half tables of a large-radius drop, once per drop (a table is up to 417 exponentials and a sequential
+// normalisation sum: rebuilt by each of a drop's 128 work units it was 40 % of the large-radius blur)
+constexpr int SLOW_CAP = 256;       // large-radius drops per frame whose tables are kept (the rest build their own)
+__global__ __launch_bounds__(256) void k_blur_big_weights(const FrameDesc* frames, int max_drops, Scratch sc) {
+  const int f = blockIdx.y;
+  __shared__ double hw[MAX_R + 1];
+  const int n_items = imin(sc.counts[f * 8 + 3], SLOW_CAP);
+  for (int w = blockIdx.x; w < 2 * n_items; w += gridDim.x) {
+    const int it = w >> 1, axis = w & 1;
+    const DropPlan& p = sc.plan[(int64_t)f * max_drops + sc.list_slow[(int64_t)f * max_drops + it]];
+    const int r = axis ? p.r2 : p.r1;
+    __syncthreads();
+    if (r > 0) {
+      gauss_half_table(axis ? p.sig2 : p.sig1, r, hw);
+      double* o = sc.wtab_big + (((int64_t)f * SLOW_CAP + it) * 2 + axis) * (MAX_R + 1);
+      for (int k = threadIdx.x; k <= r; k += 256) o[k] = hw[k];
+    }
+  }
+}
+
 template <int AXIS>
 __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_drops, Scratch sc) {
   const int f = blockIdx.y, t = threadIdx.x;
@@ -1849,7 +1881,15 @@ __global__ __launch_bounds__(256) void k_blur(const FrameDesc* frames, int max_d
     double* tmp = fin + (((int64_t)p.epitch * eh + 15) & ~15LL);   // scratch reserved by k_plan for slow drops: eh x tw
     __syncthreads();
     if (cur != it) {
-      if (r > 0) gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
+      if (r > 0) {
+        if (it < SLOW_CAP) {                               // made once per drop by k_blur_big_weights
+          const double* wt = sc.wtab_big + (((int64_t)f * SLOW_CAP + it) * 2 + AXIS) * (MAX_R + 1);
+          for (int k = t; k <= r; k += 256) hw[k] = wt[k];
+          __syncthreads();
+        } else {
+          gauss_half_table(AXIS == 0 ? p.sig1 : p.sig2, r, hw);
+        }
+      }
       cur = it;
     }
     if (AXIS == 0) {
@@ -2945,6 +2985,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.list_small, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.colpart, fd * COL_PARTS * 5))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.wtab, fd * 2 * (BR_MAX + 1)))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.wtab_big, (size_t)F * SLOW_CAP * 2 * (MAX_R + 1)))) return rc;
     if (general) {                     // polygons and the prefix table only exist on the general colour path
       if ((rc = dev_alloc(ctx, ctx->sc.poly, fd * 2 * POLY_STRIDE))) return rc;
       if ((rc = dev_alloc(ctx, ctx->sc.prefix, (size_t)F * dm.He * (size_t)(dm.We + 1) * 4))) return rc;
@@ -3133,7 +3174,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_dedup");
       HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, s));
       HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, s));
-      hipLaunchKernelGGL(k_dedup, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
+      hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
       ProfScope ps(ctx, s, "k_lists");
@@ -3212,6 +3253,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       if (ctx->blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else if (ctx->blur_wg == 5) hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else hipLaunchKernelGGL(k_blur_fused<4>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
+    }
+    {
+      ProfScope ps(ctx, s, "k_blur_big_weights");
+      hipLaunchKernelGGL(k_blur_big_weights, dim3(64, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_rows");
@@ -3503,6 +3548,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.list_small);
   hipFree(ctx->sc.colpart);
   hipFree(ctx->sc.wtab);
+  hipFree(ctx->sc.wtab_big);
   hipFree(ctx->sc.spans);
   hipFree(ctx->sc.bbox);
   hipFree(ctx->sc.clist);
