@@ -130,3 +130,52 @@ def test_png_scanlines_from_the_device(tmp_path, built):
         assert outs[0]['mask'].max() > 0 and outs[1]['mask'].max() == 0
     finally:
         rh.close()
+
+
+@pytest.mark.parametrize("copy_kernels", [0, 1])
+def test_packed_prepared_batches_and_resident_solid_angles(tmp_path, built, copy_kernels):
+    """What the driver does batch after batch: the frames of a slot back to back in ONE page-locked block per array
+    (RainHip.host_rows: the library merges them into one copy per array, padding included), descriptor arrays prepared
+    once per slot (pipeline_prepare / set_drop_count), the solid-angle map resident on the device (omega=None) -- with the
+    DMA engines (RR_OPT_COPY_KERNELS 0, the default) and with the batched copy kernels (1).  Same bits as the plain
+    synchronous call on separate pageable arrays."""
+    H, W, nf = 95, 161, 5                                    # odd sizes: every per-frame stride needs its padding
+    sc = h.Scene(tmp_path, H, W, 160, n_frames=nf, seed0=41)
+    rh = h.hb.RainHip(0)
+    try:
+        rh.set_option(h.hb.RR_OPT_COPY_KERNELS, copy_kernels)
+        rh.set_streak_db(sc.db.streaks_light)
+        rh.set_camera(sc.cam)
+        consts, We = tp._setup(rh, H, W, 25)
+        plain = []
+        for i in range(nf):
+            bg, depth = tp._scene(H, W, 41 + i)
+            plain.append(dict(bg_u8=(bg * 255).astype(np.uint8), depth=depth.astype(np.float32), fog=consts, omega=sc.omega, drops=sc.product_drops(i)))
+        ref = rh.pipeline_frames(plain, want_mask_i32=True)
+        rh.set_solid_angles(sc.omega)
+        cap = (max(len(f['drops']) for f in plain) + 3) // 4 * 4
+        blocks = [rh.host_rows(nf, shp, dt) for shp, dt in (((H, W, 3), np.uint8), ((H, W), np.float32), ((cap,), h.hb.DROP_DTYPE),
+                                                           ((H, W, 3), np.uint8), ((H, W), np.int32), ((cap,), np.int32))]
+        bg8, dep, drs, img, msk, sts = [b[1] for b in blocks]
+        frames = [dict(bg_u8=bg8[i], depth=dep[i], fog=consts, omega=None, drops=drs[i]) for i in range(nf)]
+        outs = [dict(image_u8=img[i], mask_i32=msk[i], status=sts[i]) for i in range(nf)]
+        prep = rh.pipeline_prepare(frames, outs)
+        for rep in range(2):                                  # the same prepared batch twice (second time: frames in reverse roles)
+            order = list(range(nf)) if rep == 0 else list(range(nf))[::-1]
+            for slot_k, i in enumerate(order):
+                bg8[slot_k][...] = plain[i]['bg_u8']
+                dep[slot_k][...] = plain[i]['depth']
+                nd = len(plain[i]['drops'])
+                drs[slot_k][:nd] = plain[i]['drops']
+                prep.set_drop_count(slot_k, nd)
+            rh.pipeline_submit_prepared(2, prep)
+            while not rh.pipeline_wait(2):
+                rh.pipeline_submit_prepared(2, prep)
+            for slot_k, i in enumerate(order):
+                nd = len(plain[i]['drops'])
+                assert np.array_equal(img[slot_k], ref[i]['image_u8']) and np.array_equal(msk[slot_k], ref[i]['mask_i32'])
+                assert np.array_equal(sts[slot_k][:nd], ref[i]['status'])
+        for b in blocks:
+            rh.host_free(b[0])
+    finally:
+        rh.close()
