@@ -323,7 +323,8 @@ enum {
   RR_OPT_COMPOSITE_F64 = 7,
   /* tuning: how the host-pointer entry points move a batch across PCIe.  0 (default): hipMemcpyAsync (the DMA engines),
    * after merging neighbouring pieces -- frames laid out back to back in one rr_host_alloc block, each starting on a
-   * 16-byte boundary, travel as ONE copy per array.  1: the pieces whose host side is page-locked and 16-byte aligned are
+   * 16-byte boundary, travel as ONE copy per array (so a gap of fewer than 16 bytes between two consecutive frames'
+   * arrays of one kind inside such a block is treated as padding: uploads read it, downloads may overwrite it).  1: the pieces whose host side is page-locked and 16-byte aligned are
    * moved by one copy kernel per direction that reads / writes the host memory directly (faster than many small DMA
    * requests -- 90 vs 40 GB/s both ways, scripts/probes/pcie_probe.hip -- but it takes compute units from the rendering
    * kernels it runs beside: measured slower end to end). */
@@ -340,7 +341,8 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 int rr_pipeline_submit(rr_ctx* ctx, int32_t slot, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in,
                        const rr_frame_out* out, const rr_prepass_out* pre_out);
 int rr_pipeline_wait(rr_ctx* ctx, int32_t slot);
-/* Page-locked host memory (hipHostMalloc) for the buffers of the host-pointer entry points. */
+/* Page-locked host memory (hipHostMalloc) for the buffers of the host-pointer entry points.  A block belongs to its
+ * context: rr_destroy releases whatever rr_host_free has not. */
 int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes);
 int rr_host_free(rr_ctx* ctx, void* p);
 
@@ -419,6 +421,10 @@ int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap)
  * zlib stream of known decoded size: 1 = out holds the data (Adler-32 verified), 0 = not vouched for (the readers then
  * hand the stream to zlib), < 0 = bad argument. */
 int rr_inflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len);
+/* The codec's checksums: zlib's adler32(adler, p, n) and crc32(crc, p, n) (same values, same chaining; start from 1 and 0),
+ * computed with SSSE3 / carry-less multiplication where the CPU has them (zlib's own loops otherwise). */
+uint32_t rr_adler32(uint32_t adler, const uint8_t* p, int64_t n);
+uint32_t rr_crc32(uint32_t crc, const uint8_t* p, int64_t n);
 
 /* sizes, for binding self-checks */
 int rr_sizeof_drop(void);

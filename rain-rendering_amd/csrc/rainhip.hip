@@ -3621,6 +3621,7 @@ int rr_destroy(rr_ctx* ctx) {
     hipEventDestroy(pe.b);
   }
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  for (auto& blk : ctx->host_allocs) hipHostFree(const_cast<char*>(blk.first));      // rr_host_alloc blocks the caller kept
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return RR_OK;
@@ -4194,10 +4195,19 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     dout[f].rainy_png = out[f].rainy_png ? st.png_i + (size_t)f * T.pngb : nullptr;
     dout[f].mask_png = out[f].mask_png ? st.png_m + (size_t)f * T.pngb : nullptr;
   }
-  if ((rc = issue(ctx, up, hipMemcpyHostToDevice, ctx->s_up, sl.d_up, sl.h_up, sl.cap_up))) return rc;
-  HIPCHK(hipEventRecord(sl.ev_up, ctx->s_up));
+  // from here on copies that read the caller's buffers are queued: a failing call drains them before it returns (the
+  // caller is free to release its buffers after an error)
+  auto drained = [&](int code) {
+    (void)hipStreamSynchronize(ctx->s_up);
+    (void)hipStreamSynchronize(s);
+    return code;
+  };
+  if ((rc = issue(ctx, up, hipMemcpyHostToDevice, ctx->s_up, sl.d_up, sl.h_up, sl.cap_up))) return drained(rc);
+  if (hipEventRecord(sl.ev_up, ctx->s_up) != hipSuccess || hipStreamWaitEvent(s, sl.ev_up, 0) != hipSuccess) {
+    ctx->err = "pipeline: hipEventRecord / hipStreamWaitEvent failed";
+    return drained(RR_E_HIP);
+  }
   // ---- compute ----
-  HIPCHK(hipStreamWaitEvent(s, sl.ev_up, 0));
   // bg = bytes / 255.0 (generator.py:352) formed on the device: one launch per run of consecutive byte-image frames
   for (int f = 0; pre && f < n;) {
     if (!pre[f].bg_u8) { f++; continue; }
@@ -4207,10 +4217,13 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
                        st.bg + f * T.px3d, (int64_t)(px * 3), (int64_t)T.px3b, (int64_t)T.px3d);
     f = g;
   }
-  if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return rc;
-  if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, drop_stride, st.ndrops, s))) return rc;
-  if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return rc;
-  HIPCHK(hipEventRecord(sl.ev_comp, s));
+  if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return drained(rc);
+  if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, drop_stride, st.ndrops, s))) return drained(rc);
+  if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return drained(rc);
+  if (hipEventRecord(sl.ev_comp, s) != hipSuccess) {
+    ctx->err = "pipeline: hipEventRecord failed";
+    return drained(RR_E_HIP);
+  }
   // ---- download: only the LIST is made here.  The copies are issued by rr_pipeline_wait once the kernels have finished:
   // a device-to-host copy queued now would sit in the DMA queue waiting for its kernels -- and hold up the NEXT batch's
   // upload queued behind it (measured: the GPU then idles for the length of an upload between two batches).
@@ -4252,7 +4265,11 @@ int host_wait(rr_ctx* ctx, int slot) {
     down.v = std::move(sl.down);
     sl.down.clear();
     int rc = issue(ctx, down, hipMemcpyDeviceToHost, ctx->s_down, sl.d_down, sl.h_down, sl.cap_down);
-    if (rc) return rc;
+    if (rc) {                                            // (nothing may keep writing the caller's buffers after an error)
+      (void)hipStreamSynchronize(ctx->s_down);
+      sl.busy = false;
+      return rc;
+    }
     if (sl.rendered) HIPCHK(hipMemcpyAsync(&sl.h_flags[0], ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_down));
     HIPCHK(hipStreamSynchronize(ctx->s_down));
   }

@@ -9,6 +9,7 @@
 //                                                          rr_frame_out.rainy_png / mask_png deliver (zlib deflate + framing)
 // Non-interlaced files with colour types gray / RGB / palette / RGBA are decoded; anything else returns
 // RR_E_UNSUPPORTED and the caller uses its general-purpose decoder.  zlib does the (de)compression.
+#include <immintrin.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -75,6 +76,161 @@ int parse_chunks(const std::vector<uint8_t>& f, Png& p, bool want_data) {
   return have_hdr ? RR_OK : RR_E_PARSE;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The two checksums of the format at memory speed.  A frame's files carry ~6 MB through Adler-32 (every zlib stream read
+// or written) and ~1.7 MB through CRC-32 (the IDAT chunks written); zlib's own loops move 3 and 1 GB/s on the driver's
+// hosts -- together 10 % of an I/O thread's time per frame.  Chosen once, by the CPU's feature flags; zlib's functions
+// otherwise.  (tests/test_host_logic.py compares both with zlib on every length and alignment.)
+// ---------------------------------------------------------------------------------------------------------------------
+__attribute__((target("ssse3"))) uint32_t adler32_ssse3(uint32_t adler, const uint8_t* p, size_t n) {
+  uint64_t a = adler & 0xffffu, b = adler >> 16;
+  const __m128i weights = _mm_setr_epi8(16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1);
+  const __m128i ones = _mm_set1_epi16(1), zero = _mm_setzero_si128();
+  while (n >= 16) {
+    // b grows by a for every byte: over a stretch of chunks, 16 * (a at each chunk's start) + the position-weighted bytes.
+    // 5552 bytes keep every 32-bit lane below 2^32 (zlib's NMAX)
+    const size_t blk = (n < 5552 ? n : 5552) & ~(size_t)15;
+    const uint64_t chunks = blk / 16;
+    __m128i va = zero, vprev = zero, vb = zero;
+    for (size_t k = 0; k < blk; k += 16) {
+      const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + k));
+      vprev = _mm_add_epi32(vprev, va);
+      va = _mm_add_epi32(va, _mm_sad_epu8(d, zero));
+      vb = _mm_add_epi32(vb, _mm_madd_epi16(_mm_maddubs_epi16(d, weights), ones));
+    }
+    auto hsum = [](__m128i v) {
+      alignas(16) uint32_t t[4];
+      _mm_store_si128(reinterpret_cast<__m128i*>(t), v);
+      return (uint64_t)t[0] + t[1] + t[2] + t[3];
+    };
+    b = (b + 16 * (a * chunks + hsum(vprev)) + hsum(vb)) % 65521u;
+    a = (a + hsum(va)) % 65521u;
+    p += blk;
+    n -= blk;
+  }
+  for (; n; n--) {
+    a += *p++;
+    b += a;
+  }
+  return (uint32_t)(((b % 65521u) << 16) | (a % 65521u));
+}
+
+// CRC-32 (the reflected 0xEDB88320 polynomial) by carry-less multiplication: four 128-bit lanes folded 64 bytes at a time,
+// then 128 -> 64 -> 32 bits with a Barrett reduction (Gopal et al., "Fast CRC computation for generic polynomials using
+// PCLMULQDQ", Intel 2009; the constants are x^k mod P for the fold distances).  `crc` and the result are the register's
+// inner value (the caller applies the format's initial / final inversion); n >= 64 and a multiple of 16.
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_fold_pclmul(uint32_t crc, const uint8_t* buf, size_t n) {
+  alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+  alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+  alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+  alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+  auto ld = [](const void* q) { return _mm_loadu_si128(reinterpret_cast<const __m128i*>(q)); };
+  __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+  x1 = ld(buf);
+  x2 = ld(buf + 16);
+  x3 = ld(buf + 32);
+  x4 = ld(buf + 48);
+  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+  x0 = _mm_load_si128(reinterpret_cast<const __m128i*>(k1k2));
+  buf += 64;
+  n -= 64;
+  while (n >= 64) {
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+    x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+    x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+    x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+    y5 = ld(buf);
+    y6 = ld(buf + 16);
+    y7 = ld(buf + 32);
+    y8 = ld(buf + 48);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
+    x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+    x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
+    x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+    buf += 64;
+    n -= 64;
+  }
+  x0 = _mm_load_si128(reinterpret_cast<const __m128i*>(k3k4));                // four lanes into one
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+  while (n >= 16) {
+    x2 = ld(buf);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    buf += 16;
+    n -= 16;
+  }
+  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);                                     // 128 -> 64 bits
+  x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+  x1 = _mm_srli_si128(x1, 8);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(k5k0));
+  x2 = _mm_srli_si128(x1, 4);
+  x1 = _mm_and_si128(x1, x3);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_load_si128(reinterpret_cast<const __m128i*>(poly));                 // Barrett: 64 -> 32 bits
+  x2 = _mm_and_si128(x1, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+  x2 = _mm_and_si128(x2, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+
+struct CpuFeatures {
+  bool ssse3, pclmul;
+  CpuFeatures() {
+    __builtin_cpu_init();
+    ssse3 = __builtin_cpu_supports("ssse3");
+    pclmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+  }
+};
+const CpuFeatures& cpu() {
+  static const CpuFeatures f;
+  return f;
+}
+
+// zlib's adler32(1, p, n) continued from `adler`
+uint32_t fast_adler32(uint32_t adler, const uint8_t* p, size_t n) {
+  if (cpu().ssse3) return adler32_ssse3(adler, p, n);
+  while (n > 0) {                                    // (uInt lengths)
+    const size_t part = n < (1u << 30) ? n : (1u << 30);
+    adler = (uint32_t)adler32(adler, p, (uInt)part);
+    p += part;
+    n -= part;
+  }
+  return adler;
+}
+// zlib's crc32(crc, p, n)
+uint32_t fast_crc32(uint32_t crc, const uint8_t* p, size_t n) {
+  if (cpu().pclmul && n >= 64) {
+    const size_t body = n & ~(size_t)15;
+    crc = ~crc32_fold_pclmul(~crc, p, body);
+    p += body;
+    n -= body;
+  }
+  while (n > 0) {
+    const size_t part = n < (1u << 30) ? n : (1u << 30);
+    crc = (uint32_t)crc32(crc, p, (uInt)part);
+    p += part;
+    n -= part;
+  }
+  return crc;
+}
+
 int channels_of(int ctype) { return ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0; }
 
 inline int paeth(int a, int b, int c) {
@@ -85,17 +241,17 @@ inline int paeth(int a, int b, int c) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Fast inflate of a complete zlib stream into a buffer of known size (the reader always knows it: h * (stride + 1)).
 // zlib's inflate moves ~190 MB/s here; the image of a frame (1.4 MB of scanlines) costs 7-8 ms of the I/O thread that
-// reads it.  This decoder keeps 64 bits of input in a register, resolves a symbol with one look-up in a 10-bit (literal /
-// length) or 8-bit (distance) table (longer codes: one more look-up in a sub-table) and copies matches eight bytes at a
-// time.  It accepts every valid stream (stored, fixed and dynamic blocks); anything it cannot vouch for -- a malformed
+// reads it.  This decoder keeps 64 bits of input in a register, resolves a symbol with one look-up in a 12-bit (literal /
+// length; two literals per entry where both codes fit) or 8-bit (distance) table (longer codes: one more look-up in a
+// sub-table) and copies matches eight bytes at a time.  It accepts every valid stream (stored, fixed and dynamic blocks); anything it cannot vouch for -- a malformed
 // header or code, output or input that does not end where it must, a wrong Adler-32 -- makes it return false, and the
 // caller hands the stream to zlib.  `in` must be readable for 16 bytes past n (the caller pads), `out` for 16 past out_len.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace inflate_fast {
 
-constexpr int LBITS = 10, DBITS = 8;
+constexpr int LBITS = 12, DBITS = 8;
 constexpr int LSIZE = (1 << LBITS) + 1400, DSIZE = (1 << DBITS) + 700;
-enum { K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4 };
+enum { K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4, K_LIT2 = 5 };
 inline uint32_t mk(int kind, int value, int ebits, int nbits) {
   return ((uint32_t)value << 16) | ((uint32_t)kind << 13) | ((uint32_t)ebits << 8) | (uint32_t)nbits;
 }
@@ -173,6 +329,25 @@ bool build(const uint8_t* len, int nsym, bool is_dist, int tbits, uint32_t* tab,
   return true;
 }
 
+// Two literals per look-up: where a primary entry is a literal of l1 bits and the remaining tbits - l1 index bits hold a
+// complete second literal code, the entry becomes the PAIR (value = first | second << 8, length = both).  Table-driven
+// decoding is one dependent chain per symbol (mask, load, shift: ~7 cycles); image rows are nearly all literals of 4-8
+// bits, so most look-ups of such a stream then yield two bytes.  One pass over the primary table per block.
+void pair_literals(uint32_t* tab, int tbits) {
+  const int psize = 1 << tbits;
+  uint32_t single[1 << LBITS];
+  memcpy(single, tab, sizeof(uint32_t) * (size_t)psize);
+  for (int idx = 0; idx < psize; idx++) {
+    const uint32_t e1 = single[idx];
+    if (((e1 >> 13) & 7) != K_LIT) continue;
+    const int l1 = (int)(e1 & 255), rest = tbits - l1;
+    if (rest < 1) continue;
+    const uint32_t e2 = single[idx >> l1];            // (the unknown bits above `rest` read as zeros: irrelevant for a code that fits)
+    if (((e2 >> 13) & 7) != K_LIT || (int)(e2 & 255) > rest) continue;
+    tab[idx] = mk(K_LIT2, (int)((e1 >> 16) | ((e2 >> 16) << 8)), 0, l1 + (int)(e2 & 255));
+  }
+}
+
 struct Tables {
   uint32_t lt[LSIZE], dt[DSIZE];
 };
@@ -189,6 +364,7 @@ const Tables* fixed_tables() {                          // the fixed code of RFC
       for (int i = 280; i < 288; i++) l[i] = 8;
       for (int i = 0; i < 32; i++) d[i] = 5;
       ok = build(l, 288, false, LBITS, t.lt, LSIZE) && build(d, 32, true, DBITS, t.dt, DSIZE);
+      if (ok) pair_literals(t.lt, LBITS);
     }
   };
   static const Holder h;
@@ -289,6 +465,7 @@ bool inflate(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
         }
         if (lens[256] == 0) return false;               // no end-of-block code
         if (!build(lens, hlit, false, LBITS, dyn->lt, LSIZE) || !build(lens + hlit, hdist, true, DBITS, dyn->dt, DSIZE)) return false;
+        pair_literals(dyn->lt, LBITS);
         T = dyn.get();
       }
       const uint32_t* lt = T->lt;
@@ -306,21 +483,34 @@ bool inflate(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
         }
         bb >>= (e & 255);
         bc -= (int)(e & 255);
-        if (kind == K_LIT) {
-          if (op >= oend) return false;
-          *op++ = (uint8_t)(e >> 16);
-          // a second and third literal from the bits already loaded (>= 56 - 15 left after the first)
-          uint32_t e2 = lt[bb & ((1u << LBITS) - 1)];
-          if (((e2 >> 13) & 7) == K_LIT && op < oend) {
+        if (kind == K_LIT || kind == K_LIT2) {
+          // one or two literals -- then up to three more look-ups in the primary table from the bits already loaded
+          // (>= 56 - 15 left after the first, <= LBITS = 12 per look-up)
+          if (kind == K_LIT) {
+            if (op >= oend) return false;
+            *op++ = (uint8_t)(e >> 16);
+          } else {
+            if (op + 2 > oend) return false;
+            const uint16_t two = (uint16_t)(e >> 16);
+            memcpy(op, &two, 2);                          // (little-endian host: first literal first)
+            op += 2;
+          }
+          for (int more = 0; more < 3; more++) {
+            const uint32_t e2 = lt[bb & ((1u << LBITS) - 1)];
+            const int k2 = (int)((e2 >> 13) & 7);
+            if (k2 == K_LIT) {
+              if (op >= oend) break;
+              *op++ = (uint8_t)(e2 >> 16);
+            } else if (k2 == K_LIT2) {
+              if (op + 2 > oend) break;
+              const uint16_t two = (uint16_t)(e2 >> 16);
+              memcpy(op, &two, 2);
+              op += 2;
+            } else {
+              break;
+            }
             bb >>= (e2 & 255);
             bc -= (int)(e2 & 255);
-            *op++ = (uint8_t)(e2 >> 16);
-            e2 = lt[bb & ((1u << LBITS) - 1)];
-            if (((e2 >> 13) & 7) == K_LIT && op < oend) {
-              bb >>= (e2 & 255);
-              bc -= (int)(e2 & 255);
-              *op++ = (uint8_t)(e2 >> 16);
-            }
           }
           continue;
         }
@@ -366,30 +556,49 @@ bool inflate(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
   ip -= bc >> 3;
   if (ip != iend) return false;
   const uint32_t want = ((uint32_t)iend[0] << 24) | ((uint32_t)iend[1] << 16) | ((uint32_t)iend[2] << 8) | iend[3];
-  return (uint32_t)adler32(adler32(0L, Z_NULL, 0), out, (uInt)out_len) == want;
+  return fast_adler32(1u, out, out_len) == want;
 }
 
 }  // namespace inflate_fast
 
-// Paeth rows after their first pixel (BPP = bytes per pixel: 1, 2, 3, 4, 6 or 8)
+// Paeth rows after their first pixel (BPP = bytes per pixel: 1, 2, 3, 4, 6 or 8).  The channels of a pixel sit in the
+// 16-bit lanes of one SSE2 register: the three distances, the choice (a on ties, then b: min + compare, no branches --
+// on image data the three-way choice is unpredictable) and the sum are a dozen vector operations per PIXEL instead of per
+// byte, one dependent chain through `a`.  Loads and stores move 4 (BPP <= 4) or 8 bytes: up to 3 / 2 bytes beyond the
+// pixel are read (the rows' own following bytes) and written (overwritten by the next pixel; the caller's buffers have 16
+// spare bytes behind the last row).
 template <int BPP>
 void paeth_row(uint8_t* cur, const uint8_t* src, const uint8_t* up, size_t stride) {
-  int a[BPP], c[BPP];
-  for (int k = 0; k < BPP; k++) { a[k] = cur[k]; c[k] = up[k]; }
+  const __m128i zero = _mm_setzero_si128();
+  auto load = [&](const uint8_t* q) {
+    if (BPP <= 4) {
+      uint32_t w;
+      memcpy(&w, q, 4);
+      return _mm_unpacklo_epi8(_mm_cvtsi32_si128((int)w), zero);
+    }
+    return _mm_unpacklo_epi8(_mm_loadl_epi64(reinterpret_cast<const __m128i*>(q)), zero);
+  };
+  __m128i a = load(cur), c = load(up);               // the first pixel: left / upper-left neighbours of the second
   size_t i = BPP;
   for (; i + BPP <= stride; i += BPP) {
-#pragma GCC unroll 8
-    for (int k = 0; k < BPP; k++) {
-      const int bb = up[i + k];
-      const int d1 = bb - c[k], d2 = a[k] - c[k];
-      const int pa = d1 < 0 ? -d1 : d1, pb = d2 < 0 ? -d2 : d2, pc = (d1 + d2) < 0 ? -(d1 + d2) : (d1 + d2);
-      // (selection by masks: on image data the three-way choice is unpredictable, a branch would miss every few bytes)
-      const int m2 = -(int)(pb <= pc), t1 = (bb & m2) | (c[k] & ~m2);
-      const int m1 = -(int)((pa <= pb) & (pa <= pc)), pred = (a[k] & m1) | (t1 & ~m1);
-      const int v = (uint8_t)(src[i + k] + pred);
-      cur[i + k] = (uint8_t)v;
-      a[k] = v;
-      c[k] = bb;
+    const __m128i bb = load(up + i), d = load(src + i);
+    const __m128i pa_s = _mm_sub_epi16(bb, c), pb_s = _mm_sub_epi16(a, c), pc_s = _mm_add_epi16(pa_s, pb_s);
+    const __m128i pa = _mm_max_epi16(pa_s, _mm_sub_epi16(zero, pa_s));
+    const __m128i pb = _mm_max_epi16(pb_s, _mm_sub_epi16(zero, pb_s));
+    const __m128i pc = _mm_max_epi16(pc_s, _mm_sub_epi16(zero, pc_s));
+    const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+    const __m128i is_a = _mm_cmpeq_epi16(smallest, pa), is_b = _mm_cmpeq_epi16(smallest, pb);
+    // pred = is_a ? a : (is_b ? b : c)
+    const __m128i bc = _mm_or_si128(_mm_and_si128(is_b, bb), _mm_andnot_si128(is_b, c));
+    const __m128i pred = _mm_or_si128(_mm_and_si128(is_a, a), _mm_andnot_si128(is_a, bc));
+    a = _mm_and_si128(_mm_add_epi16(pred, d), _mm_set1_epi16(0xff));
+    c = bb;
+    const __m128i packed = _mm_packus_epi16(a, a);
+    if (BPP <= 4) {
+      const uint32_t w = (uint32_t)_mm_cvtsi128_si32(packed);
+      memcpy(cur + i, &w, 4);
+    } else {
+      _mm_storel_epi64(reinterpret_cast<__m128i*>(cur + i), packed);
     }
   }
 }
@@ -412,8 +621,8 @@ int decode(const Png& p, std::vector<uint8_t>& img, size_t& stride) {
       if (uncompress(raw.data(), &out_len, p.idat.data(), (uLong)p.idat.size()) != Z_OK || out_len != raw_len) return RR_E_PARSE;
     }
   }
-  img.resize(stride * p.h);
-  const std::vector<uint8_t> zero(stride, 0);         // the row above the first one
+  img.resize(stride * p.h + 16);                       // (16 spare bytes: the Paeth rows store whole words)
+  const std::vector<uint8_t> zero(stride + 16, 0);    // the row above the first one (+ the spare bytes word-wise loads may touch)
   for (uint32_t y = 0; y < p.h; y++) {
     const uint8_t* src = &raw[(stride + 1) * y];
     const int ft = src[0];
@@ -591,6 +800,14 @@ struct ByteBuf {                                      // uninitialised storage (
   void reserve_raw(size_t c) { mem.reset(new uint8_t[c]); cap = c; len = 0; }
   uint8_t* data() { return mem.get(); }
 };
+inline uint64_t load64(const uint8_t* p) {
+  uint64_t w;
+  memcpy(&w, p, 8);
+  return w;
+}
+struct Run {                                          // a run of the byte before it: in[pos .. pos + len) == in[pos - 1]
+  uint32_t pos, len;                                  // (pos relative to the block; 3 <= len <= 258)
+};
 void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
   const LenCode* LT = length_table();
   const size_t BLOCK = 128 * 1024;
@@ -600,40 +817,82 @@ void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
   out.data()[0] = 0x78;
   out.data()[1] = 0x01;
   BitWriter bw(out.data() + 2);
-  std::vector<uint16_t> tok(BLOCK);                   // literal: byte value; match: 0x8000 | length (distance is always 1)
+  std::vector<Run> runs(BLOCK / 3 + 2);
   size_t pos = 0;
   if (n == 0) {                                       // one empty stored block
     bw.put(1, 1); bw.put(0, 2); bw.finish();
     bw.put(0xffff0000u, 32);
   }
+  const uint64_t ONES = 0x0101010101010101ull, HIGH = 0x8080808080808080ull;
   while (pos < n) {
     const size_t end = pos + BLOCK < n ? pos + BLOCK : n;
     const bool last = end == n;
-    uint32_t fl[286] = {0}, fl2[256] = {0}, fd[30] = {0};   // (two literal histograms: neighbours often repeat a value)
-    size_t nt = 0;
+    // ---- pass 1: the block's runs (the previous byte repeated >= 3 times, like Z_RLE) and the histogram of what is left.
+    // 64 bytes at a time: byte-wise compares of the chunk with itself one byte earlier give a 64-bit mask of the bytes
+    // that repeat their predecessor; three set bits in a row start a run.  Chunks without one (most chunks of filtered
+    // image rows) are 64 literals.  Eight histograms: neighbours often hold the same value (every fourth byte of an opaque
+    // RGBA row is the same alpha residual), and a counter incremented twice in a row waits for its own store.
+    uint32_t fl[286] = {0}, fd[30] = {0};
+    uint32_t h[8][256];
+    memset(h, 0, sizeof(h));
+    size_t nr = 0;
     size_t i = pos;
     if (i == 0) {                                     // the very first byte has no predecessor
-      tok[nt++] = in[0];
-      fl[in[0]]++;
+      h[0][in[0]]++;
       i = 1;
+    }
+    auto take_run = [&](size_t at) {                  // in[at - 1] == in[at] == in[at + 1] == in[at + 2], at + 2 < end: its length
+      const uint8_t b = in[at];
+      size_t r = 3;
+      const size_t lim = end - at < 258 ? end - at : 258;
+      const uint64_t bb = ONES * b;
+      bool open = true;
+      while (r + 8 <= lim) {
+        const uint64_t v = load64(in + at + r) ^ bb;
+        if (v) {
+          r += (size_t)(__builtin_ctzll(v) >> 3);
+          open = false;
+          break;
+        }
+        r += 8;
+      }
+      while (open && r < lim && in[at + r] == b) r++;
+      runs[nr++] = Run{(uint32_t)(at - pos), (uint32_t)r};
+      fl[LT[r].sym]++;
+      fd[0]++;
+      return r;
+    };
+    while (i + 66 <= end) {
+      uint64_t eq = 0;                                // bit k: in[i + k] == in[i + k - 1]
+      for (int j = 0; j < 4; j++) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in + i + 16 * j));
+        const __m128i p = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in + i + 16 * j - 1));
+        eq |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(a, p)) << (16 * j);
+      }
+      const uint64_t e64 = in[i + 64] == in[i + 63], e65 = in[i + 65] == in[i + 64];
+      uint64_t r3 = eq & ((eq >> 1) | (e64 << 63)) & ((eq >> 2) | (e64 << 62) | (e65 << 63));
+      size_t cur = 0;
+      while (r3) {
+        const size_t k = (size_t)__builtin_ctzll(r3);
+        for (size_t j = cur; j < k; j++) h[j & 7][in[i + j]]++;
+        cur = k + take_run(i + k);
+        if (cur >= 64) break;
+        r3 &= ~0ull << cur;
+      }
+      if (cur >= 64) {
+        i += cur;
+        continue;
+      }
+      const uint8_t* c = in + i;
+      for (size_t j = cur; j < 64; j++) h[j & 7][c[j]]++;
+      i += 64;
     }
     while (i < end) {
       const uint8_t b = in[i];
-      if (b == in[i - 1] && i + 2 < end && in[i + 1] == b && in[i + 2] == b) {   // a run of the previous byte, >= 3 long
-        size_t r = 3;
-        const size_t lim = end - i < 258 ? end - i : 258;
-        while (r < lim && in[i + r] == b) r++;
-        tok[nt++] = (uint16_t)(0x8000u | (uint32_t)r);
-        fl[LT[r].sym]++;
-        fd[0]++;
-        i += r;
-      } else {
-        tok[nt++] = b;
-        if (nt & 1) fl[b]++; else fl2[b]++;
-        i++;
-      }
+      if (b == in[i - 1] && i + 2 < end && in[i + 1] == b && in[i + 2] == b) i += take_run(i);
+      else h[i++ & 7][b]++;
     }
-    for (int k = 0; k < 256; k++) fl[k] += fl2[k];
+    for (int k = 0; k < 256; k++) fl[k] = (h[0][k] + h[1][k]) + (h[2][k] + h[3][k]) + ((h[4][k] + h[5][k]) + (h[6][k] + h[7][k]));
     fl[256] = 1;                                      // end of block
     if (!fd[0]) fd[0] = 1;                            // a distance code must exist
     uint8_t ll[286], dl[30];
@@ -664,26 +923,29 @@ void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
     for (int k = 0; k < ncl; k++) bw.put(cl[order[k]], 3);
     for (int k = 0; k < nlit; k++) bw.put(cc[ll[k]], cl[ll[k]]);
     for (int k = 0; k < ndist; k++) bw.put(cc[dl[k]], cl[dl[k]]);
-    // literals: code and length in one table entry; a match: length symbol + extra bits + the distance code, pre-merged
+    // ---- pass 2: the literals between two runs straight from the input, four per store (code and length in one table
+    // entry); a run: length symbol + extra bits + the distance code, pre-merged
     uint32_t lit[256];
     for (int k = 0; k < 256; k++) lit[k] = (uint32_t)lc[k] | ((uint32_t)ll[k] << 16);
-    size_t k = 0;
-    while (k < nt) {
-      if (k + 4 <= nt && (uint32_t)(tok[k] | tok[k + 1] | tok[k + 2] | tok[k + 3]) < 256u) {   // four literals, one store
-        const uint32_t a = lit[tok[k]], b = lit[tok[k + 1]], c = lit[tok[k + 2]], d = lit[tok[k + 3]];
+    const uint8_t* q = in + pos;
+    const uint8_t* const qe = in + end;
+    for (size_t r = 0; r <= nr; r++) {
+      const uint8_t* const stop = r < nr ? in + pos + runs[r].pos : qe;
+      while (q + 4 <= stop) {
+        const uint32_t a = lit[q[0]], b = lit[q[1]], c = lit[q[2]], d = lit[q[3]];
         bw.add(a & 0xffffu, (int)(a >> 16));
         bw.add(b & 0xffffu, (int)(b >> 16));
         bw.add(c & 0xffffu, (int)(c >> 16));
         bw.add(d & 0xffffu, (int)(d >> 16));
         bw.flush();
-        k += 4;
-        continue;
+        q += 4;
       }
-      const uint32_t t = tok[k++];
-      if (t < 256) {
-        bw.put(lit[t] & 0xffffu, (int)(lit[t] >> 16));
-      } else {
-        const LenCode& L = LT[t & 0x1ffu];
+      while (q < stop) {
+        const uint32_t a = lit[*q++];
+        bw.put(a & 0xffffu, (int)(a >> 16));
+      }
+      if (r < nr) {
+        const LenCode& L = LT[runs[r].len];
         uint32_t bits = lc[L.sym];
         int len = ll[L.sym];
         bits |= (uint32_t)L.eval << len;
@@ -691,14 +953,14 @@ void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
         bits |= (uint32_t)dc[0] << len;               // distance 1: code 0, no extra bits
         len += dl[0];
         bw.put(bits, len);                            // <= 12 + 5 + 1 bits
+        q += runs[r].len;
       }
     }
-    bw.flush();
     bw.put(lc[256], ll[256]);
     pos = end;
   }
   bw.finish();
-  const uLong ad = adler32(adler32(0L, Z_NULL, 0), in, (uInt)n);
+  const uint32_t ad = fast_adler32(1u, in, n);
   uint8_t* q = bw.p;
   q[0] = (uint8_t)(ad >> 24); q[1] = (uint8_t)(ad >> 16); q[2] = (uint8_t)(ad >> 8); q[3] = (uint8_t)ad;
   out.len = (size_t)(q + 4 - out.data());
@@ -819,8 +1081,8 @@ static int rr_png_write_scanlines_impl(const char* path, const uint8_t* rows, in
     uint8_t hd[8], tl[4];
     put32(hd, len);
     memcpy(hd + 4, tag, 4);
-    uLong c = crc32(0L, (const Bytef*)tag, 4);
-    if (len) c = crc32(c, data, len);
+    uint32_t c = (uint32_t)crc32(0L, (const Bytef*)tag, 4);
+    if (len) c = fast_crc32(c, data, len);
     put32(tl, (uint32_t)c);
     return fwrite(hd, 1, 8, fh) == 8 && (len == 0 || fwrite(data, 1, len, fh) == len) && fwrite(tl, 1, 4, fh) == 4;
   };
@@ -887,6 +1149,9 @@ extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int
     return RR_E_PARSE;
   }
 }
+// the writer's / reader's checksums (tests compare them with zlib's)
+extern "C" uint32_t rr_adler32(uint32_t adler, const uint8_t* p, int64_t n) { return (p && n > 0) ? fast_adler32(adler, p, (size_t)n) : adler; }
+extern "C" uint32_t rr_crc32(uint32_t crc, const uint8_t* p, int64_t n) { return (p && n > 0) ? fast_crc32(crc, p, (size_t)n) : crc; }
 extern "C" int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
   try {
     return rr_deflate_fast_impl(in, n, out, cap);

@@ -109,7 +109,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
-           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
+           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
            'rr_sizeof_sim_frame']
 
 _lib = None
@@ -175,6 +175,9 @@ def load_library(path=None):
     lib.rr_deflate_fast.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
     lib.rr_deflate_fast.restype = ctypes.c_int64
     lib.rr_inflate_fast.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+    for fn in (lib.rr_adler32, lib.rr_crc32):
+        fn.restype = ctypes.c_uint32
+        fn.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]
     lib.rr_host_parse_particles.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.rr_host_drop_draws.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,

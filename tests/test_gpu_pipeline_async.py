@@ -179,3 +179,52 @@ def test_packed_prepared_batches_and_resident_solid_angles(tmp_path, built, copy
             rh.host_free(b[0])
     finally:
         rh.close()
+
+
+def test_failed_submit_leaves_no_copy_in_flight(tmp_path, built):
+    """A batch that fails AFTER its uploads were queued (generated drop tables asked for, diameter tables never set:
+    RR_E_STATE from the particle stage) returns with nothing of it still in flight -- the caller may release or rewrite
+    its buffers at once -- and the slot and the context stay usable: the same slot then renders a good batch to the
+    bits of the synchronous call."""
+    import importlib
+    particles = importlib.import_module('rain-rendering_amd.tools.particles')
+    dbmod = importlib.import_module('rain-rendering_amd.common.db')
+    H, W = 96, 160
+    sc = h.Scene(tmp_path, H, W, 120, n_frames=2, seed0=51)
+    rh = h.hb.RainHip(0)
+    try:
+        rh.set_streak_db(sc.db.streaks_light)
+        rh.set_camera(sc.cam)
+        consts, We = tp._setup(rh, H, W, 25)
+        good = []
+        for i in range(2):
+            bg, depth = tp._scene(H, W, 51 + i)
+            bg8 = rh.host_array((H, W, 3), np.uint8)
+            bg8[...] = (bg * 255).astype(np.uint8)
+            dep = rh.host_array((H, W), np.float32)
+            dep[...] = depth.astype(np.float32)
+            good.append(dict(bg_u8=bg8, depth=dep, fog=consts, omega=sc.omega, drops=sc.product_drops(i)))
+        ref = rh.pipeline_frames(good, want_mask_i32=True)
+        opt = dict(dbmod.settings('kitti'))
+        opt.pop('sequences', None)
+        opt['cam_CCD_WH'] = [W, H]
+        sims, dgrid, cdf = particles.sim_frames(opt, 25, 2, seed=9, draw_seeds=[1, 2], count=64)
+        bad = [dict(bg_u8=g['bg_u8'], depth=g['depth'], fog=consts, omega=sc.omega, sim=sims[k], drops_cap=64) for k, g in enumerate(good)]
+        outs = [dict(image_u8=rh.host_array((H, W, 3), np.uint8), mask_i32=rh.host_array((H, W), np.int32),
+                     status=np.zeros(max(64, len(g['drops'])), np.int32)) for g in good]
+        with pytest.raises(RuntimeError):
+            rh.pipeline_submit(1, bad, outs)                    # rr_set_particle_tables was never called
+        for g in good:                                          # the caller's buffers are its own again: scribble, restore
+            keep = g['bg_u8'].copy()
+            g['bg_u8'][...] = 0
+            g['bg_u8'][...] = keep
+        assert rh.pipeline_wait(1)                              # (the slot is idle: nothing to wait for)
+        outs2 = [dict(image_u8=o['image_u8'], mask_i32=o['mask_i32'], status=o['status'][:len(g['drops'])].copy())
+                 for o, g in zip(outs, good)]
+        rh.pipeline_submit(1, good, outs2)
+        assert rh.pipeline_wait(1)
+        for o, r in zip(outs2, ref):
+            assert np.array_equal(o['image_u8'], r['image_u8']) and np.array_equal(o['mask_i32'], r['mask_i32'])
+            assert np.array_equal(o['status'], r['status'])
+    finally:
+        rh.close()

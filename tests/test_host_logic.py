@@ -428,3 +428,100 @@ def test_own_inflate_agrees_with_zlib_or_declines():
         rc, d = inf(z, len(b))
         if rc == 1:
             assert d == zlib.decompress(bytes(z))
+
+
+def test_codec_checksums_equal_zlib():
+    """rr_adler32 / rr_crc32 (SSSE3 / carry-less-multiplication paths of the PNG codec where the CPU has them) return
+    zlib's values: every length around the vector and block sizes, every alignment, chained calls, the all-0xff worst
+    case of the Adler lanes."""
+    import zlib
+    lib = h.hb.load_library()
+    rng = np.random.RandomState(3)
+    buf = rng.randint(0, 256, 1 << 20).astype(np.uint8)
+    raw = buf.tobytes()
+    base = buf.ctypes.data
+    lengths = list(range(0, 200)) + [255, 256, 257, 5551, 5552, 5553, 5552 * 2 + 15, 65535, 65536, 200003]
+    for n in lengths:
+        for off in (0, 1, 7, 13, 16, 33):
+            want_a, want_c = zlib.adler32(raw[off:off + n]), zlib.crc32(raw[off:off + n])
+            assert lib.rr_adler32(1, base + off, n) == want_a, (n, off)
+            assert lib.rr_crc32(0, base + off, n) == want_c, (n, off)
+    a, c, pos = 1, 0, 0                                        # chained over ragged pieces == one call
+    while pos < len(raw):
+        n = int(rng.randint(1, 70000))
+        a, c = lib.rr_adler32(a, base + pos, min(n, len(raw) - pos)), lib.rr_crc32(c, base + pos, min(n, len(raw) - pos))
+        pos += n
+    assert a == zlib.adler32(raw) and c == zlib.crc32(raw)
+    ff = np.full(3 << 20, 255, np.uint8)
+    assert lib.rr_adler32(1, ff.ctypes.data, len(ff)) == zlib.adler32(ff.tobytes())
+    assert lib.rr_crc32(0, ff.ctypes.data, len(ff)) == zlib.crc32(ff.tobytes())
+
+
+def test_png_reader_every_filter_every_pixel_size(tmp_path):
+    """The readers' un-filtering (SSE2 Paeth rows, word-wise loads and stores) on files written HERE with one chosen
+    filter for every row -- None, Sub, Up, Average, Paeth -- for 1, 2, 3 and 4 bytes per pixel (gray, 16-bit gray, RGB,
+    RGBA), widths from one pixel up (rows shorter than a machine word), against the pixels that went in (and PIL)."""
+    import importlib
+    import struct
+    import zlib
+    from PIL import Image
+    imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+    rng = np.random.RandomState(11)
+
+    def filtered(rows, bpp, ft):
+        """PNG-filter the byte rows [h][stride] with filter type ft."""
+        h_, stride = rows.shape
+        out = np.zeros((h_, 1 + stride), np.uint8)
+        prev = np.zeros(stride, np.int32)
+        for y in range(h_):
+            cur = rows[y].astype(np.int32)
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if stride > bpp else np.zeros(stride, np.int32)
+            c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if stride > bpp else np.zeros(stride, np.int32)
+            b = prev
+            if ft == 0:
+                pred = 0
+            elif ft == 1:
+                pred = a
+            elif ft == 2:
+                pred = b
+            elif ft == 3:
+                pred = (a + b) >> 1
+            else:
+                p = a + b - c
+                pa, pb, pc = np.abs(p - a), np.abs(p - b), np.abs(p - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+            out[y, 0] = ft
+            out[y, 1:] = (cur - pred) & 255
+            prev = cur
+        return out
+
+    def write(path, w, h_, depth, ctype, scan):
+        def chunk(tag, data):
+            return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data))
+        with open(path, 'wb') as fh:
+            fh.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h_, depth, ctype, 0, 0, 0)) +
+                     chunk(b'IDAT', zlib.compress(scan.tobytes(), 6)) + chunk(b'IEND', b''))
+
+    for w in (1, 2, 3, 5, 16, 67):
+        h_ = 9
+        for ft in range(5):
+            for kind, (ch, depth, ctype) in {'gray': (1, 8, 0), 'rgb': (3, 8, 2), 'rgba': (4, 8, 6), 'gray16': (1, 16, 0)}.items():
+                bpp = ch * depth // 8
+                smooth = rng.rand() < 0.5
+                px = rng.randint(0, 256, (h_, w * bpp))
+                if smooth:
+                    px = (np.cumsum(rng.randint(-2, 3, (h_, w * bpp)), axis=1) + 128) & 255
+                rows = px.astype(np.uint8)
+                p = str(tmp_path / ('%s_%d_%d.png' % (kind, w, ft)))
+                write(p, w, h_, depth, ctype, filtered(rows, bpp, ft))
+                if kind == 'gray16':
+                    want = (rows[:, 0::2].astype(np.uint16) << 8) | rows[:, 1::2]
+                    got = imgops.imread_unchanged(p)
+                    assert got.dtype == np.uint16 and np.array_equal(got, want), (kind, w, ft)
+                    assert np.array_equal(np.array(Image.open(p)).astype(np.uint16), want)
+                else:
+                    img = rows.reshape(h_, w, ch)
+                    want = np.repeat(img, 3, axis=2) if ch == 1 else img[..., 2::-1]
+                    got = imgops.imread_bgr(p)
+                    assert imgops._native_png(p) is not None
+                    assert np.array_equal(got, want), (kind, w, ft)
