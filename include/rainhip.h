@@ -383,6 +383,15 @@ int64_t rr_host_frame_draws(const rr_streak_table* t, int32_t W, int32_t H, cons
 int rr_host_assemble_drops(const rr_streak_table* t, int64_t n_keep, const int64_t* keep, const int32_t* tex_index,
                            const double* rot_cos, const double* rot_sin, rr_drop* out);
 int rr_sizeof_streak_table(void);
+/* A whole batch of drop tables in one call, for runs without angular noise (the reference's default): frame k = the filter,
+ * draws and records of rr_host_frame_draws + rr_host_assemble_drops on tables[k] with seed seeds[k].  Without noise the
+ * rotation terms belong to the table ENTRY: rot_cos[k] / rot_sin[k] hold them for every entry of tables[k] (the caller's
+ * numpy evaluates them once per simulated frame; frames that share a table pass the same arrays).  Frame k's records go to
+ * out + k * out_stride (records), at most cap of them; counts[k] = the number of kept streaks (it may exceed cap: size up
+ * and call again) or a negative RR_E* code.  Runs on `threads` worker threads inside the library (<= 0: up to 16). */
+int rr_host_pack_frames(int32_t n, const rr_streak_table* const* tables, const double* const* rot_cos, const double* const* rot_sin,
+                        int32_t W, int32_t H, const double* ratio_db, int32_t n_ratio, const uint32_t* seeds, rr_drop* out,
+                        int64_t out_stride, int64_t cap, int32_t threads, int64_t* counts);
 
 /* Host-only (no device, no ctx): the particles XML of the rain simulator -> flat records, replacing the reference's
  * pure-Python walk (common/bad_weather.py:192-211).  Raw attribute values only; the derived fields (render scale, y flip,
@@ -421,6 +430,18 @@ int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap)
  * zlib stream of known decoded size: 1 = out holds the data (Adler-32 verified), 0 = not vouched for (the readers then
  * hand the stream to zlib), < 0 = bad argument. */
 int rr_inflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len);
+/* Batch forms for the driver, on `threads` worker threads inside the library (<= 0: up to 16); one call per pipeline batch
+ * instead of one interpreter call per frame and file.  The calls return RR_OK unless an argument is bad; status[k] holds
+ * frame k's own result (RR_OK, RR_E_ARG: size mismatch / unreadable path, RR_E_UNSUPPORTED, RR_E_PARSE).
+ *   rr_io_read_frames   frame k: rr_png_read_bgr8(image_paths[k]) into bg_u8 + k * bg_stride (bytes) and, when depth_paths
+ *                       is given, the 16-bit depth file as float32 metres (value / 256, generator.py:360-365) into
+ *                       depth_f32 + k * depth_stride (bytes); both files must be H x W
+ *   rr_io_write_frames  frame k: rr_png_write_scanlines(strategy 3) of rows_image + k * rows_stride to image_paths[k] and of
+ *                       rows_mask + k * rows_stride to mask_paths[k] (either path array may be NULL) */
+int rr_io_read_frames(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                      uint8_t* bg_u8, int64_t bg_stride, float* depth_f32, int64_t depth_stride, int32_t threads, int32_t* status);
+int rr_io_write_frames(int32_t n, const char* const* image_paths, const char* const* mask_paths, const uint8_t* rows_image,
+                       const uint8_t* rows_mask, int64_t rows_stride, int32_t W, int32_t H, int32_t threads, int32_t* status);
 /* The codec's checksums: zlib's adler32(adler, p, n) and crc32(crc, p, n) (same values, same chaining; start from 1 and 0),
  * computed with SSSE3 / carry-less multiplication where the CPU has them (zlib's own loops otherwise). */
 uint32_t rr_adler32(uint32_t adler, const uint8_t* p, int64_t n);

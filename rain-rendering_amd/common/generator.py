@@ -116,6 +116,19 @@ class Generator:
             self._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('RAIN_IO_THREADS', 0)) or max(2, min(96, 2 * _cpu_budget())))
         return self._pool
 
+    def _io_threads(self):
+        """Worker threads of the library's batch I/O calls (rr_io_read_frames / rr_io_write_frames / rr_host_pack_frames):
+        RAIN_IO_THREADS, else the process' CPU budget."""
+        return int(os.environ.get('RAIN_IO_THREADS', 0)) or max(2, min(96, _cpu_budget()))
+
+    def _stage_pool(self):
+        """Two Python threads that each carry ONE whole-batch job at a time (decode-ahead, encode-behind) into the
+        library, where the per-frame work runs on native threads without the interpreter lock."""
+        if getattr(self, '_stages', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._stages = ThreadPoolExecutor(max_workers=2)
+        return self._stages
+
     def _pack(self, pristine, imW, imH, seed, earlier_seeds=()):
         """Frame filter + drop table with the frame's random draws (generator.py:318,413-425) on a private copy of the
         simulator frame's table.  With angular noise the reference rotates the streak end points IN the shared table
@@ -181,6 +194,8 @@ class Generator:
             row = H * (1 + 4 * W)
             self.png_i = rows((row,), np.uint8)
             self.png_m = rows((row,), np.uint8)
+            # the blocks themselves ((B, stride) bytes): what the library's batch I/O calls address
+            self.raw_bg, self.raw_depth, self.raw_drops, _, self.raw_png_i, self.raw_png_m = self._raw[:6]
             self.env = rows((H, We, 3), np.uint8) if save_envmap else None
             self.drops_cap = drops_cap
             self.key = (B, H, W, We, np.dtype(bg_dtype), np.dtype(depth_dtype), bool(save_envmap))
@@ -192,6 +207,7 @@ class Generator:
             a slot is replaced by a larger / differently shaped one, after its batch has been collected and encoded."""
             assert not self.busy and not self.encodes
             self.bg = self.depth = self.drops = self.status = self.png_i = self.png_m = self.env = None
+            self.raw_bg = self.raw_depth = self.raw_drops = self.raw_png_i = self.raw_png_m = None
             self.prep = None
             for raw in self._raw:
                 hip.host_free(raw)
@@ -395,6 +411,158 @@ class Generator:
             print("\n\nEnd of the simulation")
 
     def _run_batches(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
+        """The frames of one (sequence, weather) run through the asynchronous pipeline.  The common case -- 8-bit PNG
+        images at render scale 1, 16-bit PNG depth of the same size, no angular noise, no environment-map files -- takes
+        the batch-native route (one library call per batch and stage, nothing per frame under the interpreter lock);
+        everything else the general one (per-frame Python on an I/O thread pool)."""
+        native = (work and rs == 1 and not (bool(self.noise_std) and bool(self.noise_scale)) and not self.save_envmap and
+                  self.settings["depth_scale"] == 1 and os.environ.get('RAIN_NATIVE_IO', '1') != '0' and
+                  all(it['image_file'].endswith('.png') and it['depth_file'].endswith('.png') for it in work))
+        if native:
+            # the first frame decides: files the library's readers take, sized as the run's frames
+            i0, d0 = imgops._native_png(work[0]['image_file']), imgops._native_png(work[0]['depth_file'])
+            native = (i0 is not None and d0 is not None and (i0[1], i0[2], i0[4]) == (imW, imH, 8) and
+                      tuple(d0[1:5]) == (imW, imH, 1, 16))
+        run = self._run_batches_native if native else self._run_batches_general
+        return run(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0)
+
+    def _run_batches_native(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
+        """Batch-native route.  Per batch, three whole-batch jobs, each one call (or two) into the library:
+          decode  rr_io_read_frames (image bytes + depth metres straight into the slot's page-locked input blocks) and
+                  rr_host_pack_frames (filter, draws, drop records into the slot's drop block) -- one batch ahead of the GPU;
+          render  rr_pipeline_submit / rr_pipeline_wait on the prepared descriptors;
+          encode  rr_io_write_frames (both files of every frame from the slot's scanline blocks) -- one batch behind.
+        A slot's INPUT blocks are free again when its batch has been collected (the encoders only read the output
+        blocks), so batch b+1 is decoded into slot (b+1) % 3 while batch b renders and batch b-1 is written."""
+        stage = self._stage_pool()
+        threads = self._io_threads()
+        nslot = hip_backend.RR_PIPE_SLOTS
+        batches = [work[a:a + B] for a in range(0, len(work), B)]
+        if getattr(self, '_slots', None) is None or getattr(self, '_slots_hip', None) is not hip:
+            self._slots, self._slots_hip = [None] * nslot, hip
+        slots = self._slots
+        n_sim = len(frame_render_dict)
+        H, W = imH, imW
+        env_w = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
+        hip.set_solid_angles(solid_angle.get_solid_angles(np.empty((H, env_w, 0))))                  # generator.py:410
+        drops_cap = max(1024, max(len(fr.table) for fr in frame_render_dict))
+        assert drops_cap <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
+        key = (B, H, W, env_w, np.dtype(np.uint8), np.dtype(np.float32), False)
+        pkey = (tuple(float(v) for v in fog_const), float(self.opacity_attenuation), self.rendering_strategy)
+        for d in {os.path.dirname(it[k]) for it in work for k in ('out_rainy_path', 'out_rainy_mask_path')}:
+            os.makedirs(d, exist_ok=True)
+        encodes = [None] * nslot                                 # the slot's encode job (future) and its frames
+        done = [0]
+
+        def slot_for(si):
+            sl = slots[si]
+            if sl is None or sl.key != key or sl.drops_cap < drops_cap:
+                if sl is not None:
+                    sl.free(hip)
+                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, np.uint8, np.float32, False, drops_cap)
+            if getattr(sl, 'prep', None) is None or sl.pkey != pkey:
+                frames = [dict(bg=None, bg_u8=sl.bg[k], depth=sl.depth[k], fog=fog_const, omega=None, drops=sl.drops[k],
+                               opacity_attenuation=self.opacity_attenuation, strategy=1 if self.rendering_strategy == 'white' else 0)
+                          for k in range(B)]
+                outs = [dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k]) for k in range(B)]
+                sl.prep, sl.pkey = hip.pipeline_prepare(frames, outs), pkey
+            return sl
+
+        def decode_job(sl, items):
+            """-> (frames of the batch in slot order, their drop counts): inputs of `sl` filled for the first len() frames."""
+            st = hip_backend.io_read_frames([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
+                                            sl.raw_bg, sl.raw_depth, threads)
+            tables = [frame_render_dict[it['f_name_idx'] % n_sim].table for it in items]
+            counts = hip_backend.pack_frames(tables, [it['seeds'][-1] for it in items], self.db, imW, imH, sl.raw_drops,
+                                             sl.drops_cap, sl.drops_cap, threads)
+            ok = [True] * len(items)
+            for k in np.nonzero(st)[0]:                          # not a file the fast readers take: the general loader
+                loaded = self._load_frame(items[k]['image_file'], items[k]['depth_file'], rs)
+                if loaded is None:
+                    print('Missing/Corrupted depth data (%s)' % items[k]['depth_file'])
+                    ok[k] = False
+                    continue
+                bg, depth = loaded
+                assert bg.shape[:2] == (H, W) and bg.dtype == np.uint8 and depth.shape == (H, W), "frames of one sequence share their size"
+                np.copyto(sl.bg[k], bg)
+                np.copyto(sl.depth[k], depth.astype(np.float32))
+            order = [k for k in range(len(items)) if ok[k]]
+            for dst in [k for k in range(len(order)) if not ok[k]]:          # close the gaps of skipped frames from the back
+                src = order.pop()
+                np.copyto(sl.bg[dst], sl.bg[src])
+                np.copyto(sl.depth[dst], sl.depth[src])
+                sl.drops[dst][:counts[src]] = sl.drops[src][:counts[src]]
+                order.insert(dst, src)
+            assert int(counts.max(initial=0)) <= sl.drops_cap
+            return [items[k] for k in order], [int(counts[k]) for k in order]
+
+        def encode_job(sl, items, nds, gpu_ms):
+            st = hip_backend.io_write_frames([it['out_rainy_path'] for it in items], [it['out_rainy_mask_path'] for it in items],
+                                             sl.raw_png_i, sl.raw_png_m, W, H, threads)        # generator.py:466-467
+            if st.any():
+                bad = int(np.nonzero(st)[0][0])
+                raise IOError("could not write %s / %s (%d)" % (items[bad]['out_rainy_path'], items[bad]['out_rainy_mask_path'], st[bad]))
+            return [dict(file=it['out_rainy_path'], drops=nd, skipped=int(np.count_nonzero(sl.status[k][:nd])), gpu_ms=gpu_ms)
+                    for k, (it, nd) in enumerate(zip(items, nds))]
+
+        def finish(si):
+            sl = slots[si]
+            if sl is None or not sl.busy:
+                return
+            while not hip.pipeline_wait(si):                    # tile arena regrown: submit the batch again
+                hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
+            sl.busy = False
+            ms = 1e3 * (time.time() - sl.t_submit) / max(sl.n_valid, 1)
+            encodes[si] = stage.submit(encode_job, sl, [it for it, _ in sl.items], [nd for _, nd in sl.items], ms)
+
+        def drain(si):
+            if encodes[si] is not None:
+                for st_ in encodes[si].result():
+                    self.stats.append(st_)
+                    if st_['skipped'] and self.verbose:
+                        print("\nTrace: %d of %d rain drops not rendered in %s" % (st_['skipped'], st_['drops'], st_['file']))
+                encodes[si] = None
+
+        t_loop0 = time.time()
+        t_first = None
+        for si in range(min(nslot, len(batches))):               # page-locked buffers + descriptors of every slot: set-up, not steady state
+            slot_for(si)
+        decoding = stage.submit(decode_job, slot_for(0), batches[0]) if batches else None
+        for bi in range(len(batches)):
+            si = bi % nslot
+            sl = slots[si]
+            items, nds = decoding.result()
+            drain(si)                                            # the slot's previous files are written: its outputs may be overwritten
+            sl.items = list(zip(items, nds))
+            sl.n_valid = len(items)
+            if sl.n_valid:
+                for k, nd in enumerate(nds):
+                    sl.prep.set_drop_count(k, nd)
+                sl.t_submit = time.time()
+                hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
+                sl.busy = True
+                if t_first is None:
+                    t_first = time.time()
+                done[0] += sl.n_valid
+            finish((bi - 1) % nslot)                             # collect the previous batch, start writing its files
+            if bi + 1 < len(batches):                            # and decode the next one into the slot that is idle now
+                sn = (bi + 1) % nslot
+                finish(sn)
+                if slots[sn] is not None and (slots[sn].key != key or slots[sn].drops_cap < drops_cap):
+                    drain(sn)                                    # (a slot of another shape is replaced: its encoders first)
+                decoding = stage.submit(decode_job, slot_for(sn), batches[bi + 1])
+            if self.verbose:
+                sys.stdout.write('\r          S. {} / {}, F. {} / {}   ({:.1f}s)'.format(
+                    folder_idx + 1, folders_num, done[0], len(work), time.time() - sim_t0))
+        for si in range(nslot):
+            finish(si)
+        for si in range(nslot):
+            drain(si)
+        t_end = time.time()
+        self.timing.append(dict(frames=done[0], first_batch_s=(t_first or t_end) - t_loop0, total_s=t_end - t_loop0, route='native',
+                                steady_frames_per_s=(max(done[0] - B, 0) / (t_end - t_first)) if t_first and t_end > t_first else None))
+
+    def _run_batches_general(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
         """Batches of B frames through the three-slot asynchronous pipeline (rr_pipeline_submit / rr_pipeline_wait):
         decode + drop tables on the I/O threads (into pinned buffers), upload | kernels | download overlapped inside
         the library, deflate + file writes on the I/O threads again.  FOG.fog_rain_layer (generator.py:386),

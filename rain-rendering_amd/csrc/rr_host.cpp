@@ -16,6 +16,7 @@
 #include <cstdint>
 
 #include "rainhip.h"
+#include "rr_parallel.h"
 
 namespace {
 
@@ -174,6 +175,64 @@ extern "C" int rr_host_assemble_drops(const rr_streak_table* t, int64_t n_keep, 
     d.rot_cos = big ? 1.0 : rot_cos[k];
     d.rot_sin = big ? 0.0 : rot_sin[k];
   }
+  return RR_OK;
+}
+
+// One frame without angular noise in ONE call: filter + draws + records.  Without noise the rotation terms of a streak
+// depend on its table entry alone, so the caller evaluates them once per simulated frame (numpy: rot_cos / rot_sin per
+// table ENTRY) and every rendered frame that uses the table gathers them.  Returns the number of kept streaks; records
+// beyond `cap` are not written.
+static int64_t pack_frame_quiet(const rr_streak_table* t, int32_t W, int32_t H, const double* ratio_db, int32_t n_ratio, uint32_t seed,
+                                const double* rot_cos, const double* rot_sin, rr_drop* out, int64_t cap) {
+  if (!t || t->n < 0 || !ratio_db || n_ratio < 4 || !rot_cos || !rot_sin || (cap > 0 && !out) || cap < 0) return RR_E_ARG;
+  const int64_t m = H > W ? H : W;
+  MT s;
+  mt_seed(s, seed);
+  int64_t nk = 0;
+  for (int64_t i = 0; i < t->n; i++) {
+    const int64_t sx = t->ips[2 * i], sy = t->ips[2 * i + 1], ex = t->ipe[2 * i], ey = t->ipe[2 * i + 1];
+    const bool in_s = 0 <= sx && sx < W && 0 <= sy && sy < H, in_e = 0 <= ex && ex < W && 0 <= ey && ey < H;
+    if (!(1 <= t->max_width[i] && t->max_width[i] < m && 1 <= t->length[i] && t->length[i] < m && (in_s || in_e))) continue;
+    const double r = t->ratio[i];
+    int b = 4;
+    for (int k = 3; k >= 0; k--)
+      if (r < ratio_db[k]) b = k;
+    const int32_t tex = (int32_t)mt_randint(s, 10 * b, 10 * b + 10);
+    const bool big = t->type[i] == 0;
+    if (!big) (void)mt_gauss(s);                       // np.random.normal(0, 0) still draws (generator.py:136)
+    if (nk < cap) {
+      rr_drop& d = out[nk];
+      d.x0 = (int32_t)sx;
+      d.y0 = (int32_t)sy;
+      d.x1 = (int32_t)ex;
+      d.y1 = (int32_t)ey;
+      d.max_width = (int32_t)t->max_width[i];
+      d.length = (int32_t)t->length[i];
+      d.type = t->type[i];
+      d.tex_index = tex;
+      d.iw1 = t->iw1[i];
+      d.iw2 = t->iw2[i];
+      for (int c = 0; c < 3; c++) {
+        d.wps[c] = t->wps[3 * i + c];
+        d.wpe[c] = t->wpe[3 * i + c];
+      }
+      d.rot_cos = big ? 1.0 : rot_cos[i];
+      d.rot_sin = big ? 0.0 : rot_sin[i];
+    }
+    nk++;
+  }
+  return nk;
+}
+
+extern "C" int rr_host_pack_frames(int32_t n, const rr_streak_table* const* tables, const double* const* rot_cos, const double* const* rot_sin,
+                                   int32_t W, int32_t H, const double* ratio_db, int32_t n_ratio, const uint32_t* seeds, rr_drop* out,
+                                   int64_t out_stride, int64_t cap, int32_t threads, int64_t* counts) {
+  if (n < 0 || !counts || (n > 0 && (!tables || !rot_cos || !rot_sin || !seeds)) || out_stride < cap) return RR_E_ARG;
+  rrpar::parallel_for(n, threads, [&](int k) {
+    counts[k] = tables[k] ? pack_frame_quiet(tables[k], W, H, ratio_db, n_ratio, seeds[k], rot_cos[k], rot_sin[k],
+                                             out ? out + (size_t)k * (size_t)out_stride : nullptr, cap)
+                          : (int64_t)RR_E_ARG;
+  });
   return RR_OK;
 }
 

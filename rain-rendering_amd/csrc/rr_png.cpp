@@ -18,11 +18,66 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "rainhip.h"
+#include "rr_parallel.h"
 
 namespace {
+
+// Working memory of the codec, reused from file to file and from call to call.  A frame's files need buffers of megabytes
+// (the file, its IDAT stream, the scanlines, the pixels, the deflate output); allocated per file they are mmap'ed and
+// unmapped every time, and with a dozen threads doing that at once the process spends more time in the kernel (address-space
+// lock, page faults, TLB shoot-downs) than in the codec (measured: 7 ms of system time per frame beside 6 ms of work).
+// Buffers only grow; a lease takes a set from the pool (or makes one) and gives it back.
+template <class T>
+class Pool {
+ public:
+  class Lease {
+   public:
+    explicit Lease(Pool& p) : pool_(p), obj_(p.take()) {}
+    ~Lease() { pool_.give(obj_); }
+    Lease(const Lease&) = delete;
+    Lease& operator=(const Lease&) = delete;
+    T& operator*() { return *obj_; }
+    T* operator->() { return obj_; }
+
+   private:
+    Pool& pool_;
+    T* obj_;
+  };
+
+ private:
+  T* take() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      if (!free_.empty()) {
+        T* o = free_.back();
+        free_.pop_back();
+        return o;
+      }
+    }
+    return new T();
+  }
+  void give(T* o) {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      if (free_.size() < 64) {                          // (more than any sane number of I/O threads: the rest is freed)
+        free_.push_back(o);
+        return;
+      }
+    }
+    delete o;
+  }
+  std::mutex m_;
+  std::vector<T*> free_;
+};
+// grow-only view of a vector: at least n elements, old contents kept, nothing re-initialised once it is large enough
+template <class V>
+inline void at_least(V& v, size_t n) {
+  if (v.size() < n) v.resize(n + n / 8);
+}
 
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
@@ -30,23 +85,40 @@ struct Png {
   uint32_t w = 0, h = 0;
   int depth = 0, ctype = 0, interlace = 0;
   std::vector<uint8_t> idat, plte;
+  void reset() {                                      // (capacity kept)
+    w = h = 0;
+    depth = ctype = interlace = 0;
+    idat.clear();
+    plte.clear();
+  }
 };
 
-int read_file(const char* path, std::vector<uint8_t>& buf) {
+// the file's bytes in buf[0 .. size) (buf itself may be longer: it is reused)
+int read_file(const char* path, std::vector<uint8_t>& buf, size_t& size) {
+  size = 0;
   FILE* fh = fopen(path, "rb");
   if (!fh) return RR_E_ARG;
   fseek(fh, 0, SEEK_END);
   long sz = ftell(fh);
   fseek(fh, 0, SEEK_SET);
   if (sz < 0) { fclose(fh); return RR_E_ARG; }
-  buf.resize((size_t)sz);
+  at_least(buf, (size_t)sz);
   size_t got = fread(buf.data(), 1, (size_t)sz, fh);
   fclose(fh);
+  size = (size_t)sz;
   return got == (size_t)sz ? RR_OK : RR_E_PARSE;
 }
 
-int parse_chunks(const std::vector<uint8_t>& f, Png& p, bool want_data) {
+int parse_chunks(const std::vector<uint8_t>& fbuf, size_t fsize, Png& p, bool want_data) {
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  struct Span {                                         // (the first fsize bytes of the reused buffer)
+    const uint8_t* d;
+    size_t n;
+    size_t size() const { return n; }
+    const uint8_t* data() const { return d; }
+    const uint8_t& operator[](size_t i) const { return d[i]; }
+  } f{fbuf.data(), fsize};
+  p.reset();
   if (f.size() < 8 + 25 || memcmp(f.data(), sig, 8) != 0) return RR_E_PARSE;
   size_t pos = 8;
   bool have_hdr = false;
@@ -371,7 +443,7 @@ const Tables* fixed_tables() {                          // the fixed code of RFC
   return h.ok ? &h.t : nullptr;
 }
 
-bool inflate(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
+bool inflate(const uint8_t* in, size_t n, uint8_t* out, size_t out_len, Tables* dyn_space = nullptr) {
   if (n < 6) return false;
   if ((in[0] & 0x0f) != 8 || ((in[0] << 8) | in[1]) % 31 != 0 || (in[1] & 0x20)) return false;    // deflate, no preset dictionary
   const uint8_t* ip = in + 2;
@@ -389,7 +461,9 @@ bool inflate(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
     ip += adv;
     bc += adv << 3;
   };
-  std::unique_ptr<Tables> dyn(new Tables);
+  std::unique_ptr<Tables> own;                          // (26 KB of dynamic-block tables: the caller's when it has some)
+  if (!dyn_space) own.reset(dyn_space = new Tables);
+  Tables* const dyn = dyn_space;
   for (;;) {
     if (ip > iend + 8) return false;                    // ran far past the input
     refill();
@@ -466,7 +540,7 @@ bool inflate(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
         if (lens[256] == 0) return false;               // no end-of-block code
         if (!build(lens, hlit, false, LBITS, dyn->lt, LSIZE) || !build(lens + hlit, hdist, true, DBITS, dyn->dt, DSIZE)) return false;
         pair_literals(dyn->lt, LBITS);
-        T = dyn.get();
+        T = dyn;
       }
       const uint32_t* lt = T->lt;
       const uint32_t* dt = T->dt;
@@ -603,26 +677,39 @@ void paeth_row(uint8_t* cur, const uint8_t* src, const uint8_t* up, size_t strid
   }
 }
 
-// inflate + reverse the scanline filters: `img` = h rows of `stride` bytes
-int decode(const Png& p, std::vector<uint8_t>& img, size_t& stride) {
+struct DecodeScratch {
+  std::vector<uint8_t> file, zin, raw, img, zero;
+  std::vector<uint16_t> d16;
+  Png png;
+  inflate_fast::Tables tables;
+};
+Pool<DecodeScratch> g_decode_pool;
+
+// inflate + reverse the scanline filters: sc.img = h rows of `stride` bytes
+int decode(const Png& p, DecodeScratch& sc, size_t& stride) {
   const int ch = channels_of(p.ctype);
   if (!ch || p.interlace || (p.depth != 8 && p.depth != 16) || (p.ctype == 3 && p.depth != 8)) return RR_E_UNSUPPORTED;
   const size_t bpp = (size_t)ch * p.depth / 8;
   stride = (size_t)p.w * bpp;
   const size_t raw_len = (stride + 1) * p.h;
-  std::vector<uint8_t> raw(raw_len + 16);               // (spare bytes: the fast decoder copies matches in 8-byte pieces)
+  std::vector<uint8_t>& raw = sc.raw;
+  std::vector<uint8_t>& img = sc.img;
+  at_least(raw, raw_len + 16);                          // (spare bytes: the fast decoder copies matches in 8-byte pieces)
   {
     // (it also loads 8 bytes at a time; between two of its bound checks a malformed stream can pull the read position up
     //  to ~30 bytes past the end -- block header + code-length codes, or the refills of one match -- hence 64 spare bytes)
-    std::vector<uint8_t> zin(p.idat.size() + 64, 0);
+    std::vector<uint8_t>& zin = sc.zin;
+    at_least(zin, p.idat.size() + 64);
     memcpy(zin.data(), p.idat.data(), p.idat.size());
-    if (!inflate_fast::inflate(zin.data(), p.idat.size(), raw.data(), raw_len)) {      // anything unusual: zlib decides
+    memset(zin.data() + p.idat.size(), 0, 64);
+    if (!inflate_fast::inflate(zin.data(), p.idat.size(), raw.data(), raw_len, &sc.tables)) {      // anything unusual: zlib decides
       uLongf out_len = (uLongf)raw_len;
       if (uncompress(raw.data(), &out_len, p.idat.data(), (uLong)p.idat.size()) != Z_OK || out_len != raw_len) return RR_E_PARSE;
     }
   }
-  img.resize(stride * p.h + 16);                       // (16 spare bytes: the Paeth rows store whole words)
-  const std::vector<uint8_t> zero(stride + 16, 0);    // the row above the first one (+ the spare bytes word-wise loads may touch)
+  at_least(img, stride * p.h + 16);                    // (16 spare bytes: the Paeth rows store whole words)
+  if (sc.zero.size() < stride + 16) sc.zero.assign(stride + 16 + stride / 8, 0);      // the row above the first one, never written
+  const std::vector<uint8_t>& zero = sc.zero;
   for (uint32_t y = 0; y < p.h; y++) {
     const uint8_t* src = &raw[(stride + 1) * y];
     const int ft = src[0];
@@ -797,7 +884,13 @@ const LenCode* length_table() {
 struct ByteBuf {                                      // uninitialised storage (a std::vector would zero megabytes per file)
   std::unique_ptr<uint8_t[]> mem;
   size_t cap = 0, len = 0;
-  void reserve_raw(size_t c) { mem.reset(new uint8_t[c]); cap = c; len = 0; }
+  void reserve_raw(size_t c) {                        // (grow-only: the buffer is reused from file to file)
+    if (c > cap) {
+      mem.reset(new uint8_t[c + c / 8]);
+      cap = c + c / 8;
+    }
+    len = 0;
+  }
   uint8_t* data() { return mem.get(); }
 };
 inline uint64_t load64(const uint8_t* p) {
@@ -808,7 +901,13 @@ inline uint64_t load64(const uint8_t* p) {
 struct Run {                                          // a run of the byte before it: in[pos .. pos + len) == in[pos - 1]
   uint32_t pos, len;                                  // (pos relative to the block; 3 <= len <= 258)
 };
-void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
+struct EncodeScratch {
+  ByteBuf z;
+  std::vector<Run> runs;
+};
+Pool<EncodeScratch> g_encode_pool;
+
+void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out, std::vector<Run>& runs) {
   const LenCode* LT = length_table();
   const size_t BLOCK = 128 * 1024;
   // worst case: every byte a 15-bit literal is impossible for a Huffman code of the block's own histogram (< 9 bits per
@@ -817,7 +916,7 @@ void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
   out.data()[0] = 0x78;
   out.data()[1] = 0x01;
   BitWriter bw(out.data() + 2);
-  std::vector<Run> runs(BLOCK / 3 + 2);
+  at_least(runs, BLOCK / 3 + 2);
   size_t pos = 0;
   if (n == 0) {                                       // one empty stored block
     bw.put(1, 1); bw.put(0, 2); bw.finish();
@@ -970,11 +1069,12 @@ void fast_deflate(const uint8_t* in, size_t n, ByteBuf& out) {
 
 static int rr_png_info_impl(const char* path, int32_t* w, int32_t* h, int32_t* channels, int32_t* bit_depth) {
   if (!path || !w || !h || !channels || !bit_depth) return RR_E_ARG;
-  std::vector<uint8_t> f;
-  int rc = read_file(path, f);
+  Pool<DecodeScratch>::Lease sc(g_decode_pool);
+  size_t fsize = 0;
+  int rc = read_file(path, sc->file, fsize);
   if (rc) return rc;
-  Png p;
-  if ((rc = parse_chunks(f, p, false))) return rc;
+  Png& p = sc->png;
+  if ((rc = parse_chunks(sc->file, fsize, p, false))) return rc;
   *w = (int32_t)p.w;
   *h = (int32_t)p.h;
   *channels = p.ctype == 3 ? 3 : channels_of(p.ctype);
@@ -986,16 +1086,17 @@ static int rr_png_info_impl(const char* path, int32_t* w, int32_t* h, int32_t* c
 // cv2.imread(path): 8 bits per channel, three channels, B G R
 static int rr_png_read_bgr8_impl(const char* path, uint8_t* out, int32_t H, int32_t W) {
   if (!path || !out) return RR_E_ARG;
-  std::vector<uint8_t> f;
-  int rc = read_file(path, f);
+  Pool<DecodeScratch>::Lease sc(g_decode_pool);
+  size_t fsize = 0;
+  int rc = read_file(path, sc->file, fsize);
   if (rc) return rc;
-  Png p;
-  if ((rc = parse_chunks(f, p, true))) return rc;
+  Png& p = sc->png;
+  if ((rc = parse_chunks(sc->file, fsize, p, true))) return rc;
   if ((int32_t)p.w != W || (int32_t)p.h != H) return RR_E_ARG;
   if (p.depth != 8) return RR_E_UNSUPPORTED;          // cv2 scales 16-bit colour down: left to the general decoder
-  std::vector<uint8_t> img;
   size_t stride = 0;
-  if ((rc = decode(p, img, stride))) return rc;
+  if ((rc = decode(p, *sc, stride))) return rc;
+  const std::vector<uint8_t>& img = sc->img;
   const int ch = channels_of(p.ctype);
   if (p.ctype == 2 || p.ctype == 6) {                 // RGB / RGBA: the datasets' case, without per-pixel decisions
     for (int y = 0; y < H; y++) {
@@ -1029,16 +1130,17 @@ static int rr_png_read_bgr8_impl(const char* path, uint8_t* out, int32_t H, int3
 // cv2.imread(path, cv2.IMREAD_UNCHANGED) of a 16-bit single-channel PNG (depth maps: metres * 256, generator.py:365)
 static int rr_png_read_gray16_impl(const char* path, uint16_t* out, int32_t H, int32_t W) {
   if (!path || !out) return RR_E_ARG;
-  std::vector<uint8_t> f;
-  int rc = read_file(path, f);
+  Pool<DecodeScratch>::Lease sc(g_decode_pool);
+  size_t fsize = 0;
+  int rc = read_file(path, sc->file, fsize);
   if (rc) return rc;
-  Png p;
-  if ((rc = parse_chunks(f, p, true))) return rc;
+  Png& p = sc->png;
+  if ((rc = parse_chunks(sc->file, fsize, p, true))) return rc;
   if ((int32_t)p.w != W || (int32_t)p.h != H) return RR_E_ARG;
   if (p.ctype != 0 || p.depth != 16) return RR_E_UNSUPPORTED;
-  std::vector<uint8_t> img;
   size_t stride = 0;
-  if ((rc = decode(p, img, stride))) return rc;
+  if ((rc = decode(p, *sc, stride))) return rc;
+  const std::vector<uint8_t>& img = sc->img;
   for (size_t i = 0; i < (size_t)H * W; i++) out[i] = (uint16_t)((img[2 * i] << 8) | img[2 * i + 1]);   // PNG is big-endian
   return RR_OK;
 }
@@ -1051,11 +1153,12 @@ static int rr_png_write_scanlines_impl(const char* path, const uint8_t* rows, in
   if (!path || !rows || W <= 0 || H <= 0 || level < 0 || level > 9 || strategy < 0 || strategy > 3) return RR_E_ARG;
   const uLong n = (uLong)H * (1 + 4 * (uLong)W);
   std::vector<uint8_t> z;
-  ByteBuf zf;
+  Pool<EncodeScratch>::Lease es(g_encode_pool);
+  ByteBuf& zf = es->z;
   const uint8_t* zdata = nullptr;
   uLongf clen = 0;
   if (strategy == 3) {
-    fast_deflate(rows, (size_t)n, zf);
+    fast_deflate(rows, (size_t)n, zf, es->runs);
     zdata = zf.data();
     clen = (uLongf)zf.len;
   } else {
@@ -1101,8 +1204,9 @@ static int rr_png_write_scanlines_impl(const char* path, const uint8_t* rows, in
 extern "C" int64_t rr_deflate_bound(int64_t n) { return n + n / 4 + 4096; }
 static int64_t rr_deflate_fast_impl(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
   if (!in || !out || n < 0) return RR_E_ARG;
-  ByteBuf z;
-  fast_deflate(in, (size_t)n, z);
+  Pool<EncodeScratch>::Lease es(g_encode_pool);
+  ByteBuf& z = es->z;
+  fast_deflate(in, (size_t)n, z, es->runs);
   if ((int64_t)z.len > cap) return RR_E_ARG;
   memcpy(out, z.data(), z.len);
   return (int64_t)z.len;
@@ -1149,6 +1253,70 @@ extern "C" int rr_png_write_scanlines(const char* path, const uint8_t* rows, int
     return RR_E_PARSE;
   }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Batch forms for the driver: the frames of one pipeline batch decoded straight into the (page-locked) input block of
+// their slot, and the two files of every frame written from the slot's scanline blocks, on worker threads inside the
+// library.  One call per batch from the driver: with one Python call per frame and file, a few dozen interpreter threads
+// spent most of their time handing the interpreter lock to each other (scripts/driver_host_only.py).
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int rr_io_read_frames(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                                 uint8_t* bg_u8, int64_t bg_stride, float* depth_f32, int64_t depth_stride, int32_t threads,
+                                 int32_t* status) {
+  if (n < 0 || H <= 0 || W <= 0 || !status || (n > 0 && (!image_paths || !bg_u8)) || (depth_paths && !depth_f32) ||
+      bg_stride < (int64_t)H * W * 3 || (depth_paths && depth_stride < (int64_t)H * W * 4))
+    return RR_E_ARG;
+  rrpar::parallel_for(n, threads, [&](int k) {
+    int rc;
+    try {
+      rc = image_paths[k] ? rr_png_read_bgr8_impl(image_paths[k], bg_u8 + (size_t)k * (size_t)bg_stride, H, W) : RR_E_ARG;
+      if (rc == RR_OK && depth_paths) {
+        if (!depth_paths[k]) {
+          rc = RR_E_ARG;
+        } else {
+          // depth = cv2.imread(f, IMREAD_UNCHANGED).astype(np.float32) / 256.   (generator.py:360-365; exact: a power of two)
+          Pool<DecodeScratch>::Lease sc(g_decode_pool);      // (only its d16 buffer: the reader below leases its own set)
+          std::vector<uint16_t>& d16 = sc->d16;
+          at_least(d16, (size_t)H * W);
+          rc = rr_png_read_gray16_impl(depth_paths[k], d16.data(), H, W);
+          if (rc == RR_OK) {
+            float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(depth_f32) + (size_t)k * (size_t)depth_stride);
+            for (size_t i = 0; i < (size_t)H * W; i++) o[i] = (float)d16[i] / 256.0f;
+          }
+        }
+      }
+    } catch (...) {
+      rc = RR_E_PARSE;
+    }
+    status[k] = rc;
+  });
+  return RR_OK;
+}
+
+extern "C" int rr_io_write_frames(int32_t n, const char* const* image_paths, const char* const* mask_paths, const uint8_t* rows_image,
+                                  const uint8_t* rows_mask, int64_t rows_stride, int32_t W, int32_t H, int32_t threads, int32_t* status) {
+  if (n < 0 || H <= 0 || W <= 0 || !status || (image_paths && !rows_image) || (mask_paths && !rows_mask) ||
+      rows_stride < (int64_t)H * (1 + 4 * (int64_t)W))
+    return RR_E_ARG;
+  // two jobs per frame (the files are independent): 2n items keep every thread busy to the end of a batch
+  std::vector<int32_t> rc2((size_t)2 * (size_t)(n > 0 ? n : 0), RR_OK);
+  rrpar::parallel_for(2 * n, threads, [&](int j) {
+    const int k = j >> 1;
+    const bool mask = j & 1;
+    const char* path = mask ? (mask_paths ? mask_paths[k] : nullptr) : (image_paths ? image_paths[k] : nullptr);
+    if (!path) return;
+    const uint8_t* rows = (mask ? rows_mask : rows_image) + (size_t)k * (size_t)rows_stride;
+    int rc;
+    try {
+      rc = rr_png_write_scanlines_impl(path, rows, W, H, 1, 3);
+    } catch (...) {
+      rc = RR_E_PARSE;
+    }
+    rc2[(size_t)j] = rc;
+  });
+  for (int k = 0; k < n; k++) status[k] = rc2[2 * (size_t)k] ? rc2[2 * (size_t)k] : rc2[2 * (size_t)k + 1];
+  return RR_OK;
+}
+
 // the writer's / reader's checksums (tests compare them with zlib's)
 extern "C" uint32_t rr_adler32(uint32_t adler, const uint8_t* p, int64_t n) { return (p && n > 0) ? fast_adler32(adler, p, (size_t)n) : adler; }
 extern "C" uint32_t rr_crc32(uint32_t crc, const uint8_t* p, int64_t n) { return (p && n > 0) ? fast_crc32(crc, p, (size_t)n) : crc; }

@@ -109,7 +109,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
-           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
+           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
            'rr_sizeof_sim_frame']
 
 _lib = None
@@ -175,6 +175,13 @@ def load_library(path=None):
     lib.rr_deflate_fast.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
     lib.rr_deflate_fast.restype = ctypes.c_int64
     lib.rr_inflate_fast.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+    lib.rr_host_pack_frames.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_int32, ctypes.c_void_p]
+    lib.rr_io_read_frames.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
+    lib.rr_io_write_frames.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     for fn in (lib.rr_adler32, lib.rr_crc32):
         fn.restype = ctypes.c_uint32
         fn.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]
@@ -390,6 +397,90 @@ def pack_frame(table, db, imW, imH, seed, noise_std=0.0, noise_scale=0.0, rotati
     if rc != 0:
         raise RuntimeError("rr_host_assemble_drops failed (%d)" % rc)
     return out
+
+
+def table_rotation(table):
+    """(rot_cos, rot_sin) of EVERY entry of a streak table for a run without angular noise: the reference's chain
+    (generator.py:138-145,163: acos -> degrees -> radians -> cos / sin, evaluated by numpy exactly as pack_frame does for
+    the streaks it keeps), once per simulated frame instead of once per rendered frame; cached on the table."""
+    rot = getattr(table, '_rot', None)
+    if rot is None:
+        s = table.ips.astype(np.float64)
+        e = table.ipe.astype(np.float64)
+        with np.errstate(all='ignore'):
+            d = s - e
+            n1 = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+            theta = np.rad2deg(np.arccos((d[:, 0] / n1) * 0 + (d[:, 1] / n1) * -1))
+            ang = -(theta + np.zeros(len(theta))) * (np.pi / 180)
+            rot = (np.ascontiguousarray(np.cos(ang)), np.ascontiguousarray(np.sin(ang)))
+        table._rot = rot
+    return rot
+
+
+def _c_paths(paths):
+    """NULL-safe char*[] of file names (None entries stay NULL); the bytes objects must outlive the call."""
+    enc = [None if p is None else os.fsencode(p) for p in paths]
+    return (ctypes.c_char_p * len(enc))(*enc), enc
+
+
+def pack_frames(tables, seeds, db, imW, imH, out_block, out_stride, cap, threads=0):
+    """rr_host_pack_frames: frame k's drop table (no angular noise) from tables[k] with seed seeds[k], written to record
+    k * out_stride of the rr_drop block at address / array `out_block`; returns the kept counts (int64 array).  Same
+    records as pack_frame(tables[k], db, imW, imH, seeds[k]) -- tests/test_host_logic.py."""
+    lib = load_library()
+    n = len(tables)
+    tvs, keep = [], []
+    for t in tables:
+        tv = getattr(t, '_tv', None)
+        if tv is None:
+            tv = t._tv = _table_view(t)
+        tvs.append(tv)
+        keep.append(table_rotation(t))
+    tptr = (ctypes.c_void_p * n)(*[ctypes.addressof(tv) for tv in tvs])
+    cptr = (ctypes.c_void_p * n)(*[r[0].ctypes.data for r in keep])
+    sptr = (ctypes.c_void_p * n)(*[r[1].ctypes.data for r in keep])
+    ratio_db = np.ascontiguousarray(db.ratio, np.float64)
+    sd = np.ascontiguousarray(seeds, np.uint32)
+    if any(not 0 <= int(v) <= 2 ** 32 - 1 for v in seeds):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    counts = np.zeros(n, np.int64)
+    base = out_block.ctypes.data if isinstance(out_block, np.ndarray) else int(out_block)
+    rc = lib.rr_host_pack_frames(n, tptr, cptr, sptr, int(imW), int(imH), _ptr(ratio_db), len(ratio_db), _ptr(sd), ctypes.c_void_p(base),
+                                 int(out_stride), int(cap), int(threads), _ptr(counts))
+    if rc != 0 or (counts < 0).any():
+        raise RuntimeError("rr_host_pack_frames failed (%d, %s)" % (rc, counts[counts < 0][:4]))
+    return counts
+
+
+def io_read_frames(image_paths, depth_paths, H, W, bg_block, depth_block, threads=0):
+    """rr_io_read_frames into the frames-back-to-back blocks of RainHip.host_rows ((n, stride) uint8 arrays): frame k's
+    image bytes (B G R) at bg_block[k], its depth as float32 metres at depth_block[k].  Returns the per-frame status."""
+    lib = load_library()
+    n = len(image_paths)
+    ip, k1 = _c_paths(image_paths)
+    dp, k2 = _c_paths(depth_paths)
+    status = np.zeros(n, np.int32)
+    assert bg_block.dtype == np.uint8 and depth_block.dtype == np.uint8 and bg_block.shape[0] >= n and depth_block.shape[0] >= n
+    rc = lib.rr_io_read_frames(n, ip, dp, int(H), int(W), _ptr(bg_block), int(bg_block.strides[0]), _ptr(depth_block),
+                               int(depth_block.strides[0]), int(threads), _ptr(status))
+    if rc != 0:
+        raise RuntimeError("rr_io_read_frames failed (%d)" % rc)
+    return status
+
+
+def io_write_frames(image_paths, mask_paths, rows_image_block, rows_mask_block, W, H, threads=0):
+    """rr_io_write_frames from the scanline blocks of a pipeline slot ((n, stride) uint8 arrays).  Per-frame status."""
+    lib = load_library()
+    n = len(image_paths)
+    ip, k1 = _c_paths(image_paths)
+    mp, k2 = _c_paths(mask_paths)
+    status = np.zeros(n, np.int32)
+    assert rows_image_block.strides[0] == rows_mask_block.strides[0]
+    rc = lib.rr_io_write_frames(n, ip, mp, _ptr(rows_image_block), _ptr(rows_mask_block), int(rows_image_block.strides[0]), int(W), int(H),
+                                int(threads), _ptr(status))
+    if rc != 0:
+        raise RuntimeError("rr_io_write_frames failed (%d)" % rc)
+    return status
 
 
 def pack_streak_db(textures):

@@ -1,0 +1,139 @@
+"""CPU tier: the driver's host pipeline (Generator._run_batches, both routes) around a stand-in for the GPU context that
+records what reaches `rr_pipeline_submit` and delivers known scanlines: the frames, depth maps and drop tables the
+library would get are the ones the per-frame loaders make, skipped frames leave no gap, every output file is written from
+its own frame's scanlines, and the batch-native route feeds the library exactly what the general route does."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import helpers as h
+
+sys.path.insert(0, os.path.join(h.ROOT, 'scripts'))
+import driver_host_only as dho                                     # noqa: E402  (the stand-in context lives with the script)
+
+hb = h.hb
+generator_mod = importlib.import_module('rain-rendering_amd.common.generator')
+main_mod = importlib.import_module('rain-rendering_amd.main')
+imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+
+
+class RecordingContext(dho.HostOnlyContext):
+    """Keeps a copy of every submitted frame's inputs; "renders" scanlines that encode the frame's identity (the first
+    pixel of its image), so that a file written from another frame's buffer would be noticed."""
+    log = None
+
+    def pipeline_submit_prepared(self, slot, prep, n=None):
+        n = prep.n if n is None else n
+        for k in range(n):
+            fr = prep.frames[k]
+            nd = prep.counts.get(k, len(fr['drops']))
+            RecordingContext.log.append(dict(bg=np.array(fr['bg_u8']), depth=np.array(fr['depth']), drops=np.array(fr['drops'][:nd])))
+        super().pipeline_submit_prepared(slot, prep, n)
+
+    def pipeline_prepare(self, frames, outs):
+        p = super().pipeline_prepare(frames, outs)
+        p.counts = {}
+        p.set_drop_count = lambda k, n_: p.counts.__setitem__(k, int(n_))
+        return p
+
+    def pipeline_wait(self, slot):
+        prep, n = self.batches.pop(slot, (None, 0))
+        if prep is None:
+            return True
+        for k in range(n):
+            o, fr = prep.outs[k], prep.frames[k]
+            H, W = fr['bg_u8'].shape[:2]
+            rows = np.zeros((H, 1 + 4 * W), np.uint8)               # filter type 0 rows: every pixel = the frame's first pixel
+            rows[:, 1:] = np.tile(np.append(fr['bg_u8'][0, 0], 255).astype(np.uint8), W)
+            o['rainy_png'][...] = rows.ravel()
+            rows[:, 1:] = np.tile(np.array([k % 251, fr['bg_u8'][0, 0, 1], 7, 255], np.uint8), W)
+            o['mask_png'][...] = rows.ravel()
+            o['status'][...] = 0
+        return True
+
+
+def _dataset(tmp, n_frames, H=48, W=80):
+    src = os.path.join(tmp, 'source')
+    img_dir, dep_dir = h.synthetic.write_dataset(src, 'kitti', os.path.join('data_object', 'training'), n_frames, H, W)
+    h.synthetic.write_streak_db(os.path.join(tmp, 'rainstreakdb'))
+    frames = h.synthetic.simulate_particles(2, 200, W, H)
+    xml = os.path.join(tmp, 'particles', 'kitti', 'data_object', 'rain', '5mm', 'sim_camera0.xml')
+    h.synthetic.write_particles_xml(xml, frames)
+    return src, img_dir, dep_dir
+
+
+def _run(tmp, src, out_name, native, monkeypatch, batch=3):
+    monkeypatch.setenv('RAIN_BATCH', str(batch))
+    monkeypatch.setenv('RAIN_NATIVE_IO', '1' if native else '0')
+    monkeypatch.setattr(hb, 'RainHip', RecordingContext)
+    RecordingContext.log = []
+    argv = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd', os.path.join(tmp, 'rainstreakdb'),
+            '-i', '5', '--output', os.path.join(tmp, out_name), '--noverbose']
+    gen = main_mod.main(argv)
+    return gen, RecordingContext.log, os.path.join(tmp, out_name, 'kitti', 'data_object', 'training', 'rain', '5mm')
+
+
+def test_native_route_feeds_the_library_what_the_general_route_does(tmp_path, built, monkeypatch):
+    tmp = str(tmp_path)
+    n = 8
+    src, img_dir, dep_dir = _dataset(tmp, n)
+    # frame 2: a corrupt depth file -- both routes skip the frame (generator.py:360-363) and close the gap in its batch
+    with open(os.path.join(dep_dir, '%06d.png' % 2), 'wb') as fh:
+        fh.write(b'not a png')
+    gen_n, log_n, out_n = _run(tmp, src, 'out_native', True, monkeypatch)
+    gen_g, log_g, out_g = _run(tmp, src, 'out_general', False, monkeypatch)
+    assert gen_n.timing[0].get('route') == 'native' and gen_g.timing[0].get('route') != 'native'
+    assert len(gen_n.stats) == len(gen_g.stats) == n - 1 == len(log_n) == len(log_g)
+
+    def by_identity(log):
+        return {fr['bg'].tobytes(): fr for fr in log}
+    a, b = by_identity(log_n), by_identity(log_g)
+    assert a.keys() == b.keys() and len(a) == n - 1                 # the same frames (batches may order them differently)
+    for key in a:
+        assert a[key]['depth'].dtype == np.float32 and np.array_equal(a[key]['depth'], b[key]['depth'])
+        assert len(a[key]['drops']) > 20 and a[key]['drops'].tobytes() == b[key]['drops'].tobytes()
+    # inputs against the loaders themselves, drop tables against pack_frame
+    db = gen_n.db
+    tables = [f.table for f in db.streaks_simulator.values()]
+    for i in range(n):
+        if i == 2:
+            continue
+        bg = imgops.imread_bgr(os.path.join(img_dir, '%06d.png' % i))
+        fr = a[bg.tobytes()]
+        assert np.array_equal(fr['depth'], imgops.imread_unchanged(os.path.join(dep_dir, '%06d.png' % i)).astype(np.float32) / 256.)
+        want = hb.pack_frame(tables[i % len(tables)].take(slice(None)), db, 80, 48, i)
+        assert fr['drops'].tobytes() == want.tobytes(), i
+    # every file from its own frame's scanlines, in both routes
+    for out in (out_n, out_g):
+        for i in range(n):
+            p = os.path.join(out, 'rainy_image', '%06d.png' % i)
+            if i == 2:
+                assert not os.path.exists(p)
+                continue
+            bg = imgops.imread_bgr(os.path.join(img_dir, '%06d.png' % i))
+            img = np.array(Image.open(p))
+            assert img.shape == (48, 80, 4) and (img == np.append(bg[0, 0], 255)).all(), i
+            msk = np.array(Image.open(os.path.join(out, 'rain_mask', '%06d.png' % i)))
+            assert (msk[..., 1] == bg[0, 0, 1]).all() and (msk[..., 2] == 7).all()
+    assert sorted(s['file'][len(out_n):] for s in gen_n.stats) == sorted(s['file'][len(out_g):] for s in gen_g.stats)
+
+
+def test_native_route_is_not_taken_when_its_conditions_fail(tmp_path, built, monkeypatch):
+    """Angular noise, environment-map files, a resized render or a depth map of another size keep the general route."""
+    tmp = str(tmp_path)
+    src, img_dir, dep_dir = _dataset(tmp, 3)
+    monkeypatch.setenv('RAIN_BATCH', '2')
+    monkeypatch.setattr(hb, 'RainHip', RecordingContext)
+    base = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd', os.path.join(tmp, 'rainstreakdb'),
+            '-i', '5', '--noverbose']
+    for k, extra in enumerate((['--noise_scale', '1', '--noise_std', '3'], ['--save_envmap'])):
+        RecordingContext.log = []
+        gen = main_mod.main(base + ['--output', os.path.join(tmp, 'o%d' % k)] + extra)
+        assert gen.timing[0].get('route') != 'native' and len(RecordingContext.log) == 3
+    RecordingContext.log = []
+    gen = main_mod.main(base + ['--output', os.path.join(tmp, 'o9')])
+    assert gen.timing[0].get('route') == 'native' and len(RecordingContext.log) == 3

@@ -104,3 +104,29 @@ def test_compute_drop_seam_equals_batched_call(tmp_path, built):
     assert np.array_equal(mask, batched['mask'])
     assert np.array_equal(rainy, batched['rainy_bg'])
     rh.close()
+
+
+def test_native_and_general_routes_write_the_same_files(tmp_path, built, monkeypatch):
+    """The driver's batch-native route (rr_io_read_frames / rr_host_pack_frames / rr_io_write_frames: one library call
+    per batch and stage) and its general route (per-frame Python on I/O threads) on the same dataset: byte-identical
+    output files, frame by frame; several batches with a ragged last one."""
+    tmp = str(tmp_path)
+    src, xml = _make_dataset(tmp, n_frames=7)
+    main = importlib.import_module('rain-rendering_amd.main')
+    outs = {}
+    for route, flag in (('native', '1'), ('general', '0')):
+        monkeypatch.setenv('RAIN_NATIVE_IO', flag)
+        monkeypatch.setenv('RAIN_BATCH', '3')
+        argv = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd',
+                os.path.join(tmp, 'rainstreakdb'), '-i', '5', '--output', os.path.join(tmp, 'out_' + route), '--noverbose']
+        gen = main.main(argv)
+        assert (gen.timing[0].get('route') == 'native') == (route == 'native')
+        assert len(gen.stats) == 7 and all(s['drops'] > 50 for s in gen.stats)
+        outs[route] = os.path.join(tmp, 'out_' + route, 'kitti', 'data_object', 'training', 'rain', '5mm')
+    for i in range(7):
+        for kind in ('rainy_image', 'rain_mask'):
+            a = open(os.path.join(outs['native'], kind, '%06d.png' % i), 'rb').read()
+            b = open(os.path.join(outs['general'], kind, '%06d.png' % i), 'rb').read()
+            assert a == b and len(a) > 500, (kind, i)
+    mask = np.array(Image.open(os.path.join(outs['native'], 'rain_mask', '000003.png')))
+    assert len(np.unique(mask.reshape(-1, 4), axis=0)) > 3                  # streaks were rendered
