@@ -1071,8 +1071,14 @@ static int rr_png_info_impl(const char* path, int32_t* w, int32_t* h, int32_t* c
   if (!path || !w || !h || !channels || !bit_depth) return RR_E_ARG;
   Pool<DecodeScratch>::Lease sc(g_decode_pool);
   size_t fsize = 0;
-  int rc = read_file(path, sc->file, fsize);
-  if (rc) return rc;
+  int rc = RR_OK;
+  {                                                   // the signature and the IHDR chunk: the first 33 bytes of the file
+    FILE* fh = fopen(path, "rb");
+    if (!fh) return RR_E_ARG;
+    at_least(sc->file, 64);
+    fsize = fread(sc->file.data(), 1, 33, fh);
+    fclose(fh);
+  }
   Png& p = sc->png;
   if ((rc = parse_chunks(sc->file, fsize, p, false))) return rc;
   *w = (int32_t)p.w;

@@ -13,9 +13,10 @@ import numpy as np
 
 def rank_world():
     """(rank, world) from torch.distributed if initialised, else from the launcher's env."""
+    import sys
+    dist = sys.modules.get('torch.distributed')        # (a group can only exist if torch is loaded: a single-GPU run never imports it)
     try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
+        if dist is not None and dist.is_available() and dist.is_initialized():
             return dist.get_rank(), dist.get_world_size()
     except Exception:
         pass
