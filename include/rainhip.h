@@ -328,7 +328,11 @@ enum {
    * moved by one copy kernel per direction that reads / writes the host memory directly (faster than many small DMA
    * requests -- 90 vs 40 GB/s both ways, scripts/probes/pcie_probe.hip -- but it takes compute units from the rendering
    * kernels it runs beside: measured slower end to end). */
-  RR_OPT_COPY_KERNELS = 8
+  RR_OPT_COPY_KERNELS = 8,
+  /* tuning: 1 (default) the tile kernels stage a streak texture from a copy that already carries its 2-texel zero border
+   * (made once by rr_set_streak_db*: 16-byte copies into LDS); 0 they build the border and place the texels byte by byte.
+   * The LDS contents are the same bytes. */
+  RR_OPT_PADDED_TEXTURES = 9
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -122,6 +122,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* colpart;                  // [frame][COL_PARTS][5][drops] FOV partial sums per envmap row band
   double* wtab;                     // [frame][drops][2][BR_MAX+1] normalised Gaussian half tables of the blurred drops (k_blur_weights)
   double* wtab_big;                 // [frame][SLOW_CAP][2][MAX_R+1] the same for the first SLOW_CAP large-radius drops of a frame (k_blur_big_weights)
+  const uint8_t* tex_pad;           // the textures with their 2-texel zero border, as k_tile stages them (k_pad_textures); NULL: staged byte by byte
+  const int64_t* tex_poff;          // [texture] offset of its padded copy (a multiple of 16)
   uint32_t* spans;                  // [frame][Hp / 4][Dp][4] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4,
                                     // Dp = drops + 1 rounded up to 8; slot `drops` of every quad stays all zeros: what a drop
                                     // without a polygon reads
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
 //       2   one lane per output pixel folds s_buf top to bottom.
 //     Every fold runs in the order resizeArea_ uses, so the tile is bit-identical to
 //     raw_tile_pixel (rr_device.h, the one-thread-per-pixel definition) / the oracle.
-constexpr int TEX_LDS = 11776;      // padded texels: (h+4)*(w+4) <= TEX_LDS
+constexpr int TEX_LDS = 11776;      // padded texels: (h+4)*(w+4) <= TEX_LDS (a multiple of 16: load_tex_copy)
 constexpr int NW_MAX = 384;
 constexpr int TW_MAX = 64;
 constexpr int BUF_MAX = 512;
@@ -1007,6 +1009,28 @@ __device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
   if (p.rs_mode == RS_AREA_FAST) return true;                      // integer ratios: per-wave sequential chains
   const int rows_per_dy = (int)ceil(p.scale_y) + 3;
   return p.rs_mode == RS_AREA && rows_per_dy <= BUF_MAX;             // wide tiles are folded in column chunks
+}
+
+// The textures once more, each with its 2-texel zero border and pitch w + 4 -- byte for byte what load_tex_padded builds in
+// LDS -- made when the database is set: a tile then stages its texture with 16-byte copies (three per thread for a 32x320
+// texture) instead of placing 10 K bytes one by one (four index computations and four one-byte LDS writes per dword).
+__global__ __launch_bounds__(256) void k_pad_textures(const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w,
+                                                      const int64_t* tex_off, const int64_t* tex_poff, uint8_t* pad) {
+  const int i = blockIdx.x, sh = tex_h[i], sw = tex_w[i], P = sw + 4;
+  const uint8_t* g = texels + tex_off[i];
+  uint8_t* dst = pad + tex_poff[i];
+  for (int k = threadIdx.x; k < (sh + 4) * P; k += 256) {
+    const int y = k / P - 2, x = k - (y + 2) * P - 2;
+    dst[k] = (y >= 0 && y < sh && x >= 0 && x < sw) ? g[y * sw + x] : (uint8_t)0;
+  }
+}
+// (the copy may run up to 15 bytes past (sh + 4) * (sw + 4): zeros of the padded copy into spare bytes of s_tex, whose
+//  size is a multiple of 16)
+__device__ inline void load_tex_copy(uint8_t* s_tex, const uint8_t* gpad, int sh, int sw) {
+  const int n16 = ((sh + 4) * (sw + 4) + 15) >> 4;
+  const uint4* g = reinterpret_cast<const uint4*>(gpad);
+  uint4* d = reinterpret_cast<uint4*>(s_tex);
+  for (int k = threadIdx.x; k < n16; k += 256) d[k] = g[k];
 }
 
 // texture -> LDS with a 2-texel zero border (pitch sw+4).  Border texels are zeroed directly,
@@ -1117,7 +1141,10 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   // Staging the texture in LDS costs one pass over all its texels; a small Big tile (bicubic: 16 taps
   // per output pixel) touches fewer texels than that, and the 50 textures (~350 KB) live in L2 anyway
   const bool tex_fits = (sh + 4) * P <= TEX_LDS && !(p.kind == KIND_BIG && p.tw * p.th * 12 < sh * sw);
-  if (tex_fits) load_tex_padded(s_tex, gtex, sh, sw);
+  if (tex_fits) {
+    if (sc.tex_pad) load_tex_copy(s_tex, sc.tex_pad + sc.tex_poff[p.tex], sh, sw);
+    else load_tex_padded(s_tex, gtex, sh, sw);
+  }
   double* A0 = sc.arena + p.a0_off;      // raw tile, pitch tw
   // integer-ratio INTER_AREA (ResizeAreaFast): the per-pixel chain is sequential by definition;
   // keep it short with the LDS fixed-point sampler
@@ -1236,7 +1263,8 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
   const uint8_t* gtex = texels + tex_off[p.tex];
   const int P = sw + 4;
-  load_tex_padded(s_tex, gtex, sh, sw);
+  if (sc.tex_pad) load_tex_copy(s_tex, sc.tex_pad + sc.tex_poff[p.tex], sh, sw);
+  else load_tex_padded(s_tex, gtex, sh, sw);
   double* A0 = sc.arena + p.a0_off;
   const int tw = p.tw, th = p.th;
   const double sy_scale = p.scale_y;
@@ -2758,6 +2786,9 @@ struct rr_ctx {
   int32_t* d_tex_h = nullptr;
   int32_t* d_tex_w = nullptr;
   int64_t* d_tex_off = nullptr;
+  uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
+  int64_t* d_tex_poff = nullptr;
+  bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
   int n_tex = 0;
   float* d_ctab = nullptr;
   // particle generator (rr_set_particle_tables / rr_generate_drops_device)
@@ -3136,6 +3167,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
   const int ntiles = tiles_x * tiles_y;
   Scratch sc = ctx->sc;
+  sc.tex_pad = ctx->padded_tex ? ctx->d_tex_pad : nullptr;
+  sc.tex_poff = ctx->d_tex_poff;
   sc.blur_bx = ctx->blur_wg == 3 ? 3072 : (ctx->blur_wg == 5 ? 2304 : 2816);
   sc.blur_by = ctx->blur_wg == 5 ? 1600 : 2048;
   // One in-order stream: FOV spans -> plan -> scan -> dedup -> lists -> FOV sums -> colour -> tiles -> blur ->
@@ -3528,6 +3561,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->d_tex_h);
   hipFree(ctx->d_tex_w);
   hipFree(ctx->d_tex_off);
+  hipFree(ctx->d_tex_pad);
+  hipFree(ctx->d_tex_poff);
   hipFree(ctx->d_ctab);
   hipFree(ctx->d_lut);
   hipFree(ctx->sc.plan);
@@ -3639,6 +3674,22 @@ static int set_db_meta(rr_ctx* ctx, const int32_t* tex_h, const int32_t* tex_w, 
   HIPCHK(hipMemcpy(ctx->d_tex_off, tex_off, sizeof(int64_t) * n_tex, hipMemcpyHostToDevice));
   ctx->n_tex = n_tex;
   ctx->have_db = true;
+  {                                     // the padded copies k_tile / k_tile_generic stage from
+    std::vector<int64_t> poff((size_t)n_tex);
+    int64_t total = 0;
+    for (int i = 0; i < n_tex; i++) {
+      poff[(size_t)i] = total;
+      total += (((int64_t)tex_h[i] + 4) * ((int64_t)tex_w[i] + 4) + 15) & ~15LL;
+    }
+    if ((rc = dev_alloc(ctx, ctx->d_tex_poff, (size_t)n_tex))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_tex_pad, (size_t)total + 16))) return rc;
+    HIPCHK(hipMemcpy(ctx->d_tex_poff, poff.data(), sizeof(int64_t) * (size_t)n_tex, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ctx->d_tex_pad, 0, (size_t)total + 16));
+    hipLaunchKernelGGL(k_pad_textures, dim3(n_tex), dim3(256), 0, ctx->stream, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off,
+                       ctx->d_tex_poff, ctx->d_tex_pad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   {                                     // DBManager.ratio = np.unique(w / h) (bad_weather.py:134,144): take_drop_texture's thresholds
     std::vector<double> r;
     for (int i = 0; i < n_tex; i++) r.push_back((double)tex_w[i] / (double)tex_h[i]);
@@ -4487,6 +4538,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_DEPTH_OCCLUSION: ctx->depth_occlusion = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
+    case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
     case RR_OPT_FOV_THREADS:
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;

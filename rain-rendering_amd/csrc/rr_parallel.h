@@ -37,8 +37,11 @@ void parallel_for(int n, int threads, F f) {
     }
   };
   std::vector<std::thread> pool;
-  pool.reserve((size_t)t - 1);
-  for (int k = 1; k < t; k++) pool.emplace_back(work);
+  try {
+    pool.reserve((size_t)t - 1);
+    for (int k = 1; k < t; k++) pool.emplace_back(work);
+  } catch (...) {                                      // no more threads to be had: the ones that exist (and this one) do the work
+  }
   work();
   for (auto& th : pool) th.join();
 }

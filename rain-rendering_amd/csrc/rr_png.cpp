@@ -1304,7 +1304,12 @@ extern "C" int rr_io_write_frames(int32_t n, const char* const* image_paths, con
       rows_stride < (int64_t)H * (1 + 4 * (int64_t)W))
     return RR_E_ARG;
   // two jobs per frame (the files are independent): 2n items keep every thread busy to the end of a batch
-  std::vector<int32_t> rc2((size_t)2 * (size_t)(n > 0 ? n : 0), RR_OK);
+  std::vector<int32_t> rc2;
+  try {
+    rc2.assign((size_t)2 * (size_t)(n > 0 ? n : 0), RR_OK);
+  } catch (...) {
+    return RR_E_PARSE;
+  }
   rrpar::parallel_for(2 * n, threads, [&](int j) {
     const int k = j >> 1;
     const bool mask = j & 1;

@@ -20,6 +20,7 @@ RR_OPT_DEDUP, RR_OPT_GENERAL_FOV, RR_OPT_FOV_THREADS, RR_OPT_FOV_DROPS_PER_THREA
 RR_OPT_BLUR_WORKGROUPS = 6
 RR_OPT_COMPOSITE_F64 = 7
 RR_OPT_COPY_KERNELS = 8
+RR_OPT_PADDED_TEXTURES = 9
 
 # numpy mirror of rr_drop (112 bytes)
 DROP_DTYPE = np.dtype([
@@ -535,6 +536,9 @@ class RainHip:
             raise RuntimeError("rr_create(device=%d) failed with %d: this path needs a gfx950 GPU "
                                "(no CPU fallback)" % (device, rc))
         self.h = h
+        for item in filter(None, os.environ.get('RAINHIP_OPTIONS', '').split(',')):      # tuning switches for A/B runs: "9=0,4=5"
+            k, v = item.split('=')
+            self.set_option(int(k), int(v))
         self.device = device
         self._keep = []
 
