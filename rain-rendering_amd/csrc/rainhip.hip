@@ -3685,6 +3685,7 @@ static int set_db_meta(rr_ctx* ctx, const int32_t* tex_h, const int32_t* tex_w, 
     if ((rc = dev_alloc(ctx, ctx->d_tex_pad, (size_t)total + 16))) return rc;
     HIPCHK(hipMemcpy(ctx->d_tex_poff, poff.data(), sizeof(int64_t) * (size_t)n_tex, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(ctx->d_tex_pad, 0, (size_t)total + 16));
+    HIPCHK(hipDeviceSynchronize());    // (the copies above and the fill may still be in flight on the null stream; ours does not wait for it)
     hipLaunchKernelGGL(k_pad_textures, dim3(n_tex), dim3(256), 0, ctx->stream, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off,
                        ctx->d_tex_poff, ctx->d_tex_pad);
     HIPCHK(hipGetLastError());
