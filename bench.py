@@ -326,6 +326,24 @@ def cpu_baseline(sc, host, W, H, sample_drops, procs):
     return out
 
 
+def driver_end_to_end(frames, batch):
+    """The drop-in driver (main.py) on an on-disk synthetic dataset of the headline shape, PNG in -> PNG out, in its own
+    process after the timed region (scripts/driver_e2e.py): reported beside the headline, never `value`.  Host-bound (PNG
+    codec on the box's CPU quota)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scripts', 'driver_e2e.py'), '--frames', str(frames),
+           '--batch', str(batch)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=150, env=dict(os.environ, RAINHIP_OPTIONS=''))
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        tm = (d.get('timing') or [{}])[0]
+        return {"what": d.get('what'), "frames": d.get('frames'), "frames_per_s_steady": tm.get('steady_frames_per_s'),
+                "frames_per_s_including_setup": d.get('frames_per_s'), "host_route": tm.get('route', 'general'),
+                "cpu_quota": d.get('cpu_quota'), "frames_per_batch": batch, "workload": d.get('workload')}
+    except Exception as e:                                # (a reported extra must not take the headline down with it)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -339,6 +357,7 @@ def main():
     ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--more-variants', action='store_true', help='further host-inclusive variants (slot sizes, buffer layouts)')
     ap.add_argument('--no-traffic', action='store_true')
+    ap.add_argument('--no-driver', action='store_true', help='skip the main.py driver end-to-end leg (PNG in -> PNG out, own process)')
     ap.add_argument('--cpu-sample-drops', type=int, default=2048)
     ap.add_argument('--pipe-batch', type=int, default=128, help='frames per slot of the host-inclusive pipeline (the driver\'s default batch)')
     ap.add_argument('--opt', action='append', default=[], help='rr_set_option as ID=VALUE (tuning switches that never change results)')
@@ -348,7 +367,7 @@ def main():
     ap.add_argument('--inner', action='store_true', help='(used by the PMC passes) timed loop only, no extras, no JSON')
     args = ap.parse_args()
     if args.inner or args.sweep:
-        args.no_cpu_baseline = args.no_prepass = args.no_variants = args.no_traffic = True
+        args.no_cpu_baseline = args.no_prepass = args.no_variants = args.no_traffic = args.no_driver = True
 
     import torch
     import torch.distributed as dist
@@ -683,6 +702,8 @@ def main():
                                     for k, v in sorted((valu or {}).items(), key=lambda kv: -kv[1]["valu_util"])} if valu else None},
         }
         out.update(extras)
+        if single and not args.no_driver and not strong and not is_sim and args.workload == 'kitti100':
+            out["driver_end_to_end"] = driver_end_to_end(1024, args.pipe_batch)
         if not args.no_cpu_baseline and single and not strong and not is_sim:
             out["cpu_baseline"] = cpu_baseline(sc, batch.host, W, H, args.cpu_sample_drops, os.cpu_count() or 1)
         print(json.dumps(out))

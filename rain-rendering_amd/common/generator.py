@@ -113,13 +113,15 @@ class Generator:
         around the GPU call is what bounds the driver end to end, so it runs ahead of / behind the GPU."""
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('RAIN_IO_THREADS', 0)) or max(2, min(96, 2 * _cpu_budget())))
+            ranks_here = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
+            self._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('RAIN_IO_THREADS', 0)) or max(2, min(96, 2 * _cpu_budget() // ranks_here)))
         return self._pool
 
     def _io_threads(self):
         """Worker threads of the library's batch I/O calls (rr_io_read_frames / rr_io_write_frames / rr_host_pack_frames):
         RAIN_IO_THREADS, else the process' CPU budget."""
-        return int(os.environ.get('RAIN_IO_THREADS', 0)) or max(2, min(96, _cpu_budget()))
+        ranks_here = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))        # torch.distributed.run: ranks sharing this host's CPUs
+        return int(os.environ.get('RAIN_IO_THREADS', 0)) or max(2, min(96, _cpu_budget() // ranks_here))
 
     def _stage_pool(self):
         """Two Python threads that each carry ONE whole-batch job at a time (decode-ahead, encode-behind) into the
