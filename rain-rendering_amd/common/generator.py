@@ -446,7 +446,10 @@ class Generator:
         n_sim = len(frame_render_dict)
         H, W = imH, imW
         env_w = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
-        hip.set_solid_angles(solid_angle.get_solid_angles(np.empty((H, env_w, 0))))                  # generator.py:410
+        cache = self.__dict__.setdefault('_omega_cache', {})     # a function of the map's shape alone: once per size, not per run
+        if (H, env_w) not in cache:
+            cache[(H, env_w)] = solid_angle.get_solid_angles(np.empty((H, env_w, 0)))               # generator.py:410
+        hip.set_solid_angles(cache[(H, env_w)])
         drops_cap = max(1024, max(len(fr.table) for fr in frame_render_dict))
         assert drops_cap <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
         key = (B, H, W, env_w, np.dtype(np.uint8), np.dtype(np.float32), False)

@@ -677,6 +677,67 @@ void paeth_row(uint8_t* cur, const uint8_t* src, const uint8_t* up, size_t strid
   }
 }
 
+// TWO consecutive Paeth rows at once: a row's pixel needs the pixel above it, so row y + 1 can follow row y one pixel
+// behind -- two independent dependency chains in flight instead of one (the single-row loop is bound by the latency of
+// its chain: subtract, absolute values, minimum, compare, select, add).  cur1 = the row after cur0 (its "up" row);
+// both rows' first pixels are done by the caller.  Stores move whole words like paeth_row: the last store of row 0 runs
+// into the first bytes of row 1, which are therefore written again at the end.
+template <int BPP>
+void paeth_rows2(uint8_t* cur0, const uint8_t* src0, const uint8_t* up0, uint8_t* cur1, const uint8_t* src1, size_t stride) {
+  const __m128i zero = _mm_setzero_si128(), ff = _mm_set1_epi16(0xff);
+  auto load = [&](const uint8_t* q) {
+    if (BPP <= 4) {
+      uint32_t w;
+      memcpy(&w, q, 4);
+      return _mm_unpacklo_epi8(_mm_cvtsi32_si128((int)w), zero);
+    }
+    return _mm_unpacklo_epi8(_mm_loadl_epi64(reinterpret_cast<const __m128i*>(q)), zero);
+  };
+  auto store = [&](uint8_t* q, __m128i v) {
+    const __m128i packed = _mm_packus_epi16(v, v);
+    if (BPP <= 4) {
+      const uint32_t w = (uint32_t)_mm_cvtsi128_si32(packed);
+      memcpy(q, &w, 4);
+    } else {
+      _mm_storel_epi64(reinterpret_cast<__m128i*>(q), packed);
+    }
+  };
+  auto predict = [&](__m128i a, __m128i b, __m128i c) {
+    const __m128i pa_s = _mm_sub_epi16(b, c), pb_s = _mm_sub_epi16(a, c), pc_s = _mm_add_epi16(pa_s, pb_s);
+    const __m128i pa = _mm_max_epi16(pa_s, _mm_sub_epi16(zero, pa_s));
+    const __m128i pb = _mm_max_epi16(pb_s, _mm_sub_epi16(zero, pb_s));
+    const __m128i pc = _mm_max_epi16(pc_s, _mm_sub_epi16(zero, pc_s));
+    const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+    const __m128i is_a = _mm_cmpeq_epi16(smallest, pa), is_b = _mm_cmpeq_epi16(smallest, pb);
+    const __m128i bc = _mm_or_si128(_mm_and_si128(is_b, b), _mm_andnot_si128(is_b, c));
+    return _mm_or_si128(_mm_and_si128(is_a, a), _mm_andnot_si128(is_a, bc));
+  };
+  uint8_t lead1[8];
+  memcpy(lead1, cur1, BPP);
+  __m128i a0 = load(cur0), c0 = load(up0);            // row 0: left and upper-left of its pixel 1
+  __m128i a1 = load(cur1), c1 = a0;                    // row 1: left of its pixel 1; upper-left = row 0's pixel 0
+  size_t i = BPP;                                      // byte offset of row 0's pixel; row 1 works on i - BPP
+  for (; i + BPP <= stride; i += BPP) {
+    const __m128i b0 = load(up0 + i), d0 = load(src0 + i);
+    const __m128i n0 = _mm_and_si128(_mm_add_epi16(predict(a0, b0, c0), d0), ff);
+    if (i >= 2 * BPP) {                                // row 1's pixel i / BPP - 1: above it row 0's previous pixel (a0)
+      const __m128i d1 = load(src1 + i - BPP);
+      const __m128i n1 = _mm_and_si128(_mm_add_epi16(predict(a1, a0, c1), d1), ff);
+      store(cur1 + i - BPP, n1);
+      a1 = n1;
+      c1 = a0;
+    }
+    store(cur0 + i, n0);
+    c0 = b0;
+    a0 = n0;
+  }
+  if (i >= 2 * BPP) {                                  // row 1's last pixel
+    const __m128i d1 = load(src1 + i - BPP);
+    store(cur1 + i - BPP, _mm_and_si128(_mm_add_epi16(predict(a1, a0, c1), d1), ff));
+  }
+  memcpy(cur1, lead1, BPP);
+}
+
 struct DecodeScratch {
   std::vector<uint8_t> file, zin, raw, img, zero;
   std::vector<uint16_t> d16;
@@ -732,6 +793,22 @@ int decode(const Png& p, DecodeScratch& sc, size_t& stride) {
         break;
       case 4:
         for (size_t i = 0; i < lead; i++) cur[i] = (uint8_t)(src[i] + up[i]);          // paeth(0, b, 0) = b
+        // the next row is a Paeth row too: both at once (one-byte pixels excepted: a word-wise store at the end of row 0
+        // would run over more of row 1 than its first pixel)
+        if (y + 1 < p.h && raw[(stride + 1) * (y + 1)] == 4 && stride >= 2 * bpp && bpp >= 2) {
+          const uint8_t* src1 = &raw[(stride + 1) * (y + 1)] + 1;
+          uint8_t* cur1 = &img[stride * (y + 1)];
+          for (size_t i = 0; i < lead; i++) cur1[i] = (uint8_t)(src1[i] + cur[i]);
+          switch (bpp) {
+            case 2: paeth_rows2<2>(cur, src, up, cur1, src1, stride); break;
+            case 3: paeth_rows2<3>(cur, src, up, cur1, src1, stride); break;
+            case 4: paeth_rows2<4>(cur, src, up, cur1, src1, stride); break;
+            case 6: paeth_rows2<6>(cur, src, up, cur1, src1, stride); break;
+            default: paeth_rows2<8>(cur, src, up, cur1, src1, stride); break;
+          }
+          y++;
+          break;
+        }
         switch (bpp) {                                // left / upper-left neighbours stay in registers, one chain per channel
           case 1: paeth_row<1>(cur, src, up, stride); break;
           case 2: paeth_row<2>(cur, src, up, stride); break;
