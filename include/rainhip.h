@@ -444,6 +444,14 @@ int rr_inflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len)
  *                       rows_mask + k * rows_stride to mask_paths[k] (either path array may be NULL) */
 int rr_io_read_frames(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
                       uint8_t* bg_u8, int64_t bg_stride, float* depth_f32, int64_t depth_stride, int32_t threads, int32_t* status);
+/*   rr_io_read_frames_scaled  the same for a render scale other than 1 (generator.py:352-381, the Cityscapes plug-in's
+ *                       default): image / 255 resized (cv2.resize, INTER_LINEAR) to W x H = file size // render_scale as
+ *                       float64 into bg_f64 + k * bg_stride (bytes), the depth map resized to
+ *                       (its size * depth_scale) // render_scale when that differs from its own size; both must come out
+ *                       H x W (RR_E_ARG otherwise: the reference crops the image then -- the caller's general loader) */
+int rr_io_read_frames_scaled(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                             int32_t render_scale, int32_t depth_scale, double* bg_f64, int64_t bg_stride, float* depth_f32,
+                             int64_t depth_stride, int32_t threads, int32_t* status);
 int rr_io_write_frames(int32_t n, const char* const* image_paths, const char* const* mask_paths, const uint8_t* rows_image,
                        const uint8_t* rows_mask, int64_t rows_stride, int32_t W, int32_t H, int32_t threads, int32_t* status);
 /* The codec's checksums: zlib's adler32(adler, p, n) and crc32(crc, p, n) (same values, same chaining; start from 1 and 0),

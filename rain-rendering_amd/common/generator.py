@@ -414,17 +414,21 @@ class Generator:
 
     def _run_batches(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
         """The frames of one (sequence, weather) run through the asynchronous pipeline.  The common case -- 8-bit PNG
-        images at render scale 1, 16-bit PNG depth of the same size, no angular noise, no environment-map files -- takes
+        images, 16-bit PNG depth whose scaled size is the frame's, no angular noise, no environment-map files -- takes
         the batch-native route (one library call per batch and stage, nothing per frame under the interpreter lock);
         everything else the general one (per-frame Python on an I/O thread pool)."""
-        native = (work and rs == 1 and not (bool(self.noise_std) and bool(self.noise_scale)) and not self.save_envmap and
-                  self.settings["depth_scale"] == 1 and os.environ.get('RAIN_NATIVE_IO', '1') != '0' and
+        ds = self.settings["depth_scale"]
+        native = (work and int(rs) == rs and rs >= 1 and int(ds) == ds and ds >= 1 and
+                  not (bool(self.noise_std) and bool(self.noise_scale)) and not self.save_envmap and
+                  os.environ.get('RAIN_NATIVE_IO', '1') != '0' and
                   all(it['image_file'].endswith('.png') and it['depth_file'].endswith('.png') for it in work))
         if native:
-            # the first frame decides: files the library's readers take, sized as the run's frames
+            # the first frame decides: files the library's readers take, whose scaled sizes are the run's frame size
+            # (generator.py:355-381; a depth map of another size would make the reference crop the image: general route)
             i0, d0 = imgops._native_png(work[0]['image_file']), imgops._native_png(work[0]['depth_file'])
-            native = (i0 is not None and d0 is not None and (i0[1], i0[2], i0[4]) == (imW, imH, 8) and
-                      tuple(d0[1:5]) == (imW, imH, 1, 16))
+            native = (i0 is not None and d0 is not None and i0[4] == 8 and tuple(d0[3:5]) == (1, 16) and
+                      (i0[1] // rs, i0[2] // rs) == (imW, imH) and ((d0[1] * ds) // rs, (d0[2] * ds) // rs) == (imW, imH) and
+                      (rs != 1 or (d0[1], d0[2]) == (imW, imH)))
         run = self._run_batches_native if native else self._run_batches_general
         return run(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0)
 
@@ -452,7 +456,10 @@ class Generator:
         hip.set_solid_angles(cache[(H, env_w)])
         drops_cap = max(1024, max(len(fr.table) for fr in frame_render_dict))
         assert drops_cap <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
-        key = (B, H, W, env_w, np.dtype(np.uint8), np.dtype(np.float32), False)
+        u8 = rs == 1                                              # at render scale 1 the bytes go to the GPU; a resized image is float64
+        bg_dtype = np.uint8 if u8 else np.float64
+        ds = int(self.settings["depth_scale"])
+        key = (B, H, W, env_w, np.dtype(bg_dtype), np.dtype(np.float32), False)
         pkey = (tuple(float(v) for v in fog_const), float(self.opacity_attenuation), self.rendering_strategy)
         for d in {os.path.dirname(it[k]) for it in work for k in ('out_rainy_path', 'out_rainy_mask_path')}:
             os.makedirs(d, exist_ok=True)
@@ -464,9 +471,9 @@ class Generator:
             if sl is None or sl.key != key or sl.drops_cap < drops_cap:
                 if sl is not None:
                     sl.free(hip)
-                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, np.uint8, np.float32, False, drops_cap)
+                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, bg_dtype, np.float32, False, drops_cap)
             if getattr(sl, 'prep', None) is None or sl.pkey != pkey:
-                frames = [dict(bg=None, bg_u8=sl.bg[k], depth=sl.depth[k], fog=fog_const, omega=None, drops=sl.drops[k],
+                frames = [dict(bg=None if u8 else sl.bg[k], bg_u8=sl.bg[k] if u8 else None, depth=sl.depth[k], fog=fog_const, omega=None, drops=sl.drops[k],
                                opacity_attenuation=self.opacity_attenuation, strategy=1 if self.rendering_strategy == 'white' else 0)
                           for k in range(B)]
                 outs = [dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k]) for k in range(B)]
@@ -475,8 +482,12 @@ class Generator:
 
         def decode_job(sl, items):
             """-> (frames of the batch in slot order, their drop counts): inputs of `sl` filled for the first len() frames."""
-            st = hip_backend.io_read_frames([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
-                                            sl.raw_bg, sl.raw_depth, threads)
+            if u8:
+                st = hip_backend.io_read_frames([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
+                                                sl.raw_bg, sl.raw_depth, threads)
+            else:
+                st = hip_backend.io_read_frames_scaled([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
+                                                       int(rs), ds, sl.raw_bg, sl.raw_depth, threads)
             tables = [frame_render_dict[it['f_name_idx'] % n_sim].table for it in items]
             counts = hip_backend.pack_frames(tables, [it['seeds'][-1] for it in items], self.db, imW, imH, sl.raw_drops,
                                              sl.drops_cap, sl.drops_cap, threads)
@@ -488,7 +499,7 @@ class Generator:
                     ok[k] = False
                     continue
                 bg, depth = loaded
-                assert bg.shape[:2] == (H, W) and bg.dtype == np.uint8 and depth.shape == (H, W), "frames of one sequence share their size"
+                assert bg.shape[:2] == (H, W) and bg.dtype == bg_dtype and depth.shape == (H, W), "frames of one sequence share their size"
                 np.copyto(sl.bg[k], bg)
                 np.copyto(sl.depth[k], depth.astype(np.float32))
             order = [k for k in range(len(items)) if ok[k]]

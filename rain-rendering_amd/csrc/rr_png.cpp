@@ -13,6 +13,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -739,8 +740,10 @@ void paeth_rows2(uint8_t* cur0, const uint8_t* src0, const uint8_t* up0, uint8_t
 }
 
 struct DecodeScratch {
-  std::vector<uint8_t> file, zin, raw, img, zero;
+  std::vector<uint8_t> file, zin, raw, img, zero, bgr;
   std::vector<uint16_t> d16;
+  std::vector<int32_t> x0, x1, y0, y1;              // resize tables (rr_io_read_frames_scaled)
+  std::vector<double> wx, wy;
   Png png;
   inflate_fast::Tables tables;
 };
@@ -1364,6 +1367,128 @@ extern "C" int rr_io_read_frames(int32_t n, const char* const* image_paths, cons
           if (rc == RR_OK) {
             float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(depth_f32) + (size_t)k * (size_t)depth_stride);
             for (size_t i = 0; i < (size_t)H * W; i++) o[i] = (float)d16[i] / 256.0f;
+          }
+        }
+      }
+    } catch (...) {
+      rc = RR_E_PARSE;
+    }
+    status[k] = rc;
+  });
+  return RR_OK;
+}
+
+// cv2.resize(img, (dw, dh)) for float images as the driver states it (common/imgops.resize_linear: INTER_LINEAR, half-pixel
+// centres, edge clamp, float64): source index and weight of every destination row / column ...
+static void linear_coords(int d, int s, std::vector<int32_t>& i0, std::vector<int32_t>& i1, std::vector<double>& w) {
+  at_least(i0, (size_t)d);
+  at_least(i1, (size_t)d);
+  at_least(w, (size_t)d);
+  const double scale = (double)s / (double)d;
+  for (int k = 0; k < d; k++) {
+    const double f = ((double)k + 0.5) * scale - 0.5;
+    const double fl = std::floor(f);
+    const int64_t a = (int64_t)fl;
+    w[(size_t)k] = a < 0 ? 0.0 : f - fl;
+    const int64_t b = a + 1;
+    i0[(size_t)k] = (int32_t)(a < 0 ? 0 : (a > s - 1 ? s - 1 : a));
+    i1[(size_t)k] = (int32_t)(b < 0 ? 0 : (b > s - 1 ? s - 1 : b));
+  }
+}
+// ... and one output sample: (a00 * (1 - wx) + a01 * wx) * (1 - wy) + (a10 * (1 - wx) + a11 * wx) * wy, the products and sums
+// in numpy's order
+static inline double bilinear(double a00, double a01, double a10, double a11, double wx, double wy) {
+  const double ux = 1 - wx, uy = 1 - wy;
+  const double top = a00 * ux + a01 * wx, bot = a10 * ux + a11 * wx;
+  return top * uy + bot * wy;
+}
+struct UnitLut {                                       // byte / 255.0 (generator.py:352), as numpy divides
+  double v[256];
+  UnitLut() {
+    for (int i = 0; i < 256; i++) v[i] = (double)i / 255.0;
+  }
+};
+
+// The frame loader of Generator.run for a render scale other than 1 (generator.py:352-381; the Cityscapes plug-in's
+// default): image / 255 resized to (W, H) = file size // render_scale as float64, the depth map (metres) resized to
+// (its size * depth_scale) // render_scale when that differs from its own size.  Depth and image must end up H x W (the
+// reference would crop the image otherwise: RR_E_ARG, the caller's general loader handles such a frame).
+extern "C" int rr_io_read_frames_scaled(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                                        int32_t render_scale, int32_t depth_scale, double* bg_f64, int64_t bg_stride, float* depth_f32,
+                                        int64_t depth_stride, int32_t threads, int32_t* status) {
+  if (n < 0 || H <= 0 || W <= 0 || render_scale < 1 || depth_scale < 1 || !status || (n > 0 && (!image_paths || !bg_f64)) ||
+      (depth_paths && !depth_f32) || bg_stride < (int64_t)H * W * 24 || (depth_paths && depth_stride < (int64_t)H * W * 4))
+    return RR_E_ARG;
+  static const UnitLut lut;
+  rrpar::parallel_for(n, threads, [&](int k) {
+    int rc = RR_OK;
+    try {
+      Pool<DecodeScratch>::Lease sc(g_decode_pool);     // (the readers below lease their own sets: this one holds the temporaries)
+      int32_t sw = 0, sh = 0, ch = 0, bits = 0;
+      if (!image_paths[k] || (rc = rr_png_info_impl(image_paths[k], &sw, &sh, &ch, &bits)) != RR_OK) {
+        status[k] = rc ? rc : RR_E_ARG;
+        return;
+      }
+      if (sw / render_scale != W || sh / render_scale != H) {
+        status[k] = RR_E_ARG;
+        return;
+      }
+      std::vector<uint8_t>& bgr = sc->bgr;
+      at_least(bgr, (size_t)sh * sw * 3);
+      if ((rc = rr_png_read_bgr8_impl(image_paths[k], bgr.data(), sh, sw)) != RR_OK) {
+        status[k] = rc;
+        return;
+      }
+      double* out = reinterpret_cast<double*>(reinterpret_cast<char*>(bg_f64) + (size_t)k * (size_t)bg_stride);
+      if (sh == H && sw == W) {
+        for (size_t i = 0; i < (size_t)H * W * 3; i++) out[i] = lut.v[bgr[i]];
+      } else {
+        linear_coords(H, sh, sc->y0, sc->y1, sc->wy);
+        linear_coords(W, sw, sc->x0, sc->x1, sc->wx);
+        for (int y = 0; y < H; y++) {
+          const uint8_t* r0 = bgr.data() + (size_t)sc->y0[(size_t)y] * sw * 3;
+          const uint8_t* r1 = bgr.data() + (size_t)sc->y1[(size_t)y] * sw * 3;
+          const double wy = sc->wy[(size_t)y];
+          double* o = out + (size_t)y * W * 3;
+          for (int x = 0; x < W; x++) {
+            const size_t xa = (size_t)sc->x0[(size_t)x] * 3, xb = (size_t)sc->x1[(size_t)x] * 3;
+            const double wx = sc->wx[(size_t)x];
+            for (int c = 0; c < 3; c++)
+              o[(size_t)x * 3 + c] = bilinear(lut.v[r0[xa + c]], lut.v[r0[xb + c]], lut.v[r1[xa + c]], lut.v[r1[xb + c]], wx, wy);
+          }
+        }
+      }
+      if (depth_paths) {
+        int32_t dw = 0, dh = 0;
+        if (!depth_paths[k] || (rc = rr_png_info_impl(depth_paths[k], &dw, &dh, &ch, &bits)) != RR_OK) {
+          status[k] = rc ? rc : RR_E_ARG;
+          return;
+        }
+        const int64_t th = ((int64_t)dh * depth_scale) / render_scale, tw = ((int64_t)dw * depth_scale) / render_scale;
+        if (th != H || tw != W) {
+          status[k] = RR_E_ARG;
+          return;
+        }
+        std::vector<uint16_t>& d16 = sc->d16;
+        at_least(d16, (size_t)dh * dw);
+        if ((rc = rr_png_read_gray16_impl(depth_paths[k], d16.data(), dh, dw)) != RR_OK) {
+          status[k] = rc;
+          return;
+        }
+        float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(depth_f32) + (size_t)k * (size_t)depth_stride);
+        if (dh == H && dw == W) {
+          for (size_t i = 0; i < (size_t)H * W; i++) o[i] = (float)d16[i] / 256.0f;
+        } else {                                       // cv2.resize keeps float32: float64 inside resize_linear, rounded once
+          linear_coords(H, dh, sc->y0, sc->y1, sc->wy);
+          linear_coords(W, dw, sc->x0, sc->x1, sc->wx);
+          auto m = [&](size_t idx) { return (double)((float)d16[idx] / 256.0f); };
+          for (int y = 0; y < H; y++) {
+            const size_t r0 = (size_t)sc->y0[(size_t)y] * dw, r1 = (size_t)sc->y1[(size_t)y] * dw;
+            const double wy = sc->wy[(size_t)y];
+            for (int x = 0; x < W; x++) {
+              const size_t xa = (size_t)sc->x0[(size_t)x], xb = (size_t)sc->x1[(size_t)x];
+              o[(size_t)y * W + x] = (float)bilinear(m(r0 + xa), m(r0 + xb), m(r1 + xa), m(r1 + xb), sc->wx[(size_t)x], wy);
+            }
           }
         }
       }

@@ -110,7 +110,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
-           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
+           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_read_frames_scaled', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
            'rr_sizeof_sim_frame']
 
 _lib = None
@@ -181,6 +181,9 @@ def load_library(path=None):
                                         ctypes.c_int32, ctypes.c_void_p]
     lib.rr_io_read_frames.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
+    lib.rr_io_read_frames_scaled.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_void_p]
     lib.rr_io_write_frames.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     for fn in (lib.rr_adler32, lib.rr_crc32):
@@ -466,6 +469,22 @@ def io_read_frames(image_paths, depth_paths, H, W, bg_block, depth_block, thread
                                int(depth_block.strides[0]), int(threads), _ptr(status))
     if rc != 0:
         raise RuntimeError("rr_io_read_frames failed (%d)" % rc)
+    return status
+
+
+def io_read_frames_scaled(image_paths, depth_paths, H, W, render_scale, depth_scale, bg_block, depth_block, threads=0):
+    """rr_io_read_frames_scaled: like io_read_frames for a render scale other than 1 -- bg_block[k] receives the resized
+    float64 image (H x W x 3, B G R, in [0, 1]), depth_block[k] the float32 depth map (H x W)."""
+    lib = load_library()
+    n = len(image_paths)
+    ip, k1 = _c_paths(image_paths)
+    dp, k2 = _c_paths(depth_paths)
+    status = np.zeros(n, np.int32)
+    assert bg_block.dtype == np.uint8 and depth_block.dtype == np.uint8 and bg_block.shape[0] >= n and depth_block.shape[0] >= n
+    rc = lib.rr_io_read_frames_scaled(n, ip, dp, int(H), int(W), int(render_scale), int(depth_scale), _ptr(bg_block), int(bg_block.strides[0]),
+                                      _ptr(depth_block), int(depth_block.strides[0]), int(threads), _ptr(status))
+    if rc != 0:
+        raise RuntimeError("rr_io_read_frames_scaled failed (%d)" % rc)
     return status
 
 

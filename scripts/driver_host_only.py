@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--tiny', action='store_true', help='64x48 frames: the Python part alone')
     ap.add_argument('--distinct', type=int, default=32)
+    ap.add_argument('--size', default=None, help='WxH of the dataset frames (default 1242x375)')
+    ap.add_argument('--render-scale', type=int, default=1, help='render at 1/N of the frame size (what the Cityscapes plug-in does with N = 2)')
     args = ap.parse_args()
     os.environ['RAIN_BATCH'] = str(args.batch)
     import __graft_entry__ as ge
@@ -110,6 +112,12 @@ def main():
     hb = importlib.import_module('rain-rendering_amd.hip_backend')
     hb.RainHip = HostOnlyContext                      # (this process only)
     H, W = (48, 64) if args.tiny else (375, 1242)
+    if args.size:
+        W, H = (int(v) for v in args.size.split('x'))
+    if args.render_scale != 1:
+        kitti = importlib.import_module('rain-rendering_amd.config.kitti')
+        plain = kitti.settings
+        kitti.settings = lambda: dict(plain(), render_scale=args.render_scale)
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, 'source')
         nd = min(args.distinct, args.frames)
@@ -118,7 +126,7 @@ def main():
             os.symlink(os.path.join(img_dir, '%06d.png' % (i % nd)), os.path.join(img_dir, '%06d.png' % i))
             os.symlink(os.path.join(dep_dir, '%06d.png' % (i % nd)), os.path.join(dep_dir, '%06d.png' % i))
         synthetic.write_streak_db(os.path.join(tmp, 'rainstreakdb'))
-        frames = synthetic.simulate_particles(4, synthetic.DROPS_PER_RATE[args.rate], W, H)
+        frames = synthetic.simulate_particles(4, synthetic.DROPS_PER_RATE[args.rate], W // args.render_scale, H // args.render_scale)
         xml = os.path.join(tmp, 'particles', 'kitti', 'data_object', 'rain', '%dmm' % args.rate, 'sim_camera0.xml')
         synthetic.write_particles_xml(xml, frames)
         argv = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd',

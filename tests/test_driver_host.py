@@ -31,7 +31,8 @@ class RecordingContext(dho.HostOnlyContext):
         for k in range(n):
             fr = prep.frames[k]
             nd = prep.counts.get(k, len(fr['drops']))
-            RecordingContext.log.append(dict(bg=np.array(fr['bg_u8']), depth=np.array(fr['depth']), drops=np.array(fr['drops'][:nd])))
+            bg = fr['bg_u8'] if fr.get('bg_u8') is not None else fr['bg']
+            RecordingContext.log.append(dict(bg=np.array(bg), depth=np.array(fr['depth']), drops=np.array(fr['drops'][:nd])))
         super().pipeline_submit_prepared(slot, prep, n)
 
     def pipeline_prepare(self, frames, outs):
@@ -46,11 +47,12 @@ class RecordingContext(dho.HostOnlyContext):
             return True
         for k in range(n):
             o, fr = prep.outs[k], prep.frames[k]
-            H, W = fr['bg_u8'].shape[:2]
+            bg = fr['bg_u8'] if fr.get('bg_u8') is not None else np.round(fr['bg'] * 255).astype(np.uint8)
+            H, W = bg.shape[:2]
             rows = np.zeros((H, 1 + 4 * W), np.uint8)               # filter type 0 rows: every pixel = the frame's first pixel
-            rows[:, 1:] = np.tile(np.append(fr['bg_u8'][0, 0], 255).astype(np.uint8), W)
+            rows[:, 1:] = np.tile(np.append(bg[0, 0], 255).astype(np.uint8), W)
             o['rainy_png'][...] = rows.ravel()
-            rows[:, 1:] = np.tile(np.array([k % 251, fr['bg_u8'][0, 0, 1], 7, 255], np.uint8), W)
+            rows[:, 1:] = np.tile(np.array([k % 251, bg[0, 0, 1], 7, 255], np.uint8), W)
             o['mask_png'][...] = rows.ravel()
             o['status'][...] = 0
         return True
@@ -137,3 +139,34 @@ def test_native_route_is_not_taken_when_its_conditions_fail(tmp_path, built, mon
     RecordingContext.log = []
     gen = main_mod.main(base + ['--output', os.path.join(tmp, 'o9')])
     assert gen.timing[0].get('route') == 'native' and len(RecordingContext.log) == 3
+
+
+def test_native_route_at_render_scale_two(tmp_path, built, monkeypatch):
+    """A plug-in that renders at half resolution (what config/cityscapes.py does by default): the batch-native route
+    resizes image and depth in the library (rr_io_read_frames_scaled) and hands the GPU the float64 frames, float32
+    depth maps and drop tables the general route's per-frame loader makes."""
+    tmp = str(tmp_path)
+    n = 5
+    src, img_dir, dep_dir = _dataset(tmp, n, H=96, W=160)
+    kitti = importlib.import_module('rain-rendering_amd.config.kitti')
+    plain = kitti.settings
+
+    def half():
+        st = dict(plain())
+        st["render_scale"] = 2
+        return st
+    monkeypatch.setattr(kitti, 'settings', half)
+    gen_n, log_n, out_n = _run(tmp, src, 'out_native', True, monkeypatch, batch=2)
+    gen_g, log_g, out_g = _run(tmp, src, 'out_general', False, monkeypatch, batch=2)
+    assert gen_n.timing[0].get('route') == 'native' and gen_g.timing[0].get('route') != 'native'
+    assert len(log_n) == len(log_g) == n
+    a = {fr['bg'].tobytes(): fr for fr in log_n}
+    b = {fr['bg'].tobytes(): fr for fr in log_g}
+    assert a.keys() == b.keys() and len(a) == n
+    for key in a:
+        assert a[key]['bg'].dtype == np.float64 and a[key]['bg'].shape == (48, 80, 3)
+        assert a[key]['depth'].dtype == np.float32 and np.array_equal(a[key]['depth'], b[key]['depth'])
+        assert len(a[key]['drops']) > 10 and a[key]['drops'].tobytes() == b[key]['drops'].tobytes()
+    for i in range(n):
+        for out in (out_n, out_g):
+            assert np.array(Image.open(os.path.join(out, 'rainy_image', '%06d.png' % i))).shape == (48, 80, 4)

@@ -608,3 +608,49 @@ def test_batch_png_io_equals_per_file_calls(tmp_path):
             imgops.png_from_scanlines(ref, rows_i[k, :H * (1 + 4 * W)], W, H)
             assert open(ref, 'rb').read() == open(op[k], 'rb').read()
         assert np.array_equal(np.array(Image.open(mp[k])), rgba[k][::-1])
+
+
+@pytest.mark.parametrize("H0,W0,rs,ds,dshape", [(96, 160, 2, 1, None), (95, 161, 2, 1, None), (96, 160, 2, 2, (48, 80)), (90, 150, 3, 1, None),
+                                                (64, 96, 1, 1, None)])
+def test_scaled_batch_reader_equals_the_general_loader(tmp_path, H0, W0, rs, ds, dshape):
+    """rr_io_read_frames_scaled (the batch-native loader for a render scale other than 1: the Cityscapes plug-in's default)
+    against Generator._load_frame (cv2.imread / 255, cv2.resize as imgops.resize_linear states it, the depth rule of
+    generator.py:360-381): the float64 image and the float32 depth map, bit for bit; frames the reference would crop are
+    handed back (status != 0)."""
+    import importlib
+    from PIL import Image
+    generator_mod = importlib.import_module('rain-rendering_amd.common.generator')
+    rng = np.random.RandomState(H0 + rs)
+    n = 3
+    ips, dps = [], []
+    for k in range(n):
+        img = np.clip(np.cumsum(rng.randint(-9, 10, (H0, W0, 3)), axis=1) + 120, 0, 255).astype(np.uint8)
+        dh, dw = dshape or (H0, W0)
+        d16 = (np.linspace(60000, 300, dh)[:, None] * np.ones((1, dw)) + rng.randint(0, 200, (dh, dw))).astype(np.uint16)
+        ip, dp = str(tmp_path / ('i%d.png' % k)), str(tmp_path / ('d%d.png' % k))
+        Image.fromarray(img).save(ip)
+        Image.fromarray(d16).save(dp)
+        ips.append(ip)
+        dps.append(dp)
+    H, W = H0 // rs, W0 // rs
+
+    class G:
+        settings = {"depth_scale": ds}
+    want = [generator_mod.Generator._load_frame(G(), ips[k], dps[k], rs) for k in range(n)]
+    bstride, dstride = (H * W * 24 + 15) // 16 * 16, (H * W * 4 + 15) // 16 * 16
+    bg = np.zeros((n, bstride), np.uint8)
+    dep = np.zeros((n, dstride), np.uint8)
+    st = h.hb.io_read_frames_scaled(ips, dps, H, W, rs, ds, bg, dep, threads=2)
+    assert not st.any()
+    for k in range(n):
+        wbg, wdep = want[k]
+        got = bg[k, :H * W * 24].view(np.float64).reshape(H, W, 3)
+        gdep = dep[k, :H * W * 4].view(np.float32).reshape(H, W)
+        if rs == 1:
+            wbg = wbg / 255.0                                     # (at render scale 1 the loader hands the bytes on)
+        assert wbg.shape == (H, W, 3) and wbg.dtype == np.float64 and np.array_equal(got, wbg)
+        assert wdep.dtype == np.float32 and wdep.shape == (H, W) and np.array_equal(gdep, wdep)
+    # a depth map whose scaled size is not the image's: the reference crops the image -- not this loader's case
+    Image.fromarray(np.zeros((H0 // 2 + 7, W0), np.uint16)).save(dps[1])
+    st = h.hb.io_read_frames_scaled(ips, dps, H, W, rs, ds, bg, dep, threads=2)
+    assert st[0] == 0 and st[1] != 0 and st[2] == 0
