@@ -1,0 +1,136 @@
+// Test infrastructure: the PNG codec of the library (rain-rendering_amd/csrc/rr_png.cpp, compiled INTO this program) under
+// AddressSanitizer + UndefinedBehaviorSanitizer.  tests/test_codec_sanitized.py builds and runs it.
+//   readers   every PNG given on the command line, corrupted in four ways a few hundred times each (bit flips, truncation,
+//             overwritten stretches, header bytes): any answer is fine, a memory error is not;
+//   inflate   zlib streams of several kinds, intact and damaged: an intact stream must be vouched for with zlib's bytes,
+//             nothing may be written more than 7 bytes past the output (the documented slack);
+//   deflate   inputs of every length around the block and vector sizes in exact-size heap buffers: zlib must inflate the
+//             stream back to the input.
+#include "../../rain-rendering_amd/csrc/rr_png.cpp"
+
+#include <random>
+
+static int fuzz_readers(int argc, char** argv, int rounds) {
+  std::mt19937 g(7);
+  int answered = 0;
+  for (int fi = 1; fi < argc; fi++) {
+    std::vector<uint8_t> f;
+    size_t fsz = 0;
+    if (read_file(argv[fi], f, fsz)) return 1;
+    Png p0;
+    parse_chunks(f, fsz, p0, false);
+    const int H = (int)p0.h, W = (int)p0.w;
+    std::vector<uint8_t> out((size_t)H * W * 3);
+    std::vector<uint16_t> out16((size_t)H * W);
+    const std::string tmp = std::string(argv[fi]) + ".fuzz";
+    for (int it = 0; it < rounds; it++) {
+      std::vector<uint8_t> m(f.begin(), f.begin() + (long)fsz);
+      switch (it % 4) {
+        case 0:
+          for (int k = 0; k < 1 + (int)(g() % 8); k++) m[g() % m.size()] ^= (uint8_t)(1u << (g() % 8));
+          break;
+        case 1: m.resize(g() % m.size()); break;
+        case 2: {
+          const size_t a = g() % m.size(), n = g() % 2000;
+          for (size_t k = a; k < m.size() && k < a + n; k++) m[k] = (uint8_t)g();
+          break;
+        }
+        default: {
+          const size_t a = 8 + g() % 40;
+          if (a < m.size()) m[a] = (uint8_t)g();
+        }
+      }
+      FILE* fh = fopen(tmp.c_str(), "wb");
+      fwrite(m.data(), 1, m.size(), fh);
+      fclose(fh);
+      int32_t w, h, c, d;
+      rr_png_read_bgr8(tmp.c_str(), out.data(), H, W);
+      rr_png_read_gray16(tmp.c_str(), out16.data(), H, W);
+      rr_png_info(tmp.c_str(), &w, &h, &c, &d);
+      answered++;
+    }
+    remove(tmp.c_str());
+  }
+  printf("readers: %d damaged files answered\n", answered);
+  return 0;
+}
+
+static int fuzz_inflate(int rounds) {
+  std::mt19937 g(11);
+  int vouched = 0, declined = 0, wrong = 0;
+  for (int it = 0; it < rounds; it++) {
+    const size_t n = 1 + g() % (it % 50 == 0 ? 300000 : 6000);
+    std::vector<uint8_t> b(n);
+    for (size_t i = 0; i < n; i++) {
+      switch (it % 5) {
+        case 0: b[i] = (uint8_t)g(); break;
+        case 1: b[i] = (uint8_t)(g() % 4); break;
+        case 2: b[i] = (uint8_t)((i / 37) & 255); break;
+        case 3: b[i] = (uint8_t)(g() % 3 == 0 ? g() % 16 : 0); break;
+        default: b[i] = (uint8_t)("the quick brown fox "[i % 20] + (g() % 50 == 0));
+      }
+    }
+    uLongf cl = compressBound((uLong)n);
+    std::vector<uint8_t> z(cl + 64, 0);
+    compress2(z.data(), &cl, b.data(), (uLong)n, (int)(g() % 10));
+    const bool damage = it % 2;
+    size_t zl = cl;
+    if (damage) {
+      const int k = (int)(g() % 3);
+      if (k == 0) z[g() % cl] ^= (uint8_t)(1u << (g() % 8));
+      else if (k == 1) zl = g() % cl;
+      else for (int q = 0; q < 5; q++) z[g() % cl] = (uint8_t)g();
+    }
+    std::vector<uint8_t> zin(zl + 64, 0), out(n + 16, 0xAA);
+    memcpy(zin.data(), z.data(), zl);
+    const bool ok = inflate_fast::inflate(zin.data(), zl, out.data(), n);
+    if (ok) {
+      vouched++;
+      if (!damage && memcmp(out.data(), b.data(), n)) wrong++;
+    } else {
+      declined++;
+      if (!damage) wrong++;
+    }
+    for (int q = 0; q < 8; q++)
+      if (out[n + 8 + q] != 0xAA) wrong++;
+  }
+  printf("inflate: vouched %d declined %d wrong %d\n", vouched, declined, wrong);
+  return wrong != 0;
+}
+
+static int fuzz_deflate(int rounds) {
+  std::mt19937 g(5);
+  int wrong = 0;
+  ByteBuf z;
+  std::vector<Run> runs;
+  for (int it = 0; it < rounds; it++) {
+    size_t n = it < 300 ? (size_t)it : 1 + g() % (it % 40 == 0 ? 400000 : 5000);
+    if (it % 97 == 0) n = 131072 * (1 + g() % 3) + (g() % 5) - 2;
+    uint8_t* exact = new uint8_t[n ? n : 1];
+    uint8_t cur = 0;
+    for (size_t i = 0; i < n; i++) {
+      switch (it % 6) {
+        case 0: exact[i] = (uint8_t)g(); break;
+        case 1: if (g() % 20 == 0) cur = (uint8_t)g(); exact[i] = cur; break;
+        case 2: exact[i] = (uint8_t)(g() % 2); break;
+        case 3: exact[i] = 0; break;
+        case 4: if (g() % 300 == 0) cur = (uint8_t)g(); exact[i] = cur; break;
+        default: exact[i] = (uint8_t)((i % 4 == 3) ? 0 : g() % 7);
+      }
+    }
+    fast_deflate(exact, n, z, runs);
+    std::vector<uint8_t> back(n + 1);
+    uLongf bl = (uLongf)(n + 1);
+    if (uncompress(back.data(), &bl, z.data(), (uLong)z.len) != Z_OK || bl != n || memcmp(back.data(), exact, n)) wrong++;
+    delete[] exact;
+  }
+  printf("deflate: wrong %d\n", wrong);
+  return wrong != 0;
+}
+
+int main(int argc, char** argv) {
+  int rc = fuzz_readers(argc, argv, 160);
+  rc |= fuzz_inflate(1200);
+  rc |= fuzz_deflate(900);
+  return rc;
+}
