@@ -108,3 +108,21 @@ def test_whole_frame_kitti25_oracle_vs_hostemu(tmp_path):
     assert np.array_equal(emu['status'], ref['status'])
     assert np.array_equal(emu['mask'], ref['mask']) and np.array_equal(emu['mask_i32'], ref['mask_i32'])
     assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+
+
+def test_whole_frame_cityscapes_default_oracle_vs_hostemu(tmp_path):
+    """EVERY drop of a frame of BASELINE configs[3] as the Cityscapes plug-in renders it by default (render_scale 2:
+    1024x512, 50 mm/hr, its own camera) through the op-for-op numpy oracle against the g++ build of the kernel arithmetic --
+    the second configuration checked at whole-frame granularity (the GPU tier compares the kernels with hostemu at this
+    size and at 2048x1024)."""
+    import test_gpu_configs as cfg
+    H, W, N, cam, rs, _ = cfg.CONFIGS['cityscapes_half']
+    sc = h.Scene(tmp_path, H, W, N, cam=cam, render_scale=rs, seed0=4100)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=True)
+    assert len(drops) > 1000
+    assert np.array_equal(emu['status'], ref['status'])
+    assert np.array_equal(emu['mask'], ref['mask']) and np.array_equal(emu['mask_i32'], ref['mask_i32'])
+    assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
