@@ -770,6 +770,164 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
   }
 }
 
+// ---- the same sums in float32 (RR_OPT_FOV_F32; default off until measured and checked on the GPU) ----
+// The sums only feed the drop's colour constants, and those only scale rainy_image, whose contract is +-1 LSB (the mask
+// never sees them).  A float prefix row loses ~6e-5 absolute on prefixes of ~1e3, i.e. ~1e-6 of a span's sum: three orders
+// below an LSB.  One workgroup then carries ALL FOUR components (16-byte LDS entries as before, so half the LDS bytes per
+// look-up and half the workgroups, barriers and row scans of the float64 kernel), the scans move one dword per DPP step.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_move_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ inline float row16_incl_scan_f32(float v) {
+  v += dpp_move_f32<0x111, 0xf>(v);
+  v += dpp_move_f32<0x112, 0xf>(v);
+  v += dpp_move_f32<0x114, 0xf>(v);
+  v += dpp_move_f32<0x118, 0xf>(v);
+  return v;
+}
+__device__ inline float wave_incl_scan_f32(float v) {
+  v = row16_incl_scan_f32(v);
+  v += dpp_move_f32<0x142, 0xa>(v);
+  v += dpp_move_f32<0x143, 0xc>(v);
+  return v;
+}
+__device__ inline float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <int DPT, int EMAX>
+__global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int Dp, int rpb, int nchunk, Scratch sc) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn32[];
+  const int We = dm.We;
+  float4* s_P = reinterpret_cast<float4*>(s_dyn32);      // [We + 1] inclusive prefix of (x*w, y*w, Y*w, w); entry 0 = zeros
+  float* s_wt = reinterpret_cast<float*>(s_P + (We + 1));  // [16][4] wave totals of the row being scanned
+  const int f = blockIdx.y, band = blockIdx.x % COL_PARTS, chunk = blockIdx.x / COL_PARTS;
+  const int NT = blockDim.x, t = threadIdx.x, lane = t & 63, nw = NT >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const FrameDesc& fr = frames[f];
+  const int n = fr.n_drops;
+  const int per = (n + nchunk - 1) / nchunk;
+  const int d0 = chunk * per, d1 = imin(n, d0 + per);
+  if (d0 >= n) return;
+  const int y0 = band * rpb, y1 = imin(dm.He, y0 + rpb);
+  const int Cw = (((We + nw - 1) / nw) + 1) & ~1;
+  const int cw0 = wave * Cw;
+  const uint4* spf = reinterpret_cast<const uint4*>(sc.spans) + (int64_t)f * (Hp >> 2) * Dp;
+  uint32_t sp[DPT];
+#pragma unroll
+  for (int d = 0; d < DPT; d++) {
+    const int i = d0 + d * NT + t;
+    sp[d] = (uint32_t)((i < d1 && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops);
+  }
+  if (t == 0) s_P[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float S[DPT][4];
+  uint32_t any = 0;
+#pragma unroll
+  for (int d = 0; d < DPT; d++) S[d][0] = S[d][1] = S[d][2] = S[d][3] = 0.f;
+  double totY = 0.0, totw = 0.0;                         // row totals (Y*w, w), kept by the thread that owns the last column
+  float pa[EMAX][4], pb[EMAX][4];
+  auto load_row = [&](int y) {
+    const global_ptr<const double> env = as_global(fr.env) + (int64_t)y * We * 3;
+    const global_ptr<const double> om = as_global(fr.omega) + (int64_t)y * We;
+#pragma unroll
+    for (int e = 0; e < EMAX; e++) {
+      const int cl = e * 128 + 2 * lane, c = cw0 + cl;
+#pragma unroll
+      for (int k = 0; k < 4; k++) pa[e][k] = pb[e][k] = 0.f;
+      if (cl < Cw && c < We) {
+        const double w = om[c];
+        pa[e][0] = (float)(env[c * 3 + 0] * w);
+        pa[e][1] = (float)(env[c * 3 + 1] * w);
+        pa[e][2] = (float)(env[c * 3 + 2] * w);
+        pa[e][3] = (float)w;
+        if (c + 1 < We) {
+          const double w1 = om[c + 1];
+          pb[e][0] = (float)(env[c * 3 + 3] * w1);
+          pb[e][1] = (float)(env[c * 3 + 4] * w1);
+          pb[e][2] = (float)(env[c * 3 + 5] * w1);
+          pb[e][3] = (float)w1;
+        }
+      }
+    }
+  };
+  if (y0 < y1) load_row(y0);
+  for (int yq = y0; yq < y1; yq += 4) {
+    uint4 q[DPT];
+#pragma unroll
+    for (int d = 0; d < DPT; d++) q[d] = spf[(int64_t)(yq >> 2) * Dp + sp[d]];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int y = yq + j;
+      if (y >= y1) break;
+      float carry[4] = {0.f, 0.f, 0.f, 0.f};
+      float ps[EMAX][4];
+#pragma unroll
+      for (int e = 0; e < EMAX; e++) {
+        if (e * 128 < Cw) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float v = wave_incl_scan_f32(pa[e][k] + pb[e][k]) + carry[k];
+            ps[e][k] = v;
+            carry[k] = readlane_f32(v, 63);
+          }
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_wt[wave * 4 + k] = carry[k];
+      }
+      __syncthreads();
+      float basev[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float wt = row16_incl_scan_f32(lane < nw ? s_wt[lane * 4 + k] : 0.f);
+        const float u = readlane_f32(wt, wave > 0 ? wave - 1 : 0);
+        basev[k] = wave > 0 ? u : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < EMAX; e++) {
+        const int cl = e * 128 + 2 * lane, c = cw0 + cl;
+        if (cl < Cw && c < We) {
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) o[k] = basev[k] + ps[e][k];                 // through column c + 1
+          s_P[c + 1] = make_float4(o[0] - pb[e][0], o[1] - pb[e][1], o[2] - pb[e][2], o[3] - pb[e][3]);
+          if (c + 1 < We) s_P[c + 2] = make_float4(o[0], o[1], o[2], o[3]);
+          if (c == We - 1 || c + 1 == We - 1) { totY += (double)o[2]; totw += (double)o[3]; }
+        }
+      }
+      if (y + 1 < y1) load_row(y + 1);
+      __syncthreads();
+#pragma unroll
+      for (int d = 0; d < DPT; d++) {
+        const uint32_t v = j == 0 ? q[d].x : (j == 1 ? q[d].y : (j == 2 ? q[d].z : q[d].w));
+        any |= (v != 0u ? 1u : 0u) << d;
+        const float4 h = s_P[v >> 16], l = s_P[v & 0xffffu];
+        S[d][0] += h.x - l.x;
+        S[d][1] += h.y - l.y;
+        S[d][2] += h.z - l.z;
+        S[d][3] += h.w - l.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DPT; d++) {
+    const int i = d0 + d * NT + t;
+    if (i < d1) {
+      double* o = sc.colpart + ((int64_t)(f * COL_PARTS + band) * 5) * max_drops + i;
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[(int64_t)max_drops * k] = (double)S[d][k];
+      o[(int64_t)max_drops * 4] = ((any >> d) & 1u) ? 1.0 : 0.0;
+    }
+  }
+  {
+    const int cl = (We - 1 - cw0) & ~1;
+    if (chunk == 0 && We - 1 >= cw0 && cl < Cw && ((cl >> 1) & 63) == lane) {
+      sc.fband[(f * COL_PARTS + band) * 2 + 0] = totw;   // sum w
+      sc.fband[(f * COL_PARTS + band) * 2 + 1] = totY;   // sum Y*w
+    }
+  }
+}
+
 // ---- general path (maps taller than HE_MAX / wider than FOV_WE_MAX): polygon per thread, prefix table in HBM ----
 __global__ __launch_bounds__(128) void k_fov_poly_general(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, Scratch sc) {
   const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2866,6 +3024,7 @@ struct rr_ctx {
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
+  bool fov_f32 = false;              // RR_OPT_FOV_F32: float32 prefix rows / sums in the colour branch (image within 1 LSB; default off)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
   bool copy_kernels = false;         // RR_OPT_COPY_KERNELS: batched copy kernels for pinned host buffers (default: hipMemcpyAsync;
                                      // measured slower than the DMA engines once the pieces are merged)
@@ -3233,7 +3392,17 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         hipLaunchKernelGGL(kern, grid, dim3(NT), row_bytes, s, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
-      hipError_t e = e1 ? (DPT == 1 ? launch(k_fov_sums<1, 1>) : DPT == 2 ? launch(k_fov_sums<2, 1>) : DPT == 4 ? launch(k_fov_sums<4, 1>) : launch(k_fov_sums<8, 1>))
+      auto launch32 = [&](auto kern) -> hipError_t {         // all four components in one workgroup: half the grid
+        const size_t bytes = ((size_t)(dm.We + 1) * 4 + 16 * 4) * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(COL_PARTS * nchunk, n), dim3(NT), bytes, s, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
+        return hipSuccess;
+      };
+      hipError_t e = ctx->fov_f32
+                         ? (e1 ? (DPT == 1 ? launch32(k_fov_sums32<1, 1>) : DPT == 2 ? launch32(k_fov_sums32<2, 1>) : DPT == 4 ? launch32(k_fov_sums32<4, 1>) : launch32(k_fov_sums32<8, 1>))
+                               : (DPT == 1 ? launch32(k_fov_sums32<1, 2>) : DPT == 2 ? launch32(k_fov_sums32<2, 2>) : DPT == 4 ? launch32(k_fov_sums32<4, 2>) : launch32(k_fov_sums32<8, 2>)))
+                     : e1 ? (DPT == 1 ? launch(k_fov_sums<1, 1>) : DPT == 2 ? launch(k_fov_sums<2, 1>) : DPT == 4 ? launch(k_fov_sums<4, 1>) : launch(k_fov_sums<8, 1>))
                         : (DPT == 1 ? launch(k_fov_sums<1, 2>) : DPT == 2 ? launch(k_fov_sums<2, 2>) : DPT == 4 ? launch(k_fov_sums<4, 2>) : launch(k_fov_sums<8, 2>));
       if (e != hipSuccess) {
         ctx->err = std::string("k_fov_sums: ") + hipGetErrorString(e);
@@ -4540,6 +4709,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
+    case RR_OPT_FOV_F32: ctx->fov_f32 = value != 0; return RR_OK;
     case RR_OPT_FOV_THREADS:
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;

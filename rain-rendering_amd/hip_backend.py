@@ -21,6 +21,7 @@ RR_OPT_BLUR_WORKGROUPS = 6
 RR_OPT_COMPOSITE_F64 = 7
 RR_OPT_COPY_KERNELS = 8
 RR_OPT_PADDED_TEXTURES = 9
+RR_OPT_FOV_F32 = 10
 
 # numpy mirror of rr_drop (112 bytes)
 DROP_DTYPE = np.dtype([
