@@ -3024,7 +3024,8 @@ struct rr_ctx {
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
-  bool fov_f32 = false;              // RR_OPT_FOV_F32: float32 prefix rows / sums in the colour branch (image within 1 LSB; default off)
+  int fov_f32 = 0;                   // RR_OPT_FOV_F32: float32 prefix rows / sums in the colour branch (image within 1 LSB): 0 never (default),
+                                     // 1 always, 2 whenever the compositor blends float colours (no float64 composite asked for)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
   bool copy_kernels = false;         // RR_OPT_COPY_KERNELS: batched copy kernels for pinned host buffers (default: hipMemcpyAsync;
                                      // measured slower than the DMA engines once the pieces are merged)
@@ -3399,7 +3400,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         hipLaunchKernelGGL(kern, dim3(COL_PARTS * nchunk, n), dim3(NT), bytes, s, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
-      hipError_t e = ctx->fov_f32
+      hipError_t e = (ctx->fov_f32 == 1 || (ctx->fov_f32 == 2 && use32))
                          ? (e1 ? (DPT == 1 ? launch32(k_fov_sums32<1, 1>) : DPT == 2 ? launch32(k_fov_sums32<2, 1>) : DPT == 4 ? launch32(k_fov_sums32<4, 1>) : launch32(k_fov_sums32<8, 1>))
                                : (DPT == 1 ? launch32(k_fov_sums32<1, 2>) : DPT == 2 ? launch32(k_fov_sums32<2, 2>) : DPT == 4 ? launch32(k_fov_sums32<4, 2>) : launch32(k_fov_sums32<8, 2>)))
                      : e1 ? (DPT == 1 ? launch(k_fov_sums<1, 1>) : DPT == 2 ? launch(k_fov_sums<2, 1>) : DPT == 4 ? launch(k_fov_sums<4, 1>) : launch(k_fov_sums<8, 1>))
@@ -4709,7 +4710,10 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
-    case RR_OPT_FOV_F32: ctx->fov_f32 = value != 0; return RR_OK;
+    case RR_OPT_FOV_F32:
+      if (value < 0 || value > 2) break;
+      ctx->fov_f32 = value;
+      return RR_OK;
     case RR_OPT_FOV_THREADS:
       if (value != 0 && value != 512 && value != 1024) break;
       ctx->fov_threads = value;
