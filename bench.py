@@ -488,7 +488,7 @@ def main():
             rh.profile(False)
             line(spec, el, rh.profile_read())
             for k, v in pairs:
-                rh.set_option(int(k), 0 if int(k) != 1 else 1)
+                rh.set_option(int(k), 1 if int(k) in (1, 9) else 0)          # back to the option's default (tile sharing and padded textures: on)
         warm(render, 1)
     nb = min(B, batch.n)
     cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)
