@@ -170,3 +170,50 @@ def test_native_route_at_render_scale_two(tmp_path, built, monkeypatch):
     for i in range(n):
         for out in (out_n, out_g):
             assert np.array(Image.open(os.path.join(out, 'rainy_image', '%06d.png' % i))).shape == (48, 80, 4)
+
+
+def _rank_worker(rank, world, port, tmp, src, q):
+    """One rank of a two-rank driver run (gloo, no GPU: the stand-in context)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RAIN_BATCH='2', RAIN_NATIVE_IO='1')
+    sys.path.insert(0, os.path.join(h.ROOT, 'scripts'))
+    import driver_host_only as dho_
+    hb_ = importlib.import_module('rain-rendering_amd.hip_backend')
+    hb_.RainHip = dho_.HostOnlyContext
+    main_ = importlib.import_module('rain-rendering_amd.main')
+    argv = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd', os.path.join(tmp, 'rainstreakdb'),
+            '-i', '5', '--output', os.path.join(tmp, 'out'), '--noverbose', '--conflict_strategy', 'rename_folder']
+    gen = main_.main(argv)
+    q.put((rank, sorted(s['file'] for s in gen.stats), gen.timing[0].get('route')))
+
+
+def test_two_ranks_share_one_run(tmp_path, built):
+    """The whole driver under two ranks (gloo; the stand-in context instead of a GPU): rank 0 decides the output folder
+    and the work list and loads the streak database, the broadcast hands them over, each rank renders its share on the
+    batch-native route, and together they write every frame of the sequence exactly once into ONE folder."""
+    import socket
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    n = 7
+    src, img_dir, dep_dir = _dataset(tmp, n)
+    os.makedirs(os.path.join(tmp, 'out', 'kitti', 'data_object', 'training', 'rain', '5mm'))    # exists already: 'rename_folder' must pick ONE new name
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, tmp, src, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, f0, route0), (_, f1, route1) = res
+    assert route0 == route1 == 'native'
+    assert len(f0) + len(f1) == n and not set(f0) & set(f1) and abs(len(f0) - len(f1)) <= 1
+    folders = {os.path.dirname(os.path.dirname(f)) for f in f0 + f1}
+    assert len(folders) == 1 and folders.pop().endswith('5mm_copy00000')
+    for f in f0 + f1:
+        assert np.array(Image.open(f)).shape == (48, 80, 4)
+        assert os.path.exists(f.replace('rainy_image', 'rain_mask'))
