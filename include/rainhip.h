@@ -427,7 +427,7 @@ int rr_sizeof_particle_frame(void);
  *   rr_png_write_scanlines  an RGBA file from H rows of 1 + 4*W filtered bytes (rr_frame_out.rainy_png / mask_png);
  *                           zlib level 0..9, strategy 0 default / 1 Z_RLE / 2 Z_HUFFMAN_ONLY / 3 the library's own
  *                           run-length + dynamic-Huffman deflate (level ignored; an ordinary zlib stream, about the size
- *                           of Z_RLE's at a third of the CPU time: the driver's bottleneck is the deflate of its two files)
+ *                           of Z_RLE's at a fifth of the CPU time)
  *   rr_deflate_fast     that encoder on n arbitrary bytes -> zlib stream in out (capacity >= rr_deflate_bound(n));
  *                       returns the stream's length or a negative RR_E* code */
 int rr_png_info(const char* path, int32_t* w, int32_t* h, int32_t* channels, int32_t* bit_depth);
@@ -436,7 +436,8 @@ int rr_png_read_gray16(const char* path, uint16_t* out, int32_t H, int32_t W);
 int rr_png_write_scanlines(const char* path, const uint8_t* rows, int32_t W, int32_t H, int32_t level, int32_t strategy);
 int64_t rr_deflate_bound(int64_t n);
 int64_t rr_deflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap);
-/* The readers' own inflate (64-bit bit buffer, table look-ups, 8-byte match copies; about twice zlib's speed) on a complete
+/* The readers' own inflate (64-bit bit buffer, 12-bit table look-ups that yield two literals where both codes fit, 8-byte
+ * match copies; 2-3 times zlib's speed on image scanlines) on a complete
  * zlib stream of known decoded size: 1 = out holds the data (Adler-32 verified), 0 = not vouched for (the readers then
  * hand the stream to zlib), < 0 = bad argument. */
 int rr_inflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len);
