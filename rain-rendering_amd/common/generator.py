@@ -75,6 +75,8 @@ class Generator:
         self.irrad_type = 'ambient'
         self.db = None
         self.renderer = None
+        self.device_particles = bool(getattr(args, 'device_particles', False))     # drop tables generated on the GPU (no XML)
+        self.sim_options = getattr(args, 'sim_options', {})
         self.batch = int(os.environ.get('RAIN_BATCH', '128'))     # frames per library call (three calls in flight); bench.py's host-inclusive leg uses the same
         self.rank, self.world = sharding.rank_world()
         self.device = int(getattr(args, 'device', os.environ.get('LOCAL_RANK', '0')))
@@ -389,9 +391,22 @@ class Generator:
                 hip.set_prepass_kernels(imgops.gaussian_kernel(25, 25), imgops.gaussian_kernel(15, 0))
                 hip.set_colormap(imgops.viridis_lut())
                 fog_const = FOG.constants()
-                self.db.load_streaks_from_xml(self.dataset, self.settings, [imW, imH], use_pickle=False, verbose=self.verbose)
-                frame_render_dict = list(self.db.streaks_simulator.values())
-                n_sim = len(frame_render_dict)
+                sims = None
+                if self.device_particles:
+                    # no particle file: the settings of the run's simulated frames (tools/particles.sim_frames: what
+                    # simulate() would have written to XML, as rr_sim_frame records) + the diameter tables they refer to
+                    if bool(self.noise_std) and bool(self.noise_scale):
+                        raise NotImplementedError("--device_particles: angular noise is not offered on the device-generated path")
+                    from ..tools import particles
+                    opts = self.sim_options[sequence]
+                    n_sim = particles.n_sim_frames(opts)
+                    sims, dgrid, cdf = particles.sim_frames(opts, fallrate, n_sim, render_scale=rs, seed=0)
+                    hip.set_particle_tables(dgrid, cdf)
+                    frame_render_dict = []
+                else:
+                    self.db.load_streaks_from_xml(self.dataset, self.settings, [imW, imH], use_pickle=False, verbose=self.verbose)
+                    frame_render_dict = list(self.db.streaks_simulator.values())
+                    n_sim = len(frame_render_dict)
 
                 f_end = len(files) if self.frame_end is None else min(self.frame_end, len(files))
                 if self.frames:
@@ -407,12 +422,12 @@ class Generator:
                     lambda: self._work_list(files, depth_files, idx, out_dir, out_seq_dir, n_sim), self.rank, self.world)
                 work = sharding.shard(work, self.rank, self.world)
                 sim_t0 = time.time()
-                self._run_batches(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0)
+                self._run_batches(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0, sims)
                 if frames_exist_nb > 0:
                     print("Skipped {}/{} already existing renderings".format(frames_exist_nb, len(idx)))
             print("\n\nEnd of the simulation")
 
-    def _run_batches(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
+    def _run_batches(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0, sims=None):
         """The frames of one (sequence, weather) run through the asynchronous pipeline.  The common case -- 8-bit PNG
         images, 16-bit PNG depth whose scaled size is the frame's, no angular noise, no environment-map files -- takes
         the batch-native route (one library call per batch and stage, nothing per frame under the interpreter lock);
@@ -429,10 +444,16 @@ class Generator:
             native = (i0 is not None and d0 is not None and i0[4] == 8 and tuple(d0[3:5]) == (1, 16) and
                       (i0[1] // rs, i0[2] // rs) == (imW, imH) and ((d0[1] * ds) // rs, (d0[2] * ds) // rs) == (imW, imH) and
                       (rs != 1 or (d0[1], d0[2]) == (imW, imH)))
+        if sims is not None:
+            if work and not native:
+                raise NotImplementedError("--device_particles needs the batch-native route: PNG frames and depth maps of matching "
+                                          "scaled sizes, no environment-map files (RAIN_NATIVE_IO not 0)")
+            return self._run_batches_native(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num,
+                                            sim_t0, sims)
         run = self._run_batches_native if native else self._run_batches_general
         return run(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0)
 
-    def _run_batches_native(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
+    def _run_batches_native(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0, sims=None):
         """Batch-native route.  Per batch, three whole-batch jobs, each one call (or two) into the library:
           decode  rr_io_read_frames (image bytes + depth metres straight into the slot's page-locked input blocks) and
                   rr_host_pack_frames (filter, draws, drop records into the slot's drop block) -- one batch ahead of the GPU;
@@ -447,20 +468,21 @@ class Generator:
         if getattr(self, '_slots', None) is None or getattr(self, '_slots_hip', None) is not hip:
             self._slots, self._slots_hip = [None] * nslot, hip
         slots = self._slots
-        n_sim = len(frame_render_dict)
+        n_sim = len(sims) if sims is not None else len(frame_render_dict)
         H, W = imH, imW
         env_w = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
         cache = self.__dict__.setdefault('_omega_cache', {})     # a function of the map's shape alone: once per size, not per run
         if (H, env_w) not in cache:
             cache[(H, env_w)] = solid_angle.get_solid_angles(np.empty((H, env_w, 0)))               # generator.py:410
         hip.set_solid_angles(cache[(H, env_w)])
-        drops_cap = max(1024, max(len(fr.table) for fr in frame_render_dict))
+        # capacity of a frame's drop table: every streak of its simulated frame (the frame filter can only remove some)
+        drops_cap = max(1024, int(sims['n_particles'].max()) if sims is not None else max(len(fr.table) for fr in frame_render_dict))
         assert drops_cap <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
         u8 = rs == 1                                              # at render scale 1 the bytes go to the GPU; a resized image is float64
         bg_dtype = np.uint8 if u8 else np.float64
         ds = int(self.settings["depth_scale"])
         key = (B, H, W, env_w, np.dtype(bg_dtype), np.dtype(np.float32), False)
-        pkey = (tuple(float(v) for v in fog_const), float(self.opacity_attenuation), self.rendering_strategy)
+        pkey = (tuple(float(v) for v in fog_const), float(self.opacity_attenuation), self.rendering_strategy, sims is not None)
         for d in {os.path.dirname(it[k]) for it in work for k in ('out_rainy_path', 'out_rainy_mask_path')}:
             os.makedirs(d, exist_ok=True)
         encodes = [None] * nslot                                 # the slot's encode job (future) and its frames
@@ -477,6 +499,13 @@ class Generator:
                                opacity_attenuation=self.opacity_attenuation, strategy=1 if self.rendering_strategy == 'white' else 0)
                           for k in range(B)]
                 outs = [dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k]) for k in range(B)]
+                if sims is not None:                             # the descriptors point at these records: rewritten in place per batch
+                    sl.sim_recs = [np.zeros(1, hip_backend.SIM_FRAME_DTYPE) for _ in range(B)]
+                    sl.n_out = [np.zeros(1, np.int32) for _ in range(B)]
+                    for k in range(B):
+                        sl.sim_recs[k][0] = sims[0]
+                        frames[k].update(sim=sl.sim_recs[k], drops_cap=sl.drops_cap)
+                        outs[k]['n_drops'] = sl.n_out[k]
                 sl.prep, sl.pkey = hip.pipeline_prepare(frames, outs), pkey
             return sl
 
@@ -488,9 +517,12 @@ class Generator:
             else:
                 st = hip_backend.io_read_frames_scaled([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
                                                        int(rs), ds, sl.raw_bg, sl.raw_depth, threads)
-            tables = [frame_render_dict[it['f_name_idx'] % n_sim].table for it in items]
-            counts = hip_backend.pack_frames(tables, [it['seeds'][-1] for it in items], self.db, imW, imH, sl.raw_drops,
-                                             sl.drops_cap, sl.drops_cap, threads)
+            if sims is not None:                                # the drop tables are made on the GPU: only their settings travel
+                counts = np.zeros(len(items), np.int64)
+            else:
+                tables = [frame_render_dict[it['f_name_idx'] % n_sim].table for it in items]
+                counts = hip_backend.pack_frames(tables, [it['seeds'][-1] for it in items], self.db, imW, imH, sl.raw_drops,
+                                                 sl.drops_cap, sl.drops_cap, threads)
             ok = [True] * len(items)
             for k in np.nonzero(st)[0]:                          # not a file the fast readers take: the general loader
                 loaded = self._load_frame(items[k]['image_file'], items[k]['depth_file'], rs)
@@ -507,7 +539,8 @@ class Generator:
                 src = order.pop()
                 np.copyto(sl.bg[dst], sl.bg[src])
                 np.copyto(sl.depth[dst], sl.depth[src])
-                sl.drops[dst][:counts[src]] = sl.drops[src][:counts[src]]
+                if sims is None:
+                    sl.drops[dst][:counts[src]] = sl.drops[src][:counts[src]]
                 order.insert(dst, src)
             assert int(counts.max(initial=0)) <= sl.drops_cap
             return [items[k] for k in order], [int(counts[k]) for k in order]
@@ -529,6 +562,8 @@ class Generator:
                 hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
             sl.busy = False
             ms = 1e3 * (time.time() - sl.t_submit) / max(sl.n_valid, 1)
+            if sims is not None:                                # the counts only exist now
+                sl.items = [(it, int(sl.n_out[k][0])) for k, (it, _) in enumerate(sl.items)]
             encodes[si] = stage.submit(encode_job, sl, [it for it, _ in sl.items], [nd for _, nd in sl.items], ms)
 
         def drain(si):
@@ -553,7 +588,12 @@ class Generator:
             sl.n_valid = len(items)
             if sl.n_valid:
                 for k, nd in enumerate(nds):
-                    sl.prep.set_drop_count(k, nd)
+                    if sims is not None:                         # simulated frame f % n_sim with the draws of frame f (generator.py:318-321)
+                        f_idx = items[k]['f_name_idx']
+                        sl.sim_recs[k][0] = sims[f_idx % n_sim]
+                        sl.sim_recs[k]['draw_seed'] = f_idx
+                    else:
+                        sl.prep.set_drop_count(k, nd)
                 sl.t_submit = time.time()
                 hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
                 sl.busy = True

@@ -54,6 +54,8 @@ _FLAGS = [
     (('--save_envmap',), dict(action='store_true', help='also write the estimated environment maps')),
     (('--noverbose',), dict(action='store_true', help='no progress output')),
     (('--force_particles',), dict(action='store_true', help='(reference only) re-run the particle simulator')),
+    (('--device_particles',), dict(action='store_true', help='simulate the rain particles on the GPU, frame by frame (no particle '
+                                                             'file is read or written; this build only)')),
 ]
 
 
@@ -129,6 +131,12 @@ def _locate_particles(ns):
         from .tools import particles
         from . import sharding
     root = _J(ns.particles, ns.dataset)
+    if getattr(ns, 'device_particles', False):
+        # BASELINE.json configs[4] from the command line: no XML at all -- the generator's settings go to the GPU with every
+        # batch (rr_frame_in.sim) and the drop tables are born there (same model, seed 0, as the files simulate() writes)
+        ns.sim_options = {seq: db.sim(ns.dataset, seq, root)["options"] for seq in ns.sequences}
+        ns.particles = {seq: [None] * len(ns.weather) for seq in ns.sequences}
+        return
 
     def locate():
         print("\nResolving particles simulations...")

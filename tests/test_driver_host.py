@@ -32,7 +32,8 @@ class RecordingContext(dho.HostOnlyContext):
             fr = prep.frames[k]
             nd = prep.counts.get(k, len(fr['drops']))
             bg = fr['bg_u8'] if fr.get('bg_u8') is not None else fr['bg']
-            RecordingContext.log.append(dict(bg=np.array(bg), depth=np.array(fr['depth']), drops=np.array(fr['drops'][:nd])))
+            RecordingContext.log.append(dict(bg=np.array(bg), depth=np.array(fr['depth']), drops=np.array(fr['drops'][:nd]),
+                                             sim=None if fr.get('sim') is None else np.array(fr['sim'][0])))
         super().pipeline_submit_prepared(slot, prep, n)
 
     def pipeline_prepare(self, frames, outs):
@@ -55,6 +56,8 @@ class RecordingContext(dho.HostOnlyContext):
             rows[:, 1:] = np.tile(np.array([k % 251, bg[0, 0, 1], 7, 255], np.uint8), W)
             o['mask_png'][...] = rows.ravel()
             o['status'][...] = 0
+            if o.get('n_drops') is not None:                       # (what the device-side generator would report)
+                o['n_drops'][0] = 100 + int(fr['sim'][0]['draw_seed'])
         return True
 
 
@@ -217,3 +220,41 @@ def test_two_ranks_share_one_run(tmp_path, built):
     for f in f0 + f1:
         assert np.array(Image.open(f)).shape == (48, 80, 4)
         assert os.path.exists(f.replace('rainy_image', 'rain_mask'))
+
+
+def test_device_particles_mode_sends_the_generator_settings(tmp_path, built, monkeypatch):
+    """`--device_particles` (BASELINE configs[4] from the command line): no particle file is read or written; every frame's
+    descriptor carries the rr_sim_frame record of its simulated frame (tools/particles.sim_frames: what simulate() would have
+    put into the XML file) with the frame's own draw seed, no drop table is made on the host, and the counts the library
+    reports end up in the statistics."""
+    tmp = str(tmp_path)
+    n = 5
+    src, img_dir, dep_dir = _dataset(tmp, n)
+    import shutil
+    shutil.rmtree(os.path.join(tmp, 'particles'))                  # there is no particle file -- and none may appear
+    monkeypatch.setenv('RAIN_BATCH', '2')
+    monkeypatch.setattr(hb, 'RainHip', RecordingContext)
+    RecordingContext.log = []
+    tables = []
+    monkeypatch.setattr(RecordingContext, 'set_particle_tables', lambda self, dgrid, cdf: tables.append((np.array(dgrid), np.array(cdf))), raising=False)
+    gen = main_mod.main(['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd', os.path.join(tmp, 'rainstreakdb'),
+                         '-i', '5', '--output', os.path.join(tmp, 'out'), '--noverbose', '--device_particles'])
+    assert not os.path.exists(os.path.join(tmp, 'particles'))
+    assert gen.timing[0].get('route') == 'native' and len(RecordingContext.log) == n and len(tables) == 1
+    particles = importlib.import_module('rain-rendering_amd.tools.particles')
+    db = importlib.import_module('rain-rendering_amd.common.db')
+    opts = db.sim('kitti', 'data_object/training', os.path.join(tmp, 'particles', 'kitti'))['options']
+    n_sim = particles.n_sim_frames(opts)
+    want, dgrid, cdf = particles.sim_frames(opts, 5, n_sim, render_scale=1, seed=0)
+    assert np.array_equal(tables[0][0], dgrid) and np.array_equal(tables[0][1], cdf)
+    seen = set()
+    for fr in RecordingContext.log:
+        f = int(fr['sim']['draw_seed'])
+        seen.add(f)
+        ref = want[f % n_sim].copy()
+        ref['draw_seed'] = f
+        assert fr['sim'].tobytes() == ref.tobytes(), f
+    assert seen == set(range(n))
+    assert sorted(s['drops'] for s in gen.stats) == [100 + f for f in range(n)]
+    for i in range(n):
+        assert os.path.exists(os.path.join(tmp, 'out', 'kitti', 'data_object', 'training', 'rain', '5mm', 'rainy_image', '%06d.png' % i))
