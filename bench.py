@@ -70,10 +70,13 @@ def algorithmic_bytes(H, W, He, We, N):
 class DeviceBatch:
     """n frames resident in HBM as torch tensors + the ctypes descriptors rr_render_frames_device takes."""
 
-    def __init__(self, torch, hb, sc, dev, frame_ids, drop_ids, noise_std=0.0, sims=None):
+    def __init__(self, torch, hb, sc, dev, frame_ids, drop_ids, noise_std=0.0, sims=None, in_dtype='f32'):
         """sims: SIM_FRAME_DTYPE records, one per frame: the drop tables are generated on the device (generate()), `drops`
-        and the drop counts live in HBM only."""
+        and the drop counts live in HBM only.  in_dtype: element type of the image / map inputs in HBM ('f32': float32 image,
+        float32 xyY map and solid angles, rr_frame_in.in_types -- what the colour channels need; 'f64': the reference's arrays)."""
         self.n = len(frame_ids)
+        f32 = in_dtype == 'f32'
+        self.in_types = (hb.RR_IN_BG_F32 | hb.RR_IN_ENV_F32) if f32 else 0
         self.sims = sims
         if sims is not None:
             self.cap = max(int(sims['n_particles'].max()), 1)
@@ -84,7 +87,7 @@ class DeviceBatch:
         self.fout = (hb.rr_frame_out * max(self.n, 1))()
         self.host = []
         H, W, He, We = sc.H, sc.W, sc.He, sc.We
-        omega_t = torch.from_numpy(np.ascontiguousarray(sc.omega)).to(dev)
+        omega_t = torch.from_numpy(np.ascontiguousarray(sc.omega, np.float32 if f32 else np.float64)).to(dev)
         self.keep.append(omega_t)
         for k, (fi, di) in enumerate(zip(frame_ids, drop_ids)):
             bg, env = sc.frame_inputs(fi)
@@ -95,8 +98,8 @@ class DeviceBatch:
                 drops = np.zeros(self.cap, hb.DROP_DTYPE)           # (length = capacity; the records are made on the device)
                 t_dr = self.t_drops[k]
             self.host.append((bg, env, drops))
-            t_bg = torch.from_numpy(bg).to(dev)
-            t_env = torch.from_numpy(env).to(dev)
+            t_bg = torch.from_numpy(bg.astype(np.float32) if f32 else bg).to(dev)
+            t_env = torch.from_numpy(env.astype(np.float32) if f32 else env).to(dev)
             o_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
             o_m = torch.empty((H, W), dtype=torch.float64, device=dev)
             o_mi = torch.empty((H, W), dtype=torch.int32, device=dev)
@@ -107,6 +110,7 @@ class DeviceBatch:
             fi_.bg = fi_.rainy_bg = t_bg.data_ptr()
             fi_.env_xyY = t_env.data_ptr()
             fi_.omega = omega_t.data_ptr()
+            fi_.in_types = self.in_types
             fi_.drops = t_dr.data_ptr()
             fi_.n_drops = len(drops)
             if sims is not None:
@@ -170,7 +174,7 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
             out = tempfile.mkdtemp(prefix='rainpmc_', dir='/tmp')
             cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
                    os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1', '--batch', str(args.batch),
-                   '--workload', args.workload] + sum((['--opt', o] for o in args.opt), [])
+                   '--workload', args.workload, '--input-dtype', args.input_dtype] + sum((['--opt', o] for o in args.opt), [])
             if scene_dir:
                 cmd += ['--scene-dir', scene_dir]                   # the simulation this process already wrote
             env = dict(os.environ, TMPDIR='/tmp')
@@ -216,7 +220,7 @@ def measure_valu(args, scene_dir=None):
         out = tempfile.mkdtemp(prefix='rainpmc_', dir='/tmp')
         cmd = [exe, '--kernel-trace', '--pmc', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE',
                '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1',
-               '--batch', str(args.batch), '--workload', args.workload] + sum((['--opt', o] for o in args.opt), [])
+               '--batch', str(args.batch), '--workload', args.workload, '--input-dtype', args.input_dtype] + sum((['--opt', o] for o in args.opt), [])
         if scene_dir:
             cmd += ['--scene-dir', scene_dir]
         proc = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
@@ -360,6 +364,8 @@ def main():
     ap.add_argument('--no-driver', action='store_true', help='skip the main.py driver end-to-end leg (PNG in -> PNG out, own process)')
     ap.add_argument('--cpu-sample-drops', type=int, default=2048)
     ap.add_argument('--pipe-batch', type=int, default=128, help='frames per slot of the host-inclusive pipeline (the driver\'s default batch)')
+    ap.add_argument('--input-dtype', choices=('f32', 'f64'), default='f32', help='element type of the image / map inputs resident in HBM '
+                    '(rr_frame_in.in_types); f64 = the reference\'s float64 arrays (timed as a variant)')
     ap.add_argument('--opt', action='append', default=[], help='rr_set_option as ID=VALUE (tuning switches that never change results)')
     ap.add_argument('--sweep', action='append', default=[], help='A/B: after the headline, time the loop again under these '
                     'rr_set_option sets ("6=3,3=512"); one JSON line each on stderr; implies the lean run')
@@ -444,7 +450,7 @@ def main():
 
     # --- inputs resident in HBM ----------------------------------------------------------------
     fids = [f if strong else f + 100 * rank for f in my_frames]
-    batch = DeviceBatch(torch, hb, sc, dev, fids, my_frames, sims=sims)
+    batch = DeviceBatch(torch, hb, sc, dev, fids, my_frames, sims=sims, in_dtype=args.input_dtype)
     stream = torch.cuda.current_stream().cuda_stream
     chunks = [batch.chunk(hb, a, min(a + B, batch.n)) for a in range(0, batch.n, B)]
     bounds = [(a, min(a + B, batch.n)) for a in range(0, batch.n, B)]
@@ -488,7 +494,7 @@ def main():
             rh.profile(False)
             line(spec, el, rh.profile_read())
             for k, v in pairs:
-                rh.set_option(int(k), 1 if int(k) in (1, 9) else 0)          # back to the option's default (tile sharing and padded textures: on)
+                rh.set_option(int(k), {1: 1, 9: 1, 10: 2}.get(int(k), 0))  # back to the option's default
         warm(render, 1)
     nb = min(B, batch.n)
     cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)
@@ -510,7 +516,7 @@ def main():
         var["no_tile_sharing"] = {"frames_per_s": rate(render, batch.n), "what": "RR_OPT_DEDUP=0: every drop renders its own raw tile"}
         rh.set_option(hb.RR_OPT_DEDUP, 1)
         nn = min(64, batch.n)
-        nz = DeviceBatch(torch, hb, sc, dev, fids[:nn], my_frames[:nn], noise_std=3.0)
+        nz = DeviceBatch(torch, hb, sc, dev, fids[:nn], my_frames[:nn], noise_std=3.0, in_dtype=args.input_dtype)
         nzc = [nz.chunk(hb, 0, nz.n)]
         var["noise_std_3"] = {"frames_per_s": rate(lambda: render(nzc), nz.n),
                               "what": "%d frames with --noise_std 3 --noise_scale 1 (rotations differ per drop: raw tiles stop being shareable)" % nn}
@@ -520,6 +526,13 @@ def main():
         if mid:
             var["calls_of_32"] = {"frames_per_s": rate(lambda: render(mid), 32 * len(mid)), "what": "library calls of 32 frames (the driver's default)"}
         del nz, nzc
+        other = 'f64' if args.input_dtype == 'f32' else 'f32'
+        ob = DeviceBatch(torch, hb, sc, dev, fids[:nn], my_frames[:nn], in_dtype=other)
+        obc = [ob.chunk(hb, 0, ob.n)]
+        var["inputs_" + other] = {"frames_per_s": rate(lambda: render(obc), ob.n),
+                                  "frames_per_s_same_call_size_%s" % args.input_dtype: rate(lambda: render([batch.chunk(hb, 0, nn)]), nn),
+                                  "what": "%d frames per call with the image / map inputs resident as %s instead of %s" % (nn, other, args.input_dtype)}
+        del ob, obc
         warm(render, 1)                      # back to the headline configuration (arena / scratch sized for it)
         extras["variants"] = var
 
@@ -542,8 +555,9 @@ def main():
         for i in range(nb_pre):
             o_r = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
             o_e = torch.empty((He, We, 3), dtype=torch.float64, device=dev)
-            keep += [o_r, o_e]
-            pin[i].H, pin[i].W, pin[i].bg, pin[i].depth, pin[i].depth_f64 = H, W, batch.fin[i].bg, depth_t.data_ptr(), 0
+            i_bg = torch.from_numpy(batch.host[i][0]).to(dev)          # (float64: the pre-pass' input type)
+            keep += [o_r, o_e, i_bg]
+            pin[i].H, pin[i].W, pin[i].bg, pin[i].depth, pin[i].depth_f64 = H, W, i_bg.data_ptr(), depth_t.data_ptr(), 0
             pin[i].beta_ext, pin[i].beta_hg, pin[i].irr_num, pin[i].irr_den = [float(v) for v in consts]
             pout[i].rainy_bg, pout[i].env_xyY, pout[i].env_bgr_u8 = o_r.data_ptr(), o_e.data_ptr(), None
 
@@ -677,13 +691,15 @@ def main():
             "metric": wl['metric'],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64 alpha/mask, f32 colour", "data": "synthetic",
             "config": {"workload": ("%s shape %dx%d, %d mm/hr (%d streaks/frame simulated, %.0f after the frame filter), precomputed "
                                     "particles; BASELINE.json %s" % (wl['cam'], W, H, wl['rate'], N, batch.mean_drops, wl['cfg'])) if not is_sim else
                                    ("%s shape %dx%d, %d mm/hr, IN-KERNEL particle simulation inside the timed step (%.0f particles/frame "
                                     "simulated on the device, %.0f drops after the frame filter; no XML, no host drop table); BASELINE.json %s"
                                     % (wl['cam'], W, H, wl['rate'], float(sims['n_particles'].mean()), batch.mean_drops, wl['cfg'])),
                        "frames_per_call": nb, "frames_per_step": frames_step, "envmap": "%dx%d" % (We, He),
+                       "inputs_in_hbm": ("float32 image + float32 xyY map / solid angles (rr_frame_in.in_types)" if args.input_dtype == 'f32' else
+                                         "float64 image, map and solid angles (the reference's arrays)") + ", 112-byte drop records",
                        "parallelism": "frames sharded round-robin, dp%d; one RCCL broadcast of the streak DB" % world,
                        "raw_tiles_last_call": {"rotate_resize": int(cnts[:, 0].sum()), "bicubic_warp": int(cnts[:, 5].sum()),
                                                "generic": int(cnts[:, 1].sum()), "shared_bit_identical": int(cnts[:, 7].sum())},

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RR_VERSION 300            /* 0.3.0: + device-side particle generator (rr_sim_frame), rr_frame_out.drop_colour */
+#define RR_VERSION 400            /* 0.4.0: + rr_frame_in.in_types (float32 / uint8 image and map inputs), float32 colour branch by default */
 
 enum {
   RR_OK = 0,
@@ -105,18 +105,27 @@ typedef struct {
 typedef struct {
   int32_t H, W;                   /* frame */
   int32_t He, We;                 /* lat-long environment map */
-  const double* bg;               /* H*W*3 BGR, un-fogged image / 255 (used for the mean shift, generator.py:462) */
-  const double* rainy_bg;         /* H*W*3 BGR, output of the fog pre-pass (generator.py:386): values in [0, 1] (it ends with
+  /* the four arrays below are float64 unless in_types says otherwise */
+  const void* bg;                 /* H*W*3 BGR, un-fogged image / 255 (used for the mean shift, generator.py:462) */
+  const void* rainy_bg;           /* H*W*3 BGR, output of the fog pre-pass (generator.py:386): values in [0, 1] (it ends with
                                    * np.clip); a NaN stays a NaN like in the reference */
-  const double* env_xyY;          /* He*We*3 (generator.py:407-408) */
-  const double* omega;            /* He*We solid angles (generator.py:410); NULL: the map given to rr_set_solid_angles */
+  const void* env_xyY;            /* He*We*3 (generator.py:407-408) */
+  const void* omega;              /* He*We solid angles (generator.py:410); NULL: the map given to rr_set_solid_angles */
   const rr_drop* drops;           /* n_drops records in reference order */
   int32_t n_drops;
   int32_t strategy;               /* 0: default (rendering_strategy=None); 1: 'white' (bad_weather.py:349-353) */
   double opacity_attenuation;     /* --opacity_attenuation */
   const void* depth;              /* optional, only read with RR_OPT_DEPTH_OCCLUSION: scene depth in metres, H*W float32
                                    * (depth_f64 == 0) or float64; rr_pipeline_* use the pre-pass' depth instead */
-  int32_t depth_f64, reserved;
+  int32_t depth_f64;
+  /* Element types of the image and map inputs (0: everything float64, the reference's arrays).  The three colour channels
+   * and the drop colour only have to land within 1 LSB of a uint8 (BASELINE.json) and the mask never reads these arrays, so
+   * a caller that holds them narrower hands them over as they are -- a third to an eighth of the HBM bytes:
+   *   RR_IN_BG_F32 / RR_IN_BG_U8         `bg` is float32 / uint8 (uint8: the bytes cv2.imread returned; bg = bytes / 255.0)
+   *   RR_IN_RAINY_F32 / RR_IN_RAINY_U8   the same for `rainy_bg` (when rainy_bg == bg the BG flags count for both)
+   *   RR_IN_ENV_F32                      `env_xyY` AND `omega` (when not NULL) are float32
+   * rr_render_frames_device and rr_render_frames; rr_pipeline_* produce rainy_bg / env_xyY themselves. */
+  int32_t in_types;
   const rr_ext_tile* ext;         /* optional: n_drops entries (rr_render_frames / rr_render_frames_device only) */
   /* Drop tables born on the device (rr_generate_drops_device): with n_drops_dev != NULL (a DEVICE pointer to one int32;
    * rr_render_frames_device only) the frame's drop count is read from there when the kernels run, clamped to n_drops, which
@@ -128,6 +137,8 @@ typedef struct {
    * the launch is sized for (0: sim->n_particles).  The count comes back in rr_frame_out.n_drops_out. */
   const struct rr_sim_frame* sim;
 } rr_frame_in;
+
+enum { RR_IN_BG_F32 = 1, RR_IN_BG_U8 = 2, RR_IN_ENV_F32 = 4, RR_IN_RAINY_F32 = 8, RR_IN_RAINY_U8 = 16 };
 
 typedef struct {
   uint8_t* rainy_rgb;             /* H*W*3 RGB: what plt.imsave(rainy_image) stores (generator.py:461-466), alpha omitted */
@@ -333,11 +344,12 @@ enum {
    * (made once by rr_set_streak_db*: 16-byte copies into LDS); 0 they build the border and place the texels byte by byte.
    * The LDS contents are the same bytes. */
   RR_OPT_PADDED_TEXTURES = 9,
-  /* precision of the colour branch (default 0): the environment-map sums under a drop's field of view in float32 -- 1 always,
-   * 2 whenever the compositor blends float colours (no frame of the batch asks for the float64 composite: the same switch as
-   * RR_OPT_COMPOSITE_F64's default).  The sums only feed the drop's colour constants, which only scale rainy_image (contract:
-   * +-1 LSB; the mask never sees them).  Measured (k_fov_sums 3.3 -> 2.1 ms) and checked at five configurations, but off until
-   * the whole GPU tier has run with it. */
+  /* precision of the colour branch: 0 float64 throughout (the reference's arithmetic), 1 float32 always, 2 (default) float32
+   * whenever the compositor blends float colours (no frame of the batch asks for the float64 composite: the same switch as
+   * RR_OPT_COMPOSITE_F64's default).  Float32 = the field-of-view vertices (every predicate that decides a drop's status or
+   * the wrap structure of its polygon is checked against an error bound; a drop that comes close is evaluated in float64)
+   * and the environment-map sums under the polygon.  They only feed the drop's colour constants, which only scale
+   * rainy_image (contract: +-1 LSB; the mask and the drop statuses never see the difference). */
   RR_OPT_FOV_F32 = 10
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);

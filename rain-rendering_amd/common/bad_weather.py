@@ -424,7 +424,10 @@ class RainRenderer:
             (rainy_bg, rainy_mask, rainy_saturation_mask, drop_vis, drop_blend, drop_minC)
 
         as the reference does (:462): `drop_vis` the coloured, defocused tile cropped to the frame (h x w x 4: alpha =
-        what was added to the mask, colour = alpha x the drop's colour constants), `drop_blend` the blended image region
+        what was added to the mask, colour = alpha x the drop's colour constants K -- shape and alpha channel are the
+        reference's; its COLOUR channels are blur(K * [raw alpha > 0]) (it paints K where the raw tile is positive and
+        blurs all four channels, :378-381,286-298), which differs from K * blur(alpha) wherever the raw tile has fractional
+        alpha; the only consumer, make_rain_layer's rain_layer, is a dead output), `drop_blend` the blended image region
         under it (h x w x 3) and `drop_minC` the tile's clamped position (:418-419) -- what the reference's caller passes
         on to make_rain_layer (generator.py:437-438).  Colour from the environment map, defocus, placement, blend and mask
         accumulation run in the library (rr_ext_tile entry of rr_render_frames: one launch chain per call -- use

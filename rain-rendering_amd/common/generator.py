@@ -427,12 +427,28 @@ class Generator:
                     print("Skipped {}/{} already existing renderings".format(frames_exist_nb, len(idx)))
             print("\n\nEnd of the simulation")
 
+    def _cap_batch(self, B, imH, imW, frame_render_dict, sims):
+        """Frames per library call, bounded by the page-locked memory a rank may hold: three slots of B frames, each frame
+        its input bytes (image, float32 depth), both PNG scanline blocks and the drop / status tables -- about 15 bytes per
+        pixel + 116 per drop: 7.9 MB at KITTI size (3 GB for 3 x 128 frames), 32 MB at Cityscapes full size.  Budget:
+        RAIN_PINNED_MB per rank (default 8192 / the ranks on this host).  The library's device staging per slot is about
+        nine times the pinned bytes (float64 images inside the chain)."""
+        try:
+            local = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
+        except ValueError:
+            local = 1
+        budget = float(os.environ.get('RAIN_PINNED_MB', 8192.0 / local)) * 2 ** 20
+        n_max = int(sims['n_particles'].max()) if sims is not None else max((len(getattr(fr, 'table', ())) for fr in (frame_render_dict or ())), default=0)
+        per_frame = imH * imW * 15 + 2 * imH + min(max(n_max, 1024), 2 ** 16) * 116
+        return max(1, min(B, int(budget // (hip_backend.RR_PIPE_SLOTS * per_frame))))
+
     def _run_batches(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0, sims=None):
         """The frames of one (sequence, weather) run through the asynchronous pipeline.  The common case -- 8-bit PNG
         images, 16-bit PNG depth whose scaled size is the frame's, no angular noise, no environment-map files -- takes
         the batch-native route (one library call per batch and stage, nothing per frame under the interpreter lock);
         everything else the general one (per-frame Python on an I/O thread pool)."""
         ds = self.settings["depth_scale"]
+        B = self._cap_batch(B, imH, imW, frame_render_dict, sims)
         native = (work and int(rs) == rs and rs >= 1 and int(ds) == ds and ds >= 1 and
                   not (bool(self.noise_std) and bool(self.noise_scale)) and not self.save_envmap and
                   os.environ.get('RAIN_NATIVE_IO', '1') != '0' and
@@ -475,9 +491,10 @@ class Generator:
         if (H, env_w) not in cache:
             cache[(H, env_w)] = solid_angle.get_solid_angles(np.empty((H, env_w, 0)))               # generator.py:410
         hip.set_solid_angles(cache[(H, env_w)])
-        # capacity of a frame's drop table: every streak of its simulated frame (the frame filter can only remove some)
-        drops_cap = max(1024, int(sims['n_particles'].max()) if sims is not None else max(len(fr.table) for fr in frame_render_dict))
-        assert drops_cap <= 2 ** 16, "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"
+        # capacity of a frame's drop table: every streak of its simulated frame (the frame filter can only remove some), but
+        # never more than the 2 ** 16 the reference allows AFTER the filter (generator.py:424): a simulated frame with more
+        # streaks than that is fine as long as fewer land inside the image -- checked on the filtered counts below
+        drops_cap = min(max(1024, int(sims['n_particles'].max()) if sims is not None else max(len(fr.table) for fr in frame_render_dict)), 2 ** 16)
         u8 = rs == 1                                              # at render scale 1 the bytes go to the GPU; a resized image is float64
         bg_dtype = np.uint8 if u8 else np.float64
         ds = int(self.settings["depth_scale"])
@@ -542,7 +559,9 @@ class Generator:
                 if sims is None:
                     sl.drops[dst][:counts[src]] = sl.drops[src][:counts[src]]
                 order.insert(dst, src)
-            assert int(counts.max(initial=0)) <= sl.drops_cap
+            # (rr_host_pack_frames stores at most drops_cap records and reports the full count)
+            assert int(counts.max(initial=0)) <= sl.drops_cap, \
+                "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"       # generator.py:424
             return [items[k] for k in order], [int(counts[k]) for k in order]
 
         def encode_job(sl, items, nds, gpu_ms):
@@ -564,6 +583,8 @@ class Generator:
             ms = 1e3 * (time.time() - sl.t_submit) / max(sl.n_valid, 1)
             if sims is not None:                                # the counts only exist now
                 sl.items = [(it, int(sl.n_out[k][0])) for k, (it, _) in enumerate(sl.items)]
+                assert max((nd for _, nd in sl.items), default=0) <= sl.drops_cap, \
+                    "Assert that the number of drops doesn't overpass the uint16 rain_mask capacity"   # generator.py:424
             encodes[si] = stage.submit(encode_job, sl, [it for it, _ in sl.items], [nd for _, nd in sl.items], ms)
 
         def drain(si):

@@ -47,10 +47,10 @@ constexpr int COL_PARTS = 8;        // row bands of the environment map; partial
                                     // do not depend on the batch size)
 
 struct FrameDesc {
-  const double* bg;
-  const double* rainy_bg;
-  const double* env;
-  const double* omega;
+  const void* bg;                  // float64, float32 or uint8 (in_types: RR_IN_BG_*)
+  const void* rainy_bg;            // float64, float32 or uint8 (RR_IN_RAINY_*; the BG flags when rainy_bg == bg)
+  const void* env;                 // float64 or float32 (RR_IN_ENV_F32)
+  const void* omega;               // as env
   const rr_drop* drops;
   uint8_t* rgb;
   double* comp_out;                // H*W*3 composite before the mean shift (user buffer or ctx scratch); float[] when comp_f32
@@ -63,7 +63,7 @@ struct FrameDesc {
   const rr_ext_tile* ext;          // optional: caller-made tiles / FOV polygons per drop (device pointers inside)
   double* colour_out;              // optional: n_drops * 3 colour constants (rr_frame_out.drop_colour)
   const int32_t* n_drops_dev;      // optional: the drop count lives on the device (k_patch_counts)
-  int32_t comp_f32, pad0;          // comp_out holds floats (the float-colour compositor wrote it)
+  int32_t comp_f32, in_types;      // comp_out holds floats (the float-colour compositor wrote it); element types of the inputs
   int32_t depth_f64;
   int32_t n_drops;
   int32_t strategy;
@@ -92,6 +92,28 @@ __device__ inline rr_drop load_drop(const rr_drop* p) {       // 14 global 8-byt
   return d;
 }
 
+// three channels of pixel `pix` of an image input as float64: kind 0 float64, 1 float32, 2 uint8 (value / 255.0, the
+// reference's bg = cv2.imread(...) / 255.0, generator.py:352)
+__device__ inline void load_px3(const void* base, int kind, int64_t pix, double out[3]) {
+  if (kind == 0) {
+    const global_ptr<const double> s = as_global(static_cast<const double*>(base)) + pix * 3;
+    out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
+  } else if (kind == 1) {
+    const global_ptr<const float> s = as_global(static_cast<const float*>(base)) + pix * 3;
+    out[0] = (double)s[0]; out[1] = (double)s[1]; out[2] = (double)s[2];
+  } else {
+    const global_ptr<const uint8_t> s = as_global(static_cast<const uint8_t*>(base)) + pix * 3;
+    out[0] = (double)s[0] / 255.0; out[1] = (double)s[1] / 255.0; out[2] = (double)s[2] / 255.0;
+  }
+}
+__device__ inline int bg_kind(const FrameDesc& fr) { return (fr.in_types & RR_IN_BG_U8) ? 2 : ((fr.in_types & RR_IN_BG_F32) ? 1 : 0); }
+__device__ inline int rainy_kind(const FrameDesc& fr) {
+  if (fr.rainy_bg == fr.bg) return bg_kind(fr);
+  return (fr.in_types & RR_IN_RAINY_U8) ? 2 : ((fr.in_types & RR_IN_RAINY_F32) ? 1 : 0);
+}
+// float loads that may straddle an 8-byte boundary (rows of an odd-width map start on odd elements)
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
+
 __device__ inline void wave_lds_sync() {
   // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
   // stops the compiler from moving accesses across the hand-off point.
@@ -112,7 +134,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* partial;                  // [frame][ntiles][4] per screen tile: sum(composite), sum(bg), min(mask), max(mask)
   double* means;                    // [frame][4] = mean(composite), mean(bg), min(mask), max(mask)
   int64_t* arena_need;              // [frame]
-  int32_t* overflow;                // [1]
+  int32_t* overflow;                // the batch's own arena-overflow flag (ctx: [1 + RR_PIPE_SLOTS], one per pipeline slot + the device-pointer calls)
   unsigned long long* need_max;     // [1] largest per-frame arena need of every batch since the arena was last (re)sized
   int32_t* list_rot;                // [frame][drops]  drops taken by k_tile
   int32_t* list_gen;                // [frame][drops]  drops taken by k_tile_generic
@@ -150,8 +172,11 @@ __global__ __launch_bounds__(256) void k_env_prefix(const FrameDesc* frames, Dim
   if (row >= dm.He) return;
   const FrameDesc& fr = frames[f];
   const int We = dm.We;
-  const global_ptr<const double> env = as_global(fr.env) + (int64_t)row * We * 3;
-  const global_ptr<const double> om = as_global(fr.omega) + (int64_t)row * We;
+  const bool e32 = (fr.in_types & RR_IN_ENV_F32) != 0;
+  const global_ptr<const double> env = as_global(static_cast<const double*>(fr.env)) + (int64_t)row * We * 3;
+  const global_ptr<const double> om = as_global(static_cast<const double*>(fr.omega)) + (int64_t)row * We;
+  const global_ptr<const float> envf = as_global(static_cast<const float*>(fr.env)) + (int64_t)row * We * 3;
+  const global_ptr<const float> omf = as_global(static_cast<const float*>(fr.omega)) + (int64_t)row * We;
   double* P = prefix + ((int64_t)f * dm.He + row) * (int64_t)(We + 1) * 4;
   if (lane == 0) { P[0] = 0.0; P[1] = 0.0; P[2] = 0.0; P[3] = 0.0; }
   double carry[4] = {0, 0, 0, 0};
@@ -159,10 +184,10 @@ __global__ __launch_bounds__(256) void k_env_prefix(const FrameDesc* frames, Dim
     const int c = c0 + lane;
     double v[4] = {0, 0, 0, 0};
     if (c < We) {
-      const double w = om[c];
-      v[0] = env[c * 3 + 0] * w;
-      v[1] = env[c * 3 + 1] * w;
-      v[2] = env[c * 3 + 2] * w;
+      const double w = e32 ? (double)omf[c] : om[c];
+      v[0] = (e32 ? (double)envf[c * 3 + 0] : env[c * 3 + 0]) * w;
+      v[1] = (e32 ? (double)envf[c * 3 + 1] : env[c * 3 + 1]) * w;
+      v[2] = (e32 ? (double)envf[c * 3 + 2] : env[c * 3 + 2]) * w;
       v[3] = w;
     }
 #pragma unroll
@@ -432,17 +457,20 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
 //      ds_min / ds_max (order-free, no return value).  The spans leave as one u32 per row, xl | (xr + 1) << 16
 //      (0 = empty), in the [row quad][drop] layout k_fov_sums reads coalesced.
 template <int NCH>
-__global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
+__global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int use32, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
   const int N = cam.n_fov, G = imin(64 / N, FOV_GROUPS);
   __shared__ double s_phi[2][RR_MAX_FOV];
+  __shared__ float s_phi32[2][RR_MAX_FOV];
   __shared__ int s_px[4][FOV_GROUPS][POLY_STRIDE], s_py[4][FOV_GROUPS][POLY_STRIDE];
   __shared__ int s_xl[4][NCH * 64], s_xr[4][NCH * 64];         // per wave: the row spans of the drop being converted
   __shared__ int4 s_edge[4][2 * POLY_STRIDE];                  // per wave: the edges of that drop
   if (threadIdx.x < RR_MAX_FOV) {
     s_phi[0][threadIdx.x] = cam.phi_cos[threadIdx.x];
     s_phi[1][threadIdx.x] = cam.phi_sin[threadIdx.x];
+    s_phi32[0][threadIdx.x] = (float)cam.phi_cos[threadIdx.x];
+    s_phi32[1][threadIdx.x] = (float)cam.phi_sin[threadIdx.x];
   }
   __syncthreads();
   const int i0 = (blockIdx.x * 4 + wave) * G;                  // first drop of this wave
@@ -454,21 +482,68 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     if (act && k == 0) sc.npts[gi] = -1;
     return;
   }
-  double az = 0.0, ptx = 0.0, pty = 0.0;
-  bool ok = false;
   const bool ext = act && fr.ext && fr.ext[i0 + g].alpha != nullptr;      // the caller's polygon (rr_ext_tile)
-  if (act && !ext) {
-    FovSetup F;
-    const rr_drop d = load_drop(fr.drops + i0 + g);
-    ok = fov_setup(d, cam, F);
-    fov_vertex(F, cam, s_phi[0][k], s_phi[1][k], dm.He, dm.We, az, ptx, pty);
-  }
   const int base = g * N, nxt_lane = base + (k + 1 == N ? 0 : k + 1);
-  const double az_next = __shfl(az, act ? nxt_lane : lane), pty_next = __shfl(pty, act ? nxt_lane : lane);
-  const bool cnd = act && fov_wrap_cnd(az, az_next);
   const unsigned long long gmask = act ? (((N >= 64 ? 0ull : (1ull << N)) - 1ull) << base) : 0ull;
-  const unsigned long long bt = __ballot(cnd) & gmask, bf = __ballot(act && !cnd) & gmask;
-  const unsigned long long bad = __ballot(act && (!fov_coord_ok(ptx) || !fov_coord_ok(pty))) & gmask;
+  // the vertex of this lane: its pixel on the map (truncated like pyclipper's integer cast), the wrap test of the side
+  // that starts here, whether its coordinates are finite; ok: fov_setup's verdict for the drop
+  int ipx = 0, ipy = 0;
+  bool cnd = false, vbad = true, ok = false;
+  bool need64 = act && !ext && !use32;
+  if (use32) {
+    // float vertices (rr_device.h, "the same polygon in float32"): every predicate that decides the drop's status or the
+    // wrap structure carries an error bound; a drop that comes close is evaluated again in float64 below
+    float azf = 0.f, erf = 0.f, pxf = 0.f, pyf = 0.f;
+    int uns = 0;
+    if (act && !ext) {
+      FovSetup32 F;
+      const rr_drop d = load_drop(fr.drops + i0 + g);
+      fov_setup32(d, (float)cam.fov_cos, (float)cam.fov_sin, F, uns);
+      fov_vertex32(F, (float)cam.radius, s_phi32[0][k], s_phi32[1][k], dm.He, dm.We, azf, erf, pxf, pyf, uns);
+    }
+    const float az_n = __shfl(azf, act ? nxt_lane : lane), er_n = __shfl(erf, act ? nxt_lane : lane);
+    bool c32 = false;
+    if (act && !ext) c32 = fov_wrap_cnd32(azf, az_n, erf, er_n, uns);
+    unsigned gor = 0;                                          // the reason bits of all vertices of the drop
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+      if (__ballot((uns >> b) & 1) & gmask) gor |= 1u << b;
+    const bool certain_fail = (gor & 128u) && !(gor & 3u);     // a vertex without intersection: [] like the reference
+    const unsigned long long bt32 = __ballot(act && !ext && c32) & gmask, bf32 = __ballot(act && !ext && !c32) & gmask;
+    const bool wrap32 = __popcll(bt32) == 1 || __popcll(bf32) == 1;
+    const int r = imin(imax((int)pyf, 0), dm.He - 1);
+    const int r0 = __shfl(r, act ? base : lane);
+    const bool spread = (__ballot(iabs(r - r0) >= 2) & gmask) != 0ull;       // some vertex two rows away from the first one
+    need64 = act && !ext && !certain_fail && ((gor & ~128u) != 0u || !bt32 || !bf32 || (!wrap32 && !spread));
+    if (act && !ext && !need64) {
+      ipx = (int)pxf;
+      ipy = (int)pyf;
+      cnd = c32;
+      vbad = certain_fail;
+      ok = true;
+    }
+  }
+  if (__ballot(need64) != 0ull) {                              // (wave-uniform) float64: every drop, or the ones float cannot decide
+    double az = 0.0, ptx = 0.0, pty = 0.0;
+    bool ok64 = false;
+    if (need64) {
+      FovSetup F;
+      const rr_drop d = load_drop(fr.drops + i0 + g);
+      ok64 = fov_setup(d, cam, F);
+      fov_vertex(F, cam, s_phi[0][k], s_phi[1][k], dm.He, dm.We, az, ptx, pty);
+    }
+    const double az_next = __shfl(az, need64 ? nxt_lane : lane);
+    if (need64) {
+      cnd = fov_wrap_cnd(az, az_next);
+      vbad = !fov_coord_ok(ptx) || !fov_coord_ok(pty);
+      ok = ok64;
+      ipx = vbad ? 0 : (int32_t)ptx;
+      ipy = vbad ? 0 : (int32_t)pty;
+    }
+  }
+  const int ipy_next = __shfl(ipy, act ? nxt_lane : lane);
+  const unsigned long long bt = __ballot(act && cnd) & gmask, bf = __ballot(act && !cnd) & gmask;
+  const unsigned long long bad = __ballot(act && vbad) & gmask;
   int m = 0;
   if (act && ok && bt && bf && !bad) {
     const int count_true = __popcll(bt), count_false = __popcll(bf);
@@ -478,20 +553,20 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     int* qx = s_px[wave][g];
     int* qy = s_py[wave][g];
     const int idx = (wrap && k > pp) ? k + 4 : k;
-    qx[idx] = (int32_t)ptx;
-    qy[idx] = (int32_t)pty;
+    qx[idx] = ipx;
+    qy[idx] = ipy;
     if (wrap && k == pp) {                                     // the border vertices between pp and pp + 1
       const int cols = dm.We, rows = dm.He;
       if (top) {
-        qx[pp + 1] = cols; qy[pp + 1] = (int32_t)pty;
+        qx[pp + 1] = cols; qy[pp + 1] = ipy;
         qx[pp + 2] = cols; qy[pp + 2] = 0;
         qx[pp + 3] = 0;    qy[pp + 3] = 0;
-        qx[pp + 4] = 0;    qy[pp + 4] = (int32_t)pty_next;
+        qx[pp + 4] = 0;    qy[pp + 4] = ipy_next;
       } else {
-        qx[pp + 1] = 0;    qy[pp + 1] = (int32_t)pty;
+        qx[pp + 1] = 0;    qy[pp + 1] = ipy;
         qx[pp + 2] = 0;    qy[pp + 2] = rows;
         qx[pp + 3] = cols; qy[pp + 3] = rows;
-        qx[pp + 4] = cols; qy[pp + 4] = (int32_t)pty_next;
+        qx[pp + 4] = cols; qy[pp + 4] = ipy_next;
       }
     }
   }
@@ -677,21 +752,26 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
   for (int d = 0; d < DPT; d++) S[d][0] = S[d][1] = 0.0;
   double tot0 = 0.0, tot1 = 0.0;                         // row totals, kept by the thread that owns the last column
   double pa[EMAX][2], pb[EMAX][2];                       // the lane's column pair (first / second column) x two components
+  const bool e32 = (fr.in_types & RR_IN_ENV_F32) != 0;
   auto load_row = [&](int y) {
-    const global_ptr<const double> env = as_global(fr.env) + (int64_t)y * We * 3;
-    const global_ptr<const double> om = as_global(fr.omega) + (int64_t)y * We;
+    const global_ptr<const double> env = as_global(static_cast<const double*>(fr.env)) + (int64_t)y * We * 3;
+    const global_ptr<const double> om = as_global(static_cast<const double*>(fr.omega)) + (int64_t)y * We;
+    const global_ptr<const float> envf = as_global(static_cast<const float*>(fr.env)) + (int64_t)y * We * 3;
+    const global_ptr<const float> omf = as_global(static_cast<const float*>(fr.omega)) + (int64_t)y * We;
+    auto E = [&](int i) { return e32 ? (double)envf[i] : env[i]; };
+    auto O = [&](int i) { return e32 ? (double)omf[i] : om[i]; };
 #pragma unroll
     for (int e = 0; e < EMAX; e++) {
       const int cl = e * 128 + 2 * lane, c = cw0 + cl;
       pa[e][0] = pa[e][1] = pb[e][0] = pb[e][1] = 0.0;
       if (cl < Cw && c < We) {
-        const double w = om[c];
-        pa[e][0] = (half ? env[c * 3 + 2] : env[c * 3 + 0]) * w;
-        pa[e][1] = half ? w : env[c * 3 + 1] * w;
+        const double w = O(c);
+        pa[e][0] = (half ? E(c * 3 + 2) : E(c * 3 + 0)) * w;
+        pa[e][1] = half ? w : E(c * 3 + 1) * w;
         if (c + 1 < We) {
-          const double w1 = om[c + 1];
-          pb[e][0] = (half ? env[c * 3 + 5] : env[c * 3 + 3]) * w1;
-          pb[e][1] = half ? w1 : env[c * 3 + 4] * w1;
+          const double w1 = O(c + 1);
+          pb[e][0] = (half ? E(c * 3 + 5) : E(c * 3 + 3)) * w1;
+          pb[e][1] = half ? w1 : E(c * 3 + 4) * w1;
         }
       }
     }
@@ -825,9 +905,32 @@ __global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Di
   for (int d = 0; d < DPT; d++) S[d][0] = S[d][1] = S[d][2] = S[d][3] = 0.f;
   double totY = 0.0, totw = 0.0;                         // row totals (Y*w, w), kept by the thread that owns the last column
   float pa[EMAX][4], pb[EMAX][4];
+  const bool e32 = (fr.in_types & RR_IN_ENV_F32) != 0;
   auto load_row = [&](int y) {
-    const global_ptr<const double> env = as_global(fr.env) + (int64_t)y * We * 3;
-    const global_ptr<const double> om = as_global(fr.omega) + (int64_t)y * We;
+    if (e32) {                                             // float map: 12 + 4 bytes per texel, two texels per lane as 8-byte pieces
+      const global_ptr<const float> env = as_global(static_cast<const float*>(fr.env)) + (int64_t)y * We * 3;
+      const global_ptr<const float> om = as_global(static_cast<const float*>(fr.omega)) + (int64_t)y * We;
+#pragma unroll
+      for (int e = 0; e < EMAX; e++) {
+        const int cl = e * 128 + 2 * lane, c = cw0 + cl;
+#pragma unroll
+        for (int k = 0; k < 4; k++) pa[e][k] = pb[e][k] = 0.f;
+        if (cl < Cw && c + 1 < We) {
+          const float2_u a = *reinterpret_cast<const global_ptr<const float2_u>>(env + c * 3);
+          const float2_u b = *reinterpret_cast<const global_ptr<const float2_u>>(env + c * 3 + 2);
+          const float2_u d = *reinterpret_cast<const global_ptr<const float2_u>>(env + c * 3 + 4);
+          const float2_u w = *reinterpret_cast<const global_ptr<const float2_u>>(om + c);
+          pa[e][0] = a.x * w.x; pa[e][1] = a.y * w.x; pa[e][2] = b.x * w.x; pa[e][3] = w.x;
+          pb[e][0] = b.y * w.y; pb[e][1] = d.x * w.y; pb[e][2] = d.y * w.y; pb[e][3] = w.y;
+        } else if (cl < Cw && c < We) {                      // the map's last column
+          const float w = om[c];
+          pa[e][0] = env[c * 3 + 0] * w; pa[e][1] = env[c * 3 + 1] * w; pa[e][2] = env[c * 3 + 2] * w; pa[e][3] = w;
+        }
+      }
+      return;
+    }
+    const global_ptr<const double> env = as_global(static_cast<const double*>(fr.env)) + (int64_t)y * We * 3;
+    const global_ptr<const double> om = as_global(static_cast<const double*>(fr.omega)) + (int64_t)y * We;
 #pragma unroll
     for (int e = 0; e < EMAX; e++) {
       const int cl = e * 128 + 2 * lane, c = cw0 + cl;
@@ -2182,14 +2285,12 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
   double c[3] = {0, 0, 0}, m = 0.0;
   double sum_b = 0.0;                // this pixel's share of sum(bg) for the mean shift (generator.py:462)
   if (live) {
-    const global_ptr<const double> s = as_global(fr.rainy_bg) + pix * 3;
-    c[0] = s[0];
-    c[1] = s[1];
-    c[2] = s[2];
+    load_px3(fr.rainy_bg, rainy_kind(fr), pix, c);
     if (fr.bg == fr.rainy_bg) {      // no fog pre-pass: one read serves both
       sum_b = (c[0] + c[1]) + c[2];
     } else {
-      const global_ptr<const double> b = as_global(fr.bg) + pix * 3;
+      double b[3];
+      load_px3(fr.bg, bg_kind(fr), pix, b);
       sum_b = (b[0] + b[1]) + b[2];
     }
   }
@@ -2386,23 +2487,20 @@ __global__ __launch_bounds__(256) void k_composite32(const FrameDesc* frames, Di
   bool ok_px = true;                 // every colour value of the lane's live pixels is in [0, 1]
   {
     double in0[3] = {0, 0, 0}, in1[3] = {0, 0, 0};
-    if (live0) {
-      const global_ptr<const double> s = as_global(fr.rainy_bg) + pix0 * 3;
-      in0[0] = s[0]; in0[1] = s[1]; in0[2] = s[2];
-    }
-    if (live1) {
-      const global_ptr<const double> s = as_global(fr.rainy_bg) + pix1 * 3;
-      in1[0] = s[0]; in1[1] = s[1]; in1[2] = s[2];
-    }
+    const int rk = rainy_kind(fr);
+    if (live0) load_px3(fr.rainy_bg, rk, pix0, in0);
+    if (live1) load_px3(fr.rainy_bg, rk, pix1, in1);
     if (fr.bg == fr.rainy_bg) {
       sum_b = ((in0[0] + in0[1]) + in0[2]) + ((in1[0] + in1[1]) + in1[2]);
     } else {
+      const int bk = bg_kind(fr);
+      double b[3];
       if (live0) {
-        const global_ptr<const double> b = as_global(fr.bg) + pix0 * 3;
+        load_px3(fr.bg, bk, pix0, b);
         sum_b = (b[0] + b[1]) + b[2];
       }
       if (live1) {
-        const global_ptr<const double> b = as_global(fr.bg) + pix1 * 3;
+        load_px3(fr.bg, bk, pix1, b);
         sum_b += (b[0] + b[1]) + b[2];
       }
     }
@@ -2917,6 +3015,8 @@ __global__ __launch_bounds__(256) void k_copy_small(const uint32_t* src_pinned_h
 
 // drop counts that only exist on the device (rr_frame_in.n_drops_dev): patched into the frame descriptors before the
 // first kernel of the chain reads them; n_drops of the descriptor is the capacity
+__global__ void k_set_i32(int32_t* p, int32_t v) { *p = v; }
+
 __global__ void k_patch_counts(FrameDesc* frames, int n) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n || !frames[f].n_drops_dev) return;
@@ -3024,12 +3124,13 @@ struct rr_ctx {
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
   int blur_wg = 4;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
-  int fov_f32 = 0;                   // RR_OPT_FOV_F32: float32 prefix rows / sums in the colour branch (image within 1 LSB): 0 never (default),
-                                     // 1 always, 2 whenever the compositor blends float colours (no float64 composite asked for)
+  int fov_f32 = 2;                   // RR_OPT_FOV_F32: float32 vertices / prefix rows / sums in the colour branch (image within 1 LSB): 0 never,
+                                     // 1 always, 2 (default) whenever the compositor blends float colours (no float64 composite asked for)
   bool depth_occlusion = false;      // RR_OPT_DEPTH_OCCLUSION: hide drops behind the scene depth (changes the output; default off)
   bool copy_kernels = false;         // RR_OPT_COPY_KERNELS: batched copy kernels for pinned host buffers (default: hipMemcpyAsync;
                                      // measured slower than the DMA engines once the pieces are merged)
   double* d_omega = nullptr;         // resident solid-angle map (rr_set_solid_angles): frames may pass omega == NULL
+  float* d_omega32 = nullptr;        // the same as floats (frames whose map is float: RR_IN_ENV_F32)
   int omega_He = 0, omega_We = 0;
   std::vector<std::pair<const char*, size_t>> host_allocs;   // rr_host_alloc blocks: pieces inside one block may be merged across padding
   bool composite_f64 = false;        // RR_OPT_COMPOSITE_F64: float64 colours in the compositor even when nobody asks for the composite
@@ -3206,12 +3307,6 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.partial, (size_t)F * ntiles * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.means, (size_t)F * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.arena_need, (size_t)F))) return rc;
-    if (!ctx->sc.overflow) {
-      if ((rc = dev_alloc(ctx, ctx->sc.overflow, 1))) return rc;
-      HIPCHK(hipMemset(ctx->sc.overflow, 0, sizeof(int32_t)));
-      if ((rc = dev_alloc(ctx, ctx->sc.need_max, 1))) return rc;
-      HIPCHK(hipMemset(ctx->sc.need_max, 0, sizeof(unsigned long long)));
-    }
     if ((rc = dev_alloc(ctx, ctx->d_frames, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->d_comp_out, (size_t)F * dm.H * dm.W * 3))) return rc;
     // arena: keep per-frame capacity, reallocate for the new frame count
@@ -3227,21 +3322,25 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
 // After an overflow: a larger arena, sized by the largest need any batch reported since the last (re)size (need_max is
 // sticky on the device, so the batch that overflowed is covered even when later batches were queued behind it); the
 // capacity never shrinks.
+// Every batch has its OWN overflow flag (per pipeline slot; flag 0 for the device-pointer calls): with several batches in
+// flight a shared flag cannot say WHICH of them ran against the short arena.  A batch that finds its flag set calls this:
+// the arena only grows if the sticky maximum says it is still too small (an earlier wait may have grown it already for
+// both), and the caller clears its own flag.
 int grow_arena(rr_ctx* ctx) {
   HIPCHK(hipDeviceSynchronize());
   unsigned long long need = 0;
   HIPCHK(hipMemcpy(&need, ctx->sc.need_max, sizeof(need), hipMemcpyDeviceToHost));
-  int64_t cap = ((int64_t)need + (int64_t)need / 4 + (1 << 16) + 15) & ~15LL;
-  if (cap < ctx->arena_cap) cap = ctx->arena_cap;
-  ctx->arena_cap = cap;
-  int rc = dev_alloc(ctx, ctx->sc.arena, (size_t)ctx->cap_frames * (size_t)cap);
-  if (rc) return rc;
-  HIPCHK(hipMemset(ctx->sc.overflow, 0, sizeof(int32_t)));
+  if ((int64_t)need > ctx->arena_cap) {
+    const int64_t cap = ((int64_t)need + (int64_t)need / 4 + (1 << 16) + 15) & ~15LL;
+    ctx->arena_cap = cap;
+    int rc = dev_alloc(ctx, ctx->sc.arena, (size_t)ctx->cap_frames * (size_t)cap);
+    if (rc) return rc;
+  }
   HIPCHK(hipMemset(ctx->sc.need_max, 0, sizeof(unsigned long long)));
   return RR_OK;
 }
 
-int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, hipStream_t s) {
+int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, hipStream_t s, int ovf_idx = 0) {
   if (!ctx->have_cam || !ctx->have_db) {
     ctx->err = "streak DB and camera must be set before rendering";
     return RR_E_STATE;
@@ -3262,6 +3361,14 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ctx->err = "rendering strategy must be 0 (default) or 1 ('white'); 'naive_db' is broken in the reference (bad_weather.py:355)";
       return RR_E_ARG;
     }
+    {
+      const int t = in[f].in_types;
+      if ((t & ~(RR_IN_BG_F32 | RR_IN_BG_U8 | RR_IN_ENV_F32 | RR_IN_RAINY_F32 | RR_IN_RAINY_U8)) || ((t & RR_IN_BG_F32) && (t & RR_IN_BG_U8)) ||
+          ((t & RR_IN_RAINY_F32) && (t & RR_IN_RAINY_U8))) {
+        ctx->err = "rr_frame_in.in_types: unknown bits, or two element types for one array";
+        return RR_E_ARG;
+      }
+    }
     if (!in[f].omega && !(ctx->d_omega && ctx->omega_He == dm.He && ctx->omega_We == dm.We)) {
       ctx->err = "omega == NULL needs rr_set_solid_angles for this map size";
       return RR_E_STATE;
@@ -3281,6 +3388,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     want_png = want_png || out[f].rainy_png || out[f].mask_png;
   }
   const bool use32 = !any_f64_comp && !ctx->composite_f64;
+  const bool fov32 = ctx->fov_f32 == 1 || (ctx->fov_f32 == 2 && use32);      // float colour branch (RR_OPT_FOV_F32)
   if (dm.H <= 0 || dm.W <= 0 || dm.He <= 0 || dm.We <= 0) {
     ctx->err = "bad frame size";
     return RR_E_ARG;
@@ -3298,7 +3406,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.bg = in[f].bg;
     fd.rainy_bg = in[f].rainy_bg;
     fd.env = in[f].env_xyY;
-    fd.omega = in[f].omega ? in[f].omega : ctx->d_omega;
+    fd.omega = in[f].omega ? (const void*)in[f].omega : ((in[f].in_types & RR_IN_ENV_F32) ? (const void*)ctx->d_omega32 : (const void*)ctx->d_omega);
     fd.drops = in[f].drops;
     fd.rgb = out[f].rainy_rgb;
     fd.comp_out = out[f].rainy_bg_out ? out[f].rainy_bg_out : ctx->d_comp_out + (size_t)f * dm.H * dm.W * 3;
@@ -3313,7 +3421,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.colour_out = out[f].drop_colour;
     fd.n_drops_dev = in[f].n_drops_dev;
     fd.comp_f32 = use32 ? 1 : 0;
-    fd.pad0 = 0;
+    fd.in_types = in[f].in_types;
     any_dev_count = any_dev_count || in[f].n_drops_dev;
     fd.n_drops = in[f].n_drops;
     fd.strategy = in[f].strategy;
@@ -3327,6 +3435,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int tiles_x = (dm.W + TILE - 1) / TILE, tiles_y = (dm.H + TILE - 1) / TILE;
   const int ntiles = tiles_x * tiles_y;
   Scratch sc = ctx->sc;
+  sc.overflow = ctx->sc.overflow + ovf_idx;
   sc.tex_pad = ctx->padded_tex ? ctx->d_tex_pad : nullptr;
   sc.tex_poff = ctx->d_tex_poff;
   sc.blur_bx = ctx->blur_wg == 3 ? 3072 : (ctx->blur_wg == 5 ? 2304 : 2816);
@@ -3344,12 +3453,13 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_fov_spans");
       const int G = imin(64 / ctx->cam.n_fov, FOV_GROUPS);
       const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
+      const int v32 = fov32 ? 1 : 0;
       if (dm.He <= 384)
-        hipLaunchKernelGGL(k_fov_spans<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
+        hipLaunchKernelGGL(k_fov_spans<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
       else if (dm.He <= 512)
-        hipLaunchKernelGGL(k_fov_spans<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
+        hipLaunchKernelGGL(k_fov_spans<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
       else
-        hipLaunchKernelGGL(k_fov_spans<16>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
+        hipLaunchKernelGGL(k_fov_spans<16>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
     } else {
       ProfScope ps(ctx, s, "k_fov_poly");
       hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, dm, ctx->cam, D, sc);
@@ -3400,7 +3510,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         hipLaunchKernelGGL(kern, dim3(COL_PARTS * nchunk, n), dim3(NT), bytes, s, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
-      hipError_t e = (ctx->fov_f32 == 1 || (ctx->fov_f32 == 2 && use32))
+      hipError_t e = fov32
                          ? (e1 ? (DPT == 1 ? launch32(k_fov_sums32<1, 1>) : DPT == 2 ? launch32(k_fov_sums32<2, 1>) : DPT == 4 ? launch32(k_fov_sums32<4, 1>) : launch32(k_fov_sums32<8, 1>))
                                : (DPT == 1 ? launch32(k_fov_sums32<1, 2>) : DPT == 2 ? launch32(k_fov_sums32<2, 2>) : DPT == 4 ? launch32(k_fov_sums32<4, 2>) : launch32(k_fov_sums32<8, 2>)))
                      : e1 ? (DPT == 1 ? launch(k_fov_sums<1, 1>) : DPT == 2 ? launch(k_fov_sums<2, 1>) : DPT == 4 ? launch(k_fov_sums<4, 1>) : launch(k_fov_sums<8, 1>))
@@ -3681,6 +3791,7 @@ int check_overflow(rr_ctx* ctx, hipStream_t s) {
   if (!ovf) return RR_OK;
   int rc = grow_arena(ctx);
   if (rc) return rc;
+  HIPCHK(hipMemset(ctx->sc.overflow, 0, sizeof(int32_t)));      // flag 0: the device-pointer calls since the last rr_synchronize
   ctx->err = "tile arena overflow: arena regrown, re-enqueue the batch";
   return RR_E_ARENA;
 }
@@ -3715,8 +3826,13 @@ int rr_create(rr_ctx** out, int device) {
   float tab[128];
   build_cubic_tab(tab);
   if (hipMalloc((void**)&ctx->d_ctab, sizeof(tab)) != hipSuccess ||
-      hipMemcpy(ctx->d_ctab, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
-    delete ctx;
+      hipMemcpy(ctx->d_ctab, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess ||
+      // arena-overflow flags (one per pipeline slot + one for the device-pointer calls) and the sticky largest need
+      hipMalloc((void**)&ctx->sc.overflow, sizeof(int32_t) * (1 + RR_PIPE_SLOTS)) != hipSuccess ||
+      hipMemset(ctx->sc.overflow, 0, sizeof(int32_t) * (1 + RR_PIPE_SLOTS)) != hipSuccess ||
+      hipMalloc((void**)&ctx->sc.need_max, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->sc.need_max, 0, sizeof(unsigned long long)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    rr_destroy(ctx);
     return RR_E_HIP;
   }
   *out = ctx;
@@ -3767,6 +3883,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.overflow);
   hipFree(ctx->sc.need_max);
   hipFree(ctx->d_omega);
+  hipFree(ctx->d_omega32);
   hipFree(ctx->d_dgrid);
   hipFree(ctx->d_cdf);
   hipFree(ctx->d_ratio_db);
@@ -4360,12 +4477,20 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     } else {
       din[f].depth = nullptr;
     }
+    // element sizes of the caller's arrays (rr_frame_in.in_types; the staging is sized for float64)
+    const int ty = pre ? 0 : in[f].in_types;
+    din[f].in_types = ty;                                      // (the pre-pass hands float64 arrays on)
+    const size_t bg_el = (ty & RR_IN_BG_U8) ? 1 : ((ty & RR_IN_BG_F32) ? 4 : 8);
+    const bool shared_bg = in[f].rainy_bg == in[f].bg;         // one array for both: one upload, and the kernels see one pointer
+    const size_t rainy_el = shared_bg ? bg_el : ((ty & RR_IN_RAINY_U8) ? 1 : ((ty & RR_IN_RAINY_F32) ? 4 : 8));
+    const size_t env_el = (ty & RR_IN_ENV_F32) ? 4 : 8;
     if (!pre) {
-      up.add((void*)din[f].bg, in[f].bg, px * 3 * sizeof(double));
-      up.add((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * sizeof(double));
-      up.add((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * sizeof(double));
+      up.add((void*)din[f].bg, in[f].bg, px * 3 * bg_el);
+      if (shared_bg) din[f].rainy_bg = din[f].bg;
+      else up.add((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * rainy_el);
+      up.add((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * env_el);
     }
-    if (!same_omega) up.add((void*)din[f].omega, in[f].omega, ex * sizeof(double));
+    if (!same_omega) up.add((void*)din[f].omega, in[f].omega, ex * env_el);
     din[f].sim = nullptr;
     if (in[f].sim) {                  // the drop table is generated on the device (below): nothing to upload
       sims.push_back(*in[f].sim);
@@ -4441,7 +4566,10 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   }
   if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return drained(rc);
   if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, drop_stride, st.ndrops, s))) return drained(rc);
-  if (in && (rc = enqueue(ctx, n, din.data(), dout.data(), s))) return drained(rc);
+  if (in) {                           // the slot's own overflow flag, cleared in stream order before the batch's k_scan may set it
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, s, ctx->sc.overflow + 1 + slot, 0);
+    if ((rc = enqueue(ctx, n, din.data(), dout.data(), s, 1 + slot))) return drained(rc);
+  }
   if (hipEventRecord(sl.ev_comp, s) != hipSuccess) {
     ctx->err = "pipeline: hipEventRecord failed";
     return drained(RR_E_HIP);
@@ -4492,19 +4620,16 @@ int host_wait(rr_ctx* ctx, int slot) {
       sl.busy = false;
       return rc;
     }
-    if (sl.rendered) HIPCHK(hipMemcpyAsync(&sl.h_flags[0], ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_down));
+    if (sl.rendered) HIPCHK(hipMemcpyAsync(&sl.h_flags[0], ctx->sc.overflow + 1 + slot, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_down));
     HIPCHK(hipStreamSynchronize(ctx->s_down));
   }
   sl.busy = false;
   if (sl.rendered && (int32_t)sl.h_flags[0] != 0) {
-    // every batch submitted since the overflow ran against the short arena too: they all report it
-    HIPCHK(hipDeviceSynchronize());
-    int32_t still = 0;
-    HIPCHK(hipMemcpy(&still, ctx->sc.overflow, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (still) {
-      int rc = grow_arena(ctx);
-      if (rc) return rc;
-    }
+    // THIS batch ran against a short arena (its own flag, read behind its own kernels).  Other batches in flight report
+    // through their own flags; the arena grows once for all of them (the sticky maximum covers every batch whose k_scan
+    // has run: grow_arena waits for the device first).
+    int rc = grow_arena(ctx);
+    if (rc) return rc;
     ctx->err = "tile arena overflow: arena regrown, submit the batch again";
     return RR_E_ARENA;
   }
@@ -4605,6 +4730,12 @@ int rr_set_solid_angles(rr_ctx* ctx, int32_t He, int32_t We, const double* omega
   int rc = dev_alloc(ctx, ctx->d_omega, (size_t)He * We);
   if (rc) return rc;
   HIPCHK(hipMemcpy(ctx->d_omega, omega, sizeof(double) * (size_t)He * We, hipMemcpyHostToDevice));
+  {
+    std::vector<float> of((size_t)He * We);
+    for (size_t i = 0; i < of.size(); i++) of[i] = (float)omega[i];
+    if ((rc = dev_alloc(ctx, ctx->d_omega32, of.size()))) return rc;
+    HIPCHK(hipMemcpy(ctx->d_omega32, of.data(), sizeof(float) * of.size(), hipMemcpyHostToDevice));
+  }
   ctx->omega_He = He;
   ctx->omega_We = We;
   return RR_OK;

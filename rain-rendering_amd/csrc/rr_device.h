@@ -547,6 +547,165 @@ RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, in
   return m;
 }
 
+// ---------------------------------------------------------------------------
+// the same polygon in float32 (colour branch; k_fov_spans' default)
+// ---------------------------------------------------------------------------
+// The polygon only feeds the drop's colour constants (rainy_image: +-1 LSB); what it must NOT change is a drop's status
+// (the mask is bit-exact) or the shape of the polygon (20 vertices, or 24 with a wrap inserted in front of one of them).
+// So the vertices are evaluated in float, and every predicate that decides a status or the wrap structure is checked
+// against an error bound: a drop any of whose predicates is closer to its threshold than that bound is `unsure` and is
+// evaluated again by the float64 functions above -- its polygon is then the reference's, bit for bit.  A float vertex
+// lands within ~1e-3 texels of the float64 one; where that crosses an integer the truncated pixel moves by one texel
+// (a relative change of the span sums of ~1e-4 in a few rows: three orders below an LSB of the image).
+struct FovSetup32 {
+  float pos[3], n[3], v[3];
+};
+RR_HD void rotmat32(const float a[3], float c, float s, float R[9]) {
+  float omc = 1.0f - c;
+  R[0] = c + omc * (a[0] * a[0]);
+  R[1] = s * (-a[2]) + omc * (a[0] * a[1]);
+  R[2] = s * (a[1]) + omc * (a[0] * a[2]);
+  R[3] = s * (a[2]) + omc * (a[1] * a[0]);
+  R[4] = c + omc * (a[1] * a[1]);
+  R[5] = s * (-a[0]) + omc * (a[1] * a[2]);
+  R[6] = s * (-a[1]) + omc * (a[2] * a[0]);
+  R[7] = s * (a[0]) + omc * (a[2] * a[1]);
+  R[8] = c + omc * (a[2] * a[2]);
+}
+RR_HD void vecmat32(const float v[3], const float R[9], float o[3]) {
+  o[0] = v[0] * R[0] + v[1] * R[3] + v[2] * R[6];
+  o[1] = v[0] * R[1] + v[1] * R[4] + v[2] * R[7];
+  o[2] = v[0] * R[2] + v[1] * R[5] + v[2] * R[8];
+}
+// returns false where fov_setup would (never when `unsure` is clear); unsure: a float64 evaluation must decide
+RR_HD bool fov_setup32(const rr_drop& d, float fov_cos, float fov_sin, FovSetup32& F, int& unsure) {
+  float* pos = F.pos;
+  float* n = F.n;
+  pos[0] = (float)((d.wps[0] + d.wpe[0]) / 2.0);
+  pos[1] = (float)((d.wps[2] + d.wpe[2]) / 2.0);
+  pos[2] = (float)((d.wps[1] + d.wpe[1]) / 2.0);
+  float nrm = sqrtf(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+  n[0] = pos[0] / nrm; n[1] = pos[1] / nrm; n[2] = pos[2] / nrm;
+  float a = n[0], b = n[1], c = n[2];
+  float dd = pos[0] * n[0] + pos[1] * n[1] + pos[2] * n[2];
+  // b == 0 -> 0.001 in the reference: a drop whose mid-point has (nearly) no depth; the in-plane direction below is
+  // ill-conditioned for small |b| anyway
+  if (!(fabsf(b) > 1e-2f) || !(nrm > 1e-6f) || !(nrm < 1e6f)) unsure |= 1;
+  float ppx = pos[1], ppz = 0.0f;
+  float ppy = (-a * ppx + dd - c * ppz) / b;
+  float uu[3] = {pos[0] - ppx, pos[1] - ppy, pos[2] - ppz};
+  float un = sqrtf(uu[0] * uu[0] + uu[1] * uu[1] + uu[2] * uu[2]);
+  if (!(un > 1e-3f * nrm)) unsure |= 1;                    // (also NaN)
+  uu[0] /= un; uu[1] /= un; uu[2] /= un;
+  float rv[3] = {uu[1] * n[2] - uu[2] * n[1], uu[2] * n[0] - uu[0] * n[2], uu[0] * n[1] - uu[1] * n[0]};
+  float R[9];
+  rotmat32(rv, fov_cos, fov_sin, R);
+  vecmat32(n, R, F.v);
+  return true;
+}
+// vertex k in float: azimuth, a bound of its error (grows towards the poles of the map), float pixel position
+RR_HD void fov_vertex32(const FovSetup32& F, float radius, float phi_cos, float phi_sin, int He, int We, float& azimuth, float& az_err,
+                        float& ptx, float& pty, int& unsure) {
+  const float PI = 3.14159265358979f, TWO_PI = 6.28318530717959f;
+  const float* pos = F.pos;
+  float M[9], dir[3];
+  rotmat32(F.n, phi_cos, phi_sin, M);
+  vecmat32(F.v, M, dir);
+  float qa = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+  float qb = 2.0f * (dir[0] * pos[0] + dir[1] * pos[1] + dir[2] * pos[2]);
+  float p2 = pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2];
+  float qc = p2 - radius * radius;
+  float disc = qb * qb - 4.0f * qa * qc;
+  // the sign of the discriminant decides a status (no intersection -> NaN -> no polygon): clearly negative is a certain
+  // failure (bit 128: the drop is farther out than the sphere), close to zero is for float64 to decide
+  {
+    const float scale = 1e-3f * (qb * qb + 4.0f * qa * fabsf(qc));
+    if (disc < -scale) unsure |= 128;
+    else if (!(disc > scale)) unsure |= 2;
+  }
+  float t1 = (-qb + sqrtf(fmaxf(disc, 0.0f))) / (2.0f * qa);
+  float P[3] = {pos[0] + t1 * dir[0], pos[1] + t1 * dir[1], pos[2] + t1 * dir[2]};
+  float rho = sqrtf(P[0] * P[0] + P[1] * P[1]);
+  float el = atan2f(P[2], rho);
+  float az = atan2f(P[1], P[0]);
+  if (az < 0.0f) az += TWO_PI;
+  float x = (TWO_PI - az) - 0.5f * PI;                          // in (-pi/2, 3 pi/2]: one conditional add is the modulus
+  if (x < 0.0f) x += TWO_PI;
+  azimuth = x;
+  // |P| = radius up to rounding; the azimuth of a point at horizontal distance rho is known to ~(absolute error of P) / rho
+  az_err = 1e-6f * (radius + sqrtf(p2)) / fmaxf(rho, 1e-30f) + 2e-6f;   // (measured: <= 0.3 of this, scripts/fov_f32_polygons.py)
+  if (!(az_err < 0.05f)) unsure |= 4;                        // on top of a pole (also NaN)
+  if (azimuth < 4.0f * az_err || azimuth > TWO_PI - 4.0f * az_err) unsure |= 8;   // which side of the seam of the map?
+  float elevation = el + 0.5f * PI;                            // [0, pi]
+  ptx = (azimuth / TWO_PI) * (float)We;
+  pty = (1.0f - elevation / PI) * (float)He;
+}
+// wrap test of one polygon side; unsure when the difference is within the two vertices' error of either threshold
+RR_HD bool fov_wrap_cnd32(float az_k, float az_next, float err_k, float err_next, int& unsure) {
+  float df = az_next - az_k;
+  if (!(fabsf(df) > 4.0f * (err_k + err_next) + 1e-5f)) unsure |= 16;
+  return df < 0.0f;
+}
+// serial composition (tests/hostemu): the float polygon when every predicate is clear of its threshold, else the float64
+// one; *used32 says which.  Same vertex order and wrap insertion as fov_polygon.
+RR_HD int fov_polygon_auto(const rr_drop& d, const rr_camera& cam, int He, int We, int32_t* px, int32_t* py, int* used32) {
+  const int N = cam.n_fov;
+  int unsure = 0;
+  FovSetup32 F;
+  fov_setup32(d, (float)cam.fov_cos, (float)cam.fov_sin, F, unsure);
+  float ptx[RR_MAX_FOV], pty[RR_MAX_FOV], azs[RR_MAX_FOV + 1], ers[RR_MAX_FOV + 1];
+  for (int k = 0; k < N; k++)
+    fov_vertex32(F, (float)cam.radius, (float)cam.phi_cos[k], (float)cam.phi_sin[k], He, We, azs[k], ers[k], ptx[k], pty[k], unsure);
+  azs[N] = azs[0];
+  ers[N] = ers[0];
+  int count_true = 0, count_false = 0, pos_true = -1, pos_false = -1;
+  for (int k = 0; k < N; k++) {
+    bool cnd = fov_wrap_cnd32(azs[k], azs[k + 1], ers[k], ers[k + 1], unsure);
+    if (cnd) { count_true++; if (pos_true < 0) pos_true = k; }
+    else { count_false++; if (pos_false < 0) pos_false = k; }
+  }
+  int m = 0;
+  if ((unsure & 128) && !(unsure & (1 | 2))) {                 // a vertex certainly has no intersection: [] like the reference
+    if (used32) *used32 = 1;
+    return 0;
+  }
+  if (!unsure && pos_true >= 0 && pos_false >= 0) {
+    const bool wrap = count_true == 1 || count_false == 1, top = count_true == 1;
+    const int pp = top ? pos_true : pos_false;
+    const int rows = He, cols = We;
+    for (int k = 0; k < N; k++) {
+      px[m] = (int32_t)ptx[k]; py[m] = (int32_t)pty[k]; m++;
+      if (wrap && k == pp) {
+        const int nxt = (pp + 1) % N;
+        if (top) {
+          px[m] = cols; py[m] = (int32_t)pty[pp]; m++;
+          px[m] = cols; py[m] = 0; m++;
+          px[m] = 0; py[m] = 0; m++;
+          px[m] = 0; py[m] = (int32_t)pty[nxt]; m++;
+        } else {
+          px[m] = 0; py[m] = (int32_t)pty[pp]; m++;
+          px[m] = 0; py[m] = rows; m++;
+          px[m] = cols; py[m] = rows; m++;
+          px[m] = cols; py[m] = (int32_t)pty[nxt]; m++;
+        }
+      }
+    }
+    // a polygon that covers (almost) no row of the map could flip RR_DROP_EMPTY_FOV with a one-texel move: float64 decides
+    // (the kernel's rule: no vertex two rows away from the first one; a wrapping polygon spans the map)
+    if (!wrap) {
+      const int r0 = imin(imax((int)pty[0], 0), He - 1);
+      bool spread = false;
+      for (int k = 1; k < N; k++) spread = spread || iabs(imin(imax((int)pty[k], 0), He - 1) - r0) >= 2;
+      if (!spread) unsure |= 32;
+    }
+  } else {
+    unsure |= 64;                                              // (or already unsure) all sides alike: the reference returns [] -- float64 says so
+  }
+  if (used32) *used32 = unsure ? -unsure : 1;            // (tests: <= 0 tells why the float64 polygon was taken)
+  if (unsure) return fov_polygon(d, cam, He, We, px, py);
+  return m;
+}
+
 // FOV row span at pixel row y (oracle/cvlike.py fov_rowspans). false if the row is empty.
 RR_HD bool fov_rowspan(const int32_t* px, const int32_t* py, int n, int y, int We, int& xl, int& xr) {
   int lo = 1 << 30, hi = -(1 << 30);

@@ -22,6 +22,7 @@ RR_OPT_COMPOSITE_F64 = 7
 RR_OPT_COPY_KERNELS = 8
 RR_OPT_PADDED_TEXTURES = 9
 RR_OPT_FOV_F32 = 10
+RR_IN_BG_F32, RR_IN_BG_U8, RR_IN_ENV_F32, RR_IN_RAINY_F32, RR_IN_RAINY_U8 = 1, 2, 4, 8, 16      # rr_frame_in.in_types
 
 # numpy mirror of rr_drop (112 bytes)
 DROP_DTYPE = np.dtype([
@@ -57,7 +58,7 @@ class rr_frame_in(ctypes.Structure):
                 ('omega', ctypes.c_void_p), ('drops', ctypes.c_void_p),
                 ('n_drops', ctypes.c_int32), ('strategy', ctypes.c_int32),
                 ('opacity_attenuation', ctypes.c_double), ('depth', ctypes.c_void_p), ('depth_f64', ctypes.c_int32),
-                ('reserved', ctypes.c_int32), ('ext', ctypes.c_void_p), ('n_drops_dev', ctypes.c_void_p), ('sim', ctypes.c_void_p)]
+                ('in_types', ctypes.c_int32), ('ext', ctypes.c_void_p), ('n_drops_dev', ctypes.c_void_p), ('sim', ctypes.c_void_p)]
 
 
 class rr_ext_tile(ctypes.Structure):
@@ -773,7 +774,9 @@ class RainHip:
 
     def render_frames(self, frames, want_composite=True, want_colour=False):
         """frames: list of dict(bg, rainy_bg, env_xyY, omega, drops[, opacity_attenuation]) with
-        C-contiguous float64 arrays and a DROP_DTYPE drop table.  Returns a list of
+        C-contiguous arrays and a DROP_DTYPE drop table.  The image arrays may be float32 or uint8 (uint8 = the bytes
+        cv2.imread returned: value / 255.0), the map float32 (omega then travels as float32 too): rr_frame_in.in_types;
+        anything else is taken as float64.  Returns a list of
         dict(image_u8 RGB, rainy_bg, mask, mask_i32, status[, colour = (n, 3) BGR colour constants])."""
         n = len(frames)
         fin = (rr_frame_in * n)()
@@ -781,10 +784,18 @@ class RainHip:
         outs = []
         keep = []
         for k, fr in enumerate(frames):
-            bg = np.ascontiguousarray(fr['bg'], np.float64)
-            rb = np.ascontiguousarray(fr['rainy_bg'], np.float64)
-            env = np.ascontiguousarray(fr['env_xyY'], np.float64)
-            om = np.ascontiguousarray(fr['omega'], np.float64)
+            def image(a):
+                a = np.asarray(a)
+                return np.ascontiguousarray(a, a.dtype if a.dtype in (np.float32, np.uint8) else np.float64)
+            same = fr['rainy_bg'] is fr['bg']
+            bg = image(fr['bg'])
+            rb = bg if same else image(fr['rainy_bg'])
+            env = np.asarray(fr['env_xyY'])
+            env = np.ascontiguousarray(env, np.float32 if env.dtype == np.float32 else np.float64)
+            om = None if fr.get('omega') is None else np.ascontiguousarray(fr['omega'], env.dtype)   # None: rr_set_solid_angles' map
+            types = ({np.dtype(np.float32): RR_IN_BG_F32, np.dtype(np.uint8): RR_IN_BG_U8}.get(bg.dtype, 0) |
+                     {np.dtype(np.float32): RR_IN_RAINY_F32, np.dtype(np.uint8): RR_IN_RAINY_U8}.get(rb.dtype, 0) |
+                     (RR_IN_ENV_F32 if env.dtype == np.float32 else 0))
             sim = fr.get('sim')                        # one SIM_FRAME_DTYPE record: the drop table is generated on the device
             if sim is not None:
                 sim = np.ascontiguousarray(sim, SIM_FRAME_DTYPE).reshape(1)
@@ -793,8 +804,8 @@ class RainHip:
             else:
                 drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
             H, W = bg.shape[:2]
-            He, We = om.shape[:2]
-            assert bg.shape == (H, W, 3) and rb.shape == (H, W, 3) and env.shape == (He, We, 3)
+            He, We = env.shape[:2]
+            assert bg.shape == (H, W, 3) and rb.shape == (H, W, 3) and env.shape == (He, We, 3) and (om is None or om.shape == (He, We))
             o = dict(image_u8=np.zeros((H, W, 3), np.uint8),
                      rainy_bg=np.zeros((H, W, 3), np.float64) if want_composite else None,
                      mask=np.zeros((H, W), np.float64), mask_i32=np.zeros((H, W), np.int32),
@@ -803,7 +814,8 @@ class RainHip:
                 o['colour'] = np.zeros((len(drops), 3), np.float64)
                 fout[k].drop_colour = _ptr(o['colour']) if len(drops) else None
             fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, He, We
-            fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY, fin[k].omega = _ptr(bg), _ptr(rb), _ptr(env), _ptr(om)
+            fin[k].bg, fin[k].rainy_bg, fin[k].env_xyY, fin[k].omega = _ptr(bg), _ptr(rb), _ptr(env), (_ptr(om) if om is not None else None)
+            fin[k].in_types = types
             fin[k].drops = _ptr(drops) if len(drops) and sim is None else None
             fin[k].n_drops = len(drops)
             if sim is not None:

@@ -42,9 +42,22 @@ def rank0_decides(fn, rank, world):
         return fn()
     import torch.distributed as dist
     ensure_group(rank, world)
-    box = [fn() if rank == 0 else None]
+    # An exception on rank 0 (a missing file, an unsupported --conflict_strategy, a failing simulator) travels with the
+    # broadcast and is raised on EVERY rank: the others would otherwise sit in the collective until its time-out.
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = (True, fn())
+        except Exception as e:                                     # noqa: BLE001 -- re-raised below, on all ranks
+            box[0] = (False, (type(e).__name__, str(e)))
+            err = e
     dist.broadcast_object_list(box, src=0)
-    return box[0]
+    ok, val = box[0]
+    if ok:
+        return val
+    if rank == 0:
+        raise err
+    raise RuntimeError("rank 0 failed: %s: %s" % val)
 
 
 def shard(indices, rank, world):
@@ -52,13 +65,13 @@ def shard(indices, rank, world):
     return list(indices)[rank::world]
 
 
-def broadcast_streak_db(packed, src=0, device=None):
+def broadcast_streak_db(packed, src=0, device=None, force=False):
     """packed = (texels u8[], tex_h i32[], tex_w i32[], tex_off i64[]) on `src`, None elsewhere.
     Returns (texels torch.uint8 tensor on `device`, tex_h, tex_w, tex_off numpy).  With an
     uninitialised process group this is a plain upload."""
     import torch
     import torch.distributed as dist
-    live = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    live = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
     dev = device if device is not None else torch.device('cpu')
     if not live:
         texels, hs, ws, offs = packed
@@ -85,22 +98,25 @@ def broadcast_streak_db(packed, src=0, device=None):
     return buf[meta_bytes:], hs, ws, offs
 
 
-def load_and_broadcast_streak_db(db, hip, rank, world):
+def load_and_broadcast_streak_db(db, hip, rank, world, force_collective=False):
     """DBManager.load_streak_database on rank 0 only, then the broadcast; every rank ends up
-    with the database resident on its GPU and with db.ratio / db.streaks_light populated."""
+    with the database resident on its GPU and with db.ratio / db.streaks_light populated.
+    force_collective: take the collective route in a group of ONE rank too (the GPU test tier walks
+    init_process_group('nccl') -> device-tensor broadcast -> rr_set_streak_db_device on the one GPU it has)."""
     from . import hip_backend
-    if world <= 1:
+    if world <= 1 and not force_collective:
         db.load_streak_database()
         hip.set_streak_db(db.streaks_light)
         return
     import torch
-    ensure_group(rank, world)
+    if world > 1:
+        ensure_group(rank, world)
     packed = None
     if rank == 0:
         db.load_streak_database()
         packed = hip_backend.pack_streak_db(db.streaks_light)
     dev = torch.device('cuda', hip.device) if torch.cuda.is_available() else torch.device('cpu')
-    texels, hs, ws, offs = broadcast_streak_db(packed, 0, dev)
+    texels, hs, ws, offs = broadcast_streak_db(packed, 0, dev, force=force_collective)
     if rank != 0:
         host = texels.cpu().numpy()
         db.streaks_light = [host[o:o + h * w].reshape(h, w).copy() for h, w, o in zip(hs, ws, offs)]

@@ -36,6 +36,49 @@ int emu_plan(const rr_drop* drops, int n, const rr_camera* cam, int H, int W, in
   return 0;
 }
 
+// the colour branch's default polygon: float32 vertices unless a status / wrap predicate is within its error bound of the
+// threshold (then the float64 polygon).  poly: n*2*36 int32, npts: n, used32: n (1 = the float polygon was kept)
+int emu_fov_auto(const rr_drop* drops, int n, const rr_camera* cam, int He, int We, int32_t* poly, int32_t* npts, int32_t* used32) {
+  for (int i = 0; i < n; i++) {
+    int32_t* px = poly + (int64_t)i * 2 * 36;
+    int u = 0;
+    npts[i] = fov_polygon_auto(drops[i], *cam, He, We, px, px + 36, &u);
+    used32[i] = u;
+  }
+  return 0;
+}
+
+// the float vertices' error model: out[i] = max over the vertices of drop i of |azimuth32 - azimuth64| / az_err (the bound
+// fov_vertex32 reports), -1 for drops either evaluation rejects.  What the unsure margins (8 x the bound) rest on.
+int emu_fov_error_ratio(const rr_drop* drops, int n, const rr_camera* cam, int He, int We, double* out, double* max_px) {
+  for (int i = 0; i < n; i++) {
+    out[i] = -1.0;
+    max_px[i] = 0.0;
+    FovSetup F;
+    FovSetup32 G;
+    int unsure = 0;
+    if (!fov_setup(drops[i], *cam, F)) continue;
+    fov_setup32(drops[i], (float)cam->fov_cos, (float)cam->fov_sin, G, unsure);
+    double worst = 0.0;
+    bool okd = true;
+    for (int k = 0; k < cam->n_fov; k++) {
+      double az, ptx, pty;
+      float az32, err, px32, py32;
+      fov_vertex(F, *cam, cam->phi_cos[k], cam->phi_sin[k], He, We, az, ptx, pty);
+      fov_vertex32(G, (float)cam->radius, (float)cam->phi_cos[k], (float)cam->phi_sin[k], He, We, az32, err, px32, py32, unsure);
+      if (!(fabs(ptx) < 1e15) || !(fabs(pty) < 1e15)) { okd = false; break; }
+      double d = fabs((double)az32 - az);
+      if (d > 3.14159265358979) d = 6.283185307179586 - d;      // the two sides of the seam are neighbours
+      worst = fmax(worst, d / (double)err);
+      double dx = fabs((double)px32 - ptx);
+      if (dx > 0.5 * We) dx = We - dx;
+      max_px[i] = fmax(max_px[i], fmax(dx, fabs((double)py32 - pty)));
+    }
+    if (okd && !(unsure & 7)) out[i] = worst;
+  }
+  return 0;
+}
+
 // finished (padded, blurred) alpha tile of one drop into out[ph*pw]
 int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
              double* out) {

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     for n in names:
         assert hasattr(lib, n), "librainhip.so does not export %s" % n
     assert sorted(h.hb.EXPORTS) == names
-    assert lib.rr_version() == 300
+    assert lib.rr_version() == 400
 
 
 def test_struct_layouts(built):

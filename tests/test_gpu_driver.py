@@ -130,3 +130,132 @@ def test_native_and_general_routes_write_the_same_files(tmp_path, built, monkeyp
             assert a == b and len(a) > 500, (kind, i)
     mask = np.array(Image.open(os.path.join(outs['native'], 'rain_mask', '000003.png')))
     assert len(np.unique(mask.reshape(-1, 4), axis=0)) > 3                  # streaks were rendered
+
+
+def test_main_device_particles_on_a_nuscenes_tree(tmp_path, built, monkeypatch):
+    """BASELINE.json configs[4] from the command line, on the GPU: `main.py --dataset nuscenes --device_particles` on a
+    nuScenes-shaped tree (1600x900, f/1.8) -- no particle file is read or written, the drop tables are born on the device --
+    against rr_pipeline_submit fed the very rr_sim_frame records the driver must have sent (tools/particles.sim_frames,
+    simulated frame f % n_sim with the draws of frame f: reference generator.py:304-321): the PNG files decode to the same
+    pixels.  Reference role: main.py:187-220 (particles resolution / auto-simulation)."""
+    tmp = str(tmp_path)
+    H, W, n = 900, 1600, 3
+    scene = os.path.join(tmp, 'source', 'nuscenes', 'scene-0001')
+    os.makedirs(os.path.join(scene, 'rgb'))
+    os.makedirs(os.path.join(scene, 'depth'))
+    for i in range(n):
+        bgr = h.synthetic.make_frame(40 + i, H, W)
+        Image.fromarray((bgr[..., ::-1] * 255).astype(np.uint8)).save(os.path.join(scene, 'rgb', '%06d.png' % i))
+        ramp = np.linspace(80.0, 2.0, H)[:, None] * np.ones((1, W))
+        Image.fromarray(np.round(ramp * 256).astype(np.uint16)).save(os.path.join(scene, 'depth', '%06d.png' % i))
+    tex_dir, norm = h.synthetic.write_streak_db(os.path.join(tmp, 'rainstreakdb'))
+    monkeypatch.setenv('RAIN_BATCH', '2')                              # two batches, the second ragged
+    main = importlib.import_module('rain-rendering_amd.main')
+    src = os.path.join(tmp, 'source')
+    gen = main.main(['--dataset', 'nuscenes', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd', os.path.join(tmp, 'rainstreakdb'),
+                     '-i', '5', '--output', os.path.join(tmp, 'out'), '--noverbose', '--device_particles'])
+    assert not os.path.exists(os.path.join(tmp, 'particles'))          # no particle file appeared
+    assert gen.timing[0].get('route') == 'native' and len(gen.stats) == n and all(s['drops'] > 50 for s in gen.stats)
+    out_dir = os.path.join(tmp, 'out', 'nuscenes', 'scene-0001', 'rain', '5mm')
+
+    # the same frames through the library, fed the records the driver sends
+    particles = importlib.import_module('rain-rendering_amd.tools.particles')
+    dbmod = importlib.import_module('rain-rendering_amd.common.db')
+    imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+    fogmod = importlib.import_module('rain-rendering_amd.common.add_attenuation')
+    envmod = importlib.import_module('rain-rendering_amd.common.envmap')
+    st = dbmod.settings('nuscenes')
+    opts = dbmod.sim('nuscenes', 'scene-0001', os.path.join(tmp, 'particles', 'nuscenes'))['options']
+    n_sim = particles.n_sim_frames(opts)
+    sims, dgrid, cdf = particles.sim_frames(opts, 5, n_sim, render_scale=1, seed=0)
+    f_idx = [int(v) for v in np.linspace(0, n_sim, n, endpoint=False, dtype=int)]      # generator.py:304-312
+    db = h.bw.DBManager(streaks_path=tex_dir, norm_coeff_path=norm)
+    db.load_streak_database()
+    focal = st['cam_focal'] / 1000.
+    consts = fogmod.FogRain(rain_intensity=5, focal=focal, f_number=st['cam_f_number'], angle=90, exposure=st['cam_exposure'],
+                            camera_gain=st['cam_gain']).constants()
+    rh = h.hb.RainHip(0)
+    try:
+        rh.set_streak_db(db.streaks_light)
+        rh.set_camera(h.hb.make_camera(focal, st['cam_f_number'], st['cam_exposure']))
+        rh.set_prepass_kernels(imgops.gaussian_kernel(25, 25), imgops.gaussian_kernel(15, 0))
+        rh.set_colormap(imgops.viridis_lut())
+        rh.set_particle_tables(dgrid, cdf)
+        we = rh.set_envmap_geometry(H, W, *envmod.EnvironmentMapGenerator(focal, W, H).device_tables(H, W))
+        omega = h.solid_angle.get_solid_angles(np.empty((H, we, 0)))
+        frames, outs = [], []
+        for i in range(n):
+            rec = sims[f_idx[i] % n_sim:f_idx[i] % n_sim + 1].copy()
+            rec['draw_seed'] = f_idx[i]
+            bg8 = imgops.imread_bgr(os.path.join(scene, 'rgb', '%06d.png' % i))
+            depth = imgops.imread_unchanged(os.path.join(scene, 'depth', '%06d.png' % i)).astype(np.float32) / 256.
+            cap = int(sims['n_particles'].max())
+            frames.append(dict(bg_u8=np.ascontiguousarray(bg8), depth=np.ascontiguousarray(depth), fog=consts, omega=omega, sim=rec, drops_cap=cap))
+            outs.append(dict(image_u8=np.zeros((H, W, 3), np.uint8), mask=np.zeros((H, W)), status=np.zeros(cap, np.int32),
+                             n_drops=np.zeros(1, np.int32)))
+        rh.pipeline_submit(0, frames, outs)
+        while not rh.pipeline_wait(0):
+            rh.pipeline_submit(0, frames, outs)
+    finally:
+        rh.close()
+    by_file = {os.path.basename(s['file']): s for s in gen.stats}
+    for i in range(n):
+        name = '%06d.png' % i
+        got = np.array(Image.open(os.path.join(out_dir, 'rainy_image', name)))
+        assert got.shape == (H, W, 4) and np.array_equal(got[..., :3], outs[i]['image_u8']), name
+        ref_mask = os.path.join(tmp, 'ref_mask.png')
+        imgops.imsave_scalar(ref_mask, outs[i]['mask'])
+        assert np.array_equal(np.array(Image.open(os.path.join(out_dir, 'rain_mask', name))), np.array(Image.open(ref_mask))), name
+        assert by_file[name]['drops'] == int(outs[i]['n_drops'][0]) and outs[i]['mask'].max() > 0
+
+
+def test_rccl_broadcast_of_the_streak_database_world1(tmp_path, built):
+    """The N>1 start-up on the one GPU of the test tier: init_process_group('nccl', device_id=...) with a single rank, then
+    sharding.load_and_broadcast_streak_db's collective route -- RCCL broadcast of the header and of the packed database as
+    DEVICE tensors, rr_set_streak_db_device on the received buffer -- and a frame rendered from it, equal to a frame rendered
+    from a plainly uploaded database.  (The 8-GPU scaling run is the driver's; this is the code it executes first.)
+    Reference role: main_threaded.py:98-200 (the reference's parallel mode)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    sharding = importlib.import_module('rain-rendering_amd.sharding')
+    assert torch.cuda.is_available()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    sc = h.Scene(tmp_path, 96, 160, 150, seed0=61)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    plain = h.hb.RainHip(0)
+    try:
+        plain.set_streak_db(sc.db.streaks_light)
+        plain.set_camera(sc.cam)
+        want = plain.render_frames([fr])[0]
+    finally:
+        plain.close()
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+    rh = h.hb.RainHip(0)
+    try:
+        assert dist.get_backend() == 'nccl'
+        db = h.bw.DBManager(streaks_path=sc.tex_dir, norm_coeff_path=sc.norm)
+        sharding.load_and_broadcast_streak_db(db, rh, 0, 1, force_collective=True)
+        # rank0_decides in a live group of one rank is a plain call; an object broadcast works too
+        box = ['work list']
+        dist.broadcast_object_list(box, src=0)
+        assert box == ['work list']
+        rh.set_camera(sc.cam)
+        got = rh.render_frames([fr])[0]
+        torch.cuda.synchronize()
+    finally:
+        rh.close()
+        if created:
+            dist.destroy_process_group()
+    for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
+        assert np.array_equal(got[k], want[k]), k
+    assert len(db.streaks_light) == 50 and (want['status'] == 0).sum() > 100

@@ -96,6 +96,59 @@ def test_arena_regrowth_mid_batch(tmp_path, built):
         rh.close()
 
 
+def test_arena_overflow_is_reported_per_batch(tmp_path, built):
+    """Several batches in flight, each with its own overflow flag (a shared flag read at wait time blamed the
+    wrong batch).  (i) a small batch A and a large batch B behind it: only B overflows -- wait(A) is complete and correct,
+    wait(B) reports the overflow, its re-submission is complete.  (ii) in a fresh context both overflow: both waits report
+    it (the arena grows once, for the larger need), both re-submissions are complete."""
+    big = h.Scene(tmp_path / 'big', edge.H, edge.W, 0, frames=_defocused_frames(420))
+    small = h.Scene(tmp_path / 'small', edge.H, edge.W, 0, frames=_defocused_frames(40))
+    bg, env = big.frame_inputs(0)
+    d_big, d_small = big.product_drops(0), small.product_drops(0)
+    emu_big, emu_small = h.emu_render(big, bg, bg, env, d_big), h.emu_render(small, bg, bg, env, d_small)
+    f_big = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=big.omega, drops=d_big)
+    f_small = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=big.omega, drops=d_small)
+
+    def outputs(n):
+        return dict(image_u8=np.zeros((edge.H, edge.W, 3), np.uint8), mask=np.zeros((edge.H, edge.W)),
+                    mask_i32=np.zeros((edge.H, edge.W), np.int32), status=np.zeros(n, np.int32))
+
+    def same(out, emu):
+        return all(np.array_equal(out[k], emu[k]) for k in ('mask', 'mask_i32', 'status')) and \
+            np.abs(out['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+
+    rh = h.hb.RainHip(0)
+    try:                                                            # (i) only the second batch overflows
+        rh.set_streak_db(big.db.streaks_light)
+        rh.set_camera(big.cam)
+        oa, ob = outputs(len(d_small)), outputs(len(d_big))
+        rh.pipeline_submit(0, [f_small], [oa])
+        rh.pipeline_submit(1, [f_big], [ob])
+        assert rh.pipeline_wait(0) is True and same(oa, emu_small)   # A is not blamed for B's overflow
+        assert rh.pipeline_wait(1) is False
+        rh.pipeline_submit(1, [f_big], [ob])
+        assert rh.pipeline_wait(1) is True and same(ob, emu_big)
+    finally:
+        rh.close()
+    rh = h.hb.RainHip(0)
+    try:                                                            # (ii) both overflow; a third, small batch behind them does not
+        rh.set_streak_db(big.db.streaks_light)
+        rh.set_camera(big.cam)
+        oa, ob, oc = outputs(len(d_big)), outputs(len(d_big)), outputs(len(d_small))
+        rh.pipeline_submit(0, [f_big], [oa])
+        rh.pipeline_submit(1, [f_big, f_big], [ob, outputs(len(d_big))])
+        rh.pipeline_submit(2, [f_small], [oc])
+        assert rh.pipeline_wait(0) is False
+        assert rh.pipeline_wait(1) is False                         # B ran against the short arena too: its own flag says so
+        assert rh.pipeline_wait(2) is True and same(oc, emu_small)
+        rh.pipeline_submit(0, [f_big], [oa])
+        rh.pipeline_submit(1, [f_big, f_big], [ob, outputs(len(d_big))])
+        assert rh.pipeline_wait(0) is True and same(oa, emu_big)
+        assert rh.pipeline_wait(1) is True and same(ob, emu_big)
+    finally:
+        rh.close()
+
+
 def test_png_scanlines_from_the_device(tmp_path, built):
     """rr_frame_out.rainy_png / mask_png: the PNG files built from the device's Sub-filtered scanlines decode to the
     very pixels the host-side writers produce from image_u8 / mask (generator.py:466-467)."""

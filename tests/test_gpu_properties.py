@@ -172,3 +172,50 @@ def test_float_colour_compositor(setup):
     assert np.array_equal(out['status'], ref['status'])
     assert np.array_equal(out['mask'], ref['mask']) and np.array_equal(out['mask_i32'], ref['mask_i32'])
     assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+
+
+def test_narrow_input_types(setup):
+    """rr_frame_in.in_types: the image as float32 or as the bytes cv2.imread returned, the xyY map and the solid angles as
+    float32 -- a third to an eighth of the HBM bytes of the float64 arrays.  The mask never reads them (bit-exact, statuses
+    equal); the image stays within 1 LSB of the float64-input rendering and of the g++ build of the kernel arithmetic.
+    Both compositors, a fogged image of its own type next to the plain one, and the colour branch forced to float64."""
+    sc, bg, env, drops, rh, base = setup
+    emu = h.emu_render(sc, bg, bg, env, drops)
+
+    def check(out, ref_img, tag):
+        assert np.array_equal(out['status'], base['status']), tag
+        assert np.array_equal(out['mask'], base['mask']) and np.array_equal(out['mask_i32'], base['mask_i32']), tag
+        d = np.abs(out['image_u8'].astype(int) - ref_img.astype(int)).max()
+        assert d <= 1, '%s: image differs by %d LSB' % (tag, d)
+
+    bg32, env32 = bg.astype(np.float32), env.astype(np.float32)
+    for comp in (False, True):
+        out = rh.render_frames([dict(bg=bg32, rainy_bg=bg32, env_xyY=env32, omega=sc.omega, drops=drops)], want_composite=comp)[0]
+        check(out, base['image_u8'], 'float32 image + map, composite=%s' % comp)
+        check(out, emu['image_u8'], 'float32 image + map vs hostemu, composite=%s' % comp)
+        out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env32, omega=sc.omega, drops=drops)], want_composite=comp)[0]
+        check(out, base['image_u8'], 'float64 image, float32 map, composite=%s' % comp)
+    # bytes: the reference's own input (bg = imread / 255.0); rainy_bg a separate float32 array (a fogged image)
+    bg8 = np.round(bg * 255).astype(np.uint8)
+    ref8 = rh.render_frames([dict(bg=bg8 / 255.0, rainy_bg=bg8 / 255.0, env_xyY=env, omega=sc.omega, drops=drops)])[0]
+    for comp in (False, True):
+        out = rh.render_frames([dict(bg=bg8, rainy_bg=bg8, env_xyY=env32, omega=sc.omega, drops=drops)], want_composite=comp)[0]
+        check(out, ref8['image_u8'], 'uint8 image, composite=%s' % comp)
+        rainy = (0.9 * (bg8 / 255.0)).astype(np.float32)
+        ref = rh.render_frames([dict(bg=bg8 / 255.0, rainy_bg=rainy.astype(np.float64), env_xyY=env, omega=sc.omega, drops=drops)])[0]
+        out = rh.render_frames([dict(bg=bg8, rainy_bg=rainy, env_xyY=env, omega=sc.omega, drops=drops)], want_composite=comp)[0]
+        check(out, ref['image_u8'], 'uint8 bg + float32 rainy_bg, composite=%s' % comp)
+    # float32 inputs inside a batch next to float64 ones, device-resident solid angles as float32
+    rh.set_solid_angles(sc.omega)
+    outs = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[:200]),
+                             dict(bg=bg32, rainy_bg=bg32, env_xyY=env32, omega=None, drops=drops)], want_composite=False)
+    check(outs[1], base['image_u8'], 'mixed batch')
+    # the colour branch in float64 throughout (RR_OPT_FOV_F32 0) and in float always (1): same statuses, same mask
+    for v in (0, 1):
+        rh.set_option(h.hb.RR_OPT_FOV_F32, v)
+        try:
+            for comp in (False, True):
+                out = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)], want_composite=comp)[0]
+                check(out, base['image_u8'], 'RR_OPT_FOV_F32 %d, composite=%s' % (v, comp))
+        finally:
+            rh.set_option(h.hb.RR_OPT_FOV_F32, 2)

@@ -148,3 +148,40 @@ def test_work_list_is_decided_once_world2(tmp_path):
     assert w0 == w1 == list(range(7)) and e0 == e1 == 0             # one list, made before any rank wrote
     assert sorted(m0 + m1) == list(range(7)) and not set(m0) & set(m1)
     assert s0 == s1 and s0[3] == (0, 3) and s0[6] == (0, 3, 6)      # noise-seed history: frames 0, 3, 6 share simulated frame 0
+
+
+def _failing_worker(rank, world, port, q):
+    import importlib
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sharding = importlib.import_module('rain-rendering_amd.sharding')
+
+    def decide():
+        raise FileNotFoundError("no such particles file")        # only ever evaluated on rank 0
+    try:
+        sharding.rank0_decides(decide, rank, world)
+        q.put((rank, 'returned'))
+    except Exception as e:                                          # noqa: BLE001
+        q.put((rank, type(e).__name__ + ': ' + str(e)))
+    assert sharding.rank0_decides(lambda: 41 + 1, rank, world) == 42   # the group is still usable afterwards
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_failure_reaches_every_rank_world2():
+    """A decision that raises on rank 0 raises on every rank (the others used to wait in the broadcast for its time-out)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == 'FileNotFoundError: no such particles file'
+    assert res[1] == 'RuntimeError: rank 0 failed: FileNotFoundError: no such particles file'
