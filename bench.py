@@ -370,6 +370,7 @@ def main():
     ap.add_argument('--sweep', action='append', default=[], help='A/B: after the headline, time the loop again under these '
                     'rr_set_option sets ("6=3,3=512"); one JSON line each on stderr; implies the lean run')
     ap.add_argument('--scene-dir', default=None, help='(used by the PMC passes) directory of a simulation to reuse')
+    ap.add_argument('--phases', action='store_true', help='(phase-clock build of the library) print the per-phase wave cycles')
     ap.add_argument('--inner', action='store_true', help='(used by the PMC passes) timed loop only, no extras, no JSON')
     args = ap.parse_args()
     if args.inner or args.sweep:
@@ -475,6 +476,21 @@ def main():
     rh.profile(False)
     assert rh.synchronize(), "tile arena regrew inside the timed region"
     stats = rh.profile_read()
+    if args.phases and hasattr(rh.lib, 'rr_debug_phases'):         # phase-clock build of the library (scripts/phase_timing.sh)
+        buf = (ctypes.c_ulonglong * 64)()
+        rh.lib.rr_debug_phases.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        rh._check(rh.lib.rr_debug_phases(rh.h, buf, 1), 'rr_debug_phases')
+        names = {0: ('k_tile', ['stage plan+texture', 'row intervals', 'samples', 'horizontal folds', 'wait for waves', 'vertical folds+store', '-', 'barrier at item start']),
+                 1: ('k_tile_big', ['search+barriers', 'plan fields', 'pixel']),
+                 2: ('k_blur_small', ['plan+weights+raw->LDS', 'row pass', 'column pass+store']),
+                 3: ('k_blur_fused', ['issue loads', 'barrier (loads land)', 'row pass', 'barrier', 'column pass+store', 'barrier'])}
+        calls = args.steps + args.warmup
+        sys.stderr.write("PHASES (shader cycles summed over waves, per call; share of the kernel's wave time)\n")
+        for kid, (kn, ph) in names.items():
+            row = [int(buf[kid * 8 + q]) for q in range(8)]
+            tot = sum(row) or 1
+            sys.stderr.write("  %-14s %s\n" % (kn, ', '.join('%s %.1f%% (%.3g)' % (ph[q] if q < len(ph) else '?', 100.0 * row[q] / tot, row[q] / calls)
+                                                              for q in range(8) if row[q])))
     if args.inner:
         rh.close()
         return

@@ -121,6 +121,29 @@ __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Phase clocks (builds with -DRR_PHASES only: scripts/phase_timing.sh): shader cycles a wave spends between the PH()
+// marks of a kernel, summed over all waves -- where the latency-bound tile / blur kernels spend their time.  The product
+// build carries none of this.
+#ifdef RR_PHASES
+__device__ unsigned long long g_phase[8][8];
+#define PH_DECL unsigned long long ph_t0_ = __builtin_readcyclecounter(), ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(k)                                                   \
+  {                                                             \
+    const unsigned long long ph_n_ = __builtin_readcyclecounter(); \
+    ph_acc_[k] += ph_n_ - ph_t0_;                               \
+    ph_t0_ = ph_n_;                                             \
+  }
+#define PH_FLUSH(kid)                                           \
+  if ((threadIdx.x & 63) == 0) {                                \
+    for (int ph_q_ = 0; ph_q_ < 8; ph_q_++)                     \
+      if (ph_acc_[ph_q_]) atomicAdd(&g_phase[kid][ph_q_], ph_acc_[ph_q_]); \
+  }
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_FLUSH(kid)
+#endif
+
 struct Scratch {                    // per-batch device scratch, all indexed [frame][...]
   DropPlan* plan;
   CompRec* comp;
@@ -874,7 +897,7 @@ __device__ inline float wave_incl_scan_f32(float v) {
 }
 __device__ inline float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
-template <int DPT, int EMAX>
+template <int DPT, int EMAX, bool E32>
 __global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int Dp, int rpb, int nchunk, Scratch sc) {
   extern __shared__ __attribute__((aligned(16))) float s_dyn32[];
   const int We = dm.We;
@@ -905,9 +928,8 @@ __global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Di
   for (int d = 0; d < DPT; d++) S[d][0] = S[d][1] = S[d][2] = S[d][3] = 0.f;
   double totY = 0.0, totw = 0.0;                         // row totals (Y*w, w), kept by the thread that owns the last column
   float pa[EMAX][4], pb[EMAX][4];
-  const bool e32 = (fr.in_types & RR_IN_ENV_F32) != 0;
   auto load_row = [&](int y) {
-    if (e32) {                                             // float map: 12 + 4 bytes per texel, two texels per lane as 8-byte pieces
+    if (E32) {                                             // float map: 12 + 4 bytes per texel, two texels per lane as 8-byte pieces
       const global_ptr<const float> env = as_global(static_cast<const float*>(fr.env)) + (int64_t)y * We * 3;
       const global_ptr<const float> om = as_global(static_cast<const float*>(fr.omega)) + (int64_t)y * We;
 #pragma unroll
@@ -1456,6 +1478,24 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
 }
 
 
+// TexLut whose at4 -- the four neighbours of one texture row the bicubic interior case reads -- is ONE (unaligned) 4-byte
+// global load instead of four 1-byte loads: a Big pixel then issues 4 loads, not 16 (the texture bytes come from L2).
+struct TexLutWide {
+  const uint8_t* t;
+  const double* lut;
+  int h, w;
+  __device__ double at(int64_t y, int64_t x) const { return lut[t[y * w + x]]; }
+  __device__ void at4(int64_t y, int64_t x, double v[4]) const {
+    uint32_t u;
+    __builtin_memcpy(&u, as_global(t) + (y * w + x), 4);
+    v[0] = lut[u & 0xffu]; v[1] = lut[(u >> 8) & 0xffu]; v[2] = lut[(u >> 16) & 0xffu]; v[3] = lut[u >> 24];
+  }
+  __device__ double tap(int64_t y, int64_t x) const {
+    if (y < 0 || y >= h || x < 0 || x >= w) return 0.0;
+    return at(y, x);
+  }
+};
+
 // Big drops (cv2.warpPerspective, INTER_CUBIC): ONE THREAD PER OUTPUT PIXEL over the concatenation of
 // all Big tiles of the frame (k_lists' pixel prefix).  A Big tile has ~400 pixels, so a workgroup per
 // drop was all per-item latency; flattened, every lane has a pixel and the grid is full.  Texels come
@@ -1472,6 +1512,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
   const int n_big = sc.counts[f * 8 + 5], total = sc.counts[f * 8 + 6];
   const int32_t* lbig = sc.list_big + (int64_t)f * max_drops;
   const int32_t* boff = sc.big_off + (int64_t)f * max_drops + f;
+  PH_DECL
   for (int pb = blockIdx.x * 256; pb < total; pb += gridDim.x * 256) {
     __syncthreads();
     if (t == 0) {                                   // last item whose first pixel is <= pb
@@ -1483,6 +1524,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
       s_first = lo;
     }
     __syncthreads();
+    PH(0)                                           // search + barriers
     const int pix = pb + t;
     if (pix >= total) continue;
     int j = s_first;
@@ -1491,9 +1533,12 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
     const DropPlan& p = sc.plan[gi];
     const int local = pix - boff[j];
     const int y = local / p.tw, x = local - y * p.tw;
-    TexLut tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
+    TexLutWide tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
+    PH(1)                                           // plan fields
     sc.arena[p.a0_off + local] = warp_big_pixel(p, tx, s_ctab, x, y);
+    PH(2)                                           // the pixel
   }
+  PH_FLUSH(1)
 }
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
@@ -1511,9 +1556,11 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   const int n_items = sc.counts[f * 8 + 0];
   if ((int)blockIdx.x >= n_items) return;                                // (before the division table: most frames have few tiles left after k_dedup)
   s_lut[t] = (double)t / 255.0;
+  PH_DECL
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the rot-fast list
   const int64_t gi = (int64_t)f * max_drops + sc.list_rot[(int64_t)f * max_drops + item];
   __syncthreads();
+  PH(7)
   {
     const int32_t* src = reinterpret_cast<const int32_t*>(&sc.plan[gi]);
     int32_t* dst = reinterpret_cast<int32_t*>(&sp);
@@ -1532,6 +1579,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   for (int rx = t; rx < p.nW; rx += 256) s_adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
   for (int dx = t; dx < tw; dx += 256) s_ax[dx] = area_span(p.nW, p.scale_x, dx);
   __syncthreads();
+  PH(0)                                             // plan + texture + per-column tables staged
   const RowGeom geom = row_geom(p, sh, sw);
   const int pitch = imin(imax(tile_pitch(p, sh, sw), 1), CAN_W);
   const int Rw = imax(imin(ROWS_W, CAN_W / pitch), 1);       // canvas rows a wave stages at a time
@@ -1630,6 +1678,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
         rowp[lane] = make_int4(X0, Y0, xa, imin(n, pitch));
       }
       wave_lds_sync();
+      PH(1)                                         // row intervals
       // ---- 1a: bilinear samples of the rotated texture, lanes flattened over (row, column) ----
       const int nidx = nr * pitch;
       for (int idx = lane; idx < nidx; idx += 128) {
@@ -1645,6 +1694,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
         if (okb) can[ib] = vb;
       }
       wave_lds_sync();
+      PH(2)                                         // samples
       // ---- 1b: horizontal folds, one lane per (row, destination column) ----
       const int items = nr * twc;
       for (int it = lane; it < items; it += 64) {
@@ -1674,8 +1724,10 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
         s_buf[(r0 - lo + r) * twc + dxl] = b;
       }
       wave_lds_sync();
+      PH(3)                                         // horizontal folds
     }
     __syncthreads();
+    PH(4)                                           // waiting for the other waves
     // ---- 2: vertical folds ----
     const int npx = (dy1 - dy0) * twc;
     for (int it = t; it < npx; it += 256) {
@@ -1700,9 +1752,11 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       A0[dy * tw + dx] = clip01(acc);
     }
     __syncthreads();
+    PH(5)                                           // vertical folds + store
   }
   }
   }
+  PH_FLUSH(0)
 }
 
 // ---------------------------------------------------------------------------
@@ -1899,6 +1953,7 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
   const int n_items = sc.counts[f * 8 + 2];
   const int4* items = sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP;
   int cur = -1;
+  PH_DECL
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // grid-stride over (drop, sub-tile range) items
   const int4 item = items[it];
   const int64_t gi = (int64_t)f * max_drops + item.x;
@@ -1961,7 +2016,9 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
         double2* Y2 = reinterpret_cast<double2*>(Y);
         for (int i = t; i < nz2; i += 256) Y2[i] = make_double2(0.0, 0.0);
       }
+      PH(0)                                         // plan, tables, raw sub-tile -> LDS (issue)
       __syncthreads();
+      PH(1)                                         // barrier: the loads land
       // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns data column xc and FOUR consecutive
       // rows; as the tap distance shrinks the upper/lower operand windows slide by one row, so each
       // step needs two new LDS values instead of eight (register rotation).  Lanes run along x.
@@ -1980,7 +2037,9 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
           o[3 * yp] = acc3;
         }
       }
+      PH(2)                                         // row pass
       __syncthreads();
+      PH(3)
       // axis 1 (columns, sigma = c/2): a thread owns row y and four consecutive columns; lanes run
       // down the rows (odd pitch -> distinct banks).
       {
@@ -2007,10 +2066,13 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
           }
         }
       }
+      PH(4)                                         // column pass + store
       __syncthreads();
+      PH(5)
     }
   }
   }
+  PH_FLUSH(3)
 }
 
 // Small blurred tiles (most of them): one WAVE per drop, wave-private LDS, no block barrier.  Same scheme as the fused
@@ -2024,6 +2086,7 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
   double* Y = Ys[wave];
   const int n_items = sc.counts[f * 8 + 4];
   const int32_t* list = sc.list_small + (int64_t)f * max_drops;
+  PH_DECL
   for (int it = blockIdx.x * 4 + wave; it < n_items; it += gridDim.x * 4) {
     const DropPlan& p = sc.plan[(int64_t)f * max_drops + list[it]];
     const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;          // effective tile
@@ -2064,6 +2127,7 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
       for (int i = lane; i < nz2; i += 64) Y2[i] = make_double2(0.0, 0.0);
     }
     wave_lds_sync();
+    PH(0)                                           // plan, weights, raw tile -> LDS
     // axis 0 (rows): a lane owns data column x and four consecutive rows
     {
       const int nv = (php >> 2) * tw;
@@ -2080,6 +2144,7 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
       }
     }
     wave_lds_sync();
+    PH(1)                                           // row pass
     // axis 1 (columns) -> global: a lane owns row y and four consecutive columns; lanes run down the rows
     {
       const int ncb = (pw + 3) >> 2, nh = ncb * ph;
@@ -2105,7 +2170,9 @@ __global__ __launch_bounds__(256) void k_blur_small(const FrameDesc* frames, int
       }
     }
     wave_lds_sync();
+    PH(2)                                           // column pass + store
   }
+  PH_FLUSH(2)
 }
 
 // ---- large defocus radii (r > BR_MAX: drops a few centimetres from a fast lens) and tiles no LDS layout takes ----
@@ -3510,9 +3577,20 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         hipLaunchKernelGGL(kern, dim3(COL_PARTS * nchunk, n), dim3(NT), bytes, s, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
+      // (the element type of the map is a template parameter: a run-time choice inside the row loader cost the 8-drops-per-
+      //  thread variant 250 bytes of scratch per lane; a batch is all float or takes the float64 loader)
+      bool all32 = true;
+      for (int f = 0; f < n; f++) all32 = all32 && (in[f].in_types & RR_IN_ENV_F32);
+      for (int f = 0; f < n && !all32; f++)
+        if (in[f].in_types & RR_IN_ENV_F32) {
+          ctx->err = "RR_IN_ENV_F32 must be set for every frame of a batch or for none";
+          return RR_E_ARG;
+        }
       hipError_t e = fov32
-                         ? (e1 ? (DPT == 1 ? launch32(k_fov_sums32<1, 1>) : DPT == 2 ? launch32(k_fov_sums32<2, 1>) : DPT == 4 ? launch32(k_fov_sums32<4, 1>) : launch32(k_fov_sums32<8, 1>))
-                               : (DPT == 1 ? launch32(k_fov_sums32<1, 2>) : DPT == 2 ? launch32(k_fov_sums32<2, 2>) : DPT == 4 ? launch32(k_fov_sums32<4, 2>) : launch32(k_fov_sums32<8, 2>)))
+                         ? (all32 ? (e1 ? (DPT == 1 ? launch32(k_fov_sums32<1, 1, true>) : DPT == 2 ? launch32(k_fov_sums32<2, 1, true>) : DPT == 4 ? launch32(k_fov_sums32<4, 1, true>) : launch32(k_fov_sums32<8, 1, true>))
+                                        : (DPT == 1 ? launch32(k_fov_sums32<1, 2, true>) : DPT == 2 ? launch32(k_fov_sums32<2, 2, true>) : DPT == 4 ? launch32(k_fov_sums32<4, 2, true>) : launch32(k_fov_sums32<8, 2, true>)))
+                                  : (e1 ? (DPT == 1 ? launch32(k_fov_sums32<1, 1, false>) : DPT == 2 ? launch32(k_fov_sums32<2, 1, false>) : DPT == 4 ? launch32(k_fov_sums32<4, 1, false>) : launch32(k_fov_sums32<8, 1, false>))
+                                        : (DPT == 1 ? launch32(k_fov_sums32<1, 2, false>) : DPT == 2 ? launch32(k_fov_sums32<2, 2, false>) : DPT == 4 ? launch32(k_fov_sums32<4, 2, false>) : launch32(k_fov_sums32<8, 2, false>))))
                      : e1 ? (DPT == 1 ? launch(k_fov_sums<1, 1>) : DPT == 2 ? launch(k_fov_sums<2, 1>) : DPT == 4 ? launch(k_fov_sums<4, 1>) : launch(k_fov_sums<8, 1>))
                         : (DPT == 1 ? launch(k_fov_sums<1, 2>) : DPT == 2 ? launch(k_fov_sums<2, 2>) : DPT == 4 ? launch(k_fov_sums<4, 2>) : launch(k_fov_sums<8, 2>));
       if (e != hipSuccess) {
@@ -4898,3 +4976,18 @@ int rr_profile_read(rr_ctx* ctx, rr_kernel_stat* out, int32_t cap) {
 }
 
 }  // extern "C"
+
+#ifdef RR_PHASES
+// (phase-clock builds only; not part of include/rainhip.h) out[64] = g_phase, then cleared when `reset`
+extern "C" int rr_debug_phases(rr_ctx* ctx, unsigned long long* out, int reset) {
+  if (!ctx || !out) return RR_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64));
+  if (reset) {
+    unsigned long long z[64] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+  }
+  return RR_OK;
+}
+#endif

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'librainhip.so')
+# (RAINHIP_LIB: another build of the same library -- the phase-clock build of scripts/phase_timing.sh; the C library itself reads no environment)
+LIB_PATH = os.environ.get('RAINHIP_LIB') or os.path.join(_HERE, 'csrc', 'librainhip.so')
 
 RR_MAX_FOV = 32
 RR_E_ARENA = -5

@@ -213,49 +213,12 @@ def test_rccl_broadcast_of_the_streak_database_world1(tmp_path, built):
     """The N>1 start-up on the one GPU of the test tier: init_process_group('nccl', device_id=...) with a single rank, then
     sharding.load_and_broadcast_streak_db's collective route -- RCCL broadcast of the header and of the packed database as
     DEVICE tensors, rr_set_streak_db_device on the received buffer -- and a frame rendered from it, equal to a frame rendered
-    from a plainly uploaded database.  (The 8-GPU scaling run is the driver's; this is the code it executes first.)
-    Reference role: main_threaded.py:98-200 (the reference's parallel mode)."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    sharding = importlib.import_module('rain-rendering_amd.sharding')
-    assert torch.cuda.is_available()
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    sc = h.Scene(tmp_path, 96, 160, 150, seed0=61)
-    bg, env = sc.frame_inputs(0)
-    drops = sc.product_drops(0)
-    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
-    plain = h.hb.RainHip(0)
-    try:
-        plain.set_streak_db(sc.db.streaks_light)
-        plain.set_camera(sc.cam)
-        want = plain.render_frames([fr])[0]
-    finally:
-        plain.close()
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(dev)
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
-    rh = h.hb.RainHip(0)
-    try:
-        assert dist.get_backend() == 'nccl'
-        db = h.bw.DBManager(streaks_path=sc.tex_dir, norm_coeff_path=sc.norm)
-        sharding.load_and_broadcast_streak_db(db, rh, 0, 1, force_collective=True)
-        # rank0_decides in a live group of one rank is a plain call; an object broadcast works too
-        box = ['work list']
-        dist.broadcast_object_list(box, src=0)
-        assert box == ['work list']
-        rh.set_camera(sc.cam)
-        got = rh.render_frames([fr])[0]
-        torch.cuda.synchronize()
-    finally:
-        rh.close()
-        if created:
-            dist.destroy_process_group()
-    for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
-        assert np.array_equal(got[k], want[k]), k
-    assert len(db.streaks_light) == 50 and (want['status'] == 0).sum() > 100
+    from a plainly uploaded database.  (The 8-GPU scaling run is the driver's; this is the code it executes first.)  In a
+    process of its own that imports torch BEFORE the library is loaded, the order bench.py and main.py use under a launcher
+    (this pytest process has librainhip.so's HIP runtime loaded already).  Reference role: main_threaded.py:98-200."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nccl_world1_worker.py')
+    r = subprocess.run([sys.executable, worker, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and b'NCCL-WORLD1-OK' in r.stdout, (r.stdout.decode()[-2000:], r.stderr.decode()[-4000:])
