@@ -123,7 +123,7 @@ typedef struct {
    * a caller that holds them narrower hands them over as they are -- a third to an eighth of the HBM bytes:
    *   RR_IN_BG_F32 / RR_IN_BG_U8         `bg` is float32 / uint8 (uint8: the bytes cv2.imread returned; bg = bytes / 255.0)
    *   RR_IN_RAINY_F32 / RR_IN_RAINY_U8   the same for `rainy_bg` (when rainy_bg == bg the BG flags count for both)
-   *   RR_IN_ENV_F32                      `env_xyY` AND `omega` (when not NULL) are float32
+   *   RR_IN_ENV_F32                      `env_xyY` AND `omega` (when not NULL) are float32; for every frame of a batch or for none
    * rr_render_frames_device and rr_render_frames; rr_pipeline_* produce rainy_bg / env_xyY themselves. */
   int32_t in_types;
   const rr_ext_tile* ext;         /* optional: n_drops entries (rr_render_frames / rr_render_frames_device only) */
@@ -350,7 +350,11 @@ enum {
    * the wrap structure of its polygon is checked against an error bound; a drop that comes close is evaluated in float64)
    * and the environment-map sums under the polygon.  They only feed the drop's colour constants, which only scale
    * rainy_image (contract: +-1 LSB; the mask and the drop statuses never see the difference). */
-  RR_OPT_FOV_F32 = 10
+  RR_OPT_FOV_F32 = 10,
+  /* tuning: 1 (default) a rotate + resize tile is rendered by ONE wave that reads the padded texture copies through the
+   * vector cache (no block barrier inside a tile; needs RR_OPT_PADDED_TEXTURES 1); 0: by a workgroup with the texture staged
+   * in LDS.  The same folds in the same order: identical tiles. */
+  RR_OPT_TILE_WAVES = 11
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

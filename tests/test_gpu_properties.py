@@ -122,17 +122,20 @@ def test_colour_path_options_do_not_change_results(setup):
         assert np.array_equal(out['mask'], base['mask']) and np.array_equal(out['mask_i32'], base['mask_i32']), opts
         assert np.abs(out['image_u8'].astype(int) - base['image_u8'].astype(int)).max() <= 1, opts
         assert np.abs(out['rainy_bg'] - base['rainy_bg']).max() < 1e-9, opts
-    # texture staging from the pre-padded copies (default) or byte by byte: the same LDS bytes, so every output bit equal
-    alt = h.hb.RainHip(0)
-    try:
-        alt.set_option(h.hb.RR_OPT_PADDED_TEXTURES, 0)
-        alt.set_streak_db(sc.db.streaks_light)
-        alt.set_camera(sc.cam)
-        out = alt.render_frames([fr])[0]
-    finally:
-        alt.close()
-    for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
-        assert np.array_equal(out[k], base[k]), k
+    # the rotate + resize tiles by a wave each reading the padded texture copies (default), by a workgroup with the texture
+    # staged in LDS from those copies (RR_OPT_TILE_WAVES 0), or staged byte by byte (RR_OPT_PADDED_TEXTURES 0): the same
+    # folds in the same order, so every output bit is equal
+    for opt in (h.hb.RR_OPT_TILE_WAVES, h.hb.RR_OPT_PADDED_TEXTURES):
+        alt = h.hb.RainHip(0)
+        try:
+            alt.set_option(opt, 0)
+            alt.set_streak_db(sc.db.streaks_light)
+            alt.set_camera(sc.cam)
+            out = alt.render_frames([fr])[0]
+        finally:
+            alt.close()
+        for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
+            assert np.array_equal(out[k], base[k]), (opt, k)
     with pytest.raises(RuntimeError):
         rh.set_option(99, 1)
 
@@ -205,11 +208,15 @@ def test_narrow_input_types(setup):
         ref = rh.render_frames([dict(bg=bg8 / 255.0, rainy_bg=rainy.astype(np.float64), env_xyY=env, omega=sc.omega, drops=drops)])[0]
         out = rh.render_frames([dict(bg=bg8, rainy_bg=rainy, env_xyY=env, omega=sc.omega, drops=drops)], want_composite=comp)[0]
         check(out, ref['image_u8'], 'uint8 bg + float32 rainy_bg, composite=%s' % comp)
-    # float32 inputs inside a batch next to float64 ones, device-resident solid angles as float32
+    # inside a batch: image types may differ from frame to frame, the map's type is one per batch (RR_E_ARG otherwise);
+    # device-resident solid angles (omega=None) as float32
     rh.set_solid_angles(sc.omega)
-    outs = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[:200]),
+    outs = rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env32, omega=None, drops=drops[:200]),
                              dict(bg=bg32, rainy_bg=bg32, env_xyY=env32, omega=None, drops=drops)], want_composite=False)
     check(outs[1], base['image_u8'], 'mixed batch')
+    with pytest.raises(RuntimeError):
+        rh.render_frames([dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops[:200]),
+                          dict(bg=bg32, rainy_bg=bg32, env_xyY=env32, omega=None, drops=drops[:200])], want_composite=False)
     # the colour branch in float64 throughout (RR_OPT_FOV_F32 0) and in float always (1): same statuses, same mask
     for v in (0, 1):
         rh.set_option(h.hb.RR_OPT_FOV_F32, v)
