@@ -2257,6 +2257,7 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
 //     holds the tw columns under the raw tile with 2*r1 zero rows above: its data rows ARE the raw tile's dense layout, so
 //     the load is a linear copy -- four 16-byte loads per lane cover the 512 doubles X can hold -- written to LDS when
 //     the previous drop's column pass has finished; only the halo rows are cleared.
+typedef double double2_v __attribute__((ext_vector_type(2)));     // (a native vector: loads through address-space pointers)
 struct SmallItem {                  // what k_blur_small needs of a drop, all wave-uniform
   int li, r1, r2, tw, th, pw, ph, epitch, epad;
   long long a0, a1;
@@ -2278,15 +2279,15 @@ __global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, 
     SmallItem o{li, p->r1, p->r2, p->tw, p->th, p->ew, p->eh, p->epitch, p->epad, (long long)p->a0_off, (long long)p->a1_off};
     return o;
   };
-  double2 R[4];                       // the raw tile of the drop AFTER the current one, lane-linear
+  double2_v R[4];                     // the raw tile of the drop AFTER the current one, lane-linear
   double nw1 = 0.0, nw2 = 0.0;        // its weights: lane l holds w(distance l) of each axis
   auto issue = [&](const SmallItem& d) {
-    const global_ptr<const double2> raw2 = as_global(reinterpret_cast<const double2*>(sc.arena + d.a0));   // tiles start on 128-byte lines
+    const global_ptr<const double2_v> raw2 = as_global(reinterpret_cast<const double2_v*>(sc.arena + d.a0));   // tiles start on 128-byte lines
     const int n = d.tw * d.th;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int k2 = lane + 64 * j;
-      R[j] = make_double2(0.0, 0.0);
+      R[j] = double2_v{0.0, 0.0};
       if (2 * k2 < n) R[j] = raw2[k2];               // (an odd tile's last pair reads one double of the arena's own padding)
     }
     const global_ptr<const double> wt = as_global(sc.wtab + ((int64_t)f * max_drops + d.li) * 2 * (BR_MAX + 1));   // hw[k] = w(|k - r|), k_blur_weights

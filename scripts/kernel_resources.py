@@ -8,7 +8,11 @@ os.makedirs(tmp, exist_ok=True)
 cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-unused-value', '-Wno-unused-result',
        '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '--save-temps', '-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, 'rainhip.hip'),
        '-o', os.path.join(tmp, 'rainhip.o')]
-txt = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True).stderr
+r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+txt = r.stderr
+if r.returncode != 0:
+    sys.stderr.write('\n'.join(l for l in txt.split('\n') if 'error' in l or 'note:' in l)[:4000] + '\n')
+    raise SystemExit('hipcc failed (%d)' % r.returncode)
 rows = []
 for b in re.split(r'remark: [^\n]*Function Name: ', txt)[1:]:
     name = b.split('\n')[0].split(' [-Rpass')[0].strip()
