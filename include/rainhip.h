@@ -351,10 +351,8 @@ enum {
    * and the environment-map sums under the polygon.  They only feed the drop's colour constants, which only scale
    * rainy_image (contract: +-1 LSB; the mask and the drop statuses never see the difference). */
   RR_OPT_FOV_F32 = 10,
-  /* tuning: 1 (default) a rotate + resize tile is rendered by ONE wave that reads the padded texture copies through the
-   * vector cache (no block barrier inside a tile; needs RR_OPT_PADDED_TEXTURES 1); 0: by a workgroup with the texture staged
-   * in LDS.  The same folds in the same order: identical tiles. */
-  RR_OPT_TILE_WAVES = 11
+  RR_OPT_COMPOSITE_WAVES = 11       /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
+                                     * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -23,6 +23,7 @@
 // rr_prepass.h holds the fog / environment-map pre-pass kernels, rr_host.cpp the host-only helpers.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -159,8 +160,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int64_t* arena_need;              // [frame]
   int32_t* overflow;                // the batch's own arena-overflow flag (ctx: [1 + RR_PIPE_SLOTS], one per pipeline slot + the device-pointer calls)
   unsigned long long* need_max;     // [1] largest per-frame arena need of every batch since the arena was last (re)sized
-  int32_t* list_rot;                // [frame][drops]  drops taken by k_tile / k_tile_wave (integer-ratio drops first)
-  int32_t* rot_int;                 // [frame] how many integer-ratio (ResizeAreaFast) drops lead list_rot
+  int32_t* list_rot;                // [frame][drops]  drops taken by k_tile
   int32_t* list_gen;                // [frame][drops]  drops taken by k_tile_generic
   int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
   int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
 
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
-                                              int only_int, Scratch sc) {
+                                              Scratch sc) {
   const int f = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   __shared__ DropPlan sp;
   __shared__ double s_lut[256];
@@ -1558,8 +1558,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ double s_buf[BUF_MAX];
   __shared__ double s_can[4][CAN_W];
   __shared__ int4 s_row[4][ROWS_W];
-  // only_int: the integer-ratio tiles at the front of the list (the general ones are k_tile_wave's)
-  const int n_items = only_int ? sc.rot_int[f] : sc.counts[f * 8 + 0];
+  const int n_items = sc.counts[f * 8 + 0];
   if ((int)blockIdx.x >= n_items) return;                                // (before the division table: most frames have few tiles left after k_dedup)
   s_lut[t] = (double)t / 255.0;
   PH_DECL
@@ -1672,9 +1671,13 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     const int dy1 = imin(dy0 + k_dy, th);
     const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
     const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, p.nH - 1);
-    // ---- canvas rows lo..hi: each wave takes groups of Rw rows, no block barrier needed ----
-    for (int r0 = lo + wave * Rw; r0 <= hi; r0 += 4 * Rw) {
-      const int nr = imin(Rw, hi - r0 + 1);
+    // ---- canvas rows lo..hi: every wave takes an EQUAL contiguous share, Rw rows at a time, no block barrier needed
+    //      (r04: with chunks of Rw rows dealt round-robin the waves finished a group up to a chunk apart -- 7 chunks for
+    //      4 waves -- and the phase clocks showed 35 % of the kernel's wave time spent at the barrier below) ----
+    const int share = (hi - lo + 4) >> 2;
+    const int w_lo = lo + wave * share, w_hi = imin(hi, w_lo + share - 1);
+    for (int r0 = w_lo; r0 <= w_hi; r0 += Rw) {
+      const int nr = imin(Rw, w_hi - r0 + 1);
       if (lane < nr) {
         const int c = r0 + lane;
         const int ry = p.flip ? (p.nH - 1 - c) : c;
@@ -1766,170 +1769,6 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
 }
 
 // ---------------------------------------------------------------------------
-// rotate + flip + INTER_AREA tiles, one WAVE per tile (r04)
-// ---------------------------------------------------------------------------
-// k_tile gives a tile to a workgroup: the phase clocks (scripts/phase_timing.sh) showed its waves waiting for each other
-// at the block barriers between canvas-row groups for 35 % of their time, and another 5 % at the barriers around the
-// texture staging.  Here a tile belongs to ONE wave, and nothing in the tile loop is a block barrier:
-//   * the texture is not staged at all: the bilinear taps read the pre-padded copy (k_pad_textures) through the vector
-//     cache -- two unaligned 2-byte loads per sample; the 50 textures (~400 KB) live in L2;
-//   * the plan travels as wave-uniform values (scalar loads), the per-column fixed-point terms and the resizeArea_ column
-//     tables are per wave (LDS);
-//   * a unit of work is (destination row, group of <= 16 destination columns): the wave samples the canvas rows that row
-//     needs, restricted to the canvas columns of the group, in chunks -- 1a samples (lanes flattened over row x column),
-//     1b horizontal folds (one lane per row x destination column), 2 the vertical fold carried in a register per
-//     destination column from chunk to chunk (canvas rows arrive in the order resizeArea_ adds them).
-// Every fold runs in the order of raw_tile_pixel / the oracle: the tile's bits are k_tile's.  A canvas row that two
-// neighbouring destination rows share (their partial cells) is sampled twice: ~5 % more samples, no synchronisation.
-constexpr int TW_CAN = 512;         // doubles of sample staging per wave
-constexpr int TW_BUF = 128;         // horizontal-fold results of one chunk per wave
-constexpr int TW_COLS = 16;         // destination columns per unit
-__device__ inline void gl_rot_sample2(const global_ptr<const uint8_t> gpad, const double* s_lut, int P, int sh, int sw, int XA, int YA, int2 dA,
-                                      int XB, int YB, int2 dB, double& outA, double& outB) {
-  const int Xa = (XA + dA.x) >> 5, Ya = (YA + dA.y) >> 5, Xb = (XB + dB.x) >> 5, Yb = (YB + dB.y) >> 5;
-  const int sxa = imin(imax(Xa >> 5, -2), sw), sya = imin(imax(Ya >> 5, -2), sh);
-  const int sxb = imin(imax(Xb >> 5, -2), sw), syb = imin(imax(Yb >> 5, -2), sh);
-  const global_ptr<const uint8_t> qa = gpad + ((sya + 2) * P + (sxa + 2));
-  const global_ptr<const uint8_t> qb = gpad + ((syb + 2) * P + (sxb + 2));
-  uint16_t a01, a23, b01, b23;                           // two neighbouring texels per load (any alignment)
-  __builtin_memcpy(&a01, qa, 2);
-  __builtin_memcpy(&a23, qa + P, 2);
-  __builtin_memcpy(&b01, qb, 2);
-  __builtin_memcpy(&b23, qb + P, 2);
-  const double va0 = s_lut[a01 & 0xff], va1 = s_lut[a01 >> 8], va2 = s_lut[a23 & 0xff], va3 = s_lut[a23 >> 8];
-  const double vb0 = s_lut[b01 & 0xff], vb1 = s_lut[b01 >> 8], vb2 = s_lut[b23 & 0xff], vb3 = s_lut[b23 >> 8];
-  const int fxa = Xa & 31, fya = Ya & 31, fxb = Xb & 31, fyb = Yb & 31;
-  const double axa = (double)(32 - fxa), bxa = (double)fxa, aya = (double)(32 - fya), bya = (double)fya;
-  const double axb = (double)(32 - fxb), bxb = (double)fxb, ayb = (double)(32 - fyb), byb = (double)fyb;
-  const double sa = ((va0 * (aya * axa) + va1 * (aya * bxa)) + va2 * (bya * axa)) + va3 * (bya * bxa);
-  const double sb = ((vb0 * (ayb * axb) + vb1 * (ayb * bxb)) + vb2 * (byb * axb)) + vb3 * (byb * bxb);
-  outA = sa * (1.0 / 1024.0);
-  outB = sb * (1.0 / 1024.0);
-}
-
-__global__ __launch_bounds__(256) void k_tile_wave(const FrameDesc* frames, int max_drops, const int32_t* tex_h, const int32_t* tex_w, Scratch sc) {
-  const int f = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  __shared__ double s_lut[256];
-  __shared__ int2 s_adbd[4][NW_MAX];
-  __shared__ AreaSpan s_ax[4][TW_MAX];
-  __shared__ double s_can[4][TW_CAN];
-  __shared__ double s_bufw[4][TW_BUF];
-  __shared__ int4 s_row[4][ROWS_W];
-  s_lut[t] = (double)t / 255.0;
-  __syncthreads();                                       // the only block barrier
-  const int n_items = sc.counts[f * 8 + 0];
-  const const_ptr<int32_t> list = as_constant(sc.list_rot + (int64_t)f * max_drops);
-  const const_ptr<DropPlan> plans = as_constant(sc.plan + (int64_t)f * max_drops);
-  int2* adbd = s_adbd[wave];
-  AreaSpan* axs = s_ax[wave];
-  double* can = s_can[wave];
-  double* bufw = s_bufw[wave];
-  int4* rowp = s_row[wave];
-  for (int item = sc.rot_int[f] + blockIdx.x * 4 + wave; item < n_items; item += gridDim.x * 4) {
-    const const_ptr<DropPlan> cp = plans + __builtin_amdgcn_readfirstlane(list[item]);
-    DropPlan p;                                          // the fields the tile needs, wave-uniform
-    p.tex = cp->tex; p.flip = cp->flip; p.tw = cp->tw; p.th = cp->th; p.nW = cp->nW; p.nH = cp->nH;
-#pragma unroll
-    for (int k = 0; k < 6; k++) p.ma[k] = cp->ma[k];
-    p.scale_x = cp->scale_x; p.scale_y = cp->scale_y;
-    const int64_t a0_off = cp->a0_off;
-    const int sh = as_constant(tex_h)[p.tex], sw = as_constant(tex_w)[p.tex];
-    const global_ptr<const uint8_t> gpad = as_global(sc.tex_pad) + as_constant(sc.tex_poff)[p.tex];
-    const int P = sw + 4, tw = p.tw, th = p.th;
-    double* A0 = sc.arena + a0_off;
-    for (int rx = lane; rx < p.nW; rx += 64) adbd[rx] = make_int2((int)rot_adelta(p, rx), (int)rot_bdelta(p, rx));
-    for (int dx = lane; dx < tw; dx += 64) axs[dx] = area_span(p.nW, p.scale_x, dx);
-    wave_lds_sync();
-    const RowGeom geom = row_geom(p, sh, sw);
-    const int pitch = imin(imax(tile_pitch(p, sh, sw), 1), TW_CAN);
-    for (int dy = 0; dy < th; dy++) {
-      const AreaSpan ay = area_span(p.nH, p.scale_y, dy);
-      const int ra = ay.has_l ? ay.s1 - 1 : ay.s1, rb = ay.has_r ? ay.s2 : ay.s2 - 1;     // canvas rows of this destination row, in fold order
-      for (int dxa = 0; dxa < tw; dxa += TW_COLS) {
-        const int twg = imin(TW_COLS, tw - dxa);
-        const AreaSpan axa = axs[dxa], axb = axs[dxa + twg - 1];
-        const int colA = axa.has_l ? axa.s1 - 1 : axa.s1, colB = axb.has_r ? axb.s2 + 1 : axb.s2;   // canvas columns [colA, colB) of the group
-        const int pitch2 = imax(imin(pitch, colB - colA), 1);
-        const int Rw = imax(imin(imin(ROWS_W, TW_CAN / pitch2), TW_BUF / twg), 1);
-        const float inv_pitch = 1.0f / (float)pitch2, inv_twg = 1.0f / (float)twg;
-        double acc = 0.0;                                 // lane dxl < twg: destination pixel (dy, dxa + dxl)
-        bool first = true;
-        for (int r0 = ra; r0 <= rb; r0 += Rw) {
-          const int nr = imin(Rw, rb - r0 + 1);
-          if (lane < nr) {
-            const int c = r0 + lane;
-            const int ry = p.flip ? (p.nH - 1 - c) : c;
-            const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
-            int xa, n;
-            row_interval(p, geom, X0, Y0, xa, n);
-            const int xa2 = imax(xa, colA), xe2 = imin(xa + n, colB);
-            rowp[lane] = make_int4(X0, Y0, xa2, imax(imin(xe2 - xa2, pitch2), 0));
-          }
-          wave_lds_sync();
-          // ---- 1a: bilinear samples, lanes flattened over (row, column), two per lane and step ----
-          const int nidx = nr * pitch2;
-          for (int idx = lane; idx < nidx; idx += 128) {
-            const int ia = idx, ib = imin(idx + 64, nidx - 1);
-            const int rra = (int)(((float)ia + 0.5f) * inv_pitch), xa = ia - rra * pitch2;
-            const int rrb = (int)(((float)ib + 0.5f) * inv_pitch), xb = ib - rrb * pitch2;
-            const int4 rwa = rowp[rra], rwb = rowp[rrb];
-            const bool oka = xa < rwa.w, okb = (idx + 64 < nidx) && xb < rwb.w;
-            const int2 da = adbd[rwa.z + (oka ? xa : 0)], db = adbd[rwb.z + (okb ? xb : 0)];
-            double va, vb;
-            gl_rot_sample2(gpad, s_lut, P, sh, sw, rwa.x, rwa.y, da, rwb.x, rwb.y, db, va, vb);
-            if (oka) can[ia] = va;
-            if (okb) can[ib] = vb;
-          }
-          wave_lds_sync();
-          // ---- 1b: horizontal folds, one lane per (row, destination column) ----
-          const int items = nr * twg;
-          for (int it = lane; it < items; it += 64) {
-            const int r = (int)(((float)it + 0.5f) * inv_twg), dxl = it - r * twg;
-            const AreaSpan ax = axs[dxa + dxl];
-            const int4 rw = rowp[r];
-            const int xlo = rw.z, xhi = rw.z + rw.w - 1;          // staged (possibly non-zero) columns
-            const double* row = can + r * pitch2 - rw.z;
-            double b = 0.0;
-            // resizeArea_ order: left partial cell, full cells, right partial cell; columns outside
-            // [xlo, xhi] hold exact zeros and are skipped
-            if (ax.has_l && ax.s1 - 1 >= xlo && ax.s1 - 1 <= xhi) b = b + row[ax.s1 - 1] * (double)ax.a_l;
-            {
-              const int m0 = imax(ax.s1, xlo), m1 = imin(ax.s2 - 1, xhi);
-              const double am = (double)ax.a_m;
-              int sx = m0;
-              for (; sx + 3 <= m1; sx += 4) {
-                const double v0 = row[sx], v1 = row[sx + 1], v2 = row[sx + 2], v3 = row[sx + 3];
-                b = b + v0 * am;
-                b = b + v1 * am;
-                b = b + v2 * am;
-                b = b + v3 * am;
-              }
-              for (; sx <= m1; sx++) b = b + row[sx] * am;
-            }
-            if (ax.has_r && ax.s2 >= xlo && ax.s2 <= xhi) b = b + row[ax.s2] * (double)ax.a_r;
-            bufw[r * twg + dxl] = b;
-          }
-          wave_lds_sync();
-          // ---- 2: vertical fold of this chunk's rows into the running value (resizeArea_'s order: top partial row,
-          //         full rows, bottom partial row) ----
-          if (lane < twg) {
-            for (int r = 0; r < nr; r++) {
-              const int c = r0 + r;
-              const float a = c < ay.s1 ? ay.a_l : (c >= ay.s2 ? ay.a_r : ay.a_m);
-              const double v = (double)a * bufw[r * twg + lane];
-              acc = first ? v : acc + v;
-              first = false;
-            }
-          }
-          wave_lds_sync();
-        }
-        if (lane < twg) A0[dy * tw + dxa + lane] = clip01(acc);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // work lists: which kernel takes which drop, blur work split into items of sub-tiles
 // ---------------------------------------------------------------------------
 constexpr int BLUR_ITEMS_PER_DROP = 8;
@@ -2011,7 +1850,6 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   if (t == 1023) {
     for (int k = 0; k < 5; k++) sc.counts[f * 8 + k] = sh[1023][k];
     sc.counts[f * 8 + 0] = sh[1023][0] + sh[1023][5];
-    sc.rot_int[f] = sh[1023][5];
     sc.counts[f * 8 + 5] = sh[1023][6];
     sc.counts[f * 8 + 6] = sh[1023][7];
     boff[sh[1023][6]] = sh[1023][7];
@@ -2252,7 +2090,10 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
 // w(distance l) of each axis and the fold loop takes them with v_readlane.
 // r04: the phase clocks showed 63 % of this kernel's wave time in the load phase (a chain of dependent global loads per
 // drop: list entry -> plan -> raw tile / weights, ~2 us each time).  It is now a software pipeline over the wave's drops:
-//   * a drop's plan fields travel as wave-uniform values (scalar loads, constant address space), fetched TWO drops ahead;
+//   * a drop's plan fields travel as wave-uniform values, fetched TWO drops ahead -- by VECTOR loads (lane l reads dword l
+//     of the record, v_readlane hands out the fields): scalar loads share the LDS operations' counter and return out of
+//     order, so a scalar prefetch in flight turned every LDS wait of the row pass into a wait for memory (measured: the
+//     row pass went from 11 % to 54 % of the wave time);
 //   * its raw tile and weights are loaded ONE drop ahead, into registers, while the current drop is being filtered.  X
 //     holds the tw columns under the raw tile with 2*r1 zero rows above: its data rows ARE the raw tile's dense layout, so
 //     the load is a linear copy -- four 16-byte loads per lane cover the 512 doubles X can hold -- written to LDS when
@@ -2268,15 +2109,22 @@ __global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, 
   double* X = Xs[wave];
   double* Y = Ys[wave];
   const int n_items = sc.counts[f * 8 + 4];
-  const const_ptr<int32_t> list = as_constant(sc.list_small + (int64_t)f * max_drops);
-  const const_ptr<DropPlan> plans = as_constant(sc.plan + (int64_t)f * max_drops);
+  const global_ptr<const int32_t> list = as_global(sc.list_small + (int64_t)f * max_drops);
+  const DropPlan* plans = sc.plan + (int64_t)f * max_drops;
   const int stride = gridDim.x * 4;
   int it = blockIdx.x * 4 + wave;
   if (it >= n_items) return;
-  auto fetch = [&](int item) {
-    const int li = __builtin_amdgcn_readfirstlane(list[item]);
-    const const_ptr<DropPlan> p = plans + li;
-    SmallItem o{li, p->r1, p->r2, p->tw, p->th, p->ew, p->eh, p->epitch, p->epad, (long long)p->a0_off, (long long)p->a1_off};
+  // dword `lane` of a plan (its first 256 bytes hold every field used here); unpack: the fields as wave-uniform values
+  auto load_plan = [&](int li) { return as_global(reinterpret_cast<const uint32_t*>(plans + li))[lane]; };
+  auto unpack = [&](uint32_t pv, int li) {
+    auto F = [&](size_t byte_off) { return (int)__builtin_amdgcn_readlane((int)pv, (int)(byte_off / 4)); };
+    static_assert(offsetof(DropPlan, a1_off) + 8 <= 256, "DropPlan layout");
+    SmallItem o;
+    o.li = li;
+    o.r1 = F(offsetof(DropPlan, r1)); o.r2 = F(offsetof(DropPlan, r2)); o.tw = F(offsetof(DropPlan, tw)); o.th = F(offsetof(DropPlan, th));
+    o.pw = F(offsetof(DropPlan, ew)); o.ph = F(offsetof(DropPlan, eh)); o.epitch = F(offsetof(DropPlan, epitch)); o.epad = F(offsetof(DropPlan, epad));
+    o.a0 = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a0_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a0_off)));
+    o.a1 = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a1_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a1_off)));
     return o;
   };
   double2_v R[4];                     // the raw tile of the drop AFTER the current one, lane-linear
@@ -2295,10 +2143,14 @@ __global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, 
     nw2 = (d.r2 > 0 && lane <= d.r2) ? wt[(BR_MAX + 1) + d.r2 - lane] : 0.0;
   };
   PH_DECL
-  SmallItem cur = fetch(it);
+  // prologue: drop `it` entirely, the plan of the next one and the list entry of the one after that in flight
+  const int li0 = __builtin_amdgcn_readfirstlane(list[it]);
+  SmallItem cur = unpack(load_plan(li0), li0);
   issue(cur);
   bool has_next = it + stride < n_items;
-  SmallItem nxt = has_next ? fetch(it + stride) : cur;
+  int li1 = has_next ? __builtin_amdgcn_readfirstlane(list[it + stride]) : li0;
+  uint32_t pv_next = load_plan(li1);
+  int32_t li2_v = (it + 2 * stride < n_items) ? list[it + 2 * stride] : 0;
   for (;;) {
     const int r1 = cur.r1, r2 = cur.r2, pw = cur.pw, ph = cur.ph, tw = cur.tw, th = cur.th;   // effective tile pw x ph
     const int php = (ph + 3) & ~3, hi = php + 2 * r1, yp = blur_y_pitch(pw, r2);
@@ -2323,11 +2175,17 @@ __global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, 
     const double w1 = nw1, w2 = nw2;
     wave_lds_sync();
     PH(0)                                           // waiting for the prefetched tile + staging it
-    // ---- the next drop's loads go out now and land under this drop's arithmetic ----
-    SmallItem nn = nxt;
+    // ---- the next drop's loads go out now and land under this drop's arithmetic (its plan arrived with this drop's
+    //      tile: vector loads return in order) ----
+    SmallItem nxt = cur;
     if (has_next) {
+      nxt = unpack(pv_next, li1);
       issue(nxt);
-      if (it + 2 * stride < n_items) nn = fetch(it + 2 * stride);
+      if (it + 2 * stride < n_items) {
+        li1 = __builtin_amdgcn_readfirstlane(li2_v);
+        pv_next = load_plan(li1);
+        if (it + 3 * stride < n_items) li2_v = list[it + 3 * stride];
+      }
     }
     const float inv_tw = 1.0f / (float)tw;
     // axis 0 (rows): a lane owns data column x and four consecutive rows
@@ -2376,7 +2234,6 @@ __global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, 
     if (!has_next) break;
     it += stride;
     cur = nxt;
-    nxt = nn;
     has_next = it + stride < n_items;
   }
   PH_FLUSH(2)
@@ -2741,7 +2598,8 @@ __device__ inline float2_t pk_fma_clamp(float2_t a, float2_t b, float2_t c) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-__global__ __launch_bounds__(256) void k_composite32(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
+template <int WPE>                  // waves per SIMD the register allocation is held to (RR_OPT_COMPOSITE_WAVES)
+__global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
                                                      int tiles_y, int ctiles_x, int nct, int64_t arena_cap, Scratch sc) {
   const int f = blockIdx.y;
   const int ntiles = tiles_x * tiles_y, per_xcd = (ntiles + 7) / 8;
@@ -3321,7 +3179,7 @@ struct rr_ctx {
   uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
   int64_t* d_tex_poff = nullptr;
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
-  bool tile_waves = true;            // RR_OPT_TILE_WAVES: a wave per rotate+resize tile (k_tile_wave) instead of a workgroup (k_tile)
+  int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
   int n_tex = 0;
   float* d_ctab = nullptr;
   // particle generator (rr_set_particle_tables / rr_generate_drops_device)
@@ -3573,7 +3431,6 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
       if ((rc = dev_alloc(ctx, ctx->sc.ccount, (size_t)F * nct))) return rc;
     }
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.rot_int, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.canon, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_big, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.big_off, fd + F))) return rc;
@@ -3835,13 +3692,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_tile");
       // after de-duplication a frame keeps a fraction of its tiles: a capped grid (items are taken
       // grid-stride) avoids dispatching tens of thousands of empty workgroups
-      // general tiles: a wave each (k_tile_wave reads the padded texture copies; without them -- RR_OPT_PADDED_TEXTURES 0,
-      // or RR_OPT_TILE_WAVES 0 -- everything goes through the workgroup-per-tile kernel); integer-ratio tiles: k_tile
-      const bool waves = ctx->tile_waves && sc.tex_pad != nullptr;
-      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, grid_cap(waves ? 256 : 1536)), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
-                         ctx->d_tex_off, waves ? 1 : 0, sc);
-      if (waves)
-        hipLaunchKernelGGL(k_tile_wave, dim3(imin((max_drops + 3) / 4, grid_cap(1024)), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
+      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, grid_cap(1536)), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+                         ctx->d_tex_off, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_weights");
@@ -3883,8 +3735,13 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     const int tiles_y32 = (dm.H + TILE32_H - 1) / TILE32_H;
     ntiles_c = tiles_x * tiles_y32;
     ProfScope ps(ctx, s, "k_composite");
-    hipLaunchKernelGGL(k_composite32, dim3(((ntiles_c + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x,
-                       nct, ctx->arena_cap, sc);
+    const dim3 grid(((ntiles_c + 7) / 8) * 8, n);
+    if (ctx->comp_waves == 8)
+      hipLaunchKernelGGL(k_composite32<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x, nct, ctx->arena_cap, sc);
+    else if (ctx->comp_waves == 7)
+      hipLaunchKernelGGL(k_composite32<7>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x, nct, ctx->arena_cap, sc);
+    else
+      hipLaunchKernelGGL(k_composite32<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x, nct, ctx->arena_cap, sc);
   } else {
     ProfScope ps(ctx, s, "k_composite");
     hipLaunchKernelGGL(k_composite, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
@@ -4154,7 +4011,6 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.list_slow);
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
-  hipFree(ctx->sc.rot_int);
   hipFree(ctx->sc.canon);
   hipFree(ctx->sc.list_big);
   hipFree(ctx->sc.big_off);
@@ -5134,7 +4990,10 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
-    case RR_OPT_TILE_WAVES: ctx->tile_waves = value != 0; return RR_OK;
+    case RR_OPT_COMPOSITE_WAVES:
+      if (value != 0 && value != 6 && value != 7 && value != 8) break;
+      ctx->comp_waves = value ? value : 6;
+      return RR_OK;
     case RR_OPT_FOV_F32:
       if (value < 0 || value > 2) break;
       ctx->fov_f32 = value;

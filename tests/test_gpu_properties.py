@@ -122,20 +122,17 @@ def test_colour_path_options_do_not_change_results(setup):
         assert np.array_equal(out['mask'], base['mask']) and np.array_equal(out['mask_i32'], base['mask_i32']), opts
         assert np.abs(out['image_u8'].astype(int) - base['image_u8'].astype(int)).max() <= 1, opts
         assert np.abs(out['rainy_bg'] - base['rainy_bg']).max() < 1e-9, opts
-    # the rotate + resize tiles by a wave each reading the padded texture copies (default), by a workgroup with the texture
-    # staged in LDS from those copies (RR_OPT_TILE_WAVES 0), or staged byte by byte (RR_OPT_PADDED_TEXTURES 0): the same
-    # folds in the same order, so every output bit is equal
-    for opt in (h.hb.RR_OPT_TILE_WAVES, h.hb.RR_OPT_PADDED_TEXTURES):
-        alt = h.hb.RainHip(0)
-        try:
-            alt.set_option(opt, 0)
-            alt.set_streak_db(sc.db.streaks_light)
-            alt.set_camera(sc.cam)
-            out = alt.render_frames([fr])[0]
-        finally:
-            alt.close()
-        for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
-            assert np.array_equal(out[k], base[k]), (opt, k)
+    # texture staging from the pre-padded copies (default) or byte by byte: the same LDS bytes, so every output bit equal
+    alt = h.hb.RainHip(0)
+    try:
+        alt.set_option(h.hb.RR_OPT_PADDED_TEXTURES, 0)
+        alt.set_streak_db(sc.db.streaks_light)
+        alt.set_camera(sc.cam)
+        out = alt.render_frames([fr])[0]
+    finally:
+        alt.close()
+    for k in ('mask', 'mask_i32', 'image_u8', 'status', 'rainy_bg'):
+        assert np.array_equal(out[k], base[k]), k
     with pytest.raises(RuntimeError):
         rh.set_option(99, 1)
 
