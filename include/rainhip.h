@@ -351,8 +351,6 @@ enum {
    * and the environment-map sums under the polygon.  They only feed the drop's colour constants, which only scale
    * rainy_image (contract: +-1 LSB; the mask and the drop statuses never see the difference). */
   RR_OPT_FOV_F32 = 10,
-  RR_OPT_BLUR_PIPELINE = 12,        /* tuning: 1 (default) the fused defocus blur runs as a software pipeline (the next sub-tile is
-                                     * gathered while the current one is filtered); 0: load, filter, store in turn.  Same bits. */
   RR_OPT_COMPOSITE_WAVES = 11       /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
                                      * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
 };

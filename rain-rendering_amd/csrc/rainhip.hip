@@ -2084,207 +2084,6 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
   PH_FLUSH(3)
 }
 
-// ---------------------------------------------------------------------------
-// fused defocus blur as a software pipeline (r04; RR_OPT_BLUR_PIPELINE, default on)
-// ---------------------------------------------------------------------------
-// The phase clocks (scripts/phase_timing.sh) put 48 % of k_blur_fused's wave time into its load phase: per sub-tile a chain
-// of dependent global loads (item -> plan -> raw tile, weight tables) that nothing overlaps -- a workgroup owns its LDS
-// tiles and 4 workgroups fill a CU.  Here a workgroup walks its (item, sub-tile) steps as a pipeline:
-//   step s     its raw sub-tile arrives in registers (gathered one step earlier) -> X, Y cleared, tables -> barrier
-//              the gather of step s+1 goes out (up to 12 elements per thread) -- under the arithmetic below
-//              row pass -> barrier -> column pass to global memory -> barrier
-// and, at item boundaries, the plan of the next item (vector loads: lane l holds dword l, fields by v_readlane -- scalar
-// loads would share the LDS counter and turn every LDS wait into a memory wait) one item ahead, the item record two ahead.
-// The arithmetic -- blur4 over the same LDS tiles in the same order -- is k_blur_fused's: identical bits.
-struct FusedPlan {                  // wave-uniform view of the drop being blurred
-  int i, r1, r2, pw, ph, tw, th, epitch, epad;
-  long long a0, a1;
-};
-struct FusedGeo {                   // one sub-tile of its effective tile
-  int y0, x0, ho, wo, hop, hi, yp, xa, wd, wdd, nx, xs, ys;
-};
-__device__ inline FusedGeo fused_geo(const FusedPlan& p, int Lwo, int Lho, int st) {
-  FusedGeo g;
-  const int ntx = (p.pw + Lwo - 1) / Lwo;
-  const int sty = st / ntx, stx = st - sty * ntx;
-  g.y0 = sty * Lho;
-  g.x0 = stx * Lwo;
-  g.ho = imin(Lho, p.ph - g.y0);
-  g.wo = imin(Lwo, p.pw - g.x0);
-  g.hop = (g.ho + 3) & ~3;                              // rows/columns padded to the 4-output blocks
-  const int wi = g.wo + 2 * p.r2;
-  g.hi = g.hop + 2 * p.r1;                              // LDS input tile with zero halos (+ slack rows)
-  g.yp = blur_y_pitch(g.wo, p.r2);                      // odd pitch of the row-pass result
-  g.xa = imax(0, 2 * p.r2 - g.x0);                      // data columns of the haloed sub-tile: those under the raw tile
-  const int xb = imin(wi, p.tw + 2 * p.r2 - g.x0);
-  g.wd = imax(xb - g.xa, 0);
-  g.wdd = imax(g.wd, 1);
-  g.nx = g.wd * g.hi;
-  g.xs = g.x0 - 2 * p.r2 + g.xa;
-  g.ys = g.y0 - 2 * p.r1;
-  return g;
-}
-constexpr int FUSED_PF = 12;        // elements a thread gathers per sub-tile: 256 * 12 = 3072 >= the largest X
-template <int WPE>
-__global__ __launch_bounds__(256, WPE) void k_blur_fused_pipe(const FrameDesc* frames, int max_drops, Scratch sc) {
-  const int f = blockIdx.y, t = threadIdx.x, lane = t & 63;
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  double* hw1 = s_dyn;
-  double* hw2 = s_dyn + (BR_MAX + 1);
-  double* X = s_dyn + 2 * (BR_MAX + 1);
-  double* Y = X + sc.blur_bx;
-  const int n_items = sc.counts[f * 8 + 2];
-  int it = blockIdx.x;
-  if (it >= n_items) return;
-  const int G = gridDim.x;
-  const global_ptr<const uint32_t> items_w = as_global(reinterpret_cast<const uint32_t*>(sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP));
-  const DropPlan* plans = sc.plan + (int64_t)f * max_drops;
-  // lane l & 3 reads word l & 3 of an item record, lane l dword l of a plan: wave-uniform values by v_readlane later
-  auto load_item = [&](int item) { return items_w[(int64_t)item * 4 + (lane & 3)]; };
-  auto load_plan = [&](int i) { return as_global(reinterpret_cast<const uint32_t*>(plans + i))[lane]; };
-  auto item_word = [&](uint32_t iv, int k) { return (int)__builtin_amdgcn_readlane((int)iv, k); };
-  auto unpack = [&](uint32_t pv, int i) {
-    auto F = [&](size_t byte_off) { return (int)__builtin_amdgcn_readlane((int)pv, (int)(byte_off / 4)); };
-    FusedPlan o;
-    o.i = i;
-    o.r1 = F(offsetof(DropPlan, r1)); o.r2 = F(offsetof(DropPlan, r2)); o.pw = F(offsetof(DropPlan, ew)); o.ph = F(offsetof(DropPlan, eh));
-    o.tw = F(offsetof(DropPlan, tw)); o.th = F(offsetof(DropPlan, th)); o.epitch = F(offsetof(DropPlan, epitch)); o.epad = F(offsetof(DropPlan, epad));
-    o.a0 = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a0_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a0_off)));
-    o.a1 = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a1_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a1_off)));
-    return o;
-  };
-  double PR[FUSED_PF];                // the gathered sub-tile of the NEXT step, element e = t + 256 j
-  double nwt = 0.0;                   // and, when that step starts a new drop, its weights (threads 0.. : axis 0, 64.. : axis 1)
-  auto gather = [&](const FusedPlan& p, const FusedGeo& g, bool tables) {
-    const global_ptr<const double> src = as_global(sc.arena + p.a0);
-    const float inv_wd = 1.0f / (float)g.wdd;
-#pragma unroll
-    for (int j = 0; j < FUSED_PF; j++) {
-      const int e = t + 256 * j;
-      const int yy = (int)(((float)e + 0.5f) * inv_wd), xc = e - yy * g.wdd;
-      const int y = g.ys + yy;
-      PR[j] = (e < g.nx && (unsigned)y < (unsigned)p.th) ? src[y * p.tw + (g.xs + xc)] : 0.0;
-    }
-    if (tables) {
-      const global_ptr<const double> wt = as_global(sc.wtab + ((int64_t)f * max_drops + p.i) * 2 * (BR_MAX + 1));   // built by k_blur_weights
-      nwt = 0.0;
-      if (t <= p.r1) nwt = wt[t];
-      if (t >= 64 && t - 64 <= p.r2 && p.r2 > 0) nwt = wt[(BR_MAX + 1) + t - 64];
-    }
-  };
-  // ---- prologue: the first item entirely; the next item's plan and the item record after that in flight ----
-  uint32_t iv = load_item(it);
-  int ci = item_word(iv, 0), st = item_word(iv, 1), st_end = st + item_word(iv, 2), lay = item_word(iv, 3);
-  FusedPlan cur = unpack(load_plan(ci), ci);
-  FusedGeo g = fused_geo(cur, lay & 0xffff, lay >> 16, st);
-  gather(cur, g, true);
-  bool cur_tables = true;             // this step's weights arrive with its tile
-  uint32_t iv1 = (it + G < n_items) ? load_item(it + G) : 0u;          // next item's record ...
-  uint32_t pv1 = 0u;                                                   // ... and plan (loaded once the record is known)
-  int ni = 0;
-  if (it + G < n_items) {
-    ni = item_word(iv1, 0);
-    pv1 = load_plan(ni);
-  }
-  uint32_t iv2 = (it + 2 * G < n_items) ? load_item(it + 2 * G) : 0u;
-  for (;;) {
-    const int r1 = cur.r1, r2 = cur.r2, wd = g.wd, hop = g.hop, yp = g.yp, ho = g.ho, wo = g.wo;
-    // ---- stage: the gathered sub-tile -> X (data columns only), Y := 0, this drop's tables ----
-#pragma unroll
-    for (int j = 0; j < FUSED_PF; j++) {
-      const int e = t + 256 * j;
-      if (e < g.nx) X[e] = PR[j];
-    }
-    if (cur_tables) {
-      if (t <= r1) hw1[t] = nwt;
-      if (t >= 64 && t - 64 <= r2 && r2 > 0) hw2[t - 64] = nwt;
-    }
-    {
-      const int nz2 = (yp * hop + 1) >> 1;              // Y := 0, two doubles per store (capacity is even: no overrun)
-      double2* Y2 = reinterpret_cast<double2*>(Y);
-      for (int i = t; i < nz2; i += 256) Y2[i] = make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    // ---- what comes next, and its loads ----
-    const bool more_sub = st + 1 < st_end, more_items = it + G < n_items;
-    FusedPlan nxt = cur;
-    FusedGeo gn = g;
-    int n_st = st + 1, n_end = st_end, n_lay = lay;
-    bool n_tables = false;
-    if (more_sub) {
-      gn = fused_geo(cur, lay & 0xffff, lay >> 16, n_st);
-      gather(cur, gn, false);
-    } else if (more_items) {
-      n_st = item_word(iv1, 1);
-      n_end = n_st + item_word(iv1, 2);
-      n_lay = item_word(iv1, 3);
-      n_tables = ni != cur.i;                           // (the sub-tile ranges of one drop may be spread over several items)
-      nxt = unpack(pv1, ni);
-      gn = fused_geo(nxt, n_lay & 0xffff, n_lay >> 16, n_st);
-      gather(nxt, gn, n_tables);
-      if (it + 2 * G < n_items) {                       // one level further: the plan of the item after, the record after that
-        iv1 = iv2;
-        ni = item_word(iv1, 0);
-        pv1 = load_plan(ni);
-        if (it + 3 * G < n_items) iv2 = load_item(it + 3 * G);
-      }
-    }
-    double* dst = sc.arena + cur.a1;                    // finished effective tile (ew x eh); raw sits at (r2, r1) inside it
-    const float inv_wd = 1.0f / (float)g.wdd;
-    // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns data column xc and FOUR consecutive rows (blur4).
-    {
-      const int nrb = hop >> 2;
-      const int nv = nrb * wd;
-      for (int idx = t; idx < nv; idx += 256) {
-        const int rb = (int)(((float)idx + 0.5f) * inv_wd), xq = idx - rb * wd;
-        const double* c0 = X + (4 * rb + r1) * wd + xq;                     // centre of the first of the four rows
-        double acc0, acc1, acc2, acc3;
-        blur4(c0, wd, [&](int k) { return hw1[k]; }, r1, acc0, acc1, acc2, acc3);
-        double* o = Y + 4 * rb * yp + g.xa + xq;                            // Y has hop rows: the slack rows are never read
-        o[0] = acc0;
-        o[yp] = acc1;
-        o[2 * yp] = acc2;
-        o[3 * yp] = acc3;
-      }
-    }
-    __syncthreads();
-    // axis 1 (columns, sigma = c/2): a thread owns row y and four consecutive columns; lanes run down the rows
-    {
-      const int ncb = (wo + 3) >> 2;
-      const int nh = ncb * ho;
-      const float inv_ho = 1.0f / (float)ho;
-      for (int idx = t; idx < nh; idx += 256) {
-        const int cb = (int)(((float)idx + 0.5f) * inv_ho), yq = idx - cb * ho;
-        const double* c0 = Y + yq * yp + 4 * cb + r2;                       // centre of the first of the four columns
-        double acc0, acc1, acc2, acc3;
-        if (r2 > 0) {
-          blur4(c0, 1, [&](int k) { return hw2[k]; }, r2, acc0, acc1, acc2, acc3);
-        } else {
-          acc0 = c0[0]; acc1 = c0[1]; acc2 = c0[2]; acc3 = c0[3];
-        }
-        const int xo = 4 * cb;
-        double* o = dst + (int64_t)(g.y0 + yq) * cur.epitch + cur.epad + (g.x0 + xo);
-        if (xo + 3 < wo) {
-          o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3;
-        } else {
-          o[0] = acc0;
-          if (xo + 1 < wo) o[1] = acc1;
-          if (xo + 2 < wo) o[2] = acc2;
-        }
-      }
-    }
-    __syncthreads();
-    if (!more_sub && !more_items) break;
-    if (!more_sub) it += G;
-    cur = nxt;
-    g = gn;
-    st = n_st;
-    st_end = n_end;
-    lay = n_lay;
-    cur_tables = n_tables;
-  }
-}
-
 // Small blurred tiles (most of them): one WAVE per drop, wave-private LDS, no block barrier.  Same scheme as the fused
 // kernel -- data columns of the haloed tile in X, row pass into Y (odd pitch), column pass to global memory, four
 // outputs per lane with the rotating register window of blur4 -- with the filter weights in registers: lane l holds
@@ -3380,7 +3179,6 @@ struct rr_ctx {
   uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
   int64_t* d_tex_poff = nullptr;
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
-  bool blur_pipe = true;             // RR_OPT_BLUR_PIPELINE: the fused blur as a software pipeline (k_blur_fused_pipe)
   int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
   int n_tex = 0;
   float* d_ctab = nullptr;
@@ -3457,7 +3255,7 @@ struct rr_ctx {
   // options (rr_set_option): none of them changes a result bit
   bool dedup = true;                 // RR_OPT_DEDUP: share bit-identical raw tiles inside a batch (k_dedup)
   int fov_threads = 0, fov_dpt = 0;  // RR_OPT_FOV_THREADS / RR_OPT_FOV_DROPS_PER_THREAD: 0 = chosen by the library
-  int blur_wg = 0;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5); 0: 3 for the pipelined kernel, else 4
+  int blur_wg = 0;                   // RR_OPT_BLUR_WORKGROUPS: workgroups per CU of the fused blur (3, 4 or 5); 0: the library's choice (4)
   bool general_fov = false;          // RR_OPT_GENERAL_FOV: force the general colour path (prefix table in HBM)
   int fov_f32 = 2;                   // RR_OPT_FOV_F32: float32 vertices / prefix rows / sums in the colour branch (image within 1 LSB): 0 never,
                                      // 1 always, 2 (default) whenever the compositor blends float colours (no float64 composite asked for)
@@ -3773,8 +3571,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   sc.overflow = ctx->sc.overflow + ovf_idx;
   sc.tex_pad = ctx->padded_tex ? ctx->d_tex_pad : nullptr;
   sc.tex_poff = ctx->d_tex_poff;
-  // workgroups per CU the fused blur is sized for: the pipelined kernel holds a gathered sub-tile in registers (3 per CU)
-  const int blur_wg = ctx->blur_wg ? ctx->blur_wg : (ctx->blur_pipe ? 3 : 4);
+  const int blur_wg = ctx->blur_wg ? ctx->blur_wg : 4;      // workgroups per CU the fused blur is sized for
   sc.blur_bx = blur_wg == 3 ? 3072 : (blur_wg == 5 ? 2304 : 2816);
   sc.blur_by = blur_wg == 5 ? 1600 : 2048;
   // One in-order stream: FOV spans -> plan -> scan -> dedup -> lists -> FOV sums -> colour -> tiles -> blur ->
@@ -3911,11 +3708,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_blur_fused");
       const size_t lds = sizeof(double) * (size_t)(2 * (BR_MAX + 1) + sc.blur_bx + sc.blur_by);
       const dim3 grid(imin((max_drops + 1) / 2, grid_cap(4096)), n);
-      if (ctx->blur_pipe) {             // the pipelined form
-        if (blur_wg == 4) hipLaunchKernelGGL(k_blur_fused_pipe<4>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
-        else if (blur_wg == 5) hipLaunchKernelGGL(k_blur_fused_pipe<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
-        else hipLaunchKernelGGL(k_blur_fused_pipe<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
-      } else if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
+      if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else if (blur_wg == 5) hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else hipLaunchKernelGGL(k_blur_fused<4>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
     }
@@ -5198,7 +4991,6 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
-    case RR_OPT_BLUR_PIPELINE: ctx->blur_pipe = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_WAVES:
       if (value != 0 && value != 6 && value != 7 && value != 8) break;
       ctx->comp_waves = value ? value : 6;

@@ -54,4 +54,38 @@ def main():
     key = np.stack([p['kind'], p['tex'], p['flip'], p['tw'], p['th']] + [p['mi'][:, k].view('i8') for k in range(9)] + [p['ma'][:, k].view('i8') for k in range(6)], 1)
     print('distinct raw tiles', len(np.unique(key, axis=0)), 'of', len(p))
 
-main()
+if '--blur' not in sys.argv:
+    main()
+
+
+def blur_classes():
+    """Which blur kernel takes which drops, and how the filter work splits by radius (same scene as above)."""
+    import ctypes
+    emu = th.hostemu()
+    a_frames = 3
+    sc = th.Scene(tempfile.mkdtemp(), 375, 1242, 8192, n_frames=a_frames, cam=th.KITTI, seed0=3000)
+    texels, hs, ws, offs = hb.pack_streak_db(sc.db.streaks_light)
+    rows = []
+    for i in range(a_frames):
+        drops = np.ascontiguousarray(sc.product_drops(i)); n = len(drops)
+        plans = np.zeros(n, PLAN); poly = np.zeros(n * 72, np.int32); npts = np.zeros(n, np.int32); sizes = np.zeros(n, np.int64)
+        emu.emu_plan(th._p(drops), n, ctypes.byref(sc.cam), 375, 1242, sc.He, sc.We, th._p(hs), th._p(ws), ctypes.c_double(1.0), th._p(plans), th._p(poly), th._p(npts), th._p(sizes))
+        p = plans[(plans['status'] == 0) & (sizes > 0) & (plans['r1'] > 0)]
+        out = np.zeros(4, np.int32)
+        for q in p:
+            emu.emu_blur_layout(int(q['ew']), int(q['eh']), int(q['r1']), int(q['r2']), int(q['tw']), int(q['th']), 2816, 2048, th._p(out))
+            macs = int(q['tw']) * int(q['eh']) * (int(q['r1']) + 1) + int(q['ew']) * int(q['eh']) * (int(q['r2']) + 1)
+            rows.append(('small' if out[0] else ('fused' if out[1] else 'slow'), int(q['r1']), macs, int(q['ew']) * int(q['eh'])))
+    for cls in ('small', 'fused', 'slow'):
+        r = [x for x in rows if x[0] == cls]
+        if not r:
+            continue
+        r1 = np.array([x[1] for x in r]); m = np.array([x[2] for x in r]); px = np.array([x[3] for x in r])
+        print('%s: %d drops/frame, MACs/frame %.3g (mean %d), output px/frame %.3g; r1 mean %.1f' % (cls, len(r) / a_frames, m.sum() / a_frames, m.mean(), px.sum() / a_frames, r1.mean()))
+        for lo, hi in ((1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 48)):
+            k = (r1 >= lo) & (r1 <= hi)
+            print('   r1 %2d..%2d: %5.1f %% of drops, %5.1f %% of MACs' % (lo, hi, 100.0 * k.mean(), 100.0 * m[k].sum() / m.sum()))
+
+
+if '--blur' in sys.argv:
+    blur_classes()

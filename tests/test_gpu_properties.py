@@ -107,8 +107,7 @@ def test_colour_path_options_do_not_change_results(setup):
                  {h.hb.RR_OPT_FOV_THREADS: 512, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 4},
                  {h.hb.RR_OPT_FOV_THREADS: 1024, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 2},
                  {h.hb.RR_OPT_FOV_THREADS: 1024, h.hb.RR_OPT_FOV_DROPS_PER_THREAD: 8},
-                 {h.hb.RR_OPT_BLUR_WORKGROUPS: 4}, {h.hb.RR_OPT_BLUR_WORKGROUPS: 5},
-                 {h.hb.RR_OPT_BLUR_PIPELINE: 0}, {h.hb.RR_OPT_BLUR_PIPELINE: 0, h.hb.RR_OPT_BLUR_WORKGROUPS: 3},
+                 {h.hb.RR_OPT_BLUR_WORKGROUPS: 3}, {h.hb.RR_OPT_BLUR_WORKGROUPS: 5},
                  {h.hb.RR_OPT_GENERAL_FOV: 1}):
         alt = h.hb.RainHip(0)
         try:
