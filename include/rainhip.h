@@ -351,6 +351,10 @@ enum {
    * and the environment-map sums under the polygon.  They only feed the drop's colour constants, which only scale
    * rainy_image (contract: +-1 LSB; the mask and the drop statuses never see the difference). */
   RR_OPT_FOV_F32 = 10,
+  RR_OPT_FOV_DDA = 12,              /* tuning: 1 (default) the float colour branch evaluates a drop's field-of-view polygon and its row
+                                     * spans with one thread per drop (two cursors down the polygon's sides; wrapping polygons and
+                                     * float64 decisions through a list to the edge-parallel kernel); 0: the edge-parallel kernel for
+                                     * every drop.  The spans are the same: identical results. */
   RR_OPT_COMPOSITE_WAVES = 11       /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
                                      * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
 };

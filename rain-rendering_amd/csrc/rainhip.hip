@@ -170,6 +170,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* wtab_big;                 // [frame][SLOW_CAP][2][MAX_R+1] the same for the first SLOW_CAP large-radius drops of a frame (k_blur_big_weights)
   const uint8_t* tex_pad;           // the textures with their 2-texel zero border, as k_tile stages them (k_pad_textures); NULL: staged byte by byte
   const int64_t* tex_poff;          // [texture] offset of its padded copy (a multiple of 16)
+  int32_t* fov_list;                // [frame][drops] drops k_fov_dda leaves to k_fov_spans (wrapping polygons, float64 decisions)
+  int32_t* fov_list_n;              // [frame] their number
   uint32_t* spans;                  // [frame][Hp / 4][Dp][4] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4,
                                     // Dp = drops + 1 rounded up to 8; slot `drops` of every quad stays all zeros: what a drop
                                     // without a polygon reads
@@ -480,7 +482,7 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
 //      integer fix-up (|2*dx*dy| < 2^23 is checked by the host), folded into the row's [min, max] with LDS
 //      ds_min / ds_max (order-free, no return value).  The spans leave as one u32 per row, xl | (xr + 1) << 16
 //      (0 = empty), in the [row quad][drop] layout k_fov_sums reads coalesced.
-template <int NCH>
+template <int NCH, bool from_list>
 __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int use32, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
@@ -497,16 +499,19 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     s_phi32[1][threadIdx.x] = (float)cam.phi_sin[threadIdx.x];
   }
   __syncthreads();
-  const int i0 = (blockIdx.x * 4 + wave) * G;                  // first drop of this wave
-  if (i0 >= fr.n_drops) return;
+  // from_list: the wave's drops are entries of the frame's list of drops k_fov_dda left to this kernel, not neighbours
+  const int n_eff = from_list ? sc.fov_list_n[f] : fr.n_drops;
+  for (int wslot = blockIdx.x * 4 + wave; wslot * G < n_eff; wslot += gridDim.x * 4) {      // (a loop in list mode only: the grid covers every drop otherwise)
+  const int s0 = wslot * G;                                    // first drop slot of this wave
   const int g = lane / N, k = lane - g * N;                    // (drop slot, vertex)
-  const bool act = g < G && i0 + g < fr.n_drops;
-  const int64_t gi = (int64_t)f * max_drops + i0 + (act ? g : 0);
+  const bool act = g < G && s0 + g < n_eff;
+  const int dg = act ? (from_list ? sc.fov_list[(int64_t)f * max_drops + s0 + g] : s0 + g) : 0;       // the drop of this lane's group
+  const int64_t gi = (int64_t)f * max_drops + dg;
   if (fr.strategy == 1) {                                      // 'white': the FOV is computed by the reference but never used
     if (act && k == 0) sc.npts[gi] = -1;
     return;
   }
-  const bool ext = act && fr.ext && fr.ext[i0 + g].alpha != nullptr;      // the caller's polygon (rr_ext_tile)
+  const bool ext = act && fr.ext && fr.ext[dg].alpha != nullptr;      // the caller's polygon (rr_ext_tile)
   const int base = g * N, nxt_lane = base + (k + 1 == N ? 0 : k + 1);
   const unsigned long long gmask = act ? (((N >= 64 ? 0ull : (1ull << N)) - 1ull) << base) : 0ull;
   // the vertex of this lane: its pixel on the map (truncated like pyclipper's integer cast), the wrap test of the side
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     int uns = 0;
     if (act && !ext) {
       FovSetup32 F;
-      const rr_drop d = load_drop(fr.drops + i0 + g);
+      const rr_drop d = load_drop(fr.drops + dg);
       fov_setup32(d, (float)cam.fov_cos, (float)cam.fov_sin, F, uns);
       fov_vertex32(F, (float)cam.radius, s_phi32[0][k], s_phi32[1][k], dm.He, dm.We, azf, erf, pxf, pyf, uns);
     }
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     bool ok64 = false;
     if (need64) {
       FovSetup F;
-      const rr_drop d = load_drop(fr.drops + i0 + g);
+      const rr_drop d = load_drop(fr.drops + dg);
       ok64 = fov_setup(d, cam, F);
       fov_vertex(F, cam, s_phi[0][k], s_phi[1][k], dm.He, dm.We, az, ptx, pty);
     }
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     }
   }
   if (ext) {                                                   // lane k of the group copies vertex k, k + N, ...
-    const rr_ext_tile e = fr.ext[i0 + g];
+    const rr_ext_tile e = fr.ext[dg];
     const int np = imin(imax(e.n_poly, 0), POLY_STRIDE);
     bool fine = true;
     for (int v = k; v < np; v += N) {
@@ -683,17 +688,145 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   // contiguous (and the next waves' follow them); k_fov_sums reads one 16-byte piece per lane, lanes = consecutive drops
   const int NQ = Hp >> 2;
   bool have[FOV_GROUPS];                                       // (cross-lane reads stay outside the divergent stores)
+  int dk[FOV_GROUPS];                                          // the drop of group k
 #pragma unroll
-  for (int k = 0; k < FOV_GROUPS; k++) have[k] = k < G && __builtin_amdgcn_readfirstlane(__shfl(m, k < G ? k * N : 0)) > 0;
+  for (int k = 0; k < FOV_GROUPS; k++) {
+    have[k] = k < G && __builtin_amdgcn_readfirstlane(__shfl(m, k < G ? k * N : 0)) > 0;
+    dk[k] = __builtin_amdgcn_readfirstlane(__shfl(dg, k < G ? k * N : 0));
+  }
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int y = c * 64 + lane;
     if (y < Hp) {
-      uint32_t* out = sc.spans + (((int64_t)f * NQ + (y >> 2)) * Dp + i0) * 4 + (y & 3);
+      uint32_t* out = sc.spans + ((int64_t)f * NQ + (y >> 2)) * Dp * 4 + (y & 3);
 #pragma unroll
       for (int k = 0; k < FOV_GROUPS; k++)
-        if (have[k]) out[k * 4] = packed[k][c];
+        if (have[k]) out[(int64_t)dk[k] * 4] = packed[k][c];
     }
+  }
+  if (!from_list) break;
+  wave_lds_sync();                                             // (the wave's LDS tables are free for its next drops)
+  }
+}
+
+// ---------------------------------------------------------------------------
+// FOV polygon and row spans, one THREAD per drop (r04; float colour branch)
+// ---------------------------------------------------------------------------
+// k_fov_spans spreads a drop over a third of a wave: its edge walk (LDS min / max per row, a read-out pass) costs ~850
+// issued instructions per drop, most of them with few lanes busy -- the kernel saturates the vector AND the scalar unit.
+// Here a lane owns a drop from beginning to end:
+//   1. the N vertices in float (fov_vertex32), the wrap test against the previous vertex, the predicates' error bounds --
+//      fov_polygon_auto lane by lane; the vertex pixels go to wave-private LDS as pix[vertex][lane] (a lane reading its own
+//      vertex k touches bank `lane`: no conflicts whatever k);
+//   2. a drop whose polygon float can decide and that does not wrap has N vertices on a closed curve that every map row
+//      crosses at most twice (a circle around the drop's direction that contains no pole): two cursors walk down from its
+//      top vertex, one along each side, and every row's span is the min / max over the edges that touch the row -- the
+//      very candidates fov_rowspan / k_fov_spans fold, evaluated with the same exact integer division -- so the spans
+//      are identical.  Rows leave four at a time: 16 bytes per lane, 1 KB per wave, contiguous (the [row quad][drop]
+//      layout k_fov_sums reads).  ~350 issued instructions per drop, every lane busy;
+//   3. everything else -- a wrapping polygon (24 vertices, not monotone), a predicate within its error bound (float64
+//      decides), a vertex sequence that is not monotone after all -- goes to the frame's list for k_fov_spans (from_list),
+//      a fraction of a percent of the drops.
+__global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
+  const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const FrameDesc& fr = frames[f];
+  const int N = cam.n_fov;
+  __shared__ float s_phi32[2][RR_MAX_FOV];
+  extern __shared__ uint32_t s_pix_dyn[];                      // [4 waves][N vertices][64 lanes]: pix[vertex][lane] = x | y << 16
+  if (threadIdx.x < RR_MAX_FOV) {
+    s_phi32[0][threadIdx.x] = (float)cam.phi_cos[threadIdx.x];
+    s_phi32[1][threadIdx.x] = (float)cam.phi_sin[threadIdx.x];
+  }
+  __syncthreads();
+  const int i = (blockIdx.x * 4 + wave) * 64 + lane;           // this lane's drop
+  const bool act = i < fr.n_drops;
+  const int64_t gi = (int64_t)f * max_drops + (act ? i : 0);
+  if (fr.strategy == 1) {                                      // 'white': the FOV is computed by the reference but never used
+    if (act) sc.npts[gi] = -1;
+    return;
+  }
+  uint32_t* pix = s_pix_dyn + wave * N * 64;
+  // ---- 1. vertices ----
+  int uns = 0;                                                 // reason bits (rr_device.h): float64 has to decide
+  int count_true = 0, count_false = 0;
+  int ktop = 0, ytop = 1 << 30, ybot = -(1 << 30), r_first = 0;
+  bool spread = false;
+  int turns = 0, dir = 0, dir_first = 0;                       // sign changes of the vertices' row sequence (a closed monotone curve: 2)
+  if (act) {
+    FovSetup32 F;
+    const rr_drop d = load_drop(fr.drops + i);
+    fov_setup32(d, (float)cam.fov_cos, (float)cam.fov_sin, F, uns);
+    float az_prev = 0.f, er_prev = 0.f, az0 = 0.f, er0 = 0.f;
+    int y_prev = 0, y0v = 0;
+    for (int k = 0; k < N; k++) {
+      float az, er, pxf, pyf;
+      fov_vertex32(F, (float)cam.radius, s_phi32[0][k], s_phi32[1][k], dm.He, dm.We, az, er, pxf, pyf, uns);
+      const int ix = (int)pxf, iy = (int)pyf;
+      pix[k * 64 + lane] = (uint32_t)(ix & 0xffff) | ((uint32_t)(iy & 0xffff) << 16);
+      const int r = imin(imax(iy, 0), dm.He - 1);
+      if (k == 0) { az0 = az; er0 = er; r_first = r; y0v = iy; }
+      else {
+        const bool c = fov_wrap_cnd32(az_prev, az, er_prev, er, uns);      // side k-1 -> k
+        count_true += c ? 1 : 0;
+        count_false += c ? 0 : 1;
+        spread = spread || iabs(r - r_first) >= 2;
+        const int sg = iy > y_prev ? 1 : (iy < y_prev ? -1 : 0);
+        if (sg != 0) {
+          if (dir == 0) dir_first = sg;
+          else if (sg != dir) turns++;
+          dir = sg;
+        }
+      }
+      if (iy < ytop) { ytop = iy; ktop = k; }
+      ybot = imax(ybot, iy);
+      az_prev = az; er_prev = er; y_prev = iy;
+    }
+    {                                                          // the closing side N-1 -> 0
+      const bool c = fov_wrap_cnd32(az_prev, az0, er_prev, er0, uns);
+      count_true += c ? 1 : 0;
+      count_false += c ? 0 : 1;
+      const int sg = y0v > y_prev ? 1 : (y0v < y_prev ? -1 : 0);
+      if (sg != 0) {
+        if (dir != 0 && sg != dir) turns++;
+        dir = sg;
+      }
+      if (dir != 0 && dir_first != 0 && dir != dir_first) turns++;        // around the closing point
+    }
+  }
+  // ---- classification (fov_polygon_auto) ----
+  const bool certain_fail = (uns & 128) && !(uns & 3);         // a vertex without intersection: [] like the reference
+  const bool wrap = count_true == 1 || count_false == 1;
+  const bool undecided = (uns & ~128) != 0 || count_true == 0 || count_false == 0 || (!wrap && !spread);
+  const bool monotone = turns <= 2;
+  const bool mine = act && !certain_fail && !undecided && !wrap && monotone;     // a sure, closed, monotone N-gon: spans below
+  if (act && certain_fail) sc.npts[gi] = 0;
+  if (act && !certain_fail && !mine) {                         // float64 / the general edge walk: k_fov_spans, from the list
+    const int pos = atomicAdd(&sc.fov_list_n[f], 1);
+    sc.fov_list[(int64_t)f * max_drops + pos] = i;
+  }
+  if (mine) sc.npts[gi] = N;
+  if (__ballot(mine) == 0ull) return;
+  // ---- 2. spans of the sure drops: two cursors down from the top vertex (rr_device.h DdaCursors) ----
+  auto vertex = [&](int kk, int& x, int& y) {
+    const uint32_t v = pix[kk * 64 + lane];
+    x = (int)(v & 0xffffu);
+    y = (int)(v >> 16);
+  };
+  DdaCursors<decltype(vertex)> cur;
+  cur.init(vertex, N, ktop);
+  const int NQ = Hp >> 2;
+  uint4* out = reinterpret_cast<uint4*>(sc.spans) + (int64_t)f * NQ * Dp + i;
+  for (int yq = 0; yq < Hp; yq += 4) {
+    uint32_t pk[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int y = yq + j;
+      int lo = 1 << 30, hi = -(1 << 30);
+      if (mine && y >= ytop && y <= ybot) cur.row(vertex, y, lo, hi);
+      const int a = imax(lo, 0), b = imin(hi, dm.We - 1);
+      pk[j] = (y < dm.He && a <= b) ? ((uint32_t)a | ((uint32_t)(b + 1) << 16)) : 0u;
+    }
+    if (mine) out[(int64_t)(yq >> 2) * Dp] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
 }
 
@@ -3179,6 +3312,7 @@ struct rr_ctx {
   uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
   int64_t* d_tex_poff = nullptr;
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
+  bool fov_dda = true;               // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (k_fov_dda)
   int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
   int n_tex = 0;
   float* d_ctab = nullptr;
@@ -3404,6 +3538,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.npts, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.sizes, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_rot, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.fov_list, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.fov_list_n, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_gen, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_slow, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.blur_items, fd * 8))) return rc;
@@ -3586,14 +3722,31 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     if (fast) {
       ProfScope ps(ctx, s, "k_fov_spans");
       const int G = imin(64 / ctx->cam.n_fov, FOV_GROUPS);
-      const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
+      // float colour branch: a thread per drop (k_fov_dda) for the polygons float decides and that do not wrap; the rest
+      // (a fraction of a percent) through the frame's list to k_fov_spans in float64.  Caller-made polygons (rr_ext_tile)
+      // and the float64 colour branch: k_fov_spans for every drop.
+      bool any_ext = false;
+      for (int f = 0; f < n; f++) any_ext = any_ext || in[f].ext != nullptr;
+      const bool dda = fov32 && ctx->fov_dda && !any_ext;
       const int v32 = fov32 ? 1 : 0;
-      if (dm.He <= 384)
-        hipLaunchKernelGGL(k_fov_spans<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+      const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
+      if (dda) {
+        HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, s));
+        hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 255) / 256, n), dim3(256), sizeof(uint32_t) * 4 * 64 * (size_t)ctx->cam.n_fov, s, ctx->d_frames, dm,
+                           ctx->cam, D, Hp, Dp, sc);
+        const dim3 lgrid(imin((int)grid.x, 8), n);           // the list is short: a few workgroups per frame walk it, in float64
+        if (dm.He <= 384)
+          hipLaunchKernelGGL((k_fov_spans<6, true>), lgrid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+        else if (dm.He <= 512)
+          hipLaunchKernelGGL((k_fov_spans<8, true>), lgrid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+        else
+          hipLaunchKernelGGL((k_fov_spans<16, true>), lgrid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+      } else if (dm.He <= 384)
+        hipLaunchKernelGGL((k_fov_spans<6, false>), grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
       else if (dm.He <= 512)
-        hipLaunchKernelGGL(k_fov_spans<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<8, false>), grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
       else
-        hipLaunchKernelGGL(k_fov_spans<16>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<16, false>), grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
     } else {
       ProfScope ps(ctx, s, "k_fov_poly");
       hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, dm, ctx->cam, D, sc);
@@ -4008,6 +4161,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.npts);
   hipFree(ctx->sc.sizes);
   hipFree(ctx->sc.list_rot);
+  hipFree(ctx->sc.fov_list);
+  hipFree(ctx->sc.fov_list_n);
   hipFree(ctx->sc.list_gen);
   hipFree(ctx->sc.list_slow);
   hipFree(ctx->sc.blur_items);
@@ -4991,6 +5146,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
+    case RR_OPT_FOV_DDA: ctx->fov_dda = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_WAVES:
       if (value != 0 && value != 6 && value != 7 && value != 8) break;
       ctx->comp_waves = value ? value : 6;

@@ -736,6 +736,91 @@ RR_HD bool fov_rowspan(const int32_t* px, const int32_t* py, int n, int y, int W
   return xl <= xr;
 }
 
+// Row spans of a closed polygon whose vertex rows go down one side and up the other (every row crosses it at most twice:
+// a circle on the sphere that contains no pole), by two cursors walking down from its top vertex, one along each side
+// (k_fov_dda: a thread per drop).  row(y) returns the min / max over the edges that touch row y -- the candidates
+// fov_rowspan folds, with the same exact integer division -- for y from the top vertex' row to the bottom one, IN
+// ASCENDING ORDER (every call advances the cursors).  V: vertex(k, x, y).
+RR_HD int mul24i(int a, int b) {                            // a * b for |a|, |b| < 2^23 (the 24-bit multiplier on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __mul24(a, b);
+#else
+  return a * b;
+#endif
+}
+template <class V>
+struct DdaCursors {
+  int xa[2], ya[2], xb[2], yb[2], kv[2], used, N;
+  float inv[2];
+  RR_HD static float half_recip(int den) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return den > 0 ? __builtin_amdgcn_rcpf((float)(2 * den)) : 0.f;          // (the quotient is made exact below)
+#else
+    return den > 0 ? 1.0f / (float)(2 * den) : 0.f;
+#endif
+  }
+  RR_HD void init(const V& vertex, int n, int ktop) {
+    N = n;
+    used = 2;                                                // edges taken so far (both cursors together; N in all)
+    for (int c = 0; c < 2; c++) {
+      vertex(ktop, xa[c], ya[c]);
+      kv[c] = c == 0 ? (ktop + 1 == N ? 0 : ktop + 1) : (ktop == 0 ? N - 1 : ktop - 1);
+      vertex(kv[c], xb[c], yb[c]);
+      inv[c] = half_recip(yb[c] - ya[c]);
+    }
+  }
+  RR_HD void row(const V& vertex, int y, int& lo, int& hi) {
+    lo = 1 << 30;
+    hi = -(1 << 30);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 2; c++) {
+      {                                                      // the current edge at row y (ya <= y <= yb)
+        const int den = yb[c] - ya[c], dx = xb[c] - xa[c];
+        int x0 = xa[c], x1 = xa[c];
+        if (den == 0) x1 = xb[c];                            // horizontal: both end points
+        else {
+          const int dn = 2 * den, nn = mul24i(2 * dx, y - ya[c]) + den;        // exact: |2 dx dy| < 2^23 (host check)
+          int q = (int)floorf((float)nn * inv[c]);           // floor(nn / dn) up to +-1 ...
+          const int rem = nn - mul24i(q, dn);
+          q += rem < 0 ? -1 : (rem >= dn ? 1 : 0);           // ... made exact
+          x0 = x1 = xa[c] + q;
+        }
+        lo = imin(lo, imin(x0, x1));
+        hi = imax(hi, imax(x0, x1));
+      }
+      while (y == yb[c] && used < N) {                       // a vertex row: the edges that start here touch it too
+        used++;
+        xa[c] = xb[c];
+        ya[c] = yb[c];
+        kv[c] = c == 0 ? (kv[c] + 1 == N ? 0 : kv[c] + 1) : (kv[c] == 0 ? N - 1 : kv[c] - 1);
+        vertex(kv[c], xb[c], yb[c]);
+        if (yb[c] == ya[c]) {                                // a horizontal one: its far end point
+          lo = imin(lo, xb[c]);
+          hi = imax(hi, xb[c]);
+        }
+        inv[c] = half_recip(yb[c] - ya[c]);
+      }
+    }
+  }
+};
+// number of times the vertices' row sequence changes direction around the loop (a closed monotone curve: 2; all on one row: 0)
+RR_HD int poly_row_turns(const int32_t* py, int n) {
+  int turns = 0, dir = 0, dir_first = 0;
+  for (int k = 1; k <= n; k++) {
+    const int a = py[k - 1], b = py[k == n ? 0 : k];
+    const int sg = b > a ? 1 : (b < a ? -1 : 0);
+    if (sg != 0) {
+      if (dir == 0) dir_first = sg;
+      else if (sg != dir) turns++;
+      dir = sg;
+    }
+  }
+  if (dir != 0 && dir_first != 0 && dir != dir_first) turns++;
+  return turns;
+}
+
 // colour constants from the FOV sums (bad_weather.py:397-412, my_utils.py:55-85)
 // S = {sum x*w, sum y*w, sum Y*w, sum w} over the FOV mask.
 RR_HD void colour_from_sums(const double S[4], double sum_omega, double ambient, double Kbgr[3]) {

@@ -24,6 +24,7 @@ RR_OPT_COPY_KERNELS = 8
 RR_OPT_PADDED_TEXTURES = 9
 RR_OPT_FOV_F32 = 10
 RR_OPT_COMPOSITE_WAVES = 11
+RR_OPT_FOV_DDA = 12
 RR_IN_BG_F32, RR_IN_BG_U8, RR_IN_ENV_F32, RR_IN_RAINY_F32, RR_IN_RAINY_U8 = 1, 2, 4, 8, 16      # rr_frame_in.in_types
 
 # numpy mirror of rr_drop (112 bytes)

@@ -79,6 +79,31 @@ int emu_fov_error_ratio(const rr_drop* drops, int n, const rr_camera* cam, int H
   return 0;
 }
 
+// k_fov_dda's row spans (rr_device.h DdaCursors) of polygon (px, py)[n] against the rule itself (fov_rowspan: min / max over
+// every edge that touches the row): returns the number of rows of [0, He) on which they differ, -1 when the polygon's rows
+// are not monotone (the kernel hands those to the edge-parallel kernel).
+int emu_dda_check(const int32_t* px, const int32_t* py, int n, int He, int We) {
+  if (poly_row_turns(py, n) > 2) return -1;
+  int ktop = 0, ytop = py[0], ybot = py[0];
+  for (int k = 1; k < n; k++) {
+    if (py[k] < ytop) { ytop = py[k]; ktop = k; }
+    if (py[k] > ybot) ybot = py[k];
+  }
+  auto vertex = [&](int k, int& x, int& y) { x = px[k]; y = py[k]; };
+  DdaCursors<decltype(vertex)> cur;
+  cur.init(vertex, n, ktop);
+  int bad = 0;
+  for (int y = 0; y < He; y++) {
+    int lo = 1 << 30, hi = -(1 << 30);
+    if (y >= ytop && y <= ybot) cur.row(vertex, y, lo, hi);
+    const int a = imax(lo, 0), b = imin(hi, We - 1);
+    int xl, xr;
+    const bool any = fov_rowspan(px, py, n, y, We, xl, xr);
+    if (any != (a <= b) || (any && (xl != a || xr != b))) bad++;
+  }
+  return bad;
+}
+
 // finished (padded, blurred) alpha tile of one drop into out[ph*pw]
 int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
              double* out) {

@@ -73,3 +73,48 @@ def test_float_polygon_unsure_cases_go_to_float64(tmp_path):
     for k in range(n):
         if used[k] <= 0:
             assert np.array_equal(p32.reshape(n, 2, 36)[k], p64.reshape(n, 2, 36)[k])
+
+
+def _dda_bad(px, py, He, We):
+    emu = h.hostemu()
+    px, py = np.ascontiguousarray(px, np.int32), np.ascontiguousarray(py, np.int32)
+    return emu.emu_dda_check(h._p(px), h._p(py), len(px), He, We)
+
+
+def test_thread_per_drop_spans_equal_the_rule(tmp_path):
+    """k_fov_dda's two cursors (rr_device.h DdaCursors) against fov_rowspan, the rule they implement (min / max over every
+    edge that touches the row): the polygons of a KITTI and a wide-angle scene, and hand-made ones with flat tops and
+    bottoms, repeated vertices, a single row, vertices on the map's border rows."""
+    He, We = 375, 1909
+    n_checked = n_general = 0
+    for cam, H, W in ((h.KITTI, 375, 1242), (h.NUSCENES, 450, 800)):
+        sc = h.Scene(tmp_path / ('s%d' % H), H, W, 3000, cam=cam, seed0=5300, far_fraction=0.2)
+        drops, p64, n64, p32, n32, used, ratio, off = _polygons(sc, 0)
+        for P, Nn in ((p64, n64), (p32, n32)):
+            for k in range(len(drops)):
+                if Nn[k] > 0:
+                    bad = _dda_bad(P[k, 0, :Nn[k]], P[k, 1, :Nn[k]], sc.He, sc.We)
+                    if bad < 0:
+                        n_general += 1                           # not monotone: the kernel's list (wrapping polygons)
+                    else:
+                        assert bad == 0, (k, P[k, :, :Nn[k]])
+                        n_checked += 1
+                    if Nn[k] == 20:
+                        assert bad == 0, "a 20-gon that is not monotone: %r" % (P[k, :, :20],)
+    assert n_checked > 4000 and n_general < 0.05 * n_checked
+    rng = np.random.RandomState(5)
+    for trial in range(400):                                     # random monotone polygons, many ties
+        n_l, n_r = rng.randint(1, 9), rng.randint(1, 9)
+        y_top, y_bot = sorted(rng.randint(0, He + 1, 2))
+        ys_l = np.sort(rng.randint(y_top, y_bot + 1, n_l))
+        ys_r = np.sort(rng.randint(y_top, y_bot + 1, n_r))[::-1]
+        xs_l, xs_r = rng.randint(0, We // 2, n_l), rng.randint(We // 2, We + 1, n_r)
+        px = np.concatenate([[rng.randint(0, We)], xs_r[::-1] if False else xs_l, [rng.randint(0, We)], xs_r])
+        py = np.concatenate([[y_top], ys_l, [y_bot], ys_r])
+        roll = rng.randint(0, len(px))                           # the top vertex anywhere in the loop
+        bad = _dda_bad(np.roll(px, roll), np.roll(py, roll), He, We)
+        assert bad == 0, (trial, px, py)
+    assert _dda_bad([5, 90, 40], [7, 7, 7], He, We) == 0        # all on one row
+    assert _dda_bad([5, 9, 9, 5], [0, 0, He, He], He, We) == 0   # border rows (row He lies outside the map)
+    assert _dda_bad([3, 3, 8, 8, 8], [2, 2, 2, 9, 9], He, We) == 0   # repeated vertices
+    assert _dda_bad([0, 50, 20, 70, 10], [0, 40, 10, 40, 80], He, We) == -1   # up and down twice: not for the cursors

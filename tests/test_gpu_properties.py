@@ -223,3 +223,29 @@ def test_narrow_input_types(setup):
                 check(out, base['image_u8'], 'RR_OPT_FOV_F32 %d, composite=%s' % (v, comp))
         finally:
             rh.set_option(h.hb.RR_OPT_FOV_F32, 2)
+
+
+def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path_factory):
+    """The float colour branch's default kernel (k_fov_dda: a thread per drop, two cursors down the polygon's sides; wrapping
+    polygons and float64 decisions through a list to k_fov_spans) against k_fov_spans for every drop (RR_OPT_FOV_DDA 0): the
+    row spans are the same, so the colour constants are the same BITS, and so is every output.  KITTI 100 mm/hr (a few
+    wrapping polygons per frame) and a wide-angle scene where drops all around the camera wrap often."""
+    sc, bg, env, drops, rh, base = setup
+    scenes = [(sc, bg, env, drops)]
+    wide = h.Scene(tmp_path_factory.mktemp('wide'), 180, 320, 1500, cam=h.NUSCENES, seed0=777, far_fraction=0.3)
+    wbg, wenv = wide.frame_inputs(0)
+    scenes.append((wide, wbg, wenv, wide.product_drops(0)))
+    for S, b, e, d in scenes:
+        outs = []
+        for dda in (1, 0):
+            alt = h.hb.RainHip(0)
+            try:
+                alt.set_option(h.hb.RR_OPT_FOV_DDA, dda)
+                alt.set_streak_db(S.db.streaks_light)
+                alt.set_camera(S.cam)
+                outs.append(alt.render_frames([dict(bg=b, rainy_bg=b, env_xyY=e, omega=S.omega, drops=d)], want_composite=False, want_colour=True)[0])
+            finally:
+                alt.close()
+        assert (outs[0]['status'] == 0).sum() > 0.8 * len(d)
+        for k in ('status', 'colour', 'mask', 'mask_i32', 'image_u8'):
+            assert np.array_equal(outs[0][k], outs[1][k]), k
