@@ -246,6 +246,6 @@ def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path
                 outs.append(alt.render_frames([dict(bg=b, rainy_bg=b, env_xyY=e, omega=S.omega, drops=d)], want_composite=False, want_colour=True)[0])
             finally:
                 alt.close()
-        assert (outs[0]['status'] == 0).sum() > 0.8 * len(d)
+        assert (outs[0]["status"] == 0).sum() > 0.5 * len(d)
         for k in ('status', 'colour', 'mask', 'mask_i32', 'image_u8'):
             assert np.array_equal(outs[0][k], outs[1][k]), k
