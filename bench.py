@@ -62,6 +62,39 @@ WORKLOADS['nuscenes200x'] = dict(H=900, W=1600, rate=200, cam='NUSCENES', rs=1, 
                                  metric="rainy frames/sec @ 1600x900, 200 mm/hr (16384 particles/frame), in-kernel particles")
 
 
+F64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X float64 vector peak, FMA = 2 flops: half of MI355X_MICROARCH.md's 157.3 TFLOP/s float32
+                                 # vector figure (a wave64 float64 instruction holds its SIMD-32 for 4 cycles, a float32 one for 2)
+
+
+def blur_flop_model(drops, status, cam, H, W):
+    """Float64 operations of the defocus blur of one frame, per kernel, from the drop records (the arithmetic of
+    rr_device.h plan_drop restated with numpy: tile size, circle of confusion, radii).  A filter output of radius r costs
+    1 + 3 r operations (centre product; per tap one add of the two symmetric samples, one product, one add into the sum --
+    no FMA contraction on the alpha path: the additions and products are separate instructions by contract).  Which kernel
+    takes a drop: blur_is_small (rr_device.h)."""
+    d = drops[status == 0]
+    big = d['type'] == 0
+    d0, d1 = np.floor(d['iw1']), np.floor(d['iw2'])
+    minx = np.maximum(np.minimum(d['x0'], d['x1']), 0)
+    miny = np.maximum(np.minimum(d['y0'], d['y1']), 0)
+    maxx = np.minimum(np.maximum(d['x0'] + d0, d['x1'] + d1), W)
+    maxy = np.minimum(np.maximum(d['y0'], d['y1']), H)
+    tw = np.where(big, np.maximum((maxx - minx).astype(np.int64), 1), np.maximum(np.abs(d['x1'] - d['x0']), d['max_width'] + 2))
+    th = np.where(big, np.maximum(maxy - miny, 1), np.maximum(np.abs(d['y1'] - d['y0']), 2))
+    o = np.abs(d['wps'][:, 2])
+    cc = np.abs(((o - cam.focus_plane) * cam.focal_sq) / (o * (cam.focus_plane - cam.focal_m) * cam.f_number) / cam.sensor_px)
+    r1 = np.where(cc > 1e-15, (4.0 * cc + 0.5).astype(np.int64), 0)
+    r2 = np.where(cc / 2 > 1e-15, (2.0 * cc + 0.5).astype(np.int64), 0)
+    ew, eh = tw + 2 * r2, th + 2 * r1
+    flops = tw * eh * (1 + 3 * r1) + np.where(r2 > 0, ew * eh * (1 + 3 * r2), 0)
+    php = (eh + 3) & ~3
+    ypitch = (((ew + 3) & ~3) + 2 * r2) | 1
+    small = (r1 > 0) & (r1 <= 31) & (tw * (php + 2 * r1) <= 512) & (ypitch * php <= 768)
+    rest = (r1 > 0) & ~small
+    return {"k_blur_small": float(flops[small].sum()), "k_blur_fused": float(flops[rest & (r1 <= 48)].sum()),
+            "k_blur_rows": float(flops[rest & (r1 > 48)].sum()), "blurred_drops": int((r1 > 0).sum()), "output_px": float((ew * eh)[r1 > 0].sum())}
+
+
 def algorithmic_bytes(H, W, He, We, N):
     """bytes(frame) = 27*H*W + 16*He*We + 64*N."""
     return 27 * H * W + 16 * He * We + 64 * N
@@ -83,6 +116,7 @@ class DeviceBatch:
             self.t_drops = torch.empty((self.n, self.cap * hb.DROP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
             self.t_counts = torch.zeros((self.n,), dtype=torch.int32, device=dev)
         self.keep = []
+        self.status_tensors = []
         self.fin = (hb.rr_frame_in * max(self.n, 1))()
         self.fout = (hb.rr_frame_out * max(self.n, 1))()
         self.host = []
@@ -105,6 +139,7 @@ class DeviceBatch:
             o_mi = torch.empty((H, W), dtype=torch.int32, device=dev)
             o_st = torch.empty((max(len(drops), 1),), dtype=torch.int32, device=dev)
             self.keep += [t_bg, t_env, t_dr, o_rgb, o_m, o_mi, o_st]
+            self.status_tensors.append(o_st)
             fi_, fo_ = self.fin[k], self.fout[k]
             fi_.H, fi_.W, fi_.He, fi_.We = H, W, He, We
             fi_.bg = fi_.rainy_bg = t_bg.data_ptr()
@@ -700,9 +735,45 @@ def main():
             parts = {'k_env_prefix': ['k_env_prefix', 'k_env_consts']}.get(dom_name, [dom_name])
             traffic, traffic_how = measure_traffic(args, parts, scene_dir=tmp)
         chain_ms = sum(per_launch.values())
+        compute = None
+        if not is_sim and not strong:
+            try:                       # float64 operation model of the blur kernels (the dominant ones), a few frames scaled to the call
+                acc = {}
+                nfr = min(8, batch.n)
+                for k in range(nfr):       # per-frame statuses live in the output tensors of the batch
+                    st = batch.status_tensors[k].cpu().numpy()
+                    m = blur_flop_model(batch.host[k][2], st[:len(batch.host[k][2])], sc.cam, H, W)
+                    for kk, vv in m.items():
+                        acc[kk] = acc.get(kk, 0.0) + vv
+                scale = nb / float(nfr)
+                compute = {"what": "float64 operations of the defocus blur per library call: 1 + 3 r per filter output of radius r (plan "
+                                   "geometry restated with numpy from the drop records, %d frames scaled to %d); no FMA contraction on the "
+                                   "alpha path, so the attainable rate is HALF the peak quoted" % (nfr, nb),
+                           "peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS, "kernels": {}}
+                for kn in ("k_blur_fused", "k_blur_small", "k_blur_rows"):
+                    if kn in per_launch and acc.get(kn, 0.0) > 0:
+                        tf = acc[kn] * scale / (per_launch[kn] * 1e-3) / 1e12
+                        compute["kernels"][kn] = {"flops_per_launch": acc[kn] * scale, "ms": per_launch[kn], "achieved_TFLOPs": tf,
+                                                  "frac_of_f64_vector_peak": tf / F64_VECTOR_PEAK_TFLOPS,
+                                                  "frac_of_rate_without_fma": 2.0 * tf / F64_VECTOR_PEAK_TFLOPS}
+            except Exception as e:                                  # noqa: BLE001 -- reported, never fatal
+                compute = {"error": repr(e)}
         valu, valu_how = None, "not measured (--no-traffic, N>1 or strong scaling)"
         if single and not args.no_traffic and not strong:
             valu, valu_how = measure_valu(args, scene_dir=tmp)
+        # which roof is nearer for the dominant kernel: its share of the HBM peak (measured traffic, else algorithmic bytes) or of the
+        # float64 vector rate (operation model for the blur kernels, else the PMC pass' issue-slot share)
+        hbm_frac = ((traffic if traffic else alg) / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if (traffic and dom_name) else achieved / HBM_PEAK_GBS
+        valu_frac = None
+        if compute and dom_name in (compute.get("kernels") or {}):
+            valu_frac = compute["kernels"][dom_name]["frac_of_rate_without_fma"]
+        elif valu and dom_name in valu:
+            valu_frac = valu[dom_name]["valu_util"]
+        bound = "hbm" if (valu_frac is None or (traffic and hbm_frac >= valu_frac)) else "valu-f64"
+        bound_detail = ("dominant kernel %s: %.0f %% of the HBM peak by its measured traffic%s; neither roof is reached -- the kernel waits on "
+                        "dependent loads and LDS phases (DESIGN.md, phase clocks); no MFMA: the path has no dense contraction"
+                        % (dom_name, 100.0 * hbm_frac if traffic else float('nan'),
+                           (", %.0f %% of the float64 vector rate attainable without FMA contraction" % (100.0 * valu_frac)) if valu_frac is not None else ""))
         out = {
             "metric": wl['metric'],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -721,7 +792,7 @@ def main():
                                                "generic": int(cnts[:, 1].sum()), "shared_bit_identical": int(cnts[:, 7].sum())},
                        "blur_last_call": {"fused_items": int(cnts[:, 2].sum()), "wave_per_drop": int(cnts[:, 4].sum()),
                                           "two_pass": int(cnts[:, 3].sum())}},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound, "bound_detail": bound_detail, "compute": compute, "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_how,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
                          "definition": "algorithmic bytes of the frames of one launch (27*H*W + 16*He*We + 64*N each, SURVEY 8d) / "

@@ -7,6 +7,7 @@
 #                                                               -> <tag>_bench_default.json
 #     3. rocprofv3 kernel stats + PMC passes (scripts/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in passes of their own,
 #        VALU / wait / LDS / L2 counters)                       -> pmc_<tag>/summary.json, pmc_<tag>.txt
+#     3b. phase clocks of the tile / blur kernels (scripts/phase_timing.sh: a -DRR_PHASES build in /tmp) -> <tag>_phases.txt
 #   scripts/gpu_full_measure.sh <tag> b     (~12 min)
 #     4. one lean bench line per other BASELINE configuration   -> <tag>_bench_<workload>.json
 #     5. driver end to end (PNG in -> PNG out, main.py)         -> <tag>_e2e.json
@@ -23,6 +24,7 @@ if [ "$PART" = "a" ]; then
     "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
     "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
     "TCC_HIT_sum TCC_MISS_sum" > $OUT/pmc_$TAG.txt 2>&1; echo "pmc exit $?"; grep -A12 "== pmc" $OUT/pmc_$TAG.txt | cut -c1-300
+  timeout -k 10 600 scripts/phase_timing.sh $TAG > $OUT/${TAG}_phases.log 2>&1; echo "phases exit $?"; grep -A6 "^PHASES" $OUT/${TAG}_phases.log | cut -c1-400
 else
   LEAN="--steps 5 --warmup 2 --no-cpu-baseline --no-prepass --no-variants --no-traffic"
   for WL in "kitti25 128" "cityscapes50 32" "cityscapes50_rs2 128" "nuscenes1 64" "nuscenes5 64" "nuscenes25 64" "nuscenes100 64" "nuscenes200 64" "nuscenes200x 64"; do
