@@ -1366,7 +1366,8 @@ constexpr int TEX_LDS = 11776;      // padded texels: (h+4)*(w+4) <= TEX_LDS (a 
 constexpr int NW_MAX = 384;
 constexpr int TW_MAX = 64;
 constexpr int BUF_MAX = 512;
-constexpr int CAN_W = 512;        // doubles of sample staging per wave
+constexpr int CAN_W = 480;        // doubles of sample staging per wave
+constexpr int ROWS_S = 32;        // canvas rows whose intervals a wave works out at a time (general path)
 constexpr int ROWS_W = 16;        // canvas rows a wave stages at most
 
 // Columns rx of canvas row `ry` (un-flipped row number) whose bilinear footprint can touch
@@ -1690,7 +1691,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ AreaSpan s_ax[TW_MAX];
   __shared__ double s_buf[BUF_MAX];
   __shared__ double s_can[4][CAN_W];
-  __shared__ int4 s_row[4][ROWS_W];
+  __shared__ int4 s_row[4][ROWS_S];
   const int n_items = sc.counts[f * 8 + 0];
   if ((int)blockIdx.x >= n_items) return;                                // (before the division table: most frames have few tiles left after k_dedup)
   s_lut[t] = (double)t / 255.0;
@@ -1809,17 +1810,22 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
     //      4 waves -- and the phase clocks showed 35 % of the kernel's wave time spent at the barrier below) ----
     const int share = (hi - lo + 4) >> 2;
     const int w_lo = lo + wave * share, w_hi = imin(hi, w_lo + share - 1);
-    for (int r0 = w_lo; r0 <= w_hi; r0 += Rw) {
-      const int nr = imin(Rw, w_hi - r0 + 1);
-      if (lane < nr) {
-        const int c = r0 + lane;
-        const int ry = p.flip ? (p.nH - 1 - c) : c;
-        const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
-        int xa, n;
-        row_interval(p, geom, X0, Y0, xa, n);
-        rowp[lane] = make_int4(X0, Y0, xa, imin(n, pitch));
-      }
-      wave_lds_sync();
+    // the rows' sampling intervals, up to ROWS_S rows at a time (one lane each: in chunks of Rw ~ 12 rows three quarters of
+    // this float64 arithmetic ran on a fifth of the lanes -- 13 % of the kernel's wave time)
+    for (int q0 = w_lo; q0 <= w_hi; q0 += ROWS_S) {
+    const int nq = imin(ROWS_S, w_hi - q0 + 1);
+    if (lane < nq) {
+      const int c = q0 + lane;
+      const int ry = p.flip ? (p.nH - 1 - c) : c;
+      const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
+      int xa, n;
+      row_interval(p, geom, X0, Y0, xa, n);
+      s_row[wave][lane] = make_int4(X0, Y0, xa, imin(n, pitch));
+    }
+    wave_lds_sync();
+    for (int r0 = q0; r0 < q0 + nq; r0 += Rw) {
+      const int nr = imin(Rw, q0 + nq - r0);
+      const int4* rowp = s_row[wave] + (r0 - q0);
       PH(1)                                         // row intervals
       // ---- 1a: bilinear samples of the rotated texture, lanes flattened over (row, column) ----
       const int nidx = nr * pitch;
@@ -1867,6 +1873,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
       }
       wave_lds_sync();
       PH(3)                                         // horizontal folds
+    }
     }
     __syncthreads();
     PH(4)                                           // waiting for the other waves
