@@ -123,15 +123,19 @@ class DeviceBatch:
         H, W, He, We = sc.H, sc.W, sc.He, sc.We
         omega_t = torch.from_numpy(np.ascontiguousarray(sc.omega, np.float32 if f32 else np.float64)).to(dev)
         self.keep.append(omega_t)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as pool:       # (seeded per frame: the order of evaluation is free)
+            inputs = list(pool.map(sc.frame_inputs, frame_ids))
         for k, (fi, di) in enumerate(zip(frame_ids, drop_ids)):
-            bg, env = sc.frame_inputs(fi)
+            bg, env = inputs[k]
+            inputs[k] = None
             if sims is None:
                 drops = sc.product_drops(di, noise_std=noise_std, noise_scale=1.0 if noise_std else 0.0)
                 t_dr = torch.from_numpy(drops.view(np.uint8).reshape(-1)).to(dev)
             else:
                 drops = np.zeros(self.cap, hb.DROP_DTYPE)           # (length = capacity; the records are made on the device)
                 t_dr = self.t_drops[k]
-            self.host.append((bg, env, drops))
+            self.host.append((bg, env if k < 8 else None, drops))      # (host copies of the maps: the CPU legs use frame 0)
             t_bg = torch.from_numpy(bg.astype(np.float32) if f32 else bg).to(dev)
             t_env = torch.from_numpy(env.astype(np.float32) if f32 else env).to(dev)
             o_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
@@ -388,7 +392,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=256, help='frames per library call (and, in weak scaling, per step and GPU)')
+    ap.add_argument('--batch', type=int, default=512, help='frames per library call (and, in weak scaling, per step and GPU); raw tiles '
+                    'that are bit-identical across the frames of a call are rendered once: 256 -> 512 frames per call is +9 %% frames/s')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='kitti100')
     ap.add_argument('--total-frames', type=int, default=0, help='strong scaling: one sequence of this many frames sharded over the ranks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -576,6 +581,9 @@ def main():
         mid = [batch.chunk(hb, a, a + 32) for a in range(0, min(batch.n, 128) - 31, 32)]
         if mid:
             var["calls_of_32"] = {"frames_per_s": rate(lambda: render(mid), 32 * len(mid)), "what": "library calls of 32 frames (the driver's default)"}
+        if batch.n >= 512:
+            half = [batch.chunk(hb, a, a + 256) for a in range(0, batch.n - 255, 256)]
+            var["calls_of_256"] = {"frames_per_s": rate(lambda: render(half), 256 * len(half)), "what": "library calls of 256 frames (the round-3 headline's call size)"}
         del nz, nzc
         other = 'f64' if args.input_dtype == 'f32' else 'f32'
         ob = DeviceBatch(torch, hb, sc, dev, fids[:nn], my_frames[:nn], in_dtype=other)

@@ -1671,7 +1671,9 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
     const int64_t gi = (int64_t)f * max_drops + lbig[j];
     const DropPlan& p = sc.plan[gi];
     const int local = pix - boff[j];
-    const int y = local / p.tw, x = local - y * p.tw;
+    int y = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)p.tw)), x = local - y * p.tw;     // local / tw without the integer division
+    if (x < 0) { y--; x += p.tw; }                       // (the reciprocal is good to an ulp: at most one off)
+    else if (x >= p.tw) { y++; x -= p.tw; }
     TexLutWide tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
     PH(1)                                           // plan fields
     sc.arena[p.a0_off + local] = warp_big_pixel(p, tx, s_ctab, x, y);
@@ -2100,13 +2102,46 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
   double* X = s_dyn + 2 * (BR_MAX + 1);                                 // 98 doubles in front: X and Y stay 16-byte aligned
   double* Y = X + sc.blur_bx;
   const int n_items = sc.counts[f * 8 + 2];
-  const int4* items = sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP;
+  if ((int)blockIdx.x >= n_items) return;
+  // r04: the item record and the plan of the NEXT item travel ahead of the current one's arithmetic, by vector loads (lane l
+  // reads dword l of the record; the fields come out by v_readlane): the load phase of an item was a chain of three
+  // dependent round trips (item -> plan -> raw tile), 48 % of the kernel's wave time, and only the last one is left.
+  // (Scalar loads cannot do this: they share the LDS operations' counter and return out of order.)
+  const int lane = t & 63, G = gridDim.x;
+  const global_ptr<const uint32_t> items_w = as_global(reinterpret_cast<const uint32_t*>(sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP));
+  const DropPlan* plans = sc.plan + (int64_t)f * max_drops;
+  auto load_item = [&](int item) { return items_w[(int64_t)item * 4 + (lane & 3)]; };
+  auto load_plan = [&](int i) { return as_global(reinterpret_cast<const uint32_t*>(plans + i))[lane]; };
+  struct PlanView {                   // the plan fields this kernel uses, wave-uniform
+    int r1, r2, ew, eh, tw, th, epitch, epad;
+    long long a0_off, a1_off;
+  };
+  auto unpack = [&](uint32_t pv) {
+    auto F = [&](size_t byte_off) { return (int)__builtin_amdgcn_readlane((int)pv, (int)(byte_off / 4)); };
+    PlanView o;
+    o.r1 = F(offsetof(DropPlan, r1)); o.r2 = F(offsetof(DropPlan, r2)); o.ew = F(offsetof(DropPlan, ew)); o.eh = F(offsetof(DropPlan, eh));
+    o.tw = F(offsetof(DropPlan, tw)); o.th = F(offsetof(DropPlan, th)); o.epitch = F(offsetof(DropPlan, epitch)); o.epad = F(offsetof(DropPlan, epad));
+    o.a0_off = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a0_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a0_off)));
+    o.a1_off = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a1_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a1_off)));
+    return o;
+  };
+  uint32_t iv_cur = load_item(blockIdx.x);
+  uint32_t pv_cur = load_plan((int)__builtin_amdgcn_readlane((int)iv_cur, 0));
+  uint32_t iv_nxt = ((int)blockIdx.x + G < n_items) ? load_item(blockIdx.x + G) : 0u;
   int cur = -1;
   PH_DECL
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {            // grid-stride over (drop, sub-tile range) items
-  const int4 item = items[it];
+  for (int it = blockIdx.x; it < n_items; it += G) {                    // grid-stride over (drop, sub-tile range) items
+  const int4 item = make_int4((int)__builtin_amdgcn_readlane((int)iv_cur, 0), (int)__builtin_amdgcn_readlane((int)iv_cur, 1),
+                              (int)__builtin_amdgcn_readlane((int)iv_cur, 2), (int)__builtin_amdgcn_readlane((int)iv_cur, 3));
   const int64_t gi = (int64_t)f * max_drops + item.x;
-  const DropPlan& p = sc.plan[gi];
+  const PlanView p = unpack(pv_cur);
+  {                                   // the next item's plan (its record arrived an item ago) and the record after that
+    const uint32_t pv_n = (it + G < n_items) ? load_plan((int)__builtin_amdgcn_readlane((int)iv_nxt, 0)) : 0u;
+    const uint32_t iv_n = (it + 2 * G < n_items) ? load_item(it + 2 * G) : 0u;
+    iv_cur = iv_nxt;
+    pv_cur = pv_n;
+    iv_nxt = iv_n;
+  }
   BlurLayout L{1, item.w & 0xffff, item.w >> 16, 0};               // computed once, by k_lists
   const int r1 = p.r1, r2 = p.r2, pw = p.ew, ph = p.eh;            // the tile being produced is the EFFECTIVE tile
   // the weight tables depend on the drop only; they are fetched by waves 0 and 1 while the first

@@ -47,10 +47,11 @@ class Scene:
         if stamp is not None and os.path.exists(xml) and os.path.exists(stamp_path) and open(stamp_path).read() == stamp:
             self.xml = xml
         else:
-            if frames is None:
-                frames = synthetic.simulate_particles(n_frames, n_drops, W * render_scale, H * render_scale, cam['focal_mm'],
-                                                      cam['pix_um'], cam['exposure_ms'], seed0=seed0, far_fraction=far_fraction)
-            self.xml = synthetic.write_particles_xml(xml, frames)
+            if frames is None:            # (frame by frame on a pool of processes: the same bytes as simulate + write)
+                self.xml = synthetic.simulate_to_xml(xml, n_frames, n_drops, W * render_scale, H * render_scale, cam['focal_mm'],
+                                                     cam['pix_um'], cam['exposure_ms'], seed0=seed0, far_fraction=far_fraction)
+            else:
+                self.xml = synthetic.write_particles_xml(xml, frames)
             if stamp is not None:
                 with open(stamp_path, 'w') as fh:
                     fh.write(stamp)

@@ -155,20 +155,87 @@ def write_particles_xml(path, frames):
     wd1, wd2, ip1, ip2, iw1, iw2); vectors are "(a;b;c)".  Numbers are written with 17 significant
     digits (they parse back to the same doubles), formatted a frame at a time."""
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    fmt = ('    <streak pid="%d" wp1="(%.17g;%.17g;%.17g)" wp2="(%.17g;%.17g;%.17g)" wd1="%.17g" wd2="%.17g" '
-           'ip1="(%.17g;%.17g)" ip2="(%.17g;%.17g)" iw1="%.17g" iw2="%.17g"/>')
     with open(path, 'w') as fh:
         fh.write('<?xml version="1.0" ?>\n<simulation>\n')
         for fr in frames:
-            ds = fr['drops']
-            fh.write('  <frame id="%d" t="%d" d="%d" rs="%d">\n' % (fr['id'], fr['t'], fr['d'], len(ds)))
-            if ds:
-                rows = [(d['pid'],) + tuple(float(c) for c in d['wp1']) + tuple(float(c) for c in d['wp2']) +
-                        (float(d['wd1']), float(d['wd2'])) + tuple(float(c) for c in d['ip1']) + tuple(float(c) for c in d['ip2']) +
-                        (float(d['iw1']), float(d['iw2'])) for d in ds]
-                fh.write('\n'.join(fmt % r for r in rows))
-                fh.write('\n')
-            fh.write('  </frame>\n')
+            fh.write(_format_frame(fr))
+        fh.write('</simulation>\n')
+    return path
+
+
+_STREAK_FMT = ('    <streak pid="%d" wp1="(%.17g;%.17g;%.17g)" wp2="(%.17g;%.17g;%.17g)" wd1="%.17g" wd2="%.17g" '
+               'ip1="(%.17g;%.17g)" ip2="(%.17g;%.17g)" iw1="%.17g" iw2="%.17g"/>')
+
+
+def _format_frame(fr):
+    ds = fr['drops']
+    out = ['  <frame id="%d" t="%d" d="%d" rs="%d">\n' % (fr['id'], fr['t'], fr['d'], len(ds))]
+    if ds:
+        rows = [(d['pid'],) + tuple(float(c) for c in d['wp1']) + tuple(float(c) for c in d['wp2']) +
+                (float(d['wd1']), float(d['wd2'])) + tuple(float(c) for c in d['ip1']) + tuple(float(c) for c in d['ip2']) +
+                (float(d['iw1']), float(d['iw2'])) for d in ds]
+        out.append('\n'.join(_STREAK_FMT % r for r in rows))
+        out.append('\n')
+    out.append('  </frame>\n')
+    return ''.join(out)
+
+
+def _frame_xml(args):
+    """One simulated frame as the text write_particles_xml would write for it (a pool worker)."""
+    fi, n_drops, W, H, focal_mm, pix_um, exposure_ms, seed0, far_fraction = args
+    fr = simulate_particles(1, n_drops, W, H, focal_mm, pix_um, exposure_ms, seed0=seed0 + fi, far_fraction=far_fraction)[0]
+    fr['id'], fr['d'] = fi, fi * 100000
+    return _format_frame(fr)
+
+
+def simulate_to_xml(path, n_frames, n_drops, W, H, focal_mm=6.0, pix_um=4.65, exposure_ms=2.0, seed0=3000, far_fraction=0.02, workers=None):
+    """simulate_particles + write_particles_xml, the frames split over worker PROCESSES (every frame has its own seed): the
+    file is byte for byte what the two calls write -- bench.py's 256-frame scenes take a minute of one core otherwise.
+    The workers are plain child interpreters running this file (no fork of a process that may hold a GPU context, no
+    re-import of the caller's main module); any failure falls back to the sequential path."""
+    import subprocess
+    import sys
+    workers = workers if workers is not None else max(1, min(8, (os.cpu_count() or 1)))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    common = (n_drops, W, H, focal_mm, pix_um, exposure_ms, seed0, far_fraction)
+    parts = []
+    if workers > 1 and n_frames >= 16:
+        per = (n_frames + workers - 1) // workers
+        procs = []
+        for k in range(workers):
+            a, b = k * per, min(n_frames, (k + 1) * per)
+            if a >= b:
+                break
+            part = '%s.part%d' % (path, k)
+            cmd = [sys.executable, os.path.abspath(__file__), part, str(a), str(b)] + [repr(v) for v in common]
+            procs.append((subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), part))
+        ok = True
+        for pr, part in procs:
+            try:
+                ok = (pr.wait(timeout=900) == 0) and ok
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                ok = False
+            parts.append(part)
+        if not ok:
+            for part in parts:
+                if os.path.exists(part):
+                    os.remove(part)
+            parts = []
+    with open(path, 'w') as fh:
+        fh.write('<?xml version="1.0" ?>\n<simulation>\n')
+        if parts:
+            for part in parts:
+                with open(part) as src:
+                    while True:
+                        blk = src.read(1 << 24)
+                        if not blk:
+                            break
+                        fh.write(blk)
+                os.remove(part)
+        else:
+            for fi in range(n_frames):
+                fh.write(_frame_xml((fi,) + common))
         fh.write('</simulation>\n')
     return path
 
@@ -191,3 +258,13 @@ def write_dataset(root, dataset, sequence, n_frames, H, W, depth_m=20.0):
         with open(os.path.join(cal_dir, '%06d.txt' % i), 'w') as fh:
             fh.write('P2: ' + ' '.join(['0'] * 12) + '\n')
     return img_dir, dep_dir
+
+
+if __name__ == '__main__':        # worker of simulate_to_xml: frames [a, b) as XML text into a part file
+    import sys
+    _part, _a, _b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    _n_drops, _W, _H = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    _rest = [float(v) for v in sys.argv[7:10]] + [int(sys.argv[10]), float(sys.argv[11])]
+    with open(_part, 'w') as _fh:
+        for _fi in range(_a, _b):
+            _fh.write(_frame_xml((_fi, _n_drops, _W, _H) + tuple(_rest)))
