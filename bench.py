@@ -607,33 +607,42 @@ def main():
         we = rh.set_envmap_geometry(H, W, *envmod.EnvironmentMapGenerator(cs['focal_mm'] / 1000., W, H).device_tables(H, W))
         assert we == We
         nb_pre = min(batch.n, 64)
-        pin = (hb.rr_prepass_in * nb_pre)()
-        pout = (hb.rr_prepass_out * nb_pre)()
         depth_t = torch.from_numpy((np.linspace(80, 2, H, dtype=np.float32)[:, None] * np.ones((1, W), np.float32))).to(dev)
-        keep = [depth_t]
-        for i in range(nb_pre):
-            o_r = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
-            o_e = torch.empty((He, We, 3), dtype=torch.float64, device=dev)
-            i_bg = torch.from_numpy(batch.host[i][0]).to(dev)          # (float64: the pre-pass' input type)
-            keep += [o_r, o_e, i_bg]
-            pin[i].H, pin[i].W, pin[i].bg, pin[i].depth, pin[i].depth_f64 = H, W, i_bg.data_ptr(), depth_t.data_ptr(), 0
-            pin[i].beta_ext, pin[i].beta_hg, pin[i].irr_num, pin[i].irr_den = [float(v) for v in consts]
-            pout[i].rainy_bg, pout[i].env_xyY, pout[i].env_bgr_u8 = o_r.data_ptr(), o_e.data_ptr(), None
 
-        def run_pre():
-            rh._check(rh.lib.rr_prepass_frames_device(rh.h, nb_pre, pin, pout, ctypes.c_void_p(stream)), 'prepass')
-        run_pre()
-        torch.cuda.synchronize()
-        rh.profile_reset()
-        rh.profile(True)
-        t = timed(torch, dist, 1, dev, run_pre, args.steps)
-        rh.profile(False)
-        pstats = rh.profile_read()
-        extras["prepass"] = {"what": "fog attenuation + environment map + xyY (rr_prepass_frames_device), %d frames per call; not in value" % nb_pre,
-                             "ms_per_frame": 1e3 * t / args.steps / nb_pre, "frames_per_s": nb_pre * args.steps / t,
-                             "kernels_ms_per_call": {k: v[1] / args.steps for k, v in sorted(pstats.items(), key=lambda kv: -kv[1][1])}}
+        def pre_leg(narrow):
+            """narrow: the pipeline's types (uint8 image in, float32 fog layer and xyY map out: the float64 results rounded
+            once); else float64 in and out (the reference's arrays)."""
+            pin = (hb.rr_prepass_in * nb_pre)()
+            pout = (hb.rr_prepass_out * nb_pre)()
+            keep = []
+            for i in range(nb_pre):
+                img = np.asarray(batch.host[i % len(batch.host)][0], np.float64)
+                o_r = torch.empty((H, W, 3), dtype=torch.float32 if narrow else torch.float64, device=dev)
+                o_e = torch.empty((He, We, 3), dtype=torch.float32 if narrow else torch.float64, device=dev)
+                i_bg = torch.from_numpy((img * 255).astype(np.uint8) if narrow else img).to(dev)
+                keep += [o_r, o_e, i_bg]
+                pin[i].H, pin[i].W, pin[i].bg, pin[i].depth, pin[i].depth_f64 = H, W, i_bg.data_ptr(), depth_t.data_ptr(), 0
+                pin[i].in_types = hb.RR_IN_BG_U8 if narrow else 0
+                pin[i].beta_ext, pin[i].beta_hg, pin[i].irr_num, pin[i].irr_den = [float(v) for v in consts]
+                pout[i].rainy_bg, pout[i].env_xyY, pout[i].env_bgr_u8 = o_r.data_ptr(), o_e.data_ptr(), None
+                pout[i].out_types = (hb.RR_OUT_RAINY_F32 | hb.RR_OUT_ENV_F32) if narrow else 0
+
+            def run_pre():
+                rh._check(rh.lib.rr_prepass_frames_device(rh.h, nb_pre, pin, pout, ctypes.c_void_p(stream)), 'prepass')
+            run_pre()
+            torch.cuda.synchronize()
+            rh.profile_reset()
+            rh.profile(True)
+            t = timed(torch, dist, 1, dev, run_pre, args.steps)
+            rh.profile(False)
+            pstats = rh.profile_read()
+            del keep
+            return {"ms_per_frame": 1e3 * t / args.steps / nb_pre, "frames_per_s": nb_pre * args.steps / t,
+                    "kernels_ms_per_call": {k: v[1] / args.steps for k, v in sorted(pstats.items(), key=lambda kv: -kv[1][1])}}
+        extras["prepass"] = dict(pre_leg(True), what="fog attenuation + environment map + xyY (rr_prepass_frames_device), %d frames per call, "
+                                 "uint8 image in, float32 fog layer + xyY map out (the types rr_pipeline_* hand to the hot path; float64 "
+                                 "arithmetic); not in value" % nb_pre, float64_in_and_out=pre_leg(False))
         depth_h = np.ascontiguousarray(depth_t.cpu().numpy())
-        del keep, pin, pout
 
         # --- host-inclusive (SURVEY 8d's rate: "including H2D of frame inputs and D2H of outputs"): pinned buffers, three
         #     slots in flight (upload | kernels | download overlap); PCIe up (u8 image + f32 depth + drop table), fog +

@@ -218,7 +218,8 @@ typedef struct {
 
 typedef struct {
   int32_t H, W;
-  const double* bg;               /* H*W*3 BGR image / 255 (generator.py:352) */
+  const void* bg;                 /* H*W*3 BGR image / 255 (generator.py:352): float64, or -- in_types -- float32 (RR_IN_BG_F32), or the
+                                   * bytes cv2.imread returned (RR_IN_BG_U8: bg = bytes / 255.0 is formed where the kernels read it) */
   const void* depth;              /* H*W metres, float32 (depth_f64 == 0) or float64 (generator.py:362-383) */
   int32_t depth_f64;
   int32_t mode;                   /* 0: fog layer (+ the map if an output asks for it).  RR_PRE_ENV_ONLY (1), rr_prepass_frames*
@@ -228,15 +229,23 @@ typedef struct {
   double beta_ext;                /* 0.312 * R**0.67                               add_attenuation.py:40-43 */
   double beta_hg;                 /* Henyey-Greenstein phase term, g = 0.97         add_attenuation.py:60-64 */
   double irr_num, irr_den;        /* 4*N**2  and  exposure_s*gain*pi                add_attenuation.py:51-54 */
-  const uint8_t* bg_u8;           /* optional, HOST entry points only: the H*W*3 BGR bytes cv2.imread returned; when set,
-                                   * `bg` is ignored and bg = bytes / 255.0 (generator.py:352) is formed on the device:
-                                   * 1/8 of the PCIe traffic of the float64 image */
+  const uint8_t* bg_u8;           /* HOST entry points, kept from version 300: when set, the same as bg = bg_u8 with RR_IN_BG_U8
+                                   * (1/8 of the PCIe traffic of the float64 image) */
+  int32_t in_types;               /* RR_IN_BG_F32 or RR_IN_BG_U8 (or 0: float64); the other RR_IN_* bits are not for the pre-pass */
+  int32_t reserved;
 } rr_prepass_in;
 
+/* Element types of the pre-pass' outputs (rr_prepass_out.out_types).  The pre-pass computes in float64 whatever the
+ * types: a float32 output is the float64 result rounded once (what numpy's astype(float32) of the reference's arrays
+ * gives), and the uint8 map does not depend on them.  The hot path takes both widths (rr_frame_in.in_types). */
+enum { RR_OUT_RAINY_F32 = 1, RR_OUT_ENV_F32 = 2 };
+
 typedef struct {
-  double* rainy_bg;               /* H*W*3: FOG.fog_rain_layer(bg, depth) */
-  double* env_xyY;                /* H*We*3, We = cw + 2*(cw/2) (may be NULL) */
+  void* rainy_bg;                 /* H*W*3: FOG.fog_rain_layer(bg, depth); float64, or float32 with RR_OUT_RAINY_F32 */
+  void* env_xyY;                  /* H*We*3, We = cw + 2*(cw/2) (may be NULL); float64, or float32 with RR_OUT_ENV_F32 */
   uint8_t* env_bgr_u8;            /* H*We*3: the map the reference saves with --save_envmap (may be NULL) */
+  int32_t out_types;              /* one value for every frame of a batch */
+  int32_t reserved;
 } rr_prepass_out;
 
 int rr_set_prepass_kernels(rr_ctx* ctx, const rr_prepass_kernels* k);
@@ -256,7 +265,11 @@ int rr_prepass_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* in, const rr_
 /* Pre-pass + hot path for n frames with HOST pointers and no host round trip in between:
  * in[f].rainy_bg and in[f].env_xyY are ignored (produced on the device from pre[f]); in[f].bg is ignored
  * too (the mean shift uses pre[f]'s background); in[f].He/We must be H / rr_envmap_width().  pre_out may be NULL, as may each of
- * its members: what is non-NULL is downloaded as well. */
+ * its members: what is non-NULL is downloaded as well.
+ * Width of the arrays handed from the pre-pass to the hot path (they never leave the device unless pre_out asks): what
+ * pre_out[].out_types says where pre_out downloads them; otherwise float32 (RR_OPT_PIPELINE_F32, default 1: the mask does
+ * not read them, the image contract is +-1 LSB) -- the environment map only when every in[f].omega is NULL (the resident
+ * solid angles exist in both widths).  A byte image (bg_u8 / RR_IN_BG_U8) stays bytes on the device. */
 int rr_pipeline_frames(rr_ctx* ctx, int32_t n, const rr_prepass_in* pre, const rr_frame_in* in, const rr_frame_out* out,
                        const rr_prepass_out* pre_out);
 
@@ -355,8 +368,10 @@ enum {
                                      * spans with one thread per drop (two cursors down the polygon's sides; wrapping polygons and
                                      * float64 decisions through a list to the edge-parallel kernel); 0: the edge-parallel kernel for
                                      * every drop.  The spans are the same: identical results. */
-  RR_OPT_COMPOSITE_WAVES = 11       /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
+  RR_OPT_COMPOSITE_WAVES = 11,      /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
                                      * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
+  RR_OPT_PIPELINE_F32 = 13          /* 1 (default): rr_pipeline_* hand the fog layer and the xyY map from the pre-pass to the hot path
+                                     * as float32 unless pre_out asks for float64 copies (see rr_pipeline_frames); 0: float64 */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

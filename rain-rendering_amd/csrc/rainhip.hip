@@ -1671,9 +1671,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
     const int64_t gi = (int64_t)f * max_drops + lbig[j];
     const DropPlan& p = sc.plan[gi];
     const int local = pix - boff[j];
-    int y = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)p.tw)), x = local - y * p.tw;     // local / tw without the integer division
-    if (x < 0) { y--; x += p.tw; }                       // (the reciprocal is good to an ulp: at most one off)
-    else if (x >= p.tw) { y++; x -= p.tw; }
+    const int y = local / p.tw, x = local - y * p.tw;     // (r04: a reciprocal-multiply with a fix-up in place of this division measured 9 % SLOWER)
     TexLutWide tx{texels + tex_off[p.tex], s_lut, tex_h[p.tex], tex_w[p.tex]};
     PH(1)                                           // plan fields
     sc.arena[p.a0_off + local] = warp_big_pixel(p, tx, s_ctab, x, y);
@@ -3354,6 +3352,7 @@ struct rr_ctx {
   uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
   int64_t* d_tex_poff = nullptr;
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
+  bool pipe_f32 = true;              // RR_OPT_PIPELINE_F32: float32 hand-over from the pre-pass to the hot path inside rr_pipeline_*
   bool fov_dda = true;               // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (k_fov_dda)
   int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
   int n_tex = 0;
@@ -3426,6 +3425,7 @@ struct rr_ctx {
   rrpre::PreScratch psc{};
   rrpre::PreFrame* d_pre = nullptr;
   int pre_frames = 0, pre_H = 0, pre_W = 0, pre_We = 0;
+  bool pre_planes = false;           // the float64 planes of the three-kernel fog layer are allocated (tap counts other than 25)
   // profiling
   bool prof = false;
   // options (rr_set_option): none of them changes a result bit
@@ -3992,6 +3992,11 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
       ctx->err = "pre-pass: null pointer or zero irradiance denominator (bg_u8 is for the host entry points only)";
       return RR_E_ARG;
     }
+    if ((in[f].in_types & ~(RR_IN_BG_F32 | RR_IN_BG_U8)) || in[f].in_types == (RR_IN_BG_F32 | RR_IN_BG_U8) ||
+        (out[f].out_types & ~(RR_OUT_RAINY_F32 | RR_OUT_ENV_F32)) || out[f].out_types != out[0].out_types) {
+      ctx->err = "pre-pass: in_types is RR_IN_BG_F32 or RR_IN_BG_U8 (or 0), out_types RR_OUT_* bits, the same for every frame";
+      return RR_E_ARG;
+    }
     if (out[f].env_xyY || out[f].env_bgr_u8) want_env = true;
   }
   if (want_env && (!ctx->have_eg || ctx->eg.H != H || ctx->eg.W != W)) {
@@ -3999,15 +4004,19 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     return RR_E_STATE;
   }
   const int We = want_env ? ctx->eg.We : 0;
-  if (n > ctx->pre_frames || H != ctx->pre_H || W != ctx->pre_W || We > ctx->pre_We) {
+  const bool tiled = ctx->pk.fog_k == 25;        // the reference's 25 taps: the one-kernel fog layer (FogTile), no float64 planes in HBM
+  const bool planes = !env_only && !tiled;
+  if (n > ctx->pre_frames || H != ctx->pre_H || W != ctx->pre_W || We > ctx->pre_We || (planes && !ctx->pre_planes)) {
     HIPCHK(hipDeviceSynchronize());
     const int F = n > ctx->pre_frames ? n : ctx->pre_frames;
     const int we = We > ctx->pre_We ? We : ctx->pre_We;
     const size_t px = (size_t)H * W, ex = (size_t)H * (we > 0 ? we : 1);
+    const bool pl = planes || ctx->pre_planes;
     int rc;
-    if ((rc = dev_alloc(ctx, ctx->psc.fext, F * px))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->psc.tmpF, F * px))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->psc.tmpL, F * px * 3))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.fext, pl ? F * px : 1))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.tmpF, pl ? F * px : 1))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.tmpL, pl ? F * px * 3 : 1))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->psc.r8, F * px * 3))) return rc;
     if ((rc = dev_alloc(ctx, ctx->psc.part, (size_t)F * rrpre::FOG_BLOCKS * 3))) return rc;
     if ((rc = dev_alloc(ctx, ctx->psc.mean, (size_t)F * 3))) return rc;
     if ((rc = dev_alloc(ctx, ctx->psc.epack, F * ex))) return rc;
@@ -4017,6 +4026,7 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     ctx->pre_H = H;
     ctx->pre_W = W;
     ctx->pre_We = we;
+    ctx->pre_planes = pl;
   }
   int ring_idx, rrc;
   void* ring_host;
@@ -4026,15 +4036,17 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     rrpre::PreFrame& p = h_pre[f];
     p.bg = in[f].bg;
     p.depth = in[f].depth;
-    p.rainy = env_only ? const_cast<double*>(in[f].bg) : out[f].rainy_bg;   // env-only: the map kernels read the caller's image
+    p.rainy = env_only ? nullptr : out[f].rainy_bg;     // (map-only: the map kernels read the caller's image, `bg`)
     p.env_xyY = out[f].env_xyY;
     p.env_u8 = out[f].env_bgr_u8;
+    p.r8 = (!env_only && want_env) ? ctx->psc.r8 + (size_t)f * H * W * 3 : nullptr;
     p.beta_ext = in[f].beta_ext;
     p.beta_hg = in[f].beta_hg;
     p.irr_num = in[f].irr_num;
     p.irr_den = in[f].irr_den;
     p.depth_f64 = in[f].depth_f64;
-    p.pad = 0;
+    p.types = ((in[f].in_types & RR_IN_BG_F32) ? rrpre::PRE_BG_F32 : 0) | ((in[f].in_types & RR_IN_BG_U8) ? rrpre::PRE_BG_U8 : 0) |
+              ((out[f].out_types & RR_OUT_RAINY_F32) ? rrpre::PRE_RAINY_F32 : 0) | ((out[f].out_types & RR_OUT_ENV_F32) ? rrpre::PRE_ENV_F32 : 0);
   }
   hipLaunchKernelGGL(k_copy_small, dim3(16), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(h_pre), reinterpret_cast<uint32_t*>(ctx->d_pre),
                      (int)(sizeof(rrpre::PreFrame) * (size_t)n / 4));
@@ -4045,19 +4057,26 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     ProfScope ps(ctx, s, "k_fog_stats");
     hipLaunchKernelGGL(rrpre::k_fog_sum, dim3(rrpre::FOG_BLOCKS, n), dim3(256), 0, s, ctx->d_pre, H, W, sc);
     hipLaunchKernelGGL(rrpre::k_fog_mean, dim3(n), dim3(64), 0, s, H, W, sc);
-    hipLaunchKernelGGL(rrpre::k_fog_ext, dim3(px_blocks, n), dim3(256), 0, s, ctx->d_pre, H, W, sc);
+    if (!tiled) hipLaunchKernelGGL(rrpre::k_fog_ext, dim3(px_blocks, n), dim3(256), 0, s, ctx->d_pre, H, W, sc);
   }
-  if (!env_only) {
+  if (!env_only && tiled) {
+    // column strips x row segments x frames; a segment costs 2 * 12 rows of horizontal sums it shares with its neighbours,
+    // so segments are only cut while the grid is short of a few workgroups per slot (3 per CU fit: 46 KB of LDS each)
+    using T = rrpre::FogTile<12>;
+    const int strips = (W + T::TC - 1) / T::TC;
+    int segs = 1;
+    while ((int64_t)strips * n * segs < 3072 && H / (segs + 1) >= 64) segs++;
+    const int seg_rows = (((H + segs - 1) / segs) + T::RB - 1) / T::RB * T::RB;
+    ProfScope ps(ctx, s, "k_fog_tile");
+    hipLaunchKernelGGL(rrpre::k_fog_tile<12>, dim3(strips, (H + seg_rows - 1) / seg_rows, n), dim3(256), 0, s, ctx->d_pre, H, W, seg_rows, ctx->pk, sc);
+  }
+  if (!env_only && !tiled) {
     ProfScope ps(ctx, s, "k_fog_h");
     hipLaunchKernelGGL(rrpre::k_fog_h, dim3((W + rrpre::FOG_SEG - 1) / rrpre::FOG_SEG, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
   }
-  if (!env_only) {
+  if (!env_only && !tiled) {
     ProfScope ps(ctx, s, "k_fog_v");
-    if (ctx->pk.fog_k == 25)        // the reference's 25 taps: register strips of FOG_RV rows
-      hipLaunchKernelGGL(rrpre::k_fog_v_strip<12>, dim3((W + 255) / 256, (H + rrpre::FOG_RV - 1) / rrpre::FOG_RV, n), dim3(256), 0, s,
-                         ctx->d_pre, H, W, ctx->pk, sc);
-    else
-      hipLaunchKernelGGL(rrpre::k_fog_v, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
+    hipLaunchKernelGGL(rrpre::k_fog_v, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
   }
   if (want_env) {
     const rrpre::EnvGeom g = ctx->eg;
@@ -4281,6 +4300,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->psc.fext);
   hipFree(ctx->psc.tmpF);
   hipFree(ctx->psc.tmpL);
+  hipFree(ctx->psc.r8);
   hipFree(ctx->psc.part);
   hipFree(ctx->psc.mean);
   hipFree(ctx->psc.epack);
@@ -4688,6 +4708,11 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         ctx->err = "null pre-pass pointer or zero irradiance denominator";
         return RR_E_ARG;
       }
+      if ((pre[f].in_types & ~(RR_IN_BG_F32 | RR_IN_BG_U8)) || pre[f].in_types == (RR_IN_BG_F32 | RR_IN_BG_U8) ||
+          (pre_out && ((pre_out[f].out_types & ~(RR_OUT_RAINY_F32 | RR_OUT_ENV_F32)) || pre_out[f].out_types != pre_out[0].out_types))) {
+        ctx->err = "pre-pass: in_types is RR_IN_BG_F32 or RR_IN_BG_U8 (or 0), out_types RR_OUT_* bits, the same for every frame";
+        return RR_E_ARG;
+      }
       if (!in && !env_only && !pre_out[f].rainy_bg) {
         ctx->err = "pre-pass: null rainy_bg output";
         return RR_E_ARG;
@@ -4790,16 +4815,42 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   up.host_is_src = true;
   down.host_is_src = false;
   std::vector<rr_sim_frame> sims;
+  // Width of the two arrays the pre-pass hands on (the staging is sized for float64 either way).  Where pre_out downloads
+  // one, its out_types decide; an array that never leaves the device is float32 in the pipeline (RR_OPT_PIPELINE_F32; the
+  // map only with the resident solid angles, which exist in both widths) and float64 in a pre-pass-only call.
+  int pre_types = 0;
+  if (pre) {
+    const int asked = pre_out ? pre_out[0].out_types : 0;
+    bool down_rainy = false, down_env = false, resident_omega = in != nullptr;
+    for (int f = 0; f < n; f++) {
+      down_rainy = down_rainy || (pre_out && pre_out[f].rainy_bg);
+      down_env = down_env || (pre_out && pre_out[f].env_xyY);
+      resident_omega = resident_omega && !in[f].omega;
+    }
+    const bool narrow = in && ctx->pipe_f32;
+    if (down_rainy ? (asked & RR_OUT_RAINY_F32) != 0 : narrow) pre_types |= RR_OUT_RAINY_F32;
+    if (down_env ? (asked & RR_OUT_ENV_F32) != 0 : (narrow && resident_omega)) pre_types |= RR_OUT_ENV_F32;
+    if (in && (pre_types & RR_OUT_ENV_F32) && !resident_omega) {
+      ctx->err = "pipeline: a float32 xyY map (RR_OUT_ENV_F32) needs the resident solid angles (omega == NULL in every frame)";
+      return RR_E_ARG;
+    }
+  }
+  const size_t rainy_el = (pre_types & RR_OUT_RAINY_F32) ? 4 : 8, penv_el = (pre_types & RR_OUT_ENV_F32) ? 4 : 8;
   // ---- upload ----
   for (int f = 0; pre && f < n; f++) {
     pin[f] = pre[f];
-    pin[f].bg = st.bg + f * T.px3d;
+    // the image in the caller's element type: bytes stay bytes (bg = bytes / 255.0 is formed where a kernel reads it)
+    const void* src = pre[f].bg_u8 ? (const void*)pre[f].bg_u8 : pre[f].bg;
+    pin[f].in_types = pre[f].bg_u8 ? RR_IN_BG_U8 : pre[f].in_types;
+    const size_t bg_el = (pin[f].in_types & RR_IN_BG_U8) ? 1 : ((pin[f].in_types & RR_IN_BG_F32) ? 4 : 8);
+    pin[f].bg = bg_el == 1 ? (const void*)(st.bg8 + f * T.px3b) : (const void*)(st.bg + f * T.px3d);
     pin[f].bg_u8 = nullptr;
     pin[f].depth = depth_at(f);
-    if (pre[f].bg_u8) up.add(st.bg8 + f * T.px3b, pre[f].bg_u8, px * 3);      // bytes over PCIe: 1/8 of the float64 image
-    else up.add((void*)pin[f].bg, pre[f].bg, px * 3 * sizeof(double));
+    up.add(const_cast<void*>(pin[f].bg), src, px * 3 * bg_el);
     const bool env_only = pre[f].mode == RR_PRE_ENV_ONLY;
     if (!env_only) up.add((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4));
+    pout[f].out_types = pre_types;
+    pout[f].reserved = 0;
     pout[f].rainy_bg = st.rainy + f * T.px3d;
     const bool env = in || pre_out[f].env_xyY || pre_out[f].env_bgr_u8;
     pout[f].env_xyY = env ? st.env + f * T.ex3d : nullptr;
@@ -4807,7 +4858,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   }
   for (int f = 0; in && f < n; f++) {
     din[f] = in[f];
-    din[f].bg = st.bg + f * T.px3d;
+    din[f].bg = pre ? pin[f].bg : (const void*)(st.bg + f * T.px3d);
     din[f].rainy_bg = st.rainy + f * T.px3d;
     din[f].env_xyY = st.env + f * T.ex3d;
     // the solid-angle map depends on the map size only: NULL = the resident one (rr_set_solid_angles); frames that pass
@@ -4825,16 +4876,18 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
       din[f].depth = nullptr;
     }
     // element sizes of the caller's arrays (rr_frame_in.in_types; the staging is sized for float64)
-    const int ty = pre ? 0 : in[f].in_types;
-    din[f].in_types = ty;                                      // (the pre-pass hands float64 arrays on)
+    // (behind the pre-pass: the image as the caller gave it to the pre-pass, the fog layer and the map at the hand-over width)
+    const int ty = !pre ? in[f].in_types
+                        : (pin[f].in_types | ((pre_types & RR_OUT_RAINY_F32) ? RR_IN_RAINY_F32 : 0) | ((pre_types & RR_OUT_ENV_F32) ? RR_IN_ENV_F32 : 0));
+    din[f].in_types = ty;
     const size_t bg_el = (ty & RR_IN_BG_U8) ? 1 : ((ty & RR_IN_BG_F32) ? 4 : 8);
     const bool shared_bg = in[f].rainy_bg == in[f].bg;         // one array for both: one upload, and the kernels see one pointer
-    const size_t rainy_el = shared_bg ? bg_el : ((ty & RR_IN_RAINY_U8) ? 1 : ((ty & RR_IN_RAINY_F32) ? 4 : 8));
+    const size_t rainy_in_el = shared_bg ? bg_el : ((ty & RR_IN_RAINY_U8) ? 1 : ((ty & RR_IN_RAINY_F32) ? 4 : 8));
     const size_t env_el = (ty & RR_IN_ENV_F32) ? 4 : 8;
     if (!pre) {
       up.add((void*)din[f].bg, in[f].bg, px * 3 * bg_el);
       if (shared_bg) din[f].rainy_bg = din[f].bg;
-      else up.add((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * rainy_el);
+      else up.add((void*)din[f].rainy_bg, in[f].rainy_bg, px * 3 * rainy_in_el);
       up.add((void*)din[f].env_xyY, in[f].env_xyY, ex * 3 * env_el);
     }
     if (!same_omega) up.add((void*)din[f].omega, in[f].omega, ex * env_el);
@@ -4902,15 +4955,6 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     return drained(RR_E_HIP);
   }
   // ---- compute ----
-  // bg = bytes / 255.0 (generator.py:352) formed on the device: one launch per run of consecutive byte-image frames
-  for (int f = 0; pre && f < n;) {
-    if (!pre[f].bg_u8) { f++; continue; }
-    int g = f;
-    while (g < n && pre[g].bg_u8) g++;
-    hipLaunchKernelGGL(rrpre::k_bytes_to_unit, dim3((unsigned)((px * 3 + 255) / 256), (unsigned)(g - f)), dim3(256), 0, s, st.bg8 + f * T.px3b,
-                       st.bg + f * T.px3d, (int64_t)(px * 3), (int64_t)T.px3b, (int64_t)T.px3d);
-    f = g;
-  }
   if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return drained(rc);
   if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, drop_stride, st.ndrops, s))) return drained(rc);
   if (in) {                           // the slot's own overflow flag, cleared in stream order before the batch's k_scan may set it
@@ -4936,8 +4980,8 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     if (out[f].mask_png) down.add(out[f].mask_png, dout[f].mask_png, png_bytes);
   }
   for (int f = 0; pre && pre_out && f < n; f++) {
-    if (pre_out[f].rainy_bg && pre[f].mode != RR_PRE_ENV_ONLY) down.add(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * sizeof(double));
-    if (pre_out[f].env_xyY) down.add(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * sizeof(double));
+    if (pre_out[f].rainy_bg && pre[f].mode != RR_PRE_ENV_ONLY) down.add(pre_out[f].rainy_bg, pout[f].rainy_bg, px * 3 * rainy_el);
+    if (pre_out[f].env_xyY) down.add(pre_out[f].env_xyY, pout[f].env_xyY, ex * 3 * penv_el);
     if (pre_out[f].env_bgr_u8) down.add(pre_out[f].env_bgr_u8, pout[f].env_bgr_u8, ex * 3);
   }
   sl.down = std::move(down.v);
@@ -5189,6 +5233,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
     case RR_OPT_FOV_DDA: ctx->fov_dda = value != 0; return RR_OK;
+    case RR_OPT_PIPELINE_F32: ctx->pipe_f32 = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_WAVES:
       if (value != 0 && value != 6 && value != 7 && value != 8) break;
       ctx->comp_waves = value ? value : 6;

@@ -217,7 +217,7 @@ template <class Tex>
 RR_HD double warp_big_pixel(const DropPlan& p, const Tex& tx, const float* ctab, int x, int y) {
   const double* Mi = p.mi;
   const int sh = tx.h, sw = tx.w;
-  int bx = x < p.bw0 ? 0 : (x / p.bw0) * p.bw0;              // (tiles narrower than a block -- nearly all -- skip the division)
+  int bx = (x / p.bw0) * p.bw0;
   double x1 = (double)(x - bx);
   double bxf = (double)bx, yf = (double)y;
   double X0 = Mi[0] * bxf + Mi[1] * yf + Mi[2];

@@ -33,15 +33,32 @@ struct Kernels {                    // passed by value to the kernels
   double env_w[KMAX];
 };
 
+// element types of a frame's arrays (PreFrame.types).  The arithmetic is float64 whatever the types: a float32 output is
+// the float64 result rounded once, a uint8 image is bytes / 255.0 (generator.py:352) formed where it is read.
+enum { PRE_BG_F32 = 1, PRE_BG_U8 = 2, PRE_RAINY_F32 = 4, PRE_ENV_F32 = 8 };
+
 struct PreFrame {
-  const double* bg;                 // H*W*3
+  const void* bg;                   // H*W*3: float64, float32 (PRE_BG_F32) or uint8 (PRE_BG_U8)
   const void* depth;                // H*W float32 or float64
-  double* rainy;                    // H*W*3
-  double* env_xyY;                  // H*We*3 (may be null)
+  void* rainy;                      // H*W*3: float64 or float32 (PRE_RAINY_F32)
+  void* env_xyY;                    // H*We*3: float64 or float32 (PRE_ENV_F32) (may be null)
   uint8_t* env_u8;                  // H*We*3 BGR (may be null)
+  uint8_t* r8;                      // H*W*3 (rainy * 255).astype(uint8) of the fog pass' float64 result: what the map's gather
+                                    // reads (bad_weather.py:764); null in the map-only mode (the gather then reads `bg`)
   double beta_ext, beta_hg, irr_num, irr_den;
-  int32_t depth_f64, pad;
+  int32_t depth_f64, types;
 };
+
+RRP_HD double load_unit(const void* a, int types, int64_t i) {          // one element of `bg`
+  if (types & PRE_BG_U8) return (double)((const uint8_t*)a)[i] / 255.0;
+  if (types & PRE_BG_F32) return (double)((const float*)a)[i];
+  return ((const double*)a)[i];
+}
+RRP_HD void store_rainy(const void* a, int types, int64_t i, double v) {
+  if (types & PRE_RAINY_F32) ((float*)const_cast<void*>(a))[i] = (float)v;
+  else ((double*)const_cast<void*>(a))[i] = v;
+}
+RRP_HD uint8_t unit_to_byte(double v) { return (uint8_t)((uint32_t)(int)(v * 255.0) & 255u); }   // (image * 255).astype(uint8)
 
 struct EnvGeom {
   int H, W, cw, lw, We;
@@ -51,9 +68,10 @@ struct EnvGeom {
 };
 
 struct PreScratch {                 // [frame][...]
-  double* fext;                     // [H*W]
+  double* fext;                     // [H*W]       (these three: tap counts other than 25 only -- the three-kernel form)
   double* tmpF;                     // [H*W]
   double* tmpL;                     // [3][H*W] (planar: the vertical pass reads whole rows of one plane)
+  uint8_t* r8;                      // [H*W*3] PreFrame.r8 of the frames
   double* part;                     // [64*3]
   double* mean;                     // [3]
   uint32_t* epack;                  // [H*We] b | g<<8 | r<<16 | mask<<24
@@ -79,9 +97,9 @@ __global__ void __launch_bounds__(256) k_fog_sum(const PreFrame* fr, int H, int 
   const int64_t px = (int64_t)H * W;
   double s0 = 0, s1 = 0, s2 = 0;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < px; p += (int64_t)FOG_BLOCKS * 256) {
-    s0 += (F.irr_num * F.bg[p * 3 + 0]) / F.irr_den;
-    s1 += (F.irr_num * F.bg[p * 3 + 1]) / F.irr_den;
-    s2 += (F.irr_num * F.bg[p * 3 + 2]) / F.irr_den;
+    s0 += (F.irr_num * load_unit(F.bg, F.types, p * 3 + 0)) / F.irr_den;
+    s1 += (F.irr_num * load_unit(F.bg, F.types, p * 3 + 1)) / F.irr_den;
+    s2 += (F.irr_num * load_unit(F.bg, F.types, p * 3 + 2)) / F.irr_den;
   }
   __shared__ double red[3][256];
   red[0][threadIdx.x] = s0;
@@ -107,16 +125,14 @@ __global__ void k_fog_mean(int H, int W, PreScratch sc) {
 #endif
 
 // extinction map f_ext = exp(-beta_ext * depth_km)                      add_attenuation.py:45-49
+RRP_HD double fog_ext_val(const PreFrame& F, double d64, float d32) {
+  if (F.depth_f64) return exp(-F.beta_ext * (d64 / 1000.0));
+  const float t = d32 / 1000.0f;    // numpy keeps float32: float32 / int, weak python scalar * float32
+  return (double)expf((float)(-F.beta_ext) * t);
+}
 RRP_HD void fog_ext_px(const PreFrame& F, int f, int H, int W, const PreScratch& sc, int64_t p) {
   const int64_t px = (int64_t)H * W;
-  double e;
-  if (F.depth_f64) {
-    e = exp(-F.beta_ext * (((const double*)F.depth)[p] / 1000.0));
-  } else {                          // numpy keeps float32: float32 / int, weak python scalar * float32
-    const float t = ((const float*)F.depth)[p] / 1000.0f;
-    e = (double)expf((float)(-F.beta_ext) * t);
-  }
-  sc.fext[f * px + p] = e;
+  sc.fext[f * px + p] = F.depth_f64 ? fog_ext_val(F, ((const double*)F.depth)[p], 0.0f) : fog_ext_val(F, 0.0, ((const float*)F.depth)[p]);
 }
 
 
@@ -142,7 +158,6 @@ RRP_HD void fog_h_taps(const double* S, int pitch, int i, const Kernels& kn, int
 }
 
 constexpr int FOG_SEG = 256;        // output columns per staged row segment
-constexpr int FOG_RV = 8;           // output rows per thread of the vertical pass
 
 // stages plane values of columns x0-half .. x0+n+half-1 of row y (reflect-101) into S[4][pitch]
 RRP_HD void fog_stage_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y, int x0, int i,
@@ -160,35 +175,7 @@ RRP_HD void fog_h_store(int f, int H, int W, const PreScratch& sc, int y, int x,
   for (int c = 0; c < 3; c++) sc.tmpL[(f * 3 + c) * px + q] = o[1 + c];
 }
 
-// vertical pass + rainy = clip(image * f_ext + l_in, 0, 1)  (:82-86,93) for FOG_RV consecutive rows of
-// column x.  The HALF + FOG_RV + HALF source rows of a plane are read once into registers and shared by
-// the FOG_RV outputs (the per-pixel form reads 2*HALF+1 rows per output through L2: the pass was L2-bound).
-template <int HALF>
-RRP_HD void fog_v_strip(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y0, int x) {
-  const int64_t px = (int64_t)H * W;
-  double outF[FOG_RV];
-#pragma unroll 1                      // one plane's window live at a time (registers)
-  for (int plane = 0; plane < 4; plane++) {
-    const double* src = (plane == 0 ? sc.tmpF + f * px : sc.tmpL + (f * 3 + (plane - 1)) * px) + x;
-    double v[FOG_RV + 2 * HALF];
-#pragma unroll
-    for (int k = 0; k < FOG_RV + 2 * HALF; k++) v[k] = src[(int64_t)reflect101(y0 - HALF + k, H) * W];
-#pragma unroll
-    for (int r = 0; r < FOG_RV; r++) {
-      double a = v[HALF + r] * kn.fog_w[HALF];
-#pragma unroll
-      for (int j = -HALF; j < 0; j++) a += (v[HALF + r + j] + v[HALF + r - j]) * kn.fog_w[HALF + j];
-      if (plane == 0) {
-        outF[r] = F.depth_f64 ? a : (double)(float)a;
-      } else if (y0 + r < H) {
-        const int64_t q = ((int64_t)(y0 + r) * W + x) * 3 + (plane - 1);
-        F.rainy[q] = clip01(F.bg[q] * outF[r] + a);
-      }
-    }
-  }
-}
-
-// generic tap count: one output per call
+// vertical pass + rainy = clip(image * f_ext + l_in, 0, 1)  (:82-86,93), any tap count: one output per call
 RRP_HD void fog_v_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, const PreScratch& sc, int y, int x) {
   const int64_t px = (int64_t)H * W, base = f * px;
   const int half = kn.fog_k / 2;
@@ -203,20 +190,128 @@ RRP_HD void fog_v_px(const PreFrame& F, int f, int H, int W, const Kernels& kn, 
   }
   if (!F.depth_f64) aF = (double)(float)aF;
   const int64_t q = ((int64_t)y * W + x) * 3;
-  for (int c = 0; c < 3; c++) F.rainy[q + c] = clip01(F.bg[q + c] * aF + aL[c]);
+  for (int c = 0; c < 3; c++) {
+    const double v = clip01(load_unit(F.bg, F.types, q + c) * aF + aL[c]);
+    store_rainy(F.rainy, F.types, q + c, v);
+    if (F.r8) F.r8[q + c] = unit_to_byte(v);
+  }
 }
 
+// --- the 25-tap fog layer in ONE kernel (round 4) --------------------------------------------------------------------
+// The three-kernel form above writes f_ext, then four planes of horizontal sums, then reads those planes back 32 rows per
+// 8 output rows: 150 B of HBM traffic per pixel for a result of 24 B.  FogTile keeps all of it in LDS: a workgroup owns
+// TC columns and walks down a segment of rows RB rows at a time;
+//   stage   RB source rows x (TC + 2 HALF) columns: f_ext from the depth (fog_ext_val) and the three l_in planes -> S
+//   hpass   the horizontal sums of those RB rows -> a ring of RB + 2 HALF rows of horizontal sums
+//   vpass   the vertical sums of the RB output rows whose window is now complete, the blend with the image, the stores.
+// Rows and columns beyond the frame are staged from their BORDER_REFLECT_101 sources, so that the passes never index
+// outside [0, H) x [0, W); every sum folds its taps in the order of fog_h_taps / fog_v_px above, so that the float64
+// result is THE SAME BITS as the three-kernel form's (tests/test_prepass_hostemu.py runs both on the host).
+// Thread roles (256 threads; the __global__ wrapper and tests/hostemu call the same functions with tid = 0..255):
+//   stage   item i = tid, tid + 256 < RB * PITCH: source row i / PITCH, staged column i % PITCH
+//   hpass   row tid >> 5, planes 2 * ((tid >> 4) & 1) + {0, 1}, columns 2 * (tid & 15) + {0, 1}: a window of 26 staged
+//           values gives both columns' sums (13 taps each side shared)
+//   vpass   wave w = tid >> 6: columns 16 * (w & 1) + (lane & 15), rows 4 * (w >> 1) + {0..3}, plane lane >> 4: a window of
+//           28 ring rows gives the four rows' sums; planes 1..3 need plane 0's sum of their pixel: lane & 15 of the same wave
+//           (a wave shuffle on the device), then store 48 consecutive channel values per row.
+template <int HALF>
+struct FogTile {
+  static constexpr int TC = 32, RB = 8, PITCH = TC + 2 * HALF, RING = RB + 2 * HALF, NB = RING / RB, VR = 4;
+  static_assert((2 * HALF) % RB == 0 && RB * TC == 256 && PITCH % 2 == 0, "tile shape");
+  typedef double d2 __attribute__((vector_size(16)));
+
+  // (source pixel index of stage item i of h-block k, or -1) -- the depth value is loaded by the caller (the device
+  // prefetches the next block's while this block's sums are folded)
+  RRP_HD static int64_t stage_src(int H, int W, int x0, int hs, int k, int i) {
+    if (i >= RB * PITCH) return -1;
+    const int rr = i / PITCH, ci = i - rr * PITCH;
+    return (int64_t)reflect101(hs + k * RB + rr, H) * W + reflect101(x0 - HALF + ci, W);
+  }
+  RRP_HD static void stage_put(const PreFrame& F, const double k3[3], int i, double d64, float d32, double* S) {
+    const int rr = i / PITCH, ci = i - rr * PITCH;
+    double o[4];
+    fog_src(fog_ext_val(F, d64, d32), F.depth_f64, k3, o);
+    for (int p = 0; p < 4; p++) S[(rr * 4 + p) * PITCH + ci] = o[p];
+  }
+  RRP_HD static void hpass(const Kernels& kn, int f64, int k, int tid, const double* S, double* ring) {
+    const int rr = tid >> 5, pp = (tid >> 4) & 1, cp = tid & 15;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int p = 2 * pp + u;
+      const d2* src = reinterpret_cast<const d2*>(S + (rr * 4 + p) * PITCH + 2 * cp);
+      double v[2 * HALF + 2];
+#pragma unroll
+      for (int j = 0; j <= HALF; j++) {
+        const d2 t = src[j];
+        v[2 * j] = t[0];
+        v[2 * j + 1] = t[1];
+      }
+      double a0 = v[HALF] * kn.fog_w[HALF], a1 = v[HALF + 1] * kn.fog_w[HALF];
+#pragma unroll
+      for (int j = -HALF; j < 0; j++) {
+        a0 += (v[HALF + j] + v[HALF - j]) * kn.fog_w[HALF + j];
+        a1 += (v[HALF + 1 + j] + v[HALF + 1 - j]) * kn.fog_w[HALF + j];
+      }
+      if (p == 0 && !f64) {                          // the float32 depth path keeps f_ext in float32
+        a0 = (double)(float)a0;
+        a1 = (double)(float)a1;
+      }
+      d2 o;
+      o[0] = a0;
+      o[1] = a1;
+      *reinterpret_cast<d2*>(ring + (((k & (NB - 1)) * RB + rr) * 4 + p) * TC + 2 * cp) = o;
+    }
+  }
+  // the VR vertical sums of v-block m (whose window is h-blocks m .. m + NB - 1) for thread tid's column and plane
+  RRP_HD static void vtaps(const Kernels& kn, int f64, int m, int tid, const double* ring, double a[VR]) {
+    const int w = tid >> 6, lane = tid & 63, col = 16 * (w & 1) + (lane & 15), p = lane >> 4, r0 = VR * (w >> 1);
+    double v[VR + 2 * HALF];
+#pragma unroll
+    for (int j = 0; j < VR + 2 * HALF; j++) {
+      const int q = r0 + j;                          // row of the 32-row window
+      v[j] = ring[((((m + (q / RB)) & (NB - 1)) * RB + (q % RB)) * 4 + p) * TC + col];
+    }
+#pragma unroll
+    for (int r = 0; r < VR; r++) {
+      double s = v[HALF + r] * kn.fog_w[HALF];
+#pragma unroll
+      for (int j = -HALF; j < 0; j++) s += (v[HALF + r + j] + v[HALF + r - j]) * kn.fog_w[HALF + j];
+      a[r] = (p == 0 && !f64) ? (double)(float)s : s;
+    }
+  }
+  // rainy = clip(image * f_ext + l_in, 0, 1) (:93) of the thread's channel; aF = plane 0's sums of the same pixels
+  RRP_HD static void vstore(const PreFrame& F, int H, int W, int x0, int ys, int ye, int m, int tid, const double a[VR], const double aF[VR]) {
+    const int w = tid >> 6, lane = tid & 63, x = x0 + 16 * (w & 1) + (lane & 15), p = lane >> 4, y0 = ys + m * RB + VR * (w >> 1);
+    if (p == 0 || x >= W) return;
+    double img[VR];
+#pragma unroll
+    for (int r = 0; r < VR; r++) {
+      const int y = y0 + r < ye ? y0 + r : ye - 1;
+      img[r] = load_unit(F.bg, F.types, ((int64_t)y * W + x) * 3 + (p - 1));
+    }
+#pragma unroll
+    for (int r = 0; r < VR; r++) {
+      if (y0 + r >= ye) break;
+      const int64_t q = ((int64_t)(y0 + r) * W + x) * 3 + (p - 1);
+      const double v = clip01(img[r] * aF[r] + a[r]);
+      store_rainy(F.rainy, F.types, q, v);
+      if (F.r8) F.r8[q] = unit_to_byte(v);
+    }
+  }
+};
+
 // --- environment map ------------------------------------------------------------------------
-RRP_HD uint32_t bg8_px(const double* img, int32_t p) {      // (background*255).astype(uint8)
-  const uint32_t b = (uint32_t)(int)(img[(int64_t)p * 3 + 0] * 255.0) & 255u;
-  const uint32_t g = (uint32_t)(int)(img[(int64_t)p * 3 + 1] * 255.0) & 255u;
-  const uint32_t r = (uint32_t)(int)(img[(int64_t)p * 3 + 2] * 255.0) & 255u;
+RRP_HD uint32_t bg8_px(const PreFrame& F, int32_t p) {      // (background*255).astype(uint8)
+  const int64_t q = (int64_t)p * 3;
+  if (F.r8) return (uint32_t)F.r8[q] | ((uint32_t)F.r8[q + 1] << 8) | ((uint32_t)F.r8[q + 2] << 16);
+  const uint32_t b = unit_to_byte(load_unit(F.bg, F.types, q + 0));
+  const uint32_t g = unit_to_byte(load_unit(F.bg, F.types, q + 1));
+  const uint32_t r = unit_to_byte(load_unit(F.bg, F.types, q + 2));
   return b | (g << 8) | (r << 16);
 }
 
 // cylindrical un-projection, column fills, mirrored sides                    bad_weather.py:742-813
 RRP_HD void env_build_px(const PreFrame& F, int f, const EnvGeom& g, const PreScratch& sc, int r, int x) {
-  const double* img = F.rainy;
   const int wr = g.cw - g.cw / 2;
   int c;
   if (x >= g.We - wr) c = g.cw - 1 - (x - (g.We - wr));      // right side (written last, :806-811)
@@ -226,14 +321,14 @@ RRP_HD void env_build_px(const PreFrame& F, int f, const EnvGeom& g, const PreSc
   const int half = g.H / 2;
   uint32_t v = 0;
   if (s >= 0) {
-    v = bg8_px(img, s) | 0xff000000u;
+    v = bg8_px(F, s) | 0xff000000u;
   } else {
     int rr = -1;
     if (r < half) rr = g.top_row[c];
     else if (r >= g.H - half) rr = g.bot_row[c];
     if (rr >= 0) {
       const int32_t s2 = g.src[(int64_t)rr * g.cw + c];
-      if (s2 >= 0) v = bg8_px(img, s2);
+      if (s2 >= 0) v = bg8_px(F, s2);
     }
   }
   sc.epack[((int64_t)f * g.H + r) * g.We + x] = v;
@@ -292,9 +387,17 @@ RRP_HD void env_v_px(const PreFrame& F, int f, const EnvGeom& g, const Kernels& 
     double xx = X / s, yy = Y / s;
     if (xx != xx) xx = 0.0;
     if (yy != yy) yy = 0.0;
-    F.env_xyY[q * 3 + 0] = xx;
-    F.env_xyY[q * 3 + 1] = yy;
-    F.env_xyY[q * 3 + 2] = Y;
+    if (F.types & PRE_ENV_F32) {
+      float* o = (float*)F.env_xyY + q * 3;
+      o[0] = (float)xx;
+      o[1] = (float)yy;
+      o[2] = (float)Y;
+    } else {
+      double* o = (double*)F.env_xyY + q * 3;
+      o[0] = xx;
+      o[1] = yy;
+      o[2] = Y;
+    }
   }
 }
 
@@ -330,12 +433,6 @@ inline bool build_env_tables(int H, int W, int cw, int n_uniq, const int32_t* un
 }
 
 #if defined(__HIPCC__)
-// bg = cv2.imread(...) / 255.0 (generator.py:352) from the bytes: IEEE division, same bits as numpy's
-// (blockIdx.y = frame; the frames' byte images / float64 images lie src_stride bytes / dst_stride doubles apart)
-__global__ void __launch_bounds__(256) k_bytes_to_unit(const uint8_t* src, double* dst, int64_t n, int64_t src_stride, int64_t dst_stride) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[(int64_t)blockIdx.y * dst_stride + i] = (double)src[(int64_t)blockIdx.y * src_stride + i] / 255.0;
-}
 __global__ void __launch_bounds__(256) k_fog_ext(const PreFrame* fr, int H, int W, PreScratch sc) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p < (int64_t)H * W) fog_ext_px(fr[blockIdx.y], blockIdx.y, H, W, sc, p);
@@ -361,10 +458,48 @@ __global__ void __launch_bounds__(256) k_fog_v(const PreFrame* fr, int H, int W,
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x < W) fog_v_px(fr[blockIdx.z], blockIdx.z, H, W, kn, sc, blockIdx.y, x);
 }
+// the fog layer of one column strip and row segment (FogTile above); grid (strips, segments, frames)
 template <int HALF>
-__global__ void __launch_bounds__(256) k_fog_v_strip(const PreFrame* fr, int H, int W, Kernels kn, PreScratch sc) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x < W) fog_v_strip<HALF>(fr[blockIdx.z], blockIdx.z, H, W, kn, sc, blockIdx.y * FOG_RV, x);
+__global__ void __launch_bounds__(256, 3) k_fog_tile(const PreFrame* fr, int H, int W, int seg_rows, Kernels kn, PreScratch sc) {
+  using T = FogTile<HALF>;
+  __shared__ double S[T::RB * 4 * T::PITCH] __attribute__((aligned(16)));
+  __shared__ double ring[T::RING * 4 * T::TC] __attribute__((aligned(16)));
+  const int f = blockIdx.z, tid = threadIdx.x, x0 = blockIdx.x * T::TC, ys = blockIdx.y * seg_rows;
+  const PreFrame F = fr[f];
+  const int ye = min(H, ys + seg_rows), hs = ys - HALF;
+  const int n_iter = (ye - ys + T::RB - 1) / T::RB + T::NB - 1;
+  double k3[3];
+  for (int c = 0; c < 3; c++) k3[c] = F.beta_hg * sc.mean[f * 3 + c];
+  // the depth values of the NEXT block's stage items are in flight while this block's sums are folded
+  double d64[2] = {0.0, 0.0};
+  float d32[2] = {0.0f, 0.0f};
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int64_t p = T::stage_src(H, W, x0, hs, k, tid + 256 * u);
+      if (p < 0) continue;
+      if (F.depth_f64) d64[u] = ((const double*)F.depth)[p];
+      else d32[u] = ((const float*)F.depth)[p];
+    }
+  };
+  fetch(0);
+  for (int k = 0; k < n_iter; k++) {
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+      if (tid + 256 * u < T::RB * T::PITCH) T::stage_put(F, k3, tid + 256 * u, d64[u], d32[u], S);
+    if (k + 1 < n_iter) fetch(k + 1);
+    __syncthreads();
+    T::hpass(kn, F.depth_f64, k, tid, S, ring);
+    __syncthreads();                                   // (also: the next stage may overwrite S, the next hpass the oldest ring rows)
+    const int m = k - (T::NB - 1);
+    if (m >= 0) {
+      double a[T::VR], aF[T::VR];
+      T::vtaps(kn, F.depth_f64, m, tid, ring, a);
+#pragma unroll
+      for (int r = 0; r < T::VR; r++) aF[r] = __shfl(a[r], (int)(threadIdx.x & 15));
+      T::vstore(F, H, W, x0, ys, ye, m, tid, a, aF);
+    }
+  }
 }
 __global__ void __launch_bounds__(256) k_env_build(const PreFrame* fr, EnvGeom g, PreScratch sc) {
   const int x = blockIdx.x * 256 + threadIdx.x;

@@ -25,6 +25,8 @@ RR_OPT_PADDED_TEXTURES = 9
 RR_OPT_FOV_F32 = 10
 RR_OPT_COMPOSITE_WAVES = 11
 RR_OPT_FOV_DDA = 12
+RR_OPT_PIPELINE_F32 = 13
+RR_OUT_RAINY_F32, RR_OUT_ENV_F32 = 1, 2                 # rr_prepass_out.out_types
 RR_IN_BG_F32, RR_IN_BG_U8, RR_IN_ENV_F32, RR_IN_RAINY_F32, RR_IN_RAINY_U8 = 1, 2, 4, 8, 16      # rr_frame_in.in_types
 
 # numpy mirror of rr_drop (112 bytes)
@@ -93,7 +95,8 @@ class rr_prepass_in(ctypes.Structure):
     _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('bg', ctypes.c_void_p), ('depth', ctypes.c_void_p),
                 ('depth_f64', ctypes.c_int32), ('mode', ctypes.c_int32),
                 ('beta_ext', ctypes.c_double), ('beta_hg', ctypes.c_double),
-                ('irr_num', ctypes.c_double), ('irr_den', ctypes.c_double), ('bg_u8', ctypes.c_void_p)]
+                ('irr_num', ctypes.c_double), ('irr_den', ctypes.c_double), ('bg_u8', ctypes.c_void_p),
+                ('in_types', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class rr_streak_table(ctypes.Structure):
@@ -103,7 +106,8 @@ class rr_streak_table(ctypes.Structure):
 
 
 class rr_prepass_out(ctypes.Structure):
-    _fields_ = [('rainy_bg', ctypes.c_void_p), ('env_xyY', ctypes.c_void_p), ('env_bgr_u8', ctypes.c_void_p)]
+    _fields_ = [('rainy_bg', ctypes.c_void_p), ('env_xyY', ctypes.c_void_p), ('env_bgr_u8', ctypes.c_void_p),
+                ('out_types', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_streak_db', 'rr_set_streak_db_device',
@@ -885,13 +889,15 @@ class RainHip:
 
     @staticmethod
     def _fill_prepass(pin, fr, keep):
-        """fr['bg'] float64 in [0,1], or fr['bg_u8'] = the uint8 BGR image (bg = bg_u8 / 255.0 on the device)."""
+        """fr['bg']: the image / 255 as float64 (or float32: taken as it is, rr_prepass_in.in_types), or fr['bg_u8'] = the
+        uint8 BGR image (bg = bg_u8 / 255.0 is formed on the device)."""
         if fr.get('bg_u8') is not None:
             bg = np.ascontiguousarray(fr['bg_u8'], np.uint8)
-            pin.bg, pin.bg_u8 = None, _ptr(bg)
+            pin.bg, pin.bg_u8, pin.in_types = None, _ptr(bg), 0
         else:
-            bg = np.ascontiguousarray(fr['bg'], np.float64)
-            pin.bg, pin.bg_u8 = _ptr(bg), None
+            bg = np.asarray(fr['bg'])
+            bg = np.ascontiguousarray(bg, np.float32 if bg.dtype == np.float32 else np.float64)
+            pin.bg, pin.bg_u8, pin.in_types = _ptr(bg), None, RR_IN_BG_F32 if bg.dtype == np.float32 else 0
         depth = np.asarray(fr['depth'])
         depth = np.ascontiguousarray(depth, np.float32 if depth.dtype == np.float32 else np.float64)
         H, W = bg.shape[:2]
@@ -902,25 +908,28 @@ class RainHip:
         keep.append((bg, depth))
         return bg
 
-    def prepass_frames(self, frames, want_env=True, want_env_u8=False):
-        """frames: list of dict(bg, depth, fog=(beta_ext, beta_hg, irr_num, irr_den)).  Returns a list of
-        dict(rainy_bg[, env_xyY][, env_bgr_u8])."""
+    def prepass_frames(self, frames, want_env=True, want_env_u8=False, out_dtype=np.float64):
+        """frames: list of dict(bg | bg_u8, depth, fog=(beta_ext, beta_hg, irr_num, irr_den)).  Returns a list of
+        dict(rainy_bg[, env_xyY][, env_bgr_u8]); out_dtype float32: rr_prepass_out.out_types (the float64 results rounded once)."""
         n = len(frames)
         pin = (rr_prepass_in * n)()
         pout = (rr_prepass_out * n)()
         keep, outs = [], []
+        out_dtype = np.dtype(out_dtype)
+        assert out_dtype in (np.dtype(np.float32), np.dtype(np.float64))
         We = self._check(self.lib.rr_envmap_width(self.h), 'rr_envmap_width') if (want_env or want_env_u8) else 0
         for k, fr in enumerate(frames):
             bg = self._fill_prepass(pin[k], fr, keep)
             H, W = bg.shape[:2]
-            o = dict(rainy_bg=np.zeros((H, W, 3), np.float64))
+            o = dict(rainy_bg=np.zeros((H, W, 3), out_dtype))
             if want_env:
-                o['env_xyY'] = np.zeros((H, We, 3), np.float64)
+                o['env_xyY'] = np.zeros((H, We, 3), out_dtype)
             if want_env_u8:
                 o['env_bgr_u8'] = np.zeros((H, We, 3), np.uint8)
             pout[k].rainy_bg = _ptr(o['rainy_bg'])
             pout[k].env_xyY = _ptr(o.get('env_xyY'))
             pout[k].env_bgr_u8 = _ptr(o.get('env_bgr_u8'))
+            pout[k].out_types = (RR_OUT_RAINY_F32 | RR_OUT_ENV_F32) if out_dtype == np.float32 else 0
             outs.append(o)
         self._check(self.lib.rr_prepass_frames(self.h, n, pin, pout), 'rr_prepass_frames')
         return outs
@@ -946,9 +955,11 @@ class RainHip:
         self._check(self.lib.rr_prepass_frames(self.h, n, pin, pout), 'rr_prepass_frames')
         return outs
 
-    def pipeline_frames(self, frames, want_composite=False, want_rainy_bg=False, want_env_u8=False, want_mask_i32=True):
+    def pipeline_frames(self, frames, want_composite=False, want_rainy_bg=False, want_env_u8=False, want_mask_i32=True,
+                        fog_dtype=np.float64):
         """Pre-pass + hot path without a host round trip.  frames: list of dict(bg, depth, fog, omega, drops
-        [, opacity_attenuation, strategy]).  Returns what render_frames returns (+ env_bgr_u8 / fog_bg)."""
+        [, opacity_attenuation, strategy]); omega None = the resident solid angles (set_solid_angles).  Returns what
+        render_frames returns (+ env_bgr_u8 / fog_bg, the fog layer as fog_dtype: its width on the device follows)."""
         n = len(frames)
         pin = (rr_prepass_in * n)()
         pout = (rr_prepass_out * n)()
@@ -959,14 +970,14 @@ class RainHip:
         for k, fr in enumerate(frames):
             bg = self._fill_prepass(pin[k], fr, keep)
             H, W = bg.shape[:2]
-            om = np.ascontiguousarray(fr['omega'], np.float64)
-            assert om.shape == (H, We), (om.shape, (H, We))
+            om = None if fr.get('omega') is None else np.ascontiguousarray(fr['omega'], np.float64)
+            assert om is None or om.shape == (H, We), (om.shape, (H, We))
             drops = np.ascontiguousarray(fr['drops'], DROP_DTYPE)
             o = dict(image_u8=np.zeros((H, W, 3), np.uint8),
                      rainy_bg=np.zeros((H, W, 3), np.float64) if want_composite else None,
                      mask=np.zeros((H, W), np.float64), mask_i32=np.zeros((H, W), np.int32) if want_mask_i32 else None,
                      status=np.zeros(len(drops), np.int32),
-                     fog_bg=np.zeros((H, W, 3), np.float64) if want_rainy_bg else None,
+                     fog_bg=np.zeros((H, W, 3), fog_dtype) if want_rainy_bg else None,
                      env_bgr_u8=np.zeros((H, We, 3), np.uint8) if want_env_u8 else None)
             fin[k].H, fin[k].W, fin[k].He, fin[k].We = H, W, H, We
             fin[k].bg, fin[k].omega = None, _ptr(om)           # the background comes from the pre-pass input
@@ -980,6 +991,7 @@ class RainHip:
             fout[k].mask_i32 = _ptr(o['mask_i32'])
             fout[k].drop_status = _ptr(o['status']) if len(drops) else None
             pout[k].rainy_bg = _ptr(o['fog_bg'])
+            pout[k].out_types = RR_OUT_RAINY_F32 if np.dtype(fog_dtype) == np.float32 else 0
             pout[k].env_xyY = None
             pout[k].env_bgr_u8 = _ptr(o['env_bgr_u8'])
             keep.append((om, drops))

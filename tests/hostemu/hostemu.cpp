@@ -265,9 +265,13 @@ int emu_render_frame(int H, int W, int He, int We, const double* bg, const doubl
 
 // Pre-pass of one frame (fog + environment map) with the per-pixel bodies of rr_prepass.h.
 // rainy: H*W*3, env_xyY: H*We*3, env_u8: H*We*3 (We = cw + 2*(cw/2)); returns We or < 0.
-int emu_prepass(int H, int W, const double* bg, const void* depth, int depth_f64, double beta_ext, double beta_hg, double irr_num,
+// types: rrpre::PRE_* bits (element types of bg / rainy / env_xyY).  tiled: 0 = the three-kernel fog layer (k_fog_ext,
+// k_fog_h, k_fog_v), 1 = FogTile<12> the way k_fog_tile drives it (column strips x segments of seg_rows rows, 256 thread
+// roles per step, "barriers" = the ends of the loops over tid).
+int emu_prepass(int H, int W, const void* bg, const void* depth, int depth_f64, double beta_ext, double beta_hg, double irr_num,
                 double irr_den, int fog_k, const double* fog_w, int env_k, const double* env_w, int cw, int n_uniq,
-                const int32_t* uniq, const int32_t* first, double* rainy, double* env_xyY, uint8_t* env_u8) {
+                const int32_t* uniq, const int32_t* first, void* rainy, void* env_xyY, uint8_t* env_u8, int types, int tiled,
+                int seg_rows) {
   using namespace rrpre;
   Kernels kn{};
   kn.fog_k = fog_k;
@@ -280,32 +284,53 @@ int emu_prepass(int H, int W, const double* bg, const void* depth, int depth_f64
   const size_t px = (size_t)H * W, ex = (size_t)H * g.We;
   std::vector<double> fext(px), tmpF(px), tmpL(px * 3), mean(3), etmp(ex * 3);
   std::vector<uint32_t> epack(ex);
-  PreScratch sc{fext.data(), tmpF.data(), tmpL.data(), nullptr, mean.data(), epack.data(), etmp.data()};
-  PreFrame F{bg, depth, rainy, env_xyY, env_u8, beta_ext, beta_hg, irr_num, irr_den, depth_f64, 0};
+  std::vector<uint8_t> r8(px * 3);
+  PreScratch sc{fext.data(), tmpF.data(), tmpL.data(), r8.data(), nullptr, mean.data(), epack.data(), etmp.data()};
+  PreFrame F{bg, depth, rainy, env_xyY, env_u8, r8.data(), beta_ext, beta_hg, irr_num, irr_den, depth_f64, types};
   for (int c = 0; c < 3; c++) {         // k_fog_sum / k_fog_mean (sum order differs from the device's tree: ~1e-16)
     double s = 0;
-    for (size_t p = 0; p < px; p++) s += (irr_num * bg[p * 3 + c]) / irr_den;
+    for (size_t p = 0; p < px; p++) s += (irr_num * load_unit(bg, types, (int64_t)(p * 3 + c))) / irr_den;
     mean[c] = s / (double)px;
   }
-  for (size_t p = 0; p < px; p++) fog_ext_px(F, 0, H, W, sc, (int64_t)p);
-  {                                     // k_fog_h: staged row segments (LDS on the device)
-    const int half = fog_k / 2, pitch = FOG_SEG + KMAX - 1;
-    std::vector<double> S(4 * pitch);
-    for (int y = 0; y < H; y++)
-      for (int x0 = 0; x0 < W; x0 += FOG_SEG) {
-        const int nseg = (W - x0 < FOG_SEG ? W - x0 : FOG_SEG);
-        for (int i = 0; i < nseg + 2 * half; i++) fog_stage_px(F, 0, H, W, kn, sc, y, x0, i, S.data(), pitch);
-        for (int t = 0; t < nseg; t++) {
-          double o[4];
-          fog_h_taps(S.data(), pitch, half + t, kn, depth_f64, o);
-          fog_h_store(0, H, W, sc, y, x0 + t, o);
+  if (tiled) {
+    if (fog_k != 25 || seg_rows <= 0 || seg_rows % 8) return -2;
+    using T = FogTile<12>;
+    std::vector<double> S(T::RB * 4 * T::PITCH), ring(T::RING * 4 * T::TC);
+    double k3[3];
+    for (int c = 0; c < 3; c++) k3[c] = beta_hg * mean[c];
+    for (int ys = 0; ys < H; ys += seg_rows)
+      for (int x0 = 0; x0 < W; x0 += T::TC) {
+        const int ye = ys + seg_rows < H ? ys + seg_rows : H, hs = ys - 12;
+        const int n_iter = (ye - ys + T::RB - 1) / T::RB + T::NB - 1;
+        for (int k = 0; k < n_iter; k++) {
+          for (int i = 0; i < T::RB * T::PITCH; i++) {
+            const int64_t p = T::stage_src(H, W, x0, hs, k, i);
+            T::stage_put(F, k3, i, depth_f64 ? ((const double*)depth)[p] : 0.0, depth_f64 ? 0.0f : ((const float*)depth)[p], S.data());
+          }
+          for (int tid = 0; tid < 256; tid++) T::hpass(kn, depth_f64, k, tid, S.data(), ring.data());
+          const int m = k - (T::NB - 1);
+          if (m < 0) continue;
+          double a[256][T::VR];
+          for (int tid = 0; tid < 256; tid++) T::vtaps(kn, depth_f64, m, tid, ring.data(), a[tid]);
+          for (int tid = 0; tid < 256; tid++) T::vstore(F, H, W, x0, ys, ye, m, tid, a[tid], a[(tid & ~63) | (tid & 15)]);
         }
       }
-  }
-  if (fog_k == 25) {                    // k_fog_v_strip<12>
-    for (int y0 = 0; y0 < H; y0 += FOG_RV)
-      for (int x = 0; x < W; x++) fog_v_strip<12>(F, 0, H, W, kn, sc, y0, x);
   } else {
+    for (size_t p = 0; p < px; p++) fog_ext_px(F, 0, H, W, sc, (int64_t)p);
+    {                                     // k_fog_h: staged row segments (LDS on the device)
+      const int half = fog_k / 2, pitch = FOG_SEG + KMAX - 1;
+      std::vector<double> S(4 * pitch);
+      for (int y = 0; y < H; y++)
+        for (int x0 = 0; x0 < W; x0 += FOG_SEG) {
+          const int nseg = (W - x0 < FOG_SEG ? W - x0 : FOG_SEG);
+          for (int i = 0; i < nseg + 2 * half; i++) fog_stage_px(F, 0, H, W, kn, sc, y, x0, i, S.data(), pitch);
+          for (int t = 0; t < nseg; t++) {
+            double o[4];
+            fog_h_taps(S.data(), pitch, half + t, kn, depth_f64, o);
+            fog_h_store(0, H, W, sc, y, x0 + t, o);
+          }
+        }
+    }
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) fog_v_px(F, 0, H, W, kn, sc, y, x);
   }

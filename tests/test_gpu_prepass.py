@@ -155,3 +155,78 @@ def test_byte_background_equals_float_background(tmp_path, built):
     pb = rh.prepass_frames([dict(bg_u8=bg8, depth=depth, fog=consts)])[0]
     assert np.array_equal(pa['rainy_bg'], pb['rainy_bg']) and np.array_equal(pa['env_xyY'], pb['env_xyY'])
     rh.close()
+
+
+def test_narrow_types_are_the_float64_results_rounded_once(built):
+    """rr_prepass_in.in_types / rr_prepass_out.out_types: a uint8 (or float32) image in, float32 fog layer and xyY map out.
+    The kernels compute in float64 whatever the types, so the narrow outputs are astype(float32) of the wide ones, bit for
+    bit, and the uint8 map (gathered from the float64 fog layer's bytes) does not move."""
+    for H, W in ((96, 160), (375, 1242)):
+        rh = h.hb.RainHip(0)
+        consts, We = _setup(rh, H, W, 50)
+        bg, depth = _scene(H, W, 3)
+        bg8 = (bg * 255).astype(np.uint8)
+        wide = rh.prepass_frames([dict(bg=bg8 / 255.0, depth=depth, fog=consts)], want_env=True, want_env_u8=True)[0]
+        nar = rh.prepass_frames([dict(bg_u8=bg8, depth=depth, fog=consts)], want_env=True, want_env_u8=True, out_dtype=np.float32)[0]
+        assert nar['rainy_bg'].dtype == np.float32 and nar['env_xyY'].dtype == np.float32
+        assert np.array_equal(nar['rainy_bg'], wide['rainy_bg'].astype(np.float32))
+        assert np.array_equal(nar['env_xyY'], wide['env_xyY'].astype(np.float32))
+        assert np.array_equal(nar['env_bgr_u8'], wide['env_bgr_u8'])
+        b32 = bg.astype(np.float32)
+        f32 = rh.prepass_frames([dict(bg=b32, depth=depth, fog=consts)], want_env=True, want_env_u8=True, out_dtype=np.float32)[0]
+        ref = rh.prepass_frames([dict(bg=b32.astype(np.float64), depth=depth, fog=consts)], want_env=True, want_env_u8=True)[0]
+        assert np.array_equal(f32['rainy_bg'], ref['rainy_bg'].astype(np.float32)) and np.array_equal(f32['env_bgr_u8'], ref['env_bgr_u8'])
+        rh.close()
+
+
+def test_pipeline_hands_float32_arrays_to_the_hot_path(tmp_path, built):
+    """rr_pipeline_*: the fog layer and the xyY map go from the pre-pass to the hot path as float32 (RR_OPT_PIPELINE_F32, the
+    default; the byte image stays bytes).  Against the float64 hand-over: the same mask, statuses and uint8 map, bit for bit
+    (none of them reads those arrays); the image within 1 LSB; a float32 download of the fog layer = the float64 one rounded."""
+    H, W = 96, 160
+    sc = h.Scene(tmp_path, H, W, 150, seed0=31)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    consts, We = _setup(rh, H, W, 25)
+    rh.set_solid_angles(sc.omega)
+    bg, depth = _scene(H, W, 31)
+    bg8 = (bg * 255).astype(np.uint8)
+    fr = dict(bg_u8=bg8, depth=depth, fog=consts, omega=None, drops=sc.product_drops(0))
+    nar = rh.pipeline_frames([fr], want_env_u8=True)[0]                                           # nothing downloaded: float32 inside
+    nar_dl = rh.pipeline_frames([fr], want_env_u8=True, want_rainy_bg=True, fog_dtype=np.float32)[0]
+    rh.set_option(h.hb.RR_OPT_PIPELINE_F32, 0)
+    wide = rh.pipeline_frames([fr], want_env_u8=True, want_rainy_bg=True)[0]
+    for o in (nar, nar_dl):
+        for k in ('mask', 'mask_i32', 'status', 'env_bgr_u8'):
+            assert np.array_equal(o[k], wide[k]), k
+        assert np.abs(o['image_u8'].astype(int) - wide['image_u8'].astype(int)).max() <= 1
+    assert np.array_equal(nar['image_u8'], nar_dl['image_u8'])
+    assert nar_dl['fog_bg'].dtype == np.float32 and np.array_equal(nar_dl['fog_bg'], wide['fog_bg'].astype(np.float32))
+    # and against the all-numpy pipeline
+    rainy = op.fog_rain_layer(bg8 / 255.0, depth, 25, FNUM, EXPO, GAIN)
+    env = op.env_to_xyY(op.generate_env_map(rainy, FOCAL))
+    textures, ratio = sc.oracle_db()
+    ref = orc.render_frame(bg8 / 255.0, rainy, env, sc.omega, sc.oracle_streaks(0), textures, ratio, sc.ocam, frame_seed=0)
+    assert np.array_equal(nar['mask'], ref['mask'])
+    assert np.abs(nar['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+    rh.close()
+
+
+def test_other_tap_counts_take_the_three_kernel_form(built):
+    """rr_set_prepass_kernels with a tap count other than the reference's 25: k_fog_ext / k_fog_h / k_fog_v (float64 planes in
+    HBM) instead of the one-kernel tile.  Against the host build of the same functions (tests/hostemu): equal up to the two
+    libms' expf."""
+    import test_prepass_hostemu as tp
+    H, W = 75, 131
+    bg, depth = _scene(H, W, 4)
+    rh = h.hb.RainHip(0)
+    fog = fogmod.FogRain(rain_intensity=50, focal=FOCAL, f_number=FNUM, angle=90, exposure=EXPO, camera_gain=GAIN)
+    rh.set_prepass_kernels(op.gaussian_kernel(9, 9), op.gaussian_kernel(15, 0))
+    rh.set_envmap_geometry(H, W, *envmod.EnvironmentMapGenerator(FOCAL, W, H).device_tables(H, W))
+    for dt in (np.float64, np.float32):
+        o = rh.prepass_frames([dict(bg=bg, depth=depth, fog=fog.constants())], want_env=True, want_env_u8=True, out_dtype=dt)[0]
+        want = tp.emu_prepass(bg, depth, 50, tiled=0, fog_taps=9, narrow=dt is np.float32)
+        assert np.abs(o['rainy_bg'].astype(np.float64) - want[0]).max() < 3e-7
+        assert np.abs(o['env_bgr_u8'].astype(int) - want[2].astype(int)).max() <= 1
+    rh.close()
