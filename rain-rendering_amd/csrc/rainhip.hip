@@ -3420,6 +3420,9 @@ struct rr_ctx {
   // pre-pass (fog + environment map)
   rrpre::Kernels pk{};
   bool have_pk = false, have_eg = false;
+  std::vector<int32_t> eg_src_host;  // the geometry's cell -> source pixel table (host copy: rrpre::build_env_need)
+  uint8_t* d_need_h = nullptr;
+  int need_half = -1;
   rrpre::EnvGeom eg{};
   int32_t *d_esrc = nullptr, *d_etop = nullptr, *d_ebot = nullptr;
   rrpre::PreScratch psc{};
@@ -4079,6 +4082,16 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     hipLaunchKernelGGL(rrpre::k_fog_v, dim3((W + 255) / 256, H, n), dim3(256), 0, s, ctx->d_pre, H, W, ctx->pk, sc);
   }
   if (want_env) {
+    if (ctx->need_half != ctx->pk.env_k / 2) {           // once per geometry and tap count
+      std::vector<uint8_t> need((size_t)H * ctx->eg.We);
+      rrpre::build_env_need(H, ctx->eg.cw, ctx->pk.env_k / 2, ctx->eg_src_host.data(), need.data());
+      HIPCHK(hipStreamSynchronize(s));
+      int rc = dev_alloc(ctx, ctx->d_need_h, need.size());
+      if (rc) return rc;
+      HIPCHK(hipMemcpy(ctx->d_need_h, need.data(), need.size(), hipMemcpyHostToDevice));
+      ctx->eg.need_h = ctx->d_need_h;
+      ctx->need_half = ctx->pk.env_k / 2;
+    }
     const rrpre::EnvGeom g = ctx->eg;
     const dim3 grid((g.We + 255) / 256, H, n);
     {
@@ -4301,6 +4314,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->psc.tmpF);
   hipFree(ctx->psc.tmpL);
   hipFree(ctx->psc.r8);
+  hipFree(ctx->d_need_h);
   hipFree(ctx->psc.part);
   hipFree(ctx->psc.mean);
   hipFree(ctx->psc.epack);
@@ -5196,6 +5210,9 @@ int rr_set_envmap_geometry(rr_ctx* ctx, int32_t H, int32_t W, int32_t cw, int32_
   ctx->eg.src = ctx->d_esrc;
   ctx->eg.top_row = ctx->d_etop;
   ctx->eg.bot_row = ctx->d_ebot;
+  ctx->eg.need_h = nullptr;
+  ctx->eg_src_host = std::move(src);
+  ctx->need_half = -1;                 // the map of needed horizontal sums is made with the first batch (it depends on the tap count)
   ctx->have_eg = true;
   return RR_OK;
 }

@@ -65,6 +65,8 @@ struct EnvGeom {
   const int32_t* src;               // [H*cw] source pixel index (r*W+c) or -1
   const int32_t* top_row;           // [cw] row the unfilled pixels of the top half copy
   const int32_t* bot_row;           // [cw] same, bottom half
+  const uint8_t* need_h;            // [H*We] 1 where the horizontal blur's value is read by some unfilled cell's vertical blur
+                                    // (build_env_need; a function of the geometry and the tap count); null = every cell
 };
 
 struct PreScratch {                 // [frame][...]
@@ -310,13 +312,17 @@ RRP_HD uint32_t bg8_px(const PreFrame& F, int32_t p) {      // (background*255).
   return b | (g << 8) | (r << 16);
 }
 
+// the cylinder column a map column shows: centre strip, mirrored left and right sides
+RRP_HD int env_col(int cw, int x) {
+  const int lw = cw / 2, We = cw + 2 * lw, wr = cw - cw / 2;
+  if (x >= We - wr) return cw - 1 - (x - (We - wr));          // right side (written last, :806-811)
+  if (x < lw) return lw - 1 - x;                               // left side (:798-804)
+  return x - lw;                                               // centre (:792-796)
+}
+
 // cylindrical un-projection, column fills, mirrored sides                    bad_weather.py:742-813
 RRP_HD void env_build_px(const PreFrame& F, int f, const EnvGeom& g, const PreScratch& sc, int r, int x) {
-  const int wr = g.cw - g.cw / 2;
-  int c;
-  if (x >= g.We - wr) c = g.cw - 1 - (x - (g.We - wr));      // right side (written last, :806-811)
-  else if (x < g.lw) c = g.lw - 1 - x;                         // left side (:798-804)
-  else c = x - g.lw;                                           // centre (:792-796)
+  const int c = env_col(g.cw, x);
   const int32_t s = g.src[(int64_t)r * g.cw + c];
   const int half = g.H / 2;
   uint32_t v = 0;
@@ -334,7 +340,10 @@ RRP_HD void env_build_px(const PreFrame& F, int f, const EnvGeom& g, const PreSc
   sc.epack[((int64_t)f * g.H + r) * g.We + x] = v;
 }
 
+// (only the cells without a source pixel are blurred (:815-817) -- a tenth of the map -- and which they are is a property of
+// the geometry: the horizontal sums nobody reads are not made)
 RRP_HD void env_h_px(int f, const EnvGeom& g, const Kernels& kn, const PreScratch& sc, int r, int x) {
+  if (g.need_h && !g.need_h[(int64_t)r * g.We + x]) return;
   const uint32_t* row = sc.epack + ((int64_t)f * g.H + r) * g.We;
   const int half = kn.env_k / 2;
   const uint32_t v0 = row[x];
@@ -345,26 +354,27 @@ RRP_HD void env_h_px(int f, const EnvGeom& g, const Kernels& kn, const PreScratc
     const double w = kn.env_w[half + j];
     for (int c = 0; c < 3; c++) a[c] += ((double)((va >> (8 * c)) & 255u) + (double)((vb >> (8 * c)) & 255u)) * w;
   }
-  double* o = sc.etmp + (((int64_t)f * g.H + r) * g.We + x) * 3;
+  const int64_t plane = (int64_t)g.H * g.We;                    // planar [channel][row][column]: the vertical pass reads columns
+  double* o = sc.etmp + (int64_t)f * 3 * plane + (int64_t)r * g.We + x;
   o[0] = a[0];
-  o[1] = a[1];
-  o[2] = a[2];
+  o[plane] = a[1];
+  o[2 * plane] = a[2];
 }
 
 // vertical pass where the map is unfilled (:815-817), /255, RGB -> xyY (my_utils.py:55-68), nan -> 0
-RRP_HD void env_v_px(const PreFrame& F, int f, const EnvGeom& g, const Kernels& kn, const PreScratch& sc, int r, int x) {
-  const int64_t fb = (int64_t)f * g.H * g.We, q = (int64_t)r * g.We + x;
-  const uint32_t v0 = sc.epack[fb + q];
-  double bgr[3];
+// the three bytes of map cell (r, x), as doubles 0..255
+RRP_HD void env_v_bgr(int f, const EnvGeom& g, const Kernels& kn, const PreScratch& sc, int r, int x, double bgr[3]) {
+  const int64_t plane = (int64_t)g.H * g.We, q = (int64_t)r * g.We + x;
+  const uint32_t v0 = sc.epack[(int64_t)f * plane + q];
   if ((v0 >> 24) == 0) {
     const int half = kn.env_k / 2;
-    const double* t = sc.etmp + fb * 3;
+    const double* t = sc.etmp + (int64_t)f * 3 * plane;
     double a[3];
-    for (int c = 0; c < 3; c++) a[c] = t[q * 3 + c] * kn.env_w[half];
+    for (int c = 0; c < 3; c++) a[c] = t[c * plane + q] * kn.env_w[half];
     for (int j = -half; j < 0; j++) {
       const int64_t qa = (int64_t)reflect101(r + j, g.H) * g.We + x, qb = (int64_t)reflect101(r - j, g.H) * g.We + x;
       const double w = kn.env_w[half + j];
-      for (int c = 0; c < 3; c++) a[c] += (t[qa * 3 + c] + t[qb * 3 + c]) * w;
+      for (int c = 0; c < 3; c++) a[c] += (t[c * plane + qa] + t[c * plane + qb]) * w;
     }
     for (int c = 0; c < 3; c++) {
       double v = rint(a[c]);
@@ -373,32 +383,57 @@ RRP_HD void env_v_px(const PreFrame& F, int f, const EnvGeom& g, const Kernels& 
   } else {
     for (int c = 0; c < 3; c++) bgr[c] = (double)((v0 >> (8 * c)) & 255u);
   }
+}
+// RGB / 255 -> xyY (my_utils.py:55-68), nan -> 0
+RRP_HD void env_xyY_of(double R, double G, double B, double out[3]) {
+  const double X = (R * 0.49000 + G * 0.17697 + B * 0.00000) / 0.17697;
+  const double Y = (R * 0.31000 + G * 0.81240 + B * 0.01000) / 0.17697;
+  const double Z = (R * 0.20000 + G * 0.01063 + B * 0.99000) / 0.17697;
+  const double s = X + Y + Z;
+  double xx = X / s, yy = Y / s;
+  if (xx != xx) xx = 0.0;
+  if (yy != yy) yy = 0.0;
+  out[0] = xx;
+  out[1] = yy;
+  out[2] = Y;
+}
+RRP_HD void env_v_out(const PreFrame& F, const EnvGeom& g, int r, int x, const double bgr[3]) {
+  const int64_t q = (int64_t)r * g.We + x;
   if (F.env_u8) {
     F.env_u8[q * 3 + 0] = (uint8_t)bgr[0];
     F.env_u8[q * 3 + 1] = (uint8_t)bgr[1];
     F.env_u8[q * 3 + 2] = (uint8_t)bgr[2];
   }
   if (F.env_xyY) {
-    const double R = bgr[2] / 255.0, G = bgr[1] / 255.0, B = bgr[0] / 255.0;
-    const double X = (R * 0.49000 + G * 0.17697 + B * 0.00000) / 0.17697;
-    const double Y = (R * 0.31000 + G * 0.81240 + B * 0.01000) / 0.17697;
-    const double Z = (R * 0.20000 + G * 0.01063 + B * 0.99000) / 0.17697;
-    const double s = X + Y + Z;
-    double xx = X / s, yy = Y / s;
-    if (xx != xx) xx = 0.0;
-    if (yy != yy) yy = 0.0;
+    double o3[3];
+    env_xyY_of(bgr[2] / 255.0, bgr[1] / 255.0, bgr[0] / 255.0, o3);
     if (F.types & PRE_ENV_F32) {
       float* o = (float*)F.env_xyY + q * 3;
-      o[0] = (float)xx;
-      o[1] = (float)yy;
-      o[2] = (float)Y;
+      o[0] = (float)o3[0];
+      o[1] = (float)o3[1];
+      o[2] = (float)o3[2];
     } else {
       double* o = (double*)F.env_xyY + q * 3;
-      o[0] = xx;
-      o[1] = yy;
-      o[2] = Y;
+      o[0] = o3[0];
+      o[1] = o3[1];
+      o[2] = o3[2];
     }
   }
+}
+RRP_HD void env_v_px(const PreFrame& F, int f, const EnvGeom& g, const Kernels& kn, const PreScratch& sc, int r, int x) {
+  double bgr[3];
+  env_v_bgr(f, g, kn, sc, r, x, bgr);
+  env_v_out(F, g, r, x, bgr);
+}
+
+// Host: the cells of the horizontal blur that some unfilled cell's vertical blur (half taps up and down, reflected rows) reads.
+inline void build_env_need(int H, int cw, int half, const int32_t* src, uint8_t* need) {
+  const int We = cw + 2 * (cw / 2);
+  for (int64_t i = 0; i < (int64_t)H * We; i++) need[i] = 0;
+  for (int r = 0; r < H; r++)
+    for (int x = 0; x < We; x++)
+      if (src[(int64_t)r * cw + env_col(cw, x)] < 0)
+        for (int j = -half; j <= half; j++) need[(int64_t)reflect101(r + j, H) * We + x] = 1;
 }
 
 // Host side of rr_set_envmap_geometry: cell -> source-pixel table and the column-fill rows of
@@ -509,9 +544,38 @@ __global__ void __launch_bounds__(256) k_env_h(EnvGeom g, Kernels kn, PreScratch
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x < g.We) env_h_px(blockIdx.z, g, kn, sc, blockIdx.y, x);
 }
+// 256 cells of a map row per workgroup.  The cell bytes are whole numbers 0..255, so value / 255.0 comes from a table of the 256
+// quotients (one IEEE division per thread instead of three per cell: the same bits); the three values of a cell go through
+// LDS so that the workgroup stores its 768 values as consecutive elements.
+// (r04, measured and dropped: a thread per column and 8 rows with the column's 22 horizontal sums in registers -- 0.70 ms per
+// 64 KITTI frames against 0.47: a tenth of the cells is blurred at all, and the row-strided stores cost more than the shared
+// window saves; and 4 rows per workgroup with one table of quotients -- 0.52 against 0.47.)
 __global__ void __launch_bounds__(256) k_env_v(const PreFrame* fr, EnvGeom g, Kernels kn, PreScratch sc) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x < g.We) env_v_px(fr[blockIdx.z], blockIdx.z, g, kn, sc, blockIdx.y, x);
+  __shared__ double s_unit[256];
+  __shared__ double s_val[768];
+  __shared__ uint8_t s_byte[768];
+  const int f = blockIdx.z, r = blockIdx.y, x0 = blockIdx.x * 256, tid = threadIdx.x, x = x0 + tid;
+  const PreFrame F = fr[f];
+  s_unit[tid] = (double)tid / 255.0;
+  double bgr[3] = {0.0, 0.0, 0.0};
+  if (x < g.We) env_v_bgr(f, g, kn, sc, r, x, bgr);
+  __syncthreads();
+  for (int c = 0; c < 3; c++) s_byte[tid * 3 + c] = (uint8_t)bgr[c];
+  if (F.env_xyY) {
+    double o3[3];
+    env_xyY_of(s_unit[(int)bgr[2] & 255], s_unit[(int)bgr[1] & 255], s_unit[(int)bgr[0] & 255], o3);
+    for (int c = 0; c < 3; c++) s_val[tid * 3 + c] = o3[c];
+  }
+  __syncthreads();
+  const int n = 3 * min(256, g.We - x0);
+  const int64_t base = ((int64_t)r * g.We + x0) * 3;
+  for (int i = tid; i < n; i += 256) {
+    if (F.env_u8) F.env_u8[base + i] = s_byte[i];
+    if (F.env_xyY) {
+      if (F.types & PRE_ENV_F32) ((float*)F.env_xyY)[base + i] = (float)s_val[i];
+      else ((double*)F.env_xyY)[base + i] = s_val[i];
+    }
+  }
 }
 #endif
 

@@ -280,9 +280,11 @@ int emu_prepass(int H, int W, const void* bg, const void* depth, int depth_f64, 
   for (int i = 0; i < env_k; i++) kn.env_w[i] = env_w[i];
   std::vector<int32_t> src((size_t)H * cw), top(cw), bot(cw);
   if (!build_env_tables(H, W, cw, n_uniq, uniq, first, src.data(), top.data(), bot.data())) return -1;
-  EnvGeom g{H, W, cw, cw / 2, cw + 2 * (cw / 2), src.data(), top.data(), bot.data()};
+  std::vector<uint8_t> need((size_t)H * (cw + 2 * (cw / 2)));
+  build_env_need(H, cw, env_k / 2, src.data(), need.data());
+  EnvGeom g{H, W, cw, cw / 2, cw + 2 * (cw / 2), src.data(), top.data(), bot.data(), tiled ? need.data() : nullptr};
   const size_t px = (size_t)H * W, ex = (size_t)H * g.We;
-  std::vector<double> fext(px), tmpF(px), tmpL(px * 3), mean(3), etmp(ex * 3);
+  std::vector<double> fext(px), tmpF(px), tmpL(px * 3), mean(3), etmp(ex * 3, -1.0e300);     // (a sum read without having been made would show)
   std::vector<uint32_t> epack(ex);
   std::vector<uint8_t> r8(px * 3);
   PreScratch sc{fext.data(), tmpF.data(), tmpL.data(), r8.data(), nullptr, mean.data(), epack.data(), etmp.data()};
