@@ -370,8 +370,14 @@ enum {
                                      * every drop.  The spans are the same: identical results. */
   RR_OPT_COMPOSITE_WAVES = 11,      /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
                                      * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
-  RR_OPT_PIPELINE_F32 = 13          /* 1 (default): rr_pipeline_* hand the fog layer and the xyY map from the pre-pass to the hot path
+  RR_OPT_PIPELINE_F32 = 13,         /* 1 (default): rr_pipeline_* hand the fog layer and the xyY map from the pre-pass to the hot path
                                      * as float32 unless pre_out asks for float64 copies (see rr_pipeline_frames); 0: float64 */
+  RR_OPT_WILD_PIXELS = 14           /* 1: rainy_bg may hold values outside [0, 1] (a third party's array; the fog pre-pass ends with a
+                                     * clip, so its output never does).  The reference blends a drop over its whole padded rectangle
+                                     * (bad_weather.py:429-446): where the drop image is zero that is np.clip(pixel, 0, 1), a no-op for
+                                     * values in [0, 1] -- the library never visits the pad.  With this option the pads are tracked
+                                     * (two int32 per pixel, one more kernel) and a pixel some pad reaches before any tile is clipped
+                                     * first: the reference's result for any input.  Default 0.  Not with rr_ext_tile. */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -172,6 +172,9 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   const int64_t* tex_poff;          // [texture] offset of its padded copy (a multiple of 16)
   int32_t* fov_list;                // [frame][drops] drops k_fov_dda leaves to k_fov_spans (wrapping polygons, float64 decisions)
   int32_t* fov_list_n;              // [frame] their number
+  uint8_t* blended;                 // [frame][drop] 1: the drop is composited (k_colour)
+  int32_t* pad_first;               // RR_OPT_WILD_PIXELS only (else null), [frame][H*W]: lowest index of a composited drop whose padded
+  int32_t* eff_first;               //   rectangle covers the pixel OUTSIDE / INSIDE the tile the compositor blends (k_pad_visits)
   uint32_t* spans;                  // [frame][Hp / 4][Dp][4] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4,
                                     // Dp = drops + 1 rounded up to 8; slot `drops` of every quad stays all zeros: what a drop
                                     // without a polygon reads
@@ -1261,10 +1264,12 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
   rec.K[0] = rec.K[1] = rec.K[2] = 0;
   rec.zdist = fr.depth ? fabs(as_global((const double*)fr.drops[i].wps)[2]) : 0.0;
   int status = p.status;
+  bool blended = false;
   const int n = sc.npts[gi];
   if (n == 0) status = RR_DROP_FOV_FAIL;
   if (n < 0) {                         // rendering_strategy 'white': gray tile, no colour
     if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
+      blended = true;
       rec.K[0] = rec.K[1] = rec.K[2] = 1.0;
       rec.x0 = p.vis_x0;
       rec.y0 = p.vis_y0;
@@ -1291,6 +1296,7 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     }
     if (!any) status = RR_DROP_EMPTY_FOV;
     if (status == RR_DROP_OK && sc.sizes[gi] > 0) {
+      blended = true;
       colour_from_sums(S, sumW, sumY / sumW, rec.K);
       if (p.r1 > 0) {                  // finished effective tile written by the blur kernels
         const int fx0 = p.vis_x0 - p.crop_x + (p.shift - p.r2), fy0 = p.vis_y0 - p.crop_y + (p.shift - p.r1);   // its frame position
@@ -1341,6 +1347,7 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     sc.comp32[gi] = r32;
   }
   sc.bbox[gi] = make_int4(rec.x0, rec.y0, rec.x1, rec.y1);
+  sc.blended[gi] = blended ? 1 : 0;
   if (fr.colour_out) {
     const global_ptr<double> ko = as_global(fr.colour_out) + (int64_t)i * 3;
     ko[0] = rec.K[0]; ko[1] = rec.K[1]; ko[2] = rec.K[2];
@@ -2567,6 +2574,31 @@ __global__ __launch_bounds__(256) void k_bin(const FrameDesc* frames, Dims dm, i
   if (t == 0) sc.ccount[(int64_t)f * nct + ct] = total;
 }
 
+// RR_OPT_WILD_PIXELS: the reference blends a drop over its whole PADDED rectangle (bad_weather.py:429-446); outside the tile the
+// compositor reads, the drop image is exact zeros and the blend reduces to np.clip(pixel, 0, 1) -- a no-op for the values in
+// [0, 1] that rainy_bg holds by contract, which is why the compositor never visits the pad.  For a caller whose rainy_bg holds
+// anything, that clip is the one thing the pad does, and only where it comes BEFORE the pixel's first real blend (every blend
+// ends with a clip, and a clip of a clipped value changes nothing).  One wave per drop marks, per pixel, the lowest index of a
+// composited drop that covers it with its pad (pad_first) / with its tile (eff_first); the compositors clip a pixel's input
+// value first where pad_first < eff_first.
+__global__ __launch_bounds__(256) void k_pad_visits(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= frames[f].n_drops) return;
+  const int64_t gi = (int64_t)f * max_drops + i;
+  if (!sc.blended[gi]) return;
+  const DropPlan& p = sc.plan[gi];
+  const int4 e = sc.bbox[gi];
+  const int w = p.vis_w, n = p.vis_w * p.vis_h;
+  const int64_t base = (int64_t)f * dm.H * dm.W;
+  for (int k = lane; k < n; k += 64) {
+    const int y = p.vis_y0 + k / w, x = p.vis_x0 + k % w;
+    if (x < 0 || y < 0 || x >= dm.W || y >= dm.H) continue;
+    const bool in_tile = x >= e.x && x < e.z && y >= e.y && y < e.w;
+    atomicMin((in_tile ? sc.eff_first : sc.pad_first) + base + (int64_t)y * dm.W + x, i);
+  }
+}
+__device__ inline double clip_unit_np(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }   // np.clip(v, 0, 1): a NaN stays
+
 __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
                                                    int tiles_y, int ctiles_x, int nct, Scratch sc) {
   const int f = blockIdx.y;
@@ -2597,6 +2629,11 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
       load_px3(fr.bg, bg_kind(fr), pix, b);
       sum_b = (b[0] + b[1]) + b[2];
     }
+  }
+  if (sc.pad_first && live) {        // RR_OPT_WILD_PIXELS: some drop's all-zero pad reaches this pixel before any tile does
+    const int64_t q = (int64_t)f * dm.H * dm.W + pix;
+    if (sc.pad_first[q] < sc.eff_first[q])
+      for (int k = 0; k < 3; k++) c[k] = clip_unit_np(c[k]);
   }
   // depth-occlusion option (default off; not part of the reference's output): a drop farther than the scene at a
   // pixel is hidden there
@@ -2808,6 +2845,13 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
         load_px3(fr.bg, bk, pix1, b);
         sum_b += (b[0] + b[1]) + b[2];
       }
+    }
+    if (sc.pad_first) {              // RR_OPT_WILD_PIXELS (see k_pad_visits)
+      const int64_t q = (int64_t)f * dm.H * dm.W;
+      if (live0 && sc.pad_first[q + pix0] < sc.eff_first[q + pix0])
+        for (int k = 0; k < 3; k++) in0[k] = clip_unit_np(in0[k]);
+      if (live1 && sc.pad_first[q + pix1] < sc.eff_first[q + pix1])
+        for (int k = 0; k < 3; k++) in1[k] = clip_unit_np(in1[k]);
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) ok_px = ok_px && in0[k] >= 0.0 && in0[k] <= 1.0 && in1[k] >= 0.0 && in1[k] <= 1.0;
@@ -3352,6 +3396,9 @@ struct rr_ctx {
   uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
   int64_t* d_tex_poff = nullptr;
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
+  bool wild_pixels = false;          // RR_OPT_WILD_PIXELS: rainy_bg may hold values outside [0, 1] (k_pad_visits)
+  int32_t *d_pad_first = nullptr, *d_eff_first = nullptr;
+  size_t pad_cap = 0;                // elements of each
   bool pipe_f32 = true;              // RR_OPT_PIPELINE_F32: float32 hand-over from the pre-pass to the hot path inside rr_pipeline_*
   bool fov_dda = true;               // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (k_fov_dda)
   int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
@@ -3606,6 +3653,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     ctx->scratch_general = general;
     ctx->scratch_hp = Hp;
     if ((rc = dev_alloc(ctx, ctx->sc.bbox, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.blended, fd))) return rc;
     {
       const size_t nct = (size_t)((dm.W + CTILE - 1) / CTILE) * ((dm.H + CTILE - 1) / CTILE);
       if ((rc = dev_alloc(ctx, ctx->sc.clist, fd * nct))) return rc;
@@ -3927,6 +3975,25 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   {
     ProfScope ps(ctx, s, "k_bin");
     hipLaunchKernelGGL(k_bin, dim3(nct, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctiles_x, nct, sc);
+  }
+  sc.pad_first = sc.eff_first = nullptr;
+  bool wild = ctx->wild_pixels;
+  for (int f = 0; f < n; f++) wild = wild && !in[f].ext;
+  if (wild) {
+    const size_t need = (size_t)n * dm.H * dm.W;
+    if (need > ctx->pad_cap) {
+      HIPCHK(hipDeviceSynchronize());
+      int rc;
+      if ((rc = dev_alloc(ctx, ctx->d_pad_first, need))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->d_eff_first, need))) return rc;
+      ctx->pad_cap = need;
+    }
+    sc.pad_first = ctx->d_pad_first;
+    sc.eff_first = ctx->d_eff_first;
+    HIPCHK(hipMemsetAsync(sc.pad_first, 0x7f, sizeof(int32_t) * need, s));
+    HIPCHK(hipMemsetAsync(sc.eff_first, 0x7f, sizeof(int32_t) * need, s));
+    ProfScope ps(ctx, s, "k_pad_visits");
+    hipLaunchKernelGGL(k_pad_visits, dim3((D + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
   }
   // float colours unless a caller wants the float64 composite (or RR_OPT_COMPOSITE_F64): see k_composite32
   int ntiles_c = ntiles;
@@ -4251,6 +4318,9 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.wtab_big);
   hipFree(ctx->sc.spans);
   hipFree(ctx->sc.bbox);
+  hipFree(ctx->sc.blended);
+  hipFree(ctx->d_pad_first);
+  hipFree(ctx->d_eff_first);
   hipFree(ctx->sc.clist);
   hipFree(ctx->sc.ccount);
   hipFree(ctx->sc.prefix);
@@ -5251,6 +5321,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
     case RR_OPT_FOV_DDA: ctx->fov_dda = value != 0; return RR_OK;
     case RR_OPT_PIPELINE_F32: ctx->pipe_f32 = value != 0; return RR_OK;
+    case RR_OPT_WILD_PIXELS: ctx->wild_pixels = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_WAVES:
       if (value != 0 && value != 6 && value != 7 && value != 8) break;
       ctx->comp_waves = value ? value : 6;

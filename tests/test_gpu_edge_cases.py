@@ -132,7 +132,8 @@ def test_nan_pixels_follow_the_reference_blend(tmp_path, built):
     """The compositor's short blend (exact reciprocal division, hardware clamp) is only taken where every factor is tame;
     a NaN in rainy_bg must survive every blend the way np.clip keeps it (bad_weather.py:443-446) -- the literal
     blend_pixel, compared with its host build value for value.  (Values outside [0, 1] are outside the contract of
-    rainy_bg: the reference would clip them wherever a drop's all-zero pad covers them, the library never visits the pad.)"""
+    rainy_bg: the reference clips them wherever a drop's all-zero pad covers them; the library visits the pads only with
+    RR_OPT_WILD_PIXELS -- the next test.)"""
     H2, W2 = 96, 160
     sc = h.Scene(tmp_path, H2, W2, 400, seed0=77)
     bg, env = sc.frame_inputs(0)
@@ -160,4 +161,52 @@ def test_nan_pixels_follow_the_reference_blend(tmp_path, built):
         assert np.array_equal(out32['mask'], emu['mask']) and np.array_equal(out32['status'], out['status'])
         if rb is bg:
             assert np.abs(out32['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+    rh.close()
+
+
+def test_wild_pixel_values_follow_the_reference_blend(tmp_path, built):
+    """rainy_bg from a third party may hold anything.  The reference blends a drop over its whole padded rectangle
+    (bad_weather.py:429-446): over the all-zero pad that is np.clip(pixel, 0, 1) -- +-inf, 1e60, -3, 7.5 are clipped wherever
+    some drop's pad covers them, before or without any real blend.  With RR_OPT_WILD_PIXELS the library tracks the pads
+    (k_pad_visits) and reproduces it: the float64 composite against the host build of the same blend, which walks every
+    drop's padded rectangle the way the reference does -- value for value, NaN for NaN."""
+    H2, W2 = 96, 160
+    sc = h.Scene(tmp_path, H2, W2, 400, seed0=77)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    rng = np.random.RandomState(6)
+    ys, xs, cs = rng.randint(0, H2, 1500), rng.randint(0, W2, 1500), rng.randint(0, 3, 1500)
+    any_vals = np.array([np.nan, np.inf, -np.inf, 1e60, -1e60, -3.0, 7.5, 1e-300, -0.0, 1.0])
+    fin_vals = np.array([-3.0, 7.5, 1.25, -1e-9, 1.0 + 1e-12, 1e-300, -0.0, 1.0])
+    wild_any, wild_fin = bg.copy(), bg.copy()
+    wild_any[ys, xs, cs] = any_vals[rng.randint(0, len(any_vals), 1500)]
+    wild_fin[ys, xs, cs] = fin_vals[rng.randint(0, len(fin_vals), 1500)]
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    rh.set_option(h.hb.RR_OPT_WILD_PIXELS, 1)
+    differs_without = False
+    for rb in (bg, wild_fin, wild_any):
+        fr = dict(bg=bg, rainy_bg=rb, env_xyY=env, omega=sc.omega, drops=drops)
+        out = rh.render_frames([fr])[0]
+        emu = h.emu_render(sc, bg, rb, env, drops)
+        assert np.array_equal(out['mask'], emu['mask']) and np.array_equal(out['status'], emu['status'][:len(out['status'])])
+        a, b = out['rainy_bg'], emu['rainy_bg']
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(np.isinf(a), np.isinf(b)) and np.array_equal(a[np.isinf(a)], b[np.isinf(b)])
+        fin = np.isfinite(b)
+        # colour constants come from FOV sums added in another order: 1e-9 (relative, for the 1e60s no pad reaches)
+        assert (np.abs(a[fin] - b[fin]) <= 1e-9 * np.maximum(1.0, np.abs(b[fin]))).all()
+        out32 = rh.render_frames([fr], want_composite=False)[0]                  # the float-colour compositor clips first too
+        assert np.array_equal(out32['mask'], emu['mask'])
+        if rb is not wild_any:                                                    # (an inf or NaN left in the composite poisons the mean shift)
+            assert np.abs(out['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+            assert np.abs(out32['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+        if rb is wild_fin:                                                        # the pads matter: without the option the composite differs
+            rh.set_option(h.hb.RR_OPT_WILD_PIXELS, 0)
+            plain = rh.render_frames([fr])[0]
+            rh.set_option(h.hb.RR_OPT_WILD_PIXELS, 1)
+            differs_without = np.abs(plain['rainy_bg'] - b).max() > 0.1
+            assert np.array_equal(plain['mask'], emu['mask'])
+    assert differs_without
     rh.close()
