@@ -372,12 +372,18 @@ enum {
                                      * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
   RR_OPT_PIPELINE_F32 = 13,         /* 1 (default): rr_pipeline_* hand the fog layer and the xyY map from the pre-pass to the hot path
                                      * as float32 unless pre_out asks for float64 copies (see rr_pipeline_frames); 0: float64 */
-  RR_OPT_WILD_PIXELS = 14           /* 1: rainy_bg may hold values outside [0, 1] (a third party's array; the fog pre-pass ends with a
+  RR_OPT_WILD_PIXELS = 14,          /* 1: rainy_bg may hold values outside [0, 1] (a third party's array; the fog pre-pass ends with a
                                      * clip, so its output never does).  The reference blends a drop over its whole padded rectangle
                                      * (bad_weather.py:429-446): where the drop image is zero that is np.clip(pixel, 0, 1), a no-op for
                                      * values in [0, 1] -- the library never visits the pad.  With this option the pads are tracked
                                      * (two int32 per pixel, one more kernel) and a pixel some pad reaches before any tile is clipped
                                      * first: the reference's result for any input.  Default 0.  Not with rr_ext_tile. */
+  RR_OPT_PNG_DEFLATE = 15           /* 1: rr_frame_out.rainy_png / mask_png are entropy-coded on the device.  The buffer (same size) then
+                                     * starts with 16 bytes {'R','R','Z','1', uint32 length L, 0, 0} followed by the L bytes of the file's
+                                     * zlib stream (one dynamic-Huffman deflate block per 32 KB of scanlines; any inflate reads it):
+                                     * the IDAT payload as it is.  A file whose stream would not fit its buffer (incompressible pixels)
+                                     * keeps its scanlines (first byte = a filter type, never 'R').  rr_png_write_scanlines /
+                                     * rr_io_write_frames take either form.  Default 0 (scanlines). */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

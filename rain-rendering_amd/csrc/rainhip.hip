@@ -34,6 +34,7 @@
 #include "rainhip.h"
 #include "rr_device.h"
 #include "rr_prepass.h"
+#include "rr_deflate.h"
 #include "rr_particles.h"
 
 using namespace rr;
@@ -3145,6 +3146,99 @@ __global__ __launch_bounds__(256) void k_png_mask(const FrameDesc* frames, Dims 
   for (int k = 0; k < 4; k++) o[k] = (uint8_t)(((c >> (8 * k)) & 0xffu) - ((l >> (8 * k)) & 0xffu));
 }
 
+// RR_OPT_PNG_DEFLATE: the scanlines of both files become the zlib streams of their IDAT chunks on the device (rr_deflate.h).
+// k_pngz_blocks: one workgroup per 32 KB block of a file's scanlines (grid: blocks x files; file = 2 * frame + {image, mask});
+// its working set (the block, its compressed form, the code tables: 77 KB) is dynamic LDS.  The compressed block goes to the
+// block's slot in the scratch, its size and Adler-32 sums to its record.
+__global__ __launch_bounds__(256) void k_pngz_blocks(const FrameDesc* frames, int64_t n_bytes, int nb, uint8_t* slots, rrz::BlockMeta* meta) {
+  using namespace rrz;
+  extern __shared__ __attribute__((aligned(16))) uint8_t pngz_lds[];
+  BlockState& S = *reinterpret_cast<BlockState*>(pngz_lds);
+  const int file = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+  const FrameDesc& fr = frames[file >> 1];
+  const uint8_t* rows = (file & 1) ? fr.png_mask : fr.png_image;
+  if (!rows) return;
+  const int64_t at = (int64_t)k * BLOCK;
+  const int len = (int)(n_bytes - at < BLOCK ? n_bytes - at : BLOCK), last = k == nb - 1;
+  const uint8_t* src = rows + at;
+  if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+    const global_ptr<const uint32_t> w = as_global(reinterpret_cast<const uint32_t*>(src));
+    uint32_t* d = reinterpret_cast<uint32_t*>(S.in);
+    for (int i = tid; i < (len >> 2); i += NT) d[i] = w[i];
+    for (int i = (len & ~3) + tid; i < len; i += NT) S.in[i] = src[i];
+  } else {
+    for (int i = tid; i < len; i += NT) S.in[i] = src[i];
+  }
+  __syncthreads();
+  p0_init(S, tid, len, last);
+  __syncthreads();
+  p1_hist(S, tid);
+  __syncthreads();
+  p2_rank(S, tid);
+  __syncthreads();
+  p3_tree(S, tid);
+  __syncthreads();
+  p4_depth(S, tid);
+  __syncthreads();
+  p5_limit(S, tid);
+  __syncthreads();
+  p6_assign(S, tid);
+  __syncthreads();
+  p7_codes(S, tid);
+  __syncthreads();
+  p8_header(S, tid);
+  __syncthreads();
+  p9_hdr_bits(S, tid);
+  for (int st = 0; st < 8; st++) {
+    __syncthreads();
+    scan_step(S, tid, st);
+  }
+  __syncthreads();
+  p9_hdr_emit(S, tid);
+  __syncthreads();
+  p10_span_bits(S, tid);
+  for (int st = 0; st < 8; st++) {
+    __syncthreads();
+    scan_step(S, tid, st);
+  }
+  __syncthreads();
+  p10_decide(S, tid);
+  __syncthreads();
+  p11_clear(S, tid);
+  __syncthreads();
+  p12_emit(S, tid);
+  __syncthreads();
+  p12b_stored_bytes(S, tid);
+  p13_meta(S, tid, meta + (int64_t)file * nb + k);
+  __syncthreads();
+  uint32_t* dst = reinterpret_cast<uint32_t*>(slots + ((int64_t)file * nb + k) * SLOT_BYTES);
+  const int words = (int)((S.bytes + 3) >> 2);
+  for (int i = tid; i < words; i += NT) dst[i] = S.out[i];
+}
+// k_pngz_pack: the blocks of a file behind each other in the file's scanline buffer, in front of them the 16-byte header and
+// the zlib header, behind them the Adler-32 -- if all of it fits the buffer; else the scanlines stay (every workgroup of the
+// file reaches the same verdict from the same records).
+__global__ __launch_bounds__(256) void k_pngz_pack(const FrameDesc* frames, int64_t n_bytes, int nb, const uint8_t* slots, const rrz::BlockMeta* meta) {
+  using namespace rrz;
+  const int file = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+  const FrameDesc& fr = frames[file >> 1];
+  uint8_t* rows = (file & 1) ? fr.png_mask : fr.png_image;
+  if (!rows) return;
+  const BlockMeta* fm = meta + (int64_t)file * nb;
+  __shared__ int64_t s_total, s_off;
+  if (tid == 0) {
+    s_total = stream_bytes(fm, nb);
+    s_off = block_offset(fm, k);
+  }
+  __syncthreads();
+  if (PNGZ_HEADER + s_total > n_bytes) return;
+  const uint8_t* src = slots + ((int64_t)file * nb + k) * SLOT_BYTES;
+  uint8_t* dst = rows + s_off;
+  const int bytes = (int)fm[k].bytes;
+  for (int i = tid; i < bytes; i += NT) dst[i] = src[i];
+  if (k == 0 && tid == 0) pack_ends(rows, fm, nb);
+}
+
 
 // ---------------------------------------------------------------------------
 // drop tables born on the device: particle generator + packer (BASELINE configs[4])
@@ -3396,6 +3490,11 @@ struct rr_ctx {
   uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
   int64_t* d_tex_poff = nullptr;
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
+  bool png_deflate = false;          // RR_OPT_PNG_DEFLATE: the PNG outputs hold zlib streams (rr_deflate.h)
+  uint8_t* d_pngz_slots = nullptr;
+  rrz::BlockMeta* d_pngz_meta = nullptr;
+  size_t pngz_cap = 0;               // blocks
+  bool pngz_attr = false;
   bool wild_pixels = false;          // RR_OPT_WILD_PIXELS: rainy_bg may hold values outside [0, 1] (k_pad_visits)
   int32_t *d_pad_first = nullptr, *d_eff_first = nullptr;
   size_t pad_cap = 0;                // elements of each
@@ -4027,6 +4126,25 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     hipLaunchKernelGGL(k_png_image, grid, dim3(256), 0, s, ctx->d_frames, dm);
     if (ctx->have_lut) hipLaunchKernelGGL(k_png_mask, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->d_lut, sc);
   }
+  if (want_png && ctx->png_deflate) {
+    const int64_t n_bytes = (int64_t)dm.H * (1 + 4 * (int64_t)dm.W);
+    const int nb = (int)rrz::blocks_of(n_bytes);
+    const size_t need = (size_t)2 * n * nb;
+    if (need > ctx->pngz_cap) {
+      HIPCHK(hipDeviceSynchronize());
+      int rc;
+      if ((rc = dev_alloc(ctx, ctx->d_pngz_slots, need * rrz::SLOT_BYTES))) return rc;
+      if ((rc = dev_alloc(ctx, ctx->d_pngz_meta, need))) return rc;
+      ctx->pngz_cap = need;
+    }
+    if (!ctx->pngz_attr) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pngz_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(rrz::BlockState)));
+      ctx->pngz_attr = true;
+    }
+    ProfScope ps(ctx, s, "k_pngz");
+    hipLaunchKernelGGL(k_pngz_blocks, dim3(nb, 2 * n), dim3(256), sizeof(rrz::BlockState), s, ctx->d_frames, n_bytes, nb, ctx->d_pngz_slots, ctx->d_pngz_meta);
+    hipLaunchKernelGGL(k_pngz_pack, dim3(nb, 2 * n), dim3(256), 0, s, ctx->d_frames, n_bytes, nb, ctx->d_pngz_slots, ctx->d_pngz_meta);
+  }
   HIPCHK(hipGetLastError());
   ctx->last_n = n;
   return RR_OK;
@@ -4320,6 +4438,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.bbox);
   hipFree(ctx->sc.blended);
   hipFree(ctx->d_pad_first);
+  hipFree(ctx->d_pngz_slots);
+  hipFree(ctx->d_pngz_meta);
   hipFree(ctx->d_eff_first);
   hipFree(ctx->sc.clist);
   hipFree(ctx->sc.ccount);
@@ -5322,6 +5442,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_FOV_DDA: ctx->fov_dda = value != 0; return RR_OK;
     case RR_OPT_PIPELINE_F32: ctx->pipe_f32 = value != 0; return RR_OK;
     case RR_OPT_WILD_PIXELS: ctx->wild_pixels = value != 0; return RR_OK;
+    case RR_OPT_PNG_DEFLATE: ctx->png_deflate = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_WAVES:
       if (value != 0 && value != 6 && value != 7 && value != 8) break;
       ctx->comp_waves = value ? value : 6;

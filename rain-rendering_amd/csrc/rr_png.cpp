@@ -1243,7 +1243,13 @@ static int rr_png_write_scanlines_impl(const char* path, const uint8_t* rows, in
   ByteBuf& zf = es->z;
   const uint8_t* zdata = nullptr;
   uLongf clen = 0;
-  if (strategy == 3) {
+  if (memcmp(rows, "RRZ1", 4) == 0) {               // entropy-coded on the device (RR_OPT_PNG_DEFLATE): the IDAT payload as it is
+    uint32_t L;                                       // (a scanline buffer starts with a filter type 0..4)
+    memcpy(&L, rows + 4, 4);
+    if ((uLong)L + 16 > n || L < 6) return RR_E_PARSE;
+    zdata = rows + 16;
+    clen = L;
+  } else if (strategy == 3) {
     fast_deflate(rows, (size_t)n, zf, es->runs);
     zdata = zf.data();
     clen = (uLongf)zf.len;

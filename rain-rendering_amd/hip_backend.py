@@ -27,6 +27,7 @@ RR_OPT_COMPOSITE_WAVES = 11
 RR_OPT_FOV_DDA = 12
 RR_OPT_PIPELINE_F32 = 13
 RR_OPT_WILD_PIXELS = 14
+RR_OPT_PNG_DEFLATE = 15
 RR_OUT_RAINY_F32, RR_OUT_ENV_F32 = 1, 2                 # rr_prepass_out.out_types
 RR_IN_BG_F32, RR_IN_BG_U8, RR_IN_ENV_F32, RR_IN_RAINY_F32, RR_IN_RAINY_U8 = 1, 2, 4, 8, 16      # rr_frame_in.in_types
 

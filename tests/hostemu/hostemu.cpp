@@ -12,6 +12,7 @@
 
 #include "rr_device.h"
 #include "rr_prepass.h"
+#include "rr_deflate.h"
 #include "rr_particles.h"
 
 using namespace rr;
@@ -466,6 +467,51 @@ int emu_generate_drops(const rr_sim_frame* sf, int H, int W, const double* dgrid
     }
   }
   return 0;
+}
+
+
+// The device's PNG entropy coder (rr_deflate.h: k_pngz_blocks + k_pngz_pack) on the host, thread roles in loops.  rows: n bytes of
+// filtered scanlines; dst: n bytes.  Returns the length of the zlib stream that now lies behind the 16-byte header in dst, or 0
+// if header + stream do not fit n bytes (dst is then a copy of rows, as the device leaves the scanlines in place).
+int64_t emu_pngz(const uint8_t* rows, int64_t n, uint8_t* dst) {
+  using namespace rrz;
+  const int nb = (int)blocks_of(n);
+  std::vector<BlockMeta> meta(nb);
+  std::vector<uint8_t> slots((size_t)nb * SLOT_BYTES);
+  std::vector<BlockState> st(1);
+  BlockState& S = st[0];
+  for (int k = 0; k < nb; k++) {
+    const int len = (int)(n - (int64_t)k * BLOCK < BLOCK ? n - (int64_t)k * BLOCK : BLOCK), last = k == nb - 1;
+    memcpy(S.in, rows + (int64_t)k * BLOCK, len);
+#define ALL(call) for (int tid = 0; tid < NT; tid++) call
+    ALL(p0_init(S, tid, len, last));
+    ALL(p1_hist(S, tid));
+    ALL(p2_rank(S, tid));
+    ALL(p3_tree(S, tid));
+    ALL(p4_depth(S, tid));
+    ALL(p5_limit(S, tid));
+    ALL(p6_assign(S, tid));
+    ALL(p7_codes(S, tid));
+    ALL(p8_header(S, tid));
+    ALL(p9_hdr_bits(S, tid));
+    for (int s_ = 0; s_ < 8; s_++) ALL(scan_step(S, tid, s_));
+    ALL(p9_hdr_emit(S, tid));
+    ALL(p10_span_bits(S, tid));
+    for (int s_ = 0; s_ < 8; s_++) ALL(scan_step(S, tid, s_));
+    ALL(p10_decide(S, tid));
+    ALL(p11_clear(S, tid));
+    ALL(p12_emit(S, tid));
+    ALL(p12b_stored_bytes(S, tid));
+    ALL(p13_meta(S, tid, &meta[k]));
+#undef ALL
+    memcpy(slots.data() + (size_t)k * SLOT_BYTES, S.out, S.bytes);
+  }
+  memcpy(dst, rows, (size_t)n);
+  const int64_t total = stream_bytes(meta.data(), nb);
+  if (PNGZ_HEADER + total > n) return 0;
+  for (int k = 0; k < nb; k++) memcpy(dst + block_offset(meta.data(), k), slots.data() + (size_t)k * SLOT_BYTES, meta[k].bytes);
+  pack_ends(dst, meta.data(), nb);
+  return total;
 }
 
 }  // extern "C"

@@ -185,6 +185,55 @@ def test_png_scanlines_from_the_device(tmp_path, built):
         rh.close()
 
 
+@pytest.mark.parametrize("H,W", [(96, 160), (375, 1242)])
+def test_png_streams_entropy_coded_on_the_device(tmp_path, built, H, W):
+    """RR_OPT_PNG_DEFLATE: rainy_png / mask_png come back as the files' zlib streams (k_pngz_blocks / k_pngz_pack, rr_deflate.h)
+    behind a 16-byte header.  zlib inflates them to the very scanlines the plain mode delivers (Adler-32 included), the
+    writer takes the stream as the IDAT payload, and the files decode to the same pixels."""
+    import importlib
+    import zlib
+    from PIL import Image
+    imgops = importlib.import_module('rain-rendering_amd.common.imgops')
+    sc = h.Scene(tmp_path, H, W, 150, n_frames=3, seed0=31)
+    rh = h.hb.RainHip(0)
+    try:
+        rh.set_streak_db(sc.db.streaks_light)
+        rh.set_camera(sc.cam)
+        rh.set_colormap(imgops.viridis_lut())
+        consts, We = tp._setup(rh, H, W, 25)
+        frames = []
+        for i in range(3):
+            bg, depth = tp._scene(H, W, 31 + i)
+            frames.append(dict(bg_u8=(bg * 255).astype(np.uint8), depth=depth, fog=consts, omega=sc.omega,
+                               drops=sc.product_drops(i) if i != 1 else np.zeros(0, h.hb.DROP_DTYPE)))   # frame 1: empty mask
+        n = H * (1 + 4 * W)
+
+        def run():
+            outs = [dict(image_u8=np.zeros((H, W, 3), np.uint8), mask=np.zeros((H, W)), rainy_png=np.zeros(n, np.uint8),
+                         mask_png=np.zeros(n, np.uint8)) for _ in frames]
+            rh.pipeline_submit(0, frames, outs)
+            assert rh.pipeline_wait(0)
+            return outs
+        plain = run()
+        rh.set_option(h.hb.RR_OPT_PNG_DEFLATE, 1)
+        coded = run()
+        rh.set_option(h.hb.RR_OPT_PNG_DEFLATE, 0)
+        for i, (a, b) in enumerate(zip(plain, coded)):
+            assert np.array_equal(a['image_u8'], b['image_u8']) and np.array_equal(a['mask'], b['mask'])
+            for key in ('rainy_png', 'mask_png'):
+                z = b[key]
+                assert z[:4].tobytes() == b'RRZ1', (i, key)
+                L = int(z[4:8].view(np.uint32)[0])
+                assert 16 + L <= n and L < (0.9 if key == 'rainy_png' else 0.6) * n
+                assert zlib.decompress(z[16:16 + L].tobytes()) == a[key].tobytes()
+                pa, pb = str(tmp_path / ('a%d%s.png' % (i, key))), str(tmp_path / ('b%d%s.png' % (i, key)))
+                imgops.png_from_scanlines(pa, a[key], W, H)
+                imgops.png_from_scanlines(pb, z, W, H)
+                assert np.array_equal(np.array(Image.open(pa)), np.array(Image.open(pb)))
+    finally:
+        rh.close()
+
+
 @pytest.mark.parametrize("copy_kernels", [0, 1])
 def test_packed_prepared_batches_and_resident_solid_angles(tmp_path, built, copy_kernels):
     """What the driver does batch after batch: the frames of a slot back to back in ONE page-locked block per array
