@@ -644,6 +644,39 @@ def main():
                                  "arithmetic); not in value" % nb_pre, float64_in_and_out=pre_leg(False))
         depth_h = np.ascontiguousarray(depth_t.cpu().numpy())
 
+        # --- the two output files as PNG payloads made on the device: Sub-filtered scanlines (k_png_rows), and -- RR_OPT_PNG_DEFLATE --
+        #     their zlib streams (k_pngz: csrc/rr_deflate.h); what the drop-in driver downloads instead of pixels.  Not in `value`.
+        nb_png = min(batch.n, 64)
+        pfin, pfout, _ = batch.chunk(hb, 0, nb_png)
+        row_bytes = H * (1 + 4 * W)
+        t_png = torch.zeros((nb_png, 2, row_bytes), dtype=torch.uint8, device=dev)
+        for k in range(nb_png):
+            pfout[k].rainy_png, pfout[k].mask_png = t_png[k, 0].data_ptr(), t_png[k, 1].data_ptr()
+        rh.set_colormap(imgops.viridis_lut())
+        png_leg = {}
+        for mode, name in ((0, "scanlines"), (1, "zlib_streams")):
+            rh.set_option(hb.RR_OPT_PNG_DEFLATE, mode)
+
+            def run_png():
+                rh.render_frames_device(pfin, pfout, nb_png, stream)
+            run_png()
+            assert rh.synchronize()
+            rh.profile_reset()
+            rh.profile(True)
+            t = timed(torch, dist, 1, dev, run_png, args.steps)
+            rh.profile(False)
+            ks = {k: v[1] / args.steps for k, v in rh.profile_read().items() if k.startswith('k_png')}
+            png_leg[name] = {"ms_per_call": 1e3 * t / args.steps, "kernels_ms_per_call": ks}
+            if mode == 1:
+                heads = t_png[:, :, :8].cpu().numpy()
+                coded = (heads[:, :, :4].reshape(-1, 4) == np.frombuffer(b'RRZ1', np.uint8)).all(1)
+                lens = heads[:, :, 4:8].copy().view(np.uint32).reshape(nb_png, 2)
+                png_leg[name]["files_coded"] = int(coded.sum())
+                png_leg[name]["mean_stream_bytes"] = {"image": float(lens[:, 0].mean()), "mask": float(lens[:, 1].mean()), "scanlines": row_bytes}
+        rh.set_option(hb.RR_OPT_PNG_DEFLATE, 0)
+        extras["png_on_device"] = dict(png_leg, what="%d frames per call with both PNG payloads as outputs; not in value" % nb_png)
+        del t_png, pfin, pfout
+
         # --- host-inclusive (SURVEY 8d's rate: "including H2D of frame inputs and D2H of outputs"): pinned buffers, three
         #     slots in flight (upload | kernels | download overlap); PCIe up (u8 image + f32 depth + drop table), fog +
         #     environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask) -----------------------

@@ -491,6 +491,9 @@ class Generator:
         if (H, env_w) not in cache:
             cache[(H, env_w)] = solid_angle.get_solid_angles(np.empty((H, env_w, 0)))               # generator.py:410
         hip.set_solid_angles(cache[(H, env_w)])
+        # both output files leave the device as the zlib streams of their IDAT chunks (RR_OPT_PNG_DEFLATE, csrc/rr_deflate.h):
+        # the encode stage below only frames chunks and checksums them.  RAIN_PNG_DEVICE=0: scanlines, deflated by the host.
+        hip.set_option(hip_backend.RR_OPT_PNG_DEFLATE, 0 if os.environ.get('RAIN_PNG_DEVICE', '1') == '0' else 1)
         # capacity of a frame's drop table: every streak of its simulated frame (the frame filter can only remove some), but
         # never more than the 2 ** 16 the reference allows AFTER the filter (generator.py:424): a simulated frame with more
         # streaks than that is fine as long as fewer land inside the image -- checked on the filtered counts below
@@ -712,6 +715,7 @@ class Generator:
                 state['env_w'] = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
                 state['omega'] = solid_angle.get_solid_angles(np.empty((H, state['env_w'], 0)))    # generator.py:410
                 hip.set_solid_angles(state['omega'])            # resident on the device: not uploaded with every batch
+                hip.set_option(hip_backend.RR_OPT_PNG_DEFLATE, 0 if os.environ.get('RAIN_PNG_DEVICE', '1') == '0' else 1)   # (see _run_batches_native)
                 state['geom'] = (H, W)
             bg0, dep0 = valid[0][1][0], valid[0][1][1]
             need_drops = max(len(ld[2]) for _, ld in valid)

@@ -1033,6 +1033,15 @@ __device__ inline float wave_incl_scan_f32(float v) {
   v += dpp_move_f32<0x143, 0xc>(v);
   return v;
 }
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {              // (zeros shift in: bound_ctrl)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
+  return v;
+}
 __device__ inline float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 template <int DPT, int EMAX, bool E32>
@@ -3147,32 +3156,77 @@ __global__ __launch_bounds__(256) void k_png_mask(const FrameDesc* frames, Dims 
 }
 
 // RR_OPT_PNG_DEFLATE: the scanlines of both files become the zlib streams of their IDAT chunks on the device (rr_deflate.h).
-// k_pngz_blocks: one workgroup per 32 KB block of a file's scanlines (grid: blocks x files; file = 2 * frame + {image, mask});
-// its working set (the block, its compressed form, the code tables: 77 KB) is dynamic LDS.  The compressed block goes to the
+// k_pngz_blocks: one workgroup of 512 threads per 32 KB block of a file's scanlines (grid: blocks x files; file = 2 * frame +
+// {image, mask}); its working set (the block, its compressed form, the code tables: 76 KB) is dynamic LDS.  The compressed block goes to the
 // block's slot in the scratch, its size and Adler-32 sums to its record.
-__global__ __launch_bounds__(256) void k_pngz_blocks(const FrameDesc* frames, int64_t n_bytes, int nb, uint8_t* slots, rrz::BlockMeta* meta) {
+__global__ __launch_bounds__(512) void k_pngz_blocks(const FrameDesc* frames, int64_t n_bytes, int nb, uint8_t* slots, rrz::BlockMeta* meta) {
   using namespace rrz;
   extern __shared__ __attribute__((aligned(16))) uint8_t pngz_lds[];
   BlockState& S = *reinterpret_cast<BlockState*>(pngz_lds);
-  const int file = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+  const int file = blockIdx.y, k = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const FrameDesc& fr = frames[file >> 1];
   const uint8_t* rows = (file & 1) ? fr.png_mask : fr.png_image;
   if (!rows) return;
   const int64_t at = (int64_t)k * BLOCK;
   const int len = (int)(n_bytes - at < BLOCK ? n_bytes - at : BLOCK), last = k == nb - 1;
   const uint8_t* src = rows + at;
-  if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
-    const global_ptr<const uint32_t> w = as_global(reinterpret_cast<const uint32_t*>(src));
-    uint32_t* d = reinterpret_cast<uint32_t*>(S.in);
-    for (int i = tid; i < (len >> 2); i += NT) d[i] = w[i];
-    for (int i = (len & ~3) + tid; i < len; i += NT) S.in[i] = src[i];
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {       // (the library's own staging: 16-byte loads, all of a thread's in flight)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const global_ptr<const u32x4> w = as_global(reinterpret_cast<const u32x4*>(src));
+    u32x4* d = reinterpret_cast<u32x4*>(S.in);
+    const int nq = len >> 4;
+    u32x4 v[BLOCK / 16 / NT];
+#pragma unroll
+    for (int u = 0; u < BLOCK / 16 / NT; u++) v[u] = tid + u * NT < nq ? w[tid + u * NT] : u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < BLOCK / 16 / NT; u++)
+      if (tid + u * NT < nq) d[tid + u * NT] = v[u];
+    for (int i = (len & ~15) + tid; i < len; i += NT) S.in[i] = src[i];
   } else {
     for (int i = tid; i < len; i += NT) S.in[i] = src[i];
   }
-  __syncthreads();
   p0_init(S, tid, len, last);
   __syncthreads();
-  p1_hist(S, tid);
+  // The lane's token of a chunk of the wave's quarter: lane_token from the ballot of the sequence starts.  A lane's byte and its
+  // predecessor are two independent LDS reads, and the NEXT chunk's pair is in flight while this chunk's token is worked out.
+  const int w0 = wave * WAVE_BYTES;
+  const int n_chunks = len > w0 ? (min(len - w0, WAVE_BYTES) + CHUNK - 1) / CHUNK : 0;
+  auto fetch = [&](int c, int& b, int& prev) {
+    const int idx = w0 + c * CHUNK + lane;
+    b = (int)S.in[idx < len ? idx : 0];
+    prev = (int)S.in[lane > 0 && idx <= len ? idx - 1 : 0];
+  };
+  auto token_of = [&](int c, int b, int prev, bool& valid) {
+    const int nv = min(CHUNK, len - (w0 + c * CHUNK));
+    valid = lane < nv;
+    const unsigned long long start = __ballot(valid && (lane == 0 || b != prev));
+    return lane_token(lane, nv, start, b);
+  };
+  {                                                      // (two chunks per iteration: two independent chains for the scheduler)
+    uint32_t s1 = 0, s2 = 0;
+    int b0 = 0, p0 = 0, b1 = 0, p1 = 0, c0n = 0, p0n = 0, c1n = 0, p1n = 0;
+    if (n_chunks > 0) fetch(0, b0, p0);
+    if (n_chunks > 1) fetch(1, b1, p1);
+    for (int c = 0; c < n_chunks; c += 2) {
+      if (c + 2 < n_chunks) fetch(c + 2, c0n, p0n);
+      if (c + 3 < n_chunks) fetch(c + 3, c1n, p1n);
+      bool v0, v1 = false;
+      const Tok t0 = token_of(c, b0, p0, v0);
+      Tok t1{0, 0};
+      if (c + 1 < n_chunks) t1 = token_of(c + 1, b1, p1, v1);
+      p1_lane(S, wave, t0, b0, len - (w0 + c * CHUNK + lane), v0, s1, s2);
+      p1_lane(S, wave, t1, b1, len - (w0 + (c + 1) * CHUNK + lane), v1, s1, s2);
+      b0 = c0n; p0 = p0n; b1 = c1n; p1 = p1n;
+    }
+    s1 = wave_incl_scan_u32(s1);                         // the wave's sums: lane 63 of the inclusive scans
+    s2 = wave_incl_scan_u32(s2 % 65521u);
+    if (lane == 63) {
+      S.ad1[wave] = s1;
+      S.ad2[wave] = s2;
+    }
+  }
+  __syncthreads();
+  p1_sum(S, tid);
   __syncthreads();
   p2_rank(S, tid);
   __syncthreads();
@@ -3185,29 +3239,36 @@ __global__ __launch_bounds__(256) void k_pngz_blocks(const FrameDesc* frames, in
   p6_assign(S, tid);
   __syncthreads();
   p7_codes(S, tid);
-  __syncthreads();
-  p8_header(S, tid);
-  __syncthreads();
-  p9_hdr_bits(S, tid);
-  for (int st = 0; st < 8; st++) {
-    __syncthreads();
-    scan_step(S, tid, st);
-  }
-  __syncthreads();
-  p9_hdr_emit(S, tid);
-  __syncthreads();
-  p10_span_bits(S, tid);
-  for (int st = 0; st < 8; st++) {
-    __syncthreads();
-    scan_step(S, tid, st);
-  }
+  p8_header(S, tid);                                     // (reads the lengths only)
+  p9_wave_bits(S, tid);
   __syncthreads();
   p10_decide(S, tid);
   __syncthreads();
   p11_clear(S, tid);
   __syncthreads();
-  p12_emit(S, tid);
-  __syncthreads();
+  p12_ends(S, tid);
+  if (!S.stored) {
+    uint32_t base = wave_base(S, wave);
+    int b0 = 0, p0 = 0, b1 = 0, p1 = 0, c0n = 0, p0n = 0, c1n = 0, p1n = 0;
+    if (n_chunks > 0) fetch(0, b0, p0);
+    if (n_chunks > 1) fetch(1, b1, p1);
+    for (int c = 0; c < n_chunks; c += 2) {
+      if (c + 2 < n_chunks) fetch(c + 2, c0n, p0n);
+      if (c + 3 < n_chunks) fetch(c + 3, c1n, p1n);
+      bool v0, v1 = false;
+      const Tok t0 = token_of(c, b0, p0, v0);
+      Tok t1{0, 0};
+      if (c + 1 < n_chunks) t1 = token_of(c + 1, b1, p1, v1);
+      uint32_t n0, n1;
+      const uint32_t code0 = token_code(S, t0, n0), code1 = token_code(S, t1, n1);
+      const uint32_t i0 = wave_incl_scan_u32(n0), i1 = wave_incl_scan_u32(n1);
+      const uint32_t base1 = base + (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+      if (n0) or_bits(S.out, base + i0 - n0, code0, n0);
+      if (n1) or_bits(S.out, base1 + i1 - n1, code1, n1);
+      base = base1 + (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+      b0 = c0n; p0 = p0n; b1 = c1n; p1 = p1n;
+    }
+  }
   p12b_stored_bytes(S, tid);
   p13_meta(S, tid, meta + (int64_t)file * nb + k);
   __syncthreads();
@@ -3235,7 +3296,7 @@ __global__ __launch_bounds__(256) void k_pngz_pack(const FrameDesc* frames, int6
   const uint8_t* src = slots + ((int64_t)file * nb + k) * SLOT_BYTES;
   uint8_t* dst = rows + s_off;
   const int bytes = (int)fm[k].bytes;
-  for (int i = tid; i < bytes; i += NT) dst[i] = src[i];
+  for (int i = tid; i < bytes; i += 256) dst[i] = src[i];
   if (k == 0 && tid == 0) pack_ends(rows, fm, nb);
 }
 
@@ -4142,7 +4203,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ctx->pngz_attr = true;
     }
     ProfScope ps(ctx, s, "k_pngz");
-    hipLaunchKernelGGL(k_pngz_blocks, dim3(nb, 2 * n), dim3(256), sizeof(rrz::BlockState), s, ctx->d_frames, n_bytes, nb, ctx->d_pngz_slots, ctx->d_pngz_meta);
+    hipLaunchKernelGGL(k_pngz_blocks, dim3(nb, 2 * n), dim3(rrz::NT), sizeof(rrz::BlockState), s, ctx->d_frames, n_bytes, nb, ctx->d_pngz_slots, ctx->d_pngz_meta);
     hipLaunchKernelGGL(k_pngz_pack, dim3(nb, 2 * n), dim3(256), 0, s, ctx->d_frames, n_bytes, nb, ctx->d_pngz_slots, ctx->d_pngz_meta);
   }
   HIPCHK(hipGetLastError());

@@ -2,14 +2,18 @@
 // the reference saves both with plt.imsave, generator.py:466-467).
 // k_png_image / k_png_mask leave the filtered scanlines of a file in HBM: H rows of 1 + 4 W bytes.  This header turns them
 // into the zlib stream of the file's IDAT chunk, so that the host only frames chunks and computes one CRC:
-//   * the scanlines are cut into blocks of 32 KB, one workgroup of 256 threads each; a thread owns a span of 128 bytes
-//   * tokens of a span: its first byte is a literal; a byte that repeats its predecessor at least three times in a row starts
-//     a run (length 3 .. the rest of the span, distance 1), anything else is a literal -- the rule of the host encoder
-//     (rr_png.cpp fast_deflate, like zlib's Z_RLE), except that a run ends with its span, so that spans are independent
+//   * the scanlines are cut into blocks of 32 KB, one workgroup of 512 threads each; a wave owns an eighth of the block and
+//     walks it in chunks of 64 bytes, one lane per byte
+//   * tokens of a chunk: a byte that differs from its predecessor (or opens the chunk) starts a sequence of equal bytes; a
+//     sequence of four or more is its first byte as a literal and one run (length = the rest, distance 1), a shorter one is
+//     literals -- what the host encoder's rule (rr_png.cpp fast_deflate, like zlib's Z_RLE) gives inside 64 bytes.  Which
+//     token a lane emits follows from the ballot of the sequence starts by bit operations: no lane waits for another
 //   * one dynamic-Huffman deflate block per 32 KB: histogram (LDS atomics), symbols ranked by (count, symbol) in parallel,
 //     the two-queue tree construction by one thread (the only serial step: <= 286 iterations), depths, the count-based fix-up
-//     to 15 bits, canonical codes; the code lengths themselves Huffman-coded without repeat symbols
-//   * bit positions by a workgroup scan of the spans' bit counts, every span's codes OR-ed into the block's buffer in LDS
+//     to 15 bits, canonical codes; the code lengths themselves go out with a fixed 4-bit code (no repeat symbols: 144 bytes of
+//     header per block, and nothing serial to build)
+//   * bit positions: a wave's first bit from the per-wave histograms (sum of count x code length), inside the wave a running
+//     base plus the wave's prefix sum of the chunk's code lengths; every lane ORs its code into the block's buffer in LDS
 //   * a block that is not the file's last ends with an empty stored block (the "sync flush" of zlib / pigz), so every block
 //     starts on a byte boundary and the blocks of a file are simply laid behind each other (k_pngz_pack); a block whose
 //     dynamic form would be larger than its bytes is a stored block
@@ -33,7 +37,7 @@
 
 namespace rrz {
 
-constexpr int SPAN = 128, NT = 256, BLOCK = SPAN * NT;
+constexpr int NT = 512, NW = NT / 64, BLOCK = 32768, WAVE_BYTES = BLOCK / NW, CHUNK = 64;
 constexpr int NSYM = 288;            // literals 0..255, end of block 256, lengths 257..285 (286, 287 never used)
 constexpr int MAXL = 15;
 constexpr int OUT_WORDS = BLOCK / 4 + 16;
@@ -60,20 +64,19 @@ struct BlockMeta {                   // per block, in HBM: what the pack kernel 
 struct BlockState {                  // one workgroup's working set: LDS on the device
   uint8_t in[BLOCK];
   uint32_t out[OUT_WORDS];
+  uint32_t freq4[NW][NSYM / 2];      // per wave: what the wave's eighth of the block holds (its bit count follows from it);
+                                     // two 16-bit counters per word (a wave sees 4096 bytes)
   uint32_t freq[NSYM];
   uint32_t w[2 * NSYM];              // tree: weights of the leaves (in sorted order) and of the inner nodes
-  uint32_t scan[2][NT];              // workgroup scan (double-buffered Hillis-Steele)
   uint32_t cnt[MAXL + 1];            // symbols per code length
-  uint32_t ad1[NT], ad2[NT];
-  uint32_t own[NT];                  // bits of each span's tokens
+  uint32_t ad1[NW], ad2[NW];         // Adler partials of the waves' eighths
+  uint32_t wave_bits[NW];
   uint16_t sorted[NSYM];             // used symbols by rising (count, symbol)
   uint16_t parent[2 * NSYM];
-  uint16_t code[NSYM];               // canonical code, bit-reversed (deflate packs codes most significant bit first)
-  uint16_t cc[19];
+  uint32_t cl32[NSYM];               // canonical code, bit-reversed (deflate packs codes most significant bit first) | length << 16
   uint8_t len[NSYM];
-  uint8_t cl[19];
-  int32_t n, last, m, nlit, ncl, stored;
-  uint32_t hdr_fixed, hdr_var, data_bits, bytes;
+  int32_t n, last, m, nlit, stored;
+  uint32_t hdr_bits, data_bits, bytes;
 };
 
 // length symbol of a run of r bytes (3 <= r <= 257): symbol, number of extra bits, their value (RFC 1951 3.2.5)
@@ -85,31 +88,81 @@ RRZ_HD void length_code(int r, int& sym, int& ebits, int& eval) {
     eval = 0;
     return;
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int lg = 31 - __builtin_clz((unsigned)x);       // floor(log2 x), 3..7
+#else
   int lg = 0;
-  while ((x >> (lg + 1)) != 0) lg++;                    // floor(log2 x), 3..7
+  while ((x >> (lg + 1)) != 0) lg++;
+#endif
   ebits = lg - 2;
   sym = 265 + 4 * (ebits - 1) + ((x >> ebits) - 4);
   eval = x & ((1 << ebits) - 1);
 }
 
-// the tokens of a span: f(value, is_run) -- a literal byte, or a run of `value` bytes at distance 1
-template <class F>
-RRZ_HD void for_tokens(const uint8_t* s, int n, F&& f) {
-  if (n <= 0) return;
-  f((int)s[0], 0);
-  int i = 1;
-  while (i < n) {
-    const uint8_t b = s[i];
-    if (b == s[i - 1] && i + 2 < n && s[i + 1] == b && s[i + 2] == b) {
-      int r = 3;
-      while (i + r < n && s[i + r] == b) r++;           // (a span has 128 bytes: r <= 127 < 258)
-      f(r, 1);
-      i += r;
-    } else {
-      f((int)b, 0);
-      i++;
-    }
+// The token lane `lane` of a chunk emits.  nv: bytes in the chunk (lanes >= nv hold nothing); start: bit i set where byte i
+// opens a sequence of equal bytes (bit 0 always); b: the lane's byte.  kind 0: nothing (the byte lies inside a run), 1: the
+// literal b, 2: a run of v bytes at distance 1.
+struct Tok {
+  int kind, v;
+};
+RRZ_HD int ctz64(uint64_t x) {
+  int n = 0;
+  while (!(x & 1ull)) {
+    x >>= 1;
+    n++;
   }
+  return n;
+}
+RRZ_HD int fls64(uint64_t x) {                           // index of the highest set bit (x != 0)
+  int n = 0;
+  while (x >>= 1) n++;
+  return n;
+}
+RRZ_HD Tok lane_token(int lane, int nv, uint64_t start, int b) {
+  if (lane >= nv) return Tok{0, 0};
+  const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int j0 = 63 - __builtin_clzll(start & upto);
+  const uint64_t above = lane == 63 ? 0ull : (start >> (lane + 1));
+  const int next = above ? lane + 1 + __builtin_ctzll(above) : 64;
+#else
+  const int j0 = fls64(start & upto);
+  const uint64_t above = lane == 63 ? 0ull : (start >> (lane + 1));
+  const int next = above ? lane + 1 + ctz64(above) : 64;
+#endif
+  const int L = (next < nv ? next : nv) - j0;            // length of the lane's sequence
+  if (lane == j0 || L < 4) return Tok{1, b};
+  return lane == j0 + 1 ? Tok{2, L - 1} : Tok{0, 0};
+}
+// a token under the block's code: its bits (at most 15 + 5 + 1, the distance bit of a run -- 0 -- on top) and their number
+RRZ_HD uint32_t token_code(const BlockState& S, Tok t, uint32_t& nbits) {
+  if (t.kind == 1) {
+    const uint32_t e = S.cl32[t.v];
+    nbits = e >> 16;
+    return e & 0xffffu;
+  }
+  if (t.kind != 2) {
+    nbits = 0;
+    return 0;
+  }
+  int sym, eb, ev;
+  length_code(t.v, sym, eb, ev);
+  const uint32_t e = S.cl32[sym];
+  nbits = (e >> 16) + (uint32_t)eb + 1u;
+  return (e & 0xffffu) | ((uint32_t)ev << (e >> 16));
+}
+RRZ_HD int token_symbol(Tok t) {
+  if (t.kind == 1) return t.v;
+  int sym, eb, ev;
+  length_code(t.v, sym, eb, ev);
+  return sym;
+}
+// a code of n bits at bit position pos of the block's buffer (other lanes write the bits around it)
+RRZ_HD void or_bits(uint32_t* out, uint32_t pos, uint32_t bits, uint32_t n) {
+  if (!n) return;
+  const uint32_t w = pos >> 5, sh = pos & 31u;
+  RRZ_OR(out + w, bits << sh);
+  if (sh + n > 32u) RRZ_OR(out + w + 1, bits >> (32u - sh));
 }
 
 RRZ_HD uint32_t bit_reverse(uint32_t v, int n) {
@@ -145,15 +198,17 @@ struct BitOut {
 };
 
 // ---- the phases of one block (every function: one thread role; a barrier after each) --------------------------------------
-// P0: the block's bytes into S.in (the caller copies them: coalesced on the device), then: clear, Adler partials
+// P0: the block's bytes are in S.in (the caller copies them); clear the rest
 RRZ_HD void p0_init(BlockState& S, int tid, int n, int last) {
   for (int k = tid; k < OUT_WORDS; k += NT) S.out[k] = 0;
   for (int k = tid; k < NSYM; k += NT) {
-    S.freq[k] = 0;
+    if (k < NSYM / 2)
+      for (int w = 0; w < NW; w++) S.freq4[w][k] = 0;
     S.len[k] = 0;
-    S.code[k] = 0;
+    S.cl32[k] = 0;
   }
   if (tid <= MAXL) S.cnt[tid] = 0;
+  if (tid < NW) S.wave_bits[tid] = 0;
   if (tid == 0) {
     S.n = n;
     S.last = last;
@@ -161,28 +216,27 @@ RRZ_HD void p0_init(BlockState& S, int tid, int n, int last) {
     S.nlit = 257;
     S.stored = 0;
   }
-  const int a = tid * SPAN, b = a + SPAN < n ? a + SPAN : n;
-  uint32_t s1 = 0, s2 = 0;
-  for (int i = a; i < b; i++) {
-    s1 += S.in[i];
-    s2 += (uint32_t)(n - i) * S.in[i];                  // <= 128 * 32768 * 255 < 2^31
-  }
-  S.ad1[tid] = s1;
-  S.ad2[tid] = s2 % 65521u;
 }
-// P1: histogram of the tokens
-RRZ_HD void p1_hist(BlockState& S, int tid) {
-  const int a = tid * SPAN, b = a + SPAN < S.n ? a + SPAN : S.n;
-  for_tokens(S.in + a, b - a, [&](int v, int run) {
-    if (run) {
-      int sym, eb, ev;
-      length_code(v, sym, eb, ev);
-      RRZ_ADD(&S.freq[sym], 1u);
-    } else {
-      RRZ_ADD(&S.freq[v], 1u);
-    }
-  });
-  if (tid == 0) RRZ_ADD(&S.freq[256], 1u);              // end of block
+// P1 (wave form, see k_pngz_blocks / emu_pngz): one chunk of a wave's quarter -- the lane's token into the wave's histogram, its
+// byte into the lane's Adler partials.
+RRZ_HD void p1_lane(BlockState& S, int wave, Tok t, int b, int left, bool valid, uint32_t& s1, uint32_t& s2) {
+  if (t.kind) {
+    const int sym = token_symbol(t);
+    RRZ_ADD(&S.freq4[wave][sym >> 1], 1u << (16 * (sym & 1)));
+  }
+  if (valid) {                                           // left: the block's length minus the byte's position in it
+    s1 += (uint32_t)b;
+    s2 += (uint32_t)left * (uint32_t)b;                  // per lane: 64 chunks x 32768 x 255 < 2^32            // per lane: 128 chunks x 32768 x 255 < 2^32
+  }
+}
+RRZ_HD uint32_t wave_count(const BlockState& S, int w, int sym) { return (S.freq4[w][sym >> 1] >> (16 * (sym & 1))) & 0xffffu; }
+// P1b: the block's histogram
+RRZ_HD void p1_sum(BlockState& S, int tid) {
+  for (int k = tid; k < NSYM; k += NT) {
+    uint32_t f = k == 256 ? 1u : 0u;                     // end of block
+    for (int w = 0; w < NW; w++) f += wave_count(S, w, k);
+    S.freq[k] = f;
+  }
 }
 // P2: rank of every used symbol among the used ones by (count, symbol)
 RRZ_HD void p2_rank(BlockState& S, int tid) {
@@ -203,16 +257,24 @@ RRZ_HD void p3_tree(BlockState& S, int tid) {
   if (tid != 0) return;
   const int m = S.m;                                      // >= 2: a block has at least one byte and the end-of-block symbol
   for (int i = 0; i < m; i++) S.w[i] = S.freq[S.sorted[i]];
+  // (the heads of the two queues stay in registers: one load per node taken, not two per comparison)
   int leaf = 0, inner = m, made = m;
+  uint32_t wl = S.w[0], wi = 0;
   while (made < 2 * m - 1) {
-    int pick[2];
+    uint32_t sum = 0;
     for (int k = 0; k < 2; k++) {
-      if (leaf < m && (inner >= made || S.w[leaf] <= S.w[inner])) pick[k] = leaf++;
-      else pick[k] = inner++;
+      if (leaf < m && (inner >= made || wl <= wi)) {
+        sum += wl;
+        S.parent[leaf++] = (uint16_t)made;
+        if (leaf < m) wl = S.w[leaf];
+      } else {
+        sum += wi;
+        S.parent[inner++] = (uint16_t)made;
+        if (inner < made) wi = S.w[inner];
+      }
     }
-    S.w[made] = S.w[pick[0]] + S.w[pick[1]];
-    S.parent[pick[0]] = (uint16_t)made;
-    S.parent[pick[1]] = (uint16_t)made;
+    S.w[made] = sum;
+    if (inner == made) wi = sum;                          // the new node is the head of the inner queue
     made++;
   }
 }
@@ -269,142 +331,53 @@ RRZ_HD void p7_codes(BlockState& S, int tid) {
     for (int b = 1; b <= L; b++) c = (c + (b > 1 ? S.cnt[b - 1] : 0u)) << 1;
     uint32_t idx = 0;
     for (int j = 0; j < s; j++) idx += S.len[j] == L ? 1u : 0u;
-    S.code[s] = (uint16_t)bit_reverse(c + idx, L);
+    S.cl32[s] = bit_reverse(c + idx, L) | ((uint32_t)L << 16);
   }
 }
-// serial Huffman lengths of a small alphabet (the 19 code-length symbols, limit 7)
-RRZ_HD void small_lengths(const uint32_t* freq, int nsym, int max_len, uint8_t* len) {
-  int used[19], m = 0;
-  for (int i = 0; i < nsym; i++) {
-    len[i] = 0;
-    if (freq[i]) used[m++] = i;
-  }
-  if (m == 0) return;
-  if (m == 1) {
-    len[used[0]] = 1;
-    return;
-  }
-  for (int i = 1; i < m; i++) {                          // insertion sort by (count, symbol)
-    const int u = used[i];
-    int j = i - 1;
-    while (j >= 0 && (freq[used[j]] > freq[u] || (freq[used[j]] == freq[u] && used[j] > u))) {
-      used[j + 1] = used[j];
-      j--;
-    }
-    used[j + 1] = u;
-  }
-  uint32_t w[38];
-  int parent[38];
-  for (int i = 0; i < m; i++) w[i] = freq[used[i]];
-  int leaf = 0, inner = m, made = m;
-  while (made < 2 * m - 1) {
-    int pick[2];
-    for (int k = 0; k < 2; k++) {
-      if (leaf < m && (inner >= made || w[leaf] <= w[inner])) pick[k] = leaf++;
-      else pick[k] = inner++;
-    }
-    w[made] = w[pick[0]] + w[pick[1]];
-    parent[pick[0]] = parent[pick[1]] = made;
-    made++;
-  }
-  uint32_t cnt[16] = {0};
-  for (int i = 0; i < m; i++) {
-    int d = 0, v = i;
-    while (v != 2 * m - 2) {
-      v = parent[v];
-      d++;
-    }
-    cnt[d > max_len ? max_len : d]++;
-  }
-  kraft_fix(cnt, max_len);
-  int l = max_len;
-  for (int i = 0; i < m; i++) {
-    while (l > 0 && cnt[l] == 0) l--;
-    len[used[i]] = (uint8_t)l;
-    cnt[l]--;
-  }
-}
-RRZ_HD void small_codes(const uint8_t* len, int nsym, uint16_t* code) {
-  int bl[16] = {0};
-  for (int i = 0; i < nsym; i++) bl[len[i]]++;
-  bl[0] = 0;
-  int next[16] = {0}, c = 0;
-  for (int b = 1; b <= 15; b++) {
-    c = (c + bl[b - 1]) << 1;
-    next[b] = c;
-  }
-  for (int i = 0; i < nsym; i++) code[i] = len[i] ? (uint16_t)bit_reverse((uint32_t)next[len[i]]++, len[i]) : 0;
-}
-RRZ_HD int cl_order(int k) {
-  const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-  return order[k];
-}
-// P8 (thread 0): the code of the code lengths; the fixed part of the block header goes out
+// P8: the block header.  Fixed part by thread 0: BFINAL, BTYPE 10, HLIT, HDIST 0 (one distance code), HCLEN 15 and the 19
+// code-length-code lengths in the order of RFC 1951 3.2.7: symbols 16, 17, 18 unused, every length 0..15 a 4-bit code (the
+// canonical code of sixteen 4-bit symbols: the length value itself, bits reversed).  Then the nlit literal/length code lengths
+// and the distance code's length 1, four bits each: entry k at bit 74 + 4 k, two entries per thread, no scan needed.
+constexpr uint32_t HDR_FIXED = 17 + 3 * 19;
 RRZ_HD void p8_header(BlockState& S, int tid) {
-  if (tid != 0) return;
-  uint32_t fc[19];
-  for (int k = 0; k < 19; k++) fc[k] = k <= MAXL ? S.cnt[k] : 0u;
-  fc[0] = (uint32_t)(S.nlit - S.m);                       // the unused symbols below nlit
-  fc[1] += 1;                                             // the one distance code (distance 1), length 1
-  small_lengths(fc, 19, 7, S.cl);
-  small_codes(S.cl, 19, S.cc);
-  int ncl = 19;
-  while (ncl > 4 && S.cl[cl_order(ncl - 1)] == 0) ncl--;
-  S.ncl = ncl;
-  BitOut bo(S.out, 0);
-  bo.put(S.last ? 1u : 0u, 1);
-  bo.put(2u, 2);
-  bo.put((uint32_t)(S.nlit - 257), 5);
-  bo.put(0u, 5);                                          // HDIST: one distance code
-  bo.put((uint32_t)(ncl - 4), 4);
-  for (int k = 0; k < ncl; k++) bo.put(S.cl[cl_order(k)], 3);
-  bo.finish();
-  S.hdr_fixed = 17u + 3u * (uint32_t)ncl;
-}
-// bit count of entry k of the code-length sequence (the nlit literal/length code lengths, then the distance code's)
-RRZ_HD uint32_t hdr_entry_bits(const BlockState& S, int k) { return k < S.nlit ? S.cl[S.len[k]] : (k == S.nlit ? S.cl[1] : 0u); }
-// P9a: scan input = bits of the two entries 2 tid, 2 tid + 1
-RRZ_HD void p9_hdr_bits(BlockState& S, int tid) { S.scan[0][tid] = hdr_entry_bits(S, 2 * tid) + hdr_entry_bits(S, 2 * tid + 1); }
-// workgroup scan, step s = 0..7 (inclusive Hillis-Steele from buffer s & 1 to the other); the result is in scan[0]
-RRZ_HD void scan_step(BlockState& S, int tid, int s) {
-  const uint32_t* a = S.scan[s & 1];
-  uint32_t* b = S.scan[(s & 1) ^ 1];
-  const int d = 1 << s;
-  b[tid] = a[tid] + (tid >= d ? a[tid - d] : 0u);
-}
-// P9b: the entries' codes at their positions (scan[0] = inclusive sums)
-RRZ_HD void p9_hdr_emit(BlockState& S, int tid) {
-  const uint32_t incl = S.scan[0][tid];
-  const uint32_t b0 = hdr_entry_bits(S, 2 * tid), b1 = hdr_entry_bits(S, 2 * tid + 1);
-  if (b0 + b1) {
-    BitOut bo(S.out, S.hdr_fixed + incl - b0 - b1);
-    if (b0) bo.put(2 * tid < S.nlit ? S.cc[S.len[2 * tid]] : S.cc[1], (int)b0);
-    if (b1) bo.put(2 * tid + 1 < S.nlit ? S.cc[S.len[2 * tid + 1]] : S.cc[1], (int)b1);
+  if (tid == 0) {
+    BitOut bo(S.out, 0);
+    bo.put(S.last ? 1u : 0u, 1);
+    bo.put(2u, 2);
+    bo.put((uint32_t)(S.nlit - 257), 5);
+    bo.put(0u, 5);
+    bo.put(15u, 4);
+    for (int k = 0; k < 19; k++) bo.put(k < 3 ? 0u : 4u, 3);
+    bo.finish();
+    S.hdr_bits = HDR_FIXED + 4u * (uint32_t)(S.nlit + 1);
+  }
+  const int k0 = 2 * tid;
+  if (k0 <= S.nlit) {
+    BitOut bo(S.out, HDR_FIXED + 4u * (uint32_t)k0);
+    bo.put(bit_reverse(k0 < S.nlit ? S.len[k0] : 1u, 4), 4);
+    if (k0 + 1 <= S.nlit) bo.put(bit_reverse(k0 + 1 < S.nlit ? S.len[k0 + 1] : 1u, 4), 4);
     bo.finish();
   }
-  if (tid == NT - 1) S.hdr_var = incl;
 }
-// P10a: bits of a span's tokens
-RRZ_HD void p10_span_bits(BlockState& S, int tid) {
-  const int a = tid * SPAN, b = a + SPAN < S.n ? a + SPAN : S.n;
-  uint32_t bits = 0;
-  for_tokens(S.in + a, b - a, [&](int v, int run) {
-    if (run) {
-      int sym, eb, ev;
-      length_code(v, sym, eb, ev);
-      bits += (uint32_t)S.len[sym] + (uint32_t)eb + 1u;  // + the distance code: one bit
-    } else {
-      bits += S.len[v];
+// P9: a wave's bit count from its histogram: sum of count x (code length + extra bits + the distance bit of a run)
+RRZ_HD void p9_wave_bits(BlockState& S, int tid) {
+  for (int k = tid; k < NSYM; k += NT) {
+    if (!S.len[k] || k == 256) continue;
+    uint32_t cost = S.len[k];
+    if (k > 256) {
+      const int j = k - 257;                              // extra bits of length symbol 257 + j (RFC 1951 3.2.5)
+      cost += (j < 8 ? 0u : (uint32_t)((j - 4) >> 2)) + 1u;
     }
-  });
-  S.scan[0][tid] = bits;
-  S.own[tid] = bits;
+    for (int w = 0; w < NW; w++)
+      if (wave_count(S, w, k)) RRZ_ADD(&S.wave_bits[w], wave_count(S, w, k) * cost);
+  }
 }
-// P10b (after the scan): size of the dynamic form; a block that does not shrink is stored
+// P10 (thread 0): size of the dynamic form; a block that does not shrink is stored
 RRZ_HD void p10_decide(BlockState& S, int tid) {
   if (tid != 0) return;
-  S.data_bits = S.scan[0][NT - 1];
-  const uint64_t bits = (uint64_t)S.hdr_fixed + S.hdr_var + S.data_bits + S.len[256];
+  S.data_bits = 0;
+  for (int w = 0; w < NW; w++) S.data_bits += S.wave_bits[w];
+  const uint64_t bits = (uint64_t)S.hdr_bits + S.data_bits + S.len[256];
   // (not the last block: three header bits of the empty stored block, padding, then LEN and NLEN)
   uint32_t bytes = S.last ? (uint32_t)((bits + 7) >> 3) : (uint32_t)((bits + 3 + 7) >> 3) + 4u;
   if (bytes >= (uint32_t)S.n + 5u) {
@@ -418,62 +391,45 @@ RRZ_HD void p11_clear(BlockState& S, int tid) {
   if (!S.stored) return;
   for (int k = tid; k < OUT_WORDS; k += NT) S.out[k] = 0;
 }
-// P12: the block's data
-RRZ_HD void p12_emit(BlockState& S, int tid) {
+// first data bit of a wave's quarter
+RRZ_HD uint32_t wave_base(const BlockState& S, int wave) {
+  uint32_t b = S.hdr_bits;
+  for (int w = 0; w < wave; w++) b += S.wave_bits[w];
+  return b;
+}
+// P12 (thread 0 of a dynamic block): end of block, then -- unless the file ends here -- the empty stored block; (of a stored
+// block): its five header bytes.  The tokens themselves go out in wave form (or_bits at base + prefix sums).
+RRZ_HD void p12_ends(BlockState& S, int tid) {
+  if (tid != 0) return;
   if (S.stored) {
     uint8_t* ob = reinterpret_cast<uint8_t*>(S.out);
-    if (tid == 0) {
-      ob[0] = S.last ? 1 : 0;                             // BFINAL, BTYPE 00, padding
-      ob[1] = (uint8_t)(S.n & 255);
-      ob[2] = (uint8_t)(S.n >> 8);
-      ob[3] = (uint8_t)(~S.n & 255);
-      ob[4] = (uint8_t)((~S.n >> 8) & 255);
-    }
-    return;                                               // (the bytes follow in p12b: other words than the header's)
+    ob[0] = S.last ? 1 : 0;                               // BFINAL, BTYPE 00, padding
+    ob[1] = (uint8_t)(S.n & 255);
+    ob[2] = (uint8_t)(S.n >> 8);
+    ob[3] = (uint8_t)(~S.n & 255);
+    ob[4] = (uint8_t)((~S.n >> 8) & 255);
+    return;
   }
-  const int a = tid * SPAN, b = a + SPAN < S.n ? a + SPAN : S.n;
-  const uint32_t incl = S.scan[0][tid], own = S.own[tid];
-  const uint32_t base = S.hdr_fixed + S.hdr_var;
-  if (own) {
-    BitOut bo(S.out, base + incl - own);
-    for_tokens(S.in + a, b - a, [&](int v, int run) {
-      if (run) {
-        int sym, eb, ev;
-        length_code(v, sym, eb, ev);
-        bo.put(S.code[sym], S.len[sym]);
-        if (eb) bo.put((uint32_t)ev, eb);
-        bo.put(0u, 1);                                    // distance 1: the only distance code, one bit
-      } else {
-        bo.put(S.code[v], S.len[v]);
-      }
-    });
-    bo.finish();
-  }
-  if (tid == 0) {                                         // end of block, then -- unless the file ends here -- the empty stored block
-    const uint32_t endpos = base + S.data_bits;
-    BitOut bo(S.out, endpos);
-    bo.put(S.code[256], S.len[256]);
-    bo.finish();
-    if (!S.last) {
-      const uint32_t after = endpos + S.len[256] + 3;     // three zero bits: BFINAL 0, BTYPE 00
-      const uint32_t at = (after + 7) >> 3;               // LEN 0000, NLEN ffff on the next byte boundary
-      RRZ_OR(&S.out[(at + 2) >> 2], 0xffu << (8 * ((at + 2) & 3)));
-      RRZ_OR(&S.out[(at + 3) >> 2], 0xffu << (8 * ((at + 3) & 3)));
-    }
+  const uint32_t endpos = S.hdr_bits + S.data_bits;
+  or_bits(S.out, endpos, S.cl32[256] & 0xffffu, S.len[256]);
+  if (!S.last) {
+    const uint32_t after = endpos + S.len[256] + 3;       // three zero bits: BFINAL 0, BTYPE 00
+    const uint32_t at = (after + 7) >> 3;                 // LEN 0000, NLEN ffff on the next byte boundary
+    RRZ_OR(&S.out[(at + 2) >> 2], 0xffu << (8 * ((at + 2) & 3)));
+    RRZ_OR(&S.out[(at + 3) >> 2], 0xffu << (8 * ((at + 3) & 3)));
   }
 }
 // P12b (stored blocks): the raw bytes behind the five header bytes
 RRZ_HD void p12b_stored_bytes(BlockState& S, int tid) {
   if (!S.stored) return;
   uint8_t* ob = reinterpret_cast<uint8_t*>(S.out) + 5;
-  const int a = tid * SPAN, b = a + SPAN < S.n ? a + SPAN : S.n;
-  for (int i = a; i < b; i++) ob[i] = S.in[i];
+  for (int i = tid; i < S.n; i += NT) ob[i] = S.in[i];
 }
 // P13 (thread 0): the block's record
 RRZ_HD void p13_meta(BlockState& S, int tid, BlockMeta* meta) {
   if (tid != 0) return;
   uint64_t s1 = 0, s2 = 0;
-  for (int k = 0; k < NT; k++) {
+  for (int k = 0; k < NW; k++) {
     s1 += S.ad1[k];
     s2 += S.ad2[k];
   }

@@ -10,7 +10,7 @@ import json
 try:
     d = json.load(open("$OUT/${TAG}_bench.json"))
     print(round(d["value"], 1), "frames/s", round(d["ms_per_step"], 2), "ms/step")
-    for k in ("prepass", "host_inclusive"):
+    for k in ("prepass", "png_on_device", "host_inclusive"):
         print(k, json.dumps(d.get(k))[:1400])
 except Exception as e:
     print("parse failed", e)

@@ -484,8 +484,41 @@ int64_t emu_pngz(const uint8_t* rows, int64_t n, uint8_t* dst) {
     const int len = (int)(n - (int64_t)k * BLOCK < BLOCK ? n - (int64_t)k * BLOCK : BLOCK), last = k == nb - 1;
     memcpy(S.in, rows + (int64_t)k * BLOCK, len);
 #define ALL(call) for (int tid = 0; tid < NT; tid++) call
+    // the lanes' tokens of chunk c of wave `wave` (k_pngz_blocks: a shuffle for the predecessor, a ballot for the starts)
+    auto chunk = [&](int wave, int c, Tok* tok, int* bs, int* idx, bool* valid) {
+      const int w0 = wave * WAVE_BYTES, nv = len - (w0 + c * CHUNK) < CHUNK ? len - (w0 + c * CHUNK) : CHUNK;
+      uint64_t start = 0;
+      for (int lane = 0; lane < 64; lane++) {
+        idx[lane] = w0 + c * CHUNK + lane;
+        valid[lane] = lane < nv;
+        bs[lane] = valid[lane] ? S.in[idx[lane]] : 0;
+        if (valid[lane] && (lane == 0 || bs[lane] != bs[lane - 1])) start |= 1ull << lane;
+      }
+      for (int lane = 0; lane < 64; lane++) tok[lane] = lane_token(lane, nv, start, bs[lane]);
+    };
+    auto chunks_of = [&](int wave) {
+      const int w0 = wave * WAVE_BYTES;
+      return len > w0 ? ((len - w0 < WAVE_BYTES ? len - w0 : WAVE_BYTES) + CHUNK - 1) / CHUNK : 0;
+    };
+    Tok tok[64];
+    int bs[64], idx[64];
+    bool valid[64];
     ALL(p0_init(S, tid, len, last));
-    ALL(p1_hist(S, tid));
+    for (int wave = 0; wave < NW; wave++) {
+      uint32_t s1[64] = {0}, s2[64] = {0};
+      for (int c = 0; c < chunks_of(wave); c++) {
+        chunk(wave, c, tok, bs, idx, valid);
+        for (int lane = 0; lane < 64; lane++) p1_lane(S, wave, tok[lane], bs[lane], len - idx[lane], valid[lane], s1[lane], s2[lane]);
+      }
+      uint32_t a1 = 0, a2 = 0;                            // (the wave's sums: a DPP reduction on the device)
+      for (int lane = 0; lane < 64; lane++) {
+        a1 += s1[lane];
+        a2 += s2[lane] % 65521u;
+      }
+      S.ad1[wave] = a1;
+      S.ad2[wave] = a2;
+    }
+    ALL(p1_sum(S, tid));
     ALL(p2_rank(S, tid));
     ALL(p3_tree(S, tid));
     ALL(p4_depth(S, tid));
@@ -493,14 +526,23 @@ int64_t emu_pngz(const uint8_t* rows, int64_t n, uint8_t* dst) {
     ALL(p6_assign(S, tid));
     ALL(p7_codes(S, tid));
     ALL(p8_header(S, tid));
-    ALL(p9_hdr_bits(S, tid));
-    for (int s_ = 0; s_ < 8; s_++) ALL(scan_step(S, tid, s_));
-    ALL(p9_hdr_emit(S, tid));
-    ALL(p10_span_bits(S, tid));
-    for (int s_ = 0; s_ < 8; s_++) ALL(scan_step(S, tid, s_));
+    ALL(p9_wave_bits(S, tid));
     ALL(p10_decide(S, tid));
     ALL(p11_clear(S, tid));
-    ALL(p12_emit(S, tid));
+    ALL(p12_ends(S, tid));
+    if (!S.stored)
+      for (int wave = 0; wave < NW; wave++) {
+        uint32_t base = wave_base(S, wave);
+        for (int c = 0; c < chunks_of(wave); c++) {
+          chunk(wave, c, tok, bs, idx, valid);
+          for (int lane = 0; lane < 64; lane++) {
+            uint32_t nbits;
+            const uint32_t code = token_code(S, tok[lane], nbits);
+            if (nbits) or_bits(S.out, base, code, nbits);
+            base += nbits;
+          }
+        }
+      }
     ALL(p12b_stored_bytes(S, tid));
     ALL(p13_meta(S, tid, &meta[k]));
 #undef ALL
