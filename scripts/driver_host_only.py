@@ -33,6 +33,7 @@ class _Prepared:
 class HostOnlyContext:
     """Accepts the calls Generator makes on RainHip; pipeline_wait fills the batch's scanline buffers from templates."""
     device = 0
+    device_png = False                                # --device-png: the buffers hold zlib streams (RR_OPT_PNG_DEFLATE)
 
     def __init__(self, device=0):
         self.batches = {}
@@ -82,6 +83,20 @@ class HostOnlyContext:
                 m += np.exp(-(((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2)) * rng.uniform(0.1, 1)
             lut = imgops.viridis_lut()
             self.rows = (hib.sub_rows(rgba).reshape(-1), hib.sub_rows(lut[np.clip((m / m.max() * 255).astype(int), 0, 255)]).reshape(-1))
+            if HostOnlyContext.device_png:              # what RR_OPT_PNG_DEFLATE delivers: the zlib streams (host build of csrc/rr_deflate.h)
+                import ctypes
+                sys.path.insert(0, os.path.join(ROOT, 'tests'))
+                import helpers
+                emu = helpers.hostemu()
+                emu.emu_pngz.restype = ctypes.c_int64
+                emu.emu_pngz.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+                coded = []
+                for r in self.rows:
+                    r = np.ascontiguousarray(r, np.uint8)
+                    d = np.zeros_like(r)
+                    assert emu.emu_pngz(r.ctypes.data, r.size, d.ctypes.data) > 0
+                    coded.append(d)
+                self.rows = tuple(coded)
         if not getattr(prep, 'filled', False):         # (the "rendered" scanlines never change: written once per slot)
             for o in prep.outs:
                 np.copyto(o['rainy_png'], self.rows[0])
@@ -101,6 +116,7 @@ def main():
     ap.add_argument('--tiny', action='store_true', help='64x48 frames: the Python part alone')
     ap.add_argument('--distinct', type=int, default=32)
     ap.add_argument('--size', default=None, help='WxH of the dataset frames (default 1242x375)')
+    ap.add_argument('--device-png', action='store_true', help='the stand-in delivers the PNG payloads entropy-coded, as the device does with RR_OPT_PNG_DEFLATE')
     ap.add_argument('--render-scale', type=int, default=1, help='render at 1/N of the frame size (what the Cityscapes plug-in does with N = 2)')
     args = ap.parse_args()
     os.environ['RAIN_BATCH'] = str(args.batch)
@@ -111,6 +127,7 @@ def main():
     generator_mod = importlib.import_module('rain-rendering_amd.common.generator')
     hb = importlib.import_module('rain-rendering_amd.hip_backend')
     hb.RainHip = HostOnlyContext                      # (this process only)
+    HostOnlyContext.device_png = args.device_png
     H, W = (48, 64) if args.tiny else (375, 1242)
     if args.size:
         W, H = (int(v) for v in args.size.split('x'))
