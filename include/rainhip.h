@@ -149,7 +149,8 @@ typedef struct {
   /* Optional: the two PNG files the reference writes per frame (generator.py:466-467), as PNG
    * scanlines ready for deflate: H rows of 1 + 4*W bytes = filter byte 1 (Sub) + the Sub-filtered RGBA pixels.
    * rainy_png: plt.imsave(rainy_image) (alpha 255); mask_png: plt.imsave(rainy_mask) = (mask - min) / (max - min) through
-   * the 256-entry colour map given to rr_set_colormap (needs mask_f64 in the device-pointer entry points). */
+   * the 256-entry colour map given to rr_set_colormap (needs mask_f64 in the device-pointer entry points).
+   * With RR_OPT_PNG_DEFLATE the same buffers come back entropy-coded (see the option): 16-byte header + the file's zlib stream. */
   uint8_t* rainy_png;
   uint8_t* mask_png;
   /* Optional: n_drops * 3 doubles, the B, G, R colour constants K of every drop: the tile colour the reference derives
@@ -472,7 +473,8 @@ int rr_sizeof_particle_frame(void);
  *   rr_png_write_scanlines  an RGBA file from H rows of 1 + 4*W filtered bytes (rr_frame_out.rainy_png / mask_png);
  *                           zlib level 0..9, strategy 0 default / 1 Z_RLE / 2 Z_HUFFMAN_ONLY / 3 the library's own
  *                           run-length + dynamic-Huffman deflate (level ignored; an ordinary zlib stream, about the size
- *                           of Z_RLE's at a fifth of the CPU time)
+ *                           of Z_RLE's at a fifth of the CPU time); rows that begin with 'R','R','Z','1' are a stream the
+ *                           device made (RR_OPT_PNG_DEFLATE) and go out as the IDAT payload as they are
  *   rr_deflate_fast     that encoder on n arbitrary bytes -> zlib stream in out (capacity >= rr_deflate_bound(n));
  *                       returns the stream's length or a negative RR_E* code */
 int rr_png_info(const char* path, int32_t* w, int32_t* h, int32_t* channels, int32_t* bit_depth);

@@ -22,8 +22,10 @@
 // stream, 0, 0} followed by the stream -- if that fits (always, unless the image is incompressible: the first byte of a
 // scanline buffer is a PNG filter type 0..4, never the magic's 'R').  Otherwise the scanlines are left as they are and the
 // host compresses them as before.  rr_png_write_scanlines / rr_io_write_frames (rr_png.cpp) take either.
-// The functions are `__host__ __device__` in "thread role" form (tid = 0..255, barriers between the phases) like FogTile in
-// rr_prepass.h: tests/hostemu runs the same code on the CPU and zlib inflates what it produces (tests/test_deflate_hostemu.py).
+// The functions are `__host__ __device__`: the phases in "thread role" form (tid = 0..511, barriers between them) like FogTile
+// in rr_prepass.h, the two token passes per lane (lane_token / token_code from a chunk's ballot; the ballot, the prefix sum and
+// the running base are three lines of wave intrinsics in k_pngz_blocks and three loops in tests/hostemu): the same code runs
+// on the CPU and zlib inflates what it produces (tests/test_deflate_hostemu.py).
 #pragma once
 #include <stdint.h>
 #include <string.h>

@@ -10,7 +10,8 @@
 #     3b. phase clocks of the tile / blur kernels (scripts/phase_timing.sh: a -DRR_PHASES build in /tmp) -> <tag>_phases.txt
 #   scripts/gpu_full_measure.sh <tag> b     (~12 min)
 #     4. one lean bench line per other BASELINE configuration   -> <tag>_bench_<workload>.json
-#     5. driver end to end (PNG in -> PNG out, main.py)         -> <tag>_e2e.json
+#     5. driver end to end (PNG in -> PNG out, main.py), PNG payloads from the device / deflated by the host
+#                                                               -> <tag>_e2e.json, <tag>_e2e_host_deflate.json
 #     6. two ranks on the one GPU (gloo): the N>1 launch line   -> two_ranks_<tag>.log
 #     7. host CPU scaling probe (deflate threads)               -> <tag>_cpuscale.txt
 TAG=${1:-full}; PART=${2:-a}
@@ -39,7 +40,8 @@ except Exception as e:
     print("   parse failed", e)
 PY
   done
-  timeout -k 10 400 python scripts/driver_e2e.py --frames 1024 --batch 128 2> $OUT/${TAG}_e2e.err | tail -1 > $OUT/${TAG}_e2e.json; echo "e2e exit $?"; cut -c1-600 $OUT/${TAG}_e2e.json
+  timeout -k 10 400 python scripts/driver_e2e.py --frames 2048 --batch 128 2> $OUT/${TAG}_e2e.err | tail -1 > $OUT/${TAG}_e2e.json; echo "e2e exit $?"; cut -c1-600 $OUT/${TAG}_e2e.json
+  RAIN_PNG_DEVICE=0 timeout -k 10 400 python scripts/driver_e2e.py --frames 2048 --batch 128 2> $OUT/${TAG}_e2e_host_deflate.err | tail -1 > $OUT/${TAG}_e2e_host_deflate.json; echo "e2e (host deflate) exit $?"; cut -c1-600 $OUT/${TAG}_e2e_host_deflate.json
   timeout -k 10 500 scripts/bench_two_ranks.sh $TAG; echo "two ranks exit $?"
   timeout -k 10 120 python scripts/cpuscale_probe.py > $OUT/${TAG}_cpuscale.txt 2>&1; cat $OUT/${TAG}_cpuscale.txt
 fi
