@@ -1,9 +1,19 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): the driver tests, then the driver end to end with the host's deflate and with the device's.
-# Usage: scripts/gpu_e2e_ab.sh <tag>
-TAG=${1:-e2e}
+# Run on the GPU box (via gpurun): the driver end to end with the device's and with the host's deflate, alternating (the box's
+# host side is noisy: one pair says little).  Usage: scripts/gpu_e2e_ab.sh <tag> [rounds]
+TAG=${1:-e2e}; ROUNDS=${2:-3}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out; mkdir -p $OUT; cd $REPO
-timeout -k 10 900 python -m pytest tests/test_gpu_driver.py tests/test_gpu_pipeline_async.py -m gpu -q > $OUT/${TAG}_tests.log 2>&1; echo "tests exit $?"; tail -8 $OUT/${TAG}_tests.log
-for DEV in 0 1; do
-  RAIN_PNG_DEVICE=$DEV timeout -k 10 500 python scripts/driver_e2e.py --frames 1024 --batch 128 2> $OUT/${TAG}_e2e_dev$DEV.err | tail -1 > $OUT/${TAG}_e2e_dev$DEV.json; echo "e2e device=$DEV exit $?"; cut -c1-700 $OUT/${TAG}_e2e_dev$DEV.json
+: > $OUT/${TAG}_e2e_ab.jsonl
+for R in $(seq 1 $ROUNDS); do
+  for DEV in 1 0; do
+    RAIN_PNG_DEVICE=$DEV timeout -k 10 500 python scripts/driver_e2e.py --frames 2048 --batch 128 2> $OUT/${TAG}_e2e_dev$DEV.err | tail -1 > $OUT/${TAG}_tmp.json
+    python - <<PY
+import json
+d = json.load(open("$OUT/${TAG}_tmp.json"))
+t = d["timing"][0]
+line = {"png_on_device": bool($DEV), "round": $R, "steady_frames_per_s": t["steady_frames_per_s"], "frames_per_s_including_setup": d["frames_per_s"], "first_batch_s": t["first_batch_s"], "frames": d["frames"], "cpu_quota": d["cpu_quota"]}
+print(json.dumps(line))
+open("$OUT/${TAG}_e2e_ab.jsonl", "a").write(json.dumps(line) + "\n")
+PY
+  done
 done
