@@ -401,6 +401,7 @@ def main():
     ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--more-variants', action='store_true', help='further host-inclusive variants (slot sizes, buffer layouts)')
     ap.add_argument('--no-traffic', action='store_true')
+    ap.add_argument('--copy-sweep', default='', help='comma-separated workgroup counts of the batched copy kernels to time the host-inclusive leg with')
     ap.add_argument('--no-driver', action='store_true', help='skip the main.py driver end-to-end leg (PNG in -> PNG out, own process)')
     ap.add_argument('--cpu-sample-drops', type=int, default=2048)
     ap.add_argument('--pipe-batch', type=int, default=128, help='frames per slot of the host-inclusive pipeline (the driver\'s default batch)')
@@ -690,7 +691,7 @@ def main():
             """packed: the frames of a slot back to back in one page-locked block per array (RainHip.host_rows: one copy per
             array and batch) -- else every frame its own allocations (one copy per frame and array).  prepared: descriptor
             arrays built once per slot (what Generator does) -- else rebuilt in Python for every submission."""
-            rh.set_option(hb.RR_OPT_COPY_KERNELS, 1 if copy_kernels else 0)
+            rh.set_option(hb.RR_OPT_COPY_KERNELS, int(copy_kernels))           # (0: hipMemcpyAsync; 1: 64 workgroups; n > 1: n workgroups)
             cap = max(len(h_[2]) for h_ in batch.host)
             cap = (cap + 3) // 4 * 4
             slots, blocks = [], []
@@ -750,7 +751,7 @@ def main():
                 rh.host_free(a_)
             rh.set_option(hb.RR_OPT_COPY_KERNELS, 0)
             return {"frames_per_s": done / (h1 - h0), "ms_per_frame": 1e3 * (h1 - h0) / done, "frames_per_slot": PB, "frames_timed": done,
-                    "copies": ("one copy kernel per direction and batch (RR_OPT_COPY_KERNELS 1)" if copy_kernels else
+                    "copies": ("one copy kernel per direction and batch (RR_OPT_COPY_KERNELS %d)" % int(copy_kernels) if copy_kernels else
                                ("hipMemcpyAsync, one per array and batch (frames back to back in one page-locked block per array)" if packed
                                 else "hipMemcpyAsync, one per frame and array (separate allocations)")),
                     "descriptors": "prepared once per slot" if prepared else "rebuilt in Python for every submission",
@@ -762,6 +763,8 @@ def main():
                       % (nslot, PB))
         hi["pcie_bytes_per_frame"] = {"up": up, "down": down}
         extras["host_inclusive"] = hi
+        if args.copy_sweep:
+            extras["host_inclusive_copy_sweep"] = {"blocks_%s" % b: host_inclusive(PB, copy_kernels=int(b))["frames_per_s"] for b in args.copy_sweep.split(',')}
         if not args.no_variants:
             extras["host_inclusive_variants"] = {"slots_of_32": host_inclusive(min(32, batch.n)),
                                                  "slots_of_256": host_inclusive(min(256, batch.n)),

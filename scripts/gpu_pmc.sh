@@ -9,7 +9,9 @@ TAG=$1; BARGS=$2; shift 2
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --inner $BARGS"
+# (PMC_LEGS=1: not only the hot path -- the bench line's pre-pass / PNG / host-inclusive legs run too, so their kernels are profiled)
+if [ "${PMC_LEGS:-0}" = "1" ]; then INNER=""; else INNER="--inner"; fi
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 $INNER $BARGS"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 i=0
 for C in "$@"; do
