@@ -63,16 +63,31 @@ def main():
         m += np.exp(-(((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2)) * rng.uniform(0.1, 1)
     rows_mask = sub_rows(lut[np.clip((m / m.max() * 255).astype(int), 0, 255)])
 
+    # the payloads as RR_OPT_PNG_DEFLATE delivers them: entropy-coded on the device (here: the host build of csrc/rr_deflate.h)
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    emu = helpers.hostemu()
+    emu.emu_pngz.restype = ctypes.c_int64
+    emu.emu_pngz.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    coded = []
+    for r in (rows_img, rows_mask):
+        r = np.ascontiguousarray(r, np.uint8).reshape(-1)
+        d = np.zeros_like(r)
+        assert emu.emu_pngz(r.ctypes.data, r.size, d.ctypes.data) > 0
+        coded.append(d)
+
     def frame(i, strategy):
         bg = imgops.imread_bgr(os.path.join(tmp, 'i%02d.png' % (i % nd)))
         dep = imgops.imread_unchanged(os.path.join(tmp, 'd%02d.png' % (i % nd))).astype(np.float32) / 256.
         drops = hb.pack_frame(table, sc.db, W, H, i)
-        imgops.png_from_scanlines(os.path.join(tmp, 'o%d_a.png' % (i % 64)), rows_img, W, H, strategy=strategy)
-        imgops.png_from_scanlines(os.path.join(tmp, 'o%d_m.png' % (i % 64)), rows_mask, W, H, strategy=strategy)
+        a, m_ = (coded[0], coded[1]) if strategy is None else (rows_img, rows_mask)
+        imgops.png_from_scanlines(os.path.join(tmp, 'o%d_a.png' % (i % 64)), a, W, H, strategy=strategy)
+        imgops.png_from_scanlines(os.path.join(tmp, 'o%d_m.png' % (i % 64)), m_, W, H, strategy=strategy)
         return bg.shape[0] + dep.shape[0] + len(drops)
 
     res = {}
-    for name, strategy in (('zlib_rle', 1), ('own_deflate', 3)):
+    for name, strategy in (('zlib_rle', 1), ('own_deflate', 3), ('payloads_coded_on_the_device', None)):
         with ThreadPoolExecutor(args.threads) as ex:
             list(ex.map(lambda i: frame(i, strategy), range(args.threads)))            # warm
             t = time.time()
