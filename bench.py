@@ -687,23 +687,28 @@ def main():
 
         rh.set_solid_angles(sc.omega)                     # resident: frames pass omega=None
 
-        def host_inclusive(PB, copy_kernels=False, packed=True, prepared=True):
+        def host_inclusive(PB, copy_kernels=False, packed=True, prepared=True, depth_u16=True):
             """packed: the frames of a slot back to back in one page-locked block per array (RainHip.host_rows: one copy per
             array and batch) -- else every frame its own allocations (one copy per frame and array).  prepared: descriptor
-            arrays built once per slot (what Generator does) -- else rebuilt in Python for every submission."""
+            arrays built once per slot (what Generator does) -- else rebuilt in Python for every submission.  depth_u16: the
+            depth file's uint16 samples travel (RR_DEPTH_U16, what the driver's batch-native route uploads since round 4) --
+            else the float32 metres the host made of them (rounds 2-3)."""
+            dtd = np.uint16 if depth_u16 else np.float32
+            dval = np.rint(depth_h.astype(np.float64) * 256.0).astype(np.uint16) if depth_u16 else depth_h
+            up_b = 3 * H * W + (2 if depth_u16 else 4) * H * W + 112 * batch.mean_drops
             rh.set_option(hb.RR_OPT_COPY_KERNELS, int(copy_kernels))           # (0: hipMemcpyAsync; 1: 64 workgroups; n > 1: n workgroups)
             cap = max(len(h_[2]) for h_ in batch.host)
             cap = (cap + 3) // 4 * 4
             slots, blocks = [], []
             for s_ in range(nslot):
                 if packed:
-                    arrs = [rh.host_rows(PB, shp, dt) for shp, dt in (((H, W, 3), np.uint8), ((H, W), np.float32), ((cap,), hb.DROP_DTYPE),
+                    arrs = [rh.host_rows(PB, shp, dt) for shp, dt in (((H, W, 3), np.uint8), ((H, W), dtd), ((cap,), hb.DROP_DTYPE),
                                                                       ((H, W, 3), np.uint8), ((H, W), np.int32))]
                     blocks += [a[0] for a in arrs]
                     bg8s, deps, drs, ims, mks = [a[1] for a in arrs]
                 else:
                     bg8s = [rh.host_array((H, W, 3), np.uint8) for _ in range(PB)]
-                    deps = [rh.host_array((H, W), np.float32) for _ in range(PB)]
+                    deps = [rh.host_array((H, W), dtd) for _ in range(PB)]
                     drs = [rh.host_array((cap,), hb.DROP_DTYPE) for _ in range(PB)]
                     ims = [rh.host_array((H, W, 3), np.uint8) for _ in range(PB)]
                     mks = [rh.host_array((H, W), np.int32) for _ in range(PB)]
@@ -712,7 +717,7 @@ def main():
                 for k in range(PB):
                     i = (s_ * PB + k) % batch.n
                     bg8s[k][...] = (batch.host[i][0] * 255).astype(np.uint8)
-                    deps[k][...] = depth_h
+                    deps[k][...] = dval
                     nd = len(batch.host[i][2])
                     drs[k][:nd] = batch.host[i][2]
                     nds.append(nd)
@@ -755,20 +760,22 @@ def main():
                                ("hipMemcpyAsync, one per array and batch (frames back to back in one page-locked block per array)" if packed
                                 else "hipMemcpyAsync, one per frame and array (separate allocations)")),
                     "descriptors": "prepared once per slot" if prepared else "rebuilt in Python for every submission",
-                    "pcie_GBps": {"up": up * done / (h1 - h0) / 1e9, "down": down * done / (h1 - h0) / 1e9}}
+                    "depth_upload": "uint16 samples of the depth file (RR_DEPTH_U16)" if depth_u16 else "float32 metres",
+                    "pcie_bytes_per_frame": {"up": up_b, "down": down},
+                    "pcie_GBps": {"up": up_b * done / (h1 - h0) / 1e9, "down": down * done / (h1 - h0) / 1e9}}
         PB = max(1, min(args.pipe_batch, batch.n))
         hi = host_inclusive(PB)
-        hi["what"] = ("rr_pipeline_submit/wait, %d slots x %d frames, pinned host buffers (rr_host_alloc): PCIe up (u8 image + f32 depth + drop "
-                      "table), fog + environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask); PNG codec excluded"
+        hi["what"] = ("rr_pipeline_submit/wait, %d slots x %d frames, pinned host buffers (rr_host_alloc): PCIe up (u8 image + u16 depth samples "
+                      "+ drop table), fog + environment-map pre-pass + hot path on the device, PCIe down (u8 image + int32 mask); PNG codec excluded"
                       % (nslot, PB))
-        hi["pcie_bytes_per_frame"] = {"up": up, "down": down}
         extras["host_inclusive"] = hi
         if args.copy_sweep:
             extras["host_inclusive_copy_sweep"] = {"blocks_%s" % b: host_inclusive(PB, copy_kernels=int(b))["frames_per_s"] for b in args.copy_sweep.split(',')}
         if not args.no_variants:
             extras["host_inclusive_variants"] = {"slots_of_32": host_inclusive(min(32, batch.n)),
                                                  "slots_of_256": host_inclusive(min(256, batch.n)),
-                                                 "copy_kernels": host_inclusive(PB, copy_kernels=True)}
+                                                 "copy_kernels": host_inclusive(PB, copy_kernels=True),
+                                                 "depth_as_float32": host_inclusive(PB, depth_u16=False)}
             if args.more_variants:
                 extras["host_inclusive_variants"].update({"slots_of_64": host_inclusive(min(64, batch.n)),
                                                           "separate_allocations": host_inclusive(PB, packed=False),

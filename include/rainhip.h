@@ -210,6 +210,7 @@ int rr_synchronize(rr_ctx* ctx);
  * As with rr_camera, everything derived from transcendentals is computed once by the host. */
 #define RR_MAX_TAPS 33
 #define RR_PRE_ENV_ONLY 1
+#define RR_DEPTH_U16 2
 
 typedef struct {
   int32_t fog_ksize, env_ksize;   /* 25 (add_attenuation.py:79), 15 (bad_weather.py:815); odd, <= RR_MAX_TAPS */
@@ -221,7 +222,10 @@ typedef struct {
   int32_t H, W;
   const void* bg;                 /* H*W*3 BGR image / 255 (generator.py:352): float64, or -- in_types -- float32 (RR_IN_BG_F32), or the
                                    * bytes cv2.imread returned (RR_IN_BG_U8: bg = bytes / 255.0 is formed where the kernels read it) */
-  const void* depth;              /* H*W metres, float32 (depth_f64 == 0) or float64 (generator.py:362-383) */
+  const void* depth;              /* H*W metres, float32 (depth_f64 == 0) or float64 (1) (generator.py:362-383) -- or (RR_DEPTH_U16 = 2)
+                                   * the uint16 samples of the 16-bit depth PNG as cv2.imread(.., IMREAD_UNCHANGED) returns them:
+                                   * metres = sample.astype(float32) / 256 (generator.py:366) is formed where the kernels read it,
+                                   * half the upload of the float32 map.  Not with RR_OPT_DEPTH_OCCLUSION. */
   int32_t depth_f64;
   int32_t mode;                   /* 0: fog layer (+ the map if an output asks for it).  RR_PRE_ENV_ONLY (1), rr_prepass_frames*
                                    * only: `bg` IS the fogged image and only the map is made -- the stand-alone
@@ -498,6 +502,10 @@ int rr_inflate_fast(const uint8_t* in, int64_t n, uint8_t* out, int64_t out_len)
  *                       rows_mask + k * rows_stride to mask_paths[k] (either path array may be NULL) */
 int rr_io_read_frames(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
                       uint8_t* bg_u8, int64_t bg_stride, float* depth_f32, int64_t depth_stride, int32_t threads, int32_t* status);
+/*   rr_io_read_frames_u16  the same with the depth file's uint16 samples as they are (rr_prepass_in.depth_f64 = RR_DEPTH_U16) into
+ *                       depth_u16 + k * depth_stride (bytes): no conversion pass on the host, half the bytes over PCIe */
+int rr_io_read_frames_u16(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                          uint8_t* bg_u8, int64_t bg_stride, uint16_t* depth_u16, int64_t depth_stride, int32_t threads, int32_t* status);
 /*   rr_io_read_frames_scaled  the same for a render scale other than 1 (generator.py:352-381, the Cityscapes plug-in's
  *                       default): image / 255 resized (cv2.resize, INTER_LINEAR) to W x H = file size // render_scale as
  *                       float64 into bg_f64 + k * bg_stride (bytes), the depth map resized to

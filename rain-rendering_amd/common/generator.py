@@ -501,7 +501,12 @@ class Generator:
         u8 = rs == 1                                              # at render scale 1 the bytes go to the GPU; a resized image is float64
         bg_dtype = np.uint8 if u8 else np.float64
         ds = int(self.settings["depth_scale"])
-        key = (B, H, W, env_w, np.dtype(bg_dtype), np.dtype(np.float32), False)
+        # at render scale 1 the depth file's uint16 samples travel as they are (rr_prepass_in.depth_f64 = RR_DEPTH_U16: metres =
+        # sample / 256 in float32, generator.py:366, is formed on the device): half the depth bytes over PCIe, no conversion pass
+        # on the host.  RAIN_DEPTH_U16=0: float32 metres made by the host, as before.
+        d16 = u8 and os.environ.get('RAIN_DEPTH_U16', '1') != '0'
+        depth_dtype = np.uint16 if d16 else np.float32
+        key = (B, H, W, env_w, np.dtype(bg_dtype), np.dtype(depth_dtype), False)
         pkey = (tuple(float(v) for v in fog_const), float(self.opacity_attenuation), self.rendering_strategy, sims is not None)
         for d in {os.path.dirname(it[k]) for it in work for k in ('out_rainy_path', 'out_rainy_mask_path')}:
             os.makedirs(d, exist_ok=True)
@@ -513,7 +518,7 @@ class Generator:
             if sl is None or sl.key != key or sl.drops_cap < drops_cap:
                 if sl is not None:
                     sl.free(hip)
-                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, bg_dtype, np.float32, False, drops_cap)
+                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, bg_dtype, depth_dtype, False, drops_cap)
             if getattr(sl, 'prep', None) is None or sl.pkey != pkey:
                 frames = [dict(bg=None if u8 else sl.bg[k], bg_u8=sl.bg[k] if u8 else None, depth=sl.depth[k], fog=fog_const, omega=None, drops=sl.drops[k],
                                opacity_attenuation=self.opacity_attenuation, strategy=1 if self.rendering_strategy == 'white' else 0)
@@ -533,7 +538,7 @@ class Generator:
             """-> (frames of the batch in slot order, their drop counts): inputs of `sl` filled for the first len() frames."""
             if u8:
                 st = hip_backend.io_read_frames([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
-                                                sl.raw_bg, sl.raw_depth, threads)
+                                                sl.raw_bg, sl.raw_depth, threads, depth_u16=d16)
             else:
                 st = hip_backend.io_read_frames_scaled([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
                                                        int(rs), ds, sl.raw_bg, sl.raw_depth, threads)
@@ -553,7 +558,8 @@ class Generator:
                 bg, depth = loaded
                 assert bg.shape[:2] == (H, W) and bg.dtype == bg_dtype and depth.shape == (H, W), "frames of one sequence share their size"
                 np.copyto(sl.bg[k], bg)
-                np.copyto(sl.depth[k], depth.astype(np.float32))
+                # (a PNG depth map is sample / 256 in float32: the samples come back exactly)
+                np.copyto(sl.depth[k], np.rint(depth.astype(np.float64) * 256.0).astype(np.uint16) if d16 else depth.astype(np.float32))
             order = [k for k in range(len(items)) if ok[k]]
             for dst in [k for k in range(len(order)) if not ok[k]]:          # close the gaps of skipped frames from the back
                 src = order.pop()

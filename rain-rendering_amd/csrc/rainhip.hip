@@ -3937,8 +3937,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.status = out[f].drop_status;
     fd.png_image = out[f].rainy_png;
     fd.png_mask = out[f].mask_png;
+    if (ctx->depth_occlusion && in[f].depth && in[f].depth_f64 != 0 && in[f].depth_f64 != 1) {
+      ctx->err = "RR_OPT_DEPTH_OCCLUSION needs a float32 or float64 depth map";
+      return RR_E_ARG;
+    }
     fd.depth = ctx->depth_occlusion ? in[f].depth : nullptr;
-    fd.depth_f64 = in[f].depth_f64;
+    fd.depth_f64 = in[f].depth_f64 == 1 ? 1 : 0;
     fd.ext = in[f].ext;
     fd.colour_out = out[f].drop_colour;
     fd.n_drops_dev = in[f].n_drops_dev;
@@ -4241,6 +4245,10 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
       ctx->err = "pre-pass: null pointer or zero irradiance denominator (bg_u8 is for the host entry points only)";
       return RR_E_ARG;
     }
+    if (in[f].depth_f64 < 0 || in[f].depth_f64 > RR_DEPTH_U16) {
+      ctx->err = "pre-pass: depth_f64 is 0 (float32), 1 (float64) or RR_DEPTH_U16";
+      return RR_E_ARG;
+    }
     if ((in[f].in_types & ~(RR_IN_BG_F32 | RR_IN_BG_U8)) || in[f].in_types == (RR_IN_BG_F32 | RR_IN_BG_U8) ||
         (out[f].out_types & ~(RR_OUT_RAINY_F32 | RR_OUT_ENV_F32)) || out[f].out_types != out[0].out_types) {
       ctx->err = "pre-pass: in_types is RR_IN_BG_F32 or RR_IN_BG_U8 (or 0), out_types RR_OUT_* bits, the same for every frame";
@@ -4293,8 +4301,9 @@ int enqueue_prepass(rr_ctx* ctx, int n, const rr_prepass_in* in, const rr_prepas
     p.beta_hg = in[f].beta_hg;
     p.irr_num = in[f].irr_num;
     p.irr_den = in[f].irr_den;
-    p.depth_f64 = in[f].depth_f64;
-    p.types = ((in[f].in_types & RR_IN_BG_F32) ? rrpre::PRE_BG_F32 : 0) | ((in[f].in_types & RR_IN_BG_U8) ? rrpre::PRE_BG_U8 : 0) |
+    p.depth_f64 = in[f].depth_f64 == 1 ? 1 : 0;            // (uint16 samples become float32 metres: the float32 arithmetic)
+    p.types = (in[f].depth_f64 == RR_DEPTH_U16 ? rrpre::PRE_DEPTH_U16 : 0) |
+              ((in[f].in_types & RR_IN_BG_F32) ? rrpre::PRE_BG_F32 : 0) | ((in[f].in_types & RR_IN_BG_U8) ? rrpre::PRE_BG_U8 : 0) |
               ((out[f].out_types & RR_OUT_RAINY_F32) ? rrpre::PRE_RAINY_F32 : 0) | ((out[f].out_types & RR_OUT_ENV_F32) ? rrpre::PRE_ENV_F32 : 0);
   }
   hipLaunchKernelGGL(k_copy_small, dim3(16), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(h_pre), reinterpret_cast<uint32_t*>(ctx->d_pre),
@@ -5063,8 +5072,9 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   }
   if ((rc = slot_reserve(ctx, st, n, drop_stride ? drop_stride : max_drops, dm))) return rc;
   if (!drop_stride) drop_stride = st.drops_cap;
-  bool all_f32_depth = pre != nullptr || in != nullptr;
-  for (int f = 0; f < n; f++) all_f32_depth = all_f32_depth && !(pre ? pre[f].depth_f64 : in[f].depth_f64);
+  bool all_f32_depth = pre != nullptr || in != nullptr;     // (no float64 map in the batch: uint16 samples fit the float32 slots too)
+  for (int f = 0; f < n; f++) all_f32_depth = all_f32_depth && (pre ? pre[f].depth_f64 : in[f].depth_f64) != 1;
+  auto depth_el = [](int kind) { return kind == 1 ? (size_t)8 : (kind == RR_DEPTH_U16 ? (size_t)2 : (size_t)4); };
   const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We, png_bytes = (size_t)dm.H * (1 + 4 * (size_t)dm.W);
   const Strides T = strides_of(dm);
   // the depth slot: float32 maps of a batch lie 4 * H * W bytes (rounded to 16) apart, float64 ones (or a mix) 8 * H * W
@@ -5113,7 +5123,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     pin[f].depth = depth_at(f);
     up.add(const_cast<void*>(pin[f].bg), src, px * 3 * bg_el);
     const bool env_only = pre[f].mode == RR_PRE_ENV_ONLY;
-    if (!env_only) up.add((void*)pin[f].depth, pre[f].depth, px * (pre[f].depth_f64 ? 8 : 4));
+    if (!env_only) up.add((void*)pin[f].depth, pre[f].depth, px * depth_el(pre[f].depth_f64));
     pout[f].out_types = pre_types;
     pout[f].reserved = 0;
     pout[f].rainy_bg = st.rainy + f * T.px3d;
@@ -5132,8 +5142,12 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     din[f].omega = !in[f].omega ? nullptr : (same_omega ? din[0].omega : st.omega + f * T.exd);
     din[f].drops = st.drops + (size_t)f * drop_stride;
     if (pre) {                        // the pre-pass' depth buffer doubles as the occlusion depth
-      din[f].depth = depth_at(f);
-      din[f].depth_f64 = pre[f].depth_f64;
+      if (pre[f].depth_f64 == RR_DEPTH_U16 && ctx->depth_occlusion) {
+        ctx->err = "RR_OPT_DEPTH_OCCLUSION needs a float depth map (not RR_DEPTH_U16)";
+        return RR_E_ARG;
+      }
+      din[f].depth = pre[f].depth_f64 == RR_DEPTH_U16 ? nullptr : depth_at(f);
+      din[f].depth_f64 = pre[f].depth_f64 == 1 ? 1 : 0;
     } else if (in[f].depth && ctx->depth_occlusion) {
       up.add((void*)depth_at(f), in[f].depth, px * (in[f].depth_f64 ? 8 : 4));
       din[f].depth = depth_at(f);

@@ -1386,6 +1386,27 @@ extern "C" int rr_io_read_frames(int32_t n, const char* const* image_paths, cons
 
 // cv2.resize(img, (dw, dh)) for float images as the driver states it (common/imgops.resize_linear: INTER_LINEAR, half-pixel
 // centres, edge clamp, float64): source index and weight of every destination row / column ...
+extern "C" int rr_io_read_frames_u16(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                                     uint8_t* bg_u8, int64_t bg_stride, uint16_t* depth_u16, int64_t depth_stride, int32_t threads,
+                                     int32_t* status) {
+  if (n < 0 || H <= 0 || W <= 0 || !status || (n > 0 && (!image_paths || !bg_u8)) || (depth_paths && !depth_u16) ||
+      bg_stride < (int64_t)H * W * 3 || (depth_paths && depth_stride < (int64_t)H * W * 2))
+    return RR_E_ARG;
+  rrpar::parallel_for(n, threads, [&](int k) {
+    int rc;
+    try {
+      rc = image_paths[k] ? rr_png_read_bgr8_impl(image_paths[k], bg_u8 + (size_t)k * (size_t)bg_stride, H, W) : RR_E_ARG;
+      if (rc == RR_OK && depth_paths)     // the samples as cv2.imread(f, IMREAD_UNCHANGED) returns them; / 256 happens on the device
+        rc = depth_paths[k] ? rr_png_read_gray16_impl(depth_paths[k], reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(depth_u16) + (size_t)k * (size_t)depth_stride), H, W)
+                            : RR_E_ARG;
+    } catch (...) {
+      rc = RR_E_PARSE;
+    }
+    status[k] = rc;
+  });
+  return RR_OK;
+}
+
 static void linear_coords(int d, int s, std::vector<int32_t>& i0, std::vector<int32_t>& i1, std::vector<double>& w) {
   at_least(i0, (size_t)d);
   at_least(i1, (size_t)d);

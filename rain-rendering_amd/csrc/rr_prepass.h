@@ -35,11 +35,12 @@ struct Kernels {                    // passed by value to the kernels
 
 // element types of a frame's arrays (PreFrame.types).  The arithmetic is float64 whatever the types: a float32 output is
 // the float64 result rounded once, a uint8 image is bytes / 255.0 (generator.py:352) formed where it is read.
-enum { PRE_BG_F32 = 1, PRE_BG_U8 = 2, PRE_RAINY_F32 = 4, PRE_ENV_F32 = 8 };
+enum { PRE_BG_F32 = 1, PRE_BG_U8 = 2, PRE_RAINY_F32 = 4, PRE_ENV_F32 = 8, PRE_DEPTH_U16 = 16 };
 
 struct PreFrame {
   const void* bg;                   // H*W*3: float64, float32 (PRE_BG_F32) or uint8 (PRE_BG_U8)
-  const void* depth;                // H*W float32 or float64
+  const void* depth;                // H*W float32 or float64 metres, or (PRE_DEPTH_U16, depth_f64 == 0) the uint16 samples of the depth
+                                    // file: metres = sample / 256 in float32 (generator.py:366: exact, a power of two)
   void* rainy;                      // H*W*3: float64 or float32 (PRE_RAINY_F32)
   void* env_xyY;                    // H*We*3: float64 or float32 (PRE_ENV_F32) (may be null)
   uint8_t* env_u8;                  // H*We*3 BGR (may be null)
@@ -132,9 +133,12 @@ RRP_HD double fog_ext_val(const PreFrame& F, double d64, float d32) {
   const float t = d32 / 1000.0f;    // numpy keeps float32: float32 / int, weak python scalar * float32
   return (double)expf((float)(-F.beta_ext) * t);
 }
+RRP_HD float depth_f32_at(const PreFrame& F, int64_t p) {     // (depth_f64 == 0)
+  return (F.types & PRE_DEPTH_U16) ? (float)((const uint16_t*)F.depth)[p] / 256.0f : ((const float*)F.depth)[p];
+}
 RRP_HD void fog_ext_px(const PreFrame& F, int f, int H, int W, const PreScratch& sc, int64_t p) {
   const int64_t px = (int64_t)H * W;
-  sc.fext[f * px + p] = F.depth_f64 ? fog_ext_val(F, ((const double*)F.depth)[p], 0.0f) : fog_ext_val(F, 0.0, ((const float*)F.depth)[p]);
+  sc.fext[f * px + p] = F.depth_f64 ? fog_ext_val(F, ((const double*)F.depth)[p], 0.0f) : fog_ext_val(F, 0.0, depth_f32_at(F, p));
 }
 
 
@@ -514,7 +518,7 @@ __global__ void __launch_bounds__(256, 3) k_fog_tile(const PreFrame* fr, int H, 
       const int64_t p = T::stage_src(H, W, x0, hs, k, tid + 256 * u);
       if (p < 0) continue;
       if (F.depth_f64) d64[u] = ((const double*)F.depth)[p];
-      else d32[u] = ((const float*)F.depth)[p];
+      else d32[u] = depth_f32_at(F, p);
     }
   };
   fetch(0);

@@ -29,6 +29,7 @@ RR_OPT_PIPELINE_F32 = 13
 RR_OPT_WILD_PIXELS = 14
 RR_OPT_PNG_DEFLATE = 15
 RR_OUT_RAINY_F32, RR_OUT_ENV_F32 = 1, 2                 # rr_prepass_out.out_types
+RR_DEPTH_U16 = 2                                        # rr_prepass_in.depth_f64: the uint16 samples of the depth file (metres = sample / 256)
 RR_IN_BG_F32, RR_IN_BG_U8, RR_IN_ENV_F32, RR_IN_RAINY_F32, RR_IN_RAINY_U8 = 1, 2, 4, 8, 16      # rr_frame_in.in_types
 
 # numpy mirror of rr_drop (112 bytes)
@@ -121,7 +122,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
-           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_read_frames_scaled', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
+           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_read_frames_u16', 'rr_io_read_frames_scaled', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
            'rr_sizeof_sim_frame']
 
 _lib = None
@@ -192,6 +193,7 @@ def load_library(path=None):
                                         ctypes.c_int32, ctypes.c_void_p]
     lib.rr_io_read_frames.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
+    lib.rr_io_read_frames_u16.argtypes = lib.rr_io_read_frames.argtypes
     lib.rr_io_read_frames_scaled.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_void_p]
@@ -467,17 +469,19 @@ def pack_frames(tables, seeds, db, imW, imH, out_block, out_stride, cap, threads
     return counts
 
 
-def io_read_frames(image_paths, depth_paths, H, W, bg_block, depth_block, threads=0):
+def io_read_frames(image_paths, depth_paths, H, W, bg_block, depth_block, threads=0, depth_u16=False):
     """rr_io_read_frames into the frames-back-to-back blocks of RainHip.host_rows ((n, stride) uint8 arrays): frame k's
-    image bytes (B G R) at bg_block[k], its depth as float32 metres at depth_block[k].  Returns the per-frame status."""
+    image bytes (B G R) at bg_block[k], its depth as float32 metres at depth_block[k] -- or (depth_u16, rr_io_read_frames_u16)
+    the depth file's uint16 samples as they are (rr_prepass_in.depth_f64 = RR_DEPTH_U16).  Returns the per-frame status."""
     lib = load_library()
     n = len(image_paths)
     ip, k1 = _c_paths(image_paths)
     dp, k2 = _c_paths(depth_paths)
     status = np.zeros(n, np.int32)
     assert bg_block.dtype == np.uint8 and depth_block.dtype == np.uint8 and bg_block.shape[0] >= n and depth_block.shape[0] >= n
-    rc = lib.rr_io_read_frames(n, ip, dp, int(H), int(W), _ptr(bg_block), int(bg_block.strides[0]), _ptr(depth_block),
-                               int(depth_block.strides[0]), int(threads), _ptr(status))
+    fn = lib.rr_io_read_frames_u16 if depth_u16 else lib.rr_io_read_frames
+    rc = fn(n, ip, dp, int(H), int(W), _ptr(bg_block), int(bg_block.strides[0]), _ptr(depth_block),
+            int(depth_block.strides[0]), int(threads), _ptr(status))
     if rc != 0:
         raise RuntimeError("rr_io_read_frames failed (%d)" % rc)
     return status
@@ -900,12 +904,12 @@ class RainHip:
             bg = np.asarray(fr['bg'])
             bg = np.ascontiguousarray(bg, np.float32 if bg.dtype == np.float32 else np.float64)
             pin.bg, pin.bg_u8, pin.in_types = _ptr(bg), None, RR_IN_BG_F32 if bg.dtype == np.float32 else 0
-        depth = np.asarray(fr['depth'])
-        depth = np.ascontiguousarray(depth, np.float32 if depth.dtype == np.float32 else np.float64)
+        depth = np.asarray(fr['depth'])                        # float32 / float64 metres, or the uint16 samples of the depth file
+        depth = np.ascontiguousarray(depth, depth.dtype if depth.dtype in (np.float32, np.uint16) else np.float64)
         H, W = bg.shape[:2]
         assert bg.shape == (H, W, 3) and depth.shape == (H, W), (bg.shape, depth.shape)
         pin.H, pin.W, pin.depth = H, W, _ptr(depth)
-        pin.depth_f64 = 1 if depth.dtype == np.float64 else 0
+        pin.depth_f64 = 1 if depth.dtype == np.float64 else (RR_DEPTH_U16 if depth.dtype == np.uint16 else 0)
         pin.beta_ext, pin.beta_hg, pin.irr_num, pin.irr_den = [float(v) for v in fr['fog']]
         keep.append((bg, depth))
         return bg

@@ -308,7 +308,7 @@ int emu_prepass(int H, int W, const void* bg, const void* depth, int depth_f64, 
         for (int k = 0; k < n_iter; k++) {
           for (int i = 0; i < T::RB * T::PITCH; i++) {
             const int64_t p = T::stage_src(H, W, x0, hs, k, i);
-            T::stage_put(F, k3, i, depth_f64 ? ((const double*)depth)[p] : 0.0, depth_f64 ? 0.0f : ((const float*)depth)[p], S.data());
+            T::stage_put(F, k3, i, depth_f64 ? ((const double*)depth)[p] : 0.0, depth_f64 ? 0.0f : depth_f32_at(F, p), S.data());
           }
           for (int tid = 0; tid < 256; tid++) T::hpass(kn, depth_f64, k, tid, S.data(), ring.data());
           const int m = k - (T::NB - 1);

@@ -99,7 +99,9 @@ def test_native_route_feeds_the_library_what_the_general_route_does(tmp_path, bu
     a, b = by_identity(log_n), by_identity(log_g)
     assert a.keys() == b.keys() and len(a) == n - 1                 # the same frames (batches may order them differently)
     for key in a:
-        assert a[key]['depth'].dtype == np.float32 and np.array_equal(a[key]['depth'], b[key]['depth'])
+        # (the batch-native route hands over the depth file's uint16 samples, RR_DEPTH_U16: metres = sample / 256 on the device)
+        assert a[key]['depth'].dtype == np.uint16 and b[key]['depth'].dtype == np.float32
+        assert np.array_equal(a[key]['depth'].astype(np.float32) / np.float32(256.), b[key]['depth'])
         assert len(a[key]['drops']) > 20 and a[key]['drops'].tobytes() == b[key]['drops'].tobytes()
     # inputs against the loaders themselves, drop tables against pack_frame
     db = gen_n.db
@@ -109,7 +111,7 @@ def test_native_route_feeds_the_library_what_the_general_route_does(tmp_path, bu
             continue
         bg = imgops.imread_bgr(os.path.join(img_dir, '%06d.png' % i))
         fr = a[bg.tobytes()]
-        assert np.array_equal(fr['depth'], imgops.imread_unchanged(os.path.join(dep_dir, '%06d.png' % i)).astype(np.float32) / 256.)
+        assert np.array_equal(fr['depth'], imgops.imread_unchanged(os.path.join(dep_dir, '%06d.png' % i)))
         want = hb.pack_frame(tables[i % len(tables)].take(slice(None)), db, 80, 48, i)
         assert fr['drops'].tobytes() == want.tobytes(), i
     # every file from its own frame's scanlines, in both routes

@@ -230,3 +230,32 @@ def test_other_tap_counts_take_the_three_kernel_form(built):
         assert np.abs(o['rainy_bg'].astype(np.float64) - want[0]).max() < 3e-7
         assert np.abs(o['env_bgr_u8'].astype(int) - want[2].astype(int)).max() <= 1
     rh.close()
+
+
+def test_depth_samples_as_uint16_equal_the_float32_metres(tmp_path, built):
+    """RR_DEPTH_U16: the depth file's uint16 samples go to the device as they are (half the bytes of the float32 map) and
+    metres = sample / 256 (generator.py:366) is formed where the kernels read them: the pre-pass and the pipeline give the same
+    bits as with the float32 map the host would make."""
+    H, W = 96, 160
+    sc = h.Scene(tmp_path, H, W, 150, seed0=31)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    consts, We = _setup(rh, H, W, 25)
+    bg, _ = _scene(H, W, 31)
+    rng = np.random.RandomState(4)
+    d16 = (np.linspace(80, 2, H)[:, None] * np.ones((1, W)) * 256 + rng.uniform(0, 700, (H, W))).astype(np.uint16)
+    d32 = d16.astype(np.float32) / np.float32(256.)
+    a = rh.prepass_frames([dict(bg=bg, depth=d16, fog=consts)], want_env=True, want_env_u8=True)[0]
+    b = rh.prepass_frames([dict(bg=bg, depth=d32, fog=consts)], want_env=True, want_env_u8=True)[0]
+    for k in ('rainy_bg', 'env_xyY', 'env_bgr_u8'):
+        assert np.array_equal(a[k], b[k]), k
+    drops = sc.product_drops(0)
+    pa = rh.pipeline_frames([dict(bg_u8=(bg * 255).astype(np.uint8), depth=d16, fog=consts, omega=sc.omega, drops=drops)], want_rainy_bg=True)[0]
+    pb = rh.pipeline_frames([dict(bg_u8=(bg * 255).astype(np.uint8), depth=d32, fog=consts, omega=sc.omega, drops=drops)], want_rainy_bg=True)[0]
+    for k in ('image_u8', 'mask', 'mask_i32', 'status', 'fog_bg'):
+        assert np.array_equal(pa[k], pb[k]), k
+    rh.set_option(h.hb.RR_OPT_DEPTH_OCCLUSION, 1)                 # the occlusion option needs metres it can compare: float maps only
+    with pytest.raises(RuntimeError, match='float depth'):
+        rh.pipeline_frames([dict(bg_u8=(bg * 255).astype(np.uint8), depth=d16, fog=consts, omega=sc.omega, drops=drops)])
+    rh.close()

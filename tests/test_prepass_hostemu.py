@@ -21,7 +21,7 @@ def scene(H, W, seed, dtype=np.float32):
     return bg, depth
 
 
-PRE_BG_F32, PRE_BG_U8, PRE_RAINY_F32, PRE_ENV_F32 = 1, 2, 4, 8         # rrpre::PRE_* (csrc/rr_prepass.h)
+PRE_BG_F32, PRE_BG_U8, PRE_RAINY_F32, PRE_ENV_F32, PRE_DEPTH_U16 = 1, 2, 4, 8, 16         # rrpre::PRE_* (csrc/rr_prepass.h)
 
 
 def emu_prepass(bg, depth, rain, focal_m=0.006, f_number=6.0, exposure=2, gain=20, tiled=1, seg_rows=64, narrow=False, fog_taps=25):
@@ -42,6 +42,8 @@ def emu_prepass(bg, depth, rain, focal_m=0.006, f_number=6.0, exposure=2, gain=2
     bg = np.ascontiguousarray(bg)
     types = {np.dtype(np.float64): 0, np.dtype(np.float32): PRE_BG_F32, np.dtype(np.uint8): PRE_BG_U8}[bg.dtype]
     types |= (PRE_RAINY_F32 | PRE_ENV_F32) if narrow else 0
+    types |= PRE_DEPTH_U16 if depth.dtype == np.uint16 else 0
+    depth = np.ascontiguousarray(depth)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     emu.emu_prepass.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + \
         [ctypes.c_double] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
@@ -107,3 +109,19 @@ def test_host_constants_equal_oracle():
     cw, uniq, first = envmod.EnvironmentMapGenerator(0.006, 160, 96).device_tables(96, 160)
     ocw, ouniq, ofirst = op.env_geometry(0.006, 96, 160)
     assert cw == ocw and np.array_equal(uniq, ouniq) and np.array_equal(first, ofirst)
+
+
+def test_depth_samples_as_uint16_equal_the_float32_metres():
+    """rr_prepass_in.depth_f64 = RR_DEPTH_U16: the uint16 samples of the depth file, metres = sample / 256 in float32
+    (generator.py:366) formed where the kernels read them -- the same bits as the float32 map made by the host."""
+    H, W = 96, 160
+    bg, _ = scene(H, W, 9)
+    rng = np.random.RandomState(4)
+    d16 = (np.linspace(80, 2, H)[:, None] * np.ones((1, W)) * 256 + rng.uniform(0, 700, (H, W))).astype(np.uint16)
+    a = emu_prepass(bg, d16, 50)
+    b = emu_prepass(bg, d16.astype(np.float32) / np.float32(256.), 50)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    a = emu_prepass(bg, d16, 50, tiled=0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
