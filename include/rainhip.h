@@ -138,7 +138,7 @@ typedef struct {
   const struct rr_sim_frame* sim;
 } rr_frame_in;
 
-enum { RR_IN_BG_F32 = 1, RR_IN_BG_U8 = 2, RR_IN_ENV_F32 = 4, RR_IN_RAINY_F32 = 8, RR_IN_RAINY_U8 = 16 };
+enum { RR_IN_BG_F32 = 1, RR_IN_BG_U8 = 2, RR_IN_ENV_F32 = 4, RR_IN_RAINY_F32 = 8, RR_IN_RAINY_U8 = 16, RR_IN_BG_PNG_ROWS = 32 };
 
 typedef struct {
   uint8_t* rainy_rgb;             /* H*W*3 RGB: what plt.imsave(rainy_image) stores (generator.py:461-466), alpha omitted */
@@ -211,6 +211,7 @@ int rr_synchronize(rr_ctx* ctx);
 #define RR_MAX_TAPS 33
 #define RR_PRE_ENV_ONLY 1
 #define RR_DEPTH_U16 2
+#define RR_DEPTH_PNG_ROWS 3
 
 typedef struct {
   int32_t fog_ksize, env_ksize;   /* 25 (add_attenuation.py:79), 15 (bad_weather.py:815); odd, <= RR_MAX_TAPS */
@@ -236,7 +237,11 @@ typedef struct {
   double irr_num, irr_den;        /* 4*N**2  and  exposure_s*gain*pi                add_attenuation.py:51-54 */
   const uint8_t* bg_u8;           /* HOST entry points, kept from version 300: when set, the same as bg = bg_u8 with RR_IN_BG_U8
                                    * (1/8 of the PCIe traffic of the float64 image) */
-  int32_t in_types;               /* RR_IN_BG_F32 or RR_IN_BG_U8 (or 0: float64); the other RR_IN_* bits are not for the pre-pass */
+  int32_t in_types;               /* RR_IN_BG_F32 or RR_IN_BG_U8 (or 0: float64); the other RR_IN_* bits are not for the pre-pass.
+                                   * rr_pipeline_* / rr_prepass_frames (host pointers) also take RR_IN_BG_PNG_ROWS: `bg` holds the H rows of
+                                   * 1 + 3*W bytes an 8-bit RGB PNG's IDAT stream inflates to (filter type + filtered R G B bytes, as
+                                   * rr_io_read_frames_rows delivers them), and depth_f64 = RR_DEPTH_PNG_ROWS: `depth` holds the H rows of
+                                   * 1 + 2*W bytes of the 16-bit gray depth file; the filters are reversed on the device */
   int32_t reserved;
 } rr_prepass_in;
 
@@ -504,6 +509,15 @@ int rr_io_read_frames(int32_t n, const char* const* image_paths, const char* con
                       uint8_t* bg_u8, int64_t bg_stride, float* depth_f32, int64_t depth_stride, int32_t threads, int32_t* status);
 /*   rr_io_read_frames_u16  the same with the depth file's uint16 samples as they are (rr_prepass_in.depth_f64 = RR_DEPTH_U16) into
  *                       depth_u16 + k * depth_stride (bytes): no conversion pass on the host, half the bytes over PCIe */
+/*   rr_io_read_frames_rows  both files of a frame INFLATED ONLY: image_rows + k * image_stride receives H rows of 1 + 3*W bytes (filter
+ *                       type + filtered R G B bytes) of the 8-bit RGB image, depth_rows + k * depth_stride H rows of 1 + 2*W
+ *                       bytes of the 16-bit gray depth file -- what rr_prepass_in takes with RR_IN_BG_PNG_ROWS /
+ *                       RR_DEPTH_PNG_ROWS: the scanline filters are reversed on the device (csrc/rr_pngrows.h), 40 % of the
+ *                       host's decode time.  A file of another kind that the readers above accept is decoded on the host
+ *                       and handed over as rows of filter type 0. */
+int rr_io_read_frames_rows(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                           uint8_t* image_rows, int64_t image_stride, uint8_t* depth_rows, int64_t depth_stride, int32_t threads,
+                           int32_t* status);
 int rr_io_read_frames_u16(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
                           uint8_t* bg_u8, int64_t bg_stride, uint16_t* depth_u16, int64_t depth_stride, int32_t threads, int32_t* status);
 /*   rr_io_read_frames_scaled  the same for a render scale other than 1 (generator.py:352-381, the Cityscapes plug-in's

@@ -35,6 +35,7 @@
 #include "rr_device.h"
 #include "rr_prepass.h"
 #include "rr_deflate.h"
+#include "rr_pngrows.h"
 #include "rr_particles.h"
 
 using namespace rr;
@@ -3155,6 +3156,75 @@ __global__ __launch_bounds__(256) void k_png_mask(const FrameDesc* frames, Dims 
   for (int k = 0; k < 4; k++) o[k] = (uint8_t)(((c >> (8 * k)) & 0xffu) - ((l >> (8 * k)) & 0xffu));
 }
 
+// The scanline filters of an INPUT file reversed (rr_pngrows.h): one wave per file, 64 consecutive rows at a time, lane l on
+// row r0 + l one pixel behind lane l - 1.  At step s lane l reconstructs pixel x = s - l: its left neighbour is its own last
+// output, its upper neighbour what lane l - 1 produced a step ago (a wave shuffle; for lane 0 the last row of the previous 64,
+// kept in LDS by lane 63), its upper-left neighbour the upper one of its previous step.  The filtered bytes of the next step
+// are loaded a step ahead.  BPP 3: R G B bytes -> the B G R uint8 image; BPP 2: big-endian samples -> uint16.
+template <int BPP>
+__global__ __launch_bounds__(64) void k_png_unfilter(const uint8_t* rows_base, int64_t rows_stride, uint8_t* out_base, int64_t out_stride, int H, int W) {
+  extern __shared__ uint8_t unf_prev[];                 // BPP * W: the row above the wave's first one
+  const int lane = threadIdx.x;
+  const uint8_t* rows = rows_base + (int64_t)blockIdx.x * rows_stride;
+  uint8_t* out = out_base + (int64_t)blockIdx.x * out_stride;
+  const int64_t RB = 1 + (int64_t)BPP * W;
+  for (int r0 = 0; r0 < H; r0 += 64) {
+    const int r = r0 + lane;
+    const bool valid = r < H;
+    const uint8_t* row = rows + (int64_t)(valid ? r : 0) * RB;
+    const int ft = valid ? (int)row[0] : 0;
+    int left[BPP], upl[BPP], cur[BPP], nxt[BPP];
+#pragma unroll
+    for (int c = 0; c < BPP; c++) left[c] = upl[c] = cur[c] = nxt[c] = 0;
+    if (valid && lane == 0) {
+#pragma unroll
+      for (int c = 0; c < BPP; c++) nxt[c] = row[1 + c];
+    }
+    for (int s = 0; s < W + 63; s++) {
+      const int x = s - lane;
+      const bool active = valid && x >= 0 && x < W;
+      int f[BPP], up[BPP];
+#pragma unroll
+      for (int c = 0; c < BPP; c++) {
+        f[c] = nxt[c];
+        up[c] = __shfl_up(cur[c], 1);                     // lane l - 1 at pixel x, one step ago
+      }
+      if (lane == 0 && active) {
+#pragma unroll
+        for (int c = 0; c < BPP; c++) up[c] = r0 > 0 ? (int)unf_prev[x * BPP + c] : 0;
+      }
+      {                                                   // the filtered bytes of the next step (pixel x + 1)
+        const int xn = x + 1;
+        if (valid && xn >= 0 && xn < W) {
+#pragma unroll
+          for (int c = 0; c < BPP; c++) nxt[c] = row[1 + (int64_t)xn * BPP + c];
+        }
+      }
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < BPP; c++) {
+          const int o = rrrows::png_unfilter_byte(ft, f[c], left[c], up[c], upl[c]);
+          upl[c] = up[c];
+          left[c] = o;
+          cur[c] = o;
+        }
+        if (BPP == 3) {
+          uint8_t* o = out + ((int64_t)r * W + x) * 3;
+          o[0] = (uint8_t)cur[2];
+          o[1] = (uint8_t)cur[1];
+          o[2] = (uint8_t)cur[0];
+        } else {
+          reinterpret_cast<uint16_t*>(out)[(int64_t)r * W + x] = (uint16_t)((cur[0] << 8) | cur[1]);
+        }
+        if (lane == 63) {
+#pragma unroll
+          for (int c = 0; c < BPP; c++) unf_prev[x * BPP + c] = (uint8_t)cur[c];
+        }
+      }
+    }
+  }
+}
+
 // RR_OPT_PNG_DEFLATE: the scanlines of both files become the zlib streams of their IDAT chunks on the device (rr_deflate.h).
 // k_pngz_blocks: one workgroup of 512 threads per 32 KB block of a file's scanlines (grid: blocks x files; file = 2 * frame +
 // {image, mask}); its working set (the block, its compressed form, the code tables: 76 KB) is dynamic LDS.  The compressed block goes to the
@@ -4982,9 +5052,18 @@ int validate_host_batch(rr_ctx* ctx, int n, const rr_prepass_in* pre, const rr_f
         ctx->err = "null pre-pass pointer or zero irradiance denominator";
         return RR_E_ARG;
       }
-      if ((pre[f].in_types & ~(RR_IN_BG_F32 | RR_IN_BG_U8)) || pre[f].in_types == (RR_IN_BG_F32 | RR_IN_BG_U8) ||
+      const int bgk = pre[f].in_types & (RR_IN_BG_F32 | RR_IN_BG_U8 | RR_IN_BG_PNG_ROWS);
+      if ((pre[f].in_types & ~(RR_IN_BG_F32 | RR_IN_BG_U8 | RR_IN_BG_PNG_ROWS)) || (bgk & (bgk - 1)) ||
           (pre_out && ((pre_out[f].out_types & ~(RR_OUT_RAINY_F32 | RR_OUT_ENV_F32)) || pre_out[f].out_types != pre_out[0].out_types))) {
-        ctx->err = "pre-pass: in_types is RR_IN_BG_F32 or RR_IN_BG_U8 (or 0), out_types RR_OUT_* bits, the same for every frame";
+        ctx->err = "pre-pass: in_types is ONE of RR_IN_BG_F32 / RR_IN_BG_U8 / RR_IN_BG_PNG_ROWS (or 0), out_types RR_OUT_* bits, the same for every frame";
+        return RR_E_ARG;
+      }
+      // files handed over as filtered scanlines (rr_io_read_frames_rows): for every frame of the batch or for none (one launch
+      // of the un-filter kernel per kind of file), and not in the map-only mode (its image is any float image)
+      if (((pre[f].in_types ^ pre[0].in_types) & RR_IN_BG_PNG_ROWS) || ((pre[f].depth_f64 == RR_DEPTH_PNG_ROWS) != (pre[0].depth_f64 == RR_DEPTH_PNG_ROWS)) ||
+          (env_only && ((pre[f].in_types & RR_IN_BG_PNG_ROWS) || pre[f].depth_f64 == RR_DEPTH_PNG_ROWS)) ||
+          ((pre[f].in_types & RR_IN_BG_PNG_ROWS) && pre[f].bg_u8) || pre[f].depth_f64 < 0 || pre[f].depth_f64 > RR_DEPTH_PNG_ROWS) {
+        ctx->err = "pre-pass: PNG scanlines (RR_IN_BG_PNG_ROWS / RR_DEPTH_PNG_ROWS) for every frame of a batch or for none, not with bg_u8 or RR_PRE_ENV_ONLY";
         return RR_E_ARG;
       }
       if (!in && !env_only && !pre_out[f].rainy_bg) {
@@ -5073,7 +5152,7 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   if ((rc = slot_reserve(ctx, st, n, drop_stride ? drop_stride : max_drops, dm))) return rc;
   if (!drop_stride) drop_stride = st.drops_cap;
   bool all_f32_depth = pre != nullptr || in != nullptr;     // (no float64 map in the batch: uint16 samples fit the float32 slots too)
-  for (int f = 0; f < n; f++) all_f32_depth = all_f32_depth && (pre ? pre[f].depth_f64 : in[f].depth_f64) != 1;
+  for (int f = 0; f < n; f++) all_f32_depth = all_f32_depth && (pre ? pre[f].depth_f64 : in[f].depth_f64) != 1;      // (RR_DEPTH_PNG_ROWS becomes uint16 samples)
   auto depth_el = [](int kind) { return kind == 1 ? (size_t)8 : (kind == RR_DEPTH_U16 ? (size_t)2 : (size_t)4); };
   const size_t px = (size_t)dm.H * dm.W, ex = (size_t)dm.He * dm.We, png_bytes = (size_t)dm.H * (1 + 4 * (size_t)dm.W);
   const Strides T = strides_of(dm);
@@ -5116,14 +5195,23 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     pin[f] = pre[f];
     // the image in the caller's element type: bytes stay bytes (bg = bytes / 255.0 is formed where a kernel reads it)
     const void* src = pre[f].bg_u8 ? (const void*)pre[f].bg_u8 : pre[f].bg;
-    pin[f].in_types = pre[f].bg_u8 ? RR_IN_BG_U8 : pre[f].in_types;
+    const bool rows_i = (pre[f].in_types & RR_IN_BG_PNG_ROWS) != 0, rows_d = pre[f].depth_f64 == RR_DEPTH_PNG_ROWS;
+    pin[f].in_types = (pre[f].bg_u8 || rows_i) ? RR_IN_BG_U8 : pre[f].in_types;
     const size_t bg_el = (pin[f].in_types & RR_IN_BG_U8) ? 1 : ((pin[f].in_types & RR_IN_BG_F32) ? 4 : 8);
     pin[f].bg = bg_el == 1 ? (const void*)(st.bg8 + f * T.px3b) : (const void*)(st.bg + f * T.px3d);
     pin[f].bg_u8 = nullptr;
     pin[f].depth = depth_at(f);
-    up.add(const_cast<void*>(pin[f].bg), src, px * 3 * bg_el);
+    // a file's filtered scanlines (k_png_unfilter makes the image bytes / the depth samples of them before the pre-pass) wait in
+    // the frame's fog-layer / composite slots: free until the pre-pass / the compositor write them
+    if (rows_i) up.add(st.rainy + f * T.px3d, src, (size_t)dm.H * (1 + 3 * (size_t)dm.W));
+    else up.add(const_cast<void*>(pin[f].bg), src, px * 3 * bg_el);
     const bool env_only = pre[f].mode == RR_PRE_ENV_ONLY;
-    if (!env_only) up.add((void*)pin[f].depth, pre[f].depth, px * depth_el(pre[f].depth_f64));
+    if (rows_d) {
+      up.add(st.comp + f * T.px3d, pre[f].depth, (size_t)dm.H * (1 + 2 * (size_t)dm.W));
+      pin[f].depth_f64 = RR_DEPTH_U16;
+    } else if (!env_only) {
+      up.add((void*)pin[f].depth, pre[f].depth, px * depth_el(pre[f].depth_f64));
+    }
     pout[f].out_types = pre_types;
     pout[f].reserved = 0;
     pout[f].rainy_bg = st.rainy + f * T.px3d;
@@ -5142,11 +5230,11 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     din[f].omega = !in[f].omega ? nullptr : (same_omega ? din[0].omega : st.omega + f * T.exd);
     din[f].drops = st.drops + (size_t)f * drop_stride;
     if (pre) {                        // the pre-pass' depth buffer doubles as the occlusion depth
-      if (pre[f].depth_f64 == RR_DEPTH_U16 && ctx->depth_occlusion) {
-        ctx->err = "RR_OPT_DEPTH_OCCLUSION needs a float depth map (not RR_DEPTH_U16)";
+      if (pre[f].depth_f64 >= RR_DEPTH_U16 && ctx->depth_occlusion) {
+        ctx->err = "RR_OPT_DEPTH_OCCLUSION needs a float depth map (not RR_DEPTH_U16 / RR_DEPTH_PNG_ROWS)";
         return RR_E_ARG;
       }
-      din[f].depth = pre[f].depth_f64 == RR_DEPTH_U16 ? nullptr : depth_at(f);
+      din[f].depth = pre[f].depth_f64 >= RR_DEPTH_U16 ? nullptr : depth_at(f);
       din[f].depth_f64 = pre[f].depth_f64 == 1 ? 1 : 0;
     } else if (in[f].depth && ctx->depth_occlusion) {
       up.add((void*)depth_at(f), in[f].depth, px * (in[f].depth_f64 ? 8 : 4));
@@ -5234,6 +5322,15 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
     return drained(RR_E_HIP);
   }
   // ---- compute ----
+  if (pre && ((pre[0].in_types & RR_IN_BG_PNG_ROWS) || pre[0].depth_f64 == RR_DEPTH_PNG_ROWS)) {
+    ProfScope ps(ctx, s, "k_png_unfilter");
+    if (pre[0].in_types & RR_IN_BG_PNG_ROWS)
+      hipLaunchKernelGGL(k_png_unfilter<3>, dim3(n), dim3(64), 3 * (size_t)dm.W, s, reinterpret_cast<const uint8_t*>(st.rainy), (int64_t)(T.px3d * 8),
+                         st.bg8, (int64_t)T.px3b, dm.H, dm.W);
+    if (pre[0].depth_f64 == RR_DEPTH_PNG_ROWS)
+      hipLaunchKernelGGL(k_png_unfilter<2>, dim3(n), dim3(64), 2 * (size_t)dm.W, s, reinterpret_cast<const uint8_t*>(st.comp), (int64_t)(T.px3d * 8),
+                         reinterpret_cast<uint8_t*>(st.depth), (int64_t)depth_stride, dm.H, dm.W);
+  }
   if (pre && (rc = enqueue_prepass(ctx, n, pin.data(), pout.data(), s))) return drained(rc);
   if (!sims.empty() && (rc = enqueue_particles(ctx, n, sims.data(), dm.H, dm.W, st.drops, drop_stride, st.ndrops, s))) return drained(rc);
   if (in) {                           // the slot's own overflow flag, cleared in stream order before the batch's k_scan may set it

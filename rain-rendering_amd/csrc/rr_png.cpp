@@ -749,15 +749,14 @@ struct DecodeScratch {
 };
 Pool<DecodeScratch> g_decode_pool;
 
-// inflate + reverse the scanline filters: sc.img = h rows of `stride` bytes
-int decode(const Png& p, DecodeScratch& sc, size_t& stride) {
+// inflate: sc.raw = h rows of 1 + `stride` bytes, the filter type of a row in front of its filtered bytes
+int inflate_rows(const Png& p, DecodeScratch& sc, size_t& stride) {
   const int ch = channels_of(p.ctype);
   if (!ch || p.interlace || (p.depth != 8 && p.depth != 16) || (p.ctype == 3 && p.depth != 8)) return RR_E_UNSUPPORTED;
   const size_t bpp = (size_t)ch * p.depth / 8;
   stride = (size_t)p.w * bpp;
   const size_t raw_len = (stride + 1) * p.h;
   std::vector<uint8_t>& raw = sc.raw;
-  std::vector<uint8_t>& img = sc.img;
   at_least(raw, raw_len + 16);                          // (spare bytes: the fast decoder copies matches in 8-byte pieces)
   {
     // (it also loads 8 bytes at a time; between two of its bound checks a malformed stream can pull the read position up
@@ -771,6 +770,17 @@ int decode(const Png& p, DecodeScratch& sc, size_t& stride) {
       if (uncompress(raw.data(), &out_len, p.idat.data(), (uLong)p.idat.size()) != Z_OK || out_len != raw_len) return RR_E_PARSE;
     }
   }
+  return RR_OK;
+}
+
+// inflate + reverse the scanline filters: sc.img = h rows of `stride` bytes
+int decode(const Png& p, DecodeScratch& sc, size_t& stride) {
+  int rc = inflate_rows(p, sc, stride);
+  if (rc) return rc;
+  const int ch = channels_of(p.ctype);
+  const size_t bpp = (size_t)ch * p.depth / 8;
+  std::vector<uint8_t>& raw = sc.raw;
+  std::vector<uint8_t>& img = sc.img;
   at_least(img, stride * p.h + 16);                    // (16 spare bytes: the Paeth rows store whole words)
   if (sc.zero.size() < stride + 16) sc.zero.assign(stride + 16 + stride / 8, 0);      // the row above the first one, never written
   const std::vector<uint8_t>& zero = sc.zero;
@@ -1399,6 +1409,74 @@ extern "C" int rr_io_read_frames_u16(int32_t n, const char* const* image_paths, 
       if (rc == RR_OK && depth_paths)     // the samples as cv2.imread(f, IMREAD_UNCHANGED) returns them; / 256 happens on the device
         rc = depth_paths[k] ? rr_png_read_gray16_impl(depth_paths[k], reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(depth_u16) + (size_t)k * (size_t)depth_stride), H, W)
                             : RR_E_ARG;
+    } catch (...) {
+      rc = RR_E_PARSE;
+    }
+    status[k] = rc;
+  });
+  return RR_OK;
+}
+
+// One file as filtered scanlines for the device (rr_io_read_frames_rows): H rows of 1 + bpp * W bytes.  A file of exactly the
+// expected kind (8-bit RGB for bpp 3, 16-bit gray for bpp 2; not interlaced) hands over what its IDAT stream inflates to,
+// filter types checked; any other file the readers above accept is decoded here and laid out as rows of filter type 0 in
+// PNG sample order (R G B / big-endian), so that the device sees one format.
+static int read_rows_impl(const char* path, uint8_t* rows, int32_t H, int32_t W, int bpp) {
+  if (!path || !rows) return RR_E_ARG;
+  const size_t rb = 1 + (size_t)bpp * W;
+  {
+    Pool<DecodeScratch>::Lease sc(g_decode_pool);
+    size_t fsize = 0;
+    int rc = read_file(path, sc->file, fsize);
+    if (rc) return rc;
+    Png& p = sc->png;
+    if ((rc = parse_chunks(sc->file, fsize, p, true))) return rc;
+    if ((int32_t)p.w != W || (int32_t)p.h != H) return RR_E_ARG;
+    const bool native = !p.interlace && ((bpp == 3 && p.ctype == 2 && p.depth == 8) || (bpp == 2 && p.ctype == 0 && p.depth == 16));
+    if (native) {
+      size_t stride = 0;
+      if ((rc = inflate_rows(p, *sc, stride))) return rc;
+      const uint8_t* raw = sc->raw.data();
+      for (int y = 0; y < H; y++)
+        if (raw[rb * (size_t)y] > 4) return RR_E_PARSE;
+      memcpy(rows, raw, rb * (size_t)H);
+      return RR_OK;
+    }
+  }
+  if (bpp == 3) {
+    std::vector<uint8_t> bgr((size_t)H * W * 3);
+    int rc = rr_png_read_bgr8_impl(path, bgr.data(), H, W);
+    if (rc) return rc;
+    for (int y = 0; y < H; y++) {
+      uint8_t* o = rows + rb * (size_t)y;
+      const uint8_t* s = &bgr[(size_t)y * W * 3];
+      *o++ = 0;
+      for (int x = 0; x < W; x++, s += 3, o += 3) { o[0] = s[2]; o[1] = s[1]; o[2] = s[0]; }
+    }
+    return RR_OK;
+  }
+  std::vector<uint16_t> d16((size_t)H * W);
+  int rc = rr_png_read_gray16_impl(path, d16.data(), H, W);
+  if (rc) return rc;
+  for (int y = 0; y < H; y++) {
+    uint8_t* o = rows + rb * (size_t)y;
+    *o++ = 0;
+    for (int x = 0; x < W; x++, o += 2) { const uint16_t v = d16[(size_t)y * W + x]; o[0] = (uint8_t)(v >> 8); o[1] = (uint8_t)v; }
+  }
+  return RR_OK;
+}
+
+extern "C" int rr_io_read_frames_rows(int32_t n, const char* const* image_paths, const char* const* depth_paths, int32_t H, int32_t W,
+                                      uint8_t* image_rows, int64_t image_stride, uint8_t* depth_rows, int64_t depth_stride, int32_t threads,
+                                      int32_t* status) {
+  if (n < 0 || H <= 0 || W <= 0 || !status || (n > 0 && (!image_paths || !image_rows)) || (depth_paths && !depth_rows) ||
+      image_stride < (int64_t)H * (1 + 3 * (int64_t)W) || (depth_paths && depth_stride < (int64_t)H * (1 + 2 * (int64_t)W)))
+    return RR_E_ARG;
+  rrpar::parallel_for(n, threads, [&](int k) {
+    int rc;
+    try {
+      rc = image_paths[k] ? read_rows_impl(image_paths[k], image_rows + (size_t)k * (size_t)image_stride, H, W, 3) : RR_E_ARG;
+      if (rc == RR_OK && depth_paths) rc = depth_paths[k] ? read_rows_impl(depth_paths[k], depth_rows + (size_t)k * (size_t)depth_stride, H, W, 2) : RR_E_ARG;
     } catch (...) {
       rc = RR_E_PARSE;
     }

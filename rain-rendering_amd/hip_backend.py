@@ -29,6 +29,7 @@ RR_OPT_PIPELINE_F32 = 13
 RR_OPT_WILD_PIXELS = 14
 RR_OPT_PNG_DEFLATE = 15
 RR_OUT_RAINY_F32, RR_OUT_ENV_F32 = 1, 2                 # rr_prepass_out.out_types
+RR_IN_BG_PNG_ROWS, RR_DEPTH_PNG_ROWS = 32, 3              # a file's filtered scanlines (rr_io_read_frames_rows): un-filtered on the device
 RR_DEPTH_U16 = 2                                        # rr_prepass_in.depth_f64: the uint16 samples of the depth file (metres = sample / 256)
 RR_IN_BG_F32, RR_IN_BG_U8, RR_IN_ENV_F32, RR_IN_RAINY_F32, RR_IN_RAINY_U8 = 1, 2, 4, 8, 16      # rr_frame_in.in_types
 
@@ -122,7 +123,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
-           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_read_frames_u16', 'rr_io_read_frames_scaled', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
+           'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_read_frames_u16', 'rr_io_read_frames_rows', 'rr_io_read_frames_scaled', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
            'rr_sizeof_sim_frame']
 
 _lib = None
@@ -194,6 +195,7 @@ def load_library(path=None):
     lib.rr_io_read_frames.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
     lib.rr_io_read_frames_u16.argtypes = lib.rr_io_read_frames.argtypes
+    lib.rr_io_read_frames_rows.argtypes = lib.rr_io_read_frames.argtypes
     lib.rr_io_read_frames_scaled.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_void_p]
@@ -487,6 +489,35 @@ def io_read_frames(image_paths, depth_paths, H, W, bg_block, depth_block, thread
     return status
 
 
+def io_read_frames_rows(image_paths, depth_paths, H, W, image_rows_block, depth_rows_block, threads=0):
+    """rr_io_read_frames_rows: both files of every frame inflated only -- image_rows_block[k] receives the H rows of 1 + 3 W
+    bytes (filter type + filtered R G B bytes) of frame k's image, depth_rows_block[k] the H rows of 1 + 2 W bytes of its
+    16-bit depth file (rr_prepass_in: RR_IN_BG_PNG_ROWS / RR_DEPTH_PNG_ROWS; the filters are reversed on the device)."""
+    lib = load_library()
+    n = len(image_paths)
+    ip, k1 = _c_paths(image_paths)
+    dp, k2 = _c_paths(depth_paths)
+    status = np.zeros(n, np.int32)
+    assert image_rows_block.dtype == np.uint8 and depth_rows_block.dtype == np.uint8 and image_rows_block.shape[0] >= n and depth_rows_block.shape[0] >= n
+    rc = lib.rr_io_read_frames_rows(n, ip, dp, int(H), int(W), _ptr(image_rows_block), int(image_rows_block.strides[0]), _ptr(depth_rows_block),
+                                    int(depth_rows_block.strides[0]), int(threads), _ptr(status))
+    if rc != 0:
+        raise RuntimeError("rr_io_read_frames_rows failed (%d)" % rc)
+    return status
+
+
+def png_rows_of(samples):
+    """An array of samples as PNG scanlines of filter type 0: (H, W, 3) uint8 B G R -> H rows of 1 + 3 W bytes (R G B);
+    (H, W) uint16 -> H rows of 1 + 2 W bytes (big-endian).  What a frame that the row reader did not take is handed over as."""
+    a = np.asarray(samples)
+    H, W = a.shape[:2]
+    if a.ndim == 3:
+        body = np.ascontiguousarray(a[..., ::-1], np.uint8).reshape(H, 3 * W)
+    else:
+        body = np.ascontiguousarray(a, np.uint16).astype('>u2').view(np.uint8).reshape(H, 2 * W)
+    return np.concatenate([np.zeros((H, 1), np.uint8), body], axis=1).reshape(-1)
+
+
 def io_read_frames_scaled(image_paths, depth_paths, H, W, render_scale, depth_scale, bg_block, depth_block, threads=0):
     """rr_io_read_frames_scaled: like io_read_frames for a render scale other than 1 -- bg_block[k] receives the resized
     float64 image (H x W x 3, B G R, in [0, 1]), depth_block[k] the float32 depth map (H x W)."""
@@ -629,7 +660,7 @@ class RainHip:
         prepares once per slot and calls pipeline_submit_prepared (the per-frame Python work is what bounds a fast GPU);
         Prepared.set_drop_count(k, n) adjusts a frame's drop count in place."""
         n = len(frames)
-        with_pre = 'depth' in frames[0]
+        with_pre = 'depth' in frames[0] or 'depth_png_rows' in frames[0]
         pin = (rr_prepass_in * n)() if with_pre else None
         fin = (rr_frame_in * n)()
         fout = (rr_frame_out * n)()
@@ -897,19 +928,31 @@ class RainHip:
     def _fill_prepass(pin, fr, keep):
         """fr['bg']: the image / 255 as float64 (or float32: taken as it is, rr_prepass_in.in_types), or fr['bg_u8'] = the
         uint8 BGR image (bg = bg_u8 / 255.0 is formed on the device)."""
-        if fr.get('bg_u8') is not None:
+        if fr.get('bg_png_rows') is not None:              # H rows of 1 + 3 W bytes: an 8-bit RGB PNG inflated, not un-filtered; 'shape' = (H, W)
+            rows = np.ascontiguousarray(fr['bg_png_rows'], np.uint8).reshape(-1)
+            H, W = fr['shape']
+            assert rows.size == H * (1 + 3 * W), (rows.size, H, W)
+            pin.bg, pin.bg_u8, pin.in_types = _ptr(rows), None, RR_IN_BG_PNG_ROWS
+            bg = np.empty((H, W, 3), np.uint8)              # (only its shape is used by the callers)
+            keep.append(rows)
+        elif fr.get('bg_u8') is not None:
             bg = np.ascontiguousarray(fr['bg_u8'], np.uint8)
             pin.bg, pin.bg_u8, pin.in_types = None, _ptr(bg), 0
         else:
             bg = np.asarray(fr['bg'])
             bg = np.ascontiguousarray(bg, np.float32 if bg.dtype == np.float32 else np.float64)
             pin.bg, pin.bg_u8, pin.in_types = _ptr(bg), None, RR_IN_BG_F32 if bg.dtype == np.float32 else 0
-        depth = np.asarray(fr['depth'])                        # float32 / float64 metres, or the uint16 samples of the depth file
-        depth = np.ascontiguousarray(depth, depth.dtype if depth.dtype in (np.float32, np.uint16) else np.float64)
         H, W = bg.shape[:2]
-        assert bg.shape == (H, W, 3) and depth.shape == (H, W), (bg.shape, depth.shape)
-        pin.H, pin.W, pin.depth = H, W, _ptr(depth)
-        pin.depth_f64 = 1 if depth.dtype == np.float64 else (RR_DEPTH_U16 if depth.dtype == np.uint16 else 0)
+        if fr.get('depth_png_rows') is not None:            # H rows of 1 + 2 W bytes: the 16-bit depth PNG inflated, not un-filtered
+            depth = np.ascontiguousarray(fr['depth_png_rows'], np.uint8).reshape(-1)
+            assert depth.size == H * (1 + 2 * W), (depth.size, H, W)
+            pin.H, pin.W, pin.depth, pin.depth_f64 = H, W, _ptr(depth), RR_DEPTH_PNG_ROWS
+        else:
+            depth = np.asarray(fr['depth'])                    # float32 / float64 metres, or the uint16 samples of the depth file
+            depth = np.ascontiguousarray(depth, depth.dtype if depth.dtype in (np.float32, np.uint16) else np.float64)
+            assert bg.shape == (H, W, 3) and depth.shape == (H, W), (bg.shape, depth.shape)
+            pin.H, pin.W, pin.depth = H, W, _ptr(depth)
+            pin.depth_f64 = 1 if depth.dtype == np.float64 else (RR_DEPTH_U16 if depth.dtype == np.uint16 else 0)
         pin.beta_ext, pin.beta_hg, pin.irr_num, pin.irr_den = [float(v) for v in fr['fog']]
         keep.append((bg, depth))
         return bg

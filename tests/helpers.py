@@ -49,7 +49,7 @@ _emu = None
 def build_hostemu():
     src = os.path.join(ROOT, 'tests', 'hostemu', 'hostemu.cpp')
     out = os.path.join(ROOT, 'tests', 'hostemu', 'libhostemu.so')
-    hdrs = [os.path.join(ROOT, 'rain-rendering_amd', 'csrc', h) for h in ('rr_device.h', 'rr_prepass.h', 'rr_deflate.h')]
+    hdrs = [os.path.join(ROOT, 'rain-rendering_amd', 'csrc', h) for h in ('rr_device.h', 'rr_prepass.h', 'rr_deflate.h', 'rr_pngrows.h')]
     if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
                                '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'rain-rendering_amd', 'csrc'),

@@ -13,6 +13,7 @@
 #include "rr_device.h"
 #include "rr_prepass.h"
 #include "rr_deflate.h"
+#include "rr_pngrows.h"
 #include "rr_particles.h"
 
 using namespace rr;
@@ -554,6 +555,35 @@ int64_t emu_pngz(const uint8_t* rows, int64_t n, uint8_t* dst) {
   for (int k = 0; k < nb; k++) memcpy(dst + block_offset(meta.data(), k), slots.data() + (size_t)k * SLOT_BYTES, meta[k].bytes);
   pack_ends(dst, meta.data(), nb);
   return total;
+}
+
+
+// The scanline filters of an input file reversed with the rule k_png_unfilter applies (rr_pngrows.h), pixel by pixel in raster
+// order.  rows: H rows of 1 + bpp * W bytes; out: bpp 3 -> H*W*3 bytes B G R, bpp 2 -> H*W uint16.  Returns 0, or -1 for a bad
+// filter type.
+int emu_png_unfilter(const uint8_t* rows, int H, int W, int bpp, uint8_t* out) {
+  const size_t rb = 1 + (size_t)bpp * W;
+  std::vector<uint8_t> img((size_t)H * W * bpp);
+  for (int y = 0; y < H; y++) {
+    const int ft = rows[rb * y];
+    if (ft > 4) return -1;
+    for (int x = 0; x < W; x++)
+      for (int c = 0; c < bpp; c++) {
+        const size_t i = ((size_t)y * W + x) * bpp + c;
+        const int left = x > 0 ? img[i - bpp] : 0, up = y > 0 ? img[i - (size_t)W * bpp] : 0, upl = (x > 0 && y > 0) ? img[i - (size_t)W * bpp - bpp] : 0;
+        img[i] = (uint8_t)rrrows::png_unfilter_byte(ft, rows[rb * y + 1 + (size_t)x * bpp + c], left, up, upl);
+      }
+  }
+  for (size_t px = 0; px < (size_t)H * W; px++) {
+    if (bpp == 3) {
+      out[px * 3] = img[px * 3 + 2];
+      out[px * 3 + 1] = img[px * 3 + 1];
+      out[px * 3 + 2] = img[px * 3];
+    } else {
+      reinterpret_cast<uint16_t*>(out)[px] = (uint16_t)((img[px * 2] << 8) | img[px * 2 + 1]);
+    }
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -60,7 +60,7 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
-                assert 'hostemu' not in src or f in ('rr_device.h', 'rr_prepass.h', 'rr_particles.h', 'rr_deflate.h'), f
+                assert 'hostemu' not in src or f in ('rr_device.h', 'rr_prepass.h', 'rr_particles.h', 'rr_deflate.h', 'rr_pngrows.h'), f
 
 
 def test_library_reads_no_environment_switches():

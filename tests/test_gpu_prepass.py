@@ -259,3 +259,32 @@ def test_depth_samples_as_uint16_equal_the_float32_metres(tmp_path, built):
     with pytest.raises(RuntimeError, match='float depth'):
         rh.pipeline_frames([dict(bg_u8=(bg * 255).astype(np.uint8), depth=d16, fog=consts, omega=sc.omega, drops=drops)])
     rh.close()
+
+
+@pytest.mark.parametrize("H,W", [(96, 160), (130, 75), (375, 1242)])
+def test_input_files_as_filtered_scanlines_are_unfiltered_on_the_device(tmp_path, built, H, W):
+    """RR_IN_BG_PNG_ROWS / RR_DEPTH_PNG_ROWS: the host only inflates the two files of a frame (rr_io_read_frames_rows); the device
+    reverses the scanline filters (k_png_unfilter: a wave per file, 64 rows skewed by a pixel per lane) -- PIL's adaptive
+    filtering puts all five filter types into the files.  The pipeline gives the same bits as with the decoded arrays."""
+    import test_pngrows_host as tr
+    sc = h.Scene(tmp_path, H, W, 150, seed0=31)
+    rh = h.hb.RainHip(0)
+    rh.set_streak_db(sc.db.streaks_light)
+    rh.set_camera(sc.cam)
+    consts, We = _setup(rh, H, W, 25)
+    files = [tr._write(str(tmp_path), H, W, s_, 'noise' if s_ == 2 else 'smooth') for s_ in (1, 2, 3)]
+    st, ri, rd = tr._rows([f[0] for f in files], [f[1] for f in files], H, W)
+    assert (st == 0).all()
+    drops = [sc.product_drops(0), np.zeros(0, h.hb.DROP_DTYPE), sc.product_drops(0)]
+    a = rh.pipeline_frames([dict(bg_png_rows=ri[k], shape=(H, W), depth_png_rows=rd[k], fog=consts, omega=sc.omega, drops=drops[k])
+                            for k in range(3)], want_rainy_bg=True, want_env_u8=True)
+    b = rh.pipeline_frames([dict(bg_u8=files[k][2], depth=files[k][3], fog=consts, omega=sc.omega, drops=drops[k])
+                            for k in range(3)], want_rainy_bg=True, want_env_u8=True)
+    for k in range(3):
+        for key in ('image_u8', 'mask', 'mask_i32', 'status', 'fog_bg', 'env_bgr_u8'):
+            assert np.array_equal(a[k][key], b[k][key]), (k, key)
+    # a batch may not mix the two forms
+    with pytest.raises(RuntimeError, match='for every frame'):
+        rh.pipeline_frames([dict(bg_png_rows=ri[0], shape=(H, W), depth_png_rows=rd[0], fog=consts, omega=sc.omega, drops=drops[0]),
+                            dict(bg_u8=files[1][2], depth=files[1][3], fog=consts, omega=sc.omega, drops=drops[1])])
+    rh.close()
