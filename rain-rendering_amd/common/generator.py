@@ -182,7 +182,9 @@ class Generator:
         Every array is one page-locked block with the frames back to back, each on a 16-byte boundary (RainHip.host_rows):
         the library then moves an array of the whole batch with ONE copy instead of one DMA request per frame."""
 
-        def __init__(self, hip, B, H, W, We, bg_dtype, depth_dtype, save_envmap, drops_cap):
+        def __init__(self, hip, B, H, W, We, bg_dtype, depth_dtype, save_envmap, drops_cap, png_rows=False):
+            """png_rows: the image / depth blocks hold the files' filtered scanlines (rr_io_read_frames_rows: H rows of 1 + 3 W /
+            1 + 2 W bytes per frame) instead of pixels."""
             self.B, self.H, self.W = B, H, W
             self._raw = []
 
@@ -191,8 +193,8 @@ class Generator:
                 self._raw.append(raw)
                 return views
             drops_cap = (drops_cap + 3) // 4 * 4
-            self.bg = rows((H, W, 3), bg_dtype)
-            self.depth = rows((H, W), depth_dtype)
+            self.bg = rows((H * (1 + 3 * W),), np.uint8) if png_rows else rows((H, W, 3), bg_dtype)
+            self.depth = rows((H * (1 + 2 * W),), np.uint8) if png_rows else rows((H, W), depth_dtype)
             self.drops = rows((drops_cap,), hip_backend.DROP_DTYPE)
             self.status = rows((drops_cap,), np.int32)
             row = H * (1 + 4 * W)
@@ -202,7 +204,7 @@ class Generator:
             self.raw_bg, self.raw_depth, self.raw_drops, _, self.raw_png_i, self.raw_png_m = self._raw[:6]
             self.env = rows((H, We, 3), np.uint8) if save_envmap else None
             self.drops_cap = drops_cap
-            self.key = (B, H, W, We, np.dtype(bg_dtype), np.dtype(depth_dtype), bool(save_envmap))
+            self.key = (B, H, W, We, 'png rows' if png_rows else np.dtype(bg_dtype), 'png rows' if png_rows else np.dtype(depth_dtype), bool(save_envmap))
             self.items, self.encodes, self.busy = [], [], False
             self.prep, self.pkey, self.n_valid = None, None, 0
 
@@ -506,7 +508,10 @@ class Generator:
         # on the host.  RAIN_DEPTH_U16=0: float32 metres made by the host, as before.
         d16 = u8 and os.environ.get('RAIN_DEPTH_U16', '1') != '0'
         depth_dtype = np.uint16 if d16 else np.float32
-        key = (B, H, W, env_w, np.dtype(bg_dtype), np.dtype(depth_dtype), False)
+        # ... and both files as the filtered scanlines their IDAT streams inflate to (rr_io_read_frames_rows): the scanline filters
+        # are reversed on the device (k_png_unfilter), 40 % of the host's decode time.  RAIN_PNG_ROWS=0: pixels decoded by the host.
+        rows_in = u8 and os.environ.get('RAIN_PNG_ROWS', '1') != '0'
+        key = (B, H, W, env_w, 'png rows' if rows_in else np.dtype(bg_dtype), 'png rows' if rows_in else np.dtype(depth_dtype), False)
         pkey = (tuple(float(v) for v in fog_const), float(self.opacity_attenuation), self.rendering_strategy, sims is not None)
         for d in {os.path.dirname(it[k]) for it in work for k in ('out_rainy_path', 'out_rainy_mask_path')}:
             os.makedirs(d, exist_ok=True)
@@ -518,9 +523,11 @@ class Generator:
             if sl is None or sl.key != key or sl.drops_cap < drops_cap:
                 if sl is not None:
                     sl.free(hip)
-                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, bg_dtype, depth_dtype, False, drops_cap)
+                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, bg_dtype, depth_dtype, False, drops_cap, png_rows=rows_in)
             if getattr(sl, 'prep', None) is None or sl.pkey != pkey:
-                frames = [dict(bg=None if u8 else sl.bg[k], bg_u8=sl.bg[k] if u8 else None, depth=sl.depth[k], fog=fog_const, omega=None, drops=sl.drops[k],
+                inputs = ((lambda k: dict(bg_png_rows=sl.bg[k], shape=(H, W), depth_png_rows=sl.depth[k])) if rows_in else
+                          (lambda k: dict(bg=None if u8 else sl.bg[k], bg_u8=sl.bg[k] if u8 else None, depth=sl.depth[k])))
+                frames = [dict(inputs(k), fog=fog_const, omega=None, drops=sl.drops[k],
                                opacity_attenuation=self.opacity_attenuation, strategy=1 if self.rendering_strategy == 'white' else 0)
                           for k in range(B)]
                 outs = [dict(image_u8=None, rainy_png=sl.png_i[k], mask_png=sl.png_m[k], status=sl.status[k]) for k in range(B)]
@@ -536,7 +543,10 @@ class Generator:
 
         def decode_job(sl, items):
             """-> (frames of the batch in slot order, their drop counts): inputs of `sl` filled for the first len() frames."""
-            if u8:
+            if rows_in:
+                st = hip_backend.io_read_frames_rows([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
+                                                     sl.raw_bg, sl.raw_depth, threads)
+            elif u8:
                 st = hip_backend.io_read_frames([it['image_file'] for it in items], [it['depth_file'] for it in items], H, W,
                                                 sl.raw_bg, sl.raw_depth, threads, depth_u16=d16)
             else:
@@ -557,9 +567,14 @@ class Generator:
                     continue
                 bg, depth = loaded
                 assert bg.shape[:2] == (H, W) and bg.dtype == bg_dtype and depth.shape == (H, W), "frames of one sequence share their size"
-                np.copyto(sl.bg[k], bg)
                 # (a PNG depth map is sample / 256 in float32: the samples come back exactly)
-                np.copyto(sl.depth[k], np.rint(depth.astype(np.float64) * 256.0).astype(np.uint16) if d16 else depth.astype(np.float32))
+                samples = np.rint(depth.astype(np.float64) * 256.0).astype(np.uint16)
+                if rows_in:                                         # as scanlines of filter type 0
+                    np.copyto(sl.bg[k], hip_backend.png_rows_of(bg))
+                    np.copyto(sl.depth[k], hip_backend.png_rows_of(samples))
+                else:
+                    np.copyto(sl.bg[k], bg)
+                    np.copyto(sl.depth[k], samples if d16 else depth.astype(np.float32))
             order = [k for k in range(len(items)) if ok[k]]
             for dst in [k for k in range(len(order)) if not ok[k]]:          # close the gaps of skipped frames from the back
                 src = order.pop()

@@ -21,6 +21,16 @@ main_mod = importlib.import_module('rain-rendering_amd.main')
 imgops = importlib.import_module('rain-rendering_amd.common.imgops')
 
 
+def _frame_inputs(fr):
+    """(image, depth) of a prepared frame in whichever form the driver hands them over: pixels, or -- the batch-native route --
+    the files' filtered scanlines (un-filtered here by the host build of the device's rule)."""
+    if fr.get('bg_png_rows') is not None:
+        import test_pngrows_host as tr
+        H, W = fr['shape']
+        return tr._unfilter(np.ascontiguousarray(fr['bg_png_rows']), H, W, 3), tr._unfilter(np.ascontiguousarray(fr['depth_png_rows']), H, W, 2)
+    return (fr['bg_u8'] if fr.get('bg_u8') is not None else fr['bg']), fr['depth']
+
+
 class RecordingContext(dho.HostOnlyContext):
     """Keeps a copy of every submitted frame's inputs; "renders" scanlines that encode the frame's identity (the first
     pixel of its image), so that a file written from another frame's buffer would be noticed."""
@@ -31,8 +41,8 @@ class RecordingContext(dho.HostOnlyContext):
         for k in range(n):
             fr = prep.frames[k]
             nd = prep.counts.get(k, len(fr['drops']))
-            bg = fr['bg_u8'] if fr.get('bg_u8') is not None else fr['bg']
-            RecordingContext.log.append(dict(bg=np.array(bg), depth=np.array(fr['depth']), drops=np.array(fr['drops'][:nd]),
+            bg, depth = _frame_inputs(fr)
+            RecordingContext.log.append(dict(bg=np.array(bg), depth=np.array(depth), drops=np.array(fr['drops'][:nd]),
                                              sim=None if fr.get('sim') is None else np.array(fr['sim'][0])))
         super().pipeline_submit_prepared(slot, prep, n)
 
@@ -48,7 +58,8 @@ class RecordingContext(dho.HostOnlyContext):
             return True
         for k in range(n):
             o, fr = prep.outs[k], prep.frames[k]
-            bg = fr['bg_u8'] if fr.get('bg_u8') is not None else np.round(fr['bg'] * 255).astype(np.uint8)
+            bg = _frame_inputs(fr)[0]
+            bg = bg if bg.dtype == np.uint8 else np.round(bg * 255).astype(np.uint8)
             H, W = bg.shape[:2]
             rows = np.zeros((H, 1 + 4 * W), np.uint8)               # filter type 0 rows: every pixel = the frame's first pixel
             rows[:, 1:] = np.tile(np.append(bg[0, 0], 255).astype(np.uint8), W)
