@@ -22,6 +22,7 @@ static int fuzz_readers(int argc, char** argv, int rounds) {
     const int H = (int)p0.h, W = (int)p0.w;
     std::vector<uint8_t> out((size_t)H * W * 3);
     std::vector<uint16_t> out16((size_t)H * W);
+    std::vector<uint8_t> rows3((size_t)H * (1 + 3 * (size_t)W)), rows2((size_t)H * (1 + 2 * (size_t)W));   // exact sizes: an overrun is seen
     const std::string tmp = std::string(argv[fi]) + ".fuzz";
     for (int it = 0; it < rounds; it++) {
       std::vector<uint8_t> m(f.begin(), f.begin() + (long)fsz);
@@ -46,6 +47,15 @@ static int fuzz_readers(int argc, char** argv, int rounds) {
       int32_t w, h, c, d;
       rr_png_read_bgr8(tmp.c_str(), out.data(), H, W);
       rr_png_read_gray16(tmp.c_str(), out16.data(), H, W);
+      {                                   // the inflate-only reader (rr_io_read_frames_rows): the file as image and as depth map
+        const char* path = tmp.c_str();
+        int32_t st = 0;
+        rr_io_read_frames_rows(1, &path, nullptr, H, W, rows3.data(), (int64_t)rows3.size(), nullptr, 0, 1, &st);
+        if (st == RR_OK)
+          for (int y = 0; y < H; y++)
+            if (rows3[(size_t)y * (1 + 3 * (size_t)W)] > 4) return 2;          // only valid filter types may be handed to the device
+        rr_io_read_frames_rows(1, &path, &path, H, W, rows3.data(), (int64_t)rows3.size(), rows2.data(), (int64_t)rows2.size(), 1, &st);
+      }
       rr_png_info(tmp.c_str(), &w, &h, &c, &d);
       answered++;
     }
@@ -128,8 +138,35 @@ static int fuzz_deflate(int rounds) {
   return wrong != 0;
 }
 
+// rows that claim to be a stream the device made (RR_OPT_PNG_DEFLATE: 'RRZ1', length, stream): lengths that do not fit the
+// buffer must be refused, a fitting one is written as the IDAT payload without being looked at
+static int fuzz_device_payload(const char* dir) {
+  const int W = 7, H = 5;
+  const size_t n = (size_t)H * (1 + 4 * W);
+  const std::string path = std::string(dir) + "/payload.png";
+  int bad = 0;
+  for (uint32_t L : {0u, 5u, 6u, (uint32_t)(n - 16), (uint32_t)(n - 15), (uint32_t)n, 0x7fffffffu, 0xffffffffu}) {
+    uint8_t* rows = new uint8_t[n];
+    memset(rows, 0, n);
+    memcpy(rows, "RRZ1", 4);
+    memcpy(rows + 4, &L, 4);
+    const int rc = rr_png_write_scanlines(path.c_str(), rows, W, H, 1, 3);
+    const bool fits = L >= 6 && (size_t)L + 16 <= n;
+    if ((rc == RR_OK) != fits) bad++;
+    delete[] rows;
+  }
+  remove(path.c_str());
+  printf("device payloads: wrong %d\n", bad);
+  return bad != 0;
+}
+
 int main(int argc, char** argv) {
   int rc = fuzz_readers(argc, argv, 160);
+  if (argc > 1) {
+    std::string dir(argv[1]);
+    dir = dir.substr(0, dir.find_last_of('/'));
+    rc |= fuzz_device_payload(dir.c_str());
+  }
   rc |= fuzz_inflate(1200);
   rc |= fuzz_deflate(900);
   return rc;

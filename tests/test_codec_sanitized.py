@@ -32,4 +32,20 @@ def test_codec_under_sanitizers(tmp_path):
     run = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, ASAN_OPTIONS='detect_leaks=0'))          # (the buffer pools live until exit by design)
     assert run.returncode == 0, (run.stdout[-600:], run.stderr[-3000:])
-    assert 'wrong 0' in run.stdout and 'readers:' in run.stdout
+    assert 'wrong 0' in run.stdout and 'readers:' in run.stdout and 'device payloads: wrong 0' in run.stdout
+
+
+def test_device_byte_code_under_sanitizers(tmp_path):
+    """The host build of the device's entropy coder (csrc/rr_deflate.h) and scanline-filter rule (csrc/rr_pngrows.h) with
+    AddressSanitizer + UndefinedBehaviorSanitizer on inputs of every awkward length in exact-size buffers
+    (tests/sanitize/device_code_fuzz.cpp): zlib inflates every stream back."""
+    src = os.path.join(h.ROOT, 'tests', 'sanitize', 'device_code_fuzz.cpp')
+    exe = str(tmp_path / 'device_code_fuzz')
+    cc = ['g++', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-std=c++17', '-ffp-contract=off',
+          '-I' + os.path.join(h.ROOT, 'include'), '-I' + os.path.join(h.ROOT, 'rain-rendering_amd', 'csrc'), src, '-lz', '-o', exe]
+    r = subprocess.run(cc, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer build here: " + r.stderr[-300:])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS='detect_leaks=0'))
+    assert run.returncode == 0, (run.stdout[-600:], run.stderr[-3000:])
+    assert 'wrong 0' in run.stdout and 'unfilter: wrong 0' in run.stdout and 'coded' in run.stdout
