@@ -374,10 +374,11 @@ enum {
    * and the environment-map sums under the polygon.  They only feed the drop's colour constants, which only scale
    * rainy_image (contract: +-1 LSB; the mask and the drop statuses never see the difference). */
   RR_OPT_FOV_F32 = 10,
-  RR_OPT_FOV_DDA = 12,              /* tuning: 1 (default) the float colour branch evaluates a drop's field-of-view polygon and its row
-                                     * spans with one thread per drop (two cursors down the polygon's sides; wrapping polygons and
-                                     * float64 decisions through a list to the edge-parallel kernel); 0: the edge-parallel kernel for
-                                     * every drop.  The spans are the same: identical results. */
+  RR_OPT_FOV_DDA = 12,              /* tuning: the float colour branch evaluates a drop's field-of-view polygon and its row spans with one
+                                     * thread per drop (two cursors down the polygon's sides; wrapping polygons and float64 decisions
+                                     * through a list to the edge-parallel kernel) -- 2 (default, r05): incremental cursors over
+                                     * per-edge records, 1: an exact division per cursor and row (r04); 0: the edge-parallel kernel
+                                     * for every drop.  The spans are the same: identical results. */
   RR_OPT_COMPOSITE_WAVES = 11,      /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
                                      * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
   RR_OPT_PIPELINE_F32 = 13,         /* 1 (default): rr_pipeline_* hand the fog layer and the xyY map from the pre-pass to the hot path
@@ -388,12 +389,21 @@ enum {
                                      * values in [0, 1] -- the library never visits the pad.  With this option the pads are tracked
                                      * (two int32 per pixel, one more kernel) and a pixel some pad reaches before any tile is clipped
                                      * first: the reference's result for any input.  Default 0.  Not with rr_ext_tile. */
-  RR_OPT_PNG_DEFLATE = 15           /* 1: rr_frame_out.rainy_png / mask_png are entropy-coded on the device.  The buffer (same size) then
+  RR_OPT_PNG_DEFLATE = 15,          /* 1: rr_frame_out.rainy_png / mask_png are entropy-coded on the device.  The buffer (same size) then
                                      * starts with 16 bytes {'R','R','Z','1', uint32 length L, 0, 0} followed by the L bytes of the file's
                                      * zlib stream (one dynamic-Huffman deflate block per 32 KB of scanlines; any inflate reads it):
                                      * the IDAT payload as it is.  A file whose stream would not fit its buffer (incompressible pixels)
                                      * keeps its scanlines (first byte = a filter type, never 'R').  rr_png_write_scanlines /
                                      * rr_io_write_frames take either form.  Default 0 (scanlines). */
+  RR_OPT_COMPOSITE_U16 = 16,        /* tuning (r05): 1 (default) the float compositor leaves the composite before the mean shift in the
+                                     * library's scratch as three 16-bit codes per pixel (rint(v * 65534); 65535 = "outside [0, 1]:
+                                     * take the pixel's own rainy_bg value", which is then what the composite holds) instead of three
+                                     * floats: half the bytes written there and read back by the final pass.  The code is 2^-17 off at
+                                     * most (an LSB of rainy_image is 2^-8): the image contract (+-1 LSB) holds, the mask never sees it.
+                                     * Ignored with RR_OPT_WILD_PIXELS, and whenever a caller asks for the composite itself. */
+  RR_OPT_BLUR_PREFETCH = 17         /* tuning (r05): 1 (default) the fused defocus blur pulls the NEXT work item's raw tile towards the
+                                     * L2 while it filters the current one (gfx950 LDS-DMA loads into a scratch line of LDS: no
+                                     * registers, nothing waits for them).  Same results. */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -189,6 +189,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
   int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
   int32_t blur_bx, blur_by;         // LDS capacities (doubles) of the fused blur's two staging tiles (RR_OPT_BLUR_WORKGROUPS)
+  int32_t blur_pf;                  // RR_OPT_BLUR_PREFETCH: k_blur_fused pulls the next item's raw tile towards the L2 (LDS-DMA into a scratch line)
 };
 
 // ---------------------------------------------------------------------------
@@ -830,6 +831,134 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
       if (mine && y >= ytop && y <= ybot) cur.row(vertex, y, lo, hi);
       const int a = imax(lo, 0), b = imin(hi, dm.We - 1);
       pk[j] = (y < dm.He && a <= b) ? ((uint32_t)a | ((uint32_t)(b + 1) << 16)) : 0u;
+    }
+    if (mine) out[(int64_t)(yq >> 2) * Dp] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// FOV polygon and row spans, one thread per drop, incremental cursors (r05; the float colour branch's default)
+// ---------------------------------------------------------------------------
+// k_fov_dda spends 120 vector + 78 scalar instructions per map row and wave: an exact division per cursor and row, and a
+// divergent search for the next vertex inside the row loop.  Here (rr_device.h DdaWalk):
+//   * the vertex loop leaves one 8-byte RECORD per polygon edge in wave-private LDS, rec[edge][lane] (a lane touches bank
+//     pair `lane`: no conflicts): floor(dx / den) + 1, 2 (dx mod den), den and the edge's last row -- the edge's one
+//     division is done there, by every lane at once;
+//   * the row loop is uniform over the map's rows, four per 16-byte store: a cursor steps with five integer instructions
+//     (the sign of the running remainder is the carry), a row's span is min / max of the two cursors;
+//   * a lane whose cursor reaches its edge's last row takes the next record -- fetched from LDS an edge ahead, so the
+//     event itself waits for nothing.  Horizontal edges (rare) fold their far end on the spot.
+// Lanes above their polygon's first row are parked on the top vertex (a step that moves nothing), rows below the last one
+// are masked at the store.  Classification, the frame's list for k_fov_spans and the span layout are k_fov_dda's: the
+// spans are the same bits (RR_OPT_FOV_DDA 0 / 1 / 2 give identical colour constants: tests/test_gpu_properties.py).
+__global__ __launch_bounds__(256) void k_fov_walk(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
+  const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const FrameDesc& fr = frames[f];
+  const int N = cam.n_fov;
+  __shared__ float s_phi32[2][RR_MAX_FOV];
+  extern __shared__ __attribute__((aligned(8))) uint2 s_rec_dyn[];      // [4 waves][N edges][64 lanes]
+  if (threadIdx.x < RR_MAX_FOV) {
+    s_phi32[0][threadIdx.x] = (float)cam.phi_cos[threadIdx.x];
+    s_phi32[1][threadIdx.x] = (float)cam.phi_sin[threadIdx.x];
+  }
+  __syncthreads();
+  const int i = (blockIdx.x * 4 + wave) * 64 + lane;           // this lane's drop
+  const bool act = i < fr.n_drops;
+  const int64_t gi = (int64_t)f * max_drops + (act ? i : 0);
+  if (fr.strategy == 1) {                                      // 'white': the FOV is computed by the reference but never used
+    if (act) sc.npts[gi] = -1;
+    return;
+  }
+  uint2* recs = s_rec_dyn + wave * N * 64 + lane;              // this lane's column: recs[edge * 64]
+  // ---- 1. vertices, and the record of every edge as soon as both its ends are known ----
+  int uns = 0;
+  int count_true = 0, count_false = 0;
+  int ktop = 0, xtop = 0, ytop = 1 << 30, ybot = -(1 << 30), r_first = 0;
+  bool spread = false;
+  int turns = 0, dir = 0, dir_first = 0;
+  if (act) {
+    FovSetup32 F;
+    const rr_drop d = load_drop(fr.drops + i);
+    fov_setup32(d, (float)cam.fov_cos, (float)cam.fov_sin, F, uns);
+    float az_prev = 0.f, er_prev = 0.f, az0 = 0.f, er0 = 0.f;
+    int x_prev = 0, y_prev = 0, x0v = 0, y0v = 0;
+    for (int k = 0; k < N; k++) {
+      float az, er, pxf, pyf;
+      fov_vertex32(F, (float)cam.radius, s_phi32[0][k], s_phi32[1][k], dm.He, dm.We, az, er, pxf, pyf, uns);
+      const int ix = (int)pxf & 0x7fff, iy = (int)pyf & 0x7fff;              // (a sure drop's vertices lie on the map: the masks keep the
+      const int r = imin(imax((int)pyf, 0), dm.He - 1);                      //  records of the others inside their fields)
+      if (k == 0) { az0 = az; er0 = er; r_first = r; x0v = ix; y0v = iy; }
+      else {
+        const bool c = fov_wrap_cnd32(az_prev, az, er_prev, er, uns);      // side k-1 -> k
+        count_true += c ? 1 : 0;
+        count_false += c ? 0 : 1;
+        spread = spread || iabs(r - r_first) >= 2;
+        const int sg = iy > y_prev ? 1 : (iy < y_prev ? -1 : 0);
+        if (sg != 0) {
+          if (dir == 0) dir_first = sg;
+          else if (sg != dir) turns++;
+          dir = sg;
+        }
+        uint32_t w0, w1;
+        dda_edge_record(x_prev, y_prev, ix, iy, w0, w1);
+        recs[(k - 1) * 64] = make_uint2(w0, w1);
+      }
+      if (iy < ytop) { ytop = iy; ktop = k; xtop = ix; }
+      ybot = imax(ybot, iy);
+      az_prev = az; er_prev = er; x_prev = ix; y_prev = iy;
+    }
+    {                                                          // the closing side N-1 -> 0
+      const bool c = fov_wrap_cnd32(az_prev, az0, er_prev, er0, uns);
+      count_true += c ? 1 : 0;
+      count_false += c ? 0 : 1;
+      const int sg = y0v > y_prev ? 1 : (y0v < y_prev ? -1 : 0);
+      if (sg != 0) {
+        if (dir != 0 && sg != dir) turns++;
+        dir = sg;
+      }
+      if (dir != 0 && dir_first != 0 && dir != dir_first) turns++;        // around the closing point
+      uint32_t w0, w1;
+      dda_edge_record(x_prev, y_prev, x0v, y0v, w0, w1);
+      recs[(N - 1) * 64] = make_uint2(w0, w1);
+    }
+  }
+  // ---- classification (fov_polygon_auto), as k_fov_dda ----
+  const bool certain_fail = (uns & 128) && !(uns & 3);
+  const bool wrap = count_true == 1 || count_false == 1;
+  const bool undecided = (uns & ~128) != 0 || count_true == 0 || count_false == 0 || (!wrap && !spread);
+  const bool monotone = turns <= 2;
+  const bool mine = act && !certain_fail && !undecided && !wrap && monotone;
+  if (act && certain_fail) sc.npts[gi] = 0;
+  if (act && !certain_fail && !mine) {
+    const int pos = atomicAdd(&sc.fov_list_n[f], 1);
+    sc.fov_list[(int64_t)f * max_drops + pos] = i;
+  }
+  if (mine) sc.npts[gi] = N;
+  if (__ballot(mine) == 0ull) return;
+  wave_lds_sync();                                             // (records: written and read by the same lane; compiler ordering only)
+  // ---- 2. spans: two cursors down from the top vertex, a record per edge ----
+  auto rec = [&](int k, uint32_t& a, uint32_t& b) {
+    const uint2 v = recs[k * 64];
+    a = v.x;
+    b = v.y;
+  };
+  DdaWalk<decltype(rec)> cur;
+  if (!mine) { ktop = 0; xtop = 0; ytop = 1 << 20; ybot = 0; }   // (never reaches its first row: parked throughout)
+  cur.init(rec, N, ktop, xtop, ytop);
+  const unsigned span_rows = mine ? (unsigned)(ybot - ytop) : 0u;
+  const int NQ = Hp >> 2;
+  uint4* out = reinterpret_cast<uint4*>(sc.spans) + (int64_t)f * NQ * Dp + i;
+  const int xmax = dm.We - 1;
+  for (int yq = 0; yq < Hp; yq += 4) {
+    uint32_t pk[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int y = yq + j;
+      int lo, hi;
+      cur.row(rec, y, lo, hi);
+      const int b = imin(hi, xmax);                            // (lo >= 0: vertex coordinates are not negative)
+      const bool in = mine && (unsigned)(y - ytop) <= span_rows && y < dm.He && lo <= b;
+      pk[j] = in ? ((uint32_t)lo | ((uint32_t)(b + 1) << 16)) : 0u;
     }
     if (mine) out[(int64_t)(yq >> 2) * Dp] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
@@ -2117,6 +2246,8 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
   double* hw2 = s_dyn + (BR_MAX + 1);
   double* X = s_dyn + 2 * (BR_MAX + 1);                                 // 98 doubles in front: X and Y stay 16-byte aligned
   double* Y = X + sc.blur_bx;
+  // 256 bytes behind Y that nothing reads: where the prefetch DMAs of the next item land (see below)
+  const uint32_t pf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(Y + sc.blur_by);
   const int n_items = sc.counts[f * 8 + 2];
   if ((int)blockIdx.x >= n_items) return;
   // r04: the item record and the plan of the NEXT item travel ahead of the current one's arithmetic, by vector loads (lane l
@@ -2219,6 +2350,29 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
       PH(0)                                         // plan, tables, raw sub-tile -> LDS (issue)
       __syncthreads();
       PH(1)                                         // barrier: the loads land
+      // r05: the load phase above is this kernel's largest (47 % of its wave time: a round trip to HBM per item, the raw
+      // tiles were written several kernels ago).  While this item is filtered, the NEXT item's raw tile and weight tables
+      // are pulled towards the L2: one gfx950 LDS-DMA load (global_load_lds_dword) per 128-byte line, a thread per
+      // line, all of them into one scratch line of LDS -- no register receives anything, nothing ever waits for them
+      // (inline assembly: the compiler neither counts them nor orders LDS reads behind them; an uncounted load in flight
+      // can only make a later counted wait longer), and the next item's own loads then hit the L2.
+      if (sc.blur_pf && st == item.y && it + G < n_items) {
+        const int nd = (int)__builtin_amdgcn_readlane((int)iv_cur, 0);         // (iv_cur / pv_cur hold the next item already)
+        if (nd != item.x) {
+          const PlanView q = unpack(pv_cur);
+          const char* raw = reinterpret_cast<const char*>(sc.arena + q.a0_off);      // raw tiles start on 128-byte lines
+          const int lines = imin((q.tw * q.th * 8 + 127) >> 7, 248);
+          const char* wt = reinterpret_cast<const char*>(sc.wtab + ((int64_t)f * max_drops + nd) * 2 * (BR_MAX + 1));
+          const char* src = t < lines ? raw + (int64_t)t * 128 : wt + (int64_t)(t - lines) * 128;
+          if (t < lines + 7) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(pf_lds)
+                         : "memory");
+          }
+        }
+      }
       // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns data column xc and FOUR consecutive
       // rows; as the tap distance shrinks the upper/lower operand windows slide by one row, so each
       // step needs two new LDS values instead of eight (register rotation).  Lanes run along x.
@@ -3011,17 +3165,34 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     }
     __syncthreads();
   }
+  // The composite before the mean shift goes to the library's scratch (this compositor only runs when no caller wants it):
+  // as three floats per pixel, or (r05, RR_OPT_COMPOSITE_U16, default) as three 16-bit codes -- half the bytes here and in
+  // k_finalize.  A value in [0, 1] becomes rint(v * 65534) (error <= 2^-17, an LSB of the uint8 image is 2^-8); anything
+  // else -- only possible where no drop was blended, every blend ends with a clamp, or where the input was NaN -- becomes
+  // the code 65535: k_finalize then takes the pixel's channel from rainy_bg itself, which is what this lane holds.
+  auto code16 = [](float v) -> uint32_t { return (v >= 0.f && v <= 1.f) ? (uint32_t)(v * 65534.0f + 0.5f) : 65535u; };
+  const bool c16 = fr.comp_f32 == 2;
   double sum_c = 0.0;
   if (live0) {
-    const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix0 * 3;
-    o[0] = c0.x; o[1] = c1.x; o[2] = c2.x;
+    if (c16) {
+      const global_ptr<uint16_t> o = as_global(reinterpret_cast<uint16_t*>(fr.comp_out)) + pix0 * 3;
+      o[0] = (uint16_t)code16(c0.x); o[1] = (uint16_t)code16(c1.x); o[2] = (uint16_t)code16(c2.x);
+    } else {
+      const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix0 * 3;
+      o[0] = c0.x; o[1] = c1.x; o[2] = c2.x;
+    }
     if (fr.mask_f64) as_global(fr.mask_f64)[pix0] = m0;
     if (fr.mask_i32) as_global(fr.mask_i32)[pix0] = (int32_t)floor(m0 * 255.0);
     sum_c = ((double)c0.x + (double)c1.x) + (double)c2.x;
   }
   if (live1) {
-    const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix1 * 3;
-    o[0] = c0.y; o[1] = c1.y; o[2] = c2.y;
+    if (c16) {
+      const global_ptr<uint16_t> o = as_global(reinterpret_cast<uint16_t*>(fr.comp_out)) + pix1 * 3;
+      o[0] = (uint16_t)code16(c0.y); o[1] = (uint16_t)code16(c1.y); o[2] = (uint16_t)code16(c2.y);
+    } else {
+      const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix1 * 3;
+      o[0] = c0.y; o[1] = c1.y; o[2] = c2.y;
+    }
     if (fr.mask_f64) as_global(fr.mask_f64)[pix1] = m1;
     if (fr.mask_i32) as_global(fr.mask_i32)[pix1] = (int32_t)floor(m1 * 255.0);
     sum_c += ((double)c0.y + (double)c1.y) + (double)c2.y;
@@ -3093,7 +3264,18 @@ __global__ __launch_bounds__(256) void k_finalize(const FrameDesc* frames, Dims 
   const double diff = sc.means[f * 4 + 0] - sc.means[f * 4 + 1];
   const global_ptr<uint8_t> o = as_global(fr.rgb) + pix * 3;
   double c[3];
-  if (fr.comp_f32) {
+  if (fr.comp_f32 == 2) {                          // 16-bit codes (k_composite32): 65535 = the pixel's own rainy_bg value
+    const global_ptr<const uint16_t> s = as_global(reinterpret_cast<const uint16_t*>(fr.comp_out)) + pix * 3;
+    const uint32_t q0 = s[0], q1 = s[1], q2 = s[2];
+    c[0] = (double)q0 * (1.0 / 65534.0); c[1] = (double)q1 * (1.0 / 65534.0); c[2] = (double)q2 * (1.0 / 65534.0);
+    if (q0 == 65535u || q1 == 65535u || q2 == 65535u) {
+      double in[3];
+      load_px3(fr.rainy_bg, rainy_kind(fr), pix, in);
+      if (q0 == 65535u) c[0] = (double)(float)in[0];
+      if (q1 == 65535u) c[1] = (double)(float)in[1];
+      if (q2 == 65535u) c[2] = (double)(float)in[2];
+    }
+  } else if (fr.comp_f32) {
     const global_ptr<const float> s = as_global(reinterpret_cast<const float*>(fr.comp_out)) + pix * 3;
     c[0] = (double)s[0]; c[1] = (double)s[1]; c[2] = (double)s[2];
   } else {
@@ -3630,7 +3812,10 @@ struct rr_ctx {
   int32_t *d_pad_first = nullptr, *d_eff_first = nullptr;
   size_t pad_cap = 0;                // elements of each
   bool pipe_f32 = true;              // RR_OPT_PIPELINE_F32: float32 hand-over from the pre-pass to the hot path inside rr_pipeline_*
-  bool fov_dda = true;               // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (k_fov_dda)
+  bool walk_attr = false;
+  bool composite_u16 = true;         // RR_OPT_COMPOSITE_U16
+  bool blur_prefetch = true;         // RR_OPT_BLUR_PREFETCH
+  int fov_dda = 2;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (2: k_fov_walk, 1: k_fov_dda)
   int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
   int n_tex = 0;
   float* d_ctab = nullptr;
@@ -4016,7 +4201,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     fd.ext = in[f].ext;
     fd.colour_out = out[f].drop_colour;
     fd.n_drops_dev = in[f].n_drops_dev;
-    fd.comp_f32 = use32 ? 1 : 0;
+    fd.comp_f32 = use32 ? ((ctx->composite_u16 && !ctx->wild_pixels) ? 2 : 1) : 0;
     fd.in_types = in[f].in_types;
     any_dev_count = any_dev_count || in[f].n_drops_dev;
     fd.n_drops = in[f].n_drops;
@@ -4037,6 +4222,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int blur_wg = ctx->blur_wg ? ctx->blur_wg : 4;      // workgroups per CU the fused blur is sized for
   sc.blur_bx = blur_wg == 3 ? 3072 : (blur_wg == 5 ? 2304 : 2816);
   sc.blur_by = blur_wg == 5 ? 1600 : 2048;
+  sc.blur_pf = ctx->blur_prefetch ? 1 : 0;
   // One in-order stream: FOV spans -> plan -> scan -> dedup -> lists -> FOV sums -> colour -> tiles -> blur ->
   // composite -> finalise.
   // Work-list kernels take their items grid-stride, the list lengths only exist on the device: with many frames per call
@@ -4054,13 +4240,22 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       // and the float64 colour branch: k_fov_spans for every drop.
       bool any_ext = false;
       for (int f = 0; f < n; f++) any_ext = any_ext || in[f].ext != nullptr;
-      const bool dda = fov32 && ctx->fov_dda && !any_ext;
+      const bool dda = fov32 && ctx->fov_dda != 0 && !any_ext;
       const int v32 = fov32 ? 1 : 0;
       const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
       if (dda) {
         HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, s));
-        hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 255) / 256, n), dim3(256), sizeof(uint32_t) * 4 * 64 * (size_t)ctx->cam.n_fov, s, ctx->d_frames, dm,
-                           ctx->cam, D, Hp, Dp, sc);
+        if (ctx->fov_dda == 1) {
+          hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 255) / 256, n), dim3(256), sizeof(uint32_t) * 4 * 64 * (size_t)ctx->cam.n_fov, s, ctx->d_frames, dm,
+                             ctx->cam, D, Hp, Dp, sc);
+        } else {                                              // r05: incremental cursors over per-edge records
+          const size_t lds = sizeof(uint2) * 4 * 64 * (size_t)ctx->cam.n_fov;
+          if (!ctx->walk_attr) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint2) * 4 * 64 * RR_MAX_FOV)));
+            ctx->walk_attr = true;
+          }
+          hipLaunchKernelGGL(k_fov_walk, dim3((max_drops + 255) / 256, n), dim3(256), lds, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
+        }
         const dim3 lgrid(imin((int)grid.x, 8), n);           // the list is short: a few workgroups per frame walk it, in float64
         if (dm.He <= 384)
           hipLaunchKernelGGL((k_fov_spans<6, true>), lgrid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
@@ -4186,7 +4381,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_fused");
-      const size_t lds = sizeof(double) * (size_t)(2 * (BR_MAX + 1) + sc.blur_bx + sc.blur_by);
+      const size_t lds = sizeof(double) * (size_t)(2 * (BR_MAX + 1) + sc.blur_bx + sc.blur_by) + 256;     // + the prefetch DMAs' scratch line
       const dim3 grid(imin((max_drops + 1) / 2, grid_cap(4096)), n);
       if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else if (blur_wg == 5) hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
@@ -5611,7 +5806,9 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
-    case RR_OPT_FOV_DDA: ctx->fov_dda = value != 0; return RR_OK;
+    case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;
+    case RR_OPT_BLUR_PREFETCH: ctx->blur_prefetch = value != 0; return RR_OK;
+    case RR_OPT_FOV_DDA: ctx->fov_dda = value < 0 ? 0 : (value > 2 ? 2 : value); return RR_OK;
     case RR_OPT_PIPELINE_F32: ctx->pipe_f32 = value != 0; return RR_OK;
     case RR_OPT_WILD_PIXELS: ctx->wild_pixels = value != 0; return RR_OK;
     case RR_OPT_PNG_DEFLATE: ctx->png_deflate = value != 0; return RR_OK;

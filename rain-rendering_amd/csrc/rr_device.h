@@ -805,6 +805,98 @@ struct DdaCursors {
     }
   }
 };
+// r05: the same spans by INCREMENTAL stepping (k_fov_walk).  DdaCursors evaluates the rule's exact division on every row
+// and looks for the next vertex inside the row loop (120 vector + 78 scalar instructions per map row and wave); here every
+// edge's division is done ONCE, when its record is made, and a cursor walks down it with adds only:
+//   x(t) = xa + floor((2 dx t + den) / (2 den)),  t = y - ya.   With dx = q den + r (0 <= r < den), Q(t), R(t) the quotient and
+//   remainder of 2 dx t + den by 2 den:   Q(0) = 0, R(0) = den;   R + 2 r < 4 den, so a row adds q to Q plus at most one
+//   carry:  R' = R + 2 r,  carry = R' >= 2 den,  Q += q + carry,  R = R' - carry * 2 den.
+// The cursor keeps rem = R - 2 den (negative; the sign bit of rem + 2 r is the carry) and the record holds q + 1, 2 r,
+// den and the edge's last row.  At t = den the formula gives xb exactly, so a cursor that arrives at a vertex holds that
+// vertex' x: the row's span is min / max of the two cursors' x, plus -- only when an edge is horizontal -- the far ends of
+// the horizontal edges met on that row.  That is the set fov_rowspan folds (every edge that touches the row evaluates to
+// one of these values), so the spans are identical (tests/test_fov_f32_host.py).
+//
+// Record of the undirected edge {k, k + 1} (vertices (x0, y0), (x1, y1); coordinates in [0, 32767], rows in [0, 32767]):
+//   w1 = den | (last row << 16);  den > 0:  w0 = ((q + 1) & 0xffff) | (2 r << 16);   den == 0:  w0 = x0 | (x1 << 16).
+RR_HD void dda_edge_record(int x0, int y0, int x1, int y1, uint32_t& w0, uint32_t& w1) {
+  if (y0 == y1) {
+    w0 = (uint32_t)x0 | ((uint32_t)x1 << 16);
+    w1 = (uint32_t)y0 << 16;
+    return;
+  }
+  const bool swp = y1 < y0;
+  const int xa = swp ? x1 : x0, ya = swp ? y1 : y0, xb = swp ? x0 : x1, yb = swp ? y0 : y1;
+  const int den = yb - ya, dx = xb - xa;
+  // floor(dx / den): a float quotient is within one of it (|dx| < 2^15), the remainder makes it exact
+#if defined(__HIP_DEVICE_COMPILE__)
+  int q = (int)floorf((float)dx * __builtin_amdgcn_rcpf((float)den));
+#else
+  int q = (int)floorf((float)dx / (float)den);
+#endif
+  int r = dx - mul24i(q, den);
+  if (r < 0) { q -= 1; r += den; }
+  else if (r >= den) { q += 1; r -= den; }
+  w0 = ((uint32_t)(q + 1) & 0xffffu) | ((uint32_t)(2 * r) << 16);
+  w1 = (uint32_t)den | ((uint32_t)yb << 16);
+}
+// R: rec(k, w0, w1) hands out the record of edge {k, k + 1}.  Cursor 0 walks the vertices upwards in index from the top
+// vertex, cursor 1 downwards; `used` counts the edges taken by both (N in all), as in DdaCursors.  Before the top row the
+// cursors are parked on the top vertex (q + 1 = 1, 2 r = 0: a step moves nothing); row(y) must be called for every y from
+// the top vertex' row (or before) in ascending order; rows below the bottom vertex return garbage.
+template <class R>
+struct DdaWalk {
+  int x[2], rem[2], sq1[2], sr[2], dn[2], yb[2], kv[2], used, N;
+  uint32_t n0[2], n1[2];                                     // the record of the edge the cursor takes next, fetched an edge ahead
+  RR_HD void init(const R& rec, int n, int ktop, int xtop, int ytop) {
+    N = n;
+    used = 0;
+    for (int c = 0; c < 2; c++) {
+      x[c] = xtop; rem[c] = -1; sq1[c] = 1; sr[c] = 0; dn[c] = 0; yb[c] = ytop; kv[c] = ktop;
+    }
+    rec(ktop, n0[0], n1[0]);
+    rec(ktop == 0 ? n - 1 : ktop - 1, n0[1], n1[1]);
+  }
+  RR_HD void row(const R& rec, int y, int& lo, int& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 2; c++) {                            // one row down the current edges
+      const int r = rem[c] + sr[c];
+      const int m = r >> 31;                                 // -1: no carry
+      x[c] += sq1[c] + m;
+      rem[c] = r - (dn[c] & ~m);
+    }
+    lo = imin(x[0], x[1]);
+    hi = imax(x[0], x[1]);
+    if (y != yb[0] && y != yb[1]) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 2; c++) {
+      while (y == yb[c] && used < N) {                       // at a vertex: the next edge of this side
+        used++;
+        const uint32_t w0 = n0[c], w1 = n1[c];
+        const int kn = c == 0 ? (kv[c] + 1 == N ? 0 : kv[c] + 1) : (kv[c] == 0 ? N - 1 : kv[c] - 1);
+        kv[c] = kn;
+        rec(c == 0 ? kn : (kn == 0 ? N - 1 : kn - 1), n0[c], n1[c]);
+        const int den = (int)(w1 & 0xffffu);
+        if (den == 0) {                                      // horizontal: its far end lies on this row too
+          x[c] = c == 0 ? (int)(w0 >> 16) : (int)(w0 & 0xffffu);
+          lo = imin(lo, x[c]);
+          hi = imax(hi, x[c]);
+          rem[c] = -1; sq1[c] = 1; sr[c] = 0; dn[c] = 0;     // (parked until the next edge is taken)
+        } else {
+          sq1[c] = (int)(int16_t)(w0 & 0xffffu);
+          sr[c] = (int)(w0 >> 16);
+          dn[c] = 2 * den;
+          rem[c] = -den;
+          yb[c] = (int)(w1 >> 16);
+        }
+      }
+    }
+  }
+};
 // number of times the vertices' row sequence changes direction around the loop (a closed monotone curve: 2; all on one row: 0)
 RR_HD int poly_row_turns(const int32_t* py, int n) {
   int turns = 0, dir = 0, dir_first = 0;

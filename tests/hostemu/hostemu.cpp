@@ -106,6 +106,35 @@ int emu_dda_check(const int32_t* px, const int32_t* py, int n, int He, int We) {
   return bad;
 }
 
+// The same check for k_fov_walk's incremental cursors (rr_device.h DdaWalk over dda_edge_record records).
+int emu_walk_check(const int32_t* px, const int32_t* py, int n, int He, int We) {
+  if (poly_row_turns(py, n) > 2) return -1;
+  int ktop = 0, ytop = py[0], ybot = py[0];
+  for (int k = 1; k < n; k++) {
+    if (py[k] < ytop) { ytop = py[k]; ktop = k; }
+    if (py[k] > ybot) ybot = py[k];
+  }
+  std::vector<uint32_t> w0(n), w1(n);
+  for (int k = 0; k < n; k++) {
+    const int j = k + 1 == n ? 0 : k + 1;
+    dda_edge_record(px[k], py[k], px[j], py[j], w0[k], w1[k]);
+  }
+  auto rec = [&](int k, uint32_t& a, uint32_t& b) { a = w0[k]; b = w1[k]; };
+  DdaWalk<decltype(rec)> cur;
+  cur.init(rec, n, ktop, px[ktop], ytop);
+  int bad = 0;
+  for (int y = 0; y < He; y++) {
+    int lo = 1 << 30, hi = -(1 << 30);
+    cur.row(rec, y, lo, hi);                       // (every row, like the kernel: parked above the polygon, garbage below it)
+    if (y < ytop || y > ybot) { lo = 1 << 30; hi = -(1 << 30); }
+    const int a = imax(lo, 0), b = imin(hi, We - 1);
+    int xl, xr;
+    const bool any = fov_rowspan(px, py, n, y, We, xl, xr);
+    if (any != (a <= b) || (any && (xl != a || xr != b))) bad++;
+  }
+  return bad;
+}
+
 // finished (padded, blurred) alpha tile of one drop into out[ph*pw]
 int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
              double* out) {

@@ -76,9 +76,13 @@ def test_float_polygon_unsure_cases_go_to_float64(tmp_path):
 
 
 def _dda_bad(px, py, He, We):
+    """rows on which the cursors of k_fov_dda (DdaCursors) or of k_fov_walk (DdaWalk, r05) differ from the rule; -1: not monotone"""
     emu = h.hostemu()
     px, py = np.ascontiguousarray(px, np.int32), np.ascontiguousarray(py, np.int32)
-    return emu.emu_dda_check(h._p(px), h._p(py), len(px), He, We)
+    a = emu.emu_dda_check(h._p(px), h._p(py), len(px), He, We)
+    b = emu.emu_walk_check(h._p(px), h._p(py), len(px), He, We)
+    assert (a < 0) == (b < 0)
+    return a if a < 0 else a + b
 
 
 def test_thread_per_drop_spans_equal_the_rule(tmp_path):

@@ -237,7 +237,7 @@ def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path
     scenes.append((wide, wbg, wenv, wide.product_drops(0)))
     for S, b, e, d in scenes:
         outs = []
-        for dda in (1, 0):
+        for dda in (2, 1, 0):
             alt = h.hb.RainHip(0)
             try:
                 alt.set_option(h.hb.RR_OPT_FOV_DDA, dda)
@@ -247,5 +247,39 @@ def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path
             finally:
                 alt.close()
         assert (outs[0]["status"] == 0).sum() > 0.5 * len(d)
-        for k in ('status', 'colour', 'mask', 'mask_i32', 'image_u8'):
-            assert np.array_equal(outs[0][k], outs[1][k]), k
+        for other in outs[1:]:           # 2 = incremental cursors over edge records (k_fov_walk, r05), 1 = k_fov_dda, 0 = k_fov_spans
+            for k in ('status', 'colour', 'mask', 'mask_i32', 'image_u8'):
+                assert np.array_equal(outs[0][k], other[k]), k
+
+
+def test_composite_codes_and_blur_prefetch(setup):
+    """r05 tuning switches of the float-colour route.  RR_OPT_BLUR_PREFETCH (LDS-DMA loads that pull the next work item's
+    raw tile towards the L2) changes no bit.  RR_OPT_COMPOSITE_U16 (the composite before the mean shift as 16-bit codes
+    instead of floats) keeps mask and statuses and moves the uint8 image by at most 1 LSB on a few pixels in a thousand;
+    values outside [0, 1] -- a pixel no drop was blended into -- go through the code 65535 and come out as
+    before."""
+    sc, bg, env, drops, rh, base = setup
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    wild = bg.copy()
+    wild[5, 7] = (0.25, 7.5, -3.0)             # (finite: the mean shift of the frame stays a number)
+    wild[200:204, 600:640] = (1.5, -0.5, 2.0)
+    wild[300:310, 40:50] = 1.0
+    wild[310:320, 40:50] = 0.0
+    frw = dict(fr, bg=wild, rainy_bg=wild)
+    ref = rh.render_frames([fr, frw], want_composite=False)
+    for opt in (h.hb.RR_OPT_BLUR_PREFETCH, h.hb.RR_OPT_COMPOSITE_U16):
+        rh.set_option(opt, 0)
+        try:
+            alt = rh.render_frames([fr, frw], want_composite=False)
+        finally:
+            rh.set_option(opt, 1)
+        for a, b in zip(ref, alt):
+            for k in ('status', 'mask', 'mask_i32'):
+                assert np.array_equal(a[k], b[k]), (opt, k)
+            d = np.abs(a['image_u8'].astype(int) - b['image_u8'].astype(int))
+            if opt == h.hb.RR_OPT_BLUR_PREFETCH:
+                assert d.max() == 0
+            else:
+                assert d.max() <= 1 and (d != 0).mean() < 4e-3, (d.max(), (d != 0).mean())
+    # the coded composite against the float64 compositor and the host build (the 1-LSB bar of BASELINE.json)
+    assert np.abs(ref[0]['image_u8'].astype(int) - base['image_u8'].astype(int)).max() <= 1
