@@ -524,7 +524,7 @@ def main():
         names = {0: ('k_tile', ['stage plan+texture', 'row intervals', 'samples', 'horizontal folds', 'wait for waves', 'vertical folds+store', '-', 'barrier at item start']),
                  1: ('k_tile_big', ['search+barriers', 'plan fields', 'pixel']),
                  2: ('k_blur_small', ['plan+weights+raw->LDS', 'row pass', 'column pass+store']),
-                 3: ('k_blur_fused', ['issue loads', 'barrier (loads land)', 'row pass', 'barrier', 'column pass+store', 'barrier'])}
+                 3: ('k_blur_fused[_dma]', ['issue loads | dma: clear Y + wait for the loads + halo', 'barrier A (loads land)', 'row pass', 'barrier B', 'column pass+store', 'barrier C', 'dma: next loads issued'])}
         calls = args.steps + args.warmup
         sys.stderr.write("PHASES (shader cycles summed over waves, per call; share of the kernel's wave time)\n")
         for kid, (kn, ph) in names.items():

@@ -401,9 +401,10 @@ enum {
                                      * floats: half the bytes written there and read back by the final pass.  The code is 2^-17 off at
                                      * most (an LSB of rainy_image is 2^-8): the image contract (+-1 LSB) holds, the mask never sees it.
                                      * Ignored with RR_OPT_WILD_PIXELS, and whenever a caller asks for the composite itself. */
-  RR_OPT_BLUR_PREFETCH = 17         /* tuning (r05): 1 (default) the fused defocus blur pulls the NEXT work item's raw tile towards the
-                                     * L2 while it filters the current one (gfx950 LDS-DMA loads into a scratch line of LDS: no
-                                     * registers, nothing waits for them).  Same results. */
+  RR_OPT_BLUR_DMA = 17              /* tuning (r05): 1 (default) the fused defocus blur stages its raw sub-tiles and weight tables with
+                                     * gfx950 LDS-DMA loads (global_load_lds: no registers in between), issued a sub-tile AHEAD: they land
+                                     * while the current sub-tile's column pass runs; 0: the r04 kernel (loads through registers at the
+                                     * start of every sub-tile).  Same results. */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -189,7 +189,6 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
   int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
   int32_t blur_bx, blur_by;         // LDS capacities (doubles) of the fused blur's two staging tiles (RR_OPT_BLUR_WORKGROUPS)
-  int32_t blur_pf;                  // RR_OPT_BLUR_PREFETCH: k_blur_fused pulls the next item's raw tile towards the L2 (LDS-DMA into a scratch line)
 };
 
 // ---------------------------------------------------------------------------
@@ -2246,8 +2245,6 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
   double* hw2 = s_dyn + (BR_MAX + 1);
   double* X = s_dyn + 2 * (BR_MAX + 1);                                 // 98 doubles in front: X and Y stay 16-byte aligned
   double* Y = X + sc.blur_bx;
-  // 256 bytes behind Y that nothing reads: where the prefetch DMAs of the next item land (see below)
-  const uint32_t pf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(Y + sc.blur_by);
   const int n_items = sc.counts[f * 8 + 2];
   if ((int)blockIdx.x >= n_items) return;
   // r04: the item record and the plan of the NEXT item travel ahead of the current one's arithmetic, by vector loads (lane l
@@ -2350,29 +2347,6 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
       PH(0)                                         // plan, tables, raw sub-tile -> LDS (issue)
       __syncthreads();
       PH(1)                                         // barrier: the loads land
-      // r05: the load phase above is this kernel's largest (47 % of its wave time: a round trip to HBM per item, the raw
-      // tiles were written several kernels ago).  While this item is filtered, the NEXT item's raw tile and weight tables
-      // are pulled towards the L2: one gfx950 LDS-DMA load (global_load_lds_dword) per 128-byte line, a thread per
-      // line, all of them into one scratch line of LDS -- no register receives anything, nothing ever waits for them
-      // (inline assembly: the compiler neither counts them nor orders LDS reads behind them; an uncounted load in flight
-      // can only make a later counted wait longer), and the next item's own loads then hit the L2.
-      if (sc.blur_pf && st == item.y && it + G < n_items) {
-        const int nd = (int)__builtin_amdgcn_readlane((int)iv_cur, 0);         // (iv_cur / pv_cur hold the next item already)
-        if (nd != item.x) {
-          const PlanView q = unpack(pv_cur);
-          const char* raw = reinterpret_cast<const char*>(sc.arena + q.a0_off);      // raw tiles start on 128-byte lines
-          const int lines = imin((q.tw * q.th * 8 + 127) >> 7, 248);
-          const char* wt = reinterpret_cast<const char*>(sc.wtab + ((int64_t)f * max_drops + nd) * 2 * (BR_MAX + 1));
-          const char* src = t < lines ? raw + (int64_t)t * 128 : wt + (int64_t)(t - lines) * 128;
-          if (t < lines + 7) {
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(src), "s"(pf_lds)
-                         : "memory");
-          }
-        }
-      }
       // axis 0 (rows, sigma = c): symmetric correlate1d.  A thread owns data column xc and FOUR consecutive
       // rows; as the tap distance shrinks the upper/lower operand windows slide by one row, so each
       // step needs two new LDS values instead of eight (register rotation).  Lanes run along x.
@@ -2425,6 +2399,254 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
       PH(5)
     }
   }
+  }
+  PH_FLUSH(3)
+}
+
+// ---------------------------------------------------------------------------
+// fused defocus blur, staged by LDS-DMA a sub-tile ahead (r05; the default)
+// ---------------------------------------------------------------------------
+// k_blur_fused spends 47 % of its wave time in the load phase of a sub-tile (a round trip to memory through registers,
+// nothing else to do meanwhile) and its software-pipelined form died of register pressure (r04: 168 VGPRs).  gfx950's
+// LDS-DMA loads (global_load_lds_dword: every lane names a global address, the 64 dwords land side by side in LDS, no
+// register in between) make the pipeline free:
+//   barrier A | row pass (X, hw1 -> Y) | barrier B | ISSUE the next sub-tile's loads into X | column pass (Y, hw2 -> HBM)
+//   | barrier C | clear Y | wait for the loads, zero the halo rows | barrier A ...
+// X is dead after the row pass, so the next sub-tile's raw data (same item or the next item of the workgroup) travels
+// while the column pass, its stores and the clearing of Y run.  The weight tables of a new drop travel the same way into
+// the other of two table slots (the column pass still reads the current drop's hw2).
+//   * an element of X is two dwords: lanes 2j, 2j + 1 of a wave carry element j of its 32-element piece; a round of the four
+//     waves moves 128 consecutive elements of X; (row, column) of a lane's element by the incremental division of the
+//     r04 loader.  Rows of the haloed tile outside the raw tile are not loaded (lanes masked) and zeroed after the wait;
+//   * the loads are issued by inline assembly (M0 = LDS address of the wave's piece): the compiler neither counts them nor
+//     orders LDS reads behind them -- a counted wait of its own can only wait longer; the one wait that matters is the
+//     explicit vmcnt(0) in front of barrier A;
+//   * item records and plans travel two items ahead (vector loads, fields by v_readlane), as the plan of the next item is
+//     needed a sub-tile early.
+// Arithmetic, fold order and the LDS images of X, Y and the tables are k_blur_fused's: the tiles are the same bits
+// (tests/test_gpu_properties.py, RR_OPT_BLUR_DMA 0 / 1).
+__device__ inline void glds_dword(const void* src, uint32_t lds_byte) {     // LDS[lds_byte + 4 * lane] <- *(const uint32_t*)src, asynchronously
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte))      // (wave-uniform by construction; the compiler wants the proof)
+               : "memory");
+}
+__device__ inline void glds_dwordx4(const void* src, uint32_t lds_byte) {   // LDS[lds_byte + 16 * lane .. + 16) <- 16 bytes at src (both 16-byte aligned)
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte))
+               : "memory");
+}
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void k_blur_fused_dma(const FrameDesc* frames, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, t = threadIdx.x, lane = t & 63, G = gridDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  constexpr int TAB = 2 * (BR_MAX + 1);                                 // hw1 | hw2 of one drop
+  double* tabs = s_dyn;                                                 // two generations
+  double* X = s_dyn + 2 * TAB;                                          // 196 doubles in front: X and Y stay 16-byte aligned
+  double* Y = X + sc.blur_bx;
+  const uint32_t lds_tabs = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)tabs;
+  const uint32_t lds_x = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)X;
+  const int n_items = sc.counts[f * 8 + 2];
+  if ((int)blockIdx.x >= n_items) return;
+  const global_ptr<const uint32_t> items_w = as_global(reinterpret_cast<const uint32_t*>(sc.blur_items + (int64_t)f * max_drops * BLUR_ITEMS_PER_DROP));
+  const DropPlan* plans = sc.plan + (int64_t)f * max_drops;
+  auto load_item = [&](int item) { return items_w[(int64_t)item * 4 + (lane & 3)]; };
+  auto load_plan = [&](int i) { return as_global(reinterpret_cast<const uint32_t*>(plans + i))[lane]; };
+  struct PlanView {                   // the plan fields this kernel uses, wave-uniform
+    int r1, r2, ew, eh, tw, th, epitch, epad;
+    long long a0_off, a1_off;
+  };
+  auto unpack = [&](uint32_t pv) {
+    auto F = [&](size_t byte_off) { return (int)__builtin_amdgcn_readlane((int)pv, (int)(byte_off / 4)); };
+    PlanView o;
+    o.r1 = F(offsetof(DropPlan, r1)); o.r2 = F(offsetof(DropPlan, r2)); o.ew = F(offsetof(DropPlan, ew)); o.eh = F(offsetof(DropPlan, eh));
+    o.tw = F(offsetof(DropPlan, tw)); o.th = F(offsetof(DropPlan, th)); o.epitch = F(offsetof(DropPlan, epitch)); o.epad = F(offsetof(DropPlan, epad));
+    o.a0_off = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a0_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a0_off)));
+    o.a1_off = (long long)(((unsigned long long)(unsigned)F(offsetof(DropPlan, a1_off) + 4) << 32) | (unsigned)F(offsetof(DropPlan, a1_off)));
+    return o;
+  };
+  auto item_of = [&](uint32_t iv) {
+    return make_int4((int)__builtin_amdgcn_readlane((int)iv, 0), (int)__builtin_amdgcn_readlane((int)iv, 1),
+                     (int)__builtin_amdgcn_readlane((int)iv, 2), (int)__builtin_amdgcn_readlane((int)iv, 3));
+  };
+  struct Geo {                        // one sub-tile (wave-uniform), k_blur_fused's quantities
+    int y0, x0, ho, wo, hop, hi, yp, xa, wd, nx, xs, ys, e_lo, e_hi;
+  };
+  auto geo = [&](const PlanView& p, int Lwo, int Lho, int st) {
+    Geo g;
+    const int ntx = (p.ew + Lwo - 1) / Lwo;
+    const int sty = st / ntx, stx = st - sty * ntx;
+    g.y0 = sty * Lho; g.x0 = stx * Lwo;
+    g.ho = imin(Lho, p.eh - g.y0);
+    g.wo = imin(Lwo, p.ew - g.x0);
+    g.hop = (g.ho + 3) & ~3;
+    const int wi = g.wo + 2 * p.r2;
+    g.hi = g.hop + 2 * p.r1;
+    g.yp = blur_y_pitch(g.wo, p.r2);
+    g.xa = imax(0, 2 * p.r2 - g.x0);
+    const int xb = imin(wi, p.tw + 2 * p.r2 - g.x0);
+    g.wd = imax(xb - g.xa, 0);
+    g.nx = g.wd * g.hi;
+    g.xs = g.x0 - 2 * p.r2 + g.xa; g.ys = g.y0 - 2 * p.r1;
+    // rows [ra, rb) of the haloed tile lie inside the raw tile: elements [e_lo, e_hi) of X are loaded, the rest is zero
+    const int ra = imin(imax(-g.ys, 0), g.hi), rb = imax(imin(p.th - g.ys, g.hi), ra);
+    g.e_lo = ra * g.wd; g.e_hi = rb * g.wd;
+    return g;
+  };
+  // the loads of one sub-tile: raw data rows into X, and (new drop) its two weight tables into table slot tb
+  auto stage = [&](const PlanView& p, const Geo& g, int drop, bool tables, int tb) {
+    if (g.e_hi > g.e_lo && g.wd == p.tw) {
+      // A sub-tile as wide as the raw tile (nearly all of them: blur_layout prefers full-width bands) is ONE contiguous run
+      // of the raw tile: element e of X is element ys * tw + e of the tile.  16 bytes per lane -- a quarter of the load
+      // instructions: the dword form spent more wave time ISSUING its loads (64 addresses per 256 bytes) than the column
+      // pass takes (profiles/r05_phase_clocks_blur_dma_dword.txt).  The LDS side of a 16-byte piece is aligned (pairs start
+      // on even elements), the global side need not be (scripts/probes/glds_probe.hip: any 4-byte alignment loads
+      // correctly, lanes switched off in EXEC write nothing).  An odd first / last loaded element travels alone (two
+      // dwords): a pair must not reach into the halo, whose zeros are STORED after the wait -- nothing orders a plain LDS
+      // store behind a DMA write to the same address (a first version let the pair bring the neighbour's element along and
+      // zeroed it afterwards: wrong tiles now and then).
+      const char* src = reinterpret_cast<const char*>(sc.arena + p.a0_off + (int64_t)g.ys * p.tw);
+      const int a = (g.e_lo + 1) & ~1, b = g.e_hi & ~1;
+      for (int e0 = (a & ~511); e0 < b; e0 += 512) {
+        const int e = e0 + wave * 128 + 2 * lane;
+        if (e >= a && e < b) glds_dwordx4(src + (int64_t)e * 8, lds_x + (uint32_t)(e0 + wave * 128) * 8u);
+      }
+      if (wave == 0 && (g.e_lo & 1) && lane < 2) glds_dword(src + (int64_t)g.e_lo * 8 + lane * 4, lds_x + (uint32_t)g.e_lo * 8u);
+      if (wave == 1 && (g.e_hi & 1) && g.e_hi - 1 >= g.e_lo && lane < 2) glds_dword(src + (int64_t)(g.e_hi - 1) * 8 + lane * 4, lds_x + (uint32_t)(g.e_hi - 1) * 8u);
+    } else if (g.e_hi > g.e_lo) {
+      const int wdd = imax(g.wd, 1);
+      const float inv_wd = 1.0f / (float)wdd;
+      const int dq = (int)((128.0f + 0.5f) * inv_wd), dr = 128 - dq * wdd;
+      const char* src = reinterpret_cast<const char*>(sc.arena + p.a0_off) + (lane & 1) * 4;
+      const int c0 = g.e_lo >> 7, c1 = (g.e_hi + 127) >> 7;               // pieces of 128 elements that hold loaded rows
+      int e = c0 * 128 + wave * 32 + (lane >> 1);
+      int yy = (int)(((float)e + 0.5f) * inv_wd), xc = e - yy * wdd;
+      for (int c = c0; c < c1; c++) {
+        if (e >= g.e_lo && e < g.e_hi)
+          glds_dword(src + (int64_t)((g.ys + yy) * p.tw + (g.xs + xc)) * 8, lds_x + (uint32_t)(c * 128 + wave * 32) * 8u);
+        e += 128;
+        xc += dr;
+        yy += dq;
+        if (xc >= wdd) { xc -= wdd; yy += 1; }
+      }
+    }
+    if (tables) {                     // 2 * 49 doubles = 196 dwords, as they lie in wtab (k_blur_weights): hw1 | hw2
+      const char* wt = reinterpret_cast<const char*>(sc.wtab + ((int64_t)f * max_drops + drop) * TAB);     // (784 bytes per drop: 16-byte aligned)
+      if (wave == 3 && lane < TAB / 2) glds_dwordx4(wt + lane * 16, lds_tabs + (uint32_t)(tb * TAB) * 8u);
+    }
+  };
+  // item records and plans, two items ahead
+  uint32_t iv0 = load_item(blockIdx.x);
+  uint32_t pv0 = load_plan((int)__builtin_amdgcn_readlane((int)iv0, 0));
+  uint32_t iv1 = load_item(imin((int)blockIdx.x + G, n_items - 1));
+  uint32_t pv1 = load_plan((int)__builtin_amdgcn_readlane((int)iv1, 0));
+  uint32_t iv2 = load_item(imin((int)blockIdx.x + 2 * G, n_items - 1));
+  int it = blockIdx.x;
+  int4 item = item_of(iv0);
+  PlanView p = unpack(pv0);
+  int st = item.y, tb = 0;
+  Geo g = geo(p, item.w & 0xffff, item.w >> 16, st);
+  stage(p, g, item.x, true, tb);
+  PH_DECL
+  for (;;) {
+    const int r1 = p.r1, r2 = p.r2;
+    const double* hw1 = tabs + tb * TAB;
+    const double* hw2 = hw1 + (BR_MAX + 1);
+    {
+      const int nz2 = (g.yp * g.hop + 1) >> 1;            // Y := 0, two doubles per store (capacity is even: no overrun)
+      double2* Y2 = reinterpret_cast<double2*>(Y);
+      for (int i = t; i < nz2; i += 256) Y2[i] = make_double2(0.0, 0.0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this sub-tile's loads (issued a sub-tile ago) have landed
+    // (here, where everything in flight has just been waited for: the compiler guards the reads of the prefetched record /
+    //  plan with vmcnt(0), which after barrier B would wait for the column pass' stores -- 9 % of the wave time)
+    // ---- the next sub-tile: of this item, or the first one of the workgroup's next item (its loads go out after barrier B) ----
+    bool has_next = true, new_item = false;
+    int4 nitem = item;
+    PlanView np = p;
+    int nst = st + 1, ntb = tb;
+    if (nst >= item.y + item.z) {
+      if (it + G < n_items) {
+        new_item = true;
+        nitem = item_of(iv1);
+        np = unpack(pv1);
+        nst = nitem.y;
+        if (nitem.x != item.x) ntb = tb ^ 1;
+      } else {
+        has_next = false;
+      }
+    }
+    {
+      // keep the records / plans two items ahead.  Unconditional loads (the same record again while the item lasts): a
+      // load whose result had to be merged with the old value at the end of a branch was waited for on the spot.  BEFORE the
+      // sub-tile's loads go out: the compiler waits for the previous round of these two with vmcnt(0), which would drain them.
+      iv1 = new_item ? iv2 : iv1;
+      pv1 = load_plan((int)__builtin_amdgcn_readlane((int)iv1, 0));
+      iv2 = load_item(imin(new_item ? it + 3 * G : it + 2 * G, n_items - 1));              // (past the list: the last record again, never used)
+    }
+    for (int i = t; i < g.e_lo; i += 256) X[i] = 0.0;     // halo rows above / below the raw tile
+    for (int i = g.e_hi + t; i < g.nx; i += 256) X[i] = 0.0;
+    PH(0)
+    __syncthreads();                                      // A
+    PH(1)
+    {                                                     // axis 0 (rows): as k_blur_fused
+      const int wd = g.wd, nrb = g.hop >> 2, nv = nrb * wd;
+      const float inv_wd = 1.0f / (float)imax(wd, 1);
+      for (int idx = t; idx < nv; idx += 256) {
+        const int rb = (int)(((float)idx + 0.5f) * inv_wd), xq = idx - rb * wd;
+        const double* c0 = X + (4 * rb + r1) * wd + xq;
+        double acc0, acc1, acc2, acc3;
+        blur4(c0, wd, [&](int k) { return hw1[k]; }, r1, acc0, acc1, acc2, acc3);
+        double* o = Y + 4 * rb * g.yp + g.xa + xq;
+        o[0] = acc0;
+        o[g.yp] = acc1;
+        o[2 * g.yp] = acc2;
+        o[3 * g.yp] = acc3;
+      }
+    }
+    PH(2)
+    __syncthreads();                                      // B: X is free
+    PH(3)
+    Geo ng = g;
+    if (has_next) {
+      ng = geo(np, nitem.w & 0xffff, nitem.w >> 16, nst);
+      stage(np, ng, nitem.x, ntb != tb, ntb);
+    }
+    PH(6)                                                 // the next sub-tile's loads issued
+    {                                                     // axis 1 (columns) -> global: as k_blur_fused
+      const int ncb = (g.wo + 3) >> 2, nh = ncb * g.ho;
+      const float inv_ho = 1.0f / (float)g.ho;
+      double* dst = sc.arena + p.a1_off;
+      for (int idx = t; idx < nh; idx += 256) {
+        const int cb = (int)(((float)idx + 0.5f) * inv_ho), yq = idx - cb * g.ho;
+        const double* c0 = Y + yq * g.yp + 4 * cb + r2;
+        double acc0, acc1, acc2, acc3;
+        if (r2 > 0) {
+          blur4(c0, 1, [&](int k) { return hw2[k]; }, r2, acc0, acc1, acc2, acc3);
+        } else {
+          acc0 = c0[0]; acc1 = c0[1]; acc2 = c0[2]; acc3 = c0[3];
+        }
+        const int xo = 4 * cb;
+        double* o = dst + (int64_t)(g.y0 + yq) * p.epitch + p.epad + (g.x0 + xo);
+        if (xo + 3 < g.wo) {
+          o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3;
+        } else {
+          o[0] = acc0;
+          if (xo + 1 < g.wo) o[1] = acc1;
+          if (xo + 2 < g.wo) o[2] = acc2;
+        }
+      }
+    }
+    PH(4)
+    if (!has_next) break;
+    __syncthreads();                                      // C: Y and the old table slot are free
+    PH(5)
+    if (new_item) it += G;
+    item = nitem; p = np; st = nst; tb = ntb; g = ng;
   }
   PH_FLUSH(3)
 }
@@ -3814,7 +4036,7 @@ struct rr_ctx {
   bool pipe_f32 = true;              // RR_OPT_PIPELINE_F32: float32 hand-over from the pre-pass to the hot path inside rr_pipeline_*
   bool walk_attr = false;
   bool composite_u16 = true;         // RR_OPT_COMPOSITE_U16
-  bool blur_prefetch = true;         // RR_OPT_BLUR_PREFETCH
+  bool blur_dma = true;              // RR_OPT_BLUR_DMA
   int fov_dda = 2;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (2: k_fov_walk, 1: k_fov_dda)
   int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
   int n_tex = 0;
@@ -4222,7 +4444,6 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int blur_wg = ctx->blur_wg ? ctx->blur_wg : 4;      // workgroups per CU the fused blur is sized for
   sc.blur_bx = blur_wg == 3 ? 3072 : (blur_wg == 5 ? 2304 : 2816);
   sc.blur_by = blur_wg == 5 ? 1600 : 2048;
-  sc.blur_pf = ctx->blur_prefetch ? 1 : 0;
   // One in-order stream: FOV spans -> plan -> scan -> dedup -> lists -> FOV sums -> colour -> tiles -> blur ->
   // composite -> finalise.
   // Work-list kernels take their items grid-stride, the list lengths only exist on the device: with many frames per call
@@ -4381,9 +4602,14 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_fused");
-      const size_t lds = sizeof(double) * (size_t)(2 * (BR_MAX + 1) + sc.blur_bx + sc.blur_by) + 256;     // + the prefetch DMAs' scratch line
+      const size_t lds = sizeof(double) * (size_t)(2 * (BR_MAX + 1) + sc.blur_bx + sc.blur_by);
       const dim3 grid(imin((max_drops + 1) / 2, grid_cap(4096)), n);
-      if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
+      if (ctx->blur_dma) {                                 // r05: staged a sub-tile ahead by LDS-DMA; + a second generation of weight tables
+        const size_t lds2 = lds + sizeof(double) * 2 * (BR_MAX + 1);
+        if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused_dma<3>, grid, dim3(256), lds2, s, ctx->d_frames, D, sc);
+        else if (blur_wg == 5) hipLaunchKernelGGL(k_blur_fused_dma<5>, grid, dim3(256), lds2, s, ctx->d_frames, D, sc);
+        else hipLaunchKernelGGL(k_blur_fused_dma<4>, grid, dim3(256), lds2, s, ctx->d_frames, D, sc);
+      } else if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else if (blur_wg == 5) hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else hipLaunchKernelGGL(k_blur_fused<4>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
     }
@@ -5807,7 +6033,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;
-    case RR_OPT_BLUR_PREFETCH: ctx->blur_prefetch = value != 0; return RR_OK;
+    case RR_OPT_BLUR_DMA: ctx->blur_dma = value != 0; return RR_OK;
     case RR_OPT_FOV_DDA: ctx->fov_dda = value < 0 ? 0 : (value > 2 ? 2 : value); return RR_OK;
     case RR_OPT_PIPELINE_F32: ctx->pipe_f32 = value != 0; return RR_OK;
     case RR_OPT_WILD_PIXELS: ctx->wild_pixels = value != 0; return RR_OK;

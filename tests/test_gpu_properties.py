@@ -253,8 +253,8 @@ def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path
 
 
 def test_composite_codes_and_blur_prefetch(setup):
-    """r05 tuning switches of the float-colour route.  RR_OPT_BLUR_PREFETCH (LDS-DMA loads that pull the next work item's
-    raw tile towards the L2) changes no bit.  RR_OPT_COMPOSITE_U16 (the composite before the mean shift as 16-bit codes
+    """r05 tuning switches of the float-colour route.  RR_OPT_BLUR_DMA (the fused blur's sub-tiles staged a sub-tile ahead by
+    LDS-DMA loads) changes no bit.  RR_OPT_COMPOSITE_U16 (the composite before the mean shift as 16-bit codes
     instead of floats) keeps mask and statuses and moves the uint8 image by at most 1 LSB on a few pixels in a thousand;
     values outside [0, 1] -- a pixel no drop was blended into -- go through the code 65535 and come out as
     before."""
@@ -267,7 +267,7 @@ def test_composite_codes_and_blur_prefetch(setup):
     wild[310:320, 40:50] = 0.0
     frw = dict(fr, bg=wild, rainy_bg=wild)
     ref = rh.render_frames([fr, frw], want_composite=False)
-    for opt in (h.hb.RR_OPT_BLUR_PREFETCH, h.hb.RR_OPT_COMPOSITE_U16):
+    for opt in (h.hb.RR_OPT_BLUR_DMA, h.hb.RR_OPT_COMPOSITE_U16):
         rh.set_option(opt, 0)
         try:
             alt = rh.render_frames([fr, frw], want_composite=False)
@@ -277,7 +277,7 @@ def test_composite_codes_and_blur_prefetch(setup):
             for k in ('status', 'mask', 'mask_i32'):
                 assert np.array_equal(a[k], b[k]), (opt, k)
             d = np.abs(a['image_u8'].astype(int) - b['image_u8'].astype(int))
-            if opt == h.hb.RR_OPT_BLUR_PREFETCH:
+            if opt != h.hb.RR_OPT_COMPOSITE_U16:
                 assert d.max() == 0
             else:
                 assert d.max() <= 1 and (d != 0).mean() < 4e-3, (d.max(), (d != 0).mean())
