@@ -458,7 +458,7 @@ def _div_round_half_up(num, den):
     return (2 * num + den) // (2 * den)
 
 
-def fov_rowspans(poly_int, rows, cols):
+def fov_rowspans_span_rule(poly_int, rows, cols):
     """Row spans of the FOV polygon inside the rows x cols map.
 
     Rule (ours; the reference goes pyclipper-intersection -> cv2.fillConvexPoly,
@@ -510,12 +510,291 @@ def fov_rowspans(poly_int, rows, cols):
     return ya, xl, xr
 
 
-def fill_fov_mask(mask, poly_int):
-    """mask[...] = 1 inside the FOV row spans (the oracle's stand-in for
-    cv2.fillConvexPoly(mask, s, 1) at reference common/bad_weather.py:388)."""
+def fill_fov_mask_span_rule(mask, poly_int):
+    """mask[...] = 1 inside the row spans of fov_rowspans_span_rule."""
     rows, cols = mask.shape
-    y0, xl, xr = fov_rowspans(poly_int, rows, cols)
+    y0, xl, xr = fov_rowspans_span_rule(poly_int, rows, cols)
     for k in range(len(xl)):
         if xl[k] <= xr[k]:
             mask[y0 + k, xl[k]:xr[k] + 1] = 1
     return mask
+
+
+# Which rule stands in for cv2.fillConvexPoly(mask, s, 1) (reference common/bad_weather.py:388):
+#   'span' (default; what the library's fast colour kernels implement) -- fov_rowspans_span_rule;
+#   'cv'   -- OpenCV's algorithm as restated at the end of this file (cv_fill_convex_poly) for the closed N_FOV-gon that does
+#             not wrap; wrapping polygons keep the span rule (FillConvexPoly's result for them depends on the vertex Clipper
+#             lists first).  The library's RR_OPT_FOV_FILL_RULE 1 / rr_device.h fov_rowspan_cv.
+# tests/test_fill_rules.py and scripts/fill_rule_study.py measure what the choice changes (colour only: <= 0.3 % of a drop's
+# colour constants, <= 1 LSB of rainy_image on 1.4 % of its values at KITTI 100 mm/hr; the mask never sees it).
+FILL_RULE = 'span'
+N_FOV = 20
+
+
+def set_fill_rule(rule, n_fov=20):
+    global FILL_RULE, N_FOV
+    assert rule in ('span', 'cv')
+    FILL_RULE, N_FOV = rule, n_fov
+
+
+def poly_row_turns(py):
+    """rr_device.h poly_row_turns: direction changes of the vertices' row sequence around the loop."""
+    turns = d = d_first = 0
+    n = len(py)
+    for k in range(1, n + 1):
+        a, b = int(py[k - 1]), int(py[k % n])
+        sg = (b > a) - (b < a)
+        if sg:
+            if d == 0:
+                d_first = sg
+            elif sg != d:
+                turns += 1
+            d = sg
+    if d and d_first and d != d_first:
+        turns += 1
+    return turns
+
+
+def fill_rule_cv_applies(poly_int, rows, cols):
+    """rr_device.h fov_fill_rule_cv_applies."""
+    P = np.asarray(poly_int, np.int64).reshape(-1, 2)
+    if len(P) != N_FOV or len(P) < 3:
+        return False
+    if (P[:, 0] < 0).any() or (P[:, 0] >= cols).any() or (P[:, 1] < 0).any() or (P[:, 1] >= rows).any():
+        return False
+    return poly_row_turns(P[:, 1]) <= 2
+
+
+def fov_rowspans(poly_int, rows, cols):
+    """(y0, xl[], xr[]) under FILL_RULE; xl > xr marks an empty row."""
+    if FILL_RULE == 'cv' and fill_rule_cv_applies(poly_int, rows, cols):
+        return fov_rowspans_cv(poly_int, rows, cols)
+    return fov_rowspans_span_rule(poly_int, rows, cols)
+
+
+def fill_fov_mask(mask, poly_int):
+    """The oracle's stand-in for cv2.fillConvexPoly(mask, s, 1) at reference common/bad_weather.py:388, under FILL_RULE."""
+    if FILL_RULE == 'cv' and fill_rule_cv_applies(poly_int, *mask.shape):
+        return fill_fov_mask_cv(mask, poly_int)
+    return fill_fov_mask_span_rule(mask, poly_int)
+
+
+# --------------------------------------------------------------------------
+# cv2.fillConvexPoly as OpenCV 3.x implements it (r05): outline by Line(), interior by the 16.16 edge walk
+# --------------------------------------------------------------------------
+# VERDICT r03 / r04 asked for the published algorithm instead of the "nearest x of every edge" rule above.  What follows
+# restates modules/imgproc/src/drawing.cpp of OpenCV 3.2 (FillConvexPoly, Line, LineIterator, clipLine) operation by
+# operation -- from the published source as remembered, UNPINNED like everything in this file (cv2 is not installed here;
+# README "parity unpinned").  Call site: reference common/bad_weather.py:367-389 --
+#     s = pyclipper intersection of the polygon with the map rectangle, closed by repeating its first vertex
+#     cv2.fillConvexPoly(mask_float64, s, 1)            # lineType = LINE_8, shift = 0
+# The intersection leaves the polygon as it is (all its vertices lie in [0, cols] x [0, rows]); which vertex Clipper starts
+# its output with is not known -- `cv_fill_convex_poly` is evaluated for every rotation / both orientations in
+# tests/test_fill_rules.py: for the CONVEX 20-gons the result does not depend on it, for the wrapping 24-gons it does.
+XY_SHIFT = 16
+XY_ONE = 1 << XY_SHIFT
+
+
+def _c_div(a, b):
+    """C integer division (truncation toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def cv_clip_line(cols, rows, p1, p2):
+    """cv::clipLine(Size, Point&, Point&), integer form of OpenCV 3.2.  Returns (inside, p1, p2)."""
+    x1, y1 = int(p1[0]), int(p1[1])
+    x2, y2 = int(p2[0]), int(p2[1])
+    right, bottom = cols - 1, rows - 1
+    if cols <= 0 or rows <= 0:
+        return False, (x1, y1), (x2, y2)
+    c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8
+    c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8
+    if (c1 & c2) == 0 and (c1 | c2) != 0:
+        if c1 & 12:
+            a = 0 if c1 < 8 else bottom
+            x1 += _c_div((a - y1) * (x2 - x1), (y2 - y1))
+            y1 = a
+            c1 = (x1 < 0) + (x1 > right) * 2
+        if c2 & 12:
+            a = 0 if c2 < 8 else bottom
+            x2 += _c_div((a - y2) * (x2 - x1), (y2 - y1))
+            y2 = a
+            c2 = (x2 < 0) + (x2 > right) * 2
+        if (c1 & c2) == 0 and (c1 | c2) != 0:
+            if c1:
+                a = 0 if c1 == 1 else right
+                y1 += _c_div((a - x1) * (y2 - y1), (x2 - x1))
+                x1 = a
+                c1 = 0
+            if c2:
+                a = 0 if c2 == 1 else right
+                y2 += _c_div((a - x2) * (y2 - y1), (x2 - x1))
+                x2 = a
+                c2 = 0
+    return (c1 | c2) == 0, (x1, y1), (x2, y2)
+
+
+def cv_line_pixels(cols, rows, p1, p2):
+    """Pixels Line(img, p1, p2, color, 8) writes: LineIterator(img, p1, p2, 8, left_to_right=True)."""
+    x1, y1 = int(p1[0]), int(p1[1])
+    x2, y2 = int(p2[0]), int(p2[1])
+    if not (0 <= x1 < cols and 0 <= x2 < cols and 0 <= y1 < rows and 0 <= y2 < rows):
+        ok, (x1, y1), (x2, y2) = cv_clip_line(cols, rows, (x1, y1), (x2, y2))
+        if not ok:
+            return []
+    dx, dy = x2 - x1, y2 - y1
+    if dx < 0:                                   # left_to_right: start from the left end point
+        dx, dy = -dx, -dy
+        x1, y1 = x2, y2
+    sy = -1 if dy < 0 else 1
+    dy = abs(dy)
+    steep = dy > dx                              # the major axis is y
+    if steep:
+        dx, dy = dy, dx
+    err = dx - (dy + dy)
+    plus_delta, minus_delta = dx + dx, -(dy + dy)
+    x, y = x1, y1
+    out = []
+    for _ in range(dx + 1):
+        out.append((x, y))
+        m = err < 0
+        err += minus_delta + (plus_delta if m else 0)
+        if steep:                                # minusStep = one row, plusStep = one pixel to the right
+            y += sy
+            if m:
+                x += 1
+        else:                                    # minusStep = one pixel to the right, plusStep = one row
+            x += 1
+            if m:
+                y += sy
+    return out
+
+
+def cv_fill_convex_poly(mask, pts, value=1):
+    """cv2.fillConvexPoly(mask, pts, value) with lineType = 8, shift = 0: FillConvexPoly of OpenCV 3.2's drawing.cpp."""
+    rows, cols = mask.shape
+    v = [(int(p[0]), int(p[1])) for p in np.asarray(pts).reshape(-1, 2)]
+    npts = len(v)
+    if npts == 0:
+        return mask
+    edges = npts
+    delta1 = delta2 = XY_ONE >> 1
+    xmin = xmax = v[0][0]
+    ymin = ymax = v[0][1]
+    imin = 0
+    p0 = v[npts - 1]
+    for i in range(npts):
+        p = v[i]
+        if p[1] < ymin:
+            ymin = p[1]
+            imin = i
+        ymax = max(ymax, p[1])
+        xmax = max(xmax, p[0])
+        xmin = min(xmin, p[0])
+        for (x, y) in cv_line_pixels(cols, rows, p0, p):          # the outline
+            mask[y, x] = value
+        p0 = p
+    if npts < 3 or xmax < 0 or ymax < 0 or xmin >= cols or ymin >= rows:
+        return mask
+    ymax = min(ymax, rows - 1)
+    e_idx = [imin, imin]
+    e_ye = [ymin, ymin]
+    e_di = [1, npts - 1]
+    e_x = [0, 0]
+    e_dx = [0, 0]
+    left, right = 0, 1
+    y = ymin
+    while True:
+        for i in range(2):
+            if y >= e_ye[i]:
+                idx, di = e_idx[i], e_di[i]
+                xs, ty = 0, 0
+                while True:
+                    ty = v[idx][1]
+                    if ty > y or edges == 0:
+                        break
+                    xs = v[idx][0]
+                    idx += di
+                    if idx >= npts:
+                        idx -= npts
+                    edges -= 1
+                ye = ty
+                xs <<= XY_SHIFT
+                xe = v[idx][0] << XY_SHIFT
+                if y >= ye:                      # no more edges
+                    return mask
+                e_ye[i] = ye
+                e_dx[i] = _c_div((xe - xs) * 2 + (ye - y), 2 * (ye - y))
+                e_x[i] = xs
+                e_idx[i] = idx
+        if e_x[left] > e_x[right]:
+            left, right = right, left
+        x1, x2 = e_x[left], e_x[right]
+        if y >= 0:
+            xx1 = (x1 + delta1) >> XY_SHIFT
+            xx2 = (x2 + delta2) >> XY_SHIFT
+            if xx2 >= 0 and xx1 < cols:
+                xx1 = max(xx1, 0)
+                xx2 = min(xx2, cols - 1)
+                if xx1 <= xx2:
+                    mask[y, xx1:xx2 + 1] = value
+        e_x[left] = x1 + e_dx[left]
+        e_x[right] = x2 + e_dx[right]
+        y += 1
+        if y > ymax:
+            break
+    return mask
+
+
+def fill_fov_mask_cv(mask, poly_int):
+    """The reference's call: the polygon closed by repeating its first vertex (bad_weather.py:373), then fillConvexPoly."""
+    P = np.asarray(poly_int, np.int64).reshape(-1, 2)
+    if len(P) == 0:
+        return mask
+    return cv_fill_convex_poly(mask, np.vstack([P, P[:1]]), 1)
+
+
+def fov_rowspans_cv(poly_int, rows, cols):
+    """Closed form of cv_fill_convex_poly per edge and row (rr_device.h fov_rowspan_cv, where the derivation is): valid when
+    fill_rule_cv_applies.  Same return convention as fov_rowspans_span_rule."""
+    P = np.asarray(poly_int, np.int64).reshape(-1, 2)
+    n = len(P)
+    ya_, yb_ = max(int(P[:, 1].min()), 0), min(int(P[:, 1].max()), rows - 1)
+    if n < 3 or ya_ > yb_:
+        return 0, np.zeros(0, np.int64), np.zeros(0, np.int64)
+    ys = np.arange(ya_, yb_ + 1)
+    big = np.int64(1) << 40
+    xl = np.full(len(ys), big)
+    xr = np.full(len(ys), -big)
+    for i in range(n):
+        x0, y0 = (int(v) for v in P[i])
+        x1, y1 = (int(v) for v in P[(i + 1) % n])
+        sel = (ys >= min(y0, y1)) & (ys <= max(y0, y1))
+        if not sel.any():
+            continue
+        if y0 == y1:
+            xl[sel] = np.minimum(xl[sel], min(x0, x1))
+            xr[sel] = np.maximum(xr[sel], max(x0, x1))
+            continue
+        xa, ya, xb, yb = (x1, y1, x0, y0) if y1 < y0 else (x0, y0, x1, y1)
+        den, dx = yb - ya, xb - xa
+        dn, dxa = 2 * den, abs(dx)
+        t = ys[sel] - ya
+        N2 = 2 * dx * t
+        Q = N2 // dn                                      # numpy floor division
+        R = N2 - Q * dn
+        if den > dxa:
+            lo = hi = xa + Q + (R >= den + 1)
+        else:
+            hh, hr = divmod(dxa, dn)
+            lo = np.maximum(xa + Q - hh + (R >= hr), min(xa, xb))
+            hi = np.minimum(xa + Q + hh + (R + hr >= dn), max(xa, xb))
+        dx16 = _c_div((dx << 17) + den, dn)
+        sc = ((xa << 16) + t * dx16 + 32768) >> 16
+        walker = t < den
+        lo = np.where(walker, np.minimum(lo, sc), lo)
+        hi = np.where(walker, np.maximum(hi, sc), hi)
+        xl[sel] = np.minimum(xl[sel], lo)
+        xr[sel] = np.maximum(xr[sel], hi)
+    return ya_, np.maximum(xl, 0), np.minimum(xr, cols - 1)

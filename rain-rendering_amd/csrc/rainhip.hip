@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(128) void k_fov_poly_general(const FrameDesc* frame
 }
 
 // one wave per drop: per-row edge scan x prefix table (gathers from HBM / L2)
-__global__ __launch_bounds__(256) void k_fov_sums_general(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc) {
+__global__ __launch_bounds__(256) void k_fov_sums_general(const FrameDesc* frames, Dims dm, int max_drops, Scratch sc, int cv_rule, int n_fov) {
   const int f = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
@@ -1362,9 +1362,11 @@ __global__ __launch_bounds__(256) void k_fov_sums_general(const FrameDesc* frame
     }
     const int ya = max(ymin, 0), yb = min(ymax, dm.He - 1);
     const double* P = sc.prefix + (int64_t)f * dm.He * (int64_t)(dm.We + 1) * 4;
+    // RR_OPT_FOV_FILL_RULE 1: OpenCV's own fill rule for the polygons it is defined for (rr_device.h fov_rowspan_cv)
+    const bool cv = cv_rule && fov_fill_rule_cv_applies(px, py, n, n_fov, dm.He, dm.We);
     for (int y = ya + lane; y <= yb; y += 64) {
       int xl_, xr_;
-      if (fov_rowspan_fast(px, py, n, y, dm.We, xl_, xr_)) {
+      if (cv ? fov_rowspan_cv(px, py, n, y, dm.We, xl_, xr_) : fov_rowspan_fast(px, py, n, y, dm.We, xl_, xr_)) {
         any = 1;
         const double* row = P + (int64_t)y * (dm.We + 1) * 4;
         const double* hi = row + (int64_t)(xr_ + 1) * 4;
@@ -4035,6 +4037,7 @@ struct rr_ctx {
   size_t pad_cap = 0;                // elements of each
   bool pipe_f32 = true;              // RR_OPT_PIPELINE_F32: float32 hand-over from the pre-pass to the hot path inside rr_pipeline_*
   bool walk_attr = false;
+  int fill_rule = 0;                 // RR_OPT_FOV_FILL_RULE
   bool composite_u16 = true;         // RR_OPT_COMPOSITE_U16
   bool blur_dma = true;              // RR_OPT_BLUR_DMA
   int fov_dda = 2;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (2: k_fov_walk, 1: k_fov_dda)
@@ -4245,7 +4248,7 @@ void prof_collect(rr_ctx* ctx) {
 // the fast colour path needs the span state of a drop in registers and a map row in LDS, and its exact span
 // arithmetic needs |2*dx*dy| < 2^23 (k_fov_spans)
 bool fov_fast_path(const rr_ctx* ctx, const Dims& dm) {
-  return !ctx->general_fov && dm.He <= HE_MAX && dm.We <= FOV_WE_MAX && (int64_t)dm.We * dm.He < (1 << 22) && ctx->cam.n_fov * 1 <= 64 &&
+  return !ctx->general_fov && ctx->fill_rule == 0 && dm.He <= HE_MAX && dm.We <= FOV_WE_MAX && (int64_t)dm.We * dm.He < (1 << 22) && ctx->cam.n_fov * 1 <= 64 &&
          ctx->cam.n_fov >= 3;
 }
 
@@ -4568,7 +4571,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       }
       {
         ProfScope ps(ctx, s, "k_fov_sums_general");
-        hipLaunchKernelGGL(k_fov_sums_general, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc);
+        hipLaunchKernelGGL(k_fov_sums_general, dim3((max_drops + 3) / 4, n), dim3(256), 0, s, ctx->d_frames, dm, D, sc, ctx->fill_rule, ctx->cam.n_fov);
       }
     }
     {
@@ -6032,6 +6035,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
+    case RR_OPT_FOV_FILL_RULE: ctx->fill_rule = value == 1 ? 1 : 0; return RR_OK;
     case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;
     case RR_OPT_BLUR_DMA: ctx->blur_dma = value != 0; return RR_OK;
     case RR_OPT_FOV_DDA: ctx->fov_dda = value < 0 ? 0 : (value > 2 ? 2 : value); return RR_OK;

@@ -736,6 +736,68 @@ RR_HD bool fov_rowspan(const int32_t* px, const int32_t* py, int n, int y, int W
   return xl <= xr;
 }
 
+// ---- OpenCV's own rule (r05): what cv2.fillConvexPoly(mask, s, 1) sets in row y ----
+// The reference fills the polygon with OpenCV 3.2's FillConvexPoly (bad_weather.py:388): the OUTLINE drawn edge by edge
+// with Line() -- an 8-connected Bresenham line from the edge's left end point -- and the interior by two edge walkers in
+// 16.16 fixed point, x += dx per row with dx = ((xb - xa) * 2^17 + den) / (2 den) (C division), a row filled from
+// (min + 2^15) >> 16 to (max + 2^15) >> 16; the walkers take an edge on the rows ya <= y < yb.  oracle/cvlike.py
+// cv_fill_convex_poly restates it literally (pixel by pixel); this is its closed form per edge and row, t = y - ya:
+//   N = 2 dx t = Q * 2 den + R   (0 <= R < 2 den)
+//   steep edge (den > |dx|): one pixel per row, xa + ceil((2 |dx| i - den) / (2 den)) from the left end -- for either
+//     direction that is  xa + Q + [R >= den + 1]   (the span rule above has [R >= den]: ties round the other way);
+//   shallow edge: a run of pixels per row,  [xa + Q - h + [R >= hr],  xa + Q + h + [R + hr >= 2 den]]  with
+//     |dx| = h * 2 den + hr, clamped to the edge's own x range (the runs of the first and the last row stop at the vertex);
+//   walker: (xa * 2^16 + t * dx16 + 2^15) >> 16 on the rows t < den.
+// A row's span is min / max over the edges that touch it.  Applies to the closed N-gon that compute_fov_plane_points
+// returns when it does not wrap (rows monotone down one side and up the other, every vertex on the map: no clipLine, no
+// dependence on where Clipper starts its output); a wrapping (N + 4)-gon is not y-monotone, FillConvexPoly's result for it
+// depends on the vertex Clipper happens to list first, which cannot be reconstructed: those keep the span rule.
+// tests/test_fill_rules.py: closed form == the literal restatement on every polygon of the test scenes, in any rotation
+// and orientation of the vertex list.
+RR_HD bool fov_fill_rule_cv_applies(const int32_t* px, const int32_t* py, int n, int n_fov, int He, int We);
+RR_HD bool fov_rowspan_cv(const int32_t* px, const int32_t* py, int n, int y, int We, int& xl, int& xr) {
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int i = 0; i < n; i++) {
+    const int j = (i + 1 == n) ? 0 : i + 1;
+    const int x0 = px[i], y0 = py[i], x1 = px[j], y1 = py[j];
+    if (y < imin(y0, y1) || y > imax(y0, y1)) continue;
+    if (y0 == y1) {                                          // Line() along the row
+      lo = imin(lo, imin(x0, x1));
+      hi = imax(hi, imax(x0, x1));
+      continue;
+    }
+    const bool swp = y1 < y0;
+    const int xa = swp ? x1 : x0, ya = swp ? y1 : y0, xb = swp ? x0 : x1, yb = swp ? y0 : y1;
+    const int den = yb - ya, dn = 2 * den, dx = xb - xa, dxa = iabs(dx), t = y - ya;
+    const int64_t N2 = (int64_t)2 * dx * t;
+    int64_t Q = N2 / dn;
+    if (N2 % dn != 0 && N2 < 0) Q -= 1;                      // floor
+    const int R = (int)(N2 - Q * dn);
+    int l, h_;
+    if (den > dxa) {
+      l = h_ = xa + (int)Q + (R >= den + 1 ? 1 : 0);
+    } else {
+      const int hh = dxa / dn, hr = dxa - hh * dn;
+      l = xa + (int)Q - hh + (R >= hr ? 1 : 0);
+      h_ = xa + (int)Q + hh + (R + hr >= dn ? 1 : 0);
+      l = imax(l, imin(xa, xb));
+      h_ = imin(h_, imax(xa, xb));
+    }
+    lo = imin(lo, l);
+    hi = imax(hi, h_);
+    if (t < den) {                                           // the edge walker's pixel
+      const int64_t num = ((int64_t)dx << 17) + den;
+      const int64_t dx16 = num / dn;                         // C division: toward zero
+      const int s = (int)((((int64_t)xa << 16) + (int64_t)t * dx16 + 32768) >> 16);
+      lo = imin(lo, s);
+      hi = imax(hi, s);
+    }
+  }
+  xl = imax(lo, 0);
+  xr = imin(hi, We - 1);
+  return xl <= xr;
+}
+
 // Row spans of a closed polygon whose vertex rows go down one side and up the other (every row crosses it at most twice:
 // a circle on the sphere that contains no pole), by two cursors walking down from its top vertex, one along each side
 // (k_fov_dda: a thread per drop).  row(y) returns the min / max over the edges that touch row y -- the candidates
@@ -911,6 +973,13 @@ RR_HD int poly_row_turns(const int32_t* py, int n) {
   }
   if (dir != 0 && dir_first != 0 && dir != dir_first) turns++;
   return turns;
+}
+
+RR_HD bool fov_fill_rule_cv_applies(const int32_t* px, const int32_t* py, int n, int n_fov, int He, int We) {
+  if (n != n_fov || n < 3) return false;                     // (a wrapping polygon has n_fov + 4 vertices)
+  for (int k = 0; k < n; k++)
+    if (px[k] < 0 || px[k] >= We || py[k] < 0 || py[k] >= He) return false;
+  return poly_row_turns(py, n) <= 2;
 }
 
 // colour constants from the FOV sums (bad_weather.py:397-412, my_utils.py:55-85)

@@ -81,6 +81,21 @@ int emu_fov_error_ratio(const rr_drop* drops, int n, const rr_camera* cam, int H
   return 0;
 }
 
+// RR_OPT_FOV_FILL_RULE of the library: 0 the span rule (fov_rowspan), 1 OpenCV's rule where it applies (fov_rowspan_cv)
+static int g_fill_rule = 0;
+void emu_set_fill_rule(int rule) { g_fill_rule = rule; }
+// spans of polygon (px, py)[n] under either rule: xl[y], xr[y] for y in [0, He), xl > xr = empty; returns 1 when OpenCV's rule applies
+int emu_rowspans(const int32_t* px, const int32_t* py, int n, int n_fov, int He, int We, int rule, int32_t* xl, int32_t* xr) {
+  const bool cv = rule == 1 && fov_fill_rule_cv_applies(px, py, n, n_fov, He, We);
+  for (int y = 0; y < He; y++) {
+    int a, b;
+    const bool any = cv ? fov_rowspan_cv(px, py, n, y, We, a, b) : fov_rowspan(px, py, n, y, We, a, b);
+    xl[y] = any ? a : 1;
+    xr[y] = any ? b : 0;
+  }
+  return cv ? 1 : 0;
+}
+
 // k_fov_dda's row spans (rr_device.h DdaCursors) of polygon (px, py)[n] against the rule itself (fov_rowspan: min / max over
 // every edge that touches the row): returns the number of rows of [0, He) on which they differ, -1 when the polygon's rows
 // are not monotone (the kernel hands those to the edge-parallel kernel).
@@ -235,9 +250,10 @@ int emu_render_frame_depth(int H, int W, int He, int We, const double* bg, const
       int ya = imax(ymin, 0), yb = imin(ymax, He - 1);
       double S[4] = {0, 0, 0, 0};
       bool any = false;
+      const bool cv_rule = g_fill_rule == 1 && fov_fill_rule_cv_applies(px, py, np_, cam->n_fov, He, We);
       for (int y = ya; y <= yb; y++) {
         int xl, xr;
-        if (fov_rowspan(px, py, np_, y, We, xl, xr)) {
+        if (cv_rule ? fov_rowspan_cv(px, py, np_, y, We, xl, xr) : fov_rowspan(px, py, np_, y, We, xl, xr)) {
           any = true;
           const double* row = P.data() + (size_t)y * (We + 1) * 4;
           for (int k = 0; k < 4; k++) S[k] += row[(size_t)(xr + 1) * 4 + k] - row[(size_t)xl * 4 + k];

@@ -283,3 +283,39 @@ def test_composite_codes_and_blur_prefetch(setup):
                 assert d.max() <= 1 and (d != 0).mean() < 4e-3, (d.max(), (d != 0).mean())
     # the coded composite against the float64 compositor and the host build (the 1-LSB bar of BASELINE.json)
     assert np.abs(ref[0]['image_u8'].astype(int) - base['image_u8'].astype(int)).max() <= 1
+
+
+def test_opencv_fill_rule_option(setup):
+    """RR_OPT_FOV_FILL_RULE 1: OpenCV 3.2's own fillConvexPoly algorithm (Bresenham outline + 16.16 edge walkers; rr_device.h
+    fov_rowspan_cv, pinned against the literal restatement in tests/test_fill_rules.py) instead of the row-span rule of the fast
+    colour kernels.  The option's colour constants equal the host build's under the same rule; against the default rule they
+    move by a few parts in a thousand -- rainy_image stays within 1 LSB, mask and statuses are untouched."""
+    sc, bg, env, drops, rh, base = setup
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    dflt = rh.render_frames([fr], want_colour=True)[0]
+    alt = h.hb.RainHip(0)
+    try:
+        alt.set_option(h.hb.RR_OPT_FOV_FILL_RULE, 1)
+        alt.set_streak_db(sc.db.streaks_light)
+        alt.set_camera(sc.cam)
+        out = alt.render_frames([fr], want_colour=True)[0]
+        f32 = alt.render_frames([fr], want_composite=False)[0]
+    finally:
+        alt.close()
+    emu = h.hostemu()
+    emu.emu_set_fill_rule(1)
+    try:
+        ref = h.emu_render(sc, bg, bg, env, drops)
+    finally:
+        emu.emu_set_fill_rule(0)
+    for k in ('status', 'mask', 'mask_i32'):
+        assert np.array_equal(out[k], base[k]) and np.array_equal(out[k], ref[k]) and np.array_equal(f32[k], base[k]), k
+    ok = out['status'] == 0
+    assert np.abs(out['colour'][ok] - ref['K'][ok]).max() <= 1e-9 * np.abs(ref['K'][ok]).max()
+    assert np.abs(out['rainy_bg'] - ref['rainy_bg']).max() < 1e-9
+    assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+    rel = np.abs(out['colour'][ok] - dflt['colour'][ok]) / np.abs(dflt['colour'][ok])
+    assert 1e-5 < rel.max() < 4e-3, rel.max()
+    for o in (out, f32):
+        d = np.abs(o['image_u8'].astype(int) - base['image_u8'].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 0.05, (d.max(), (d != 0).mean())
