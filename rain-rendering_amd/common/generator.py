@@ -79,7 +79,7 @@ class Generator:
         self.sim_options = getattr(args, 'sim_options', {})
         self.batch = int(os.environ.get('RAIN_BATCH', '128'))     # frames per library call (three calls in flight); bench.py's host-inclusive leg uses the same
         self.rank, self.world = sharding.rank_world()
-        self.device = int(getattr(args, 'device', os.environ.get('LOCAL_RANK', '0')))
+        self.device = int(getattr(args, 'device', os.environ.get('RAIN_DEVICE', os.environ.get('LOCAL_RANK', '0'))))   # (RAIN_DEVICE: main.py)
         self._hip = None
         self._pool = None
         self.stats = []

@@ -173,11 +173,13 @@ def main(argv=None):
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # before anything rank 0 decides for the others (particle files)
         import torch
         import torch.distributed as dist
+        # RAIN_DEVICE pins every rank to one device and RAIN_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one
+        # GPU): how the GPU test tier runs this driver under N > 1 on the one GPU it has (tests/test_gpu_driver.py)
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            torch.cuda.set_device(int(os.environ.get('RAIN_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+            dist.init_process_group(os.environ.get('RAIN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo'))
     args = check_arg(sys.argv[1:] if argv is None else argv)
     print("\nRunning renderers...")
     generator = Generator(args)

@@ -33,7 +33,7 @@ def ensure_group(rank, world):
     if dist.is_available() and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get('RAIN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo'), rank=rank, world_size=world)
 
 
 def rank0_decides(fn, rank, world):

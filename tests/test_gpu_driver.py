@@ -222,3 +222,54 @@ def test_rccl_broadcast_of_the_streak_database_world1(tmp_path, built):
     r = subprocess.run([sys.executable, worker, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0 and b'NCCL-WORLD1-OK' in r.stdout, (r.stdout.decode()[-2000:], r.stderr.decode()[-4000:])
+
+
+def test_two_ranks_on_the_one_gpu_write_the_single_rank_files(tmp_path, built):
+    """The real driver under N > 1 on the hardware there is (the role of the reference's main_threaded.py:98-200):
+    `python -m torch.distributed.run --nproc-per-node 2 rain-rendering_amd/main.py ...`, both ranks on GPU 0 (RAIN_DEVICE=0) with
+    gloo for the process group (RCCL refuses two ranks on one device; the one-rank RCCL path is the test above).  Rank 0 names
+    the output folder and the work list and loads the streak database, the broadcast hands them over (device tensors), each
+    rank renders its round-robin share through its own context on the shared GPU: every frame is written exactly once into ONE
+    folder and every file is byte for byte the file of the single-rank run.  Then bench.py's strong-scaling launch line with
+    two ranks on the same GPU (a smoke of the line the driver uses for SCALE_rNN.json; not a scaling number)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    tmp = str(tmp_path)
+    n = 12
+    src, xml = _make_dataset(tmp, n_frames=n)
+    main = importlib.import_module('rain-rendering_amd.main')
+    common = ['--dataset', 'kitti', '-k', src, '-d', src, '-r', os.path.join(tmp, 'particles'), '-sd', os.path.join(tmp, 'rainstreakdb'),
+              '-i', '5', '--noverbose']
+    main.main(common + ['--output', os.path.join(tmp, 'out1')])
+
+    def free_port():
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            return s_.getsockname()[1]
+    env = dict(os.environ, RAIN_DEVICE='0', RAIN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', RAIN_BATCH='4')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(free_port()), os.path.join(h.ROOT, 'rain-rendering_amd', 'main.py')] + common +
+                       ['--output', os.path.join(tmp, 'out2'), '--conflict_strategy', 'rename_folder'],
+                       env=env, cwd=h.ROOT, capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout.decode()[-3000:], r.stderr.decode()[-3000:])
+    sub = os.path.join('kitti', 'data_object', 'training', 'rain', '5mm')
+    for kind in ('rainy_image', 'rain_mask'):
+        a, b = os.path.join(tmp, 'out1', sub, kind), os.path.join(tmp, 'out2', sub, kind)
+        assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == ['%06d.png' % i for i in range(n)]
+        for f in os.listdir(a):
+            assert open(os.path.join(a, f), 'rb').read() == open(os.path.join(b, f), 'rb').read(), (kind, f)
+    assert sorted(os.listdir(os.path.join(tmp, 'out2', 'kitti', 'data_object', 'training', 'rain'))) == ['5mm']     # ONE folder
+    # bench.py, two ranks, one 64-frame sequence (strong scaling)
+    benv = dict(os.environ, RAIN_BENCH_DEVICE='0', RAIN_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    b = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(free_port()), os.path.join(h.ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '32',
+                        '--total-frames', '64', '--no-cpu-baseline', '--no-prepass', '--no-variants', '--no-traffic', '--no-driver'],
+                       env=benv, cwd=h.ROOT, capture_output=True, timeout=900)
+    assert b.returncode == 0, (b.stdout.decode()[-2000:], b.stderr.decode()[-3000:])
+    lines = [l for l in b.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines                                              # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] > 0 and line['steps'] == 2
+    assert line['config']['frames_per_step'] == 64 and 'dp2' in line['config']['parallelism']
