@@ -829,7 +829,10 @@ def main():
             valu_frac = compute["kernels"][dom_name]["frac_of_rate_without_fma"]
         elif valu and dom_name in valu:
             valu_frac = valu[dom_name]["valu_util"]
-        bound = "hbm" if (valu_frac is None or (traffic and hbm_frac >= valu_frac)) else "valu-f64"
+        nearest = "hbm" if (valu_frac is None or (traffic and hbm_frac >= valu_frac)) else "valu-f64"
+        # neither roof within a factor of two: what bounds the kernel is the latency of its dependent memory / LDS phases at the
+        # occupancy its registers and LDS tiles allow -- say so instead of naming a roof it is far from
+        bound = nearest if max(hbm_frac, valu_frac or 0.0) >= 0.5 else "latency"
         bound_detail = ("dominant kernel %s: %.0f %% of the HBM peak by its measured traffic%s; neither roof is reached -- the kernel waits on "
                         "dependent loads and LDS phases (DESIGN.md, phase clocks); no MFMA: the path has no dense contraction"
                         % (dom_name, 100.0 * hbm_frac if traffic else float('nan'),
@@ -852,8 +855,10 @@ def main():
                                                "generic": int(cnts[:, 1].sum()), "shared_bit_identical": int(cnts[:, 7].sum())},
                        "blur_last_call": {"fused_items": int(cnts[:, 2].sum()), "wave_per_drop": int(cnts[:, 4].sum()),
                                           "two_pass": int(cnts[:, 3].sum())}},
-            "roofline": {"bound": bound, "bound_detail": bound_detail, "compute": compute, "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_how,
+            "roofline": {"bound": bound, "nearest_roof": nearest, "bound_detail": bound_detail, "compute": compute, "kernel": dom_name, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "chain_frac_of_hbm_peak": alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,      # the same bytes over the SUM of all kernels of the step
+                         "traffic": traffic, "traffic_source": traffic_how,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
                          "definition": "algorithmic bytes of the frames of one launch (27*H*W + 16*He*We + 64*N each, SURVEY 8d) / "
                                        "average launch time of the slowest kernel of the chain (HIP events on the launch stream)"},

@@ -471,6 +471,16 @@ class Generator:
         run = self._run_batches_native if native else self._run_batches_general
         return run(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0)
 
+    @staticmethod
+    def _set_png_deflate(hip):
+        """RR_OPT_PNG_DEFLATE for the driver: on (the library's own default is off), unless RAIN_PNG_DEVICE=0 says so -- or
+        RAINHIP_OPTIONS already names option 15: the A/B switch that RainHip applied at construction has the last word
+        (precedence: RAINHIP_OPTIONS > RAIN_PNG_DEVICE > the driver's default)."""
+        named = {kv.split('=')[0].strip() for kv in os.environ.get('RAINHIP_OPTIONS', '').split(',') if '=' in kv}
+        if str(hip_backend.RR_OPT_PNG_DEFLATE) in named:
+            return
+        hip.set_option(hip_backend.RR_OPT_PNG_DEFLATE, 0 if os.environ.get('RAIN_PNG_DEVICE', '1') == '0' else 1)
+
     def _run_batches_native(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0, sims=None):
         """Batch-native route.  Per batch, three whole-batch jobs, each one call (or two) into the library:
           decode  rr_io_read_frames (image bytes + depth metres straight into the slot's page-locked input blocks) and
@@ -495,7 +505,7 @@ class Generator:
         hip.set_solid_angles(cache[(H, env_w)])
         # both output files leave the device as the zlib streams of their IDAT chunks (RR_OPT_PNG_DEFLATE, csrc/rr_deflate.h):
         # the encode stage below only frames chunks and checksums them.  RAIN_PNG_DEVICE=0: scanlines, deflated by the host.
-        hip.set_option(hip_backend.RR_OPT_PNG_DEFLATE, 0 if os.environ.get('RAIN_PNG_DEVICE', '1') == '0' else 1)
+        self._set_png_deflate(hip)
         # capacity of a frame's drop table: every streak of its simulated frame (the frame filter can only remove some), but
         # never more than the 2 ** 16 the reference allows AFTER the filter (generator.py:424): a simulated frame with more
         # streaks than that is fine as long as fewer land inside the image -- checked on the filtered counts below
@@ -567,8 +577,14 @@ class Generator:
                     continue
                 bg, depth = loaded
                 assert bg.shape[:2] == (H, W) and bg.dtype == bg_dtype and depth.shape == (H, W), "frames of one sequence share their size"
-                # (a PNG depth map is sample / 256 in float32: the samples come back exactly)
-                samples = np.rint(depth.astype(np.float64) * 256.0).astype(np.uint16)
+                samples = None
+                if rows_in or d16:
+                    # a 16-bit PNG depth map is sample / 256 in float32: the samples come back exactly -- anything else (an 8-bit
+                    # or converted file that reached this route) must not be re-quantised silently
+                    samples = np.rint(depth.astype(np.float64) * 256.0).astype(np.uint16)
+                    if not np.array_equal(samples.astype(np.float32) / np.float32(256.0), depth.astype(np.float32)):
+                        raise ValueError("%s: depth values are not the samples of a 16-bit file / 256; run with RAIN_NATIVE_IO=0"
+                                         % items[k]['depth_file'])
                 if rows_in:                                         # as scanlines of filter type 0
                     np.copyto(sl.bg[k], hip_backend.png_rows_of(bg))
                     np.copyto(sl.depth[k], hip_backend.png_rows_of(samples))
@@ -736,7 +752,7 @@ class Generator:
                 state['env_w'] = hip.set_envmap_geometry(H, W, *map_generator.device_tables(H, W))
                 state['omega'] = solid_angle.get_solid_angles(np.empty((H, state['env_w'], 0)))    # generator.py:410
                 hip.set_solid_angles(state['omega'])            # resident on the device: not uploaded with every batch
-                hip.set_option(hip_backend.RR_OPT_PNG_DEFLATE, 0 if os.environ.get('RAIN_PNG_DEVICE', '1') == '0' else 1)   # (see _run_batches_native)
+                self._set_png_deflate(hip)                      # (see _run_batches_native)
                 state['geom'] = (H, W)
             bg0, dep0 = valid[0][1][0], valid[0][1][1]
             need_drops = max(len(ld[2]) for _, ld in valid)

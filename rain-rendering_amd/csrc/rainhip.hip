@@ -4943,6 +4943,9 @@ int rr_create(rr_ctx** out, int device) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RR_E_NO_DEVICE;
   if (strncmp(prop.gcnArchName, "gfx9", 4) != 0) return RR_E_NO_DEVICE;
+  // every kernel here is written for wave64: ballots are 64 bits wide, scans run over 64 lanes, k_png_unfilter and the
+  // wave-per-item kernels hand data between the lanes of ONE wave without a barrier (a 64-thread block must be one wave)
+  if (prop.warpSize != 64) return RR_E_NO_DEVICE;
   rr_ctx* ctx = new rr_ctx();
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -1254,9 +1254,16 @@ static int rr_png_write_scanlines_impl(const char* path, const uint8_t* rows, in
   const uint8_t* zdata = nullptr;
   uLongf clen = 0;
   if (memcmp(rows, "RRZ1", 4) == 0) {               // entropy-coded on the device (RR_OPT_PNG_DEFLATE): the IDAT payload as it is
-    uint32_t L;                                       // (a scanline buffer starts with a filter type 0..4)
-    memcpy(&L, rows + 4, 4);
-    if ((uLong)L + 16 > n || L < 6) return RR_E_PARSE;
+    // (a scanline buffer starts with a filter type 0..4).  The stream is written as it stands, so what can be checked
+    // cheaply is: the header's two reserved words are zero, the length fits the buffer, the payload opens with the zlib
+    // header the device writes (CMF 0x78, FLG 0x01: a valid pair, no preset dictionary) and is long enough to hold one
+    // block and the Adler-32 -- a stale or half-written buffer (a download after a failed batch) fails one of them.
+    if (n < 16) return RR_E_PARSE;
+    uint32_t hd[4];
+    memcpy(hd, rows, 16);
+    const uint32_t L = hd[1];
+    if (hd[2] != 0 || hd[3] != 0 || (uLong)L + 16 > n || L < 2 + 5 + 4) return RR_E_PARSE;
+    if (rows[16] != 0x78 || rows[17] != 0x01) return RR_E_PARSE;
     zdata = rows + 16;
     clen = L;
   } else if (strategy == 3) {

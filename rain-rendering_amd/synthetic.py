@@ -197,32 +197,40 @@ def simulate_to_xml(path, n_frames, n_drops, W, H, focal_mm=6.0, pix_um=4.65, ex
     import sys
     workers = workers if workers is not None else max(1, min(8, (os.cpu_count() or 1)))
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    common = (n_drops, W, H, focal_mm, pix_um, exposure_ms, seed0, far_fraction)
+    # plain Python numbers whatever the caller passed (a numpy scalar's repr is not a literal the worker can parse)
+    common = (int(n_drops), int(W), int(H), float(focal_mm), float(pix_um), float(exposure_ms), int(seed0), float(far_fraction))
     parts = []
     if workers > 1 and n_frames >= 16:
+        import uuid
+        tag = '%d_%s' % (os.getpid(), uuid.uuid4().hex[:8])       # two processes building the same scene do not share part files
         per = (n_frames + workers - 1) // workers
         procs = []
         for k in range(workers):
             a, b = k * per, min(n_frames, (k + 1) * per)
             if a >= b:
                 break
-            part = '%s.part%d' % (path, k)
+            part = '%s.%s.part%d' % (path, tag, k)
             cmd = [sys.executable, os.path.abspath(__file__), part, str(a), str(b)] + [repr(v) for v in common]
-            procs.append((subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), part))
+            procs.append((subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE), part))
         ok = True
         for pr, part in procs:
             try:
-                ok = (pr.wait(timeout=900) == 0) and ok
+                err = pr.communicate(timeout=900)[1]
+                if pr.returncode != 0:
+                    ok = False
+                    sys.stderr.write("simulate_to_xml: worker for %s failed (%d): %s\n" % (part, pr.returncode, err.decode(errors='replace')[-500:]))
             except subprocess.TimeoutExpired:
                 pr.kill()
                 ok = False
             parts.append(part)
         if not ok:
+            sys.stderr.write("simulate_to_xml: falling back to the sequential path\n")
             for part in parts:
                 if os.path.exists(part):
                     os.remove(part)
             parts = []
-    with open(path, 'w') as fh:
+    tmp_path = '%s.%d.tmp' % (path, os.getpid())               # (the finished file appears under its name at once)
+    with open(tmp_path, 'w') as fh:
         fh.write('<?xml version="1.0" ?>\n<simulation>\n')
         if parts:
             for part in parts:
@@ -237,6 +245,7 @@ def simulate_to_xml(path, n_frames, n_drops, W, H, focal_mm=6.0, pix_um=4.65, ex
             for fi in range(n_frames):
                 fh.write(_frame_xml((fi,) + common))
         fh.write('</simulation>\n')
+    os.replace(tmp_path, path)
     return path
 
 

@@ -138,23 +138,28 @@ static int fuzz_deflate(int rounds) {
   return wrong != 0;
 }
 
-// rows that claim to be a stream the device made (RR_OPT_PNG_DEFLATE: 'RRZ1', length, stream): lengths that do not fit the
-// buffer must be refused, a fitting one is written as the IDAT payload without being looked at
+// rows that claim to be a stream the device made (RR_OPT_PNG_DEFLATE: 'RRZ1', length, two zero words, stream).  The writer takes
+// the stream as the IDAT payload as it is, so it must refuse what a stale or half-written buffer looks like: a length that does
+// not fit the buffer or cannot hold a block and the Adler-32, reserved words that are not zero, a payload that does not open
+// with the zlib header the device writes (0x78 0x01).
 static int fuzz_device_payload(const char* dir) {
   const int W = 7, H = 5;
   const size_t n = (size_t)H * (1 + 4 * W);
   const std::string path = std::string(dir) + "/payload.png";
   int bad = 0;
-  for (uint32_t L : {0u, 5u, 6u, (uint32_t)(n - 16), (uint32_t)(n - 15), (uint32_t)n, 0x7fffffffu, 0xffffffffu}) {
-    uint8_t* rows = new uint8_t[n];
-    memset(rows, 0, n);
-    memcpy(rows, "RRZ1", 4);
-    memcpy(rows + 4, &L, 4);
-    const int rc = rr_png_write_scanlines(path.c_str(), rows, W, H, 1, 3);
-    const bool fits = L >= 6 && (size_t)L + 16 <= n;
-    if ((rc == RR_OK) != fits) bad++;
-    delete[] rows;
-  }
+  for (int variant = 0; variant < 4; variant++)                  // 0: well-formed header, 1: no zlib header, 2 / 3: a reserved word set
+    for (uint32_t L : {0u, 5u, 6u, 10u, 11u, (uint32_t)(n - 16), (uint32_t)(n - 15), (uint32_t)n, 0x7fffffffu, 0xffffffffu}) {
+      uint8_t* rows = new uint8_t[n];
+      memset(rows, 0, n);
+      memcpy(rows, "RRZ1", 4);
+      memcpy(rows + 4, &L, 4);
+      if (variant != 1) { rows[16] = 0x78; rows[17] = 0x01; }
+      if (variant >= 2) rows[8 + 4 * (variant - 2)] = 1;
+      const int rc = rr_png_write_scanlines(path.c_str(), rows, W, H, 1, 3);
+      const bool fits = variant == 0 && L >= 11 && (size_t)L + 16 <= n;
+      if ((rc == RR_OK) != fits) bad++;
+      delete[] rows;
+    }
   remove(path.c_str());
   printf("device payloads: wrong %d\n", bad);
   return bad != 0;
