@@ -405,13 +405,16 @@ enum {
                                      * gfx950 LDS-DMA loads (global_load_lds: no registers in between), issued a sub-tile AHEAD: they land
                                      * while the current sub-tile's column pass runs; 0: the r04 kernel (loads through registers at the
                                      * start of every sub-tile).  Same results. */
-  RR_OPT_FOV_FILL_RULE = 18         /* which restatement of cv2.fillConvexPoly (bad_weather.py:388) decides the texels of a drop's field of
+  RR_OPT_FOV_FILL_RULE = 18,        /* which restatement of cv2.fillConvexPoly (bad_weather.py:388) decides the texels of a drop's field of
                                      * view: 0 (default) the row-span rule of the fast colour kernels (nearest x of every edge on the
                                      * row, min / max); 1 OpenCV 3.2's own algorithm -- Bresenham outline + 16.16 edge walkers, in closed
                                      * form per edge and row (csrc/rr_device.h fov_rowspan_cv) -- for the closed polygons it is defined
                                      * for; takes the general (slow) colour path.  Colour only: a drop's colour constants move by
                                      * <= 0.3 %, rainy_image by <= 1 LSB on 1.4 % of its values (README, profiles/r05_fill_rule_study.txt);
                                      * mask and statuses are the same. */
+  RR_OPT_BIN_ROWS = 19              /* tuning (r05): 1 (default) the ordered per-tile drop lists are made by a workgroup per ROW of coarse
+                                     * tiles (drops filtered by row first, then a wave per tile); 0: a workgroup per coarse tile that
+                                     * tests every drop (r04).  Same lists. */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -2963,6 +2963,70 @@ __global__ __launch_bounds__(256) void k_bin(const FrameDesc* frames, Dims dm, i
   if (t == 0) sc.ccount[(int64_t)f * nct + ct] = total;
 }
 
+// r05: the same lists, a workgroup per ROW of coarse tiles.  k_bin tests every footprint against every coarse tile (120 tiles
+// x 7200 drops per KITTI frame, two block barriers per 256 tests).  Here the drops are taken in segments of BIN_SEG: the
+// workgroup first keeps, in drop order, the ones that reach its 64-pixel row of the frame (a quarter of them) with their x
+// range in LDS; then every WAVE takes tiles of the row by itself and walks that short list with ballots -- no block barrier,
+// a third of the tests.  Same lists, same order (tests/test_gpu_properties.py compares every output with RR_OPT_BIN_ROWS 0).
+constexpr int BIN_SEG = 8192;
+__global__ __launch_bounds__(256) void k_bin_rows(const FrameDesc* frames, Dims dm, int max_drops, int ctiles_x, int nct, Scratch sc) {
+  const int f = blockIdx.y, cty = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = frames[f].n_drops;
+  const int y0 = cty * CTILE, y1 = min(y0 + CTILE, dm.H);
+  const int4* bbox = sc.bbox + (int64_t)f * max_drops;
+  __shared__ uint16_t s_idx[BIN_SEG], s_x0[BIN_SEG], s_x1[BIN_SEG];
+  __shared__ int s_cnt[4];
+  __shared__ int s_total[64];                            // entries written so far, per tile of the row (ctiles_x <= 64: frames up to 4096 wide)
+  for (int k = t; k < ctiles_x; k += 256) s_total[k] = 0;
+  for (int seg = 0; seg < n; seg += BIN_SEG) {
+    const int seg_n = min(BIN_SEG, n - seg);
+    int m = 0;                                           // drops of the segment that reach this row
+    for (int base = 0; base < seg_n; base += 256) {
+      const int i = seg + base + t;
+      bool hit = false;
+      int4 bb = make_int4(0, 0, 0, 0);
+      if (base + t < seg_n) {
+        bb = bbox[i];
+        hit = bb.x < bb.z && bb.y < y1 && bb.w > y0;      // (an empty footprint reaches nothing)
+      }
+      const unsigned long long bal = __ballot(hit);
+      if (lane == 0) s_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int off = m;
+      for (int w = 0; w < 4; w++) {
+        const int cw = s_cnt[w];
+        if (w < wave) off += cw;
+        m += cw;
+      }
+      if (hit) {
+        const int o = off + __popcll(bal & ((1ull << lane) - 1ull));
+        s_idx[o] = (uint16_t)i;
+        s_x0[o] = (uint16_t)imax(bb.x, 0);
+        s_x1[o] = (uint16_t)imin(bb.z, 65535);
+      }
+      __syncthreads();
+    }
+    // every wave: its tiles of the row against the row's list
+    for (int ctx_ = wave; ctx_ < ctiles_x; ctx_ += 4) {
+      const int x0 = ctx_ * CTILE, x1 = min(x0 + CTILE, dm.W);
+      uint16_t* out = sc.clist + ((int64_t)f * nct + (cty * ctiles_x + ctx_)) * max_drops;
+      int total = s_total[ctx_];
+      for (int base = 0; base < m; base += 64) {
+        const int k = base + lane;
+        const bool hit = k < m && (int)s_x0[k] < x1 && (int)s_x1[k] > x0;
+        const unsigned long long bal = __ballot(hit);
+        if (hit) out[total + __popcll(bal & ((1ull << lane) - 1ull))] = s_idx[k];
+        total += __popcll(bal);
+      }
+      if (lane == 0) s_total[ctx_] = total;              // (a tile belongs to one wave: no one else reads it before the end)
+    }
+    __syncthreads();                                     // the list is free for the next segment
+  }
+  __syncthreads();
+  for (int k = t; k < ctiles_x; k += 256) sc.ccount[(int64_t)f * nct + cty * ctiles_x + k] = s_total[k];
+}
+
 // RR_OPT_WILD_PIXELS: the reference blends a drop over its whole PADDED rectangle (bad_weather.py:429-446); outside the tile the
 // compositor reads, the drop image is exact zeros and the blend reduces to np.clip(pixel, 0, 1) -- a no-op for the values in
 // [0, 1] that rainy_bg holds by contract, which is why the compositor never visits the pad.  For a caller whose rainy_bg holds
@@ -3480,6 +3544,65 @@ __global__ __launch_bounds__(256) void k_means(Dims dm, int ntiles, Scratch sc) 
 }
 
 // generator.py:461-466 + matplotlib's float->uint8 truncation
+// The same for the 16-bit composite codes of k_composite32 (RR_OPT_COMPOSITE_U16), FOUR pixels per thread: 24 bytes in by
+// three 8-byte loads, 12 bytes out by one 12-byte store (a thread per pixel moved its 6 + 3 bytes with three 2-byte loads
+// and three byte stores and was slower than the float form it replaces, which reads twice the bytes).  The last pixels of a
+// frame (H * W is not a multiple of four) and a frame whose uint8 image does not start on a 4-byte boundary take scalar
+// accesses.  Code 65535 = the pixel's own rainy_bg value (see k_composite32).
+__global__ __launch_bounds__(256) void k_finalize16(const FrameDesc* frames, Dims dm, Scratch sc) {
+  const int f = blockIdx.y;
+  const int64_t npix = (int64_t)dm.H * dm.W;
+  const int64_t pix0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (pix0 >= npix) return;
+  const FrameDesc& fr = frames[f];
+  const double diff = sc.means[f * 4 + 0] - sc.means[f * 4 + 1];
+  const global_ptr<const uint16_t> s = as_global(reinterpret_cast<const uint16_t*>(fr.comp_out)) + pix0 * 3;
+  const global_ptr<uint8_t> o = as_global(fr.rgb) + pix0 * 3;
+  const int cnt = (int)(npix - pix0 < 4 ? npix - pix0 : 4);
+  uint32_t q[12];
+  if (cnt == 4) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const global_ptr<const u32x2> s2 = reinterpret_cast<global_ptr<const u32x2>>(s);       // (24 * group bytes into the frame's composite: 8-byte aligned)
+    const u32x2 a = s2[0], b = s2[1], c = s2[2];
+    const uint32_t w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+#pragma unroll
+    for (int k = 0; k < 6; k++) { q[2 * k] = w[k] & 0xffffu; q[2 * k + 1] = w[k] >> 16; }
+  } else {
+    for (int k = 0; k < 12; k++) q[k] = k < 3 * cnt ? (uint32_t)s[k] : 0u;
+  }
+  uint32_t out[3] = {0u, 0u, 0u};                  // 12 bytes: R G B of four pixels
+#pragma unroll
+  for (int px = 0; px < 4; px++) {
+    double c[3];
+    bool special = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      c[k] = (double)q[px * 3 + k] * (1.0 / 65534.0);
+      special = special || q[px * 3 + k] == 65535u;
+    }
+    if (special && px < cnt) {
+      double in[3];
+      load_px3(fr.rainy_bg, rainy_kind(fr), pix0 + px, in);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        if (q[px * 3 + k] == 65535u) c[k] = (double)(float)in[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double v = clip01(c[2 - k] - diff);      // BGR -> RGB
+      const uint32_t byte = (uint32_t)(uint8_t)(int)(v * 255.0);
+      const int bi = px * 3 + k;
+      out[bi >> 2] |= byte << (8 * (bi & 3));
+    }
+  }
+  if (cnt == 4 && (reinterpret_cast<uintptr_t>(fr.rgb) & 3u) == 0) {
+    const global_ptr<uint32_t> o4 = reinterpret_cast<global_ptr<uint32_t>>(o);
+    o4[0] = out[0]; o4[1] = out[1]; o4[2] = out[2];
+  } else {
+    for (int k = 0; k < 3 * cnt; k++) o[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+  }
+}
+
 __global__ __launch_bounds__(256) void k_finalize(const FrameDesc* frames, Dims dm, Scratch sc) {
   const int f = blockIdx.y;
   const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -4037,6 +4160,7 @@ struct rr_ctx {
   size_t pad_cap = 0;                // elements of each
   bool pipe_f32 = true;              // RR_OPT_PIPELINE_F32: float32 hand-over from the pre-pass to the hot path inside rr_pipeline_*
   bool walk_attr = false;
+  bool bin_rows = true;              // RR_OPT_BIN_ROWS
   int fill_rule = 0;                 // RR_OPT_FOV_FILL_RULE
   bool composite_u16 = true;         // RR_OPT_COMPOSITE_U16
   bool blur_dma = true;              // RR_OPT_BLUR_DMA
@@ -4632,7 +4756,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   const int ctiles_x = (dm.W + CTILE - 1) / CTILE, nct = ctiles_x * ((dm.H + CTILE - 1) / CTILE);
   {
     ProfScope ps(ctx, s, "k_bin");
-    hipLaunchKernelGGL(k_bin, dim3(nct, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctiles_x, nct, sc);
+    if (ctx->bin_rows && ctiles_x <= 64)
+      hipLaunchKernelGGL(k_bin_rows, dim3(nct / ctiles_x, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctiles_x, nct, sc);
+    else
+      hipLaunchKernelGGL(k_bin, dim3(nct, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctiles_x, nct, sc);
   }
   sc.pad_first = sc.eff_first = nullptr;
   bool wild = ctx->wild_pixels;
@@ -4677,7 +4804,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   {
     ProfScope ps(ctx, s, "k_finalize");
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)(((int64_t)dm.H * dm.W + 255) / 256), n), dim3(256), 0, s, ctx->d_frames, dm, sc);
+    if (use32 && ctx->composite_u16 && !ctx->wild_pixels)       // (every frame's comp_f32 is 2: the coded composite, four pixels per thread)
+      hipLaunchKernelGGL(k_finalize16, dim3((unsigned)(((int64_t)dm.H * dm.W + 1023) / 1024), n), dim3(256), 0, s, ctx->d_frames, dm, sc);
+    else
+      hipLaunchKernelGGL(k_finalize, dim3((unsigned)(((int64_t)dm.H * dm.W + 255) / 256), n), dim3(256), 0, s, ctx->d_frames, dm, sc);
   }
   if (want_png) {
     ProfScope ps(ctx, s, "k_png_rows");
@@ -6039,6 +6169,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
     case RR_OPT_FOV_FILL_RULE: ctx->fill_rule = value == 1 ? 1 : 0; return RR_OK;
+    case RR_OPT_BIN_ROWS: ctx->bin_rows = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;
     case RR_OPT_BLUR_DMA: ctx->blur_dma = value != 0; return RR_OK;
     case RR_OPT_FOV_DDA: ctx->fov_dda = value < 0 ? 0 : (value > 2 ? 2 : value); return RR_OK;
