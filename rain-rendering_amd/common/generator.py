@@ -355,7 +355,12 @@ class Generator:
             return int(np.linspace(0, n_sim, n_files, endpoint=False, dtype=int)[i])
         return i
 
+    def _mark(self, name):
+        """set-up clock: seconds since run() began at which a stage of the set-up was finished (timing[...]['setup'])"""
+        self._marks.append((name, round(time.time() - self._t_run0, 4)))
+
     def run(self):
+        self._t_run0, self._marks = time.time(), []
         folders_num = len(self.images)
         B = max(1, self.batch)
         for folder_idx, sequence in enumerate(self.sequences):
@@ -387,8 +392,11 @@ class Generator:
                 map_generator = envmap.EnvironmentMapGenerator(self.focal, imW, imH)
                 FOG = add_attenuation.FogRain(**fog_params)
                 # streak DB: loaded by rank 0, one broadcast, then resident on every GPU
+                self._mark('file lists, first image size')
                 hip = self._hip_ctx()
+                self._mark('library context (HIP runtime, device)')
                 sharding.load_and_broadcast_streak_db(self.db, hip, self.rank, self.world)
+                self._mark('streak database loaded + resident')
                 hip.set_camera(hip_backend.make_camera(self.focal, self.f_number, self.exposure))
                 hip.set_prepass_kernels(imgops.gaussian_kernel(25, 25), imgops.gaussian_kernel(15, 0))
                 hip.set_colormap(imgops.viridis_lut())
@@ -409,6 +417,7 @@ class Generator:
                     self.db.load_streaks_from_xml(self.dataset, self.settings, [imW, imH], use_pickle=False, verbose=self.verbose)
                     frame_render_dict = list(self.db.streaks_simulator.values())
                     n_sim = len(frame_render_dict)
+                self._mark('particle file parsed' if not self.device_particles else 'particle generator tables')
 
                 f_end = len(files) if self.frame_end is None else min(self.frame_end, len(files))
                 if self.frames:
@@ -423,6 +432,7 @@ class Generator:
                 work, frames_exist_nb = sharding.rank0_decides(
                     lambda: self._work_list(files, depth_files, idx, out_dir, out_seq_dir, n_sim), self.rank, self.world)
                 work = sharding.shard(work, self.rank, self.world)
+                self._mark('work list')
                 sim_t0 = time.time()
                 self._run_batches(hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0, sims)
                 if frames_exist_nb > 0:
@@ -528,12 +538,19 @@ class Generator:
         encodes = [None] * nslot                                 # the slot's encode job (future) and its frames
         done = [0]
 
+        pending = {}                                             # slots being page-locked by the helper thread (see below)
+
+        def new_slot():
+            return Generator._Slot(hip, B, H, W, env_w, bg_dtype, depth_dtype, False, drops_cap, png_rows=rows_in)
+
         def slot_for(si):
+            if si in pending:
+                slots[si] = pending.pop(si).result()
             sl = slots[si]
             if sl is None or sl.key != key or sl.drops_cap < drops_cap:
                 if sl is not None:
                     sl.free(hip)
-                sl = slots[si] = Generator._Slot(hip, B, H, W, env_w, bg_dtype, depth_dtype, False, drops_cap, png_rows=rows_in)
+                sl = slots[si] = new_slot()
             if getattr(sl, 'prep', None) is None or sl.pkey != pkey:
                 inputs = ((lambda k: dict(bg_png_rows=sl.bg[k], shape=(H, W), depth_png_rows=sl.depth[k])) if rows_in else
                           (lambda k: dict(bg=None if u8 else sl.bg[k], bg_u8=sl.bg[k] if u8 else None, depth=sl.depth[k])))
@@ -618,8 +635,12 @@ class Generator:
             if sl is None or not sl.busy:
                 return
             while not hip.pipeline_wait(si):                    # tile arena regrown: submit the batch again
+                retries[0] += 1
                 hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
             sl.busy = False
+            if not first_done[0]:
+                first_done[0] = True
+                self._mark('first batch collected (%d frames)' % sl.n_valid)
             ms = 1e3 * (time.time() - sl.t_submit) / max(sl.n_valid, 1)
             if sims is not None:                                # the counts only exist now
                 sl.items = [(it, int(sl.n_out[k][0])) for k, (it, _) in enumerate(sl.items)]
@@ -637,8 +658,23 @@ class Generator:
 
         t_loop0 = time.time()
         t_first = None
-        for si in range(min(nslot, len(batches))):               # page-locked buffers + descriptors of every slot: set-up, not steady state
-            slot_for(si)
+        retries, first_done = [0], [False]
+        # Page-locking a slot (1 GB at 128 KITTI frames) takes 0.15 s: the first slot now, the others on a helper thread while the
+        # first batch is decoded and rendered (rr_host_alloc is safe beside the submitting thread; r05: set-up 0.49 -> 0.17 s)
+        if batches:
+            slot_for(0)
+        self._mark('first page-locked slot + descriptors')
+        maker = None
+        for si in range(1, min(nslot, len(batches))):
+            sl = slots[si]
+            if sl is None or sl.key != key or sl.drops_cap < drops_cap:
+                if sl is not None:
+                    sl.free(hip)
+                    slots[si] = None
+                if maker is None:
+                    from concurrent.futures import ThreadPoolExecutor as _TPE
+                    maker = _TPE(max_workers=1)
+                pending[si] = maker.submit(new_slot)
         decoding = stage.submit(decode_job, slot_for(0), batches[0]) if batches else None
         for bi in range(len(batches)):
             si = bi % nslot
@@ -675,9 +711,14 @@ class Generator:
             finish(si)
         for si in range(nslot):
             drain(si)
+        for si in list(pending):                                 # (a run shorter than its slots: keep them for the next run)
+            slots[si] = pending.pop(si).result()
+        if maker is not None:
+            maker.shutdown(wait=True)
         t_end = time.time()
         self.timing.append(dict(frames=done[0], first_batch_s=(t_first or t_end) - t_loop0, total_s=t_end - t_loop0, route='native',
-                                steady_frames_per_s=(max(done[0] - B, 0) / (t_end - t_first)) if t_first and t_end > t_first else None))
+                                steady_frames_per_s=(max(done[0] - B, 0) / (t_end - t_first)) if t_first and t_end > t_first else None,
+                                arena_resubmits=retries[0], setup=list(self._marks)))
 
     def _run_batches_general(self, hip, work, B, rs, imW, imH, frame_render_dict, fog_const, map_generator, folder_idx, folders_num, sim_t0):
         """Batches of B frames through the three-slot asynchronous pipeline (rr_pipeline_submit / rr_pipeline_wait):

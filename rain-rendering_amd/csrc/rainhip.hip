@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "rainhip.h"
@@ -2166,10 +2167,12 @@ __device__ void gauss_half_table(double sigma, int r, double* hw /*LDS, r+1*/) {
 // normalisation sum.  16 lanes per (drop, axis): the r + 1 exponentials (the expensive part: exp from + - * / only) are
 // spread over the lanes, one lane adds them up in the oracle's order (x = -r..r), every lane divides its own entries.
 // A table is 8*(r+1) bytes for the blur kernels to load.
+constexpr int BW_LANES = 4;         // lanes per (drop, axis): most radii are below 8 -- with 16 lanes per table (r04) a third of them had an exponential to evaluate
 __global__ __launch_bounds__(256) void k_blur_weights(const FrameDesc* frames, int max_drops, Scratch sc) {
-  __shared__ double s_hw[16][BR_MAX + 2];
-  const int f = blockIdx.y, grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-  const int idx = blockIdx.x * 16 + grp;
+  constexpr int NG = 256 / BW_LANES;
+  __shared__ double s_hw[NG][BR_MAX + 2];
+  const int f = blockIdx.y, grp = threadIdx.x / BW_LANES, l = threadIdx.x % BW_LANES;
+  const int idx = blockIdx.x * NG + grp;
   const int i = idx >> 1, axis = idx & 1;
   int r = 0;
   double sigma = 0.0;
@@ -2182,7 +2185,7 @@ __global__ __launch_bounds__(256) void k_blur_weights(const FrameDesc* frames, i
     }
   }
   double* tab = s_hw[grp];
-  for (int k = l; k <= r && r > 0; k += 16) tab[k] = gauss_phi(sigma, r - k);       // hw[k] = phi(|k - r|)
+  for (int k = l; k <= r && r > 0; k += BW_LANES) tab[k] = gauss_phi(sigma, r - k);       // hw[k] = phi(|k - r|)
   wave_lds_sync();                                       // (a group never spans two waves)
   if (l == 0 && r > 0) {
     double tot = 0.0;
@@ -2193,7 +2196,7 @@ __global__ __launch_bounds__(256) void k_blur_weights(const FrameDesc* frames, i
   if (r > 0) {
     const double tot = tab[BR_MAX + 1];
     double* hw = sc.wtab + (gi * 2 + axis) * (BR_MAX + 1);
-    for (int k = l; k <= r; k += 16) hw[k] = tab[k] / tot;
+    for (int k = l; k <= r; k += BW_LANES) hw[k] = tab[k] / tot;
   }
 }
 
@@ -4256,6 +4259,8 @@ struct rr_ctx {
   float* d_omega32 = nullptr;        // the same as floats (frames whose map is float: RR_IN_ENV_F32)
   int omega_He = 0, omega_We = 0;
   std::vector<std::pair<const char*, size_t>> host_allocs;   // rr_host_alloc blocks: pieces inside one block may be merged across padding
+  std::mutex host_mu;                // guards host_allocs: rr_host_alloc / rr_host_free may be called from another thread than the one that
+                                     // submits batches (the driver page-locks the slots of later batches while the first one is decoded)
   bool composite_f64 = false;        // RR_OPT_COMPOSITE_F64: float64 colours in the compositor even when nobody asks for the composite
   int scratch_hp = 0;                // span pitch the scratch was sized for
   bool scratch_general = false;      // prefix table / polygons of the general colour path allocated
@@ -4721,7 +4726,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_blur_weights");
-      hipLaunchKernelGGL(k_blur_weights, dim3((2 * max_drops + 15) / 16, n), dim3(256), 0, s, ctx->d_frames, D, sc);
+      hipLaunchKernelGGL(k_blur_weights, dim3((2 * max_drops + 256 / BW_LANES - 1) / (256 / BW_LANES), n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_small");
@@ -5722,7 +5727,12 @@ int host_submit(rr_ctx* ctx, int slot, int32_t n, const rr_prepass_in* pre, cons
   std::vector<rr_prepass_in> pin(pre ? n : 0);
   std::vector<rr_prepass_out> pout(pre ? n : 0);
   CopyList up, down;
-  up.blocks = down.blocks = &ctx->host_allocs;
+  std::vector<std::pair<const char*, size_t>> host_blocks;     // (a snapshot: another thread may be page-locking further blocks)
+  {
+    std::lock_guard<std::mutex> lk(ctx->host_mu);
+    host_blocks = ctx->host_allocs;
+  }
+  up.blocks = down.blocks = &host_blocks;
   up.host_is_src = true;
   down.host_is_src = false;
   std::vector<rr_sim_frame> sims;
@@ -6024,8 +6034,15 @@ int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes) {
     return RR_E_ARG;
   }
   *out = nullptr;
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  {
+    hipError_t e = hipSetDevice(ctx->device);                  // (no ctx->err from here on: this may be a second thread)
+    if (e == hipSuccess) e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return RR_E_HIP;
+    }
+  }
+  std::lock_guard<std::mutex> lk(ctx->host_mu);
   ctx->host_allocs.emplace_back((const char*)*out, (size_t)bytes);
   return RR_OK;
 }
@@ -6033,11 +6050,14 @@ int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes) {
 int rr_host_free(rr_ctx* ctx, void* p) {
   if (!ctx) return RR_E_ARG;
   if (p) {
-    for (size_t k = 0; k < ctx->host_allocs.size(); k++)
-      if (ctx->host_allocs[k].first == (const char*)p) {
-        ctx->host_allocs.erase(ctx->host_allocs.begin() + (ptrdiff_t)k);
-        break;
-      }
+    {
+      std::lock_guard<std::mutex> lk(ctx->host_mu);
+      for (size_t k = 0; k < ctx->host_allocs.size(); k++)
+        if (ctx->host_allocs[k].first == (const char*)p) {
+          ctx->host_allocs.erase(ctx->host_allocs.begin() + (ptrdiff_t)k);
+          break;
+        }
+    }
     HIPCHK(hipHostFree(p));
   }
   return RR_OK;
