@@ -117,6 +117,7 @@ __device__ inline int rainy_kind(const FrameDesc& fr) {
 }
 // float loads that may straddle an 8-byte boundary (rows of an odd-width map start on odd elements)
 typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ inline void wave_lds_sync() {
   // wave-private LDS hand-off: LDS operations of one wave execute in issue order; this only
@@ -178,9 +179,10 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   uint8_t* blended;                 // [frame][drop] 1: the drop is composited (k_colour)
   int32_t* pad_first;               // RR_OPT_WILD_PIXELS only (else null), [frame][H*W]: lowest index of a composited drop whose padded
   int32_t* eff_first;               //   rectangle covers the pixel OUTSIDE / INSIDE the tile the compositor blends (k_pad_visits)
-  uint32_t* spans;                  // [frame][Hp / 4][Dp][4] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4,
-                                    // Dp = drops + 1 rounded up to 8; slot `drops` of every quad stays all zeros: what a drop
-                                    // without a polygon reads
+  uint32_t* spans;                  // [frame][Hp][Dp] FOV row spans xl | (xr+1) << 16, 0 = empty row; Hp = He rounded up to 4, Dp = drops + 1
+                                    // rounded up to 8; column `drops` of every row stays all zeros: what a drop without a polygon
+                                    // reads.  (r05: a row at a time -- k_fov_sums32 fetches the NEXT row's spans while it works on
+                                    // this one; the [row quad][drop][4] layout of r04 cost it a memory round trip per four rows.)
   int4* bbox;                       // [frame][drops] footprint (x0,y0,x1,y1), empty when not composited
   uint16_t* clist;                  // [frame][coarse tiles][drops] ordered drop indices per 64x64 coarse tile
   int32_t* ccount;                  // [frame][coarse tiles]
@@ -690,9 +692,7 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
         if (k == gg) packed[k][c] = v;
     }
   }
-  // spans[frame][row quad][drop slot][4 rows]: the wave's drops are neighbours, so the 16-byte pieces of a quad are
-  // contiguous (and the next waves' follow them); k_fov_sums reads one 16-byte piece per lane, lanes = consecutive drops
-  const int NQ = Hp >> 2;
+  // spans[frame][row][drop]
   bool have[FOV_GROUPS];                                       // (cross-lane reads stay outside the divergent stores)
   int dk[FOV_GROUPS];                                          // the drop of group k
 #pragma unroll
@@ -704,10 +704,10 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   for (int c = 0; c < NCH; c++) {
     const int y = c * 64 + lane;
     if (y < Hp) {
-      uint32_t* out = sc.spans + ((int64_t)f * NQ + (y >> 2)) * Dp * 4 + (y & 3);
+      uint32_t* out = sc.spans + ((int64_t)f * Hp + y) * Dp;
 #pragma unroll
       for (int k = 0; k < FOV_GROUPS; k++)
-        if (have[k]) out[(int64_t)dk[k] * 4] = packed[k][c];
+        if (have[k]) out[dk[k]] = packed[k][c];
     }
   }
   if (!from_list) break;
@@ -820,19 +820,12 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
   };
   DdaCursors<decltype(vertex)> cur;
   cur.init(vertex, N, ktop);
-  const int NQ = Hp >> 2;
-  uint4* out = reinterpret_cast<uint4*>(sc.spans) + (int64_t)f * NQ * Dp + i;
-  for (int yq = 0; yq < Hp; yq += 4) {
-    uint32_t pk[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int y = yq + j;
-      int lo = 1 << 30, hi = -(1 << 30);
-      if (mine && y >= ytop && y <= ybot) cur.row(vertex, y, lo, hi);
-      const int a = imax(lo, 0), b = imin(hi, dm.We - 1);
-      pk[j] = (y < dm.He && a <= b) ? ((uint32_t)a | ((uint32_t)(b + 1) << 16)) : 0u;
-    }
-    if (mine) out[(int64_t)(yq >> 2) * Dp] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;
+  for (int y = 0; y < Hp; y++) {
+    int lo = 1 << 30, hi = -(1 << 30);
+    if (mine && y >= ytop && y <= ybot) cur.row(vertex, y, lo, hi);
+    const int a = imax(lo, 0), b = imin(hi, dm.We - 1);
+    if (mine) out[(int64_t)y * Dp] = (y < dm.He && a <= b) ? ((uint32_t)a | ((uint32_t)(b + 1) << 16)) : 0u;
   }
 }
 
@@ -844,7 +837,7 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
 //   * the vertex loop leaves one 8-byte RECORD per polygon edge in wave-private LDS, rec[edge][lane] (a lane touches bank
 //     pair `lane`: no conflicts): floor(dx / den) + 1, 2 (dx mod den), den and the edge's last row -- the edge's one
 //     division is done there, by every lane at once;
-//   * the row loop is uniform over the map's rows, four per 16-byte store: a cursor steps with five integer instructions
+//   * the row loop is uniform over the map's rows: a cursor steps with five integer instructions
 //     (the sign of the running remainder is the carry), a row's span is min / max of the two cursors;
 //   * a lane whose cursor reaches its edge's last row takes the next record -- fetched from LDS an edge ahead, so the
 //     event itself waits for nothing.  Horizontal edges (rare) fold their far end on the spot.
@@ -946,21 +939,14 @@ __global__ __launch_bounds__(256) void k_fov_walk(const FrameDesc* frames, Dims 
   if (!mine) { ktop = 0; xtop = 0; ytop = 1 << 20; ybot = 0; }   // (never reaches its first row: parked throughout)
   cur.init(rec, N, ktop, xtop, ytop);
   const unsigned span_rows = mine ? (unsigned)(ybot - ytop) : 0u;
-  const int NQ = Hp >> 2;
-  uint4* out = reinterpret_cast<uint4*>(sc.spans) + (int64_t)f * NQ * Dp + i;
+  uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;        // a wave stores 256 consecutive bytes per row
   const int xmax = dm.We - 1;
-  for (int yq = 0; yq < Hp; yq += 4) {
-    uint32_t pk[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int y = yq + j;
-      int lo, hi;
-      cur.row(rec, y, lo, hi);
-      const int b = imin(hi, xmax);                            // (lo >= 0: vertex coordinates are not negative)
-      const bool in = mine && (unsigned)(y - ytop) <= span_rows && y < dm.He && lo <= b;
-      pk[j] = in ? ((uint32_t)lo | ((uint32_t)(b + 1) << 16)) : 0u;
-    }
-    if (mine) out[(int64_t)(yq >> 2) * Dp] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  for (int y = 0; y < Hp; y++) {
+    int lo, hi;
+    cur.row(rec, y, lo, hi);
+    const int b = imin(hi, xmax);                              // (lo >= 0: vertex coordinates are not negative)
+    const bool in = mine && (unsigned)(y - ytop) <= span_rows && y < dm.He && lo <= b;
+    if (mine) out[(int64_t)y * Dp] = in ? ((uint32_t)lo | ((uint32_t)(b + 1) << 16)) : 0u;
   }
 }
 
@@ -1027,9 +1013,9 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
   const int y0 = band * rpb, y1 = imin(dm.He, y0 + rpb);
   const int Cw = (((We + nw - 1) / nw) + 1) & ~1;        // columns per wave (even), taken in passes of 128 (<= EMAX passes)
   const int cw0 = wave * Cw;
-  // spans of frame f: [Hp / 4][Dp] pieces of 16 bytes (4 rows); slot max_drops of every quad is all zeros (what a
+  // spans of frame f: [Hp][Dp]; column max_drops of every row is all zeros (what a
   // drop without a polygon reads)
-  const uint4* spf = reinterpret_cast<const uint4*>(sc.spans) + (int64_t)f * (Hp >> 2) * Dp;
+  const uint32_t* spf = sc.spans + (int64_t)f * Hp * Dp;
   uint32_t sp[DPT];
 #pragma unroll
   for (int d = 0; d < DPT; d++) {
@@ -1071,7 +1057,9 @@ __global__ __launch_bounds__(1024) void k_fov_sums(const FrameDesc* frames, Dims
   for (int yq = y0; yq < y1; yq += 4) {                  // y0 is a multiple of four: one 16-byte span load per drop and quad
     uint4 q[DPT];
 #pragma unroll
-    for (int d = 0; d < DPT; d++) q[d] = spf[(int64_t)(yq >> 2) * Dp + sp[d]];
+    for (int d = 0; d < DPT; d++)                          // (rows yq .. yq + 3 < Hp: the spans are padded to a multiple of four rows)
+      q[d] = make_uint4(spf[(int64_t)yq * Dp + sp[d]], spf[(int64_t)(yq + 1) * Dp + sp[d]], spf[(int64_t)(yq + 2) * Dp + sp[d]],
+                        spf[(int64_t)(yq + 3) * Dp + sp[d]]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int y = yq + j;
@@ -1174,6 +1162,14 @@ __device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {              // (zer
 }
 __device__ inline float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// r05: the kernel's time per map row was 4.75 us for 1 us of vector work: with ONE workgroup per CU nothing covers the
+// latency of the next row's loads (issued a lookup phase ahead) nor that of the span pieces (four rows at a time, used at
+// once).  Measured with the loads replaced by arithmetic: 3.8 ms -> 2.7 (no row loads) / 3.1 (no span loads) / 1.8 (neither).
+// Now both travel a whole row ahead: a row's texels stay in registers AS LOADED and the scan forms its products from them
+// first thing -- the same registers then receive the next row at once (r04 asked for it after the prefix row had been
+// written, a lookup phase before it was needed); the spans come a dword per drop and row ([row][drop] layout), the next
+// row's requested at the top of the current one: 16 registers in place of the quads' 32, and the kernel no longer spills.
+// Sums, scan and their order are unchanged: same bits.
 template <int DPT, int EMAX, bool E32>
 __global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Dims dm, int max_drops, int Hp, int Dp, int rpb, int nchunk, Scratch sc) {
   extern __shared__ __attribute__((aligned(16))) float s_dyn32[];
@@ -1191,12 +1187,11 @@ __global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Di
   const int y0 = band * rpb, y1 = imin(dm.He, y0 + rpb);
   const int Cw = (((We + nw - 1) / nw) + 1) & ~1;
   const int cw0 = wave * Cw;
-  const uint4* spf = reinterpret_cast<const uint4*>(sc.spans) + (int64_t)f * (Hp >> 2) * Dp;
   uint32_t sp[DPT];
 #pragma unroll
   for (int d = 0; d < DPT; d++) {
     const int i = d0 + d * NT + t;
-    sp[d] = (uint32_t)((i < d1 && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops);
+    sp[d] = 4u * (uint32_t)((i < d1 && sc.npts[(int64_t)f * max_drops + i] > 0) ? i : max_drops);      // byte offset inside a span row
   }
   if (t == 0) s_P[0] = make_float4(0.f, 0.f, 0.f, 0.f);
   float S[DPT][4];
@@ -1204,113 +1199,123 @@ __global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Di
 #pragma unroll
   for (int d = 0; d < DPT; d++) S[d][0] = S[d][1] = S[d][2] = S[d][3] = 0.f;
   double totY = 0.0, totw = 0.0;                         // row totals (Y*w, w), kept by the thread that owns the last column
-  float pa[EMAX][4], pb[EMAX][4];
-  auto load_row = [&](int y) {
-    if (E32) {                                             // float map: 12 + 4 bytes per texel, two texels per lane as 8-byte pieces
-      const global_ptr<const float> env = as_global(static_cast<const float*>(fr.env)) + (int64_t)y * We * 3;
-      const global_ptr<const float> om = as_global(static_cast<const float*>(fr.omega)) + (int64_t)y * We;
-#pragma unroll
-      for (int e = 0; e < EMAX; e++) {
-        const int cl = e * 128 + 2 * lane, c = cw0 + cl;
-#pragma unroll
-        for (int k = 0; k < 4; k++) pa[e][k] = pb[e][k] = 0.f;
-        if (cl < Cw && c + 1 < We) {
-          const float2_u a = *reinterpret_cast<const global_ptr<const float2_u>>(env + c * 3);
-          const float2_u b = *reinterpret_cast<const global_ptr<const float2_u>>(env + c * 3 + 2);
-          const float2_u d = *reinterpret_cast<const global_ptr<const float2_u>>(env + c * 3 + 4);
-          const float2_u w = *reinterpret_cast<const global_ptr<const float2_u>>(om + c);
-          pa[e][0] = a.x * w.x; pa[e][1] = a.y * w.x; pa[e][2] = b.x * w.x; pa[e][3] = w.x;
-          pb[e][0] = b.y * w.y; pb[e][1] = d.x * w.y; pb[e][2] = d.y * w.y; pb[e][3] = w.y;
-        } else if (cl < Cw && c < We) {                      // the map's last column
-          const float w = om[c];
-          pa[e][0] = env[c * 3 + 0] * w; pa[e][1] = env[c * 3 + 1] * w; pa[e][2] = env[c * 3 + 2] * w; pa[e][3] = w;
-        }
-      }
-      return;
-    }
-    const global_ptr<const double> env = as_global(static_cast<const double*>(fr.env)) + (int64_t)y * We * 3;
-    const global_ptr<const double> om = as_global(static_cast<const double*>(fr.omega)) + (int64_t)y * We;
+  // A map row in registers: the lane's two texels per pass AS LOADED (x y Y x' | y' Y' | w w') -- the products with the solid
+  // angle are formed where the scan takes them (formed at the load, they made the load synchronous: the multiplications
+  // waited for the data a few instructions after the request).  The two array pointers of the frame are read ONCE, into
+  // scalar registers: left to the compiler they were fetched from the frame descriptor again for every row, with a
+  // vmcnt(0) that drained every load in flight.
+  struct RowRegs {
+    float4_u a[EMAX];
+    float2_u d[EMAX], w[EMAX];
+  };
+  // Loads of the row loop go through buffer descriptors (base in scalar registers, a 32-bit lane offset, a scalar row offset):
+  // no 64-bit address per load and lane -- with plain pointers the addresses alone took 30 registers and the kernel spilled.
+  // Every one of them is UNCONDITIONAL and the same for every lane (clamped offsets; what a lane must not use is discarded
+  // where the scan forms its products): the compiler then counts the loads in flight exactly.  With a load inside a branch it
+  // waited with vmcnt(0) -- for the row it had just requested.
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  auto descriptor = [](const void* p) {                    // raw buffer, no stride, 2 GB range (gfx9 word 3: 32-bit data format)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rs_env = descriptor(fr.env), rs_om = descriptor(fr.omega);
+  const __amdgpu_buffer_rsrc_t rs_sp = descriptor(sc.spans + (int64_t)f * Hp * Dp);
+  auto load_row = [&](int y, RowRegs& R) {
 #pragma unroll
     for (int e = 0; e < EMAX; e++) {
-      const int cl = e * 128 + 2 * lane, c = cw0 + cl;
-#pragma unroll
-      for (int k = 0; k < 4; k++) pa[e][k] = pb[e][k] = 0.f;
-      if (cl < Cw && c < We) {
-        const double w = om[c];
-        pa[e][0] = (float)(env[c * 3 + 0] * w);
-        pa[e][1] = (float)(env[c * 3 + 1] * w);
-        pa[e][2] = (float)(env[c * 3 + 2] * w);
-        pa[e][3] = (float)w;
-        if (c + 1 < We) {
-          const double w1 = om[c + 1];
-          pb[e][0] = (float)(env[c * 3 + 3] * w1);
-          pb[e][1] = (float)(env[c * 3 + 4] * w1);
-          pb[e][2] = (float)(env[c * 3 + 5] * w1);
-          pb[e][3] = (float)w1;
-        }
+      const int c = cw0 + e * 128 + 2 * lane;
+      const int cb = imax(imin(c, We - 2), 0);             // the pair (cb, cb + 1) exists; the lane of the map's last column reads (We - 2, We - 1)
+      if (E32) {                                           // float map: 12 + 4 bytes per texel
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_env, cb * 12, y * We * 12, 0);          // x y Y of texel cb, x of texel cb + 1
+        const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs_env, cb * 12 + 16, y * We * 12, 0);      // y Y of texel cb + 1
+        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs_om, cb * 4, y * We * 4, 0);
+        R.a[e] = float4_u{__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+        R.d[e] = float2_u{__uint_as_float(d.x), __uint_as_float(d.y)};
+        R.w[e] = float2_u{__uint_as_float(w.x), __uint_as_float(w.y)};
+      } else {                                             // float64 map: rounded to float as it arrives (the products are float either way)
+        auto f64at = [&](const __amdgpu_buffer_rsrc_t& rs, int voff, int soff) {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+          return (float)__hiloint2double((int)v.y, (int)v.x);
+        };
+        const int so = y * We * 24, vo = cb * 24;
+        R.a[e] = float4_u{f64at(rs_env, vo, so), f64at(rs_env, vo + 8, so), f64at(rs_env, vo + 16, so), f64at(rs_env, vo + 24, so)};
+        R.d[e] = float2_u{f64at(rs_env, vo + 32, so), f64at(rs_env, vo + 40, so)};
+        R.w[e] = float2_u{f64at(rs_om, cb * 8, y * We * 8), f64at(rs_om, cb * 8 + 8, y * We * 8)};
       }
     }
   };
-  if (y0 < y1) load_row(y0);
-  for (int yq = y0; yq < y1; yq += 4) {
-    uint4 q[DPT];
+  // one map row: R holds it; `cur` are this row's spans, `nxt` receives the next row's
+  auto row = [&](int y, RowRegs& R, uint32_t (&cur)[DPT], uint32_t (&nxt)[DPT]) {
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    float ps[EMAX][4], pa[EMAX][4], pb[EMAX][4];           // the lane's two columns per pass: (x*w, y*w, Y*w, w)
 #pragma unroll
-    for (int d = 0; d < DPT; d++) q[d] = spf[(int64_t)(yq >> 2) * Dp + sp[d]];
+    for (int e = 0; e < EMAX; e++) {
+      const int cl = e * 128 + 2 * lane, c = cw0 + cl;
+      const bool v0 = cl < Cw && c < We, v1 = cl < Cw && c + 1 < We, last = v0 && !v1;       // last: the map's last column (the SECOND texel of what was loaded)
+      const float wa = v0 ? (last ? R.w[e].y : R.w[e].x) : 0.f, wb = v1 ? R.w[e].y : 0.f;
+      pa[e][0] = (last ? R.a[e].w : R.a[e].x) * wa; pa[e][1] = (last ? R.d[e].x : R.a[e].y) * wa; pa[e][2] = (last ? R.d[e].y : R.a[e].z) * wa; pa[e][3] = wa;
+      pb[e][0] = R.a[e].w * wb; pb[e][1] = R.d[e].x * wb; pb[e][2] = R.d[e].y * wb; pb[e][3] = wb;
+    }
+    load_row(imin(y + 1, y1 - 1), R);                      // R is free: the next row, a whole row ahead (the last row asks for itself again)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int y = yq + j;
-      if (y >= y1) break;
-      float carry[4] = {0.f, 0.f, 0.f, 0.f};
-      float ps[EMAX][4];
+    for (int d = 0; d < DPT; d++) nxt[d] = __builtin_amdgcn_raw_buffer_load_b32(rs_sp, (int)sp[d], imin(y + 1, Hp - 1) * Dp * 4, 0);
 #pragma unroll
-      for (int e = 0; e < EMAX; e++) {
-        if (e * 128 < Cw) {
+    for (int e = 0; e < EMAX; e++) {
+      if (e * 128 < Cw) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float v = wave_incl_scan_f32(pa[e][k] + pb[e][k]) + carry[k];
-            ps[e][k] = v;
-            carry[k] = readlane_f32(v, 63);
-          }
+        for (int k = 0; k < 4; k++) {
+          const float v = wave_incl_scan_f32(pa[e][k] + pb[e][k]) + carry[k];
+          ps[e][k] = v;
+          carry[k] = readlane_f32(v, 63);
         }
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) s_wt[wave * 4 + k] = carry[k];
-      }
-      __syncthreads();
-      float basev[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float wt = row16_incl_scan_f32(lane < nw ? s_wt[lane * 4 + k] : 0.f);
-        const float u = readlane_f32(wt, wave > 0 ? wave - 1 : 0);
-        basev[k] = wave > 0 ? u : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < EMAX; e++) {
-        const int cl = e * 128 + 2 * lane, c = cw0 + cl;
-        if (cl < Cw && c < We) {
-          float o[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) o[k] = basev[k] + ps[e][k];                 // through column c + 1
-          s_P[c + 1] = make_float4(o[0] - pb[e][0], o[1] - pb[e][1], o[2] - pb[e][2], o[3] - pb[e][3]);
-          if (c + 1 < We) s_P[c + 2] = make_float4(o[0], o[1], o[2], o[3]);
-          if (c == We - 1 || c + 1 == We - 1) { totY += (double)o[2]; totw += (double)o[3]; }
-        }
-      }
-      if (y + 1 < y1) load_row(y + 1);
-      __syncthreads();
-#pragma unroll
-      for (int d = 0; d < DPT; d++) {
-        const uint32_t v = j == 0 ? q[d].x : (j == 1 ? q[d].y : (j == 2 ? q[d].z : q[d].w));
-        any |= (v != 0u ? 1u : 0u) << d;
-        const float4 h = s_P[v >> 16], l = s_P[v & 0xffffu];
-        S[d][0] += h.x - l.x;
-        S[d][1] += h.y - l.y;
-        S[d][2] += h.z - l.z;
-        S[d][3] += h.w - l.w;
       }
     }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) s_wt[wave * 4 + k] = carry[k];
+    }
+    __syncthreads();
+    float basev[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float wt = row16_incl_scan_f32(lane < nw ? s_wt[lane * 4 + k] : 0.f);
+      const float u = readlane_f32(wt, wave > 0 ? wave - 1 : 0);
+      basev[k] = wave > 0 ? u : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; e++) {
+      const int cl = e * 128 + 2 * lane, c = cw0 + cl;
+      if (cl < Cw && c < We) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = basev[k] + ps[e][k];                 // through column c + 1
+        s_P[c + 1] = make_float4(o[0] - pb[e][0], o[1] - pb[e][1], o[2] - pb[e][2], o[3] - pb[e][3]);
+        if (c + 1 < We) s_P[c + 2] = make_float4(o[0], o[1], o[2], o[3]);
+        if (c == We - 1 || c + 1 == We - 1) { totY += (double)o[2]; totw += (double)o[3]; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DPT; d++) {
+      const uint32_t v = cur[d];
+      any |= (v != 0u ? 1u : 0u) << d;
+      const float4 h = s_P[v >> 16], l = s_P[v & 0xffffu];
+      S[d][0] += h.x - l.x;
+      S[d][1] += h.y - l.y;
+      S[d][2] += h.z - l.z;
+      S[d][3] += h.w - l.w;
+    }
+#pragma unroll
+    for (int d = 0; d < DPT; d++) cur[d] = nxt[d];
+  };
+  RowRegs RA;
+  uint32_t qa[DPT], qb[DPT];
+  if (y0 < y1) {
+    load_row(y0, RA);
+#pragma unroll
+    for (int d = 0; d < DPT; d++) qa[d] = __builtin_amdgcn_raw_buffer_load_b32(rs_sp, (int)sp[d], y0 * Dp * 4, 0);
   }
+  for (int y = y0; y < y1; y++) row(y, RA, qa, qb);
 #pragma unroll
   for (int d = 0; d < DPT; d++) {
     const int i = d0 + d * NT + t;
