@@ -551,7 +551,7 @@ def main():
             rh.profile(False)
             line(spec, el, rh.profile_read())
             for k, v in pairs:
-                rh.set_option(int(k), {1: 1, 9: 1, 10: 2, 12: 2, 16: 1, 17: 1, 19: 1}.get(int(k), 0))  # back to the option's default
+                rh.set_option(int(k), {1: 1, 9: 1, 10: 2, 12: 1, 16: 1, 17: 1, 19: 1}.get(int(k), 0))  # back to the option's default
         warm(render, 1)
     nb = min(B, batch.n)
     cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)

@@ -376,9 +376,10 @@ enum {
   RR_OPT_FOV_F32 = 10,
   RR_OPT_FOV_DDA = 12,              /* tuning: the float colour branch evaluates a drop's field-of-view polygon and its row spans with one
                                      * thread per drop (two cursors down the polygon's sides; wrapping polygons and float64 decisions
-                                     * through a list to the edge-parallel kernel) -- 2 (default, r05): incremental cursors over
-                                     * per-edge records, 1: an exact division per cursor and row (r04); 0: the edge-parallel kernel
-                                     * for every drop.  The spans are the same: identical results. */
+                                     * through a list to the edge-parallel kernel) -- 1 (default): an exact division per cursor and row;
+                                     * 2 (r05): incremental cursors over per-edge records (a quarter of the instructions per row, no
+                                     * faster: profiles/r05_ab_log.md); 0: the edge-parallel kernel for every drop.  The spans are the
+                                     * same: identical results. */
   RR_OPT_COMPOSITE_WAVES = 11,      /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
                                      * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
   RR_OPT_PIPELINE_F32 = 13,         /* 1 (default): rr_pipeline_* hand the fog layer and the xyY map from the pre-pass to the hot path

@@ -830,7 +830,8 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
 }
 
 // ---------------------------------------------------------------------------
-// FOV polygon and row spans, one thread per drop, incremental cursors (r05; the float colour branch's default)
+// FOV polygon and row spans, one thread per drop, incremental cursors (r05; RR_OPT_FOV_DDA 2 -- NOT the default: see the end
+// of this comment)
 // ---------------------------------------------------------------------------
 // k_fov_dda spends 120 vector + 78 scalar instructions per map row and wave: an exact division per cursor and row, and a
 // divergent search for the next vertex inside the row loop.  Here (rr_device.h DdaWalk):
@@ -844,6 +845,10 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
 // Lanes above their polygon's first row are parked on the top vertex (a step that moves nothing), rows below the last one
 // are masked at the store.  Classification, the frame's list for k_fov_spans and the span layout are k_fov_dda's: the
 // spans are the same bits (RR_OPT_FOV_DDA 0 / 1 / 2 give identical colour constants: tests/test_gpu_properties.py).
+// Measured (profiles/r05_ab_log.md): 3.29 ms against k_fov_dda's 3.28 per 512 frames with the r04 span layout, 3.76 against
+// 3.45 with the [row][drop] layout k_fov_sums32 wants now -- a quarter of the static instructions per row, the same time:
+// with 64 unrelated polygons per wave some lane meets a vertex on 97 % of the rows and the divergent "next edge" path runs
+// nearly every row (vertex phase alone 0.71 ms, row loop without its stores 2.3 ms).  k_fov_dda stays the default.
 __global__ __launch_bounds__(256) void k_fov_walk(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
@@ -4172,7 +4177,7 @@ struct rr_ctx {
   int fill_rule = 0;                 // RR_OPT_FOV_FILL_RULE
   bool composite_u16 = true;         // RR_OPT_COMPOSITE_U16
   bool blur_dma = true;              // RR_OPT_BLUR_DMA
-  int fov_dda = 2;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (2: k_fov_walk, 1: k_fov_dda)
+  int fov_dda = 1;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (1: k_fov_dda, 2: k_fov_walk)
   int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
   int n_tex = 0;
   float* d_ctab = nullptr;
