@@ -2218,15 +2218,20 @@ __global__ __launch_bounds__(256) void k_blur_weights(const FrameDesc* frames, i
 // hw(k) = w(|k - r|), k = 0..r: an LDS table (fused kernel) or the lanes of a register (wave-per-drop kernel).
 template <class W>
 __device__ inline void blur4(const double* c0, int st, W hw, int r, double& acc0, double& acc1, double& acc2, double& acc3) {
+  // element k * st of the window: a 24-bit multiply (|k| <= 2 r + 4, st < 4096).  A full 32-bit one compiles to v_mad_u64_u32 with a
+  // 64-bit addend, for whose unused upper half the register allocator may pick a register that a prefetch load is still writing:
+  // the wait-count pass then guards the multiplication with vmcnt(0) -- k_blur_small waited for its NEXT drop's loads in the
+  // middle of the current drop's row pass (r05).
+  auto at = [&](int k) { return c0[__mul24(k, st)]; };
   const double wc = hw(r);
-  acc0 = c0[0] * wc; acc1 = c0[st] * wc; acc2 = c0[2 * st] * wc; acc3 = c0[3 * st] * wc;
-  double a0 = c0[(-r) * st], a1 = c0[(1 - r) * st], a2 = c0[(2 - r) * st], a3 = c0[(3 - r) * st];
-  double b0 = c0[r * st], b1 = c0[(1 + r) * st], b2 = c0[(2 + r) * st], b3 = c0[(3 + r) * st];
+  acc0 = c0[0] * wc; acc1 = at(1) * wc; acc2 = at(2) * wc; acc3 = at(3) * wc;
+  double a0 = at(-r), a1 = at(1 - r), a2 = at(2 - r), a3 = at(3 - r);
+  double b0 = at(r), b1 = at(1 + r), b2 = at(2 + r), b3 = at(3 + r);
   int ii = -r;
   for (; ii + 3 < 0; ii += 4) {
     const double w0 = hw(ii + r), w1 = hw(ii + 1 + r), w2 = hw(ii + 2 + r), w3 = hw(ii + 3 + r);
-    const double na0 = c0[(4 + ii) * st], na1 = c0[(5 + ii) * st], na2 = c0[(6 + ii) * st], na3 = c0[(7 + ii) * st];
-    const double nb0 = c0[(-ii - 1) * st], nb1 = c0[(-ii - 2) * st], nb2 = c0[(-ii - 3) * st], nb3 = c0[(-ii - 4) * st];
+    const double na0 = at(4 + ii), na1 = at(5 + ii), na2 = at(6 + ii), na3 = at(7 + ii);
+    const double nb0 = at(-ii - 1), nb1 = at(-ii - 2), nb2 = at(-ii - 3), nb3 = at(-ii - 4);
     acc0 = acc0 + (a0 + b0) * w0; acc1 = acc1 + (a1 + b1) * w0; acc2 = acc2 + (a2 + b2) * w0; acc3 = acc3 + (a3 + b3) * w0;
     acc0 = acc0 + (a1 + nb0) * w1; acc1 = acc1 + (a2 + b0) * w1; acc2 = acc2 + (a3 + b1) * w1; acc3 = acc3 + (na0 + b2) * w1;
     acc0 = acc0 + (a2 + nb1) * w2; acc1 = acc1 + (a3 + nb0) * w2; acc2 = acc2 + (na0 + b0) * w2; acc3 = acc3 + (na1 + b1) * w2;
@@ -2236,8 +2241,8 @@ __device__ inline void blur4(const double* c0, int st, W hw, int r, double& acc0
   }
   for (; ii < 0; ii++) {
     const double w = hw(ii + r);
-    const double na = c0[(4 + ii) * st];                               // next upper element of output 3
-    const double nb = c0[(-ii - 1) * st];                              // next lower element of output 0
+    const double na = at(4 + ii);                               // next upper element of output 3
+    const double nb = at(-ii - 1);                              // next lower element of output 0
     acc0 = acc0 + (a0 + b0) * w;
     acc1 = acc1 + (a1 + b1) * w;
     acc2 = acc2 + (a2 + b2) * w;
@@ -2775,10 +2780,10 @@ __global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, 
       const int nv = (php >> 2) * tw;
       for (int idx = lane; idx < nv; idx += 64) {
         const int rb = (int)(((float)idx + 0.5f) * inv_tw), x = idx - rb * tw;
-        const double* c0 = X + (4 * rb + r1) * tw + x;
+        const double* c0 = X + (__mul24(4 * rb + r1, tw) + x);       // (24-bit multiply-add: see the note at the prefetch below)
         double a0, a1, a2, a3;
         blur4(c0, tw, [&](int k) { return readlane_f64(w1, r1 - k); }, r1, a0, a1, a2, a3);
-        double* o = Y + 4 * rb * yp + 2 * r2 + x;                 // Y has php rows: the slack rows are never read
+        double* o = Y + (__mul24(4 * rb, yp) + 2 * r2 + x);          // Y has php rows: the slack rows are never read
         o[0] = a0;
         o[yp] = a1;
         o[2 * yp] = a2;
@@ -2793,7 +2798,7 @@ __global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, 
       const float inv_ph = 1.0f / (float)ph;
       for (int idx = lane; idx < nh; idx += 64) {
         const int cb = (int)(((float)idx + 0.5f) * inv_ph), yq = idx - cb * ph;
-        const double* c0 = Y + yq * yp + 4 * cb + r2;
+        const double* c0 = Y + (__mul24(yq, yp) + 4 * cb + r2);
         double a0, a1, a2, a3;
         if (r2 > 0) {
           blur4(c0, 1, [&](int k) { return readlane_f64(w2, r2 - k); }, r2, a0, a1, a2, a3);
