@@ -524,7 +524,9 @@ def main():
         names = {0: ('k_tile', ['stage plan+texture', 'row intervals', 'samples', 'horizontal folds', 'wait for waves', 'vertical folds+store', '-', 'barrier at item start']),
                  1: ('k_tile_big', ['search+barriers', 'plan fields', 'pixel']),
                  2: ('k_blur_small', ['plan+weights+raw->LDS', 'row pass', 'column pass+store']),
-                 3: ('k_blur_fused[_dma]', ['issue loads | dma: clear Y + wait for the loads + halo', 'barrier A (loads land)', 'row pass', 'barrier B', 'column pass+store', 'barrier C', 'dma: next loads issued'])}
+                 3: ('k_blur_fused[_dma]', ['issue loads | dma: clear Y + wait for the loads + halo', 'barrier A (loads land)', 'row pass', 'barrier B', 'column pass+store', 'barrier C', 'dma: next loads issued']),
+                 4: ('k_composite32', ['background / depth loads', 'list piece: clist + bbox loads, ballots, list', 'barriers of the list piece', 'record batch arrives', 'entry loop',
+                                       'barrier at the piece end', 'stores + tile reduction'])}
         calls = args.steps + args.warmup
         sys.stderr.write("PHASES (shader cycles summed over waves, per call; share of the kernel's wave time)\n")
         for kid, (kn, ph) in names.items():
@@ -551,7 +553,7 @@ def main():
             rh.profile(False)
             line(spec, el, rh.profile_read())
             for k, v in pairs:
-                rh.set_option(int(k), {1: 1, 9: 1, 10: 2, 12: 1, 16: 1, 17: 1, 19: 1}.get(int(k), 0))  # back to the option's default
+                rh.set_option(int(k), {1: 1, 9: 1, 10: 2, 12: 1, 16: 1, 17: 1, 19: 1, 20: 1}.get(int(k), 0))  # back to the option's default
         warm(render, 1)
     nb = min(B, batch.n)
     cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)

@@ -381,7 +381,8 @@ enum {
                                      * faster: profiles/r05_ab_log.md); 0: the edge-parallel kernel for every drop.  The spans are the
                                      * same: identical results. */
   RR_OPT_COMPOSITE_WAVES = 11,      /* tuning: waves per SIMD the float compositor's register allocation is held to: 0 (library's
-                                     * choice = 6), 6, 7 or 8 (more waves in flight hide more of the alpha-sample latency) */
+                                     * choice), 4..8 (more waves in flight hide more of the alpha-sample latency; 4 and 5 only with
+                                     * RR_OPT_COMPOSITE_BATCH) */
   RR_OPT_PIPELINE_F32 = 13,         /* 1 (default): rr_pipeline_* hand the fog layer and the xyY map from the pre-pass to the hot path
                                      * as float32 unless pre_out asks for float64 copies (see rr_pipeline_frames); 0: float64 */
   RR_OPT_WILD_PIXELS = 14,          /* 1: rainy_bg may hold values outside [0, 1] (a third party's array; the fog pre-pass ends with a
@@ -413,9 +414,13 @@ enum {
                                      * for; takes the general (slow) colour path.  Colour only: a drop's colour constants move by
                                      * <= 0.3 %, rainy_image by <= 1 LSB on 1.4 % of its values (README, profiles/r05_fill_rule_study.txt);
                                      * mask and statuses are the same. */
-  RR_OPT_BIN_ROWS = 19              /* tuning (r05): 1 (default) the ordered per-tile drop lists are made by a workgroup per ROW of coarse
+  RR_OPT_BIN_ROWS = 19,             /* tuning (r05): 1 (default) the ordered per-tile drop lists are made by a workgroup per ROW of coarse
                                      * tiles (drops filtered by row first, then a wave per tile); 0: a workgroup per coarse tile that
                                      * tests every drop (r04).  Same lists. */
+  RR_OPT_COMPOSITE_BATCH = 20       /* tuning (r05): 1 (default) the float compositor keeps the records of 64 list entries at a time in
+                                     * vector registers (a lane per entry) and runs its alpha samples two entries ahead of the blend;
+                                     * 0: a scalar record fetch per entry, samples one entry ahead (r04).  Same operations in the same
+                                     * order: same bits. */
 };
 int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value);
 

@@ -110,6 +110,45 @@ __device__ inline void load_px3(const void* base, int kind, int64_t pix, double 
     out[0] = (double)s[0] / 255.0; out[1] = (double)s[1] / 255.0; out[2] = (double)s[2] / 255.0;
   }
 }
+// The same in two steps -- the loads now, the conversion when the values are needed -- for two pixels of one image: a kernel
+// that asks for all its pixels first and converts afterwards waits for one memory round trip instead of one per load_px3.
+struct RawPx {
+  uint32_t a, b, c, d, e, f;         // float64: three (lo, hi) pairs; float32: a b c; uint8: a b c
+};
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ inline void load_px3_raw2(const void* base, int kind, int64_t pa, int64_t pb, RawPx& qa, RawPx& qb) {
+  if (kind == 0) {
+    const global_ptr<const u32x2_t> s = as_global(static_cast<const u32x2_t*>(base));
+    const u32x2_t a0 = s[pa * 3], a1 = s[pa * 3 + 1], a2 = s[pa * 3 + 2], b0 = s[pb * 3], b1 = s[pb * 3 + 1], b2 = s[pb * 3 + 2];
+    qa = RawPx{a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+    qb = RawPx{b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+  } else if (kind == 1) {
+    const global_ptr<const uint32_t> s = as_global(static_cast<const uint32_t*>(base));
+    const uint32_t a0 = s[pa * 3], a1 = s[pa * 3 + 1], a2 = s[pa * 3 + 2], b0 = s[pb * 3], b1 = s[pb * 3 + 1], b2 = s[pb * 3 + 2];
+    qa = RawPx{a0, a1, a2, 0u, 0u, 0u};
+    qb = RawPx{b0, b1, b2, 0u, 0u, 0u};
+  } else {
+    const global_ptr<const uint8_t> s = as_global(static_cast<const uint8_t*>(base));
+    const uint32_t a0 = s[pa * 3], a1 = s[pa * 3 + 1], a2 = s[pa * 3 + 2], b0 = s[pb * 3], b1 = s[pb * 3 + 1], b2 = s[pb * 3 + 2];
+    qa = RawPx{a0, a1, a2, 0u, 0u, 0u};
+    qb = RawPx{b0, b1, b2, 0u, 0u, 0u};
+  }
+}
+__device__ inline void decode_px3(const RawPx& q, int kind, double out[3]) {
+  if (kind == 0) {
+    out[0] = __hiloint2double((int)q.b, (int)q.a);
+    out[1] = __hiloint2double((int)q.d, (int)q.c);
+    out[2] = __hiloint2double((int)q.f, (int)q.e);
+  } else if (kind == 1) {
+    out[0] = (double)__uint_as_float(q.a);
+    out[1] = (double)__uint_as_float(q.b);
+    out[2] = (double)__uint_as_float(q.c);
+  } else {
+    out[0] = (double)q.a / 255.0;
+    out[1] = (double)q.b / 255.0;
+    out[2] = (double)q.c / 255.0;
+  }
+}
 __device__ inline int bg_kind(const FrameDesc& fr) { return (fr.in_types & RR_IN_BG_U8) ? 2 : ((fr.in_types & RR_IN_BG_F32) ? 1 : 0); }
 __device__ inline int rainy_kind(const FrameDesc& fr) {
   if (fr.rainy_bg == fr.bg) return bg_kind(fr);
@@ -132,6 +171,7 @@ __device__ inline void wave_lds_sync() {
 #ifdef RR_PHASES
 __device__ unsigned long long g_phase[8][8];
 #define PH_DECL unsigned long long ph_t0_ = __builtin_readcyclecounter(), ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define PH(k)                                                   \
   {                                                             \
     const unsigned long long ph_n_ = __builtin_readcyclecounter(); \
@@ -145,6 +185,7 @@ __device__ unsigned long long g_phase[8][8];
   }
 #else
 #define PH_DECL
+#define PH_WAITVM
 #define PH(k)
 #define PH_FLUSH(kid)
 #endif
@@ -976,6 +1017,32 @@ __device__ inline double wave_incl_scan_f64(double v) {
   v += dpp_move_f64<0x143, 0xc>(v);                      // row_bcast:31 into rows 2 and 3
   return v;
 }
+// the same scans for min / max: a lane without a source (and a row the mask leaves out) keeps its own value -- min(v, v) = v
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_keep_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_min_scan_f64(double v) {     // lane 63: the wave's minimum
+  v = dmin(v, dpp_keep_f64<0x111, 0xf>(v));
+  v = dmin(v, dpp_keep_f64<0x112, 0xf>(v));
+  v = dmin(v, dpp_keep_f64<0x114, 0xf>(v));
+  v = dmin(v, dpp_keep_f64<0x118, 0xf>(v));
+  v = dmin(v, dpp_keep_f64<0x142, 0xa>(v));
+  v = dmin(v, dpp_keep_f64<0x143, 0xc>(v));
+  return v;
+}
+__device__ inline double wave_max_scan_f64(double v) {     // lane 63: the wave's maximum
+  v = dmax(v, dpp_keep_f64<0x111, 0xf>(v));
+  v = dmax(v, dpp_keep_f64<0x112, 0xf>(v));
+  v = dmax(v, dpp_keep_f64<0x114, 0xf>(v));
+  v = dmax(v, dpp_keep_f64<0x118, 0xf>(v));
+  v = dmax(v, dpp_keep_f64<0x142, 0xa>(v));
+  v = dmax(v, dpp_keep_f64<0x143, 0xc>(v));
+  return v;
+}
 __device__ inline double readlane_f64(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, l);
@@ -1490,12 +1557,13 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     CompRec32 r32;
     r32.xx = (uint32_t)(rec.x0 & 0xffff) | ((uint32_t)(rec.x1 & 0xffff) << 16);
     r32.yy = (uint32_t)(rec.y0 & 0xffff) | ((uint32_t)(rec.y1 & 0xffff) << 16);
-    r32.ox = rec.ox; r32.oy = rec.oy; r32.pitch = rec.pitch; r32.slow = rec.pad;
-    r32.off = rec.off;
+    r32.base = rec.off + ((int64_t)rec.oy * rec.pitch + rec.ox);
+    r32.pitch_slow = (uint32_t)rec.pitch | ((uint32_t)(rec.pad ? 1 : 0) << 31);
     r32.te = (float)(rec.tau_one / cam_exposure);
     r32.kg[0] = (float)(rec.K[0] * rec.g); r32.kg[1] = (float)(rec.K[1] * rec.g); r32.kg[2] = (float)(rec.K[2] * rec.g);
     r32.zdist = rec.zdist;
-    r32.spare[0] = r32.spare[1] = 0;
+    r32.spare0 = 0;
+    r32.spare[0] = r32.spare[1] = r32.spare[2] = r32.spare[3] = 0;
     sc.comp32[gi] = r32;
   }
   sc.bbox[gi] = make_int4(rec.x0, rec.y0, rec.x1, rec.y1);
@@ -2690,7 +2758,7 @@ struct SmallItem {                  // what k_blur_small needs of a drop, all wa
   int li, r1, r2, tw, th, pw, ph, epitch, epad;
   long long a0, a1;
 };
-__global__ __launch_bounds__(256, 3) void k_blur_small(const FrameDesc* frames, int max_drops, Scratch sc) {
+__global__ __launch_bounds__(256, 4) void k_blur_small(const FrameDesc* frames, int max_drops, Scratch sc) {
   const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ __attribute__((aligned(16))) double Xs[4][BS_X], Ys[4][BS_Y];
   double* X = Xs[wave];
@@ -3272,6 +3340,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameDesc* frames, Dims
 // after every blend; a wave that finds anything else (NaN, out of range) among its pixels, and an entry whose factors are
 // not tame, take the literal float64 blend_pixel per pixel instead.  The composite leaves as floats (12 B per pixel).
 typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int TILE32_H = 32;
 // clamp(a * b + c, 0, 1) on both halves in one packed instruction (the compiler keeps the clamp as two extra instructions)
 __device__ inline float2_t pk_fma_clamp(float2_t a, float2_t b, float2_t c) {
@@ -3279,7 +3348,7 @@ __device__ inline float2_t pk_fma_clamp(float2_t a, float2_t b, float2_t c) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-template <int WPE>                  // waves per SIMD the register allocation is held to (RR_OPT_COMPOSITE_WAVES)
+template <int WPE, bool BATCH>      // WPE: waves per SIMD the register allocation is held to (RR_OPT_COMPOSITE_WAVES); BATCH: RR_OPT_COMPOSITE_BATCH
 __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int tiles_x,
                                                      int tiles_y, int ctiles_x, int nct, int64_t arena_cap, Scratch sc) {
   const int f = blockIdx.y;
@@ -3288,6 +3357,7 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
   if (tile >= ntiles) return;
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  PH_DECL
   const FrameDesc& fr = frames[f];
   const int tx0 = txi * TILE, ty0 = tyi * TILE32_H, tx1 = min(tx0 + TILE, dm.W), ty1 = min(ty0 + TILE32_H, dm.H);
   const int px = tx0 + 8 * (wave & 1) + (lane & 7);
@@ -3298,22 +3368,50 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
   double m0 = 0.0, m1 = 0.0;
   double sum_b = 0.0;
   bool ok_px = true;                 // every colour value of the lane's live pixels is in [0, 1]
+  // Everything the wave needs before its first blend is REQUESTED first and looked at afterwards (r05: the phase clocks gave
+  // a quarter of the kernel's wave time to this prologue when every load_px3 was waited for in turn): the first entry of the
+  // tile's list, the pixels of both images as raw words (a pixel outside the frame reads the tile's first pixel: no lane
+  // branches around a load), the scene depth, then the box of that first entry.
+  const int ct = (ty0 / CTILE) * ctiles_x + (tx0 / CTILE);
+  const uint16_t* clist = sc.clist + ((int64_t)f * nct + ct) * max_drops;
+  const int4* bbox = sc.bbox + (int64_t)f * max_drops;
+  const int i_first = imin((int)as_global(clist)[imin(t, max_drops - 1)], max_drops - 1);      // (past the list's end: any valid index)
+  const int64_t pq = (int64_t)ty0 * dm.W + tx0, pq0 = live0 ? pix0 : pq, pq1 = live1 ? pix1 : pq;
+  const int rk = rainy_kind(fr), bk = bg_kind(fr);
+  const bool same_bg = fr.bg == fr.rainy_bg;
+  RawPx qr0 = {0u, 0u, 0u, 0u, 0u, 0u}, qr1 = qr0, qb0 = qr0, qb1 = qr0;
+  load_px3_raw2(fr.rainy_bg, rk, pq0, pq1, qr0, qr1);
+  const int4 bb_first = bbox[i_first];
+  if (!same_bg) load_px3_raw2(fr.bg, bk, pq0, pq1, qb0, qb1);
+  double scene0 = 1.0e300, scene1 = 1.0e300;
+  if (fr.depth) {
+    if (fr.depth_f64) {
+      scene0 = as_global((const double*)fr.depth)[pq0];
+      scene1 = as_global((const double*)fr.depth)[pq1];
+    } else {
+      const float d0 = as_global((const float*)fr.depth)[pq0], d1 = as_global((const float*)fr.depth)[pq1];
+      scene0 = (double)d0;
+      scene1 = (double)d1;
+    }
+    scene0 = live0 ? scene0 : 1.0e300;
+    scene1 = live1 ? scene1 : 1.0e300;
+  }
   {
-    double in0[3] = {0, 0, 0}, in1[3] = {0, 0, 0};
-    const int rk = rainy_kind(fr);
-    if (live0) load_px3(fr.rainy_bg, rk, pix0, in0);
-    if (live1) load_px3(fr.rainy_bg, rk, pix1, in1);
-    if (fr.bg == fr.rainy_bg) {
+    double in0[3], in1[3];
+    decode_px3(qr0, rk, in0);
+    decode_px3(qr1, rk, in1);
+    if (!live0) in0[0] = in0[1] = in0[2] = 0.0;
+    if (!live1) in1[0] = in1[1] = in1[2] = 0.0;
+    if (same_bg) {
       sum_b = ((in0[0] + in0[1]) + in0[2]) + ((in1[0] + in1[1]) + in1[2]);
     } else {
-      const int bk = bg_kind(fr);
       double b[3];
       if (live0) {
-        load_px3(fr.bg, bk, pix0, b);
+        decode_px3(qb0, bk, b);
         sum_b = (b[0] + b[1]) + b[2];
       }
       if (live1) {
-        load_px3(fr.bg, bk, pix1, b);
+        decode_px3(qb1, bk, b);
         sum_b += (b[0] + b[1]) + b[2];
       }
     }
@@ -3330,32 +3428,26 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     c1 = float2_t{(float)in0[1], (float)in1[1]};
     c2 = float2_t{(float)in0[2], (float)in1[2]};
   }
-  double scene0 = 1.0e300, scene1 = 1.0e300;
-  if (fr.depth) {
-    if (live0) scene0 = fr.depth_f64 ? as_global((const double*)fr.depth)[pix0] : (double)as_global((const float*)fr.depth)[pix0];
-    if (live1) scene1 = fr.depth_f64 ? as_global((const double*)fr.depth)[pix1] : (double)as_global((const float*)fr.depth)[pix1];
-  }
   const bool has_depth = fr.depth != nullptr;
   const bool slow_wave = __ballot(!ok_px) != 0ull;
   const CompRec32* comp = sc.comp32 + (int64_t)f * max_drops;
   const CompRec* comp64 = sc.comp + (int64_t)f * max_drops;
-  const int4* bbox = sc.bbox + (int64_t)f * max_drops;
   const double* arena = sc.arena;
-  const int ct = (ty0 / CTILE) * ctiles_x + (tx0 / CTILE);
-  const uint16_t* clist = sc.clist + ((int64_t)f * nct + ct) * max_drops;
   const int n = sc.ccount[(int64_t)f * nct + ct];
   __shared__ int s_list[4][256];
   __shared__ int s_cnt[4][4];
   const int xm = tx0 + 8, ym = ty0 + 16;
   const float2_t one2 = {1.f, 1.f};
   const int64_t zero_at = (int64_t)f * arena_cap;                  // the frame's all-zero arena line (k_scan)
+  PH_WAITVM
+  PH(0)
   for (int base = 0; base < n; base += 256) {
     const int k = base + t;
     unsigned hitm = 0;
     int i = 0;
     if (k < n) {
-      i = clist[k];
-      const int4 bb = bbox[i];
+      i = base == 0 ? i_first : (int)clist[k];
+      const int4 bb = base == 0 ? bb_first : bbox[i];
       if (bb.x < tx1 && bb.z > tx0 && bb.y < ty1 && bb.w > ty0) {
         const unsigned xl = bb.x < xm, xr = bb.z > xm, yt = bb.y < ym, yb = bb.w > ym;
         hitm = (xl & yt) | ((xr & yt) << 1) | ((xl & yb) << 2) | ((xr & yb) << 3);
@@ -3365,7 +3457,9 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
 #pragma unroll
     for (int q = 0; q < 4; q++) bal[q] = __ballot((hitm >> q) & 1u);
     if (lane < 4) s_cnt[wave][lane] = __popcll(lane == 0 ? bal[0] : (lane == 1 ? bal[1] : (lane == 2 ? bal[2] : bal[3])));
+    PH(1)
     __syncthreads();
+    PH(2)
     int total = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -3378,9 +3472,104 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
       if ((hitm >> q) & 1u) s_list[q][off + __popcll(bal[q] & ((1ull << lane) - 1ull))] = i;
       if (q == wave) total = tq;
     }
+    PH(1)
     __syncthreads();
+    PH(2)
     const int* lst = s_list[wave];
     total = __builtin_amdgcn_readfirstlane(total);
+    if constexpr (BATCH) {
+    // r05: the records of up to 64 list entries at a time live in twelve VECTOR registers, lane j holding entry j's (three
+    // 16-byte loads per lane, all 64 records in flight at once), and an entry's fields reach the scalar registers by
+    // v_readlane when they are needed.  The entry loop then holds no scalar load and no LDS read: nothing in it waits on
+    // lgkmcnt (the scalar record fetch of the r04 loop, issued a step ahead, had to be complete at the top of the next
+    // step -- scalar loads return out of order, any wait on them is a wait for all), one record set is live instead of
+    // three, and the alpha samples run TWO entries ahead of the blend instead of one.
+    for (int sub = 0; sub < total; sub += 64) {
+      const int nb = imin(64, total - sub);
+      const int my = lst[sub + imin(lane, nb - 1)];               // this lane's entry: its drop
+      const auto rp = as_global(reinterpret_cast<const u32x4_t*>(comp + my));
+      const u32x4_t ra = rp[0], rb = rp[1], rc = rp[2];
+      PH_WAITVM
+      PH(3)
+      auto rl = [](uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); };
+      // the two samples of entry j (a pixel outside the footprint, and every pixel of an entry past the batch, reads the
+      // frame's zero line: the sample IS 0.0)
+      auto issue = [&](int j, double& An0, double& An1, int& inb) {
+        const int jj = imin(j, nb - 1);
+        const uint32_t xx = rl(ra.x, jj), yy = rl(ra.y, jj);
+        const int64_t bs = (int64_t)(((uint64_t)rl(ra.w, jj) << 32) | (uint64_t)rl(ra.z, jj));
+        const int pitch = (int)(rl(rb.x, jj) & 0x7fffffffu);
+        const int x0 = (int)(xx & 0xffffu), x1 = (int)(xx >> 16), y0 = (int)(yy & 0xffffu), y1 = (int)(yy >> 16);
+        const bool inx = (px >= x0) & (px < x1) & (j < nb);
+        const bool in0 = inx & live0 & (py0 >= y0) & (py0 < y1), in1 = inx & live1 & (py1 >= y0) & (py1 < y1);
+        const int64_t o0 = in0 ? bs + ((int64_t)py0 * pitch + px) : zero_at;
+        const int64_t o1 = in1 ? bs + ((int64_t)py1 * pitch + px) : zero_at;
+        An0 = arena[o0];
+        An1 = arena[o1];
+        inb = (in0 ? 1 : 0) | (in1 ? 2 : 0);
+      };
+      auto blend = [&](int j, double Acur0, double Acur1, int inb) {
+        const float te = __uint_as_float(rl(rb.y, j)), k0 = __uint_as_float(rl(rb.z, j)), k1 = __uint_as_float(rl(rb.w, j)),
+                    k2 = __uint_as_float(rl(rc.x, j));
+        const bool slow = (rl(rb.x, j) >> 31) != 0u;
+        bool v0 = (inb & 1) != 0, v1 = (inb & 2) != 0;
+        double A0 = Acur0, A1 = Acur1;                            // (0.0 outside the footprint)
+        if (has_depth) {                                          // depth-occlusion option: hidden where the drop is behind the scene
+          const double z = __hiloint2double((int)rl(rc.w, j), (int)rl(rc.z, j));
+          v0 = v0 && !(z > scene0);
+          v1 = v1 && !(z > scene1);
+          A0 = v0 ? Acur0 : 0.0;
+          A1 = v1 ? Acur1 : 0.0;
+        }
+        if (slow_wave | slow) {                                   // (wave-uniform) literal float64 blend, pixel by pixel
+          const const_ptr<CompRec> r64 = as_constant(comp64) + __builtin_amdgcn_readlane(my, j);
+          const double K[3] = {r64->K[0], r64->K[1], r64->K[2]};
+          const double tau = r64->tau_one, g = r64->g;
+          if (v0) {
+            double c[3] = {(double)c0.x, (double)c1.x, (double)c2.x};
+            blend_pixel(Acur0, tau, cam.exposure_s, g, K, c, m0);
+            c0.x = (float)c[0]; c1.x = (float)c[1]; c2.x = (float)c[2];
+          }
+          if (v1) {
+            double c[3] = {(double)c0.y, (double)c1.y, (double)c2.y};
+            blend_pixel(Acur1, tau, cam.exposure_s, g, K, c, m1);
+            c0.y = (float)c[0]; c1.y = (float)c[1]; c2.y = (float)c[2];
+          }
+        } else {
+          const float2_t Af = {(float)A0, (float)A1};
+          const float2_t u = __builtin_elementwise_fma(Af, float2_t{-te, -te}, one2);        // 1 - A te
+          c0 = pk_fma_clamp(u, c0, Af * k0);                      // clamp((1 - A te) c + A kg, 0, 1)
+          c1 = pk_fma_clamp(u, c1, Af * k1);
+          c2 = pk_fma_clamp(u, c2, Af * k2);
+          m0 = m0 + A0;                                           // (+ 0.0 outside the footprint: the mask keeps its bits)
+          m1 = m1 + A1;
+        }
+      };
+      double A00, A01, A10, A11, A20, A21;
+      int b0, b1, b2;
+      issue(0, A00, A01, b0);
+      issue(1, A10, A11, b1);
+      // Whole triples in a loop without an early exit (a `break` between the steps becomes, after the compiler has
+      // structurised the loop, an edge from the middle of the body back to its header -- never taken, but the wait-count
+      // pass then opens EVERY iteration with vmcnt(0): the r04 loop had that wait), the last one or two entries behind it.
+      // Every step issues exactly two loads: the counts are static.
+      int e = 0;
+      for (; e + 3 <= nb; e += 3) {
+        issue(e + 2, A20, A21, b2);
+        blend(e, A00, A01, b0);
+        issue(e + 3, A00, A01, b0);
+        blend(e + 1, A10, A11, b1);
+        issue(e + 4, A10, A11, b1);
+        blend(e + 2, A20, A21, b2);
+      }
+      if (e < nb) blend(e, A00, A01, b0);
+      if (e + 1 < nb) blend(e + 1, A10, A11, b1);
+      // the (zero-line) samples requested past the batch's end are waited for here: a load left in flight would make the
+      // compiler open the next batch's loop with vmcnt(0) on every iteration (it cannot place the stray load in the queue)
+      asm volatile("" ::"v"(A00), "v"(A01), "v"(A10), "v"(A11));
+      PH(4)
+    }
+    } else {
     struct RecS {
       uint32_t xx, yy;
       int ox, oy, pitch, slow;
@@ -3390,7 +3579,8 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     };
     auto fetch = [&](int idx) {
       const const_ptr<CompRec32> r = as_constant(comp) + __builtin_amdgcn_readfirstlane(idx);
-      RecS o{r->xx, r->yy, r->ox, r->oy, r->pitch, r->slow, (long long)r->off, r->te, r->kg[0], r->kg[1], r->kg[2], r->zdist};
+      const uint32_t ps = r->pitch_slow;
+      RecS o{r->xx, r->yy, 0, 0, (int)(ps & 0x7fffffffu), (int)(ps >> 31), (long long)r->base, r->te, r->kg[0], r->kg[1], r->kg[2], r->zdist};
       return o;
     };
     // Three stages, as in k_composite: entry e is blended while the samples of entry e + 1 are in flight and the record of
@@ -3469,7 +3659,10 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
         step(e + 2, R2, A20, A21, in2 | (id2 << 2), R0, A00, A01, in0, R1, i_nn, id1);
       }
     }
+    }
+    PH(4)
     __syncthreads();
+    PH(5)
   }
   // The composite before the mean shift goes to the library's scratch (this compositor only runs when no caller wants it):
   // as three floats per pixel, or (r05, RR_OPT_COMPOSITE_U16, default) as three 16-bit codes -- half the bytes here and in
@@ -3480,9 +3673,8 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
   const bool c16 = fr.comp_f32 == 2;
   double sum_c = 0.0;
   if (live0) {
-    if (c16) {
-      const global_ptr<uint16_t> o = as_global(reinterpret_cast<uint16_t*>(fr.comp_out)) + pix0 * 3;
-      o[0] = (uint16_t)code16(c0.x); o[1] = (uint16_t)code16(c1.x); o[2] = (uint16_t)code16(c2.x);
+    if (c16) {                                                    // four 16-bit words per pixel (the fourth is 0): one 8-byte store
+      as_global(reinterpret_cast<u32x2_t*>(fr.comp_out))[pix0] = u32x2_t{code16(c0.x) | (code16(c1.x) << 16), code16(c2.x)};
     } else {
       const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix0 * 3;
       o[0] = c0.x; o[1] = c1.x; o[2] = c2.x;
@@ -3493,8 +3685,7 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
   }
   if (live1) {
     if (c16) {
-      const global_ptr<uint16_t> o = as_global(reinterpret_cast<uint16_t*>(fr.comp_out)) + pix1 * 3;
-      o[0] = (uint16_t)code16(c0.y); o[1] = (uint16_t)code16(c1.y); o[2] = (uint16_t)code16(c2.y);
+      as_global(reinterpret_cast<u32x2_t*>(fr.comp_out))[pix1] = u32x2_t{code16(c0.y) | (code16(c1.y) << 16), code16(c2.y)};
     } else {
       const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix1 * 3;
       o[0] = c0.y; o[1] = c1.y; o[2] = c2.y;
@@ -3503,20 +3694,25 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     if (fr.mask_i32) as_global(fr.mask_i32)[pix1] = (int32_t)floor(m1 * 255.0);
     sum_c += ((double)c0.y + (double)c1.y) + (double)c2.y;
   }
-  __shared__ double ra[256], rb[256], rlo[256], rhi[256];
-  ra[t] = sum_c;
-  rb[t] = sum_b;
-  rlo[t] = dmin(live0 ? m0 : 1.0e300, live1 ? m1 : 1.0e300);
-  rhi[t] = dmax(live0 ? m0 : -1.0e300, live1 ? m1 : -1.0e300);
+  // the tile's four numbers: inside a wave by DPP (no LDS, no barrier), across the four waves through 16 doubles of LDS
+  // and ONE barrier (r04: a 256-entry LDS tree with nine)
+  const double wa = readlane_f64(wave_incl_scan_f64(sum_c), 63), wb = readlane_f64(wave_incl_scan_f64(sum_b), 63);
+  const double wlo = readlane_f64(wave_min_scan_f64(dmin(live0 ? m0 : 1.0e300, live1 ? m1 : 1.0e300)), 63);
+  const double whi = readlane_f64(wave_max_scan_f64(dmax(live0 ? m0 : -1.0e300, live1 ? m1 : -1.0e300)), 63);
+  __shared__ double s_red[4][4];
+  if (lane == 0) {
+    s_red[wave][0] = wa;
+    s_red[wave][1] = wb;
+    s_red[wave][2] = wlo;
+    s_red[wave][3] = whi;
+  }
   __syncthreads();
-  for (int ofs = 128; ofs > 0; ofs >>= 1) {
-    if (t < ofs) {
-      ra[t] += ra[t + ofs];
-      rb[t] += rb[t + ofs];
-      rlo[t] = dmin(rlo[t], rlo[t + ofs]);
-      rhi[t] = dmax(rhi[t], rhi[t + ofs]);
-    }
-    __syncthreads();
+  double ra[1], rb[1], rlo[1], rhi[1];
+  if (t == 0) {
+    ra[0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+    rb[0] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+    rlo[0] = dmin(dmin(s_red[0][2], s_red[1][2]), dmin(s_red[2][2], s_red[3][2]));
+    rhi[0] = dmax(dmax(s_red[0][3], s_red[1][3]), dmax(s_red[2][3], s_red[3][3]));
   }
   if (t == 0) {
     double* part = sc.partial + ((int64_t)f * tiles_x * tiles_y + tile) * 4;
@@ -3525,6 +3721,8 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     part[2] = rlo[0];
     part[3] = rhi[0];
   }
+  PH(6)
+  PH_FLUSH(4)
 }
 
 __global__ __launch_bounds__(256) void k_means(Dims dm, int ntiles, Scratch sc) {
@@ -3574,19 +3772,16 @@ __global__ __launch_bounds__(256) void k_finalize16(const FrameDesc* frames, Dim
   if (pix0 >= npix) return;
   const FrameDesc& fr = frames[f];
   const double diff = sc.means[f * 4 + 0] - sc.means[f * 4 + 1];
-  const global_ptr<const uint16_t> s = as_global(reinterpret_cast<const uint16_t*>(fr.comp_out)) + pix0 * 3;
+  const global_ptr<const u32x2_t> s = as_global(reinterpret_cast<const u32x2_t*>(fr.comp_out)) + pix0;      // a coded pixel: c0 | c1 << 16, c2
   const global_ptr<uint8_t> o = as_global(fr.rgb) + pix0 * 3;
   const int cnt = (int)(npix - pix0 < 4 ? npix - pix0 : 4);
   uint32_t q[12];
-  if (cnt == 4) {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const global_ptr<const u32x2> s2 = reinterpret_cast<global_ptr<const u32x2>>(s);       // (24 * group bytes into the frame's composite: 8-byte aligned)
-    const u32x2 a = s2[0], b = s2[1], c = s2[2];
-    const uint32_t w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+  {
+    u32x2_t w[4];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { q[2 * k] = w[k] & 0xffffu; q[2 * k + 1] = w[k] >> 16; }
-  } else {
-    for (int k = 0; k < 12; k++) q[k] = k < 3 * cnt ? (uint32_t)s[k] : 0u;
+    for (int k = 0; k < 4; k++) w[k] = s[k < cnt ? k : 0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { q[3 * k] = w[k].x & 0xffffu; q[3 * k + 1] = w[k].x >> 16; q[3 * k + 2] = w[k].y & 0xffffu; }
   }
   uint32_t out[3] = {0u, 0u, 0u};                  // 12 bytes: R G B of four pixels
 #pragma unroll
@@ -3630,8 +3825,8 @@ __global__ __launch_bounds__(256) void k_finalize(const FrameDesc* frames, Dims 
   const global_ptr<uint8_t> o = as_global(fr.rgb) + pix * 3;
   double c[3];
   if (fr.comp_f32 == 2) {                          // 16-bit codes (k_composite32): 65535 = the pixel's own rainy_bg value
-    const global_ptr<const uint16_t> s = as_global(reinterpret_cast<const uint16_t*>(fr.comp_out)) + pix * 3;
-    const uint32_t q0 = s[0], q1 = s[1], q2 = s[2];
+    const u32x2_t w = as_global(reinterpret_cast<const u32x2_t*>(fr.comp_out))[pix];
+    const uint32_t q0 = w.x & 0xffffu, q1 = w.x >> 16, q2 = w.y & 0xffffu;
     c[0] = (double)q0 * (1.0 / 65534.0); c[1] = (double)q1 * (1.0 / 65534.0); c[2] = (double)q2 * (1.0 / 65534.0);
     if (q0 == 65535u || q1 == 65535u || q2 == 65535u) {
       double in[3];
@@ -4183,7 +4378,8 @@ struct rr_ctx {
   bool composite_u16 = true;         // RR_OPT_COMPOSITE_U16
   bool blur_dma = true;              // RR_OPT_BLUR_DMA
   int fov_dda = 1;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (1: k_fov_dda, 2: k_fov_walk)
-  int comp_waves = 6;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (6, 7 or 8)
+  int comp_waves = 0;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (0: the kernel's own choice)
+  bool comp_batch = true;            // RR_OPT_COMPOSITE_BATCH: list entries' records 64 at a time in vector registers, samples two entries ahead
   int n_tex = 0;
   float* d_ctab = nullptr;
   // particle generator (rr_set_particle_tables / rr_generate_drops_device)
@@ -4807,12 +5003,14 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     ntiles_c = tiles_x * tiles_y32;
     ProfScope ps(ctx, s, "k_composite");
     const dim3 grid(((ntiles_c + 7) / 8) * 8, n);
-    if (ctx->comp_waves == 8)
-      hipLaunchKernelGGL(k_composite32<8>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x, nct, ctx->arena_cap, sc);
-    else if (ctx->comp_waves == 7)
-      hipLaunchKernelGGL(k_composite32<7>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x, nct, ctx->arena_cap, sc);
-    else
-      hipLaunchKernelGGL(k_composite32<6>, grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x, nct, ctx->arena_cap, sc);
+#define RR_COMP32(W, B) hipLaunchKernelGGL((k_composite32<W, B>), grid, dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y32, ctiles_x, nct, ctx->arena_cap, sc)
+    const int cw = ctx->comp_waves ? ctx->comp_waves : (ctx->comp_batch ? 5 : 6);
+    if (ctx->comp_batch) {
+      if (cw == 8) RR_COMP32(8, true); else if (cw == 7) RR_COMP32(7, true); else if (cw == 6) RR_COMP32(6, true); else if (cw == 5) RR_COMP32(5, true); else RR_COMP32(4, true);
+    } else {
+      if (cw == 8) RR_COMP32(8, false); else if (cw == 7) RR_COMP32(7, false); else RR_COMP32(6, false);
+    }
+#undef RR_COMP32
   } else {
     ProfScope ps(ctx, s, "k_composite");
     hipLaunchKernelGGL(k_composite, dim3(((ntiles + 7) / 8) * 8, n), dim3(256), 0, s, ctx->d_frames, dm, ctx->cam, D, tiles_x, tiles_y, ctiles_x, nct,
@@ -6212,9 +6410,10 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_WILD_PIXELS: ctx->wild_pixels = value != 0; return RR_OK;
     case RR_OPT_PNG_DEFLATE: ctx->png_deflate = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_WAVES:
-      if (value != 0 && value != 6 && value != 7 && value != 8) break;
-      ctx->comp_waves = value ? value : 6;
+      if (value != 0 && (value < 4 || value > 8)) break;
+      ctx->comp_waves = value;
       return RR_OK;
+    case RR_OPT_COMPOSITE_BATCH: ctx->comp_batch = value != 0; return RR_OK;
     case RR_OPT_FOV_F32:
       if (value < 0 || value > 2) break;
       ctx->fov_f32 = value;

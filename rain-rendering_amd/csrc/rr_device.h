@@ -75,20 +75,21 @@ struct CompRec {
   double zdist;              // distance of the drop from the camera, |world z| (depth-occlusion option only)
 };
 
-// The same record for the float-colour compositor (k_composite32): 64 bytes = one scalar 16-dword load.  The alpha
-// path (footprint, tile address) is unchanged; the colour factors are pre-multiplied and rounded to float:
+// The same record for the float-colour compositor (k_composite32): 64 bytes, of which the kernel reads the first 48 as three
+// 16-byte words.  The tile address is folded: sample (px, py) of the frame is arena[base + py * pitch + px]
+// (base = off + oy * pitch + ox of CompRec); the colour factors are pre-multiplied and rounded to float:
 //   te = tau_one / exposure, kg[c] = K[c] * g   (blend: c' = clamp((1 - A te) c + A kg))
 struct CompRec32 {
   uint32_t xx;               // x0 | x1 << 16  (footprint, exclusive upper bounds; empty if x1 <= x0)
   uint32_t yy;               // y0 | y1 << 16
-  int32_t ox, oy;            // tile_x = px + ox, tile_y = py + oy
-  int32_t pitch;
-  int32_t slow;              // 1: a factor is not tame (or the tile is the caller's): the literal double blend
-  int64_t off;               // arena offset of the finished tile
+  int64_t base;              // arena index of the sample under frame pixel (0, 0)
+  uint32_t pitch_slow;       // pitch | slow << 31; slow: a factor is not tame (or the tile is the caller's): the literal double blend
   float te, kg[3];
+  int32_t spare0;
   double zdist;
-  int32_t spare[2];
+  int32_t spare[4];
 };
+static_assert(sizeof(CompRec32) == 64, "CompRec32 is read as 16-byte words");
 
 // ---------------------------------------------------------------------------
 // small helpers

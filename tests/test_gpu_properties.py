@@ -254,7 +254,8 @@ def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path
 
 def test_composite_codes_and_blur_prefetch(setup):
     """r05 tuning switches of the float-colour route.  RR_OPT_BLUR_DMA (the fused blur's sub-tiles staged a sub-tile ahead by
-    LDS-DMA loads) and RR_OPT_BIN_ROWS (how the ordered per-tile drop lists are made) change no bit.  RR_OPT_COMPOSITE_U16 (the composite before the mean shift as 16-bit codes
+    LDS-DMA loads), RR_OPT_BIN_ROWS (how the ordered per-tile drop lists are made) and RR_OPT_COMPOSITE_BATCH (how the
+    compositor gets at its list entries' records) change no bit.  RR_OPT_COMPOSITE_U16 (the composite before the mean shift as 16-bit codes
     instead of floats) keeps mask and statuses and moves the uint8 image by at most 1 LSB on a few pixels in a thousand;
     values outside [0, 1] -- a pixel no drop was blended into -- go through the code 65535 and come out as
     before."""
@@ -267,7 +268,7 @@ def test_composite_codes_and_blur_prefetch(setup):
     wild[310:320, 40:50] = 0.0
     frw = dict(fr, bg=wild, rainy_bg=wild)
     ref = rh.render_frames([fr, frw], want_composite=False)
-    for opt in (h.hb.RR_OPT_BLUR_DMA, h.hb.RR_OPT_BIN_ROWS, h.hb.RR_OPT_COMPOSITE_U16):
+    for opt in (h.hb.RR_OPT_BLUR_DMA, h.hb.RR_OPT_BIN_ROWS, h.hb.RR_OPT_COMPOSITE_BATCH, h.hb.RR_OPT_COMPOSITE_U16):
         rh.set_option(opt, 0)
         try:
             alt = rh.render_frames([fr, frw], want_composite=False)
@@ -283,6 +284,31 @@ def test_composite_codes_and_blur_prefetch(setup):
                 assert d.max() <= 1 and (d != 0).mean() < 4e-3, (d.max(), (d != 0).mean())
     # the coded composite against the float64 compositor and the host build (the 1-LSB bar of BASELINE.json)
     assert np.abs(ref[0]['image_u8'].astype(int) - base['image_u8'].astype(int)).max() <= 1
+
+
+def test_compositor_record_batches(setup):
+    """The float compositor holds the records of 64 list entries at a time (RR_OPT_COMPOSITE_BATCH) and takes a coarse tile's
+    list in pieces of 256.  A frame whose drops are 100 streaks repeated 80 times makes every list that is not empty longer
+    than a batch and many longer than a piece: same bits as the entry-at-a-time compositor at every register allocation,
+    and the mask of the float64 compositor."""
+    sc, bg, env, drops, rh, base = setup
+    dense = np.concatenate([drops[:100]] * 80)
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=dense)
+    ref = rh.render_frames([fr], want_composite=False)[0]
+    f64 = rh.render_frames([fr])[0]
+    assert np.array_equal(ref['mask'], f64['mask']) and np.array_equal(ref['status'], f64['status'])
+    assert np.abs(ref['image_u8'].astype(int) - f64['image_u8'].astype(int)).max() <= 1
+    assert ref['mask'].max() > 40.0                                       # (80 copies of a streak on top of each other)
+    for batch, waves in ((0, 0), (0, 8), (1, 4), (1, 6), (1, 8)):
+        rh.set_option(h.hb.RR_OPT_COMPOSITE_BATCH, batch)
+        rh.set_option(h.hb.RR_OPT_COMPOSITE_WAVES, waves)
+        try:
+            alt = rh.render_frames([fr], want_composite=False)[0]
+        finally:
+            rh.set_option(h.hb.RR_OPT_COMPOSITE_BATCH, 1)
+            rh.set_option(h.hb.RR_OPT_COMPOSITE_WAVES, 0)
+        for k in ('status', 'mask', 'mask_i32', 'image_u8'):
+            assert np.array_equal(ref[k], alt[k]), (batch, waves, k)
 
 
 def test_opencv_fill_rule_option(setup):
