@@ -213,7 +213,7 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
             out = tempfile.mkdtemp(prefix='rainpmc_', dir='/tmp')
             cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
                    os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1', '--batch', str(args.batch),
-                   '--workload', args.workload, '--input-dtype', args.input_dtype] + sum((['--opt', o] for o in args.opt), [])
+                   '--workload', args.workload, '--input-dtype', args.input_dtype] + sum((['--opt', o] for o in args.opt), []) + ['--opt', '21=0']      # (counters per kernel: every kernel alone on the device)
             if scene_dir:
                 cmd += ['--scene-dir', scene_dir]                   # the simulation this process already wrote
             env = dict(os.environ, TMPDIR='/tmp')
@@ -259,7 +259,7 @@ def measure_valu(args, scene_dir=None):
         out = tempfile.mkdtemp(prefix='rainpmc_', dir='/tmp')
         cmd = [exe, '--kernel-trace', '--pmc', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE',
                '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__), '--inner', '--steps', '2', '--warmup', '1',
-               '--batch', str(args.batch), '--workload', args.workload, '--input-dtype', args.input_dtype] + sum((['--opt', o] for o in args.opt), [])
+               '--batch', str(args.batch), '--workload', args.workload, '--input-dtype', args.input_dtype] + sum((['--opt', o] for o in args.opt), []) + ['--opt', '21=0']      # (counters per kernel: every kernel alone on the device)
         if scene_dir:
             cmd += ['--scene-dir', scene_dir]
         proc = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
@@ -411,6 +411,7 @@ def main():
     ap.add_argument('--sweep', action='append', default=[], help='A/B: after the headline, time the loop again under these '
                     'rr_set_option sets ("6=3,3=512"); one JSON line each on stderr; implies the lean run')
     ap.add_argument('--scene-dir', default=None, help='(used by the PMC passes) directory of a simulation to reuse')
+    ap.add_argument('--no-serial', action='store_true', help='skip the extra pass with the colour branch on the main stream (per-kernel durations without overlap)')
     ap.add_argument('--phases', action='store_true', help='(phase-clock build of the library) print the per-phase wave cycles')
     ap.add_argument('--inner', action='store_true', help='(used by the PMC passes) timed loop only, no extras, no JSON')
     args = ap.parse_args()
@@ -553,7 +554,21 @@ def main():
             rh.profile(False)
             line(spec, el, rh.profile_read())
             for k, v in pairs:
-                rh.set_option(int(k), {1: 1, 9: 1, 10: 2, 12: 1, 16: 1, 17: 1, 19: 1, 20: 1}.get(int(k), 0))  # back to the option's default
+                rh.set_option(int(k), {1: 1, 9: 1, 10: 2, 12: 1, 16: 1, 17: 1, 19: 1, 20: 1, 21: 1}.get(int(k), 0))  # back to the option's default
+        warm(render, 1)
+    # The colour branch runs on the library's second stream (RR_OPT_COLOUR_STREAM, default): the event pairs around ITS kernels
+    # then span the time they waited for room beside the other stream's kernels, not their cost.  One more pass of the same
+    # step with everything on one in-order stream gives every kernel's own duration (and what the overlap is worth).
+    stats_serial, elapsed_serial = None, None
+    if rank == 0 and world == 1 and not args.no_serial and hasattr(hb, 'RR_OPT_COLOUR_STREAM'):
+        rh.set_option(hb.RR_OPT_COLOUR_STREAM, 0)
+        warm(render, 1)
+        rh.profile_reset()
+        rh.profile(True)
+        elapsed_serial = timed(torch, dist, world, dev, render, args.steps)
+        rh.profile(False)
+        stats_serial = rh.profile_read()
+        rh.set_option(hb.RR_OPT_COLOUR_STREAM, 1)
         warm(render, 1)
     nb = min(B, batch.n)
     cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)
@@ -788,15 +803,19 @@ def main():
         frames_step = args.total_frames if strong else B * world
         fps = frames_step * args.steps / elapsed
         per_launch = {k: v[1] / v[0] for k, v in stats.items()}
-        dom_name = max(per_launch, key=per_launch.get)
-        avg_ms = per_launch[dom_name]
+        COLOUR = ('k_fov_spans', 'k_fov_sums', 'k_fov_poly', 'k_env_prefix', 'k_fov_sums_general')      # launched on the second stream
+        overlapped = {k: v for k, v in per_launch.items() if k in COLOUR} if stats_serial is not None else {}
+        per_main = {k: v for k, v in per_launch.items() if k not in overlapped}
+        dom_name = max(per_main, key=per_main.get)
+        avg_ms = per_main[dom_name]
+        per_serial = {k: v[1] / v[0] for k, v in stats_serial.items()} if stats_serial is not None else None
         alg = algorithmic_bytes(H, W, He, We, batch.mean_drops) * nb
         achieved = alg / (avg_ms * 1e-3) / 1e9
         traffic, traffic_how = None, "not measured (--no-traffic, N>1 or strong scaling)"
         if single and not args.no_traffic and not strong:
             parts = {'k_env_prefix': ['k_env_prefix', 'k_env_consts']}.get(dom_name, [dom_name])
             traffic, traffic_how = measure_traffic(args, parts, scene_dir=tmp)
-        chain_ms = sum(per_launch.values())
+        chain_ms = sum((per_serial or per_launch).values())         # every kernel's own duration: the one-stream pass when there is one
         compute = None
         if not is_sim and not strong:
             try:                       # float64 operation model of the blur kernels (the dominant ones), a few frames scaled to the call
@@ -866,7 +885,15 @@ def main():
                                        "average launch time of the slowest kernel of the chain (HIP events on the launch stream)"},
             "chain": {"ms_per_call_sum_of_kernels": chain_ms, "algorithmic_GBps": alg / (chain_ms * 1e-3) / 1e9,
                       "frac_of_hbm_peak": alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "kernels_ms_per_call": {k: v for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
+            "kernels_ms_per_call": {k: v for k, v in sorted(per_main.items(), key=lambda kv: -kv[1])},
+            "overlap": None if per_serial is None else {
+                "what": "the colour branch (FOV polygons, spans, sums over the environment map) runs on a second stream beside plan .. tiles .. blur "
+                        "(RR_OPT_COLOUR_STREAM).  kernels_ms_per_call: the first stream's kernels in the timed region; colour_branch_ms_between_events: "
+                        "the second stream's kernels between their event pairs -- including the time their workgroups waited for room on the "
+                        "CUs, not a cost; kernels_ms_per_call_one_stream: the same step with the option off, every kernel alone on the device",
+                "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_one_stream": 1e3 * elapsed_serial / args.steps,
+                "colour_branch_ms_between_events": {k: v for k, v in sorted(overlapped.items(), key=lambda kv: -kv[1])},
+                "kernels_ms_per_call_one_stream": {k: v for k, v in sorted(per_serial.items(), key=lambda kv: -kv[1])}},
             "valu": {"what": valu_how, "dominant_kernel": (valu or {}).get(dom_name, {}).get("valu_util") if valu else None,
                      "per_kernel": {k: {"valu_util": round(v["valu_util"], 4), "waiting": round(v["waiting"], 4) if v["waiting"] is not None else None}
                                     for k, v in sorted((valu or {}).items(), key=lambda kv: -kv[1]["valu_util"])} if valu else None},

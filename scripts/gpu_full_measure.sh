@@ -16,12 +16,15 @@
 #     7. host CPU scaling probe (deflate threads)               -> <tag>_cpuscale.txt
 TAG=${1:-full}; PART=${2:-a}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out; mkdir -p $OUT
+OUT=$REPO/gpurun_out; mkdir -p $OUT $OUT/pmc_$TAG
 cd $REPO
 if [ "$PART" = "a" ]; then
   timeout -k 10 1200 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_tests.log 2>&1; echo "tests exit $?"; tail -3 $OUT/${TAG}_gpu_tests.log
   timeout -k 10 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; echo "bench exit $?"; tail -c 300 $OUT/${TAG}_bench_default.json
-  timeout -k 10 1500 scripts/gpu_pmc.sh $TAG "" "FETCH_SIZE" "WRITE_SIZE" \
+  # kernel stats of the default step (colour branch on the second stream: its kernels' durations include waiting for room) ...
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pmc_$TAG/stats_overlap -- python $REPO/bench.py --steps 3 --warmup 1 --inner > $OUT/pmc_$TAG.overlap.log 2>&1); echo "stats (overlap) exit $?"
+  # ... and stats + counters with everything on one stream (RR_OPT_COLOUR_STREAM 0): every kernel alone on the device
+  timeout -k 10 1500 scripts/gpu_pmc.sh $TAG "--opt 21=0" "FETCH_SIZE" "WRITE_SIZE" \
     "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
     "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
     "TCC_HIT_sum TCC_MISS_sum" > $OUT/pmc_$TAG.txt 2>&1; echo "pmc exit $?"; grep -A12 "== pmc" $OUT/pmc_$TAG.txt | cut -c1-300
