@@ -4823,6 +4823,20 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       HIPCHK(hipStreamWaitEvent(ctx->s_col, ctx->ev_fork, 0));
       cs = ctx->s_col;
     }
+    // (whatever way this block is left -- an error return included -- the caller's stream waits for the second one: a
+    // synchronisation of `s` then covers everything that was enqueued here)
+    struct Join {
+      rr_ctx* c;
+      hipStream_t s, cs;
+      bool open;
+      hipError_t now() {
+        if (!open) return hipSuccess;
+        open = false;
+        hipError_t e = hipEventRecord(c->ev_join, cs);
+        return e != hipSuccess ? e : hipStreamWaitEvent(s, c->ev_join, 0);
+      }
+      ~Join() { (void)now(); }
+    } join{ctx, s, cs, cs != s};
     const int Hp = ctx->scratch_hp, Dp = (D + 1 + 7) & ~7;
     if (fast) {
       ProfScope ps(ctx, cs, "k_fov_spans");
@@ -4992,10 +5006,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_blur_cols");
       hipLaunchKernelGGL(k_blur<1>, dim3(256, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
-    if (cs != s) {                                         // the colour branch joins: k_colour needs its sums and the plan / scan
-      HIPCHK(hipEventRecord(ctx->ev_join, cs));
-      HIPCHK(hipStreamWaitEvent(s, ctx->ev_join, 0));
-    }
+    HIPCHK(join.now());                                    // the colour branch joins: k_colour needs its sums and the plan / scan
     {
       ProfScope ps(ctx, s, "k_colour");
       hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
