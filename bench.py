@@ -231,7 +231,7 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
             for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
                 for row in csv.DictReader(open(f)):
                     m = re.search(r'(k_[a-z_0-9]+)', row.get('Kernel_Name', ''))
-                    if m and m.group(1) in dom_kernels and row['Counter_Name'] == counter:
+                    if m and (m.group(1) in dom_kernels or scope_of(m.group(1)) in dom_kernels) and row['Counter_Name'] == counter:
                         tot += float(row['Counter_Value'])
                         cnt += 1
             shutil.rmtree(out, ignore_errors=True)
@@ -242,6 +242,15 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
                 "(2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per launch, two rocprofv3 --pmc passes of this workload spawned by bench.py")
     except Exception as e:                                          # noqa: BLE001 -- reported, never fatal
         return None, "pmc pass failed: %r" % (e,)
+
+
+# kernel symbol -> the name of the timing scope (rr_profile_read) it is launched under
+SCOPE_OF = {'k_blur_fused_dma': 'k_blur_fused', 'k_composite32': 'k_composite', 'k_fov_sums32': 'k_fov_sums', 'k_fov_dda': 'k_fov_spans',
+            'k_fov_walk': 'k_fov_spans', 'k_finalize16': 'k_finalize', 'k_bin_rows': 'k_bin', 'k_env_consts': 'k_env_prefix'}
+
+
+def scope_of(kernel):
+    return SCOPE_OF.get(kernel, kernel)
 
 
 def measure_valu(args, scene_dir=None):
@@ -846,10 +855,11 @@ def main():
         # float64 vector rate (operation model for the blur kernels, else the PMC pass' issue-slot share)
         hbm_frac = ((traffic if traffic else alg) / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if (traffic and dom_name) else achieved / HBM_PEAK_GBS
         valu_frac = None
+        dom_valu = next((v for k, v in (valu or {}).items() if scope_of(k) == dom_name), None)      # (the longest-running kernel of the scope comes first)
         if compute and dom_name in (compute.get("kernels") or {}):
             valu_frac = compute["kernels"][dom_name]["frac_of_rate_without_fma"]
-        elif valu and dom_name in valu:
-            valu_frac = valu[dom_name]["valu_util"]
+        elif valu and dom_valu:
+            valu_frac = dom_valu["valu_util"]
         nearest = "hbm" if (valu_frac is None or (traffic and hbm_frac >= valu_frac)) else "valu-f64"
         # neither roof within a factor of two: what bounds the kernel is the latency of its dependent memory / LDS phases at the
         # occupancy its registers and LDS tiles allow -- say so instead of naming a roof it is far from
@@ -894,7 +904,7 @@ def main():
                 "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_one_stream": 1e3 * elapsed_serial / args.steps,
                 "colour_branch_ms_between_events": {k: v for k, v in sorted(overlapped.items(), key=lambda kv: -kv[1])},
                 "kernels_ms_per_call_one_stream": {k: v for k, v in sorted(per_serial.items(), key=lambda kv: -kv[1])}},
-            "valu": {"what": valu_how, "dominant_kernel": (valu or {}).get(dom_name, {}).get("valu_util") if valu else None,
+            "valu": {"what": valu_how, "dominant_kernel": dom_valu["valu_util"] if dom_valu else None,
                      "per_kernel": {k: {"valu_util": round(v["valu_util"], 4), "waiting": round(v["waiting"], 4) if v["waiting"] is not None else None}
                                     for k, v in sorted((valu or {}).items(), key=lambda kv: -kv[1]["valu_util"])} if valu else None},
         }

@@ -398,9 +398,9 @@ enum {
                                      * keeps its scanlines (first byte = a filter type, never 'R').  rr_png_write_scanlines /
                                      * rr_io_write_frames take either form.  Default 0 (scanlines). */
   RR_OPT_COMPOSITE_U16 = 16,        /* tuning (r05): 1 (default) the float compositor leaves the composite before the mean shift in the
-                                     * library's scratch as three 16-bit codes per pixel (rint(v * 65534); 65535 = "outside [0, 1]:
+                                     * library's scratch as three 16-bit codes in one 8-byte word per pixel (rint(v * 65534); 65535 = "outside [0, 1]:
                                      * take the pixel's own rainy_bg value", which is then what the composite holds) instead of three
-                                     * floats: half the bytes written there and read back by the final pass.  The code is 2^-17 off at
+                                     * floats: one store per pixel, two thirds of the bytes written there and read back by the final pass.  The code is 2^-17 off at
                                      * most (an LSB of rainy_image is 2^-8): the image contract (+-1 LSB) holds, the mask never sees it.
                                      * Ignored with RR_OPT_WILD_PIXELS, and whenever a caller asks for the composite itself. */
   RR_OPT_BLUR_DMA = 17,             /* tuning (r05): 1 (default) the fused defocus blur stages its raw sub-tiles and weight tables with

@@ -3668,7 +3668,7 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     PH(5)
   }
   // The composite before the mean shift goes to the library's scratch (this compositor only runs when no caller wants it):
-  // as three floats per pixel, or (r05, RR_OPT_COMPOSITE_U16, default) as three 16-bit codes -- half the bytes here and in
+  // as three floats per pixel, or (r05, RR_OPT_COMPOSITE_U16, default) as three 16-bit codes in an 8-byte word -- one store per pixel, two thirds of the bytes here and in
   // k_finalize.  A value in [0, 1] becomes rint(v * 65534) (error <= 2^-17, an LSB of the uint8 image is 2^-8); anything
   // else -- only possible where no drop was blended, every blend ends with a clamp, or where the input was NaN -- becomes
   // the code 65535: k_finalize then takes the pixel's channel from rainy_bg itself, which is what this lane holds.
