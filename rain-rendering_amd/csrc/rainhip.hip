@@ -3697,18 +3697,32 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     if (fr.mask_i32) as_global(fr.mask_i32)[pix1] = (int32_t)floor(m1 * 255.0);
     sum_c += ((double)c0.y + (double)c1.y) + (double)c2.y;
   }
-  // the four numbers of the wave's 8 x 16 pixels by DPP -- no LDS, no barrier, and the stores above are not waited for
-  // (r04: a 256-entry LDS tree with nine block barriers, each of them behind the stores' acknowledgement); k_means adds up
-  // four entries per tile
+  // the tile's four numbers: inside a wave by DPP (no LDS, no barrier), across the four waves through 16 doubles of LDS
+  // and ONE barrier (r04: a 256-entry LDS tree with nine)
   const double wa = readlane_f64(wave_incl_scan_f64(sum_c), 63), wb = readlane_f64(wave_incl_scan_f64(sum_b), 63);
   const double wlo = readlane_f64(wave_min_scan_f64(dmin(live0 ? m0 : 1.0e300, live1 ? m1 : 1.0e300)), 63);
   const double whi = readlane_f64(wave_max_scan_f64(dmax(live0 ? m0 : -1.0e300, live1 ? m1 : -1.0e300)), 63);
+  __shared__ double s_red[4][4];
   if (lane == 0) {
-    double* part = sc.partial + (((int64_t)f * tiles_x * tiles_y + tile) * 4 + wave) * 4;
-    part[0] = wa;
-    part[1] = wb;
-    part[2] = wlo;
-    part[3] = whi;
+    s_red[wave][0] = wa;
+    s_red[wave][1] = wb;
+    s_red[wave][2] = wlo;
+    s_red[wave][3] = whi;
+  }
+  __syncthreads();
+  double ra[1], rb[1], rlo[1], rhi[1];
+  if (t == 0) {
+    ra[0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+    rb[0] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+    rlo[0] = dmin(dmin(s_red[0][2], s_red[1][2]), dmin(s_red[2][2], s_red[3][2]));
+    rhi[0] = dmax(dmax(s_red[0][3], s_red[1][3]), dmax(s_red[2][3], s_red[3][3]));
+  }
+  if (t == 0) {
+    double* part = sc.partial + ((int64_t)f * tiles_x * tiles_y + tile) * 4;
+    part[0] = ra[0];
+    part[1] = rb[0];
+    part[2] = rlo[0];
+    part[3] = rhi[0];
   }
   PH(6)
   PH_FLUSH(4)
@@ -4638,7 +4652,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.htab, fd * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fband, (size_t)F * COL_PARTS * 2))) return rc;
     const int ntiles = ((dm.W + TILE - 1) / TILE) * ((dm.H + TILE - 1) / TILE);
-    if ((rc = dev_alloc(ctx, ctx->sc.partial, (size_t)F * ntiles * 16))) return rc;     // (k_composite32: four entries of four numbers per 16 x 32 tile, at most one such tile per 16 x 16 one)
+    if ((rc = dev_alloc(ctx, ctx->sc.partial, (size_t)F * ntiles * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.means, (size_t)F * 4))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.arena_need, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->d_frames, (size_t)F))) return rc;
@@ -5047,7 +5061,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   }
   {
     ProfScope ps(ctx, s, "k_means");
-    hipLaunchKernelGGL(k_means, dim3(n), dim3(256), 0, s, dm, use32 ? 4 * ntiles_c : ntiles_c, sc);
+    hipLaunchKernelGGL(k_means, dim3(n), dim3(256), 0, s, dm, ntiles_c, sc);
   }
   {
     ProfScope ps(ctx, s, "k_finalize");
