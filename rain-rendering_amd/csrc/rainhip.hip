@@ -2,24 +2,33 @@
 // rendering + compositing hot path.  Written for MI355X only: wave64, 256 CUs, no
 // portability layer.  See DESIGN.md for the kernel chain and the HBM layout.
 //
-//   k_env_prefix   row-wise prefix sums of (x*w, y*w, Y*w, w) of the environment map
-//   k_env_consts   sum(w), sum(Y*w)/sum(w)                       (bad_weather.py:403-404)
-//   k_plan         one thread per drop: geometry, homography / rotation, CoC, FOV polygon
-//   k_scan         per-frame exclusive scan of tile sizes -> arena offsets
-//   k_dedup        drops with bit-identical raw-tile parameters share one tile (batch-wide election)
-//   k_lists        work lists: rotate/resize tiles, Big tiles (+ pixel prefix), generic, blur items
-//   k_col_order / k_colour_bands / k_colour
-//                  one wave per drop, grouped by image region per XCD: FOV row spans x prefix table
-//                  -> colour constants and the compositor record
-//   k_tile         one workgroup per rotate+flip+INTER_AREA tile, texture and samples staged in LDS
-//   k_tile_big     Big drops (bicubic warpPerspective): one thread per output pixel
-//   k_tile_generic the rare rest (up-sampling resize, oversize textures)
-//   k_blur_small / k_blur_fused / k_blur<0|1>
-//                  separable defocus blur of the effective tile (raw tile dilated by the radii)
-//   k_bin / k_composite
-//                  ordered per-tile drop lists (ballot compaction, no atomics), in-register alpha
-//                  blend + mask accumulate per 16x16 screen tile
-//   k_means / k_finalize   mean-contrast shift, clip, truncating u8 quantisation
+// The chain of one call (grid.y = frame; DESIGN.md section 5 has the measurements):
+//   second stream (RR_OPT_COLOUR_STREAM), the colour branch -- three numbers per drop:
+//     k_fov_dda        a thread per drop: FOV polygon in float with error bounds, row spans by two cursors  (k_fov_walk:
+//                      incremental cursors, an option; k_fov_spans<NCH, false>: edge-parallel, float64 / caller-made polygons)
+//     k_fov_spans<NCH, true>   the drops float cannot decide and the wrapping polygons, from the frame's list, in float64
+//     k_fov_sums32 / k_fov_sums   workgroup (frame, band of map rows, chunk of drops): prefix rows in LDS, P[xr+1] - P[xl]
+//     (general path, maps beyond the fast path's limits or RR_OPT_FOV_FILL_RULE: k_fov_poly_general, k_env_prefix,
+//      k_env_consts, k_fov_sums_general)
+//   caller's stream:
+//     k_plan           one thread per drop: geometry, homography / rotation, CoC, footprint -> DropPlan
+//     k_scan           per-frame exclusive scan of tile sizes -> arena offsets (+ the frame's zero line)
+//     k_dedup          drops with bit-identical raw-tile parameters share one tile (batch-wide election)
+//     k_lists          work lists: rotate/resize tiles, Big tiles (+ pixel prefix), generic, blur items by size
+//     k_tile_generic / k_tile_big / k_tile   raw alpha tiles: rare modes; bicubic warpPerspective, a thread per pixel;
+//                      rotate + flip + INTER_AREA, a workgroup per tile with the texture in LDS
+//     k_blur_weights, k_blur_small, k_blur_fused_dma (k_blur_fused), k_blur_big_weights, k_blur<0|1>
+//                      separable defocus blur of the effective tile: a wave per small tile; LDS sub-tiles staged by
+//                      LDS-DMA for radii 5..48; zero-skipping taps for larger ones
+//     -- join --
+//     k_colour         band partials -> colour constants, compositor records, bbox, status
+//     k_bin_rows (k_bin), [k_pad_visits], k_composite32 (k_composite)
+//                      ordered per-tile drop lists (ballot compaction, no atomics); float64 mask in drop order, float
+//                      (or float64) colours, tile sums
+//     k_means, k_finalize16 (k_finalize), [k_png_image, k_png_mask, k_pngz_blocks, k_pngz_pack]
+//                      mean-contrast shift, clip, truncating u8 quantisation; optional PNG scanlines / zlib streams
+//   elsewhere: k_particles / k_particle_draws (drop tables born on the device), k_png_unfilter (input files' scanlines),
+//   k_pad_textures, k_copy_pieces / k_copy_small (batched copies, descriptors)
 // rr_prepass.h holds the fog / environment-map pre-pass kernels, rr_host.cpp the host-only helpers.
 #include <hip/hip_runtime.h>
 
