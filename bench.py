@@ -812,7 +812,7 @@ def main():
         frames_step = args.total_frames if strong else B * world
         fps = frames_step * args.steps / elapsed
         per_launch = {k: v[1] / v[0] for k, v in stats.items()}
-        COLOUR = ('k_fov_spans', 'k_fov_sums', 'k_fov_poly', 'k_env_prefix', 'k_fov_sums_general')      # launched on the second stream
+        COLOUR = ('k_fov_spans', 'k_fov_sums', 'k_fov_poly', 'k_env_prefix', 'k_fov_sums_general')      # launched on the library's second stream (RR_OPT_COLOUR_STREAM 1)
         overlapped = {k: v for k, v in per_launch.items() if k in COLOUR} if stats_serial is not None else {}
         per_main = {k: v for k, v in per_launch.items() if k not in overlapped}
         dom_name = max(per_main, key=per_main.get)
@@ -897,12 +897,13 @@ def main():
                       "frac_of_hbm_peak": alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernels_ms_per_call": {k: v for k, v in sorted(per_main.items(), key=lambda kv: -kv[1])},
             "overlap": None if per_serial is None else {
-                "what": "the colour branch (FOV polygons, spans, sums over the environment map) runs on a second stream beside plan .. tiles .. blur "
-                        "(RR_OPT_COLOUR_STREAM).  kernels_ms_per_call: the first stream's kernels in the timed region; colour_branch_ms_between_events: "
-                        "the second stream's kernels between their event pairs -- including the time their workgroups waited for room on the "
-                        "CUs, not a cost; kernels_ms_per_call_one_stream: the same step with the option off, every kernel alone on the device",
+                "what": "the FOV chain (polygons, spans, sums over the environment map) runs on a second stream of the library beside plan .. "
+                        "tiles .. blur (RR_OPT_COLOUR_STREAM 1).  kernels_ms_per_call: the caller's stream's kernels in the timed region; "
+                        "second_stream_ms_between_events: the second stream's kernels between their event pairs -- including the time their "
+                        "workgroups waited for room on the CUs, not a cost; kernels_ms_per_call_one_stream: the same step with the option 0, "
+                        "every kernel alone on the device",
                 "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_one_stream": 1e3 * elapsed_serial / args.steps,
-                "colour_branch_ms_between_events": {k: v for k, v in sorted(overlapped.items(), key=lambda kv: -kv[1])},
+                "second_stream_ms_between_events": {k: v for k, v in sorted(overlapped.items(), key=lambda kv: -kv[1])},
                 "kernels_ms_per_call_one_stream": {k: v for k, v in sorted(per_serial.items(), key=lambda kv: -kv[1])}},
             "valu": {"what": valu_how, "dominant_kernel": dom_valu["valu_util"] if dom_valu else None,
                      "per_kernel": {k: {"valu_util": round(v["valu_util"], 4), "waiting": round(v["waiting"], 4) if v["waiting"] is not None else None}

@@ -417,10 +417,12 @@ enum {
   RR_OPT_BIN_ROWS = 19,             /* tuning (r05): 1 (default) the ordered per-tile drop lists are made by a workgroup per ROW of coarse
                                      * tiles (drops filtered by row first, then a wave per tile); 0: a workgroup per coarse tile that
                                      * tests every drop (r04).  Same lists. */
-  RR_OPT_COLOUR_STREAM = 21,        /* tuning (r05): 1 (default) the colour branch (FOV polygons, spans, sums over the environment map)
-                                     * runs on a second stream of the library beside plan .. tiles .. blur and joins at k_colour; 0: one
-                                     * in-order stream (r04).  Same results (a drop without a FOV polygon gets its raw tile rendered
-                                     * for nothing with 1: it is still not blended and keeps its status). */
+  RR_OPT_COLOUR_STREAM = 21,        /* tuning (r05): two chains of the step that only meet in k_colour run on two streams of the library.
+                                     * 1 (default): the FOV chain (polygons, spans, sums over the environment map) on the second stream
+                                     * beside plan .. tiles .. blur; 2: plan .. lists and k_colour on the second stream beside the FOV
+                                     * chain, which then runs in front of the tile kernels on the caller's stream (measured slower);
+                                     * 0: one in-order stream (r04).  Same results (with 1 and 2 a drop without a FOV polygon gets its
+                                     * raw tile rendered for nothing: it is still not blended and keeps its status). */
   RR_OPT_COMPOSITE_BATCH = 20       /* tuning (r05): 1 (default) the float compositor keeps the records of 64 list entries at a time in
                                      * vector registers (a lane per entry) and runs its alpha samples two entries ahead of the blend;
                                      * 0: a scalar record fetch per entry, samples one entry ahead (r04).  Same operations in the same

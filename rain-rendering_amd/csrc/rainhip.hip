@@ -4391,9 +4391,9 @@ struct rr_ctx {
   bool blur_dma = true;              // RR_OPT_BLUR_DMA
   int fov_dda = 1;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (1: k_fov_dda, 2: k_fov_walk)
   int comp_waves = 0;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (0: the kernel's own choice)
-  bool colour_stream = true;         // RR_OPT_COLOUR_STREAM: FOV spans / sums on a second stream, beside plan .. blur
+  int colour_stream = 1;             // RR_OPT_COLOUR_STREAM: 0 one stream; 1 the FOV chain on a second stream; 2 plan .. lists + k_colour on it
   hipStream_t s_col = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lists = nullptr, ev_sums = nullptr;
   bool comp_batch = true;            // RR_OPT_COMPOSITE_BATCH: list entries' records 64 at a time in vector registers, samples two entries ahead
   int n_tex = 0;
   float* d_ctab = nullptr;
@@ -4810,27 +4810,31 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   auto grid_cap = [&](int single_frame) { return imax(64, imin(single_frame, 16384 / n)); };
   if (max_drops > 0) {
     const bool fast = fov_fast_path(ctx, dm);
-    // r05 (RR_OPT_COLOUR_STREAM, default): the colour branch -- FOV polygons, spans, sums over the map: three numbers per drop
-    // that nothing reads before k_colour -- runs on a second stream beside plan .. lists .. tiles .. blur.  Its kernels are
-    // bound by integer issue (k_fov_dda) and by load latency with one workgroup per CU (k_fov_sums32), the bookkeeping
-    // kernels by dependent loads, the tile / blur kernels by float64 issue and LDS: side by side they fill each other's
-    // gaps.  k_colour, moved behind the blur, joins the two.
-    hipStream_t cs = s;
+    // r05 (RR_OPT_COLOUR_STREAM): two chains that only meet in k_colour can run on two streams of the library.
+    //   the FOV chain   k_fov_dda -> k_fov_spans (the list) -> k_fov_sums32: three numbers per drop; integer issue, then
+    //                   one 1024-thread workgroup per CU waiting on loads
+    //   bookkeeping     k_plan -> k_scan -> k_dedup -> k_lists (-> k_colour): chains of dependent loads, small workgroups
+    // 1 (default): the FOV chain on the second stream beside plan .. tiles .. blur, k_colour behind the blur: 31.3 ms per 512
+    //    frames against 32.2 on one stream.  k_fov_sums32's workgroups (16 waves and a map row of LDS) only get onto a CU when
+    //    the tile / blur kernels, which fill the LDS, leave one: 19 ms between its events instead of 2.6, and the caller's
+    //    stream waits a millisecond for it at the end (profiles/r05_two_stream_timeline.txt); a high-priority stream
+    //    changes nothing.
+    // 2: bookkeeping (and k_colour) on the second stream, the FOV chain in front of the tile kernels on the caller's, so
+    //    that the tile / blur kernels have the device to themselves: 31.6 ms -- k_fov_dda (4.5 ms beside k_plan instead of 3.4)
+    //    and k_fov_sums32 (3.8 beside k_dedup / k_lists instead of 2.6) lose what the tail gains (r05_ab_w.txt).
+    // 0: one in-order stream (r04).
+    hipStream_t fs = s, bs = s;
     if (ctx->colour_stream) {
       if (!ctx->s_col) {
-        // at the HIGHEST priority: k_fov_sums32's workgroups are 1024 threads with a map row of LDS -- beside the tile / blur
-        // kernels at equal priority they waited for a whole CU's worth of free wave slots and the kernel took 19 ms
-        // instead of 2.6 (r05_ab_r.txt); dispatched first, the colour branch runs at its own pace and the other kernels
-        // fill what it leaves
-        int pr_lo = 0, pr_hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-        HIPCHK(hipStreamCreateWithPriority(&ctx->s_col, hipStreamNonBlocking, pr_hi));
+        HIPCHK(hipStreamCreateWithFlags(&ctx->s_col, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_lists, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_sums, hipEventDisableTiming));
       }
       HIPCHK(hipEventRecord(ctx->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(ctx->s_col, ctx->ev_fork, 0));
-      cs = ctx->s_col;
+      if (ctx->colour_stream == 1) fs = ctx->s_col; else bs = ctx->s_col;
     }
     // (whatever way this block is left -- an error return included -- the caller's stream waits for the second one: a
     // synchronisation of `s` then covers everything that was enqueued here)
@@ -4845,10 +4849,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         return e != hipSuccess ? e : hipStreamWaitEvent(s, c->ev_join, 0);
       }
       ~Join() { (void)now(); }
-    } join{ctx, s, cs, cs != s};
+    } join{ctx, s, ctx->s_col, fs != bs};
     const int Hp = ctx->scratch_hp, Dp = (D + 1 + 7) & ~7;
     if (fast) {
-      ProfScope ps(ctx, cs, "k_fov_spans");
+      ProfScope ps(ctx, fs, "k_fov_spans");
       const int G = imin(64 / ctx->cam.n_fov, FOV_GROUPS);
       // float colour branch: a thread per drop (k_fov_dda) for the polygons float decides and that do not wrap; the rest
       // (a fraction of a percent) through the frame's list to k_fov_spans in float64.  Caller-made polygons (rr_ext_tile)
@@ -4859,9 +4863,9 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       const int v32 = fov32 ? 1 : 0;
       const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
       if (dda) {
-        HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, cs));
+        HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, fs));
         if (ctx->fov_dda == 1) {
-          hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 255) / 256, n), dim3(256), sizeof(uint32_t) * 4 * 64 * (size_t)ctx->cam.n_fov, cs, ctx->d_frames, dm,
+          hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 255) / 256, n), dim3(256), sizeof(uint32_t) * 4 * 64 * (size_t)ctx->cam.n_fov, fs, ctx->d_frames, dm,
                              ctx->cam, D, Hp, Dp, sc);
         } else {                                              // r05: incremental cursors over per-edge records
           const size_t lds = sizeof(uint2) * 4 * 64 * (size_t)ctx->cam.n_fov;
@@ -4869,27 +4873,27 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint2) * 4 * 64 * RR_MAX_FOV)));
             ctx->walk_attr = true;
           }
-          hipLaunchKernelGGL(k_fov_walk, dim3((max_drops + 255) / 256, n), dim3(256), lds, cs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
+          hipLaunchKernelGGL(k_fov_walk, dim3((max_drops + 255) / 256, n), dim3(256), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
         }
         const dim3 lgrid(imin((int)grid.x, 8), n);           // the list is short: a few workgroups per frame walk it, in float64
         if (dm.He <= 384)
-          hipLaunchKernelGGL((k_fov_spans<6, true>), lgrid, dim3(256), 0, cs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+          hipLaunchKernelGGL((k_fov_spans<6, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
         else if (dm.He <= 512)
-          hipLaunchKernelGGL((k_fov_spans<8, true>), lgrid, dim3(256), 0, cs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+          hipLaunchKernelGGL((k_fov_spans<8, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
         else
-          hipLaunchKernelGGL((k_fov_spans<16, true>), lgrid, dim3(256), 0, cs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+          hipLaunchKernelGGL((k_fov_spans<16, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
       } else if (dm.He <= 384)
-        hipLaunchKernelGGL((k_fov_spans<6, false>), grid, dim3(256), 0, cs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<6, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
       else if (dm.He <= 512)
-        hipLaunchKernelGGL((k_fov_spans<8, false>), grid, dim3(256), 0, cs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<8, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
       else
-        hipLaunchKernelGGL((k_fov_spans<16, false>), grid, dim3(256), 0, cs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<16, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
     } else {
-      ProfScope ps(ctx, cs, "k_fov_poly");
-      hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, cs, ctx->d_frames, dm, ctx->cam, D, sc);
+      ProfScope ps(ctx, fs, "k_fov_poly");
+      hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, fs, ctx->d_frames, dm, ctx->cam, D, sc);
     }
     if (fast) {
-      ProfScope ps(ctx, cs, "k_fov_sums");
+      ProfScope ps(ctx, fs, "k_fov_sums");
       // a chunk of NT*DPT drops re-scans the band's rows, so DPT grows with the drop count (register budget: 4
       // doubles of running sums + one 16-byte span piece per drop)
       const size_t row_bytes = ((size_t)(dm.We + 1) * 2 + 16 * 2) * sizeof(double);      // P + wave totals
@@ -4905,14 +4909,14 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(NT), row_bytes, cs, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), row_bytes, fs, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
       auto launch32 = [&](auto kern) -> hipError_t {         // all four components in one workgroup: half the grid
         const size_t bytes = ((size_t)(dm.We + 1) * 4 + 16 * 4) * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(COL_PARTS * nchunk, n), dim3(NT), bytes, cs, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
+        hipLaunchKernelGGL(kern, dim3(COL_PARTS * nchunk, n), dim3(NT), bytes, fs, ctx->d_frames, dm, D, Hp, Dp, rpb, nchunk, sc);
         return hipSuccess;
       };
       // (the element type of the map is a template parameter: a run-time choice inside the row loader cost the 8-drops-per-
@@ -4937,33 +4941,43 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       }
     } else {
       {
-        ProfScope ps(ctx, cs, "k_env_prefix");
-        hipLaunchKernelGGL(k_env_prefix, dim3((dm.He + 3) / 4, n), dim3(256), 0, cs, ctx->d_frames, dm, sc.prefix);
-        hipLaunchKernelGGL(k_env_consts, dim3(n), dim3(256), 0, cs, dm, sc.prefix, sc.fband);
+        ProfScope ps(ctx, fs, "k_env_prefix");
+        hipLaunchKernelGGL(k_env_prefix, dim3((dm.He + 3) / 4, n), dim3(256), 0, fs, ctx->d_frames, dm, sc.prefix);
+        hipLaunchKernelGGL(k_env_consts, dim3(n), dim3(256), 0, fs, dm, sc.prefix, sc.fband);
       }
       {
-        ProfScope ps(ctx, cs, "k_fov_sums_general");
-        hipLaunchKernelGGL(k_fov_sums_general, dim3((max_drops + 3) / 4, n), dim3(256), 0, cs, ctx->d_frames, dm, D, sc, ctx->fill_rule, ctx->cam.n_fov);
+        ProfScope ps(ctx, fs, "k_fov_sums_general");
+        hipLaunchKernelGGL(k_fov_sums_general, dim3((max_drops + 3) / 4, n), dim3(256), 0, fs, ctx->d_frames, dm, D, sc, ctx->fill_rule, ctx->cam.n_fov);
       }
     }
+    if (bs != s) HIPCHK(hipEventRecord(ctx->ev_sums, s));     // (mode 2: k_colour, on the second stream, waits for the sums)
     {
-      ProfScope ps(ctx, s, "k_plan");
-      hipLaunchKernelGGL(k_plan, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, dm, ctx->cam, ctx->d_tex_h,
-                         ctx->d_tex_w, D, cs == s ? 1 : 0, sc);
+      ProfScope ps(ctx, bs, "k_plan");
+      hipLaunchKernelGGL(k_plan, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, dm, ctx->cam, ctx->d_tex_h,
+                         ctx->d_tex_w, D, fs == bs ? 1 : 0, sc);
     }
     {
-      ProfScope ps(ctx, s, "k_scan");
-      hipLaunchKernelGGL(k_scan, dim3(n), dim3(1024), 0, s, ctx->d_frames, D, ctx->arena_cap, sc);
+      ProfScope ps(ctx, bs, "k_scan");
+      hipLaunchKernelGGL(k_scan, dim3(n), dim3(1024), 0, bs, ctx->d_frames, D, ctx->arena_cap, sc);
     }
     {
-      ProfScope ps(ctx, s, "k_dedup");
-      HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, s));
-      HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, s));
-      hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, s, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
+      ProfScope ps(ctx, bs, "k_dedup");
+      HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, bs));
+      HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, bs));
+      hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
-      ProfScope ps(ctx, s, "k_lists");
-      hipLaunchKernelGGL(k_lists, dim3(n), dim3(1024), 0, s, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
+      ProfScope ps(ctx, bs, "k_lists");
+      hipLaunchKernelGGL(k_lists, dim3(n), dim3(1024), 0, bs, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
+    }
+    if (bs != s) {                                         // mode 2: k_colour beside the tile kernels; the tiles wait for the lists
+      HIPCHK(hipEventRecord(ctx->ev_lists, bs));
+      HIPCHK(hipStreamWaitEvent(bs, ctx->ev_sums, 0));
+      {
+        ProfScope ps(ctx, bs, "k_colour");
+        hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, bs, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
+      }
+      HIPCHK(hipStreamWaitEvent(s, ctx->ev_lists, 0));
     }
     {
       ProfScope ps(ctx, s, "k_tile_generic");
@@ -5015,10 +5029,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_blur_cols");
       hipLaunchKernelGGL(k_blur<1>, dim3(256, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
-    HIPCHK(join.now());                                    // the colour branch joins: k_colour needs its sums and the plan / scan
-    {
-      ProfScope ps(ctx, s, "k_colour");
-      hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
+    HIPCHK(join.now());                                    // the caller's stream waits for the second one: k_bin needs k_colour's records
+    if (bs == s) {                                         // modes 0 and 1: k_colour here, behind the blur (mode 1: and behind the join)
+      {
+        ProfScope ps(ctx, s, "k_colour");
+        hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
+      }
     }
   }
   const int ctiles_x = (dm.W + CTILE - 1) / CTILE, nct = ctiles_x * ((dm.H + CTILE - 1) / CTILE);
@@ -5464,6 +5480,8 @@ int rr_destroy(rr_ctx* ctx) {
   if (ctx->s_col) hipStreamDestroy(ctx->s_col);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_lists) hipEventDestroy(ctx->ev_lists);
+  if (ctx->ev_sums) hipEventDestroy(ctx->ev_sums);
   if (ctx->s_up) hipStreamDestroy(ctx->s_up);
   if (ctx->s_down) hipStreamDestroy(ctx->s_down);
   hipFree(ctx->d_esrc);
@@ -6469,7 +6487,10 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
       ctx->comp_waves = value;
       return RR_OK;
     case RR_OPT_COMPOSITE_BATCH: ctx->comp_batch = value != 0; return RR_OK;
-    case RR_OPT_COLOUR_STREAM: ctx->colour_stream = value != 0; return RR_OK;
+    case RR_OPT_COLOUR_STREAM:
+      if (value < 0 || value > 2) break;
+      ctx->colour_stream = value;
+      return RR_OK;
     case RR_OPT_FOV_F32:
       if (value < 0 || value > 2) break;
       ctx->fov_f32 = value;

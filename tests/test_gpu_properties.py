@@ -255,8 +255,8 @@ def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path
 def test_composite_codes_and_blur_prefetch(setup):
     """r05 tuning switches of the float-colour route.  RR_OPT_BLUR_DMA (the fused blur's sub-tiles staged a sub-tile ahead by
     LDS-DMA loads), RR_OPT_BIN_ROWS (how the ordered per-tile drop lists are made) and RR_OPT_COMPOSITE_BATCH (how the
-    compositor gets at its list entries' records) and RR_OPT_COLOUR_STREAM (the colour branch on a second stream beside
-    plan .. blur, or everything on one in-order stream) change no bit.  RR_OPT_COMPOSITE_U16 (the composite before the mean shift as 16-bit codes
+    compositor gets at its list entries' records) and RR_OPT_COLOUR_STREAM (which of the step's two chains runs on the library's
+    second stream, or everything on one in-order stream) change no bit.  RR_OPT_COMPOSITE_U16 (the composite before the mean shift as 16-bit codes
     instead of floats) keeps mask and statuses and moves the uint8 image by at most 1 LSB on a few pixels in a thousand;
     values outside [0, 1] -- a pixel no drop was blended into -- go through the code 65535 and come out as
     before."""
@@ -269,12 +269,13 @@ def test_composite_codes_and_blur_prefetch(setup):
     wild[310:320, 40:50] = 0.0
     frw = dict(fr, bg=wild, rainy_bg=wild)
     ref = rh.render_frames([fr, frw], want_composite=False)
-    for opt in (h.hb.RR_OPT_BLUR_DMA, h.hb.RR_OPT_BIN_ROWS, h.hb.RR_OPT_COMPOSITE_BATCH, h.hb.RR_OPT_COLOUR_STREAM, h.hb.RR_OPT_COMPOSITE_U16):
-        rh.set_option(opt, 0)
+    for opt, off, on in ((h.hb.RR_OPT_BLUR_DMA, 0, 1), (h.hb.RR_OPT_BIN_ROWS, 0, 1), (h.hb.RR_OPT_COMPOSITE_BATCH, 0, 1),
+                         (h.hb.RR_OPT_COLOUR_STREAM, 0, 1), (h.hb.RR_OPT_COLOUR_STREAM, 2, 1), (h.hb.RR_OPT_COMPOSITE_U16, 0, 1)):
+        rh.set_option(opt, off)
         try:
             alt = rh.render_frames([fr, frw], want_composite=False)
         finally:
-            rh.set_option(opt, 1)
+            rh.set_option(opt, on)
         for a, b in zip(ref, alt):
             for k in ('status', 'mask', 'mask_i32'):
                 assert np.array_equal(a[k], b[k]), (opt, k)
