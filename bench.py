@@ -899,11 +899,11 @@ def main():
             "overlap": None if per_serial is None else {
                 "what": "the FOV chain (polygons, spans, sums over the environment map) runs on a second stream of the library beside plan .. "
                         "tiles .. blur (RR_OPT_COLOUR_STREAM 1).  kernels_ms_per_call: the caller's stream's kernels in the timed region; "
-                        "second_stream_ms_between_events: the second stream's kernels between their event pairs -- including the time their "
+                        "colour_branch_ms_between_events: the second stream's kernels between their event pairs -- including the time their "
                         "workgroups waited for room on the CUs, not a cost; kernels_ms_per_call_one_stream: the same step with the option 0, "
                         "every kernel alone on the device",
                 "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_one_stream": 1e3 * elapsed_serial / args.steps,
-                "second_stream_ms_between_events": {k: v for k, v in sorted(overlapped.items(), key=lambda kv: -kv[1])},
+                "colour_branch_ms_between_events": {k: v for k, v in sorted(overlapped.items(), key=lambda kv: -kv[1])},
                 "kernels_ms_per_call_one_stream": {k: v for k, v in sorted(per_serial.items(), key=lambda kv: -kv[1])}},
             "valu": {"what": valu_how, "dominant_kernel": dom_valu["valu_util"] if dom_valu else None,
                      "per_kernel": {k: {"valu_util": round(v["valu_util"], 4), "waiting": round(v["waiting"], 4) if v["waiting"] is not None else None}
