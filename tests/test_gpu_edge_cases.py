@@ -202,6 +202,12 @@ def test_wild_pixel_values_follow_the_reference_blend(tmp_path, built):
         if rb is not wild_any:                                                    # (an inf or NaN left in the composite poisons the mean shift)
             assert np.abs(out['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
             assert np.abs(out32['image_u8'].astype(int) - emu['image_u8'].astype(int)).max() <= 1
+        if rb is wild_fin:                                                        # ... and against the numpy oracle itself, which blends every
+            ref = h.oracle_render(sc, 0, bg, rb, env, faithful=True)             # drop over its whole padded rectangle like the reference
+            assert np.array_equal(out['mask'], ref['mask']) and np.array_equal(out['status'], ref['status'][:len(out['status'])])
+            assert (np.abs(a - ref['rainy_bg']) <= 2e-9 * np.maximum(1.0, np.abs(ref['rainy_bg']))).all()
+            assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+            assert np.abs(out32['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
         if rb is wild_fin:                                                        # the pads matter: without the option the composite differs
             rh.set_option(h.hb.RR_OPT_WILD_PIXELS, 0)
             plain = rh.render_frames([fr])[0]
