@@ -569,7 +569,7 @@ def main():
     # then span the time they waited for room beside the other stream's kernels, not their cost.  One more pass of the same
     # step with everything on one in-order stream gives every kernel's own duration (and what the overlap is worth).
     stats_serial, elapsed_serial = None, None
-    if rank == 0 and world == 1 and not args.no_serial and hasattr(hb, 'RR_OPT_COLOUR_STREAM'):
+    if not args.no_serial and not args.inner and hasattr(hb, 'RR_OPT_COLOUR_STREAM'):      # (every rank: the timed loop holds collectives)
         rh.set_option(hb.RR_OPT_COLOUR_STREAM, 0)
         warm(render, 1)
         rh.profile_reset()
