@@ -231,7 +231,7 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
             for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
                 for row in csv.DictReader(open(f)):
                     m = re.search(r'(k_[a-z_0-9]+)', row.get('Kernel_Name', ''))
-                    if m and (m.group(1) in dom_kernels or scope_of(m.group(1)) in dom_kernels) and row['Counter_Name'] == counter:
+                    if m and (m.group(1) in dom_kernels or scope_of_name(row.get('Kernel_Name', '')) in dom_kernels) and row['Counter_Name'] == counter:
                         tot += float(row['Counter_Value'])
                         cnt += 1
             shutil.rmtree(out, ignore_errors=True)
@@ -246,11 +246,23 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
 
 # kernel symbol -> the name of the timing scope (rr_profile_read) it is launched under
 SCOPE_OF = {'k_blur_fused_dma': 'k_blur_fused', 'k_composite32': 'k_composite', 'k_fov_sums32': 'k_fov_sums', 'k_fov_dda': 'k_fov_spans',
-            'k_fov_walk': 'k_fov_spans', 'k_finalize16': 'k_finalize', 'k_bin_rows': 'k_bin', 'k_env_consts': 'k_env_prefix'}
+            'k_fov_walk': 'k_fov_spans', 'k_finalize16': 'k_finalize', 'k_bin_rows': 'k_bin', 'k_env_consts': 'k_env_prefix',
+            'k_fov_poly_general': 'k_fov_poly', 'k_png_image': 'k_png_rows', 'k_png_mask': 'k_png_rows', 'k_pngz_blocks': 'k_pngz',
+            'k_pngz_pack': 'k_pngz'}
 
 
 def scope_of(kernel):
     return SCOPE_OF.get(kernel, kernel)
+
+
+def scope_of_name(full_name):
+    """Timing scope of a kernel from its (demangled) name as rocprofv3 prints it; '' when it is none of the library's."""
+    m = re.search(r'(k_[a-z_0-9]+)(<[^>]*>)?', full_name or '')
+    if not m:
+        return ''
+    if m.group(1) == 'k_blur' and m.group(2) in ('<0>', '<1>'):              # the two-pass blur: one kernel template, a scope per pass
+        return 'k_blur_rows' if m.group(2) == '<0>' else 'k_blur_cols'
+    return scope_of(m.group(1))
 
 
 def measure_valu(args, scene_dir=None):
