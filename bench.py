@@ -248,7 +248,7 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
 SCOPE_OF = {'k_blur_fused_dma': 'k_blur_fused', 'k_composite32': 'k_composite', 'k_fov_sums32': 'k_fov_sums', 'k_fov_dda': 'k_fov_spans',
             'k_fov_walk': 'k_fov_spans', 'k_finalize16': 'k_finalize', 'k_bin_rows': 'k_bin', 'k_env_consts': 'k_env_prefix',
             'k_fov_poly_general': 'k_fov_poly', 'k_png_image': 'k_png_rows', 'k_png_mask': 'k_png_rows', 'k_pngz_blocks': 'k_pngz',
-            'k_pngz_pack': 'k_pngz'}
+            'k_pngz_pack': 'k_pngz', 'k_rows_scatter': 'k_lists'}
 
 
 def scope_of(kernel):
@@ -547,6 +547,7 @@ def main():
                  1: ('k_tile_big', ['search+barriers', 'plan fields', 'pixel']),
                  2: ('k_blur_small', ['plan+weights+raw->LDS', 'row pass', 'column pass+store']),
                  3: ('k_blur_fused[_dma]', ['issue loads | dma: clear Y + wait for the loads + halo', 'barrier A (loads land)', 'row pass', 'barrier B', 'column pass+store', 'barrier C', 'dma: next loads issued']),
+                 5: ('k_tile_rows', ['pull + plan', 'column table', 'group set-up (clear, row terms, intervals)', 'row walks', 'vertical folds+store', 'texture switch (wait + stage)']),
                  4: ('k_composite32', ['background / depth loads', 'list piece: clist + bbox loads, ballots, list', 'barriers of the list piece', 'record batch arrives', 'entry loop',
                                        'barrier at the piece end', 'stores + tile reduction'])}
         calls = args.steps + args.warmup

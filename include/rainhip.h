@@ -423,6 +423,9 @@ enum {
                                      * chain, which then runs in front of the tile kernels on the caller's stream (measured slower);
                                      * 0: one in-order stream (r04).  Same results (with 1 and 2 a drop without a FOV polygon gets its
                                      * raw tile rendered for nothing: it is still not blended and keeps its status). */
+  RR_OPT_TILE_ROWS = 22,            /* tuning (r06): 1 (default) rotate + flip + INTER_AREA tiles (Medium / Small drops, generator.py:163-170)
+                                     * are rendered by k_tile_rows -- the batch's tiles in one list bucketed by texture, a wave per tile,
+                                     * a lane per canvas row, horizontal folds in registers; 0: k_tile (a workgroup per tile).  Same bits. */
   RR_OPT_COMPOSITE_BATCH = 20       /* tuning (r05): 1 (default) the float compositor keeps the records of 64 list entries at a time in
                                      * vector registers (a lane per entry) and runs its alpha samples two entries ahead of the blend;
                                      * 0: a scalar record fetch per entry, samples one entry ahead (r04).  Same operations in the same

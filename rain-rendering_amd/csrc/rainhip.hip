@@ -192,7 +192,11 @@ __device__ unsigned long long g_phase[8][8];
     for (int ph_q_ = 0; ph_q_ < 8; ph_q_++)                     \
       if (ph_acc_[ph_q_]) atomicAdd(&g_phase[kid][ph_q_], ph_acc_[ph_q_]); \
   }
+#define PH_PARAMS , unsigned long long& ph_t0_, unsigned long long (&ph_acc_)[8]
+#define PH_PASS , ph_t0_, ph_acc_
 #else
+#define PH_PARAMS
+#define PH_PASS
 #define PH_DECL
 #define PH_WAITVM
 #define PH(k)
@@ -242,6 +246,15 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
   int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
   int32_t blur_bx, blur_by;         // LDS capacities (doubles) of the fused blur's two staging tiles (RR_OPT_BLUR_WORKGROUPS)
+  // k_tile_rows (r06): the rotate + INTER_AREA tiles of the WHOLE batch in one list, bucketed by texture
+  int32_t* rows_list;               // [frame][drops] frame-local indices of the drops k_tile_rows renders (k_lists)
+  int32_t* rows_n;                  // [frame] their number
+  int32_t* rows_hist;               // [RW_TEX_MAX] tiles per texture, batch-wide (zeroed per call)
+  int32_t* rows_fbase;              // [frame][RW_TEX_MAX] first slot of the frame inside its textures' buckets
+  int32_t* rows_sorted;             // [frames * drops] batch-global drop indices, bucket after bucket (k_rows_scatter)
+  const uint8_t* tex_pair;          // pair textures (k_pair_textures) and their offsets (multiples of 16)
+  const int64_t* tex_qoff;
+  int32_t rows_on, n_tex;           // RR_OPT_TILE_ROWS and a database of at most RW_TEX_MAX textures
 };
 
 // ---------------------------------------------------------------------------
@@ -1664,8 +1677,40 @@ __device__ inline bool tile_coords_safe(const DropPlan& p) {
 __device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
   if (!((sh + 4) * (sw + 4) <= TEX_LDS && p.kind == KIND_ROT && p.nW <= NW_MAX && p.tw <= TW_MAX && tile_coords_safe(p))) return false;
   if (p.rs_mode == RS_AREA_FAST) return true;                      // integer ratios: per-wave sequential chains
-  const int rows_per_dy = (int)ceil(p.scale_y) + 3;
+  const int rows_per_dy = (int)ceil(p.scale_y) + 4;          // (floor(dy1 * s) + 1) - (floor(dy0 * s) - 1) + 1 <= floor(k * s) + 4 rows per group
   return p.rs_mode == RS_AREA && rows_per_dy <= BUF_MAX;             // wide tiles are folded in column chunks
+}
+
+// ---- k_tile_rows (round 6): a WAVE per rotate + INTER_AREA tile, lanes = canvas rows (rr_device.h "row walks") ----
+constexpr int RW_WAVES = 16;          // waves of a workgroup (one workgroup per CU: the LDS holds one texture for all of them)
+constexpr int RW_NW = 324;            // canvas columns of a tile (sh = 320, sw = 32: nW <= 321)
+constexpr int RW_BUF = 352;           // doubles of cell sums per wave
+constexpr int RW_PAIR_BYTES = 24640;  // pair texture in LDS: (320 + 3) * 38 * 2 rounded up to 16
+constexpr int RW_TEX_MAX = 1024;      // textures of a database the batch-wide list is bucketed by
+struct RowsWave {                     // wave-private LDS of k_tile_rows
+  ColEnt col[RW_NW];
+  double buf[RW_BUF];
+  uint8_t cell[RW_NW + 12];
+};
+static_assert(sizeof(RowsWave) == 8336 && sizeof(RowsWave) % 16 == 0, "RowsWave layout (col[] is read 16 bytes at a time)");
+// estimated cost of a tile of this texture (its samples ~ the padded texture's area, plus the per-tile set-up), for the
+// split of the sorted list among the workgroups
+__device__ inline int64_t rows_tex_cost(int sh, int sw) { return (int64_t)(sh + 8) * (sw + 12) + 2000; }
+__device__ inline bool tile_is_rows(const DropPlan& p, int sh, int sw) {
+  return p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.nW <= RW_NW && p.tw <= 64 && p.tw >= 1 && p.th >= 1 &&
+         (int)ceil(p.scale_y) + 4 <= RW_BUF && pair_bytes(sh, sw) <= RW_PAIR_BYTES && tile_coords_safe(p);
+}
+__global__ __launch_bounds__(256) void k_pair_textures(const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w,
+                                                       const int64_t* tex_off, const int64_t* tex_qoff, uint8_t* pairs) {
+  const int i = blockIdx.x, sh = tex_h[i], sw = tex_w[i], P = pair_pitch(sw);
+  const uint8_t* g = texels + tex_off[i];
+  uint16_t* dst = reinterpret_cast<uint16_t*>(pairs + tex_qoff[i]);
+  for (int k = threadIdx.x; k < (sh + 3) * P; k += 256) {
+    const int y = k / P - 2, x = k - (y + 2) * P - 2;
+    const bool xin = x >= 0 && x < sw;
+    const uint32_t lo = (xin && y >= 0 && y < sh) ? g[y * sw + x] : 0u, hi = (xin && y + 1 >= 0 && y + 1 < sh) ? g[(y + 1) * sw + x] : 0u;
+    dst[k] = (uint16_t)(lo | (hi << 8));
+  }
 }
 
 // The textures once more, each with its 2-texel zero border and pitch w + 4 -- byte for byte what load_tex_padded builds in
@@ -2034,11 +2079,11 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   }
   // very wide tiles: the row sums of one destination row must fit s_buf, so the destination columns
   // are taken in chunks of twc (a handful of drops per frame; their canvas rows are sampled once per chunk)
-  const int twc_max = imax(imin(tw, BUF_MAX / ((int)ceil(sy_scale) + 3)), 1);
+  const int twc_max = imax(imin(tw, BUF_MAX / ((int)ceil(sy_scale) + 4)), 1);
   for (int dxa = 0; dxa < tw; dxa += twc_max) {
   const int twc = imin(twc_max, tw - dxa);
   const float inv_twc = 1.0f / (float)twc;
-  int k_dy = (int)(((double)(BUF_MAX / twc) - 3.0) / sy_scale);
+  int k_dy = (int)(((double)(BUF_MAX / twc) - 4.0) / sy_scale);      // (r06: was - 3.0; a group could be one row longer than s_buf)
   if (k_dy < 1) k_dy = 1;
   for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
     const int dy1 = imin(dy0 + k_dy, th);
@@ -2148,6 +2193,276 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
 }
 
 // ---------------------------------------------------------------------------
+// k_tile_rows (round 6): rotate_bound -> flip -> resize(INTER_AREA) (generator.py:163-170) by row walks
+// ---------------------------------------------------------------------------
+// k_tile gave a workgroup to every tile and staged plan + texture for each (a fifth of its wave time), passed every sample
+// through LDS twice (sample -> horizontal fold -> vertical fold) and met at block barriers.  Here:
+//   * the batch's tiles are one list bucketed by texture (k_lists' histogram, k_rows_scatter); a workgroup of 16 waves --
+//     one per CU, the LDS holds ONE texture for all of them -- takes a contiguous share of it (split by estimated cost), so
+//     a texture is staged a couple of times per workgroup instead of once per tile;
+//   * a WAVE renders a tile: no block barrier inside a tile.  Waves pull the share's tiles one by one (an LDS counter); the
+//     workgroup only meets when a wave pulls a tile of another texture than the resident one (the list is sorted, so every
+//     wave soon does): barrier, stage the texture of the lowest pending tile, barrier;
+//   * a LANE owns a canvas row and walks its columns left to right (rr_device.h): row terms X0 / Y0 and the interval of
+//     columns that can touch the texture live in the lane's registers, the per-column terms (adelta, bdelta, the fold
+//     weights) in a 16-byte table entry, the 2 x 2 texels of a sample are two adjacent elements of the "pair texture"
+//     (texel | texel below << 8), the horizontal fold runs in a register.  Two columns per iteration: both columns' table
+//     entries, then both texel pairs, then all eight table values are requested before any is used;
+//   * cell sums -> LDS (one double per row and destination column) -> the vertical fold, a lane per output pixel.
+// Every sum folds in resizeArea_'s order: the tile is bit-identical to raw_tile_pixel (the CPU tier runs the same column table
+// and walk rule against it: tests/test_tile_rows_host.py; test_raw_tile_dedup_is_invisible, test_known_answers and the oracle
+// tests on the GPU).
+__device__ inline int pair_addr(int X, int Y, int P2, int sh, int sw) {
+  const int sx = imin(imax(X >> 10, -2), sw), sy = imin(imax(Y >> 10, -2), sh);
+  return (sy + 2) * P2 + ((sx + 2) << 1);
+}
+__device__ inline uint32_t pair_fetch(const uint8_t* s_pair, int off) {            // t00 | t10 << 8 | t01 << 16 | t11 << 24
+  const uint16_t* q = reinterpret_cast<const uint16_t*>(s_pair + off);
+  return (uint32_t)q[0] | ((uint32_t)q[1] << 16);
+}
+__device__ inline double pair_blend(uint32_t u, int X, int Y, const double* s_lut) {   // lds_rot_sample's arithmetic
+  const double v00 = s_lut[u & 0xffu], v10 = s_lut[(u >> 8) & 0xffu], v01 = s_lut[(u >> 16) & 0xffu], v11 = s_lut[u >> 24];
+  const int fx = (X >> 5) & 31, fy = (Y >> 5) & 31;
+  const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
+  const double sm = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
+  return sm * (1.0 / 1024.0);
+}
+
+// one tile, by one wave.  s_pair / s_lut: the workgroup's texture and v / 255.0 table.
+__device__ inline void rows_tile(const DropPlan& p, int sh, int sw, const uint8_t* s_pair, const double* s_lut, RowsWave& W, double* arena PH_PARAMS) {
+  const int lane = threadIdx.x & 63;
+  const int tw = p.tw, th = p.th, nW = p.nW, nH = p.nH;
+  const int P2 = pair_pitch(sw) * 2;
+  double* A0 = arena + p.a0_off;
+  // ---- column table ----
+  for (int x = lane; x < nW; x += 64) {
+    W.col[x] = ColEnt{(int32_t)rot_adelta(p, x), (int32_t)rot_bdelta(p, x), 0u, 0u};
+    W.cell[x] = 0;
+  }
+  wave_lds_sync();
+  if (lane < tw) coltab_cell_pass1(p, lane, W.col, W.cell);
+  wave_lds_sync();
+  if (lane < tw) coltab_cell_pass2(p, lane, W.col, W.cell);
+  wave_lds_sync();
+  PH(1)                                               // column table
+  const RowGeom geom = row_geom(p, sh, sw);
+  const double sy_scale = p.scale_y;
+  const int twc_max = rows_twc_max(p, RW_BUF);
+  for (int dxa = 0; dxa < tw; dxa += twc_max) {
+    const int twc = imin(twc_max, tw - dxa);
+    int colA, colB;
+    cells_columns(p, dxa, dxa + twc, colA, colB);
+    const int k_dy = rows_k_dy(p, twc, RW_BUF);
+    for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
+      const int dy1 = imin(dy0 + k_dy, th);
+      const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
+      const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, nH - 1);
+      const int nrows = hi - lo + 1;
+      for (int k = lane; k < nrows * twc; k += 64) W.buf[k] = 0.0;
+      wave_lds_sync();
+      for (int r0 = 0; r0 < nrows; r0 += 64) {
+        const int r = r0 + lane;
+        int X0 = 0, Y0 = 0, xq = 0, left = 0;
+        if (r < nrows) {
+          const int c = lo + r;
+          const int ry = p.flip ? (nH - 1 - c) : c;
+          X0 = (int)rot_X0(p, ry);
+          Y0 = (int)rot_Y0(p, ry);
+          int xa, n;
+          row_interval(p, geom, X0, Y0, xa, n);
+          xq = imax(xa, colA);
+          left = imax(imin(xa + n - 1, colB) - xq + 1, 0);
+        }
+        double* out = W.buf + r * twc;
+        double* const rowend = out + twc;
+        const bool any_col = left > 0;
+        PH(2)                                         // group set-up: clear, row terms, intervals
+        double b = 0.0;
+        if (any_col) {
+          const int d0 = W.cell[xq];
+          if (d0 < dxa) {                            // (wide tiles only) the chunk's first column still ends the previous chunk's last cell:
+            const ColEnt e = W.col[xq];              //  only its left-partial role is ours
+            const int X = X0 + e.ad, Y = Y0 + e.bd;
+            b = pair_blend(pair_fetch(s_pair, pair_addr(X, Y, P2, sh, sw)), X, Y, s_lut) * (double)bits_f32(e.w2);
+            xq++;
+            left--;
+          } else {
+            out += d0 - dxa;
+          }
+        }
+        while (__ballot(left > 0) != 0ull) {
+          const bool okA = left > 0, okB = left > 1;
+          const ColEnt ea = W.col[okA ? xq : 0], eb = W.col[okB ? xq + 1 : 0];
+          const int XA = X0 + ea.ad, YA = Y0 + ea.bd, XB = X0 + eb.ad, YB = Y0 + eb.bd;
+          const uint32_t ua = pair_fetch(s_pair, pair_addr(XA, YA, P2, sh, sw)), ub = pair_fetch(s_pair, pair_addr(XB, YB, P2, sh, sw));
+          const double sa = pair_blend(ua, XA, YA, s_lut), sb = pair_blend(ub, XB, YB, s_lut);
+          const uint32_t wa = okA ? ea.w1 : 0u, wb = okB ? eb.w1 : 0u;
+          b = b + sa * (double)bits_f32(wa & 0x7fffffffu);
+          if ((int32_t)wa < 0) {
+            *out++ = b;
+            b = sa * (double)bits_f32(ea.w2);
+          }
+          b = b + sb * (double)bits_f32(wb & 0x7fffffffu);
+          if ((int32_t)wb < 0) {
+            *out++ = b;
+            b = sb * (double)bits_f32(eb.w2);
+          }
+          xq += 2;
+          left -= 2;
+        }
+        if (any_col && out < rowend) *out = b;        // the row's interval ended inside a cell
+        PH(3)                                         // the walk
+      }
+      wave_lds_sync();
+      // ---- vertical folds: a lane per output pixel of the group ----
+      const int npx = (dy1 - dy0) * twc;
+      for (int it = lane; it < npx; it += 64) {
+        const int rr_ = it / twc, dxl = it - rr_ * twc, dx = dxa + dxl, dy = dy0 + rr_;
+        const AreaSpan ay = area_span(nH, sy_scale, dy);
+        double acc = 0.0;
+        bool first = true;
+        if (ay.has_l) {
+          acc = (double)ay.a_l * W.buf[(ay.s1 - 1 - lo) * twc + dxl];
+          first = false;
+        }
+        for (int sy = ay.s1; sy < ay.s2; sy++) {
+          const double v = (double)ay.a_m * W.buf[(sy - lo) * twc + dxl];
+          acc = first ? v : acc + v;
+          first = false;
+        }
+        if (ay.has_r) {
+          const double v = (double)ay.a_r * W.buf[(ay.s2 - lo) * twc + dxl];
+          acc = first ? v : acc + v;
+        }
+        A0[dy * tw + dx] = clip01(acc);
+      }
+      wave_lds_sync();
+      PH(4)                                           // vertical folds + store
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t* tex_h, const int32_t* tex_w, Scratch sc) {
+  __shared__ __attribute__((aligned(16))) RowsWave s_w[RW_WAVES];
+  __shared__ __attribute__((aligned(16))) uint8_t s_pair[RW_PAIR_BYTES];
+  __shared__ double s_lut[256];
+  __shared__ int s_pend[RW_WAVES], s_ptex[RW_WAVES];
+  __shared__ int s_next, s_first, s_end, s_cur;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n_tex = sc.n_tex;
+  // ---- this workgroup's share of the list: buckets weighted by their texture's cost, cut into gridDim.x equal parts ----
+  int64_t* cum_cost = reinterpret_cast<int64_t*>(s_pair);                  // [n_tex + 1] (the texture is staged later)
+  int32_t* cum_cnt = reinterpret_cast<int32_t*>(s_pair + 8 * (RW_TEX_MAX + 1));   // [n_tex + 1]
+  if (wave == 0) {
+    const int per = (n_tex + 63) >> 6;
+    int64_t c_cost = 0;
+    int c_cnt = 0;
+    for (int k = 0; k < per; k++) {
+      const int tt = lane * per + k;
+      if (tt < n_tex) {
+        const int cn = sc.rows_hist[tt];
+        c_cnt += cn;
+        c_cost += (int64_t)cn * rows_tex_cost(tex_h[tt], tex_w[tt]);
+      }
+    }
+    int64_t i_cost = c_cost;
+    int i_cnt = c_cnt;
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+      const int64_t vc = (int64_t)__shfl_up((long long)i_cost, ofs);
+      const int vn = __shfl_up(i_cnt, ofs);
+      if (lane >= ofs) { i_cost += vc; i_cnt += vn; }
+    }
+    int64_t e_cost = i_cost - c_cost;
+    int e_cnt = i_cnt - c_cnt;
+    for (int k = 0; k < per; k++) {
+      const int tt = lane * per + k;
+      if (tt < n_tex) {
+        cum_cost[tt] = e_cost;
+        cum_cnt[tt] = e_cnt;
+        const int cn = sc.rows_hist[tt];
+        e_cnt += cn;
+        e_cost += (int64_t)cn * rows_tex_cost(tex_h[tt], tex_w[tt]);
+      }
+    }
+    if (lane == 63) { cum_cost[n_tex] = i_cost; cum_cnt[n_tex] = i_cnt; }
+  }
+  s_lut[t & 255] = (double)(t & 255) / 255.0;
+  __syncthreads();
+  if (t == 0) {
+    const int64_t total = cum_cost[n_tex];
+    int bound[2];
+    for (int q = 0; q < 2; q++) {
+      const int w = (int)blockIdx.x + q;
+      if (w >= (int)gridDim.x || total == 0) { bound[q] = cum_cnt[n_tex]; continue; }
+      const int64_t target = total / (int64_t)gridDim.x * w + (total % (int64_t)gridDim.x) * w / (int64_t)gridDim.x;
+      int lo = 0, hi = n_tex;                    // the last bucket whose first tile starts at or before `target`
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cum_cost[mid] <= target) lo = mid; else hi = mid;
+      }
+      const int cn = cum_cnt[lo + 1] - cum_cnt[lo];
+      const int64_t cost = rows_tex_cost(tex_h[lo], tex_w[lo]);
+      const int64_t into = (target - cum_cost[lo]) / cost;
+      bound[q] = cum_cnt[lo] + (into < (int64_t)cn ? (int)into : cn);
+    }
+    s_next = s_first = bound[0];
+    s_end = bound[1];
+    s_cur = -1;
+  }
+  __syncthreads();
+  const int end = s_end;
+  if (s_first >= end) return;                    // (the whole workgroup)
+  RowsWave& W = s_w[wave];
+  int pending = -1, ptex = -1, gi = 0;           // pending: index of the pulled tile in the list; INT_MAX: the share is used up
+  constexpr int DONE = 0x7fffffff;
+  PH_DECL
+  for (;;) {
+    if (pending < 0) {
+      int i = 0;
+      if (lane == 0) i = atomicAdd(&s_next, 1);
+      i = __builtin_amdgcn_readfirstlane(i);
+      if (i < end) {
+        pending = i;
+        gi = __builtin_amdgcn_readfirstlane(sc.rows_sorted[i]);
+        ptex = __builtin_amdgcn_readfirstlane(as_constant(&sc.plan[gi])->tex);
+      } else {
+        pending = DONE;
+      }
+    }
+    if (pending != DONE && ptex == s_cur) {
+      DropPlan p;
+      {
+        const const_ptr<uint32_t> src = as_constant(reinterpret_cast<const uint32_t*>(&sc.plan[gi]));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(DropPlan) / 4); k++) dst[k] = src[k];
+      }
+      PH(0)                                       // pull + plan
+      rows_tile(p, tex_h[ptex], tex_w[ptex], s_pair, s_lut, W, sc.arena PH_PASS);
+      pending = -1;
+      continue;
+    }
+    // another texture (or nothing left): meet the other waves
+    if (lane == 0) { s_pend[wave] = pending; s_ptex[wave] = ptex; }
+    __syncthreads();                              // nobody reads the resident texture any more
+    int m = DONE, mtex = -1;
+    for (int k = 0; k < RW_WAVES; k++)
+      if (s_pend[k] < m) { m = s_pend[k]; mtex = s_ptex[k]; }
+    if (m == DONE) break;                         // every wave is out of tiles
+    {
+      const int64_t nb = pair_bytes(tex_h[mtex], tex_w[mtex]);
+      const uint4* g = reinterpret_cast<const uint4*>(sc.tex_pair + sc.tex_qoff[mtex]);
+      uint4* d = reinterpret_cast<uint4*>(s_pair);
+      for (int k = t; k < (int)(nb >> 4); k += 1024) d[k] = g[k];
+    }
+    if (t == 0) s_cur = mtex;
+    __syncthreads();
+    PH(5)                                         // texture switch (waiting for the other waves + staging)
+  }
+  PH_FLUSH(5)
+}
+
+// ---------------------------------------------------------------------------
 // work lists: which kernel takes which drop, blur work split into items of sub-tiles
 // ---------------------------------------------------------------------------
 constexpr int BLUR_ITEMS_PER_DROP = 8;
@@ -2163,13 +2478,20 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   const int chunk = (n + 1023) / 1024;
   const int i0 = t * chunk, i1 = min(i0 + chunk, n);
   const int64_t base = (int64_t)f * max_drops;
-  // #rot-fast (general), #generic, #fused blur items, #slow blur, #small blur, #rot-fast (integer ratio), #big, big pixels
-  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  __shared__ int s_hist[RW_TEX_MAX];
+  if (sc.rows_on) {
+    for (int k = t; k < sc.n_tex; k += 1024) s_hist[k] = 0;
+    __syncthreads();
+  }
+  // #rot-fast (general), #generic, #fused blur items, #slow blur, #small blur, #rot-fast (integer ratio), #big, big pixels, #row-walk tiles
+  constexpr int NC = 9;
+  int c[NC] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {         // duplicates of another drop's raw tile render nothing
       if (p.kind == KIND_BIG) { c[6]++; c[7] += p.tw * p.th; }
+      else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) { c[8]++; atomicAdd(&s_hist[p.tex], 1); }
       else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
     }
     if (p.r1 > 0) {
@@ -2178,19 +2500,19 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
       if (L.fused) c[2] += imin(blur_subtiles(p, L), BLUR_ITEMS_PER_DROP); else c[3]++;
     }
   }
-  __shared__ int sh[1024][8];
-  for (int k = 0; k < 8; k++) sh[t][k] = c[k];
+  __shared__ int sh[1024][NC];
+  for (int k = 0; k < NC; k++) sh[t][k] = c[k];
   __syncthreads();
   for (int ofs = 1; ofs < 1024; ofs <<= 1) {
-    int v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int v[NC] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (t >= ofs)
-      for (int k = 0; k < 8; k++) v[k] = sh[t - ofs][k];
+      for (int k = 0; k < NC; k++) v[k] = sh[t - ofs][k];
     __syncthreads();
-    for (int k = 0; k < 8; k++) sh[t][k] += v[k];
+    for (int k = 0; k < NC; k++) sh[t][k] += v[k];
     __syncthreads();
   }
-  int o[8];
-  for (int k = 0; k < 8; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
+  int o[NC];
+  for (int k = 0; k < NC; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
   const int n_int = sh[1023][5];     // integer-ratio drops go to the FRONT of the rot list (longest blocks first)
   o[0] += n_int;
   int32_t* lrot = sc.list_rot + base;
@@ -2198,6 +2520,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   int32_t* lslow = sc.list_slow + base;
   int32_t* lsmall = sc.list_small + base;
   int32_t* lbig = sc.list_big + base;
+  int32_t* lrows = sc.rows_list + base;
   int32_t* boff = sc.big_off + base + f;                 // n_big + 1 entries per frame
   int4* items = sc.blur_items + base * BLUR_ITEMS_PER_DROP;
   for (int i = i0; i < i1; i++) {
@@ -2208,7 +2531,8 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
         boff[o[6]] = o[7];
         lbig[o[6]++] = i;
         o[7] += p.tw * p.th;
-      } else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
+      } else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) lrows[o[8]++] = i;
+      else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
@@ -2232,6 +2556,43 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     sc.counts[f * 8 + 5] = sh[1023][6];
     sc.counts[f * 8 + 6] = sh[1023][7];
     boff[sh[1023][6]] = sh[1023][7];
+    sc.rows_n[f] = sh[1023][8];
+  }
+  if (sc.rows_on) {                  // the frame's place inside the batch-wide buckets (any order of the frames will do)
+    for (int k = t; k < sc.n_tex; k += 1024) {
+      const int cnt = s_hist[k];
+      sc.rows_fbase[(int64_t)f * RW_TEX_MAX + k] = cnt ? atomicAdd(&sc.rows_hist[k], cnt) : 0;
+    }
+  }
+}
+
+// The frame's row-walk tiles into the batch-wide list: bucket start (prefix of the batch's histogram) + the frame's slot
+// inside the bucket + a rank among the frame's tiles of that texture.  One workgroup per frame.
+__global__ __launch_bounds__(1024) void k_rows_scatter(int max_drops, Scratch sc) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  __shared__ int s_start[RW_TEX_MAX], s_rank[RW_TEX_MAX];
+  const int nf = sc.rows_n[f];
+  if (nf == 0) return;
+  const int own = t < sc.n_tex ? sc.rows_hist[t] : 0;
+  s_start[t] = own;
+  __syncthreads();
+  for (int ofs = 1; ofs < 1024; ofs <<= 1) {
+    const int v = t >= ofs ? s_start[t - ofs] : 0;
+    __syncthreads();
+    s_start[t] += v;
+    __syncthreads();
+  }
+  const int excl = s_start[t] - own;
+  __syncthreads();
+  s_start[t] = excl;
+  s_rank[t] = t < sc.n_tex ? sc.rows_fbase[(int64_t)f * RW_TEX_MAX + t] : 0;
+  __syncthreads();
+  const int64_t base = (int64_t)f * max_drops;
+  for (int j = t; j < nf; j += 1024) {
+    const int i = sc.rows_list[base + j];
+    const int tex = sc.plan[base + i].tex;
+    const int pos = s_start[tex] + atomicAdd(&s_rank[tex], 1);
+    sc.rows_sorted[pos] = (int32_t)(base + i);
   }
 }
 
@@ -4375,6 +4736,10 @@ struct rr_ctx {
   uint8_t* d_tex_pad = nullptr;      // padded copies (k_pad_textures) + their offsets
   int64_t* d_tex_poff = nullptr;
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
+  uint8_t* d_tex_pair = nullptr;     // pair textures (k_pair_textures) + their offsets: what k_tile_rows stages
+  int64_t* d_tex_qoff = nullptr;
+  bool tile_rows = true;             // RR_OPT_TILE_ROWS: rotate + INTER_AREA tiles by row walks, a wave per tile (k_tile_rows)
+  int n_cu = 256;                    // compute units of the device (persistent kernels size their grid by it)
   bool png_deflate = false;          // RR_OPT_PNG_DEFLATE: the PNG outputs hold zlib streams (rr_deflate.h)
   uint8_t* d_pngz_slots = nullptr;
   rrz::BlockMeta* d_pngz_meta = nullptr;
@@ -4625,6 +4990,11 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.npts, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.sizes, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_rot, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_list, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_sorted, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_n, (size_t)F))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_hist, (size_t)RW_TEX_MAX))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_fbase, (size_t)F * RW_TEX_MAX))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list_n, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_gen, fd))) return rc;
@@ -4799,6 +5169,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   sc.overflow = ctx->sc.overflow + ovf_idx;
   sc.tex_pad = ctx->padded_tex ? ctx->d_tex_pad : nullptr;
   sc.tex_poff = ctx->d_tex_poff;
+  sc.tex_pair = ctx->d_tex_pair;
+  sc.tex_qoff = ctx->d_tex_qoff;
+  sc.n_tex = ctx->n_tex;
+  sc.rows_on = (ctx->tile_rows && ctx->d_tex_pair && ctx->n_tex <= RW_TEX_MAX) ? 1 : 0;
   const int blur_wg = ctx->blur_wg ? ctx->blur_wg : 4;      // workgroups per CU the fused blur is sized for
   sc.blur_bx = blur_wg == 3 ? 3072 : (blur_wg == 5 ? 2304 : 2816);
   sc.blur_by = blur_wg == 5 ? 1600 : 2048;
@@ -4964,11 +5338,13 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, bs, "k_dedup");
       HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, bs));
       HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, bs));
+      if (sc.rows_on) HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * RW_TEX_MAX, bs));
       hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
       ProfScope ps(ctx, bs, "k_lists");
       hipLaunchKernelGGL(k_lists, dim3(n), dim3(1024), 0, bs, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
+      if (sc.rows_on) hipLaunchKernelGGL(k_rows_scatter, dim3(n), dim3(1024), 0, bs, D, sc);
     }
     if (bs != s) {                                         // mode 2: k_colour beside the tile kernels; the tiles wait for the lists
       HIPCHK(hipEventRecord(ctx->ev_lists, bs));
@@ -4988,6 +5364,14 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_tile_big");
       hipLaunchKernelGGL(k_tile_big, dim3(1024, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
                          ctx->d_tex_off, ctx->d_ctab, sc);
+    }
+    if (sc.rows_on) {
+      ProfScope ps(ctx, s, "k_tile_rows");
+      // one workgroup of 16 waves per CU (the LDS holds one texture + 16 wave-private tables); fewer for small batches:
+      // a workgroup's share of the list should be worth staging a texture for
+      const int64_t tiles_max = (int64_t)n * max_drops;
+      const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, (tiles_max + 31) / 32));
+      hipLaunchKernelGGL(k_tile_rows, dim3(wgs), dim3(64 * RW_WAVES), 0, s, D, ctx->d_tex_h, ctx->d_tex_w, sc);
     }
     {
       ProfScope ps(ctx, s, "k_tile");
@@ -5364,6 +5748,7 @@ int rr_create(rr_ctx** out, int device) {
   if (prop.warpSize != 64) return RR_E_NO_DEVICE;
   rr_ctx* ctx = new rr_ctx();
   ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return RR_E_HIP;
@@ -5403,6 +5788,13 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.npts);
   hipFree(ctx->sc.sizes);
   hipFree(ctx->sc.list_rot);
+  hipFree(ctx->sc.rows_list);
+  hipFree(ctx->sc.rows_sorted);
+  hipFree(ctx->sc.rows_n);
+  hipFree(ctx->sc.rows_hist);
+  hipFree(ctx->sc.rows_fbase);
+  hipFree(ctx->d_tex_pair);
+  hipFree(ctx->d_tex_qoff);
   hipFree(ctx->sc.fov_list);
   hipFree(ctx->sc.fov_list_n);
   hipFree(ctx->sc.list_gen);
@@ -5534,6 +5926,23 @@ static int set_db_meta(rr_ctx* ctx, const int32_t* tex_h, const int32_t* tex_w, 
     HIPCHK(hipDeviceSynchronize());    // (the copies above and the fill may still be in flight on the null stream; ours does not wait for it)
     hipLaunchKernelGGL(k_pad_textures, dim3(n_tex), dim3(256), 0, ctx->stream, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off,
                        ctx->d_tex_poff, ctx->d_tex_pad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  {                                     // the pair textures k_tile_rows stages (texel | texel below << 8, rr_device.h)
+    std::vector<int64_t> qoff((size_t)n_tex);
+    int64_t total = 0;
+    for (int i = 0; i < n_tex; i++) {
+      qoff[(size_t)i] = total;
+      total += pair_bytes(tex_h[i], tex_w[i]);
+    }
+    if ((rc = dev_alloc(ctx, ctx->d_tex_qoff, (size_t)n_tex))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->d_tex_pair, (size_t)total + 16))) return rc;
+    HIPCHK(hipMemcpy(ctx->d_tex_qoff, qoff.data(), sizeof(int64_t) * (size_t)n_tex, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ctx->d_tex_pair, 0, (size_t)total + 16));
+    HIPCHK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_pair_textures, dim3(n_tex), dim3(256), 0, ctx->stream, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off,
+                       ctx->d_tex_qoff, ctx->d_tex_pair);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
@@ -6474,6 +6883,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
+    case RR_OPT_TILE_ROWS: ctx->tile_rows = value != 0; return RR_OK;
     case RR_OPT_FOV_FILL_RULE: ctx->fill_rule = value == 1 ? 1 : 0; return RR_OK;
     case RR_OPT_BIN_ROWS: ctx->bin_rows = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;

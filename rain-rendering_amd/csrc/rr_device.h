@@ -409,6 +409,72 @@ RR_HD double raw_tile_pixel(const DropPlan& p, const Tex& tx, const float* ctab,
 }
 
 // ---------------------------------------------------------------------------
+// The same tile by ROW WALKS (k_tile_rows, round 6): one lane owns one canvas row and walks the columns that can touch
+// the texture from left to right.  The horizontal folds of resizeArea_ then run in a register -- a column's sample is
+// added to the sum of the destination cell it belongs to, with that cell's weight, in exactly area_hsum's order -- and
+// only the finished cell sums (one double per row and destination column) pass through LDS for the vertical fold.
+//
+// A column table says, per canvas column, what a walk does with the sample s it took there:
+//     b = b + s * |w1|;  if (sign bit of w1) { cell sum is complete: store b, next cell; b = s * w2; }
+//   w1   the column's weight in the cell it is a full or right-partial column of (a_m / a_r); a_l when the column is
+//        ONLY the left partial of a cell (no cell owns it: 0.0 + s * a_l == s * a_l, the value area_hsum starts from);
+//        0 when no cell reads the column.  Sign bit: the column is the last one its cell reads.
+//   w2   a_l of the NEXT cell when the column is also that cell's left partial, else 0 (then b restarts at +0.0).
+// Requires scale_x >= 2 (every cell then has a full or right-partial column to carry the sign bit).
+// ---------------------------------------------------------------------------
+struct ColEnt {
+  int32_t ad, bd;            // rot_adelta / rot_bdelta of the column
+  uint32_t w1, w2;           // float bits, see above
+};
+RR_HD uint32_t f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+RR_HD float bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+// pass 1, one call per destination column d (after every entry was set to {ad, bd, 0, 0} and cell[] to 0): the columns
+// cell d owns.  `cell[x]` = the destination column a walk that STARTS at x is in.
+RR_HD void coltab_cell_pass1(const DropPlan& p, int d, ColEnt* col, uint8_t* cell) {
+  const AreaSpan A = area_span(p.nW, p.scale_x, d);
+  const uint32_t am = f32_bits(A.a_m);
+  for (int x = A.s1; x < A.s2; x++) { col[x].w1 = am; cell[x] = (uint8_t)d; }
+  int R = A.s2 - 1;
+  if (A.has_r) { col[A.s2].w1 = f32_bits(A.a_r); cell[A.s2] = (uint8_t)d; R = A.s2; }
+  if (R >= 0) col[R].w1 |= 0x80000000u;
+}
+// pass 2 (after pass 1 of EVERY cell): the left partial column of cell d -- shared with the end of cell d - 1, or nobody's
+RR_HD void coltab_cell_pass2(const DropPlan& p, int d, ColEnt* col, uint8_t* cell) {
+  const AreaSpan A = area_span(p.nW, p.scale_x, d);
+  if (!A.has_l || A.s1 < 1) return;
+  const int c = A.s1 - 1;
+  if (col[c].w1 & 0x80000000u) col[c].w2 = f32_bits(A.a_l);
+  else { col[c].w1 = f32_bits(A.a_l); cell[c] = (uint8_t)d; }
+}
+// first / last canvas column the cells [da, db) read
+RR_HD void cells_columns(const DropPlan& p, int da, int db, int& c0, int& c1) {
+  const AreaSpan A = area_span(p.nW, p.scale_x, da), B = area_span(p.nW, p.scale_x, db - 1);
+  c0 = (A.has_l && A.s1 >= 1) ? A.s1 - 1 : A.s1;
+  c1 = B.has_r ? B.s2 : B.s2 - 1;
+}
+// destination columns a wave takes at a time (the row sums of one destination row must fit `buf` doubles) and
+// destination rows per group of canvas rows: the k that needs the fewest passes of 64 canvas rows over the tile
+RR_HD int rows_twc_max(const DropPlan& p, int buf) { return imax(imin(p.tw, buf / ((int)ceil(p.scale_y) + 4)), 1); }
+RR_HD int rows_group_rows(const DropPlan& p, int k) { return (int)floor((double)k * p.scale_y) + 4; }     // upper bound of hi - lo + 1 (a row of margin either side)
+RR_HD int rows_k_dy(const DropPlan& p, int twc, int buf) {
+  int kmax = (int)(((double)(buf / twc) - 4.0) / p.scale_y);
+  kmax = imax(imin(kmax, p.th), 1);
+  int best = kmax, best_cost = ((p.th + kmax - 1) / kmax) * ((rows_group_rows(p, kmax) + 63) >> 6);
+  for (int m = 1; m * 64 < rows_group_rows(p, kmax); m++) {
+    int k = imax(imin((int)(((double)(64 * m) - 4.0) / p.scale_y), kmax), 1);
+    const int cost = ((p.th + k - 1) / k) * ((rows_group_rows(p, k) + 63) >> 6);
+    if (cost < best_cost) { best = k; best_cost = cost; }
+  }
+  return best;
+}
+// pair texture: u16 element (y, x) = texel (y, x) | texel (y + 1, x) << 8 for y = -2 .. sh, x = -2 .. pitch - 3 (zeros
+// outside the texture): the 2 x 2 neighbourhood of a bilinear sample is two adjacent elements.  pitch / 2 is odd, so
+// lanes on consecutive texture rows read different LDS banks.
+RR_HD int pair_pitch(int sw) { int q = sw + 4; while ((q & 3) != 2) q++; return q; }
+RR_HD int64_t pair_bytes(int sh, int sw) { return ((int64_t)(sh + 3) * pair_pitch(sw) * 2 + 15) & ~15LL; }
+
+// ---------------------------------------------------------------------------
 // field-of-view polygon   (bad_weather.py:596-704)
 // ---------------------------------------------------------------------------
 RR_HD void rotmat(const double a[3], double c, double s, double R[9]) {   // bad_weather.py:532-538

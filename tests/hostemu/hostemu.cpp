@@ -194,6 +194,128 @@ int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, con
   return 0;
 }
 
+// ---- the row-walk form of the rotate + INTER_AREA tile (k_tile_rows, rainhip.hip), lane by lane ----
+// Same column table (coltab_cell_pass1 / 2), same walk rule, same chunking (rows_twc_max / rows_k_dy with `buf` doubles of
+// cell sums) and the same 2 x 2 fetch from a pair texture as the kernel; the lanes of a wave run one after the other.
+// out[th*tw] = the raw tile; also out_def[th*tw] = raw_tile_pixel (the definition).  Returns the number of pixels that
+// differ in any bit, or -1 when the plan is not one k_tile_rows takes.
+int emu_tile_rows(const DropPlan* pp, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off, int buf,
+                  double* out, double* out_def) {
+  const DropPlan& p = *pp;
+  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  if (!(p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.tw >= 1 && p.tw <= 64 && p.th >= 1 && (int)ceil(p.scale_y) + 4 <= buf)) return -1;
+  float ctab[128];
+  build_cubic_tab(ctab);
+  TexGlobal tx{texels + tex_off[p.tex], sh, sw};
+  const uint8_t* g = texels + tex_off[p.tex];
+  // pair texture (k_pair_textures)
+  const int P = pair_pitch(sw);
+  std::vector<uint16_t> pair((size_t)(sh + 3) * P);
+  for (int k = 0; k < (sh + 3) * P; k++) {
+    const int y = k / P - 2, x = k - (y + 2) * P - 2;
+    const bool xin = x >= 0 && x < sw;
+    const uint32_t lo = (xin && y >= 0 && y < sh) ? g[y * sw + x] : 0u, hi = (xin && y + 1 >= 0 && y + 1 < sh) ? g[(y + 1) * sw + x] : 0u;
+    pair[k] = (uint16_t)(lo | (hi << 8));
+  }
+  double lut[256];
+  for (int k = 0; k < 256; k++) lut[k] = (double)k / 255.0;
+  auto sample = [&](int X, int Y) {
+    const int sx = imin(imax(X >> 10, -2), sw), sy = imin(imax(Y >> 10, -2), sh);
+    const int e = (sy + 2) * P + (sx + 2);
+    const uint32_t u = (uint32_t)pair[e] | ((uint32_t)pair[e + 1] << 16);
+    const double v00 = lut[u & 0xffu], v10 = lut[(u >> 8) & 0xffu], v01 = lut[(u >> 16) & 0xffu], v11 = lut[u >> 24];
+    const int fx = (X >> 5) & 31, fy = (Y >> 5) & 31;
+    const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
+    const double sm = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
+    return sm * (1.0 / 1024.0);
+  };
+  const int tw = p.tw, th = p.th, nW = p.nW, nH = p.nH;
+  std::vector<ColEnt> col((size_t)nW);
+  std::vector<uint8_t> cell((size_t)nW, 0);
+  for (int x = 0; x < nW; x++) col[x] = ColEnt{(int32_t)rot_adelta(p, x), (int32_t)rot_bdelta(p, x), 0u, 0u};
+  for (int d = 0; d < tw; d++) coltab_cell_pass1(p, d, col.data(), cell.data());
+  for (int d = 0; d < tw; d++) coltab_cell_pass2(p, d, col.data(), cell.data());
+  std::vector<double> B((size_t)buf);
+  const double sy_scale = p.scale_y;
+  const int twc_max = rows_twc_max(p, buf);
+  for (int dxa = 0; dxa < tw; dxa += twc_max) {
+    const int twc = imin(twc_max, tw - dxa);
+    int colA, colB;
+    cells_columns(p, dxa, dxa + twc, colA, colB);
+    const int k_dy = rows_k_dy(p, twc, buf);
+    for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
+      const int dy1 = imin(dy0 + k_dy, th);
+      const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
+      const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, nH - 1);
+      const int nrows = hi - lo + 1;
+      if (nrows * twc > buf) return -2;
+      for (int k = 0; k < nrows * twc; k++) B[k] = 0.0;
+      for (int r = 0; r < nrows; r++) {
+        const int c = lo + r, ry = p.flip ? (nH - 1 - c) : c;
+        const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
+        // the interval of columns whose samples can be non-zero, found by brute force with a margin (the kernel's row_interval
+        // is a conservative bound of the same thing; any superset gives the same sums)
+        int xa = nW, xe = -1;
+        for (int x = 0; x < nW; x++)
+          if (sample(X0 + col[x].ad, Y0 + col[x].bd) != 0.0) { xa = imin(xa, x); xe = imax(xe, x); }
+        xa = imax(xa - (r % 3), 0);                   // ragged margins: a walk may start and end anywhere outside the non-zero run
+        xe = imin(xe + (r % 2), nW - 1);
+        int xq = imax(xa, colA), left = imax(imin(xe, colB) - xq + 1, 0);
+        double* o = B.data() + r * twc;
+        double* const rowend = o + twc;
+        const bool any_col = left > 0;
+        double b = 0.0;
+        if (any_col) {
+          const int d0 = cell[xq];
+          if (d0 < dxa) {
+            const ColEnt e = col[xq];
+            b = sample(X0 + e.ad, Y0 + e.bd) * (double)bits_f32(e.w2);
+            xq++;
+            left--;
+          } else {
+            o += d0 - dxa;
+          }
+        }
+        for (; left > 0; left--, xq++) {
+          const ColEnt e = col[xq];
+          const double s = sample(X0 + e.ad, Y0 + e.bd);
+          b = b + s * (double)bits_f32(e.w1 & 0x7fffffffu);
+          if ((int32_t)e.w1 < 0) {
+            if (o >= rowend) return -3;
+            *o++ = b;
+            b = s * (double)bits_f32(e.w2);
+          }
+        }
+        if (any_col && o < rowend) *o = b;
+      }
+      for (int it = 0; it < (dy1 - dy0) * twc; it++) {
+        const int rr_ = it / twc, dxl = it - rr_ * twc, dx = dxa + dxl, dy = dy0 + rr_;
+        const AreaSpan ay = area_span(nH, sy_scale, dy);
+        double acc = 0.0;
+        bool first = true;
+        if (ay.has_l) { acc = (double)ay.a_l * B[(ay.s1 - 1 - lo) * twc + dxl]; first = false; }
+        for (int sy = ay.s1; sy < ay.s2; sy++) {
+          const double v = (double)ay.a_m * B[(sy - lo) * twc + dxl];
+          acc = first ? v : acc + v;
+          first = false;
+        }
+        if (ay.has_r) {
+          const double v = (double)ay.a_r * B[(ay.s2 - lo) * twc + dxl];
+          acc = first ? v : acc + v;
+        }
+        out[dy * tw + dx] = clip01(acc);
+      }
+    }
+  }
+  int bad = 0;
+  for (int y = 0; y < th; y++)
+    for (int x = 0; x < tw; x++) {
+      out_def[y * tw + x] = raw_tile_pixel(p, tx, ctab, x, y);
+      if (memcmp(&out_def[y * tw + x], &out[y * tw + x], 8) != 0) bad++;
+    }
+  return bad;
+}
+
 // whole frame, mirroring the kernel chain.  depth (may be NULL): the depth-occlusion OPTION (RR_OPT_DEPTH_OCCLUSION;
 // definition: oracle/render.py _visible) -- H*W scene depth in metres, float32 or float64; a drop whose |world z| is
 // greater than the scene depth at a pixel is neither blended nor added to the mask there.
