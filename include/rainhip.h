@@ -448,7 +448,7 @@ int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes);
 int rr_host_free(rr_ctx* ctx, void* p);
 
 /* Work-list sizes of frame `frame` of the last batch (after completion): out[0] drops whose raw tile went
- * through the rotate+resize kernel, [1] through the generic kernel, [2] fused-blur work items, [3] slow-blur
+ * through the rotate+resize kernels (k_tile_rows + k_tile), [1] through the generic kernel, [2] fused-blur work items, [3] slow-blur
  * drops, [4] small-blur drops, [5] Big drops (bicubic warp kernel), [6] their pixels, [7] drops that re-used
  * another drop's bit-identical raw tile (k_dedup). */
 int rr_batch_counts(rr_ctx* ctx, int32_t frame, int32_t out[8]);

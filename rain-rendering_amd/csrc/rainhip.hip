@@ -250,6 +250,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* rows_list;               // [frame][drops] frame-local indices of the drops k_tile_rows renders (k_lists)
   int32_t* rows_n;                  // [frame] their number
   int32_t* rows_hist;               // [RW_TEX_MAX] tiles per texture, batch-wide (zeroed per call)
+  unsigned long long* rows_cost;    // [RW_TEX_MAX] their estimated cost (behind rows_hist: one memset)
   int32_t* rows_fbase;              // [frame][RW_TEX_MAX] first slot of the frame inside its textures' buckets
   int32_t* rows_sorted;             // [frames * drops] batch-global drop indices, bucket after bucket (k_rows_scatter)
   const uint8_t* tex_pair;          // pair textures (k_pair_textures) and their offsets (multiples of 16)
@@ -1695,10 +1696,15 @@ struct RowsWave {                     // wave-private LDS of k_tile_rows
 static_assert(sizeof(RowsWave) == 8336 && sizeof(RowsWave) % 16 == 0, "RowsWave layout (col[] is read 16 bytes at a time)");
 // estimated cost of a tile of this texture (its samples ~ the padded texture's area, plus the per-tile set-up), for the
 // split of the sorted list among the workgroups
-__device__ inline int64_t rows_tex_cost(int sh, int sw) { return (int64_t)(sh + 8) * (sw + 12) + 2000; }
+// estimated cost of a tile in walk iterations (passes x columns a row can touch, + the per-pass and per-tile set-up)
+__device__ inline int rows_tile_cost(const DropPlan& p, int sh, int sw) {
+  const int twc = rows_twc_max(p, RW_BUF), R = rows_per_pass(twc, RW_BUF);
+  const int passes = ((p.nH + R - 1) / R) * ((p.tw + twc - 1) / twc);
+  return passes * (imin(tile_pitch(p, sh, sw), p.nW) / 2 + 12) + 24;
+}
 __device__ inline bool tile_is_rows(const DropPlan& p, int sh, int sw) {
   return p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.nW <= RW_NW && p.tw <= 64 && p.tw >= 1 && p.th >= 1 &&
-         (int)ceil(p.scale_y) + 4 <= RW_BUF && pair_bytes(sh, sw) <= RW_PAIR_BYTES && tile_coords_safe(p);
+         pair_bytes(sh, sw) <= RW_PAIR_BYTES && tile_coords_safe(p);
 }
 __global__ __launch_bounds__(256) void k_pair_textures(const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w,
                                                        const int64_t* tex_off, const int64_t* tex_qoff, uint8_t* pairs) {
@@ -2212,27 +2218,52 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
 // Every sum folds in resizeArea_'s order: the tile is bit-identical to raw_tile_pixel (the CPU tier runs the same column table
 // and walk rule against it: tests/test_tile_rows_host.py; test_raw_tile_dedup_is_invisible, test_known_answers and the oracle
 // tests on the GPU).
-__device__ inline int pair_addr(int X, int Y, int P2, int sh, int sw) {
-  const int sx = imin(imax(X >> 10, -2), sw), sy = imin(imax(Y >> 10, -2), sh);
-  return (sy + 2) * P2 + ((sx + 2) << 1);
+struct RowsShared {                   // the ONE shared variable of k_tile_rows
+  double lut[256];                    // v / 255.0; first, i.e. at LDS address 0 (checked at run time): the sampler's byte * 8 IS the address
+  uint8_t pair[RW_PAIR_BYTES];        // the resident texture
+  RowsWave w[RW_WAVES];
+  int pend[RW_WAVES], ptex[RW_WAVES];
+  int next, first, end, cur;
+};
+typedef const double __attribute__((address_space(3)))* lds_cdouble;
+// (byte B of v) << 3 in one instruction
+template <int B>
+__device__ inline uint32_t byte_x8(uint32_t v, uint32_t three) {
+  uint32_t r;
+  if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(v));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(v));
+  return r;
 }
-__device__ inline uint32_t pair_fetch(const uint8_t* s_pair, int off) {            // t00 | t10 << 8 | t01 << 16 | t11 << 24
-  const uint16_t* q = reinterpret_cast<const uint16_t*>(s_pair + off);
-  return (uint32_t)q[0] | ((uint32_t)q[1] << 16);
+__device__ inline int med3i(int x, int lo, int hi) {      // clamp(x, lo, hi), lo <= hi
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+  return r;
 }
-__device__ inline double pair_blend(uint32_t u, int X, int Y, const double* s_lut) {   // lds_rot_sample's arithmetic
-  const double v00 = s_lut[u & 0xffu], v10 = s_lut[(u >> 8) & 0xffu], v01 = s_lut[(u >> 16) & 0xffu], v11 = s_lut[u >> 24];
-  const int fx = (X >> 5) & 31, fy = (Y >> 5) & 31;
-  const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
-  const double sm = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
-  return sm * (1.0 / 1024.0);
+// Bilinear sample of warpAffine (rot_sample's arithmetic) WITHOUT its division by 1024 (the column table's weights carry
+// it).  Xb, Yb: the 10-bit fixed-point source coordinates + 2048 (two texels of zero border, so that the clamped
+// coordinates index the pair texture directly).  The two halves: addresses + texel fetch, then table look-ups + blend.
+struct RowsSample {
+  uint32_t ta, tb;                    // pair elements (sy, sx), (sy, sx + 1): texel | texel below << 8
+};
+__device__ inline RowsSample rows_fetch(const uint8_t* s_pair, int Xb, int Yb, int P2, int sh2, int sw2) {
+  const int sx = med3i(Xb >> 10, 0, sw2), sy = med3i(Yb >> 10, 0, sh2);
+  const uint16_t* q = reinterpret_cast<const uint16_t*>(s_pair + (sy * P2 + (sx << 1)));
+  return RowsSample{q[0], q[1]};
+}
+__device__ inline double rows_blend(const RowsSample& t, int Xb, int Yb, uint32_t three) {
+  const double v00 = *(lds_cdouble)(uintptr_t)byte_x8<0>(t.ta, three), v10 = *(lds_cdouble)(uintptr_t)byte_x8<1>(t.ta, three);
+  const double v01 = *(lds_cdouble)(uintptr_t)byte_x8<0>(t.tb, three), v11 = *(lds_cdouble)(uintptr_t)byte_x8<1>(t.tb, three);
+  const double bx_ = (double)((Xb >> 5) & 31), by_ = (double)((Yb >> 5) & 31);
+  const double ax_ = 32.0 - bx_, ay_ = 32.0 - by_;
+  return ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
 }
 
-// one tile, by one wave.  s_pair / s_lut: the workgroup's texture and v / 255.0 table.
-__device__ inline void rows_tile(const DropPlan& p, int sh, int sw, const uint8_t* s_pair, const double* s_lut, RowsWave& W, double* arena PH_PARAMS) {
+// one tile, by one wave
+__device__ inline void rows_tile(const DropPlan& p, int sh, int sw, RowsShared& S, RowsWave& W, double* arena, uint32_t three PH_PARAMS) {
   const int lane = threadIdx.x & 63;
   const int tw = p.tw, th = p.th, nW = p.nW, nH = p.nH;
-  const int P2 = pair_pitch(sw) * 2;
+  const int P2 = pair_pitch(sw) * 2, sh2 = sh + 2, sw2 = sw + 2;
+  const uint8_t* s_pair = S.pair;
   double* A0 = arena + p.a0_off;
   // ---- column table ----
   for (int x = lane; x < nW; x += 64) {
@@ -2252,89 +2283,88 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, const uint8_
     const int twc = imin(twc_max, tw - dxa);
     int colA, colB;
     cells_columns(p, dxa, dxa + twc, colA, colB);
-    const int k_dy = rows_k_dy(p, twc, RW_BUF);
-    for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
-      const int dy1 = imin(dy0 + k_dy, th);
-      const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
-      const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, nH - 1);
-      const int nrows = hi - lo + 1;
+    const int R = rows_per_pass(twc, RW_BUF);
+    double* const carry = W.buf + R * twc;            // accumulators of the destination row that straddles a pass end
+    for (int R0 = 0; R0 < nH; R0 += R) {
+      const int R1 = imin(R0 + R, nH) - 1, nrows = R1 - R0 + 1;
       for (int k = lane; k < nrows * twc; k += 64) W.buf[k] = 0.0;
-      wave_lds_sync();
-      for (int r0 = 0; r0 < nrows; r0 += 64) {
-        const int r = r0 + lane;
-        int X0 = 0, Y0 = 0, xq = 0, left = 0;
-        if (r < nrows) {
-          const int c = lo + r;
-          const int ry = p.flip ? (nH - 1 - c) : c;
-          X0 = (int)rot_X0(p, ry);
-          Y0 = (int)rot_Y0(p, ry);
-          int xa, n;
-          row_interval(p, geom, X0, Y0, xa, n);
-          xq = imax(xa, colA);
-          left = imax(imin(xa + n - 1, colB) - xq + 1, 0);
-        }
-        double* out = W.buf + r * twc;
-        double* const rowend = out + twc;
-        const bool any_col = left > 0;
-        PH(2)                                         // group set-up: clear, row terms, intervals
-        double b = 0.0;
-        if (any_col) {
-          const int d0 = W.cell[xq];
-          if (d0 < dxa) {                            // (wide tiles only) the chunk's first column still ends the previous chunk's last cell:
-            const ColEnt e = W.col[xq];              //  only its left-partial role is ours
-            const int X = X0 + e.ad, Y = Y0 + e.bd;
-            b = pair_blend(pair_fetch(s_pair, pair_addr(X, Y, P2, sh, sw)), X, Y, s_lut) * (double)bits_f32(e.w2);
-            xq++;
-            left--;
-          } else {
-            out += d0 - dxa;
-          }
-        }
-        while (__ballot(left > 0) != 0ull) {
-          const bool okA = left > 0, okB = left > 1;
-          const ColEnt ea = W.col[okA ? xq : 0], eb = W.col[okB ? xq + 1 : 0];
-          const int XA = X0 + ea.ad, YA = Y0 + ea.bd, XB = X0 + eb.ad, YB = Y0 + eb.bd;
-          const uint32_t ua = pair_fetch(s_pair, pair_addr(XA, YA, P2, sh, sw)), ub = pair_fetch(s_pair, pair_addr(XB, YB, P2, sh, sw));
-          const double sa = pair_blend(ua, XA, YA, s_lut), sb = pair_blend(ub, XB, YB, s_lut);
-          const uint32_t wa = okA ? ea.w1 : 0u, wb = okB ? eb.w1 : 0u;
-          b = b + sa * (double)bits_f32(wa & 0x7fffffffu);
-          if ((int32_t)wa < 0) {
-            *out++ = b;
-            b = sa * (double)bits_f32(ea.w2);
-          }
-          b = b + sb * (double)bits_f32(wb & 0x7fffffffu);
-          if ((int32_t)wb < 0) {
-            *out++ = b;
-            b = sb * (double)bits_f32(eb.w2);
-          }
-          xq += 2;
-          left -= 2;
-        }
-        if (any_col && out < rowend) *out = b;        // the row's interval ended inside a cell
-        PH(3)                                         // the walk
+      // ---- the pass: lane = canvas row R0 + lane ----
+      int X0 = 0, Y0 = 0, xq = 0, left = 0;
+      if (lane < nrows) {
+        const int c = R0 + lane;
+        const int ry = p.flip ? (nH - 1 - c) : c;
+        X0 = (int)rot_X0(p, ry);
+        Y0 = (int)rot_Y0(p, ry);
+        int xa, n;
+        row_interval(p, geom, X0, Y0, xa, n);
+        xq = imax(xa, colA);
+        left = imax(imin(xa + n - 1, colB) - xq + 1, 0);
+        X0 += 2048;
+        Y0 += 2048;
       }
       wave_lds_sync();
-      // ---- vertical folds: a lane per output pixel of the group ----
-      const int npx = (dy1 - dy0) * twc;
-      for (int it = lane; it < npx; it += 64) {
-        const int rr_ = it / twc, dxl = it - rr_ * twc, dx = dxa + dxl, dy = dy0 + rr_;
+      double* out = W.buf + lane * twc;
+      double* const rowend = out + twc;
+      const bool any_col = left > 0;
+      double b = 0.0;
+      if (any_col) {
+        const int d0 = W.cell[xq];
+        if (d0 < dxa) {                              // (wide tiles only) the chunk's first column still ends the previous chunk's last cell:
+          const ColEnt e = W.col[xq];                //  only its left-partial role is ours
+          const int X = X0 + e.ad, Y = Y0 + e.bd;
+          b = rows_blend(rows_fetch(s_pair, X, Y, P2, sh2, sw2), X, Y, three) * (double)bits_f32(e.w2);
+          xq++;
+          left--;
+        } else {
+          out += d0 - dxa;
+        }
+      }
+      PH(2)                                           // pass set-up: clear, row terms, intervals
+      // Two columns per iteration.  The table entries are read whether or not the lane still has columns (a lane that is
+      // done reads on into whatever follows -- always inside the workgroup's LDS, always a finite sample -- and folds it
+      // with weight 0).
+      const ColEnt* cp = W.col + xq;
+      while (__ballot(left > 0) != 0ull) {
+        const ColEnt ea = cp[0], eb = cp[1];
+        const int XA = X0 + ea.ad, YA = Y0 + ea.bd, XB = X0 + eb.ad, YB = Y0 + eb.bd;
+        const RowsSample ta = rows_fetch(s_pair, XA, YA, P2, sh2, sw2), tb = rows_fetch(s_pair, XB, YB, P2, sh2, sw2);
+        const double sa = rows_blend(ta, XA, YA, three), sb = rows_blend(tb, XB, YB, three);
+        const uint32_t wa = left > 0 ? ea.w1 : 0u, wb = left > 1 ? eb.w1 : 0u;
+        b = b + sa * (double)bits_f32(wa & 0x7fffffffu);
+        if ((int32_t)wa < 0) {
+          *out++ = b;
+          b = sa * (double)bits_f32(ea.w2);
+        }
+        b = b + sb * (double)bits_f32(wb & 0x7fffffffu);
+        if ((int32_t)wb < 0) {
+          *out++ = b;
+          b = sb * (double)bits_f32(eb.w2);
+        }
+        cp += 2;
+        left -= 2;
+      }
+      if (any_col && out < rowend) *out = b;          // the row's interval ended inside a cell
+      PH(3)                                           // the walk
+      wave_lds_sync();
+      // ---- vertical folds of the destination rows that read rows R0 .. R1: a lane per (destination row, column) ----
+      const int dyG = imax((int)floor((double)R0 * p.inv_sy) - 1, 0);            // the first candidate; rows before it ended before R0
+      const int dyE = imin((int)floor((double)(R1 + 1) * p.inv_sy) + 2, th);     // one past the last candidate
+      const int n_out = (dyE - dyG) * twc;
+      for (int it = lane; it < n_out; it += 64) {
+        const int dq = it / twc, dxl = it - dq * twc, dy = dyG + dq;
         const AreaSpan ay = area_span(nH, sy_scale, dy);
+        int fr, lr;
+        vfold_rows(ay, fr, lr);
+        if (lr < R0 || fr > R1) continue;
         double acc = 0.0;
         bool first = true;
-        if (ay.has_l) {
-          acc = (double)ay.a_l * W.buf[(ay.s1 - 1 - lo) * twc + dxl];
+        if (fr < R0) {                               // begun in an earlier pass
+          acc = carry[dxl];
           first = false;
         }
-        for (int sy = ay.s1; sy < ay.s2; sy++) {
-          const double v = (double)ay.a_m * W.buf[(sy - lo) * twc + dxl];
-          acc = first ? v : acc + v;
-          first = false;
-        }
-        if (ay.has_r) {
-          const double v = (double)ay.a_r * W.buf[(ay.s2 - lo) * twc + dxl];
-          acc = first ? v : acc + v;
-        }
-        A0[dy * tw + dx] = clip01(acc);
+        vfold_part(ay, R0, R1, acc, first, [&](int row) { return W.buf[(row - R0) * twc + dxl]; });
+        if (lr <= R1) A0[dy * tw + dxa + dxl] = clip01(acc);
+        else carry[dxl] = acc;
       }
       wave_lds_sync();
       PH(4)                                           // vertical folds + store
@@ -2343,16 +2373,13 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, const uint8_
 }
 
 __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t* tex_h, const int32_t* tex_w, Scratch sc) {
-  __shared__ __attribute__((aligned(16))) RowsWave s_w[RW_WAVES];
-  __shared__ __attribute__((aligned(16))) uint8_t s_pair[RW_PAIR_BYTES];
-  __shared__ double s_lut[256];
-  __shared__ int s_pend[RW_WAVES], s_ptex[RW_WAVES];
-  __shared__ int s_next, s_first, s_end, s_cur;
+  __shared__ __attribute__((aligned(16))) RowsShared S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n_tex = sc.n_tex;
-  // ---- this workgroup's share of the list: buckets weighted by their texture's cost, cut into gridDim.x equal parts ----
-  int64_t* cum_cost = reinterpret_cast<int64_t*>(s_pair);                  // [n_tex + 1] (the texture is staged later)
-  int32_t* cum_cnt = reinterpret_cast<int32_t*>(s_pair + 8 * (RW_TEX_MAX + 1));   // [n_tex + 1]
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)S.lut != 0u) __builtin_trap();   // (see RowsShared)
+  // ---- this workgroup's share of the list: buckets weighted by the cost of their tiles, cut into gridDim.x equal parts ----
+  int64_t* cum_cost = reinterpret_cast<int64_t*>(S.pair);                  // [n_tex + 1] (the texture is staged later)
+  int32_t* cum_cnt = reinterpret_cast<int32_t*>(S.pair + 8 * (RW_TEX_MAX + 1));   // [n_tex + 1]
   if (wave == 0) {
     const int per = (n_tex + 63) >> 6;
     int64_t c_cost = 0;
@@ -2360,9 +2387,8 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t
     for (int k = 0; k < per; k++) {
       const int tt = lane * per + k;
       if (tt < n_tex) {
-        const int cn = sc.rows_hist[tt];
-        c_cnt += cn;
-        c_cost += (int64_t)cn * rows_tex_cost(tex_h[tt], tex_w[tt]);
+        c_cnt += sc.rows_hist[tt];
+        c_cost += (int64_t)sc.rows_cost[tt];
       }
     }
     int64_t i_cost = c_cost;
@@ -2379,14 +2405,13 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t
       if (tt < n_tex) {
         cum_cost[tt] = e_cost;
         cum_cnt[tt] = e_cnt;
-        const int cn = sc.rows_hist[tt];
-        e_cnt += cn;
-        e_cost += (int64_t)cn * rows_tex_cost(tex_h[tt], tex_w[tt]);
+        e_cnt += sc.rows_hist[tt];
+        e_cost += (int64_t)sc.rows_cost[tt];
       }
     }
     if (lane == 63) { cum_cost[n_tex] = i_cost; cum_cnt[n_tex] = i_cnt; }
   }
-  s_lut[t & 255] = (double)(t & 255) / 255.0;
+  S.lut[t & 255] = (double)(t & 255) / 255.0;
   __syncthreads();
   if (t == 0) {
     const int64_t total = cum_cost[n_tex];
@@ -2401,25 +2426,27 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t
         if (cum_cost[mid] <= target) lo = mid; else hi = mid;
       }
       const int cn = cum_cnt[lo + 1] - cum_cnt[lo];
-      const int64_t cost = rows_tex_cost(tex_h[lo], tex_w[lo]);
-      const int64_t into = (target - cum_cost[lo]) / cost;
+      const int64_t bucket = cum_cost[lo + 1] - cum_cost[lo];                    // the bucket's tiles at their average cost
+      const int64_t into = bucket > 0 ? (target - cum_cost[lo]) * cn / bucket : 0;
       bound[q] = cum_cnt[lo] + (into < (int64_t)cn ? (int)into : cn);
     }
-    s_next = s_first = bound[0];
-    s_end = bound[1];
-    s_cur = -1;
+    S.next = S.first = bound[0];
+    S.end = bound[1];
+    S.cur = -1;
   }
   __syncthreads();
-  const int end = s_end;
-  if (s_first >= end) return;                    // (the whole workgroup)
-  RowsWave& W = s_w[wave];
-  int pending = -1, ptex = -1, gi = 0;           // pending: index of the pulled tile in the list; INT_MAX: the share is used up
+  const int end = S.end;
+  if (S.first >= end) return;                    // (the whole workgroup)
+  RowsWave& W = S.w[wave];
+  uint32_t three = 3;
+  asm volatile("" : "+v"(three));                // (a vector register: the SDWA shift takes no literal)
+  int pending = -1, ptex = -1, gi = 0;           // pending: index of the pulled tile in the list; DONE: the share is used up
   constexpr int DONE = 0x7fffffff;
   PH_DECL
   for (;;) {
     if (pending < 0) {
       int i = 0;
-      if (lane == 0) i = atomicAdd(&s_next, 1);
+      if (lane == 0) i = atomicAdd(&S.next, 1);
       i = __builtin_amdgcn_readfirstlane(i);
       if (i < end) {
         pending = i;
@@ -2429,7 +2456,7 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t
         pending = DONE;
       }
     }
-    if (pending != DONE && ptex == s_cur) {
+    if (pending != DONE && ptex == S.cur) {
       DropPlan p;
       {
         const const_ptr<uint32_t> src = as_constant(reinterpret_cast<const uint32_t*>(&sc.plan[gi]));
@@ -2438,24 +2465,24 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t
         for (int k = 0; k < (int)(sizeof(DropPlan) / 4); k++) dst[k] = src[k];
       }
       PH(0)                                       // pull + plan
-      rows_tile(p, tex_h[ptex], tex_w[ptex], s_pair, s_lut, W, sc.arena PH_PASS);
+      rows_tile(p, tex_h[ptex], tex_w[ptex], S, W, sc.arena, three PH_PASS);
       pending = -1;
       continue;
     }
     // another texture (or nothing left): meet the other waves
-    if (lane == 0) { s_pend[wave] = pending; s_ptex[wave] = ptex; }
+    if (lane == 0) { S.pend[wave] = pending; S.ptex[wave] = ptex; }
     __syncthreads();                              // nobody reads the resident texture any more
     int m = DONE, mtex = -1;
     for (int k = 0; k < RW_WAVES; k++)
-      if (s_pend[k] < m) { m = s_pend[k]; mtex = s_ptex[k]; }
+      if (S.pend[k] < m) { m = S.pend[k]; mtex = S.ptex[k]; }
     if (m == DONE) break;                         // every wave is out of tiles
     {
       const int64_t nb = pair_bytes(tex_h[mtex], tex_w[mtex]);
       const uint4* g = reinterpret_cast<const uint4*>(sc.tex_pair + sc.tex_qoff[mtex]);
-      uint4* d = reinterpret_cast<uint4*>(s_pair);
+      uint4* d = reinterpret_cast<uint4*>(S.pair);
       for (int k = t; k < (int)(nb >> 4); k += 1024) d[k] = g[k];
     }
-    if (t == 0) s_cur = mtex;
+    if (t == 0) S.cur = mtex;
     __syncthreads();
     PH(5)                                         // texture switch (waiting for the other waves + staging)
   }
@@ -2478,9 +2505,9 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   const int chunk = (n + 1023) / 1024;
   const int i0 = t * chunk, i1 = min(i0 + chunk, n);
   const int64_t base = (int64_t)f * max_drops;
-  __shared__ int s_hist[RW_TEX_MAX];
+  __shared__ int s_hist[RW_TEX_MAX], s_cost[RW_TEX_MAX];
   if (sc.rows_on) {
-    for (int k = t; k < sc.n_tex; k += 1024) s_hist[k] = 0;
+    for (int k = t; k < sc.n_tex; k += 1024) s_hist[k] = s_cost[k] = 0;
     __syncthreads();
   }
   // #rot-fast (general), #generic, #fused blur items, #slow blur, #small blur, #rot-fast (integer ratio), #big, big pixels, #row-walk tiles
@@ -2491,7 +2518,11 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {         // duplicates of another drop's raw tile render nothing
       if (p.kind == KIND_BIG) { c[6]++; c[7] += p.tw * p.th; }
-      else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) { c[8]++; atomicAdd(&s_hist[p.tex], 1); }
+      else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) {
+        c[8]++;
+        atomicAdd(&s_hist[p.tex], 1);
+        atomicAdd(&s_cost[p.tex], rows_tile_cost(p, tex_h[p.tex], tex_w[p.tex]));
+      }
       else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
     }
     if (p.r1 > 0) {
@@ -2562,6 +2593,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     for (int k = t; k < sc.n_tex; k += 1024) {
       const int cnt = s_hist[k];
       sc.rows_fbase[(int64_t)f * RW_TEX_MAX + k] = cnt ? atomicAdd(&sc.rows_hist[k], cnt) : 0;
+      if (cnt) atomicAdd(&sc.rows_cost[k], (unsigned long long)s_cost[k]);
     }
   }
 }
@@ -4993,7 +5025,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.rows_list, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_sorted, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_n, (size_t)F))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.rows_hist, (size_t)RW_TEX_MAX))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_hist, (size_t)RW_TEX_MAX * 3))) return rc;      // + RW_TEX_MAX 8-byte cost sums
+    ctx->sc.rows_cost = reinterpret_cast<unsigned long long*>(ctx->sc.rows_hist + RW_TEX_MAX);
     if ((rc = dev_alloc(ctx, ctx->sc.rows_fbase, (size_t)F * RW_TEX_MAX))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list_n, (size_t)F))) return rc;
@@ -5338,7 +5371,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, bs, "k_dedup");
       HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, bs));
       HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, bs));
-      if (sc.rows_on) HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * RW_TEX_MAX, bs));
+      if (sc.rows_on) HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * RW_TEX_MAX * 3, bs));
       hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
@@ -6928,6 +6961,9 @@ int rr_batch_counts(rr_ctx* ctx, int32_t frame, int32_t out[8]) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, ctx->sc.counts + (size_t)frame * 8, sizeof(int32_t) * 8, hipMemcpyDeviceToHost));
+  int32_t rows = 0;                    // the row-walk kernel's share of the rotate + resize tiles (k_lists writes it with or without the option)
+  HIPCHK(hipMemcpy(&rows, ctx->sc.rows_n + frame, sizeof(int32_t), hipMemcpyDeviceToHost));
+  out[0] += rows;
   return RR_OK;
 }
 

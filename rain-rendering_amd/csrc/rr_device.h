@@ -421,11 +421,14 @@ RR_HD double raw_tile_pixel(const DropPlan& p, const Tex& tx, const float* ctab,
 //        0 when no cell reads the column.  Sign bit: the column is the last one its cell reads.
 //   w2   a_l of the NEXT cell when the column is also that cell's left partial, else 0 (then b restarts at +0.0).
 // Requires scale_x >= 2 (every cell then has a full or right-partial column to carry the sign bit).
+// s is the bilinear sample BEFORE its division by 1024 and the table holds weight * 2^-10 (exact in float): the factor
+// is a power of two, so s * (w * 2^-10) and (s * 2^-10) * w round the same exact product to the same double.
 // ---------------------------------------------------------------------------
-struct ColEnt {
+struct alignas(16) ColEnt {
   int32_t ad, bd;            // rot_adelta / rot_bdelta of the column
   uint32_t w1, w2;           // float bits, see above
 };
+constexpr float COL_W_SCALE = 1.0f / 1024.0f;
 RR_HD uint32_t f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 RR_HD float bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 
@@ -433,10 +436,10 @@ RR_HD float bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return 
 // cell d owns.  `cell[x]` = the destination column a walk that STARTS at x is in.
 RR_HD void coltab_cell_pass1(const DropPlan& p, int d, ColEnt* col, uint8_t* cell) {
   const AreaSpan A = area_span(p.nW, p.scale_x, d);
-  const uint32_t am = f32_bits(A.a_m);
+  const uint32_t am = f32_bits(A.a_m * COL_W_SCALE);
   for (int x = A.s1; x < A.s2; x++) { col[x].w1 = am; cell[x] = (uint8_t)d; }
   int R = A.s2 - 1;
-  if (A.has_r) { col[A.s2].w1 = f32_bits(A.a_r); cell[A.s2] = (uint8_t)d; R = A.s2; }
+  if (A.has_r) { col[A.s2].w1 = f32_bits(A.a_r * COL_W_SCALE); cell[A.s2] = (uint8_t)d; R = A.s2; }
   if (R >= 0) col[R].w1 |= 0x80000000u;
 }
 // pass 2 (after pass 1 of EVERY cell): the left partial column of cell d -- shared with the end of cell d - 1, or nobody's
@@ -444,8 +447,8 @@ RR_HD void coltab_cell_pass2(const DropPlan& p, int d, ColEnt* col, uint8_t* cel
   const AreaSpan A = area_span(p.nW, p.scale_x, d);
   if (!A.has_l || A.s1 < 1) return;
   const int c = A.s1 - 1;
-  if (col[c].w1 & 0x80000000u) col[c].w2 = f32_bits(A.a_l);
-  else { col[c].w1 = f32_bits(A.a_l); cell[c] = (uint8_t)d; }
+  if (col[c].w1 & 0x80000000u) col[c].w2 = f32_bits(A.a_l * COL_W_SCALE);
+  else { col[c].w1 = f32_bits(A.a_l * COL_W_SCALE); cell[c] = (uint8_t)d; }
 }
 // first / last canvas column the cells [da, db) read
 RR_HD void cells_columns(const DropPlan& p, int da, int db, int& c0, int& c1) {
@@ -453,20 +456,35 @@ RR_HD void cells_columns(const DropPlan& p, int da, int db, int& c0, int& c1) {
   c0 = (A.has_l && A.s1 >= 1) ? A.s1 - 1 : A.s1;
   c1 = B.has_r ? B.s2 : B.s2 - 1;
 }
-// destination columns a wave takes at a time (the row sums of one destination row must fit `buf` doubles) and
-// destination rows per group of canvas rows: the k that needs the fewest passes of 64 canvas rows over the tile
-RR_HD int rows_twc_max(const DropPlan& p, int buf) { return imax(imin(p.tw, buf / ((int)ceil(p.scale_y) + 4)), 1); }
-RR_HD int rows_group_rows(const DropPlan& p, int k) { return (int)floor((double)k * p.scale_y) + 4; }     // upper bound of hi - lo + 1 (a row of margin either side)
-RR_HD int rows_k_dy(const DropPlan& p, int twc, int buf) {
-  int kmax = (int)(((double)(buf / twc) - 4.0) / p.scale_y);
-  kmax = imax(imin(kmax, p.th), 1);
-  int best = kmax, best_cost = ((p.th + kmax - 1) / kmax) * ((rows_group_rows(p, kmax) + 63) >> 6);
-  for (int m = 1; m * 64 < rows_group_rows(p, kmax); m++) {
-    int k = imax(imin((int)(((double)(64 * m) - 4.0) / p.scale_y), kmax), 1);
-    const int cost = ((p.th + k - 1) / k) * ((rows_group_rows(p, k) + 63) >> 6);
-    if (cost < best_cost) { best = k; best_cost = cost; }
+// k_tile_rows takes the canvas rows of a tile in PASSES of R consecutive rows (a lane per row).  The cell sums of a pass
+// (R x twc doubles) and the accumulators of the one destination row whose rows straddle the end of the pass (twc doubles)
+// share `buf` doubles; tiles wider than buf / 9 columns are folded in column chunks (at least 8 rows per pass).
+RR_HD int rows_twc_max(const DropPlan& p, int buf) { return imax(imin(p.tw, buf / 9), 1); }
+RR_HD int rows_per_pass(int twc, int buf) { return imin(64, buf / twc - 1); }
+// canvas rows destination row dy reads: left partial, full rows, right partial (area_span of the vertical axis)
+RR_HD void vfold_rows(const AreaSpan& a, int& first_row, int& last_row) {
+  first_row = a.has_l ? a.s1 - 1 : a.s1;
+  last_row = a.has_r ? a.s2 : a.s2 - 1;
+}
+// The part of a destination pixel's vertical fold that lies in canvas rows [R0, R1], in resize_pixel's order: continues
+// `acc` (first: no term yet).  get(row) = the horizontal cell sum of that canvas row.
+template <class Get>
+RR_HD void vfold_part(const AreaSpan& ay, int R0, int R1, double& acc, bool& first, Get&& get) {
+  if (ay.has_l && ay.s1 - 1 >= R0 && ay.s1 - 1 <= R1) {
+    acc = (double)ay.a_l * get(ay.s1 - 1);
+    first = false;
   }
-  return best;
+  const int m1 = imin(ay.s2 - 1, R1);
+  for (int sy = imax(ay.s1, R0); sy <= m1; sy++) {
+    const double v = (double)ay.a_m * get(sy);
+    acc = first ? v : acc + v;
+    first = false;
+  }
+  if (ay.has_r && ay.s2 >= R0 && ay.s2 <= R1) {
+    const double v = (double)ay.a_r * get(ay.s2);
+    acc = first ? v : acc + v;
+    first = false;
+  }
 }
 // pair texture: u16 element (y, x) = texel (y, x) | texel (y + 1, x) << 8 for y = -2 .. sh, x = -2 .. pitch - 3 (zeros
 // outside the texture): the 2 x 2 neighbourhood of a bilinear sample is two adjacent elements.  pitch / 2 is odd, so

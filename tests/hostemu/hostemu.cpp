@@ -195,15 +195,16 @@ int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, con
 }
 
 // ---- the row-walk form of the rotate + INTER_AREA tile (k_tile_rows, rainhip.hip), lane by lane ----
-// Same column table (coltab_cell_pass1 / 2), same walk rule, same chunking (rows_twc_max / rows_k_dy with `buf` doubles of
-// cell sums) and the same 2 x 2 fetch from a pair texture as the kernel; the lanes of a wave run one after the other.
+// Same column table (coltab_cell_pass1 / 2), same walk rule, same passes (rows_twc_max / rows_per_pass with `buf` doubles of
+// cell sums; the vertical folds continue across passes through the carry) and the same 2 x 2 fetch from a pair texture as
+// the kernel; the lanes of a wave run one after the other.
 // out[th*tw] = the raw tile; also out_def[th*tw] = raw_tile_pixel (the definition).  Returns the number of pixels that
 // differ in any bit, or -1 when the plan is not one k_tile_rows takes.
 int emu_tile_rows(const DropPlan* pp, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off, int buf,
                   double* out, double* out_def) {
   const DropPlan& p = *pp;
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
-  if (!(p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.tw >= 1 && p.tw <= 64 && p.th >= 1 && (int)ceil(p.scale_y) + 4 <= buf)) return -1;
+  if (!(p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.tw >= 1 && p.tw <= 64 && p.th >= 1)) return -1;
   float ctab[128];
   build_cubic_tab(ctab);
   TexGlobal tx{texels + tex_off[p.tex], sh, sw};
@@ -226,8 +227,7 @@ int emu_tile_rows(const DropPlan* pp, const uint8_t* texels, const int32_t* tex_
     const double v00 = lut[u & 0xffu], v10 = lut[(u >> 8) & 0xffu], v01 = lut[(u >> 16) & 0xffu], v11 = lut[u >> 24];
     const int fx = (X >> 5) & 31, fy = (Y >> 5) & 31;
     const double ax_ = (double)(32 - fx), bx_ = (double)fx, ay_ = (double)(32 - fy), by_ = (double)fy;
-    const double sm = ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);
-    return sm * (1.0 / 1024.0);
+    return ((v00 * (ay_ * ax_) + v01 * (ay_ * bx_)) + v10 * (by_ * ax_)) + v11 * (by_ * bx_);   // (the table's weights carry the / 1024)
   };
   const int tw = p.tw, th = p.th, nW = p.nW, nH = p.nH;
   std::vector<ColEnt> col((size_t)nW);
@@ -242,16 +242,14 @@ int emu_tile_rows(const DropPlan* pp, const uint8_t* texels, const int32_t* tex_
     const int twc = imin(twc_max, tw - dxa);
     int colA, colB;
     cells_columns(p, dxa, dxa + twc, colA, colB);
-    const int k_dy = rows_k_dy(p, twc, buf);
-    for (int dy0 = 0; dy0 < th; dy0 += k_dy) {
-      const int dy1 = imin(dy0 + k_dy, th);
-      const int lo = imax((int)floor((double)dy0 * sy_scale) - 1, 0);
-      const int hi = imin((int)floor((double)dy1 * sy_scale) + 1, nH - 1);
-      const int nrows = hi - lo + 1;
-      if (nrows * twc > buf) return -2;
+    const int R = rows_per_pass(twc, buf);
+    if (R < 1) return -2;
+    double* const carry = B.data() + R * twc;
+    for (int R0 = 0; R0 < nH; R0 += R) {
+      const int R1 = imin(R0 + R, nH) - 1, nrows = R1 - R0 + 1;
       for (int k = 0; k < nrows * twc; k++) B[k] = 0.0;
       for (int r = 0; r < nrows; r++) {
-        const int c = lo + r, ry = p.flip ? (nH - 1 - c) : c;
+        const int c = R0 + r, ry = p.flip ? (nH - 1 - c) : c;
         const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
         // the interval of columns whose samples can be non-zero, found by brute force with a margin (the kernel's row_interval
         // is a conservative bound of the same thing; any superset gives the same sums)
@@ -288,22 +286,28 @@ int emu_tile_rows(const DropPlan* pp, const uint8_t* texels, const int32_t* tex_
         }
         if (any_col && o < rowend) *o = b;
       }
-      for (int it = 0; it < (dy1 - dy0) * twc; it++) {
-        const int rr_ = it / twc, dxl = it - rr_ * twc, dx = dxa + dxl, dy = dy0 + rr_;
+      const int dyG = imax((int)floor((double)R0 * p.inv_sy) - 1, 0);
+      const int dyE = imin((int)floor((double)(R1 + 1) * p.inv_sy) + 2, th);
+      // (the candidates must cover every destination row that reads a row of the pass)
+      for (int dy = 0; dy < th; dy++) {
         const AreaSpan ay = area_span(nH, sy_scale, dy);
+        int fr, lr;
+        vfold_rows(ay, fr, lr);
+        if (!(lr < R0 || fr > R1) && (dy < dyG || dy >= dyE)) return -4;
+      }
+      std::vector<double> carry_in(carry, carry + twc);       // lanes read the carry before any lane writes it
+      for (int it = 0; it < (dyE - dyG) * twc; it++) {
+        const int dq = it / twc, dxl = it - dq * twc, dy = dyG + dq;
+        const AreaSpan ay = area_span(nH, sy_scale, dy);
+        int fr, lr;
+        vfold_rows(ay, fr, lr);
+        if (lr < R0 || fr > R1) continue;
         double acc = 0.0;
         bool first = true;
-        if (ay.has_l) { acc = (double)ay.a_l * B[(ay.s1 - 1 - lo) * twc + dxl]; first = false; }
-        for (int sy = ay.s1; sy < ay.s2; sy++) {
-          const double v = (double)ay.a_m * B[(sy - lo) * twc + dxl];
-          acc = first ? v : acc + v;
-          first = false;
-        }
-        if (ay.has_r) {
-          const double v = (double)ay.a_r * B[(ay.s2 - lo) * twc + dxl];
-          acc = first ? v : acc + v;
-        }
-        out[dy * tw + dx] = clip01(acc);
+        if (fr < R0) { acc = carry_in[dxl]; first = false; }
+        vfold_part(ay, R0, R1, acc, first, [&](int row) { return B[(row - R0) * twc + dxl]; });
+        if (lr <= R1) out[dy * tw + dxa + dxl] = clip01(acc);
+        else carry[dxl] = acc;
       }
     }
   }
