@@ -2323,9 +2323,13 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, RowsShared& 
       // Two columns per iteration.  The table entries are read whether or not the lane still has columns (a lane that is
       // done reads on into whatever follows -- always inside the workgroup's LDS, always a finite sample -- and folds it
       // with weight 0).
-      const ColEnt* cp = W.col + xq;
+      // (entries as ONE 16-byte read each: left to itself the compiler reads 12 bytes and fetches w2 inside the flush branch,
+      // a second LDS round trip on the critical path of nearly every iteration)
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      const volatile u32x4_t __attribute__((address_space(3)))* cp = (const volatile u32x4_t __attribute__((address_space(3)))*)(W.col + xq);
       while (__ballot(left > 0) != 0ull) {
-        const ColEnt ea = cp[0], eb = cp[1];
+        const u32x4_t qa = cp[0], qb = cp[1];
+        const ColEnt ea{(int32_t)qa.x, (int32_t)qa.y, qa.z, qa.w}, eb{(int32_t)qb.x, (int32_t)qb.y, qb.z, qb.w};
         const int XA = X0 + ea.ad, YA = Y0 + ea.bd, XB = X0 + eb.ad, YB = Y0 + eb.bd;
         const RowsSample ta = rows_fetch(s_pair, XA, YA, P2, sh2, sw2), tb = rows_fetch(s_pair, XB, YB, P2, sh2, sw2);
         const double sa = rows_blend(ta, XA, YA, three), sb = rows_blend(tb, XB, YB, three);
