@@ -194,9 +194,11 @@ __device__ unsigned long long g_phase[8][8];
   }
 #define PH_PARAMS , unsigned long long& ph_t0_, unsigned long long (&ph_acc_)[8]
 #define PH_PASS , ph_t0_, ph_acc_
+#define PH_COUNT(k) ph_acc_[k] += 1;
 #else
 #define PH_PARAMS
 #define PH_PASS
+#define PH_COUNT(k)
 #define PH_DECL
 #define PH_WAITVM
 #define PH(k)
@@ -1685,25 +1687,27 @@ __device__ inline bool tile_is_fast(const DropPlan& p, int sh, int sw) {
 // ---- k_tile_rows (round 6): a WAVE per rotate + INTER_AREA tile, lanes = canvas rows (rr_device.h "row walks") ----
 constexpr int RW_WAVES = 16;          // waves of a workgroup (one workgroup per CU: the LDS holds one texture for all of them)
 constexpr int RW_NW = 324;            // canvas columns of a tile (sh = 320, sw = 32: nW <= 321)
-constexpr int RW_BUF = 352;           // doubles of cell sums per wave
+constexpr int RW_BUF = 344;           // doubles of cell sums per wave
 constexpr int RW_PAIR_BYTES = 24640;  // pair texture in LDS: (320 + 3) * 38 * 2 rounded up to 16
 constexpr int RW_TEX_MAX = 1024;      // textures of a database the batch-wide list is bucketed by
 struct RowsWave {                     // wave-private LDS of k_tile_rows
   ColEnt col[RW_NW];
   double buf[RW_BUF];
   uint8_t cell[RW_NW + 12];
+  uint16_t cfirst[64], clast[64];     // first / last canvas column of every destination cell
 };
-static_assert(sizeof(RowsWave) == 8336 && sizeof(RowsWave) % 16 == 0, "RowsWave layout (col[] is read 16 bytes at a time)");
+static_assert(sizeof(RowsWave) == 8528 && sizeof(RowsWave) % 16 == 0, "RowsWave layout (col[] is read 16 bytes at a time)");
 // estimated cost of a tile of this texture (its samples ~ the padded texture's area, plus the per-tile set-up), for the
 // split of the sorted list among the workgroups
 // estimated cost of a tile in walk iterations (passes x columns a row can touch, + the per-pass and per-tile set-up)
 __device__ inline int rows_tile_cost(const DropPlan& p, int sh, int sw) {
-  const int twc = rows_twc_max(p, RW_BUF), R = rows_per_pass(twc, RW_BUF);
-  const int passes = ((p.nH + R - 1) / R) * ((p.tw + twc - 1) / twc);
-  return passes * (imin(tile_pitch(p, sh, sw), p.nW) / 2 + 12) + 24;
+  int R, NS;
+  rows_pass_shape(p.tw, RW_BUF, R, NS);
+  const int passes = (p.nH + R - 1) / R;
+  return passes * ((imin(tile_pitch(p, sh, sw), p.nW) / NS + 3) / 2 + 6) + 24;
 }
 __device__ inline bool tile_is_rows(const DropPlan& p, int sh, int sw) {
-  return p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.nW <= RW_NW && p.tw <= 64 && p.tw >= 1 && p.th >= 1 &&
+  return p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.nW <= RW_NW && p.tw <= 64 && p.tw >= 1 && p.th >= 1 && p.th <= 64 &&
          pair_bytes(sh, sw) <= RW_PAIR_BYTES && tile_coords_safe(p);
 }
 __global__ __launch_bounds__(256) void k_pair_textures(const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w,
@@ -2271,108 +2275,136 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, RowsShared& 
     W.cell[x] = 0;
   }
   wave_lds_sync();
-  if (lane < tw) coltab_cell_pass1(p, lane, W.col, W.cell);
+  if (lane < tw) coltab_cell_pass1(p, lane, W.col, W.cell, W.cfirst, W.clast);
   wave_lds_sync();
   if (lane < tw) coltab_cell_pass2(p, lane, W.col, W.cell);
+  // the vertical axis: lane dy keeps area_span(dy) -- a pass' folds fetch theirs with four lane shuffles instead of
+  // evaluating it (three float64 divisions) per pass
+  uint32_t vq0, vq1, vq2, vq3;
+  {
+    const AreaSpan ay = area_span(nH, p.scale_y, imin(lane, th - 1));
+    vq0 = (uint32_t)ay.s1 | ((uint32_t)ay.s2 << 15) | ((uint32_t)(ay.has_l ? 1 : 0) << 30) | ((uint32_t)(ay.has_r ? 1 : 0) << 31);
+    vq1 = f32_bits(ay.a_l);
+    vq2 = f32_bits(ay.a_m);
+    vq3 = f32_bits(ay.a_r);
+  }
   wave_lds_sync();
   PH(1)                                               // column table
   const RowGeom geom = row_geom(p, sh, sw);
-  const double sy_scale = p.scale_y;
-  const int twc_max = rows_twc_max(p, RW_BUF);
-  for (int dxa = 0; dxa < tw; dxa += twc_max) {
-    const int twc = imin(twc_max, tw - dxa);
-    int colA, colB;
-    cells_columns(p, dxa, dxa + twc, colA, colB);
-    const int R = rows_per_pass(twc, RW_BUF);
-    double* const carry = W.buf + R * twc;            // accumulators of the destination row that straddles a pass end
-    for (int R0 = 0; R0 < nH; R0 += R) {
-      const int R1 = imin(R0 + R, nH) - 1, nrows = R1 - R0 + 1;
-      for (int k = lane; k < nrows * twc; k += 64) W.buf[k] = 0.0;
-      // ---- the pass: lane = canvas row R0 + lane ----
-      int X0 = 0, Y0 = 0, xq = 0, left = 0;
-      if (lane < nrows) {
-        const int c = R0 + lane;
-        const int ry = p.flip ? (nH - 1 - c) : c;
-        X0 = (int)rot_X0(p, ry);
-        Y0 = (int)rot_Y0(p, ry);
-        int xa, n;
-        row_interval(p, geom, X0, Y0, xa, n);
-        xq = imax(xa, colA);
-        left = imax(imin(xa + n - 1, colB) - xq + 1, 0);
-        X0 += 2048;
-        Y0 += 2048;
-      }
-      wave_lds_sync();
-      double* out = W.buf + lane * twc;
-      double* const rowend = out + twc;
-      const bool any_col = left > 0;
-      double b = 0.0;
-      if (any_col) {
-        const int d0 = W.cell[xq];
-        if (d0 < dxa) {                              // (wide tiles only) the chunk's first column still ends the previous chunk's last cell:
-          const ColEnt e = W.col[xq];                //  only its left-partial role is ours
-          const int X = X0 + e.ad, Y = Y0 + e.bd;
-          b = rows_blend(rows_fetch(s_pair, X, Y, P2, sh2, sw2), X, Y, three) * (double)bits_f32(e.w2);
-          xq++;
-          left--;
-        } else {
-          out += d0 - dxa;
+  int R, NS;
+  rows_pass_shape(tw, RW_BUF, R, NS);
+  const int seg = (int)(((float)lane + 0.5f) / (float)R), r = lane - seg * R;     // this lane's segment and row of the pass
+  const int colA = W.cfirst[0], colB = W.clast[tw - 1];
+  const float inv_tw = 1.0f / (float)tw;
+  double* const carry = W.buf + R * tw;               // accumulators of the destination row that straddles a pass end
+  for (int R0 = 0; R0 < nH; R0 += R) {
+    const int R1 = imin(R0 + R, nH) - 1, nrows = R1 - R0 + 1;
+    for (int k = lane; k < nrows * tw; k += 64) W.buf[k] = 0.0;
+    // ---- the pass: lane = (canvas row R0 + r, segment `seg` of the cells the row touches) ----
+    int X0 = 0, Y0 = 0, xq = 0, left = 0, dA = 0, dB = 0;
+    if (r < nrows && seg < NS) {
+      const int c = R0 + r;
+      const int ry = p.flip ? (nH - 1 - c) : c;
+      X0 = (int)rot_X0(p, ry);
+      Y0 = (int)rot_Y0(p, ry);
+      int xa, n;
+      row_interval(p, geom, X0, Y0, xa, n);
+      const int xs0 = imax(xa, colA), xe0 = imin(xa + n - 1, colB);
+      if (xs0 <= xe0) {
+        const int dlo = W.cell[xs0], dhi = imin(W.cell[xe0] + 1, tw - 1);   // (+ 1: the row's last column may also start the next cell)
+        rows_segment(dlo, dhi, NS, seg, dA, dB);
+        if (dA <= dhi) {
+          xq = imax(xs0, (int)W.cfirst[dA]);
+          left = imax(imin(xe0, (int)W.clast[dB - 1]) - xq + 1, 0);
         }
       }
-      PH(2)                                           // pass set-up: clear, row terms, intervals
-      // Two columns per iteration.  The table entries are read whether or not the lane still has columns (a lane that is
-      // done reads on into whatever follows -- always inside the workgroup's LDS, always a finite sample -- and folds it
-      // with weight 0).
-      // (entries as ONE 16-byte read each: left to itself the compiler reads 12 bytes and fetches w2 inside the flush branch,
-      // a second LDS round trip on the critical path of nearly every iteration)
-      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-      const volatile u32x4_t __attribute__((address_space(3)))* cp = (const volatile u32x4_t __attribute__((address_space(3)))*)(W.col + xq);
-      while (__ballot(left > 0) != 0ull) {
-        const u32x4_t qa = cp[0], qb = cp[1];
-        const ColEnt ea{(int32_t)qa.x, (int32_t)qa.y, qa.z, qa.w}, eb{(int32_t)qb.x, (int32_t)qb.y, qb.z, qb.w};
-        const int XA = X0 + ea.ad, YA = Y0 + ea.bd, XB = X0 + eb.ad, YB = Y0 + eb.bd;
-        const RowsSample ta = rows_fetch(s_pair, XA, YA, P2, sh2, sw2), tb = rows_fetch(s_pair, XB, YB, P2, sh2, sw2);
-        const double sa = rows_blend(ta, XA, YA, three), sb = rows_blend(tb, XB, YB, three);
-        const uint32_t wa = left > 0 ? ea.w1 : 0u, wb = left > 1 ? eb.w1 : 0u;
-        b = b + sa * (double)bits_f32(wa & 0x7fffffffu);
-        if ((int32_t)wa < 0) {
-          *out++ = b;
-          b = sa * (double)bits_f32(ea.w2);
-        }
-        b = b + sb * (double)bits_f32(wb & 0x7fffffffu);
-        if ((int32_t)wb < 0) {
-          *out++ = b;
-          b = sb * (double)bits_f32(eb.w2);
-        }
-        cp += 2;
-        left -= 2;
-      }
-      if (any_col && out < rowend) *out = b;          // the row's interval ended inside a cell
-      PH(3)                                           // the walk
-      wave_lds_sync();
-      // ---- vertical folds of the destination rows that read rows R0 .. R1: a lane per (destination row, column) ----
-      const int dyG = imax((int)floor((double)R0 * p.inv_sy) - 1, 0);            // the first candidate; rows before it ended before R0
-      const int dyE = imin((int)floor((double)(R1 + 1) * p.inv_sy) + 2, th);     // one past the last candidate
-      const int n_out = (dyE - dyG) * twc;
-      for (int it = lane; it < n_out; it += 64) {
-        const int dq = it / twc, dxl = it - dq * twc, dy = dyG + dq;
-        const AreaSpan ay = area_span(nH, sy_scale, dy);
-        int fr, lr;
-        vfold_rows(ay, fr, lr);
-        if (lr < R0 || fr > R1) continue;
-        double acc = 0.0;
-        bool first = true;
-        if (fr < R0) {                               // begun in an earlier pass
-          acc = carry[dxl];
-          first = false;
-        }
-        vfold_part(ay, R0, R1, acc, first, [&](int row) { return W.buf[(row - R0) * twc + dxl]; });
-        if (lr <= R1) A0[dy * tw + dxa + dxl] = clip01(acc);
-        else carry[dxl] = acc;
-      }
-      wave_lds_sync();
-      PH(4)                                           // vertical folds + store
+      X0 += 2048;
+      Y0 += 2048;
     }
+    wave_lds_sync();
+    double* out = W.buf + r * tw;
+    double* const lane_end = out + dB;
+    const bool any_col = left > 0;
+    double b = 0.0;
+    if (any_col) {
+      const int d0 = W.cell[xq];
+      if (d0 < dA) {                                 // the segment's first column still ends the cell before it (the lane to the
+        const ColEnt e = W.col[xq];                  //  left folds that): only its left-partial role is ours
+        const int X = X0 + e.ad, Y = Y0 + e.bd;
+        b = rows_blend(rows_fetch(s_pair, X, Y, P2, sh2, sw2), X, Y, three) * (double)bits_f32(e.w2);
+        out += dA;
+        xq++;
+        left--;
+      } else {
+        out += d0;
+      }
+    }
+    PH(2)                                             // pass set-up: clear, row terms, intervals
+    // Two columns per iteration.  The table entries are read whether or not the lane still has columns (a lane that is
+    // done reads on into whatever follows -- always inside the workgroup's LDS, always a finite sample -- and folds it
+    // with weight 0); each entry as ONE 16-byte read (left to itself the compiler reads 12 bytes and fetches w2 inside the
+    // flush branch: a second LDS round trip on the critical path of nearly every iteration).
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const volatile u32x4_t __attribute__((address_space(3)))* cp = (const volatile u32x4_t __attribute__((address_space(3)))*)(W.col + xq);
+    while (__ballot(left > 0) != 0ull) {
+      const u32x4_t qa = cp[0], qb = cp[1];
+      const ColEnt ea{(int32_t)qa.x, (int32_t)qa.y, qa.z, qa.w}, eb{(int32_t)qb.x, (int32_t)qb.y, qb.z, qb.w};
+      const int XA = X0 + ea.ad, YA = Y0 + ea.bd, XB = X0 + eb.ad, YB = Y0 + eb.bd;
+      const RowsSample ta = rows_fetch(s_pair, XA, YA, P2, sh2, sw2), tb = rows_fetch(s_pair, XB, YB, P2, sh2, sw2);
+      const double sa = rows_blend(ta, XA, YA, three), sb = rows_blend(tb, XB, YB, three);
+      const uint32_t wa = left > 0 ? ea.w1 : 0u, wb = left > 1 ? eb.w1 : 0u;
+      b = b + sa * (double)bits_f32(wa & 0x7fffffffu);
+      if ((int32_t)wa < 0) {
+        *out++ = b;
+        b = sa * (double)bits_f32(ea.w2);
+      }
+      b = b + sb * (double)bits_f32(wb & 0x7fffffffu);
+      if ((int32_t)wb < 0) {
+        *out++ = b;
+        b = sb * (double)bits_f32(eb.w2);
+      }
+      cp += 2;
+      left -= 2;
+      PH_COUNT(6)
+    }
+    PH_COUNT(7)
+    if (any_col && out < lane_end) *out = b;          // the columns ended inside a cell
+    PH(3)                                             // the walk
+    wave_lds_sync();
+    // ---- vertical folds of the destination rows that read rows R0 .. R1: a lane per (destination row, column) ----
+    const int dyG = imax((int)floor((double)R0 * p.inv_sy) - 1, 0);            // the first candidate; rows before it ended before R0
+    const int dyE = imin((int)floor((double)(R1 + 1) * p.inv_sy) + 2, th);     // one past the last candidate
+    const int n_out = (dyE - dyG) * tw;
+    for (int it0 = 0; it0 < n_out; it0 += 64) {
+      const int it = it0 + lane;
+      const bool valid = it < n_out;
+      const int dq = (int)(((float)it + 0.5f) * inv_tw), dx = it - dq * tw, dy = valid ? dyG + dq : 0;
+      AreaSpan ay;
+      {
+        const uint32_t q0 = (uint32_t)__shfl((int)vq0, dy);
+        ay.s1 = (int16_t)(q0 & 0x7fffu);
+        ay.s2 = (int16_t)((q0 >> 15) & 0x7fffu);
+        ay.has_l = (int16_t)((q0 >> 30) & 1u);
+        ay.has_r = (int16_t)(q0 >> 31);
+        ay.a_l = bits_f32((uint32_t)__shfl((int)vq1, dy));
+        ay.a_m = bits_f32((uint32_t)__shfl((int)vq2, dy));
+        ay.a_r = bits_f32((uint32_t)__shfl((int)vq3, dy));
+      }
+      int fr, lr;
+      vfold_rows(ay, fr, lr);
+      if (!valid || lr < R0 || fr > R1) continue;
+      double acc = 0.0;
+      bool first = true;
+      if (fr < R0) {                                 // begun in an earlier pass
+        acc = carry[dx];
+        first = false;
+      }
+      vfold_part(ay, R0, R1, acc, first, [&](int row) { return W.buf[(row - R0) * tw + dx]; });
+      if (lr <= R1) A0[dy * tw + dx] = clip01(acc);
+      else carry[dx] = acc;
+    }
+    wave_lds_sync();
+    PH(4)                                             // vertical folds + store
   }
 }
 

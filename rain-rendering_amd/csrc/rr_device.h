@@ -434,8 +434,10 @@ RR_HD float bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return 
 
 // pass 1, one call per destination column d (after every entry was set to {ad, bd, 0, 0} and cell[] to 0): the columns
 // cell d owns.  `cell[x]` = the destination column a walk that STARTS at x is in.
-RR_HD void coltab_cell_pass1(const DropPlan& p, int d, ColEnt* col, uint8_t* cell) {
+RR_HD void coltab_cell_pass1(const DropPlan& p, int d, ColEnt* col, uint8_t* cell, uint16_t* cfirst, uint16_t* clast) {
   const AreaSpan A = area_span(p.nW, p.scale_x, d);
+  cfirst[d] = (uint16_t)((A.has_l && A.s1 >= 1) ? A.s1 - 1 : A.s1);       // first / last canvas column the cell reads
+  clast[d] = (uint16_t)(A.has_r ? A.s2 : A.s2 - 1);
   const uint32_t am = f32_bits(A.a_m * COL_W_SCALE);
   for (int x = A.s1; x < A.s2; x++) { col[x].w1 = am; cell[x] = (uint8_t)d; }
   int R = A.s2 - 1;
@@ -450,17 +452,20 @@ RR_HD void coltab_cell_pass2(const DropPlan& p, int d, ColEnt* col, uint8_t* cel
   if (col[c].w1 & 0x80000000u) col[c].w2 = f32_bits(A.a_l * COL_W_SCALE);
   else { col[c].w1 = f32_bits(A.a_l * COL_W_SCALE); cell[c] = (uint8_t)d; }
 }
-// first / last canvas column the cells [da, db) read
-RR_HD void cells_columns(const DropPlan& p, int da, int db, int& c0, int& c1) {
-  const AreaSpan A = area_span(p.nW, p.scale_x, da), B = area_span(p.nW, p.scale_x, db - 1);
-  c0 = (A.has_l && A.s1 >= 1) ? A.s1 - 1 : A.s1;
-  c1 = B.has_r ? B.s2 : B.s2 - 1;
+// k_tile_rows takes the canvas rows of a tile in PASSES of R consecutive rows, every row cut into S segments of whole
+// destination cells: R * S <= 64 lanes, a lane per (row, segment).  The cell sums of a pass (R x tw doubles) and the
+// accumulators of the one destination row whose rows straddle the end of the pass (tw doubles) share `buf` doubles.
+RR_HD void rows_pass_shape(int tw, int buf, int& R, int& S) {
+  const int r_max = imax(imin(64, buf / tw - 1), 1);
+  S = (64 + r_max - 1) / r_max;
+  R = 64 / S;
 }
-// k_tile_rows takes the canvas rows of a tile in PASSES of R consecutive rows (a lane per row).  The cell sums of a pass
-// (R x twc doubles) and the accumulators of the one destination row whose rows straddle the end of the pass (twc doubles)
-// share `buf` doubles; tiles wider than buf / 9 columns are folded in column chunks (at least 8 rows per pass).
-RR_HD int rows_twc_max(const DropPlan& p, int buf) { return imax(imin(p.tw, buf / 9), 1); }
-RR_HD int rows_per_pass(int twc, int buf) { return imin(64, buf / twc - 1); }
+// the cells [dA, dB) lane segment j of S takes of a row that touches cells dlo .. dhi
+RR_HD void rows_segment(int dlo, int dhi, int S, int j, int& dA, int& dB) {
+  const int cps = (dhi - dlo + S) / S;             // ceil((dhi - dlo + 1) / S)
+  dA = dlo + j * cps;
+  dB = imin(dA + cps, dhi + 1);
+}
 // canvas rows destination row dy reads: left partial, full rows, right partial (area_span of the vertical axis)
 RR_HD void vfold_rows(const AreaSpan& a, int& first_row, int& last_row) {
   first_row = a.has_l ? a.s1 - 1 : a.s1;

@@ -195,9 +195,9 @@ int emu_tile(const DropPlan* p, const uint8_t* texels, const int32_t* tex_h, con
 }
 
 // ---- the row-walk form of the rotate + INTER_AREA tile (k_tile_rows, rainhip.hip), lane by lane ----
-// Same column table (coltab_cell_pass1 / 2), same walk rule, same passes (rows_twc_max / rows_per_pass with `buf` doubles of
-// cell sums; the vertical folds continue across passes through the carry) and the same 2 x 2 fetch from a pair texture as
-// the kernel; the lanes of a wave run one after the other.
+// Same column table (coltab_cell_pass1 / 2), same walk rule, same passes and row segments (rows_pass_shape / rows_segment
+// with `buf` doubles of cell sums; the vertical folds continue across passes through the carry) and the same 2 x 2 fetch
+// from a pair texture as the kernel; the lanes of a wave run one after the other.
 // out[th*tw] = the raw tile; also out_def[th*tw] = raw_tile_pixel (the definition).  Returns the number of pixels that
 // differ in any bit, or -1 when the plan is not one k_tile_rows takes.
 int emu_tile_rows(const DropPlan* pp, const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off, int buf,
@@ -233,82 +233,92 @@ int emu_tile_rows(const DropPlan* pp, const uint8_t* texels, const int32_t* tex_
   std::vector<ColEnt> col((size_t)nW);
   std::vector<uint8_t> cell((size_t)nW, 0);
   for (int x = 0; x < nW; x++) col[x] = ColEnt{(int32_t)rot_adelta(p, x), (int32_t)rot_bdelta(p, x), 0u, 0u};
-  for (int d = 0; d < tw; d++) coltab_cell_pass1(p, d, col.data(), cell.data());
+  uint16_t cfirst[64], clast[64];
+  for (int d = 0; d < tw; d++) coltab_cell_pass1(p, d, col.data(), cell.data(), cfirst, clast);
   for (int d = 0; d < tw; d++) coltab_cell_pass2(p, d, col.data(), cell.data());
   std::vector<double> B((size_t)buf);
   const double sy_scale = p.scale_y;
-  const int twc_max = rows_twc_max(p, buf);
-  for (int dxa = 0; dxa < tw; dxa += twc_max) {
-    const int twc = imin(twc_max, tw - dxa);
-    int colA, colB;
-    cells_columns(p, dxa, dxa + twc, colA, colB);
-    const int R = rows_per_pass(twc, buf);
-    if (R < 1) return -2;
-    double* const carry = B.data() + R * twc;
-    for (int R0 = 0; R0 < nH; R0 += R) {
-      const int R1 = imin(R0 + R, nH) - 1, nrows = R1 - R0 + 1;
-      for (int k = 0; k < nrows * twc; k++) B[k] = 0.0;
-      for (int r = 0; r < nrows; r++) {
-        const int c = R0 + r, ry = p.flip ? (nH - 1 - c) : c;
-        const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
-        // the interval of columns whose samples can be non-zero, found by brute force with a margin (the kernel's row_interval
-        // is a conservative bound of the same thing; any superset gives the same sums)
-        int xa = nW, xe = -1;
-        for (int x = 0; x < nW; x++)
-          if (sample(X0 + col[x].ad, Y0 + col[x].bd) != 0.0) { xa = imin(xa, x); xe = imax(xe, x); }
-        xa = imax(xa - (r % 3), 0);                   // ragged margins: a walk may start and end anywhere outside the non-zero run
-        xe = imin(xe + (r % 2), nW - 1);
-        int xq = imax(xa, colA), left = imax(imin(xe, colB) - xq + 1, 0);
-        double* o = B.data() + r * twc;
-        double* const rowend = o + twc;
-        const bool any_col = left > 0;
-        double b = 0.0;
-        if (any_col) {
-          const int d0 = cell[xq];
-          if (d0 < dxa) {
-            const ColEnt e = col[xq];
-            b = sample(X0 + e.ad, Y0 + e.bd) * (double)bits_f32(e.w2);
-            xq++;
-            left--;
-          } else {
-            o += d0 - dxa;
-          }
+  int R, NS;
+  rows_pass_shape(tw, buf, R, NS);
+  if ((R + 1) * tw > buf || R * NS > 64) return -2;
+  const int colA = cfirst[0], colB = clast[tw - 1];
+  double* const carry = B.data() + R * tw;
+  for (int R0 = 0; R0 < nH; R0 += R) {
+    const int R1 = imin(R0 + R, nH) - 1, nrows = R1 - R0 + 1;
+    for (int k = 0; k < nrows * tw; k++) B[k] = 0.0;
+    for (int lane = 0; lane < 64; lane++) {
+      const int seg = (int)(((float)lane + 0.5f) / (float)R), r = lane - seg * R;
+      if (!(r < nrows && seg < NS)) continue;
+      const int c = R0 + r, ry = p.flip ? (nH - 1 - c) : c;
+      const int X0 = (int)rot_X0(p, ry), Y0 = (int)rot_Y0(p, ry);
+      // the interval of columns whose samples can be non-zero, found by brute force with a margin (the kernel's row_interval
+      // is a conservative bound of the same thing; any superset gives the same sums)
+      int xa = nW, xe = -1;
+      for (int x = 0; x < nW; x++)
+        if (sample(X0 + col[x].ad, Y0 + col[x].bd) != 0.0) { xa = imin(xa, x); xe = imax(xe, x); }
+      xa = imax(xa - (c % 3), 0);                     // ragged margins: a walk may start and end anywhere outside the non-zero run
+      xe = imin(xe + (c % 2), nW - 1);
+      const int xs0 = imax(xa, colA), xe0 = imin(xe, colB);
+      if (xs0 > xe0) continue;
+      const int dlo = cell[xs0], dhi = imin(cell[xe0] + 1, tw - 1);
+      int dA, dB;
+      rows_segment(dlo, dhi, NS, seg, dA, dB);
+      if (dA > dhi) continue;
+      int xq = imax(xs0, (int)cfirst[dA]), left = imax(imin(xe0, (int)clast[dB - 1]) - xq + 1, 0);
+      double* o = B.data() + r * tw;
+      double* const lane_end = o + dB;
+      if (left <= 0) continue;
+      double b = 0.0;
+      const int d0 = cell[xq];
+      if (d0 < dA) {
+        const ColEnt e = col[xq];
+        b = sample(X0 + e.ad, Y0 + e.bd) * (double)bits_f32(e.w2);
+        o += dA;
+        xq++;
+        left--;
+      } else {
+        o += d0;
+      }
+      for (; left > 0; left--, xq++) {
+        const ColEnt e = col[xq];
+        const double sv = sample(X0 + e.ad, Y0 + e.bd);
+        b = b + sv * (double)bits_f32(e.w1 & 0x7fffffffu);
+        if ((int32_t)e.w1 < 0) {
+          if (o >= lane_end) return -3;
+          if (*o != 0.0) return -5;                   // two lanes wrote one cell
+          *o++ = b;
+          b = sv * (double)bits_f32(e.w2);
         }
-        for (; left > 0; left--, xq++) {
-          const ColEnt e = col[xq];
-          const double s = sample(X0 + e.ad, Y0 + e.bd);
-          b = b + s * (double)bits_f32(e.w1 & 0x7fffffffu);
-          if ((int32_t)e.w1 < 0) {
-            if (o >= rowend) return -3;
-            *o++ = b;
-            b = s * (double)bits_f32(e.w2);
-          }
-        }
-        if (any_col && o < rowend) *o = b;
       }
-      const int dyG = imax((int)floor((double)R0 * p.inv_sy) - 1, 0);
-      const int dyE = imin((int)floor((double)(R1 + 1) * p.inv_sy) + 2, th);
-      // (the candidates must cover every destination row that reads a row of the pass)
-      for (int dy = 0; dy < th; dy++) {
-        const AreaSpan ay = area_span(nH, sy_scale, dy);
-        int fr, lr;
-        vfold_rows(ay, fr, lr);
-        if (!(lr < R0 || fr > R1) && (dy < dyG || dy >= dyE)) return -4;
+      if (o < lane_end) {
+        if (*o != 0.0) return -5;
+        *o = b;
       }
-      std::vector<double> carry_in(carry, carry + twc);       // lanes read the carry before any lane writes it
-      for (int it = 0; it < (dyE - dyG) * twc; it++) {
-        const int dq = it / twc, dxl = it - dq * twc, dy = dyG + dq;
-        const AreaSpan ay = area_span(nH, sy_scale, dy);
-        int fr, lr;
-        vfold_rows(ay, fr, lr);
-        if (lr < R0 || fr > R1) continue;
-        double acc = 0.0;
-        bool first = true;
-        if (fr < R0) { acc = carry_in[dxl]; first = false; }
-        vfold_part(ay, R0, R1, acc, first, [&](int row) { return B[(row - R0) * twc + dxl]; });
-        if (lr <= R1) out[dy * tw + dxa + dxl] = clip01(acc);
-        else carry[dxl] = acc;
-      }
+    }
+    const int dyG = imax((int)floor((double)R0 * p.inv_sy) - 1, 0);
+    const int dyE = imin((int)floor((double)(R1 + 1) * p.inv_sy) + 2, th);
+    // (the candidates must cover every destination row that reads a row of the pass)
+    for (int dy = 0; dy < th; dy++) {
+      const AreaSpan ay = area_span(nH, sy_scale, dy);
+      int fr, lr;
+      vfold_rows(ay, fr, lr);
+      if (!(lr < R0 || fr > R1) && (dy < dyG || dy >= dyE)) return -4;
+    }
+    std::vector<double> carry_in(carry, carry + tw);       // lanes read the carry before any lane writes it
+    const float inv_tw = 1.0f / (float)tw;
+    for (int it = 0; it < (dyE - dyG) * tw; it++) {
+      const int dq = (int)(((float)it + 0.5f) * inv_tw), dx = it - dq * tw, dy = dyG + dq;
+      if (dx < 0 || dx >= tw) return -6;
+      const AreaSpan ay = area_span(nH, sy_scale, dy);
+      int fr, lr;
+      vfold_rows(ay, fr, lr);
+      if (lr < R0 || fr > R1) continue;
+      double acc = 0.0;
+      bool first = true;
+      if (fr < R0) { acc = carry_in[dx]; first = false; }
+      vfold_part(ay, R0, R1, acc, first, [&](int row) { return B[(row - R0) * tw + dx]; });
+      if (lr <= R1) out[dy * tw + dx] = clip01(acc);
+      else carry[dx] = acc;
     }
   }
   int bad = 0;

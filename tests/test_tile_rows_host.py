@@ -49,7 +49,7 @@ def test_row_walk_tiles_equal_the_definition_on_a_kitti_scene(tmp_path):
         ints = plans[k][:24 * 4].view(np.int32)
         if ints[PLAN_INT['status']] != 0 or sizes[k] == 0 or ints[PLAN_INT['kind']] != 1:
             continue
-        for buf in (352, 96):                          # the kernel's buffer; one that forces column chunks and one-row groups
+        for buf in (344, 96):                          # the kernel's buffer; one that forces column chunks and one-row groups
             rc, out, ref = _run(lib, plans[k], db, buf)
             if rc == -1:
                 continue
@@ -91,7 +91,7 @@ def test_row_walk_on_awkward_scales(tmp_path):
                     continue
                 fast = abs(sc_[0] - isx) < eps and abs(sc_[1] - isy) < eps
                 qi[PLAN_INT['rs_mode']] = 1 if fast else 0
-                rc, out, ref = _run(lib, q, db, 352)
+                rc, out, ref = _run(lib, q, db, 344)
                 if rc == -1:
                     continue
                 assert rc == 0, (k, tw, th, nW, nH, rc)
