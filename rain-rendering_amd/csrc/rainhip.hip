@@ -253,6 +253,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* rows_n;                  // [frame] their number
   int32_t* rows_hist;               // [RW_TEX_MAX] tiles per texture, batch-wide (zeroed per call)
   unsigned long long* rows_cost;    // [RW_TEX_MAX] their estimated cost (behind rows_hist: one memset)
+  int32_t* rows_next;               // [1] the next share of the list (behind rows_cost: the same memset)
+  int32_t* rows_bounds;             // [RW_SHARE_MAX + 1] first tile of every share (k_rows_shares)
   int32_t* rows_fbase;              // [frame][RW_TEX_MAX] first slot of the frame inside its textures' buckets
   int32_t* rows_sorted;             // [frames * drops] batch-global drop indices, bucket after bucket (k_rows_scatter)
   const uint8_t* tex_pair;          // pair textures (k_pair_textures) and their offsets (multiples of 16)
@@ -1690,6 +1692,8 @@ constexpr int RW_NW = 324;            // canvas columns of a tile (sh = 320, sw 
 constexpr int RW_BUF = 344;           // doubles of cell sums per wave
 constexpr int RW_PAIR_BYTES = 24640;  // pair texture in LDS: (320 + 3) * 38 * 2 rounded up to 16
 constexpr int RW_TEX_MAX = 1024;      // textures of a database the batch-wide list is bucketed by
+constexpr int RW_SHARES = 6;          // shares of the list per workgroup of k_tile_rows
+constexpr int RW_SHARE_MAX = 4096;    // (>= compute units * RW_SHARES)
 struct RowsWave {                     // wave-private LDS of k_tile_rows
   ColEnt col[RW_NW];
   double buf[RW_BUF];
@@ -2222,6 +2226,64 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
 // Every sum folds in resizeArea_'s order: the tile is bit-identical to raw_tile_pixel (the CPU tier runs the same column table
 // and walk rule against it: tests/test_tile_rows_host.py; test_raw_tile_dedup_is_invisible, test_known_answers and the oracle
 // tests on the GPU).
+// The batch-wide list cut into n_shares pieces of equal estimated cost: bounds[q] = first tile of share q (k_tile_rows'
+// workgroups take shares off a counter).  Buckets are weighted by the summed cost of their tiles (k_lists), a bucket's
+// tiles count at their average.  One workgroup.
+__global__ __launch_bounds__(1024) void k_rows_shares(int n_shares, Scratch sc) {
+  __shared__ int64_t cum_cost[RW_TEX_MAX + 1];
+  __shared__ int32_t cum_cnt[RW_TEX_MAX + 1];
+  const int t = threadIdx.x, lane = t & 63, n_tex = sc.n_tex;
+  if (t < 64) {
+    const int per = (n_tex + 63) >> 6;
+    int64_t c_cost = 0;
+    int c_cnt = 0;
+    for (int k = 0; k < per; k++) {
+      const int tt = lane * per + k;
+      if (tt < n_tex) {
+        c_cnt += sc.rows_hist[tt];
+        c_cost += (int64_t)sc.rows_cost[tt];
+      }
+    }
+    int64_t i_cost = c_cost;
+    int i_cnt = c_cnt;
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+      const int64_t vc = (int64_t)__shfl_up((long long)i_cost, ofs);
+      const int vn = __shfl_up(i_cnt, ofs);
+      if (lane >= ofs) { i_cost += vc; i_cnt += vn; }
+    }
+    int64_t e_cost = i_cost - c_cost;
+    int e_cnt = i_cnt - c_cnt;
+    for (int k = 0; k < per; k++) {
+      const int tt = lane * per + k;
+      if (tt < n_tex) {
+        cum_cost[tt] = e_cost;
+        cum_cnt[tt] = e_cnt;
+        e_cnt += sc.rows_hist[tt];
+        e_cost += (int64_t)sc.rows_cost[tt];
+      }
+    }
+    if (lane == 63) { cum_cost[n_tex] = i_cost; cum_cnt[n_tex] = i_cnt; }
+  }
+  __syncthreads();
+  const int64_t total = cum_cost[n_tex];
+  for (int w = t; w <= n_shares; w += 1024) {
+    int bound = cum_cnt[n_tex];
+    if (w < n_shares && total > 0) {
+      const int64_t target = total / (int64_t)n_shares * w + (total % (int64_t)n_shares) * w / (int64_t)n_shares;
+      int lo = 0, hi = n_tex;                    // the last bucket whose first tile starts at or before `target`
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cum_cost[mid] <= target) lo = mid; else hi = mid;
+      }
+      const int cn = cum_cnt[lo + 1] - cum_cnt[lo];
+      const int64_t bucket = cum_cost[lo + 1] - cum_cost[lo];
+      const int64_t into = bucket > 0 ? (target - cum_cost[lo]) * cn / bucket : 0;
+      bound = cum_cnt[lo] + (into < (int64_t)cn ? (int)into : cn);
+    }
+    sc.rows_bounds[w] = bound;
+  }
+}
+
 struct RowsShared {                   // the ONE shared variable of k_tile_rows
   double lut[256];                    // v / 255.0; first, i.e. at LDS address 0 (checked at run time): the sampler's byte * 8 IS the address
   uint8_t pair[RW_PAIR_BYTES];        // the resident texture
@@ -2411,116 +2473,73 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, RowsShared& 
 __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t* tex_h, const int32_t* tex_w, Scratch sc) {
   __shared__ __attribute__((aligned(16))) RowsShared S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int n_tex = sc.n_tex;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)S.lut != 0u) __builtin_trap();   // (see RowsShared)
-  // ---- this workgroup's share of the list: buckets weighted by the cost of their tiles, cut into gridDim.x equal parts ----
-  int64_t* cum_cost = reinterpret_cast<int64_t*>(S.pair);                  // [n_tex + 1] (the texture is staged later)
-  int32_t* cum_cnt = reinterpret_cast<int32_t*>(S.pair + 8 * (RW_TEX_MAX + 1));   // [n_tex + 1]
-  if (wave == 0) {
-    const int per = (n_tex + 63) >> 6;
-    int64_t c_cost = 0;
-    int c_cnt = 0;
-    for (int k = 0; k < per; k++) {
-      const int tt = lane * per + k;
-      if (tt < n_tex) {
-        c_cnt += sc.rows_hist[tt];
-        c_cost += (int64_t)sc.rows_cost[tt];
-      }
-    }
-    int64_t i_cost = c_cost;
-    int i_cnt = c_cnt;
-    for (int ofs = 1; ofs < 64; ofs <<= 1) {
-      const int64_t vc = (int64_t)__shfl_up((long long)i_cost, ofs);
-      const int vn = __shfl_up(i_cnt, ofs);
-      if (lane >= ofs) { i_cost += vc; i_cnt += vn; }
-    }
-    int64_t e_cost = i_cost - c_cost;
-    int e_cnt = i_cnt - c_cnt;
-    for (int k = 0; k < per; k++) {
-      const int tt = lane * per + k;
-      if (tt < n_tex) {
-        cum_cost[tt] = e_cost;
-        cum_cnt[tt] = e_cnt;
-        e_cnt += sc.rows_hist[tt];
-        e_cost += (int64_t)sc.rows_cost[tt];
-      }
-    }
-    if (lane == 63) { cum_cost[n_tex] = i_cost; cum_cnt[n_tex] = i_cnt; }
-  }
   S.lut[t & 255] = (double)(t & 255) / 255.0;
-  __syncthreads();
-  if (t == 0) {
-    const int64_t total = cum_cost[n_tex];
-    int bound[2];
-    for (int q = 0; q < 2; q++) {
-      const int w = (int)blockIdx.x + q;
-      if (w >= (int)gridDim.x || total == 0) { bound[q] = cum_cnt[n_tex]; continue; }
-      const int64_t target = total / (int64_t)gridDim.x * w + (total % (int64_t)gridDim.x) * w / (int64_t)gridDim.x;
-      int lo = 0, hi = n_tex;                    // the last bucket whose first tile starts at or before `target`
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (cum_cost[mid] <= target) lo = mid; else hi = mid;
-      }
-      const int cn = cum_cnt[lo + 1] - cum_cnt[lo];
-      const int64_t bucket = cum_cost[lo + 1] - cum_cost[lo];                    // the bucket's tiles at their average cost
-      const int64_t into = bucket > 0 ? (target - cum_cost[lo]) * cn / bucket : 0;
-      bound[q] = cum_cnt[lo] + (into < (int64_t)cn ? (int)into : cn);
-    }
-    S.next = S.first = bound[0];
-    S.end = bound[1];
-    S.cur = -1;
-  }
-  __syncthreads();
-  const int end = S.end;
-  if (S.first >= end) return;                    // (the whole workgroup)
   RowsWave& W = S.w[wave];
   uint32_t three = 3;
   asm volatile("" : "+v"(three));                // (a vector register: the SDWA shift takes no literal)
-  int pending = -1, ptex = -1, gi = 0;           // pending: index of the pulled tile in the list; DONE: the share is used up
   constexpr int DONE = 0x7fffffff;
   PH_DECL
+  // The list is cut into RW_SHARES shares per workgroup of equal estimated cost; a workgroup takes the next share off a
+  // device-wide counter when its waves have run out of tiles (a static cut left the slowest workgroup 40 % behind the mean).
+  const int n_shares = (int)gridDim.x * RW_SHARES;
+  if (t == 0) S.cur = -1;
   for (;;) {
-    if (pending < 0) {
-      int i = 0;
-      if (lane == 0) i = atomicAdd(&S.next, 1);
-      i = __builtin_amdgcn_readfirstlane(i);
-      if (i < end) {
-        pending = i;
-        gi = __builtin_amdgcn_readfirstlane(sc.rows_sorted[i]);
-        ptex = __builtin_amdgcn_readfirstlane(as_constant(&sc.plan[gi])->tex);
-      } else {
-        pending = DONE;
-      }
+    __syncthreads();                             // (later rounds: every wave is done with its share)
+    if (t == 0) {
+      const int share = (int)atomicAdd(sc.rows_next, 1);
+      const bool any = share < n_shares;
+      S.next = any ? sc.rows_bounds[share] : 0;
+      S.end = any ? sc.rows_bounds[share + 1] : 0;
+      S.first = any ? 1 : 0;
     }
-    if (pending != DONE && ptex == S.cur) {
-      DropPlan p;
-      {
-        const const_ptr<uint32_t> src = as_constant(reinterpret_cast<const uint32_t*>(&sc.plan[gi]));
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(DropPlan) / 4); k++) dst[k] = src[k];
-      }
-      PH(0)                                       // pull + plan
-      rows_tile(p, tex_h[ptex], tex_w[ptex], S, W, sc.arena, three PH_PASS);
-      pending = -1;
-      continue;
-    }
-    // another texture (or nothing left): meet the other waves
-    if (lane == 0) { S.pend[wave] = pending; S.ptex[wave] = ptex; }
-    __syncthreads();                              // nobody reads the resident texture any more
-    int m = DONE, mtex = -1;
-    for (int k = 0; k < RW_WAVES; k++)
-      if (S.pend[k] < m) { m = S.pend[k]; mtex = S.ptex[k]; }
-    if (m == DONE) break;                         // every wave is out of tiles
-    {
-      const int64_t nb = pair_bytes(tex_h[mtex], tex_w[mtex]);
-      const uint4* g = reinterpret_cast<const uint4*>(sc.tex_pair + sc.tex_qoff[mtex]);
-      uint4* d = reinterpret_cast<uint4*>(S.pair);
-      for (int k = t; k < (int)(nb >> 4); k += 1024) d[k] = g[k];
-    }
-    if (t == 0) S.cur = mtex;
     __syncthreads();
-    PH(5)                                         // texture switch (waiting for the other waves + staging)
+    if (!S.first) break;                         // no share left
+    const int end = S.end;
+    int pending = -1, ptex = -1, gi = 0;         // pending: index of the pulled tile in the list; DONE: the share is used up
+    for (;;) {
+      if (pending < 0) {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(&S.next, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i < end) {
+          pending = i;
+          gi = __builtin_amdgcn_readfirstlane(sc.rows_sorted[i]);
+          ptex = __builtin_amdgcn_readfirstlane(as_constant(&sc.plan[gi])->tex);
+        } else {
+          pending = DONE;
+        }
+      }
+      if (pending != DONE && ptex == S.cur) {
+        DropPlan p;
+        {
+          const const_ptr<uint32_t> src = as_constant(reinterpret_cast<const uint32_t*>(&sc.plan[gi]));
+          uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+          for (int k = 0; k < (int)(sizeof(DropPlan) / 4); k++) dst[k] = src[k];
+        }
+        PH(0)                                     // pull + plan
+        rows_tile(p, tex_h[ptex], tex_w[ptex], S, W, sc.arena, three PH_PASS);
+        pending = -1;
+        continue;
+      }
+      // another texture (or nothing left): meet the other waves
+      if (lane == 0) { S.pend[wave] = pending; S.ptex[wave] = ptex; }
+      __syncthreads();                            // nobody reads the resident texture any more
+      int m = DONE, mtex = -1;
+      for (int k = 0; k < RW_WAVES; k++)
+        if (S.pend[k] < m) { m = S.pend[k]; mtex = S.ptex[k]; }
+      if (m == DONE) break;                       // every wave is out of tiles
+      {
+        const int64_t nb = pair_bytes(tex_h[mtex], tex_w[mtex]);
+        const uint4* g = reinterpret_cast<const uint4*>(sc.tex_pair + sc.tex_qoff[mtex]);
+        uint4* d = reinterpret_cast<uint4*>(S.pair);
+        for (int k = t; k < (int)(nb >> 4); k += 1024) d[k] = g[k];
+      }
+      if (t == 0) S.cur = mtex;
+      __syncthreads();
+      PH(5)                                       // texture switch (waiting for the other waves + staging)
+    }
   }
   PH_FLUSH(5)
 }
@@ -5061,8 +5080,10 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.rows_list, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_sorted, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_n, (size_t)F))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.rows_hist, (size_t)RW_TEX_MAX * 3))) return rc;      // + RW_TEX_MAX 8-byte cost sums
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_hist, (size_t)RW_TEX_MAX * 3 + 16))) return rc;      // + RW_TEX_MAX 8-byte cost sums + the share counter
     ctx->sc.rows_cost = reinterpret_cast<unsigned long long*>(ctx->sc.rows_hist + RW_TEX_MAX);
+    ctx->sc.rows_next = ctx->sc.rows_hist + 3 * RW_TEX_MAX;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_bounds, (size_t)RW_SHARE_MAX + 1))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_fbase, (size_t)F * RW_TEX_MAX))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list_n, (size_t)F))) return rc;
@@ -5242,6 +5263,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   sc.tex_qoff = ctx->d_tex_qoff;
   sc.n_tex = ctx->n_tex;
   sc.rows_on = (ctx->tile_rows && ctx->d_tex_pair && ctx->n_tex <= RW_TEX_MAX) ? 1 : 0;
+  // k_tile_rows: one workgroup of 16 waves per CU (the LDS holds one texture + 16 wave-private tables); fewer for small batches
+  const int rows_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ctx->n_cu, RW_SHARE_MAX / RW_SHARES), ((int64_t)n * max_drops + 31) / 32));
   const int blur_wg = ctx->blur_wg ? ctx->blur_wg : 4;      // workgroups per CU the fused blur is sized for
   sc.blur_bx = blur_wg == 3 ? 3072 : (blur_wg == 5 ? 2304 : 2816);
   sc.blur_by = blur_wg == 5 ? 1600 : 2048;
@@ -5407,13 +5430,16 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, bs, "k_dedup");
       HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, bs));
       HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, bs));
-      if (sc.rows_on) HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * RW_TEX_MAX * 3, bs));
+      if (sc.rows_on) HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * (RW_TEX_MAX * 3 + 16), bs));
       hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
       ProfScope ps(ctx, bs, "k_lists");
       hipLaunchKernelGGL(k_lists, dim3(n), dim3(1024), 0, bs, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
-      if (sc.rows_on) hipLaunchKernelGGL(k_rows_scatter, dim3(n), dim3(1024), 0, bs, D, sc);
+      if (sc.rows_on) {
+        hipLaunchKernelGGL(k_rows_scatter, dim3(n), dim3(1024), 0, bs, D, sc);
+        hipLaunchKernelGGL(k_rows_shares, dim3(1), dim3(1024), 0, bs, rows_wgs * RW_SHARES, sc);
+      }
     }
     if (bs != s) {                                         // mode 2: k_colour beside the tile kernels; the tiles wait for the lists
       HIPCHK(hipEventRecord(ctx->ev_lists, bs));
@@ -5426,7 +5452,9 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_tile_generic");
-      hipLaunchKernelGGL(k_tile_generic, dim3(imin((max_drops + 3) / 4, 64), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex,
+      // (rare modes: a few workgroups per frame take them grid-stride; r06: 64 per frame were 32 K workgroups per 512 frames, 0.2 ms of
+      //  launches that found nothing to do)
+      hipLaunchKernelGGL(k_tile_generic, dim3(imin((max_drops + 3) / 4, imax(2, imin(64, 2048 / n))), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex,
                          ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, ctx->d_ctab, sc);
     }
     {
@@ -5438,15 +5466,16 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_tile_rows");
       // one workgroup of 16 waves per CU (the LDS holds one texture + 16 wave-private tables); fewer for small batches:
       // a workgroup's share of the list should be worth staging a texture for
-      const int64_t tiles_max = (int64_t)n * max_drops;
-      const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, (tiles_max + 31) / 32));
-      hipLaunchKernelGGL(k_tile_rows, dim3(wgs), dim3(64 * RW_WAVES), 0, s, D, ctx->d_tex_h, ctx->d_tex_w, sc);
+      hipLaunchKernelGGL(k_tile_rows, dim3(rows_wgs), dim3(64 * RW_WAVES), 0, s, D, ctx->d_tex_h, ctx->d_tex_w, sc);
     }
     {
       ProfScope ps(ctx, s, "k_tile");
       // after de-duplication a frame keeps a fraction of its tiles: a capped grid (items are taken
       // grid-stride) avoids dispatching tens of thousands of empty workgroups
-      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, grid_cap(1536)), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+      // (with k_tile_rows in front only the integer-ratio and out-of-range tiles are left: 64 workgroups per frame were 0.8 ms of empty
+      //  launches per 512 frames)
+      const int per_frame = sc.rows_on ? imax(4, imin(1536, 2048 / n)) : grid_cap(1536);
+      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, per_frame), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
                          ctx->d_tex_off, sc);
     }
     {
@@ -5862,6 +5891,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.rows_n);
   hipFree(ctx->sc.rows_hist);
   hipFree(ctx->sc.rows_fbase);
+  hipFree(ctx->sc.rows_bounds);
   hipFree(ctx->d_tex_pair);
   hipFree(ctx->d_tex_qoff);
   hipFree(ctx->sc.fov_list);

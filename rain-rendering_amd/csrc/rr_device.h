@@ -462,7 +462,7 @@ RR_HD void rows_pass_shape(int tw, int buf, int& R, int& S) {
 }
 // the cells [dA, dB) lane segment j of S takes of a row that touches cells dlo .. dhi
 RR_HD void rows_segment(int dlo, int dhi, int S, int j, int& dA, int& dB) {
-  const int cps = (dhi - dlo + S) / S;             // ceil((dhi - dlo + 1) / S)
+  const int cps = (int)(((float)(dhi - dlo + S) + 0.5f) / (float)S);     // ceil((dhi - dlo + 1) / S): small integers, exact in float
   dA = dlo + j * cps;
   dB = imin(dA + cps, dhi + 1);
 }
