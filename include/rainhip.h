@@ -426,6 +426,9 @@ enum {
   RR_OPT_TILE_ROWS = 22,            /* tuning (r06): 1 (default) rotate + flip + INTER_AREA tiles (Medium / Small drops, generator.py:163-170)
                                      * are rendered by k_tile_rows -- the batch's tiles in one list bucketed by texture, a wave per tile,
                                      * a lane per canvas row, horizontal folds in registers; 0: k_tile (a workgroup per tile).  Same bits. */
+  RR_OPT_ROWS_SHARES = 23,          /* tuning (r06): k_tile_rows' workgroups take the batch's tile list in shares of equal estimated cost off a
+                                     * device-wide counter; this many shares per workgroup (1 .. 8, default 2): more shares even out the
+                                     * workgroups, fewer leave less waiting at a share's end */
   RR_OPT_COMPOSITE_BATCH = 20       /* tuning (r05): 1 (default) the float compositor keeps the records of 64 list entries at a time in
                                      * vector registers (a lane per entry) and runs its alpha samples two entries ahead of the blend;
                                      * 0: a scalar record fetch per entry, samples one entry ahead (r04).  Same operations in the same

@@ -220,7 +220,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int64_t* arena_need;              // [frame]
   int32_t* overflow;                // the batch's own arena-overflow flag (ctx: [1 + RR_PIPE_SLOTS], one per pipeline slot + the device-pointer calls)
   unsigned long long* need_max;     // [1] largest per-frame arena need of every batch since the arena was last (re)sized
-  int32_t* list_rot;                // [frame][drops]  drops taken by k_tile
+  int32_t* list_rot;                // [frames * drops] batch-global indices of the drops k_tile renders, a piece per frame (r06)
+  int32_t* rot_total;               // [1] their number (behind rows_next: the same memset)
   int32_t* list_gen;                // [frame][drops]  drops taken by k_tile_generic
   int32_t* list_slow;               // [frame][drops]  blurred drops the fused kernel cannot take
   int4* blur_items;                 // [frame][8*drops] (drop, first sub-tile, #sub-tiles, -)
@@ -1692,7 +1693,6 @@ constexpr int RW_NW = 324;            // canvas columns of a tile (sh = 320, sw 
 constexpr int RW_BUF = 344;           // doubles of cell sums per wave
 constexpr int RW_PAIR_BYTES = 24640;  // pair texture in LDS: (320 + 3) * 38 * 2 rounded up to 16
 constexpr int RW_TEX_MAX = 1024;      // textures of a database the batch-wide list is bucketed by
-constexpr int RW_SHARES = 6;          // shares of the list per workgroup of k_tile_rows
 constexpr int RW_SHARE_MAX = 4096;    // (>= compute units * RW_SHARES)
 struct RowsWave {                     // wave-private LDS of k_tile_rows
   ColEnt col[RW_NW];
@@ -1981,7 +1981,7 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
 __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_drops, const uint8_t* texels,
                                               const int32_t* tex_h, const int32_t* tex_w, const int64_t* tex_off,
                                               Scratch sc) {
-  const int f = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   __shared__ DropPlan sp;
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
@@ -1990,12 +1990,12 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
   __shared__ double s_buf[BUF_MAX];
   __shared__ double s_can[4][CAN_W];
   __shared__ int4 s_row[4][ROWS_S];
-  const int n_items = sc.counts[f * 8 + 0];
-  if ((int)blockIdx.x >= n_items) return;                                // (before the division table: most frames have few tiles left after k_dedup)
+  const int n_items = *sc.rot_total;                                       // (r06: ONE list for the batch -- with k_tile_rows in front a frame has a handful of these tiles or none)
+  if ((int)blockIdx.x >= n_items) return;
   s_lut[t] = (double)t / 255.0;
   PH_DECL
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // grid-stride over the rot-fast list
-  const int64_t gi = (int64_t)f * max_drops + sc.list_rot[(int64_t)f * max_drops + item];
+  const int64_t gi = sc.list_rot[item];
   __syncthreads();
   PH(7)
   {
@@ -2470,7 +2470,7 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, RowsShared& 
   }
 }
 
-__global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t* tex_h, const int32_t* tex_w, Scratch sc) {
+__global__ __launch_bounds__(1024) void k_tile_rows(int n_shares, const int32_t* tex_h, const int32_t* tex_w, Scratch sc) {
   __shared__ __attribute__((aligned(16))) RowsShared S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)S.lut != 0u) __builtin_trap();   // (see RowsShared)
@@ -2480,9 +2480,8 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int max_drops, const int32_t
   asm volatile("" : "+v"(three));                // (a vector register: the SDWA shift takes no literal)
   constexpr int DONE = 0x7fffffff;
   PH_DECL
-  // The list is cut into RW_SHARES shares per workgroup of equal estimated cost; a workgroup takes the next share off a
+  // The list is cut into n_shares shares (a few per workgroup) of equal estimated cost; a workgroup takes the next share off a
   // device-wide counter when its waves have run out of tiles (a static cut left the slowest workgroup 40 % behind the mean).
-  const int n_shares = (int)gridDim.x * RW_SHARES;
   if (t == 0) S.cur = -1;
   for (;;) {
     __syncthreads();                             // (later rounds: every wave is done with its share)
@@ -2601,7 +2600,10 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   for (int k = 0; k < NC; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
   const int n_int = sh[1023][5];     // integer-ratio drops go to the FRONT of the rot list (longest blocks first)
   o[0] += n_int;
-  int32_t* lrot = sc.list_rot + base;
+  __shared__ int s_rot_base;
+  if (t == 0) s_rot_base = atomicAdd(sc.rot_total, sh[1023][0] + sh[1023][5]);      // the frame's piece of the batch-wide list (any order of the frames)
+  __syncthreads();
+  int32_t* lrot = sc.list_rot + s_rot_base;
   int32_t* lgen = sc.list_gen + base;
   int32_t* lslow = sc.list_slow + base;
   int32_t* lsmall = sc.list_small + base;
@@ -2618,7 +2620,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
         lbig[o[6]++] = i;
         o[7] += p.tw * p.th;
       } else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) lrows[o[8]++] = i;
-      else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = i; else lrot[o[0]++] = i; } else lgen[o[1]++] = i;
+      else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = (int32_t)(base + i); else lrot[o[0]++] = (int32_t)(base + i); } else lgen[o[1]++] = i;
     }
     if (p.r1 > 0) {
       if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
@@ -4827,6 +4829,7 @@ struct rr_ctx {
   int64_t* d_tex_qoff = nullptr;
   bool tile_rows = true;             // RR_OPT_TILE_ROWS: rotate + INTER_AREA tiles by row walks, a wave per tile (k_tile_rows)
   int n_cu = 256;                    // compute units of the device (persistent kernels size their grid by it)
+  int rows_shares = 2;               // RR_OPT_ROWS_SHARES: shares of the tile list per workgroup of k_tile_rows
   bool png_deflate = false;          // RR_OPT_PNG_DEFLATE: the PNG outputs hold zlib streams (rr_deflate.h)
   uint8_t* d_pngz_slots = nullptr;
   rrz::BlockMeta* d_pngz_meta = nullptr;
@@ -5083,6 +5086,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.rows_hist, (size_t)RW_TEX_MAX * 3 + 16))) return rc;      // + RW_TEX_MAX 8-byte cost sums + the share counter
     ctx->sc.rows_cost = reinterpret_cast<unsigned long long*>(ctx->sc.rows_hist + RW_TEX_MAX);
     ctx->sc.rows_next = ctx->sc.rows_hist + 3 * RW_TEX_MAX;
+    ctx->sc.rot_total = ctx->sc.rows_next + 1;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_bounds, (size_t)RW_SHARE_MAX + 1))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_fbase, (size_t)F * RW_TEX_MAX))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list, fd))) return rc;
@@ -5264,7 +5268,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   sc.n_tex = ctx->n_tex;
   sc.rows_on = (ctx->tile_rows && ctx->d_tex_pair && ctx->n_tex <= RW_TEX_MAX) ? 1 : 0;
   // k_tile_rows: one workgroup of 16 waves per CU (the LDS holds one texture + 16 wave-private tables); fewer for small batches
-  const int rows_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ctx->n_cu, RW_SHARE_MAX / RW_SHARES), ((int64_t)n * max_drops + 31) / 32));
+  const int rows_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ctx->n_cu, RW_SHARE_MAX / ctx->rows_shares), ((int64_t)n * max_drops + 31) / 32));
   const int blur_wg = ctx->blur_wg ? ctx->blur_wg : 4;      // workgroups per CU the fused blur is sized for
   sc.blur_bx = blur_wg == 3 ? 3072 : (blur_wg == 5 ? 2304 : 2816);
   sc.blur_by = blur_wg == 5 ? 1600 : 2048;
@@ -5430,7 +5434,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, bs, "k_dedup");
       HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, bs));
       HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, bs));
-      if (sc.rows_on) HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * (RW_TEX_MAX * 3 + 16), bs));
+      HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * (RW_TEX_MAX * 3 + 16), bs));      // histogram, cost sums, share counter, rot_total
       hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
@@ -5438,7 +5442,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       hipLaunchKernelGGL(k_lists, dim3(n), dim3(1024), 0, bs, ctx->d_frames, D, ctx->d_tex_h, ctx->d_tex_w, sc);
       if (sc.rows_on) {
         hipLaunchKernelGGL(k_rows_scatter, dim3(n), dim3(1024), 0, bs, D, sc);
-        hipLaunchKernelGGL(k_rows_shares, dim3(1), dim3(1024), 0, bs, rows_wgs * RW_SHARES, sc);
+        hipLaunchKernelGGL(k_rows_shares, dim3(1), dim3(1024), 0, bs, rows_wgs * ctx->rows_shares, sc);
       }
     }
     if (bs != s) {                                         // mode 2: k_colour beside the tile kernels; the tiles wait for the lists
@@ -5466,17 +5470,17 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, s, "k_tile_rows");
       // one workgroup of 16 waves per CU (the LDS holds one texture + 16 wave-private tables); fewer for small batches:
       // a workgroup's share of the list should be worth staging a texture for
-      hipLaunchKernelGGL(k_tile_rows, dim3(rows_wgs), dim3(64 * RW_WAVES), 0, s, D, ctx->d_tex_h, ctx->d_tex_w, sc);
+      hipLaunchKernelGGL(k_tile_rows, dim3(rows_wgs), dim3(64 * RW_WAVES), 0, s, rows_wgs * ctx->rows_shares, ctx->d_tex_h, ctx->d_tex_w, sc);
     }
     {
       ProfScope ps(ctx, s, "k_tile");
       // after de-duplication a frame keeps a fraction of its tiles: a capped grid (items are taken
       // grid-stride) avoids dispatching tens of thousands of empty workgroups
-      // (with k_tile_rows in front only the integer-ratio and out-of-range tiles are left: 64 workgroups per frame were 0.8 ms of empty
-      //  launches per 512 frames)
-      const int per_frame = sc.rows_on ? imax(4, imin(1536, 2048 / n)) : grid_cap(1536);
-      hipLaunchKernelGGL(k_tile, dim3(imin(max_drops, per_frame), n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
-                         ctx->d_tex_off, sc);
+      // one batch-wide list, taken grid-stride (the length only exists on the device): with k_tile_rows in front only the
+      // integer-ratio and out-of-range tiles are left -- 64 workgroups per FRAME were 0.8 ms of empty launches per 512 frames
+      const int64_t cap = sc.rows_on ? 2048 : 16384;
+      hipLaunchKernelGGL(k_tile, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n * max_drops, cap))), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex,
+                         ctx->d_tex_h, ctx->d_tex_w, ctx->d_tex_off, sc);
     }
     {
       ProfScope ps(ctx, s, "k_blur_weights");
@@ -6983,6 +6987,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
     case RR_OPT_TILE_ROWS: ctx->tile_rows = value != 0; return RR_OK;
+    case RR_OPT_ROWS_SHARES: ctx->rows_shares = value < 1 ? 1 : (value > 8 ? 8 : value); return RR_OK;
     case RR_OPT_FOV_FILL_RULE: ctx->fill_rule = value == 1 ? 1 : 0; return RR_OK;
     case RR_OPT_BIN_ROWS: ctx->bin_rows = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;

@@ -35,6 +35,7 @@ RR_OPT_BIN_ROWS = 19
 RR_OPT_COMPOSITE_BATCH = 20
 RR_OPT_COLOUR_STREAM = 21
 RR_OPT_TILE_ROWS = 22
+RR_OPT_ROWS_SHARES = 23
 RR_OUT_RAINY_F32, RR_OUT_ENV_F32 = 1, 2                 # rr_prepass_out.out_types
 RR_IN_BG_PNG_ROWS, RR_DEPTH_PNG_ROWS = 32, 3              # a file's filtered scanlines (rr_io_read_frames_rows): un-filtered on the device
 RR_DEPTH_U16 = 2                                        # rr_prepass_in.depth_f64: the uint16 samples of the depth file (metres = sample / 256)
