@@ -1835,8 +1835,9 @@ __global__ __launch_bounds__(256) void k_tile_generic(const FrameDesc* frames, i
   __shared__ double s_lut[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_tex[TEX_LDS];
   __shared__ int2 s_adbd[NW_MAX];
-  s_lut[t] = (double)t / 255.0;
   const int n_items = sc.counts[f * 8 + 1];
+  if ((int)blockIdx.x >= n_items * GEN_SLICES) return;                    // (nearly every frame: nothing here)
+  s_lut[t] = (double)t / 255.0;
   // the generic list is a handful of heavy tiles (every pixel a long sequential sum): each is split
   // over GEN_SLICES workgroups by pixel index, or one of them would be the tail of the whole batch
   for (int work = blockIdx.x; work < n_items * GEN_SLICES; work += gridDim.x) {      // grid-stride over (item, slice)
