@@ -521,18 +521,22 @@ def fill_fov_mask_span_rule(mask, poly_int):
 
 
 # Which rule stands in for cv2.fillConvexPoly(mask, s, 1) (reference common/bad_weather.py:388):
-#   'span' (default; what the library's fast colour kernels implement) -- fov_rowspans_span_rule;
-#   'cv'   -- OpenCV's algorithm as restated at the end of this file (cv_fill_convex_poly) for the closed N_FOV-gon that does
+#   'cv'   (default since round 6; the library's RR_OPT_FOV_FILL_RULE 1 / rr_device.h fov_rowspan_cv, also its default) --
+#             OpenCV's algorithm as restated at the end of this file (cv_fill_convex_poly) for the closed N_FOV-gon that does
 #             not wrap; wrapping polygons keep the span rule (FillConvexPoly's result for them depends on the vertex Clipper
-#             lists first).  The library's RR_OPT_FOV_FILL_RULE 1 / rr_device.h fov_rowspan_cv.
+#             lists first, which cannot be reconstructed);
+#   'span' (rounds 1-5; RR_OPT_FOV_FILL_RULE 0) -- fov_rowspans_span_rule for every polygon.
 # tests/test_fill_rules.py and scripts/fill_rule_study.py measure what the choice changes (colour only: <= 0.3 % of a drop's
 # colour constants, <= 1 LSB of rainy_image on 1.4 % of its values at KITTI 100 mm/hr; the mask never sees it).
-FILL_RULE = 'span'
+DEFAULT_FILL_RULE = 'cv'
+FILL_RULE = DEFAULT_FILL_RULE
 N_FOV = 20
 
 
-def set_fill_rule(rule, n_fov=20):
+def set_fill_rule(rule=None, n_fov=20):
+    """rule None: back to the default."""
     global FILL_RULE, N_FOV
+    rule = DEFAULT_FILL_RULE if rule is None else rule
     assert rule in ('span', 'cv')
     FILL_RULE, N_FOV = rule, n_fov
 

@@ -563,7 +563,7 @@ __device__ inline bool fov_rowspan_fast(const int32_t* px, const int32_t* py, in
 //      ds_min / ds_max (order-free, no return value).  The spans leave as one u32 per row, xl | (xr + 1) << 16
 //      (0 = empty), in the [row quad][drop] layout k_fov_sums reads coalesced.
 template <int NCH, bool from_list>
-__global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int use32, Scratch sc) {
+__global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int use32, int cv_rule, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
   const int N = cam.n_fov, G = imin(64 / N, FOV_GROUPS);
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   __shared__ float s_phi32[2][RR_MAX_FOV];
   __shared__ int s_px[4][FOV_GROUPS][POLY_STRIDE], s_py[4][FOV_GROUPS][POLY_STRIDE];
   __shared__ int s_xl[4][NCH * 64], s_xr[4][NCH * 64];         // per wave: the row spans of the drop being converted
-  __shared__ int4 s_edge[4][2 * POLY_STRIDE];                  // per wave: the edges of that drop
+  __shared__ int4 s_edge[4][3 * POLY_STRIDE];                  // per wave: the edges of that drop
   if (threadIdx.x < RR_MAX_FOV) {
     s_phi[0][threadIdx.x] = cam.phi_cos[threadIdx.x];
     s_phi[1][threadIdx.x] = cam.phi_sin[threadIdx.x];
@@ -708,7 +708,11 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
   for (int gg = 0; gg < G; gg++) {
     const int mg = __builtin_amdgcn_readfirstlane(__shfl(m, gg * N));
     if (mg <= 0) continue;                                     // no polygon: k_fov_sums never reads this drop's spans
-    // lane e describes edge e and leaves the description in LDS: (ylo, first row, last row, xa), (dx, den, 1/(2 den))
+    // RR_OPT_FOV_FILL_RULE 1: OpenCV's rule (rr_device.h fov_rowspan_cv) for the closed, monotone N-gon with every vertex on the
+    // map (fov_fill_rule_cv_applies); everything else -- the wrapping polygons above all -- keeps the span rule
+    const bool cvg = cv_rule && fov_fill_rule_cv_applies(s_px[wave][gg], s_py[wave][gg], mg, N, He, dm.We);     // (wave-uniform)
+    // lane e describes edge e and leaves the description in LDS: (ylo, first row, last row, xa), (dx, den, 1/(2 den)),
+    // (walker step, hh, hr: edge_cv_consts)
     int cnt = 0;                                               // rows of the map the edge touches (<= 0: none)
     if (lane < mg) {
       const int j = (lane + 1 == mg) ? 0 : lane + 1;
@@ -720,33 +724,39 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
       const float inv = den > 0 ? 1.0f / (float)(2 * den) : 0.f;
       const int ra = imax(ylo, 0), rb = imin(yhi, He - 1);
       cnt = rb - ra + 1;
-      s_edge[wave][2 * lane] = make_int4(ylo, ra, rb, xa);
-      s_edge[wave][2 * lane + 1] = make_int4(dx, den, __float_as_int(inv), 0);
+      int d16 = 0, q_hh = 0, q_hr = 0;
+      if (cvg && den > 0) edge_cv_consts(dx, den, d16, q_hh, q_hr);
+      s_edge[wave][3 * lane] = make_int4(ylo, ra, rb, xa);
+      s_edge[wave][3 * lane + 1] = make_int4(dx, den, __float_as_int(inv), 0);
+      s_edge[wave][3 * lane + 2] = make_int4(d16, q_hh, q_hr, 0);
     }
     wave_lds_sync();                                           // edges published; span tables initialised (start / previous read-out)
     // Two edges per step, one per half wave (an edge covers ~30 rows: a whole wave per edge would idle half its
-    // lanes), 32 rows of each per inner step; every lane fetches its edge's description with two 16-byte reads.
+    // lanes), 32 rows of each per inner step; every lane fetches its edge's description with 16-byte reads.
     for (int e = 0; e < mg; e += 2) {
       const int eb = imin(e + 1, mg - 1);                      // (an odd last edge is done by both halves: min / max are idempotent)
       const int nmax = imax(__builtin_amdgcn_readlane(cnt, e), __builtin_amdgcn_readlane(cnt, eb));
       if (nmax <= 0) continue;
       const int me = lane < 32 ? e : eb;
-      const int4 A = s_edge[wave][2 * me], B = s_edge[wave][2 * me + 1];
+      const int4 A = s_edge[wave][3 * me], B = s_edge[wave][3 * me + 1], C = s_edge[wave][3 * me + 2];
       const int ylo = A.x, ra = A.y, rbv = A.z, xa = A.w, dx = B.x, den = B.y;
       const float inv = __int_as_float(B.z);
       const bool hz = den == 0;                                // horizontal edge: both end points on its one row
-      const int hl = imin(xa, xa + dx), hh = imax(xa, xa + dx);
+      const int hz_l = imin(xa, xa + dx), hz_h = imax(xa, xa + dx);
       const int dx2 = 2 * dx, dn = 2 * den;
       for (int c = 0; c < nmax; c += 32) {
         const int y = ra + c + (lane & 31);
         if (y <= rbv) {                                        // a row is touched by one lane
           const int t = y - ylo;
-          const int nn = __mul24(dx2, t) + den;                // exact: |dx2 * t| < 2^23 (host check)
-          int q = (int)floorf((float)nn * inv);                // floor(nn / dn) up to +-1 ...
-          const int rem = nn - __mul24(q, dn);
-          q += rem < 0 ? -1 : (rem >= dn ? 1 : 0);             // ... made exact
-          atomicMin(&xl[y], hz ? hl : xa + q);
-          atomicMax(&xr[y], hz ? hh : xa + q);
+          const int n2 = __mul24(dx2, t);                      // exact: |dx2 * t| < 2^23 (host check)
+          int q = (int)floorf((float)n2 * inv);                // floor(n2 / dn) up to +-1 ...
+          int rem = n2 - __mul24(q, dn);
+          if (rem < 0) { q -= 1; rem += dn; }
+          else if (rem >= dn) { q += 1; rem -= dn; }           // ... made exact
+          int l = xa + q + (rem >= den ? 1 : 0), h = l;        // the span rule: floor((n2 + den) / dn)
+          if (cvg && !hz) edge_row_cv(xa, xa + dx, den, dx, C.x, C.y, C.z, t, q, rem, l, h);
+          atomicMin(&xl[y], hz ? hz_l : l);
+          atomicMax(&xr[y], hz ? hz_h : h);
         }
       }
     }
@@ -805,6 +815,10 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
 //   3. everything else -- a wrapping polygon (24 vertices, not monotone), a predicate within its error bound (float64
 //      decides), a vertex sequence that is not monotone after all -- goes to the frame's list for k_fov_spans (from_list),
 //      a fraction of a percent of the drops.
+// CV (r06, RR_OPT_FOV_FILL_RULE 1, the default): the spans are what cv2.fillConvexPoly sets (rr_device.h fov_rowspan_cv: the
+// outline's Bresenham pixels + the 16.16 edge walkers, in closed form per edge and row) for the polygons OpenCV's rule
+// applies to (every vertex on the map); the per-edge constants are made before the walk, two dwords per edge and lane.
+template <bool CV>
 __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
@@ -828,7 +842,7 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
   int uns = 0;                                                 // reason bits (rr_device.h): float64 has to decide
   int count_true = 0, count_false = 0;
   int ktop = 0, ytop = 1 << 30, ybot = -(1 << 30), r_first = 0;
-  bool spread = false;
+  bool spread = false, on_map = true;
   int turns = 0, dir = 0, dir_first = 0;                       // sign changes of the vertices' row sequence (a closed monotone curve: 2)
   if (act) {
     FovSetup32 F;
@@ -841,6 +855,7 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
       fov_vertex32(F, (float)cam.radius, s_phi32[0][k], s_phi32[1][k], dm.He, dm.We, az, er, pxf, pyf, uns);
       const int ix = (int)pxf, iy = (int)pyf;
       pix[k * 64 + lane] = (uint32_t)(ix & 0xffff) | ((uint32_t)(iy & 0xffff) << 16);
+      on_map = on_map && ix >= 0 && ix < dm.We && iy >= 0 && iy < dm.He;      // (fov_fill_rule_cv_applies)
       const int r = imin(imax(iy, 0), dm.He - 1);
       if (k == 0) { az0 = az; er0 = er; r_first = r; y0v = iy; }
       else {
@@ -890,140 +905,41 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
     x = (int)(v & 0xffffu);
     y = (int)(v >> 16);
   };
+  // OpenCV's rule: the constants of edge {k, k + 1} (upper end first), behind the vertices: econ[(2 k + w) * 64 + lane]
+  uint32_t* econ = s_pix_dyn + 4 * N * 64 + wave * 2 * N * 64;
+  const bool cvr = CV && mine && on_map;                       // (a vertex off the map: the span rule, like the oracle)
+  if (CV) {
+    if (cvr) {
+      for (int k = 0; k < N; k++) {
+        int x0, y0, x1, y1;
+        vertex(k, x0, y0);
+        vertex(k + 1 == N ? 0 : k + 1, x1, y1);
+        const bool swp = y1 < y0;
+        const int den = swp ? y0 - y1 : y1 - y0, dx = swp ? x0 - x1 : x1 - x0;
+        int d16 = 0, hh = 0, hr = 0;
+        if (den > 0) edge_cv_consts(dx, den, d16, hh, hr);
+        econ[(2 * k) * 64 + lane] = (uint32_t)d16;
+        econ[(2 * k + 1) * 64 + lane] = (uint32_t)(hh | (hr << 12));
+      }
+    }
+    wave_lds_sync();
+  }
+  auto edgec = [&](int kk, int& d16, int& hhr) {
+    d16 = (int)econ[(2 * kk) * 64 + lane];
+    hhr = (int)econ[(2 * kk + 1) * 64 + lane];
+  };
   DdaCursors<decltype(vertex)> cur;
-  cur.init(vertex, N, ktop);
+  if (CV && cvr) cur.init_cv(vertex, edgec, N, ktop);
+  else cur.init(vertex, N, ktop);
   uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;
   for (int y = 0; y < Hp; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
-    if (mine && y >= ytop && y <= ybot) cur.row(vertex, y, lo, hi);
+    if (mine && y >= ytop && y <= ybot) {
+      if (CV && cvr) cur.template row_rule<true>(vertex, edgec, y, lo, hi);
+      else cur.row(vertex, y, lo, hi);
+    }
     const int a = imax(lo, 0), b = imin(hi, dm.We - 1);
     if (mine) out[(int64_t)y * Dp] = (y < dm.He && a <= b) ? ((uint32_t)a | ((uint32_t)(b + 1) << 16)) : 0u;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// FOV polygon and row spans, one thread per drop, incremental cursors (r05; RR_OPT_FOV_DDA 2 -- NOT the default: see the end
-// of this comment)
-// ---------------------------------------------------------------------------
-// k_fov_dda spends 120 vector + 78 scalar instructions per map row and wave: an exact division per cursor and row, and a
-// divergent search for the next vertex inside the row loop.  Here (rr_device.h DdaWalk):
-//   * the vertex loop leaves one 8-byte RECORD per polygon edge in wave-private LDS, rec[edge][lane] (a lane touches bank
-//     pair `lane`: no conflicts): floor(dx / den) + 1, 2 (dx mod den), den and the edge's last row -- the edge's one
-//     division is done there, by every lane at once;
-//   * the row loop is uniform over the map's rows: a cursor steps with five integer instructions
-//     (the sign of the running remainder is the carry), a row's span is min / max of the two cursors;
-//   * a lane whose cursor reaches its edge's last row takes the next record -- fetched from LDS an edge ahead, so the
-//     event itself waits for nothing.  Horizontal edges (rare) fold their far end on the spot.
-// Lanes above their polygon's first row are parked on the top vertex (a step that moves nothing), rows below the last one
-// are masked at the store.  Classification, the frame's list for k_fov_spans and the span layout are k_fov_dda's: the
-// spans are the same bits (RR_OPT_FOV_DDA 0 / 1 / 2 give identical colour constants: tests/test_gpu_properties.py).
-// Measured (profiles/r05_ab_log.md): 3.29 ms against k_fov_dda's 3.28 per 512 frames with the r04 span layout, 3.76 against
-// 3.45 with the [row][drop] layout k_fov_sums32 wants now -- a quarter of the static instructions per row, the same time:
-// with 64 unrelated polygons per wave some lane meets a vertex on 97 % of the rows and the divergent "next edge" path runs
-// nearly every row (vertex phase alone 0.71 ms, row loop without its stores 2.3 ms).  k_fov_dda stays the default.
-__global__ __launch_bounds__(256) void k_fov_walk(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
-  const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const FrameDesc& fr = frames[f];
-  const int N = cam.n_fov;
-  __shared__ float s_phi32[2][RR_MAX_FOV];
-  extern __shared__ __attribute__((aligned(8))) uint2 s_rec_dyn[];      // [4 waves][N edges][64 lanes]
-  if (threadIdx.x < RR_MAX_FOV) {
-    s_phi32[0][threadIdx.x] = (float)cam.phi_cos[threadIdx.x];
-    s_phi32[1][threadIdx.x] = (float)cam.phi_sin[threadIdx.x];
-  }
-  __syncthreads();
-  const int i = (blockIdx.x * 4 + wave) * 64 + lane;           // this lane's drop
-  const bool act = i < fr.n_drops;
-  const int64_t gi = (int64_t)f * max_drops + (act ? i : 0);
-  if (fr.strategy == 1) {                                      // 'white': the FOV is computed by the reference but never used
-    if (act) sc.npts[gi] = -1;
-    return;
-  }
-  uint2* recs = s_rec_dyn + wave * N * 64 + lane;              // this lane's column: recs[edge * 64]
-  // ---- 1. vertices, and the record of every edge as soon as both its ends are known ----
-  int uns = 0;
-  int count_true = 0, count_false = 0;
-  int ktop = 0, xtop = 0, ytop = 1 << 30, ybot = -(1 << 30), r_first = 0;
-  bool spread = false;
-  int turns = 0, dir = 0, dir_first = 0;
-  if (act) {
-    FovSetup32 F;
-    const rr_drop d = load_drop(fr.drops + i);
-    fov_setup32(d, (float)cam.fov_cos, (float)cam.fov_sin, F, uns);
-    float az_prev = 0.f, er_prev = 0.f, az0 = 0.f, er0 = 0.f;
-    int x_prev = 0, y_prev = 0, x0v = 0, y0v = 0;
-    for (int k = 0; k < N; k++) {
-      float az, er, pxf, pyf;
-      fov_vertex32(F, (float)cam.radius, s_phi32[0][k], s_phi32[1][k], dm.He, dm.We, az, er, pxf, pyf, uns);
-      const int ix = (int)pxf & 0x7fff, iy = (int)pyf & 0x7fff;              // (a sure drop's vertices lie on the map: the masks keep the
-      const int r = imin(imax((int)pyf, 0), dm.He - 1);                      //  records of the others inside their fields)
-      if (k == 0) { az0 = az; er0 = er; r_first = r; x0v = ix; y0v = iy; }
-      else {
-        const bool c = fov_wrap_cnd32(az_prev, az, er_prev, er, uns);      // side k-1 -> k
-        count_true += c ? 1 : 0;
-        count_false += c ? 0 : 1;
-        spread = spread || iabs(r - r_first) >= 2;
-        const int sg = iy > y_prev ? 1 : (iy < y_prev ? -1 : 0);
-        if (sg != 0) {
-          if (dir == 0) dir_first = sg;
-          else if (sg != dir) turns++;
-          dir = sg;
-        }
-        uint32_t w0, w1;
-        dda_edge_record(x_prev, y_prev, ix, iy, w0, w1);
-        recs[(k - 1) * 64] = make_uint2(w0, w1);
-      }
-      if (iy < ytop) { ytop = iy; ktop = k; xtop = ix; }
-      ybot = imax(ybot, iy);
-      az_prev = az; er_prev = er; x_prev = ix; y_prev = iy;
-    }
-    {                                                          // the closing side N-1 -> 0
-      const bool c = fov_wrap_cnd32(az_prev, az0, er_prev, er0, uns);
-      count_true += c ? 1 : 0;
-      count_false += c ? 0 : 1;
-      const int sg = y0v > y_prev ? 1 : (y0v < y_prev ? -1 : 0);
-      if (sg != 0) {
-        if (dir != 0 && sg != dir) turns++;
-        dir = sg;
-      }
-      if (dir != 0 && dir_first != 0 && dir != dir_first) turns++;        // around the closing point
-      uint32_t w0, w1;
-      dda_edge_record(x_prev, y_prev, x0v, y0v, w0, w1);
-      recs[(N - 1) * 64] = make_uint2(w0, w1);
-    }
-  }
-  // ---- classification (fov_polygon_auto), as k_fov_dda ----
-  const bool certain_fail = (uns & 128) && !(uns & 3);
-  const bool wrap = count_true == 1 || count_false == 1;
-  const bool undecided = (uns & ~128) != 0 || count_true == 0 || count_false == 0 || (!wrap && !spread);
-  const bool monotone = turns <= 2;
-  const bool mine = act && !certain_fail && !undecided && !wrap && monotone;
-  if (act && certain_fail) sc.npts[gi] = 0;
-  if (act && !certain_fail && !mine) {
-    const int pos = atomicAdd(&sc.fov_list_n[f], 1);
-    sc.fov_list[(int64_t)f * max_drops + pos] = i;
-  }
-  if (mine) sc.npts[gi] = N;
-  if (__ballot(mine) == 0ull) return;
-  wave_lds_sync();                                             // (records: written and read by the same lane; compiler ordering only)
-  // ---- 2. spans: two cursors down from the top vertex, a record per edge ----
-  auto rec = [&](int k, uint32_t& a, uint32_t& b) {
-    const uint2 v = recs[k * 64];
-    a = v.x;
-    b = v.y;
-  };
-  DdaWalk<decltype(rec)> cur;
-  if (!mine) { ktop = 0; xtop = 0; ytop = 1 << 20; ybot = 0; }   // (never reaches its first row: parked throughout)
-  cur.init(rec, N, ktop, xtop, ytop);
-  const unsigned span_rows = mine ? (unsigned)(ybot - ytop) : 0u;
-  uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;        // a wave stores 256 consecutive bytes per row
-  const int xmax = dm.We - 1;
-  for (int y = 0; y < Hp; y++) {
-    int lo, hi;
-    cur.row(rec, y, lo, hi);
-    const int b = imin(hi, xmax);                              // (lo >= 0: vertex coordinates are not negative)
-    const bool in = mine && (unsigned)(y - ytop) <= span_rows && y < dm.He && lo <= b;
-    if (mine) out[(int64_t)y * Dp] = in ? ((uint32_t)lo | ((uint32_t)(b + 1) << 16)) : 0u;
   }
 }
 
@@ -4840,9 +4756,9 @@ struct rr_ctx {
   int32_t *d_pad_first = nullptr, *d_eff_first = nullptr;
   size_t pad_cap = 0;                // elements of each
   bool pipe_f32 = true;              // RR_OPT_PIPELINE_F32: float32 hand-over from the pre-pass to the hot path inside rr_pipeline_*
-  bool walk_attr = false;
+  bool dda_attr = false;
   bool bin_rows = true;              // RR_OPT_BIN_ROWS
-  int fill_rule = 0;                 // RR_OPT_FOV_FILL_RULE
+  int fill_rule = 1;                 // RR_OPT_FOV_FILL_RULE: 1 (default since r06) OpenCV's fillConvexPoly; 0 the span rule of rounds 1-5
   bool composite_u16 = true;         // RR_OPT_COMPOSITE_U16
   bool blur_dma = true;              // RR_OPT_BLUR_DMA
   int fov_dda = 1;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (1: k_fov_dda, 2: k_fov_walk)
@@ -5059,7 +4975,7 @@ void prof_collect(rr_ctx* ctx) {
 // the fast colour path needs the span state of a drop in registers and a map row in LDS, and its exact span
 // arithmetic needs |2*dx*dy| < 2^23 (k_fov_spans)
 bool fov_fast_path(const rr_ctx* ctx, const Dims& dm) {
-  return !ctx->general_fov && ctx->fill_rule == 0 && dm.He <= HE_MAX && dm.We <= FOV_WE_MAX && (int64_t)dm.We * dm.He < (1 << 22) && ctx->cam.n_fov * 1 <= 64 &&
+  return !ctx->general_fov && dm.He <= HE_MAX && dm.We <= FOV_WE_MAX && (int64_t)dm.We * dm.He < (1 << 22) && ctx->cam.n_fov * 1 <= 64 &&
          ctx->cam.n_fov >= 3;
 }
 
@@ -5281,6 +5197,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   auto grid_cap = [&](int single_frame) { return imax(64, imin(single_frame, 16384 / n)); };
   if (max_drops > 0) {
     const bool fast = fov_fast_path(ctx, dm);
+    const bool cv_rule = ctx->fill_rule == 1;              // RR_OPT_FOV_FILL_RULE: OpenCV's fillConvexPoly where it applies
     // r05 (RR_OPT_COLOUR_STREAM): two chains that only meet in k_colour can run on two streams of the library.
     //   the FOV chain   k_fov_dda -> k_fov_spans (the list) -> k_fov_sums32: three numbers per drop; integer issue, then
     //                   one 1024-thread workgroup per CU waiting on loads
@@ -5335,30 +5252,32 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       const dim3 grid((max_drops + 4 * G - 1) / (4 * G), n);
       if (dda) {
         HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, fs));
-        if (ctx->fov_dda == 1) {
-          hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 255) / 256, n), dim3(256), sizeof(uint32_t) * 4 * 64 * (size_t)ctx->cam.n_fov, fs, ctx->d_frames, dm,
-                             ctx->cam, D, Hp, Dp, sc);
-        } else {                                              // r05: incremental cursors over per-edge records
-          const size_t lds = sizeof(uint2) * 4 * 64 * (size_t)ctx->cam.n_fov;
-          if (!ctx->walk_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint2) * 4 * 64 * RR_MAX_FOV)));
-            ctx->walk_attr = true;
+        {
+          // (r06, OpenCV's rule: + two dwords per edge and lane -- the walker's step and the outline's run lengths, made before the walk)
+          const size_t lds = sizeof(uint32_t) * (cv_rule ? 3 : 1) * 4 * 64 * (size_t)ctx->cam.n_fov;
+          if (cv_rule) {
+            if (!ctx->dda_attr) {
+              HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 3 * 4 * 64 * RR_MAX_FOV)));
+              ctx->dda_attr = true;
+            }
+            hipLaunchKernelGGL(k_fov_dda<true>, dim3((max_drops + 255) / 256, n), dim3(256), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
+          } else {
+            hipLaunchKernelGGL(k_fov_dda<false>, dim3((max_drops + 255) / 256, n), dim3(256), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
           }
-          hipLaunchKernelGGL(k_fov_walk, dim3((max_drops + 255) / 256, n), dim3(256), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
         }
         const dim3 lgrid(imin((int)grid.x, 8), n);           // the list is short: a few workgroups per frame walk it, in float64
         if (dm.He <= 384)
-          hipLaunchKernelGGL((k_fov_spans<6, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+          hipLaunchKernelGGL((k_fov_spans<6, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, cv_rule ? 1 : 0, sc);
         else if (dm.He <= 512)
-          hipLaunchKernelGGL((k_fov_spans<8, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+          hipLaunchKernelGGL((k_fov_spans<8, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, cv_rule ? 1 : 0, sc);
         else
-          hipLaunchKernelGGL((k_fov_spans<16, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, sc);
+          hipLaunchKernelGGL((k_fov_spans<16, true>), lgrid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, 0, cv_rule ? 1 : 0, sc);
       } else if (dm.He <= 384)
-        hipLaunchKernelGGL((k_fov_spans<6, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<6, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, cv_rule ? 1 : 0, sc);
       else if (dm.He <= 512)
-        hipLaunchKernelGGL((k_fov_spans<8, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<8, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, cv_rule ? 1 : 0, sc);
       else
-        hipLaunchKernelGGL((k_fov_spans<16, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, sc);
+        hipLaunchKernelGGL((k_fov_spans<16, false>), grid, dim3(256), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, v32, cv_rule ? 1 : 0, sc);
     } else {
       ProfScope ps(ctx, fs, "k_fov_poly");
       hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, fs, ctx->d_frames, dm, ctx->cam, D, sc);
@@ -6993,7 +6912,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_BIN_ROWS: ctx->bin_rows = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;
     case RR_OPT_BLUR_DMA: ctx->blur_dma = value != 0; return RR_OK;
-    case RR_OPT_FOV_DDA: ctx->fov_dda = value < 0 ? 0 : (value > 2 ? 2 : value); return RR_OK;
+    case RR_OPT_FOV_DDA: ctx->fov_dda = value != 0 ? 1 : 0; return RR_OK;       // (2 was k_fov_walk, r05: measured, no faster, removed in r06)
     case RR_OPT_PIPELINE_F32: ctx->pipe_f32 = value != 0; return RR_OK;
     case RR_OPT_WILD_PIXELS: ctx->wild_pixels = value != 0; return RR_OK;
     case RR_OPT_PNG_DEFLATE: ctx->png_deflate = value != 0; return RR_OK;

@@ -888,6 +888,34 @@ RR_HD bool fov_rowspan_cv(const int32_t* px, const int32_t* py, int n, int y, in
   return xl <= xr;
 }
 
+// The per-edge constants of OpenCV's rule (upper end (xa, ya), lower end (xb, yb), den = yb - ya > 0, dx = xb - xa):
+//   dx16  the walker's step,  hh / hr  quotient / remainder of |dx| by 2 den (the outline's pixels per row).
+RR_HD void edge_cv_consts(int dx, int den, int& dx16, int& hh, int& hr) {
+  const int dn = 2 * den, dxa = iabs(dx);
+  const int64_t num = ((int64_t)dx << 17) + den;
+  dx16 = (int)(num / dn);                                    // C division: toward zero
+  hh = dxa / dn;
+  hr = dxa - hh * dn;
+}
+// One edge's part of row t = y - ya (0 <= t <= den) under OpenCV's rule: [l, h].  Q, R: floor quotient and remainder of
+// 2 dx t by 2 den.  (fov_rowspan_cv evaluates the same per edge; the span rule's single pixel is xa + Q + [R >= den].)
+RR_HD void edge_row_cv(int xa, int xb, int den, int dx, int dx16, int hh, int hr, int t, int Q, int R, int& l, int& h) {
+  const int dn = 2 * den;
+  if (den > iabs(dx)) {
+    l = h = xa + Q + (R >= den + 1 ? 1 : 0);
+  } else {
+    l = xa + Q - hh + (R >= hr ? 1 : 0);
+    h = xa + Q + hh + (R + hr >= dn ? 1 : 0);
+    l = imax(l, imin(xa, xb));
+    h = imin(h, imax(xa, xb));
+  }
+  if (t < den) {                                             // the edge walker's pixel: |t * dx16| <= |dx| * 2^16 < 2^29
+    const int s = xa + ((t * dx16 + 32768) >> 16);
+    l = imin(l, s);
+    h = imax(h, s);
+  }
+}
+
 // Row spans of a closed polygon whose vertex rows go down one side and up the other (every row crosses it at most twice:
 // a circle on the sphere that contains no pole), by two cursors walking down from its top vertex, one along each side
 // (k_fov_dda: a thread per drop).  row(y) returns the min / max over the edges that touch row y -- the candidates
@@ -904,6 +932,7 @@ template <class V>
 struct DdaCursors {
   int xa[2], ya[2], xb[2], yb[2], kv[2], used, N;
   float inv[2];
+  int dx16[2], hhr[2];                                       // cv mode: the current edge's walker step, hh | hr << 12
   RR_HD static float half_recip(int den) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return den > 0 ? __builtin_amdgcn_rcpf((float)(2 * den)) : 0.f;          // (the quotient is made exact below)
@@ -911,6 +940,8 @@ struct DdaCursors {
     return den > 0 ? 1.0f / (float)(2 * den) : 0.f;
 #endif
   }
+  // index of the undirected edge {k, k + 1} a cursor is on: cursor 0 walks k -> k + 1 (edge of its OLD vertex), cursor 1
+  // k -> k - 1 (edge of its NEW vertex)
   RR_HD void init(const V& vertex, int n, int ktop) {
     N = n;
     used = 2;                                                // edges taken so far (both cursors together; N in all)
@@ -919,131 +950,72 @@ struct DdaCursors {
       kv[c] = c == 0 ? (ktop + 1 == N ? 0 : ktop + 1) : (ktop == 0 ? N - 1 : ktop - 1);
       vertex(kv[c], xb[c], yb[c]);
       inv[c] = half_recip(yb[c] - ya[c]);
+      dx16[c] = hhr[c] = 0;
+    }
+  }
+  // E: edgec(k, dx16, hh | hr << 12) hands out the constants of edge {k, k + 1} (edge_cv_consts), made before the walk
+  template <class E>
+  RR_HD void init_cv(const V& vertex, const E& edgec, int n, int ktop) {
+    init(vertex, n, ktop);
+    edgec(ktop, dx16[0], hhr[0]);
+    edgec(kv[1], dx16[1], hhr[1]);
+  }
+  // the current edge of cursor c at row y (ya <= y <= yb): its pixels [x0, x1] under the span rule (CV false) or OpenCV's
+  template <bool CV>
+  RR_HD void edge_at(int c, int y, int& x0, int& x1) const {
+    const int den = yb[c] - ya[c], dx = xb[c] - xa[c];
+    x0 = x1 = xa[c];
+    if (den == 0) {                                          // horizontal: both end points
+      x0 = imin(xa[c], xb[c]);
+      x1 = imax(xa[c], xb[c]);
+      return;
+    }
+    const int dn = 2 * den, t = y - ya[c], n2 = mul24i(2 * dx, t);          // exact: |2 dx dy| < 2^23 (host check)
+    int q = (int)floorf((float)n2 * inv[c]);                 // floor(n2 / dn) up to +-1 ...
+    int rem = n2 - mul24i(q, dn);
+    if (rem < 0) { q -= 1; rem += dn; }
+    else if (rem >= dn) { q += 1; rem -= dn; }               // ... made exact
+    if (!CV) {
+      x0 = x1 = xa[c] + q + (rem >= den ? 1 : 0);            // floor((n2 + den) / dn)
+    } else {
+      edge_row_cv(xa[c], xb[c], den, dx, dx16[c], hhr[c] & 0xfff, hhr[c] >> 12, t, q, rem, x0, x1);
     }
   }
   RR_HD void row(const V& vertex, int y, int& lo, int& hi) {
+    auto none = [](int, int&, int&) {};
+    row_rule<false>(vertex, none, y, lo, hi);
+  }
+  template <bool CV, class E>
+  RR_HD void row_rule(const V& vertex, const E& edgec, int y, int& lo, int& hi) {
     lo = 1 << 30;
     hi = -(1 << 30);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int c = 0; c < 2; c++) {
-      {                                                      // the current edge at row y (ya <= y <= yb)
-        const int den = yb[c] - ya[c], dx = xb[c] - xa[c];
-        int x0 = xa[c], x1 = xa[c];
-        if (den == 0) x1 = xb[c];                            // horizontal: both end points
-        else {
-          const int dn = 2 * den, nn = mul24i(2 * dx, y - ya[c]) + den;        // exact: |2 dx dy| < 2^23 (host check)
-          int q = (int)floorf((float)nn * inv[c]);           // floor(nn / dn) up to +-1 ...
-          const int rem = nn - mul24i(q, dn);
-          q += rem < 0 ? -1 : (rem >= dn ? 1 : 0);           // ... made exact
-          x0 = x1 = xa[c] + q;
-        }
-        lo = imin(lo, imin(x0, x1));
-        hi = imax(hi, imax(x0, x1));
+      {
+        int x0, x1;
+        edge_at<CV>(c, y, x0, x1);
+        lo = imin(lo, x0);
+        hi = imax(hi, x1);
       }
       while (y == yb[c] && used < N) {                       // a vertex row: the edges that start here touch it too
         used++;
         xa[c] = xb[c];
         ya[c] = yb[c];
+        const int kold = kv[c];
         kv[c] = c == 0 ? (kv[c] + 1 == N ? 0 : kv[c] + 1) : (kv[c] == 0 ? N - 1 : kv[c] - 1);
         vertex(kv[c], xb[c], yb[c]);
+        if (CV) edgec(c == 0 ? kold : kv[c], dx16[c], hhr[c]);
+        inv[c] = half_recip(yb[c] - ya[c]);
         if (yb[c] == ya[c]) {                                // a horizontal one: its far end point
           lo = imin(lo, xb[c]);
           hi = imax(hi, xb[c]);
-        }
-        inv[c] = half_recip(yb[c] - ya[c]);
-      }
-    }
-  }
-};
-// r05: the same spans by INCREMENTAL stepping (k_fov_walk).  DdaCursors evaluates the rule's exact division on every row
-// and looks for the next vertex inside the row loop (120 vector + 78 scalar instructions per map row and wave); here every
-// edge's division is done ONCE, when its record is made, and a cursor walks down it with adds only:
-//   x(t) = xa + floor((2 dx t + den) / (2 den)),  t = y - ya.   With dx = q den + r (0 <= r < den), Q(t), R(t) the quotient and
-//   remainder of 2 dx t + den by 2 den:   Q(0) = 0, R(0) = den;   R + 2 r < 4 den, so a row adds q to Q plus at most one
-//   carry:  R' = R + 2 r,  carry = R' >= 2 den,  Q += q + carry,  R = R' - carry * 2 den.
-// The cursor keeps rem = R - 2 den (negative; the sign bit of rem + 2 r is the carry) and the record holds q + 1, 2 r,
-// den and the edge's last row.  At t = den the formula gives xb exactly, so a cursor that arrives at a vertex holds that
-// vertex' x: the row's span is min / max of the two cursors' x, plus -- only when an edge is horizontal -- the far ends of
-// the horizontal edges met on that row.  That is the set fov_rowspan folds (every edge that touches the row evaluates to
-// one of these values), so the spans are identical (tests/test_fov_f32_host.py).
-//
-// Record of the undirected edge {k, k + 1} (vertices (x0, y0), (x1, y1); coordinates in [0, 32767], rows in [0, 32767]):
-//   w1 = den | (last row << 16);  den > 0:  w0 = ((q + 1) & 0xffff) | (2 r << 16);   den == 0:  w0 = x0 | (x1 << 16).
-RR_HD void dda_edge_record(int x0, int y0, int x1, int y1, uint32_t& w0, uint32_t& w1) {
-  if (y0 == y1) {
-    w0 = (uint32_t)x0 | ((uint32_t)x1 << 16);
-    w1 = (uint32_t)y0 << 16;
-    return;
-  }
-  const bool swp = y1 < y0;
-  const int xa = swp ? x1 : x0, ya = swp ? y1 : y0, xb = swp ? x0 : x1, yb = swp ? y0 : y1;
-  const int den = yb - ya, dx = xb - xa;
-  // floor(dx / den): a float quotient is within one of it (|dx| < 2^15), the remainder makes it exact
-#if defined(__HIP_DEVICE_COMPILE__)
-  int q = (int)floorf((float)dx * __builtin_amdgcn_rcpf((float)den));
-#else
-  int q = (int)floorf((float)dx / (float)den);
-#endif
-  int r = dx - mul24i(q, den);
-  if (r < 0) { q -= 1; r += den; }
-  else if (r >= den) { q += 1; r -= den; }
-  w0 = ((uint32_t)(q + 1) & 0xffffu) | ((uint32_t)(2 * r) << 16);
-  w1 = (uint32_t)den | ((uint32_t)yb << 16);
-}
-// R: rec(k, w0, w1) hands out the record of edge {k, k + 1}.  Cursor 0 walks the vertices upwards in index from the top
-// vertex, cursor 1 downwards; `used` counts the edges taken by both (N in all), as in DdaCursors.  Before the top row the
-// cursors are parked on the top vertex (q + 1 = 1, 2 r = 0: a step moves nothing); row(y) must be called for every y from
-// the top vertex' row (or before) in ascending order; rows below the bottom vertex return garbage.
-template <class R>
-struct DdaWalk {
-  int x[2], rem[2], sq1[2], sr[2], dn[2], yb[2], kv[2], used, N;
-  uint32_t n0[2], n1[2];                                     // the record of the edge the cursor takes next, fetched an edge ahead
-  RR_HD void init(const R& rec, int n, int ktop, int xtop, int ytop) {
-    N = n;
-    used = 0;
-    for (int c = 0; c < 2; c++) {
-      x[c] = xtop; rem[c] = -1; sq1[c] = 1; sr[c] = 0; dn[c] = 0; yb[c] = ytop; kv[c] = ktop;
-    }
-    rec(ktop, n0[0], n1[0]);
-    rec(ktop == 0 ? n - 1 : ktop - 1, n0[1], n1[1]);
-  }
-  RR_HD void row(const R& rec, int y, int& lo, int& hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int c = 0; c < 2; c++) {                            // one row down the current edges
-      const int r = rem[c] + sr[c];
-      const int m = r >> 31;                                 // -1: no carry
-      x[c] += sq1[c] + m;
-      rem[c] = r - (dn[c] & ~m);
-    }
-    lo = imin(x[0], x[1]);
-    hi = imax(x[0], x[1]);
-    if (y != yb[0] && y != yb[1]) return;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int c = 0; c < 2; c++) {
-      while (y == yb[c] && used < N) {                       // at a vertex: the next edge of this side
-        used++;
-        const uint32_t w0 = n0[c], w1 = n1[c];
-        const int kn = c == 0 ? (kv[c] + 1 == N ? 0 : kv[c] + 1) : (kv[c] == 0 ? N - 1 : kv[c] - 1);
-        kv[c] = kn;
-        rec(c == 0 ? kn : (kn == 0 ? N - 1 : kn - 1), n0[c], n1[c]);
-        const int den = (int)(w1 & 0xffffu);
-        if (den == 0) {                                      // horizontal: its far end lies on this row too
-          x[c] = c == 0 ? (int)(w0 >> 16) : (int)(w0 & 0xffffu);
-          lo = imin(lo, x[c]);
-          hi = imax(hi, x[c]);
-          rem[c] = -1; sq1[c] = 1; sr[c] = 0; dn[c] = 0;     // (parked until the next edge is taken)
-        } else {
-          sq1[c] = (int)(int16_t)(w0 & 0xffffu);
-          sr[c] = (int)(w0 >> 16);
-          dn[c] = 2 * den;
-          rem[c] = -den;
-          yb[c] = (int)(w1 >> 16);
+        } else if (CV) {                                     // OpenCV's rule: the new edge's own pixels of its first row
+          int x0, x1;
+          edge_at<true>(c, y, x0, x1);
+          lo = imin(lo, x0);
+          hi = imax(hi, x1);
         }
       }
     }

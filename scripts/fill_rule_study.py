@@ -23,7 +23,7 @@ outs = []
 for rule in (0, 1):
     emu.emu_set_fill_rule(rule)
     outs.append(h.emu_render(sc, bg, bg, env, drops))
-emu.emu_set_fill_rule(0)
+emu.emu_set_fill_rule(1)
 a, b = outs
 ok = a['status'] == 0
 _, p64, n64, *_ = _polygons(sc, 0)
@@ -35,7 +35,7 @@ for k in np.nonzero(applies)[0][:400]:
     m1 = cvlike.fill_fov_mask_cv(np.zeros((sc.He, sc.We)), P)
     m0 = cvlike.fill_fov_mask_span_rule(np.zeros((sc.He, sc.We)), P)
     px.append((m0.sum(), m1.sum(), (m0 != m1).sum(), ((m0 == 1) & (m1 == 0)).sum()))
-cvlike.set_fill_rule('span')
+cvlike.set_fill_rule()
 px = np.array(px)
 say("KITTI 1242x375, map 1909x375, %d drops (%d composited); OpenCV's rule applies to %d polygons (%d wrap or fail and keep the span rule)"
     % (len(drops), int(ok.sum()), int(applies.sum()), int((~applies).sum())))

@@ -11,7 +11,7 @@ installed here, and numpy >= 1.24 dropped np.int / np.float / np.bool.  The shim
   * cv2.copyMakeBorder     -> np.pad(mode='constant')   (definitionally identical)
   * cv2.imread / cvtColor  -> PIL decode / channel replicate (I/O only)
   * pyclipper.Pyclipper    -> pass-through of the integer-truncated clip path        } NOT the real
-  * cv2.fillConvexPoly     -> oracle.cvlike.fill_fov_mask (our row-span rule)        } library: see below
+  * cv2.fillConvexPoly     -> oracle.cvlike.fill_fov_mask (OpenCV's algorithm RESTATED) } library: see below
   * imutils                -> empty module (never reached by the functions called here)
 
 Functions exercised through the reference's own code (=> these pin the oracle):
@@ -67,7 +67,10 @@ def install_shims():
         return np.dstack([img, img, img])
 
     def fillConvexPoly(img, pts, color):
-        cvlike.fill_fov_mask(img, np.asarray(pts).reshape(-1, 2))
+        P = np.asarray(pts).reshape(-1, 2)
+        if len(P) > 1 and np.array_equal(P[0], P[-1]):      # the reference closes the path by repeating its first vertex (bad_weather.py:373);
+            P = P[:-1]                                        # fill_fov_mask takes the open polygon and closes it the same way
+        cvlike.fill_fov_mask(img, P)                         # round 6: OpenCV's algorithm as restated in cvlike (cv_fill_convex_poly), the default rule
         return img
 
     cv2.copyMakeBorder = copyMakeBorder

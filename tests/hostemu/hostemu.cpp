@@ -81,8 +81,8 @@ int emu_fov_error_ratio(const rr_drop* drops, int n, const rr_camera* cam, int H
   return 0;
 }
 
-// RR_OPT_FOV_FILL_RULE of the library: 0 the span rule (fov_rowspan), 1 OpenCV's rule where it applies (fov_rowspan_cv)
-static int g_fill_rule = 0;
+// RR_OPT_FOV_FILL_RULE of the library: 1 (default since r06) OpenCV's rule where it applies (fov_rowspan_cv), 0 the span rule (fov_rowspan)
+static int g_fill_rule = 1;
 void emu_set_fill_rule(int rule) { g_fill_rule = rule; }
 // spans of polygon (px, py)[n] under either rule: xl[y], xr[y] for y in [0, He), xl > xr = empty; returns 1 when OpenCV's rule applies
 int emu_rowspans(const int32_t* px, const int32_t* py, int n, int n_fov, int He, int We, int rule, int32_t* xl, int32_t* xr) {
@@ -96,55 +96,45 @@ int emu_rowspans(const int32_t* px, const int32_t* py, int n, int n_fov, int He,
   return cv ? 1 : 0;
 }
 
-// k_fov_dda's row spans (rr_device.h DdaCursors) of polygon (px, py)[n] against the rule itself (fov_rowspan: min / max over
-// every edge that touches the row): returns the number of rows of [0, He) on which they differ, -1 when the polygon's rows
-// are not monotone (the kernel hands those to the edge-parallel kernel).
-int emu_dda_check(const int32_t* px, const int32_t* py, int n, int He, int We) {
+// k_fov_dda's row spans (rr_device.h DdaCursors) of polygon (px, py)[n] against the rule itself (rule 0: fov_rowspan, min / max
+// over every edge that touches the row; rule 1: fov_rowspan_cv, OpenCV's FillConvexPoly in closed form): returns the number of
+// rows of [0, He) on which they differ, -1 when the polygon's rows are not monotone (the kernel hands those to the
+// edge-parallel kernel) or, for rule 1, when OpenCV's rule does not apply to it.
+int emu_dda_check(const int32_t* px, const int32_t* py, int n, int He, int We, int rule) {
   if (poly_row_turns(py, n) > 2) return -1;
+  if (rule == 1 && !fov_fill_rule_cv_applies(px, py, n, n, He, We)) return -1;
   int ktop = 0, ytop = py[0], ybot = py[0];
   for (int k = 1; k < n; k++) {
     if (py[k] < ytop) { ytop = py[k]; ktop = k; }
     if (py[k] > ybot) ybot = py[k];
   }
   auto vertex = [&](int k, int& x, int& y) { x = px[k]; y = py[k]; };
-  DdaCursors<decltype(vertex)> cur;
-  cur.init(vertex, n, ktop);
-  int bad = 0;
-  for (int y = 0; y < He; y++) {
-    int lo = 1 << 30, hi = -(1 << 30);
-    if (y >= ytop && y <= ybot) cur.row(vertex, y, lo, hi);
-    const int a = imax(lo, 0), b = imin(hi, We - 1);
-    int xl, xr;
-    const bool any = fov_rowspan(px, py, n, y, We, xl, xr);
-    if (any != (a <= b) || (any && (xl != a || xr != b))) bad++;
-  }
-  return bad;
-}
-
-// The same check for k_fov_walk's incremental cursors (rr_device.h DdaWalk over dda_edge_record records).
-int emu_walk_check(const int32_t* px, const int32_t* py, int n, int He, int We) {
-  if (poly_row_turns(py, n) > 2) return -1;
-  int ktop = 0, ytop = py[0], ybot = py[0];
-  for (int k = 1; k < n; k++) {
-    if (py[k] < ytop) { ytop = py[k]; ktop = k; }
-    if (py[k] > ybot) ybot = py[k];
-  }
-  std::vector<uint32_t> w0(n), w1(n);
-  for (int k = 0; k < n; k++) {
+  std::vector<int> c16(n), chr_(n);
+  for (int k = 0; k < n; k++) {                   // the constants of edge {k, k + 1}, upper end first (k_fov_dda makes them before its row loop)
     const int j = k + 1 == n ? 0 : k + 1;
-    dda_edge_record(px[k], py[k], px[j], py[j], w0[k], w1[k]);
+    const bool swp = py[j] < py[k];
+    const int xa = swp ? px[j] : px[k], ya = swp ? py[j] : py[k], xb = swp ? px[k] : px[j], yb = swp ? py[k] : py[j];
+    c16[k] = chr_[k] = 0;
+    if (yb > ya) {
+      int hh, hr;
+      edge_cv_consts(xb - xa, yb - ya, c16[k], hh, hr);
+      chr_[k] = hh | (hr << 12);
+    }
   }
-  auto rec = [&](int k, uint32_t& a, uint32_t& b) { a = w0[k]; b = w1[k]; };
-  DdaWalk<decltype(rec)> cur;
-  cur.init(rec, n, ktop, px[ktop], ytop);
+  auto edgec = [&](int k, int& d16, int& hhr) { d16 = c16[k]; hhr = chr_[k]; };
+  DdaCursors<decltype(vertex)> cur;
+  if (rule == 1) cur.init_cv(vertex, edgec, n, ktop);
+  else cur.init(vertex, n, ktop);
   int bad = 0;
   for (int y = 0; y < He; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
-    cur.row(rec, y, lo, hi);                       // (every row, like the kernel: parked above the polygon, garbage below it)
-    if (y < ytop || y > ybot) { lo = 1 << 30; hi = -(1 << 30); }
+    if (y >= ytop && y <= ybot) {
+      if (rule == 1) cur.row_rule<true>(vertex, edgec, y, lo, hi);
+      else cur.row(vertex, y, lo, hi);
+    }
     const int a = imax(lo, 0), b = imin(hi, We - 1);
     int xl, xr;
-    const bool any = fov_rowspan(px, py, n, y, We, xl, xr);
+    const bool any = rule == 1 ? fov_rowspan_cv(px, py, n, y, We, xl, xr) : fov_rowspan(px, py, n, y, We, xl, xr);
     if (any != (a <= b) || (any && (xl != a || xr != b))) bad++;
   }
   return bad;

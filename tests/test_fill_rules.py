@@ -78,7 +78,7 @@ def test_closed_forms_equal_the_literal_restatement(tmp_path):
                             assert np.array_equal(cvlike.fill_fov_mask_cv(np.zeros((He, We)), Q), lit)
                 n_checked += bool(applies)
         finally:
-            cvlike.set_fill_rule('span')
+            cvlike.set_fill_rule()
     assert n_checked > 300
 
 
@@ -95,7 +95,7 @@ def test_how_far_apart_the_two_rules_are(tmp_path):
         try:
             outs.append(h.emu_render(sc, bg, bg, env, drops))
         finally:
-            emu.emu_set_fill_rule(0)
+            emu.emu_set_fill_rule(1)
     a, b = outs
     assert np.array_equal(a['status'], b['status']) and np.array_equal(a['mask'], b['mask'])
     ok = a['status'] == 0
@@ -112,7 +112,7 @@ def test_how_far_apart_the_two_rules_are(tmp_path):
         try:
             refs.append(h.oracle_render(sc, 0, bg, bg, env, faithful=True, first_drop=lo, max_drops=hi))
         finally:
-            cvlike.set_fill_rule('span')
+            cvlike.set_fill_rule()
     assert np.array_equal(refs[0]['mask'], refs[1]['mask']) and np.array_equal(refs[0]['status'], refs[1]['status'])
     assert np.abs(refs[0]['image_u8'].astype(int) - refs[1]['image_u8'].astype(int)).max() <= 1
     # and the host build of the kernel arithmetic agrees with the oracle under OpenCV's rule as it does under the span rule
@@ -120,6 +120,6 @@ def test_how_far_apart_the_two_rules_are(tmp_path):
     try:
         e = h.emu_render(sc, bg, bg, env, drops[lo:hi])
     finally:
-        emu.emu_set_fill_rule(0)
+        emu.emu_set_fill_rule(1)
     assert np.array_equal(e['mask'], refs[1]['mask'])
     assert np.abs(e['rainy_bg'] - refs[1]['rainy_bg']).max() < 1e-9

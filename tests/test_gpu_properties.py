@@ -236,20 +236,21 @@ def test_thread_per_drop_polygons_equal_the_edge_parallel_kernel(setup, tmp_path
     wbg, wenv = wide.frame_inputs(0)
     scenes.append((wide, wbg, wenv, wide.product_drops(0)))
     for S, b, e, d in scenes:
-        outs = []
-        for dda in (2, 1, 0):
-            alt = h.hb.RainHip(0)
-            try:
-                alt.set_option(h.hb.RR_OPT_FOV_DDA, dda)
-                alt.set_streak_db(S.db.streaks_light)
-                alt.set_camera(S.cam)
-                outs.append(alt.render_frames([dict(bg=b, rainy_bg=b, env_xyY=e, omega=S.omega, drops=d)], want_composite=False, want_colour=True)[0])
-            finally:
-                alt.close()
-        assert (outs[0]["status"] == 0).sum() > 0.5 * len(d)
-        for other in outs[1:]:           # 2 = incremental cursors over edge records (k_fov_walk, r05), 1 = k_fov_dda, 0 = k_fov_spans
+        for rule in (1, 0):              # OpenCV's fillConvexPoly (default) and the span rule: the cursors walk either
+            outs = []
+            for dda in (1, 0):           # 1 = k_fov_dda + the list, 0 = k_fov_spans for every drop
+                alt = h.hb.RainHip(0)
+                try:
+                    alt.set_option(h.hb.RR_OPT_FOV_DDA, dda)
+                    alt.set_option(h.hb.RR_OPT_FOV_FILL_RULE, rule)
+                    alt.set_streak_db(S.db.streaks_light)
+                    alt.set_camera(S.cam)
+                    outs.append(alt.render_frames([dict(bg=b, rainy_bg=b, env_xyY=e, omega=S.omega, drops=d)], want_composite=False, want_colour=True)[0])
+                finally:
+                    alt.close()
+            assert (outs[0]["status"] == 0).sum() > 0.5 * len(d)
             for k in ('status', 'colour', 'mask', 'mask_i32', 'image_u8'):
-                assert np.array_equal(outs[0][k], other[k]), k
+                assert np.array_equal(outs[0][k], outs[1][k]), (rule, k)
 
 
 def test_composite_codes_and_blur_prefetch(setup):
@@ -313,37 +314,49 @@ def test_compositor_record_batches(setup):
             assert np.array_equal(ref[k], alt[k]), (batch, waves, k)
 
 
-def test_opencv_fill_rule_option(setup):
-    """RR_OPT_FOV_FILL_RULE 1: OpenCV 3.2's own fillConvexPoly algorithm (Bresenham outline + 16.16 edge walkers; rr_device.h
-    fov_rowspan_cv, pinned against the literal restatement in tests/test_fill_rules.py) instead of the row-span rule of the fast
-    colour kernels.  The option's colour constants equal the host build's under the same rule; against the default rule they
-    move by a few parts in a thousand -- rainy_image stays within 1 LSB, mask and statuses are untouched."""
+def test_fill_rule_option(setup):
+    """RR_OPT_FOV_FILL_RULE.  The default (1, since round 6) is OpenCV 3.2's own fillConvexPoly algorithm on the FAST colour path
+    (k_fov_dda's cursors evaluate rr_device.h fov_rowspan_cv's closed form: Bresenham outline + 16.16 edge walkers; pinned
+    against the literal restatement in tests/test_fill_rules.py); 0 is the row-span rule of rounds 1-5.  Under either rule
+    the library's colour constants equal the host build's under the same rule, with the float64 and with the float colour
+    branch, and the general colour path (RR_OPT_GENERAL_FOV) agrees with the fast one; between the rules the constants move
+    by a few parts in a thousand -- rainy_image stays within 1 LSB, mask and statuses are untouched."""
     sc, bg, env, drops, rh, base = setup
     fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
-    dflt = rh.render_frames([fr], want_colour=True)[0]
-    alt = h.hb.RainHip(0)
-    try:
-        alt.set_option(h.hb.RR_OPT_FOV_FILL_RULE, 1)
-        alt.set_streak_db(sc.db.streaks_light)
-        alt.set_camera(sc.cam)
-        out = alt.render_frames([fr], want_colour=True)[0]
-        f32 = alt.render_frames([fr], want_composite=False)[0]
-    finally:
-        alt.close()
     emu = h.hostemu()
-    emu.emu_set_fill_rule(1)
-    try:
-        ref = h.emu_render(sc, bg, bg, env, drops)
-    finally:
-        emu.emu_set_fill_rule(0)
-    for k in ('status', 'mask', 'mask_i32'):
-        assert np.array_equal(out[k], base[k]) and np.array_equal(out[k], ref[k]) and np.array_equal(f32[k], base[k]), k
-    ok = out['status'] == 0
-    assert np.abs(out['colour'][ok] - ref['K'][ok]).max() <= 1e-9 * np.abs(ref['K'][ok]).max()
-    assert np.abs(out['rainy_bg'] - ref['rainy_bg']).max() < 1e-9
-    assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
-    rel = np.abs(out['colour'][ok] - dflt['colour'][ok]) / np.abs(dflt['colour'][ok])
+    res = {}
+    for rule in (1, 0):
+        alt = h.hb.RainHip(0)
+        try:
+            alt.set_option(h.hb.RR_OPT_FOV_FILL_RULE, rule)
+            alt.set_streak_db(sc.db.streaks_light)
+            alt.set_camera(sc.cam)
+            out = alt.render_frames([fr], want_colour=True)[0]                  # float64 colour branch (k_fov_spans)
+            f32 = alt.render_frames([fr], want_composite=False)[0]              # float colour branch (k_fov_dda + the list)
+            alt.set_option(h.hb.RR_OPT_GENERAL_FOV, 1)
+            gen = alt.render_frames([fr], want_colour=True)[0]                  # prefix table in HBM, fov_rowspan[_cv] per drop and row
+        finally:
+            alt.close()
+        emu.emu_set_fill_rule(rule)
+        try:
+            ref = h.emu_render(sc, bg, bg, env, drops)
+        finally:
+            emu.emu_set_fill_rule(1)
+        for k in ('status', 'mask', 'mask_i32'):
+            assert np.array_equal(out[k], base[k]) and np.array_equal(out[k], ref[k]) and np.array_equal(f32[k], base[k]), (rule, k)
+        ok = out['status'] == 0
+        assert np.abs(out['colour'][ok] - ref['K'][ok]).max() <= 1e-9 * np.abs(ref['K'][ok]).max(), rule
+        assert np.abs(gen['colour'][ok] - ref['K'][ok]).max() <= 1e-9 * np.abs(ref['K'][ok]).max(), rule
+        assert np.abs(out['rainy_bg'] - ref['rainy_bg']).max() < 1e-9
+        assert np.abs(out['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+        assert np.abs(f32['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+        res[rule] = (out, f32)
+    # the default IS rule 1
+    dflt = rh.render_frames([fr], want_colour=True)[0]
+    assert np.array_equal(dflt['colour'], res[1][0]['colour']) and np.array_equal(base['image_u8'], res[1][1]['image_u8'])
+    ok = dflt['status'] == 0
+    rel = np.abs(res[0][0]['colour'][ok] - dflt['colour'][ok]) / np.abs(dflt['colour'][ok])
     assert 1e-5 < rel.max() < 4e-3, rel.max()
-    for o in (out, f32):
+    for o in res[0]:
         d = np.abs(o['image_u8'].astype(int) - base['image_u8'].astype(int))
         assert d.max() <= 1 and (d != 0).mean() < 0.05, (d.max(), (d != 0).mean())
