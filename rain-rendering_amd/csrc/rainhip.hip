@@ -815,22 +815,24 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
 //   3. everything else -- a wrapping polygon (24 vertices, not monotone), a predicate within its error bound (float64
 //      decides), a vertex sequence that is not monotone after all -- goes to the frame's list for k_fov_spans (from_list),
 //      a fraction of a percent of the drops.
-// CV (r06, RR_OPT_FOV_FILL_RULE 1, the default): the spans are what cv2.fillConvexPoly sets (rr_device.h fov_rowspan_cv: the
-// outline's Bresenham pixels + the 16.16 edge walkers, in closed form per edge and row) for the polygons OpenCV's rule
-// applies to (every vertex on the map); the per-edge constants are made before the walk, two dwords per edge and lane.
-template <bool CV>
-__global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, Scratch sc) {
+// r06, RR_OPT_FOV_FILL_RULE 1 (the default): the spans are what cv2.fillConvexPoly sets (rr_device.h fov_rowspan_cv: the
+// outline's Bresenham pixels + the 16.16 edge walkers) for the polygons OpenCV's rule applies to (every vertex on the map),
+// the span rule's otherwise.  Both by incremental cursors (rr_device.h DdaCursors): every edge's divisions are done once,
+// before the walk, into a 12-byte record per edge and lane; a row costs adds and compares.  DDA_WAVES waves per workgroup:
+// 16 bytes of LDS per vertex and lane.
+constexpr int DDA_WAVES = 2;
+__global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int cv_rule, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
   const int N = cam.n_fov;
   __shared__ float s_phi32[2][RR_MAX_FOV];
-  extern __shared__ uint32_t s_pix_dyn[];                      // [4 waves][N vertices][64 lanes]: pix[vertex][lane] = x | y << 16
+  extern __shared__ uint32_t s_pix_dyn[];                      // [waves][N vertices][64 lanes]: pix[vertex][lane] = x | y << 16; then the edge records
   if (threadIdx.x < RR_MAX_FOV) {
     s_phi32[0][threadIdx.x] = (float)cam.phi_cos[threadIdx.x];
     s_phi32[1][threadIdx.x] = (float)cam.phi_sin[threadIdx.x];
   }
   __syncthreads();
-  const int i = (blockIdx.x * 4 + wave) * 64 + lane;           // this lane's drop
+  const int i = (blockIdx.x * DDA_WAVES + wave) * 64 + lane;   // this lane's drop
   const bool act = i < fr.n_drops;
   const int64_t gi = (int64_t)f * max_drops + (act ? i : 0);
   if (fr.strategy == 1) {                                      // 'white': the FOV is computed by the reference but never used
@@ -905,39 +907,34 @@ __global__ __launch_bounds__(256) void k_fov_dda(const FrameDesc* frames, Dims d
     x = (int)(v & 0xffffu);
     y = (int)(v >> 16);
   };
-  // OpenCV's rule: the constants of edge {k, k + 1} (upper end first), behind the vertices: econ[(2 k + w) * 64 + lane]
-  uint32_t* econ = s_pix_dyn + 4 * N * 64 + wave * 2 * N * 64;
-  const bool cvr = CV && mine && on_map;                       // (a vertex off the map: the span rule, like the oracle)
-  if (CV) {
-    if (cvr) {
-      for (int k = 0; k < N; k++) {
-        int x0, y0, x1, y1;
-        vertex(k, x0, y0);
-        vertex(k + 1 == N ? 0 : k + 1, x1, y1);
-        const bool swp = y1 < y0;
-        const int den = swp ? y0 - y1 : y1 - y0, dx = swp ? x0 - x1 : x1 - x0;
-        int d16 = 0, hh = 0, hr = 0;
-        if (den > 0) edge_cv_consts(dx, den, d16, hh, hr);
-        econ[(2 * k) * 64 + lane] = (uint32_t)d16;
-        econ[(2 * k + 1) * 64 + lane] = (uint32_t)(hh | (hr << 12));
-      }
+  // the records of the edges {k, k + 1} (upper end first), behind the vertices: erec[(3 k + w) * 64 + lane]
+  uint32_t* erec = s_pix_dyn + DDA_WAVES * N * 64 + wave * 3 * N * 64;
+  const bool cvr = cv_rule && on_map;                          // (a vertex off the map: the span rule, like the oracle)
+  if (mine) {
+    for (int k = 0; k < N; k++) {
+      int x0, y0, x1, y1;
+      vertex(k, x0, y0);
+      vertex(k + 1 == N ? 0 : k + 1, x1, y1);
+      const bool swp = y1 < y0;
+      uint32_t w0, w1, w2;
+      dda_edge_record(swp ? x1 : x0, swp ? y1 : y0, swp ? x0 : x1, swp ? y0 : y1, cvr, w0, w1, w2);
+      erec[(3 * k) * 64 + lane] = w0;
+      erec[(3 * k + 1) * 64 + lane] = w1;
+      erec[(3 * k + 2) * 64 + lane] = w2;
     }
-    wave_lds_sync();
   }
-  auto edgec = [&](int kk, int& d16, int& hhr) {
-    d16 = (int)econ[(2 * kk) * 64 + lane];
-    hhr = (int)econ[(2 * kk + 1) * 64 + lane];
+  wave_lds_sync();
+  auto rec = [&](int kk, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    w0 = erec[(3 * kk) * 64 + lane];
+    w1 = erec[(3 * kk + 1) * 64 + lane];
+    w2 = erec[(3 * kk + 2) * 64 + lane];
   };
-  DdaCursors<decltype(vertex)> cur;
-  if (CV && cvr) cur.init_cv(vertex, edgec, N, ktop);
-  else cur.init(vertex, N, ktop);
+  DdaCursors<decltype(vertex), decltype(rec)> cur;
+  if (mine) cur.init(vertex, rec, N, ktop);
   uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;
   for (int y = 0; y < Hp; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
-    if (mine && y >= ytop && y <= ybot) {
-      if (CV && cvr) cur.template row_rule<true>(vertex, edgec, y, lo, hi);
-      else cur.row(vertex, y, lo, hi);
-    }
+    if (mine && y >= ytop && y <= ybot) cur.row(vertex, rec, y, lo, hi);
     const int a = imax(lo, 0), b = imin(hi, dm.We - 1);
     if (mine) out[(int64_t)y * Dp] = (y < dm.He && a <= b) ? ((uint32_t)a | ((uint32_t)(b + 1) << 16)) : 0u;
   }
@@ -5253,17 +5250,14 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       if (dda) {
         HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, fs));
         {
-          // (r06, OpenCV's rule: + two dwords per edge and lane -- the walker's step and the outline's run lengths, made before the walk)
-          const size_t lds = sizeof(uint32_t) * (cv_rule ? 3 : 1) * 4 * 64 * (size_t)ctx->cam.n_fov;
-          if (cv_rule) {
-            if (!ctx->dda_attr) {
-              HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 3 * 4 * 64 * RR_MAX_FOV)));
-              ctx->dda_attr = true;
-            }
-            hipLaunchKernelGGL(k_fov_dda<true>, dim3((max_drops + 255) / 256, n), dim3(256), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
-          } else {
-            hipLaunchKernelGGL(k_fov_dda<false>, dim3((max_drops + 255) / 256, n), dim3(256), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp, sc);
+          // (16 bytes of LDS per vertex and lane: the vertex' pixel and the 12-byte record of the edge that starts there)
+          const size_t lds = sizeof(uint32_t) * 4 * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
+          if (!ctx->dda_attr) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 4 * DDA_WAVES * 64 * RR_MAX_FOV)));
+            ctx->dda_attr = true;
           }
+          hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 64 * DDA_WAVES - 1) / (64 * DDA_WAVES), n), dim3(64 * DDA_WAVES), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp,
+                             cv_rule ? 1 : 0, sc);
         }
         const dim3 lgrid(imin((int)grid.x, 8), n);           // the list is short: a few workgroups per frame walk it, in float64
         if (dm.He <= 384)

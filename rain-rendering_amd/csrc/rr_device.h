@@ -892,8 +892,8 @@ RR_HD bool fov_rowspan_cv(const int32_t* px, const int32_t* py, int n, int y, in
 //   dx16  the walker's step,  hh / hr  quotient / remainder of |dx| by 2 den (the outline's pixels per row).
 RR_HD void edge_cv_consts(int dx, int den, int& dx16, int& hh, int& hr) {
   const int dn = 2 * den, dxa = iabs(dx);
-  const int64_t num = ((int64_t)dx << 17) + den;
-  dx16 = (int)(num / dn);                                    // C division: toward zero
+  const int num = dx * 131072 + den;                         // |dx| <= 4095 (the fast colour path's maps): below 2^30
+  dx16 = num / dn;                                           // C division: toward zero
   hh = dxa / dn;
   hr = dxa - hh * dn;
 }
@@ -918,75 +918,96 @@ RR_HD void edge_row_cv(int xa, int xb, int den, int dx, int dx16, int hh, int hr
 
 // Row spans of a closed polygon whose vertex rows go down one side and up the other (every row crosses it at most twice:
 // a circle on the sphere that contains no pole), by two cursors walking down from its top vertex, one along each side
-// (k_fov_dda: a thread per drop).  row(y) returns the min / max over the edges that touch row y -- the candidates
-// fov_rowspan folds, with the same exact integer division -- for y from the top vertex' row to the bottom one, IN
-// ASCENDING ORDER (every call advances the cursors).  V: vertex(k, x, y).
-RR_HD int mul24i(int a, int b) {                            // a * b for |a|, |b| < 2^23 (the 24-bit multiplier on the device)
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __mul24(a, b);
-#else
-  return a * b;
-#endif
+// (k_fov_dda: a thread per drop).  row(y) returns the min / max over the edges that touch row y of their pixels on that row
+// -- under the span rule (fov_rowspan) or OpenCV's (fov_rowspan_cv), per polygon -- for y from the top vertex' row to the
+// bottom one, IN ASCENDING ORDER (every call advances the cursors).
+//
+// Round 6: both rules by INCREMENTAL stepping.  With Q(t), R(t) the floor quotient and remainder of 2 dx t by 2 den (t = y - ya):
+//   span rule      x = xa + Q + [R >= den]
+//   OpenCV, steep  x = xa + Q + [R >= den + 1]
+//   OpenCV, shallow  [xa + Q - hh + [R >= hr],  xa + Q + hh + [R >= 2 den - hr]]  clamped to the edge's own x range
+// i.e. one form  [xa + Q - hh + [R >= tl],  xa + Q + hh + [R >= th]]  with per-edge constants, and a row down the edge is
+// Q += qs + carry, R += rs - carry * 2 den  (qs, rs: quotient and remainder of 2 dx by 2 den); OpenCV's edge walker adds the
+// pixel xa + (w >> 16), w = 2^15 + t * dx16.  Every division happens ONCE per edge, when its record is made (before the walk,
+// all lanes busy), not per row; at a vertex a cursor only loads the next record.
+// Record of the undirected edge between an upper end (xu, yu) and a lower end (xl, yl), den = yl - yu, dx = xl - xu:
+//   w0 = dx16 (OpenCV's walker step; 0 under the span rule)
+//   w1 = hh | tl << 11 | same << 22 | walker << 23     (same: th = tl; else th = 2 den - tl)
+//   w2 = (qs & 0xffff) | rs << 16
+// Limits: den <= 1023, |dx| <= 4095 (maps of the fast colour path: 1024 x 4096).
+RR_HD int floor_div_i(int a, int b) {                        // b > 0
+  int q = a / b;
+  if (a % b != 0 && a < 0) q -= 1;
+  return q;
 }
-template <class V>
-struct DdaCursors {
-  int xa[2], ya[2], xb[2], yb[2], kv[2], used, N;
-  float inv[2];
-  int dx16[2], hhr[2];                                       // cv mode: the current edge's walker step, hh | hr << 12
-  RR_HD static float half_recip(int den) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return den > 0 ? __builtin_amdgcn_rcpf((float)(2 * den)) : 0.f;          // (the quotient is made exact below)
-#else
-    return den > 0 ? 1.0f / (float)(2 * den) : 0.f;
-#endif
+RR_HD void dda_edge_record(int xu, int yu, int xl, int yl, bool cv, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+  const int den = yl - yu, dx = xl - xu;
+  w0 = w1 = w2 = 0;
+  if (den <= 0) return;                                      // horizontal: the cursor takes both end points
+  const int dn = 2 * den;
+  const int qs = floor_div_i(2 * dx, dn), rs = 2 * dx - qs * dn;
+  w2 = ((uint32_t)qs & 0xffffu) | ((uint32_t)rs << 16);
+  if (!cv) {
+    w1 = 0u | ((uint32_t)den << 11) | (1u << 22);
+    return;
   }
-  // index of the undirected edge {k, k + 1} a cursor is on: cursor 0 walks k -> k + 1 (edge of its OLD vertex), cursor 1
-  // k -> k - 1 (edge of its NEW vertex)
-  RR_HD void init(const V& vertex, int n, int ktop) {
+  int dx16, hh, hr;
+  edge_cv_consts(dx, den, dx16, hh, hr);
+  w0 = (uint32_t)dx16;
+  if (den > iabs(dx)) w1 = 0u | ((uint32_t)(den + 1) << 11) | (1u << 22) | (1u << 23);
+  else w1 = (uint32_t)hh | ((uint32_t)hr << 11) | (1u << 23);
+}
+// V: vertex(k, x, y).  E: rec(k, w0, w1, w2) hands out the record of edge {k, k + 1} (upper end first).
+template <class V, class E>
+struct DdaCursors {
+  int xa[2], xb[2], yb[2], kv[2], used, N;
+  int Q[2], R[2], W[2];                                      // the current edge at the row the cursor stands on
+  int dn[2], hh[2], tl[2], th[2], qs[2], rs[2], d16[2], wk[2];      // its constants (dn == 0: horizontal; wk: OpenCV's walker applies)
+  RR_HD void take(const E& rec, int c, int kedge) {          // the cursor's next edge; xa, xb, yb and dn set by the caller
+    uint32_t w0, w1, w2;
+    rec(kedge, w0, w1, w2);
+    d16[c] = (int)w0;
+    hh[c] = (int)(w1 & 0x7ffu);
+    tl[c] = (int)((w1 >> 11) & 0x7ffu);
+    th[c] = ((w1 >> 22) & 1u) ? tl[c] : dn[c] - tl[c];
+    wk[c] = (int)((w1 >> 23) & 1u);
+    qs[c] = (int)(int16_t)(w2 & 0xffffu);
+    rs[c] = (int)(w2 >> 16);
+    Q[c] = 0;
+    R[c] = 0;
+    W[c] = 32768;
+  }
+  RR_HD void init(const V& vertex, const E& rec, int n, int ktop) {
     N = n;
     used = 2;                                                // edges taken so far (both cursors together; N in all)
     for (int c = 0; c < 2; c++) {
-      vertex(ktop, xa[c], ya[c]);
+      int ya;
+      vertex(ktop, xa[c], ya);
       kv[c] = c == 0 ? (ktop + 1 == N ? 0 : ktop + 1) : (ktop == 0 ? N - 1 : ktop - 1);
       vertex(kv[c], xb[c], yb[c]);
-      inv[c] = half_recip(yb[c] - ya[c]);
-      dx16[c] = hhr[c] = 0;
+      dn[c] = 2 * (yb[c] - ya);
+      take(rec, c, c == 0 ? ktop : kv[c]);
     }
   }
-  // E: edgec(k, dx16, hh | hr << 12) hands out the constants of edge {k, k + 1} (edge_cv_consts), made before the walk
-  template <class E>
-  RR_HD void init_cv(const V& vertex, const E& edgec, int n, int ktop) {
-    init(vertex, n, ktop);
-    edgec(ktop, dx16[0], hhr[0]);
-    edgec(kv[1], dx16[1], hhr[1]);
-  }
-  // the current edge of cursor c at row y (ya <= y <= yb): its pixels [x0, x1] under the span rule (CV false) or OpenCV's
-  template <bool CV>
-  RR_HD void edge_at(int c, int y, int& x0, int& x1) const {
-    const int den = yb[c] - ya[c], dx = xb[c] - xa[c];
-    x0 = x1 = xa[c];
-    if (den == 0) {                                          // horizontal: both end points
+  // the pixels [x0, x1] of cursor c's edge on the row it stands on (y; y == yb: its last row)
+  RR_HD void pixels(int c, int y, int& x0, int& x1) const {
+    if (dn[c] == 0) {
       x0 = imin(xa[c], xb[c]);
       x1 = imax(xa[c], xb[c]);
       return;
     }
-    const int dn = 2 * den, t = y - ya[c], n2 = mul24i(2 * dx, t);          // exact: |2 dx dy| < 2^23 (host check)
-    int q = (int)floorf((float)n2 * inv[c]);                 // floor(n2 / dn) up to +-1 ...
-    int rem = n2 - mul24i(q, dn);
-    if (rem < 0) { q -= 1; rem += dn; }
-    else if (rem >= dn) { q += 1; rem -= dn; }               // ... made exact
-    if (!CV) {
-      x0 = x1 = xa[c] + q + (rem >= den ? 1 : 0);            // floor((n2 + den) / dn)
-    } else {
-      edge_row_cv(xa[c], xb[c], den, dx, dx16[c], hhr[c] & 0xfff, hhr[c] >> 12, t, q, rem, x0, x1);
+    const int base = xa[c] + Q[c];
+    x0 = base - hh[c] + (R[c] >= tl[c] ? 1 : 0);
+    x1 = base + hh[c] + (R[c] >= th[c] ? 1 : 0);
+    x0 = imax(x0, imin(xa[c], xb[c]));                       // (a no-op for the one-pixel forms)
+    x1 = imin(x1, imax(xa[c], xb[c]));
+    if (wk[c] && y < yb[c]) {                                // OpenCV's walker: rows ya <= y < yb
+      const int sx = xa[c] + (W[c] >> 16);
+      x0 = imin(x0, sx);
+      x1 = imax(x1, sx);
     }
   }
-  RR_HD void row(const V& vertex, int y, int& lo, int& hi) {
-    auto none = [](int, int&, int&) {};
-    row_rule<false>(vertex, none, y, lo, hi);
-  }
-  template <bool CV, class E>
-  RR_HD void row_rule(const V& vertex, const E& edgec, int y, int& lo, int& hi) {
+  RR_HD void row(const V& vertex, const E& rec, int y, int& lo, int& hi) {
     lo = 1 << 30;
     hi = -(1 << 30);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -995,32 +1016,41 @@ struct DdaCursors {
     for (int c = 0; c < 2; c++) {
       {
         int x0, x1;
-        edge_at<CV>(c, y, x0, x1);
+        pixels(c, y, x0, x1);
         lo = imin(lo, x0);
         hi = imax(hi, x1);
+      }
+      {                                                      // a row down the edge (unused once the cursor switches below)
+        const int r = R[c] + rs[c];
+        const int carry = r >= dn[c] ? 1 : 0;
+        R[c] = r - (carry ? dn[c] : 0);
+        Q[c] += qs[c] + carry;
+        W[c] += d16[c];
       }
       while (y == yb[c] && used < N) {                       // a vertex row: the edges that start here touch it too
         used++;
         xa[c] = xb[c];
-        ya[c] = yb[c];
-        const int kold = kv[c];
+        const int ya = yb[c], kold = kv[c];
         kv[c] = c == 0 ? (kv[c] + 1 == N ? 0 : kv[c] + 1) : (kv[c] == 0 ? N - 1 : kv[c] - 1);
         vertex(kv[c], xb[c], yb[c]);
-        if (CV) edgec(c == 0 ? kold : kv[c], dx16[c], hhr[c]);
-        inv[c] = half_recip(yb[c] - ya[c]);
-        if (yb[c] == ya[c]) {                                // a horizontal one: its far end point
-          lo = imin(lo, xb[c]);
-          hi = imax(hi, xb[c]);
-        } else if (CV) {                                     // OpenCV's rule: the new edge's own pixels of its first row
-          int x0, x1;
-          edge_at<true>(c, y, x0, x1);
-          lo = imin(lo, x0);
-          hi = imax(hi, x1);
+        dn[c] = 2 * (yb[c] - ya);
+        take(rec, c, c == 0 ? kold : kv[c]);
+        int x0, x1;
+        pixels(c, y, x0, x1);                                // the new edge's first row (a horizontal one: both end points)
+        lo = imin(lo, x0);
+        hi = imax(hi, x1);
+        if (dn[c] != 0 && y < yb[c]) {                       // (stays on this row's edge only if another vertex follows here: dn == 0)
+          const int r = R[c] + rs[c];
+          const int carry = r >= dn[c] ? 1 : 0;
+          R[c] = r - (carry ? dn[c] : 0);
+          Q[c] += qs[c] + carry;
+          W[c] += d16[c];
         }
       }
     }
   }
 };
+
 // number of times the vertices' row sequence changes direction around the loop (a closed monotone curve: 2; all on one row: 0)
 RR_HD int poly_row_turns(const int32_t* py, int n) {
   int turns = 0, dir = 0, dir_first = 0;

@@ -109,29 +109,19 @@ int emu_dda_check(const int32_t* px, const int32_t* py, int n, int He, int We, i
     if (py[k] > ybot) ybot = py[k];
   }
   auto vertex = [&](int k, int& x, int& y) { x = px[k]; y = py[k]; };
-  std::vector<int> c16(n), chr_(n);
-  for (int k = 0; k < n; k++) {                   // the constants of edge {k, k + 1}, upper end first (k_fov_dda makes them before its row loop)
+  std::vector<uint32_t> r0(n), r1(n), r2(n);
+  for (int k = 0; k < n; k++) {                   // the record of edge {k, k + 1}, upper end first (k_fov_dda makes them before its row loop)
     const int j = k + 1 == n ? 0 : k + 1;
     const bool swp = py[j] < py[k];
-    const int xa = swp ? px[j] : px[k], ya = swp ? py[j] : py[k], xb = swp ? px[k] : px[j], yb = swp ? py[k] : py[j];
-    c16[k] = chr_[k] = 0;
-    if (yb > ya) {
-      int hh, hr;
-      edge_cv_consts(xb - xa, yb - ya, c16[k], hh, hr);
-      chr_[k] = hh | (hr << 12);
-    }
+    dda_edge_record(swp ? px[j] : px[k], swp ? py[j] : py[k], swp ? px[k] : px[j], swp ? py[k] : py[j], rule == 1, r0[k], r1[k], r2[k]);
   }
-  auto edgec = [&](int k, int& d16, int& hhr) { d16 = c16[k]; hhr = chr_[k]; };
-  DdaCursors<decltype(vertex)> cur;
-  if (rule == 1) cur.init_cv(vertex, edgec, n, ktop);
-  else cur.init(vertex, n, ktop);
+  auto rec = [&](int k, uint32_t& a, uint32_t& b, uint32_t& c) { a = r0[k]; b = r1[k]; c = r2[k]; };
+  DdaCursors<decltype(vertex), decltype(rec)> cur;
+  cur.init(vertex, rec, n, ktop);
   int bad = 0;
   for (int y = 0; y < He; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
-    if (y >= ytop && y <= ybot) {
-      if (rule == 1) cur.row_rule<true>(vertex, edgec, y, lo, hi);
-      else cur.row(vertex, y, lo, hi);
-    }
+    if (y >= ytop && y <= ybot) cur.row(vertex, rec, y, lo, hi);
     const int a = imax(lo, 0), b = imin(hi, We - 1);
     int xl, xr;
     const bool any = rule == 1 ? fov_rowspan_cv(px, py, n, y, We, xl, xr) : fov_rowspan(px, py, n, y, We, xl, xr);

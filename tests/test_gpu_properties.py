@@ -353,7 +353,8 @@ def test_fill_rule_option(setup):
         res[rule] = (out, f32)
     # the default IS rule 1
     dflt = rh.render_frames([fr], want_colour=True)[0]
-    assert np.array_equal(dflt['colour'], res[1][0]['colour']) and np.array_equal(base['image_u8'], res[1][1]['image_u8'])
+    d32 = rh.render_frames([fr], want_composite=False)[0]
+    assert np.array_equal(dflt['colour'], res[1][0]['colour']) and np.array_equal(d32['image_u8'], res[1][1]['image_u8'])
     ok = dflt['status'] == 0
     rel = np.abs(res[0][0]['colour'][ok] - dflt['colour'][ok]) / np.abs(dflt['colour'][ok])
     assert 1e-5 < rel.max() < 4e-3, rel.max()
