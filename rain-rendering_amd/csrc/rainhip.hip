@@ -818,9 +818,9 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
 // r06, RR_OPT_FOV_FILL_RULE 1 (the default): the spans are what cv2.fillConvexPoly sets (rr_device.h fov_rowspan_cv: the
 // outline's Bresenham pixels + the 16.16 edge walkers) for the polygons OpenCV's rule applies to (every vertex on the map),
 // the span rule's otherwise.  Both by incremental cursors (rr_device.h DdaCursors): every edge's divisions are done once,
-// before the walk, into a 12-byte record per edge and lane; a row costs adds and compares.  DDA_WAVES waves per workgroup:
-// 16 bytes of LDS per vertex and lane.
-constexpr int DDA_WAVES = 2;
+// before the walk (one per edge: its walker step dx16, from which the other constants follow when a cursor takes the edge);
+// a row costs adds and compares.  8 bytes of LDS per vertex and lane.
+constexpr int DDA_WAVES = 4;
 __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int cv_rule, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
@@ -907,8 +907,8 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     x = (int)(v & 0xffffu);
     y = (int)(v >> 16);
   };
-  // the records of the edges {k, k + 1} (upper end first), behind the vertices: erec[(3 k + w) * 64 + lane]
-  uint32_t* erec = s_pix_dyn + DDA_WAVES * N * 64 + wave * 3 * N * 64;
+  // dx16 of the edges {k, k + 1} (upper end first; the one division an edge needs), behind the vertices: erec[k * 64 + lane]
+  uint32_t* erec = s_pix_dyn + DDA_WAVES * N * 64 + wave * N * 64;
   const bool cvr = cv_rule && on_map;                          // (a vertex off the map: the span rule, like the oracle)
   if (mine) {
     for (int k = 0; k < N; k++) {
@@ -916,21 +916,14 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
       vertex(k, x0, y0);
       vertex(k + 1 == N ? 0 : k + 1, x1, y1);
       const bool swp = y1 < y0;
-      uint32_t w0, w1, w2;
-      dda_edge_record(swp ? x1 : x0, swp ? y1 : y0, swp ? x0 : x1, swp ? y0 : y1, cvr, w0, w1, w2);
-      erec[(3 * k) * 64 + lane] = w0;
-      erec[(3 * k + 1) * 64 + lane] = w1;
-      erec[(3 * k + 2) * 64 + lane] = w2;
+      const int den = swp ? y0 - y1 : y1 - y0, dx = swp ? x0 - x1 : x1 - x0;
+      erec[k * 64 + lane] = den > 0 ? (uint32_t)dda_edge_dx16(dx, den) : 0u;
     }
   }
   wave_lds_sync();
-  auto rec = [&](int kk, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-    w0 = erec[(3 * kk) * 64 + lane];
-    w1 = erec[(3 * kk + 1) * 64 + lane];
-    w2 = erec[(3 * kk + 2) * 64 + lane];
-  };
+  auto rec = [&](int kk) { return (int)erec[kk * 64 + lane]; };
   DdaCursors<decltype(vertex), decltype(rec)> cur;
-  if (mine) cur.init(vertex, rec, N, ktop);
+  if (mine) cur.init(vertex, rec, N, ktop, cvr);
   uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;
   for (int y = 0; y < Hp; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
@@ -5250,10 +5243,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       if (dda) {
         HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, fs));
         {
-          // (16 bytes of LDS per vertex and lane: the vertex' pixel and the 12-byte record of the edge that starts there)
-          const size_t lds = sizeof(uint32_t) * 4 * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
+          // (8 bytes of LDS per vertex and lane: the vertex' pixel and dx16 of the edge that starts there)
+          const size_t lds = sizeof(uint32_t) * 2 * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
           if (!ctx->dda_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 4 * DDA_WAVES * 64 * RR_MAX_FOV)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 2 * DDA_WAVES * 64 * RR_MAX_FOV)));
             ctx->dda_attr = true;
           }
           hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 64 * DDA_WAVES - 1) / (64 * DDA_WAVES), n), dim3(64 * DDA_WAVES), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp,

@@ -928,126 +928,126 @@ RR_HD void edge_row_cv(int xa, int xb, int den, int dx, int dx16, int hh, int hr
 //   OpenCV, shallow  [xa + Q - hh + [R >= hr],  xa + Q + hh + [R >= 2 den - hr]]  clamped to the edge's own x range
 // i.e. one form  [xa + Q - hh + [R >= tl],  xa + Q + hh + [R >= th]]  with per-edge constants, and a row down the edge is
 // Q += qs + carry, R += rs - carry * 2 den  (qs, rs: quotient and remainder of 2 dx by 2 den); OpenCV's edge walker adds the
-// pixel xa + (w >> 16), w = 2^15 + t * dx16.  Every division happens ONCE per edge, when its record is made (before the walk,
-// all lanes busy), not per row; at a vertex a cursor only loads the next record.
-// Record of the undirected edge between an upper end (xu, yu) and a lower end (xl, yl), den = yl - yu, dx = xl - xu:
-//   w0 = dx16 (OpenCV's walker step; 0 under the span rule)
-//   w1 = hh | tl << 11 | same << 22 | walker << 23     (same: th = tl; else th = 2 den - tl)
-//   w2 = (qs & 0xffff) | rs << 16
+// pixel xa + (w >> 16), w = 2^15 + t * dx16.  The ONE division an edge needs -- dx16 = ((dx << 17) + den) / (2 den), C division
+// -- is done before the walk (all lanes busy) and kept per edge and lane; everything else follows from it when a cursor takes
+// the edge:  qs = dx16 >> 16  (the fraction of 2 dx / 2 den is 0 or at least 1 / 2046: the half a unit dx16 is rounded by never
+// reaches the next integer),  rs = 2 dx - qs * 2 den,  hh = floor(2 |dx| / 2 den) >> 1,  hr = |dx| - hh * 2 den.
 // Limits: den <= 1023, |dx| <= 4095 (maps of the fast colour path: 1024 x 4096).
-RR_HD int floor_div_i(int a, int b) {                        // b > 0
-  int q = a / b;
-  if (a % b != 0 && a < 0) q -= 1;
-  return q;
+RR_HD int mul24i(int a, int b) {                            // a * b for |a|, |b| < 2^23 (the 24-bit multiplier on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __mul24(a, b);
+#else
+  return a * b;
+#endif
 }
-RR_HD void dda_edge_record(int xu, int yu, int xl, int yl, bool cv, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-  const int den = yl - yu, dx = xl - xu;
-  w0 = w1 = w2 = 0;
-  if (den <= 0) return;                                      // horizontal: the cursor takes both end points
-  const int dn = 2 * den;
-  const int qs = floor_div_i(2 * dx, dn), rs = 2 * dx - qs * dn;
-  w2 = ((uint32_t)qs & 0xffffu) | ((uint32_t)rs << 16);
-  if (!cv) {
-    w1 = 0u | ((uint32_t)den << 11) | (1u << 22);
-    return;
-  }
-  int dx16, hh, hr;
-  edge_cv_consts(dx, den, dx16, hh, hr);
-  w0 = (uint32_t)dx16;
-  if (den > iabs(dx)) w1 = 0u | ((uint32_t)(den + 1) << 11) | (1u << 22) | (1u << 23);
-  else w1 = (uint32_t)hh | ((uint32_t)hr << 11) | (1u << 23);
+RR_HD int dda_edge_dx16(int dx, int den) {                   // den > 0
+  return (dx * 131072 + den) / (2 * den);                    // C division: toward zero; |dx| <= 4095: below 2^30
 }
-// V: vertex(k, x, y).  E: rec(k, w0, w1, w2) hands out the record of edge {k, k + 1} (upper end first).
+// V: vertex(k, x, y).  E: rec(k) = dx16 of edge {k, k + 1} taken from its upper to its lower end (0 for a horizontal one).
+struct DdaSide {                                             // one cursor: its current edge (xa, ya) .. (xb, yb)
+  int xa, xb, yb, kv;
+  int Q, R, W;                                               // at the row the cursor stands on
+  int dn, hh, tl, th, qs, rs, d16;                           // the edge's constants (dn == 0: horizontal)
+};
 template <class V, class E>
 struct DdaCursors {
-  int xa[2], xb[2], yb[2], kv[2], used, N;
-  int Q[2], R[2], W[2];                                      // the current edge at the row the cursor stands on
-  int dn[2], hh[2], tl[2], th[2], qs[2], rs[2], d16[2], wk[2];      // its constants (dn == 0: horizontal; wk: OpenCV's walker applies)
-  RR_HD void take(const E& rec, int c, int kedge) {          // the cursor's next edge; xa, xb, yb and dn set by the caller
-    uint32_t w0, w1, w2;
-    rec(kedge, w0, w1, w2);
-    d16[c] = (int)w0;
-    hh[c] = (int)(w1 & 0x7ffu);
-    tl[c] = (int)((w1 >> 11) & 0x7ffu);
-    th[c] = ((w1 >> 22) & 1u) ? tl[c] : dn[c] - tl[c];
-    wk[c] = (int)((w1 >> 23) & 1u);
-    qs[c] = (int)(int16_t)(w2 & 0xffffu);
-    rs[c] = (int)(w2 >> 16);
-    Q[c] = 0;
-    R[c] = 0;
-    W[c] = 32768;
+  DdaSide s0, s1;                                            // cursor 0 walks the vertices upwards in index from the top vertex, cursor 1 downwards
+  int used, N;
+  bool cv;                                                   // OpenCV's rule (else the span rule)
+  RR_HD void take(DdaSide& S, const E& rec, int kedge, int ya) const {      // the cursor's next edge; xa, xb, yb set by the caller
+    const int den = S.yb - ya, dx = S.xb - S.xa;
+    S.dn = 2 * den;
+    S.Q = 0;
+    S.R = 0;
+    S.W = 32768;
+    S.d16 = S.qs = S.rs = S.hh = S.tl = S.th = 0;
+    if (den != 0) {
+      const int v16 = rec(kedge);
+      S.qs = v16 >> 16;
+      S.rs = 2 * dx - mul24i(S.qs, S.dn);
+      const int adx = iabs(dx);
+      if (!cv) {
+        S.tl = S.th = den;
+      } else if (den > adx) {                                // steep: one pixel per row
+        S.d16 = v16;
+        S.tl = S.th = den + 1;
+      } else {
+        S.d16 = v16;
+        const int q2 = dx >= 0 ? S.qs : -(S.qs + (S.rs != 0 ? 1 : 0));     // floor(2 |dx| / 2 den)
+        S.hh = q2 >> 1;
+        S.tl = adx - mul24i(S.hh, S.dn);                     // hr
+        S.th = S.dn - S.tl;
+      }
+    }
   }
-  RR_HD void init(const V& vertex, const E& rec, int n, int ktop) {
+  template <int C>
+  RR_HD static int next_k(int k, int n) { return C == 0 ? (k + 1 == n ? 0 : k + 1) : (k == 0 ? n - 1 : k - 1); }
+  template <int C>
+  RR_HD void init_side(DdaSide& S, const V& vertex, const E& rec, int ktop) const {
+    int ya;
+    vertex(ktop, S.xa, ya);
+    S.kv = next_k<C>(ktop, N);
+    vertex(S.kv, S.xb, S.yb);
+    take(S, rec, C == 0 ? ktop : S.kv, ya);
+  }
+  RR_HD void init(const V& vertex, const E& rec, int n, int ktop, bool cv_rule) {
     N = n;
+    cv = cv_rule;
     used = 2;                                                // edges taken so far (both cursors together; N in all)
-    for (int c = 0; c < 2; c++) {
-      int ya;
-      vertex(ktop, xa[c], ya);
-      kv[c] = c == 0 ? (ktop + 1 == N ? 0 : ktop + 1) : (ktop == 0 ? N - 1 : ktop - 1);
-      vertex(kv[c], xb[c], yb[c]);
-      dn[c] = 2 * (yb[c] - ya);
-      take(rec, c, c == 0 ? ktop : kv[c]);
-    }
+    init_side<0>(s0, vertex, rec, ktop);
+    init_side<1>(s1, vertex, rec, ktop);
   }
-  // the pixels [x0, x1] of cursor c's edge on the row it stands on (y; y == yb: its last row)
-  RR_HD void pixels(int c, int y, int& x0, int& x1) const {
-    if (dn[c] == 0) {
-      x0 = imin(xa[c], xb[c]);
-      x1 = imax(xa[c], xb[c]);
-      return;
-    }
-    const int base = xa[c] + Q[c];
-    x0 = base - hh[c] + (R[c] >= tl[c] ? 1 : 0);
-    x1 = base + hh[c] + (R[c] >= th[c] ? 1 : 0);
-    x0 = imax(x0, imin(xa[c], xb[c]));                       // (a no-op for the one-pixel forms)
-    x1 = imin(x1, imax(xa[c], xb[c]));
-    if (wk[c] && y < yb[c]) {                                // OpenCV's walker: rows ya <= y < yb
-      const int sx = xa[c] + (W[c] >> 16);
+  // the pixels [x0, x1] of the cursor's edge on the row it stands on (y; y == yb: its last row)
+  RR_HD void pixels(const DdaSide& S, int y, int& x0, int& x1) const {
+    const int mn = imin(S.xa, S.xb), mx = imax(S.xa, S.xb);
+    const int base = S.xa + S.Q;
+    x0 = imax(base - S.hh + (S.R >= S.tl ? 1 : 0), mn);      // (the clamps: no-ops for the one-pixel forms)
+    x1 = imin(base + S.hh + (S.R >= S.th ? 1 : 0), mx);
+    if (cv && y < S.yb) {                                    // OpenCV's walker: rows ya <= y < yb
+      const int sx = S.xa + (S.W >> 16);
       x0 = imin(x0, sx);
       x1 = imax(x1, sx);
+    }
+    if (S.dn == 0) {                                         // horizontal: both end points
+      x0 = mn;
+      x1 = mx;
+    }
+  }
+  RR_HD static void step(DdaSide& S) {                       // a row down the current edge
+    const int r = S.R + S.rs;
+    const int carry = r >= S.dn ? 1 : 0;
+    S.R = r - (carry ? S.dn : 0);
+    S.Q += S.qs + carry;
+    S.W += S.d16;
+  }
+  template <int C>
+  RR_HD void side_row(DdaSide& S, const V& vertex, const E& rec, int y, int& lo, int& hi) {
+    {
+      int x0, x1;
+      pixels(S, y, x0, x1);
+      lo = imin(lo, x0);
+      hi = imax(hi, x1);
+    }
+    step(S);                                                 // (unused once the cursor switches below)
+    while (y == S.yb && used < N) {                          // a vertex row: the edges that start here touch it too
+      used++;
+      S.xa = S.xb;
+      const int ya = S.yb, kold = S.kv;
+      S.kv = next_k<C>(S.kv, N);
+      vertex(S.kv, S.xb, S.yb);
+      take(S, rec, C == 0 ? kold : S.kv, ya);
+      int x0, x1;
+      pixels(S, y, x0, x1);                                  // the new edge's first row (a horizontal one: both end points)
+      lo = imin(lo, x0);
+      hi = imax(hi, x1);
+      if (y < S.yb) step(S);                                 // (a horizontal edge: the next vertex follows on this row)
     }
   }
   RR_HD void row(const V& vertex, const E& rec, int y, int& lo, int& hi) {
     lo = 1 << 30;
     hi = -(1 << 30);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int c = 0; c < 2; c++) {
-      {
-        int x0, x1;
-        pixels(c, y, x0, x1);
-        lo = imin(lo, x0);
-        hi = imax(hi, x1);
-      }
-      {                                                      // a row down the edge (unused once the cursor switches below)
-        const int r = R[c] + rs[c];
-        const int carry = r >= dn[c] ? 1 : 0;
-        R[c] = r - (carry ? dn[c] : 0);
-        Q[c] += qs[c] + carry;
-        W[c] += d16[c];
-      }
-      while (y == yb[c] && used < N) {                       // a vertex row: the edges that start here touch it too
-        used++;
-        xa[c] = xb[c];
-        const int ya = yb[c], kold = kv[c];
-        kv[c] = c == 0 ? (kv[c] + 1 == N ? 0 : kv[c] + 1) : (kv[c] == 0 ? N - 1 : kv[c] - 1);
-        vertex(kv[c], xb[c], yb[c]);
-        dn[c] = 2 * (yb[c] - ya);
-        take(rec, c, c == 0 ? kold : kv[c]);
-        int x0, x1;
-        pixels(c, y, x0, x1);                                // the new edge's first row (a horizontal one: both end points)
-        lo = imin(lo, x0);
-        hi = imax(hi, x1);
-        if (dn[c] != 0 && y < yb[c]) {                       // (stays on this row's edge only if another vertex follows here: dn == 0)
-          const int r = R[c] + rs[c];
-          const int carry = r >= dn[c] ? 1 : 0;
-          R[c] = r - (carry ? dn[c] : 0);
-          Q[c] += qs[c] + carry;
-          W[c] += d16[c];
-        }
-      }
-    }
+    side_row<0>(s0, vertex, rec, y, lo, hi);
+    side_row<1>(s1, vertex, rec, y, lo, hi);
   }
 };
 
