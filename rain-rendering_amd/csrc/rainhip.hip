@@ -818,9 +818,9 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
 // r06, RR_OPT_FOV_FILL_RULE 1 (the default): the spans are what cv2.fillConvexPoly sets (rr_device.h fov_rowspan_cv: the
 // outline's Bresenham pixels + the 16.16 edge walkers) for the polygons OpenCV's rule applies to (every vertex on the map),
 // the span rule's otherwise.  Both by incremental cursors (rr_device.h DdaCursors): every edge's divisions are done once,
-// before the walk (one per edge: its walker step dx16, from which the other constants follow when a cursor takes the edge);
-// a row costs adds and compares.  8 bytes of LDS per vertex and lane.
-constexpr int DDA_WAVES = 4;
+// before the walk, into an 8-byte record per edge and lane; a row costs adds and compares, and a cursor fetches its next
+// vertex and record an edge ahead.  12 bytes of LDS per vertex and lane.
+constexpr int DDA_WAVES = 2;
 __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int cv_rule, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
@@ -902,28 +902,34 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
   if (mine) sc.npts[gi] = N;
   if (__ballot(mine) == 0ull) return;
   // ---- 2. spans of the sure drops: two cursors down from the top vertex (rr_device.h DdaCursors) ----
-  auto vertex = [&](int kk, int& x, int& y) {
+  auto vertex_xy = [&](int kk, int& x, int& y) {
     const uint32_t v = pix[kk * 64 + lane];
     x = (int)(v & 0xffffu);
     y = (int)(v >> 16);
   };
-  // dx16 of the edges {k, k + 1} (upper end first; the one division an edge needs), behind the vertices: erec[k * 64 + lane]
-  uint32_t* erec = s_pix_dyn + DDA_WAVES * N * 64 + wave * N * 64;
+  // the records of the edges {k, k + 1} (upper end first), behind the vertices: erec[(2 k + w) * 64 + lane]
+  uint32_t* erec = s_pix_dyn + DDA_WAVES * N * 64 + wave * 2 * N * 64;
   const bool cvr = cv_rule && on_map;                          // (a vertex off the map: the span rule, like the oracle)
   if (mine) {
     for (int k = 0; k < N; k++) {
       int x0, y0, x1, y1;
-      vertex(k, x0, y0);
-      vertex(k + 1 == N ? 0 : k + 1, x1, y1);
+      vertex_xy(k, x0, y0);
+      vertex_xy(k + 1 == N ? 0 : k + 1, x1, y1);
       const bool swp = y1 < y0;
-      const int den = swp ? y0 - y1 : y1 - y0, dx = swp ? x0 - x1 : x1 - x0;
-      erec[k * 64 + lane] = den > 0 ? (uint32_t)dda_edge_dx16(dx, den) : 0u;
+      uint32_t w0, w1;
+      dda_edge_record(swp ? x1 : x0, swp ? y1 : y0, swp ? x0 : x1, swp ? y0 : y1, cvr, w0, w1);
+      erec[(2 * k) * 64 + lane] = w0;
+      erec[(2 * k + 1) * 64 + lane] = w1;
     }
   }
   wave_lds_sync();
-  auto rec = [&](int kk) { return (int)erec[kk * 64 + lane]; };
+  auto vertex = [&](int kk) { return pix[kk * 64 + lane]; };
+  auto rec = [&](int kk, uint32_t& w0, uint32_t& w1) {
+    w0 = erec[(2 * kk) * 64 + lane];
+    w1 = erec[(2 * kk + 1) * 64 + lane];
+  };
   DdaCursors<decltype(vertex), decltype(rec)> cur;
-  if (mine) cur.init(vertex, rec, N, ktop, cvr);
+  if (mine) cur.init(vertex, rec, N, ktop);
   uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;
   for (int y = 0; y < Hp; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
@@ -5243,10 +5249,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       if (dda) {
         HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, fs));
         {
-          // (8 bytes of LDS per vertex and lane: the vertex' pixel and dx16 of the edge that starts there)
-          const size_t lds = sizeof(uint32_t) * 2 * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
+          // (12 bytes of LDS per vertex and lane: the vertex' pixel and the record of the edge that starts there)
+          const size_t lds = sizeof(uint32_t) * 3 * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
           if (!ctx->dda_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 2 * DDA_WAVES * 64 * RR_MAX_FOV)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 3 * DDA_WAVES * 64 * RR_MAX_FOV)));
             ctx->dda_attr = true;
           }
           hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 64 * DDA_WAVES - 1) / (64 * DDA_WAVES), n), dim3(64 * DDA_WAVES), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp,

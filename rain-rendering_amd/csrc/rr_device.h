@@ -928,10 +928,9 @@ RR_HD void edge_row_cv(int xa, int xb, int den, int dx, int dx16, int hh, int hr
 //   OpenCV, shallow  [xa + Q - hh + [R >= hr],  xa + Q + hh + [R >= 2 den - hr]]  clamped to the edge's own x range
 // i.e. one form  [xa + Q - hh + [R >= tl],  xa + Q + hh + [R >= th]]  with per-edge constants, and a row down the edge is
 // Q += qs + carry, R += rs - carry * 2 den  (qs, rs: quotient and remainder of 2 dx by 2 den); OpenCV's edge walker adds the
-// pixel xa + (w >> 16), w = 2^15 + t * dx16.  The ONE division an edge needs -- dx16 = ((dx << 17) + den) / (2 den), C division
-// -- is done before the walk (all lanes busy) and kept per edge and lane; everything else follows from it when a cursor takes
-// the edge:  qs = dx16 >> 16  (the fraction of 2 dx / 2 den is 0 or at least 1 / 2046: the half a unit dx16 is rounded by never
-// reaches the next integer),  rs = 2 dx - qs * 2 den,  hh = floor(2 |dx| / 2 den) >> 1,  hr = |dx| - hh * 2 den.
+// pixel xa + (w >> 16), w = 2^15 + t * dx16.  An edge's divisions are done ONCE, before the walk (all lanes busy), into an
+// 8-byte record per edge and lane; a cursor fetches the next vertex and record an edge ahead, so that taking an edge costs no
+// wait for the LDS.
 // Limits: den <= 1023, |dx| <= 4095 (maps of the fast colour path: 1024 x 4096).
 RR_HD int mul24i(int a, int b) {                            // a * b for |a|, |b| < 2^23 (the 24-bit multiplier on the device)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -940,70 +939,86 @@ RR_HD int mul24i(int a, int b) {                            // a * b for |a|, |b
   return a * b;
 #endif
 }
-RR_HD int dda_edge_dx16(int dx, int den) {                   // den > 0
-  return (dx * 131072 + den) / (2 * den);                    // C division: toward zero; |dx| <= 4095: below 2^30
+// Record of the undirected edge between an upper end (xu, yu) and a lower end (xl, yl), den = yl - yu, dx = xl - xu, made
+// before the walk (all lanes busy: this is where the divisions are):
+//   w0 = dx16 = ((dx << 17) + den) / (2 den), C division: OpenCV's walker step -- and qs = w0 >> 16 (the fraction of
+//        2 dx / 2 den is 0 or at least 1 / 2046: the half a unit dx16 is rounded by never reaches the next integer)
+//   w1 = hh | tl << 11 | same << 22 | walker << 23     (same: th = tl; else th = 2 den - tl)
+RR_HD void dda_edge_record(int xu, int yu, int xl, int yl, bool cv, uint32_t& w0, uint32_t& w1) {
+  const int den = yl - yu, dx = xl - xu;
+  w0 = w1 = 0;
+  if (den <= 0) return;                                      // horizontal: the cursor takes both end points
+  int dx16, hh, hr;
+  edge_cv_consts(dx, den, dx16, hh, hr);
+  w0 = (uint32_t)dx16;
+  if (!cv) w1 = 0u | ((uint32_t)den << 11) | (1u << 22);
+  else if (den > iabs(dx)) w1 = 0u | ((uint32_t)(den + 1) << 11) | (1u << 22) | (1u << 23);
+  else w1 = (uint32_t)hh | ((uint32_t)hr << 11) | (1u << 23);
 }
-// V: vertex(k, x, y).  E: rec(k) = dx16 of edge {k, k + 1} taken from its upper to its lower end (0 for a horizontal one).
+// V: vertex(k) = x | y << 16.  E: rec(k, w0, w1) = the record of edge {k, k + 1} (upper end first).
 struct DdaSide {                                             // one cursor: its current edge (xa, ya) .. (xb, yb)
   int xa, xb, yb, kv;
   int Q, R, W;                                               // at the row the cursor stands on
-  int dn, hh, tl, th, qs, rs, d16;                           // the edge's constants (dn == 0: horizontal)
+  int dn, hh, tl, th, qs, rs, d16, wk;                       // the edge's constants (dn == 0: horizontal; wk: OpenCV's walker)
+  uint32_t n_pix, n_w0, n_w1;                                // the NEXT vertex and edge, fetched an edge ahead
 };
 template <class V, class E>
 struct DdaCursors {
   DdaSide s0, s1;                                            // cursor 0 walks the vertices upwards in index from the top vertex, cursor 1 downwards
   int used, N;
-  bool cv;                                                   // OpenCV's rule (else the span rule)
-  RR_HD void take(DdaSide& S, const E& rec, int kedge, int ya) const {      // the cursor's next edge; xa, xb, yb set by the caller
+  template <int C>
+  RR_HD static int next_k(int k, int n) { return C == 0 ? (k + 1 == n ? 0 : k + 1) : (k == 0 ? n - 1 : k - 1); }
+  // the cursor moves on to the edge that was fetched ahead (from (xb, yb), which becomes (xa, ya)) and fetches the one after it
+  template <int C>
+  RR_HD void advance_edge(DdaSide& S, const V& vertex, const E& rec) const {
+    const int ya = S.yb;
+    S.xa = S.xb;
+    S.xb = (int)(S.n_pix & 0xffffu);
+    S.yb = (int)(S.n_pix >> 16);
+    const uint32_t w0 = S.n_w0, w1 = S.n_w1;
+    S.kv = next_k<C>(S.kv, N);
+    {
+      const int kn = next_k<C>(S.kv, N);
+      S.n_pix = vertex(kn);
+      rec(C == 0 ? S.kv : kn, S.n_w0, S.n_w1);
+    }
     const int den = S.yb - ya, dx = S.xb - S.xa;
     S.dn = 2 * den;
     S.Q = 0;
     S.R = 0;
     S.W = 32768;
-    S.d16 = S.qs = S.rs = S.hh = S.tl = S.th = 0;
-    if (den != 0) {
-      const int v16 = rec(kedge);
-      S.qs = v16 >> 16;
-      S.rs = 2 * dx - mul24i(S.qs, S.dn);
-      const int adx = iabs(dx);
-      if (!cv) {
-        S.tl = S.th = den;
-      } else if (den > adx) {                                // steep: one pixel per row
-        S.d16 = v16;
-        S.tl = S.th = den + 1;
-      } else {
-        S.d16 = v16;
-        const int q2 = dx >= 0 ? S.qs : -(S.qs + (S.rs != 0 ? 1 : 0));     // floor(2 |dx| / 2 den)
-        S.hh = q2 >> 1;
-        S.tl = adx - mul24i(S.hh, S.dn);                     // hr
-        S.th = S.dn - S.tl;
-      }
-    }
+    S.d16 = (int)w0;
+    S.wk = (int)((w1 >> 23) & 1u);
+    S.hh = (int)(w1 & 0x7ffu);
+    S.tl = (int)((w1 >> 11) & 0x7ffu);
+    S.th = ((w1 >> 22) & 1u) ? S.tl : S.dn - S.tl;
+    S.qs = S.d16 >> 16;
+    S.rs = 2 * dx - mul24i(S.qs, S.dn);
   }
-  template <int C>
-  RR_HD static int next_k(int k, int n) { return C == 0 ? (k + 1 == n ? 0 : k + 1) : (k == 0 ? n - 1 : k - 1); }
   template <int C>
   RR_HD void init_side(DdaSide& S, const V& vertex, const E& rec, int ktop) const {
-    int ya;
-    vertex(ktop, S.xa, ya);
-    S.kv = next_k<C>(ktop, N);
-    vertex(S.kv, S.xb, S.yb);
-    take(S, rec, C == 0 ? ktop : S.kv, ya);
+    const uint32_t p0 = vertex(ktop);
+    S.xb = (int)(p0 & 0xffffu);                              // "the end of the edge before": the top vertex
+    S.yb = (int)(p0 >> 16);
+    S.kv = ktop;
+    const int k1 = next_k<C>(ktop, N);
+    S.n_pix = vertex(k1);
+    rec(C == 0 ? ktop : k1, S.n_w0, S.n_w1);
+    advance_edge<C>(S, vertex, rec);
   }
-  RR_HD void init(const V& vertex, const E& rec, int n, int ktop, bool cv_rule) {
+  RR_HD void init(const V& vertex, const E& rec, int n, int ktop) {
     N = n;
-    cv = cv_rule;
     used = 2;                                                // edges taken so far (both cursors together; N in all)
     init_side<0>(s0, vertex, rec, ktop);
     init_side<1>(s1, vertex, rec, ktop);
   }
   // the pixels [x0, x1] of the cursor's edge on the row it stands on (y; y == yb: its last row)
-  RR_HD void pixels(const DdaSide& S, int y, int& x0, int& x1) const {
+  RR_HD static void pixels(const DdaSide& S, int y, int& x0, int& x1) {
     const int mn = imin(S.xa, S.xb), mx = imax(S.xa, S.xb);
     const int base = S.xa + S.Q;
     x0 = imax(base - S.hh + (S.R >= S.tl ? 1 : 0), mn);      // (the clamps: no-ops for the one-pixel forms)
     x1 = imin(base + S.hh + (S.R >= S.th ? 1 : 0), mx);
-    if (cv && y < S.yb) {                                    // OpenCV's walker: rows ya <= y < yb
+    if (S.wk && y < S.yb) {                                  // OpenCV's walker: rows ya <= y < yb
       const int sx = S.xa + (S.W >> 16);
       x0 = imin(x0, sx);
       x1 = imax(x1, sx);
@@ -1031,11 +1046,7 @@ struct DdaCursors {
     step(S);                                                 // (unused once the cursor switches below)
     while (y == S.yb && used < N) {                          // a vertex row: the edges that start here touch it too
       used++;
-      S.xa = S.xb;
-      const int ya = S.yb, kold = S.kv;
-      S.kv = next_k<C>(S.kv, N);
-      vertex(S.kv, S.xb, S.yb);
-      take(S, rec, C == 0 ? kold : S.kv, ya);
+      advance_edge<C>(S, vertex, rec);
       int x0, x1;
       pixels(S, y, x0, x1);                                  // the new edge's first row (a horizontal one: both end points)
       lo = imin(lo, x0);

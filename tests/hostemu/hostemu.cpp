@@ -108,17 +108,16 @@ int emu_dda_check(const int32_t* px, const int32_t* py, int n, int He, int We, i
     if (py[k] < ytop) { ytop = py[k]; ktop = k; }
     if (py[k] > ybot) ybot = py[k];
   }
-  auto vertex = [&](int k, int& x, int& y) { x = px[k]; y = py[k]; };
-  std::vector<int> r16(n);
-  for (int k = 0; k < n; k++) {                   // dx16 of edge {k, k + 1}, upper end first (k_fov_dda makes them before its row loop)
+  auto vertex = [&](int k) { return (uint32_t)px[k] | ((uint32_t)py[k] << 16); };
+  std::vector<uint32_t> r0(n), r1(n);
+  for (int k = 0; k < n; k++) {                   // the record of edge {k, k + 1}, upper end first (k_fov_dda makes them before its row loop)
     const int j = k + 1 == n ? 0 : k + 1;
     const bool swp = py[j] < py[k];
-    const int den = swp ? py[k] - py[j] : py[j] - py[k], dx = swp ? px[k] - px[j] : px[j] - px[k];
-    r16[k] = den > 0 ? dda_edge_dx16(dx, den) : 0;
+    dda_edge_record(swp ? px[j] : px[k], swp ? py[j] : py[k], swp ? px[k] : px[j], swp ? py[k] : py[j], rule == 1, r0[k], r1[k]);
   }
-  auto rec = [&](int k) { return r16[k]; };
+  auto rec = [&](int k, uint32_t& a, uint32_t& b) { a = r0[k]; b = r1[k]; };
   DdaCursors<decltype(vertex), decltype(rec)> cur;
-  cur.init(vertex, rec, n, ktop, rule == 1);
+  cur.init(vertex, rec, n, ktop);
   int bad = 0;
   for (int y = 0; y < He; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
