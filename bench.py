@@ -244,6 +244,9 @@ def measure_traffic(args, dom_kernels, scene_dir=None):
         return None, "pmc pass failed: %r" % (e,)
 
 
+# defaults of the library's rr_set_option switches (what a sweep puts back)
+OPTION_DEFAULTS = {1: 1, 9: 1, 10: 2, 12: 1, 13: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1, 22: 1, 23: 2}
+
 # kernel symbol -> the name of the timing scope (rr_profile_read) it is launched under
 SCOPE_OF = {'k_blur_fused_dma': 'k_blur_fused', 'k_composite32': 'k_composite', 'k_fov_sums32': 'k_fov_sums', 'k_fov_dda': 'k_fov_spans',
             'k_fov_walk': 'k_fov_spans', 'k_finalize16': 'k_finalize', 'k_bin_rows': 'k_bin', 'k_env_consts': 'k_env_prefix',
@@ -498,9 +501,11 @@ def main():
                                                 frame_ids=fnum, draw_seeds=[f % (2 ** 32) for f in fnum])
 
     rh = hb.RainHip(local_rank)
+    user_opts = {}
     for kv in args.opt:
         k, v = kv.split('=')
         rh.set_option(int(k), int(v))
+        user_opts[int(k)] = int(v)
     # --- the one collective: RCCL broadcast of the packed streak DB over xGMI -----------------
     texels, hs, ws, offs = hb.pack_streak_db(sc.db.streaks_light)
     t_tex = torch.from_numpy(texels).to(dev)
@@ -576,13 +581,14 @@ def main():
             rh.profile(False)
             line(spec, el, rh.profile_read())
             for k, v in pairs:
-                rh.set_option(int(k), {1: 1, 9: 1, 10: 2, 12: 1, 16: 1, 17: 1, 19: 1, 20: 1, 21: 1}.get(int(k), 0))  # back to the option's default
+                rh.set_option(int(k), user_opts.get(int(k), OPTION_DEFAULTS.get(int(k), 0)))  # back to the user's value / the option's default
         warm(render, 1)
     # The colour branch runs on the library's second stream (RR_OPT_COLOUR_STREAM, default): the event pairs around ITS kernels
     # then span the time they waited for room beside the other stream's kernels, not their cost.  One more pass of the same
     # step with everything on one in-order stream gives every kernel's own duration (and what the overlap is worth).
     stats_serial, elapsed_serial = None, None
-    if not args.no_serial and not args.inner and hasattr(hb, 'RR_OPT_COLOUR_STREAM'):      # (every rank: the timed loop holds collectives)
+    colour_mode = user_opts.get(hb.RR_OPT_COLOUR_STREAM, 1)
+    if not args.no_serial and not args.inner and colour_mode != 0:      # (every rank: the timed loop holds collectives)
         rh.set_option(hb.RR_OPT_COLOUR_STREAM, 0)
         warm(render, 1)
         rh.profile_reset()
@@ -590,7 +596,7 @@ def main():
         elapsed_serial = timed(torch, dist, world, dev, render, args.steps)
         rh.profile(False)
         stats_serial = rh.profile_read()
-        rh.set_option(hb.RR_OPT_COLOUR_STREAM, 1)
+        rh.set_option(hb.RR_OPT_COLOUR_STREAM, user_opts.get(hb.RR_OPT_COLOUR_STREAM, 1))      # (the user's --opt 21=.. stays in force)
         warm(render, 1)
     nb = min(B, batch.n)
     cnts = np.array([rh.batch_counts(i) for i in range(chunks[-1][2])]) if chunks else np.zeros((1, 8), int)
@@ -621,6 +627,9 @@ def main():
         mid = [batch.chunk(hb, a, a + 32) for a in range(0, min(batch.n, 128) - 31, 32)]
         if mid:
             var["calls_of_32"] = {"frames_per_s": rate(lambda: render(mid), 32 * len(mid)), "what": "library calls of 32 frames (the driver's default)"}
+        if batch.n >= 256:
+            q128 = [batch.chunk(hb, a, a + 128) for a in range(0, batch.n - 127, 128)]
+            var["calls_of_128"] = {"frames_per_s": rate(lambda: render(q128), 128 * len(q128)), "what": "library calls of 128 frames (the driver's slot size)"}
         if batch.n >= 512:
             half = [batch.chunk(hb, a, a + 256) for a in range(0, batch.n - 255, 256)]
             var["calls_of_256"] = {"frames_per_s": rate(lambda: render(half), 256 * len(half)), "what": "library calls of 256 frames (the round-3 headline's call size)"}
@@ -632,6 +641,22 @@ def main():
                                   "frames_per_s_same_call_size_%s" % args.input_dtype: rate(lambda: render([batch.chunk(hb, 0, nn)]), nn),
                                   "what": "%d frames per call with the image / map inputs resident as %s instead of %s" % (nn, other, args.input_dtype)}
         del ob, obc
+        # the reference's own arithmetic (bad_weather.py:397-446 is float64 throughout): float64 inputs, float64 colour branch,
+        # float64 compositor, the headline's call size
+        try:
+            rb = DeviceBatch(torch, hb, sc, dev, fids, my_frames, in_dtype='f64')
+            rbc = [rb.chunk(hb, a, min(a + B, rb.n)) for a in range(0, rb.n, B)]
+            rh.set_option(hb.RR_OPT_COMPOSITE_F64, 1)
+            rh.set_option(hb.RR_OPT_FOV_F32, 0)
+            var["reference_arithmetic"] = {"frames_per_s": rate(lambda: render(rbc), rb.n, reps=2),
+                                           "what": "%d frames per call, image / map / solid angles resident as float64, RR_OPT_COMPOSITE_F64 1 and RR_OPT_FOV_F32 0: "
+                                                   "float64 in every stage, as the reference computes" % min(B, rb.n)}
+        except Exception as e:                                 # noqa: BLE001 -- a variant never fails the line
+            var["reference_arithmetic"] = {"error": repr(e)}
+        finally:
+            rh.set_option(hb.RR_OPT_COMPOSITE_F64, user_opts.get(hb.RR_OPT_COMPOSITE_F64, 0))
+            rh.set_option(hb.RR_OPT_FOV_F32, user_opts.get(hb.RR_OPT_FOV_F32, 2))
+            rb = rbc = None
         warm(render, 1)                      # back to the headline configuration (arena / scratch sized for it)
         extras["variants"] = var
 
@@ -812,7 +837,7 @@ def main():
             extras["host_inclusive_copy_sweep"] = {"blocks_%s" % b: host_inclusive(PB, copy_kernels=int(b))["frames_per_s"] for b in args.copy_sweep.split(',')}
         if not args.no_variants:
             extras["host_inclusive_variants"] = {"slots_of_32": host_inclusive(min(32, batch.n)),
-                                                 "slots_of_256": host_inclusive(min(256, batch.n)),
+                                                 "slots_of_256": host_inclusive(min(256, batch.n)),      # (with 512 frames in all a slot size of 256 is two batches: the third slot stays empty and nothing overlaps the last download)
                                                  "copy_kernels": host_inclusive(PB, copy_kernels=True),
                                                  "depth_as_float32": host_inclusive(PB, depth_u16=False)}
             if args.more_variants:
@@ -825,7 +850,9 @@ def main():
         frames_step = args.total_frames if strong else B * world
         fps = frames_step * args.steps / elapsed
         per_launch = {k: v[1] / v[0] for k, v in stats.items()}
-        COLOUR = ('k_fov_spans', 'k_fov_sums', 'k_fov_poly', 'k_env_prefix', 'k_fov_sums_general')      # launched on the library's second stream (RR_OPT_COLOUR_STREAM 1)
+        # the scopes launched on the library's second stream: mode 1 the FOV chain, mode 2 the bookkeeping chain + k_colour
+        COLOUR = (('k_fov_spans', 'k_fov_sums', 'k_fov_poly', 'k_env_prefix', 'k_fov_sums_general') if colour_mode == 1 else
+                  ('k_plan', 'k_scan', 'k_dedup', 'k_lists', 'k_colour'))
         overlapped = {k: v for k, v in per_launch.items() if k in COLOUR} if stats_serial is not None else {}
         per_main = {k: v for k, v in per_launch.items() if k not in overlapped}
         dom_name = max(per_main, key=per_main.get)
@@ -897,6 +924,7 @@ def main():
                        "parallelism": "frames sharded round-robin, dp%d; one RCCL broadcast of the streak DB" % world,
                        "raw_tiles_last_call": {"rotate_resize": int(cnts[:, 0].sum()), "bicubic_warp": int(cnts[:, 5].sum()),
                                                "generic": int(cnts[:, 1].sum()), "shared_bit_identical": int(cnts[:, 7].sum())},
+                       "raw_tile_share": float(cnts[:, 7].sum()) / max(1.0, float(cnts[:, 0].sum() + cnts[:, 1].sum() + cnts[:, 5].sum() + cnts[:, 7].sum())),
                        "blur_last_call": {"fused_items": int(cnts[:, 2].sum()), "wave_per_drop": int(cnts[:, 4].sum()),
                                           "two_pass": int(cnts[:, 3].sum())}},
             "roofline": {"bound": bound, "nearest_roof": nearest, "bound_detail": bound_detail, "compute": compute, "kernel": dom_name, "achieved": achieved,
@@ -923,6 +951,8 @@ def main():
                                     for k, v in sorted((valu or {}).items(), key=lambda kv: -kv[1]["valu_util"])} if valu else None},
         }
         out.update(extras)
+        if "host_inclusive" in extras:                         # SURVEY 8(d)'s own rate (H2D of the inputs and D2H of the outputs included), at the top level
+            out["host_inclusive_frames_per_s"] = extras["host_inclusive"].get("frames_per_s")
         if single and not args.no_driver and not strong and not is_sim and args.workload == 'kitti100':
             out["driver_end_to_end"] = driver_end_to_end(1024, args.pipe_batch)
         if not args.no_cpu_baseline and single and not strong and not is_sim:
