@@ -231,6 +231,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* wtab_big;                 // [frame][SLOW_CAP][2][MAX_R+1] the same for the first SLOW_CAP large-radius drops of a frame (k_blur_big_weights)
   const uint8_t* tex_pad;           // the textures with their 2-texel zero border, as k_tile stages them (k_pad_textures); NULL: staged byte by byte
   const int64_t* tex_poff;          // [texture] offset of its padded copy (a multiple of 16)
+  uint2* fov_erec;                  // [frame][n_fov][drops] k_fov_dda's edge records (rr_device.h dda_edge_record)
   int32_t* fov_list;                // [frame][drops] drops k_fov_dda leaves to k_fov_spans (wrapping polygons, float64 decisions)
   int32_t* fov_list_n;              // [frame] their number
   uint8_t* blended;                 // [frame][drop] 1: the drop is composited (k_colour)
@@ -818,9 +819,9 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
 // r06, RR_OPT_FOV_FILL_RULE 1 (the default): the spans are what cv2.fillConvexPoly sets (rr_device.h fov_rowspan_cv: the
 // outline's Bresenham pixels + the 16.16 edge walkers) for the polygons OpenCV's rule applies to (every vertex on the map),
 // the span rule's otherwise.  Both by incremental cursors (rr_device.h DdaCursors): every edge's divisions are done once,
-// before the walk, into an 8-byte record per edge and lane; a row costs adds and compares, and a cursor fetches its next
-// vertex and record an edge ahead.  12 bytes of LDS per vertex and lane.
-constexpr int DDA_WAVES = 2;
+// before the walk, into an 8-byte record per edge and lane (global memory); a row costs adds and compares, and a cursor
+// fetches its next vertex and record an edge ahead.  4 bytes of LDS per vertex and lane.
+constexpr int DDA_WAVES = 4;
 __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int cv_rule, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
@@ -907,8 +908,11 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     x = (int)(v & 0xffffu);
     y = (int)(v >> 16);
   };
-  // the records of the edges {k, k + 1} (upper end first), behind the vertices: erec[(2 k + w) * 64 + lane]
-  uint32_t* erec = s_pix_dyn + DDA_WAVES * N * 64 + wave * 2 * N * 64;
+  // The records of the edges {k, k + 1} (upper end first) go to global memory, [frame][edge][drop]: a wave stores 512 bytes
+  // per edge in one piece, a cursor loads its next record an edge (~30 rows) ahead.  (In LDS, 12 bytes per vertex and lane,
+  // they left room for 10 waves per CU instead of 24: 7.8 ms against the 3.7 of round 5's kernel, whose row loop waits on
+  // dependent vector instructions more than it issues -- r06 A/B log.)
+  uint2* erec = sc.fov_erec + (int64_t)f * N * max_drops + i;
   const bool cvr = cv_rule && on_map;                          // (a vertex off the map: the span rule, like the oracle)
   if (mine) {
     for (int k = 0; k < N; k++) {
@@ -918,15 +922,14 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
       const bool swp = y1 < y0;
       uint32_t w0, w1;
       dda_edge_record(swp ? x1 : x0, swp ? y1 : y0, swp ? x0 : x1, swp ? y0 : y1, cvr, w0, w1);
-      erec[(2 * k) * 64 + lane] = w0;
-      erec[(2 * k + 1) * 64 + lane] = w1;
+      erec[(int64_t)k * max_drops] = make_uint2(w0, w1);
     }
   }
-  wave_lds_sync();
   auto vertex = [&](int kk) { return pix[kk * 64 + lane]; };
   auto rec = [&](int kk, uint32_t& w0, uint32_t& w1) {
-    w0 = erec[(2 * kk) * 64 + lane];
-    w1 = erec[(2 * kk + 1) * 64 + lane];
+    const uint2 v = erec[(int64_t)kk * max_drops];
+    w0 = v.x;
+    w1 = v.y;
   };
   DdaCursors<decltype(vertex), decltype(rec)> cur;
   if (mine) cur.init(vertex, rec, N, ktop);
@@ -4742,6 +4745,7 @@ struct rr_ctx {
   int64_t* d_tex_qoff = nullptr;
   bool tile_rows = true;             // RR_OPT_TILE_ROWS: rotate + INTER_AREA tiles by row walks, a wave per tile (k_tile_rows)
   int n_cu = 256;                    // compute units of the device (persistent kernels size their grid by it)
+  int erec_nfov = 0;                 // n_fov the edge-record scratch was sized for
   int rows_shares = 2;               // RR_OPT_ROWS_SHARES: shares of the tile list per workgroup of k_tile_rows
   bool png_deflate = false;          // RR_OPT_PNG_DEFLATE: the PNG outputs hold zlib streams (rr_deflate.h)
   uint8_t* d_pngz_slots = nullptr;
@@ -4980,7 +4984,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
   const bool grow_drops = max_drops > ctx->cap_drops;
   const bool dims_change = dm.H != ctx->cap_dims.H || dm.W != ctx->cap_dims.W || dm.He != ctx->cap_dims.He || dm.We != ctx->cap_dims.We;
   const bool general = !fov_fast_path(ctx, dm);
-  if (grow_frames || grow_drops || dims_change || (need_comp_out && !ctx->d_comp_out) || general != ctx->scratch_general) {
+  if (grow_frames || grow_drops || dims_change || (need_comp_out && !ctx->d_comp_out) || general != ctx->scratch_general || ctx->cam.n_fov > ctx->erec_nfov) {
     HIPCHK(hipDeviceSynchronize());
     const int F = grow_frames ? n : ctx->cap_frames;
     const int D = grow_drops ? max_drops : ctx->cap_drops;
@@ -5003,6 +5007,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.rows_bounds, (size_t)RW_SHARE_MAX + 1))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_fbase, (size_t)F * RW_TEX_MAX))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.fov_erec, general ? 1 : fd * (size_t)(ctx->cam.n_fov > 0 ? ctx->cam.n_fov : RR_MAX_FOV)))) return rc;
+    ctx->erec_nfov = ctx->cam.n_fov;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list_n, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_gen, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_slow, fd))) return rc;
@@ -5249,10 +5255,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       if (dda) {
         HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, fs));
         {
-          // (12 bytes of LDS per vertex and lane: the vertex' pixel and the record of the edge that starts there)
-          const size_t lds = sizeof(uint32_t) * 3 * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
+          // (4 bytes of LDS per vertex and lane: the vertex' pixel)
+          const size_t lds = sizeof(uint32_t) * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
           if (!ctx->dda_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * 3 * DDA_WAVES * 64 * RR_MAX_FOV)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * DDA_WAVES * 64 * RR_MAX_FOV)));
             ctx->dda_attr = true;
           }
           hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 64 * DDA_WAVES - 1) / (64 * DDA_WAVES), n), dim3(64 * DDA_WAVES), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp,
@@ -5803,6 +5809,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.npts);
   hipFree(ctx->sc.sizes);
   hipFree(ctx->sc.list_rot);
+  hipFree(ctx->sc.fov_erec);
   hipFree(ctx->sc.rows_list);
   hipFree(ctx->sc.rows_sorted);
   hipFree(ctx->sc.rows_n);
