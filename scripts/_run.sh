@@ -1,4 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_properties.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -4
-timeout -k 10 600 python bench.py --steps 5 --warmup 2 --opt 21=0 --sweep "18=0" --sweep "18=1" > gpurun_out/r06m_sweep.out 2> gpurun_out/r06m_sweep.err; grep '^SWEEP' gpurun_out/r06m_sweep.err | cut -c1-420
-timeout -k 10 600 python bench.py --steps 5 --warmup 2 --sweep "18=0" --sweep "18=1" > gpurun_out/r06m_sweep2.out 2> gpurun_out/r06m_sweep2.err; grep '^SWEEP' gpurun_out/r06m_sweep2.err | cut -c1-300
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+timeout -k 10 900 python bench.py --no-cpu-baseline --no-prepass --no-traffic > gpurun_out/r06n_bench.json 2> gpurun_out/r06n_bench.err; echo "bench exit $?"; python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r06n_bench.json'))
+print(d['value'], d['ms_per_step'])
+print({k: (round(v.get('frames_per_s', 0)) if isinstance(v, dict) else v) for k, v in d.get('variants', {}).items()})
+print({k: round(v, 2) for k, v in d['kernels_ms_per_call'].items()})
+print({k: round(v, 2) for k, v in d.get('overlap', {}).get('kernels_ms_per_call_one_stream').items()})
+print(d.get('host_inclusive_frames_per_s'), d['config'].get('raw_tile_share'), d.get('driver_end_to_end'))
+PY
