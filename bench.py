@@ -552,7 +552,7 @@ def main():
                  1: ('k_tile_big', ['search+barriers', 'plan fields', 'pixel']),
                  2: ('k_blur_small', ['plan+weights+raw->LDS', 'row pass', 'column pass+store']),
                  3: ('k_blur_fused[_dma]', ['issue loads | dma: clear Y + wait for the loads + halo', 'barrier A (loads land)', 'row pass', 'barrier B', 'column pass+store', 'barrier C', 'dma: next loads issued']),
-                 5: ('k_tile_rows', ['pull + plan', 'column table', 'group set-up (clear, row terms, intervals)', 'row walks', 'vertical folds+store', 'texture switch (wait + stage)', 'COUNT walk iterations', 'COUNT passes']),
+                 5: ('k_tile_rows', ['pull + plan', 'column table', 'group set-up (clear, row terms, intervals)', 'row walks', 'vertical folds+store', 'texture switch (wait + stage)', 'COUNT walk iterations', 'Big tiles (bicubic warp, a lane per pixel)']),
                  4: ('k_composite32', ['background / depth loads', 'list piece: clist + bbox loads, ballots, list', 'barriers of the list piece', 'record batch arrives', 'entry loop',
                                        'barrier at the piece end', 'stores + tile reduction'])}
         calls = args.steps + args.warmup

@@ -423,9 +423,12 @@ enum {
                                      * chain, which then runs in front of the tile kernels on the caller's stream (measured slower);
                                      * 0: one in-order stream (r04).  Same results (with 1 and 2 a drop without a FOV polygon gets its
                                      * raw tile rendered for nothing: it is still not blended and keeps its status). */
-  RR_OPT_TILE_ROWS = 22,            /* tuning (r06): 1 (default) rotate + flip + INTER_AREA tiles (Medium / Small drops, generator.py:163-170)
+  RR_OPT_TILE_ROWS = 22,            /* tuning (r06): 1, 2 rotate + flip + INTER_AREA tiles (Medium / Small drops, generator.py:163-170)
                                      * are rendered by k_tile_rows -- the batch's tiles in one list bucketed by texture, a wave per tile,
-                                     * a lane per canvas row, horizontal folds in registers; 0: k_tile (a workgroup per tile).  Same bits. */
+                                     * a lane per canvas row, horizontal folds in registers; 0: k_tile (a workgroup per tile).  2 (default):
+                                     * the Big drops' bicubic warps (generator.py:126-132) ride in the same list, their zero-bordered texture
+                                     * resident in LDS, a lane per pixel; 1: those stay with k_tile_big (a thread per pixel of a frame's
+                                     * concatenated tiles, texels from global memory).  Same bits. */
   RR_OPT_ROWS_SHARES = 23,          /* tuning (r06): k_tile_rows' workgroups take the batch's tile list in shares of equal estimated cost off a
                                      * device-wide counter; this many shares per workgroup (1 .. 8, default 2): more shares even out the
                                      * workgroups, fewer leave less waiting at a share's end */

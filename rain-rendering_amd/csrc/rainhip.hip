@@ -252,7 +252,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t blur_bx, blur_by;         // LDS capacities (doubles) of the fused blur's two staging tiles (RR_OPT_BLUR_WORKGROUPS)
   // k_tile_rows (r06): the rotate + INTER_AREA tiles of the WHOLE batch in one list, bucketed by texture
   int32_t* rows_list;               // [frame][drops] frame-local indices of the drops k_tile_rows renders (k_lists)
-  int32_t* rows_n;                  // [frame] their number
+  int32_t* rows_n;                  // [frame][2] their number: rotate + INTER_AREA tiles, Big tiles
   int32_t* rows_hist;               // [RW_TEX_MAX] tiles per texture, batch-wide (zeroed per call)
   unsigned long long* rows_cost;    // [RW_TEX_MAX] their estimated cost (behind rows_hist: one memset)
   int32_t* rows_next;               // [1] the next share of the list (behind rows_cost: the same memset)
@@ -262,6 +262,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   const uint8_t* tex_pair;          // pair textures (k_pair_textures) and their offsets (multiples of 16)
   const int64_t* tex_qoff;
   int32_t rows_on, n_tex;           // RR_OPT_TILE_ROWS and a database of at most RW_TEX_MAX textures
+  int32_t big_on, n_buckets;        // Big (bicubic) tiles ride in the same list, buckets n_tex .. 2 n_tex - 1 (2 n_tex <= RW_TEX_MAX)
 };
 
 // ---------------------------------------------------------------------------
@@ -1629,6 +1630,10 @@ __device__ inline bool tile_is_rows(const DropPlan& p, int sh, int sw) {
   return p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.nW <= RW_NW && p.tw <= 64 && p.tw >= 1 && p.th >= 1 && p.th <= 64 &&
          pair_bytes(sh, sw) <= RW_PAIR_BYTES && tile_coords_safe(p);
 }
+// Big (bicubic warp) tiles k_tile_rows takes: the padded texture (2-texel zero border, k_pad_textures) in the LDS region of the pair texture
+__device__ inline bool tile_is_big_lds(const DropPlan& p, int sh, int sw) {
+  return p.kind == KIND_BIG && (int64_t)(sh + 4) * (sw + 4) + 48 <= RW_PAIR_BYTES && p.tw >= 1 && p.th >= 1 && (int64_t)p.tw * p.th < (1 << 22) && p.bw0 >= 1;
+}
 __global__ __launch_bounds__(256) void k_pair_textures(const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w,
                                                        const int64_t* tex_off, const int64_t* tex_qoff, uint8_t* pairs) {
   const int i = blockIdx.x, sh = tex_h[i], sw = tex_w[i], P = pair_pitch(sw);
@@ -1855,9 +1860,10 @@ __global__ __launch_bounds__(256) void k_tile_big(const FrameDesc* frames, int m
   const int f = blockIdx.y, t = threadIdx.x;
   __shared__ double s_lut[256];
   __shared__ float s_ctab[128];
+  const int n_big = sc.counts[f * 8 + 5], total = sc.counts[f * 8 + 6];
+  if (total == 0) return;                           // (r06: with k_tile_rows taking the Big tiles whose texture fits its LDS, nearly every frame)
   s_lut[t] = (double)t / 255.0;
   if (t < 128) s_ctab[t] = ctab[t];
-  const int n_big = sc.counts[f * 8 + 5], total = sc.counts[f * 8 + 6];
   const int32_t* lbig = sc.list_big + (int64_t)f * max_drops;
   const int32_t* boff = sc.big_off + (int64_t)f * max_drops + f;
   const int lane = t & 63;
@@ -2148,7 +2154,7 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
 __global__ __launch_bounds__(1024) void k_rows_shares(int n_shares, Scratch sc) {
   __shared__ int64_t cum_cost[RW_TEX_MAX + 1];
   __shared__ int32_t cum_cnt[RW_TEX_MAX + 1];
-  const int t = threadIdx.x, lane = t & 63, n_tex = sc.n_tex;
+  const int t = threadIdx.x, lane = t & 63, n_tex = sc.n_buckets;      // (buckets: textures, twice over when Big tiles ride along)
   if (t < 64) {
     const int per = (n_tex + 63) >> 6;
     int64_t c_cost = 0;
@@ -2213,7 +2219,9 @@ template <int B>
 __device__ inline uint32_t byte_x8(uint32_t v, uint32_t three) {
   uint32_t r;
   if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(v));
-  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(v));
+  else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(v));
+  else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(v));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(v));
   return r;
 }
 __device__ inline int med3i(int x, int lo, int hi) {      // clamp(x, lo, hi), lo <= hi
@@ -2345,7 +2353,6 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, RowsShared& 
       left -= 2;
       PH_COUNT(6)
     }
-    PH_COUNT(7)
     if (any_col && out < lane_end) *out = b;          // the columns ended inside a cell
     PH(3)                                             // the walk
     wave_lds_sync();
@@ -2386,7 +2393,102 @@ __device__ inline void rows_tile(const DropPlan& p, int sh, int sw, RowsShared& 
   }
 }
 
-__global__ __launch_bounds__(1024) void k_tile_rows(int n_shares, const int32_t* tex_h, const int32_t* tex_w, Scratch sc) {
+// ---- Big drops in the same kernel: cv2.warpPerspective(INTER_CUBIC) (warp_big_pixel), a wave per tile, a lane per pixel ----
+// The bucket's texture is resident with its 2-texel zero border (k_pad_textures' copy, pitch sw + 4) behind 16 zero bytes
+// at S.pair: a row's four taps are the 4 bytes at the column clamped to [-4, sw] and the row clamped to [-2, sh + 1] --
+// whatever falls outside the texture is a zero of the border (or of the neighbouring row's border: the rows are
+// contiguous), which is what the reference's BORDER_CONSTANT taps are.  They are fetched as the two ALIGNED dwords around
+// them and a v_alignbit: an unaligned ds_read_b32 is legal on gfx950 and three times slower (measured: the Big tiles of
+// 512 frames 3.0 ms with it, 1.6 ms with the aligned pair; the table look-ups are 0.7 ms of that, the texel reads 0.3).  The 16 products are those of
+// warp_big_pixel; they are summed row by row for interior windows and tap by tap for windows over the border, as there.
+// The plan is wave-uniform (scalar registers): no search for a pixel's tile, no per-lane plan loads, no divisions by tw
+// beyond a float multiply with an exact fix-up (k_tile_big: one thread per pixel of the frame's concatenated tiles).
+constexpr int BIG_LDS_LEAD = 16;      // zero bytes in front of the padded texture
+#ifndef RR_BIG_NP
+#define RR_BIG_NP 1
+#endif
+__device__ inline int div_by_f(int n, int d, float inv_d) {      // n / d for 0 <= n < 2^24, d >= 1
+  int q = (int)((float)n * inv_d);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+__device__ inline void big_row_products(uint32_t u, float cyi, const float cx[4], uint32_t three, double pr[4]) {
+  const double v0 = *(lds_cdouble)(uintptr_t)byte_x8<0>(u, three), v1 = *(lds_cdouble)(uintptr_t)byte_x8<1>(u, three);
+  const double v2 = *(lds_cdouble)(uintptr_t)byte_x8<2>(u, three), v3 = *(lds_cdouble)(uintptr_t)byte_x8<3>(u, three);
+  const float w0 = cyi * cx[0], w1 = cyi * cx[1], w2 = cyi * cx[2], w3 = cyi * cx[3];
+  pr[0] = v0 * (double)w0;
+  pr[1] = v1 * (double)w1;
+  pr[2] = v2 * (double)w2;
+  pr[3] = v3 * (double)w3;
+}
+template <int NP>                    // pixels per lane and pass: their dependent chains (division, LDS round trips, 16-term sums) interleave
+__device__ inline void big_tile(const DropPlan& p, int sh, int sw, const uint8_t* s_pad, const float* s_ctab, double* arena, uint32_t three PH_PARAMS) {
+  const int lane = threadIdx.x & 63;
+  const int tw = p.tw, n = tw * p.th, bw0 = p.bw0, P = sw + 4;
+  const float inv_bw = 1.0f / (float)bw0;
+  const uint8_t* tex00 = s_pad + BIG_LDS_LEAD + 2 * P + 2;      // texel (0, 0)
+  double* A0 = arena + p.a0_off;
+  const int width1 = imax(sw - 3, 0), height1 = imax(sh - 3, 0);
+  // pixel it = it0 + 64 k + lane of the tile, row-major: (y, x) of the first one by a division, the following ones (64 apart)
+  // incrementally.  Lanes past the tile's end run on (rows >= th: any coordinates clamp into the resident texture) and store nothing.
+  const int dq = 64 / tw, dr = 64 - dq * tw;
+  int y = div_by_f(lane, tw, 1.0f / (float)tw), x = lane - y * tw;
+  for (int it0 = 0; it0 < n; it0 += 64 * NP) {
+    BigCoord c[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const int bx = tw <= bw0 ? 0 : div_by_f(x, bw0, inv_bw) * bw0;
+      c[k] = warp_big_coord(p, bx, x, y);
+      x += dr;
+      y += dq;
+      if (x >= tw) { x -= tw; y += 1; }
+    }
+    uint32_t u[NP][4];
+    float cx[NP][4], cy[NP][4];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const uint8_t* col = tex00 + med3i(c[k].sx, -4, sw);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {                   // the two aligned dwords around the window, shifted into place
+        const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)(col + med3i(c[k].sy + i, -2, sh + 1) * P);
+        const uint32_t* q = (const uint32_t*)(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(a & ~3u);
+        const uint32_t lo = q[0], hi = q[1];
+        u[k][i] = __builtin_amdgcn_alignbit(hi, lo, (a & 3u) * 8u);
+      }
+      const float4 a = *reinterpret_cast<const float4*>(s_ctab + c[k].fx * 4), b = *reinterpret_cast<const float4*>(s_ctab + c[k].fy * 4);
+      cx[k][0] = a.x; cx[k][1] = a.y; cx[k][2] = a.z; cx[k][3] = a.w;
+      cy[k][0] = b.x; cy[k][1] = b.y; cy[k][2] = b.z; cy[k][3] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      double pr[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) big_row_products(u[k][i], cy[k][i], cx[k], three, pr[i]);
+      const bool interior = c[k].sx >= 0 && c[k].sx < width1 && c[k].sy >= 0 && c[k].sy < height1;
+      double sum = 0.0;
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          double r = (pr[i][0] + pr[i][1]) + pr[i][2];
+          r = r + pr[i][3];
+          sum = (i == 0) ? r : sum + r;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) sum = sum + pr[i][j];
+      }
+      const int it = it0 + 64 * k + lane;
+      if (it < n) A0[it] = clip01(sum);
+    }
+  }
+  PH(7)                                               // a Big tile
+}
+
+__global__ __launch_bounds__(1024) void k_tile_rows(int n_shares, const int32_t* tex_h, const int32_t* tex_w, const float* ctab, Scratch sc) {
   __shared__ __attribute__((aligned(16))) RowsShared S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)S.lut != 0u) __builtin_trap();   // (see RowsShared)
@@ -2412,6 +2514,7 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int n_shares, const int32_t*
     if (!S.first) break;                         // no share left
     const int end = S.end;
     int pending = -1, ptex = -1, gi = 0;         // pending: index of the pulled tile in the list; DONE: the share is used up
+    bool ctab_ok = false;
     for (;;) {
       if (pending < 0) {
         int i = 0;
@@ -2420,7 +2523,8 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int n_shares, const int32_t*
         if (i < end) {
           pending = i;
           gi = __builtin_amdgcn_readfirstlane(sc.rows_sorted[i]);
-          ptex = __builtin_amdgcn_readfirstlane(as_constant(&sc.plan[gi])->tex);
+          ptex = __builtin_amdgcn_readfirstlane(as_constant(&sc.plan[gi])->tex);      // the tile's bucket: its texture, + n_tex for a Big tile
+          if (__builtin_amdgcn_readfirstlane(as_constant(&sc.plan[gi])->kind) == KIND_BIG) ptex += sc.n_tex;
         } else {
           pending = DONE;
         }
@@ -2434,7 +2538,20 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int n_shares, const int32_t*
           for (int k = 0; k < (int)(sizeof(DropPlan) / 4); k++) dst[k] = src[k];
         }
         PH(0)                                     // pull + plan
-        rows_tile(p, tex_h[ptex], tex_w[ptex], S, W, sc.arena, three PH_PASS);
+        if (ptex < sc.n_tex) {
+          rows_tile(p, tex_h[ptex], tex_w[ptex], S, W, sc.arena, three PH_PASS);
+          ctab_ok = false;
+        } else {
+          float* s_ctab = reinterpret_cast<float*>(W.buf);      // the bicubic weights, wave-private (W is otherwise idle in a Big tile)
+          if (!ctab_ok) {
+            wave_lds_sync();
+            s_ctab[lane] = ctab[lane];
+            s_ctab[lane + 64] = ctab[lane + 64];
+            wave_lds_sync();
+            ctab_ok = true;
+          }
+          big_tile<RR_BIG_NP>(p, tex_h[ptex - sc.n_tex], tex_w[ptex - sc.n_tex], S.pair, s_ctab, sc.arena, three PH_PASS);
+        }
         pending = -1;
         continue;
       }
@@ -2445,11 +2562,18 @@ __global__ __launch_bounds__(1024) void k_tile_rows(int n_shares, const int32_t*
       for (int k = 0; k < RW_WAVES; k++)
         if (S.pend[k] < m) { m = S.pend[k]; mtex = S.ptex[k]; }
       if (m == DONE) break;                       // every wave is out of tiles
-      {
+      if (mtex < sc.n_tex) {
         const int64_t nb = pair_bytes(tex_h[mtex], tex_w[mtex]);
         const uint4* g = reinterpret_cast<const uint4*>(sc.tex_pair + sc.tex_qoff[mtex]);
         uint4* d = reinterpret_cast<uint4*>(S.pair);
         for (int k = t; k < (int)(nb >> 4); k += 1024) d[k] = g[k];
+      } else {                                    // a Big bucket: 16 zero bytes, then the texture with its zero border (+ 2 bytes: a window's
+        const int bt = mtex - sc.n_tex;           //  last row may be read two bytes past it -- zeros of the padded copy's slack or of the next copy's border)
+        const int n16 = ((tex_h[bt] + 4) * (tex_w[bt] + 4) + 2 + 15) >> 4;
+        const uint4* g = reinterpret_cast<const uint4*>(sc.tex_pad + sc.tex_poff[bt]);
+        uint4* d = reinterpret_cast<uint4*>(S.pair);
+        if (t == 0) d[0] = uint4{0u, 0u, 0u, 0u};
+        for (int k = t; k < n16; k += 1024) d[k + 1] = g[k];
       }
       if (t == 0) S.cur = mtex;
       __syncthreads();
@@ -2477,17 +2601,23 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   const int64_t base = (int64_t)f * max_drops;
   __shared__ int s_hist[RW_TEX_MAX], s_cost[RW_TEX_MAX];
   if (sc.rows_on) {
-    for (int k = t; k < sc.n_tex; k += 1024) s_hist[k] = s_cost[k] = 0;
+    for (int k = t; k < sc.n_buckets; k += 1024) s_hist[k] = s_cost[k] = 0;
     __syncthreads();
   }
   // #rot-fast (general), #generic, #fused blur items, #slow blur, #small blur, #rot-fast (integer ratio), #big, big pixels, #row-walk tiles
-  constexpr int NC = 9;
-  int c[NC] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int NC = 10;             // (+ Big tiles that ride in the row-walk list)
+  int c[NC] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = i0; i < i1; i++) {
     const DropPlan& p = sc.plan[base + i];
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {         // duplicates of another drop's raw tile render nothing
-      if (p.kind == KIND_BIG) { c[6]++; c[7] += p.tw * p.th; }
+      if (p.kind == KIND_BIG) {
+        if (sc.big_on && tile_is_big_lds(p, tex_h[p.tex], tex_w[p.tex])) {
+          c[9]++;
+          atomicAdd(&s_hist[sc.n_tex + p.tex], 1);
+          atomicAdd(&s_cost[sc.n_tex + p.tex], (p.tw * p.th + 63) / 64 + 4);
+        } else { c[6]++; c[7] += p.tw * p.th; }
+      }
       else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) {
         c[8]++;
         atomicAdd(&s_hist[p.tex], 1);
@@ -2505,7 +2635,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   for (int k = 0; k < NC; k++) sh[t][k] = c[k];
   __syncthreads();
   for (int ofs = 1; ofs < 1024; ofs <<= 1) {
-    int v[NC] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int v[NC] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (t >= ofs)
       for (int k = 0; k < NC; k++) v[k] = sh[t - ofs][k];
     __syncthreads();
@@ -2515,6 +2645,7 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   int o[NC];
   for (int k = 0; k < NC; k++) o[k] = (t == 0) ? 0 : sh[t - 1][k];
   const int n_int = sh[1023][5];     // integer-ratio drops go to the FRONT of the rot list (longest blocks first)
+  const int n_rot_rows = sh[1023][8];
   o[0] += n_int;
   __shared__ int s_rot_base;
   if (t == 0) s_rot_base = atomicAdd(sc.rot_total, sh[1023][0] + sh[1023][5]);      // the frame's piece of the batch-wide list (any order of the frames)
@@ -2532,9 +2663,12 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {
       if (p.kind == KIND_BIG) {
-        boff[o[6]] = o[7];
-        lbig[o[6]++] = i;
-        o[7] += p.tw * p.th;
+        if (sc.big_on && tile_is_big_lds(p, tex_h[p.tex], tex_w[p.tex])) lrows[n_rot_rows + o[9]++] = i;      // (behind the frame's rotate tiles)
+        else {
+          boff[o[6]] = o[7];
+          lbig[o[6]++] = i;
+          o[7] += p.tw * p.th;
+        }
       } else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) lrows[o[8]++] = i;
       else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = (int32_t)(base + i); else lrot[o[0]++] = (int32_t)(base + i); } else lgen[o[1]++] = i;
     }
@@ -2560,10 +2694,11 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
     sc.counts[f * 8 + 5] = sh[1023][6];
     sc.counts[f * 8 + 6] = sh[1023][7];
     boff[sh[1023][6]] = sh[1023][7];
-    sc.rows_n[f] = sh[1023][8];
+    sc.rows_n[2 * f] = sh[1023][8];
+    sc.rows_n[2 * f + 1] = sh[1023][9];
   }
   if (sc.rows_on) {                  // the frame's place inside the batch-wide buckets (any order of the frames will do)
-    for (int k = t; k < sc.n_tex; k += 1024) {
+    for (int k = t; k < sc.n_buckets; k += 1024) {
       const int cnt = s_hist[k];
       sc.rows_fbase[(int64_t)f * RW_TEX_MAX + k] = cnt ? atomicAdd(&sc.rows_hist[k], cnt) : 0;
       if (cnt) atomicAdd(&sc.rows_cost[k], (unsigned long long)s_cost[k]);
@@ -2576,9 +2711,9 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
 __global__ __launch_bounds__(1024) void k_rows_scatter(int max_drops, Scratch sc) {
   const int f = blockIdx.x, t = threadIdx.x;
   __shared__ int s_start[RW_TEX_MAX], s_rank[RW_TEX_MAX];
-  const int nf = sc.rows_n[f];
+  const int nf = sc.rows_n[2 * f] + sc.rows_n[2 * f + 1];
   if (nf == 0) return;
-  const int own = t < sc.n_tex ? sc.rows_hist[t] : 0;
+  const int own = t < sc.n_buckets ? sc.rows_hist[t] : 0;
   s_start[t] = own;
   __syncthreads();
   for (int ofs = 1; ofs < 1024; ofs <<= 1) {
@@ -2590,12 +2725,13 @@ __global__ __launch_bounds__(1024) void k_rows_scatter(int max_drops, Scratch sc
   const int excl = s_start[t] - own;
   __syncthreads();
   s_start[t] = excl;
-  s_rank[t] = t < sc.n_tex ? sc.rows_fbase[(int64_t)f * RW_TEX_MAX + t] : 0;
+  s_rank[t] = t < sc.n_buckets ? sc.rows_fbase[(int64_t)f * RW_TEX_MAX + t] : 0;
   __syncthreads();
   const int64_t base = (int64_t)f * max_drops;
   for (int j = t; j < nf; j += 1024) {
     const int i = sc.rows_list[base + j];
-    const int tex = sc.plan[base + i].tex;
+    const DropPlan& p = sc.plan[base + i];
+    const int tex = p.tex + (p.kind == KIND_BIG ? sc.n_tex : 0);      // the bucket
     const int pos = s_start[tex] + atomicAdd(&s_rank[tex], 1);
     sc.rows_sorted[pos] = (int32_t)(base + i);
   }
@@ -4743,7 +4879,7 @@ struct rr_ctx {
   bool padded_tex = true;            // RR_OPT_PADDED_TEXTURES
   uint8_t* d_tex_pair = nullptr;     // pair textures (k_pair_textures) + their offsets: what k_tile_rows stages
   int64_t* d_tex_qoff = nullptr;
-  bool tile_rows = true;             // RR_OPT_TILE_ROWS: rotate + INTER_AREA tiles by row walks, a wave per tile (k_tile_rows)
+  int tile_rows = 2;                 // RR_OPT_TILE_ROWS: rotate + INTER_AREA tiles by row walks, a wave per tile (k_tile_rows); 2: the Big (bicubic) tiles as well
   int n_cu = 256;                    // compute units of the device (persistent kernels size their grid by it)
   int erec_nfov = 0;                 // n_fov the edge-record scratch was sized for
   int rows_shares = 2;               // RR_OPT_ROWS_SHARES: shares of the tile list per workgroup of k_tile_rows
@@ -4999,7 +5135,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.list_rot, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_list, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_sorted, fd))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->sc.rows_n, (size_t)F))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.rows_n, (size_t)F * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.rows_hist, (size_t)RW_TEX_MAX * 3 + 16))) return rc;      // + RW_TEX_MAX 8-byte cost sums + the share counter
     ctx->sc.rows_cost = reinterpret_cast<unsigned long long*>(ctx->sc.rows_hist + RW_TEX_MAX);
     ctx->sc.rows_next = ctx->sc.rows_hist + 3 * RW_TEX_MAX;
@@ -5186,6 +5322,8 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
   sc.tex_qoff = ctx->d_tex_qoff;
   sc.n_tex = ctx->n_tex;
   sc.rows_on = (ctx->tile_rows && ctx->d_tex_pair && ctx->n_tex <= RW_TEX_MAX) ? 1 : 0;
+  sc.big_on = (sc.rows_on && ctx->tile_rows >= 2 && ctx->padded_tex && ctx->d_tex_pad && 2 * ctx->n_tex <= RW_TEX_MAX) ? 1 : 0;
+  sc.n_buckets = sc.big_on ? 2 * ctx->n_tex : ctx->n_tex;
   // k_tile_rows: one workgroup of 16 waves per CU (the LDS holds one texture + 16 wave-private tables); fewer for small batches
   const int rows_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ctx->n_cu, RW_SHARE_MAX / ctx->rows_shares), ((int64_t)n * max_drops + 31) / 32));
   const int blur_wg = ctx->blur_wg ? ctx->blur_wg : 4;      // workgroups per CU the fused blur is sized for
@@ -5382,14 +5520,14 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_tile_big");
-      hipLaunchKernelGGL(k_tile_big, dim3(1024, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+      hipLaunchKernelGGL(k_tile_big, dim3(sc.big_on ? imax(4, imin(1024, 4096 / n)) : 1024, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
                          ctx->d_tex_off, ctx->d_ctab, sc);
     }
     if (sc.rows_on) {
       ProfScope ps(ctx, s, "k_tile_rows");
       // one workgroup of 16 waves per CU (the LDS holds one texture + 16 wave-private tables); fewer for small batches:
       // a workgroup's share of the list should be worth staging a texture for
-      hipLaunchKernelGGL(k_tile_rows, dim3(rows_wgs), dim3(64 * RW_WAVES), 0, s, rows_wgs * ctx->rows_shares, ctx->d_tex_h, ctx->d_tex_w, sc);
+      hipLaunchKernelGGL(k_tile_rows, dim3(rows_wgs), dim3(64 * RW_WAVES), 0, s, rows_wgs * ctx->rows_shares, ctx->d_tex_h, ctx->d_tex_w, ctx->d_ctab, sc);
     }
     {
       ProfScope ps(ctx, s, "k_tile");
@@ -6906,7 +7044,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_F64: ctx->composite_f64 = value != 0; return RR_OK;
     case RR_OPT_COPY_KERNELS: ctx->copy_kernels = value != 0; return RR_OK;
     case RR_OPT_PADDED_TEXTURES: ctx->padded_tex = value != 0; return RR_OK;
-    case RR_OPT_TILE_ROWS: ctx->tile_rows = value != 0; return RR_OK;
+    case RR_OPT_TILE_ROWS: ctx->tile_rows = value < 0 ? 0 : (value > 2 ? 2 : value); return RR_OK;
     case RR_OPT_ROWS_SHARES: ctx->rows_shares = value < 1 ? 1 : (value > 8 ? 8 : value); return RR_OK;
     case RR_OPT_FOV_FILL_RULE: ctx->fill_rule = value == 1 ? 1 : 0; return RR_OK;
     case RR_OPT_BIN_ROWS: ctx->bin_rows = value != 0; return RR_OK;
@@ -6953,8 +7091,11 @@ int rr_batch_counts(rr_ctx* ctx, int32_t frame, int32_t out[8]) {
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, ctx->sc.counts + (size_t)frame * 8, sizeof(int32_t) * 8, hipMemcpyDeviceToHost));
   int32_t rows = 0;                    // the row-walk kernel's share of the rotate + resize tiles (k_lists writes it with or without the option)
-  HIPCHK(hipMemcpy(&rows, ctx->sc.rows_n + frame, sizeof(int32_t), hipMemcpyDeviceToHost));
+  int32_t rows2[2] = {0, 0};
+  HIPCHK(hipMemcpy(rows2, ctx->sc.rows_n + 2 * (size_t)frame, sizeof(int32_t) * 2, hipMemcpyDeviceToHost));
+  rows = rows2[0];
   out[0] += rows;
+  out[5] += rows2[1];                  // Big tiles rendered by k_tile_rows
   return RR_OK;
 }
 

@@ -214,11 +214,14 @@ struct TexLutPad {
 // ---------------------------------------------------------------------------
 // Big drops: cv2.warpPerspective(INTER_CUBIC)  (generator.py:126-132)
 // ---------------------------------------------------------------------------
-template <class Tex>
-RR_HD double warp_big_pixel(const DropPlan& p, const Tex& tx, const float* ctab, int x, int y) {
+// source coordinates of output pixel (x, y): top-left tap (sx, sy) of the 4x4 bicubic window and the 1/32 fractions.
+// bx: the first column of the pixel's block, (x / bw0) * bw0 (WarpPerspectiveInvoker walks blocks of bw0 columns and
+// forms X0, Y0, W0 at a block's first column)
+struct BigCoord {
+  int sx, sy, fx, fy;
+};
+RR_HD BigCoord warp_big_coord(const DropPlan& p, int bx, int x, int y) {
   const double* Mi = p.mi;
-  const int sh = tx.h, sw = tx.w;
-  int bx = (x / p.bw0) * p.bw0;
   double x1 = (double)(x - bx);
   double bxf = (double)bx, yf = (double)y;
   double X0 = Mi[0] * bxf + Mi[1] * yf + Mi[2];
@@ -228,9 +231,18 @@ RR_HD double warp_big_pixel(const DropPlan& p, const Tex& tx, const float* ctab,
   W = (W != 0.0) ? 32.0 / W : 0.0;
   double fX = dmax(-2147483648.0, dmin(2147483647.0, (X0 + Mi[0] * x1) * W));
   double fY = dmax(-2147483648.0, dmin(2147483647.0, (Y0 + Mi[3] * x1) * W));
-  int64_t X = cv_round(fX), Y = cv_round(fY);
-  int64_t sx = sat_short(X >> 5) - 1, sy = sat_short(Y >> 5) - 1;
-  int fx = (int)(X & 31), fy = (int)(Y & 31);
+  // (fX, fY are inside [-2^31, 2^31 - 1] and never NaN -- dmin / dmax return their first argument for one -- so cv_round's
+  //  saturate_cast<int> is the rounding alone and fits an int: no 64-bit conversion on the device)
+  const int X = (int)rint(fX), Y = (int)rint(fY);
+  const int qx = X >> 5, qy = Y >> 5;
+  return BigCoord{(qx < -32768 ? -32768 : (qx > 32767 ? 32767 : qx)) - 1, (qy < -32768 ? -32768 : (qy > 32767 ? 32767 : qy)) - 1, X & 31, Y & 31};
+}
+template <class Tex>
+RR_HD double warp_big_pixel(const DropPlan& p, const Tex& tx, const float* ctab, int x, int y) {
+  const int sh = tx.h, sw = tx.w;
+  const BigCoord c = warp_big_coord(p, (x / p.bw0) * p.bw0, x, y);
+  const int64_t sx = c.sx, sy = c.sy;
+  const int fx = c.fx, fy = c.fy;
   const float* cx = ctab + fx * 4;
   const float* cy = ctab + fy * 4;
   int width1 = imax(sw - 3, 0), height1 = imax(sh - 3, 0);
