@@ -406,7 +406,8 @@ enum {
   RR_OPT_BLUR_DMA = 17,             /* tuning (r05): 1 (default) the fused defocus blur stages its raw sub-tiles and weight tables with
                                      * gfx950 LDS-DMA loads (global_load_lds: no registers in between), issued a sub-tile AHEAD: they land
                                      * while the current sub-tile's column pass runs; 0: the r04 kernel (loads through registers at the
-                                     * start of every sub-tile).  Same results. */
+                                     * start of every sub-tile) -- since r06 only in -DRR_EXPERIMENTS builds of the library, RR_E_ARG
+                                     * otherwise.  Same results. */
   RR_OPT_FOV_FILL_RULE = 18,        /* which restatement of cv2.fillConvexPoly (bad_weather.py:388) decides the texels of a drop's field of
                                      * view: 0 (default) the row-span rule of the fast colour kernels (nearest x of every edge on the
                                      * row, min / max); 1 OpenCV 3.2's own algorithm -- Bresenham outline + 16.16 edge walkers, in closed
@@ -419,10 +420,11 @@ enum {
                                      * tests every drop (r04).  Same lists. */
   RR_OPT_COLOUR_STREAM = 21,        /* tuning (r05): two chains of the step that only meet in k_colour run on two streams of the library.
                                      * 1 (default): the FOV chain (polygons, spans, sums over the environment map) on the second stream
-                                     * beside plan .. tiles .. blur; 2: plan .. lists and k_colour on the second stream beside the FOV
-                                     * chain, which then runs in front of the tile kernels on the caller's stream (measured slower);
-                                     * 0: one in-order stream (r04).  Same results (with 1 and 2 a drop without a FOV polygon gets its
-                                     * raw tile rendered for nothing: it is still not blended and keeps its status). */
+                                     * beside plan .. tiles .. blur; 0: one in-order stream (r04).  (2 was the other split -- plan .. lists
+                                     * and k_colour on the second stream -- measured slower in r05 and removed in r06: it runs as 1.)
+                                     * Same results (with 1 a drop without a FOV polygon gets its raw tile rendered for nothing -- it is
+                                     * still not blended and keeps its status -- and such tiles take arena space: the arena grows to the
+                                     * batches' own demand, RR_E_ARENA, so this only shows as a slightly larger arena). */
   RR_OPT_TILE_ROWS = 22,            /* tuning (r06): 1, 2 rotate + flip + INTER_AREA tiles (Medium / Small drops, generator.py:163-170)
                                      * are rendered by k_tile_rows -- the batch's tiles in one list bucketed by texture, a wave per tile,
                                      * a lane per canvas row, horizontal folds in registers; 0: k_tile (a workgroup per tile).  2 (default):
@@ -451,6 +453,10 @@ int rr_pipeline_wait(rr_ctx* ctx, int32_t slot);
 /* Page-locked host memory (hipHostMalloc) for the buffers of the host-pointer entry points.  A block belongs to its
  * context: rr_destroy releases whatever rr_host_free has not. */
 int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes);
+/* rr_host_alloc / rr_host_free may run on another thread than the context's calls, so their failures are not reported
+ * through rr_last_error(): this returns the message of the last failed rr_host_alloc ("" after a successful one); the
+ * pointer stays valid until the next rr_host_alloc on the context. */
+const char* rr_host_last_error(rr_ctx* ctx);
 int rr_host_free(rr_ctx* ctx, void* p);
 
 /* Work-list sizes of frame `frame` of the last batch (after completion): out[0] drops whose raw tile went

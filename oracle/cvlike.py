@@ -453,6 +453,20 @@ def polygon_to_int(pts):
     return np.trunc(np.asarray(pts, np.float64)).astype(np.int64)
 
 
+def polygon_all_collinear(poly_int):
+    """Clipper's AddPath (pyclipper.Pyclipper.AddPath, bad_weather.py:368) strips duplicate and collinear vertices of a
+    closed path and rejects it when fewer than three are left: a truncated polygon whose vertices all lie on one line (or
+    on one point) raises ClipperException and the drop is skipped like any other failure of add_drop_to_image
+    (generator.py:180-189).  rr_device.h poly_all_collinear."""
+    P = [(int(x), int(y)) for x, y in np.asarray(poly_int).reshape(-1, 2)]
+    x0, y0 = P[0]
+    a = next((q for q in P[1:] if q != (x0, y0)), None)
+    if a is None:
+        return True
+    ax, ay = a[0] - x0, a[1] - y0
+    return all(ax * (y - y0) - ay * (x - x0) == 0 for x, y in P)
+
+
 def _div_round_half_up(num, den):
     """round(num/den) to nearest, ties toward +inf, exact integer arithmetic, den>0."""
     return (2 * num + den) // (2 * den)

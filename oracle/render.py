@@ -602,6 +602,8 @@ def add_drop_to_image(env_map_xyY, solid_angle_map, fc, drop_fov_pts, drop_minC,
     if not np.all(np.isfinite(drop_fov_pts)):
         raise IndexError(ST_FOV_FAIL)                # Clipper range error on NaN coordinates
     poly_int = cvlike.polygon_to_int(drop_fov_pts)
+    if cvlike.polygon_all_collinear(poly_int):
+        raise IndexError(ST_FOV_FAIL)                # ClipperException: AddPath rejects a path without three non-collinear vertices
     d_avg = (drop.image_diameter_start + drop.image_diameter_end) / 2.
 
     drop_xyY = convert_rgb_to_xyY(tile[..., :3])

@@ -364,6 +364,7 @@ class Generator:
         folders_num = len(self.images)
         B = max(1, self.batch)
         for folder_idx, sequence in enumerate(self.sequences):
+            self._t_run0, self._marks = time.time(), []          # the set-up clock of THIS sequence (timing[...]['setup'])
             print('\nSequence: ' + sequence)
             depth_folder = self.depth[sequence]
             for sim_idx, sim_weather in enumerate(self.weather):
@@ -600,8 +601,11 @@ class Generator:
                     # or converted file that reached this route) must not be re-quantised silently
                     samples = np.rint(depth.astype(np.float64) * 256.0).astype(np.uint16)
                     if not np.array_equal(samples.astype(np.float32) / np.float32(256.0), depth.astype(np.float32)):
-                        raise ValueError("%s: depth values are not the samples of a 16-bit file / 256; run with RAIN_NATIVE_IO=0"
-                                         % items[k]['depth_file'])
+                        # one odd file must not end the run from the decode thread: the frame is skipped like a missing depth map
+                        print("Skipping %s: depth values are not the samples of a 16-bit file / 256 (run with RAIN_NATIVE_IO=0 to "
+                              "render such a sequence)" % items[k]['depth_file'])
+                        ok[k] = False
+                        continue
                 if rows_in:                                         # as scanlines of filter type 0
                     np.copyto(sl.bg[k], hip_backend.png_rows_of(bg))
                     np.copyto(sl.depth[k], hip_backend.png_rows_of(samples))

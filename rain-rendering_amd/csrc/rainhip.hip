@@ -625,7 +625,12 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     const int r = imin(imax((int)pyf, 0), dm.He - 1);
     const int r0 = __shfl(r, act ? base : lane);
     const bool spread = (__ballot(iabs(r - r0) >= 2) & gmask) != 0ull;       // some vertex two rows away from the first one
-    need64 = act && !ext && !certain_fail && ((gor & ~128u) != 0u || !bt32 || !bf32 || (!wrap32 && !spread));
+    // (a sliver: whether Clipper takes the path -- poly_all_collinear below -- is float64's to say)
+    const int tx = (int)pxf, ty = (int)pyf;
+    const int x0v = __shfl(tx, act ? base : lane), y0v = __shfl(ty, act ? base : lane);
+    const int xav = __shfl(tx, act ? base + N / 2 : lane), yav = __shfl(ty, act ? base + N / 2 : lane);
+    const bool sure_nc = (__ballot(poly_surely_not_collinear_step(xav - x0v, yav - y0v, tx - x0v, ty - y0v)) & gmask) != 0ull;
+    need64 = act && !ext && !certain_fail && ((gor & ~128u) != 0u || !bt32 || !bf32 || (!wrap32 && !spread) || !sure_nc);
     if (act && !ext && !need64) {
       ipx = (int)pxf;
       ipy = (int)pyf;
@@ -694,8 +699,26 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
     const unsigned long long bad_e = __ballot(!fine) & gmask;
     m = bad_e ? 0 : np;
   }
-  if (act && k == 0) sc.npts[gi] = m;
   wave_lds_sync();
+  {
+    // Clipper's AddPath rejects a path whose vertices are all collinear (rr_device.h poly_all_collinear): lane k of the
+    // group tests the vertices k, k + N, ... against the line through vertex 0 and any vertex that differs from it
+    const int* qx = s_px[wave][imin(g, FOV_GROUPS - 1)];
+    const int* qy = s_py[wave][imin(g, FOV_GROUPS - 1)];
+    const int x0v = m > 0 ? qx[0] : 0, y0v = m > 0 ? qy[0] : 0;
+    int vdif = -1;
+    for (int v = k; v < m; v += N)
+      if (vdif < 0 && (qx[v] != x0v || qy[v] != y0v)) vdif = v;
+    const unsigned long long bd = __ballot(vdif >= 0) & gmask;
+    const int va = __shfl(vdif, bd ? __ffsll((long long)bd) - 1 : lane);
+    bool nz = false;
+    if (bd) {
+      const int64_t ax = (int64_t)qx[va] - x0v, ay = (int64_t)qy[va] - y0v;
+      for (int v = k; v < m; v += N) nz = nz || (ax * ((int64_t)qy[v] - y0v) - ay * ((int64_t)qx[v] - x0v) != 0);
+    }
+    if ((__ballot(nz) & gmask) == 0ull) m = 0;                 // (also a group without a polygon)
+  }
+  if (act && k == 0) sc.npts[gi] = m;
   const int He = dm.He;
   int* xl = s_xl[wave];
   int* xr = s_xr[wave];
@@ -889,6 +912,16 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
       }
       if (dir != 0 && dir_first != 0 && dir != dir_first) turns++;        // around the closing point
     }
+  }
+  if (act) {                                                   // a sliver: whether Clipper takes the path (poly_all_collinear) is float64's to say
+    const uint32_t v0 = pix[lane], va = pix[(N / 2) * 64 + lane];
+    const int x0v = (int)(v0 & 0xffffu), y0v = (int)(v0 >> 16), ax = (int)(va & 0xffffu) - x0v, ay = (int)(va >> 16) - y0v;
+    bool sure_nc = false;
+    for (int k = 1; k < N; k++) {
+      const uint32_t v = pix[k * 64 + lane];
+      sure_nc = sure_nc || poly_surely_not_collinear_step(ax, ay, (int)(v & 0xffffu) - x0v, (int)(v >> 16) - y0v);
+    }
+    if (!sure_nc) uns |= 256;
   }
   // ---- classification (fov_polygon_auto) ----
   const bool certain_fail = (uns & 128) && !(uns & 3);         // a vertex without intersection: [] like the reference
@@ -2834,6 +2867,7 @@ __device__ inline void blur4(const double* c0, int st, W hw, int r, double& acc0
   }
 }
 
+#ifdef RR_EXPERIMENTS                // (r04's register-staged form: the LDS-DMA kernel below replaced it in r05; kept for A/B builds, RR_OPT_BLUR_DMA 0)
 // ---------------------------------------------------------------------------
 // fused defocus blur: both axes of the separable filter through LDS
 // ---------------------------------------------------------------------------
@@ -3004,6 +3038,8 @@ __global__ __launch_bounds__(256, WPE) void k_blur_fused(const FrameDesc* frames
   }
   PH_FLUSH(3)
 }
+
+#endif
 
 // ---------------------------------------------------------------------------
 // fused defocus blur, staged by LDS-DMA a sub-tile ahead (r05; the default)
@@ -4899,9 +4935,9 @@ struct rr_ctx {
   bool blur_dma = true;              // RR_OPT_BLUR_DMA
   int fov_dda = 1;                   // RR_OPT_FOV_DDA: a thread per drop for the polygons of the float colour branch (1: k_fov_dda, 2: k_fov_walk)
   int comp_waves = 0;                // RR_OPT_COMPOSITE_WAVES: waves per SIMD the float compositor's registers are held to (0: the kernel's own choice)
-  int colour_stream = 1;             // RR_OPT_COLOUR_STREAM: 0 one stream; 1 the FOV chain on a second stream; 2 plan .. lists + k_colour on it
+  int colour_stream = 1;             // RR_OPT_COLOUR_STREAM: 0 one stream; 1 the FOV chain on a second stream
   hipStream_t s_col = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lists = nullptr, ev_sums = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool comp_batch = true;            // RR_OPT_COMPOSITE_BATCH: list entries' records 64 at a time in vector registers, samples two entries ahead
   int n_tex = 0;
   float* d_ctab = nullptr;
@@ -4993,6 +5029,7 @@ struct rr_ctx {
   float* d_omega32 = nullptr;        // the same as floats (frames whose map is float: RR_IN_ENV_F32)
   int omega_He = 0, omega_We = 0;
   std::vector<std::pair<const char*, size_t>> host_allocs;   // rr_host_alloc blocks: pieces inside one block may be merged across padding
+  std::string host_err;              // rr_host_last_error (under host_mu)
   std::mutex host_mu;                // guards host_allocs: rr_host_alloc / rr_host_free may be called from another thread than the one that
                                      // submits batches (the driver page-locks the slots of later batches while the first one is decoded)
   bool composite_f64 = false;        // RR_OPT_COMPOSITE_F64: float64 colours in the compositor even when nobody asks for the composite
@@ -5351,18 +5388,16 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     //    that the tile / blur kernels have the device to themselves: 31.6 ms -- k_fov_dda (4.5 ms beside k_plan instead of 3.4)
     //    and k_fov_sums32 (3.8 beside k_dedup / k_lists instead of 2.6) lose what the tail gains (r05_ab_w.txt).
     // 0: one in-order stream (r04).
-    hipStream_t fs = s, bs = s;
+    hipStream_t fs = s;
+    const hipStream_t bs = s;                               // (r05's mode 2 had plan .. lists + k_colour on the second stream: slower, removed in r06)
     if (ctx->colour_stream) {
-      if (!ctx->s_col) {
-        HIPCHK(hipStreamCreateWithFlags(&ctx->s_col, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_lists, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_sums, hipEventDisableTiming));
-      }
+      // every handle on its own: one that could not be made is tried again by the next call instead of being used as null
+      if (!ctx->s_col) HIPCHK(hipStreamCreateWithFlags(&ctx->s_col, hipStreamNonBlocking));
+      if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      if (!ctx->ev_join) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
       HIPCHK(hipEventRecord(ctx->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(ctx->s_col, ctx->ev_fork, 0));
-      if (ctx->colour_stream == 1) fs = ctx->s_col; else bs = ctx->s_col;
+      fs = ctx->s_col;
     }
     // (whatever way this block is left -- an error return included -- the caller's stream waits for the second one: a
     // synchronisation of `s` then covers everything that was enqueued here)
@@ -5377,7 +5412,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         return e != hipSuccess ? e : hipStreamWaitEvent(s, c->ev_join, 0);
       }
       ~Join() { (void)now(); }
-    } join{ctx, s, ctx->s_col, fs != bs};
+    } join{ctx, s, ctx->s_col, fs != s};
     const int Hp = ctx->scratch_hp, Dp = (D + 1 + 7) & ~7;
     if (fast) {
       ProfScope ps(ctx, fs, "k_fov_spans");
@@ -5477,7 +5512,6 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         hipLaunchKernelGGL(k_fov_sums_general, dim3((max_drops + 3) / 4, n), dim3(256), 0, fs, ctx->d_frames, dm, D, sc, ctx->fill_rule, ctx->cam.n_fov);
       }
     }
-    if (bs != s) HIPCHK(hipEventRecord(ctx->ev_sums, s));     // (mode 2: k_colour, on the second stream, waits for the sums)
     {
       ProfScope ps(ctx, bs, "k_plan");
       hipLaunchKernelGGL(k_plan, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, dm, ctx->cam, ctx->d_tex_h,
@@ -5501,15 +5535,6 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         hipLaunchKernelGGL(k_rows_scatter, dim3(n), dim3(1024), 0, bs, D, sc);
         hipLaunchKernelGGL(k_rows_shares, dim3(1), dim3(1024), 0, bs, rows_wgs * ctx->rows_shares, sc);
       }
-    }
-    if (bs != s) {                                         // mode 2: k_colour beside the tile kernels; the tiles wait for the lists
-      HIPCHK(hipEventRecord(ctx->ev_lists, bs));
-      HIPCHK(hipStreamWaitEvent(bs, ctx->ev_sums, 0));
-      {
-        ProfScope ps(ctx, bs, "k_colour");
-        hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, bs, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
-      }
-      HIPCHK(hipStreamWaitEvent(s, ctx->ev_lists, 0));
     }
     {
       ProfScope ps(ctx, s, "k_tile_generic");
@@ -5556,9 +5581,12 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
         if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused_dma<3>, grid, dim3(256), lds2, s, ctx->d_frames, D, sc);
         else if (blur_wg == 5) hipLaunchKernelGGL(k_blur_fused_dma<5>, grid, dim3(256), lds2, s, ctx->d_frames, D, sc);
         else hipLaunchKernelGGL(k_blur_fused_dma<4>, grid, dim3(256), lds2, s, ctx->d_frames, D, sc);
-      } else if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
+      }
+#ifdef RR_EXPERIMENTS
+      else if (blur_wg == 3) hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else if (blur_wg == 5) hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
       else hipLaunchKernelGGL(k_blur_fused<4>, grid, dim3(256), lds, s, ctx->d_frames, D, sc);
+#endif
     }
     {
       ProfScope ps(ctx, s, "k_blur_big_weights");
@@ -5573,11 +5601,9 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       hipLaunchKernelGGL(k_blur<1>, dim3(256, n), dim3(256), 0, s, ctx->d_frames, D, sc);
     }
     HIPCHK(join.now());                                    // the caller's stream waits for the second one: k_bin needs k_colour's records
-    if (bs == s) {                                         // modes 0 and 1: k_colour here, behind the blur (mode 1: and behind the join)
-      {
-        ProfScope ps(ctx, s, "k_colour");
-        hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
-      }
+    {                                                      // behind the blur (mode 1: and behind the join)
+      ProfScope ps(ctx, s, "k_colour");
+      hipLaunchKernelGGL(k_colour, dim3((max_drops + 255) / 256, n), dim3(256), 0, s, ctx->d_frames, dm, D, ctx->cam.exposure_s, sc);
     }
   }
   const int ctiles_x = (dm.W + CTILE - 1) / CTILE, nct = ctiles_x * ((dm.H + CTILE - 1) / CTILE);
@@ -6033,8 +6059,6 @@ int rr_destroy(rr_ctx* ctx) {
   if (ctx->s_col) hipStreamDestroy(ctx->s_col);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-  if (ctx->ev_lists) hipEventDestroy(ctx->ev_lists);
-  if (ctx->ev_sums) hipEventDestroy(ctx->ev_sums);
   if (ctx->s_up) hipStreamDestroy(ctx->s_up);
   if (ctx->s_down) hipStreamDestroy(ctx->s_down);
   hipFree(ctx->d_esrc);
@@ -6895,12 +6919,21 @@ int rr_host_alloc(rr_ctx* ctx, void** out, int64_t bytes) {
     if (e == hipSuccess) e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
       (void)hipGetLastError();
+      std::lock_guard<std::mutex> lk(ctx->host_mu);            // (the message under the allocator's lock, not in ctx->err: see above)
+      ctx->host_err = std::string("rr_host_alloc: hipHostMalloc of ") + std::to_string((long long)bytes) + " bytes: " + hipGetErrorString(e);
       return RR_E_HIP;
     }
   }
   std::lock_guard<std::mutex> lk(ctx->host_mu);
+  ctx->host_err.clear();
   ctx->host_allocs.emplace_back((const char*)*out, (size_t)bytes);
   return RR_OK;
+}
+
+const char* rr_host_last_error(rr_ctx* ctx) {
+  if (!ctx) return "null context";
+  std::lock_guard<std::mutex> lk(ctx->host_mu);
+  return ctx->host_err.c_str();
 }
 
 int rr_host_free(rr_ctx* ctx, void* p) {
@@ -7049,7 +7082,14 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_FOV_FILL_RULE: ctx->fill_rule = value == 1 ? 1 : 0; return RR_OK;
     case RR_OPT_BIN_ROWS: ctx->bin_rows = value != 0; return RR_OK;
     case RR_OPT_COMPOSITE_U16: ctx->composite_u16 = value != 0; return RR_OK;
-    case RR_OPT_BLUR_DMA: ctx->blur_dma = value != 0; return RR_OK;
+    case RR_OPT_BLUR_DMA:
+#ifdef RR_EXPERIMENTS
+      ctx->blur_dma = value != 0;
+      return RR_OK;
+#else
+      if (value == 0) break;                                  // the register-staged kernel is only in -DRR_EXPERIMENTS builds
+      return RR_OK;
+#endif
     case RR_OPT_FOV_DDA: ctx->fov_dda = value != 0 ? 1 : 0; return RR_OK;       // (2 was k_fov_walk, r05: measured, no faster, removed in r06)
     case RR_OPT_PIPELINE_F32: ctx->pipe_f32 = value != 0; return RR_OK;
     case RR_OPT_WILD_PIXELS: ctx->wild_pixels = value != 0; return RR_OK;
@@ -7061,7 +7101,7 @@ int rr_set_option(rr_ctx* ctx, int32_t option, int32_t value) {
     case RR_OPT_COMPOSITE_BATCH: ctx->comp_batch = value != 0; return RR_OK;
     case RR_OPT_COLOUR_STREAM:
       if (value < 0 || value > 2) break;
-      ctx->colour_stream = value;
+      ctx->colour_stream = value ? 1 : 0;                   // (2: r05's other split, measured slower and removed in r06 -- runs as 1)
       return RR_OK;
     case RR_OPT_FOV_F32:
       if (value < 0 || value > 2) break;

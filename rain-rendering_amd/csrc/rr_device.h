@@ -604,6 +604,34 @@ RR_HD bool fov_coord_ok(double v) { return fabs(v) < 1e15; }   // NaN/inf -> Cli
 
 // returns the number of vertices (20 or 24), or 0 where the reference's `except:` fires;
 // vertices are truncated toward zero like pyclipper's integer cast.
+// Clipper (pyclipper.Pyclipper.AddPath, bad_weather.py:368) strips duplicate and collinear vertices of a closed path and
+// rejects it when fewer than three are left: a truncated polygon whose vertices all lie on one line (or one point) raises
+// ClipperException, i.e. the drop is skipped (oracle/cvlike.py polygon_all_collinear).
+RR_HD bool poly_all_collinear(const int32_t* px, const int32_t* py, int n) {
+  int a = -1;
+  for (int k = 1; k < n && a < 0; k++)
+    if (px[k] != px[0] || py[k] != py[0]) a = k;
+  if (a < 0) return true;
+  const int64_t ax = (int64_t)px[a] - px[0], ay = (int64_t)py[a] - py[0];
+  for (int k = 1; k < n; k++)
+    if (ax * ((int64_t)py[k] - py[0]) - ay * ((int64_t)px[k] - px[0]) != 0) return false;
+  return true;
+}
+// The float polygon's side of it: true when the vertices are not collinear whichever way each of them moved by a texel (a
+// float vertex is within 1e-3 texels of the float64 one: its truncation differs by one texel at most).  Cross product of
+// (P_a - P_0) and (P_k - P_0), a = n / 2: a move of the three points by one texel changes it by less than the bound.
+RR_HD bool poly_surely_not_collinear_step(int ax, int ay, int bx, int by) {
+  const int64_t cr = (int64_t)ax * by - (int64_t)ay * bx;
+  const int64_t bound = 2 * ((int64_t)iabs(ax) + iabs(ay) + iabs(bx) + iabs(by) + 4);
+  return (cr < 0 ? -cr : cr) > bound;
+}
+RR_HD bool poly_surely_not_collinear(const int32_t* px, const int32_t* py, int n) {
+  const int a = n / 2;
+  for (int k = 1; k < n; k++)
+    if (poly_surely_not_collinear_step(px[a] - px[0], py[a] - py[0], px[k] - px[0], py[k] - py[0])) return true;
+  return false;
+}
+
 RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, int32_t* px, int32_t* py) {
   int N = cam.n_fov;
   FovSetup F;
@@ -646,6 +674,7 @@ RR_HD int fov_polygon(const rr_drop& d, const rr_camera& cam, int He, int We, in
     px[k] = (int32_t)fx[k];
     py[k] = (int32_t)fy[k];
   }
+  if (poly_all_collinear(px, py, m)) return 0;               // Clipper rejects the path: skipped like a polygon that could not be made
   return m;
 }
 
@@ -800,6 +829,7 @@ RR_HD int fov_polygon_auto(const rr_drop& d, const rr_camera& cam, int He, int W
       for (int k = 1; k < N; k++) spread = spread || iabs(imin(imax((int)pty[k], 0), He - 1) - r0) >= 2;
       if (!spread) unsure |= 32;
     }
+    if (!poly_surely_not_collinear(px, py, m)) unsure |= 256;  // a sliver: whether Clipper takes the path is float64's to say
   } else {
     unsure |= 64;                                              // (or already unsure) all sides alike: the reference returns [] -- float64 says so
   }

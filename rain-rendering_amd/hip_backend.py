@@ -128,7 +128,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
            'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option',
-           'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_free', 'rr_host_parse_particles',
+           'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_last_error', 'rr_host_free', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
            'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_read_frames_u16', 'rr_io_read_frames_rows', 'rr_io_read_frames_scaled', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
@@ -149,6 +149,8 @@ def load_library(path=None):
     lib = ctypes.CDLL(p)
     lib.rr_last_error.restype = ctypes.c_char_p
     lib.rr_last_error.argtypes = [ctypes.c_void_p]
+    lib.rr_host_last_error.restype = ctypes.c_char_p
+    lib.rr_host_last_error.argtypes = [ctypes.c_void_p]
     lib.rr_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
     lib.rr_destroy.argtypes = [ctypes.c_void_p]
     lib.rr_set_streak_db.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -761,7 +763,9 @@ class RainHip:
 
     def _check(self, rc, what):
         if rc < 0:
-            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.rr_last_error(self.h).decode()))
+            # (rr_host_alloc may run beside the context's own calls: it reports through its own, lock-guarded message)
+            msg = self.lib.rr_host_last_error(self.h) if what == 'rr_host_alloc' else self.lib.rr_last_error(self.h)
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode()))
         return rc
 
     def set_streak_db(self, textures):

@@ -221,6 +221,7 @@ def simulate_to_xml(path, n_frames, n_drops, W, H, focal_mm=6.0, pix_um=4.65, ex
                     sys.stderr.write("simulate_to_xml: worker for %s failed (%d): %s\n" % (part, pr.returncode, err.decode(errors='replace')[-500:]))
             except subprocess.TimeoutExpired:
                 pr.kill()
+                pr.communicate()                                    # reap the worker, close its pipe
                 ok = False
             parts.append(part)
         if not ok:
@@ -230,22 +231,26 @@ def simulate_to_xml(path, n_frames, n_drops, W, H, focal_mm=6.0, pix_um=4.65, ex
                     os.remove(part)
             parts = []
     tmp_path = '%s.%d.tmp' % (path, os.getpid())               # (the finished file appears under its name at once)
-    with open(tmp_path, 'w') as fh:
-        fh.write('<?xml version="1.0" ?>\n<simulation>\n')
-        if parts:
-            for part in parts:
-                with open(part) as src:
-                    while True:
-                        blk = src.read(1 << 24)
-                        if not blk:
-                            break
-                        fh.write(blk)
-                os.remove(part)
-        else:
-            for fi in range(n_frames):
-                fh.write(_frame_xml((fi,) + common))
-        fh.write('</simulation>\n')
-    os.replace(tmp_path, path)
+    try:
+        with open(tmp_path, 'w') as fh:
+            fh.write('<?xml version="1.0" ?>\n<simulation>\n')
+            if parts:
+                for part in parts:
+                    with open(part) as src:
+                        while True:
+                            blk = src.read(1 << 24)
+                            if not blk:
+                                break
+                            fh.write(blk)
+                    os.remove(part)
+            else:
+                for fi in range(n_frames):
+                    fh.write(_frame_xml((fi,) + common))
+            fh.write('</simulation>\n')
+        os.replace(tmp_path, path)
+    finally:
+        if os.path.exists(tmp_path):                             # an exception on the way: no half-written file is left behind
+            os.remove(tmp_path)
     return path
 
 

@@ -216,3 +216,30 @@ def test_wild_pixel_values_follow_the_reference_blend(tmp_path, built):
             assert np.array_equal(plain['mask'], emu['mask'])
     assert differs_without
     rh.close()
+
+
+def test_collinear_polygons_are_skipped(tmp_path, built, monkeypatch):
+    """pyclipper's AddPath (bad_weather.py:368) raises for a path without three non-collinear vertices and the reference's
+    caller skips the drop.  A cone of a fraction of a degree makes the truncated polygons cover a texel or two: every way
+    the library evaluates a polygon -- the thread-per-drop float kernel (slivers go to float64 through the frame's list),
+    the edge-parallel kernel with float and with float64 vertices, the general path -- gives the oracle's statuses and mask."""
+    import test_hostemu_vs_oracle as tho
+    sc = tho.sliver_scene(tmp_path, monkeypatch)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=True)
+    st = ref['status']
+    assert (st == h.orc.ST_FOV_FAIL).sum() >= 10 and (st == 0).sum() >= 10
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    for opts, composite in (((), False), ((), True), (((h.hb.RR_OPT_FOV_DDA, 0),), False), (((h.hb.RR_OPT_GENERAL_FOV, 1),), False),
+                            (((h.hb.RR_OPT_FOV_F32, 0),), False)):
+        rh = h.hb.RainHip(0)
+        try:
+            rh.set_streak_db(sc.db.streaks_light)
+            rh.set_camera(sc.cam)
+            for o, v in opts:
+                rh.set_option(o, v)
+            out = rh.render_frames([fr], want_composite=composite)[0]
+        finally:
+            rh.close()
+        _check(out, ref)

@@ -271,8 +271,12 @@ def test_composite_codes_and_blur_prefetch(setup):
     frw = dict(fr, bg=wild, rainy_bg=wild)
     ref = rh.render_frames([fr, frw], want_composite=False)
     for opt, off, on in ((h.hb.RR_OPT_BLUR_DMA, 0, 1), (h.hb.RR_OPT_BIN_ROWS, 0, 1), (h.hb.RR_OPT_COMPOSITE_BATCH, 0, 1),
-                         (h.hb.RR_OPT_COLOUR_STREAM, 0, 1), (h.hb.RR_OPT_COLOUR_STREAM, 2, 1), (h.hb.RR_OPT_COMPOSITE_U16, 0, 1)):
-        rh.set_option(opt, off)
+                         (h.hb.RR_OPT_COLOUR_STREAM, 0, 1), (h.hb.RR_OPT_COMPOSITE_U16, 0, 1)):
+        try:
+            rh.set_option(opt, off)
+        except RuntimeError:
+            assert opt == h.hb.RR_OPT_BLUR_DMA         # r04's register-staged kernel: -DRR_EXPERIMENTS builds only (r06)
+            continue
         try:
             alt = rh.render_frames([fr, frw], want_composite=False)
         finally:

@@ -169,3 +169,29 @@ def test_every_drop_of_the_large_configs_oracle_vs_hostemu(name, every):
         assert ok, '%s drops [%d, %d): status / mask differ' % (name, a, b)
         assert d <= 1, '%s drops [%d, %d): image differs by %d LSB' % (name, a, b, d)
     assert sum(r[4] for r in res) > 0.8 * sum(b - a for a, b, *_ in res)
+
+
+def sliver_scene(tmp_path, monkeypatch, fov_deg=0.6):
+    """A camera whose field-of-view cone is a fraction of a degree: the truncated polygons cover a texel or two -- some
+    have three vertices that are not collinear, most do not.  Oracle and product get the same cone angle."""
+    sc = h.Scene(tmp_path, 96, 160, 150, seed0=77)
+    cs = sc.cam_settings
+    sc.cam = h.hb.make_camera(cs['focal_mm'] / 1000., cs['f_number'], cs['exposure_ms'], fov=fov_deg)
+    monkeypatch.setattr(h.orc, 'FOV_DEG', fov_deg)
+    return sc
+
+
+def test_collinear_polygons_are_skipped(tmp_path, monkeypatch):
+    """pyclipper's AddPath (bad_weather.py:368) raises for a path without three non-collinear vertices: such a drop is
+    skipped by the reference's caller (generator.py:180-189).  Oracle (cvlike.polygon_all_collinear) and kernel arithmetic
+    (rr_device.h poly_all_collinear; the float polygon hands every sliver to float64) give the same statuses and mask."""
+    sc = sliver_scene(tmp_path, monkeypatch)
+    bg, env = sc.frame_inputs(0)
+    drops = sc.product_drops(0)
+    emu = h.emu_render(sc, bg, bg, env, drops)
+    ref = h.oracle_render(sc, 0, bg, bg, env, faithful=True)
+    assert np.array_equal(emu['status'], ref['status'])
+    assert np.array_equal(emu['mask'], ref['mask'])
+    assert np.abs(emu['image_u8'].astype(int) - ref['image_u8'].astype(int)).max() <= 1
+    st = ref['status']
+    assert (st == h.orc.ST_FOV_FAIL).sum() >= 10 and (st == 0).sum() >= 10, np.bincount(st)
