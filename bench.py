@@ -567,7 +567,7 @@ def main():
         return
     if args.sweep and rank == 0:
         def line(tag, el, st):
-            ks = {k: round(v[1] / args.steps, 3) for k, v in sorted(st.items(), key=lambda kv: -kv[1][1])[:12]}
+            ks = {k: round(v[1] / args.steps, 3) for k, v in sorted(st.items(), key=lambda kv: -kv[1][1])[:18]}
             sys.stderr.write("SWEEP " + json.dumps({"opts": tag, "ms_per_step": round(1e3 * el / args.steps, 3), "kernels_ms": ks}) + "\n")
         line("default", elapsed, stats)
         for spec in args.sweep:

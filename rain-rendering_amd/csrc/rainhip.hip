@@ -247,6 +247,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small, -, -, #duplicate raw tiles
   int32_t* list_big;                // [frame][drops] Big drops (bicubic warp) rendered by k_tile_big, one thread per pixel
   int32_t* big_off;                 // [frame][drops+1] exclusive prefix of their tile sizes, in pixels
+  uint4* tkey;                      // [frame][drops][2] raw_tile_key (rr_device.h): what k_dedup compares (r06: 32 bytes instead of the plan's ~200)
+  uint4* lrec;                      // [frame][drops] ListRec: the drop's work-list classes, made once by k_plan (r06; k_lists read the plans twice)
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
   int32_t* htab;                    // [2*frames*drops] open-addressing table of k_dedup (0 = empty, else index+1)
   int32_t blur_bx, blur_by;         // LDS capacities (doubles) of the fused blur's two staging tiles (RR_OPT_BLUR_WORKGROUPS)
@@ -353,6 +355,13 @@ __device__ inline bool blur_is_slow(const DropPlan& p, const Scratch& sc) {
 // lines with 4-byte pieces (the L2 then writes partial lines back: 5x the payload); staged 32 records at a time per
 // wave, the stores are whole, consecutive lines.
 constexpr int PLAN_DW = (int)(sizeof(DropPlan) / 4);
+// A drop's work-list classes, 16 bytes (r06): k_lists walks the frame's drops twice (count, then fill) and used to derive
+// these from the 312-byte plan both times.
+//   x: tile class (bits 0-3) | blur class (bits 4-6) | texture << 8      y: tile cost (LC_ROWS, LC_BIG_LDS) / pixels (LC_BIG)
+//   z: fused blur layout wo | ho << 16                                   w: its number of sub-tiles
+enum { LC_NONE = 0, LC_BIG_LDS = 1, LC_BIG = 2, LC_ROWS = 3, LC_ROT_INT = 4, LC_ROT = 5, LC_GEN = 6 };
+enum { LB_NONE = 0, LB_SMALL = 1, LB_FUSED = 2, LB_SLOW = 3 };
+__device__ inline uint4 make_list_rec(const DropPlan& p, const int32_t* tex_h, const int32_t* tex_w, const Scratch& sc);
 __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, rr_camera cam, const int32_t* tex_h,
                                               const int32_t* tex_w, int max_drops, int use_npts, Scratch sc) {
   static_assert(sizeof(DropPlan) % 4 == 0, "DropPlan layout");
@@ -379,6 +388,12 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
     if (p.status != RR_DROP_OK || npts == 0) size = 0;
     if (size > 0 && blur_is_slow(p, sc)) size += ((int64_t)p.ew * p.eh + 15) & ~15LL;     // dense scratch tile of the two-pass blur
     sc.sizes[gi] = size;
+    uint32_t key[8];
+    raw_tile_key(d, p, key);
+    if (p.kind == KIND_EXT) key[0] = 0xffffffffu;
+    sc.tkey[2 * gi] = make_uint4(key[0], key[1], key[2], key[3]);
+    sc.tkey[2 * gi + 1] = make_uint4(key[4], key[5], key[6], key[7]);
+    sc.lrec[gi] = make_list_rec(p, tex_h, tex_w, sc);
   }
   const int wave_i0 = blockIdx.x * blockDim.x + wave * 64;         // first drop of this wave
   uint32_t* stage = s_plan[wave];
@@ -454,54 +469,31 @@ __global__ __launch_bounds__(1024) void k_scan(const FrameDesc* frames, int max_
 // through an open-addressing table (atomicCAS); the others take over its arena offset and drop
 // out of the tile work lists.  Which drop wins the election is irrelevant: every candidate
 // would write the same bits.
-__device__ inline bool same_raw_tile(const DropPlan& a, const DropPlan& b) {
-  if (a.kind != b.kind || a.tex != b.tex || a.flip != b.flip || a.tw != b.tw || a.th != b.th || a.bw0 != b.bw0 ||
-      a.nW != b.nW || a.nH != b.nH || a.rs_mode != b.rs_mode || a.isx != b.isx || a.isy != b.isy)
-    return false;
-  // doubles compared as bit patterns: -0.0 / NaN never compare "equal by accident"
-  for (int k = 0; k < 9; k++)
-    if (__double_as_longlong(a.mi[k]) != __double_as_longlong(b.mi[k])) return false;
-  for (int k = 0; k < 6; k++)
-    if (__double_as_longlong(a.ma[k]) != __double_as_longlong(b.ma[k])) return false;
-  return __double_as_longlong(a.scale_x) == __double_as_longlong(b.scale_x) &&
-         __double_as_longlong(a.scale_y) == __double_as_longlong(b.scale_y) &&
-         __double_as_longlong(a.inv_sx) == __double_as_longlong(b.inv_sx) &&
-         __double_as_longlong(a.inv_sy) == __double_as_longlong(b.inv_sy);
-}
-__device__ inline uint32_t raw_tile_hash(const DropPlan& p) {
+// r06: what is compared is the 32-byte raw_tile_key (rr_device.h) k_plan leaves per drop -- the inputs the tile is a pure
+// function of -- not the ~200 bytes of plan fields derived from them (the kernel read every 312-byte plan through LDS and
+// a second one per probe: 2.2 GB per 512 frames).
+__device__ inline uint32_t raw_tile_hash(const uint4& a, const uint4& b) {
   uint32_t h = 2166136261u;
   auto mix = [&](uint32_t v) { h = (h ^ v) * 16777619u; };
-  mix((uint32_t)p.kind); mix((uint32_t)p.tex); mix((uint32_t)p.flip); mix((uint32_t)p.tw); mix((uint32_t)p.th);
-  mix((uint32_t)p.nW); mix((uint32_t)p.nH);
-  for (int k = 0; k < 9; k++) { const long long b = __double_as_longlong(p.mi[k]); mix((uint32_t)b); mix((uint32_t)(b >> 32)); }
-  for (int k = 0; k < 6; k++) { const long long b = __double_as_longlong(p.ma[k]); mix((uint32_t)b); mix((uint32_t)(b >> 32)); }
+  mix(a.x); mix(a.y); mix(a.z); mix(a.w); mix(b.x); mix(b.y); mix(b.z); mix(b.w);
   h ^= h >> 15;
   return h;
 }
-// (The workgroup's 128 plans come in as whole lines through LDS: a thread reading its own 312-byte record field by field
-//  touches a different line with every lane of every load -- six times the payload between L1 and L2.)
-__global__ __launch_bounds__(128) void k_dedup(const FrameDesc* frames, int max_drops, int n_frames, int enable, Scratch sc) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_plan[128 * PLAN_DW];
-  const int f = blockIdx.y, i0 = blockIdx.x * 128, i = i0 + (int)threadIdx.x;
+__global__ __launch_bounds__(256) void k_dedup(const FrameDesc* frames, int max_drops, int n_frames, int enable, Scratch sc) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + (int)threadIdx.x;
   const int n = frames[f].n_drops;
-  if (i0 >= n) return;
-  {
-    const int cnt = imin(128, n - i0);
-    const global_ptr<const uint32_t> src = as_global(reinterpret_cast<const uint32_t*>(sc.plan + (int64_t)f * max_drops + i0));
-    for (int k = threadIdx.x; k < cnt * PLAN_DW; k += 128) s_plan[k] = src[k];
-  }
-  __syncthreads();
   if (i >= n) return;
   const int gi = f * max_drops + i;
-  const DropPlan& p = *reinterpret_cast<const DropPlan*>(s_plan + threadIdx.x * PLAN_DW);
+  const uint4 ka = sc.tkey[2 * (int64_t)gi], kb = sc.tkey[2 * (int64_t)gi + 1];
   int canon = gi;
-  if (enable && p.status == RR_DROP_OK && sc.sizes[gi] != 0 && p.kind != KIND_EXT) {
+  if (enable && ka.x != 0xffffffffu && sc.sizes[gi] != 0) {
     const uint32_t cap = 2u * (uint32_t)n_frames * (uint32_t)max_drops;
-    uint32_t h = raw_tile_hash(p) % cap;
+    uint32_t h = raw_tile_hash(ka, kb) % cap;
     for (;;) {
       const int prev = atomicCAS(&sc.htab[h], 0, gi + 1);
       if (prev == 0) break;                               // this drop renders the tile
-      if (same_raw_tile(sc.plan[prev - 1], p)) {
+      const uint4 pa = sc.tkey[2 * (int64_t)(prev - 1)], pb = sc.tkey[2 * (int64_t)(prev - 1) + 1];
+      if (pa.x == ka.x && pa.y == ka.y && pa.z == ka.z && pa.w == ka.w && pb.x == kb.x && pb.y == kb.y && pb.z == kb.z && pb.w == kb.w) {
         canon = prev - 1;
         break;
       }
@@ -2625,6 +2617,27 @@ __device__ inline int blur_subtiles(const DropPlan& p, const BlurLayout& L) {
   return ((p.ew + L.wo - 1) / L.wo) * ((p.eh + L.ho - 1) / L.ho);
 }
 
+__device__ inline uint4 make_list_rec(const DropPlan& p, const int32_t* tex_h, const int32_t* tex_w, const Scratch& sc) {
+  if (p.status != RR_DROP_OK) return make_uint4(0u, 0u, 0u, 0u);
+  const int sh = tex_h[p.tex], sw = tex_w[p.tex];
+  uint32_t cls, cost = 0u, bcls = LB_NONE, bwh = 0u, bns = 0u;
+  if (p.kind == KIND_BIG) {
+    if (sc.big_on && tile_is_big_lds(p, sh, sw)) { cls = LC_BIG_LDS; cost = (uint32_t)((p.tw * p.th + 63) / 64 + 4); }
+    else { cls = LC_BIG; cost = (uint32_t)(p.tw * p.th); }
+  } else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, sh, sw)) { cls = LC_ROWS; cost = (uint32_t)rows_tile_cost(p, sh, sw); }
+  else if (p.kind != KIND_EXT && tile_is_fast(p, sh, sw)) cls = p.rs_mode == RS_AREA_FAST ? LC_ROT_INT : LC_ROT;
+  else cls = LC_GEN;
+  if (p.r1 > 0) {
+    if (blur_is_small(p)) bcls = LB_SMALL;
+    else {
+      const BlurLayout L = blur_layout(p, sc.blur_bx, sc.blur_by);
+      if (L.fused) { bcls = LB_FUSED; bwh = (uint32_t)L.wo | ((uint32_t)L.ho << 16); bns = (uint32_t)blur_subtiles(p, L); }
+      else bcls = LB_SLOW;
+    }
+  }
+  return make_uint4(cls | (bcls << 4) | ((uint32_t)p.tex << 8), cost, bwh, bns);
+}
+
 __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max_drops, const int32_t* tex_h, const int32_t* tex_w,
                                                 Scratch sc) {
   const int f = blockIdx.x, t = threadIdx.x;
@@ -2641,28 +2654,28 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   constexpr int NC = 10;             // (+ Big tiles that ride in the row-walk list)
   int c[NC] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = i0; i < i1; i++) {
-    const DropPlan& p = sc.plan[base + i];
-    if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
+    const uint4 r = sc.lrec[base + i];
+    const uint32_t cls = r.x & 15u, bcls = (r.x >> 4) & 7u;
+    if (cls == LC_NONE || sc.sizes[base + i] == 0) continue;
+    const int tex = (int)(r.x >> 8);
     if (sc.canon[base + i] == (int)(base + i)) {         // duplicates of another drop's raw tile render nothing
-      if (p.kind == KIND_BIG) {
-        if (sc.big_on && tile_is_big_lds(p, tex_h[p.tex], tex_w[p.tex])) {
-          c[9]++;
-          atomicAdd(&s_hist[sc.n_tex + p.tex], 1);
-          atomicAdd(&s_cost[sc.n_tex + p.tex], (p.tw * p.th + 63) / 64 + 4);
-        } else { c[6]++; c[7] += p.tw * p.th; }
-      }
-      else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) {
+      if (cls == LC_BIG_LDS) {
+        c[9]++;
+        atomicAdd(&s_hist[sc.n_tex + tex], 1);
+        atomicAdd(&s_cost[sc.n_tex + tex], (int)r.y);
+      } else if (cls == LC_BIG) { c[6]++; c[7] += (int)r.y; }
+      else if (cls == LC_ROWS) {
         c[8]++;
-        atomicAdd(&s_hist[p.tex], 1);
-        atomicAdd(&s_cost[p.tex], rows_tile_cost(p, tex_h[p.tex], tex_w[p.tex]));
+        atomicAdd(&s_hist[tex], 1);
+        atomicAdd(&s_cost[tex], (int)r.y);
       }
-      else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) c[5]++; else c[0]++; } else c[1]++;
+      else if (cls == LC_ROT_INT) c[5]++;
+      else if (cls == LC_ROT) c[0]++;
+      else c[1]++;
     }
-    if (p.r1 > 0) {
-      if (blur_is_small(p)) { c[4]++; continue; }
-      const BlurLayout L = blur_layout(p, sc.blur_bx, sc.blur_by);
-      if (L.fused) c[2] += imin(blur_subtiles(p, L), BLUR_ITEMS_PER_DROP); else c[3]++;
-    }
+    if (bcls == LB_SMALL) c[4]++;
+    else if (bcls == LB_FUSED) c[2] += imin((int)r.w, BLUR_ITEMS_PER_DROP);
+    else if (bcls == LB_SLOW) c[3]++;
   }
   __shared__ int sh[1024][NC];
   for (int k = 0; k < NC; k++) sh[t][k] = c[k];
@@ -2692,34 +2705,30 @@ __global__ __launch_bounds__(1024) void k_lists(const FrameDesc* frames, int max
   int32_t* boff = sc.big_off + base + f;                 // n_big + 1 entries per frame
   int4* items = sc.blur_items + base * BLUR_ITEMS_PER_DROP;
   for (int i = i0; i < i1; i++) {
-    const DropPlan& p = sc.plan[base + i];
-    if (p.status != RR_DROP_OK || sc.sizes[base + i] == 0) continue;
+    const uint4 r = sc.lrec[base + i];
+    const uint32_t cls = r.x & 15u, bcls = (r.x >> 4) & 7u;
+    if (cls == LC_NONE || sc.sizes[base + i] == 0) continue;
     if (sc.canon[base + i] == (int)(base + i)) {
-      if (p.kind == KIND_BIG) {
-        if (sc.big_on && tile_is_big_lds(p, tex_h[p.tex], tex_w[p.tex])) lrows[n_rot_rows + o[9]++] = i;      // (behind the frame's rotate tiles)
-        else {
-          boff[o[6]] = o[7];
-          lbig[o[6]++] = i;
-          o[7] += p.tw * p.th;
-        }
-      } else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, tex_h[p.tex], tex_w[p.tex])) lrows[o[8]++] = i;
-      else if (p.kind != KIND_EXT && tile_is_fast(p, tex_h[p.tex], tex_w[p.tex])) { if (p.rs_mode == RS_AREA_FAST) lrot[o[5]++] = (int32_t)(base + i); else lrot[o[0]++] = (int32_t)(base + i); } else lgen[o[1]++] = i;
+      if (cls == LC_BIG_LDS) lrows[n_rot_rows + o[9]++] = i;      // (behind the frame's rotate tiles)
+      else if (cls == LC_BIG) {
+        boff[o[6]] = o[7];
+        lbig[o[6]++] = i;
+        o[7] += (int)r.y;
+      } else if (cls == LC_ROWS) lrows[o[8]++] = i;
+      else if (cls == LC_ROT_INT) lrot[o[5]++] = (int32_t)(base + i);
+      else if (cls == LC_ROT) lrot[o[0]++] = (int32_t)(base + i);
+      else lgen[o[1]++] = i;
     }
-    if (p.r1 > 0) {
-      if (blur_is_small(p)) { lsmall[o[4]++] = i; continue; }
-      const BlurLayout L = blur_layout(p, sc.blur_bx, sc.blur_by);
-      if (L.fused) {
-        const int ns = blur_subtiles(p, L);
-        const int ni = imin(ns, BLUR_ITEMS_PER_DROP);
-        const int per = (ns + ni - 1) / ni;
-        for (int k = 0; k < ni; k++) {
-          const int st0 = k * per;
-          items[o[2]++] = make_int4(i, st0, imax(imin(per, ns - st0), 0), L.wo | (L.ho << 16));   // layout travels with the item
-        }
-      } else {
-        lslow[o[3]++] = i;
+    if (bcls == LB_SMALL) lsmall[o[4]++] = i;
+    else if (bcls == LB_FUSED) {
+      const int ns = (int)r.w;
+      const int ni = imin(ns, BLUR_ITEMS_PER_DROP);
+      const int per = (ns + ni - 1) / ni;
+      for (int k = 0; k < ni; k++) {
+        const int st0 = k * per;
+        items[o[2]++] = make_int4(i, st0, imax(imin(per, ns - st0), 0), (int)r.z);   // layout travels with the item
       }
-    }
+    } else if (bcls == LB_SLOW) lslow[o[3]++] = i;
   }
   if (t == 1023) {
     for (int k = 0; k < 5; k++) sc.counts[f * 8 + k] = sh[1023][k];
@@ -5212,6 +5221,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     }
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.canon, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.tkey, fd * 2))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.lrec, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_big, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.big_off, fd + F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.htab, fd * 2))) return rc;
@@ -5526,7 +5537,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       HIPCHK(hipMemsetAsync(sc.htab, 0, sizeof(int32_t) * 2 * (size_t)n * D, bs));
       HIPCHK(hipMemsetAsync(sc.counts, 0, sizeof(int32_t) * 8 * (size_t)n, bs));
       HIPCHK(hipMemsetAsync(sc.rows_hist, 0, sizeof(int32_t) * (RW_TEX_MAX * 3 + 16), bs));      // histogram, cost sums, share counter, rot_total
-      hipLaunchKernelGGL(k_dedup, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
+      hipLaunchKernelGGL(k_dedup, dim3((max_drops + 255) / 256, n), dim3(256), 0, bs, ctx->d_frames, D, n, ctx->dedup ? 1 : 0, sc);
     }
     {
       ProfScope ps(ctx, bs, "k_lists");
@@ -5989,6 +6000,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
   hipFree(ctx->sc.canon);
+  hipFree(ctx->sc.tkey);
+  hipFree(ctx->sc.lrec);
   hipFree(ctx->sc.list_big);
   hipFree(ctx->sc.big_off);
   hipFree(ctx->sc.htab);

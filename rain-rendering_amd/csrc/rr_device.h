@@ -1209,6 +1209,40 @@ RR_HD int py_slice_index(int i, int n) {   // CPython slice normalisation of one
   return i;
 }
 
+// What a drop's RAW tile (before the defocus blur) is a function of, 32 bytes: everything plan_drop derives for the tile
+// kernels -- the inverse homography / rotation, canvas, scales, block width -- follows from these inputs and the texture's
+// size, so two drops of a batch with equal keys get bit-identical tiles and share one (k_dedup compares keys instead of
+// the ~200 bytes of derived plan fields).  key[0] = kind | flip << 4 | tex << 8 (0xffffffff: never shared -- a skipped
+// drop, a caller-made tile, endpoint widths outside int32), key[1] = tw | th << 16,
+//   Big drops (generator.py:126-132):    key[2..7] = x0 - minx, y0 - miny, x1 - minx, y1 - miny, floor(iw1), floor(iw2)
+//   Medium / Small (generator.py:133-171): key[2..5] = the bits of cos, sin of the streak's angle
+RR_HD void raw_tile_key(const rr_drop& d, const DropPlan& p, uint32_t key[8]) {
+  for (int k = 0; k < 8; k++) key[k] = 0u;
+  key[0] = 0xffffffffu;
+  if (p.status != RR_DROP_OK || (p.kind != KIND_BIG && p.kind != KIND_ROT)) return;
+  if (p.tw < 0 || p.tw > 65535 || p.th < 0 || p.th > 65535) return;
+  if (p.kind == KIND_BIG) {
+    const double d0 = floor(d.iw1), d1 = floor(d.iw2);
+    if (!(d0 > -2.0e9 && d0 < 2.0e9 && d1 > -2.0e9 && d1 < 2.0e9)) return;
+    const int minx = imax(imin(d.x0, d.x1), 0), miny = imax(imin(d.y0, d.y1), 0);
+    key[2] = (uint32_t)(d.x0 - minx);
+    key[3] = (uint32_t)(d.y0 - miny);
+    key[4] = (uint32_t)(d.x1 - minx);
+    key[5] = (uint32_t)(d.y1 - miny);
+    key[6] = (uint32_t)(int32_t)d0;
+    key[7] = (uint32_t)(int32_t)d1;
+  } else {
+    uint64_t a, b;
+    const double al = d.rot_cos, be = d.rot_sin;
+    __builtin_memcpy(&a, &al, 8);
+    __builtin_memcpy(&b, &be, 8);
+    key[2] = (uint32_t)a; key[3] = (uint32_t)(a >> 32);
+    key[4] = (uint32_t)b; key[5] = (uint32_t)(b >> 32);
+  }
+  key[0] = (uint32_t)p.kind | ((uint32_t)(p.flip & 1) << 4) | ((uint32_t)p.tex << 8);
+  key[1] = (uint32_t)p.tw | ((uint32_t)p.th << 16);
+}
+
 RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, const int32_t* tex_h, const int32_t* tex_w,
                      double opacity_attenuation, int strategy, DropPlan& p, int64_t& size_out, const rr_ext_tile* ext = nullptr) {
   size_out = 0;

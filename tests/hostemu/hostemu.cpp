@@ -38,6 +38,12 @@ int emu_plan(const rr_drop* drops, int n, const rr_camera* cam, int H, int W, in
   return 0;
 }
 
+// raw_tile_key (what k_dedup compares) of n planned drops: keys n*8 uint32
+int emu_raw_tile_keys(const rr_drop* drops, int n, const DropPlan* plans, uint32_t* keys) {
+  for (int i = 0; i < n; i++) raw_tile_key(drops[i], plans[i], keys + (int64_t)i * 8);
+  return 0;
+}
+
 // the colour branch's default polygon: float32 vertices unless a status / wrap predicate is within its error bound of the
 // threshold (then the float64 polygon).  poly: n*2*36 int32, npts: n, used32: n (1 = the float polygon was kept)
 int emu_fov_auto(const rr_drop* drops, int n, const rr_camera* cam, int He, int We, int32_t* poly, int32_t* npts, int32_t* used32) {
