@@ -2432,6 +2432,9 @@ constexpr int BIG_LDS_LEAD = 16;      // zero bytes in front of the padded textu
 #ifndef RR_BIG_NP
 #define RR_BIG_NP 1
 #endif
+#ifndef RR_BIG_COST
+#define RR_BIG_COST 2          // a pass of 64 Big pixels in walk iterations of the rotate tiles (the split of the list into shares)
+#endif
 __device__ inline int div_by_f(int n, int d, float inv_d) {      // n / d for 0 <= n < 2^24, d >= 1
   int q = (int)((float)n * inv_d);
   const int r = n - q * d;
@@ -2622,7 +2625,7 @@ __device__ inline uint4 make_list_rec(const DropPlan& p, const int32_t* tex_h, c
   const int sh = tex_h[p.tex], sw = tex_w[p.tex];
   uint32_t cls, cost = 0u, bcls = LB_NONE, bwh = 0u, bns = 0u;
   if (p.kind == KIND_BIG) {
-    if (sc.big_on && tile_is_big_lds(p, sh, sw)) { cls = LC_BIG_LDS; cost = (uint32_t)((p.tw * p.th + 63) / 64 + 4); }
+    if (sc.big_on && tile_is_big_lds(p, sh, sw)) { cls = LC_BIG_LDS; cost = (uint32_t)(RR_BIG_COST * ((p.tw * p.th + 63) / 64) + 4); }
     else { cls = LC_BIG; cost = (uint32_t)(p.tw * p.th); }
   } else if (sc.rows_on && p.kind != KIND_EXT && tile_is_rows(p, sh, sw)) { cls = LC_ROWS; cost = (uint32_t)rows_tile_cost(p, sh, sw); }
   else if (p.kind != KIND_EXT && tile_is_fast(p, sh, sw)) cls = p.rs_mode == RS_AREA_FAST ? LC_ROT_INT : LC_ROT;
