@@ -684,6 +684,8 @@ class Generator:
             si = bi % nslot
             sl = slots[si]
             items, nds = decoding.result()
+            if bi == 0:
+                self._mark('first batch decoded + packed')
             drain(si)                                            # the slot's previous files are written: its outputs may be overwritten
             sl.items = list(zip(items, nds))
             sl.n_valid = len(items)
@@ -697,6 +699,8 @@ class Generator:
                         sl.prep.set_drop_count(k, nd)
                 sl.t_submit = time.time()
                 hip.pipeline_submit_prepared(si, sl.prep, sl.n_valid)
+                if bi == 0:
+                    self._mark('first batch submitted')
                 sl.busy = True
                 if t_first is None:
                     t_first = time.time()
