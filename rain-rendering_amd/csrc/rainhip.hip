@@ -1655,9 +1655,13 @@ __device__ inline bool tile_is_rows(const DropPlan& p, int sh, int sw) {
   return p.kind == KIND_ROT && p.rs_mode == RS_AREA && p.scale_x >= 2.0 && p.nW <= RW_NW && p.tw <= 64 && p.tw >= 1 && p.th >= 1 && p.th <= 64 &&
          pair_bytes(sh, sw) <= RW_PAIR_BYTES && tile_coords_safe(p);
 }
-// Big (bicubic warp) tiles k_tile_rows takes: the padded texture (2-texel zero border, k_pad_textures) in the LDS region of the pair texture
+// Big (bicubic warp) tiles k_tile_rows takes: the padded texture (2-texel zero border, k_pad_textures) in the LDS region of the
+// pair texture.  A tile is ONE wave's work there, 64 pixels a pass: tiles of more than BIG_ROWS_MAX_PX pixels stay with
+// k_tile_big, whose threads take a pixel each across the whole device (nuScenes at f/1.8 has Big tiles of 10^5 pixels: as a
+// single wave's 1900 passes one of them was 0.75 ms, the whole kernel's time -- r06 A/B log).
+constexpr int BIG_ROWS_MAX_PX = 8192;
 __device__ inline bool tile_is_big_lds(const DropPlan& p, int sh, int sw) {
-  return p.kind == KIND_BIG && (int64_t)(sh + 4) * (sw + 4) + 48 <= RW_PAIR_BYTES && p.tw >= 1 && p.th >= 1 && (int64_t)p.tw * p.th < (1 << 22) && p.bw0 >= 1;
+  return p.kind == KIND_BIG && (int64_t)(sh + 4) * (sw + 4) + 48 <= RW_PAIR_BYTES && p.tw >= 1 && p.th >= 1 && (int64_t)p.tw * p.th <= BIG_ROWS_MAX_PX && p.bw0 >= 1;
 }
 __global__ __launch_bounds__(256) void k_pair_textures(const uint8_t* texels, const int32_t* tex_h, const int32_t* tex_w,
                                                        const int64_t* tex_off, const int64_t* tex_qoff, uint8_t* pairs) {
@@ -5559,7 +5563,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, s, "k_tile_big");
-      hipLaunchKernelGGL(k_tile_big, dim3(sc.big_on ? imax(4, imin(1024, 4096 / n)) : 1024, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
+      hipLaunchKernelGGL(k_tile_big, dim3(sc.big_on ? imax(16, imin(1024, 16384 / n)) : 1024, n), dim3(256), 0, s, ctx->d_frames, D, ctx->d_tex, ctx->d_tex_h, ctx->d_tex_w,
                          ctx->d_tex_off, ctx->d_ctab, sc);
     }
     if (sc.rows_on) {
