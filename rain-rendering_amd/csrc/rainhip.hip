@@ -2020,12 +2020,25 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
         }
         wave_lds_sync();
         const bool mine = lane < dx1 - dx0;
+        const int colL = (dx0 + lane) * isx;               // this lane's pixel: canvas columns colL .. colL + isx - 1 of every row
         for (int r = 0; r < nr; r++) {
           const int4 rw = rowp[r];
           const double* row = can + r * pitch2 - rw.z;
-          for (int kx = 0; kx < isx; kx++, k++) {
-            const int col = (dx0 + lane) * isx + kx;
-            const double v = (mine && col >= rw.z && col < rw.z + rw.w) ? row[col] : 0.0;
+          const int vlo = mine ? rw.z : (1 << 30), vhi = rw.z + rw.w;      // staged (possibly non-zero) columns; everything else is an exact zero
+          auto at = [&](int col) { return (col >= vlo && col < vhi) ? row[col] : 0.0; };
+          // k (wave-uniform) counts the chain's samples across rows: a group of four that lies inside one row is taken at once
+          // (r06: one sample per iteration with a four-way branch on k & 3 made a 107 x 107 block -- a 3-pixel-wide tile of a
+          // 321-column canvas -- 0.3 ms of one lane's dependent iterations: the whole kernel's time)
+          int kx = 0;
+          while (kx < isx) {
+            if ((k & 3) == 0 && kx + 3 < isx && k + 3 < n4) {
+              const double v0 = at(colL + kx), v1 = at(colL + kx + 1), v2 = at(colL + kx + 2), v3 = at(colL + kx + 3);
+              sum = sum + (((v0 + v1) + v2) + v3);
+              kx += 4;
+              k += 4;
+              continue;
+            }
+            const double v = at(colL + kx);
             if (k >= n4) sum = sum + v;
             else {
               const int m = k & 3;
@@ -2034,6 +2047,8 @@ __global__ __launch_bounds__(256) void k_tile(const FrameDesc* frames, int max_d
               else if (m == 2) q2 = v;
               else sum = sum + (((q0 + q1) + q2) + v);
             }
+            kx++;
+            k++;
           }
         }
         wave_lds_sync();
