@@ -4251,30 +4251,12 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
   // else -- only possible where no drop was blended, every blend ends with a clamp, or where the input was NaN -- becomes
   // the code 65535: k_finalize then takes the pixel's channel from rainy_bg itself, which is what this lane holds.
   auto code16 = [](float v) -> uint32_t { return (v >= 0.f && v <= 1.f) ? (uint32_t)(v * 65534.0f + 0.5f) : 65535u; };
-  const bool c16 = fr.comp_f32 == 2;
+  // (r06) The tile's sums FIRST, the pixel stores last: __syncthreads() carries a full memory fence, and with the stores in
+  // front of it every wave sat at the barrier until its six stores per lane had been acknowledged -- the phase clocks gave
+  // "stores + tile reduction" 38 % of the kernel's wave time.  After the barrier nothing waits for the stores any more.
   double sum_c = 0.0;
-  if (live0) {
-    if (c16) {                                                    // four 16-bit words per pixel (the fourth is 0): one 8-byte store
-      as_global(reinterpret_cast<u32x2_t*>(fr.comp_out))[pix0] = u32x2_t{code16(c0.x) | (code16(c1.x) << 16), code16(c2.x)};
-    } else {
-      const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix0 * 3;
-      o[0] = c0.x; o[1] = c1.x; o[2] = c2.x;
-    }
-    if (fr.mask_f64) as_global(fr.mask_f64)[pix0] = m0;
-    if (fr.mask_i32) as_global(fr.mask_i32)[pix0] = (int32_t)floor(m0 * 255.0);
-    sum_c = ((double)c0.x + (double)c1.x) + (double)c2.x;
-  }
-  if (live1) {
-    if (c16) {
-      as_global(reinterpret_cast<u32x2_t*>(fr.comp_out))[pix1] = u32x2_t{code16(c0.y) | (code16(c1.y) << 16), code16(c2.y)};
-    } else {
-      const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix1 * 3;
-      o[0] = c0.y; o[1] = c1.y; o[2] = c2.y;
-    }
-    if (fr.mask_f64) as_global(fr.mask_f64)[pix1] = m1;
-    if (fr.mask_i32) as_global(fr.mask_i32)[pix1] = (int32_t)floor(m1 * 255.0);
-    sum_c += ((double)c0.y + (double)c1.y) + (double)c2.y;
-  }
+  if (live0) sum_c = ((double)c0.x + (double)c1.x) + (double)c2.x;
+  if (live1) sum_c += ((double)c0.y + (double)c1.y) + (double)c2.y;
   // the tile's four numbers: inside a wave by DPP (no LDS, no barrier), across the four waves through 16 doubles of LDS
   // and ONE barrier (r04: a 256-entry LDS tree with nine)
   const double wa = readlane_f64(wave_incl_scan_f64(sum_c), 63), wb = readlane_f64(wave_incl_scan_f64(sum_b), 63);
@@ -4301,6 +4283,27 @@ __global__ __launch_bounds__(256, WPE) void k_composite32(const FrameDesc* frame
     part[1] = rb[0];
     part[2] = rlo[0];
     part[3] = rhi[0];
+  }
+  const bool c16 = fr.comp_f32 == 2;
+  if (live0) {
+    if (c16) {                                                    // four 16-bit words per pixel (the fourth is 0): one 8-byte store
+      as_global(reinterpret_cast<u32x2_t*>(fr.comp_out))[pix0] = u32x2_t{code16(c0.x) | (code16(c1.x) << 16), code16(c2.x)};
+    } else {
+      const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix0 * 3;
+      o[0] = c0.x; o[1] = c1.x; o[2] = c2.x;
+    }
+    if (fr.mask_f64) as_global(fr.mask_f64)[pix0] = m0;
+    if (fr.mask_i32) as_global(fr.mask_i32)[pix0] = (int32_t)floor(m0 * 255.0);
+  }
+  if (live1) {
+    if (c16) {
+      as_global(reinterpret_cast<u32x2_t*>(fr.comp_out))[pix1] = u32x2_t{code16(c0.y) | (code16(c1.y) << 16), code16(c2.y)};
+    } else {
+      const global_ptr<float> o = as_global(reinterpret_cast<float*>(fr.comp_out)) + pix1 * 3;
+      o[0] = c0.y; o[1] = c1.y; o[2] = c2.y;
+    }
+    if (fr.mask_f64) as_global(fr.mask_f64)[pix1] = m1;
+    if (fr.mask_i32) as_global(fr.mask_i32)[pix1] = (int32_t)floor(m1 * 255.0);
   }
   PH(6)
   PH_FLUSH(4)
