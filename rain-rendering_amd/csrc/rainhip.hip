@@ -231,7 +231,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   double* wtab_big;                 // [frame][SLOW_CAP][2][MAX_R+1] the same for the first SLOW_CAP large-radius drops of a frame (k_blur_big_weights)
   const uint8_t* tex_pad;           // the textures with their 2-texel zero border, as k_tile stages them (k_pad_textures); NULL: staged byte by byte
   const int64_t* tex_poff;          // [texture] offset of its padded copy (a multiple of 16)
-  uint2* fov_erec;                  // [frame][n_fov][drops] k_fov_dda's edge records (rr_device.h dda_edge_record)
+  uint4* fov_erec;                  // [frame][n_fov][drops] k_fov_dda's edge records (rr_device.h dda_edge_record: 16 bytes)
   int32_t* fov_list;                // [frame][drops] drops k_fov_dda leaves to k_fov_spans (wrapping polygons, float64 decisions)
   int32_t* fov_list_n;              // [frame] their number
   uint8_t* blended;                 // [frame][drop] 1: the drop is composited (k_colour)
@@ -934,11 +934,13 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     x = (int)(v & 0xffffu);
     y = (int)(v >> 16);
   };
-  // The records of the edges {k, k + 1} (upper end first) go to global memory, [frame][edge][drop]: a wave stores 512 bytes
-  // per edge in one piece, a cursor loads its next record an edge (~30 rows) ahead.  (In LDS, 12 bytes per vertex and lane,
-  // they left room for 10 waves per CU instead of 24: 7.8 ms against the 3.7 of round 5's kernel, whose row loop waits on
-  // dependent vector instructions more than it issues -- r06 A/B log.)
-  uint2* erec = sc.fov_erec + (int64_t)f * N * max_drops + i;
+  // The records of the edges {k, k + 1} (upper end first) go to global memory, [frame][edge][drop], 16 bytes each: the
+  // walker's step, the packed outline constants, the edge's pixels on its first row and its lower end.  A wave stores 1 KB
+  // per edge in one piece, a cursor loads its next record an edge (~30 rows) ahead.  (In LDS they left room for 10 waves per
+  // CU instead of 24: 7.8 ms against 5.5 -- r06 A/B log.)  Round 6, second form: with the first row's pixels and the lower
+  // end in the record a lane that takes an edge evaluates neither DdaCursors' pixels() nor a vertex fetch -- the path the whole
+  // wave walks through on the 89 % of the rows on which one of its 64 cursors meets a vertex.
+  uint4* erec = sc.fov_erec + (int64_t)f * N * max_drops + i;
   const bool cvr = cv_rule && on_map;                          // (a vertex off the map: the span rule, like the oracle)
   if (mine) {
     for (int k = 0; k < N; k++) {
@@ -946,23 +948,21 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
       vertex_xy(k, x0, y0);
       vertex_xy(k + 1 == N ? 0 : k + 1, x1, y1);
       const bool swp = y1 < y0;
-      uint32_t w0, w1;
-      dda_edge_record(swp ? x1 : x0, swp ? y1 : y0, swp ? x0 : x1, swp ? y0 : y1, cvr, w0, w1);
-      erec[(int64_t)k * max_drops] = make_uint2(w0, w1);
+      uint32_t r[4];
+      dda_edge_record(swp ? x1 : x0, swp ? y1 : y0, swp ? x0 : x1, swp ? y0 : y1, cvr, r);
+      erec[(int64_t)k * max_drops] = make_uint4(r[0], r[1], r[2], r[3]);
     }
   }
-  auto vertex = [&](int kk) { return pix[kk * 64 + lane]; };
-  auto rec = [&](int kk, uint32_t& w0, uint32_t& w1) {
-    const uint2 v = erec[(int64_t)kk * max_drops];
-    w0 = v.x;
-    w1 = v.y;
+  auto rec = [&](int kk, uint32_t r[4]) {
+    const uint4 v = erec[(int64_t)kk * max_drops];
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
   };
-  DdaCursors<decltype(vertex), decltype(rec)> cur;
-  if (mine) cur.init(vertex, rec, N, ktop);
+  DdaCursors<decltype(rec)> cur;
+  if (mine) cur.init(rec, N, ktop, pix[ktop * 64 + lane]);
   uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;
   for (int y = 0; y < Hp; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
-    if (mine && y >= ytop && y <= ybot) cur.row(vertex, rec, y, lo, hi);
+    if (mine && y >= ytop && y <= ybot) cur.row(rec, y, lo, hi);
     const int a = imax(lo, 0), b = imin(hi, dm.We - 1);
     if (mine) out[(int64_t)y * Dp] = (y < dm.He && a <= b) ? ((uint32_t)a | ((uint32_t)(b + 1) << 16)) : 0u;
   }

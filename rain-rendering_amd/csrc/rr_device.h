@@ -982,93 +982,131 @@ RR_HD int mul24i(int a, int b) {                            // a * b for |a|, |b
 #endif
 }
 // Record of the undirected edge between an upper end (xu, yu) and a lower end (xl, yl), den = yl - yu, dx = xl - xu, made
-// before the walk (all lanes busy: this is where the divisions are):
-//   w0 = dx16 = ((dx << 17) + den) / (2 den), C division: OpenCV's walker step -- and qs = w0 >> 16 (the fraction of
-//        2 dx / 2 den is 0 or at least 1 / 2046: the half a unit dx16 is rounded by never reaches the next integer)
-//   w1 = hh | tl << 11 | same << 22 | walker << 23     (same: th = tl; else th = 2 den - tl)
-RR_HD void dda_edge_record(int xu, int yu, int xl, int yl, bool cv, uint32_t& w0, uint32_t& w1) {
-  const int den = yl - yu, dx = xl - xu;
-  w0 = w1 = 0;
-  if (den <= 0) return;                                      // horizontal: the cursor takes both end points
-  int dx16, hh, hr;
-  edge_cv_consts(dx, den, dx16, hh, hr);
-  w0 = (uint32_t)dx16;
-  if (!cv) w1 = 0u | ((uint32_t)den << 11) | (1u << 22);
-  else if (den > iabs(dx)) w1 = 0u | ((uint32_t)(den + 1) << 11) | (1u << 22) | (1u << 23);
-  else w1 = (uint32_t)hh | ((uint32_t)hr << 11) | (1u << 23);
-}
-// V: vertex(k) = x | y << 16.  E: rec(k, w0, w1) = the record of edge {k, k + 1} (upper end first).
+// before the walk (all lanes busy: this is where the divisions are), 16 bytes (round 6; 8 before):
+//   r[0] = dx16 = ((dx << 17) + den) / (2 den), C division: OpenCV's walker step -- and qs = r[0] >> 16 (the fraction of
+//          2 dx / 2 den is 0 or at least 1 / 2046: the half a unit dx16 is rounded by never reaches the next integer)
+//   r[1] = hh | tl << 11 | same << 22 | walker << 23     (same: th = tl; else th = 2 den - tl)
+//   r[2] = the edge's pixels on its FIRST row (the upper end's), lo | hi << 16 -- DdaCursors::pixels at t = 0, evaluated here
+//          once instead of by every lane of a wave whenever one of its 64 cursors takes an edge
+//   r[3] = the lower end, x | y << 16: a cursor needs no vertex table while it walks
+// A horizontal edge {k, k + 1} (xu = vertex k, xl = vertex k + 1 by the callers' convention): r[1] = 0, r[2] = both end
+// points' span, and r[0] = vertex k's x -- the end of the edge for the cursor that walks the vertices downwards in index.
 struct DdaSide {                                             // one cursor: its current edge (xa, ya) .. (xb, yb)
   int xa, xb, yb, kv;
+  int mn, mx;                                                // min / max of xa, xb: the edge's own x range
   int Q, R, W;                                               // at the row the cursor stands on
   int dn, hh, tl, th, qs, rs, d16, wk;                       // the edge's constants (dn == 0: horizontal; wk: OpenCV's walker)
-  uint32_t n_pix, n_w0, n_w1;                                // the NEXT vertex and edge, fetched an edge ahead
+  uint32_t n_r0, n_r1, n_r2, n_r3;                           // the NEXT edge's record, fetched an edge ahead
 };
-template <class V, class E>
+// the edge's constants from (its ends and) the first two words of its record; the cursor at t = 0
+RR_HD void dda_take_edge(DdaSide& S, int xa, int ya, int xb, int yb, uint32_t w0, uint32_t w1) {
+  S.xa = xa;
+  S.xb = xb;
+  S.yb = yb;
+  S.mn = imin(xa, xb);
+  S.mx = imax(xa, xb);
+  const int den = yb - ya, dx = xb - xa;
+  S.dn = 2 * den;
+  S.Q = 0;
+  S.R = 0;
+  S.W = 32768;
+  S.d16 = (int)w0;
+  S.wk = (int)((w1 >> 23) & 1u);
+  S.hh = (int)(w1 & 0x7ffu);
+  S.tl = (int)((w1 >> 11) & 0x7ffu);
+  S.th = ((w1 >> 22) & 1u) ? S.tl : S.dn - S.tl;
+  S.qs = S.d16 >> 16;
+  S.rs = 2 * dx - mul24i(S.qs, S.dn);
+}
+// the pixels [x0, x1] of the cursor's edge on the row it stands on (y; y == yb: its last row)
+RR_HD void dda_pixels(const DdaSide& S, int y, int& x0, int& x1) {
+  const int base = S.xa + S.Q;
+  x0 = imax(base - S.hh + (S.R >= S.tl ? 1 : 0), S.mn);     // (the clamps: no-ops for the one-pixel forms)
+  x1 = imin(base + S.hh + (S.R >= S.th ? 1 : 0), S.mx);
+  if (S.wk && y < S.yb) {                                    // OpenCV's walker: rows ya <= y < yb
+    const int sx = S.xa + (S.W >> 16);
+    x0 = imin(x0, sx);
+    x1 = imax(x1, sx);
+  }
+  if (S.dn == 0) {                                           // horizontal: both end points
+    x0 = S.mn;
+    x1 = S.mx;
+  }
+}
+RR_HD void dda_edge_record(int xu, int yu, int xl, int yl, bool cv, uint32_t r[4]) {
+  const int den = yl - yu, dx = xl - xu;
+  r[0] = r[1] = 0u;
+  if (den > 0) {                                             // (horizontal: the cursor takes both end points)
+    int dx16, hh, hr;
+    edge_cv_consts(dx, den, dx16, hh, hr);
+    r[0] = (uint32_t)dx16;
+    if (!cv) r[1] = 0u | ((uint32_t)den << 11) | (1u << 22);
+    else if (den > iabs(dx)) r[1] = 0u | ((uint32_t)(den + 1) << 11) | (1u << 22) | (1u << 23);
+    else r[1] = (uint32_t)hh | ((uint32_t)hr << 11) | (1u << 23);
+  }
+  DdaSide S;
+  dda_take_edge(S, xu, yu, xl, yl, r[0], r[1]);
+  int x0, x1;
+  dda_pixels(S, yu, x0, x1);
+  r[2] = (uint32_t)(x0 & 0xffff) | ((uint32_t)(x1 & 0xffff) << 16);
+  r[3] = (uint32_t)(xl & 0xffff) | ((uint32_t)(yl & 0xffff) << 16);
+  if (den <= 0) r[0] = (uint32_t)(xu & 0xffff);
+}
+// E: rec(k, r) = the record of edge {k, k + 1} (upper end first).
+template <class E>
 struct DdaCursors {
   DdaSide s0, s1;                                            // cursor 0 walks the vertices upwards in index from the top vertex, cursor 1 downwards
   int used, N;
   template <int C>
   RR_HD static int next_k(int k, int n) { return C == 0 ? (k + 1 == n ? 0 : k + 1) : (k == 0 ? n - 1 : k - 1); }
-  // the cursor moves on to the edge that was fetched ahead (from (xb, yb), which becomes (xa, ya)) and fetches the one after it
+  // the record of the edge a cursor at vertex kv takes next
   template <int C>
-  RR_HD void advance_edge(DdaSide& S, const V& vertex, const E& rec) const {
-    const int ya = S.yb;
-    S.xa = S.xb;
-    S.xb = (int)(S.n_pix & 0xffffu);
-    S.yb = (int)(S.n_pix >> 16);
-    const uint32_t w0 = S.n_w0, w1 = S.n_w1;
+  RR_HD void fetch(DdaSide& S, const E& rec) const {
+    uint32_t r[4];
+    rec(C == 0 ? S.kv : next_k<C>(S.kv, N), r);
+    S.n_r0 = r[0]; S.n_r1 = r[1]; S.n_r2 = r[2]; S.n_r3 = r[3];
+  }
+  // the cursor moves on to the edge that was fetched ahead (from (xb, yb), which becomes (xa, ya)) and fetches the one after
+  // it; STEP: the cursor stands on the new edge's first row, whose pixels come from the record -- it is left on the second
+  template <int C, bool STEP>
+  RR_HD void advance_edge(DdaSide& S, const E& rec, int& lo, int& hi) const {
+    const int xa = S.xb, ya = S.yb;
+    uint32_t w0 = S.n_r0;
+    const uint32_t w1 = S.n_r1, w2 = S.n_r2, w3 = S.n_r3;
     S.kv = next_k<C>(S.kv, N);
-    {
-      const int kn = next_k<C>(S.kv, N);
-      S.n_pix = vertex(kn);
-      rec(C == 0 ? S.kv : kn, S.n_w0, S.n_w1);
+    fetch<C>(S, rec);
+    int xe = (int)(w3 & 0xffffu);
+    const int ye = (int)(w3 >> 16);
+    if (ye == ya) {                                          // horizontal: which end the cursor arrives at depends on its direction
+      if (C == 1) xe = (int)w0;
+      w0 = 0u;
     }
-    const int den = S.yb - ya, dx = S.xb - S.xa;
-    S.dn = 2 * den;
-    S.Q = 0;
-    S.R = 0;
-    S.W = 32768;
-    S.d16 = (int)w0;
-    S.wk = (int)((w1 >> 23) & 1u);
-    S.hh = (int)(w1 & 0x7ffu);
-    S.tl = (int)((w1 >> 11) & 0x7ffu);
-    S.th = ((w1 >> 22) & 1u) ? S.tl : S.dn - S.tl;
-    S.qs = S.d16 >> 16;
-    S.rs = 2 * dx - mul24i(S.qs, S.dn);
+    dda_take_edge(S, xa, ya, xe, ye, w0, w1);
+    if (STEP) {
+      lo = imin(lo, (int)(w2 & 0xffffu));
+      hi = imax(hi, (int)(w2 >> 16));
+      if (S.dn > 0) {                                        // t = 1 (a horizontal edge: the next vertex follows on this row)
+        const int carry = S.rs >= S.dn ? 1 : 0;
+        S.R = S.rs - (carry ? S.dn : 0);
+        S.Q = S.qs + carry;
+        S.W = 32768 + S.d16;
+      }
+    }
   }
   template <int C>
-  RR_HD void init_side(DdaSide& S, const V& vertex, const E& rec, int ktop) const {
-    const uint32_t p0 = vertex(ktop);
-    S.xb = (int)(p0 & 0xffffu);                              // "the end of the edge before": the top vertex
-    S.yb = (int)(p0 >> 16);
+  RR_HD void init_side(DdaSide& S, const E& rec, int ktop, uint32_t top_xy) const {
+    S.xb = (int)(top_xy & 0xffffu);                          // "the end of the edge before": the top vertex
+    S.yb = (int)(top_xy >> 16);
     S.kv = ktop;
-    const int k1 = next_k<C>(ktop, N);
-    S.n_pix = vertex(k1);
-    rec(C == 0 ? ktop : k1, S.n_w0, S.n_w1);
-    advance_edge<C>(S, vertex, rec);
+    fetch<C>(S, rec);
+    int lo = 0, hi = 0;
+    advance_edge<C, false>(S, rec, lo, hi);
   }
-  RR_HD void init(const V& vertex, const E& rec, int n, int ktop) {
+  RR_HD void init(const E& rec, int n, int ktop, uint32_t top_xy) {      // top_xy: the top vertex, x | y << 16
     N = n;
     used = 2;                                                // edges taken so far (both cursors together; N in all)
-    init_side<0>(s0, vertex, rec, ktop);
-    init_side<1>(s1, vertex, rec, ktop);
-  }
-  // the pixels [x0, x1] of the cursor's edge on the row it stands on (y; y == yb: its last row)
-  RR_HD static void pixels(const DdaSide& S, int y, int& x0, int& x1) {
-    const int mn = imin(S.xa, S.xb), mx = imax(S.xa, S.xb);
-    const int base = S.xa + S.Q;
-    x0 = imax(base - S.hh + (S.R >= S.tl ? 1 : 0), mn);      // (the clamps: no-ops for the one-pixel forms)
-    x1 = imin(base + S.hh + (S.R >= S.th ? 1 : 0), mx);
-    if (S.wk && y < S.yb) {                                  // OpenCV's walker: rows ya <= y < yb
-      const int sx = S.xa + (S.W >> 16);
-      x0 = imin(x0, sx);
-      x1 = imax(x1, sx);
-    }
-    if (S.dn == 0) {                                         // horizontal: both end points
-      x0 = mn;
-      x1 = mx;
-    }
+    init_side<0>(s0, rec, ktop, top_xy);
+    init_side<1>(s1, rec, ktop, top_xy);
   }
   RR_HD static void step(DdaSide& S) {                       // a row down the current edge
     const int r = S.R + S.rs;
@@ -1078,29 +1116,24 @@ struct DdaCursors {
     S.W += S.d16;
   }
   template <int C>
-  RR_HD void side_row(DdaSide& S, const V& vertex, const E& rec, int y, int& lo, int& hi) {
+  RR_HD void side_row(DdaSide& S, const E& rec, int y, int& lo, int& hi) {
     {
       int x0, x1;
-      pixels(S, y, x0, x1);
+      dda_pixels(S, y, x0, x1);
       lo = imin(lo, x0);
       hi = imax(hi, x1);
     }
     step(S);                                                 // (unused once the cursor switches below)
     while (y == S.yb && used < N) {                          // a vertex row: the edges that start here touch it too
       used++;
-      advance_edge<C>(S, vertex, rec);
-      int x0, x1;
-      pixels(S, y, x0, x1);                                  // the new edge's first row (a horizontal one: both end points)
-      lo = imin(lo, x0);
-      hi = imax(hi, x1);
-      if (y < S.yb) step(S);                                 // (a horizontal edge: the next vertex follows on this row)
+      advance_edge<C, true>(S, rec, lo, hi);
     }
   }
-  RR_HD void row(const V& vertex, const E& rec, int y, int& lo, int& hi) {
+  RR_HD void row(const E& rec, int y, int& lo, int& hi) {
     lo = 1 << 30;
     hi = -(1 << 30);
-    side_row<0>(s0, vertex, rec, y, lo, hi);
-    side_row<1>(s1, vertex, rec, y, lo, hi);
+    side_row<0>(s0, rec, y, lo, hi);
+    side_row<1>(s1, rec, y, lo, hi);
   }
 };
 

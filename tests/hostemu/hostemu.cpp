@@ -114,20 +114,19 @@ int emu_dda_check(const int32_t* px, const int32_t* py, int n, int He, int We, i
     if (py[k] < ytop) { ytop = py[k]; ktop = k; }
     if (py[k] > ybot) ybot = py[k];
   }
-  auto vertex = [&](int k) { return (uint32_t)px[k] | ((uint32_t)py[k] << 16); };
-  std::vector<uint32_t> r0(n), r1(n);
+  std::vector<uint32_t> recs(4 * (size_t)n);
   for (int k = 0; k < n; k++) {                   // the record of edge {k, k + 1}, upper end first (k_fov_dda makes them before its row loop)
     const int j = k + 1 == n ? 0 : k + 1;
     const bool swp = py[j] < py[k];
-    dda_edge_record(swp ? px[j] : px[k], swp ? py[j] : py[k], swp ? px[k] : px[j], swp ? py[k] : py[j], rule == 1, r0[k], r1[k]);
+    dda_edge_record(swp ? px[j] : px[k], swp ? py[j] : py[k], swp ? px[k] : px[j], swp ? py[k] : py[j], rule == 1, &recs[4 * (size_t)k]);
   }
-  auto rec = [&](int k, uint32_t& a, uint32_t& b) { a = r0[k]; b = r1[k]; };
-  DdaCursors<decltype(vertex), decltype(rec)> cur;
-  cur.init(vertex, rec, n, ktop);
+  auto rec = [&](int k, uint32_t r[4]) { for (int q = 0; q < 4; q++) r[q] = recs[4 * (size_t)k + q]; };
+  DdaCursors<decltype(rec)> cur;
+  cur.init(rec, n, ktop, (uint32_t)px[ktop] | ((uint32_t)py[ktop] << 16));
   int bad = 0;
   for (int y = 0; y < He; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
-    if (y >= ytop && y <= ybot) cur.row(vertex, rec, y, lo, hi);
+    if (y >= ytop && y <= ybot) cur.row(rec, y, lo, hi);
     const int a = imax(lo, 0), b = imin(hi, We - 1);
     int xl, xr;
     const bool any = rule == 1 ? fov_rowspan_cv(px, py, n, y, We, xl, xr) : fov_rowspan(px, py, n, y, We, xl, xr);
