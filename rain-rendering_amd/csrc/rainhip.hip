@@ -2898,6 +2898,21 @@ __device__ inline void blur4(const double* c0, int st, W hw, int r, double& acc0
   }
 }
 
+// The same outputs one or two per lane, each with its own chain (no shared window): for the tiles of k_blur_small whose
+// four-output blocks leave most of the wave idle (a 4 x 14 tile of radius 2 is 16 blocks of the row pass: a quarter of the
+// lanes).  The arithmetic of an output is blur4's, operand for operand.
+template <int NO, class W>
+__device__ inline void blur_n(const double* c0, int st, W hw, int r, double (&acc)[NO]) {
+  const double wc = hw(r);
+#pragma unroll
+  for (int j = 0; j < NO; j++) acc[j] = c0[__mul24(j, st)] * wc;
+  for (int ii = -r; ii < 0; ii++) {
+    const double w = hw(ii + r);
+#pragma unroll
+    for (int j = 0; j < NO; j++) acc[j] = acc[j] + (c0[__mul24(j + ii, st)] + c0[__mul24(j - ii, st)]) * w;
+  }
+}
+
 #ifdef RR_EXPERIMENTS                // (r04's register-staged form: the LDS-DMA kernel below replaced it in r05; kept for A/B builds, RR_OPT_BLUR_DMA 0)
 // ---------------------------------------------------------------------------
 // fused defocus blur: both axes of the separable filter through LDS
@@ -3425,8 +3440,27 @@ __global__ __launch_bounds__(256, 4) void k_blur_small(const FrameDesc* frames, 
     }
     const float inv_tw = 1.0f / (float)tw;
     // axis 0 (rows): a lane owns data column x and four consecutive rows
-    {
-      const int nv = (php >> 2) * tw;
+    const int nv4 = (php >> 2) * tw;                 // four-row blocks of the row pass
+    if (nv4 <= 16) {                                 // (r06) a quarter of the wave or less: an output per lane, php * tw <= 64 lanes
+      const int idx = lane;
+      if (idx < 4 * nv4) {
+        const int row = (int)(((float)idx + 0.5f) * inv_tw), x = idx - row * tw;
+        double a[1];
+        blur_n<1>(X + (__mul24(row + r1, tw) + x), tw, [&](int k) { return readlane_f64(w1, r1 - k); }, r1, a);
+        Y[__mul24(row, yp) + 2 * r2 + x] = a[0];
+      }
+    } else if (nv4 <= 32) {                          // half the wave: two rows per lane
+      const int idx = lane;
+      if (idx < 2 * nv4) {
+        const int rb = (int)(((float)idx + 0.5f) * inv_tw), x = idx - rb * tw;
+        double a[2];
+        blur_n<2>(X + (__mul24(2 * rb + r1, tw) + x), tw, [&](int k) { return readlane_f64(w1, r1 - k); }, r1, a);
+        double* o = Y + (__mul24(2 * rb, yp) + 2 * r2 + x);
+        o[0] = a[0];
+        o[yp] = a[1];
+      }
+    } else {
+      const int nv = nv4;
       for (int idx = lane; idx < nv; idx += 64) {
         const int rb = (int)(((float)idx + 0.5f) * inv_tw), x = idx - rb * tw;
         const double* c0 = X + (__mul24(4 * rb + r1, tw) + x);       // (24-bit multiply-add: see the note at the prefetch below)
@@ -3442,9 +3476,27 @@ __global__ __launch_bounds__(256, 4) void k_blur_small(const FrameDesc* frames, 
     wave_lds_sync();
     PH(1)                                           // row pass
     // axis 1 (columns) -> global: a lane owns row y and four consecutive columns; lanes run down the rows
-    {
-      const int ncb = (pw + 3) >> 2, nh = ncb * ph;
-      const float inv_ph = 1.0f / (float)ph;
+    const int ncb = (pw + 3) >> 2, nh = ncb * ph;
+    const float inv_ph = 1.0f / (float)ph;
+    if (nh <= 16 && r2 > 0) {                        // (r06) a column per lane: pw * ph <= 64 lanes
+      const int idx = lane;
+      if (idx < pw * ph) {
+        const int x = (int)(((float)idx + 0.5f) * inv_ph), yq = idx - x * ph;
+        double a[1];
+        blur_n<1>(Y + (__mul24(yq, yp) + x + r2), 1, [&](int k) { return readlane_f64(w2, r2 - k); }, r2, a);
+        tile[(int64_t)yq * cur.epitch + cur.epad + x] = a[0];
+      }
+    } else if (nh <= 32 && r2 > 0) {                 // two columns per lane
+      const int idx = lane, nc2 = (pw + 1) >> 1;
+      if (idx < nc2 * ph) {
+        const int cb = (int)(((float)idx + 0.5f) * inv_ph), yq = idx - cb * ph, xo = 2 * cb;
+        double a[2];
+        blur_n<2>(Y + (__mul24(yq, yp) + xo + r2), 1, [&](int k) { return readlane_f64(w2, r2 - k); }, r2, a);
+        double* o = tile + (int64_t)yq * cur.epitch + cur.epad + xo;
+        o[0] = a[0];
+        if (xo + 1 < pw) o[1] = a[1];
+      }
+    } else {
       for (int idx = lane; idx < nh; idx += 64) {
         const int cb = (int)(((float)idx + 0.5f) * inv_ph), yq = idx - cb * ph;
         const double* c0 = Y + (__mul24(yq, yp) + 4 * cb + r2);
