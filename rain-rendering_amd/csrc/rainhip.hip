@@ -842,13 +842,9 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
   const int N = cam.n_fov;
-  __shared__ float s_phi32[2][RR_MAX_FOV];
-  extern __shared__ uint32_t s_pix_dyn[];                      // [waves][N vertices][64 lanes]: pix[vertex][lane] = x | y << 16; then the edge records
-  if (threadIdx.x < RR_MAX_FOV) {
-    s_phi32[0][threadIdx.x] = (float)cam.phi_cos[threadIdx.x];
-    s_phi32[1][threadIdx.x] = (float)cam.phi_sin[threadIdx.x];
-  }
-  __syncthreads();
+  // NO LDS at all (r06): the tile / blur kernels of the other stream fill a CU's 160 KB, and a workgroup that needs a single
+  // byte of it waits for one of theirs to leave.  The spin terms come from the kernel arguments (scalar loads, k is
+  // wave-uniform), the vertex pixels wait in the fourth word of the edge records' slots (pixv below).
   const int i = (blockIdx.x * DDA_WAVES + wave) * 64 + lane;   // this lane's drop
   const bool act = i < fr.n_drops;
   const int64_t gi = (int64_t)f * max_drops + (act ? i : 0);
@@ -856,7 +852,11 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     if (act) sc.npts[gi] = -1;
     return;
   }
-  uint32_t* pix = s_pix_dyn + wave * N * 64;
+  // vertex k's pixel, x | y << 16: word 3 of the lane's record slot of edge k -- the record of edge k is written (dda_edge_record
+  // below) after vertices k and k + 1 have been read, and replaces it with the edge's lower end
+  uint4* const erec = sc.fov_erec + (int64_t)f * N * max_drops + (act ? i : 0);
+  auto pixv = [&](int kk) -> uint32_t& { return reinterpret_cast<uint32_t*>(erec + (int64_t)kk * max_drops)[3]; };
+  uint32_t top_xy = 0;
   // ---- 1. vertices ----
   int uns = 0;                                                 // reason bits (rr_device.h): float64 has to decide
   int count_true = 0, count_false = 0;
@@ -871,9 +871,10 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     int y_prev = 0, y0v = 0;
     for (int k = 0; k < N; k++) {
       float az, er, pxf, pyf;
-      fov_vertex32(F, (float)cam.radius, s_phi32[0][k], s_phi32[1][k], dm.He, dm.We, az, er, pxf, pyf, uns);
+      fov_vertex32(F, (float)cam.radius, (float)cam.phi_cos[k], (float)cam.phi_sin[k], dm.He, dm.We, az, er, pxf, pyf, uns);
       const int ix = (int)pxf, iy = (int)pyf;
-      pix[k * 64 + lane] = (uint32_t)(ix & 0xffff) | ((uint32_t)(iy & 0xffff) << 16);
+      const uint32_t vxy = (uint32_t)(ix & 0xffff) | ((uint32_t)(iy & 0xffff) << 16);
+      pixv(k) = vxy;
       on_map = on_map && ix >= 0 && ix < dm.We && iy >= 0 && iy < dm.He;      // (fov_fill_rule_cv_applies)
       const int r = imin(imax(iy, 0), dm.He - 1);
       if (k == 0) { az0 = az; er0 = er; r_first = r; y0v = iy; }
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
           dir = sg;
         }
       }
-      if (iy < ytop) { ytop = iy; ktop = k; }
+      if (iy < ytop) { ytop = iy; ktop = k; top_xy = vxy; }
       ybot = imax(ybot, iy);
       az_prev = az; er_prev = er; y_prev = iy;
     }
@@ -906,11 +907,11 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     }
   }
   if (act) {                                                   // a sliver: whether Clipper takes the path (poly_all_collinear) is float64's to say
-    const uint32_t v0 = pix[lane], va = pix[(N / 2) * 64 + lane];
+    const uint32_t v0 = pixv(0), va = pixv(N / 2);
     const int x0v = (int)(v0 & 0xffffu), y0v = (int)(v0 >> 16), ax = (int)(va & 0xffffu) - x0v, ay = (int)(va >> 16) - y0v;
     bool sure_nc = false;
     for (int k = 1; k < N; k++) {
-      const uint32_t v = pix[k * 64 + lane];
+      const uint32_t v = pixv(k);
       sure_nc = sure_nc || poly_surely_not_collinear_step(ax, ay, (int)(v & 0xffffu) - x0v, (int)(v >> 16) - y0v);
     }
     if (!sure_nc) uns |= 256;
@@ -929,28 +930,24 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
   if (mine) sc.npts[gi] = N;
   if (__ballot(mine) == 0ull) return;
   // ---- 2. spans of the sure drops: two cursors down from the top vertex (rr_device.h DdaCursors) ----
-  auto vertex_xy = [&](int kk, int& x, int& y) {
-    const uint32_t v = pix[kk * 64 + lane];
-    x = (int)(v & 0xffffu);
-    y = (int)(v >> 16);
-  };
   // The records of the edges {k, k + 1} (upper end first) go to global memory, [frame][edge][drop], 16 bytes each: the
   // walker's step, the packed outline constants, the edge's pixels on its first row and its lower end.  A wave stores 1 KB
   // per edge in one piece, a cursor loads its next record an edge (~30 rows) ahead.  (In LDS they left room for 10 waves per
   // CU instead of 24: 7.8 ms against 5.5 -- r06 A/B log.)  Round 6, second form: with the first row's pixels and the lower
   // end in the record a lane that takes an edge evaluates neither DdaCursors' pixels() nor a vertex fetch -- the path the whole
   // wave walks through on the 89 % of the rows on which one of its 64 cursors meets a vertex.
-  uint4* erec = sc.fov_erec + (int64_t)f * N * max_drops + i;
   const bool cvr = cv_rule && on_map;                          // (a vertex off the map: the span rule, like the oracle)
   if (mine) {
+    const uint32_t vfirst = pixv(0);
+    uint32_t va = vfirst;
     for (int k = 0; k < N; k++) {
-      int x0, y0, x1, y1;
-      vertex_xy(k, x0, y0);
-      vertex_xy(k + 1 == N ? 0 : k + 1, x1, y1);
+      const uint32_t vb = k + 1 == N ? vfirst : pixv(k + 1);   // (read before record k + 1 overwrites it)
+      const int x0 = (int)(va & 0xffffu), y0 = (int)(va >> 16), x1 = (int)(vb & 0xffffu), y1 = (int)(vb >> 16);
       const bool swp = y1 < y0;
       uint32_t r[4];
       dda_edge_record(swp ? x1 : x0, swp ? y1 : y0, swp ? x0 : x1, swp ? y0 : y1, cvr, r);
       erec[(int64_t)k * max_drops] = make_uint4(r[0], r[1], r[2], r[3]);
+      va = vb;
     }
   }
   auto rec = [&](int kk, uint32_t r[4]) {
@@ -958,7 +955,7 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
   };
   DdaCursors<decltype(rec)> cur;
-  if (mine) cur.init(rec, N, ktop, pix[ktop * 64 + lane]);
+  if (mine) cur.init(rec, N, ktop, top_xy);
   uint32_t* out = sc.spans + (int64_t)f * Hp * Dp + i;
   for (int y = 0; y < Hp; y++) {
     int lo = 1 << 30, hi = -(1 << 30);
@@ -5516,13 +5513,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       if (dda) {
         HIPCHK(hipMemsetAsync(sc.fov_list_n, 0, sizeof(int32_t) * (size_t)n, fs));
         {
-          // (4 bytes of LDS per vertex and lane: the vertex' pixel)
-          const size_t lds = sizeof(uint32_t) * DDA_WAVES * 64 * (size_t)ctx->cam.n_fov;
-          if (!ctx->dda_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fov_dda), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * DDA_WAVES * 64 * RR_MAX_FOV)));
-            ctx->dda_attr = true;
-          }
-          hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 64 * DDA_WAVES - 1) / (64 * DDA_WAVES), n), dim3(64 * DDA_WAVES), lds, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp,
+          hipLaunchKernelGGL(k_fov_dda, dim3((max_drops + 64 * DDA_WAVES - 1) / (64 * DDA_WAVES), n), dim3(64 * DDA_WAVES), 0, fs, ctx->d_frames, dm, ctx->cam, D, Hp, Dp,
                              cv_rule ? 1 : 0, sc);
         }
         const dim3 lgrid(imin((int)grid.x, 8), n);           // the list is short: a few workgroups per frame walk it, in float64
