@@ -365,3 +365,38 @@ def test_fill_rule_option(setup):
     for o in res[0]:
         d = np.abs(o['image_u8'].astype(int) - base['image_u8'].astype(int))
         assert d.max() <= 1 and (d != 0).mean() < 0.05, (d.max(), (d != 0).mean())
+
+
+def test_raw_tile_kernels_agree(setup, tmp_path):
+    """Round 6's batch-wide wave-per-tile kernel (k_tile_rows: row walks for the rotate + INTER_AREA tiles, a lane per pixel for
+    the Big drops' bicubic warps up to 8192 pixels) against the kernels it took the work from -- k_tile (a workgroup per
+    tile) and k_tile_big (a thread per pixel), which still render what does not fit it: RR_OPT_TILE_ROWS 0 / 1 / 2 and the
+    number of shares the tile list is cut into give the same bits.  A KITTI frame and a frame of the nuScenes camera (f/1.8:
+    Big tiles on both sides of the pixel limit), two frames per call so that tiles are shared across frames."""
+    sc, bg, env, drops, rh, base = setup
+    sc2 = h.Scene(tmp_path, 450, 800, 1500, cam=h.NUSCENES, seed0=6100, far_fraction=0.2)
+    bg2, env2 = sc2.frame_inputs(0)
+    drops2 = sc2.product_drops(0)
+    for scn, b, e, d in ((sc, bg, env, drops), (sc2, bg2, env2, drops2)):
+        fr = dict(bg=b, rainy_bg=b, env_xyY=e, omega=scn.omega, drops=d)
+        outs = []
+        for opts in ({h.hb.RR_OPT_TILE_ROWS: 0}, {h.hb.RR_OPT_TILE_ROWS: 1}, {h.hb.RR_OPT_TILE_ROWS: 2},
+                     {h.hb.RR_OPT_TILE_ROWS: 2, h.hb.RR_OPT_ROWS_SHARES: 1}, {h.hb.RR_OPT_TILE_ROWS: 2, h.hb.RR_OPT_ROWS_SHARES: 8}):
+            alt = h.hb.RainHip(0)
+            try:
+                for k, v in opts.items():
+                    alt.set_option(k, v)
+                alt.set_streak_db(scn.db.streaks_light)
+                alt.set_camera(scn.cam)
+                outs.append((alt.render_frames([fr, fr]), [alt.batch_counts(0), alt.batch_counts(1)]))
+            finally:
+                alt.close()
+        ref = outs[0][0]
+        assert (ref[0]['status'] == 0).sum() > 0.5 * len(d) and ref[0]['mask'].max() > 0
+        for out, counts in outs[1:]:
+            for a, b_ in zip(ref, out):
+                for k in ('status', 'mask', 'mask_i32', 'image_u8', 'rainy_bg'):
+                    assert np.array_equal(a[k], b_[k]), k
+            pick = lambda c: [int(c[0]), int(c[1]), int(c[5]), int(c[7])]                # rotate / generic / Big tiles rendered, tiles shared
+            # (which of two identical drops of different frames renders their tile is the election's business: the call's totals)
+            assert np.sum([pick(c) for c in counts], axis=0).tolist() == np.sum([pick(c) for c in outs[0][1]], axis=0).tolist()
