@@ -4,20 +4,22 @@
 //
 // The chain of one call (grid.y = frame; DESIGN.md section 5 has the measurements):
 //   second stream (RR_OPT_COLOUR_STREAM), the colour branch -- three numbers per drop:
-//     k_fov_dda        a thread per drop: FOV polygon in float with error bounds, row spans by two cursors  (k_fov_walk:
-//                      incremental cursors, an option; k_fov_spans<NCH, false>: edge-parallel, float64 / caller-made polygons)
+//     k_fov_dda        a thread per drop, no LDS: FOV polygon in float with error bounds, row spans by two cursors under OpenCV's
+//                      fill rule (16-byte edge records)  (k_fov_spans<NCH, false>: edge-parallel, float64 / caller-made polygons)
 //     k_fov_spans<NCH, true>   the drops float cannot decide and the wrapping polygons, from the frame's list, in float64
 //     k_fov_sums32 / k_fov_sums   workgroup (frame, band of map rows, chunk of drops): prefix rows in LDS, P[xr+1] - P[xl]
 //     (general path, maps beyond the fast path's limits or RR_OPT_FOV_FILL_RULE: k_fov_poly_general, k_env_prefix,
 //      k_env_consts, k_fov_sums_general)
 //   caller's stream:
-//     k_plan           one thread per drop: geometry, homography / rotation, CoC, footprint -> DropPlan
+//     k_plan           one thread per drop: geometry, homography / rotation, CoC, footprint -> DropPlan, raw-tile key, list record
 //     k_scan           per-frame exclusive scan of tile sizes -> arena offsets (+ the frame's zero line)
-//     k_dedup          drops with bit-identical raw-tile parameters share one tile (batch-wide election)
-//     k_lists          work lists: rotate/resize tiles, Big tiles (+ pixel prefix), generic, blur items by size
-//     k_tile_generic / k_tile_big / k_tile   raw alpha tiles: rare modes; bicubic warpPerspective, a thread per pixel;
-//                      rotate + flip + INTER_AREA, a workgroup per tile with the texture in LDS
-//     k_blur_weights, k_blur_small, k_blur_fused_dma (k_blur_fused), k_blur_big_weights, k_blur<0|1>
+//     k_dedup          drops with equal raw-tile keys share one tile (batch-wide election)
+//     k_lists, k_rows_scatter, k_rows_shares   work lists from the list records; the batch's tiles bucketed by texture, cut into shares
+//     k_tile_rows      raw alpha tiles of the whole batch (round 6): a wave per tile, the bucket's texture resident in LDS -- row
+//                      walks for rotate + flip + INTER_AREA, a lane per pixel for the Big drops' bicubic warpPerspective
+//     k_tile_generic / k_tile_big / k_tile   what k_tile_rows does not take: rare modes; Big tiles of more than 8192 pixels, a
+//                      thread per pixel; integer-ratio and oversized rotate tiles, a workgroup per tile
+//     k_blur_weights, k_blur_small, k_blur_fused_dma (-DRR_EXPERIMENTS: k_blur_fused), k_blur_big_weights, k_blur<0|1>
 //                      separable defocus blur of the effective tile: a wave per small tile; LDS sub-tiles staged by
 //                      LDS-DMA for radii 5..48; zero-skipping taps for larger ones
 //     -- join --
@@ -28,7 +30,7 @@
 //     k_means, k_finalize16 (k_finalize), [k_png_image, k_png_mask, k_pngz_blocks, k_pngz_pack]
 //                      mean-contrast shift, clip, truncating u8 quantisation; optional PNG scanlines / zlib streams
 //   elsewhere: k_particles / k_particle_draws (drop tables born on the device), k_png_unfilter (input files' scanlines),
-//   k_pad_textures, k_copy_pieces / k_copy_small (batched copies, descriptors)
+//   k_pad_textures, k_pair_textures, k_copy_pieces / k_copy_small (batched copies, descriptors)
 // rr_prepass.h holds the fog / environment-map pre-pass kernels, rr_host.cpp the host-only helpers.
 #include <hip/hip_runtime.h>
 
@@ -232,6 +234,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   const uint8_t* tex_pad;           // the textures with their 2-texel zero border, as k_tile stages them (k_pad_textures); NULL: staged byte by byte
   const int64_t* tex_poff;          // [texture] offset of its padded copy (a multiple of 16)
   uint4* fov_erec;                  // [frame][n_fov][drops] k_fov_dda's edge records (rr_device.h dda_edge_record: 16 bytes)
+  uint32_t* fov_pix;                // [frame][n_fov][drops] k_fov_dda's vertex pixels, x | y << 16 (a wave stores 256 contiguous bytes per vertex)
   int32_t* fov_list;                // [frame][drops] drops k_fov_dda leaves to k_fov_spans (wrapping polygons, float64 decisions)
   int32_t* fov_list_n;              // [frame] their number
   uint8_t* blended;                 // [frame][drop] 1: the drop is composited (k_colour)
@@ -821,22 +824,22 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
 // issued instructions per drop, most of them with few lanes busy -- the kernel saturates the vector AND the scalar unit.
 // Here a lane owns a drop from beginning to end:
 //   1. the N vertices in float (fov_vertex32), the wrap test against the previous vertex, the predicates' error bounds --
-//      fov_polygon_auto lane by lane; the vertex pixels go to wave-private LDS as pix[vertex][lane] (a lane reading its own
-//      vertex k touches bank `lane`: no conflicts whatever k);
+//      fov_polygon_auto lane by lane; the vertex pixels wait in global memory ([vertex][drop]; rounds 4-5: in wave-private
+//      LDS);
 //   2. a drop whose polygon float can decide and that does not wrap has N vertices on a closed curve that every map row
 //      crosses at most twice (a circle around the drop's direction that contains no pole): two cursors walk down from its
 //      top vertex, one along each side, and every row's span is the min / max over the edges that touch the row -- the
 //      very candidates fov_rowspan / k_fov_spans fold, evaluated with the same exact integer division -- so the spans
-//      are identical.  Rows leave four at a time: 16 bytes per lane, 1 KB per wave, contiguous (the [row quad][drop]
-//      layout k_fov_sums reads).  ~350 issued instructions per drop, every lane busy;
+//      are identical.  A row's span leaves as a dword per lane, 256 bytes per wave, contiguous (the [row][drop] layout
+//      k_fov_sums32 reads).  Every lane busy;
 //   3. everything else -- a wrapping polygon (24 vertices, not monotone), a predicate within its error bound (float64
 //      decides), a vertex sequence that is not monotone after all -- goes to the frame's list for k_fov_spans (from_list),
 //      a fraction of a percent of the drops.
 // r06, RR_OPT_FOV_FILL_RULE 1 (the default): the spans are what cv2.fillConvexPoly sets (rr_device.h fov_rowspan_cv: the
 // outline's Bresenham pixels + the 16.16 edge walkers) for the polygons OpenCV's rule applies to (every vertex on the map),
 // the span rule's otherwise.  Both by incremental cursors (rr_device.h DdaCursors): every edge's divisions are done once,
-// before the walk, into an 8-byte record per edge and lane (global memory); a row costs adds and compares, and a cursor
-// fetches its next vertex and record an edge ahead.  4 bytes of LDS per vertex and lane.
+// before the walk, into a 16-byte record per edge and lane (global memory: step, outline constants, the edge's pixels on its
+// first row, its lower end); a row costs adds and compares, and a cursor fetches its next record an edge ahead.  No LDS.
 constexpr int DDA_WAVES = 4;
 __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int cv_rule, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
   const int N = cam.n_fov;
   // NO LDS at all (r06): the tile / blur kernels of the other stream fill a CU's 160 KB, and a workgroup that needs a single
   // byte of it waits for one of theirs to leave.  The spin terms come from the kernel arguments (scalar loads, k is
-  // wave-uniform), the vertex pixels wait in the fourth word of the edge records' slots (pixv below).
+  // wave-uniform), the vertex pixels wait in global memory (pixv below).
   const int i = (blockIdx.x * DDA_WAVES + wave) * 64 + lane;   // this lane's drop
   const bool act = i < fr.n_drops;
   const int64_t gi = (int64_t)f * max_drops + (act ? i : 0);
@@ -852,10 +855,11 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     if (act) sc.npts[gi] = -1;
     return;
   }
-  // vertex k's pixel, x | y << 16: word 3 of the lane's record slot of edge k -- the record of edge k is written (dda_edge_record
-  // below) after vertices k and k + 1 have been read, and replaces it with the edge's lower end
+  // vertex k's pixel, x | y << 16, in global memory ([frame][vertex][drop]: 256 contiguous bytes per wave and vertex, read
+  // back from L2 when the edge records are made)
   uint4* const erec = sc.fov_erec + (int64_t)f * N * max_drops + (act ? i : 0);
-  auto pixv = [&](int kk) -> uint32_t& { return reinterpret_cast<uint32_t*>(erec + (int64_t)kk * max_drops)[3]; };
+  uint32_t* const gpix = sc.fov_pix + (int64_t)f * N * max_drops + (act ? i : 0);
+  auto pixv = [&](int kk) -> uint32_t& { return gpix[(int64_t)kk * max_drops]; };
   uint32_t top_xy = 0;
   // ---- 1. vertices ----
   int uns = 0;                                                 // reason bits (rr_device.h): float64 has to decide
@@ -941,7 +945,7 @@ __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* fra
     const uint32_t vfirst = pixv(0);
     uint32_t va = vfirst;
     for (int k = 0; k < N; k++) {
-      const uint32_t vb = k + 1 == N ? vfirst : pixv(k + 1);   // (read before record k + 1 overwrites it)
+      const uint32_t vb = k + 1 == N ? vfirst : pixv(k + 1);
       const int x0 = (int)(va & 0xffffu), y0 = (int)(va >> 16), x1 = (int)(vb & 0xffffu), y1 = (int)(vb >> 16);
       const bool swp = y1 < y0;
       uint32_t r[4];
@@ -5264,6 +5268,7 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     if ((rc = dev_alloc(ctx, ctx->sc.rows_fbase, (size_t)F * RW_TEX_MAX))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_erec, general ? 1 : fd * (size_t)(ctx->cam.n_fov > 0 ? ctx->cam.n_fov : RR_MAX_FOV)))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.fov_pix, general ? 1 : fd * (size_t)(ctx->cam.n_fov > 0 ? ctx->cam.n_fov : RR_MAX_FOV)))) return rc;
     ctx->erec_nfov = ctx->cam.n_fov;
     if ((rc = dev_alloc(ctx, ctx->sc.fov_list_n, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_gen, fd))) return rc;
@@ -6053,6 +6058,7 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.sizes);
   hipFree(ctx->sc.list_rot);
   hipFree(ctx->sc.fov_erec);
+  hipFree(ctx->sc.fov_pix);
   hipFree(ctx->sc.rows_list);
   hipFree(ctx->sc.rows_sorted);
   hipFree(ctx->sc.rows_n);
