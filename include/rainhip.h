@@ -174,6 +174,17 @@ int rr_create(rr_ctx** out, int device);
 int rr_destroy(rr_ctx* ctx);
 const char* rr_last_error(rr_ctx* ctx);
 
+/* SURVEY 8b's collective, for a host that drives several GPUs from ONE process: the streak database of ctxs[0]
+ * (rr_set_streak_db / rr_set_streak_db_device) becomes the database of ctxs[1 .. n_ctx - 1] without a trip through the host.
+ * Contexts on the root's device take a device-to-device copy; contexts on other devices an ncclBroadcast (RCCL over xGMI; one
+ * communicator rank per device, librccl.so.1 loaded on first use -- RR_E_STATE if it cannot be).  Synchronous; the error text
+ * is ctxs[0]'s rr_last_error.  n_ctx = 1 is a no-op.  (This repo's drivers run one PROCESS per GPU and broadcast through
+ * torch.distributed -- sharding.py; the reference has no counterpart: main_threaded.py starts a process per sequence.) */
+int rr_bcast_streak_db(rr_ctx** ctxs, int32_t n_ctx);
+/* Diagnostic: the RCCL leg of rr_bcast_streak_db on the context's OWN device (a communicator of one rank; the database
+ * broadcast into a scratch buffer and compared) -- what a box with one GPU can check of it. */
+int rr_bcast_selftest(rr_ctx* ctx);
+
 /* Streak database: n_tex gray uint8 textures, already normalised as
  * uint8((255*norm*img)/65535) (bad_weather.py:141), concatenated in `texels`
  * (host pointer) with per-texture height/width/offset. */

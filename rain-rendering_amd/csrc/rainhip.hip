@@ -34,6 +34,8 @@
 // rr_prepass.h holds the fog / environment-map pre-pass kernels, rr_host.cpp the host-only helpers.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -5027,6 +5029,9 @@ struct rr_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool comp_batch = true;            // RR_OPT_COMPOSITE_BATCH: list entries' records 64 at a time in vector registers, samples two entries ahead
   int n_tex = 0;
+  std::vector<int32_t> h_tex_h, h_tex_w;   // host copies of the database's metadata (rr_bcast_streak_db hands them to the other contexts)
+  std::vector<int64_t> h_tex_off;
+  int64_t tex_bytes = 0;             // size of the texel buffer
   float* d_ctab = nullptr;
   // particle generator (rr_set_particle_tables / rr_generate_drops_device)
   double *d_dgrid = nullptr, *d_cdf = nullptr, *d_ratio_db = nullptr;
@@ -5134,6 +5139,14 @@ namespace {
     hipError_t e_ = (call);                                                                       \
     if (e_ != hipSuccess) {                                                                       \
       ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+      return RR_E_HIP;                                                                            \
+    }                                                                                             \
+  } while (0)
+#define HIPCHK_CTX(c_, call)                                                                      \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      (c_)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
       return RR_E_HIP;                                                                            \
     }                                                                                             \
   } while (0)
@@ -6183,6 +6196,9 @@ static int set_db_meta(rr_ctx* ctx, const int32_t* tex_h, const int32_t* tex_w, 
   HIPCHK(hipMemcpy(ctx->d_tex_w, tex_w, sizeof(int32_t) * n_tex, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_tex_off, tex_off, sizeof(int64_t) * n_tex, hipMemcpyHostToDevice));
   ctx->n_tex = n_tex;
+  ctx->h_tex_h.assign(tex_h, tex_h + n_tex);
+  ctx->h_tex_w.assign(tex_w, tex_w + n_tex);
+  ctx->h_tex_off.assign(tex_off, tex_off + n_tex);
   ctx->have_db = true;
   {                                     // the padded copies k_tile / k_tile_generic stage from
     std::vector<int64_t> poff((size_t)n_tex);
@@ -6253,6 +6269,7 @@ int rr_set_streak_db(rr_ctx* ctx, const uint8_t* texels, const int32_t* tex_h, c
   HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)total));
   ctx->own_tex = true;
   HIPCHK(hipMemcpy(ctx->d_tex, texels, (size_t)total, hipMemcpyHostToDevice));
+  ctx->tex_bytes = total;
   return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
 }
 
@@ -6277,7 +6294,168 @@ int rr_set_streak_db_device(rr_ctx* ctx, const uint8_t* texels_dev, int64_t n_by
   HIPCHK(hipMalloc((void**)&ctx->d_tex, (size_t)n_bytes));
   ctx->own_tex = true;
   HIPCHK(hipMemcpy(ctx->d_tex, texels_dev, (size_t)n_bytes, hipMemcpyDeviceToDevice));
+  ctx->tex_bytes = n_bytes;
   return set_db_meta(ctx, tex_h, tex_w, tex_off, n_tex);
+}
+
+// SURVEY 8b's collective for a host that drives several GPUs from ONE process: the streak database of ctxs[0] reaches the
+// other contexts without going back through the host.  Contexts on the root's device take a device-to-device copy; contexts on
+// other devices an ncclBroadcast in one group call (RCCL, librccl.so.1 loaded on first use: the library has no link-time
+// dependency on it -- this repo's own drivers run one PROCESS per GPU and broadcast through torch.distributed, sharding.py).
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (lib) return true;
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return false;
+    CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+    Broadcast = (decltype(Broadcast))dlsym(lib, "ncclBroadcast");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast;
+  }
+};
+RcclApi g_rccl;
+}  // namespace
+
+// ncclBroadcast of nb bytes from src (on devs[0]) into dst[r] on devs[r], r = 0 .. (rank 0 receives into dst[0], which may
+// be src itself), one group call, synchronous
+static int rccl_bcast(const std::vector<int>& devs, const void* src, const std::vector<void*>& dst, const std::vector<hipStream_t>& streams,
+                      size_t nb, std::string& err) {
+  if (!g_rccl.load()) {
+    err = "rr_bcast_streak_db: contexts on several devices need RCCL (librccl.so.1 could not be loaded)";
+    return RR_E_STATE;
+  }
+  std::vector<void*> comms(devs.size(), nullptr);
+  int rc = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+  if (rc == 0) {
+    rc = g_rccl.GroupStart();
+    for (size_t r = 0; r < devs.size() && rc == 0; r++) {
+      hipSetDevice(devs[r]);
+      rc = g_rccl.Broadcast(src, dst[r], nb, /*ncclUint8*/ 1, 0, comms[r], streams[r]);
+    }
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc == 0) rc = rc2;
+    for (size_t r = 0; r < devs.size(); r++) {
+      hipSetDevice(devs[r]);
+      if (hipStreamSynchronize(streams[r]) != hipSuccess && rc == 0) rc = -1;
+    }
+  }
+  for (void* cm : comms)
+    if (cm) g_rccl.CommDestroy(cm);
+  if (rc != 0) {
+    err = std::string("rr_bcast_streak_db: RCCL: ") + (rc > 0 && g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "stream error");
+    return RR_E_HIP;
+  }
+  return RR_OK;
+}
+
+// What a box with ONE GPU can check of the multi-device leg: the context's database broadcast by RCCL in a communicator of
+// one rank (its own device) into a scratch buffer, compared byte for byte.  RR_OK, or RR_E_STATE without RCCL / a database.
+int rr_bcast_selftest(rr_ctx* ctx) {
+  if (!ctx) return RR_E_ARG;
+  if (!ctx->have_db || !ctx->d_tex || ctx->tex_bytes <= 0) {
+    ctx->err = "rr_bcast_selftest: no streak database";
+    return RR_E_STATE;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
+  uint8_t* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, (size_t)ctx->tex_bytes));
+  HIPCHK(hipMemset(tmp, 0xa5, (size_t)ctx->tex_bytes));
+  int rc = rccl_bcast({ctx->device}, ctx->d_tex, {tmp}, {ctx->stream}, (size_t)ctx->tex_bytes, ctx->err);
+  if (rc == RR_OK) {
+    std::vector<uint8_t> a((size_t)ctx->tex_bytes), b((size_t)ctx->tex_bytes);
+    if (hipMemcpy(a.data(), ctx->d_tex, a.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(b.data(), tmp, b.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+      ctx->err = "rr_bcast_selftest: read-back failed";
+      rc = RR_E_HIP;
+    } else if (a != b) {
+      ctx->err = "rr_bcast_selftest: the broadcast buffer differs from the database";
+      rc = RR_E_HIP;
+    }
+  }
+  hipFree(tmp);
+  return rc;
+}
+
+int rr_bcast_streak_db(rr_ctx** ctxs, int32_t n_ctx) {
+  if (!ctxs || n_ctx <= 0 || !ctxs[0]) return RR_E_ARG;
+  rr_ctx* root = ctxs[0];
+  if (!root->have_db || !root->d_tex || root->tex_bytes <= 0) {
+    root->err = "rr_bcast_streak_db: ctxs[0] has no streak database (rr_set_streak_db first)";
+    return RR_E_STATE;
+  }
+  for (int i = 1; i < n_ctx; i++)
+    if (!ctxs[i] || ctxs[i] == root) {
+      root->err = "rr_bcast_streak_db: null or repeated context";
+      return RR_E_ARG;
+    }
+  const int64_t nb = root->tex_bytes;
+  const int32_t n_tex = root->n_tex;
+  HIPCHK_CTX(root, hipSetDevice(root->device));
+  HIPCHK_CTX(root, hipDeviceSynchronize());
+  // receiving buffers (a context's previous database goes)
+  std::vector<rr_ctx*> remote;                               // contexts on other devices: one rank each, the root is rank 0
+  for (int i = 1; i < n_ctx; i++) {
+    rr_ctx* c = ctxs[i];
+    HIPCHK_CTX(c, hipSetDevice(c->device));
+    HIPCHK_CTX(c, hipDeviceSynchronize());
+    if (c->own_tex && c->d_tex) hipFree(c->d_tex);
+    c->d_tex = nullptr;
+    HIPCHK_CTX(c, hipMalloc((void**)&c->d_tex, (size_t)nb));
+    c->own_tex = true;
+    c->tex_bytes = nb;
+    if (c->device == root->device) HIPCHK_CTX(c, hipMemcpy(c->d_tex, root->d_tex, (size_t)nb, hipMemcpyDeviceToDevice));
+    else remote.push_back(c);
+  }
+  if (!remote.empty()) {
+    // one communicator rank per DEVICE (RCCL refuses two ranks on one): the first context of a device receives, its
+    // siblings copy from it afterwards
+    std::vector<int> devs{root->device};
+    std::vector<rr_ctx*> first{root};
+    for (rr_ctx* c : remote) {
+      bool seen = false;
+      for (int d : devs) seen = seen || d == c->device;
+      if (!seen) { devs.push_back(c->device); first.push_back(c); }
+    }
+    std::vector<void*> dst;
+    std::vector<hipStream_t> streams;
+    for (rr_ctx* c : first) { dst.push_back(c->d_tex); streams.push_back(c->stream); }
+    const int rc = rccl_bcast(devs, root->d_tex, dst, streams, (size_t)nb, root->err);
+    if (rc != RR_OK) return rc;
+    for (rr_ctx* c : remote) {                               // siblings of a receiving context on the same device
+      bool is_first = false;
+      rr_ctx* src = nullptr;
+      for (size_t r = 0; r < devs.size(); r++)
+        if (devs[r] == c->device) { src = first[r]; is_first = first[r] == c; }
+      if (!is_first) {
+        HIPCHK_CTX(c, hipSetDevice(c->device));
+        HIPCHK_CTX(c, hipMemcpy(c->d_tex, src->d_tex, (size_t)nb, hipMemcpyDeviceToDevice));
+      }
+    }
+  }
+  // metadata + the derived textures (zero-bordered copies, pair textures) on every receiving context
+  const std::vector<int32_t> th = root->h_tex_h, tw = root->h_tex_w;
+  const std::vector<int64_t> to = root->h_tex_off;
+  for (int i = 1; i < n_ctx; i++) {
+    rr_ctx* c = ctxs[i];
+    HIPCHK_CTX(c, hipSetDevice(c->device));
+    const int rc = set_db_meta(c, th.data(), tw.data(), to.data(), n_tex);
+    if (rc != RR_OK) return rc;
+  }
+  hipSetDevice(root->device);
+  return RR_OK;
 }
 
 int rr_set_camera(rr_ctx* ctx, const rr_camera* cam) {

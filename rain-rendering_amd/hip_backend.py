@@ -128,7 +128,7 @@ EXPORTS = ['rr_version', 'rr_create', 'rr_destroy', 'rr_last_error', 'rr_set_str
            'rr_sizeof_frame_out', 'rr_set_prepass_kernels', 'rr_set_envmap_geometry', 'rr_envmap_width',
            'rr_prepass_frames', 'rr_prepass_frames_device', 'rr_pipeline_frames', 'rr_sizeof_prepass_in',
            'rr_sizeof_prepass_out', 'rr_sizeof_prepass_kernels', 'rr_host_drop_draws', 'rr_batch_counts', 'rr_set_option',
-           'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_last_error', 'rr_host_free', 'rr_host_parse_particles',
+           'rr_pipeline_submit', 'rr_pipeline_wait', 'rr_host_alloc', 'rr_host_last_error', 'rr_host_free', 'rr_bcast_streak_db', 'rr_bcast_selftest', 'rr_host_parse_particles',
            'rr_sizeof_particle', 'rr_sizeof_particle_frame', 'rr_set_colormap', 'rr_host_frame_draws', 'rr_host_assemble_drops',
            'rr_sizeof_streak_table', 'rr_png_info', 'rr_png_read_bgr8', 'rr_png_read_gray16', 'rr_png_write_scanlines',
            'rr_deflate_bound', 'rr_deflate_fast', 'rr_inflate_fast', 'rr_adler32', 'rr_crc32', 'rr_host_pack_frames', 'rr_io_read_frames', 'rr_io_read_frames_u16', 'rr_io_read_frames_rows', 'rr_io_read_frames_scaled', 'rr_io_write_frames', 'rr_set_particle_tables', 'rr_generate_drops_device', 'rr_generate_drops', 'rr_set_solid_angles',
@@ -149,6 +149,8 @@ def load_library(path=None):
     lib = ctypes.CDLL(p)
     lib.rr_last_error.restype = ctypes.c_char_p
     lib.rr_last_error.argtypes = [ctypes.c_void_p]
+    lib.rr_bcast_streak_db.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32]
+    lib.rr_bcast_selftest.argtypes = [ctypes.c_void_p]
     lib.rr_host_last_error.restype = ctypes.c_char_p
     lib.rr_host_last_error.argtypes = [ctypes.c_void_p]
     lib.rr_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
@@ -616,6 +618,10 @@ class RainHip:
             self.set_option(int(k), int(v))
         self.device = device
         self._keep = []
+
+    def bcast_selftest(self):
+        """rr_bcast_selftest: the RCCL leg of rr_bcast_streak_db on this context's own device (one rank)."""
+        self._check(self.lib.rr_bcast_selftest(self.h), 'rr_bcast_selftest')
 
     def close(self):
         if self.h:
@@ -1091,3 +1097,12 @@ class RainHip:
         buf = (rr_kernel_stat * 32)()
         n = self._check(self.lib.rr_profile_read(self.h, buf, 32), 'rr_profile_read')
         return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(n)}
+
+
+def bcast_streak_db(contexts):
+    """rr_bcast_streak_db: the streak database of contexts[0] (RainHip objects of ONE process) becomes the database of the
+    others -- a device-to-device copy on the root's device, ncclBroadcast (RCCL) across devices."""
+    arr = (ctypes.c_void_p * len(contexts))(*[c.h for c in contexts])
+    contexts[0]._check(contexts[0].lib.rr_bcast_streak_db(arr, len(contexts)), 'rr_bcast_streak_db')
+    for c in contexts[1:]:
+        c._db_meta = getattr(contexts[0], '_db_meta', None)

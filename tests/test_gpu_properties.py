@@ -400,3 +400,27 @@ def test_raw_tile_kernels_agree(setup, tmp_path):
             pick = lambda c: [int(c[0]), int(c[1]), int(c[5]), int(c[7])]                # rotate / generic / Big tiles rendered, tiles shared
             # (which of two identical drops of different frames renders their tile is the election's business: the call's totals)
             assert np.sum([pick(c) for c in counts], axis=0).tolist() == np.sum([pick(c) for c in outs[0][1]], axis=0).tolist()
+
+
+def test_bcast_streak_db_in_one_process(setup):
+    """SURVEY 8b's rr_bcast_streak_db (round 6): a second context of the same process gets its streak database from the first
+    one's device memory and renders the same bits; the RCCL leg (contexts on other devices) runs here as a communicator of
+    one rank on this box's one GPU (rr_bcast_selftest).  Contexts without a database, null entries: errors."""
+    sc, bg, env, drops, rh, base = setup
+    fr = dict(bg=bg, rainy_bg=bg, env_xyY=env, omega=sc.omega, drops=drops)
+    other, third = h.hb.RainHip(0), h.hb.RainHip(0)
+    try:
+        with pytest.raises(RuntimeError):
+            h.hb.bcast_streak_db([other, third])                 # the root has no database
+        h.hb.bcast_streak_db([rh])                               # n_ctx = 1: nothing to do
+        h.hb.bcast_streak_db([rh, other, third])
+        for c in (other, third):
+            c.set_camera(sc.cam)
+            out = c.render_frames([fr])[0]
+            for k in ('status', 'mask', 'mask_i32', 'image_u8', 'rainy_bg'):
+                assert np.array_equal(out[k], base[k]), k
+        rh.bcast_selftest()
+        other.bcast_selftest()
+    finally:
+        other.close()
+        third.close()
