@@ -252,6 +252,8 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* counts;                  // [frame][8] = #rot, #gen, #blur items, #slow, #small, -, -, #duplicate raw tiles
   int32_t* list_big;                // [frame][drops] Big drops (bicubic warp) rendered by k_tile_big, one thread per pixel
   int32_t* big_off;                 // [frame][drops+1] exclusive prefix of their tile sizes, in pixels
+  int32_t* bigs_list;               // [frame][drops] the frame's Big drops (k_plan) for k_plan_big: the 8 x 8 solve of their homography
+  int32_t* bigs_n;                  // [frame] their number (zeroed per call)
   uint4* tkey;                      // [frame][drops][2] raw_tile_key (rr_device.h): what k_dedup compares (r06: 32 bytes instead of the plan's ~200)
   uint4* lrec;                      // [frame][drops] ListRec: the drop's work-list classes, made once by k_plan (r06; k_lists read the plans twice)
   int32_t* canon;                   // [frame][drops] batch-global index of the drop whose raw tile this drop uses
@@ -381,9 +383,12 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
   if (act) {
     rr_drop d = load_drop(fr.drops + i);
     int64_t size = 0;
-    rr_ext_tile ext;
-    if (fr.ext) ext = fr.ext[i];
-    plan_drop(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size, fr.ext ? &ext : nullptr);
+    ExtGeom xg{false, 0, 0, 0, 0};
+    if (fr.ext) {
+      const rr_ext_tile& e = fr.ext[i];
+      if (e.alpha) xg = ExtGeom{true, e.tw, e.th, e.min_x, e.min_y};
+    }
+    plan_drop<true>(d, cam, dm, tex_h, tex_w, fr.opacity, fr.strategy, p, size, xg);      // (a Big drop's homography: k_plan_big)
     // the FOV polygon is evaluated for every drop: in the reference its failure is raised before the circle of confusion
     // is looked at (bad_weather.py:363-373 vs :416) -- k_colour gives such a drop its status and keeps it out of the blend.
     // use_npts (the colour branch ran BEFORE this kernel, on the same stream): a drop without a polygon gets no tile either;
@@ -399,6 +404,16 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
     sc.tkey[2 * gi] = make_uint4(key[0], key[1], key[2], key[3]);
     sc.tkey[2 * gi + 1] = make_uint4(key[4], key[5], key[6], key[7]);
     sc.lrec[gi] = make_list_rec(p, tex_h, tex_w, sc);
+  }
+  {                                                          // the wave's Big drops whose tile will be rendered -> the frame's list
+    const bool big = act && p.status == RR_DROP_OK && p.kind == KIND_BIG && sc.sizes[gi] > 0;
+    const unsigned long long m = __ballot(big);
+    if (m != 0ull) {
+      int base = 0;
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&sc.bigs_n[f], __popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1);
+      if (big) sc.bigs_list[(int64_t)f * max_drops + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
   }
   const int wave_i0 = blockIdx.x * blockDim.x + wave * 64;         // first drop of this wave
   uint32_t* stage = s_plan[wave];
@@ -416,6 +431,21 @@ __global__ __launch_bounds__(128) void k_plan(const FrameDesc* frames, Dims dm, 
     for (int k = lane; k < nrec * PLAN_DW; k += 64) out[half * 32 * PLAN_DW + k] = stage[k];
     wave_lds_sync();
   }
+}
+
+// The Big drops' inverse homographies (rr_device.h plan_big_homography: the 8 x 8 solve in registers -- 170 of them and some
+// scratch), for the frame's list of Big drops only: inside k_plan it held EVERY wave of that latency-bound kernel to two per
+// SIMD for the sixth of the drops that need it.
+__global__ __launch_bounds__(128) void k_plan_big(const FrameDesc* frames, const int32_t* tex_h, const int32_t* tex_w, int max_drops, Scratch sc) {
+  const int f = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= sc.bigs_n[f]) return;
+  const int i = sc.bigs_list[(int64_t)f * max_drops + j];
+  const rr_drop d = load_drop(frames[f].drops + i);
+  double mi[9];
+  plan_big_homography(d, tex_w[d.tex_index], tex_h[d.tex_index], mi);
+  double* o = sc.plan[(int64_t)f * max_drops + i].mi;
+#pragma unroll
+  for (int k = 0; k < 9; k++) o[k] = mi[k];
 }
 
 // one block per frame: exclusive scan of arena sizes
@@ -5313,6 +5343,8 @@ int ensure_scratch(rr_ctx* ctx, int n, int max_drops, const Dims& dm, bool need_
     }
     if ((rc = dev_alloc(ctx, ctx->sc.counts, (size_t)F * 8))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.canon, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.bigs_list, fd))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->sc.bigs_n, (size_t)F))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.tkey, fd * 2))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.lrec, fd))) return rc;
     if ((rc = dev_alloc(ctx, ctx->sc.list_big, fd))) return rc;
@@ -5611,8 +5643,10 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
     }
     {
       ProfScope ps(ctx, bs, "k_plan");
+      HIPCHK(hipMemsetAsync(sc.bigs_n, 0, sizeof(int32_t) * (size_t)n, bs));
       hipLaunchKernelGGL(k_plan, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, dm, ctx->cam, ctx->d_tex_h,
                          ctx->d_tex_w, D, fs == bs ? 1 : 0, sc);
+      hipLaunchKernelGGL(k_plan_big, dim3((max_drops + 127) / 128, n), dim3(128), 0, bs, ctx->d_frames, ctx->d_tex_h, ctx->d_tex_w, D, sc);
     }
     {
       ProfScope ps(ctx, bs, "k_scan");
@@ -6087,6 +6121,8 @@ int rr_destroy(rr_ctx* ctx) {
   hipFree(ctx->sc.blur_items);
   hipFree(ctx->sc.counts);
   hipFree(ctx->sc.canon);
+  hipFree(ctx->sc.bigs_list);
+  hipFree(ctx->sc.bigs_n);
   hipFree(ctx->sc.tkey);
   hipFree(ctx->sc.lrec);
   hipFree(ctx->sc.list_big);

@@ -1276,8 +1276,60 @@ RR_HD void raw_tile_key(const rr_drop& d, const DropPlan& p, uint32_t key[8]) {
   key[1] = (uint32_t)p.tw | ((uint32_t)p.th << 16);
 }
 
+// The inverse homography of a Big drop (generator.py:126-132: warping_points -> getPerspectiveTransform -> warpPerspective's
+// inversion), from the drop's end points and the texture's size alone.  The 8 x 8 solve is the register-hungry part of the
+// per-drop plan: on the device k_plan leaves it to k_plan_big (round 6; DEFER_BIG below), which runs it for the Big drops only.
+RR_HD void plan_big_homography(const rr_drop& d, int sw, int sh, double mi[9]) {
+  const double d0 = floor(d.iw1), d1 = floor(d.iw2);
+  const int minx = imax(imin(d.x0, d.x1), 0), miny = imax(imin(d.y0, d.y1), 0);
+  float src[4][2] = {{0.f, 0.f}, {(float)sw, 0.f}, {(float)sw, (float)sh}, {0.f, (float)sh}};
+  float dst[4][2];
+  dst[0][0] = (float)(d.x0 - minx);                        dst[0][1] = (float)(d.y0 - miny);
+  dst[1][0] = (float)((double)(d.x0 - minx) + d0);         dst[1][1] = (float)(d.y0 - miny);
+  dst[2][0] = (float)(((double)(d.x1 - minx) + d1) + 0.001); dst[2][1] = (float)(d.y1 - miny);
+  dst[3][0] = (float)((double)(d.x1 - minx) + 0.001);      dst[3][1] = (float)(d.y1 - miny);
+  double A[8][8], bb[8], xx[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) A[i][j] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double sx = src[i][0], sy = src[i][1], ddx = dst[i][0], ddy = dst[i][1];
+    A[i][0] = A[i + 4][3] = sx;
+    A[i][1] = A[i + 4][4] = sy;
+    A[i][2] = A[i + 4][5] = 1.0;
+    A[i][6] = -sx * ddx;
+    A[i][7] = -sy * ddx;
+    A[i + 4][6] = -sx * ddy;
+    A[i + 4][7] = -sy * ddy;
+    bb[i] = ddx;
+    bb[i + 4] = ddy;
+  }
+  solve8(A, bb, xx);
+  double M[9] = {xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], 1.0};
+  invert3(M, mi);
+}
+
+// The caller's tile, by value: (has_ext, tw, th, min_x, min_y).  (A pointer to a local rr_ext_tile kept that struct in scratch
+// memory on the device.)
+struct ExtGeom {
+  bool has;
+  int tw, th, min_x, min_y;
+};
+template <bool DEFER_BIG = false>     // true: a Big drop's mi[] is left zero (the caller runs plan_big_homography later)
+RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, const int32_t* tex_h, const int32_t* tex_w,
+                     double opacity_attenuation, int strategy, DropPlan& p, int64_t& size_out, const ExtGeom xg);
+template <bool DEFER_BIG = false>
 RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, const int32_t* tex_h, const int32_t* tex_w,
                      double opacity_attenuation, int strategy, DropPlan& p, int64_t& size_out, const rr_ext_tile* ext = nullptr) {
+  const bool has = ext && ext->alpha;
+  plan_drop<DEFER_BIG>(d, cam, dm, tex_h, tex_w, opacity_attenuation, strategy, p, size_out,
+                       ExtGeom{has, has ? ext->tw : 0, has ? ext->th : 0, has ? ext->min_x : 0, has ? ext->min_y : 0});
+}
+template <bool DEFER_BIG>
+RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, const int32_t* tex_h, const int32_t* tex_w,
+                     double opacity_attenuation, int strategy, DropPlan& p, int64_t& size_out, const ExtGeom xg) {
   size_out = 0;
   p.status = RR_DROP_OK;
   p.tex = d.tex_index;
@@ -1300,13 +1352,13 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
   const int sh = tex_h[d.tex_index], sw = tex_w[d.tex_index];
 
   int minCx, minCy;
-  if (ext && ext->alpha) {
+  if (xg.has) {
     // the caller's tile (RainRenderer.add_drop_to_image's `drop` and `drop_minC`, bad_weather.py:336-338)
     p.kind = KIND_EXT;
-    p.tw = imax(ext->tw, 1);
-    p.th = imax(ext->th, 1);
-    minCx = ext->min_x;
-    minCy = ext->min_y;
+    p.tw = imax(xg.tw, 1);
+    p.th = imax(xg.th, 1);
+    minCx = xg.min_x;
+    minCy = xg.min_y;
   } else if (d.type == 0) {
     p.kind = KIND_BIG;
     double d0 = floor(d.iw1), d1 = floor(d.iw2);
@@ -1316,33 +1368,7 @@ RR_HD void plan_drop(const rr_drop& d, const rr_camera& cam, const Dims& dm, con
     int s0 = (int)(maxx - (double)minx), s1 = maxy - miny;
     p.tw = imax(s0, 1);
     p.th = imax(s1, 1);
-    float src[4][2] = {{0.f, 0.f}, {(float)sw, 0.f}, {(float)sw, (float)sh}, {0.f, (float)sh}};
-    float dst[4][2];
-    dst[0][0] = (float)(d.x0 - minx);                        dst[0][1] = (float)(d.y0 - miny);
-    dst[1][0] = (float)((double)(d.x0 - minx) + d0);         dst[1][1] = (float)(d.y0 - miny);
-    dst[2][0] = (float)(((double)(d.x1 - minx) + d1) + 0.001); dst[2][1] = (float)(d.y1 - miny);
-    dst[3][0] = (float)((double)(d.x1 - minx) + 0.001);      dst[3][1] = (float)(d.y1 - miny);
-    double A[8][8], bb[8], xx[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-      for (int j = 0; j < 8; j++) A[i][j] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      double sx = src[i][0], sy = src[i][1], ddx = dst[i][0], ddy = dst[i][1];
-      A[i][0] = A[i + 4][3] = sx;
-      A[i][1] = A[i + 4][4] = sy;
-      A[i][2] = A[i + 4][5] = 1.0;
-      A[i][6] = -sx * ddx;
-      A[i][7] = -sy * ddx;
-      A[i + 4][6] = -sx * ddy;
-      A[i + 4][7] = -sy * ddy;
-      bb[i] = ddx;
-      bb[i + 4] = ddy;
-    }
-    solve8(A, bb, xx);
-    double M[9] = {xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], 1.0};
-    invert3(M, p.mi);
+    if (!DEFER_BIG) plan_big_homography(d, sw, sh, p.mi);
     int bh0 = imin(16, p.th);
     int bw0 = imin(1024 / bh0, p.tw);
     p.bw0 = bw0;
