@@ -249,9 +249,9 @@ OPTION_DEFAULTS = {1: 1, 9: 1, 10: 2, 12: 1, 13: 1, 16: 1, 17: 1, 18: 1, 19: 1, 
 
 # kernel symbol -> the name of the timing scope (rr_profile_read) it is launched under
 SCOPE_OF = {'k_blur_fused_dma': 'k_blur_fused', 'k_composite32': 'k_composite', 'k_fov_sums32': 'k_fov_sums', 'k_fov_dda': 'k_fov_spans',
-            'k_fov_walk': 'k_fov_spans', 'k_finalize16': 'k_finalize', 'k_bin_rows': 'k_bin', 'k_env_consts': 'k_env_prefix',
+            'k_finalize16': 'k_finalize', 'k_bin_rows': 'k_bin', 'k_env_consts': 'k_env_prefix',
             'k_fov_poly_general': 'k_fov_poly', 'k_png_image': 'k_png_rows', 'k_png_mask': 'k_png_rows', 'k_pngz_blocks': 'k_pngz',
-            'k_pngz_pack': 'k_pngz', 'k_rows_scatter': 'k_lists', 'k_rows_shares': 'k_lists'}
+            'k_pngz_pack': 'k_pngz', 'k_rows_scatter': 'k_lists', 'k_rows_shares': 'k_lists', 'k_plan_big': 'k_plan'}
 
 
 def scope_of(kernel):
