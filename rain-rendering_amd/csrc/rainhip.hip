@@ -270,6 +270,7 @@ struct Scratch {                    // per-batch device scratch, all indexed [fr
   int32_t* rows_sorted;             // [frames * drops] batch-global drop indices, bucket after bucket (k_rows_scatter)
   const uint8_t* tex_pair;          // pair textures (k_pair_textures) and their offsets (multiples of 16)
   const int64_t* tex_qoff;
+  int32_t colpart_f32;              // the band partials lie in colpart as floats (k_fov_sums32's own width: half the bytes for it and k_colour)
   int32_t rows_on, n_tex;           // RR_OPT_TILE_ROWS and a database of at most RW_TEX_MAX textures
   int32_t big_on, n_buckets;        // Big (bicubic) tiles ride in the same list, buckets n_tex .. 2 n_tex - 1 (2 n_tex <= RW_TEX_MAX)
 };
@@ -1397,10 +1398,10 @@ __global__ __launch_bounds__(1024) void k_fov_sums32(const FrameDesc* frames, Di
   for (int d = 0; d < DPT; d++) {
     const int i = d0 + d * NT + t;
     if (i < d1) {
-      double* o = sc.colpart + ((int64_t)(f * COL_PARTS + band) * 5) * max_drops + i;
+      float* o = reinterpret_cast<float*>(sc.colpart) + ((int64_t)(f * COL_PARTS + band) * 5) * max_drops + i;      // (sc.colpart_f32)
 #pragma unroll
-      for (int k = 0; k < 4; k++) o[(int64_t)max_drops * k] = (double)S[d][k];
-      o[(int64_t)max_drops * 4] = ((any >> d) & 1u) ? 1.0 : 0.0;
+      for (int k = 0; k < 4; k++) o[(int64_t)max_drops * k] = S[d][k];
+      o[(int64_t)max_drops * 4] = ((any >> d) & 1u) ? 1.0f : 0.0f;
     }
   }
   {
@@ -1512,9 +1513,16 @@ __global__ __launch_bounds__(256) void k_colour(const FrameDesc* frames, Dims dm
     bool any = false;
     double sumW = 0.0, sumY = 0.0;                       // whole-map sums (bad_weather.py:403-404), band order
     for (int b = 0; b < COL_PARTS; b++) {
-      const double* part = sc.colpart + ((int64_t)(f * COL_PARTS + b) * 5) * max_drops + i;
-      for (int k = 0; k < 4; k++) S[k] += part[(int64_t)max_drops * k];
-      any = any || part[(int64_t)max_drops * 4] != 0.0;
+      const int64_t at = ((int64_t)(f * COL_PARTS + b) * 5) * max_drops + i;
+      if (sc.colpart_f32) {                                // (wave-uniform) float partials: the same values, read as they were summed
+        const float* part = reinterpret_cast<const float*>(sc.colpart) + at;
+        for (int k = 0; k < 4; k++) S[k] += (double)part[(int64_t)max_drops * k];
+        any = any || part[(int64_t)max_drops * 4] != 0.0f;
+      } else {
+        const double* part = sc.colpart + at;
+        for (int k = 0; k < 4; k++) S[k] += part[(int64_t)max_drops * k];
+        any = any || part[(int64_t)max_drops * 4] != 0.0;
+      }
       sumW += sc.fband[(f * COL_PARTS + b) * 2 + 0];
       sumY += sc.fband[(f * COL_PARTS + b) * 2 + 1];
     }
@@ -5583,6 +5591,7 @@ int enqueue(rr_ctx* ctx, int n, const rr_frame_in* in, const rr_frame_out* out, 
       ProfScope ps(ctx, fs, "k_fov_poly");
       hipLaunchKernelGGL(k_fov_poly_general, dim3((max_drops + 127) / 128, n), dim3(128), 0, fs, ctx->d_frames, dm, ctx->cam, D, sc);
     }
+    sc.colpart_f32 = (fast && fov32) ? 1 : 0;
     if (fast) {
       ProfScope ps(ctx, fs, "k_fov_sums");
       // a chunk of NT*DPT drops re-scans the band's rows, so DPT grows with the drop count (register budget: 4
