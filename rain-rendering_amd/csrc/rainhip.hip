@@ -873,7 +873,10 @@ __global__ __launch_bounds__(256) void k_fov_spans(const FrameDesc* frames, Dims
 // the span rule's otherwise.  Both by incremental cursors (rr_device.h DdaCursors): every edge's divisions are done once,
 // before the walk, into a 16-byte record per edge and lane (global memory: step, outline constants, the edge's pixels on its
 // first row, its lower end); a row costs adds and compares, and a cursor fetches its next record an edge ahead.  No LDS.
-constexpr int DDA_WAVES = 4;
+#ifndef RR_DDA_WAVES
+#define RR_DDA_WAVES 1          // waves per workgroup: 1 (r06: no LDS, no barrier -- single waves fit into whatever a CU has free: 5.57 -> 5.31 ms alone, step 27.9 -> 27.6)
+#endif
+constexpr int DDA_WAVES = RR_DDA_WAVES;
 __global__ __launch_bounds__(64 * DDA_WAVES) void k_fov_dda(const FrameDesc* frames, Dims dm, rr_camera cam, int max_drops, int Hp, int Dp, int cv_rule, Scratch sc) {
   const int f = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameDesc& fr = frames[f];
